@@ -1,0 +1,150 @@
+"""Expression AST subset used by the sum-check provers.  TEST INFRASTRUCTURE ONLY.
+
+Follows reference plonkish_backend/src/util/expression.rs:60-182.  Only `Rotation::cur()`
+queries and the `EqXY` common polynomial are modelled here (that is all the sum-check /
+GKR / PCS / Lasso paths use: fractional_sum_check.rs:272-281, pcs/multilinear.rs:182-190);
+`Identity`, `Lagrange` and rotations belong to the HyperPlonk zero-check.
+"""
+from .field import R_MOD as P
+
+
+class Expr:
+    def __add__(self, o):
+        return Sum(self, _wrap(o))
+
+    def __mul__(self, o):
+        if isinstance(o, int):
+            return Scaled(self, o % P)
+        return Product(self, o)
+
+    def __neg__(self):
+        return Negated(self)
+
+    def __sub__(self, o):
+        return Sum(self, Negated(_wrap(o)))
+
+
+def _wrap(o):
+    return Constant(o % P) if isinstance(o, int) else o
+
+
+class Constant(Expr):
+    def __init__(self, v):
+        self.v = v % P
+
+
+class EqXY(Expr):
+    def __init__(self, idx):
+        self.idx = idx
+
+
+class Poly(Expr):
+    """Expression::Polynomial(Query::new(poly, Rotation::cur()))"""
+
+    def __init__(self, idx):
+        self.idx = idx
+
+
+class Challenge(Expr):
+    def __init__(self, idx):
+        self.idx = idx
+
+
+class Negated(Expr):
+    def __init__(self, a):
+        self.a = a
+
+
+class Sum(Expr):
+    def __init__(self, a, b):
+        self.a, self.b = a, b
+
+
+class Product(Expr):
+    def __init__(self, a, b):
+        self.a, self.b = a, b
+
+
+class Scaled(Expr):
+    def __init__(self, a, s):
+        self.a, self.s = a, s % P
+
+
+class DistributePowers(Expr):
+    def __init__(self, exprs, base):
+        self.exprs, self.base = list(exprs), base
+
+
+def distribute_powers(exprs, base):
+    """expression.rs:92-105"""
+    exprs = list(exprs)
+    assert exprs
+    return exprs[0] if len(exprs) == 1 else DistributePowers(exprs, base)
+
+
+def sum_exprs(exprs):
+    """`impl Sum for Expression` (expression.rs): reduce with +, empty -> Constant(0)."""
+    exprs = list(exprs)
+    if not exprs:
+        return Constant(0)
+    acc = exprs[0]
+    for e in exprs[1:]:
+        acc = Sum(acc, e)
+    return acc
+
+
+def evaluate(e, constant, common_poly, poly, challenge, negated, sum_, product, scaled):
+    """expression.rs:109-169"""
+    ev = lambda x: evaluate(x, constant, common_poly, poly, challenge, negated, sum_, product, scaled)
+    if isinstance(e, Constant):
+        return constant(e.v)
+    if isinstance(e, EqXY):
+        return common_poly(e.idx)
+    if isinstance(e, Poly):
+        return poly(e.idx)
+    if isinstance(e, Challenge):
+        return challenge(e.idx)
+    if isinstance(e, Negated):
+        return negated(ev(e.a))
+    if isinstance(e, Sum):
+        a = ev(e.a)
+        b = ev(e.b)
+        return sum_(a, b)
+    if isinstance(e, Product):
+        a = ev(e.a)
+        b = ev(e.b)
+        return product(a, b)
+    if isinstance(e, Scaled):
+        return scaled(ev(e.a), e.s)
+    if isinstance(e, DistributePowers):
+        if len(e.exprs) == 1:
+            return ev(e.exprs[0])
+        base = ev(e.base)
+        acc = ev(e.exprs[0])
+        power = base
+        for sub in e.exprs[1:]:
+            acc = sum_(acc, product(power, ev(sub)))
+            power = product(power, base)
+        return acc
+    raise TypeError(e)
+
+
+def degree(e):
+    """expression.rs:171-182"""
+    return evaluate(e, lambda _: 0, lambda _: 1, lambda _: 1, lambda _: 0, lambda a: a,
+                    max, lambda a, b: a + b, lambda a, _: a)
+
+
+def evaluate_fe(e, eq_vals, poly_vals, challenges):
+    """Field evaluation given values for every EqXY / Poly / Challenge leaf."""
+    return evaluate(
+        e,
+        lambda c: c,
+        lambda i: eq_vals[i],
+        lambda i: poly_vals[i],
+        lambda i: challenges[i],
+        lambda a: (-a) % P,
+        lambda a, b: (a + b) % P,
+        lambda a, b: a * b % P,
+        lambda a, s: a * s % P,
+    )

@@ -1,0 +1,260 @@
+"""Lasso lookup argument (Surge sum-check + offline memory checking).  TEST INFRASTRUCTURE ONLY.
+
+NO REFERENCE CODE EXISTS for this layer: the snapshot under /root/reference mentions Lasso only
+in README.md:1-9.  This file is the build's own specification of the protocol,
+designed from the Lasso paper (eprint 2023/1216) on top of the reference's building blocks
+(sum_check.py, gkr.py, kzg.py restate those).  The HIP prover must reproduce these proof bytes.
+
+Protocol (transcript order == proof layout), for N = 2^n lookups into a table decomposed into
+c chunks of l bits (subtable size M = 2^l), alpha memories (chunk j(i), subtable t(i)):
+
+ 0. C   n, l, c, alpha                                  (common_field_element, domain separation)
+ 1. W   commitments  a | dim_0..c-1 | read_ts_0..c-1 | E_0..alpha-1   (n vars, eqs[n])
+        then          final_cts_0..c-1                                 (l vars, eqs[l])
+ 2. S   r[0..n)
+ 3. W   v = a(r)
+ 4.     Surge: ClassicSumCheck<EvaluationsProver>, expression eq_0 * g(E_0..E_alpha-1), ys=[r],
+        claim v  ->  point r_z ;   W  E_i(r_z) for every i
+ 5. S   gamma, tau
+ 6.     leaves (fingerprint h(a,v,t) = a*gamma^2 + v*gamma + t - tau), per memory i:
+          RS_i[k] = h(dim_j[k], E_i[k], read_ts_j[k])      WS_i[k] = RS_i[k] + 1       (N leaves)
+          Init_i[m] = h(m, T_t[m], 0)                      Final_i[m] = Init_i[m] + final_cts_j[m]
+        grand-product GKR (gkr.prove_grand_product) over
+          [RS_0, WS_0, .., RS_{alpha-1}, WS_{alpha-1}, Init_0, Final_0, .., Init_{alpha-1}, Final_{alpha-1}]
+        -> points r_N (n vars) and r_M (l vars).  Verifier: Init_i*WS_i == RS_i*Final_i (roots).
+ 7. W   dim_j(r_N) (c) | read_ts_j(r_N) (c) | E_i(r_N) (alpha) | final_cts_j(r_M) (c)
+ 8.     batch_open group A (n vars): polys [a, dim.., read_ts.., E..], points [r, r_z, r_N],
+        evals [(a,r)] + [(E_i,r_z)] + [(dim_j,r_N)] + [(read_ts_j,r_N)] + [(E_i,r_N)]
+ 9.     batch_open group B (l vars): polys [final_cts..], points [r_M]; since the reference's
+        batch_open needs >= 2 evaluations (pcs/multilinear.rs:150-154) a table with c == 1 is
+        opened with MultilinearKzg::open directly.
+"""
+from .field import R_MOD as P
+from . import expression as ex
+from . import sum_check as sc
+from . import gkr
+from . import kzg
+from .poly import evaluate, eq_xy_eval, identity_eval
+
+
+class LassoError(Exception):
+    pass
+
+
+# ------------------------------------------------------------------ decomposable tables
+SUBTABLE_IDENTITY, SUBTABLE_AND, SUBTABLE_XOR = 0, 1, 2
+
+
+def subtable_entry(kind, m, l):
+    h = l // 2
+    x, y = m >> h, m & ((1 << h) - 1)
+    if kind == SUBTABLE_IDENTITY:
+        return m
+    if kind == SUBTABLE_AND:
+        return x & y
+    if kind == SUBTABLE_XOR:
+        return x ^ y
+    raise ValueError(kind)
+
+
+def subtable_mle_eval(kind, point):
+    """MLE of the subtable at `point` (l variables, variable i = index bit i); index = x || y with
+    y in the low l/2 bits."""
+    l = len(point)
+    if kind == SUBTABLE_IDENTITY:
+        return identity_eval(point)
+    h = l // 2
+    acc = 0
+    for i in range(h):
+        yi, xi = point[i], point[h + i]
+        if kind == SUBTABLE_AND:
+            term = xi * yi
+        else:
+            term = xi + yi - 2 * xi * yi
+        acc = (acc + (term << i)) % P
+    return acc
+
+
+class TableSpec:
+    """memories: list of (chunk j, subtable kind); g = sum_m coeff_m * prod_{i in mono_m} E_i."""
+
+    def __init__(self, name, num_chunks, chunk_bits, memories, g_terms):
+        self.name, self.c, self.l = name, num_chunks, chunk_bits
+        self.memories = list(memories)
+        self.g_terms = [(coeff % P, tuple(mono)) for coeff, mono in g_terms]
+
+    @property
+    def alpha(self):
+        return len(self.memories)
+
+    def g_expression(self):
+        terms = []
+        for coeff, mono in self.g_terms:
+            e = ex.Poly(mono[0])
+            for i in mono[1:]:
+                e = e * ex.Poly(i)
+            terms.append(e * coeff)
+        return ex.sum_exprs(terms)
+
+    def g_eval(self, vals):
+        acc = 0
+        for coeff, mono in self.g_terms:
+            t = coeff
+            for i in mono:
+                t = t * vals[i] % P
+            acc = (acc + t) % P
+        return acc
+
+
+def range_table(num_chunks=2, chunk_bits=16):
+    """value < 2^(c*l): limbs looked up in the identity subtable, a = sum_j 2^(l*j) * limb_j."""
+    return TableSpec("range", num_chunks, chunk_bits,
+                     [(j, SUBTABLE_IDENTITY) for j in range(num_chunks)],
+                     [(1 << (chunk_bits * j), (j,)) for j in range(num_chunks)])
+
+
+def bitwise_table(kind, num_chunks=4, chunk_bits=16):
+    """AND / XOR of two (c*l/2)-bit operands: chunk j = x_j || y_j (l/2 bits each),
+    a = sum_j 2^(l/2*j) * T[x_j || y_j]."""
+    name = "and" if kind == SUBTABLE_AND else "xor"
+    return TableSpec(name, num_chunks, chunk_bits, [(j, kind) for j in range(num_chunks)],
+                     [(1 << (chunk_bits // 2 * j), (j,)) for j in range(num_chunks)])
+
+
+# ------------------------------------------------------------------ witness
+def witness(spec, dims):
+    """dims: c lists of N chunk indices < 2^l.  Returns dict of the committed polys."""
+    c, l = spec.c, spec.l
+    N, M = len(dims[0]), 1 << l
+    read_ts, final_cts = [], []
+    for j in range(c):
+        cnt = [0] * M
+        rts = [0] * N
+        for k, d in enumerate(dims[j]):
+            rts[k] = cnt[d]
+            cnt[d] += 1
+        read_ts.append(rts)
+        final_cts.append(cnt)
+    E = [[subtable_entry(kind, dims[j][k], l) for k in range(N)] for j, kind in spec.memories]
+    a = [spec.g_eval([E[i][k] for i in range(spec.alpha)]) for k in range(N)]
+    return dict(a=a, dim=[list(d) for d in dims], read_ts=read_ts, final_cts=final_cts, E=E)
+
+
+def _fingerprint(a, v, t, gamma, tau):
+    return (a * gamma % P * gamma + v * gamma + t - tau) % P
+
+
+def _check_shape(spec, n):
+    if n < 1 or spec.l < 1:
+        raise LassoError("need at least one variable")
+
+
+# ------------------------------------------------------------------ prover
+def prove(pp, spec, dims, transcript):
+    c, l, alpha = spec.c, spec.l, spec.alpha
+    N, M = len(dims[0]), 1 << l
+    n = N.bit_length() - 1
+    assert N == 1 << n and all(len(d) == N for d in dims) and len(dims) == c
+    _check_shape(spec, n)
+    w = witness(spec, dims)
+    transcript.common_field_elements([n, l, c, alpha])
+    polys_n = [w["a"]] + w["dim"] + w["read_ts"] + w["E"]
+    polys_l = w["final_cts"]
+    kzg.batch_commit_and_write(pp, polys_n, transcript)
+    kzg.batch_commit_and_write(pp, polys_l, transcript)
+
+    r = transcript.squeeze_challenges(n)
+    v = evaluate(w["a"], r)
+    transcript.write_field_element(v)
+    surge = ex.EqXY(0) * spec.g_expression()
+    vp = sc.VirtualPolynomial(surge, w["E"], [], [r])
+    r_z, e_rz = sc.prove(sc.EvaluationsProver, n, vp, v, transcript)
+    transcript.write_field_elements(e_rz)
+
+    gamma = transcript.squeeze_challenge()
+    tau = transcript.squeeze_challenge()
+    leaves_n, leaves_l = [], []
+    for i, (j, kind) in enumerate(spec.memories):
+        rs = [_fingerprint(w["dim"][j][k], w["E"][i][k], w["read_ts"][j][k], gamma, tau) for k in range(N)]
+        ws = [(x + 1) % P for x in rs]
+        init = [_fingerprint(m, subtable_entry(kind, m, l), 0, gamma, tau) for m in range(M)]
+        final = [(init[m] + w["final_cts"][j][m]) % P for m in range(M)]
+        leaves_n += [rs, ws]
+        leaves_l += [init, final]
+    _, claims = gkr.prove_grand_product(leaves_n + leaves_l, transcript)
+    r_N, r_M = claims[0][1], claims[2 * alpha][1]
+
+    dim_e = [evaluate(t, r_N) for t in w["dim"]]
+    rts_e = [evaluate(t, r_N) for t in w["read_ts"]]
+    e_e = [evaluate(t, r_N) for t in w["E"]]
+    fc_e = [evaluate(t, r_M) for t in w["final_cts"]]
+    transcript.write_field_elements(dim_e + rts_e + e_e + fc_e)
+
+    evals_a = _evals_group_a(spec, v, e_rz, dim_e, rts_e, e_e)
+    kzg.batch_open(pp.trim(n), n, polys_n, [r, r_z, r_N], evals_a, transcript)
+    if c >= 2:
+        evals_b = [kzg.Evaluation(j, 0, fc_e[j]) for j in range(c)]
+        kzg.batch_open(pp.trim(l), l, polys_l, [r_M], evals_b, transcript)
+    else:
+        kzg.open_(pp.trim(l), polys_l[0], r_M, transcript)
+    return transcript
+
+
+def _evals_group_a(spec, v, e_rz, dim_e, rts_e, e_e):
+    c, alpha = spec.c, spec.alpha
+    out = [kzg.Evaluation(0, 0, v)]
+    out += [kzg.Evaluation(1 + 2 * c + i, 1, e_rz[i]) for i in range(alpha)]
+    out += [kzg.Evaluation(1 + j, 2, dim_e[j]) for j in range(c)]
+    out += [kzg.Evaluation(1 + c + j, 2, rts_e[j]) for j in range(c)]
+    out += [kzg.Evaluation(1 + 2 * c + i, 2, e_e[i]) for i in range(alpha)]
+    return out
+
+
+# ------------------------------------------------------------------ verifier
+def verify(vp, spec, n, transcript):
+    c, l, alpha = spec.c, spec.l, spec.alpha
+    _check_shape(spec, n)
+    transcript.common_field_elements([n, l, c, alpha])
+    comms_n = transcript.read_commitments(1 + 2 * c + alpha)
+    comms_l = transcript.read_commitments(c)
+
+    r = transcript.squeeze_challenges(n)
+    v = transcript.read_field_element()
+    surge = ex.EqXY(0) * spec.g_expression()
+    x_eval, r_z = sc.verify(sc.Evaluations, n, ex.degree(surge), v, transcript)
+    e_rz = transcript.read_field_elements(alpha)
+    if x_eval != eq_xy_eval(r_z, r) * spec.g_eval(e_rz) % P:
+        raise LassoError("Surge sum-check final evaluation mismatch")
+
+    gamma = transcript.squeeze_challenge()
+    tau = transcript.squeeze_challenge()
+    roots, claims = gkr.verify_grand_product([n] * (2 * alpha) + [l] * (2 * alpha), transcript)
+    for i in range(alpha):
+        rs, ws = roots[2 * i], roots[2 * i + 1]
+        init, final = roots[2 * alpha + 2 * i], roots[2 * alpha + 2 * i + 1]
+        if init * ws % P != rs * final % P:
+            raise LassoError("memory %d: Init*WS != RS*Final" % i)
+    r_N, r_M = claims[0][1], claims[2 * alpha][1]
+
+    vals = transcript.read_field_elements(3 * c + alpha)
+    dim_e, rts_e = vals[:c], vals[c:2 * c]
+    e_e, fc_e = vals[2 * c:2 * c + alpha], vals[2 * c + alpha:]
+    id_M = identity_eval(r_M)
+    for i, (j, kind) in enumerate(spec.memories):
+        rs = _fingerprint(dim_e[j], e_e[i], rts_e[j], gamma, tau)
+        init = _fingerprint(id_M, subtable_mle_eval(kind, r_M), 0, gamma, tau)
+        want = [rs, (rs + 1) % P, init, (init + fc_e[j]) % P]
+        got = [claims[2 * i][0], claims[2 * i + 1][0],
+               claims[2 * alpha + 2 * i][0], claims[2 * alpha + 2 * i + 1][0]]
+        if want != got:
+            raise LassoError("memory %d: leaf claim mismatch" % i)
+
+    evals_a = _evals_group_a(spec, v, e_rz, dim_e, rts_e, e_e)
+    kzg.batch_verify(vp.trim(n), n, comms_n, [r, r_z, r_N], evals_a, transcript)
+    if c >= 2:
+        evals_b = [kzg.Evaluation(j, 0, fc_e[j]) for j in range(c)]
+        kzg.batch_verify(vp.trim(l), l, comms_l, [r_M], evals_b, transcript)
+    else:
+        kzg.verify(vp.trim(l), comms_l[0], r_M, fc_e[0], transcript)
+    if transcript.pos != len(transcript.stream):
+        raise LassoError("trailing bytes in proof")
