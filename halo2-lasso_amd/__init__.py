@@ -1,0 +1,537 @@
+"""halo2-lasso_amd: MI355X-native prover hot path of DoHoonKim8/halo2-lasso.
+
+Host-side mirror (Python, over the C-ABI in include/lasso_hip.h) of the reference's interface for
+the path: names and argument meaning follow plonkish_backend --
+  util::transcript::Keccak256Transcript, poly::multilinear::MultilinearPolynomial,
+  piop::sum_check::{ClassicSumCheck, EvaluationsProver, CoefficientsProver},
+  piop::gkr::prove_fractional_sum_check, util::arithmetic::variable_base_msm,
+  pcs::multilinear::MultilinearKzg, and the Lasso prover (no reference code).
+All compute happens in liblasso_hip.so on the GPU; this module only marshals.
+"""
+import ctypes as C
+
+from . import _ffi
+from ._ffi import (lh_fr, lh_g1, lh_sop, lh_evaluation, lh_lasso_table, lh_transcript,
+                   LH_SC_EVALUATIONS, LH_SC_COEFFICIENTS)
+
+R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+Q_MOD = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+_MONT = 1 << 256
+_MONT_INV_R = pow(_MONT, -1, R_MOD)
+_MONT_INV_Q = pow(_MONT, -1, Q_MOD)
+
+SUBTABLE_IDENTITY, SUBTABLE_AND, SUBTABLE_XOR = 0, 1, 2
+
+
+# ------------------------------------------------------------------ errors (plonkish_backend/src/lib.rs:12-20)
+class Error(Exception):
+    code = None
+
+
+class InvalidSumcheck(Error):
+    code = _ffi.LH_ERR_INVALID_SUMCHECK
+
+
+class InvalidPcsParam(Error):
+    code = _ffi.LH_ERR_INVALID_PCS_PARAM
+
+
+class InvalidPcsOpen(Error):
+    code = _ffi.LH_ERR_INVALID_PCS_OPEN
+
+
+class InvalidSnark(Error):
+    code = _ffi.LH_ERR_INVALID_SNARK
+
+
+class Serialization(Error):
+    code = _ffi.LH_ERR_SERIALIZATION
+
+
+class TranscriptError(Error):
+    code = _ffi.LH_ERR_TRANSCRIPT
+
+
+class DeviceError(Error):
+    code = _ffi.LH_ERR_DEVICE
+
+
+class ArgumentError(Error):  # an assert!/panic in the reference
+    code = _ffi.LH_ERR_ARG
+
+
+_ERRORS = {e.code: e for e in (InvalidSumcheck, InvalidPcsParam, InvalidPcsOpen, InvalidSnark,
+                               Serialization, TranscriptError, DeviceError, ArgumentError)}
+
+
+def _check(rc):
+    if rc != 0:
+        msg = _ffi.load().lh_last_error()
+        raise _ERRORS.get(rc, Error)((msg or b"").decode() or "lh_status %d" % rc)
+
+
+# ------------------------------------------------------------------ marshalling
+def fr_to_bytes(x):
+    """Python int -> 32 bytes of a Montgomery `bn256::Fr`."""
+    return (x % R_MOD * _MONT % R_MOD).to_bytes(32, "little")
+
+
+def fr_from_bytes(b):
+    return int.from_bytes(bytes(b), "little") * _MONT_INV_R % R_MOD
+
+
+def frs_to_bytes(xs):
+    return b"".join(fr_to_bytes(x) for x in xs)
+
+
+def frs_from_bytes(b):
+    return [fr_from_bytes(b[i:i + 32]) for i in range(0, len(b), 32)]
+
+
+def g1_to_bytes(pt):
+    """(x, y) ints or None (identity = (0,0)) -> 64 bytes of a Montgomery `bn256::G1Affine`."""
+    if pt is None:
+        return bytes(64)
+    return b"".join((v % Q_MOD * _MONT % Q_MOD).to_bytes(32, "little") for v in pt)
+
+
+def g1_from_bytes(b):
+    b = bytes(b)
+    x = int.from_bytes(b[:32], "little") * _MONT_INV_Q % Q_MOD
+    y = int.from_bytes(b[32:], "little") * _MONT_INV_Q % Q_MOD
+    return None if x == 0 and y == 0 else (x, y)
+
+
+def _fr_array(xs):
+    arr = (lh_fr * max(len(xs), 1))()
+    C.memmove(arr, frs_to_bytes(xs), 32 * len(xs))
+    return arr
+
+
+def _fr_list(arr, n):
+    return frs_from_bytes(C.string_at(arr, 32 * n))
+
+
+# ------------------------------------------------------------------ context / device memory
+class Context:
+    """One per process per GPU (`lh_ctx`)."""
+
+    def __init__(self, device_id=0):
+        self.lib = _ffi.load()
+        h = C.c_void_p()
+        _check(self.lib.lh_ctx_create(device_id, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.lib.lh_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        _check(self.lib.lh_ctx_sync(self.h))
+
+    @property
+    def stream(self):
+        return self.lib.lh_ctx_stream(self.h)
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def upload(self, data):
+        buf = DeviceBuffer(self, len(data))
+        buf.write(data)
+        return buf
+
+
+class DeviceBuffer:
+    def __init__(self, ctx, nbytes, ptr=None):
+        self.ctx, self.nbytes, self.owned = ctx, nbytes, ptr is None
+        if ptr is None:
+            p = C.c_void_p()
+            _check(ctx.lib.lh_alloc(ctx.h, nbytes, C.byref(p)))
+            ptr = p.value
+        self.ptr = ptr
+
+    def write(self, data, offset=0):
+        data = bytes(data)
+        assert offset + len(data) <= self.nbytes
+        _check(self.ctx.lib.lh_upload(self.ctx.h, self.ptr + offset, data, len(data)))
+
+    def read(self, nbytes=None, offset=0):
+        nbytes = self.nbytes - offset if nbytes is None else nbytes
+        out = C.create_string_buffer(nbytes)
+        _check(self.ctx.lib.lh_download(self.ctx.h, out, self.ptr + offset, nbytes))
+        return out.raw
+
+    def free(self):
+        if self.owned and self.ptr and self.ctx.h:
+            self.ctx.lib.lh_free(self.ctx.h, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _ptr_array(bufs):
+    arr = (C.c_void_p * max(len(bufs), 1))()
+    for i, b in enumerate(bufs):
+        arr[i] = b.ptr if hasattr(b, "ptr") else b
+    return arr
+
+
+# ------------------------------------------------------------------ transcript
+class Keccak256Transcript:
+    """util::transcript::Keccak256Transcript<Cursor<Vec<u8>>> (write side), living in the library."""
+
+    def __init__(self):
+        self.lib = _ffi.load()
+        p = C.POINTER(lh_transcript)()
+        _check(self.lib.lh_keccak_transcript_new(C.byref(p)))
+        self.p = p
+
+    def _vt(self):
+        return self.p.contents
+
+    def write_field_element(self, fe):
+        _check(self._vt().write_field_element(self._vt().user, C.byref(_fr_array([fe])[0])))
+
+    def write_field_elements(self, fes):
+        for fe in fes:
+            self.write_field_element(fe)
+
+    def common_field_element(self, fe):
+        _check(self._vt().common_field_element(self._vt().user, C.byref(_fr_array([fe])[0])))
+
+    def squeeze_challenge(self):
+        out = lh_fr()
+        _check(self._vt().squeeze_challenge(self._vt().user, C.byref(out)))
+        return fr_from_bytes(bytes(out))
+
+    def squeeze_challenges(self, n):
+        return [self.squeeze_challenge() for _ in range(n)]
+
+    def write_commitment(self, pt):
+        g = lh_g1()
+        C.memmove(C.byref(g), g1_to_bytes(pt), 64)
+        _check(self._vt().write_commitment(self._vt().user, C.byref(g)))
+
+    def write_commitments(self, pts):
+        for pt in pts:
+            self.write_commitment(pt)
+
+    def into_proof(self):
+        ptr, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+        _check(self.lib.lh_keccak_transcript_proof(self.p, C.byref(ptr), C.byref(n)))
+        return C.string_at(ptr, n.value)
+
+    def __del__(self):
+        try:
+            if self.p:
+                self.lib.lh_keccak_transcript_free(self.p)
+                self.p = None
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------ poly::multilinear
+class MultilinearPolynomial:
+    """Device-resident evaluation table of 2^num_vars Fr (poly/multilinear.rs:20-24)."""
+
+    def __init__(self, ctx, buf, num_vars):
+        self.ctx, self.buf, self.num_vars = ctx, buf, num_vars
+
+    @property
+    def ptr(self):
+        return self.buf.ptr
+
+    def __len__(self):
+        return 1 << self.num_vars
+
+    @classmethod
+    def new(cls, ctx, evals):
+        n = len(evals)
+        assert n and n & (n - 1) == 0
+        return cls(ctx, ctx.upload(frs_to_bytes(evals)), n.bit_length() - 1)
+
+    @classmethod
+    def from_u32(cls, ctx, values):
+        import array
+        n = len(values)
+        assert n and n & (n - 1) == 0
+        src = ctx.upload(array.array("I", values).tobytes())
+        out = ctx.alloc(32 * n)
+        _check(ctx.lib.lh_fr_from_u32(ctx.h, src.ptr, n, out.ptr))
+        ctx.sync()
+        return cls(ctx, out, n.bit_length() - 1)
+
+    @classmethod
+    def eq_xy(cls, ctx, y):
+        out = ctx.alloc(32 << len(y))
+        _check(ctx.lib.lh_eq_xy(ctx.h, _fr_array(y), len(y), out.ptr))
+        return cls(ctx, out, len(y))
+
+    def evals(self):
+        return frs_from_bytes(self.buf.read(32 << self.num_vars))
+
+    def fix_var(self, x):
+        out = self.ctx.alloc(32 << (self.num_vars - 1))
+        _check(self.ctx.lib.lh_fix_var(self.ctx.h, self.ptr, 1 << self.num_vars, _fr_array([x]), out.ptr))
+        return MultilinearPolynomial(self.ctx, out, self.num_vars - 1)
+
+    def evaluate(self, x):
+        return evaluate_polys(self.ctx, [self], x)[0]
+
+
+def evaluate_polys(ctx, polys, x):
+    out = (lh_fr * len(polys))()
+    _check(ctx.lib.lh_evaluate(ctx.h, _ptr_array(polys), len(polys), len(x), _fr_array(x), out))
+    return _fr_list(out, len(polys))
+
+
+# ------------------------------------------------------------------ piop::sum_check
+EvaluationsProver = LH_SC_EVALUATIONS
+CoefficientsProver = LH_SC_COEFFICIENTS
+
+
+class SumOfProducts:
+    """[eq_xy(ys[global_eq]) *] sum_m coeff_m * prod_k table[id]; ids < len(polys) are polys,
+    ids >= len(polys) are eq_xy(ys[id - len(polys)]) -- the Expression shapes of
+    fractional_sum_check.rs:272-281 and pcs/multilinear.rs:182-190."""
+
+    def __init__(self, terms, global_eq=-1):
+        self.terms, self.global_eq = [(c % R_MOD, list(f)) for c, f in terms], global_eq
+
+    def to_c(self):
+        s = lh_sop()
+        s.num_terms, s.global_eq = len(self.terms), self.global_eq
+        for m, (coeff, facs) in enumerate(self.terms):
+            C.memmove(C.byref(s.coeff[m]), fr_to_bytes(coeff), 32)
+            s.num_factors[m] = len(facs)
+            for k, f in enumerate(facs):
+                s.factor[m][k] = f
+        return s
+
+
+class ClassicSumCheck:
+    @staticmethod
+    def prove(ctx, prover, num_vars, expression, polys, ys, sum_, transcript):
+        """ClassicSumCheck::<P>::prove (classic.rs:208-240) -> (challenges, evals)."""
+        if len(expression.terms) > _ffi.LH_SC_MAX_TERMS:
+            raise ArgumentError("too many terms")
+        ys_flat = [v for y in ys for v in y]
+        ch = (lh_fr * max(num_vars, 1))()
+        ev = (lh_fr * max(len(polys), 1))()
+        sop = expression.to_c()
+        _check(ctx.lib.lh_sumcheck_prove(ctx.h, prover, num_vars, C.byref(sop), _ptr_array(polys), len(polys),
+                                         _fr_array(ys_flat), len(ys), _fr_array([sum_]), transcript.p, ch, ev))
+        return _fr_list(ch, num_vars), _fr_list(ev, len(polys))
+
+
+# ------------------------------------------------------------------ piop::gkr
+def prove_fractional_sum_check(ctx, claimed_p_0s, claimed_q_0s, ps, qs, transcript):
+    """fractional_sum_check.rs:89-190 -> (p_xs, q_xs, x)."""
+    B = len(ps)
+    if not (B == len(qs) == len(claimed_p_0s) == len(claimed_q_0s)):
+        raise ArgumentError("length mismatch")  # :105-107 assert_eq
+    num_vars = ps[0].num_vars if B else 0
+    for p in list(ps) + list(qs):
+        if p.num_vars != num_vars:
+            raise ArgumentError("num_vars mismatch")  # :108-110
+
+    def opt(claims):
+        keep = [_fr_array([c]) if c is not None else None for c in claims]
+        arr = (C.POINTER(lh_fr) * max(B, 1))()
+        for i, k in enumerate(keep):
+            arr[i] = C.cast(k, C.POINTER(lh_fr)) if k is not None else None
+        return arr, keep
+
+    cp, keep_p = opt(claimed_p_0s)
+    cq, keep_q = opt(claimed_q_0s)
+    p_xs, q_xs, x = (lh_fr * max(B, 1))(), (lh_fr * max(B, 1))(), (lh_fr * max(num_vars, 1))()
+    _check(ctx.lib.lh_gkr_fractional_prove(ctx.h, B, num_vars, cp, cq, _ptr_array(ps), _ptr_array(qs),
+                                           transcript.p, p_xs, q_xs, x))
+    return _fr_list(p_xs, B), _fr_list(q_xs, B), _fr_list(x, num_vars)
+
+
+def prove_grand_product(ctx, leaves, transcript):
+    """Batched product-tree GKR (Lasso memory check) -> (roots, [(claim, point)])."""
+    B = len(leaves)
+    nv = (C.c_size_t * max(B, 1))(*[p.num_vars for p in leaves])
+    total = sum(p.num_vars for p in leaves)
+    roots, claims, points = (lh_fr * max(B, 1))(), (lh_fr * max(B, 1))(), (lh_fr * max(total, 1))()
+    _check(ctx.lib.lh_grand_product_prove(ctx.h, B, _ptr_array(leaves), nv, transcript.p, roots, claims, points))
+    pts, flat, off = [], _fr_list(points, total), 0
+    for p in leaves:
+        pts.append(flat[off:off + p.num_vars])
+        off += p.num_vars
+    return _fr_list(roots, B), list(zip(_fr_list(claims, B), pts))
+
+
+# ------------------------------------------------------------------ util::arithmetic::msm
+def variable_base_msm(ctx, scalars, bases, n=None):
+    """msm.rs:84-181 on device buffers -> affine (x, y) ints or None for the identity."""
+    n = len(scalars) if n is None else n
+    out = lh_g1()
+    _check(ctx.lib.lh_msm(ctx.h, scalars.ptr, bases.ptr, n, C.byref(out)))
+    return g1_from_bytes(bytes(out))
+
+
+def variable_base_msm_u32(ctx, scalars, bases, n):
+    out = lh_g1()
+    _check(ctx.lib.lh_msm_u32(ctx.h, scalars.ptr, bases.ptr, n, C.byref(out)))
+    return g1_from_bytes(bytes(out))
+
+
+# ------------------------------------------------------------------ pcs::multilinear::kzg
+class Evaluation:
+    """pcs.rs:132-155"""
+
+    def __init__(self, poly, point, value):
+        self.poly, self.point, self.value = poly, point, value % R_MOD
+
+
+class MultilinearKzgParams:
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+
+    @property
+    def num_vars(self):
+        return self.ctx.lib.lh_srs_num_vars(self.h)
+
+    def eqs(self):
+        """All levels as lists of affine points (level k has 2^k)."""
+        n = self.num_vars
+        total = (2 << n) - 1
+        out = C.create_string_buffer(64 * total)
+        _check(self.ctx.lib.lh_srs_download(self.ctx.h, self.h, out))
+        pts = [g1_from_bytes(out.raw[64 * i:64 * i + 64]) for i in range(total)]
+        return [pts[(1 << k) - 1:(2 << k) - 1] for k in range(n + 1)]
+
+    def free(self):
+        if self.h and self.ctx.h:
+            self.ctx.lib.lh_srs_free(self.ctx.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class MultilinearKzg:
+    """pcs/multilinear/kzg.rs:150-361 (prover side)."""
+
+    @staticmethod
+    def setup(ctx, ss):
+        """kzg.rs:166-228 with the trapdoor `ss` explicit."""
+        h = C.c_void_p()
+        _check(ctx.lib.lh_mkzg_setup(ctx.h, _fr_array(ss), len(ss), C.byref(h)))
+        return MultilinearKzgParams(ctx, h)
+
+    @staticmethod
+    def upload(ctx, eqs_levels):
+        flat = b"".join(g1_to_bytes(p) for lvl in eqs_levels for p in lvl)
+        h = C.c_void_p()
+        _check(ctx.lib.lh_srs_upload(ctx.h, flat, len(eqs_levels) - 1, C.byref(h)))
+        return MultilinearKzgParams(ctx, h)
+
+    @staticmethod
+    def commit(pp, poly):
+        out = lh_g1()
+        _check(pp.ctx.lib.lh_mkzg_commit(pp.ctx.h, pp.h, poly.ptr, poly.num_vars, C.byref(out)))
+        return g1_from_bytes(bytes(out))
+
+    @staticmethod
+    def batch_commit(pp, polys):
+        if not polys:
+            return []
+        out = (lh_g1 * len(polys))()
+        _check(pp.ctx.lib.lh_mkzg_batch_commit(pp.ctx.h, pp.h, _ptr_array(polys), len(polys), polys[0].num_vars, out))
+        raw = C.string_at(out, 64 * len(polys))
+        return [g1_from_bytes(raw[64 * i:64 * i + 64]) for i in range(len(polys))]
+
+    @staticmethod
+    def batch_commit_and_write(pp, polys, transcript):
+        comms = MultilinearKzg.batch_commit(pp, polys)
+        transcript.write_commitments(comms)
+        return comms
+
+    @staticmethod
+    def open(pp, poly, point, transcript):
+        out = lh_fr()
+        _check(pp.ctx.lib.lh_mkzg_open(pp.ctx.h, pp.h, poly.ptr, poly.num_vars, _fr_array(point), transcript.p,
+                                       C.byref(out)))
+        return fr_from_bytes(bytes(out))
+
+    @staticmethod
+    def batch_open(pp, num_vars, polys, points, evals, transcript):
+        evs = (lh_evaluation * max(len(evals), 1))()
+        for i, e in enumerate(evals):
+            evs[i].poly, evs[i].point = e.poly, e.point
+            C.memmove(C.byref(evs[i].value), fr_to_bytes(e.value), 32)
+        flat = [v for p in points for v in p]
+        for p in points:
+            if len(p) != num_vars:
+                raise InvalidPcsParam("Invalid point (expect point to have %d variates but got %d)" % (num_vars, len(p)))
+        _check(pp.ctx.lib.lh_mkzg_batch_open(pp.ctx.h, pp.h, num_vars, _ptr_array(polys), len(polys), _fr_array(flat),
+                                             len(points), evs, len(evals), transcript.p))
+
+
+# ------------------------------------------------------------------ Lasso
+class LassoTable:
+    """Decomposable table: c chunks of l bits, memories (chunk, subtable), g = sum coeff * prod E_i."""
+
+    def __init__(self, num_chunks, chunk_bits, memories, g_terms):
+        self.c, self.l, self.memories = num_chunks, chunk_bits, list(memories)
+        self.g_terms = [(co % R_MOD, list(f)) for co, f in g_terms]
+
+    @classmethod
+    def range(cls, num_chunks=2, chunk_bits=16):
+        return cls(num_chunks, chunk_bits, [(j, SUBTABLE_IDENTITY) for j in range(num_chunks)],
+                   [(1 << (chunk_bits * j), [j]) for j in range(num_chunks)])
+
+    @classmethod
+    def bitwise(cls, kind, num_chunks=4, chunk_bits=16):
+        return cls(num_chunks, chunk_bits, [(j, kind) for j in range(num_chunks)],
+                   [(1 << (chunk_bits // 2 * j), [j]) for j in range(num_chunks)])
+
+    def to_c(self):
+        t = lh_lasso_table()
+        t.num_chunks, t.chunk_bits, t.num_memories = self.c, self.l, len(self.memories)
+        for i, (j, kind) in enumerate(self.memories):
+            t.memory_chunk[i], t.memory_subtable[i] = j, kind
+        t.num_terms = len(self.g_terms)
+        for m, (co, facs) in enumerate(self.g_terms):
+            C.memmove(C.byref(t.g_coeff[m]), fr_to_bytes(co), 32)
+            t.g_num_factors[m] = len(facs)
+            for k, f in enumerate(facs):
+                t.g_factor[m][k] = f
+        return t
+
+
+def lasso_prove(pp, table, num_vars, dims, transcript):
+    """dims: c device buffers of u32[2^num_vars] chunk indices. Appends the proof to `transcript`."""
+    if len(dims) != table.c:
+        raise ArgumentError("expected %d dim columns" % table.c)
+    if len(table.memories) > _ffi.LH_LASSO_MAX_MEMORIES or table.c > _ffi.LH_LASSO_MAX_CHUNKS \
+            or len(table.g_terms) > _ffi.LH_LASSO_MAX_TERMS:
+        raise ArgumentError("table too large")
+    t = table.to_c()
+    _check(pp.ctx.lib.lh_lasso_prove(pp.ctx.h, pp.h, C.byref(t), num_vars, _ptr_array(dims), transcript.p))
+
+
+def lasso_last_timing(ctx):
+    out = (C.c_double * _ffi.LH_LASSO_NUM_PHASES)()
+    _check(ctx.lib.lh_lasso_last_timing(ctx.h, out))
+    names = ["witness", "commit", "surge", "leaves", "gkr", "evals", "open_n", "open_l", "total"]
+    return dict(zip(names, list(out)))

@@ -1,0 +1,133 @@
+"""ctypes binding of liblasso_hip.so -- the declarations of include/lasso_hip.h.
+
+Loading fails loudly when the library has not been built (`__graft_entry__.build()` or
+`make -C halo2-lasso_amd/csrc`): there is no Python or CPU fallback for any compute call.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblasso_hip.so")
+
+LH_OK = 0
+LH_ERR_INVALID_SUMCHECK, LH_ERR_INVALID_PCS_PARAM, LH_ERR_INVALID_PCS_OPEN = -1, -2, -3
+LH_ERR_INVALID_SNARK, LH_ERR_SERIALIZATION, LH_ERR_TRANSCRIPT, LH_ERR_DEVICE, LH_ERR_ARG = -4, -5, -6, -7, -8
+LH_SC_EVALUATIONS, LH_SC_COEFFICIENTS = 0, 1
+LH_SC_MAX_TERMS, LH_SC_MAX_FACTORS = 48, 4
+LH_LASSO_MAX_CHUNKS, LH_LASSO_MAX_MEMORIES, LH_LASSO_MAX_TERMS = 8, 16, 16
+LH_LASSO_NUM_PHASES = 9
+
+
+class lh_fr(C.Structure):
+    _fields_ = [("l", C.c_uint64 * 4)]
+
+
+class lh_g1(C.Structure):
+    _fields_ = [("x", C.c_uint64 * 4), ("y", C.c_uint64 * 4)]
+
+
+class lh_sop(C.Structure):
+    _fields_ = [("num_terms", C.c_uint32), ("global_eq", C.c_int32),
+                ("coeff", lh_fr * LH_SC_MAX_TERMS),
+                ("num_factors", C.c_uint8 * LH_SC_MAX_TERMS),
+                ("factor", (C.c_uint8 * LH_SC_MAX_FACTORS) * LH_SC_MAX_TERMS)]
+
+
+class lh_evaluation(C.Structure):
+    _fields_ = [("poly", C.c_uint32), ("point", C.c_uint32), ("value", lh_fr)]
+
+
+class lh_lasso_table(C.Structure):
+    _fields_ = [("num_chunks", C.c_uint32), ("chunk_bits", C.c_uint32), ("num_memories", C.c_uint32),
+                ("memory_chunk", C.c_uint32 * LH_LASSO_MAX_MEMORIES),
+                ("memory_subtable", C.c_uint32 * LH_LASSO_MAX_MEMORIES),
+                ("num_terms", C.c_uint32),
+                ("g_coeff", lh_fr * LH_LASSO_MAX_TERMS),
+                ("g_num_factors", C.c_uint8 * LH_LASSO_MAX_TERMS),
+                ("g_factor", (C.c_uint8 * LH_SC_MAX_FACTORS) * LH_LASSO_MAX_TERMS)]
+
+
+_FE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(lh_fr))
+_G1_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(lh_g1))
+
+
+class lh_transcript(C.Structure):
+    _fields_ = [("user", C.c_void_p),
+                ("write_field_element", _FE_CB), ("common_field_element", _FE_CB),
+                ("squeeze_challenge", _FE_CB),
+                ("write_commitment", _G1_CB), ("common_commitment", _G1_CB)]
+
+
+_P = C.c_void_p
+_SZ = C.c_size_t
+# name -> (restype, argtypes); every symbol include/lasso_hip.h declares
+SIGNATURES = {
+    "lh_last_error": (C.c_char_p, []),
+    "lh_version": (C.c_char_p, []),
+    "lh_ctx_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "lh_ctx_destroy": (None, [_P]),
+    "lh_ctx_sync": (C.c_int, [_P]),
+    "lh_ctx_stream": (_P, [_P]),
+    "lh_alloc": (C.c_int, [_P, _SZ, C.POINTER(_P)]),
+    "lh_free": (C.c_int, [_P, _P]),
+    "lh_upload": (C.c_int, [_P, _P, _P, _SZ]),
+    "lh_download": (C.c_int, [_P, _P, _P, _SZ]),
+    "lh_keccak_transcript_new": (C.c_int, [C.POINTER(C.POINTER(lh_transcript))]),
+    "lh_keccak_transcript_free": (None, [C.POINTER(lh_transcript)]),
+    "lh_keccak_transcript_proof": (C.c_int, [C.POINTER(lh_transcript), C.POINTER(C.POINTER(C.c_uint8)),
+                                             C.POINTER(_SZ)]),
+    "lh_fr_from_u64": (C.c_int, [_P, _P, _SZ, _P]),
+    "lh_fr_from_u32": (C.c_int, [_P, _P, _SZ, _P]),
+    "lh_fr_to_repr": (C.c_int, [_P, _P, _SZ, _P]),
+    "lh_fr_from_repr": (C.c_int, [_P, _P, _SZ, _P]),
+    "lh_fr_add": (C.c_int, [_P, _P, _P, _SZ, _P]),
+    "lh_fr_sub": (C.c_int, [_P, _P, _P, _SZ, _P]),
+    "lh_fr_mul": (C.c_int, [_P, _P, _P, _SZ, _P]),
+    "lh_fr_mul_chain": (C.c_int, [_P, _P, _P, _SZ, C.c_int, _P]),
+    "lh_fr_batch_invert": (C.c_int, [_P, _P, _SZ, _P]),
+    "lh_fix_var": (C.c_int, [_P, _P, _SZ, C.POINTER(lh_fr), _P]),
+    "lh_eq_xy": (C.c_int, [_P, C.POINTER(lh_fr), _SZ, _P]),
+    "lh_evaluate": (C.c_int, [_P, C.POINTER(_P), _SZ, _SZ, C.POINTER(lh_fr), C.POINTER(lh_fr)]),
+    "lh_lincomb": (C.c_int, [_P, C.POINTER(_P), C.POINTER(lh_fr), _SZ, _SZ, _P]),
+    "lh_sumcheck_prove": (C.c_int, [_P, C.c_int, _SZ, C.POINTER(lh_sop), C.POINTER(_P), _SZ,
+                                    C.POINTER(lh_fr), _SZ, C.POINTER(lh_fr), C.POINTER(lh_transcript),
+                                    C.POINTER(lh_fr), C.POINTER(lh_fr)]),
+    "lh_gkr_fractional_prove": (C.c_int, [_P, _SZ, _SZ, C.POINTER(C.POINTER(lh_fr)), C.POINTER(C.POINTER(lh_fr)),
+                                          C.POINTER(_P), C.POINTER(_P), C.POINTER(lh_transcript),
+                                          C.POINTER(lh_fr), C.POINTER(lh_fr), C.POINTER(lh_fr)]),
+    "lh_grand_product_prove": (C.c_int, [_P, _SZ, C.POINTER(_P), C.POINTER(_SZ), C.POINTER(lh_transcript),
+                                         C.POINTER(lh_fr), C.POINTER(lh_fr), C.POINTER(lh_fr)]),
+    "lh_msm": (C.c_int, [_P, _P, _P, _SZ, C.POINTER(lh_g1)]),
+    "lh_msm_u32": (C.c_int, [_P, _P, _P, _SZ, C.POINTER(lh_g1)]),
+    "lh_mkzg_setup": (C.c_int, [_P, C.POINTER(lh_fr), _SZ, C.POINTER(_P)]),
+    "lh_srs_upload": (C.c_int, [_P, _P, _SZ, C.POINTER(_P)]),
+    "lh_srs_download": (C.c_int, [_P, _P, _P]),
+    "lh_srs_num_vars": (_SZ, [_P]),
+    "lh_srs_free": (None, [_P, _P]),
+    "lh_mkzg_commit": (C.c_int, [_P, _P, _P, _SZ, C.POINTER(lh_g1)]),
+    "lh_mkzg_batch_commit": (C.c_int, [_P, _P, C.POINTER(_P), _SZ, _SZ, C.POINTER(lh_g1)]),
+    "lh_mkzg_open": (C.c_int, [_P, _P, _P, _SZ, C.POINTER(lh_fr), C.POINTER(lh_transcript), C.POINTER(lh_fr)]),
+    "lh_mkzg_batch_open": (C.c_int, [_P, _P, _SZ, C.POINTER(_P), _SZ, C.POINTER(lh_fr), _SZ,
+                                     C.POINTER(lh_evaluation), _SZ, C.POINTER(lh_transcript)]),
+    "lh_lasso_prove": (C.c_int, [_P, _P, C.POINTER(lh_lasso_table), _SZ, C.POINTER(_P), C.POINTER(lh_transcript)]),
+    "lh_lasso_last_timing": (C.c_int, [_P, C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library and attach the signatures; raises if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(no CPU fallback exists)" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib

@@ -1,0 +1,366 @@
+// extern "C" boundary: thin wrappers translating C++ exceptions into lh_status codes.
+#include "host.hpp"
+
+using namespace lh;
+
+struct lh_ctx {
+  Ctx c;
+};
+struct lh_srs {
+  Srs s;
+};
+
+#define LH_TRY try {
+#define LH_CATCH                                  \
+  }                                               \
+  catch (const lh::Error& e) {                    \
+    lh::set_last_error(e.what());                 \
+    return e.code;                                \
+  }                                               \
+  catch (const std::exception& e) {               \
+    lh::set_last_error(e.what());                 \
+    return LH_ERR_DEVICE;                         \
+  }                                               \
+  return LH_OK;
+
+#define NEED(p) LH_REQUIRE((p) != nullptr, LH_ERR_ARG, "null argument: " #p)
+
+extern "C" {
+
+const char* lh_last_error(void) { return lh::get_last_error(); }
+const char* lh_version(void) { return "lasso-hip 0.1 (gfx950)"; }
+
+lh_status lh_ctx_create(int device_id, lh_ctx** out) {
+  LH_TRY
+  NEED(out);
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    throw lh::Error(LH_ERR_DEVICE, "no HIP device available (this library has no CPU fallback)");
+  LH_REQUIRE(device_id >= 0 && device_id < count, LH_ERR_DEVICE, "device id out of range");
+  LH_HIP(hipSetDevice(device_id));
+  lh_ctx* ctx = new lh_ctx();
+  ctx->c.device = device_id;
+  LH_HIP(hipStreamCreateWithFlags(&ctx->c.stream, hipStreamNonBlocking));
+  hipDeviceProp_t prop;
+  LH_HIP(hipGetDeviceProperties(&prop, device_id));
+  ctx->c.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  ctx->c.pin(65536);
+  *out = ctx;
+  LH_CATCH
+}
+
+void lh_ctx_destroy(lh_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->c.device);
+  (void)hipStreamSynchronize(ctx->c.stream);
+  if (ctx->c.pinned) (void)hipHostFree(ctx->c.pinned);
+  (void)hipStreamDestroy(ctx->c.stream);
+  delete ctx;
+}
+
+lh_status lh_ctx_sync(lh_ctx* ctx) {
+  LH_TRY
+  NEED(ctx);
+  ctx->c.sync();
+  LH_CATCH
+}
+void* lh_ctx_stream(lh_ctx* ctx) { return ctx ? (void*)ctx->c.stream : nullptr; }
+
+lh_status lh_alloc(lh_ctx* ctx, size_t bytes, void** d_out) {
+  LH_TRY
+  NEED(ctx);
+  NEED(d_out);
+  LH_HIP(hipSetDevice(ctx->c.device));
+  LH_HIP(hipMalloc(d_out, bytes ? bytes : 1));
+  LH_CATCH
+}
+lh_status lh_free(lh_ctx* ctx, void* d_ptr) {
+  LH_TRY
+  NEED(ctx);
+  ctx->c.sync();
+  if (d_ptr) LH_HIP(hipFree(d_ptr));
+  LH_CATCH
+}
+lh_status lh_upload(lh_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
+  LH_TRY
+  NEED(ctx);
+  if (bytes) {
+    LH_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->c.stream));
+    ctx->c.sync();
+  }
+  LH_CATCH
+}
+lh_status lh_download(lh_ctx* ctx, void* dst, const void* d_src, size_t bytes) {
+  LH_TRY
+  NEED(ctx);
+  if (bytes) {
+    LH_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->c.stream));
+    ctx->c.sync();
+  }
+  LH_CATCH
+}
+
+// ---------------------------------------------------------------- transcript
+lh_status lh_keccak_transcript_new(lh_transcript** out) {
+  LH_TRY
+  NEED(out);
+  KeccakTranscript* t = new KeccakTranscript();
+  *out = &t->vt;
+  LH_CATCH
+}
+void lh_keccak_transcript_free(lh_transcript* t) {
+  if (t) delete (KeccakTranscript*)t->user;
+}
+lh_status lh_keccak_transcript_proof(lh_transcript* t, const uint8_t** bytes, size_t* len) {
+  LH_TRY
+  NEED(t);
+  NEED(bytes);
+  NEED(len);
+  KeccakTranscript* k = (KeccakTranscript*)t->user;
+  *bytes = k->stream.data();
+  *len = k->stream.size();
+  LH_CATCH
+}
+
+// ---------------------------------------------------------------- Fr vectors
+lh_status lh_fr_from_u64(lh_ctx* ctx, const uint64_t* d_in, size_t n, lh_fr* d_out) {
+  LH_TRY NEED(ctx);
+  k_fr_from_u64(ctx->c, d_in, n, (Fr*)d_out);
+  LH_CATCH
+}
+lh_status lh_fr_from_u32(lh_ctx* ctx, const uint32_t* d_in, size_t n, lh_fr* d_out) {
+  LH_TRY NEED(ctx);
+  k_fr_from_u32(ctx->c, d_in, n, (Fr*)d_out);
+  LH_CATCH
+}
+lh_status lh_fr_to_repr(lh_ctx* ctx, const lh_fr* d_in, size_t n, uint8_t* d_out32) {
+  LH_TRY NEED(ctx);
+  k_fr_to_repr(ctx->c, (const Fr*)d_in, n, (Fr*)d_out32);
+  LH_CATCH
+}
+lh_status lh_fr_from_repr(lh_ctx* ctx, const uint8_t* d_in32, size_t n, lh_fr* d_out) {
+  LH_TRY NEED(ctx);
+  k_fr_from_repr(ctx->c, (const Fr*)d_in32, n, (Fr*)d_out);
+  LH_CATCH
+}
+lh_status lh_fr_add(lh_ctx* ctx, const lh_fr* a, const lh_fr* b, size_t n, lh_fr* out) {
+  LH_TRY NEED(ctx);
+  k_fr_binop(ctx->c, 0, (const Fr*)a, (const Fr*)b, n, (Fr*)out);
+  LH_CATCH
+}
+lh_status lh_fr_sub(lh_ctx* ctx, const lh_fr* a, const lh_fr* b, size_t n, lh_fr* out) {
+  LH_TRY NEED(ctx);
+  k_fr_binop(ctx->c, 1, (const Fr*)a, (const Fr*)b, n, (Fr*)out);
+  LH_CATCH
+}
+lh_status lh_fr_mul(lh_ctx* ctx, const lh_fr* a, const lh_fr* b, size_t n, lh_fr* out) {
+  LH_TRY NEED(ctx);
+  k_fr_binop(ctx->c, 2, (const Fr*)a, (const Fr*)b, n, (Fr*)out);
+  LH_CATCH
+}
+lh_status lh_fr_mul_chain(lh_ctx* ctx, const lh_fr* a, const lh_fr* b, size_t n, int iters, lh_fr* out) {
+  LH_TRY NEED(ctx);
+  k_fr_mul_chain(ctx->c, (const Fr*)a, (const Fr*)b, n, iters, (Fr*)out);
+  LH_CATCH
+}
+lh_status lh_fr_batch_invert(lh_ctx* ctx, const lh_fr* d_in, size_t n, lh_fr* d_out) {
+  LH_TRY NEED(ctx);
+  k_fr_batch_invert(ctx->c, (const Fr*)d_in, n, (Fr*)d_out);
+  LH_CATCH
+}
+
+// ---------------------------------------------------------------- MultilinearPolynomial
+static bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
+
+lh_status lh_fix_var(lh_ctx* ctx, const lh_fr* d_in, size_t n_in, const lh_fr* x, lh_fr* d_out) {
+  LH_TRY NEED(ctx);
+  NEED(x);
+  LH_REQUIRE(is_pow2(n_in) && n_in >= 2, LH_ERR_ARG, "fix_var: table must have 2^m >= 2 entries");
+  Fr xr;
+  memcpy(&xr, x, 32);
+  k_fix_var(ctx->c, (const Fr*)d_in, n_in, xr, (Fr*)d_out);
+  LH_CATCH
+}
+lh_status lh_eq_xy(lh_ctx* ctx, const lh_fr* y, size_t num_vars, lh_fr* d_out) {
+  LH_TRY NEED(ctx);
+  LH_REQUIRE(num_vars < 32, LH_ERR_ARG, "eq_xy: num_vars too large");
+  k_eq_xy(ctx->c, (const Fr*)y, num_vars, (Fr*)d_out);
+  LH_CATCH
+}
+lh_status lh_evaluate(lh_ctx* ctx, const lh_fr* const* d_polys, size_t num_polys, size_t num_vars,
+                      const lh_fr* point, lh_fr* out_evals) {
+  LH_TRY NEED(ctx);
+  std::vector<HFr> ev = evaluate_polys(ctx->c, (const Fr* const*)d_polys, num_polys, num_vars, (const HFr*)point);
+  memcpy(out_evals, ev.data(), num_polys * 32);
+  LH_CATCH
+}
+lh_status lh_lincomb(lh_ctx* ctx, const lh_fr* const* d_polys, const lh_fr* w, size_t num_polys, size_t n,
+                     lh_fr* d_out) {
+  LH_TRY NEED(ctx);
+  k_lincomb(ctx->c, (const Fr* const*)d_polys, (const Fr*)w, num_polys, n, (Fr*)d_out);
+  LH_CATCH
+}
+
+// ---------------------------------------------------------------- sum-check / GKR
+lh_status lh_sumcheck_prove(lh_ctx* ctx, int prover_kind, size_t num_vars, const lh_sop* expr,
+                            const lh_fr* const* d_polys, size_t num_polys, const lh_fr* ys, size_t num_ys,
+                            const lh_fr* sum, lh_transcript* t, lh_fr* out_challenges, lh_fr* out_evals) {
+  LH_TRY NEED(ctx);
+  NEED(expr);
+  NEED(sum);
+  LH_REQUIRE(prover_kind == LH_SC_EVALUATIONS || prover_kind == LH_SC_COEFFICIENTS, LH_ERR_ARG, "bad prover kind");
+  Transcript tr(t);
+  HFr s;
+  memcpy(&s, sum, 32);
+  SumCheckResult r = sum_check_prove(ctx->c, prover_kind, num_vars, *expr, (const Fr* const*)d_polys, num_polys,
+                                     (const HFr*)ys, num_ys, s, tr);
+  if (out_challenges) memcpy(out_challenges, r.challenges.data(), r.challenges.size() * 32);
+  if (out_evals) memcpy(out_evals, r.evals.data(), r.evals.size() * 32);
+  LH_CATCH
+}
+
+lh_status lh_gkr_fractional_prove(lh_ctx* ctx, size_t num_batching, size_t num_vars,
+                                  const lh_fr* const* claimed_p_0s, const lh_fr* const* claimed_q_0s,
+                                  const lh_fr* const* d_ps, const lh_fr* const* d_qs, lh_transcript* t,
+                                  lh_fr* out_p_xs, lh_fr* out_q_xs, lh_fr* out_x) {
+  LH_TRY NEED(ctx);
+  Transcript tr(t);
+  FracSumCheckResult r =
+      prove_fractional_sum_check(ctx->c, num_batching, num_vars, (const HFr* const*)claimed_p_0s,
+                                 (const HFr* const*)claimed_q_0s, (const Fr* const*)d_ps, (const Fr* const*)d_qs, tr);
+  if (out_p_xs) memcpy(out_p_xs, r.p_xs.data(), r.p_xs.size() * 32);
+  if (out_q_xs) memcpy(out_q_xs, r.q_xs.data(), r.q_xs.size() * 32);
+  if (out_x) memcpy(out_x, r.x.data(), r.x.size() * 32);
+  LH_CATCH
+}
+
+lh_status lh_grand_product_prove(lh_ctx* ctx, size_t num_trees, const lh_fr* const* d_leaves, const size_t* num_vars,
+                                 lh_transcript* t, lh_fr* out_roots, lh_fr* out_claims, lh_fr* out_points) {
+  LH_TRY NEED(ctx);
+  NEED(num_vars);
+  Transcript tr(t);
+  GrandProductResult r = prove_grand_product(ctx->c, num_trees, (const Fr* const*)d_leaves, num_vars, tr);
+  if (out_roots) memcpy(out_roots, r.roots.data(), num_trees * 32);
+  if (out_claims) memcpy(out_claims, r.claims.data(), num_trees * 32);
+  if (out_points) {
+    lh_fr* p = out_points;
+    for (size_t b = 0; b < num_trees; b++) {
+      memcpy(p, r.points[b].data(), r.points[b].size() * 32);
+      p += r.points[b].size();
+    }
+  }
+  LH_CATCH
+}
+
+// ---------------------------------------------------------------- MSM
+lh_status lh_msm(lh_ctx* ctx, const lh_fr* d_scalars, const lh_g1* d_bases, size_t n, lh_g1* out) {
+  LH_TRY NEED(ctx);
+  NEED(out);
+  MsmJob job{d_scalars, false, (const G1Affine*)d_bases, n};
+  msm_batch(ctx->c, &job, 1, (G1Affine*)out);
+  LH_CATCH
+}
+lh_status lh_msm_u32(lh_ctx* ctx, const uint32_t* d_scalars, const lh_g1* d_bases, size_t n, lh_g1* out) {
+  LH_TRY NEED(ctx);
+  NEED(out);
+  MsmJob job{d_scalars, true, (const G1Affine*)d_bases, n};
+  msm_batch(ctx->c, &job, 1, (G1Affine*)out);
+  LH_CATCH
+}
+
+// ---------------------------------------------------------------- multilinear KZG
+lh_status lh_mkzg_setup(lh_ctx* ctx, const lh_fr* ss, size_t num_vars, lh_srs** out) {
+  LH_TRY NEED(ctx);
+  NEED(out);
+  Srs* s = mkzg_setup(ctx->c, (const HFr*)ss, num_vars);
+  lh_srs* w = new lh_srs();
+  w->s = *s;
+  delete s;
+  *out = w;
+  LH_CATCH
+}
+lh_status lh_srs_upload(lh_ctx* ctx, const lh_g1* eqs_flat, size_t num_vars, lh_srs** out) {
+  LH_TRY NEED(ctx);
+  NEED(out);
+  LH_REQUIRE(num_vars < 31, LH_ERR_ARG, "srs: num_vars too large");
+  lh_srs* w = new lh_srs();
+  w->s.num_vars = num_vars;
+  size_t total = ((size_t)2 << num_vars) - 1;
+  LH_HIP(hipMalloc((void**)&w->s.d_eqs, total * sizeof(G1Affine)));
+  LH_HIP(hipMemcpyAsync(w->s.d_eqs, eqs_flat, total * sizeof(G1Affine), hipMemcpyHostToDevice, ctx->c.stream));
+  ctx->c.sync();
+  *out = w;
+  LH_CATCH
+}
+lh_status lh_srs_download(lh_ctx* ctx, const lh_srs* srs, lh_g1* eqs_flat) {
+  LH_TRY NEED(ctx);
+  NEED(srs);
+  size_t total = ((size_t)2 << srs->s.num_vars) - 1;
+  LH_HIP(hipMemcpyAsync(eqs_flat, srs->s.d_eqs, total * sizeof(G1Affine), hipMemcpyDeviceToHost, ctx->c.stream));
+  ctx->c.sync();
+  LH_CATCH
+}
+size_t lh_srs_num_vars(const lh_srs* srs) { return srs ? srs->s.num_vars : 0; }
+void lh_srs_free(lh_ctx* ctx, lh_srs* srs) {
+  if (!srs) return;
+  if (ctx) (void)hipStreamSynchronize(ctx->c.stream);
+  if (srs->s.d_eqs) (void)hipFree(srs->s.d_eqs);
+  delete srs;
+}
+
+lh_status lh_mkzg_commit(lh_ctx* ctx, const lh_srs* srs, const lh_fr* d_poly, size_t num_vars, lh_g1* out) {
+  LH_TRY NEED(ctx);
+  NEED(srs);
+  const Fr* p = (const Fr*)d_poly;
+  std::vector<HG1> c = mkzg_batch_commit(ctx->c, srs->s, &p, 1, num_vars);
+  memcpy(out, c.data(), 64);
+  LH_CATCH
+}
+lh_status lh_mkzg_batch_commit(lh_ctx* ctx, const lh_srs* srs, const lh_fr* const* d_polys, size_t num_polys,
+                               size_t num_vars, lh_g1* out_comms) {
+  LH_TRY NEED(ctx);
+  NEED(srs);
+  std::vector<HG1> c = mkzg_batch_commit(ctx->c, srs->s, (const Fr* const*)d_polys, num_polys, num_vars);
+  memcpy(out_comms, c.data(), num_polys * 64);
+  LH_CATCH
+}
+lh_status lh_mkzg_open(lh_ctx* ctx, const lh_srs* srs, const lh_fr* d_poly, size_t num_vars, const lh_fr* point,
+                       lh_transcript* t, lh_fr* out_eval) {
+  LH_TRY NEED(ctx);
+  NEED(srs);
+  Transcript tr(t);
+  HFr e = mkzg_open(ctx->c, srs->s, (const Fr*)d_poly, num_vars, (const HFr*)point, tr);
+  if (out_eval) memcpy(out_eval, &e, 32);
+  LH_CATCH
+}
+lh_status lh_mkzg_batch_open(lh_ctx* ctx, const lh_srs* srs, size_t num_vars, const lh_fr* const* d_polys,
+                             size_t num_polys, const lh_fr* points, size_t num_points, const lh_evaluation* evals,
+                             size_t num_evals, lh_transcript* t) {
+  LH_TRY NEED(ctx);
+  NEED(srs);
+  Transcript tr(t);
+  mkzg_batch_open(ctx->c, srs->s, num_vars, (const Fr* const*)d_polys, num_polys, (const HFr*)points, num_points,
+                  evals, num_evals, tr);
+  LH_CATCH
+}
+
+// ---------------------------------------------------------------- Lasso
+lh_status lh_lasso_prove(lh_ctx* ctx, const lh_srs* srs, const lh_lasso_table* table, size_t num_vars,
+                         const uint32_t* const* d_dims, lh_transcript* t) {
+  LH_TRY NEED(ctx);
+  NEED(srs);
+  NEED(table);
+  NEED(d_dims);
+  Transcript tr(t);
+  lasso_prove(ctx->c, srs->s, *table, num_vars, d_dims, tr);
+  LH_CATCH
+}
+lh_status lh_lasso_last_timing(lh_ctx* ctx, double* out_ms) {
+  LH_TRY NEED(ctx);
+  NEED(out_ms);
+  memcpy(out_ms, ctx->c.lasso_ms, sizeof(ctx->c.lasso_ms));
+  LH_CATCH
+}
+
+}  // extern "C"

@@ -1,0 +1,60 @@
+// Device context and workspace arena.
+#include "dev.hpp"
+
+namespace lh {
+
+static thread_local std::string g_last_error;
+void set_last_error(const char* msg) { g_last_error = msg ? msg : ""; }
+const char* get_last_error() { return g_last_error.c_str(); }
+
+Arena::~Arena() {
+  for (auto& b : blocks_) (void)hipFree(b.p);
+}
+
+void* Arena::alloc(size_t bytes) {
+  bytes = (bytes + 255) & ~(size_t)255;
+  if (bytes == 0) bytes = 256;
+  while (true) {
+    if (!blocks_.empty()) {
+      Block& b = blocks_[cur_];
+      if (b.used + bytes <= b.size) {
+        void* p = b.p + b.used;
+        b.used += bytes;
+        size_t tot = 0;
+        for (size_t i = 0; i <= cur_; i++) tot += blocks_[i].used;
+        if (tot > high_) high_ = tot;
+        return p;
+      }
+      if (cur_ + 1 < blocks_.size()) {
+        cur_++;
+        blocks_[cur_].used = 0;
+        continue;
+      }
+    }
+    size_t want = blocks_.empty() ? ((size_t)64 << 20) : blocks_.back().size * 2;
+    if (want < bytes) want = bytes;
+    void* p = nullptr;
+    LH_HIP(hipMalloc(&p, want));
+    blocks_.push_back(Block{(char*)p, want, 0});
+    cur_ = blocks_.size() - 1;
+  }
+}
+
+void Arena::release(Mark m) {
+  if (blocks_.empty()) return;
+  for (size_t i = m.block + 1; i < blocks_.size(); i++) blocks_[i].used = 0;
+  cur_ = m.block;
+  blocks_[cur_].used = m.used;
+}
+
+void* Ctx::pin(size_t bytes) {
+  if (bytes > pinned_bytes) {
+    if (pinned) (void)hipHostFree(pinned);
+    size_t want = bytes < 65536 ? 65536 : bytes;
+    LH_HIP(hipHostMalloc(&pinned, want, hipHostMallocDefault));
+    pinned_bytes = want;
+  }
+  return pinned;
+}
+
+}  // namespace lh

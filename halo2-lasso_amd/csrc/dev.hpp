@@ -1,0 +1,159 @@
+// Internal: device context, workspace arena, kernel launcher declarations.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include <stdexcept>
+
+#include "../../include/lasso_hip.h"
+#include "ec.cuh"
+
+namespace lh {
+
+// ------------------------------------------------------------------ errors
+struct Error : std::exception {
+  int code;
+  std::string msg;
+  Error(int c, std::string m) : code(c), msg(std::move(m)) {}
+  const char* what() const noexcept override { return msg.c_str(); }
+};
+
+void set_last_error(const char* msg);
+
+#define LH_HIP(expr)                                                                       \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      throw ::lh::Error(LH_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+#define LH_REQUIRE(cond, code, text) \
+  do {                               \
+    if (!(cond)) throw ::lh::Error((code), (text)); \
+  } while (0)
+
+// ------------------------------------------------------------------ workspace arena
+// Stack-disciplined device allocator: the prover's temporaries nest (per sum-check, per layer),
+// so a bump pointer with mark/release avoids hipMalloc/hipFree (both synchronise) on the hot path.
+class Arena {
+ public:
+  struct Mark {
+    size_t block, used;
+  };
+  ~Arena();
+  void* alloc(size_t bytes);
+  template <class T>
+  T* alloc_n(size_t n) {
+    return (T*)alloc(n * sizeof(T));
+  }
+  Mark mark() const { return {cur_, blocks_.empty() ? 0 : blocks_[cur_].used}; }
+  void release(Mark m);
+  size_t high_water() const { return high_; }
+
+ private:
+  struct Block {
+    char* p;
+    size_t size, used;
+  };
+  std::vector<Block> blocks_;
+  size_t cur_ = 0, high_ = 0;
+};
+
+struct ArenaScope {
+  Arena& a;
+  Arena::Mark m;
+  explicit ArenaScope(Arena& a_) : a(a_), m(a_.mark()) {}
+  ~ArenaScope() { a.release(m); }
+};
+
+// ------------------------------------------------------------------ context
+struct Ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  Arena arena;
+  // pinned host staging for small D2H results (round messages, window sums)
+  void* pinned = nullptr;
+  size_t pinned_bytes = 0;
+  int num_cus = 256;
+  double lasso_ms[LH_LASSO_NUM_PHASES] = {0};
+  void* pin(size_t bytes);  // grows the pinned buffer if needed
+  void sync() { LH_HIP(hipStreamSynchronize(stream)); }
+};
+
+// ------------------------------------------------------------------ kernel launchers (kernels_poly.hip)
+void k_fr_from_u64(Ctx&, const uint64_t* in, size_t n, Fr* out);
+void k_fr_from_u32(Ctx&, const uint32_t* in, size_t n, Fr* out);
+void k_fr_to_repr(Ctx&, const Fr* in, size_t n, Fr* out);
+void k_fr_from_repr(Ctx&, const Fr* in, size_t n, Fr* out);
+void k_fr_binop(Ctx&, int op, const Fr* a, const Fr* b, size_t n, Fr* out);  // 0 add 1 sub 2 mul
+void k_fr_mul_chain(Ctx&, const Fr* a, const Fr* b, size_t n, int iters, Fr* out);
+void k_fr_batch_invert(Ctx&, const Fr* in, size_t n, Fr* out);
+void k_fix_var(Ctx&, const Fr* in, size_t n_in, const Fr& x, Fr* out);
+// binds `count` tables of n_in entries each in one launch
+void k_fix_var_multi(Ctx&, const Fr* const* in, Fr* const* out, size_t count, size_t n_in, const Fr& x);
+void k_eq_xy(Ctx&, const Fr* y, size_t num_vars, Fr* out);  // y: host array
+void k_lincomb(Ctx&, const Fr* const* polys, const Fr* w, size_t count, size_t n, Fr* out);
+// out[i] = <polys[i], weights>, i < count ; result on host
+void k_inner_products(Ctx&, const Fr* const* polys, size_t count, const Fr* weights, size_t n, Fr* out_host);
+// same with u32-valued polys
+void k_inner_products_u32(Ctx&, const uint32_t* const* polys, size_t count, const Fr* weights, size_t n,
+                          Fr* out_host);
+// product tree level: out[i] = in[i] * in[half + i]
+void k_tree_up(Ctx&, const Fr* in, size_t half, Fr* out);
+// fractional layer: (p_l q_r + p_r q_l, q_l q_r)
+void k_frac_up(Ctx&, const Fr* p, const Fr* q, size_t half, Fr* vp, Fr* vq);
+// KZG quotient step at level i: q = hi - lo ; lo' = lo + (hi - lo) * x
+void k_quotient_step(Ctx&, const Fr* rem, size_t half, const Fr& x, Fr* q, Fr* rem_out);
+// Lasso fingerprints: rs = dim*g2 + e*g + ts - tau ; ws = rs + 1
+void k_lasso_rw_leaves(Ctx&, const uint32_t* dim, const uint32_t* e, const uint32_t* ts, size_t n,
+                       const Fr& gamma, const Fr& gamma2, const Fr& tau, Fr* rs, Fr* ws);
+// init = m*g2 + T[m]*g - tau ; fin = init + final_cts[m]
+void k_lasso_if_leaves(Ctx&, int subtable, uint32_t chunk_bits, const uint32_t* final_cts, size_t m,
+                       const Fr& gamma, const Fr& gamma2, const Fr& tau, Fr* init, Fr* fin);
+// Lasso witness: counters and subtable reads
+void k_lasso_counters(Ctx&, const uint32_t* dim, size_t n, size_t m, uint32_t* read_ts, uint32_t* final_cts);
+void k_lasso_subtable_read(Ctx&, int subtable, uint32_t chunk_bits, const uint32_t* dim, size_t n, uint32_t* e);
+// a[k] = g(E_0[k],..): small-integer evaluation into Fr
+struct LassoG {
+  uint32_t num_terms;
+  Fr coeff[LH_LASSO_MAX_TERMS];
+  uint8_t nfac[LH_LASSO_MAX_TERMS];
+  uint8_t fac[LH_LASSO_MAX_TERMS][LH_SC_MAX_FACTORS];
+  const uint32_t* e[LH_LASSO_MAX_MEMORIES];
+};
+void k_lasso_output(Ctx&, const LassoG& g, size_t n, Fr* a);
+
+// ------------------------------------------------------------------ sum-check round (kernels_sumcheck.hip)
+constexpr int SC_MAX_TABLES = 40;
+struct ScRound {
+  // tables of the current round: BIND ? 4*size entries in, 2*size out : 2*size entries in
+  const Fr* in[SC_MAX_TABLES];
+  Fr* out[SC_MAX_TABLES];
+  uint32_t num_tables;
+  uint32_t num_terms;
+  int32_t global_eq;  // table id multiplied onto the sum, or -1
+  Fr coeff[LH_SC_MAX_TERMS];
+  uint8_t coeff_is_one[LH_SC_MAX_TERMS];
+  uint8_t nfac[LH_SC_MAX_TERMS];
+  uint8_t fac[LH_SC_MAX_TERMS][LH_SC_MAX_FACTORS];
+  Fr r;  // challenge of the previous round (BIND only)
+};
+// evals_host[0..degree) receives sum_b expr at X = 1..degree (X = 0 is derived by the caller)
+void k_sc_round(Ctx&, const ScRound& rd, int degree, bool bind, size_t size, Fr* evals_host);
+
+// ------------------------------------------------------------------ MSM (msm.hip)
+struct MsmJob {
+  const void* scalars;  // Fr (Montgomery) or u32
+  bool scalars_u32;
+  const G1Affine* bases;
+  size_t n;
+};
+// Runs all jobs as one batched Pippenger; out[j] is the affine sum (identity = (0,0)).
+void msm_batch(Ctx&, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host);
+// out[i] = scalars[i] * G (fixed-base), normalised to affine; all on device
+void k_fixed_base_mul_g(Ctx&, const Fr* scalars, size_t n, G1Affine* out);
+
+}  // namespace lh

@@ -1,0 +1,263 @@
+// BN254 prime-field arithmetic for gfx950 (and the host): 8 x u32 limbs, Montgomery R = 2^256.
+//
+// Replaces halo2_curves 0.3.3 bn256::{Fr,Fq} as used by the reference through
+// plonkish_backend/src/util/arithmetic.rs:15-22.  The in-memory form is
+// byte-identical to halo2curves' `[u64; 4]` Montgomery representation, so a Rust `&[Fr]` can be
+// handed to the C-ABI unchanged.
+//
+// CDNA4 has no 64-bit integer multiplier: a limb product is one v_mad_u64_u32 (32x32+64->64).
+// CIOS keeps the running value in 32-bit limbs so that every mad's addend is (limb + carry).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define LH_HD __host__ __device__ __forceinline__
+#else
+#define LH_HD inline
+#endif
+
+namespace lh {
+
+struct FrParams {
+  // r = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+  static LH_HD constexpr uint32_t mod(int i) {
+    constexpr uint32_t m[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u,
+                               0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+    return m[i];
+  }
+  static LH_HD constexpr uint32_t r1(int i) {  // R mod r
+    constexpr uint32_t m[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u,
+                               0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+    return m[i];
+  }
+  static LH_HD constexpr uint32_t r2(int i) {  // R^2 mod r
+    constexpr uint32_t m[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u,
+                               0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
+    return m[i];
+  }
+  static constexpr uint32_t INV = 0xefffffffu;  // -r^{-1} mod 2^32
+};
+
+struct FqParams {
+  // q = 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47
+  static LH_HD constexpr uint32_t mod(int i) {
+    constexpr uint32_t m[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u,
+                               0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+    return m[i];
+  }
+  static LH_HD constexpr uint32_t r1(int i) {
+    constexpr uint32_t m[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u,
+                               0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+    return m[i];
+  }
+  static LH_HD constexpr uint32_t r2(int i) {
+    constexpr uint32_t m[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u,
+                               0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};
+    return m[i];
+  }
+  static constexpr uint32_t INV = 0xe4866389u;  // -q^{-1} mod 2^32
+};
+
+template <class P>
+struct alignas(16) Fp {
+  uint32_t l[8];
+
+  static LH_HD Fp zero() {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = 0;
+    return r;
+  }
+  static LH_HD Fp one() {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = P::r1(i);
+    return r;
+  }
+  static LH_HD Fp r2() {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = P::r2(i);
+    return r;
+  }
+  LH_HD bool is_zero() const {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o |= l[i];
+    return o == 0;
+  }
+  LH_HD bool operator==(const Fp& b) const {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o |= l[i] ^ b.l[i];
+    return o == 0;
+  }
+  LH_HD bool operator!=(const Fp& b) const { return !(*this == b); }
+};
+
+// r = a + b (no reduction); returns carry
+template <class P>
+LH_HD uint32_t add_raw(Fp<P>& r, const Fp<P>& a, const Fp<P>& b) {
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    uint64_t s = (uint64_t)a.l[i] + b.l[i] + c;
+    r.l[i] = (uint32_t)s;
+    c = (uint32_t)(s >> 32);
+  }
+  return c;
+}
+
+// r = a - p ; returns borrow (1 if a < p)
+template <class P>
+LH_HD uint32_t sub_mod_raw(Fp<P>& r, const Fp<P>& a) {
+  uint32_t bw = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    uint64_t s = (uint64_t)a.l[i] - P::mod(i) - bw;
+    r.l[i] = (uint32_t)s;
+    bw = (uint32_t)(s >> 63);
+  }
+  return bw;
+}
+
+template <class P>
+LH_HD Fp<P> reduce_once(const Fp<P>& a) {
+  Fp<P> t;
+  uint32_t bw = sub_mod_raw(t, a);
+  Fp<P> r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.l[i] = bw ? a.l[i] : t.l[i];
+  return r;
+}
+
+template <class P>
+LH_HD Fp<P> add(const Fp<P>& a, const Fp<P>& b) {
+  Fp<P> s;
+  add_raw(s, a, b);  // a,b < p < 2^254 : no carry out of 256 bits
+  return reduce_once(s);
+}
+
+template <class P>
+LH_HD Fp<P> sub(const Fp<P>& a, const Fp<P>& b) {
+  Fp<P> d;
+  uint32_t bw = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    uint64_t s = (uint64_t)a.l[i] - b.l[i] - bw;
+    d.l[i] = (uint32_t)s;
+    bw = (uint32_t)(s >> 63);
+  }
+  uint32_t mask = 0u - bw;
+  uint32_t c = 0;
+  Fp<P> r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    uint64_t s = (uint64_t)d.l[i] + (P::mod(i) & mask) + c;
+    r.l[i] = (uint32_t)s;
+    c = (uint32_t)(s >> 32);
+  }
+  return r;
+}
+
+template <class P>
+LH_HD Fp<P> neg(const Fp<P>& a) {
+  return sub(Fp<P>::zero(), a);
+}
+
+template <class P>
+LH_HD Fp<P> dbl(const Fp<P>& a) {
+  return add(a, a);
+}
+
+// Montgomery product a*b*R^-1 mod p, CIOS over 32-bit limbs.
+template <class P>
+LH_HD Fp<P> mul(const Fp<P>& a, const Fp<P>& b) {
+  uint32_t t[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) t[j] = 0;
+  uint32_t t8 = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    uint64_t c = 0;
+    const uint32_t bi = b.l[i];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      uint64_t s = (uint64_t)a.l[j] * bi + t[j] + c;
+      t[j] = (uint32_t)s;
+      c = s >> 32;
+    }
+    uint64_t s8 = (uint64_t)t8 + c;
+    t8 = (uint32_t)s8;
+    uint32_t t9 = (uint32_t)(s8 >> 32);
+    const uint32_t m = t[0] * P::INV;
+    uint64_t s = (uint64_t)m * P::mod(0) + t[0];
+    c = s >> 32;
+#pragma unroll
+    for (int j = 1; j < 8; j++) {
+      s = (uint64_t)m * P::mod(j) + t[j] + c;
+      t[j - 1] = (uint32_t)s;
+      c = s >> 32;
+    }
+    s8 = (uint64_t)t8 + c;
+    t[7] = (uint32_t)s8;
+    t8 = t9 + (uint32_t)(s8 >> 32);
+  }
+  Fp<P> r;
+#pragma unroll
+  for (int j = 0; j < 8; j++) r.l[j] = t[j];
+  return reduce_once(r);  // result < 2p < 2^255, t8 == 0
+}
+
+template <class P>
+LH_HD Fp<P> sqr(const Fp<P>& a) {
+  return mul(a, a);
+}
+
+// Montgomery form <-> canonical integer
+template <class P>
+LH_HD Fp<P> to_mont(const Fp<P>& canon) {
+  return mul(canon, Fp<P>::r2());
+}
+template <class P>
+LH_HD Fp<P> from_mont(const Fp<P>& a) {
+  Fp<P> one;
+#pragma unroll
+  for (int i = 0; i < 8; i++) one.l[i] = (i == 0);
+  return mul(a, one);
+}
+template <class P>
+LH_HD Fp<P> from_u64(uint64_t v) {
+  Fp<P> c = Fp<P>::zero();
+  c.l[0] = (uint32_t)v;
+  c.l[1] = (uint32_t)(v >> 32);
+  return to_mont(c);
+}
+
+// a^e for a 254-bit exponent given as canonical limbs (square-and-multiply, MSB first)
+template <class P>
+LH_HD Fp<P> pow_limbs(const Fp<P>& a, const uint32_t* e) {
+  Fp<P> acc = Fp<P>::one();
+  for (int i = 7; i >= 0; i--) {
+    for (int b = 31; b >= 0; b--) {
+      acc = sqr(acc);
+      if ((e[i] >> b) & 1u) acc = mul(acc, a);
+    }
+  }
+  return acc;
+}
+
+// Fermat inverse a^(p-2); zero maps to zero.
+template <class P>
+LH_HD Fp<P> inv(const Fp<P>& a) {
+  uint32_t e[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) e[i] = P::mod(i);
+  e[0] -= 2u;  // low limb of both moduli is > 2
+  return pow_limbs(a, e);
+}
+
+using Fr = Fp<FrParams>;
+using Fq = Fp<FqParams>;
+
+}  // namespace lh

@@ -1,0 +1,124 @@
+// Host half of the prover: mirrors the reference's trait surface for the hot path
+// (piop::sum_check, piop::gkr, pcs::multilinear::kzg) on top of the device kernels.
+#pragma once
+#include <string.h>
+#include <vector>
+#include "dev.hpp"
+#include "ff_host.hpp"
+
+namespace lh {
+
+const char* get_last_error();
+
+typedef host::Fr HFr;
+typedef host::G1Affine HG1;
+
+static inline Fr dev(const HFr& f) {
+  Fr r;
+  memcpy(&r, &f, 32);
+  return r;
+}
+static inline HFr hst(const Fr& f) {
+  HFr r;
+  memcpy(&r, &f, 32);
+  return r;
+}
+
+// ------------------------------------------------------------------ hash + transcript
+struct Keccak256 {
+  static constexpr int RATE = 136;
+  uint64_t state[25] = {0};
+  uint8_t buf[RATE];
+  size_t buf_len = 0;
+  void absorb_block(const uint8_t* block);
+  void update(const uint8_t* data, size_t len);
+  void finalize_reset(uint8_t out[32]);
+};
+
+struct KeccakTranscript {
+  lh_transcript vt;  // must stay the first member: lh_transcript* <-> KeccakTranscript*
+  Keccak256 hash;
+  std::vector<uint8_t> stream;
+  KeccakTranscript();
+};
+
+// typed view over the callback table (util/transcript.rs:15-97)
+struct Transcript {
+  lh_transcript* t;
+  explicit Transcript(lh_transcript* t_) : t(t_) {
+    LH_REQUIRE(t && t->write_field_element && t->common_field_element && t->squeeze_challenge &&
+                   t->write_commitment && t->common_commitment,
+               LH_ERR_ARG, "transcript callback table is incomplete");
+  }
+  void check(int rc) {
+    if (rc != LH_OK) throw Error(rc, get_last_error()[0] ? get_last_error() : "transcript callback failed");
+  }
+  void write_field_element(const HFr& f) { check(t->write_field_element(t->user, (const lh_fr*)&f)); }
+  void write_field_elements(const std::vector<HFr>& fs) {
+    for (auto& f : fs) write_field_element(f);
+  }
+  void common_field_element(const HFr& f) { check(t->common_field_element(t->user, (const lh_fr*)&f)); }
+  HFr squeeze_challenge() {
+    HFr f;
+    check(t->squeeze_challenge(t->user, (lh_fr*)&f));
+    return f;
+  }
+  std::vector<HFr> squeeze_challenges(size_t n) {
+    std::vector<HFr> v(n);
+    for (auto& f : v) f = squeeze_challenge();
+    return v;
+  }
+  void write_commitment(const HG1& p) { check(t->write_commitment(t->user, (const lh_g1*)&p)); }
+  void write_commitments(const std::vector<HG1>& ps) {
+    for (auto& p : ps) write_commitment(p);
+  }
+};
+
+// ------------------------------------------------------------------ poly helpers (host side, tiny inputs)
+std::vector<HFr> host_eq_xy(const std::vector<HFr>& y);           // multilinear.rs:91-127
+HFr host_eq_xy_eval(const HFr* x, const HFr* y, size_t n);         // sum_check.rs:112-121
+// evaluations of `count` device tables at `point` (multilinear.rs:137-156)
+std::vector<HFr> evaluate_polys(Ctx&, const Fr* const* d_polys, size_t count, size_t num_vars, const HFr* point);
+
+// ------------------------------------------------------------------ piop::sum_check
+struct SumCheckResult {
+  std::vector<HFr> challenges;  // x
+  std::vector<HFr> evals;       // every poly at x (classic.rs:143-149)
+};
+SumCheckResult sum_check_prove(Ctx&, int prover_kind, size_t num_vars, const lh_sop& expr, const Fr* const* d_polys,
+                               size_t num_polys, const HFr* ys, size_t num_ys, const HFr& sum, Transcript& tr);
+
+// ------------------------------------------------------------------ piop::gkr
+struct FracSumCheckResult {
+  std::vector<HFr> p_xs, q_xs, x;
+};
+FracSumCheckResult prove_fractional_sum_check(Ctx&, size_t num_batching, size_t num_vars,
+                                              const HFr* const* claimed_p_0s, const HFr* const* claimed_q_0s,
+                                              const Fr* const* d_ps, const Fr* const* d_qs, Transcript& tr);
+struct GrandProductResult {
+  std::vector<HFr> roots, claims;
+  std::vector<std::vector<HFr>> points;
+};
+GrandProductResult prove_grand_product(Ctx&, size_t num_trees, const Fr* const* d_leaves, const size_t* num_vars,
+                                       Transcript& tr);
+
+// ------------------------------------------------------------------ pcs::multilinear::kzg
+struct Srs {
+  G1Affine* d_eqs = nullptr;  // flat: level k at offset 2^k - 1
+  size_t num_vars = 0;
+  const G1Affine* eq(size_t k) const { return d_eqs + (((size_t)1 << k) - 1); }
+};
+Srs* mkzg_setup(Ctx&, const HFr* ss, size_t num_vars);
+std::vector<HG1> mkzg_batch_commit(Ctx&, const Srs&, const Fr* const* d_polys, size_t num_polys, size_t num_vars);
+std::vector<HG1> mkzg_batch_commit_u32(Ctx&, const Srs&, const uint32_t* const* d_polys, size_t num_polys,
+                                       size_t num_vars);
+HFr mkzg_open(Ctx&, const Srs&, const Fr* d_poly, size_t num_vars, const HFr* point, Transcript& tr);
+void mkzg_batch_open(Ctx&, const Srs&, size_t num_vars, const Fr* const* d_polys, size_t num_polys,
+                     const HFr* points, size_t num_points, const lh_evaluation* evals, size_t num_evals,
+                     Transcript& tr);
+
+// ------------------------------------------------------------------ Lasso
+void lasso_prove(Ctx&, const Srs&, const lh_lasso_table& table, size_t num_vars, const uint32_t* const* d_dims,
+                 Transcript& tr);
+
+}  // namespace lh

@@ -1,0 +1,426 @@
+// Element-wise / streaming kernels over tables of BN254-Fr (gfx950).
+// All are HBM- or integer-ALU-bound streams: 256-thread blocks, grid-stride, 16-B vector
+// accesses (an Fr is two dwordx4), no LDS except for block reductions.
+#include <hip/hip_runtime.h>
+#include "dev.hpp"
+#include "reduce.cuh"
+
+namespace lh {
+
+static inline dim3 grid_for(size_t n, int block = 256, size_t cap = 4096) {
+  size_t g = (n + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return dim3((unsigned)g);
+}
+#define GSTRIDE(i, n) \
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (size_t)gridDim.x * blockDim.x)
+
+// ------------------------------------------------------------------ conversions
+__global__ void fr_from_u64_kernel(const uint64_t* __restrict__ in, size_t n, Fr* __restrict__ out) {
+  GSTRIDE(i, n) out[i] = from_u64<FrParams>(in[i]);
+}
+__global__ void fr_from_u32_kernel(const uint32_t* __restrict__ in, size_t n, Fr* __restrict__ out) {
+  GSTRIDE(i, n) out[i] = from_u64<FrParams>(in[i]);
+}
+__global__ void fr_to_repr_kernel(const Fr* __restrict__ in, size_t n, Fr* __restrict__ out) {
+  GSTRIDE(i, n) out[i] = from_mont(in[i]);
+}
+__global__ void fr_from_repr_kernel(const Fr* __restrict__ in, size_t n, Fr* __restrict__ out) {
+  GSTRIDE(i, n) out[i] = to_mont(in[i]);
+}
+void k_fr_from_u64(Ctx& c, const uint64_t* in, size_t n, Fr* out) {
+  if (n) hipLaunchKernelGGL(fr_from_u64_kernel, grid_for(n), 256, 0, c.stream, in, n, out);
+}
+void k_fr_from_u32(Ctx& c, const uint32_t* in, size_t n, Fr* out) {
+  if (n) hipLaunchKernelGGL(fr_from_u32_kernel, grid_for(n), 256, 0, c.stream, in, n, out);
+}
+void k_fr_to_repr(Ctx& c, const Fr* in, size_t n, Fr* out) {
+  if (n) hipLaunchKernelGGL(fr_to_repr_kernel, grid_for(n), 256, 0, c.stream, in, n, out);
+}
+void k_fr_from_repr(Ctx& c, const Fr* in, size_t n, Fr* out) {
+  if (n) hipLaunchKernelGGL(fr_from_repr_kernel, grid_for(n), 256, 0, c.stream, in, n, out);
+}
+
+// ------------------------------------------------------------------ vector ops
+template <int OP>
+__global__ void fr_binop_kernel(const Fr* __restrict__ a, const Fr* __restrict__ b, size_t n, Fr* __restrict__ out) {
+  GSTRIDE(i, n) {
+    Fr x = a[i], y = b[i];
+    out[i] = OP == 0 ? add(x, y) : OP == 1 ? sub(x, y) : mul(x, y);
+  }
+}
+void k_fr_binop(Ctx& c, int op, const Fr* a, const Fr* b, size_t n, Fr* out) {
+  if (!n) return;
+  if (op == 0) hipLaunchKernelGGL(fr_binop_kernel<0>, grid_for(n), 256, 0, c.stream, a, b, n, out);
+  else if (op == 1) hipLaunchKernelGGL(fr_binop_kernel<1>, grid_for(n), 256, 0, c.stream, a, b, n, out);
+  else hipLaunchKernelGGL(fr_binop_kernel<2>, grid_for(n), 256, 0, c.stream, a, b, n, out);
+}
+
+__global__ void fr_mul_chain_kernel(const Fr* __restrict__ a, const Fr* __restrict__ b, size_t n, int iters,
+                                    Fr* __restrict__ out) {
+  GSTRIDE(i, n) {
+    Fr x = a[i], y = b[i];
+    for (int k = 0; k < iters; k++) x = mul(x, y);
+    out[i] = x;
+  }
+}
+void k_fr_mul_chain(Ctx& c, const Fr* a, const Fr* b, size_t n, int iters, Fr* out) {
+  if (n) hipLaunchKernelGGL(fr_mul_chain_kernel, grid_for(n, 256, 1 << 20), 256, 0, c.stream, a, b, n, iters, out);
+}
+
+// Batch inversion, Montgomery's trick per thread over a strip of CHUNK elements:
+// CHUNK-1 + 3*(CHUNK-1) multiplications and ONE Fermat inversion (~380 mul) per strip.
+constexpr int INV_CHUNK = 32;
+__global__ void fr_batch_invert_kernel(const Fr* __restrict__ in, size_t n, Fr* __restrict__ out) {
+  size_t strips = (n + INV_CHUNK - 1) / INV_CHUNK;
+  GSTRIDE(s, strips) {
+    size_t lo = s * INV_CHUNK, hi = lo + INV_CHUNK < n ? lo + INV_CHUNK : n;
+    // forward: out[i] = product of the non-zero inputs before i
+    Fr acc = Fr::one();
+    for (size_t i = lo; i < hi; i++) {
+      out[i] = acc;
+      Fr v = in[i];
+      if (!v.is_zero()) acc = mul(acc, v);
+    }
+    Fr iv = inv(acc);
+    for (size_t i = hi; i-- > lo;) {
+      Fr v = in[i];
+      if (v.is_zero()) {
+        out[i] = Fr::zero();
+      } else {
+        Fr p = out[i];
+        out[i] = mul(iv, p);
+        iv = mul(iv, v);
+      }
+    }
+  }
+}
+void k_fr_batch_invert(Ctx& c, const Fr* in, size_t n, Fr* out) {
+  if (!n) return;
+  size_t strips = (n + INV_CHUNK - 1) / INV_CHUNK;
+  hipLaunchKernelGGL(fr_batch_invert_kernel, grid_for(strips, 64), 64, 0, c.stream, in, n, out);
+}
+
+// ------------------------------------------------------------------ bind (fix_var)
+// reference poly/multilinear.rs:599-618 `merge_into`: out[b] = e[2b] + (e[2b+1]-e[2b]) * x
+__global__ void fix_var_kernel(const Fr* __restrict__ in, size_t n_out, Fr x, Fr* __restrict__ out) {
+  GSTRIDE(b, n_out) {
+    Fr e0 = in[2 * b], e1 = in[2 * b + 1];
+    out[b] = add(mul(sub(e1, e0), x), e0);
+  }
+}
+void k_fix_var(Ctx& c, const Fr* in, size_t n_in, const Fr& x, Fr* out) {
+  size_t n_out = n_in >> 1;
+  if (n_out) hipLaunchKernelGGL(fix_var_kernel, grid_for(n_out), 256, 0, c.stream, in, n_out, x, out);
+}
+
+struct PtrPack {
+  const Fr* in[SC_MAX_TABLES];
+  Fr* out[SC_MAX_TABLES];
+};
+__global__ void fix_var_multi_kernel(PtrPack p, size_t n_out, Fr x) {
+  const Fr* __restrict__ in = p.in[blockIdx.y];
+  Fr* __restrict__ out = p.out[blockIdx.y];
+  GSTRIDE(b, n_out) {
+    Fr e0 = in[2 * b], e1 = in[2 * b + 1];
+    out[b] = add(mul(sub(e1, e0), x), e0);
+  }
+}
+void k_fix_var_multi(Ctx& c, const Fr* const* in, Fr* const* out, size_t count, size_t n_in, const Fr& x) {
+  size_t n_out = n_in >> 1;
+  if (!n_out) return;
+  for (size_t base = 0; base < count; base += SC_MAX_TABLES) {
+    size_t k = count - base < (size_t)SC_MAX_TABLES ? count - base : (size_t)SC_MAX_TABLES;
+    PtrPack p;
+    for (size_t i = 0; i < k; i++) {
+      p.in[i] = in[base + i];
+      p.out[i] = out[base + i];
+    }
+    dim3 g = grid_for(n_out);
+    g.y = (unsigned)k;
+    hipLaunchKernelGGL(fix_var_multi_kernel, g, 256, 0, c.stream, p, n_out, x);
+  }
+}
+
+// ------------------------------------------------------------------ eq_xy
+// reference poly/multilinear.rs:91-127.  Level expansion: next[2k+1] = cur[k]*y, next[2k] = cur[k]-next[2k+1].
+// In place from the top: processing k descending inside a level would race across blocks, so each
+// level goes out of place between two buffers; the last level lands in `out`.
+__global__ void eq_expand_kernel(const Fr* __restrict__ cur, size_t n_cur, Fr y, Fr* __restrict__ nxt) {
+  GSTRIDE(k, n_cur) {
+    Fr e = cur[k];
+    Fr hi = mul(e, y);
+    nxt[2 * k + 1] = hi;
+    nxt[2 * k] = sub(e, hi);
+  }
+}
+__global__ void fr_set_one_kernel(Fr* p) { p[0] = Fr::one(); }
+
+void k_eq_xy(Ctx& c, const Fr* y, size_t num_vars, Fr* out) {
+  // ping-pong so that the final level (2^num_vars) is written to `out`
+  ArenaScope scope(c.arena);
+  size_t half = num_vars ? (size_t)1 << (num_vars - 1) : 1;
+  Fr* tmp = c.arena.alloc_n<Fr>(half);
+  Fr* bufs[2] = {out, tmp};
+  int cur = (num_vars & 1) ? 1 : 0;  // after num_vars flips we must end in bufs[0]
+  hipLaunchKernelGGL(fr_set_one_kernel, 1, 1, 0, c.stream, bufs[cur]);
+  size_t n = 1;
+  for (size_t i = num_vars; i-- > 0;) {
+    hipLaunchKernelGGL(eq_expand_kernel, grid_for(n), 256, 0, c.stream, bufs[cur], n, y[i], bufs[cur ^ 1]);
+    cur ^= 1;
+    n <<= 1;
+  }
+  // tmp is released when the scope ends; stream order keeps it valid for the queued kernels,
+  // later arena users are queued behind them on the same stream.
+}
+
+// ------------------------------------------------------------------ linear combination
+constexpr int LC_MAX = 32;
+struct LcPack {
+  const Fr* p[LC_MAX];
+  Fr w[LC_MAX];
+};
+__global__ void lincomb_kernel(LcPack pk, int count, size_t n, Fr* __restrict__ out, int accumulate) {
+  GSTRIDE(i, n) {
+    Fr acc = accumulate ? out[i] : Fr::zero();
+    for (int k = 0; k < count; k++) acc = add(acc, mul(pk.p[k][i], pk.w[k]));
+    out[i] = acc;
+  }
+}
+void k_lincomb(Ctx& c, const Fr* const* polys, const Fr* w, size_t count, size_t n, Fr* out) {
+  if (!n) return;
+  if (count == 0) {
+    LH_HIP(hipMemsetAsync(out, 0, n * sizeof(Fr), c.stream));
+    return;
+  }
+  for (size_t base = 0; base < count; base += LC_MAX) {
+    int k = (int)(count - base < (size_t)LC_MAX ? count - base : (size_t)LC_MAX);
+    LcPack pk;
+    for (int i = 0; i < k; i++) {
+      pk.p[i] = polys[base + i];
+      pk.w[i] = w[base + i];
+    }
+    hipLaunchKernelGGL(lincomb_kernel, grid_for(n), 256, 0, c.stream, pk, k, n, out, base ? 1 : 0);
+  }
+}
+
+// ------------------------------------------------------------------ inner products <poly_i, weights>
+constexpr int IP_MAX = 16;
+struct IpPack {
+  const void* p[IP_MAX];
+};
+template <bool U32>
+__global__ void inner_products_kernel(IpPack pk, const Fr* __restrict__ w, size_t n, Fr* __restrict__ partials) {
+  __shared__ Fr lds[4];
+  const void* src = pk.p[blockIdx.y];
+  Fr acc = Fr::zero();
+  GSTRIDE(i, n) {
+    Fr v;
+    if (U32) {
+      // small value * weight: weights are Montgomery, v canonical small -> mul(to_mont(v), w)
+      v = from_u64<FrParams>(((const uint32_t*)src)[i]);
+    } else {
+      v = ((const Fr*)src)[i];
+    }
+    acc = add(acc, mul(v, w[i]));
+  }
+  acc = block_reduce_sum(acc, lds);
+  if (threadIdx.x == 0) partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = acc;
+}
+__global__ void reduce_rows_kernel(const Fr* __restrict__ partials, int per_row, Fr* __restrict__ out) {
+  __shared__ Fr lds[4];
+  Fr acc = Fr::zero();
+  for (int i = threadIdx.x; i < per_row; i += blockDim.x) acc = add(acc, partials[(size_t)blockIdx.x * per_row + i]);
+  acc = block_reduce_sum(acc, lds);
+  if (threadIdx.x == 0) out[blockIdx.x] = acc;
+}
+template <bool U32>
+static void inner_products_impl(Ctx& c, const void* const* polys, size_t count, const Fr* weights, size_t n,
+                                Fr* out_host) {
+  if (!count) return;
+  ArenaScope scope(c.arena);
+  dim3 g = grid_for(n, 256, 1024);
+  Fr* partials = c.arena.alloc_n<Fr>((size_t)g.x * IP_MAX);
+  Fr* d_out = c.arena.alloc_n<Fr>(count);
+  for (size_t base = 0; base < count; base += IP_MAX) {
+    int k = (int)(count - base < (size_t)IP_MAX ? count - base : (size_t)IP_MAX);
+    IpPack pk;
+    for (int i = 0; i < k; i++) pk.p[i] = polys[base + i];
+    dim3 gg = g;
+    gg.y = k;
+    hipLaunchKernelGGL(inner_products_kernel<U32>, gg, 256, 0, c.stream, pk, weights, n, partials);
+    hipLaunchKernelGGL(reduce_rows_kernel, k, 256, 0, c.stream, partials, (int)g.x, d_out + base);
+  }
+  LH_HIP(hipMemcpyAsync(out_host, d_out, count * sizeof(Fr), hipMemcpyDeviceToHost, c.stream));
+  c.sync();
+}
+void k_inner_products(Ctx& c, const Fr* const* polys, size_t count, const Fr* weights, size_t n, Fr* out_host) {
+  inner_products_impl<false>(c, (const void* const*)polys, count, weights, n, out_host);
+}
+void k_inner_products_u32(Ctx& c, const uint32_t* const* polys, size_t count, const Fr* weights, size_t n,
+                          Fr* out_host) {
+  inner_products_impl<true>(c, (const void* const*)polys, count, weights, n, out_host);
+}
+
+// ------------------------------------------------------------------ GKR layer-up
+// product tree (Lasso memory check): out[i] = in[i] * in[half+i]
+__global__ void tree_up_kernel(const Fr* __restrict__ in, size_t half, Fr* __restrict__ out) {
+  GSTRIDE(i, half) out[i] = mul(in[i], in[half + i]);
+}
+void k_tree_up(Ctx& c, const Fr* in, size_t half, Fr* out) {
+  if (half) hipLaunchKernelGGL(tree_up_kernel, grid_for(half), 256, 0, c.stream, in, half, out);
+}
+// reference fractional_sum_check.rs:62-85 `Layer::up`
+__global__ void frac_up_kernel(const Fr* __restrict__ p, const Fr* __restrict__ q, size_t half, Fr* __restrict__ vp,
+                               Fr* __restrict__ vq) {
+  GSTRIDE(i, half) {
+    Fr pl = p[i], pr = p[half + i], ql = q[i], qr = q[half + i];
+    vp[i] = add(mul(pl, qr), mul(pr, ql));
+    vq[i] = mul(ql, qr);
+  }
+}
+void k_frac_up(Ctx& c, const Fr* p, const Fr* q, size_t half, Fr* vp, Fr* vq) {
+  if (half) hipLaunchKernelGGL(frac_up_kernel, grid_for(half), 256, 0, c.stream, p, q, half, vp, vq);
+}
+
+// ------------------------------------------------------------------ KZG quotient step
+// reference pcs/multilinear.rs:86-98: q = hi - lo ; lo += (hi - lo) * x_i
+__global__ void quotient_step_kernel(const Fr* __restrict__ rem, size_t half, Fr x, Fr* __restrict__ q,
+                                     Fr* __restrict__ rem_out) {
+  GSTRIDE(i, half) {
+    Fr lo = rem[i], hi = rem[half + i];
+    Fr d = sub(hi, lo);
+    q[i] = d;
+    rem_out[i] = add(lo, mul(d, x));
+  }
+}
+void k_quotient_step(Ctx& c, const Fr* rem, size_t half, const Fr& x, Fr* q, Fr* rem_out) {
+  if (half) hipLaunchKernelGGL(quotient_step_kernel, grid_for(half), 256, 0, c.stream, rem, half, x, q, rem_out);
+}
+
+// ------------------------------------------------------------------ Lasso witness + fingerprints
+__device__ __forceinline__ uint32_t subtable_entry(int kind, uint32_t m, uint32_t bits) {
+  uint32_t h = bits >> 1;
+  uint32_t x = m >> h, y = m & ((1u << h) - 1u);
+  return kind == LH_SUBTABLE_IDENTITY ? m : kind == LH_SUBTABLE_AND ? (x & y) : (x ^ y);
+}
+
+// read_ts[k] = number of earlier lookups of the same address; final_cts[m] = total count.
+// Sort-free: one thread per ADDRESS scans nothing; instead a stable counting pass is required
+// (read_ts depends on lookup order).  Stage 1: per-block LDS-free global histogram of ordered
+// ranks is not associative, so the kernel below serialises per address with a ticket taken in
+// index order: block b handles lookups [b*T, (b+1)*T) and the blocks are chained through
+// `block_base`, which is produced by a histogram+scan over blocks (counting sort, stable).
+constexpr int CNT_TILE = 2048;
+__global__ void lasso_tile_hist_kernel(const uint32_t* __restrict__ dim, size_t n, size_t m,
+                                       uint32_t* __restrict__ tile_hist /* [tiles][m] */) {
+  // each block owns one tile; counts go straight to its private row (global atomics, no sharing)
+  size_t tile = blockIdx.x;
+  uint32_t* row = tile_hist + tile * m;
+  size_t lo = tile * CNT_TILE, hi = lo + CNT_TILE < n ? lo + CNT_TILE : n;
+  for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) atomicAdd(&row[dim[i]], 1u);
+}
+// exclusive scan down the tiles for every address: tile_hist[t][a] <- sum_{t' < t} ; final_cts[a] = total
+__global__ void lasso_tile_scan_kernel(uint32_t* __restrict__ tile_hist, size_t tiles, size_t m,
+                                       uint32_t* __restrict__ final_cts) {
+  GSTRIDE(a, m) {
+    uint32_t run = 0;
+    for (size_t t = 0; t < tiles; t++) {
+      uint32_t v = tile_hist[t * m + a];
+      tile_hist[t * m + a] = run;
+      run += v;
+    }
+    final_cts[a] = run;
+  }
+}
+// inside a tile the order is resolved by one thread per lookup counting equal addresses before it
+// in the tile through LDS (tile is small); O(TILE) per thread worst case is avoided by a
+// per-address running counter processed in index order by a single wave-serial loop.
+__global__ void lasso_tile_rank_kernel(const uint32_t* __restrict__ dim, size_t n, size_t m,
+                                       const uint32_t* __restrict__ tile_hist, uint32_t* __restrict__ read_ts) {
+  __shared__ uint32_t keys[CNT_TILE];
+  size_t tile = blockIdx.x;
+  size_t lo = tile * CNT_TILE, hi = lo + CNT_TILE < n ? lo + CNT_TILE : n;
+  int cnt = (int)(hi - lo);
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x) keys[i] = dim[lo + i];
+  __syncthreads();
+  const uint32_t* row = tile_hist + tile * m;
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+    uint32_t k = keys[i];
+    uint32_t r = 0;
+    for (int j = 0; j < i; j++) r += (keys[j] == k);
+    read_ts[lo + i] = row[k] + r;
+  }
+}
+void k_lasso_counters(Ctx& c, const uint32_t* dim, size_t n, size_t m, uint32_t* read_ts, uint32_t* final_cts) {
+  ArenaScope scope(c.arena);
+  size_t tiles = (n + CNT_TILE - 1) / CNT_TILE;
+  uint32_t* tile_hist = c.arena.alloc_n<uint32_t>(tiles * m);
+  LH_HIP(hipMemsetAsync(tile_hist, 0, tiles * m * sizeof(uint32_t), c.stream));
+  hipLaunchKernelGGL(lasso_tile_hist_kernel, dim3((unsigned)tiles), 256, 0, c.stream, dim, n, m, tile_hist);
+  hipLaunchKernelGGL(lasso_tile_scan_kernel, grid_for(m), 256, 0, c.stream, tile_hist, tiles, m, final_cts);
+  hipLaunchKernelGGL(lasso_tile_rank_kernel, dim3((unsigned)tiles), 256, 0, c.stream, dim, n, m, tile_hist, read_ts);
+}
+
+__global__ void lasso_subtable_read_kernel(int kind, uint32_t bits, const uint32_t* __restrict__ dim, size_t n,
+                                           uint32_t* __restrict__ e) {
+  GSTRIDE(i, n) e[i] = subtable_entry(kind, dim[i], bits);
+}
+void k_lasso_subtable_read(Ctx& c, int subtable, uint32_t chunk_bits, const uint32_t* dim, size_t n, uint32_t* e) {
+  if (n) hipLaunchKernelGGL(lasso_subtable_read_kernel, grid_for(n), 256, 0, c.stream, subtable, chunk_bits, dim, n, e);
+}
+
+__global__ void lasso_output_kernel(LassoG g, size_t n, Fr* __restrict__ a) {
+  GSTRIDE(i, n) {
+    Fr acc = Fr::zero();
+    for (uint32_t t = 0; t < g.num_terms; t++) {
+      Fr v = g.coeff[t];
+      for (int k = 0; k < g.nfac[t]; k++) v = mul(v, from_u64<FrParams>(g.e[g.fac[t][k]][i]));
+      acc = add(acc, v);
+    }
+    a[i] = acc;
+  }
+}
+void k_lasso_output(Ctx& c, const LassoG& g, size_t n, Fr* a) {
+  if (n) hipLaunchKernelGGL(lasso_output_kernel, grid_for(n), 256, 0, c.stream, g, n, a);
+}
+
+// fingerprint h(a, v, t) = a*gamma^2 + v*gamma + t - tau
+__global__ void lasso_rw_leaves_kernel(const uint32_t* __restrict__ dim, const uint32_t* __restrict__ e,
+                                       const uint32_t* __restrict__ ts, size_t n, Fr gamma, Fr gamma2, Fr tau,
+                                       Fr* __restrict__ rs, Fr* __restrict__ ws) {
+  const Fr one = Fr::one();
+  GSTRIDE(i, n) {
+    Fr a = mul(from_u64<FrParams>(dim[i]), gamma2);
+    Fr v = mul(from_u64<FrParams>(e[i]), gamma);
+    Fr t = from_u64<FrParams>(ts[i]);
+    Fr h = sub(add(add(a, v), t), tau);
+    rs[i] = h;
+    ws[i] = add(h, one);
+  }
+}
+void k_lasso_rw_leaves(Ctx& c, const uint32_t* dim, const uint32_t* e, const uint32_t* ts, size_t n, const Fr& gamma,
+                       const Fr& gamma2, const Fr& tau, Fr* rs, Fr* ws) {
+  if (n)
+    hipLaunchKernelGGL(lasso_rw_leaves_kernel, grid_for(n), 256, 0, c.stream, dim, e, ts, n, gamma, gamma2, tau, rs,
+                       ws);
+}
+__global__ void lasso_if_leaves_kernel(int kind, uint32_t bits, const uint32_t* __restrict__ final_cts, size_t m,
+                                       Fr gamma, Fr gamma2, Fr tau, Fr* __restrict__ init, Fr* __restrict__ fin) {
+  GSTRIDE(i, m) {
+    Fr a = mul(from_u64<FrParams>(i), gamma2);
+    Fr v = mul(from_u64<FrParams>(subtable_entry(kind, (uint32_t)i, bits)), gamma);
+    Fr h = sub(add(a, v), tau);
+    init[i] = h;
+    fin[i] = add(h, from_u64<FrParams>(final_cts[i]));
+  }
+}
+void k_lasso_if_leaves(Ctx& c, int subtable, uint32_t chunk_bits, const uint32_t* final_cts, size_t m,
+                       const Fr& gamma, const Fr& gamma2, const Fr& tau, Fr* init, Fr* fin) {
+  if (m)
+    hipLaunchKernelGGL(lasso_if_leaves_kernel, grid_for(m), 256, 0, c.stream, subtable, chunk_bits, final_cts, m,
+                       gamma, gamma2, tau, init, fin);
+}
+
+}  // namespace lh

@@ -1,0 +1,157 @@
+// Sum-check round kernel: fused bind (previous challenge) + round-polynomial evaluation.
+//
+// Replaces the reference's per-round pair of passes
+//   EvaluationsProver::evals   piop/sum_check/classic/eval.rs:102-131  (evaluate)
+//   ProverState::next_round    piop/sum_check/classic.rs:90-141        (bind every table)
+// and CoefficientsProver::karatsuba (classic/coeff.rs:153-202) for expressions of the shape
+//   [eq *] sum_m coeff_m * prod_k table_{m,k}
+// One thread owns one output pair b: in BIND mode it reads the 4 entries (4b..4b+3) of every table
+// of the previous round, binds them with r (poly/multilinear.rs:609-617), stores the bound pair
+// (2b, 2b+1) once and evaluates the new round polynomial on it - each table is read once and written
+// once per round (96 B per bound pair instead of 160 B for separate bind and evaluate passes).
+// Evaluation points X = 1..D: value(X) = v1 + (X-1)*(v1 - v0) (eval.rs:228-286); X = 0 is derived
+// from the claim by the host (eval.rs:129).
+#include <hip/hip_runtime.h>
+#include "dev.hpp"
+#include "reduce.cuh"
+
+namespace lh {
+
+struct ScArgs {
+  ScRound rd;
+  uint8_t store[LH_SC_MAX_TERMS][LH_SC_MAX_FACTORS];  // first occurrence of a table stores its bound pair
+};
+
+template <bool BIND>
+__device__ __forceinline__ void load_pair(const Fr* __restrict__ in, Fr* __restrict__ out, size_t b, const Fr& r,
+                                          bool store, Fr& v0, Fr& v1) {
+  if (BIND) {
+    const Fr* p = in + 4 * b;
+    Fr e0 = p[0], e1 = p[1], e2 = p[2], e3 = p[3];
+    v0 = add(mul(sub(e1, e0), r), e0);
+    v1 = add(mul(sub(e3, e2), r), e2);
+    if (store) {
+      out[2 * b] = v0;
+      out[2 * b + 1] = v1;
+    }
+  } else {
+    v0 = in[2 * b];
+    v1 = in[2 * b + 1];
+  }
+}
+
+template <int D, bool BIND>
+__global__ __launch_bounds__(256) void sc_round_kernel(ScArgs a, size_t size, Fr* __restrict__ partials) {
+  __shared__ Fr lds[4];
+  const ScRound& rd = a.rd;
+  Fr acc[D];
+#pragma unroll
+  for (int x = 0; x < D; x++) acc[x] = Fr::zero();
+
+  for (size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x; b < size; b += (size_t)gridDim.x * blockDim.x) {
+    Fr s[D];
+#pragma unroll
+    for (int x = 0; x < D; x++) s[x] = Fr::zero();
+    for (uint32_t m = 0; m < rd.num_terms; m++) {
+      Fr pm[D];
+      const int nf = rd.nfac[m];
+      for (int k = 0; k < nf; k++) {
+        const int t = rd.fac[m][k];
+        Fr v0, v1;
+        load_pair<BIND>(rd.in[t], rd.out[t], b, rd.r, a.store[m][k] != 0, v0, v1);
+        if (k == 0) {
+          if (!rd.coeff_is_one[m]) {
+            v0 = mul(v0, rd.coeff[m]);
+            v1 = mul(v1, rd.coeff[m]);
+          }
+          Fr step = sub(v1, v0);
+          pm[0] = v1;
+#pragma unroll
+          for (int x = 1; x < D; x++) pm[x] = add(pm[x - 1], step);
+        } else {
+          Fr step = sub(v1, v0);
+          Fr val = v1;
+          pm[0] = mul(pm[0], val);
+#pragma unroll
+          for (int x = 1; x < D; x++) {
+            val = add(val, step);
+            pm[x] = mul(pm[x], val);
+          }
+        }
+      }
+#pragma unroll
+      for (int x = 0; x < D; x++) s[x] = add(s[x], pm[x]);
+    }
+    if (rd.global_eq >= 0) {
+      Fr v0, v1;
+      load_pair<BIND>(rd.in[rd.global_eq], rd.out[rd.global_eq], b, rd.r, true, v0, v1);
+      Fr step = sub(v1, v0);
+      Fr val = v1;
+      s[0] = mul(s[0], val);
+#pragma unroll
+      for (int x = 1; x < D; x++) {
+        val = add(val, step);
+        s[x] = mul(s[x], val);
+      }
+    }
+#pragma unroll
+    for (int x = 0; x < D; x++) acc[x] = add(acc[x], s[x]);
+  }
+#pragma unroll
+  for (int x = 0; x < D; x++) {
+    Fr v = block_reduce_sum(acc[x], lds);
+    if (threadIdx.x == 0) partials[(size_t)blockIdx.x * D + x] = v;
+  }
+}
+
+__global__ void sc_reduce_kernel(const Fr* __restrict__ partials, int blocks, int d, Fr* __restrict__ out) {
+  __shared__ Fr lds[4];
+  for (int x = 0; x < d; x++) {
+    Fr acc = Fr::zero();
+    for (int i = threadIdx.x; i < blocks; i += blockDim.x) acc = add(acc, partials[(size_t)i * d + x]);
+    acc = block_reduce_sum(acc, lds);
+    if (threadIdx.x == 0) out[x] = acc;
+  }
+}
+
+template <int D>
+static void launch_round(Ctx& c, const ScArgs& a, bool bind, size_t size, unsigned grid, Fr* partials) {
+  if (bind)
+    hipLaunchKernelGGL((sc_round_kernel<D, true>), dim3(grid), dim3(256), 0, c.stream, a, size, partials);
+  else
+    hipLaunchKernelGGL((sc_round_kernel<D, false>), dim3(grid), dim3(256), 0, c.stream, a, size, partials);
+}
+
+void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, Fr* evals_host) {
+  LH_REQUIRE(degree >= 1 && degree <= 6, LH_ERR_ARG, "sum-check degree must be in 1..6");
+  LH_REQUIRE(size >= 1, LH_ERR_ARG, "sum-check round over an empty table");
+  ScArgs a;
+  a.rd = rd;
+  bool seen[SC_MAX_TABLES] = {false};
+  if (rd.global_eq >= 0) seen[rd.global_eq] = true;  // stored by the eq load
+  for (uint32_t m = 0; m < rd.num_terms; m++)
+    for (int k = 0; k < rd.nfac[m]; k++) {
+      int t = rd.fac[m][k];
+      a.store[m][k] = seen[t] ? 0 : 1;
+      seen[t] = true;
+    }
+  ArenaScope scope(c.arena);
+  size_t g = (size + 255) / 256;
+  size_t cap = (size_t)c.num_cus * 4;
+  if (g > cap) g = cap;
+  Fr* partials = c.arena.alloc_n<Fr>(g * degree);
+  Fr* d_out = c.arena.alloc_n<Fr>(degree);
+  switch (degree) {
+    case 1: launch_round<1>(c, a, bind, size, (unsigned)g, partials); break;
+    case 2: launch_round<2>(c, a, bind, size, (unsigned)g, partials); break;
+    case 3: launch_round<3>(c, a, bind, size, (unsigned)g, partials); break;
+    case 4: launch_round<4>(c, a, bind, size, (unsigned)g, partials); break;
+    case 5: launch_round<5>(c, a, bind, size, (unsigned)g, partials); break;
+    default: launch_round<6>(c, a, bind, size, (unsigned)g, partials); break;
+  }
+  hipLaunchKernelGGL(sc_reduce_kernel, dim3(1), dim3(256), 0, c.stream, partials, (int)g, degree, d_out);
+  LH_HIP(hipMemcpyAsync(evals_host, d_out, degree * sizeof(Fr), hipMemcpyDeviceToHost, c.stream));
+  c.sync();
+}
+
+}  // namespace lh

@@ -1,0 +1,530 @@
+// Host orchestration of sum-check, GKR and multilinear-KZG over the device kernels.
+// Every function cites the reference routine whose transcript schedule it reproduces; all heavy
+// loops run in HIP kernels (dev.hpp), the host keeps the Fiat-Shamir state and O(n) scalars.
+#include <algorithm>
+#include "host.hpp"
+
+namespace lh {
+
+// ------------------------------------------------------------------ small host helpers
+std::vector<HFr> host_eq_xy(const std::vector<HFr>& y) {
+  if (y.empty()) return {};  // MultilinearPolynomial::zero() (multilinear.rs:92-94)
+  std::vector<HFr> evals{HFr::one()};
+  for (size_t i = y.size(); i-- > 0;) {
+    std::vector<HFr> nxt(evals.size() * 2);
+    for (size_t k = 0; k < evals.size(); k++) {
+      nxt[2 * k + 1] = evals[k] * y[i];
+      nxt[2 * k] = evals[k] - nxt[2 * k + 1];
+    }
+    evals.swap(nxt);
+  }
+  return evals;
+}
+
+HFr host_eq_xy_eval(const HFr* x, const HFr* y, size_t n) {
+  HFr acc = HFr::one();
+  for (size_t i = 0; i < n; i++) acc *= (x[i] * y[i]).dbl() + HFr::one() - x[i] - y[i];
+  return acc;
+}
+
+std::vector<HFr> evaluate_polys(Ctx& c, const Fr* const* d_polys, size_t count, size_t num_vars, const HFr* point) {
+  std::vector<HFr> out(count);
+  if (!count) return out;
+  ArenaScope scope(c.arena);
+  size_t n = (size_t)1 << num_vars;
+  Fr* eq = c.arena.alloc_n<Fr>(n);
+  k_eq_xy(c, (const Fr*)point, num_vars, eq);
+  k_inner_products(c, d_polys, count, eq, n, (Fr*)out.data());
+  return out;
+}
+
+// value at x of the polynomial through (i, evals[i]), i = 0..d
+// (barycentric_interpolate over points 0..d, reference util/arithmetic.rs:108-136)
+static HFr interpolate_evals(const std::vector<HFr>& evals, const HFr& x) {
+  const size_t d = evals.size() - 1;
+  // x in {0..d} would zero a denominator; the reference hits the same case through batch_invert
+  std::vector<HFr> pts(d + 1), num(d + 1);
+  for (size_t i = 0; i <= d; i++) pts[i] = HFr::from_u64(i);
+  for (size_t i = 0; i <= d; i++)
+    if (x == pts[i]) return evals[i];
+  HFr total = HFr::zero();
+  for (size_t j = 0; j <= d; j++) {
+    HFr nu = HFr::one(), de = HFr::one();
+    for (size_t i = 0; i <= d; i++) {
+      if (i == j) continue;
+      nu *= x - pts[i];
+      de *= pts[j] - pts[i];
+    }
+    total += evals[j] * nu * de.inv();
+  }
+  return total;
+}
+
+static HFr horner(const std::vector<HFr>& coeffs, const HFr& x) {
+  HFr acc = HFr::zero();
+  for (size_t i = coeffs.size(); i-- > 0;) acc = acc * x + coeffs[i];
+  return acc;
+}
+
+// ------------------------------------------------------------------ ClassicSumCheck::prove
+// reference piop/sum_check/classic.rs:208-240.  Round i: [fused bind with r_{i-1}] + evaluation on the
+// GPU (k_sc_round), message to the transcript, squeeze r_i.  After the last squeeze one more bind gives
+// table[0] of every poly (classic.rs:143-149).
+SumCheckResult sum_check_prove(Ctx& c, int prover_kind, size_t num_vars, const lh_sop& expr,
+                               const Fr* const* d_polys, size_t num_polys, const HFr* ys, size_t num_ys,
+                               const HFr& sum, Transcript& tr) {
+  LH_REQUIRE(num_vars > 0, LH_ERR_ARG, "sum-check needs num_vars > 0");  // classic.rs:42 assert
+  const size_t T = num_polys + num_ys;
+  LH_REQUIRE(T <= (size_t)SC_MAX_TABLES, LH_ERR_ARG, "sum-check: too many tables for one round kernel");
+  LH_REQUIRE(expr.num_terms >= 1 && expr.num_terms <= LH_SC_MAX_TERMS, LH_ERR_ARG, "sum-check: bad term count");
+  LH_REQUIRE(expr.global_eq < (int)num_ys, LH_ERR_ARG, "sum-check: global_eq out of range");
+
+  // Expression::degree() (expression.rs:171-182): every table is degree 1, products add, sums max
+  int degree = 0;
+  ScRound rd;
+  memset(&rd, 0, sizeof(rd));
+  rd.num_tables = (uint32_t)T;
+  rd.num_terms = expr.num_terms;
+  rd.global_eq = expr.global_eq >= 0 ? (int)num_polys + expr.global_eq : -1;
+  const HFr one = HFr::one();
+  std::vector<char> used(T, 0);
+  if (rd.global_eq >= 0) used[rd.global_eq] = 1;
+  for (uint32_t m = 0; m < expr.num_terms; m++) {
+    int nf = expr.num_factors[m];
+    LH_REQUIRE(nf >= 1 && nf <= LH_SC_MAX_FACTORS, LH_ERR_ARG, "sum-check: bad factor count");
+    degree = std::max(degree, nf + (expr.global_eq >= 0 ? 1 : 0));
+    memcpy(&rd.coeff[m], &expr.coeff[m], 32);
+    rd.coeff_is_one[m] = (memcmp(&expr.coeff[m], &one, 32) == 0);
+    rd.nfac[m] = (uint8_t)nf;
+    for (int k = 0; k < nf; k++) {
+      LH_REQUIRE(expr.factor[m][k] < T, LH_ERR_ARG, "sum-check: factor id out of range");
+      rd.fac[m][k] = expr.factor[m][k];
+      used[expr.factor[m][k]] = 1;
+    }
+  }
+  if (prover_kind == LH_SC_COEFFICIENTS)
+    LH_REQUIRE(degree == 2, LH_ERR_ARG, "CoefficientsProver supports degree 2 only");  // coeff.rs:143 unimplemented!()
+  else
+    LH_REQUIRE(degree >= 2, LH_ERR_ARG, "EvaluationsProver needs degree >= 2");  // eval.rs:316 debug_assert
+
+  ArenaScope scope(c.arena);
+  const size_t n = (size_t)1 << num_vars;
+  std::vector<const Fr*> cur(T);
+  for (size_t i = 0; i < num_polys; i++) cur[i] = d_polys[i];
+  for (size_t j = 0; j < num_ys; j++) {  // ProverState::new: eq_xys (classic.rs:56-60)
+    Fr* eq = c.arena.alloc_n<Fr>(n);
+    k_eq_xy(c, (const Fr*)(ys + j * num_vars), num_vars, eq);
+    cur[num_polys + j] = eq;
+  }
+  // ping-pong targets of the binds: A holds 2^(n-1), B holds 2^(n-2)
+  std::vector<Fr*> bufA(T), bufB(T);
+  for (size_t i = 0; i < T; i++) {
+    bufA[i] = c.arena.alloc_n<Fr>(std::max<size_t>(n >> 1, 1));
+    bufB[i] = c.arena.alloc_n<Fr>(std::max<size_t>(n >> 2, 1));
+  }
+  Fr* evals_host = (Fr*)c.pin(16 * sizeof(Fr));
+  const HFr inv2 = HFr::from_u64(2).inv();
+
+  SumCheckResult res;
+  HFr claim = sum;
+  HFr r_prev = HFr::zero();
+  for (size_t round = 0; round < num_vars; round++) {
+    const size_t size = (size_t)1 << (num_vars - round - 1);
+    const bool bind = round > 0;
+    std::vector<Fr*>& dst = (round & 1) ? bufA : bufB;
+    for (size_t i = 0; i < T; i++) {
+      rd.in[i] = cur[i];
+      rd.out[i] = dst[i];
+    }
+    rd.r = dev(r_prev);
+    if (bind) {
+      // tables no term touches are still bound (ProverState::next_round binds every poly)
+      for (size_t i = 0; i < T; i++)
+        if (!used[i]) k_fix_var(c, cur[i], size << 2, rd.r, dst[i]);
+    }
+    k_sc_round(c, rd, degree, bind, size, evals_host);
+    if (bind)
+      for (size_t i = 0; i < T; i++) cur[i] = dst[i];
+
+    std::vector<HFr> ev(degree + 1);
+    for (int x = 1; x <= degree; x++) ev[x] = hst(evals_host[x - 1]);
+    ev[0] = claim - ev[1];  // eval.rs:129
+    HFr r;
+    if (prover_kind == LH_SC_COEFFICIENTS) {
+      // coeff.rs:136-149: c0 = p(0), c2 = leading coefficient, c1 = claim - (2 c0 + c2)
+      std::vector<HFr> co(3);
+      co[0] = ev[0];
+      co[2] = (ev[2] - ev[1].dbl() + ev[0]) * inv2;
+      co[1] = claim - (co[0].dbl() + co[2]);
+      tr.write_field_elements(co);
+      r = tr.squeeze_challenge();
+      claim = horner(co, r);
+    } else {
+      tr.write_field_elements(ev);
+      r = tr.squeeze_challenge();
+      claim = interpolate_evals(ev, r);
+    }
+    res.challenges.push_back(r);
+    r_prev = r;
+  }
+  // into_evals: last bind (2 -> 1 entries) of every poly
+  {
+    std::vector<Fr*>& dst = (num_vars & 1) ? bufA : bufB;
+    if (num_polys) {
+      k_fix_var_multi(c, cur.data(), dst.data(), num_polys, 2, dev(r_prev));
+      Fr* stage = c.arena.alloc_n<Fr>(num_polys);
+      for (size_t i = 0; i < num_polys; i++)
+        LH_HIP(hipMemcpyAsync(stage + i, dst[i], sizeof(Fr), hipMemcpyDeviceToDevice, c.stream));
+      res.evals.resize(num_polys);
+      LH_HIP(hipMemcpyAsync(res.evals.data(), stage, num_polys * sizeof(Fr), hipMemcpyDeviceToHost, c.stream));
+      c.sync();
+    }
+  }
+  return res;
+}
+
+// ------------------------------------------------------------------ prove_fractional_sum_check
+// reference piop/gkr/fractional_sum_check.rs:89-190
+static void download(Ctx& c, void* dst, const void* src, size_t bytes) {
+  LH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c.stream));
+  c.sync();
+}
+
+FracSumCheckResult prove_fractional_sum_check(Ctx& c, size_t B, size_t num_vars, const HFr* const* claimed_p_0s,
+                                              const HFr* const* claimed_q_0s, const Fr* const* d_ps,
+                                              const Fr* const* d_qs, Transcript& tr) {
+  LH_REQUIRE(B != 0, LH_ERR_ARG, "fractional sum-check: num_batching == 0");  // :103 assert
+  LH_REQUIRE(num_vars >= 1, LH_ERR_ARG, "fractional sum-check: num_vars == 0");
+  LH_REQUIRE(3 * B <= LH_SC_MAX_TERMS && 4 * B + 1 <= (size_t)SC_MAX_TABLES, LH_ERR_ARG,
+             "fractional sum-check: too many fractions for one round kernel");
+  ArenaScope scope(c.arena);
+  // levels[h][b] = (p, q) arrays of 2^(num_vars-h) entries; Layer::bottom/up (:42-85) are views of them
+  std::vector<std::vector<const Fr*>> lp(num_vars), lq(num_vars);
+  for (size_t b = 0; b < B; b++) {
+    lp[0].push_back(d_ps[b]);
+    lq[0].push_back(d_qs[b]);
+  }
+  for (size_t h = 1; h < num_vars; h++) {
+    size_t half = (size_t)1 << (num_vars - h);
+    for (size_t b = 0; b < B; b++) {
+      Fr* vp = c.arena.alloc_n<Fr>(half);
+      Fr* vq = c.arena.alloc_n<Fr>(half);
+      k_frac_up(c, lp[h - 1][b], lq[h - 1][b], half, vp, vq);
+      lp[h].push_back(vp);
+      lq[h].push_back(vq);
+    }
+  }
+  // roots from the top (0-variable) layer (:116-125)
+  std::vector<HFr> top(4 * B);
+  {
+    Fr* stage = c.arena.alloc_n<Fr>(4 * B);
+    for (size_t b = 0; b < B; b++) {
+      LH_HIP(hipMemcpyAsync(stage + 4 * b, lp[num_vars - 1][b], 2 * sizeof(Fr), hipMemcpyDeviceToDevice, c.stream));
+      LH_HIP(hipMemcpyAsync(stage + 4 * b + 2, lq[num_vars - 1][b], 2 * sizeof(Fr), hipMemcpyDeviceToDevice, c.stream));
+    }
+    download(c, top.data(), stage, 4 * B * sizeof(Fr));
+  }
+  std::vector<HFr> claimed_p(B), claimed_q(B);
+  for (size_t b = 0; b < B; b++) {
+    const HFr &p_l = top[4 * b], &p_r = top[4 * b + 1], &q_l = top[4 * b + 2], &q_r = top[4 * b + 3];
+    claimed_p[b] = p_l * q_r + p_r * q_l;
+    claimed_q[b] = q_l * q_r;
+  }
+  for (size_t b = 0; b < B; b++) {  // :127-142: Some -> common, None -> write
+    if (claimed_p_0s && claimed_p_0s[b]) tr.common_field_element(claimed_p[b]);
+    else tr.write_field_element(claimed_p[b]);
+  }
+  for (size_t b = 0; b < B; b++) {
+    if (claimed_q_0s && claimed_q_0s[b]) tr.common_field_element(claimed_q[b]);
+    else tr.write_field_element(claimed_q[b]);
+  }
+
+  std::vector<HFr> y;
+  for (size_t h = num_vars; h-- > 0;) {  // layers.iter().rev()
+    const size_t nv = num_vars - 1 - h;  // variables of this layer
+    const size_t half = (size_t)1 << nv;
+    std::vector<HFr> x, evals;
+    if (nv == 0) {
+      evals = top;  // (p_l, p_r, q_l, q_r) per fraction
+    } else {
+      HFr gamma = tr.squeeze_challenge();
+      // sum_check_claim (:283-288) and sum_check_expression (:272-281)
+      HFr claim = HFr::zero(), power = HFr::one();
+      lh_sop expr;
+      memset(&expr, 0, sizeof(expr));
+      expr.global_eq = 0;
+      std::vector<const Fr*> polys;
+      for (size_t b = 0; b < B; b++) {
+        claim += claimed_p[b] * power;
+        HFr g_even = power;
+        power *= gamma;
+        claim += claimed_q[b] * power;
+        HFr g_odd = power;
+        power *= gamma;
+        uint8_t p_l = 4 * b, p_r = 4 * b + 1, q_l = 4 * b + 2, q_r = 4 * b + 3;
+        uint32_t m = expr.num_terms;
+        memcpy(&expr.coeff[m], &g_even, 32);
+        expr.num_factors[m] = 2, expr.factor[m][0] = p_l, expr.factor[m][1] = q_r;
+        memcpy(&expr.coeff[m + 1], &g_even, 32);
+        expr.num_factors[m + 1] = 2, expr.factor[m + 1][0] = p_r, expr.factor[m + 1][1] = q_l;
+        memcpy(&expr.coeff[m + 2], &g_odd, 32);
+        expr.num_factors[m + 2] = 2, expr.factor[m + 2][0] = q_l, expr.factor[m + 2][1] = q_r;
+        expr.num_terms += 3;
+        polys.push_back(lp[h][b]);
+        polys.push_back(lp[h][b] + half);
+        polys.push_back(lq[h][b]);
+        polys.push_back(lq[h][b] + half);
+      }
+      SumCheckResult sc = sum_check_prove(c, LH_SC_EVALUATIONS, nv, expr, polys.data(), polys.size(), y.data(), 1,
+                                          claim, tr);
+      x = sc.challenges;
+      evals = sc.evals;
+    }
+    tr.write_field_elements(evals);
+    HFr mu = tr.squeeze_challenge();
+    for (size_t b = 0; b < B; b++) {  // layer_down_claim (:290-296)
+      const HFr &p_l = evals[4 * b], &p_r = evals[4 * b + 1], &q_l = evals[4 * b + 2], &q_r = evals[4 * b + 3];
+      claimed_p[b] = p_l + mu * (p_r - p_l);
+      claimed_q[b] = q_l + mu * (q_r - q_l);
+    }
+    x.push_back(mu);
+    y = x;
+  }
+  return FracSumCheckResult{claimed_p, claimed_q, y};
+}
+
+// ------------------------------------------------------------------ grand product (Lasso memory check)
+// Product-only layered circuit; schedule in oracle/pyref/gkr.py::prove_grand_product.
+GrandProductResult prove_grand_product(Ctx& c, size_t B, const Fr* const* d_leaves, const size_t* num_vars,
+                                       Transcript& tr) {
+  LH_REQUIRE(B != 0, LH_ERR_ARG, "grand product: no trees");
+  size_t max_depth = 0;
+  for (size_t b = 0; b < B; b++) {
+    LH_REQUIRE(num_vars[b] >= 1 && num_vars[b] < 32, LH_ERR_ARG, "grand product: every tree needs >= 2 leaves");
+    max_depth = std::max(max_depth, num_vars[b]);
+  }
+  LH_REQUIRE(2 * B + 1 <= (size_t)SC_MAX_TABLES && B <= LH_SC_MAX_TERMS, LH_ERR_ARG,
+             "grand product: too many trees for one round kernel");
+  ArenaScope scope(c.arena);
+  // level[b][h]: array with 2^(h+1) nodes, h = 0 (top, two nodes) .. depth-1 (the leaves)
+  std::vector<std::vector<const Fr*>> level(B);
+  for (size_t b = 0; b < B; b++) {
+    level[b].resize(num_vars[b]);
+    level[b][num_vars[b] - 1] = d_leaves[b];
+    for (size_t h = num_vars[b] - 1; h-- > 0;) {
+      size_t half = (size_t)1 << (h + 1);
+      Fr* up = c.arena.alloc_n<Fr>(half);
+      k_tree_up(c, level[b][h + 1], half, up);
+      level[b][h] = up;
+    }
+  }
+  std::vector<HFr> top(2 * B);
+  {
+    Fr* stage = c.arena.alloc_n<Fr>(2 * B);
+    for (size_t b = 0; b < B; b++)
+      LH_HIP(hipMemcpyAsync(stage + 2 * b, level[b][0], 2 * sizeof(Fr), hipMemcpyDeviceToDevice, c.stream));
+    download(c, top.data(), stage, 2 * B * sizeof(Fr));
+  }
+  GrandProductResult res;
+  res.roots.resize(B);
+  res.claims.resize(B);
+  res.points.resize(B);
+  for (size_t b = 0; b < B; b++) res.roots[b] = top[2 * b] * top[2 * b + 1];
+  tr.write_field_elements(res.roots);
+
+  std::vector<HFr> claims = res.roots, y;
+  for (size_t h = 0; h < max_depth; h++) {
+    std::vector<size_t> active;
+    for (size_t b = 0; b < B; b++)
+      if (num_vars[b] > h) active.push_back(b);
+    const size_t half = (size_t)1 << h;
+    std::vector<HFr> x, evals;
+    if (h == 0) {
+      for (size_t b : active) {
+        evals.push_back(top[2 * b]);
+        evals.push_back(top[2 * b + 1]);
+      }
+    } else {
+      HFr lam = tr.squeeze_challenge();
+      HFr claim = HFr::zero(), power = HFr::one();
+      lh_sop expr;
+      memset(&expr, 0, sizeof(expr));
+      expr.global_eq = 0;
+      std::vector<const Fr*> polys;
+      for (size_t k = 0; k < active.size(); k++) {
+        size_t b = active[k];
+        claim += claims[b] * power;
+        memcpy(&expr.coeff[k], &power, 32);
+        expr.num_factors[k] = 2;
+        expr.factor[k][0] = (uint8_t)(2 * k);
+        expr.factor[k][1] = (uint8_t)(2 * k + 1);
+        power *= lam;
+        polys.push_back(level[b][h]);
+        polys.push_back(level[b][h] + half);
+      }
+      expr.num_terms = (uint32_t)active.size();
+      SumCheckResult sc =
+          sum_check_prove(c, LH_SC_EVALUATIONS, h, expr, polys.data(), polys.size(), y.data(), 1, claim, tr);
+      x = sc.challenges;
+      evals = sc.evals;
+    }
+    tr.write_field_elements(evals);
+    HFr mu = tr.squeeze_challenge();
+    x.push_back(mu);
+    y = x;
+    for (size_t k = 0; k < active.size(); k++) {
+      size_t b = active[k];
+      const HFr &l = evals[2 * k], &r = evals[2 * k + 1];
+      claims[b] = l + mu * (r - l);
+      if (num_vars[b] == h + 1) {
+        res.claims[b] = claims[b];
+        res.points[b] = y;
+      }
+    }
+  }
+  return res;
+}
+
+// ------------------------------------------------------------------ MultilinearKzg
+// setup: reference pcs/multilinear/kzg.rs:166-228 with the trapdoor supplied by the caller.
+Srs* mkzg_setup(Ctx& c, const HFr* ss, size_t num_vars) {
+  LH_REQUIRE(num_vars < 31, LH_ERR_ARG, "setup: num_vars too large");
+  Srs* srs = new Srs();
+  srs->num_vars = num_vars;
+  size_t total = ((size_t)2 << num_vars) - 1;
+  LH_HIP(hipMalloc((void**)&srs->d_eqs, total * sizeof(G1Affine)));
+  ArenaScope scope(c.arena);
+  Fr* scal = c.arena.alloc_n<Fr>(total);
+  // eqs[k] = eq table of (s_0..s_{k-1}) with s_{k-1} the top bit (kzg.rs:178-194) == eq_xy(s[..k])
+  for (size_t k = 0; k <= num_vars; k++) k_eq_xy(c, (const Fr*)ss, k, scal + (((size_t)1 << k) - 1));
+  k_fixed_base_mul_g(c, scal, total, srs->d_eqs);
+  return srs;
+}
+
+static void check_commit_vars(const Srs& srs, size_t num_vars, const char* what) {
+  if (num_vars > srs.num_vars)  // validate_input / err_too_many_variates (pcs/multilinear.rs:27-70)
+    throw Error(LH_ERR_INVALID_PCS_PARAM,
+                std::string("Too many variates of poly to ") + what + " (param supports variates up to " +
+                    std::to_string(srs.num_vars) + " but got " + std::to_string(num_vars) + ")");
+}
+
+std::vector<HG1> mkzg_batch_commit(Ctx& c, const Srs& srs, const Fr* const* d_polys, size_t num_polys,
+                                   size_t num_vars) {
+  check_commit_vars(srs, num_vars, "batch commit");
+  std::vector<MsmJob> jobs(num_polys);
+  for (size_t i = 0; i < num_polys; i++)
+    jobs[i] = MsmJob{d_polys[i], false, srs.eq(num_vars), (size_t)1 << num_vars};
+  std::vector<HG1> out(num_polys);
+  msm_batch(c, jobs.data(), num_polys, (G1Affine*)out.data());
+  return out;
+}
+
+std::vector<HG1> mkzg_batch_commit_u32(Ctx& c, const Srs& srs, const uint32_t* const* d_polys, size_t num_polys,
+                                       size_t num_vars) {
+  check_commit_vars(srs, num_vars, "batch commit");
+  std::vector<MsmJob> jobs(num_polys);
+  for (size_t i = 0; i < num_polys; i++)
+    jobs[i] = MsmJob{d_polys[i], true, srs.eq(num_vars), (size_t)1 << num_vars};
+  std::vector<HG1> out(num_polys);
+  msm_batch(c, jobs.data(), num_polys, (G1Affine*)out.data());
+  return out;
+}
+
+// open: kzg.rs:276-302 + quotients pcs/multilinear.rs:72-107.  The n quotient polynomials are laid out
+// back to back (q_i at offset 2^i - 1, exactly the flat SRS layout) and committed as ONE batched MSM.
+HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const HFr* point, Transcript& tr) {
+  check_commit_vars(srs, num_vars, "open");
+  ArenaScope scope(c.arena);
+  const size_t n = (size_t)1 << num_vars;
+  Fr* q = c.arena.alloc_n<Fr>(n);  // n - 1 used
+  Fr* remA = c.arena.alloc_n<Fr>(std::max<size_t>(n >> 1, 1));
+  Fr* remB = c.arena.alloc_n<Fr>(std::max<size_t>(n >> 2, 1));
+  const Fr* rem = d_poly;
+  for (size_t i = num_vars; i-- > 0;) {
+    size_t half = (size_t)1 << i;
+    Fr* dst = ((num_vars - i) & 1) ? remA : remB;
+    k_quotient_step(c, rem, half, dev(point[i]), q + (half - 1), dst);
+    rem = dst;
+  }
+  HFr remainder;
+  if (num_vars == 0) {
+    download(c, &remainder, d_poly, sizeof(Fr));
+    return remainder;
+  }
+  std::vector<MsmJob> jobs(num_vars);
+  for (size_t i = 0; i < num_vars; i++) {
+    size_t half = (size_t)1 << i;
+    jobs[i] = MsmJob{q + (half - 1), false, srs.eq(i), half};
+  }
+  std::vector<HG1> comms(num_vars);
+  msm_batch(c, jobs.data(), num_vars, (G1Affine*)comms.data());
+  download(c, &remainder, rem, sizeof(Fr));
+  tr.write_commitments(comms);  // identity -> Error::Transcript (transcript.rs:172-179,216-219)
+  return remainder;
+}
+
+// batch_open: pcs/multilinear.rs:134-235
+void mkzg_batch_open(Ctx& c, const Srs& srs, size_t num_vars, const Fr* const* d_polys, size_t num_polys,
+                     const HFr* points, size_t num_points, const lh_evaluation* evals, size_t num_evals,
+                     Transcript& tr) {
+  check_commit_vars(srs, num_vars, "batch open");
+  LH_REQUIRE(num_vars >= 1, LH_ERR_ARG, "batch open: num_vars == 0");
+  LH_REQUIRE(num_evals >= 2, LH_ERR_ARG,
+             "batch open needs >= 2 evaluations (eq_xy of an empty point is the zero poly, multilinear.rs:92-94)");
+  LH_REQUIRE(2 * num_points <= (size_t)SC_MAX_TABLES && num_points <= LH_SC_MAX_TERMS, LH_ERR_ARG,
+             "batch open: too many points");
+  for (size_t i = 0; i < num_evals; i++)
+    LH_REQUIRE(evals[i].poly < num_polys && evals[i].point < num_points, LH_ERR_ARG, "batch open: bad evaluation");
+
+  size_t ell = 0;
+  while (((size_t)1 << ell) < num_evals) ell++;  // next_power_of_two().ilog2()
+  std::vector<HFr> t = tr.squeeze_challenges(ell);
+  std::vector<HFr> eq_xt = host_eq_xy(t);
+
+  ArenaScope scope(c.arena);
+  const size_t n = (size_t)1 << num_vars;
+  // merged_j = sum_{i : point(i) = j} eq_xt[i] * poly_i  (:155-170; the lazy first scalar there is a
+  // representation detail, every field value below is the same)
+  std::vector<const Fr*> merged(num_points);
+  for (size_t j = 0; j < num_points; j++) {
+    std::vector<const Fr*> src;
+    std::vector<Fr> w;
+    for (size_t i = 0; i < num_evals; i++)
+      if (evals[i].point == j) {
+        src.push_back(d_polys[evals[i].poly]);
+        w.push_back(dev(eq_xt[i]));
+      }
+    LH_REQUIRE(!src.empty(), LH_ERR_ARG, "batch open: a point without evaluations");
+    Fr* m = c.arena.alloc_n<Fr>(n);
+    k_lincomb(c, src.data(), w.data(), src.size(), n, m);
+    merged[j] = m;
+  }
+  lh_sop expr;
+  memset(&expr, 0, sizeof(expr));
+  expr.global_eq = -1;
+  expr.num_terms = (uint32_t)num_points;
+  const HFr one = HFr::one();
+  for (size_t j = 0; j < num_points; j++) {
+    memcpy(&expr.coeff[j], &one, 32);
+    expr.num_factors[j] = 2;
+    expr.factor[j][0] = (uint8_t)(num_points + j);  // eq_xy(j)
+    expr.factor[j][1] = (uint8_t)j;                 // merged_j
+  }
+  HFr tilde_gs_sum = HFr::zero();
+  for (size_t i = 0; i < num_evals; i++) {
+    HFr v;
+    memcpy(&v, &evals[i].value, 32);
+    tilde_gs_sum += v * eq_xt[i];
+  }
+  SumCheckResult sc = sum_check_prove(c, LH_SC_COEFFICIENTS, num_vars, expr, merged.data(), num_points, points,
+                                      num_points, tilde_gs_sum, tr);
+  // g' = sum_j eq_xy_eval(challenges, z_j) * merged_j  (:200-213)
+  std::vector<Fr> w(num_points);
+  for (size_t j = 0; j < num_points; j++)
+    w[j] = dev(host_eq_xy_eval(sc.challenges.data(), points + j * num_vars, num_vars));
+  Fr* g_prime = c.arena.alloc_n<Fr>(n);
+  k_lincomb(c, merged.data(), w.data(), num_points, n, g_prime);
+  mkzg_open(c, srs, g_prime, num_vars, sc.challenges.data(), tr);
+}
+
+}  // namespace lh

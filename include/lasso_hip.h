@@ -1,0 +1,207 @@
+/* lasso_hip.h -- C-ABI of the MI355X-native prover hot path (liblasso_hip.so).
+ *
+ * The reference (DoHoonKim8/halo2-lasso, Rust) has no FFI: its seam is a set of generic traits
+ * (SURVEY.md §8b).  Every entry point below names the reference item it replaces; a Rust shim
+ * implementing those traits binds exactly these symbols.
+ *
+ * Conventions
+ *  - Field elements cross the ABI in halo2curves' in-memory form: 4 x u64 little-endian limbs,
+ *    Montgomery (R = 2^256).  `lh_fr` is therefore bit-identical to a Rust `bn256::Fr`, and
+ *    `lh_g1` ({x, y} in Fq, identity = (0,0)) to `bn256::G1Affine`.
+ *  - `d_*` arguments are DEVICE pointers (from lh_alloc, or any HIP allocation such as a torch
+ *    tensor's data_ptr on the ctx's device); everything else is host memory owned by the caller
+ *    for the duration of the call.
+ *  - Every function returns an `lh_status`; 0 is success, negatives mirror
+ *    plonkish_backend::Error (plonkish_backend/src/lib.rs:12-20).  lh_last_error() gives the
+ *    message of the last failure on the calling thread.
+ *  - One ctx per process per GPU; calls on one ctx are not re-entrant (the reference calls
+ *    `prove` from one thread and fans out on rayon, util/parallel.rs:9-46).
+ *  - There is NO CPU fallback: without a usable HIP device lh_ctx_create fails with
+ *    LH_ERR_DEVICE and nothing else can be called.
+ */
+#ifndef LASSO_HIP_H
+#define LASSO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { uint64_t l[4]; } lh_fr;      /* bn256::Fr, Montgomery */
+typedef struct { uint64_t x[4], y[4]; } lh_g1; /* bn256::G1Affine, Montgomery Fq coords */
+
+typedef int lh_status;
+#define LH_OK 0
+#define LH_ERR_INVALID_SUMCHECK (-1)  /* Error::InvalidSumcheck  lib.rs:14 */
+#define LH_ERR_INVALID_PCS_PARAM (-2) /* Error::InvalidPcsParam  lib.rs:15 */
+#define LH_ERR_INVALID_PCS_OPEN (-3)  /* Error::InvalidPcsOpen   lib.rs:16 */
+#define LH_ERR_INVALID_SNARK (-4)     /* Error::InvalidSnark     lib.rs:17 */
+#define LH_ERR_SERIALIZATION (-5)     /* Error::Serialization    lib.rs:18 */
+#define LH_ERR_TRANSCRIPT (-6)        /* Error::Transcript       lib.rs:19 */
+#define LH_ERR_DEVICE (-7)            /* no HIP device / HIP runtime failure */
+#define LH_ERR_ARG (-8)               /* assert!/panic in the reference: bad argument */
+
+typedef struct lh_ctx lh_ctx;
+
+const char* lh_last_error(void);
+const char* lh_version(void);
+
+/* ---------------------------------------------------------------- context & memory */
+lh_status lh_ctx_create(int device_id, lh_ctx** out);
+void lh_ctx_destroy(lh_ctx* ctx);
+lh_status lh_ctx_sync(lh_ctx* ctx);
+/* opaque hipStream_t the ctx launches on (for bench.py's HIP-event timing) */
+void* lh_ctx_stream(lh_ctx* ctx);
+lh_status lh_alloc(lh_ctx* ctx, size_t bytes, void** d_out);
+lh_status lh_free(lh_ctx* ctx, void* d_ptr);
+lh_status lh_upload(lh_ctx* ctx, void* d_dst, const void* src, size_t bytes);
+lh_status lh_download(lh_ctx* ctx, void* dst, const void* d_src, size_t bytes);
+
+/* ---------------------------------------------------------------- transcript
+ * Callback table standing for `&mut impl TranscriptWrite<G1Affine, Fr>`
+ * (util/transcript.rs:15-97).  Each callback returns 0 or a negative lh_status. */
+typedef struct lh_transcript {
+  void* user;
+  int (*write_field_element)(void* user, const lh_fr* fe);  /* transcript.rs:157-165 */
+  int (*common_field_element)(void* user, const lh_fr* fe); /* transcript.rs:133-136 */
+  int (*squeeze_challenge)(void* user, lh_fr* out);          /* transcript.rs:126-131 */
+  int (*write_commitment)(void* user, const lh_g1* pt);     /* transcript.rs:213-226 */
+  int (*common_commitment)(void* user, const lh_g1* pt);    /* transcript.rs:170-183 */
+} lh_transcript;
+
+/* Built-in Keccak256Transcript<Cursor<Vec<u8>>> (transcript.rs:99-121) */
+lh_status lh_keccak_transcript_new(lh_transcript** out);
+void lh_keccak_transcript_free(lh_transcript* t);
+/* InMemoryTranscript::into_proof (transcript.rs:110-112): pointer valid until the next write */
+lh_status lh_keccak_transcript_proof(lh_transcript* t, const uint8_t** bytes, size_t* len);
+
+/* ---------------------------------------------------------------- a1: Fr arithmetic
+ * halo2_curves bn256::Fr ops (via util/arithmetic.rs:15-22) over device vectors. */
+lh_status lh_fr_from_u64(lh_ctx*, const uint64_t* d_in, size_t n, lh_fr* d_out); /* Fr::from(u64) */
+lh_status lh_fr_from_u32(lh_ctx*, const uint32_t* d_in, size_t n, lh_fr* d_out);
+lh_status lh_fr_to_repr(lh_ctx*, const lh_fr* d_in, size_t n, uint8_t* d_out32); /* to_repr(): canonical LE */
+lh_status lh_fr_from_repr(lh_ctx*, const uint8_t* d_in32, size_t n, lh_fr* d_out); /* must be < r */
+lh_status lh_fr_add(lh_ctx*, const lh_fr* d_a, const lh_fr* d_b, size_t n, lh_fr* d_out);
+lh_status lh_fr_sub(lh_ctx*, const lh_fr* d_a, const lh_fr* d_b, size_t n, lh_fr* d_out);
+lh_status lh_fr_mul(lh_ctx*, const lh_fr* d_a, const lh_fr* d_b, size_t n, lh_fr* d_out);
+/* `iters` dependent multiplications per element: peak Fr-mul/s micro-benchmark */
+lh_status lh_fr_mul_chain(lh_ctx*, const lh_fr* d_a, const lh_fr* d_b, size_t n, int iters, lh_fr* d_out);
+/* ff::BatchInvert (call sites prover.rs:226-234, arithmetic.rs:121): zeros stay zero */
+lh_status lh_fr_batch_invert(lh_ctx*, const lh_fr* d_in, size_t n, lh_fr* d_out);
+
+/* ---------------------------------------------------------------- a3/a4: MultilinearPolynomial
+ * poly/multilinear.rs.  Tables are 2^num_vars device lh_fr, index bit i <-> variable i. */
+/* fix_var (multilinear.rs:179-183,599-618): d_out[b] = e[2b] + (e[2b+1]-e[2b])*x, n_in = 2^m */
+lh_status lh_fix_var(lh_ctx*, const lh_fr* d_in, size_t n_in, const lh_fr* x, lh_fr* d_out);
+/* eq_xy (multilinear.rs:91-127): d_out has 2^num_vars entries */
+lh_status lh_eq_xy(lh_ctx*, const lh_fr* y, size_t num_vars, lh_fr* d_out);
+/* evaluate (multilinear.rs:137-156) of `num_polys` tables at one point */
+lh_status lh_evaluate(lh_ctx*, const lh_fr* const* d_polys, size_t num_polys, size_t num_vars,
+                      const lh_fr* point, lh_fr* out_evals);
+/* AddAssign<(&F,&Self)> folded (multilinear.rs:294-320): d_out = sum_i w[i] * d_polys[i] */
+lh_status lh_lincomb(lh_ctx*, const lh_fr* const* d_polys, const lh_fr* w, size_t num_polys,
+                     size_t n, lh_fr* d_out);
+
+/* ---------------------------------------------------------------- a5-a8: piop::sum_check
+ * ClassicSumCheck::prove (piop/sum_check/classic.rs:208-240) for expressions of the form
+ *     [eq_xy(ys[eq_y]) *]  sum_m coeff[m] * prod_k table[factor[m][k]]
+ * which covers fractional_sum_check.rs:272-281, pcs/multilinear.rs:182-190 and the Surge /
+ * grand-product expressions.  Table ids < num_polys name d_polys, ids >= num_polys name
+ * eq_xy(ys[id - num_polys]).  `degree` is Expression::degree() (expression.rs:171-182). */
+#define LH_SC_MAX_TERMS 48
+#define LH_SC_MAX_FACTORS 4
+typedef struct lh_sop {
+  uint32_t num_terms;
+  int32_t global_eq; /* index into ys multiplied onto the whole sum, or -1 */
+  lh_fr coeff[LH_SC_MAX_TERMS];
+  uint8_t num_factors[LH_SC_MAX_TERMS];
+  uint8_t factor[LH_SC_MAX_TERMS][LH_SC_MAX_FACTORS];
+} lh_sop;
+
+#define LH_SC_EVALUATIONS 0  /* EvaluationsProver  classic/eval.rs:68-131: d+1 evals per round */
+#define LH_SC_COEFFICIENTS 1 /* CoefficientsProver classic/coeff.rs:62-150: 3 coeffs, degree 2 */
+/* Returns challenges x (num_vars) and evals = each poly at x (classic.rs:143-149). */
+lh_status lh_sumcheck_prove(lh_ctx*, int prover_kind, size_t num_vars, const lh_sop* expr,
+                            const lh_fr* const* d_polys, size_t num_polys,
+                            const lh_fr* ys, size_t num_ys, /* num_ys points of num_vars each */
+                            const lh_fr* sum, lh_transcript* t,
+                            lh_fr* out_challenges, lh_fr* out_evals);
+
+/* ---------------------------------------------------------------- a9: piop::gkr
+ * prove_fractional_sum_check (piop/gkr/fractional_sum_check.rs:89-190).  claimed_*[b] may be
+ * NULL (None => root written) or point to a claim (Some => root only hashed).  Outputs
+ * p_xs[B], q_xs[B], x[num_vars]. */
+lh_status lh_gkr_fractional_prove(lh_ctx*, size_t num_batching, size_t num_vars,
+                                  const lh_fr* const* claimed_p_0s, const lh_fr* const* claimed_q_0s,
+                                  const lh_fr* const* d_ps, const lh_fr* const* d_qs,
+                                  lh_transcript* t, lh_fr* out_p_xs, lh_fr* out_q_xs, lh_fr* out_x);
+/* Product-only layered circuit used by the Lasso memory check (no reference code; layering
+ * and schedule follow fractional_sum_check.rs:62-190 with p dropped).  Trees may have different
+ * depth (num_vars[b] >= 1).  out_points holds, per tree, num_vars[b] elements back to back. */
+lh_status lh_grand_product_prove(lh_ctx*, size_t num_trees, const lh_fr* const* d_leaves,
+                                 const size_t* num_vars, lh_transcript* t, lh_fr* out_roots,
+                                 lh_fr* out_claims, lh_fr* out_points);
+
+/* ---------------------------------------------------------------- a10: util::arithmetic::msm
+ * variable_base_msm (util/arithmetic/msm.rs:84-181); result normalised to affine. */
+lh_status lh_msm(lh_ctx*, const lh_fr* d_scalars, const lh_g1* d_bases, size_t n, lh_g1* out);
+/* same with u32 scalars (Lasso's dim / read_ts / final_cts / E polys are small-valued) */
+lh_status lh_msm_u32(lh_ctx*, const uint32_t* d_scalars, const lh_g1* d_bases, size_t n, lh_g1* out);
+
+/* ---------------------------------------------------------------- a11/a12: pcs::multilinear::kzg */
+typedef struct lh_srs lh_srs; /* MultilinearKzgProverParams (kzg.rs:56-77): eqs[0..=num_vars] on device */
+/* setup (kzg.rs:166-228) with the trapdoor given explicitly: eqs[k][b] = eq_k(b; s) * G */
+lh_status lh_mkzg_setup(lh_ctx*, const lh_fr* ss, size_t num_vars, lh_srs** out);
+/* upload of an existing param: eqs flattened, level k at offset 2^k - 1 (trim, kzg.rs:230-250) */
+lh_status lh_srs_upload(lh_ctx*, const lh_g1* eqs_flat, size_t num_vars, lh_srs** out);
+lh_status lh_srs_download(lh_ctx*, const lh_srs*, lh_g1* eqs_flat);
+size_t lh_srs_num_vars(const lh_srs*);
+void lh_srs_free(lh_ctx*, lh_srs*);
+/* commit / batch_commit (kzg.rs:252-274) */
+lh_status lh_mkzg_commit(lh_ctx*, const lh_srs*, const lh_fr* d_poly, size_t num_vars, lh_g1* out);
+lh_status lh_mkzg_batch_commit(lh_ctx*, const lh_srs*, const lh_fr* const* d_polys, size_t num_polys,
+                               size_t num_vars, lh_g1* out_comms);
+/* open (kzg.rs:276-302): writes n quotient commitments to the transcript; *out_eval = remainder */
+lh_status lh_mkzg_open(lh_ctx*, const lh_srs*, const lh_fr* d_poly, size_t num_vars,
+                       const lh_fr* point, lh_transcript* t, lh_fr* out_eval);
+/* batch_open (pcs/multilinear.rs:134-235); Evaluation = {poly, point, value} (pcs.rs:132-155) */
+typedef struct lh_evaluation { uint32_t poly, point; lh_fr value; } lh_evaluation;
+lh_status lh_mkzg_batch_open(lh_ctx*, const lh_srs*, size_t num_vars,
+                             const lh_fr* const* d_polys, size_t num_polys,
+                             const lh_fr* points, size_t num_points,
+                             const lh_evaluation* evals, size_t num_evals, lh_transcript* t);
+
+/* ---------------------------------------------------------------- a': Lasso lookup argument
+ * No reference code (README.md:1-9 only); protocol specified in oracle/pyref/lasso.py. */
+#define LH_SUBTABLE_IDENTITY 0
+#define LH_SUBTABLE_AND 1
+#define LH_SUBTABLE_XOR 2
+#define LH_LASSO_MAX_CHUNKS 8
+#define LH_LASSO_MAX_MEMORIES 16
+#define LH_LASSO_MAX_TERMS 16
+typedef struct lh_lasso_table {
+  uint32_t num_chunks;   /* c */
+  uint32_t chunk_bits;   /* l : subtable size 2^l */
+  uint32_t num_memories; /* alpha */
+  uint32_t memory_chunk[LH_LASSO_MAX_MEMORIES];    /* j(i) */
+  uint32_t memory_subtable[LH_LASSO_MAX_MEMORIES]; /* LH_SUBTABLE_* */
+  uint32_t num_terms; /* g = sum_m coeff[m] * prod_{k < num_factors[m]} E_{factor[m][k]} */
+  lh_fr g_coeff[LH_LASSO_MAX_TERMS];
+  uint8_t g_num_factors[LH_LASSO_MAX_TERMS];
+  uint8_t g_factor[LH_LASSO_MAX_TERMS][LH_SC_MAX_FACTORS];
+} lh_lasso_table;
+/* d_dims[j]: device u32[2^num_vars] chunk indices (< 2^chunk_bits) of every lookup. */
+lh_status lh_lasso_prove(lh_ctx*, const lh_srs*, const lh_lasso_table*, size_t num_vars,
+                         const uint32_t* const* d_dims, lh_transcript* t);
+
+/* per-phase wall-clock of the last lh_lasso_prove on this ctx, milliseconds:
+ * [witness, commit, surge, leaves+trees, gkr, evals, open_n, open_l, total] */
+#define LH_LASSO_NUM_PHASES 9
+lh_status lh_lasso_last_timing(lh_ctx*, double* out_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LASSO_HIP_H */

@@ -1,0 +1,383 @@
+"""GPU parity: HIP path (through the C-ABI) vs the Python big-int oracle, bit-exact.
+
+Each test mirrors a reference test: field arithmetic (arithmetic.rs:202-205), fix_var
+(poly/multilinear.rs:663-712), sum-check round trips (piop/sum_check.rs:140-177), the GKR test
+(fractional_sum_check.rs:327-370), PCS commit/open (pcs/multilinear.rs:293-406), plus the Lasso
+prove -> verify round trip.  Sizes are those the oracle finishes in seconds.
+"""
+import array
+import random
+import zlib
+
+import pytest
+
+from oracle.pyref import curve, gkr as o_gkr, kzg as o_kzg, lasso as o_lasso, sum_check as o_sc
+from oracle.pyref import expression as ex
+from oracle.pyref.field import R_MOD as P, batch_invert
+from oracle.pyref.poly import eq_xy, evaluate, fix_var
+from oracle.pyref.transcript import Keccak256Transcript as OT
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_fr(rng, n):
+    return [rng.randrange(P) for _ in range(n)]
+
+
+EDGE = [0, 1, 2, P - 1, P - 2, (1 << 253), (1 << 32) - 1, 1 << 32, (1 << 64) - 1, 1 << 64, (P - 1) // 2]
+
+
+# ------------------------------------------------------------------ a1: Fr arithmetic
+def test_fr_binops(hl, ctx):
+    rng = random.Random(1)
+    a = EDGE + rand_fr(rng, 500) + EDGE[::-1]
+    b = EDGE[::-1] + rand_fr(rng, 500) + EDGE
+    da, db = ctx.upload(hl.frs_to_bytes(a)), ctx.upload(hl.frs_to_bytes(b))
+    out = ctx.alloc(32 * len(a))
+    for fn, op in ((ctx.lib.lh_fr_add, lambda x, y: (x + y) % P), (ctx.lib.lh_fr_sub, lambda x, y: (x - y) % P),
+                   (ctx.lib.lh_fr_mul, lambda x, y: x * y % P)):
+        assert fn(ctx.h, da.ptr, db.ptr, len(a), out.ptr) == 0
+        assert hl.frs_from_bytes(out.read()) == [op(x, y) for x, y in zip(a, b)]
+    assert ctx.lib.lh_fr_mul_chain(ctx.h, da.ptr, db.ptr, len(a), 5, out.ptr) == 0
+    assert hl.frs_from_bytes(out.read()) == [x * pow(y, 5, P) % P for x, y in zip(a, b)]
+
+
+def test_fr_conversions(hl, ctx):
+    rng = random.Random(2)
+    vals = [0, 1, 2 ** 32 - 1, 2 ** 32, 2 ** 64 - 1] + [rng.randrange(2 ** 64) for _ in range(200)]
+    src = ctx.upload(array.array("Q", vals).tobytes())
+    out = ctx.alloc(32 * len(vals))
+    assert ctx.lib.lh_fr_from_u64(ctx.h, src.ptr, len(vals), out.ptr) == 0
+    assert hl.frs_from_bytes(out.read()) == vals
+    v32 = [v & 0xffffffff for v in vals]
+    src = ctx.upload(array.array("I", v32).tobytes())
+    assert ctx.lib.lh_fr_from_u32(ctx.h, src.ptr, len(v32), out.ptr) == 0
+    assert hl.frs_from_bytes(out.read()) == v32
+    a = EDGE + rand_fr(rng, 100)
+    da, rep = ctx.upload(hl.frs_to_bytes(a)), ctx.alloc(32 * len(a))
+    assert ctx.lib.lh_fr_to_repr(ctx.h, da.ptr, len(a), rep.ptr) == 0
+    raw = rep.read()
+    assert [int.from_bytes(raw[i:i + 32], "little") for i in range(0, len(raw), 32)] == a  # to_repr = canonical LE
+    back = ctx.alloc(32 * len(a))
+    assert ctx.lib.lh_fr_from_repr(ctx.h, rep.ptr, len(a), back.ptr) == 0
+    assert back.read() == hl.frs_to_bytes(a)
+
+
+def test_fr_batch_invert(hl, ctx):
+    rng = random.Random(3)
+    for n in (1, 31, 32, 33, 1000):
+        a = rand_fr(rng, n)
+        for k in range(0, n, 7):
+            a[k] = 0  # zeros stay zero (ff::BatchInvert)
+        da, out = ctx.upload(hl.frs_to_bytes(a)), ctx.alloc(32 * n)
+        assert ctx.lib.lh_fr_batch_invert(ctx.h, da.ptr, n, out.ptr) == 0
+        assert hl.frs_from_bytes(out.read()) == batch_invert(a)
+
+
+# ------------------------------------------------------------------ a3/a4: MultilinearPolynomial
+@pytest.mark.parametrize("num_vars", [1, 2, 5, 11])
+def test_fix_var_eq_evaluate(hl, ctx, num_vars):
+    rng = random.Random(10 + num_vars)
+    evals = rand_fr(rng, 1 << num_vars)
+    poly = hl.MultilinearPolynomial.new(ctx, evals)
+    x = rng.randrange(P)
+    assert poly.fix_var(x).evals() == fix_var(evals, x)
+    y = rand_fr(rng, num_vars)
+    assert hl.MultilinearPolynomial.eq_xy(ctx, y).evals() == eq_xy(y)
+    assert poly.evaluate(y) == evaluate(evals, y)
+    # fix_var vs naive fold, all variables (multilinear.rs:663-687)
+    cur, want = poly, evals
+    for x_i in y:
+        cur, want = cur.fix_var(x_i), fix_var(want, x_i)
+    assert cur.evals() == want == [evaluate(evals, y)]
+
+
+# ------------------------------------------------------------------ a10: variable_base_msm
+@pytest.fixture(scope="module")
+def bases_pool():
+    fb = curve.FixedBase()
+    rng = random.Random(99)
+    return [fb.mul(rng.randrange(1, P)) for _ in range(700)]
+
+
+def _msm_case(hl, ctx, scalars, bases):
+    ds = ctx.upload(hl.frs_to_bytes(scalars))
+    db = ctx.upload(b"".join(hl.g1_to_bytes(b) for b in bases))
+    return hl.variable_base_msm(ctx, ds, db, len(scalars))
+
+
+@pytest.mark.parametrize("n", [1, 2, 17, 64, 300, 700])
+def test_msm_random(hl, ctx, bases_pool, n):
+    rng = random.Random(n)
+    scalars = rand_fr(rng, n)
+    assert _msm_case(hl, ctx, scalars, bases_pool[:n]) == curve.msm(scalars, bases_pool[:n])
+
+
+def test_msm_edge_cases(hl, ctx, bases_pool):
+    rng = random.Random(5)
+    n = 200
+    b = bases_pool[:n]
+    assert _msm_case(hl, ctx, [0] * n, b) is None                      # all-zero scalars -> identity
+    assert _msm_case(hl, ctx, [1] * n, b) == curve.msm([1] * n, b)     # one hot bucket (skew)
+    s = [rng.choice([1, 2, 3, P - 1]) for _ in range(n)]
+    assert _msm_case(hl, ctx, s, b) == curve.msm(s, b)
+    same = [bases_pool[0]] * n                                         # equal bases: doubling inside a bucket
+    assert _msm_case(hl, ctx, [5] * n, same) == curve.mul(bases_pool[0], 5 * n)
+    pm = [bases_pool[0], curve.neg(bases_pool[0])] * (n // 2)          # P + (-P): identity inside a bucket
+    assert _msm_case(hl, ctx, [7] * n, pm) is None
+    with_id = [None if i % 3 == 0 else b[i] for i in range(n)]         # identity bases are skipped
+    s = rand_fr(rng, n)
+    assert _msm_case(hl, ctx, s, with_id) == curve.msm(s, with_id)
+    s = [P - 1] * n
+    assert _msm_case(hl, ctx, s, b) == curve.msm(s, b)
+
+
+def test_msm_u32(hl, ctx, bases_pool):
+    rng = random.Random(6)
+    n = 512
+    for vals in ([rng.randrange(16) for _ in range(n)], [rng.randrange(1 << 32) for _ in range(n)],
+                 [0] * (n - 1) + [0xffffffff]):
+        ds = ctx.upload(array.array("I", vals).tobytes())
+        db = ctx.upload(b"".join(hl.g1_to_bytes(b) for b in bases_pool[:n]))
+        assert hl.variable_base_msm_u32(ctx, ds, db, n) == curve.msm(vals, bases_pool[:n])
+
+
+# ------------------------------------------------------------------ a11: MultilinearKzg setup / commit / open
+@pytest.fixture(scope="module")
+def srs6(hl, ctx):
+    rng = random.Random(42)
+    ss = rand_fr(rng, 6)
+    return ss, o_kzg.setup(ss), hl.MultilinearKzg.setup(ctx, ss)
+
+
+def test_setup_matches_oracle(srs6):
+    ss, opp, pp = srs6
+    assert pp.num_vars == 6
+    assert pp.eqs() == opp.eqs
+
+
+def test_srs_upload_roundtrip(hl, ctx, srs6):
+    _, opp, _ = srs6
+    pp2 = hl.MultilinearKzg.upload(ctx, opp.eqs[:4])
+    assert pp2.num_vars == 3 and pp2.eqs() == opp.eqs[:4]
+
+
+@pytest.mark.parametrize("num_vars", [1, 3, 6])
+def test_commit_open(hl, ctx, srs6, num_vars):
+    """run_commit_open_verify (pcs/multilinear.rs:293-332)"""
+    _, opp, pp = srs6
+    rng = random.Random(num_vars)
+    evals = rand_fr(rng, 1 << num_vars)
+    poly = hl.MultilinearPolynomial.new(ctx, evals)
+    t, ot = hl.Keccak256Transcript(), OT()
+    comm = hl.MultilinearKzg.commit(pp, poly)
+    assert comm == o_kzg.commit(opp, evals)
+    t.write_commitment(comm), ot.write_commitment(comm)
+    point = t.squeeze_challenges(num_vars)
+    assert point == ot.squeeze_challenges(num_vars)
+    ev = poly.evaluate(point)
+    t.write_field_element(ev), ot.write_field_element(ev)
+    assert hl.MultilinearKzg.open(pp, poly, point, t) == ev == o_kzg.open_(opp.trim(num_vars), evals, point, ot)
+    proof = t.into_proof()
+    assert proof == ot.into_proof()
+    vt = OT(proof)
+    o_kzg.verify(opp.trim(num_vars), vt.read_commitment(), vt.squeeze_challenges(num_vars), vt.read_field_element(), vt)
+
+
+def test_commit_too_many_variates(hl, ctx, srs6):
+    _, _, pp = srs6
+    poly = hl.MultilinearPolynomial.new(ctx, [1] * 128)
+    with pytest.raises(hl.InvalidPcsParam):
+        hl.MultilinearKzg.commit(pp, poly)
+
+
+def test_open_identity_quotient_is_transcript_error(hl, ctx, srs6):
+    """A constant poly has zero quotients -> identity commitment -> Error::Transcript (transcript.rs:172-179)."""
+    _, _, pp = srs6
+    poly = hl.MultilinearPolynomial.new(ctx, [5] * 8)
+    with pytest.raises(hl.TranscriptError):
+        hl.MultilinearKzg.open(pp, poly, [1, 2, 3], hl.Keccak256Transcript())
+
+
+@pytest.mark.parametrize("num_vars", [2, 5])
+def test_batch_commit_open(hl, ctx, srs6, num_vars):
+    """run_batch_commit_open_verify (pcs/multilinear.rs:334-406)"""
+    _, opp, pp = srs6
+    rng = random.Random(100 + num_vars)
+    batch, num_points = 8, 4
+    pairs = [(0, p) for p in range(num_points)] + [(p, 0) for p in range(batch)]
+    pairs += [(rng.randrange(batch), rng.randrange(num_points)) for _ in range(batch)]
+    pairs = list(dict.fromkeys(pairs))
+    evals = [rand_fr(rng, 1 << num_vars) for _ in range(batch)]
+    polys = [hl.MultilinearPolynomial.new(ctx, e) for e in evals]
+    t, ot = hl.Keccak256Transcript(), OT()
+    comms = hl.MultilinearKzg.batch_commit_and_write(pp, polys, t)
+    assert comms == o_kzg.batch_commit_and_write(opp, evals, ot)
+    points = [t.squeeze_challenges(num_vars) for _ in range(num_points)]
+    assert points == [ot.squeeze_challenges(num_vars) for _ in range(num_points)]
+    vals = [evaluate(evals[p], points[q]) for p, q in pairs]
+    t.write_field_elements(vals), ot.write_field_elements(vals)
+    hl.MultilinearKzg.batch_open(pp, num_vars, polys, points, [hl.Evaluation(p, q, v) for (p, q), v in zip(pairs, vals)], t)
+    o_kzg.batch_open(opp.trim(num_vars), num_vars, evals, points,
+                     [o_kzg.Evaluation(p, q, v) for (p, q), v in zip(pairs, vals)], ot)
+    proof = t.into_proof()
+    assert proof == ot.into_proof()
+    vt = OT(proof)
+    vcomms = vt.read_commitments(batch)
+    vpoints = [vt.squeeze_challenges(num_vars) for _ in range(num_points)]
+    vevals = [o_kzg.Evaluation(p, q, v) for (p, q), v in zip(pairs, vt.read_field_elements(len(pairs)))]
+    o_kzg.batch_verify(opp.trim(num_vars), num_vars, vcomms, vpoints, vevals, vt)
+
+
+# ------------------------------------------------------------------ a5-a8: ClassicSumCheck
+@pytest.mark.parametrize("num_vars", [1, 2, 4, 9])
+def test_sum_check_evaluations(hl, ctx, num_vars):
+    """eq * (c0*p0*p1 + c1*p2 + c2*p0*p1*p2), degree 4, vs oracle bytes; then verify (sum_check.rs:140-177)."""
+    rng = random.Random(20 + num_vars)
+    tables = [rand_fr(rng, 1 << num_vars) for _ in range(3)]
+    y = rand_fr(rng, num_vars)
+    c = rand_fr(rng, 3)
+    expr = ex.EqXY(0) * (ex.Poly(0) * ex.Poly(1) * c[0] + ex.Poly(2) * c[1] + ex.Poly(0) * ex.Poly(1) * ex.Poly(2) * c[2])
+    eq = eq_xy(y)
+    claim = sum(eq[b] * (c[0] * tables[0][b] * tables[1][b] + c[1] * tables[2][b]
+                         + c[2] * tables[0][b] * tables[1][b] * tables[2][b]) for b in range(1 << num_vars)) % P
+    ot = OT()
+    ox, oev = o_sc.prove(o_sc.EvaluationsProver, num_vars, o_sc.VirtualPolynomial(expr, tables, [], [y]), claim, ot)
+    polys = [hl.MultilinearPolynomial.new(ctx, t) for t in tables]
+    sop = hl.SumOfProducts([(c[0], [0, 1]), (c[1], [2]), (c[2], [0, 1, 2])], global_eq=0)
+    t = hl.Keccak256Transcript()
+    x, ev = hl.ClassicSumCheck.prove(ctx, hl.EvaluationsProver, num_vars, sop, polys, [y], claim, t)
+    assert (x, ev) == (ox, oev)
+    assert t.into_proof() == ot.into_proof()
+    final, vx = o_sc.verify(o_sc.Evaluations, num_vars, 4, claim, OT(t.into_proof()))
+    assert vx == x and final == ex.evaluate_fe(expr, [o_kzg.eq_xy_eval(x, y)], ev, [])
+
+
+@pytest.mark.parametrize("num_vars", [1, 3, 8])
+def test_sum_check_coefficients(hl, ctx, num_vars):
+    """sum_j s_j * eq_j * poly_j (the batch_open expression) through CoefficientsProver."""
+    rng = random.Random(30 + num_vars)
+    tables = [rand_fr(rng, 1 << num_vars) for _ in range(3)]
+    ys = [rand_fr(rng, num_vars) for _ in range(3)]
+    s = rand_fr(rng, 3)
+    expr = ex.sum_exprs(ex.EqXY(j) * ex.Poly(j) * s[j] for j in range(3))
+    claim = sum(s[j] * evaluate(tables[j], ys[j]) for j in range(3)) % P
+    ot = OT()
+    ox, oev = o_sc.prove(o_sc.CoefficientsProver, num_vars, o_sc.VirtualPolynomial(expr, tables, [], ys), claim, ot)
+    polys = [hl.MultilinearPolynomial.new(ctx, t) for t in tables]
+    sop = hl.SumOfProducts([(s[j], [3 + j, j]) for j in range(3)])
+    t = hl.Keccak256Transcript()
+    x, ev = hl.ClassicSumCheck.prove(ctx, hl.CoefficientsProver, num_vars, sop, polys, ys, claim, t)
+    assert (x, ev) == (ox, oev) and t.into_proof() == ot.into_proof()
+
+
+def test_sum_check_rejects_bad_shapes(hl, ctx):
+    poly = hl.MultilinearPolynomial.new(ctx, [1, 2])
+    with pytest.raises(hl.ArgumentError):  # CoefficientsProver: degree != 2 is unimplemented!() (coeff.rs:143)
+        hl.ClassicSumCheck.prove(ctx, hl.CoefficientsProver, 1, hl.SumOfProducts([(1, [0, 0, 0])]), [poly], [], 0,
+                                 hl.Keccak256Transcript())
+    with pytest.raises(hl.ArgumentError):  # num_vars == 0 (classic.rs:42 assert)
+        hl.ClassicSumCheck.prove(ctx, hl.EvaluationsProver, 0, hl.SumOfProducts([(1, [0, 0])]), [poly], [], 0,
+                                 hl.Keccak256Transcript())
+
+
+# ------------------------------------------------------------------ a9: GKR
+@pytest.mark.parametrize("num_vars", [1, 2, 3, 7])
+def test_fractional_sum_check(hl, ctx, num_vars):
+    """fractional_sum_check.rs:327-370: 3 batched fractions, claims None."""
+    rng = random.Random(40 + num_vars)
+    B = 3
+    tabs = [rand_fr(rng, 1 << num_vars) for _ in range(2 * B)]
+    ot = OT()
+    want = o_gkr.prove_fractional_sum_check([None] * B, [None] * B, tabs[:B], tabs[B:], ot)
+    polys = [hl.MultilinearPolynomial.new(ctx, t) for t in tabs]
+    t = hl.Keccak256Transcript()
+    got = hl.prove_fractional_sum_check(ctx, [None] * B, [None] * B, polys[:B], polys[B:], t)
+    assert got == want and t.into_proof() == ot.into_proof()
+    p_xs, q_xs, x = o_gkr.verify_fractional_sum_check(num_vars, [None] * B, [None] * B, OT(t.into_proof()))
+    for tab, e in zip(tabs, p_xs + q_xs):
+        assert evaluate(tab, x) == e
+
+
+def test_fractional_sum_check_claimed_roots(hl, ctx):
+    """Some(claim) roots are hashed, not written (fractional_sum_check.rs:127-142)."""
+    rng = random.Random(47)
+    tabs = [rand_fr(rng, 8) for _ in range(2)]
+    ot = OT()
+    o_gkr.prove_fractional_sum_check([7], [None], tabs[:1], tabs[1:], ot)
+    polys = [hl.MultilinearPolynomial.new(ctx, t) for t in tabs]
+    t = hl.Keccak256Transcript()
+    hl.prove_fractional_sum_check(ctx, [7], [None], polys[:1], polys[1:], t)
+    assert t.into_proof() == ot.into_proof()
+
+
+@pytest.mark.parametrize("sizes", [[2], [2, 2], [4, 8, 2], [64, 8, 64, 8], [256, 256]])
+def test_grand_product(hl, ctx, sizes):
+    rng = random.Random(sum(sizes))
+    vs = [[rng.randrange(1, P) for _ in range(s)] for s in sizes]
+    ot = OT()
+    want = o_gkr.prove_grand_product(vs, ot)
+    t = hl.Keccak256Transcript()
+    got = hl.prove_grand_product(ctx, [hl.MultilinearPolynomial.new(ctx, v) for v in vs], t)
+    assert got[0] == want[0] and [(c, list(p)) for c, p in got[1]] == [(c, list(p)) for c, p in want[1]]
+    assert t.into_proof() == ot.into_proof()
+    o_gkr.verify_grand_product([s.bit_length() - 1 for s in sizes], OT(t.into_proof()))
+
+
+# ------------------------------------------------------------------ a': Lasso
+LASSO_CASES = [
+    ("range", 2, 3, 4), ("range", 2, 4, 6), ("range", 1, 2, 3), ("range", 3, 2, 5),
+    ("and", 2, 4, 5), ("xor", 3, 2, 3), ("and", 4, 4, 6), ("range", 2, 6, 5),
+]
+
+
+def _spec(kind, c, l):
+    if kind == "range":
+        return o_lasso.range_table(c, l)
+    return o_lasso.bitwise_table(o_lasso.SUBTABLE_AND if kind == "and" else o_lasso.SUBTABLE_XOR, c, l)
+
+
+def _table(hl, kind, c, l):
+    if kind == "range":
+        return hl.LassoTable.range(c, l)
+    return hl.LassoTable.bitwise(hl.SUBTABLE_AND if kind == "and" else hl.SUBTABLE_XOR, c, l)
+
+
+@pytest.mark.parametrize("kind,c,l,n", LASSO_CASES)
+def test_lasso_proof_bytes(hl, ctx, srs6, kind, c, l, n):
+    _, opp, pp = srs6
+    rng = random.Random(zlib.crc32(repr((kind, c, l, n)).encode()))
+    spec = _spec(kind, c, l)
+    dims = [[rng.randrange(1 << l) for _ in range(1 << n)] for _ in range(c)]
+    ot = OT()
+    o_lasso.prove(opp, spec, dims, ot)
+    d_dims = [ctx.upload(array.array("I", d).tobytes()) for d in dims]
+    t = hl.Keccak256Transcript()
+    hl.lasso_prove(pp, _table(hl, kind, c, l), n, d_dims, t)
+    proof = t.into_proof()
+    assert proof == ot.into_proof()
+    o_lasso.verify(opp, spec, n, OT(proof))
+
+
+def test_lasso_all_distinct_lookups_is_transcript_error(hl, ctx, srs6):
+    """read_ts == 0 everywhere commits to the identity, which the reference transcript rejects
+    (transcript.rs:172-179); oracle and HIP path fail the same way."""
+    _, opp, pp = srs6
+    dims = [list(range(8)), list(range(7, -1, -1))]
+    with pytest.raises(Exception) as e:
+        o_lasso.prove(opp, o_lasso.range_table(2, 3), dims, OT())
+    assert "Invalid elliptic curve point" in str(e.value)
+    d_dims = [ctx.upload(array.array("I", d).tobytes()) for d in dims]
+    with pytest.raises(hl.TranscriptError):
+        hl.lasso_prove(pp, hl.LassoTable.range(2, 3), 3, d_dims, hl.Keccak256Transcript())
+
+
+def test_lasso_rejects_bad_arguments(hl, ctx, srs6):
+    _, _, pp = srs6
+    d = [ctx.upload(bytes(4 * 16)) for _ in range(2)]
+    with pytest.raises(hl.InvalidPcsParam):  # more variables than the SRS supports
+        hl.lasso_prove(pp, hl.LassoTable.range(2, 7), 4, d, hl.Keccak256Transcript())
+    with pytest.raises(hl.ArgumentError):
+        hl.lasso_prove(pp, hl.LassoTable.range(2, 4), 4, d[:1], hl.Keccak256Transcript())
+    with pytest.raises(hl.ArgumentError):  # AND subtable needs an even chunk width
+        hl.lasso_prove(pp, hl.LassoTable.bitwise(hl.SUBTABLE_AND, 2, 3), 4, d, hl.Keccak256Transcript())
