@@ -95,6 +95,10 @@ void k_fix_var(Ctx&, const Fr* in, size_t n_in, const Fr& x, Fr* out);
 // binds `count` tables of n_in entries each in one launch
 void k_fix_var_multi(Ctx&, const Fr* const* in, Fr* const* out, size_t count, size_t n_in, const Fr& x);
 void k_eq_xy(Ctx&, const Fr* y, size_t num_vars, Fr* out);  // y: host array
+// out_host (pinned) [i] = in[i][0] + (in[i][1] - in[i][0]) * x ; synchronises
+void k_bind_first(Ctx&, const Fr* const* in, size_t count, const Fr& x, Fr* out_host);
+// out_host (pinned) [i*k + j] = in[i][j], j < k ; synchronises
+void k_gather_heads(Ctx&, const Fr* const* in, size_t count, int k, Fr* out_host);
 void k_lincomb(Ctx&, const Fr* const* polys, const Fr* w, size_t count, size_t n, Fr* out);
 // out[i] = <polys[i], weights>, i < count ; result on host
 void k_inner_products(Ctx&, const Fr* const* polys, size_t count, const Fr* weights, size_t n, Fr* out_host);

@@ -143,6 +143,40 @@ void k_fix_var_multi(Ctx& c, const Fr* const* in, Fr* const* out, size_t count, 
   }
 }
 
+// last bind of a sum-check (2 -> 1 entries) for `count` tables, results straight to (pinned) host memory
+struct FirstPack {
+  const Fr* in[SC_MAX_TABLES];
+};
+__global__ void bind_first_kernel(FirstPack p, int count, Fr x, Fr* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) {
+    Fr e0 = p.in[i][0], e1 = p.in[i][1];
+    out[i] = add(mul(sub(e1, e0), x), e0);
+  }
+}
+void k_bind_first(Ctx& c, const Fr* const* in, size_t count, const Fr& x, Fr* out_host) {
+  LH_REQUIRE(count <= (size_t)SC_MAX_TABLES, LH_ERR_ARG, "bind_first: too many tables");
+  if (!count) return;
+  FirstPack p;
+  for (size_t i = 0; i < count; i++) p.in[i] = in[i];
+  hipLaunchKernelGGL(bind_first_kernel, dim3(1), dim3(64), 0, c.stream, p, (int)count, x, out_host);
+  c.sync();
+}
+// out[i] = first `k` entries of each of `count` tables, to (pinned) host memory
+__global__ void gather_heads_kernel(FirstPack p, int count, int k, Fr* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count * k) out[i] = p.in[i / k][i % k];
+}
+void k_gather_heads(Ctx& c, const Fr* const* in, size_t count, int k, Fr* out_host) {
+  LH_REQUIRE(count <= (size_t)SC_MAX_TABLES, LH_ERR_ARG, "gather_heads: too many tables");
+  if (!count) return;
+  FirstPack p;
+  for (size_t i = 0; i < count; i++) p.in[i] = in[i];
+  int total = (int)count * k;
+  hipLaunchKernelGGL(gather_heads_kernel, dim3((total + 63) / 64), dim3(64), 0, c.stream, p, (int)count, k, out_host);
+  c.sync();
+}
+
 // ------------------------------------------------------------------ eq_xy
 // reference poly/multilinear.rs:91-127.  Level expansion: next[2k+1] = cur[k]*y, next[2k] = cur[k]-next[2k+1].
 // In place from the top: processing k descending inside a level would race across blocks, so each

@@ -40,19 +40,27 @@ __device__ __forceinline__ void load_pair(const Fr* __restrict__ in, Fr* __restr
   }
 }
 
+// `tp` (term parallelism) is 1 or num_terms: in the late, small rounds one thread per (pair, term)
+// keeps the dependent chain of a thread at one term (~15 field multiplications) instead of the
+// whole expression; the eq factor is linear, so it is applied per term before the reduction.
 template <int D, bool BIND>
-__global__ __launch_bounds__(256) void sc_round_kernel(ScArgs a, size_t size, Fr* __restrict__ partials) {
+__global__ __launch_bounds__(256) void sc_round_kernel(ScArgs a, size_t size, uint32_t tp,
+                                                       Fr* __restrict__ partials) {
   __shared__ Fr lds[4];
   const ScRound& rd = a.rd;
   Fr acc[D];
 #pragma unroll
   for (int x = 0; x < D; x++) acc[x] = Fr::zero();
 
-  for (size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x; b < size; b += (size_t)gridDim.x * blockDim.x) {
+  const size_t items = size * tp;
+  for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < items; w += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = tp == 1 ? w : w / tp;
+    const uint32_t m_lo = tp == 1 ? 0u : (uint32_t)(w % tp);
+    const uint32_t m_hi = tp == 1 ? rd.num_terms : m_lo + 1u;
     Fr s[D];
 #pragma unroll
     for (int x = 0; x < D; x++) s[x] = Fr::zero();
-    for (uint32_t m = 0; m < rd.num_terms; m++) {
+    for (uint32_t m = m_lo; m < m_hi; m++) {
       Fr pm[D];
       const int nf = rd.nfac[m];
       for (int k = 0; k < nf; k++) {
@@ -84,7 +92,7 @@ __global__ __launch_bounds__(256) void sc_round_kernel(ScArgs a, size_t size, Fr
     }
     if (rd.global_eq >= 0) {
       Fr v0, v1;
-      load_pair<BIND>(rd.in[rd.global_eq], rd.out[rd.global_eq], b, rd.r, true, v0, v1);
+      load_pair<BIND>(rd.in[rd.global_eq], rd.out[rd.global_eq], b, rd.r, m_lo == 0, v0, v1);
       Fr step = sub(v1, v0);
       Fr val = v1;
       s[0] = mul(s[0], val);
@@ -115,11 +123,11 @@ __global__ void sc_reduce_kernel(const Fr* __restrict__ partials, int blocks, in
 }
 
 template <int D>
-static void launch_round(Ctx& c, const ScArgs& a, bool bind, size_t size, unsigned grid, Fr* partials) {
+static void launch_round(Ctx& c, const ScArgs& a, bool bind, size_t size, uint32_t tp, unsigned grid, Fr* partials) {
   if (bind)
-    hipLaunchKernelGGL((sc_round_kernel<D, true>), dim3(grid), dim3(256), 0, c.stream, a, size, partials);
+    hipLaunchKernelGGL((sc_round_kernel<D, true>), dim3(grid), dim3(256), 0, c.stream, a, size, tp, partials);
   else
-    hipLaunchKernelGGL((sc_round_kernel<D, false>), dim3(grid), dim3(256), 0, c.stream, a, size, partials);
+    hipLaunchKernelGGL((sc_round_kernel<D, false>), dim3(grid), dim3(256), 0, c.stream, a, size, tp, partials);
 }
 
 void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, Fr* evals_host) {
@@ -135,22 +143,24 @@ void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, F
       a.store[m][k] = seen[t] ? 0 : 1;
       seen[t] = true;
     }
+  // small rounds: one work item per (pair, term); a single workgroup writes the sums straight into the
+  // pinned host buffer (no second kernel, no copy): the round trip is launch + kernel + one stream sync.
+  const uint32_t tp = (rd.num_terms > 1 && size * rd.num_terms <= ((size_t)1 << 16)) ? rd.num_terms : 1u;
+  const size_t items = size * tp;
   ArenaScope scope(c.arena);
-  size_t g = (size + 255) / 256;
+  size_t g = (items + 255) / 256;
   size_t cap = (size_t)c.num_cus * 4;
   if (g > cap) g = cap;
-  Fr* partials = c.arena.alloc_n<Fr>(g * degree);
-  Fr* d_out = c.arena.alloc_n<Fr>(degree);
+  Fr* partials = g == 1 ? evals_host : c.arena.alloc_n<Fr>(g * degree);
   switch (degree) {
-    case 1: launch_round<1>(c, a, bind, size, (unsigned)g, partials); break;
-    case 2: launch_round<2>(c, a, bind, size, (unsigned)g, partials); break;
-    case 3: launch_round<3>(c, a, bind, size, (unsigned)g, partials); break;
-    case 4: launch_round<4>(c, a, bind, size, (unsigned)g, partials); break;
-    case 5: launch_round<5>(c, a, bind, size, (unsigned)g, partials); break;
-    default: launch_round<6>(c, a, bind, size, (unsigned)g, partials); break;
+    case 1: launch_round<1>(c, a, bind, size, tp, (unsigned)g, partials); break;
+    case 2: launch_round<2>(c, a, bind, size, tp, (unsigned)g, partials); break;
+    case 3: launch_round<3>(c, a, bind, size, tp, (unsigned)g, partials); break;
+    case 4: launch_round<4>(c, a, bind, size, tp, (unsigned)g, partials); break;
+    case 5: launch_round<5>(c, a, bind, size, tp, (unsigned)g, partials); break;
+    default: launch_round<6>(c, a, bind, size, tp, (unsigned)g, partials); break;
   }
-  hipLaunchKernelGGL(sc_reduce_kernel, dim3(1), dim3(256), 0, c.stream, partials, (int)g, degree, d_out);
-  LH_HIP(hipMemcpyAsync(evals_host, d_out, degree * sizeof(Fr), hipMemcpyDeviceToHost, c.stream));
+  if (g > 1) hipLaunchKernelGGL(sc_reduce_kernel, dim3(1), dim3(256), 0, c.stream, partials, (int)g, degree, evals_host);
   c.sync();
 }
 

@@ -38,6 +38,8 @@ struct MsmJobDev {
   uint32_t n;
   uint32_t c, W;        // window bits, number of windows
   uint32_t key_base;    // first bucket key of this job
+  uint32_t cnt_base;    // first histogram slot of this job (bucket keys are replicated 2^rep_log times)
+  uint32_t rep_log;     // log2 of the histogram replication (spreads atomics of skewed columns)
   uint32_t seg_base;    // first reduce-segment of this job
   uint32_t seg_per_win; // segments per window
   uint32_t seg_size;    // buckets per segment
@@ -49,23 +51,70 @@ struct MsmPlanDev {
 };
 
 // ------------------------------------------------------------------ 1/3: digits, histogram, scatter
+// Wave-aggregated atomic increment: lanes that hit the same slot elect a leader that adds the group
+// size once and hands out consecutive ranks.  Lasso's committed columns are small-valued (read_ts is
+// ~Poisson, final_cts/dim/E take few values), so whole waves collide on a handful of slots; a few
+// rounds of aggregation peel off the popular slots, the rest falls back to one atomic per lane.
+constexpr int AGG_ROUNDS = 6;
+__device__ __forceinline__ uint32_t wave_agg_inc(uint32_t* arr, uint32_t slot, bool active) {
+  const int lane = __lane_id();
+  unsigned long long todo = __ballot(active);
+  uint32_t res = 0;
+#pragma unroll 1
+  for (int round = 0; round < AGG_ROUNDS && todo; round++) {
+    const int leader = __ffsll((unsigned long long)todo) - 1;
+    const uint32_t k = __shfl(slot, leader);
+    const bool mine = active && slot == k;
+    const unsigned long long same = __ballot(mine);
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&arr[k], (uint32_t)__popcll(same));
+    base = __shfl(base, leader);
+    if (mine) {
+      res = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+      active = false;
+    }
+    todo &= ~same;
+  }
+  if (active) res = atomicAdd(&arr[slot], 1u);
+  return res;
+}
+
+template <bool SCATTER>
+__device__ __forceinline__ void emit_digit(const MsmJobDev& jb, uint32_t w, uint32_t d, uint32_t rep, uint32_t i,
+                                           uint32_t* __restrict__ counts_or_cursor, uint32_t* __restrict__ sorted_key,
+                                           uint32_t* __restrict__ sorted_idx) {
+  const uint32_t local = (w << jb.c) + d;
+  const uint32_t slot = jb.cnt_base + (local << jb.rep_log) + rep;
+  const uint32_t pos = wave_agg_inc(counts_or_cursor, slot, d != 0);
+  if (SCATTER && d != 0) {
+    sorted_key[pos] = jb.key_base + local;
+    sorted_idx[pos] = i;
+  }
+}
+
 template <bool SCATTER>
 __global__ void msm_digits_kernel(MsmPlanDev plan, uint32_t* __restrict__ counts_or_cursor,
                                   uint32_t* __restrict__ sorted_key, uint32_t* __restrict__ sorted_idx) {
   const MsmJobDev& jb = plan.job[blockIdx.y];
   const uint32_t c = jb.c, mask = (1u << c) - 1u;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < jb.n; i += (size_t)gridDim.x * blockDim.x) {
+  const uint32_t rep = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & ((1u << jb.rep_log) - 1u);
+  // every lane of a wave runs the same number of iterations (digits are emitted convergently)
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t iters = (jb.n + stride - 1) / stride;
+  for (size_t it = 0; it < iters; it++) {
+    const size_t i = it * stride + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < jb.n;
     uint32_t limb[8];
-    int nlimbs;
+#pragma unroll
+    for (int k = 0; k < 8; k++) limb[k] = 0;
     if (jb.is_u32) {
-      limb[0] = ((const uint32_t*)jb.scalars)[i];
-      nlimbs = 1;
-    } else {
+      if (live) limb[0] = ((const uint32_t*)jb.scalars)[i];
+    } else if (live) {
       Fr s = from_mont(((const Fr*)jb.scalars)[i]);
 #pragma unroll
       for (int k = 0; k < 8; k++) limb[k] = s.l[k];
-      nlimbs = 8;
     }
+    const int nlimbs = jb.is_u32 ? 1 : 8;
     uint64_t buf = 0;
     int have = 0;
     uint32_t w = 0;
@@ -78,33 +127,13 @@ __global__ void msm_digits_kernel(MsmPlanDev plan, uint32_t* __restrict__ counts
           uint32_t d = (uint32_t)buf & mask;
           buf >>= c;
           have -= c;
-          if (d) {
-            uint32_t key = jb.key_base + (w << c) + d;
-            if (SCATTER) {
-              uint32_t pos = atomicAdd(&counts_or_cursor[key], 1u);
-              sorted_key[pos] = key;
-              sorted_idx[pos] = (uint32_t)i;
-            } else {
-              atomicAdd(&counts_or_cursor[key], 1u);
-            }
-          }
+          emit_digit<SCATTER>(jb, w, d, rep, (uint32_t)i, counts_or_cursor, sorted_key, sorted_idx);
           w++;
         }
       }
     }
-    if (w < jb.W) {  // top, partial window
-      uint32_t d = (uint32_t)buf & mask;
-      if (d) {
-        uint32_t key = jb.key_base + (w << c) + d;
-        if (SCATTER) {
-          uint32_t pos = atomicAdd(&counts_or_cursor[key], 1u);
-          sorted_key[pos] = key;
-          sorted_idx[pos] = (uint32_t)i;
-        } else {
-          atomicAdd(&counts_or_cursor[key], 1u);
-        }
-      }
-    }
+    if (w < jb.W)  // top, partial window
+      emit_digit<SCATTER>(jb, w, (uint32_t)buf & mask, rep, (uint32_t)i, counts_or_cursor, sorted_key, sorted_idx);
   }
 }
 
@@ -189,7 +218,8 @@ __global__ __launch_bounds__(128) void msm_accumulate0_kernel(MsmPlanDev plan, c
                                                               const uint32_t* __restrict__ sorted_idx, uint32_t K,
                                                               G1Xyzz* __restrict__ buckets,
                                                               uint32_t* __restrict__ cont_key,
-                                                              G1Xyzz* __restrict__ cont_pt, size_t nchunks) {
+                                                              G1Xyzz* __restrict__ cont_pt, size_t nchunks,
+                                                              uint32_t* __restrict__ cont_count) {
   const size_t total = *total_ptr;
   for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < nchunks; t += (size_t)gridDim.x * blockDim.x) {
     size_t p0 = t * K, p1 = p0 + K < total ? p0 + K : total;
@@ -223,6 +253,7 @@ __global__ __launch_bounds__(128) void msm_accumulate0_kernel(MsmPlanDev plan, c
       }
     }
     cont_key[t] = ck;
+    if (ck != SENTINEL) atomicAdd(cont_count, 1u);  // per-wave combined by the compiler
   }
 }
 
@@ -231,7 +262,10 @@ __global__ __launch_bounds__(128) void msm_accumulate_n_kernel(const uint32_t* _
                                                                const G1Xyzz* __restrict__ in_pt, size_t n_in,
                                                                uint32_t K, G1Xyzz* __restrict__ buckets,
                                                                uint32_t* __restrict__ out_key,
-                                                               G1Xyzz* __restrict__ out_pt, size_t nchunks) {
+                                                               G1Xyzz* __restrict__ out_pt, size_t nchunks,
+                                                               const uint32_t* __restrict__ in_count,
+                                                               uint32_t* __restrict__ out_count) {
+  if (*in_count == 0) return;  // nothing continued into this level (out_count stays 0 for the next one)
   for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < nchunks; t += (size_t)gridDim.x * blockDim.x) {
     size_t p0 = t * K, p1 = p0 + K < n_in ? p0 + K : n_in;
     uint32_t ck = SENTINEL;
@@ -266,6 +300,7 @@ __global__ __launch_bounds__(128) void msm_accumulate_n_kernel(const uint32_t* _
       }
     }
     out_key[t] = ck;
+    if (ck != SENTINEL) atomicAdd(out_count, 1u);
   }
 }
 
@@ -342,7 +377,7 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
     size_t nj = std::min(num_jobs - base, (size_t)MSM_MAX_JOBS);
     MsmPlanDev plan;
     plan.num_jobs = (int)nj;
-    uint32_t key = 0, seg = 0, win = 0;
+    uint32_t key = 0, seg = 0, win = 0, cnt = 0;
     size_t max_entries = 0, max_n = 0;
     for (size_t j = 0; j < nj; j++) {
       const MsmJob& in = jobs[base + j];
@@ -356,17 +391,20 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
       jd.c = pick_window(in.n ? in.n : 1, bits);
       jd.W = (bits + jd.c - 1) / jd.c;
       jd.key_base = key;
+      jd.cnt_base = cnt;
+      jd.rep_log = in.scalars_u32 ? 3 : 0;
       jd.seg_size = std::min<uint32_t>(16u, 1u << jd.c);
       jd.seg_per_win = (1u << jd.c) / jd.seg_size;
       jd.seg_base = seg;
       jd.win_base = win;
       key += jd.W << jd.c;
+      cnt += (jd.W << jd.c) << jd.rep_log;
       seg += jd.W * jd.seg_per_win;
       win += jd.W;
       max_entries += (size_t)jd.n * jd.W;
       max_n = std::max(max_n, in.n);
     }
-    const size_t nbuckets = key, nsegs = seg, nwins = win;
+    const size_t nbuckets = key, nsegs = seg, nwins = win, ncounts = cnt;
     std::vector<G1Xyzz> wins(nwins);
     if (max_entries == 0) {
       for (size_t j = 0; j < nj; j++) memset(&out_host[base + j], 0, sizeof(G1Affine));
@@ -375,8 +413,8 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
     LH_REQUIRE(max_entries < ((size_t)1 << 32), LH_ERR_ARG, "msm: batch too large for 32-bit entry indices");
     {
       ArenaScope scope(c.arena);
-      uint32_t* counts = c.arena.alloc_n<uint32_t>(nbuckets + 1);
-      size_t ntiles = (nbuckets + 1 + SCAN_TILE - 1) / SCAN_TILE;
+      uint32_t* counts = c.arena.alloc_n<uint32_t>(ncounts + 1);
+      size_t ntiles = (ncounts + 1 + SCAN_TILE - 1) / SCAN_TILE;
       uint32_t* tile_sums = c.arena.alloc_n<uint32_t>(ntiles);
       uint32_t* total = c.arena.alloc_n<uint32_t>(1);
       uint32_t* skey = c.arena.alloc_n<uint32_t>(max_entries);
@@ -385,14 +423,16 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
       G1Xyzz* seg_out = c.arena.alloc_n<G1Xyzz>(nsegs);
       G1Xyzz* win_out = c.arena.alloc_n<G1Xyzz>(nwins);
 
-      LH_HIP(hipMemsetAsync(counts, 0, (nbuckets + 1) * sizeof(uint32_t), c.stream));
+      uint32_t* lvl_cnt = c.arena.alloc_n<uint32_t>(64);
+      LH_HIP(hipMemsetAsync(lvl_cnt, 0, 64 * sizeof(uint32_t), c.stream));
+      LH_HIP(hipMemsetAsync(counts, 0, (ncounts + 1) * sizeof(uint32_t), c.stream));
       LH_HIP(hipMemsetAsync(buckets, 0, nbuckets * sizeof(G1Xyzz), c.stream));
       dim3 g((unsigned)std::min<size_t>((max_n + 255) / 256, 2048), (unsigned)nj);
       hipLaunchKernelGGL(msm_digits_kernel<false>, g, dim3(256), 0, c.stream, plan, counts, nullptr, nullptr);
-      hipLaunchKernelGGL(scan_tile_sums_kernel, dim3((unsigned)ntiles), dim3(256), 0, c.stream, counts, nbuckets + 1,
+      hipLaunchKernelGGL(scan_tile_sums_kernel, dim3((unsigned)ntiles), dim3(256), 0, c.stream, counts, ncounts + 1,
                          tile_sums);
       hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(256), 0, c.stream, tile_sums, ntiles, total);
-      hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)ntiles), dim3(256), 0, c.stream, counts, nbuckets + 1,
+      hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)ntiles), dim3(256), 0, c.stream, counts, ncounts + 1,
                          tile_sums);
       hipLaunchKernelGGL(msm_digits_kernel<true>, g, dim3(256), 0, c.stream, plan, counts, skey, sidx);
 
@@ -402,15 +442,18 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
       uint32_t* ckey = c.arena.alloc_n<uint32_t>(nchunks);
       G1Xyzz* cpt = c.arena.alloc_n<G1Xyzz>(nchunks);
       hipLaunchKernelGGL(msm_accumulate0_kernel, dim3((unsigned)std::min<size_t>((nchunks + 127) / 128, 1 << 16)),
-                         dim3(128), 0, c.stream, plan, total, skey, sidx, K, buckets, ckey, cpt, nchunks);
+                         dim3(128), 0, c.stream, plan, total, skey, sidx, K, buckets, ckey, cpt, nchunks, lvl_cnt);
       size_t n_in = nchunks;
       const uint32_t K2 = 8;
+      int lvl = 0;
       while (true) {
         size_t nc = (n_in + K2 - 1) / K2;
         uint32_t* okey = c.arena.alloc_n<uint32_t>(nc);
         G1Xyzz* opt = c.arena.alloc_n<G1Xyzz>(nc);
         hipLaunchKernelGGL(msm_accumulate_n_kernel, dim3((unsigned)std::min<size_t>((nc + 127) / 128, 1 << 16)),
-                           dim3(128), 0, c.stream, ckey, cpt, n_in, K2, buckets, okey, opt, nc);
+                           dim3(128), 0, c.stream, ckey, cpt, n_in, K2, buckets, okey, opt, nc, lvl_cnt + lvl,
+                           lvl_cnt + lvl + 1);
+        lvl++;
         if (n_in <= K2) break;  // a single chunk: no continuation can remain
         ckey = okey;
         cpt = opt;

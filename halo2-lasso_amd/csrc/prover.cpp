@@ -122,7 +122,7 @@ SumCheckResult sum_check_prove(Ctx& c, int prover_kind, size_t num_vars, const l
     bufA[i] = c.arena.alloc_n<Fr>(std::max<size_t>(n >> 1, 1));
     bufB[i] = c.arena.alloc_n<Fr>(std::max<size_t>(n >> 2, 1));
   }
-  Fr* evals_host = (Fr*)c.pin(16 * sizeof(Fr));
+  Fr* evals_host = (Fr*)c.pin((16 + SC_MAX_TABLES) * sizeof(Fr));
   const HFr inv2 = HFr::from_u64(2).inv();
 
   SumCheckResult res;
@@ -168,17 +168,11 @@ SumCheckResult sum_check_prove(Ctx& c, int prover_kind, size_t num_vars, const l
     r_prev = r;
   }
   // into_evals: last bind (2 -> 1 entries) of every poly
-  {
-    std::vector<Fr*>& dst = (num_vars & 1) ? bufA : bufB;
-    if (num_polys) {
-      k_fix_var_multi(c, cur.data(), dst.data(), num_polys, 2, dev(r_prev));
-      Fr* stage = c.arena.alloc_n<Fr>(num_polys);
-      for (size_t i = 0; i < num_polys; i++)
-        LH_HIP(hipMemcpyAsync(stage + i, dst[i], sizeof(Fr), hipMemcpyDeviceToDevice, c.stream));
-      res.evals.resize(num_polys);
-      LH_HIP(hipMemcpyAsync(res.evals.data(), stage, num_polys * sizeof(Fr), hipMemcpyDeviceToHost, c.stream));
-      c.sync();
-    }
+  if (num_polys) {
+    Fr* out = (Fr*)c.pin((16 + SC_MAX_TABLES) * sizeof(Fr)) + 16;
+    k_bind_first(c, cur.data(), num_polys, dev(r_prev), out);
+    res.evals.resize(num_polys);
+    memcpy(res.evals.data(), out, num_polys * sizeof(Fr));
   }
   return res;
 }
@@ -217,12 +211,14 @@ FracSumCheckResult prove_fractional_sum_check(Ctx& c, size_t B, size_t num_vars,
   // roots from the top (0-variable) layer (:116-125)
   std::vector<HFr> top(4 * B);
   {
-    Fr* stage = c.arena.alloc_n<Fr>(4 * B);
+    std::vector<const Fr*> heads;
     for (size_t b = 0; b < B; b++) {
-      LH_HIP(hipMemcpyAsync(stage + 4 * b, lp[num_vars - 1][b], 2 * sizeof(Fr), hipMemcpyDeviceToDevice, c.stream));
-      LH_HIP(hipMemcpyAsync(stage + 4 * b + 2, lq[num_vars - 1][b], 2 * sizeof(Fr), hipMemcpyDeviceToDevice, c.stream));
+      heads.push_back(lp[num_vars - 1][b]);
+      heads.push_back(lq[num_vars - 1][b]);
     }
-    download(c, top.data(), stage, 4 * B * sizeof(Fr));
+    Fr* out = (Fr*)c.pin(2 * SC_MAX_TABLES * sizeof(Fr));
+    k_gather_heads(c, heads.data(), heads.size(), 2, out);
+    memcpy(top.data(), out, 4 * B * sizeof(Fr));
   }
   std::vector<HFr> claimed_p(B), claimed_q(B);
   for (size_t b = 0; b < B; b++) {
@@ -320,10 +316,11 @@ GrandProductResult prove_grand_product(Ctx& c, size_t B, const Fr* const* d_leav
   }
   std::vector<HFr> top(2 * B);
   {
-    Fr* stage = c.arena.alloc_n<Fr>(2 * B);
-    for (size_t b = 0; b < B; b++)
-      LH_HIP(hipMemcpyAsync(stage + 2 * b, level[b][0], 2 * sizeof(Fr), hipMemcpyDeviceToDevice, c.stream));
-    download(c, top.data(), stage, 2 * B * sizeof(Fr));
+    std::vector<const Fr*> heads;
+    for (size_t b = 0; b < B; b++) heads.push_back(level[b][0]);
+    Fr* out = (Fr*)c.pin(2 * SC_MAX_TABLES * sizeof(Fr));
+    k_gather_heads(c, heads.data(), heads.size(), 2, out);
+    memcpy(top.data(), out, 2 * B * sizeof(Fr));
   }
   GrandProductResult res;
   res.roots.resize(B);
