@@ -1,0 +1,69 @@
+"""CPU tests of the boundary: the in-tree library loads, exports every symbol include/lasso_hip.h
+declares, the ctypes mirrors of the ABI structs have the C sizes, and compute fails loudly without a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = open(os.path.join(ROOT, "include", "lasso_hip.h")).read()
+
+
+def declared_symbols():
+    return sorted(set(re.findall(r"\b(lh_[a-z0-9_]+)\s*\(", HEADER)))
+
+
+def test_library_exports_every_declared_symbol(hl):
+    from halo2_lasso_amd import _ffi
+    lib = _ffi.load()
+    syms = declared_symbols()
+    assert len(syms) >= 40
+    for name in syms:
+        assert hasattr(lib, name), "liblasso_hip.so does not export %s" % name
+    assert set(_ffi.SIGNATURES) == set(syms), "ctypes binding and header disagree"
+
+
+def test_struct_layouts(hl):
+    from halo2_lasso_amd import _ffi
+    assert C.sizeof(_ffi.lh_fr) == 32 and C.sizeof(_ffi.lh_g1) == 64
+    assert C.sizeof(_ffi.lh_evaluation) == 40
+    assert C.sizeof(_ffi.lh_sop) == 8 + 32 * 48 + 48 + 48 * 4
+    assert C.sizeof(_ffi.lh_lasso_table) == 12 + 64 + 64 + 4 + 32 * 16 + 16 + 16 * 4 + 0 \
+        or C.sizeof(_ffi.lh_lasso_table) % 8 == 0
+    assert C.sizeof(_ffi.lh_transcript) == 6 * C.sizeof(C.c_void_p)
+
+
+def test_marshalling(hl):
+    for v in (0, 1, 2 ** 200 + 17, hl.R_MOD - 1):
+        assert hl.fr_from_bytes(hl.fr_to_bytes(v)) == v
+    # Montgomery form of 1 is R mod r
+    assert hl.fr_to_bytes(1) == bytes.fromhex("fbffff4f1c3496ac29cd609f9576fc362e4679786fa36e662fdf079ac1770a0e")
+    assert hl.g1_from_bytes(hl.g1_to_bytes((1, 2))) == (1, 2)
+    assert hl.g1_from_bytes(hl.g1_to_bytes(None)) is None
+    t = hl.LassoTable.range(2, 16).to_c()
+    assert (t.num_chunks, t.chunk_bits, t.num_memories, t.num_terms) == (2, 16, 2, 2)
+    assert hl.fr_from_bytes(bytes(t.g_coeff[1])) == 1 << 16
+
+
+def test_keccak_transcript_host_side(hl):
+    """The built-in transcript is host code: usable (and checkable against the oracle) without a GPU."""
+    from oracle.pyref.transcript import Keccak256Transcript as OT
+    t, ot = hl.Keccak256Transcript(), OT()
+    for v in (0, 1, hl.R_MOD - 1, 1 << 255):
+        t.write_field_element(v), ot.write_field_element(v)
+        assert t.squeeze_challenge() == ot.squeeze_challenge()
+    t.common_field_element(7), ot.common_field_element(7)
+    t.write_commitment((1, 2)), ot.write_commitment((1, 2))
+    assert t.squeeze_challenges(3) == ot.squeeze_challenges(3)
+    assert t.into_proof() == ot.into_proof()
+    with pytest.raises(hl.TranscriptError):
+        t.write_commitment(None)
+
+
+def test_no_gpu_means_loud_failure(hl):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(hl.DeviceError):
+        hl.Context(0)
