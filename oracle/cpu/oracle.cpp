@@ -1,0 +1,844 @@
+// TEST INFRASTRUCTURE ONLY - multithreaded CPU restatement of the reference prover hot path.
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the
+// product (halo2-lasso_amd/) never links or calls it.  It follows the reference's ALGORITHMS and its
+// chunk-per-thread parallelism (plonkish_backend/src/util/parallel.rs:27-46), so that timing it on
+// the GPU box's host cores is a fair stand-in for the reference's rayon path, which cannot be built
+// here (no Rust toolchain, un-vendored git dependencies: SURVEY.md §8c).  PARITY UNPINNED against the
+// reference's bytes; pinned against oracle/pyref through tests/golden/vectors.json.
+//
+// Restated routines (reference file:line):
+//   Keccak256Transcript            util/transcript.rs:101-238, util/hash.rs:19-21
+//   eq_xy / fix_var / evaluate     poly/multilinear.rs:91-127, 179-189, 599-618
+//   ClassicSumCheck::prove         piop/sum_check/classic.rs:208-240
+//   EvaluationsProver::evals       piop/sum_check/classic/eval.rs:102-131 (evaluate, THEN bind: classic.rs:90-141)
+//   CoefficientsProver::karatsuba  piop/sum_check/classic/coeff.rs:153-202
+//   prove_fractional_sum_check     piop/gkr/fractional_sum_check.rs:62-190
+//   variable_base_msm              util/arithmetic/msm.rs:84-181 (Pippenger per thread chunk, window = floor(ln n))
+//   MultilinearKzg commit/open     pcs/multilinear/kzg.rs:252-302, quotients pcs/multilinear.rs:72-107
+//   additive::batch_open           pcs/multilinear.rs:134-235
+//   Lasso                          no reference code; spec = oracle/pyref/lasso.py
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <functional>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "ff.hpp"
+
+using namespace orc;
+
+// ------------------------------------------------------------------ threads (util/parallel.rs)
+static int g_threads = 0;
+static int num_threads() {
+  if (g_threads <= 0) {
+    g_threads = (int)std::thread::hardware_concurrency();
+    if (g_threads <= 0) g_threads = 1;
+  }
+  return g_threads;
+}
+// parallelize (parallel.rs:27-46): contiguous chunks, serial when chunk_size < num_threads
+static void parallelize(size_t n, const std::function<void(size_t, size_t)>& f) {
+  size_t nt = (size_t)num_threads();
+  size_t chunk = (n + nt - 1) / nt;
+  if (nt == 1 || chunk < nt) {
+    f(0, n);
+    return;
+  }
+  std::vector<std::thread> th;
+  for (size_t s = 0; s < n; s += chunk) th.emplace_back(f, s, std::min(n, s + chunk));
+  for (auto& t : th) t.join();
+}
+
+// ------------------------------------------------------------------ Keccak-256 (sha3 0.10.6 Keccak256)
+struct Keccak {
+  uint64_t st[25];
+  uint8_t buf[136];
+  size_t len;
+  Keccak() { reset(); }
+  void reset() {
+    memset(st, 0, sizeof st);
+    len = 0;
+  }
+  static uint64_t rol(uint64_t x, int n) { return n ? (x << n) | (x >> (64 - n)) : x; }
+  void permute() {
+    static const uint64_t RC[24] = {
+        0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808Aull, 0x8000000080008000ull,
+        0x000000000000808Bull, 0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull,
+        0x000000000000008Aull, 0x0000000000000088ull, 0x0000000080008009ull, 0x000000008000000Aull,
+        0x000000008000808Bull, 0x800000000000008Bull, 0x8000000000008089ull, 0x8000000000008003ull,
+        0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800Aull, 0x800000008000000Aull,
+        0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+    // rho offsets by lane position in pi order (piln walk of the Keccak team's compact implementation)
+    static const int ROTC[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
+    static const int PILN[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
+    for (int r = 0; r < 24; r++) {
+      uint64_t bc[5];
+      for (int i = 0; i < 5; i++) bc[i] = st[i] ^ st[i + 5] ^ st[i + 10] ^ st[i + 15] ^ st[i + 20];
+      for (int i = 0; i < 5; i++) {
+        uint64_t t = bc[(i + 4) % 5] ^ rol(bc[(i + 1) % 5], 1);
+        for (int j = 0; j < 25; j += 5) st[j + i] ^= t;
+      }
+      uint64_t t = st[1];
+      for (int i = 0; i < 24; i++) {
+        int j = PILN[i];
+        uint64_t b = st[j];
+        st[j] = rol(t, ROTC[i]);
+        t = b;
+      }
+      for (int j = 0; j < 25; j += 5) {
+        for (int i = 0; i < 5; i++) bc[i] = st[j + i];
+        for (int i = 0; i < 5; i++) st[j + i] ^= (~bc[(i + 1) % 5]) & bc[(i + 2) % 5];
+      }
+      st[0] ^= RC[r];
+    }
+  }
+  void absorb() {
+    for (int i = 0; i < 17; i++) {
+      uint64_t w;
+      memcpy(&w, buf + 8 * i, 8);
+      st[i] ^= w;
+    }
+    permute();
+    len = 0;
+  }
+  void update(const uint8_t* d, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+      buf[len++] = d[i];
+      if (len == 136) absorb();
+    }
+  }
+  void finalize_reset(uint8_t out[32]) {
+    memset(buf + len, 0, 136 - len);
+    buf[len] ^= 0x01;
+    buf[135] ^= 0x80;
+    absorb();
+    memcpy(out, st, 32);
+    reset();
+  }
+};
+
+struct OracleError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+struct Transcript {
+  Keccak h;
+  std::vector<uint8_t> stream;
+  void common_fe(const Fr& f) {
+    uint64_t c[4];
+    f.to_raw(c);
+    h.update((const uint8_t*)c, 32);
+  }
+  void write_fe(const Fr& f) {
+    uint64_t c[4];
+    f.to_raw(c);
+    h.update((const uint8_t*)c, 32);
+    const uint8_t* b = (const uint8_t*)c;
+    for (int i = 31; i >= 0; i--) stream.push_back(b[i]);
+  }
+  void write_fes(const std::vector<Fr>& v) {
+    for (auto& f : v) write_fe(f);
+  }
+  Fr squeeze() {
+    uint8_t d[32];
+    h.finalize_reset(d);
+    h.update(d, 32);
+    uint64_t c[4];
+    memcpy(c, d, 32);
+    while (Fr::ge_mod(c)) Fr::sub_mod_inplace(c);  // fe_mod_from_le_bytes (arithmetic.rs:150-152)
+    return Fr::from_raw(c);
+  }
+  std::vector<Fr> squeeze_n(size_t n) {
+    std::vector<Fr> v(n);
+    for (auto& f : v) f = squeeze();
+    return v;
+  }
+  void write_comm(const Affine& p) {
+    if (p.is_identity()) throw OracleError("Invalid elliptic curve point encoding");
+    uint64_t cx[4], cy[4];
+    p.x.to_raw(cx);
+    p.y.to_raw(cy);
+    h.update((const uint8_t*)cx, 32);
+    h.update((const uint8_t*)cy, 32);
+    for (int i = 31; i >= 0; i--) stream.push_back(((const uint8_t*)cx)[i]);
+    for (int i = 31; i >= 0; i--) stream.push_back(((const uint8_t*)cy)[i]);
+  }
+};
+
+// ------------------------------------------------------------------ multilinear polys
+typedef std::vector<Fr> Poly;
+
+static Poly eq_xy(const Fr* y, size_t n) {  // multilinear.rs:91-127
+  Poly ev{Fr::one()};
+  for (size_t i = n; i-- > 0;) {
+    Poly nx(ev.size() * 2);
+    const Fr yi = y[i];
+    parallelize(ev.size(), [&](size_t s, size_t e) {
+      for (size_t k = s; k < e; k++) {
+        nx[2 * k + 1] = ev[k] * yi;
+        nx[2 * k] = ev[k] - nx[2 * k + 1];
+      }
+    });
+    ev.swap(nx);
+  }
+  return ev;
+}
+static Poly fix_var(const Poly& p, const Fr& x) {  // merge_into, multilinear.rs:599-618
+  Poly out(p.size() / 2);
+  parallelize(out.size(), [&](size_t s, size_t e) {
+    for (size_t b = s; b < e; b++) out[b] = (p[2 * b + 1] - p[2 * b]) * x + p[2 * b];
+  });
+  return out;
+}
+static Fr evaluate(const Poly& p, const Fr* x, size_t n) {
+  Poly cur = p;
+  for (size_t i = 0; i < n; i++) cur = fix_var(cur, x[i]);
+  return cur[0];
+}
+static Fr eq_xy_eval(const Fr* x, const Fr* y, size_t n) {  // sum_check.rs:112-121
+  Fr acc = Fr::one();
+  for (size_t i = 0; i < n; i++) acc = acc * ((x[i] * y[i]).dbl() + Fr::one() - x[i] - y[i]);
+  return acc;
+}
+
+// ------------------------------------------------------------------ sum-check over [eq *] sum_m c_m prod_k T
+struct Sop {  // same layout as lh_sop (include/lasso_hip.h)
+  uint32_t num_terms;
+  int32_t global_eq;
+  Fr coeff[48];
+  uint8_t num_factors[48];
+  uint8_t factor[48][4];
+};
+
+static Fr interpolate(const std::vector<Fr>& ev, const Fr& x) {  // barycentric over 0..d (arithmetic.rs:108-136)
+  size_t d = ev.size() - 1;
+  std::vector<Fr> pts(d + 1);
+  for (size_t i = 0; i <= d; i++) pts[i] = Fr::from_u64(i);
+  for (size_t i = 0; i <= d; i++)
+    if (x == pts[i]) return ev[i];
+  Fr tot = Fr::zero();
+  for (size_t j = 0; j <= d; j++) {
+    Fr nu = Fr::one(), de = Fr::one();
+    for (size_t i = 0; i <= d; i++)
+      if (i != j) {
+        nu = nu * (x - pts[i]);
+        de = de * (pts[j] - pts[i]);
+      }
+    tot = tot + ev[j] * nu * de.inv();
+  }
+  return tot;
+}
+
+struct ScOut {
+  std::vector<Fr> x, evals;
+};
+
+static ScOut sum_check_prove(Transcript& tr, int kind, size_t nv, const Sop& e, std::vector<Poly> polys,
+                             const std::vector<std::vector<Fr>>& ys, Fr claim) {
+  if (nv == 0) throw OracleError("sum-check needs num_vars > 0");
+  size_t np = polys.size();
+  std::vector<Poly> tabs = std::move(polys);
+  for (auto& y : ys) tabs.push_back(eq_xy(y.data(), nv));
+  int geq = e.global_eq >= 0 ? (int)np + e.global_eq : -1;
+  int degree = 0;
+  for (uint32_t m = 0; m < e.num_terms; m++) degree = std::max(degree, (int)e.num_factors[m] + (geq >= 0 ? 1 : 0));
+  if (kind == 1 && degree != 2) throw OracleError("CoefficientsProver: degree 2 only");
+  const Fr inv2 = Fr::from_u64(2).inv();
+  ScOut out;
+  for (size_t round = 0; round < nv; round++) {
+    size_t size = (size_t)1 << (nv - round - 1);
+    int nt = num_threads();
+    size_t chunk = (size + nt - 1) / nt;
+    size_t nchunks = (size + chunk - 1) / chunk;
+    std::vector<std::vector<Fr>> partial(nchunks, std::vector<Fr>(degree + 1, Fr::zero()));
+    auto work = [&](size_t ci) {  // EvaluationsProver::evals per-thread partials (eval.rs:105-125)
+      std::vector<Fr>& acc = partial[ci];
+      size_t lo = ci * chunk, hi = std::min(size, lo + chunk);
+      std::vector<Fr> s(degree + 1), pm(degree + 1);
+      for (size_t b = lo; b < hi; b++) {
+        for (int x = 1; x <= degree; x++) s[x] = Fr::zero();
+        for (uint32_t m = 0; m < e.num_terms; m++) {
+          for (int k = 0; k < e.num_factors[m]; k++) {
+            const Poly& t = tabs[e.factor[m][k]];
+            Fr v1 = t[2 * b + 1], step = v1 - t[2 * b], val = v1;
+            for (int x = 1; x <= degree; x++) {
+              if (x > 1) val = val + step;
+              pm[x] = k == 0 ? e.coeff[m] * val : pm[x] * val;
+            }
+          }
+          for (int x = 1; x <= degree; x++) s[x] = s[x] + pm[x];
+        }
+        if (geq >= 0) {
+          const Poly& t = tabs[geq];
+          Fr v1 = t[2 * b + 1], step = v1 - t[2 * b], val = v1;
+          for (int x = 1; x <= degree; x++) {
+            if (x > 1) val = val + step;
+            s[x] = s[x] * val;
+          }
+        }
+        for (int x = 1; x <= degree; x++) acc[x] = acc[x] + s[x];
+      }
+    };
+    if (nchunks == 1) {
+      work(0);
+    } else {
+      std::vector<std::thread> th;
+      for (size_t ci = 0; ci < nchunks; ci++) th.emplace_back(work, ci);
+      for (auto& t : th) t.join();
+    }
+    std::vector<Fr> ev(degree + 1, Fr::zero());
+    for (auto& p : partial)
+      for (int x = 1; x <= degree; x++) ev[x] = ev[x] + p[x];
+    ev[0] = claim - ev[1];  // eval.rs:129
+    Fr r;
+    if (kind == 1) {  // coeff.rs:136-149
+      std::vector<Fr> co(3);
+      co[0] = ev[0];
+      co[2] = (ev[2] - ev[1].dbl() + ev[0]) * inv2;
+      co[1] = claim - (co[0].dbl() + co[2]);
+      tr.write_fes(co);
+      r = tr.squeeze();
+      claim = (co[2] * r + co[1]) * r + co[0];
+    } else {
+      tr.write_fes(ev);
+      r = tr.squeeze();
+      claim = interpolate(ev, r);
+    }
+    out.x.push_back(r);
+    for (auto& t : tabs) t = fix_var(t, r);  // ProverState::next_round (classic.rs:90-141)
+  }
+  for (size_t i = 0; i < np; i++) out.evals.push_back(tabs[i][0]);
+  return out;
+}
+
+// ------------------------------------------------------------------ GKR
+struct FracOut {
+  std::vector<Fr> p_xs, q_xs, x;
+};
+static FracOut frac_gkr_prove(Transcript& tr, const std::vector<Poly>& ps, const std::vector<Poly>& qs) {
+  size_t B = ps.size();
+  size_t nv = 0;
+  while (((size_t)1 << nv) < ps[0].size()) nv++;
+  // levels[h] = (p, q) vectors of 2^(nv-h) entries; Layer::bottom / up (fractional_sum_check.rs:42-85)
+  std::vector<std::vector<Poly>> lp(nv), lq(nv);
+  lp[0] = ps, lq[0] = qs;
+  for (size_t h = 1; h < nv; h++) {
+    size_t half = (size_t)1 << (nv - h);
+    for (size_t b = 0; b < B; b++) {
+      Poly vp(half), vq(half);
+      const Poly &p = lp[h - 1][b], &q = lq[h - 1][b];
+      parallelize(half, [&](size_t s, size_t e) {
+        for (size_t i = s; i < e; i++) {
+          vp[i] = p[i] * q[half + i] + p[half + i] * q[i];
+          vq[i] = q[i] * q[half + i];
+        }
+      });
+      lp[h].push_back(vp), lq[h].push_back(vq);
+    }
+  }
+  std::vector<Fr> cp(B), cq(B);
+  for (size_t b = 0; b < B; b++) {
+    const Poly &p = lp[nv - 1][b], &q = lq[nv - 1][b];
+    cp[b] = p[0] * q[1] + p[1] * q[0];
+    cq[b] = q[0] * q[1];
+  }
+  tr.write_fes(cp);
+  tr.write_fes(cq);
+  std::vector<Fr> y;
+  for (size_t h = nv; h-- > 0;) {
+    size_t m = nv - 1 - h, half = (size_t)1 << m;
+    std::vector<Fr> x, evals;
+    if (m == 0) {
+      for (size_t b = 0; b < B; b++) {
+        evals.push_back(lp[h][b][0]), evals.push_back(lp[h][b][1]);
+        evals.push_back(lq[h][b][0]), evals.push_back(lq[h][b][1]);
+      }
+    } else {
+      Fr gamma = tr.squeeze(), claim = Fr::zero(), pw = Fr::one();
+      Sop e;
+      memset(&e, 0, sizeof e);
+      e.global_eq = 0;
+      std::vector<Poly> polys;
+      for (size_t b = 0; b < B; b++) {
+        claim = claim + cp[b] * pw;
+        Fr ge = pw;
+        pw = pw * gamma;
+        claim = claim + cq[b] * pw;
+        Fr go = pw;
+        pw = pw * gamma;
+        uint32_t t = e.num_terms;
+        e.coeff[t] = ge, e.num_factors[t] = 2, e.factor[t][0] = 4 * b, e.factor[t][1] = 4 * b + 3;
+        e.coeff[t + 1] = ge, e.num_factors[t + 1] = 2, e.factor[t + 1][0] = 4 * b + 1, e.factor[t + 1][1] = 4 * b + 2;
+        e.coeff[t + 2] = go, e.num_factors[t + 2] = 2, e.factor[t + 2][0] = 4 * b + 2, e.factor[t + 2][1] = 4 * b + 3;
+        e.num_terms += 3;
+        const Poly &p = lp[h][b], &q = lq[h][b];
+        polys.emplace_back(p.begin(), p.begin() + half), polys.emplace_back(p.begin() + half, p.end());
+        polys.emplace_back(q.begin(), q.begin() + half), polys.emplace_back(q.begin() + half, q.end());
+      }
+      ScOut sc = sum_check_prove(tr, 0, m, e, polys, {y}, claim);
+      x = sc.x, evals = sc.evals;
+    }
+    tr.write_fes(evals);
+    Fr mu = tr.squeeze();
+    for (size_t b = 0; b < B; b++) {
+      cp[b] = evals[4 * b] + mu * (evals[4 * b + 1] - evals[4 * b]);
+      cq[b] = evals[4 * b + 2] + mu * (evals[4 * b + 3] - evals[4 * b + 2]);
+    }
+    x.push_back(mu);
+    y = x;
+  }
+  return FracOut{cp, cq, y};
+}
+
+struct GpOut {
+  std::vector<Fr> roots, claims;
+  std::vector<std::vector<Fr>> points;
+};
+static GpOut grand_product_prove(Transcript& tr, const std::vector<Poly>& leaves) {
+  size_t B = leaves.size(), maxd = 0;
+  std::vector<size_t> depth(B);
+  std::vector<std::vector<Poly>> level(B);  // level[b][h]: 2^(h+1) nodes
+  for (size_t b = 0; b < B; b++) {
+    size_t d = 0;
+    while (((size_t)1 << d) < leaves[b].size()) d++;
+    depth[b] = d, maxd = std::max(maxd, d);
+    level[b].resize(d);
+    level[b][d - 1] = leaves[b];
+    for (size_t h = d - 1; h-- > 0;) {
+      size_t half = (size_t)1 << (h + 1);
+      Poly up(half);
+      const Poly& in = level[b][h + 1];
+      parallelize(half, [&](size_t s, size_t e) {
+        for (size_t i = s; i < e; i++) up[i] = in[i] * in[half + i];
+      });
+      level[b][h] = up;
+    }
+  }
+  GpOut out;
+  out.roots.resize(B), out.claims.resize(B), out.points.resize(B);
+  for (size_t b = 0; b < B; b++) out.roots[b] = level[b][0][0] * level[b][0][1];
+  tr.write_fes(out.roots);
+  std::vector<Fr> claims = out.roots, y;
+  for (size_t h = 0; h < maxd; h++) {
+    std::vector<size_t> act;
+    for (size_t b = 0; b < B; b++)
+      if (depth[b] > h) act.push_back(b);
+    size_t half = (size_t)1 << h;
+    std::vector<Fr> x, evals;
+    if (h == 0) {
+      for (size_t b : act) evals.push_back(level[b][0][0]), evals.push_back(level[b][0][1]);
+    } else {
+      Fr lam = tr.squeeze(), claim = Fr::zero(), pw = Fr::one();
+      Sop e;
+      memset(&e, 0, sizeof e);
+      e.global_eq = 0;
+      e.num_terms = (uint32_t)act.size();
+      std::vector<Poly> polys;
+      for (size_t k = 0; k < act.size(); k++) {
+        size_t b = act[k];
+        claim = claim + claims[b] * pw;
+        e.coeff[k] = pw, e.num_factors[k] = 2, e.factor[k][0] = 2 * k, e.factor[k][1] = 2 * k + 1;
+        pw = pw * lam;
+        const Poly& v = level[b][h];
+        polys.emplace_back(v.begin(), v.begin() + half), polys.emplace_back(v.begin() + half, v.end());
+      }
+      ScOut sc = sum_check_prove(tr, 0, h, e, polys, {y}, claim);
+      x = sc.x, evals = sc.evals;
+    }
+    tr.write_fes(evals);
+    Fr mu = tr.squeeze();
+    x.push_back(mu);
+    y = x;
+    for (size_t k = 0; k < act.size(); k++) {
+      size_t b = act[k];
+      claims[b] = evals[2 * k] + mu * (evals[2 * k + 1] - evals[2 * k]);
+      if (depth[b] == h + 1) out.claims[b] = claims[b], out.points[b] = y;
+    }
+  }
+  return out;
+}
+
+// ------------------------------------------------------------------ variable_base_msm (msm.rs:84-181)
+static size_t window_size(size_t n) { return n < 32 ? 3 : (size_t)floor(log((double)n)); }
+
+static Jac msm_serial(const Fr* scalars, const Affine* bases, size_t n) {
+  std::vector<uint64_t> repr(4 * n);
+  for (size_t i = 0; i < n; i++) scalars[i].to_raw(&repr[4 * i]);
+  size_t w = window_size(n), nb = ((size_t)1 << w) - 1, nwin = (256 + w - 1) / w;
+  Jac result = Jac::identity();
+  std::vector<Jac> buckets(nb);
+  std::vector<uint8_t> used(nb);
+  for (size_t idx = nwin; idx-- > 0;) {
+    for (size_t k = 0; k < w; k++) result = jac_dbl(result);
+    std::fill(used.begin(), used.end(), 0);
+    size_t skip = idx * w;
+    for (size_t i = 0; i < n; i++) {
+      const uint64_t* r = &repr[4 * i];
+      size_t limb = skip / 64, off = skip % 64;
+      uint64_t d = limb < 4 ? r[limb] >> off : 0;
+      if (off && limb + 1 < 4) d |= r[limb + 1] << (64 - off);
+      d &= nb;
+      if (d) {
+        if (!used[d - 1]) {
+          buckets[d - 1] = jac_from_affine(bases[i]);
+          used[d - 1] = 1;
+        } else {
+          buckets[d - 1] = jac_add_affine(buckets[d - 1], bases[i]);
+        }
+      }
+    }
+    Jac run = Jac::identity();
+    for (size_t b = nb; b-- > 0;) {
+      if (used[b]) run = jac_add(run, buckets[b]);
+      result = jac_add(result, run);
+    }
+  }
+  return result;
+}
+
+static Affine msm(const Fr* scalars, const Affine* bases, size_t n) {
+  size_t nt = (size_t)num_threads();
+  if (n == 0) return Affine{Fq::zero(), Fq::zero()};
+  if (n <= nt) return jac_to_affine(msm_serial(scalars, bases, n));
+  size_t chunk = (n + nt - 1) / nt;
+  size_t nch = (n + chunk - 1) / chunk;
+  std::vector<Jac> res(nch, Jac::identity());
+  std::vector<std::thread> th;
+  for (size_t c = 0; c < nch; c++)
+    th.emplace_back([&, c] {
+      size_t lo = c * chunk, hi = std::min(n, lo + chunk);
+      res[c] = msm_serial(scalars + lo, bases + lo, hi - lo);
+    });
+  for (auto& t : th) t.join();
+  Jac acc = Jac::identity();
+  for (auto& r : res) acc = jac_add(acc, r);
+  return jac_to_affine(acc);
+}
+
+// ------------------------------------------------------------------ MultilinearKzg (flat SRS: level k at 2^k - 1)
+struct Srs {
+  const Affine* eqs;
+  size_t nv;
+  const Affine* eq(size_t k) const { return eqs + (((size_t)1 << k) - 1); }
+};
+static Affine commit(const Srs& s, const Poly& p) {
+  size_t nv = 0;
+  while (((size_t)1 << nv) < p.size()) nv++;
+  if (nv > s.nv) throw OracleError("Too many variates of poly to commit");
+  return msm(p.data(), s.eq(nv), p.size());
+}
+static Fr kzg_open(Transcript& tr, const Srs& s, const Poly& poly, const Fr* point, size_t nv) {
+  Poly rem = poly;  // quotients (pcs/multilinear.rs:72-107)
+  std::vector<Affine> comms(nv);
+  for (size_t i = nv; i-- > 0;) {
+    size_t half = (size_t)1 << i;
+    Poly q(half), lo(half);
+    parallelize(half, [&](size_t a, size_t b) {
+      for (size_t k = a; k < b; k++) {
+        q[k] = rem[half + k] - rem[k];
+        lo[k] = rem[k] + q[k] * point[i];
+      }
+    });
+    rem.swap(lo);
+    comms[i] = msm(q.data(), s.eq(i), half);
+  }
+  for (auto& c : comms) tr.write_comm(c);
+  return rem[0];
+}
+struct Eval {  // same layout as lh_evaluation
+  uint32_t poly, point;
+  Fr value;
+};
+static void batch_open(Transcript& tr, const Srs& s, size_t nv, const std::vector<const Poly*>& polys,
+                       const std::vector<std::vector<Fr>>& points, const std::vector<Eval>& evals) {
+  if (evals.size() < 2) throw OracleError("batch open needs >= 2 evaluations");
+  size_t ell = 0;
+  while (((size_t)1 << ell) < evals.size()) ell++;
+  std::vector<Fr> t = tr.squeeze_n(ell);
+  Poly eq_xt = eq_xy(t.data(), ell);
+  size_t n = (size_t)1 << nv, np = points.size();
+  std::vector<Poly> merged(np, Poly(n, Fr::zero()));  // pcs/multilinear.rs:155-170
+  for (size_t i = 0; i < evals.size(); i++) {
+    Poly& m = merged[evals[i].point];
+    const Poly& src = *polys[evals[i].poly];
+    const Fr w = eq_xt[i];
+    parallelize(n, [&](size_t a, size_t b) {
+      for (size_t k = a; k < b; k++) m[k] = m[k] + w * src[k];
+    });
+  }
+  Sop e;
+  memset(&e, 0, sizeof e);
+  e.global_eq = -1;
+  e.num_terms = (uint32_t)np;
+  for (size_t j = 0; j < np; j++) {
+    e.coeff[j] = Fr::one();
+    e.num_factors[j] = 2;
+    e.factor[j][0] = (uint8_t)(np + j);
+    e.factor[j][1] = (uint8_t)j;
+  }
+  Fr sum = Fr::zero();
+  for (size_t i = 0; i < evals.size(); i++) sum = sum + evals[i].value * eq_xt[i];
+  ScOut sc = sum_check_prove(tr, 1, nv, e, merged, points, sum);
+  Poly g(n, Fr::zero());
+  for (size_t j = 0; j < np; j++) {
+    Fr w = eq_xy_eval(sc.x.data(), points[j].data(), nv);
+    parallelize(n, [&](size_t a, size_t b) {
+      for (size_t k = a; k < b; k++) g[k] = g[k] + w * merged[j][k];
+    });
+  }
+  kzg_open(tr, s, g, sc.x.data(), nv);
+}
+
+// ------------------------------------------------------------------ Lasso (spec: oracle/pyref/lasso.py)
+struct LassoTable {  // same layout as lh_lasso_table
+  uint32_t c, l, alpha;
+  uint32_t mem_chunk[16], mem_sub[16];
+  uint32_t num_terms;
+  Fr g_coeff[16];
+  uint8_t g_nfac[16];
+  uint8_t g_fac[16][4];
+};
+static uint32_t subtable_entry(uint32_t kind, uint32_t m, uint32_t l) {
+  uint32_t h = l / 2, x = m >> h, y = m & ((1u << h) - 1);
+  return kind == 0 ? m : kind == 1 ? (x & y) : (x ^ y);
+}
+static Poly to_poly(const std::vector<uint32_t>& v) {
+  Poly p(v.size());
+  parallelize(v.size(), [&](size_t a, size_t b) {
+    for (size_t k = a; k < b; k++) p[k] = Fr::from_u64(v[k]);
+  });
+  return p;
+}
+static void lasso_prove(Transcript& tr, const Srs& s, const LassoTable& tb, size_t n, const uint32_t* const* dims) {
+  const size_t c = tb.c, l = tb.l, alpha = tb.alpha, N = (size_t)1 << n, M = (size_t)1 << l;
+  std::vector<std::vector<uint32_t>> rts(c, std::vector<uint32_t>(N)), fcs(c, std::vector<uint32_t>(M, 0));
+  for (size_t j = 0; j < c; j++)
+    for (size_t k = 0; k < N; k++) rts[j][k] = fcs[j][dims[j][k]]++;
+  std::vector<std::vector<uint32_t>> E(alpha, std::vector<uint32_t>(N));
+  for (size_t i = 0; i < alpha; i++)
+    for (size_t k = 0; k < N; k++) E[i][k] = subtable_entry(tb.mem_sub[i], dims[tb.mem_chunk[i]][k], (uint32_t)l);
+  Poly a(N);
+  parallelize(N, [&](size_t lo, size_t hi) {
+    for (size_t k = lo; k < hi; k++) {
+      Fr acc = Fr::zero();
+      for (uint32_t m = 0; m < tb.num_terms; m++) {
+        Fr v = tb.g_coeff[m];
+        for (int f = 0; f < tb.g_nfac[m]; f++) v = v * Fr::from_u64(E[tb.g_fac[m][f]][k]);
+        acc = acc + v;
+      }
+      a[k] = acc;
+    }
+  });
+  std::vector<Poly> pn;  // a | dim | read_ts | E
+  pn.push_back(a);
+  for (size_t j = 0; j < c; j++) pn.push_back(to_poly(std::vector<uint32_t>(dims[j], dims[j] + N)));
+  for (size_t j = 0; j < c; j++) pn.push_back(to_poly(rts[j]));
+  for (size_t i = 0; i < alpha; i++) pn.push_back(to_poly(E[i]));
+  std::vector<Poly> pl;
+  for (size_t j = 0; j < c; j++) pl.push_back(to_poly(fcs[j]));
+
+  tr.common_fe(Fr::from_u64(n)), tr.common_fe(Fr::from_u64(l)), tr.common_fe(Fr::from_u64(c)), tr.common_fe(Fr::from_u64(alpha));
+  for (auto& p : pn) tr.write_comm(commit(s, p));
+  for (auto& p : pl) tr.write_comm(commit(s, p));
+
+  std::vector<Fr> r = tr.squeeze_n(n);
+  Fr v = evaluate(a, r.data(), n);
+  tr.write_fe(v);
+  Sop surge;
+  memset(&surge, 0, sizeof surge);
+  surge.global_eq = 0;
+  surge.num_terms = tb.num_terms;
+  for (uint32_t m = 0; m < tb.num_terms; m++) {
+    surge.coeff[m] = tb.g_coeff[m];
+    surge.num_factors[m] = tb.g_nfac[m];
+    memcpy(surge.factor[m], tb.g_fac[m], 4);
+  }
+  std::vector<Poly> Ep(pn.begin() + 1 + 2 * c, pn.end());
+  ScOut sc = sum_check_prove(tr, 0, n, surge, Ep, {r}, v);
+  tr.write_fes(sc.evals);
+
+  Fr gamma = tr.squeeze(), tau = tr.squeeze(), g2 = gamma * gamma, one = Fr::one();
+  std::vector<Poly> leaves(4 * alpha);
+  for (size_t i = 0; i < alpha; i++) {
+    size_t j = tb.mem_chunk[i];
+    Poly rs(N), ws(N), in(M), fi(M);
+    const Poly &dimp = pn[1 + j], &ep = pn[1 + 2 * c + i], &tsp = pn[1 + c + j], &fcp = pl[j];
+    parallelize(N, [&](size_t lo, size_t hi) {
+      for (size_t k = lo; k < hi; k++) {
+        rs[k] = dimp[k] * g2 + ep[k] * gamma + tsp[k] - tau;
+        ws[k] = rs[k] + one;
+      }
+    });
+    parallelize(M, [&](size_t lo, size_t hi) {
+      for (size_t m = lo; m < hi; m++) {
+        in[m] = Fr::from_u64(m) * g2 + Fr::from_u64(subtable_entry(tb.mem_sub[i], (uint32_t)m, (uint32_t)l)) * gamma - tau;
+        fi[m] = in[m] + fcp[m];
+      }
+    });
+    leaves[2 * i] = rs, leaves[2 * i + 1] = ws;
+    leaves[2 * alpha + 2 * i] = in, leaves[2 * alpha + 2 * i + 1] = fi;
+  }
+  GpOut gp = grand_product_prove(tr, leaves);
+  const std::vector<Fr>&r_N = gp.points[0], &r_M = gp.points[2 * alpha];
+  std::vector<Fr> ev_n, ev_l;
+  for (size_t k = 1; k < pn.size(); k++) ev_n.push_back(evaluate(pn[k], r_N.data(), n));
+  for (auto& p : pl) ev_l.push_back(evaluate(p, r_M.data(), l));
+  tr.write_fes(ev_n), tr.write_fes(ev_l);
+
+  std::vector<Eval> evs;
+  evs.push_back(Eval{0, 0, v});
+  for (size_t i = 0; i < alpha; i++) evs.push_back(Eval{(uint32_t)(1 + 2 * c + i), 1, sc.evals[i]});
+  for (size_t j = 0; j < c; j++) evs.push_back(Eval{(uint32_t)(1 + j), 2, ev_n[j]});
+  for (size_t j = 0; j < c; j++) evs.push_back(Eval{(uint32_t)(1 + c + j), 2, ev_n[c + j]});
+  for (size_t i = 0; i < alpha; i++) evs.push_back(Eval{(uint32_t)(1 + 2 * c + i), 2, ev_n[2 * c + i]});
+  std::vector<const Poly*> ppn, ppl;
+  for (auto& p : pn) ppn.push_back(&p);
+  for (auto& p : pl) ppl.push_back(&p);
+  batch_open(tr, s, n, ppn, {r, sc.x, r_N}, evs);
+  if (c >= 2) {
+    std::vector<Eval> el;
+    for (size_t j = 0; j < c; j++) el.push_back(Eval{(uint32_t)j, 0, ev_l[j]});
+    batch_open(tr, s, l, ppl, {r_M}, el);
+  } else {
+    kzg_open(tr, s, pl[0], r_M.data(), l);
+  }
+}
+
+// ------------------------------------------------------------------ C interface (ctypes)
+static thread_local std::string g_err;
+#define ORC_TRY try {
+#define ORC_CATCH                   \
+  }                                 \
+  catch (const std::exception& e) { \
+    g_err = e.what();               \
+    return -1;                      \
+  }                                 \
+  return 0;
+
+static Poly load_poly(const Fr* p, size_t n) { return Poly(p, p + n); }
+
+extern "C" {
+const char* orc_last_error() { return g_err.c_str(); }
+int orc_num_threads() { return num_threads(); }
+void orc_set_threads(int n) { g_threads = n; }
+
+void* orc_tr_new() { return new Transcript(); }
+void orc_tr_free(void* t) { delete (Transcript*)t; }
+size_t orc_tr_proof(void* t, const uint8_t** p) {
+  Transcript* tr = (Transcript*)t;
+  *p = tr->stream.data();
+  return tr->stream.size();
+}
+void orc_tr_write_fe(void* t, const Fr* f) { ((Transcript*)t)->write_fe(*f); }
+void orc_tr_common_fe(void* t, const Fr* f) { ((Transcript*)t)->common_fe(*f); }
+void orc_tr_squeeze(void* t, Fr* out) { *out = ((Transcript*)t)->squeeze(); }
+int orc_tr_write_comm(void* t, const Affine* p) {
+  ORC_TRY((Transcript*)t)->write_comm(*p);
+  ORC_CATCH
+}
+
+// eqs[k][b] = eq_k(b; s) * G, flat (kzg.rs:166-228); fixed-base by 8-bit windows of the generator
+int orc_setup(const Fr* ss, size_t nv, Affine* eqs_flat) {
+  ORC_TRY
+  size_t total = ((size_t)2 << nv) - 1;
+  std::vector<Fr> scal(total);
+  for (size_t k = 0; k <= nv; k++) {
+    Poly e = eq_xy(ss, k);
+    std::copy(e.begin(), e.end(), scal.begin() + (((size_t)1 << k) - 1));
+  }
+  std::vector<Affine> tab(32 * 255);
+  Jac off = jac_from_affine(Affine{Fq::from_u64(1), Fq::from_u64(2)});
+  for (int w = 0; w < 32; w++) {
+    Jac acc = off;
+    for (int d = 0; d < 255; d++) {
+      tab[w * 255 + d] = jac_to_affine(acc);
+      acc = jac_add(acc, off);
+    }
+    off = acc;
+  }
+  parallelize(total, [&](size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; i++) {
+      uint64_t c[4];
+      scal[i].to_raw(c);
+      Jac acc = Jac::identity();
+      for (int w = 0; w < 32; w++) {
+        uint32_t d = (c[w / 8] >> (8 * (w % 8))) & 0xff;
+        if (d) acc = jac_add_affine(acc, tab[w * 255 + d - 1]);
+      }
+      eqs_flat[i] = jac_to_affine(acc);
+    }
+  });
+  ORC_CATCH
+}
+
+int orc_msm(const Fr* scalars, const Affine* bases, size_t n, Affine* out) {
+  ORC_TRY* out = msm(scalars, bases, n);
+  ORC_CATCH
+}
+int orc_commit(const Affine* eqs, size_t srs_nv, const Fr* poly, size_t nv, Affine* out) {
+  ORC_TRY* out = commit(Srs{eqs, srs_nv}, load_poly(poly, (size_t)1 << nv));
+  ORC_CATCH
+}
+int orc_open(void* t, const Affine* eqs, size_t srs_nv, const Fr* poly, size_t nv, const Fr* point, Fr* out_eval) {
+  ORC_TRY* out_eval = kzg_open(*(Transcript*)t, Srs{eqs, srs_nv}, load_poly(poly, (size_t)1 << nv), point, nv);
+  ORC_CATCH
+}
+int orc_batch_open(void* t, const Affine* eqs, size_t srs_nv, size_t nv, const Fr* const* polys, size_t num_polys,
+                   const Fr* points, size_t num_points, const Eval* evals, size_t num_evals) {
+  ORC_TRY
+  std::vector<Poly> ps;
+  for (size_t i = 0; i < num_polys; i++) ps.push_back(load_poly(polys[i], (size_t)1 << nv));
+  std::vector<const Poly*> pp;
+  for (auto& p : ps) pp.push_back(&p);
+  std::vector<std::vector<Fr>> pts;
+  for (size_t j = 0; j < num_points; j++) pts.emplace_back(points + j * nv, points + (j + 1) * nv);
+  batch_open(*(Transcript*)t, Srs{eqs, srs_nv}, nv, pp, pts, std::vector<Eval>(evals, evals + num_evals));
+  ORC_CATCH
+}
+int orc_sumcheck_prove(void* t, int kind, size_t nv, const Sop* e, const Fr* const* polys, size_t num_polys,
+                       const Fr* ys, size_t num_ys, const Fr* sum, Fr* out_x, Fr* out_evals) {
+  ORC_TRY
+  std::vector<Poly> ps;
+  for (size_t i = 0; i < num_polys; i++) ps.push_back(load_poly(polys[i], (size_t)1 << nv));
+  std::vector<std::vector<Fr>> yv;
+  for (size_t j = 0; j < num_ys; j++) yv.emplace_back(ys + j * nv, ys + (j + 1) * nv);
+  ScOut o = sum_check_prove(*(Transcript*)t, kind, nv, *e, ps, yv, *sum);
+  std::copy(o.x.begin(), o.x.end(), out_x);
+  std::copy(o.evals.begin(), o.evals.end(), out_evals);
+  ORC_CATCH
+}
+int orc_frac_gkr_prove(void* t, size_t B, size_t nv, const Fr* const* ps, const Fr* const* qs, Fr* p_xs, Fr* q_xs,
+                       Fr* x) {
+  ORC_TRY
+  std::vector<Poly> p, q;
+  for (size_t b = 0; b < B; b++) p.push_back(load_poly(ps[b], (size_t)1 << nv)), q.push_back(load_poly(qs[b], (size_t)1 << nv));
+  FracOut o = frac_gkr_prove(*(Transcript*)t, p, q);
+  std::copy(o.p_xs.begin(), o.p_xs.end(), p_xs);
+  std::copy(o.q_xs.begin(), o.q_xs.end(), q_xs);
+  std::copy(o.x.begin(), o.x.end(), x);
+  ORC_CATCH
+}
+int orc_grand_product_prove(void* t, size_t B, const Fr* const* leaves, const size_t* nvs, Fr* roots, Fr* claims,
+                            Fr* points) {
+  ORC_TRY
+  std::vector<Poly> lv;
+  for (size_t b = 0; b < B; b++) lv.push_back(load_poly(leaves[b], (size_t)1 << nvs[b]));
+  GpOut o = grand_product_prove(*(Transcript*)t, lv);
+  std::copy(o.roots.begin(), o.roots.end(), roots);
+  std::copy(o.claims.begin(), o.claims.end(), claims);
+  for (size_t b = 0; b < B; b++) points = std::copy(o.points[b].begin(), o.points[b].end(), points);
+  ORC_CATCH
+}
+int orc_lasso_prove(void* t, const Affine* eqs, size_t srs_nv, const LassoTable* tb, size_t n,
+                    const uint32_t* const* dims) {
+  ORC_TRY lasso_prove(*(Transcript*)t, Srs{eqs, srs_nv}, *tb, n, dims);
+  ORC_CATCH
+}
+}

@@ -1,0 +1,159 @@
+"""CPU tests: the C++ oracle (oracle/cpu) against the Python oracle and the golden vectors.
+Two independent implementations (different Montgomery algorithm, Jacobian vs XYZZ-free big-ints) must
+agree byte for byte; this is what stands in for the reference's bytes (parity unpinned)."""
+import array
+import ctypes as C
+import json
+import os
+import random
+
+import pytest
+
+from oracle import cpu_oracle as co
+from oracle.pyref import curve, kzg, lasso, gkr, sum_check as sc, expression as ex
+from oracle.pyref.field import R_MOD as P
+from oracle.pyref.poly import evaluate
+from oracle.pyref.transcript import Keccak256Transcript as T
+
+GOLDEN = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "vectors.json")))
+I = lambda xs: [int(x, 16) for x in xs]
+
+
+@pytest.fixture(scope="module")
+def ffi(hl):
+    from halo2_lasso_amd import _ffi
+    return _ffi
+
+
+@pytest.fixture(scope="module")
+def srs5():
+    ss = I(GOLDEN["srs"]["ss"])
+    return ss, co.setup(ss)
+
+
+def test_transcript_matches_python_oracle():
+    a, b = co.Transcript(), T()
+    for v in (0, 1, P - 1, 12345678901234567890):
+        a.write_field_element(v), b.write_field_element(v)
+        assert a.squeeze_challenge() == b.squeeze_challenge()
+    a.common_field_element(5), b.common_field_element(5)
+    a.write_commitment((1, 2)), b.write_commitment((1, 2))
+    # > 136 bytes between squeezes: two sponge blocks
+    a.write_field_elements(range(7)), b.write_field_elements(range(7))
+    assert a.squeeze_challenges(2) == b.squeeze_challenges(2)
+    assert a.into_proof() == b.into_proof()
+    with pytest.raises(RuntimeError):
+        a.write_commitment(None)
+
+
+def test_setup_and_msm(srs5):
+    ss, srs = srs5
+    pp = kzg.setup(ss)
+    flat = [p for lvl in pp.eqs for p in lvl]
+    assert [co.g1_point(srs[64 * i:64 * i + 64]) for i in range(len(flat))] == flat
+    rng = random.Random(1)
+    for n in (1, 3, 9, 31):   # <= threads serial path, chunked path, window 3 / ln(n)
+        s = [rng.randrange(P) for _ in range(n)]
+        assert co.msm(s, srs[64 * 31:64 * (31 + n)]) == curve.msm(s, flat[31:31 + n])
+    for threads in (1, 3):
+        co.set_threads(threads)
+        s = [rng.randrange(P) for _ in range(32)]
+        assert co.msm(s, srs[64 * 31:]) == curve.msm(s, flat[31:])
+    co.set_threads(0)
+    assert co.msm([0] * 8, srs[64 * 7:64 * 15]) is None
+
+
+def test_golden_sum_checks(ffi):
+    g = GOLDEN["sum_check_eval"]
+    c = I(g["coeffs"])
+    sop = ffi.lh_sop()
+    sop.num_terms, sop.global_eq = 2, 0
+    for m, (co_, f) in enumerate(((c[0], [0, 1]), (c[1], [2]))):
+        C.memmove(C.byref(sop.coeff[m]), co.fr_bytes([co_]), 32)
+        sop.num_factors[m] = len(f)
+        for k, v in enumerate(f):
+            sop.factor[m][k] = v
+    t = co.Transcript()
+    x, ev = co.sumcheck_prove(t, 0, g["num_vars"], sop, [I(a) for a in g["tables"]], [I(g["y"])], int(g["claim"], 16))
+    assert (x, ev, t.into_proof().hex()) == (I(g["x"]), I(g["evals"]), g["proof"])
+    g = GOLDEN["sum_check_coeff"]
+    s = I(g["scalars"])
+    sop = ffi.lh_sop()
+    sop.num_terms, sop.global_eq = 2, -1
+    for j in range(2):
+        C.memmove(C.byref(sop.coeff[j]), co.fr_bytes([s[j]]), 32)
+        sop.num_factors[j] = 2
+        sop.factor[j][0], sop.factor[j][1] = 2 + j, j
+    t = co.Transcript()
+    x, ev = co.sumcheck_prove(t, 1, g["num_vars"], sop, [I(a) for a in g["tables"]], [I(a) for a in g["ys"]],
+                              int(g["claim"], 16))
+    assert (x, ev, t.into_proof().hex()) == (I(g["x"]), I(g["evals"]), g["proof"])
+
+
+def test_golden_gkr():
+    g = GOLDEN["frac_gkr"]
+    t = co.Transcript()
+    out = co.frac_gkr_prove(t, [I(a) for a in g["ps"]], [I(a) for a in g["qs"]])
+    assert out == (I(g["p_xs"]), I(g["q_xs"]), I(g["x"])) and t.into_proof().hex() == g["proof"]
+    g = GOLDEN["grand_product"]
+    t = co.Transcript()
+    roots, claims = co.grand_product_prove(t, [I(v) for v in g["leaves"]])
+    assert roots == I(g["roots"]) and t.into_proof().hex() == g["proof"]
+    assert [[hex(c), [hex(v) for v in p]] for c, p in claims] == g["claims"]
+
+
+def test_golden_kzg_batch(ffi, srs5):
+    _, srs = srs5
+    g = GOLDEN["kzg_batch"]
+    nv, polys = g["num_vars"], [I(a) for a in g["polys"]]
+    t = co.Transcript()
+    t.write_commitments([co.commit(srs, 5, p) for p in polys])
+    pts = [t.squeeze_challenges(nv) for _ in range(2)]
+    vals = [evaluate(polys[p], pts[q]) for p, q in g["pairs"]]
+    t.write_field_elements(vals)
+    evs = (ffi.lh_evaluation * len(vals))()
+    for i, ((p, q), v) in enumerate(zip(g["pairs"], vals)):
+        evs[i].poly, evs[i].point = p, q
+        C.memmove(C.byref(evs[i].value), co.fr_bytes([v]), 32)
+    co.batch_open(t, srs, 5, nv, polys, pts, evs, len(vals))
+    assert t.into_proof().hex() == g["proof"]
+
+
+def _table(hl, g):
+    return (hl.LassoTable.range(g["c"], g["l"]) if g["kind"] == "range" else hl.LassoTable.bitwise(
+        hl.SUBTABLE_AND if g["kind"] == "and" else hl.SUBTABLE_XOR, g["c"], g["l"])).to_c()
+
+
+@pytest.mark.parametrize("idx", range(3))
+def test_golden_lasso(hl, srs5, idx):
+    _, srs = srs5
+    g = GOLDEN["lasso"][idx]
+    t = co.Transcript()
+    co.lasso_prove(t, srs, 5, _table(hl, g), g["n"], [array.array("I", d).tobytes() for d in g["dims"]])
+    assert t.into_proof().hex() == g["proof"]
+
+
+@pytest.mark.parametrize("threads", [1, 2, 5])
+def test_lasso_thread_count_does_not_change_bytes(hl, srs5, threads):
+    """parallelize() chunking (parallel.rs:27-46) must be unobservable."""
+    _, srs = srs5
+    g = GOLDEN["lasso"][1]
+    co.set_threads(threads)
+    try:
+        t = co.Transcript()
+        co.lasso_prove(t, srs, 5, _table(hl, g), g["n"], [array.array("I", d).tobytes() for d in g["dims"]])
+        assert t.into_proof().hex() == g["proof"]
+    finally:
+        co.set_threads(0)
+
+
+def test_open_matches_python_oracle(srs5):
+    ss, srs = srs5
+    rng = random.Random(11)
+    pp = kzg.setup(ss)
+    for nv in (1, 4):
+        poly = [rng.randrange(P) for _ in range(1 << nv)]
+        pt = [rng.randrange(P) for _ in range(nv)]
+        a, b = co.Transcript(), T()
+        assert co.open_(a, srs, 5, poly, pt) == kzg.open_(pp.trim(nv), poly, pt, b) == evaluate(poly, pt)
+        assert a.into_proof() == b.into_proof()
