@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py -- Lasso prove time on MI355X (BASELINE.json metric), one JSON line on stdout.
+
+Step = one Lasso prove of the workload (BASELINE.json configs[1]: 2^20 range-check lookups, BN254,
+32-bit values as 2 x 16-bit limbs into the identity subtable, multilinear-KZG openings) with the lookup
+indices and the SRS already resident in HBM.  `--gpus N` (launched by torch.distributed.run, one
+rank per GPU): every rank proves its own independent batch of 2^n lookups (weak scaling, no
+data-path collective); time = max over ranks, value = ms per proof over the
+whole job = wall / (N * K).
+
+Extra objects on the line:
+  roofline      dominant kernel (by share of the profiled prove) at its largest launch shape:
+                algorithmic bytes per launch / HIP-event duration, against 8 TB/s HBM
+  alu           same kernel against the measured Fr-multiplication peak (integer-ALU bound)
+  cpu_baseline  the C++ oracle (reference algorithms, all host cores) on a bounded sample
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+SEED_BASE = 0x4C4153534F00
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log-n", type=int, default=20, help="log2 of the number of lookups per proof")
+    ap.add_argument("--table", default="range", choices=["range", "and", "xor"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-log-n", type=int, default=0, help="force the CPU sample size")
+    ap.add_argument("--no-profile", action="store_true")
+    return ap.parse_args()
+
+
+def make_table(hl, kind):
+    if kind == "range":
+        return hl.LassoTable.range(2, 16), "2^%d range-check Lasso lookup (32-bit values, 2x16-bit identity subtable)"
+    k = hl.SUBTABLE_AND if kind == "and" else hl.SUBTABLE_XOR
+    return hl.LassoTable.bitwise(k, 4, 16), "2^%d " + kind.upper() + " Lasso lookup (32-bit operands, 4 chunks of 8+8 bits)"
+
+
+def gen_dims(table, n, rank):
+    rng = np.random.Generator(np.random.PCG64(SEED_BASE + n + 1000003 * rank))
+    return [rng.integers(0, 1 << table.l, size=1 << n, dtype=np.uint32) for _ in range(table.c)]
+
+
+def trapdoor(nv):
+    rng = np.random.Generator(np.random.PCG64(SEED_BASE))
+    return [int.from_bytes(rng.bytes(31), "little") + 1 for _ in range(nv)]
+
+
+def aggregate(recs):
+    by = {}
+    for r in recs:
+        a = by.setdefault(r["name"], dict(name=r["name"], launches=0, ms=0.0, bytes=0.0, muls=0.0, big=None))
+        a["launches"] += 1
+        a["ms"] += r["ms"]
+        a["bytes"] += r["bytes"]
+        a["muls"] += r["muls"]
+        if a["big"] is None or r["bytes"] > a["big"]["bytes"]:
+            a["big"] = r
+    return sorted(by.values(), key=lambda a: -a["ms"])
+
+
+def fr_mul_peak(hl, ctx):
+    """measured peak Fr multiplications / s (dependent chains, full occupancy)"""
+    n, iters = 1 << 22, 64
+    rng = np.random.default_rng(3)
+    raw = rng.integers(0, 1 << 60, size=4 * n, dtype=np.uint64).tobytes()
+    a, b, out = ctx.upload(raw), ctx.upload(raw[::-1]), ctx.alloc(32 * n)
+    best = 0.0
+    for _ in range(3):
+        ctx.lib.lh_fr_mul_chain(ctx.h, a.ptr, b.ptr, n, iters, out.ptr)
+        ctx.sync()
+        t = time.perf_counter()
+        ctx.lib.lh_fr_mul_chain(ctx.h, a.ptr, b.ptr, n, iters, out.ptr)
+        ctx.sync()
+        best = max(best, n * iters / (time.perf_counter() - t))
+    return best
+
+
+def cpu_baseline(hl, ctx, pp, table, kind, args, gpu_proof_fn):
+    from oracle import cpu_oracle as co
+    # a library tuned for this host if the toolchain is here; else the portable prebuilt one
+    try:
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle", "cpu"), "NATIVE=1"], check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+        native = os.path.join(ROOT, "oracle", "_build", "liboracle_cpu_native.so")
+        if os.path.exists(native):
+            co.LIB_PATH = native
+            co._lib = None
+    except Exception:
+        pass
+    cores = co.num_threads()
+    srs_nv = pp.num_vars
+    total = (2 << srs_nv) - 1
+    srs = C.create_string_buffer(64 * total)
+    hl._check(ctx.lib.lh_srs_download(ctx.h, pp.h, srs))
+    tc = table.to_c()
+
+    def run(n):
+        dims = gen_dims(table, n, 0)
+        tr = co.Transcript()
+        t = time.perf_counter()
+        co.lasso_prove(tr, srs, srs_nv, tc, n, [d.tobytes() for d in dims])
+        return (time.perf_counter() - t) * 1e3, tr.into_proof(), dims
+
+    n = args.cpu_sample_log_n
+    if not n:
+        # calibrate on 2^16, then take the largest sample expected to stay under ~25 s
+        ms16, _, _ = run(min(16, args.log_n))
+        n = min(16, args.log_n)
+        while n < args.log_n and ms16 * (1 << (n + 1 - 16)) < 25e3:
+            n += 1
+    ms, proof, dims = run(n)
+    same = gpu_proof_fn(n, dims) == proof
+    frac = "the full workload" if n == args.log_n else "1/%d of the workload's lookups" % (1 << (args.log_n - n))
+    return {"value": round(ms, 2), "unit": "ms", "cores": cores, "kind": "port",
+            "sample": ("one Lasso prove of " + kind + " at 2^%d lookups (" + frac + "), same SRS and PRNG stream as the "
+                       "GPU run; C++ oracle = reference algorithms, chunk-per-thread") % n,
+            "sample_log_n": n, "proof_bytes_equal_gpu": bool(same)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo", rank=rank, world_size=world)
+
+    import halo2_lasso_amd as hl
+    ctx = hl.Context(local_rank)
+    n = args.log_n
+    table, desc = make_table(hl, args.table)
+    pp = hl.MultilinearKzg.setup(ctx, trapdoor(max(n, table.l)))
+    d_dims = [ctx.upload(d.tobytes()) for d in gen_dims(table, n, rank)]
+    ctx.sync()
+
+    def prove(nn=n, bufs=d_dims):
+        tr = hl.Keccak256Transcript()
+        hl.lasso_prove(pp, table, nn, bufs, tr)
+        return tr
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        prove()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr = prove()
+    ctx.sync()
+    elapsed = time.perf_counter() - t0
+    phases = hl.lasso_last_timing(ctx)
+    if dist is not None:
+        import torch
+        torch.cuda.synchronize()
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if torch.cuda.is_available() else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+    ms_per_step = elapsed * 1e3 / max(args.steps, 1)
+    proof_len = len(tr.into_proof())
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "lasso_prove_time_ms", "value": round(ms_per_step / world, 3), "unit": "ms",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "u256 (BN254 Fr/Fq, 8x u32 Montgomery)",
+            "data": "synthetic",
+            "config": {"workload": desc % n, "lookups_per_proof": 1 << n, "proofs_per_step": world,
+                       "pcs": "multilinear KZG (BN254)", "proof_bytes": proof_len,
+                       "parallelism": "1 proof per GPU" if world > 1 else "1 GPU"},
+            "lookups_per_s": round((1 << n) * world / (ms_per_step / 1e3)),
+            "phases_ms": {k: round(v, 3) for k, v in phases.items()},
+        }
+        if not args.no_profile:
+            hl.profile_enable(ctx, True)
+            prove()
+            ctx.sync()
+            aggs = aggregate(hl.profile_read(ctx))
+            hl.profile_enable(ctx, False)
+            tot = sum(a["ms"] for a in aggs) or 1.0
+            peak_mul = fr_mul_peak(hl, ctx)
+            dom = aggs[0]
+            big = dom["big"]
+            ach = big["bytes"] / (big["ms"] * 1e-3) / 1e9 if big["ms"] > 0 else 0.0
+            out["roofline"] = {"bound": "hbm", "kernel": dom["name"], "achieved": round(ach, 1), "peak": 8000.0,
+                               "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
+                               "launch": {"ms": round(big["ms"], 4), "bytes": big["bytes"], "items": big["items"]},
+                               "share_of_profiled_prove": round(dom["ms"] / tot, 3), "launches": dom["launches"]}
+            mul_rate = big["muls"] / (big["ms"] * 1e-3) if big["ms"] > 0 else 0.0
+            out["alu"] = {"bound": "int32-mul", "kernel": dom["name"], "achieved": round(mul_rate / 1e9, 2),
+                          "peak": round(peak_mul / 1e9, 2), "unit": "G Fr-mul/s", "frac": round(mul_rate / peak_mul, 4)}
+            out["kernels"] = [{"name": a["name"], "launches": a["launches"], "ms": round(a["ms"], 3),
+                               "GBps_all": round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1) if a["ms"] > 0 else 0.0,
+                               "GBps_largest": round(a["big"]["bytes"] / (a["big"]["ms"] * 1e-3) / 1e9, 1)
+                               if a["big"]["ms"] > 0 else 0.0}
+                              for a in aggs[:12]]
+        if not args.no_cpu_baseline:
+            def gpu_proof(nn, dims):
+                bufs = [ctx.upload(d.tobytes()) for d in dims]
+                return prove(nn, bufs).into_proof()
+            try:
+                out["cpu_baseline"] = cpu_baseline(hl, ctx, pp, table, args.table, args, gpu_proof)
+            except Exception as e:  # the oracle is a checker; its absence must not hide the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "ms", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": "unavailable: %s" % e}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

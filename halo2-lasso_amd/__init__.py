@@ -535,3 +535,16 @@ def lasso_last_timing(ctx):
     _check(ctx.lib.lh_lasso_last_timing(ctx.h, out))
     names = ["witness", "commit", "surge", "leaves", "gkr", "evals", "open_n", "open_l", "total"]
     return dict(zip(names, list(out)))
+
+
+def profile_enable(ctx, on=True):
+    _check(ctx.lib.lh_profile_enable(ctx.h, 1 if on else 0))
+
+
+def profile_read(ctx):
+    """-> list of dicts {name, ms, bytes, muls, items}, one per instrumented launch since enable."""
+    n = C.c_size_t()
+    _check(ctx.lib.lh_profile_read(ctx.h, None, 0, C.byref(n)))
+    arr = (_ffi.lh_prof_rec * max(n.value, 1))()
+    _check(ctx.lib.lh_profile_read(ctx.h, arr, n.value, C.byref(n)))
+    return [dict(name=r.name.decode(), ms=r.ms, bytes=r.bytes, muls=r.muls, items=r.items) for r in arr[:n.value]]

@@ -363,4 +363,21 @@ lh_status lh_lasso_last_timing(lh_ctx* ctx, double* out_ms) {
   LH_CATCH
 }
 
+lh_status lh_profile_enable(lh_ctx* ctx, int on) {
+  LH_TRY NEED(ctx);
+  ctx->c.sync();
+  ctx->c.prof = on != 0;
+  ctx->c.prof_recs.clear();
+  LH_CATCH
+}
+lh_status lh_profile_read(lh_ctx* ctx, lh_prof_rec* out, size_t cap, size_t* count) {
+  LH_TRY NEED(ctx);
+  NEED(count);
+  static_assert(sizeof(lh_prof_rec) == sizeof(lh::ProfRec), "profile record layout");
+  size_t n = ctx->c.prof_recs.size();
+  *count = n;
+  if (out && cap) memcpy(out, ctx->c.prof_recs.data(), (n < cap ? n : cap) * sizeof(lh_prof_rec));
+  LH_CATCH
+}
+
 }  // extern "C"

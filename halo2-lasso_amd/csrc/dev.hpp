@@ -69,6 +69,18 @@ struct ArenaScope {
   ~ArenaScope() { a.release(m); }
 };
 
+// ------------------------------------------------------------------ per-kernel profiling (off by default)
+// When enabled every instrumented launch is bracketed by HIP events on the ctx stream and synchronised,
+// so the per-kernel durations are exact but the prove as a whole is slower: bench.py runs its timed
+// region with profiling off and a separate profiled pass for the roofline numbers.
+struct ProfRec {
+  char name[40];
+  double ms;     // HIP-event duration
+  double bytes;  // algorithmic bytes of the launch (SURVEY.md §8d formulas)
+  double muls;   // field multiplications of the launch (integer-ALU roofline)
+  double items;  // work items (pairs, points, ...)
+};
+
 // ------------------------------------------------------------------ context
 struct Ctx {
   int device = 0;
@@ -79,8 +91,36 @@ struct Ctx {
   size_t pinned_bytes = 0;
   int num_cus = 256;
   double lasso_ms[LH_LASSO_NUM_PHASES] = {0};
+  bool prof = false;
+  std::vector<ProfRec> prof_recs;
+  hipEvent_t prof_ev[2] = {nullptr, nullptr};
   void* pin(size_t bytes);  // grows the pinned buffer if needed
   void sync() { LH_HIP(hipStreamSynchronize(stream)); }
+};
+
+struct ProfScope {
+  Ctx& c;
+  ProfRec rec;
+  bool on;
+  ProfScope(Ctx& c_, const char* name, double bytes, double muls, double items) : c(c_), on(c_.prof) {
+    if (!on) return;
+    snprintf(rec.name, sizeof rec.name, "%s", name);
+    rec.bytes = bytes, rec.muls = muls, rec.items = items, rec.ms = 0;
+    if (!c.prof_ev[0]) {
+      LH_HIP(hipEventCreate(&c.prof_ev[0]));
+      LH_HIP(hipEventCreate(&c.prof_ev[1]));
+    }
+    LH_HIP(hipEventRecord(c.prof_ev[0], c.stream));
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(c.prof_ev[1], c.stream);
+    (void)hipEventSynchronize(c.prof_ev[1]);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, c.prof_ev[0], c.prof_ev[1]);
+    rec.ms = ms;
+    c.prof_recs.push_back(rec);
+  }
 };
 
 // ------------------------------------------------------------------ kernel launchers (kernels_poly.hip)

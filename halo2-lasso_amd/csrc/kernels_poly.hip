@@ -33,6 +33,7 @@ void k_fr_from_u64(Ctx& c, const uint64_t* in, size_t n, Fr* out) {
   if (n) hipLaunchKernelGGL(fr_from_u64_kernel, grid_for(n), 256, 0, c.stream, in, n, out);
 }
 void k_fr_from_u32(Ctx& c, const uint32_t* in, size_t n, Fr* out) {
+  ProfScope ps(c, "fr_from_u32", 36.0 * n, 1.0 * n, (double)n);
   if (n) hipLaunchKernelGGL(fr_from_u32_kernel, grid_for(n), 256, 0, c.stream, in, n, out);
 }
 void k_fr_to_repr(Ctx& c, const Fr* in, size_t n, Fr* out) {
@@ -111,6 +112,7 @@ __global__ void fix_var_kernel(const Fr* __restrict__ in, size_t n_out, Fr x, Fr
   }
 }
 void k_fix_var(Ctx& c, const Fr* in, size_t n_in, const Fr& x, Fr* out) {
+  ProfScope ps(c, "fix_var", 96.0 * (n_in >> 1), 1.0 * (n_in >> 1), (double)(n_in >> 1));
   size_t n_out = n_in >> 1;
   if (n_out) hipLaunchKernelGGL(fix_var_kernel, grid_for(n_out), 256, 0, c.stream, in, n_out, x, out);
 }
@@ -128,6 +130,7 @@ __global__ void fix_var_multi_kernel(PtrPack p, size_t n_out, Fr x) {
   }
 }
 void k_fix_var_multi(Ctx& c, const Fr* const* in, Fr* const* out, size_t count, size_t n_in, const Fr& x) {
+  ProfScope ps(c, "fix_var_multi", 96.0 * (n_in >> 1) * count, 1.0 * (n_in >> 1) * count, (double)(n_in >> 1) * count);
   size_t n_out = n_in >> 1;
   if (!n_out) return;
   for (size_t base = 0; base < count; base += SC_MAX_TABLES) {
@@ -192,6 +195,7 @@ __global__ void eq_expand_kernel(const Fr* __restrict__ cur, size_t n_cur, Fr y,
 __global__ void fr_set_one_kernel(Fr* p) { p[0] = Fr::one(); }
 
 void k_eq_xy(Ctx& c, const Fr* y, size_t num_vars, Fr* out) {
+  ProfScope ps(c, "eq_xy", 64.0 * ((size_t)1 << num_vars), 1.0 * ((size_t)1 << num_vars), (double)((size_t)1 << num_vars));
   // ping-pong so that the final level (2^num_vars) is written to `out`
   ArenaScope scope(c.arena);
   size_t half = num_vars ? (size_t)1 << (num_vars - 1) : 1;
@@ -223,6 +227,7 @@ __global__ void lincomb_kernel(LcPack pk, int count, size_t n, Fr* __restrict__ 
   }
 }
 void k_lincomb(Ctx& c, const Fr* const* polys, const Fr* w, size_t count, size_t n, Fr* out) {
+  ProfScope ps(c, "lincomb", 32.0 * n * (count + 1), 1.0 * n * count, (double)n);
   if (!n) return;
   if (count == 0) {
     LH_HIP(hipMemsetAsync(out, 0, n * sizeof(Fr), c.stream));
@@ -272,6 +277,7 @@ __global__ void reduce_rows_kernel(const Fr* __restrict__ partials, int per_row,
 template <bool U32>
 static void inner_products_impl(Ctx& c, const void* const* polys, size_t count, const Fr* weights, size_t n,
                                 Fr* out_host) {
+  ProfScope ps(c, "inner_products", 32.0 * n * (count + 1), 1.0 * n * count, (double)n);
   if (!count) return;
   ArenaScope scope(c.arena);
   dim3 g = grid_for(n, 256, 1024);
@@ -303,6 +309,7 @@ __global__ void tree_up_kernel(const Fr* __restrict__ in, size_t half, Fr* __res
   GSTRIDE(i, half) out[i] = mul(in[i], in[half + i]);
 }
 void k_tree_up(Ctx& c, const Fr* in, size_t half, Fr* out) {
+  ProfScope ps(c, "tree_up", 96.0 * half, 1.0 * half, (double)half);
   if (half) hipLaunchKernelGGL(tree_up_kernel, grid_for(half), 256, 0, c.stream, in, half, out);
 }
 // reference fractional_sum_check.rs:62-85 `Layer::up`
@@ -315,6 +322,7 @@ __global__ void frac_up_kernel(const Fr* __restrict__ p, const Fr* __restrict__ 
   }
 }
 void k_frac_up(Ctx& c, const Fr* p, const Fr* q, size_t half, Fr* vp, Fr* vq) {
+  ProfScope ps(c, "frac_up", 192.0 * half, 3.0 * half, (double)half);
   if (half) hipLaunchKernelGGL(frac_up_kernel, grid_for(half), 256, 0, c.stream, p, q, half, vp, vq);
 }
 
@@ -330,6 +338,7 @@ __global__ void quotient_step_kernel(const Fr* __restrict__ rem, size_t half, Fr
   }
 }
 void k_quotient_step(Ctx& c, const Fr* rem, size_t half, const Fr& x, Fr* q, Fr* rem_out) {
+  ProfScope ps(c, "quotient_step", 128.0 * half, 1.0 * half, (double)half);
   if (half) hipLaunchKernelGGL(quotient_step_kernel, grid_for(half), 256, 0, c.stream, rem, half, x, q, rem_out);
 }
 
@@ -388,6 +397,7 @@ __global__ void lasso_tile_rank_kernel(const uint32_t* __restrict__ dim, size_t 
   }
 }
 void k_lasso_counters(Ctx& c, const uint32_t* dim, size_t n, size_t m, uint32_t* read_ts, uint32_t* final_cts) {
+  ProfScope ps(c, "lasso_counters", 8.0 * n + 4.0 * m, 0.0, (double)n);
   ArenaScope scope(c.arena);
   size_t tiles = (n + CNT_TILE - 1) / CNT_TILE;
   uint32_t* tile_hist = c.arena.alloc_n<uint32_t>(tiles * m);
@@ -417,6 +427,7 @@ __global__ void lasso_output_kernel(LassoG g, size_t n, Fr* __restrict__ a) {
   }
 }
 void k_lasso_output(Ctx& c, const LassoG& g, size_t n, Fr* a) {
+  ProfScope ps(c, "lasso_output", 36.0 * n, 2.0 * n, (double)n);
   if (n) hipLaunchKernelGGL(lasso_output_kernel, grid_for(n), 256, 0, c.stream, g, n, a);
 }
 
@@ -436,6 +447,7 @@ __global__ void lasso_rw_leaves_kernel(const uint32_t* __restrict__ dim, const u
 }
 void k_lasso_rw_leaves(Ctx& c, const uint32_t* dim, const uint32_t* e, const uint32_t* ts, size_t n, const Fr& gamma,
                        const Fr& gamma2, const Fr& tau, Fr* rs, Fr* ws) {
+  ProfScope ps(c, "lasso_rw_leaves", (12.0 + 64.0) * n, 5.0 * n, (double)n);
   if (n)
     hipLaunchKernelGGL(lasso_rw_leaves_kernel, grid_for(n), 256, 0, c.stream, dim, e, ts, n, gamma, gamma2, tau, rs,
                        ws);
@@ -452,6 +464,7 @@ __global__ void lasso_if_leaves_kernel(int kind, uint32_t bits, const uint32_t* 
 }
 void k_lasso_if_leaves(Ctx& c, int subtable, uint32_t chunk_bits, const uint32_t* final_cts, size_t m,
                        const Fr& gamma, const Fr& gamma2, const Fr& tau, Fr* init, Fr* fin) {
+  ProfScope ps(c, "lasso_if_leaves", (4.0 + 64.0) * m, 5.0 * m, (double)m);
   if (m)
     hipLaunchKernelGGL(lasso_if_leaves_kernel, grid_for(m), 256, 0, c.stream, subtable, chunk_bits, final_cts, m,
                        gamma, gamma2, tau, init, fin);

@@ -152,6 +152,18 @@ void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, F
   size_t cap = (size_t)c.num_cus * 4;
   if (g > cap) g = cap;
   Fr* partials = g == 1 ? evals_host : c.arena.alloc_n<Fr>(g * degree);
+  {
+    // algorithmic bytes: fused round = bind bytes only, 96 B per bound entry = 192 B per
+    // pair and table; the unfused first round reads 64 B per pair and table.
+    size_t tabs = 0;
+    for (int t = 0; t < SC_MAX_TABLES; t++) tabs += seen[t] ? 1 : 0;
+    double nfac = 0, ncoef = 0;
+    for (uint32_t m = 0; m < rd.num_terms; m++) nfac += rd.nfac[m], ncoef += rd.coeff_is_one[m] ? 0 : 2;
+    double muls_pair = (nfac - rd.num_terms) * degree + ncoef + (rd.global_eq >= 0 ? degree : 0) +
+                       (bind ? 2.0 * (nfac + (rd.global_eq >= 0 ? 1 : 0)) : 0.0);
+    char name[40];
+    snprintf(name, sizeof name, "sc_round<%d,%s>%s", degree, bind ? "bind" : "first", tp > 1 ? "/tp" : "");
+    ProfScope ps(c, name, (bind ? 192.0 : 64.0) * (double)size * (double)tabs, muls_pair * (double)size, (double)size);
   switch (degree) {
     case 1: launch_round<1>(c, a, bind, size, tp, (unsigned)g, partials); break;
     case 2: launch_round<2>(c, a, bind, size, tp, (unsigned)g, partials); break;
@@ -159,6 +171,7 @@ void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, F
     case 4: launch_round<4>(c, a, bind, size, tp, (unsigned)g, partials); break;
     case 5: launch_round<5>(c, a, bind, size, tp, (unsigned)g, partials); break;
     default: launch_round<6>(c, a, bind, size, tp, (unsigned)g, partials); break;
+  }
   }
   if (g > 1) hipLaunchKernelGGL(sc_reduce_kernel, dim3(1), dim3(256), 0, c.stream, partials, (int)g, degree, evals_host);
   c.sync();

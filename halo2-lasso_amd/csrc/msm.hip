@@ -428,23 +428,46 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
       LH_HIP(hipMemsetAsync(counts, 0, (ncounts + 1) * sizeof(uint32_t), c.stream));
       LH_HIP(hipMemsetAsync(buckets, 0, nbuckets * sizeof(G1Xyzz), c.stream));
       dim3 g((unsigned)std::min<size_t>((max_n + 255) / 256, 2048), (unsigned)nj);
-      hipLaunchKernelGGL(msm_digits_kernel<false>, g, dim3(256), 0, c.stream, plan, counts, nullptr, nullptr);
+      double total_pts = 0, full_pts = 0;
+      for (size_t j = 0; j < nj; j++) total_pts += plan.job[j].n, full_pts += plan.job[j].is_u32 ? 0 : plan.job[j].n;
+      {
+        ProfScope ps(c, "msm_digits_count", 32.0 * full_pts + 4.0 * (total_pts - full_pts), full_pts, total_pts);
+        hipLaunchKernelGGL(msm_digits_kernel<false>, g, dim3(256), 0, c.stream, plan, counts, nullptr, nullptr);
+      }
+      {
+        ProfScope ps(c, "msm_scan", 8.0 * (ncounts + 1), 0, (double)ncounts);
       hipLaunchKernelGGL(scan_tile_sums_kernel, dim3((unsigned)ntiles), dim3(256), 0, c.stream, counts, ncounts + 1,
                          tile_sums);
       hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(256), 0, c.stream, tile_sums, ntiles, total);
       hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)ntiles), dim3(256), 0, c.stream, counts, ncounts + 1,
                          tile_sums);
-      hipLaunchKernelGGL(msm_digits_kernel<true>, g, dim3(256), 0, c.stream, plan, counts, skey, sidx);
+      }
+      {
+        ProfScope ps(c, "msm_digits_scatter", 32.0 * full_pts + 4.0 * (total_pts - full_pts) + 8.0 * max_entries, full_pts,
+                     total_pts);
+        hipLaunchKernelGGL(msm_digits_kernel<true>, g, dim3(256), 0, c.stream, plan, counts, skey, sidx);
+      }
 
       // segmented accumulate, level 0 then K-fold shrinking continuation lists
       uint32_t K = max_entries > ((size_t)1 << 22) ? 16 : max_entries > ((size_t)1 << 18) ? 8 : 4;
       size_t nchunks = (max_entries + K - 1) / K;
       uint32_t* ckey = c.arena.alloc_n<uint32_t>(nchunks);
       G1Xyzz* cpt = c.arena.alloc_n<G1Xyzz>(nchunks);
+      uint32_t h_total = 0;
+      if (c.prof) {
+        LH_HIP(hipMemcpyAsync(&h_total, total, 4, hipMemcpyDeviceToHost, c.stream));
+        c.sync();
+      }
+      {
+        // MSM algorithmic bytes: 96 B per point (32 B scalar + 64 B base); a mixed add is 10 Fq muls
+        ProfScope ps(c, "msm_accumulate0", 72.0 * h_total, 10.0 * h_total, (double)h_total);
       hipLaunchKernelGGL(msm_accumulate0_kernel, dim3((unsigned)std::min<size_t>((nchunks + 127) / 128, 1 << 16)),
                          dim3(128), 0, c.stream, plan, total, skey, sidx, K, buckets, ckey, cpt, nchunks, lvl_cnt);
+      }
       size_t n_in = nchunks;
       const uint32_t K2 = 8;
+      {
+        ProfScope ps(c, "msm_accumulate_levels", 0, 0, (double)nchunks);
       int lvl = 0;
       while (true) {
         size_t nc = (n_in + K2 - 1) / K2;
@@ -459,9 +482,13 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
         cpt = opt;
         n_in = nc;
       }
+      }
+      {
+        ProfScope ps(c, "msm_bucket_reduce", 128.0 * nbuckets, 14.0 * 2.2 * nbuckets, (double)nbuckets);
       hipLaunchKernelGGL(msm_segment_reduce_kernel, dim3((unsigned)std::min<size_t>((nsegs + 63) / 64, 1 << 16)),
                          dim3(64), 0, c.stream, plan, buckets, seg_out, nsegs);
       hipLaunchKernelGGL(msm_window_sum_kernel, dim3((unsigned)nwins), dim3(256), 0, c.stream, plan, seg_out, win_out);
+      }
       LH_HIP(hipMemcpyAsync(wins.data(), win_out, nwins * sizeof(G1Xyzz), hipMemcpyDeviceToHost, c.stream));
       c.sync();
     }

@@ -201,6 +201,20 @@ lh_status lh_lasso_prove(lh_ctx*, const lh_srs*, const lh_lasso_table*, size_t n
 #define LH_LASSO_NUM_PHASES 9
 lh_status lh_lasso_last_timing(lh_ctx*, double* out_ms);
 
+/* ---------------------------------------------------------------- measurement (bench.py)
+ * Per-kernel HIP-event timing on the ctx stream.  While enabled every instrumented launch is
+ * synchronised, so whole-prove wall time is NOT representative; use a separate pass. */
+typedef struct lh_prof_rec {
+  char name[40];
+  double ms;    /* HIP-event duration of the launch */
+  double bytes; /* algorithmic bytes of the launch */
+  double muls;  /* field multiplications of the launch */
+  double items; /* work items of the launch */
+} lh_prof_rec;
+lh_status lh_profile_enable(lh_ctx*, int on); /* also clears the record list */
+/* copies up to `cap` records, returns the total number recorded in *count */
+lh_status lh_profile_read(lh_ctx*, lh_prof_rec* out, size_t cap, size_t* count);
+
 #ifdef __cplusplus
 }
 #endif
