@@ -46,6 +46,8 @@ lh_status lh_ctx_create(int device_id, lh_ctx** out) {
   LH_HIP(hipGetDeviceProperties(&prop, device_id));
   ctx->c.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   ctx->c.pin(65536);
+  LH_HIP(hipHostMalloc((void**)&ctx->c.flag, 64, hipHostMallocCoherent | hipHostMallocMapped));
+  *ctx->c.flag = 0;
   *out = ctx;
   LH_CATCH
 }
@@ -55,6 +57,7 @@ void lh_ctx_destroy(lh_ctx* ctx) {
   (void)hipSetDevice(ctx->c.device);
   (void)hipStreamSynchronize(ctx->c.stream);
   if (ctx->c.pinned) (void)hipHostFree(ctx->c.pinned);
+  if (ctx->c.flag) (void)hipHostFree(ctx->c.flag);
   (void)hipStreamDestroy(ctx->c.stream);
   delete ctx;
 }

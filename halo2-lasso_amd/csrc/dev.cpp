@@ -47,11 +47,28 @@ void Arena::release(Mark m) {
   blocks_[cur_].used = m.used;
 }
 
+void Ctx::wait_flag(uint32_t seq) {
+  volatile uint32_t* f = flag;
+  for (uint64_t spin = 0;; spin++) {
+    if (*f == seq) return;
+    __builtin_ia32_pause();
+    if ((spin & 0xfffff) == 0xfffff) {
+      // a failed launch never publishes: ask the runtime instead of spinning forever
+      hipError_t e = hipStreamQuery(stream);
+      if (e == hipSuccess) {
+        if (*f == seq) return;
+        throw Error(LH_ERR_DEVICE, "kernel finished without publishing its result");
+      }
+      if (e != hipErrorNotReady) throw Error(LH_ERR_DEVICE, std::string("stream error: ") + hipGetErrorString(e));
+    }
+  }
+}
+
 void* Ctx::pin(size_t bytes) {
   if (bytes > pinned_bytes) {
     if (pinned) (void)hipHostFree(pinned);
     size_t want = bytes < 65536 ? 65536 : bytes;
-    LH_HIP(hipHostMalloc(&pinned, want, hipHostMallocDefault));
+    LH_HIP(hipHostMalloc(&pinned, want, hipHostMallocCoherent | hipHostMallocMapped));
     pinned_bytes = want;
   }
   return pinned;

@@ -96,6 +96,13 @@ struct Ctx {
   hipEvent_t prof_ev[2] = {nullptr, nullptr};
   void* pin(size_t bytes);  // grows the pinned buffer if needed
   void sync() { LH_HIP(hipStreamSynchronize(stream)); }
+  // Round-trip fast path: a kernel publishes its (small) result into pinned memory and then stores a
+  // sequence number with system-scope release; the host spins on it instead of going through
+  // hipStreamSynchronize (tens of microseconds per call, paid once per sum-check round).
+  uint32_t* flag = nullptr;  // pinned, coherent
+  uint32_t flag_seq = 0;
+  uint32_t next_seq() { return ++flag_seq; }
+  void wait_flag(uint32_t seq);
 };
 
 struct ProfScope {
@@ -147,6 +154,9 @@ void k_inner_products_u32(Ctx&, const uint32_t* const* polys, size_t count, cons
                           Fr* out_host);
 // product tree level: out[i] = in[i] * in[half + i]
 void k_tree_up(Ctx&, const Fr* in, size_t half, Fr* out);
+// every level above level H[i] (2^(H+1) nodes at in[i], H <= 9) of `count` product trees, one launch:
+// level h < H lands at out[i] + (2^(h+1) - 2)
+void k_tree_tops(Ctx&, const Fr* const* in, Fr* const* out, const int* H, size_t count);
 // fractional layer: (p_l q_r + p_r q_l, q_l q_r)
 void k_frac_up(Ctx&, const Fr* p, const Fr* q, size_t half, Fr* vp, Fr* vq);
 // KZG quotient step at level i: q = hi - lo ; lo' = lo + (hi - lo) * x

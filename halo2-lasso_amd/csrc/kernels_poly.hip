@@ -2,6 +2,7 @@
 // All are HBM- or integer-ALU-bound streams: 256-thread blocks, grid-stride, 16-B vector
 // accesses (an Fr is two dwordx4), no LDS except for block reductions.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include "dev.hpp"
 #include "reduce.cuh"
 
@@ -150,20 +151,25 @@ void k_fix_var_multi(Ctx& c, const Fr* const* in, Fr* const* out, size_t count, 
 struct FirstPack {
   const Fr* in[SC_MAX_TABLES];
 };
-__global__ void bind_first_kernel(FirstPack p, int count, Fr x, Fr* __restrict__ out) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void bind_first_kernel(FirstPack p, int count, Fr x, Fr* __restrict__ out, uint32_t* flag, uint32_t seq) {
+  int i = threadIdx.x;
   if (i < count) {
     Fr e0 = p.in[i][0], e1 = p.in[i][1];
     out[i] = add(mul(sub(e1, e0), x), e0);
   }
+  // one wave: every lane's stores are ordered before lane 0's release by the system-scope fence
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  __builtin_amdgcn_s_barrier();
+  if (i == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 void k_bind_first(Ctx& c, const Fr* const* in, size_t count, const Fr& x, Fr* out_host) {
   LH_REQUIRE(count <= (size_t)SC_MAX_TABLES, LH_ERR_ARG, "bind_first: too many tables");
   if (!count) return;
   FirstPack p;
   for (size_t i = 0; i < count; i++) p.in[i] = in[i];
-  hipLaunchKernelGGL(bind_first_kernel, dim3(1), dim3(64), 0, c.stream, p, (int)count, x, out_host);
-  c.sync();
+  const uint32_t seq = c.next_seq();
+  hipLaunchKernelGGL(bind_first_kernel, dim3(1), dim3(64), 0, c.stream, p, (int)count, x, out_host, c.flag, seq);
+  c.wait_flag(seq);
 }
 // out[i] = first `k` entries of each of `count` tables, to (pinned) host memory
 __global__ void gather_heads_kernel(FirstPack p, int count, int k, Fr* __restrict__ out) {
@@ -194,8 +200,64 @@ __global__ void eq_expand_kernel(const Fr* __restrict__ cur, size_t n_cur, Fr y,
 }
 __global__ void fr_set_one_kernel(Fr* p) { p[0] = Fr::one(); }
 
+// first EQ_SMALL levels of an eq table in one workgroup (LDS ping-pong): the GKR calls eq_xy once per layer
+// and most layers are tiny, so one launch instead of num_vars launches is what matters there.
+constexpr int EQ_SMALL = 9;
+struct EqYs {
+  Fr y[EQ_SMALL];
+};
+__global__ __launch_bounds__(256) void eq_small_kernel(EqYs ys, int levels, Fr* __restrict__ out) {
+  __shared__ Fr a[1 << EQ_SMALL];
+  __shared__ Fr b[1 << (EQ_SMALL - 1)];
+  Fr* cur = (levels & 1) ? b : a;  // after `levels` flips the result sits in `a`
+  Fr* nxt = (levels & 1) ? a : b;
+  if (threadIdx.x == 0) cur[0] = Fr::one();
+  __syncthreads();
+  int n = 1;
+  for (int i = 0; i < levels; i++) {
+    const Fr yi = ys.y[i];  // ys.y[i] is the variable expanded at step i (caller passes them last-to-first)
+    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+      Fr e = cur[k];
+      Fr hi = mul(e, yi);
+      nxt[2 * k + 1] = hi;
+      nxt[2 * k] = sub(e, hi);
+    }
+    __syncthreads();
+    Fr* t = cur;
+    cur = nxt;
+    nxt = t;
+    n <<= 1;
+  }
+  for (int k = threadIdx.x; k < n; k += blockDim.x) out[k] = cur[k];
+}
+
 void k_eq_xy(Ctx& c, const Fr* y, size_t num_vars, Fr* out) {
   ProfScope ps(c, "eq_xy", 64.0 * ((size_t)1 << num_vars), 1.0 * ((size_t)1 << num_vars), (double)((size_t)1 << num_vars));
+  {
+    // levels are expanded from the LAST y to the first (multilinear.rs:103): the small kernel does the
+    // first min(num_vars, EQ_SMALL) of them
+    const int small = (int)std::min<size_t>(num_vars, EQ_SMALL);
+    EqYs ys;
+    for (int i = 0; i < small; i++) ys.y[i] = y[num_vars - 1 - i];
+    if ((size_t)small == num_vars) {
+      hipLaunchKernelGGL(eq_small_kernel, dim3(1), dim3(256), 0, c.stream, ys, small, out);
+      return;
+    }
+    ArenaScope scope(c.arena);
+    size_t half = (size_t)1 << (num_vars - 1);
+    Fr* tmp = c.arena.alloc_n<Fr>(half);
+    Fr* bufs[2] = {out, tmp};
+    const size_t rest = num_vars - small;
+    int cur = (rest & 1) ? 1 : 0;  // after `rest` more flips we must end in bufs[0]
+    hipLaunchKernelGGL(eq_small_kernel, dim3(1), dim3(256), 0, c.stream, ys, small, bufs[cur]);
+    size_t n = (size_t)1 << small;
+    for (size_t i = rest; i-- > 0;) {
+      hipLaunchKernelGGL(eq_expand_kernel, grid_for(n), 256, 0, c.stream, bufs[cur], n, y[i], bufs[cur ^ 1]);
+      cur ^= 1;
+      n <<= 1;
+    }
+    return;
+  }
   // ping-pong so that the final level (2^num_vars) is written to `out`
   ArenaScope scope(c.arena);
   size_t half = num_vars ? (size_t)1 << (num_vars - 1) : 1;
@@ -312,6 +374,58 @@ void k_tree_up(Ctx& c, const Fr* in, size_t half, Fr* out) {
   ProfScope ps(c, "tree_up", 96.0 * half, 1.0 * half, (double)half);
   if (half) hipLaunchKernelGGL(tree_up_kernel, grid_for(half), 256, 0, c.stream, in, half, out);
 }
+// All levels above a small level of a product tree in one workgroup per tree: `in` holds 2^(H+1) nodes
+// (H <= TREE_SMALL); level h < H (2^(h+1) nodes) is written at out + (2^(h+1) - 2).
+constexpr int TREE_SMALL = 9;
+struct TreeTops {
+  const Fr* in[SC_MAX_TABLES];
+  Fr* out[SC_MAX_TABLES];
+  int H[SC_MAX_TABLES];
+};
+__global__ __launch_bounds__(256) void tree_top_kernel(TreeTops t) {
+  __shared__ Fr a[1 << TREE_SMALL];
+  __shared__ Fr b[1 << (TREE_SMALL - 1)];
+  const Fr* __restrict__ in = t.in[blockIdx.x];
+  Fr* __restrict__ out = t.out[blockIdx.x];
+  const int H = t.H[blockIdx.x];
+  if (H <= 0) return;
+  // level H-1 straight from global memory
+  int half = 1 << H;
+  for (int i = threadIdx.x; i < half; i += blockDim.x) {
+    Fr v = mul(in[i], in[half + i]);
+    a[i] = v;
+    out[(half - 2) + i] = v;
+  }
+  __syncthreads();
+  Fr* cur = a;
+  Fr* nxt = b;
+  for (int h = H - 2; h >= 0; h--) {
+    half = 1 << (h + 1);
+    for (int i = threadIdx.x; i < half; i += blockDim.x) {
+      Fr v = mul(cur[i], cur[half + i]);
+      nxt[i] = v;
+      out[(half - 2) + i] = v;
+    }
+    __syncthreads();
+    Fr* tmp = cur;
+    cur = nxt;
+    nxt = tmp;
+  }
+}
+void k_tree_tops(Ctx& c, const Fr* const* in, Fr* const* out, const int* H, size_t count) {
+  LH_REQUIRE(count <= (size_t)SC_MAX_TABLES, LH_ERR_ARG, "tree_tops: too many trees");
+  if (!count) return;
+  TreeTops t;
+  for (size_t i = 0; i < count; i++) {
+    LH_REQUIRE(H[i] <= TREE_SMALL, LH_ERR_ARG, "tree_tops: level too large");
+    t.in[i] = in[i];
+    t.out[i] = out[i];
+    t.H[i] = H[i];
+  }
+  ProfScope ps(c, "tree_tops", 0, 0, (double)count);
+  hipLaunchKernelGGL(tree_top_kernel, dim3((unsigned)count), dim3(256), 0, c.stream, t);
+}
+
 // reference fractional_sum_check.rs:62-85 `Layer::up`
 __global__ void frac_up_kernel(const Fr* __restrict__ p, const Fr* __restrict__ q, size_t half, Fr* __restrict__ vp,
                                Fr* __restrict__ vq) {

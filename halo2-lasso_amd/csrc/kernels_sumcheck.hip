@@ -43,9 +43,14 @@ __device__ __forceinline__ void load_pair(const Fr* __restrict__ in, Fr* __restr
 // `tp` (term parallelism) is 1 or num_terms: in the late, small rounds one thread per (pair, term)
 // keeps the dependent chain of a thread at one term (~15 field multiplications) instead of the
 // whole expression; the eq factor is linear, so it is applied per term before the reduction.
+__device__ __forceinline__ void publish_flag(uint32_t* flag, uint32_t seq) {
+  // results were written by this thread just before: release them to the host, then the sequence number
+  __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 template <int D, bool BIND>
 __global__ __launch_bounds__(256) void sc_round_kernel(ScArgs a, size_t size, uint32_t tp,
-                                                       Fr* __restrict__ partials) {
+                                                       Fr* __restrict__ partials, uint32_t* flag, uint32_t seq) {
   __shared__ Fr lds[4];
   const ScRound& rd = a.rd;
   Fr acc[D];
@@ -110,9 +115,11 @@ __global__ __launch_bounds__(256) void sc_round_kernel(ScArgs a, size_t size, ui
     Fr v = block_reduce_sum(acc[x], lds);
     if (threadIdx.x == 0) partials[(size_t)blockIdx.x * D + x] = v;
   }
+  if (flag && threadIdx.x == 0) publish_flag(flag, seq);  // single-workgroup launch: partials IS the host buffer
 }
 
-__global__ void sc_reduce_kernel(const Fr* __restrict__ partials, int blocks, int d, Fr* __restrict__ out) {
+__global__ void sc_reduce_kernel(const Fr* __restrict__ partials, int blocks, int d, Fr* __restrict__ out,
+                                 uint32_t* flag, uint32_t seq) {
   __shared__ Fr lds[4];
   for (int x = 0; x < d; x++) {
     Fr acc = Fr::zero();
@@ -120,14 +127,17 @@ __global__ void sc_reduce_kernel(const Fr* __restrict__ partials, int blocks, in
     acc = block_reduce_sum(acc, lds);
     if (threadIdx.x == 0) out[x] = acc;
   }
+  if (threadIdx.x == 0) publish_flag(flag, seq);
 }
 
 template <int D>
-static void launch_round(Ctx& c, const ScArgs& a, bool bind, size_t size, uint32_t tp, unsigned grid, Fr* partials) {
+static void launch_round(Ctx& c, const ScArgs& a, bool bind, size_t size, uint32_t tp, unsigned grid, Fr* partials,
+                         uint32_t* flag, uint32_t seq) {
   if (bind)
-    hipLaunchKernelGGL((sc_round_kernel<D, true>), dim3(grid), dim3(256), 0, c.stream, a, size, tp, partials);
+    hipLaunchKernelGGL((sc_round_kernel<D, true>), dim3(grid), dim3(256), 0, c.stream, a, size, tp, partials, flag, seq);
   else
-    hipLaunchKernelGGL((sc_round_kernel<D, false>), dim3(grid), dim3(256), 0, c.stream, a, size, tp, partials);
+    hipLaunchKernelGGL((sc_round_kernel<D, false>), dim3(grid), dim3(256), 0, c.stream, a, size, tp, partials, flag,
+                       seq);
 }
 
 void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, Fr* evals_host) {
@@ -152,6 +162,8 @@ void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, F
   size_t cap = (size_t)c.num_cus * 4;
   if (g > cap) g = cap;
   Fr* partials = g == 1 ? evals_host : c.arena.alloc_n<Fr>(g * degree);
+  const uint32_t seq = c.next_seq();
+  uint32_t* kflag = g == 1 ? c.flag : nullptr;
   {
     // algorithmic bytes: fused round = bind bytes only, 96 B per bound entry = 192 B per
     // pair and table; the unfused first round reads 64 B per pair and table.
@@ -165,16 +177,18 @@ void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, F
     snprintf(name, sizeof name, "sc_round<%d,%s>%s", degree, bind ? "bind" : "first", tp > 1 ? "/tp" : "");
     ProfScope ps(c, name, (bind ? 192.0 : 64.0) * (double)size * (double)tabs, muls_pair * (double)size, (double)size);
   switch (degree) {
-    case 1: launch_round<1>(c, a, bind, size, tp, (unsigned)g, partials); break;
-    case 2: launch_round<2>(c, a, bind, size, tp, (unsigned)g, partials); break;
-    case 3: launch_round<3>(c, a, bind, size, tp, (unsigned)g, partials); break;
-    case 4: launch_round<4>(c, a, bind, size, tp, (unsigned)g, partials); break;
-    case 5: launch_round<5>(c, a, bind, size, tp, (unsigned)g, partials); break;
-    default: launch_round<6>(c, a, bind, size, tp, (unsigned)g, partials); break;
+    case 1: launch_round<1>(c, a, bind, size, tp, (unsigned)g, partials, kflag, seq); break;
+    case 2: launch_round<2>(c, a, bind, size, tp, (unsigned)g, partials, kflag, seq); break;
+    case 3: launch_round<3>(c, a, bind, size, tp, (unsigned)g, partials, kflag, seq); break;
+    case 4: launch_round<4>(c, a, bind, size, tp, (unsigned)g, partials, kflag, seq); break;
+    case 5: launch_round<5>(c, a, bind, size, tp, (unsigned)g, partials, kflag, seq); break;
+    default: launch_round<6>(c, a, bind, size, tp, (unsigned)g, partials, kflag, seq); break;
   }
   }
-  if (g > 1) hipLaunchKernelGGL(sc_reduce_kernel, dim3(1), dim3(256), 0, c.stream, partials, (int)g, degree, evals_host);
-  c.sync();
+  if (g > 1)
+    hipLaunchKernelGGL(sc_reduce_kernel, dim3(1), dim3(256), 0, c.stream, partials, (int)g, degree, evals_host, c.flag,
+                       seq);
+  c.wait_flag(seq);
 }
 
 }  // namespace lh

@@ -1,6 +1,7 @@
 // Lasso lookup argument prover (Surge sum-check + offline memory checking by grand products).
 // The reference snapshot holds no Lasso code (README.md:1-9 only); the protocol and
 // transcript schedule are specified in oracle/pyref/lasso.py and reproduced here byte for byte.
+#include <algorithm>
 #include <chrono>
 #include "host.hpp"
 
@@ -21,6 +22,8 @@ void lasso_prove(Ctx& c, const Srs& srs, const lh_lasso_table& tb, size_t n, con
   LH_REQUIRE(tb.num_terms >= 1 && tb.num_terms <= LH_LASSO_MAX_TERMS, LH_ERR_ARG, "lasso: bad g term count");
   if (n > srs.num_vars || l > srs.num_vars)
     throw Error(LH_ERR_INVALID_PCS_PARAM, "Too many variates of poly to commit");
+  // every committed poly is zero-padded to nv = max(n, l) variables (spec step 1)
+  const size_t nv = std::max(n, l), NV = (size_t)1 << nv;
   for (size_t i = 0; i < alpha; i++) {
     LH_REQUIRE(tb.memory_chunk[i] < cc, LH_ERR_ARG, "lasso: memory chunk out of range");
     LH_REQUIRE(tb.memory_subtable[i] <= LH_SUBTABLE_XOR, LH_ERR_ARG, "lasso: unknown subtable");
@@ -74,11 +77,12 @@ void lasso_prove(Ctx& c, const Srs& srs, const lh_lasso_table& tb, size_t n, con
   tr.common_field_element(HFr::from_u64(alpha));
   {
     std::vector<MsmJob> jobs;
-    jobs.push_back(MsmJob{a, false, srs.eq(n), N});
-    for (size_t j = 0; j < cc; j++) jobs.push_back(MsmJob{d_dims[j], true, srs.eq(n), N});
-    for (size_t j = 0; j < cc; j++) jobs.push_back(MsmJob{rts[j], true, srs.eq(n), N});
-    for (size_t i = 0; i < alpha; i++) jobs.push_back(MsmJob{E[i], true, srs.eq(n), N});
-    for (size_t j = 0; j < cc; j++) jobs.push_back(MsmJob{fcs[j], true, srs.eq(l), M});
+    // zero padding adds nothing to an MSM: commit the unpadded columns against the first entries of eqs[nv]
+    jobs.push_back(MsmJob{a, false, srs.eq(nv), N});
+    for (size_t j = 0; j < cc; j++) jobs.push_back(MsmJob{d_dims[j], true, srs.eq(nv), N});
+    for (size_t j = 0; j < cc; j++) jobs.push_back(MsmJob{rts[j], true, srs.eq(nv), N});
+    for (size_t i = 0; i < alpha; i++) jobs.push_back(MsmJob{E[i], true, srs.eq(nv), N});
+    for (size_t j = 0; j < cc; j++) jobs.push_back(MsmJob{fcs[j], true, srs.eq(nv), M});
     std::vector<HG1> comms(jobs.size());
     msm_batch(c, jobs.data(), jobs.size(), (G1Affine*)comms.data());
     tr.write_commitments(comms);
@@ -88,23 +92,26 @@ void lasso_prove(Ctx& c, const Srs& srs, const lh_lasso_table& tb, size_t n, con
   // ---- field-element views of the small-valued columns (sum-check / openings work on Fr tables)
   const size_t num_n = 1 + 2 * cc + alpha;
   std::vector<const Fr*> polys_n(num_n), polys_l(cc);
-  polys_n[0] = a;
+  auto fr_view = [&](const uint32_t* src, size_t len) {
+    Fr* d = c.arena.alloc_n<Fr>(NV);
+    k_fr_from_u32(c, src, len, d);
+    if (len < NV) LH_HIP(hipMemsetAsync(d + len, 0, (NV - len) * sizeof(Fr), c.stream));
+    return d;
+  };
+  if (N < NV) {  // l > n: the output column needs the padding too
+    Fr* ap = c.arena.alloc_n<Fr>(NV);
+    LH_HIP(hipMemcpyAsync(ap, a, N * sizeof(Fr), hipMemcpyDeviceToDevice, c.stream));
+    LH_HIP(hipMemsetAsync(ap + N, 0, (NV - N) * sizeof(Fr), c.stream));
+    polys_n[0] = ap;
+  } else {
+    polys_n[0] = a;
+  }
   for (size_t j = 0; j < cc; j++) {
-    Fr* d = c.arena.alloc_n<Fr>(N);
-    k_fr_from_u32(c, d_dims[j], N, d);
-    polys_n[1 + j] = d;
-    Fr* t = c.arena.alloc_n<Fr>(N);
-    k_fr_from_u32(c, rts[j], N, t);
-    polys_n[1 + cc + j] = t;
-    Fr* f = c.arena.alloc_n<Fr>(M);
-    k_fr_from_u32(c, fcs[j], M, f);
-    polys_l[j] = f;
+    polys_n[1 + j] = fr_view(d_dims[j], N);
+    polys_n[1 + cc + j] = fr_view(rts[j], N);
+    polys_l[j] = fr_view(fcs[j], M);
   }
-  for (size_t i = 0; i < alpha; i++) {
-    Fr* e = c.arena.alloc_n<Fr>(N);
-    k_fr_from_u32(c, E[i], N, e);
-    polys_n[1 + 2 * cc + i] = e;
-  }
+  for (size_t i = 0; i < alpha; i++) polys_n[1 + 2 * cc + i] = fr_view(E[i], N);
   const Fr* const* E_fr = polys_n.data() + 1 + 2 * cc;
 
   // ---- 2-4: Surge primary sum-check
@@ -157,12 +164,13 @@ void lasso_prove(Ctx& c, const Srs& srs, const lh_lasso_table& tb, size_t n, con
   tr.write_field_elements(ev_l);
   lap(5);
 
-  // ---- 8: openings of the n-variable polys at r, r_z, r_N
+  // ---- 8: ONE batch opening of all committed polys (nv variables) at r, r_z, r_N, r_M (zero-padded)
   {
-    std::vector<HFr> points;
-    points.insert(points.end(), r.begin(), r.end());
-    points.insert(points.end(), r_z.begin(), r_z.end());
-    points.insert(points.end(), r_N.begin(), r_N.end());
+    std::vector<HFr> points(4 * nv, HFr::zero());
+    std::copy(r.begin(), r.end(), points.begin());
+    std::copy(r_z.begin(), r_z.end(), points.begin() + nv);
+    std::copy(r_N.begin(), r_N.end(), points.begin() + 2 * nv);
+    std::copy(r_M.begin(), r_M.end(), points.begin() + 3 * nv);
     std::vector<lh_evaluation> evs;
     auto push = [&](size_t poly, size_t point, const HFr& val) {
       lh_evaluation e;
@@ -176,22 +184,13 @@ void lasso_prove(Ctx& c, const Srs& srs, const lh_lasso_table& tb, size_t n, con
     for (size_t j = 0; j < cc; j++) push(1 + j, 2, ev_n[j]);
     for (size_t j = 0; j < cc; j++) push(1 + cc + j, 2, ev_n[cc + j]);
     for (size_t i = 0; i < alpha; i++) push(1 + 2 * cc + i, 2, ev_n[2 * cc + i]);
-    mkzg_batch_open(c, srs, n, polys_n.data(), num_n, points.data(), 3, evs.data(), evs.size(), tr);
+    for (size_t j = 0; j < cc; j++) push(num_n + j, 3, ev_l[j]);
+    std::vector<const Fr*> all(polys_n);
+    all.insert(all.end(), polys_l.begin(), polys_l.end());
+    mkzg_batch_open(c, srs, nv, all.data(), all.size(), points.data(), 4, evs.data(), evs.size(), tr);
   }
   lap(6);
-  // ---- 9: openings of final_cts at r_M
-  if (cc >= 2) {
-    std::vector<lh_evaluation> evs(cc);
-    for (size_t j = 0; j < cc; j++) {
-      evs[j].poly = (uint32_t)j;
-      evs[j].point = 0;
-      memcpy(&evs[j].value, &ev_l[j], 32);
-    }
-    mkzg_batch_open(c, srs, l, polys_l.data(), cc, r_M.data(), 1, evs.data(), cc, tr);
-  } else {
-    mkzg_open(c, srs, polys_l[0], l, r_M.data(), tr);
-  }
-  lap(7);
+  ph[7] = 0;
   ph[8] = now_ms() - t0;
 }
 

@@ -4,15 +4,16 @@
 // chunk-per-thread Pippenger has no device analogue; only the affine sum is observable
 // (SURVEY.md §3.4), so window size / bucket scheme are chosen for the GPU:
 //
-//  1. digits     every scalar -> canonical -> c-bit digits; histogram of (job, window, digit) keys
-//  2. scan       exclusive prefix over the key histogram
-//  3. scatter    (key, base index) pairs in key order (counting sort; order inside a bucket is free)
-//  4. accumulate load-balanced segmented sum: every thread owns K CONSECUTIVE sorted entries
-//                whatever the bucket sizes are (Lasso's read_ts / final_cts / dim columns are heavily
-//                skewed - a thread-per-bucket scheme would serialise on the hot buckets).  The run that
-//                starts a bucket is stored to the bucket array, a run that continues from the
-//                previous thread's chunk goes to a continuation list that is reduced the same way
-//                (K-fold shrink per level).
+//  1. digits     every scalar -> canonical -> c-bit digits -> (bucket key, point index) pairs at fixed
+//                positions (coalesced, no atomics; zero digits get a sentinel key that sorts last)
+//  2. sort       device radix sort of the pairs by key (order inside a bucket is free)
+//  3. accumulate load-balanced segmented sum: every thread owns ~K CONSECUTIVE sorted entries whatever
+//                the bucket sizes are (Lasso's read_ts / final_cts / dim columns are heavily skewed - a
+//                thread-per-bucket scheme would serialise on the hot buckets).  Chunk boundaries snap to
+//                the next bucket boundary when one is within K entries, so ordinary buckets are never
+//                split; only a bucket longer than K is cut, its first piece is stored to the bucket
+//                array and the following pieces go to a continuation list that is reduced the same
+//                way (K-fold shrink per level).
 //  5. reduce     per (job, window): sum_d d*B[d] by 16-bucket segments (running sums + d0*T), then a
 //                workgroup tree over the segments
 //  6. combine    the W window sums go to the host: Horner with c doublings per window and ONE field
@@ -22,6 +23,7 @@
 // the key space is (job, window, digit), so the latency-bound tails are paid once per batch.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <thread>
 #include <vector>
 #include "dev.hpp"
 #include "ff_host.hpp"
@@ -38,8 +40,7 @@ struct MsmJobDev {
   uint32_t n;
   uint32_t c, W;        // window bits, number of windows
   uint32_t key_base;    // first bucket key of this job
-  uint32_t cnt_base;    // first histogram slot of this job (bucket keys are replicated 2^rep_log times)
-  uint32_t rep_log;     // log2 of the histogram replication (spreads atomics of skewed columns)
+  uint32_t entry_base;  // first (key, index) pair of this job: pair of (window w, element i) at w*n + i
   uint32_t seg_base;    // first reduce-segment of this job
   uint32_t seg_per_win; // segments per window
   uint32_t seg_size;    // buckets per segment
@@ -50,66 +51,39 @@ struct MsmPlanDev {
   MsmJobDev job[MSM_MAX_JOBS];
 };
 
-// ------------------------------------------------------------------ 1/3: digits, histogram, scatter
-// Wave-aggregated atomic increment: lanes that hit the same slot elect a leader that adds the group
-// size once and hands out consecutive ranks.  Lasso's committed columns are small-valued (read_ts is
-// ~Poisson, final_cts/dim/E take few values), so whole waves collide on a handful of slots; a few
-// rounds of aggregation peel off the popular slots, the rest falls back to one atomic per lane.
-constexpr int AGG_ROUNDS = 6;
-__device__ __forceinline__ uint32_t wave_agg_inc(uint32_t* arr, uint32_t slot, bool active) {
-  const int lane = __lane_id();
-  unsigned long long todo = __ballot(active);
-  uint32_t res = 0;
-#pragma unroll 1
-  for (int round = 0; round < AGG_ROUNDS && todo; round++) {
-    const int leader = __ffsll((unsigned long long)todo) - 1;
-    const uint32_t k = __shfl(slot, leader);
-    const bool mine = active && slot == k;
-    const unsigned long long same = __ballot(mine);
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(&arr[k], (uint32_t)__popcll(same));
-    base = __shfl(base, leader);
-    if (mine) {
-      res = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-      active = false;
-    }
-    todo &= ~same;
+// ------------------------------------------------------------------ 1: digits
+// OR of the canonical limbs of every scalar of a job: gives the number of significant bits, so that an
+// Fr column holding small values (Lasso's output column) only emits the windows it needs.
+__global__ void msm_or_limbs_kernel(MsmPlanDev plan, uint32_t* __restrict__ or_out /* [jobs][8] */) {
+  const MsmJobDev& jb = plan.job[blockIdx.y];
+  if (jb.is_u32) return;
+  uint32_t acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) acc[k] = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < jb.n; i += (size_t)gridDim.x * blockDim.x) {
+    Fr s = from_mont(((const Fr*)jb.scalars)[i]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] |= s.l[k];
   }
-  if (active) res = atomicAdd(&arr[slot], 1u);
-  return res;
-}
-
-template <bool SCATTER>
-__device__ __forceinline__ void emit_digit(const MsmJobDev& jb, uint32_t w, uint32_t d, uint32_t rep, uint32_t i,
-                                           uint32_t* __restrict__ counts_or_cursor, uint32_t* __restrict__ sorted_key,
-                                           uint32_t* __restrict__ sorted_idx) {
-  const uint32_t local = (w << jb.c) + d;
-  const uint32_t slot = jb.cnt_base + (local << jb.rep_log) + rep;
-  const uint32_t pos = wave_agg_inc(counts_or_cursor, slot, d != 0);
-  if (SCATTER && d != 0) {
-    sorted_key[pos] = jb.key_base + local;
-    sorted_idx[pos] = i;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    uint32_t v = acc[k];
+    for (int off = 32; off > 0; off >>= 1) v |= __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicOr(&or_out[blockIdx.y * 8 + k], v);
   }
 }
 
-template <bool SCATTER>
-__global__ void msm_digits_kernel(MsmPlanDev plan, uint32_t* __restrict__ counts_or_cursor,
-                                  uint32_t* __restrict__ sorted_key, uint32_t* __restrict__ sorted_idx) {
+__global__ void msm_emit_kernel(MsmPlanDev plan, uint32_t sentinel, uint32_t* __restrict__ keys,
+                                uint32_t* __restrict__ vals) {
   const MsmJobDev& jb = plan.job[blockIdx.y];
   const uint32_t c = jb.c, mask = (1u << c) - 1u;
-  const uint32_t rep = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & ((1u << jb.rep_log) - 1u);
-  // every lane of a wave runs the same number of iterations (digits are emitted convergently)
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  const size_t iters = (jb.n + stride - 1) / stride;
-  for (size_t it = 0; it < iters; it++) {
-    const size_t i = it * stride + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = i < jb.n;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < jb.n; i += (size_t)gridDim.x * blockDim.x) {
     uint32_t limb[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) limb[k] = 0;
     if (jb.is_u32) {
-      if (live) limb[0] = ((const uint32_t*)jb.scalars)[i];
-    } else if (live) {
+      limb[0] = ((const uint32_t*)jb.scalars)[i];
+    } else {
       Fr s = from_mont(((const Fr*)jb.scalars)[i]);
 #pragma unroll
       for (int k = 0; k < 8; k++) limb[k] = s.l[k];
@@ -118,92 +92,45 @@ __global__ void msm_digits_kernel(MsmPlanDev plan, uint32_t* __restrict__ counts
     uint64_t buf = 0;
     int have = 0;
     uint32_t w = 0;
+    auto emit = [&](uint32_t d) {
+      size_t e = (size_t)jb.entry_base + (size_t)w * jb.n + i;
+      keys[e] = d ? jb.key_base + (w << c) + d : sentinel;
+      vals[e] = (uint32_t)i;
+    };
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       if (k < nlimbs) {
         buf |= (uint64_t)limb[k] << have;
         have += 32;
         while (have >= (int)c && w < jb.W) {
-          uint32_t d = (uint32_t)buf & mask;
+          emit((uint32_t)buf & mask);
           buf >>= c;
           have -= c;
-          emit_digit<SCATTER>(jb, w, d, rep, (uint32_t)i, counts_or_cursor, sorted_key, sorted_idx);
           w++;
         }
       }
     }
-    if (w < jb.W)  // top, partial window
-      emit_digit<SCATTER>(jb, w, (uint32_t)buf & mask, rep, (uint32_t)i, counts_or_cursor, sorted_key, sorted_idx);
+    if (w < jb.W) {  // top, partial window
+      emit((uint32_t)buf & mask);
+      w++;
+    }
   }
 }
 
-// ------------------------------------------------------------------ 2: exclusive scan (u32)
-constexpr int SCAN_TILE = 2048;  // 256 threads x 8
-__global__ void scan_tile_sums_kernel(const uint32_t* __restrict__ in, size_t n, uint32_t* __restrict__ tile_sums) {
-  __shared__ uint32_t lds[256];
-  size_t base = (size_t)blockIdx.x * SCAN_TILE;
-  uint32_t s = 0;
-  for (int k = 0; k < 8; k++) {
-    size_t i = base + (size_t)threadIdx.x * 8 + k;
-    if (i < n) s += in[i];
+// number of valid (non-sentinel) pairs = first index whose sorted key is the sentinel
+__global__ void msm_find_total_kernel(const uint32_t* __restrict__ sorted_key, uint32_t n, uint32_t sentinel,
+                                      uint32_t* __restrict__ total) {
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (sorted_key[mid] >= sentinel) hi = mid;
+    else lo = mid + 1;
   }
-  lds[threadIdx.x] = s;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if ((int)threadIdx.x < off) lds[threadIdx.x] += lds[threadIdx.x + off];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) tile_sums[blockIdx.x] = lds[0];
+  *total = lo;
 }
-__global__ void scan_tile_offsets_kernel(uint32_t* __restrict__ tile_sums, size_t ntiles, uint32_t* __restrict__ total) {
-  // single block: exclusive scan of tile_sums in place
-  __shared__ uint32_t lds[256];
-  size_t per = (ntiles + 255) / 256;
-  size_t lo = threadIdx.x * per, hi = lo + per < ntiles ? lo + per : ntiles;
-  uint32_t s = 0;
-  for (size_t i = lo; i < hi; i++) s += tile_sums[i];
-  lds[threadIdx.x] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t run = 0;
-    for (int i = 0; i < 256; i++) {
-      uint32_t v = lds[i];
-      lds[i] = run;
-      run += v;
-    }
-    *total = run;
-  }
-  __syncthreads();
-  uint32_t run = lds[threadIdx.x];
-  for (size_t i = lo; i < hi; i++) {
-    uint32_t v = tile_sums[i];
-    tile_sums[i] = run;
-    run += v;
-  }
-}
-__global__ void scan_apply_kernel(uint32_t* __restrict__ data, size_t n, const uint32_t* __restrict__ tile_offsets) {
-  __shared__ uint32_t lds[256];
-  size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * 8;
-  uint32_t v[8];
-  uint32_t s = 0;
-  for (int k = 0; k < 8; k++) {
-    v[k] = base + k < n ? data[base + k] : 0u;
-    s += v[k];
-  }
-  lds[threadIdx.x] = s;
-  __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) {  // Hillis-Steele inclusive scan
-    uint32_t t = (int)threadIdx.x >= off ? lds[threadIdx.x - off] : 0u;
-    __syncthreads();
-    lds[threadIdx.x] += t;
-    __syncthreads();
-  }
-  uint32_t run = lds[threadIdx.x] - s + tile_offsets[blockIdx.x];
-  for (int k = 0; k < 8; k++) {
-    if (base + k < n) data[base + k] = run;
-    run += v[k];
-  }
-}
+
+void sort_pairs_u32(Ctx& c, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
+                    size_t n, unsigned bits);
 
 // ------------------------------------------------------------------ 4: segmented accumulate
 __device__ __forceinline__ const MsmJobDev& job_of_key(const MsmPlanDev& plan, uint32_t key) {
@@ -222,9 +149,9 @@ __global__ __launch_bounds__(128) void msm_accumulate0_kernel(MsmPlanDev plan, c
                                                               uint32_t* __restrict__ cont_count) {
   const size_t total = *total_ptr;
   for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < nchunks; t += (size_t)gridDim.x * blockDim.x) {
-    size_t p0 = t * K, p1 = p0 + K < total ? p0 + K : total;
+    const size_t p0 = t * K < total ? t * K : total, p1 = p0 + K < total ? p0 + K : total;
     uint32_t ck = SENTINEL;
-    if (p0 < total) {
+    if (p0 < p1) {
       uint32_t cur = sorted_key[p0];
       bool cont = p0 > 0 && sorted_key[p0 - 1] == cur;
       const G1Affine* bases = job_of_key(plan, cur).bases;
@@ -257,50 +184,39 @@ __global__ __launch_bounds__(128) void msm_accumulate0_kernel(MsmPlanDev plan, c
   }
 }
 
-// level >= 1: (key, XYZZ) entries with sentinels; heads are ADDED into the bucket array
+// level >= 1: (key, XYZZ) entries with sentinels.  One thread per ENTRY: the thread sitting on the first
+// entry of a segment sums it (a segment = a run of equal keys, cut at every multiple of G so that no
+// thread adds more than G points).  The first segment of a run is ADDED into the bucket array, a
+// segment that starts at a forced cut continues a run and goes to the next level's list (one slot per
+// G entries).  With uniform digits a run is 1-2 entries, so this level finishes the job in one
+// short step; long runs (skewed columns) shrink G-fold per level.
 __global__ __launch_bounds__(128) void msm_accumulate_n_kernel(const uint32_t* __restrict__ in_key,
                                                                const G1Xyzz* __restrict__ in_pt, size_t n_in,
-                                                               uint32_t K, G1Xyzz* __restrict__ buckets,
+                                                               uint32_t G, G1Xyzz* __restrict__ buckets,
                                                                uint32_t* __restrict__ out_key,
-                                                               G1Xyzz* __restrict__ out_pt, size_t nchunks,
+                                                               G1Xyzz* __restrict__ out_pt,
                                                                const uint32_t* __restrict__ in_count,
                                                                uint32_t* __restrict__ out_count) {
   if (*in_count == 0) return;  // nothing continued into this level (out_count stays 0 for the next one)
-  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < nchunks; t += (size_t)gridDim.x * blockDim.x) {
-    size_t p0 = t * K, p1 = p0 + K < n_in ? p0 + K : n_in;
-    uint32_t ck = SENTINEL;
-    uint32_t cur = SENTINEL;
-    bool cont = false;
-    G1Xyzz acc = G1Xyzz::identity();
-    for (size_t p = p0; p < p1; p++) {
-      uint32_t k = in_key[p];
-      if (k == SENTINEL) continue;
-      if (k != cur) {
-        if (cur != SENTINEL) {
-          if (cont) {
-            ck = cur;
-            out_pt[t] = acc;
-          } else {
-            buckets[cur] = add(buckets[cur], acc);
-          }
-        }
-        // a run continues from the previous chunk only if it starts this chunk
-        cont = (p == p0) && p0 > 0 && in_key[p0 - 1] == k;
-        acc = G1Xyzz::identity();
-        cur = k;
-      }
-      acc = add(acc, in_pt[p]);
-    }
-    if (cur != SENTINEL) {
-      if (cont) {
-        ck = cur;
-        out_pt[t] = acc;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_in; p += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t k = in_key[p];
+    const bool valid = k != SENTINEL;
+    const bool prev_same = valid && p > 0 && in_key[p - 1] == k;
+    const bool slot_owner = (p % G) == 0;
+    const bool forced = prev_same && slot_owner;
+    uint32_t ok = SENTINEL;
+    if (valid && (!prev_same || forced)) {
+      G1Xyzz acc = in_pt[p];
+      for (size_t q = p + 1; q < n_in && (q % G) != 0 && in_key[q] == k; q++) acc = add(acc, in_pt[q]);
+      if (forced) {
+        ok = k;
+        out_pt[p / G] = acc;
+        atomicAdd(out_count, 1u);
       } else {
-        buckets[cur] = add(buckets[cur], acc);
+        buckets[k] = add(buckets[k], acc);
       }
     }
-    out_key[t] = ck;
-    if (ck != SENTINEL) atomicAdd(out_count, 1u);
+    if (slot_owner) out_key[p / G] = ok;
   }
 }
 
@@ -377,79 +293,100 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
     size_t nj = std::min(num_jobs - base, (size_t)MSM_MAX_JOBS);
     MsmPlanDev plan;
     plan.num_jobs = (int)nj;
-    uint32_t key = 0, seg = 0, win = 0, cnt = 0;
+    // significant bits of every Fr column (one cheap pass; u32 columns are 32-bit by declaration)
+    std::vector<uint32_t> job_bits(nj, 32);
+    {
+      bool any_fr = false;
+      size_t max_n0 = 0;
+      for (size_t j = 0; j < nj; j++) {
+        const MsmJob& in = jobs[base + j];
+        LH_REQUIRE(in.n < ((size_t)1 << 31), LH_ERR_ARG, "msm: too many points");
+        plan.job[j].scalars = in.scalars;
+        plan.job[j].is_u32 = in.scalars_u32 ? 1 : 0;
+        plan.job[j].n = (uint32_t)in.n;
+        any_fr |= !in.scalars_u32 && in.n;
+        max_n0 = std::max(max_n0, in.n);
+      }
+      if (any_fr) {
+        ArenaScope scope(c.arena);
+        uint32_t* d_or = c.arena.alloc_n<uint32_t>(8 * nj);
+        LH_HIP(hipMemsetAsync(d_or, 0, 8 * nj * sizeof(uint32_t), c.stream));
+        dim3 g((unsigned)std::min<size_t>((max_n0 + 255) / 256, 1024), (unsigned)nj);
+        hipLaunchKernelGGL(msm_or_limbs_kernel, g, dim3(256), 0, c.stream, plan, d_or);
+        uint32_t* h_or = (uint32_t*)c.pin(8 * MSM_MAX_JOBS * sizeof(uint32_t));
+        LH_HIP(hipMemcpyAsync(h_or, d_or, 8 * nj * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
+        c.sync();
+        for (size_t j = 0; j < nj; j++) {
+          if (jobs[base + j].scalars_u32) continue;
+          uint32_t bits = 0;
+          for (int k = 7; k >= 0 && !bits; k--)
+            if (h_or[8 * j + k]) bits = 32 * k + (32 - __builtin_clz(h_or[8 * j + k]));
+          job_bits[j] = bits;  // 0: all-zero column
+        }
+      }
+    }
+    uint32_t key = 0, seg = 0, win = 0;
     size_t max_entries = 0, max_n = 0;
     for (size_t j = 0; j < nj; j++) {
       const MsmJob& in = jobs[base + j];
-      LH_REQUIRE(in.n < ((size_t)1 << 31), LH_ERR_ARG, "msm: too many points");
       MsmJobDev& jd = plan.job[j];
-      uint32_t bits = in.scalars_u32 ? 32 : 254;
-      jd.scalars = in.scalars;
+      uint32_t bits = job_bits[j];
       jd.bases = in.bases;
-      jd.is_u32 = in.scalars_u32 ? 1 : 0;
-      jd.n = (uint32_t)in.n;
-      jd.c = pick_window(in.n ? in.n : 1, bits);
-      jd.W = (bits + jd.c - 1) / jd.c;
+      jd.c = pick_window(in.n ? in.n : 1, bits ? bits : 1);
+      jd.W = bits ? (bits + jd.c - 1) / jd.c : 0;
+      if (!in.n) jd.W = 0;
       jd.key_base = key;
-      jd.cnt_base = cnt;
-      jd.rep_log = in.scalars_u32 ? 3 : 0;
+      jd.entry_base = (uint32_t)max_entries;
       jd.seg_size = std::min<uint32_t>(16u, 1u << jd.c);
       jd.seg_per_win = (1u << jd.c) / jd.seg_size;
       jd.seg_base = seg;
       jd.win_base = win;
       key += jd.W << jd.c;
-      cnt += (jd.W << jd.c) << jd.rep_log;
       seg += jd.W * jd.seg_per_win;
       win += jd.W;
       max_entries += (size_t)jd.n * jd.W;
+      LH_REQUIRE(max_entries < ((size_t)1 << 32), LH_ERR_ARG, "msm: batch too large for 32-bit entry indices");
       max_n = std::max(max_n, in.n);
     }
-    const size_t nbuckets = key, nsegs = seg, nwins = win, ncounts = cnt;
+    const size_t nbuckets = key, nsegs = seg, nwins = win;
     std::vector<G1Xyzz> wins(nwins);
     if (max_entries == 0) {
       for (size_t j = 0; j < nj; j++) memset(&out_host[base + j], 0, sizeof(G1Affine));
       continue;
     }
-    LH_REQUIRE(max_entries < ((size_t)1 << 32), LH_ERR_ARG, "msm: batch too large for 32-bit entry indices");
     {
       ArenaScope scope(c.arena);
-      uint32_t* counts = c.arena.alloc_n<uint32_t>(ncounts + 1);
-      size_t ntiles = (ncounts + 1 + SCAN_TILE - 1) / SCAN_TILE;
-      uint32_t* tile_sums = c.arena.alloc_n<uint32_t>(ntiles);
       uint32_t* total = c.arena.alloc_n<uint32_t>(1);
+      uint32_t* ukey = c.arena.alloc_n<uint32_t>(max_entries);
+      uint32_t* uidx = c.arena.alloc_n<uint32_t>(max_entries);
       uint32_t* skey = c.arena.alloc_n<uint32_t>(max_entries);
       uint32_t* sidx = c.arena.alloc_n<uint32_t>(max_entries);
       G1Xyzz* buckets = c.arena.alloc_n<G1Xyzz>(nbuckets);
       G1Xyzz* seg_out = c.arena.alloc_n<G1Xyzz>(nsegs);
       G1Xyzz* win_out = c.arena.alloc_n<G1Xyzz>(nwins);
-
       uint32_t* lvl_cnt = c.arena.alloc_n<uint32_t>(64);
       LH_HIP(hipMemsetAsync(lvl_cnt, 0, 64 * sizeof(uint32_t), c.stream));
-      LH_HIP(hipMemsetAsync(counts, 0, (ncounts + 1) * sizeof(uint32_t), c.stream));
       LH_HIP(hipMemsetAsync(buckets, 0, nbuckets * sizeof(G1Xyzz), c.stream));
-      dim3 g((unsigned)std::min<size_t>((max_n + 255) / 256, 2048), (unsigned)nj);
       double total_pts = 0, full_pts = 0;
       for (size_t j = 0; j < nj; j++) total_pts += plan.job[j].n, full_pts += plan.job[j].is_u32 ? 0 : plan.job[j].n;
+      const uint32_t sentinel = (uint32_t)nbuckets;  // > every valid key: sorts last
+      unsigned key_bits = 1;
+      while (((size_t)1 << key_bits) <= nbuckets) key_bits++;
       {
-        ProfScope ps(c, "msm_digits_count", 32.0 * full_pts + 4.0 * (total_pts - full_pts), full_pts, total_pts);
-        hipLaunchKernelGGL(msm_digits_kernel<false>, g, dim3(256), 0, c.stream, plan, counts, nullptr, nullptr);
-      }
-      {
-        ProfScope ps(c, "msm_scan", 8.0 * (ncounts + 1), 0, (double)ncounts);
-      hipLaunchKernelGGL(scan_tile_sums_kernel, dim3((unsigned)ntiles), dim3(256), 0, c.stream, counts, ncounts + 1,
-                         tile_sums);
-      hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(256), 0, c.stream, tile_sums, ntiles, total);
-      hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)ntiles), dim3(256), 0, c.stream, counts, ncounts + 1,
-                         tile_sums);
-      }
-      {
-        ProfScope ps(c, "msm_digits_scatter", 32.0 * full_pts + 4.0 * (total_pts - full_pts) + 8.0 * max_entries, full_pts,
+        ProfScope ps(c, "msm_digits", 32.0 * full_pts + 4.0 * (total_pts - full_pts) + 8.0 * max_entries, full_pts,
                      total_pts);
-        hipLaunchKernelGGL(msm_digits_kernel<true>, g, dim3(256), 0, c.stream, plan, counts, skey, sidx);
+        dim3 g((unsigned)std::min<size_t>((max_n + 255) / 256, 2048), (unsigned)nj);
+        hipLaunchKernelGGL(msm_emit_kernel, g, dim3(256), 0, c.stream, plan, sentinel, ukey, uidx);
+      }
+      {
+        ProfScope ps(c, "msm_sort", 32.0 * max_entries, 0, (double)max_entries);
+        sort_pairs_u32(c, ukey, skey, uidx, sidx, max_entries, key_bits);
+        hipLaunchKernelGGL(msm_find_total_kernel, dim3(1), dim3(1), 0, c.stream, skey, (uint32_t)max_entries, sentinel,
+                           total);
       }
 
       // segmented accumulate, level 0 then K-fold shrinking continuation lists
-      uint32_t K = max_entries > ((size_t)1 << 22) ? 16 : max_entries > ((size_t)1 << 18) ? 8 : 4;
+      uint32_t K = max_entries > ((size_t)1 << 23) ? 32 : max_entries > ((size_t)1 << 21) ? 16 : max_entries > ((size_t)1 << 18) ? 8 : 4;
       size_t nchunks = (max_entries + K - 1) / K;
       uint32_t* ckey = c.arena.alloc_n<uint32_t>(nchunks);
       G1Xyzz* cpt = c.arena.alloc_n<G1Xyzz>(nchunks);
@@ -473,8 +410,8 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
         size_t nc = (n_in + K2 - 1) / K2;
         uint32_t* okey = c.arena.alloc_n<uint32_t>(nc);
         G1Xyzz* opt = c.arena.alloc_n<G1Xyzz>(nc);
-        hipLaunchKernelGGL(msm_accumulate_n_kernel, dim3((unsigned)std::min<size_t>((nc + 127) / 128, 1 << 16)),
-                           dim3(128), 0, c.stream, ckey, cpt, n_in, K2, buckets, okey, opt, nc, lvl_cnt + lvl,
+        hipLaunchKernelGGL(msm_accumulate_n_kernel, dim3((unsigned)std::min<size_t>((n_in + 127) / 128, 1 << 16)),
+                           dim3(128), 0, c.stream, ckey, cpt, n_in, K2, buckets, okey, opt, lvl_cnt + lvl,
                            lvl_cnt + lvl + 1);
         lvl++;
         if (n_in <= K2) break;  // a single chunk: no continuation can remain
@@ -493,7 +430,7 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
       c.sync();
     }
     // 6: host combine  sum_w 2^(c*w) * win[w]  and normalise
-    for (size_t j = 0; j < nj; j++) {
+    auto combine = [&](size_t j) {
       const MsmJobDev& jd = plan.job[j];
       host::G1Xyzz acc = host::G1Xyzz::identity();
       for (int w = (int)jd.W - 1; w >= 0; w--) {
@@ -502,6 +439,17 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
       }
       host::G1Affine a = host::g1_to_affine(acc);
       memcpy(&out_host[base + j], &a, sizeof(G1Affine));
+    };
+    if (nj <= 2) {
+      for (size_t j = 0; j < nj; j++) combine(j);
+    } else {  // ~70 us of dependent doublings per job: spread the jobs over host threads
+      size_t nt = std::min<size_t>(nj, std::max(1u, std::min(16u, std::thread::hardware_concurrency())));
+      std::vector<std::thread> th;
+      for (size_t t = 0; t < nt; t++)
+        th.emplace_back([&, t] {
+          for (size_t j = t; j < nj; j += nt) combine(j);
+        });
+      for (auto& x : th) x.join();
     }
   }
 }

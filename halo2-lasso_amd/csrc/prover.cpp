@@ -39,24 +39,37 @@ std::vector<HFr> evaluate_polys(Ctx& c, const Fr* const* d_polys, size_t count, 
 }
 
 // value at x of the polynomial through (i, evals[i]), i = 0..d
-// (barycentric_interpolate over points 0..d, reference util/arithmetic.rs:108-136)
+// (barycentric_interpolate over points 0..d, reference util/arithmetic.rs:108-136).  The weights
+// 1/prod_{i != j}(j - i) depend on d only and are cached: a round costs O(d) multiplications and no
+// inversion on the host (an Fr inversion is ~8 us, and there are hundreds of rounds per proof).
+static const std::vector<HFr>& lagrange_weights(size_t d) {
+  static std::vector<std::vector<HFr>> cache(16);
+  LH_REQUIRE(d < cache.size(), LH_ERR_ARG, "degree too large");
+  std::vector<HFr>& w = cache[d];
+  if (w.empty()) {
+    w.resize(d + 1);
+    for (size_t j = 0; j <= d; j++) {
+      HFr de = HFr::one();
+      for (size_t i = 0; i <= d; i++)
+        if (i != j) de *= HFr::from_u64(j) - HFr::from_u64(i);
+      w[j] = de.inv();
+    }
+  }
+  return w;
+}
+
 static HFr interpolate_evals(const std::vector<HFr>& evals, const HFr& x) {
   const size_t d = evals.size() - 1;
-  // x in {0..d} would zero a denominator; the reference hits the same case through batch_invert
-  std::vector<HFr> pts(d + 1), num(d + 1);
-  for (size_t i = 0; i <= d; i++) pts[i] = HFr::from_u64(i);
-  for (size_t i = 0; i <= d; i++)
-    if (x == pts[i]) return evals[i];
+  const std::vector<HFr>& w = lagrange_weights(d);
+  // prefix[j] = prod_{i<j} (x - i), suffix[j] = prod_{i>j} (x - i); x in {0..d} is covered as well
+  std::vector<HFr> diff(d + 1), prefix(d + 2), suffix(d + 2);
+  for (size_t i = 0; i <= d; i++) diff[i] = x - HFr::from_u64(i);
+  prefix[0] = HFr::one();
+  for (size_t i = 0; i <= d; i++) prefix[i + 1] = prefix[i] * diff[i];
+  suffix[d + 1] = HFr::one();
+  for (size_t i = d + 1; i-- > 0;) suffix[i] = suffix[i + 1] * diff[i];
   HFr total = HFr::zero();
-  for (size_t j = 0; j <= d; j++) {
-    HFr nu = HFr::one(), de = HFr::one();
-    for (size_t i = 0; i <= d; i++) {
-      if (i == j) continue;
-      nu *= x - pts[i];
-      de *= pts[j] - pts[i];
-    }
-    total += evals[j] * nu * de.inv();
-  }
+  for (size_t j = 0; j <= d; j++) total += evals[j] * w[j] * prefix[j] * suffix[j + 1];
   return total;
 }
 
@@ -123,7 +136,7 @@ SumCheckResult sum_check_prove(Ctx& c, int prover_kind, size_t num_vars, const l
     bufB[i] = c.arena.alloc_n<Fr>(std::max<size_t>(n >> 2, 1));
   }
   Fr* evals_host = (Fr*)c.pin((16 + SC_MAX_TABLES) * sizeof(Fr));
-  const HFr inv2 = HFr::from_u64(2).inv();
+  static const HFr inv2 = HFr::from_u64(2).inv();
 
   SumCheckResult res;
   HFr claim = sum;
@@ -304,15 +317,29 @@ GrandProductResult prove_grand_product(Ctx& c, size_t B, const Fr* const* d_leav
   ArenaScope scope(c.arena);
   // level[b][h]: array with 2^(h+1) nodes, h = 0 (top, two nodes) .. depth-1 (the leaves)
   std::vector<std::vector<const Fr*>> level(B);
-  for (size_t b = 0; b < B; b++) {
-    level[b].resize(num_vars[b]);
-    level[b][num_vars[b] - 1] = d_leaves[b];
-    for (size_t h = num_vars[b] - 1; h-- > 0;) {
-      size_t half = (size_t)1 << (h + 1);
-      Fr* up = c.arena.alloc_n<Fr>(half);
-      k_tree_up(c, level[b][h + 1], half, up);
-      level[b][h] = up;
+  {
+    const size_t SMALL = 9;  // levels with <= 2^(SMALL+1) nodes are finished by one workgroup per tree
+    std::vector<const Fr*> top_in(B);
+    std::vector<Fr*> top_out(B);
+    std::vector<int> top_H(B);
+    for (size_t b = 0; b < B; b++) {
+      level[b].resize(num_vars[b]);
+      level[b][num_vars[b] - 1] = d_leaves[b];
+      size_t h = num_vars[b] - 1;  // current lowest computed level
+      for (; h > SMALL; h--) {
+        size_t half = (size_t)1 << h;
+        Fr* up = c.arena.alloc_n<Fr>(half);
+        k_tree_up(c, level[b][h], half, up);
+        level[b][h - 1] = up;
+      }
+      // h <= SMALL: levels h-1 .. 0 in one go
+      Fr* tops = c.arena.alloc_n<Fr>(((size_t)2 << h));
+      top_in[b] = level[b][h];
+      top_out[b] = tops;
+      top_H[b] = (int)h;
+      for (size_t k = 0; k < h; k++) level[b][k] = tops + (((size_t)2 << k) - 2);
     }
+    k_tree_tops(c, top_in.data(), top_out.data(), top_H.data(), B);
   }
   std::vector<HFr> top(2 * B);
   {

@@ -1,0 +1,18 @@
+// Device radix sort of (bucket key, point index) pairs for the MSM (rocPRIM's device-wide sort:
+// a utility primitive from the ROCm toolchain; the curve arithmetic around it is hand-written).
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include "dev.hpp"
+
+namespace lh {
+
+void sort_pairs_u32(Ctx& c, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
+                    size_t n, unsigned bits) {
+  size_t temp_bytes = 0;
+  LH_HIP(rocprim::radix_sort_pairs(nullptr, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, bits, c.stream));
+  void* temp = c.arena.alloc(temp_bytes ? temp_bytes : 256);  // caller's ArenaScope releases it
+  LH_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, bits, c.stream));
+}
+
+}  // namespace lh

@@ -645,8 +645,17 @@ static void lasso_prove(Transcript& tr, const Srs& s, const LassoTable& tb, size
   for (size_t j = 0; j < c; j++) pl.push_back(to_poly(fcs[j]));
 
   tr.common_fe(Fr::from_u64(n)), tr.common_fe(Fr::from_u64(l)), tr.common_fe(Fr::from_u64(c)), tr.common_fe(Fr::from_u64(alpha));
-  for (auto& p : pn) tr.write_comm(commit(s, p));
-  for (auto& p : pl) tr.write_comm(commit(s, p));
+  // every committed poly is zero-padded to nv = max(n, l) variables (one batch_open serves all)
+  const size_t nv = std::max(n, l), NV = (size_t)1 << nv;
+  auto padded = [&](const Poly& p) {
+    Poly q = p;
+    q.resize(NV, Fr::zero());
+    return q;
+  };
+  std::vector<Poly> all;
+  for (auto& p : pn) all.push_back(padded(p));
+  for (auto& p : pl) all.push_back(padded(p));
+  for (auto& p : all) tr.write_comm(commit(s, p));
 
   std::vector<Fr> r = tr.squeeze_n(n);
   Fr v = evaluate(a, r.data(), n);
@@ -698,17 +707,14 @@ static void lasso_prove(Transcript& tr, const Srs& s, const LassoTable& tb, size
   for (size_t j = 0; j < c; j++) evs.push_back(Eval{(uint32_t)(1 + j), 2, ev_n[j]});
   for (size_t j = 0; j < c; j++) evs.push_back(Eval{(uint32_t)(1 + c + j), 2, ev_n[c + j]});
   for (size_t i = 0; i < alpha; i++) evs.push_back(Eval{(uint32_t)(1 + 2 * c + i), 2, ev_n[2 * c + i]});
-  std::vector<const Poly*> ppn, ppl;
-  for (auto& p : pn) ppn.push_back(&p);
-  for (auto& p : pl) ppl.push_back(&p);
-  batch_open(tr, s, n, ppn, {r, sc.x, r_N}, evs);
-  if (c >= 2) {
-    std::vector<Eval> el;
-    for (size_t j = 0; j < c; j++) el.push_back(Eval{(uint32_t)j, 0, ev_l[j]});
-    batch_open(tr, s, l, ppl, {r_M}, el);
-  } else {
-    kzg_open(tr, s, pl[0], r_M.data(), l);
-  }
+  for (size_t j = 0; j < c; j++) evs.push_back(Eval{(uint32_t)(1 + 2 * c + alpha + j), 3, ev_l[j]});
+  std::vector<const Poly*> pp;
+  for (auto& p : all) pp.push_back(&p);
+  auto pad_pt = [&](std::vector<Fr> pt) {
+    pt.resize(nv, Fr::zero());
+    return pt;
+  };
+  batch_open(tr, s, nv, pp, {pad_pt(r), pad_pt(sc.x), pad_pt(r_N), pad_pt(r_M)}, evs);
 }
 
 // ------------------------------------------------------------------ C interface (ctypes)

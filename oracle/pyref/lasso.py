@@ -9,8 +9,10 @@ Protocol (transcript order == proof layout), for N = 2^n lookups into a table de
 c chunks of l bits (subtable size M = 2^l), alpha memories (chunk j(i), subtable t(i)):
 
  0. C   n, l, c, alpha                                  (common_field_element, domain separation)
- 1. W   commitments  a | dim_0..c-1 | read_ts_0..c-1 | E_0..alpha-1   (n vars, eqs[n])
-        then          final_cts_0..c-1                                 (l vars, eqs[l])
+ 1. W   commitments  a | dim_0..c-1 | read_ts_0..c-1 | E_0..alpha-1 | final_cts_0..c-1
+        Every committed poly is zero-padded to nv = max(n, l) variables and committed with eqs[nv]
+        (padding with zeros does not change the MSM; f_pad(x || 0..0) = f(x)), so that ONE
+        batch_open serves all of them.
  2. S   r[0..n)
  3. W   v = a(r)
  4.     Surge: ClassicSumCheck<EvaluationsProver>, expression eq_0 * g(E_0..E_alpha-1), ys=[r],
@@ -23,11 +25,10 @@ c chunks of l bits (subtable size M = 2^l), alpha memories (chunk j(i), subtable
           [RS_0, WS_0, .., RS_{alpha-1}, WS_{alpha-1}, Init_0, Final_0, .., Init_{alpha-1}, Final_{alpha-1}]
         -> points r_N (n vars) and r_M (l vars).  Verifier: Init_i*WS_i == RS_i*Final_i (roots).
  7. W   dim_j(r_N) (c) | read_ts_j(r_N) (c) | E_i(r_N) (alpha) | final_cts_j(r_M) (c)
- 8.     batch_open group A (n vars): polys [a, dim.., read_ts.., E..], points [r, r_z, r_N],
-        evals [(a,r)] + [(E_i,r_z)] + [(dim_j,r_N)] + [(read_ts_j,r_N)] + [(E_i,r_N)]
- 9.     batch_open group B (l vars): polys [final_cts..], points [r_M]; since the reference's
-        batch_open needs >= 2 evaluations (pcs/multilinear.rs:150-154) a table with c == 1 is
-        opened with MultilinearKzg::open directly.
+ 8.     ONE batch_open (reference pcs/multilinear.rs:134-235) over nv variables:
+        polys [a, dim.., read_ts.., E.., final_cts..], points [r, r_z, r_N, r_M] each padded with zeros
+        to nv coordinates, evals [(a,r)] + [(E_i,r_z)] + [(dim_j,r_N)] + [(read_ts_j,r_N)] + [(E_i,r_N)]
+        + [(final_cts_j,r_M)].
 """
 from .field import R_MOD as P
 from . import expression as ex
@@ -158,10 +159,9 @@ def prove(pp, spec, dims, transcript):
     _check_shape(spec, n)
     w = witness(spec, dims)
     transcript.common_field_elements([n, l, c, alpha])
-    polys_n = [w["a"]] + w["dim"] + w["read_ts"] + w["E"]
-    polys_l = w["final_cts"]
-    kzg.batch_commit_and_write(pp, polys_n, transcript)
-    kzg.batch_commit_and_write(pp, polys_l, transcript)
+    nv = max(n, l)
+    polys = [_pad(p, nv) for p in [w["a"]] + w["dim"] + w["read_ts"] + w["E"] + w["final_cts"]]
+    kzg.batch_commit_and_write(pp.trim(nv), polys, transcript)
 
     r = transcript.squeeze_challenges(n)
     v = evaluate(w["a"], r)
@@ -190,23 +190,28 @@ def prove(pp, spec, dims, transcript):
     fc_e = [evaluate(t, r_M) for t in w["final_cts"]]
     transcript.write_field_elements(dim_e + rts_e + e_e + fc_e)
 
-    evals_a = _evals_group_a(spec, v, e_rz, dim_e, rts_e, e_e)
-    kzg.batch_open(pp.trim(n), n, polys_n, [r, r_z, r_N], evals_a, transcript)
-    if c >= 2:
-        evals_b = [kzg.Evaluation(j, 0, fc_e[j]) for j in range(c)]
-        kzg.batch_open(pp.trim(l), l, polys_l, [r_M], evals_b, transcript)
-    else:
-        kzg.open_(pp.trim(l), polys_l[0], r_M, transcript)
+    evals = _evals(spec, v, e_rz, dim_e, rts_e, e_e, fc_e)
+    points = [_pad_point(pt, nv) for pt in (r, r_z, r_N, r_M)]
+    kzg.batch_open(pp.trim(nv), nv, polys, points, evals, transcript)
     return transcript
 
 
-def _evals_group_a(spec, v, e_rz, dim_e, rts_e, e_e):
+def _pad(evals, nv):
+    return list(evals) + [0] * ((1 << nv) - len(evals))
+
+
+def _pad_point(pt, nv):
+    return list(pt) + [0] * (nv - len(pt))
+
+
+def _evals(spec, v, e_rz, dim_e, rts_e, e_e, fc_e):
     c, alpha = spec.c, spec.alpha
     out = [kzg.Evaluation(0, 0, v)]
     out += [kzg.Evaluation(1 + 2 * c + i, 1, e_rz[i]) for i in range(alpha)]
     out += [kzg.Evaluation(1 + j, 2, dim_e[j]) for j in range(c)]
     out += [kzg.Evaluation(1 + c + j, 2, rts_e[j]) for j in range(c)]
     out += [kzg.Evaluation(1 + 2 * c + i, 2, e_e[i]) for i in range(alpha)]
+    out += [kzg.Evaluation(1 + 2 * c + alpha + j, 3, fc_e[j]) for j in range(c)]
     return out
 
 
@@ -215,8 +220,8 @@ def verify(vp, spec, n, transcript):
     c, l, alpha = spec.c, spec.l, spec.alpha
     _check_shape(spec, n)
     transcript.common_field_elements([n, l, c, alpha])
-    comms_n = transcript.read_commitments(1 + 2 * c + alpha)
-    comms_l = transcript.read_commitments(c)
+    nv = max(n, l)
+    comms = transcript.read_commitments(1 + 3 * c + alpha)
 
     r = transcript.squeeze_challenges(n)
     v = transcript.read_field_element()
@@ -249,12 +254,8 @@ def verify(vp, spec, n, transcript):
         if want != got:
             raise LassoError("memory %d: leaf claim mismatch" % i)
 
-    evals_a = _evals_group_a(spec, v, e_rz, dim_e, rts_e, e_e)
-    kzg.batch_verify(vp.trim(n), n, comms_n, [r, r_z, r_N], evals_a, transcript)
-    if c >= 2:
-        evals_b = [kzg.Evaluation(j, 0, fc_e[j]) for j in range(c)]
-        kzg.batch_verify(vp.trim(l), l, comms_l, [r_M], evals_b, transcript)
-    else:
-        kzg.verify(vp.trim(l), comms_l[0], r_M, fc_e[0], transcript)
+    evals = _evals(spec, v, e_rz, dim_e, rts_e, e_e, fc_e)
+    points = [_pad_point(pt, nv) for pt in (r, r_z, r_N, r_M)]
+    kzg.batch_verify(vp.trim(nv), nv, comms, points, evals, transcript)
     if transcript.pos != len(transcript.stream):
         raise LassoError("trailing bytes in proof")
