@@ -12,6 +12,8 @@
 // Evaluation points X = 1..D: value(X) = v1 + (X-1)*(v1 - v0) (eval.rs:228-286); X = 0 is derived
 // from the claim by the host (eval.rs:129).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <algorithm>
 #include "dev.hpp"
 #include "reduce.cuh"
 
@@ -118,6 +120,110 @@ __global__ __launch_bounds__(256) void sc_round_kernel(ScArgs a, size_t size, ui
   if (flag && threadIdx.x == 0) publish_flag(flag, seq);  // single-workgroup launch: partials IS the host buffer
 }
 
+// ------------------------------------------------------------------ small / medium rounds: LDS-staged
+// The late rounds of every sum-check (and whole GKR layers near the root) are latency-bound: few pairs,
+// but one thread walking a whole term is a chain of ~15 dependent field multiplications (~1 us each
+// on a lone wave).  Here a workgroup owns P pairs and works in three short phases:
+//   1. every thread binds ONE or two table entries (1 multiplication) into LDS (and stores them),
+//   2. every thread evaluates ONE (pair, term, X) item from LDS (nfac multiplications),
+//   3. per (term, X) the P values are summed, scaled by the term's coefficient and combined.
+// The dependent chain is ~1 + nfac + 1 multiplications whatever the expression size.
+constexpr int LDS_VALS = 1280;   // bound entries held per workgroup (40 KB)
+constexpr int LDS_ITEMS = 512;   // (pair, term, X) items per workgroup (16 KB)
+struct ScLdsArgs {
+  ScArgs a;
+  uint8_t used[SC_MAX_TABLES];   // compact list of the tables the expression touches
+  uint8_t slot_of[SC_MAX_TABLES];
+  uint32_t num_used;
+  uint32_t P;                    // pairs per workgroup
+};
+
+template <int D, bool BIND>
+__global__ __launch_bounds__(256) void sc_round_lds_kernel(ScLdsArgs g, size_t size, Fr* __restrict__ partials,
+                                                           uint32_t* flag, uint32_t seq) {
+  __shared__ Fr vals[LDS_VALS];
+  __shared__ Fr red[LDS_ITEMS];
+  const ScRound& rd = g.a.rd;
+  const uint32_t P = g.P, U = g.num_used;
+  const size_t b0 = (size_t)blockIdx.x * P;
+  // phase 1: entry e = (slot u, local pair pl, which) -> vals[(u*P + pl)*2 + which]
+  for (uint32_t e = threadIdx.x; e < U * P * 2; e += blockDim.x) {
+    const uint32_t which = e & 1u, pl = (e >> 1) % P, u = (e >> 1) / P;
+    const size_t b = b0 + pl;
+    Fr v = Fr::zero();
+    if (b < size) {
+      const int t = g.used[u];
+      if (BIND) {
+        const Fr* p = rd.in[t] + 4 * b + 2 * which;
+        Fr e0 = p[0], e1 = p[1];
+        v = add(mul(sub(e1, e0), rd.r), e0);
+        rd.out[t][2 * b + which] = v;
+      } else {
+        v = rd.in[t][2 * b + which];
+      }
+    }
+    vals[e] = v;
+  }
+  __syncthreads();
+  // phase 2: item it = ((m*D + x)*P + pl)
+  const uint32_t items = rd.num_terms * D * P;
+  for (uint32_t it = threadIdx.x; it < items; it += blockDim.x) {
+    const uint32_t pl = it % P, mx = it / P, x = mx % D, m = mx / D;
+    Fr acc = Fr::zero();
+    if (b0 + pl < size) {
+      const int nf = rd.nfac[m];
+      for (int k = 0; k <= nf; k++) {
+        int t;
+        if (k < nf) t = rd.fac[m][k];
+        else if (rd.global_eq >= 0) t = rd.global_eq;
+        else break;
+        const Fr* pv = vals + ((uint32_t)g.slot_of[t] * P + pl) * 2;
+        Fr v0 = pv[0], v1 = pv[1];
+        Fr val = v1;
+        if (x > 0) {
+          Fr step = sub(v1, v0);
+          for (uint32_t j = 0; j < x; j++) val = add(val, step);
+        }
+        acc = k == 0 ? val : mul(acc, val);
+      }
+    }
+    red[it] = acc;
+  }
+  __syncthreads();
+  // phase 3a: per (term, X): sum over the pairs, times the coefficient
+  const uint32_t groups = rd.num_terms * D;
+  Fr gsum = Fr::zero();
+  if (threadIdx.x < groups) {
+    for (uint32_t pl = 0; pl < P; pl++) gsum = add(gsum, red[threadIdx.x * P + pl]);
+    const uint32_t m = threadIdx.x / D;
+    if (!rd.coeff_is_one[m]) gsum = mul(gsum, rd.coeff[m]);
+  }
+  __syncthreads();
+  if (threadIdx.x < groups) red[threadIdx.x] = gsum;
+  __syncthreads();
+  // phase 3b: per X: sum over the terms
+  if (threadIdx.x < D) {
+    Fr s = Fr::zero();
+    for (uint32_t m = 0; m < rd.num_terms; m++) s = add(s, red[m * D + threadIdx.x]);
+    partials[(size_t)blockIdx.x * D + threadIdx.x] = s;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  }
+  if (flag) {
+    __syncthreads();
+    if (threadIdx.x == 0) publish_flag(flag, seq);
+  }
+}
+
+template <int D>
+static void launch_lds(Ctx& c, const ScLdsArgs& g, bool bind, size_t size, unsigned grid, Fr* partials, uint32_t* flag,
+                       uint32_t seq) {
+  if (bind)
+    hipLaunchKernelGGL((sc_round_lds_kernel<D, true>), dim3(grid), dim3(256), 0, c.stream, g, size, partials, flag, seq);
+  else
+    hipLaunchKernelGGL((sc_round_lds_kernel<D, false>), dim3(grid), dim3(256), 0, c.stream, g, size, partials, flag,
+                       seq);
+}
+
 __global__ void sc_reduce_kernel(const Fr* __restrict__ partials, int blocks, int d, Fr* __restrict__ out,
                                  uint32_t* flag, uint32_t seq) {
   __shared__ Fr lds[4];
@@ -153,37 +259,90 @@ void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, F
       a.store[m][k] = seen[t] ? 0 : 1;
       seen[t] = true;
     }
-  // small rounds: one work item per (pair, term); a single workgroup writes the sums straight into the
-  // pinned host buffer (no second kernel, no copy): the round trip is launch + kernel + one stream sync.
-  const uint32_t tp = (rd.num_terms > 1 && size * rd.num_terms <= ((size_t)1 << 16)) ? rd.num_terms : 1u;
-  const size_t items = size * tp;
+  // count the tables the expression touches
+  size_t tabs = 0;
+  for (int t = 0; t < SC_MAX_TABLES; t++) tabs += seen[t] ? 1 : 0;
+  double nfac = 0, ncoef = 0;
+  for (uint32_t m = 0; m < rd.num_terms; m++) nfac += rd.nfac[m], ncoef += rd.coeff_is_one[m] ? 0 : 2;
+  const double muls_pair = (nfac - rd.num_terms) * degree + ncoef + (rd.global_eq >= 0 ? degree : 0) +
+                           (bind ? 2.0 * (nfac + (rd.global_eq >= 0 ? 1 : 0)) : 0.0);
+  // algorithmic bytes: fused round = bind bytes only, 96 B per bound entry = 192 B per pair
+  // and table; the unfused first round reads 64 B per pair and table.
+  const double bytes = (bind ? 192.0 : 64.0) * (double)size * (double)tabs;
+  const uint32_t seq = c.next_seq();
   ArenaScope scope(c.arena);
-  size_t g = (items + 255) / 256;
+
+  // pairs per workgroup of the LDS-staged kernel
+  uint32_t P = (uint32_t)std::min<size_t>(size, 64);
+  P = std::min<uint32_t>(P, LDS_VALS / (2 * (uint32_t)tabs));
+  P = std::min<uint32_t>(P, LDS_ITEMS / (rd.num_terms * degree));
+  static const size_t lds_max = [] {
+    const char* e = getenv("LH_SC_LDS_MAX_ITEMS");  // tuning knob: (pairs * terms) up to which the LDS kernel is used
+    return e ? (size_t)atoll(e) : ((size_t)1 << 16);
+  }();
+  const bool use_lds = P >= 1 && rd.num_terms * degree <= 256 && size * rd.num_terms <= lds_max;
+  if (use_lds) {
+    // fill a workgroup's 256 threads in the item phase when there are pairs enough
+    // ... and keep the bind phase at one entry per thread
+    uint32_t want = (256 + rd.num_terms * degree - 1) / (rd.num_terms * degree);
+    want = std::min<uint32_t>(want, std::max<uint32_t>(1, 256 / (2 * (uint32_t)tabs)));
+    if (P > want && want >= 1) P = std::max<uint32_t>(want, 1);
+    ScLdsArgs g;
+    g.a = a;
+    g.num_used = 0;
+    for (int t = 0; t < SC_MAX_TABLES; t++)
+      if (seen[t]) {
+        g.slot_of[t] = (uint8_t)g.num_used;
+        g.used[g.num_used++] = (uint8_t)t;
+      }
+    g.P = P;
+    size_t grid = (size + P - 1) / P;
+    Fr* partials = grid == 1 ? evals_host : c.arena.alloc_n<Fr>(grid * degree);
+    uint32_t* kflag = grid == 1 ? c.flag : nullptr;
+    {
+      char name[40];
+      snprintf(name, sizeof name, "sc_round<%d,%s>/lds", degree, bind ? "bind" : "first");
+      ProfScope ps(c, name, bytes, muls_pair * (double)size, (double)size);
+      switch (degree) {
+        case 1: launch_lds<1>(c, g, bind, size, (unsigned)grid, partials, kflag, seq); break;
+        case 2: launch_lds<2>(c, g, bind, size, (unsigned)grid, partials, kflag, seq); break;
+        case 3: launch_lds<3>(c, g, bind, size, (unsigned)grid, partials, kflag, seq); break;
+        case 4: launch_lds<4>(c, g, bind, size, (unsigned)grid, partials, kflag, seq); break;
+        case 5: launch_lds<5>(c, g, bind, size, (unsigned)grid, partials, kflag, seq); break;
+        default: launch_lds<6>(c, g, bind, size, (unsigned)grid, partials, kflag, seq); break;
+      }
+    }
+    if (grid > 1)
+      hipLaunchKernelGGL(sc_reduce_kernel, dim3(1), dim3(256), 0, c.stream, partials, (int)grid, degree, evals_host,
+                         c.flag, seq);
+    c.wait_flag(seq);
+    return;
+  }
+
+  // large rounds: one thread per pair keeps everything in registers; in between, one thread per
+  // (pair, term) so that a launch that cannot fill the chip is not also a long dependent chain
+  static const size_t tp_max = [] {
+    const char* e = getenv("LH_SC_TP_MAX_ITEMS");
+    return e ? (size_t)atoll(e) : ((size_t)1 << 17);
+  }();
+  const uint32_t tp = (rd.num_terms > 1 && size * rd.num_terms <= tp_max) ? rd.num_terms : 1u;
+  size_t g = (size * tp + 255) / 256;
   size_t cap = (size_t)c.num_cus * 4;
   if (g > cap) g = cap;
   Fr* partials = g == 1 ? evals_host : c.arena.alloc_n<Fr>(g * degree);
-  const uint32_t seq = c.next_seq();
   uint32_t* kflag = g == 1 ? c.flag : nullptr;
   {
-    // algorithmic bytes: fused round = bind bytes only, 96 B per bound entry = 192 B per
-    // pair and table; the unfused first round reads 64 B per pair and table.
-    size_t tabs = 0;
-    for (int t = 0; t < SC_MAX_TABLES; t++) tabs += seen[t] ? 1 : 0;
-    double nfac = 0, ncoef = 0;
-    for (uint32_t m = 0; m < rd.num_terms; m++) nfac += rd.nfac[m], ncoef += rd.coeff_is_one[m] ? 0 : 2;
-    double muls_pair = (nfac - rd.num_terms) * degree + ncoef + (rd.global_eq >= 0 ? degree : 0) +
-                       (bind ? 2.0 * (nfac + (rd.global_eq >= 0 ? 1 : 0)) : 0.0);
     char name[40];
     snprintf(name, sizeof name, "sc_round<%d,%s>%s", degree, bind ? "bind" : "first", tp > 1 ? "/tp" : "");
-    ProfScope ps(c, name, (bind ? 192.0 : 64.0) * (double)size * (double)tabs, muls_pair * (double)size, (double)size);
-  switch (degree) {
-    case 1: launch_round<1>(c, a, bind, size, tp, (unsigned)g, partials, kflag, seq); break;
-    case 2: launch_round<2>(c, a, bind, size, tp, (unsigned)g, partials, kflag, seq); break;
-    case 3: launch_round<3>(c, a, bind, size, tp, (unsigned)g, partials, kflag, seq); break;
-    case 4: launch_round<4>(c, a, bind, size, tp, (unsigned)g, partials, kflag, seq); break;
-    case 5: launch_round<5>(c, a, bind, size, tp, (unsigned)g, partials, kflag, seq); break;
-    default: launch_round<6>(c, a, bind, size, tp, (unsigned)g, partials, kflag, seq); break;
-  }
+    ProfScope ps(c, name, bytes, muls_pair * (double)size, (double)size);
+    switch (degree) {
+      case 1: launch_round<1>(c, a, bind, size, tp, (unsigned)g, partials, kflag, seq); break;
+      case 2: launch_round<2>(c, a, bind, size, tp, (unsigned)g, partials, kflag, seq); break;
+      case 3: launch_round<3>(c, a, bind, size, tp, (unsigned)g, partials, kflag, seq); break;
+      case 4: launch_round<4>(c, a, bind, size, tp, (unsigned)g, partials, kflag, seq); break;
+      case 5: launch_round<5>(c, a, bind, size, tp, (unsigned)g, partials, kflag, seq); break;
+      default: launch_round<6>(c, a, bind, size, tp, (unsigned)g, partials, kflag, seq); break;
+    }
   }
   if (g > 1)
     hipLaunchKernelGGL(sc_reduce_kernel, dim3(1), dim3(256), 0, c.stream, partials, (int)g, degree, evals_host, c.flag,
