@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-SEED_BASE = 0x4C4153534F00
+SEED_BASE = 0x4C4153534F00  # SURVEY.md §8d (same constant as halo2-lasso_amd/dist.py)
 
 
 def parse():
@@ -51,7 +51,8 @@ def make_table(hl, kind):
 
 
 def gen_dims(table, n, rank):
-    rng = np.random.Generator(np.random.PCG64(SEED_BASE + n + 1000003 * rank))
+    from halo2_lasso_amd import dist as hdist
+    rng = np.random.Generator(np.random.PCG64(hdist.batch_seed(n, rank)))
     return [rng.integers(0, 1 << table.l, size=1 << n, dtype=np.uint32) for _ in range(table.c)]
 
 
@@ -134,17 +135,9 @@ def cpu_baseline(hl, ctx, pp, table, kind, args, gpu_proof_fn):
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist_
-        dist = dist_
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo", rank=rank, world_size=world)
+    from halo2_lasso_amd import dist as hdist
+    rank, local_rank, world = hdist.env_rank()
+    dist = hdist.init()
 
     import halo2_lasso_amd as hl
     ctx = hl.Context(local_rank)
@@ -164,7 +157,7 @@ def main():
         if dist is not None:
             import torch
             torch.cuda.synchronize()
-            dist.barrier()
+        hdist.barrier(dist)
 
     for _ in range(args.warmup):
         prove()
@@ -173,15 +166,12 @@ def main():
     for _ in range(args.steps):
         tr = prove()
     ctx.sync()
-    elapsed = time.perf_counter() - t0
-    phases = hl.lasso_last_timing(ctx)
     if dist is not None:
         import torch
         torch.cuda.synchronize()
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if torch.cuda.is_available() else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        dist.barrier()
+    elapsed = hdist.max_over_ranks(dist, time.perf_counter() - t0)
+    hdist.barrier(dist)
+    phases = hl.lasso_last_timing(ctx)
     ms_per_step = elapsed * 1e3 / max(args.steps, 1)
     proof_len = len(tr.into_proof())
 

@@ -1,0 +1,60 @@
+"""Multi-GPU plumbing (torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" on CPU for tests).
+
+Round 1 shards the UNITS of work: every rank proves its own independent batch of lookups (its own
+witness, the same SRS), there is no data-path collective; the only exchanges are the barrier and the
+max-over-ranks of the timed region that bench.py's contract asks for.  (Sharding ONE proof across ranks
+- SURVEY.md §8e - needs the partial-sum exchange inside the host prover and is the next row.)
+"""
+import os
+
+SEED_BASE = 0x4C4153534F00
+
+
+def env_rank():
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init(backend=None):
+    """Returns the torch.distributed module (initialised) or None for a single process."""
+    rank, local_rank, world = env_rank()
+    if world <= 1:
+        return None
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+    if not dist.is_initialized():
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return dist
+
+
+def batch_seed(log_n, rank):
+    """PRNG seed of the lookup batch that `rank` proves: disjoint streams per rank, reproducible."""
+    return SEED_BASE + log_n + 1000003 * rank
+
+
+def max_over_ranks(dist, seconds):
+    if dist is None:
+        return seconds
+    import torch
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier(dist):
+    if dist is not None:
+        dist.barrier()
+
+
+def job_metrics(elapsed_s, steps, world, lookups_per_proof):
+    """bench.py numbers for a weak-scaling job: every rank did `steps` proofs in (max) elapsed_s."""
+    ms_per_step = elapsed_s * 1e3 / max(steps, 1)
+    return {"ms_per_step": ms_per_step, "value_ms_per_proof": ms_per_step / world,
+            "lookups_per_s": lookups_per_proof * world / (ms_per_step / 1e3)}
