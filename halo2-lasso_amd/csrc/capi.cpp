@@ -48,6 +48,8 @@ lh_status lh_ctx_create(int device_id, lh_ctx** out) {
   ctx->c.pin(65536);
   LH_HIP(hipHostMalloc((void**)&ctx->c.flag, 64, hipHostMallocCoherent | hipHostMallocMapped));
   *ctx->c.flag = 0;
+  LH_HIP(hipMalloc((void**)&ctx->c.ticket, 64));
+  LH_HIP(hipMemset(ctx->c.ticket, 0, 64));
   *out = ctx;
   LH_CATCH
 }
@@ -58,6 +60,7 @@ void lh_ctx_destroy(lh_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->c.stream);
   if (ctx->c.pinned) (void)hipHostFree(ctx->c.pinned);
   if (ctx->c.flag) (void)hipHostFree(ctx->c.flag);
+  if (ctx->c.ticket) (void)hipFree(ctx->c.ticket);
   (void)hipStreamDestroy(ctx->c.stream);
   delete ctx;
 }

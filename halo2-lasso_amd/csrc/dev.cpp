@@ -64,6 +64,12 @@ void Ctx::wait_flag(uint32_t seq) {
   }
 }
 
+ScFinishArgs Ctx::finish_for(uint32_t grid, Fr* out_host, uint32_t seq) {
+  ScFinishArgs f{ticket, (uint32_t)(ticket_base + grid - 1), out_host, flag, seq};
+  if (grid > 1) ticket_base += grid;  // single-workgroup launches draw no ticket
+  return f;
+}
+
 void* Ctx::pin(size_t bytes) {
   if (bytes > pinned_bytes) {
     if (pinned) (void)hipHostFree(pinned);

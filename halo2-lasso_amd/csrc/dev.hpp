@@ -81,6 +81,14 @@ struct ProfRec {
   double items;  // work items (pairs, points, ...)
 };
 
+struct ScFinishArgs {
+  uint32_t* ticket;      // device counter
+  uint32_t last_ticket;  // value the last workgroup of this launch draws
+  Fr* out_host;          // pinned
+  uint32_t* flag;        // pinned
+  uint32_t seq;
+};
+
 // ------------------------------------------------------------------ context
 struct Ctx {
   int device = 0;
@@ -101,6 +109,9 @@ struct Ctx {
   // hipStreamSynchronize (tens of microseconds per call, paid once per sum-check round).
   uint32_t* flag = nullptr;  // pinned, coherent
   uint32_t flag_seq = 0;
+  uint32_t* ticket = nullptr;  // device counter for in-launch final reductions; only ever grows
+  uint32_t ticket_base = 0;    // its value before the next launch
+  struct ScFinishArgs finish_for(uint32_t grid, Fr* out_host, uint32_t seq);
   uint32_t next_seq() { return ++flag_seq; }
   void wait_flag(uint32_t seq);
 };

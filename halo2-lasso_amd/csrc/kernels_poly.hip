@@ -231,48 +231,43 @@ __global__ __launch_bounds__(256) void eq_small_kernel(EqYs ys, int levels, Fr* 
   for (int k = threadIdx.x; k < n; k += blockDim.x) out[k] = cur[k];
 }
 
+// out[(hi << lo_bits) | lo] = hi_tab[hi] * lo_tab[lo]: eq tables factor over disjoint variable sets
+__global__ void eq_outer_kernel(const Fr* __restrict__ lo_tab, int lo_bits, const Fr* __restrict__ hi_tab, size_t n,
+                                Fr* __restrict__ out) {
+  const size_t mask = ((size_t)1 << lo_bits) - 1;
+  GSTRIDE(i, n) out[i] = mul(hi_tab[i >> lo_bits], lo_tab[i & mask]);
+}
+
+// eq_xy(y) for any size in at most 5 launches: tables of <= 9 variables come from one workgroup each
+// (eq_small_kernel), larger ones are outer products of those (1 multiplication per entry, as the
+// level-by-level expansion, but without a launch per variable).
 void k_eq_xy(Ctx& c, const Fr* y, size_t num_vars, Fr* out) {
   ProfScope ps(c, "eq_xy", 64.0 * ((size_t)1 << num_vars), 1.0 * ((size_t)1 << num_vars), (double)((size_t)1 << num_vars));
-  {
-    // levels are expanded from the LAST y to the first (multilinear.rs:103): the small kernel does the
-    // first min(num_vars, EQ_SMALL) of them
-    const int small = (int)std::min<size_t>(num_vars, EQ_SMALL);
+  auto small = [&](size_t first, size_t cnt, Fr* dst) {  // eq over y[first .. first+cnt), cnt <= EQ_SMALL
     EqYs ys;
-    for (int i = 0; i < small; i++) ys.y[i] = y[num_vars - 1 - i];
-    if ((size_t)small == num_vars) {
-      hipLaunchKernelGGL(eq_small_kernel, dim3(1), dim3(256), 0, c.stream, ys, small, out);
-      return;
-    }
-    ArenaScope scope(c.arena);
-    size_t half = (size_t)1 << (num_vars - 1);
-    Fr* tmp = c.arena.alloc_n<Fr>(half);
-    Fr* bufs[2] = {out, tmp};
-    const size_t rest = num_vars - small;
-    int cur = (rest & 1) ? 1 : 0;  // after `rest` more flips we must end in bufs[0]
-    hipLaunchKernelGGL(eq_small_kernel, dim3(1), dim3(256), 0, c.stream, ys, small, bufs[cur]);
-    size_t n = (size_t)1 << small;
-    for (size_t i = rest; i-- > 0;) {
-      hipLaunchKernelGGL(eq_expand_kernel, grid_for(n), 256, 0, c.stream, bufs[cur], n, y[i], bufs[cur ^ 1]);
-      cur ^= 1;
-      n <<= 1;
-    }
+    for (size_t i = 0; i < cnt; i++) ys.y[i] = y[first + cnt - 1 - i];  // expanded last-to-first (multilinear.rs:103)
+    hipLaunchKernelGGL(eq_small_kernel, dim3(1), dim3(256), 0, c.stream, ys, (int)cnt, dst);
+  };
+  if (num_vars <= (size_t)EQ_SMALL) {
+    small(0, num_vars, out);
     return;
   }
-  // ping-pong so that the final level (2^num_vars) is written to `out`
   ArenaScope scope(c.arena);
-  size_t half = num_vars ? (size_t)1 << (num_vars - 1) : 1;
-  Fr* tmp = c.arena.alloc_n<Fr>(half);
-  Fr* bufs[2] = {out, tmp};
-  int cur = (num_vars & 1) ? 1 : 0;  // after num_vars flips we must end in bufs[0]
-  hipLaunchKernelGGL(fr_set_one_kernel, 1, 1, 0, c.stream, bufs[cur]);
-  size_t n = 1;
-  for (size_t i = num_vars; i-- > 0;) {
-    hipLaunchKernelGGL(eq_expand_kernel, grid_for(n), 256, 0, c.stream, bufs[cur], n, y[i], bufs[cur ^ 1]);
-    cur ^= 1;
-    n <<= 1;
+  // split the variables into groups of <= 9: index bits [0,9) | [9,18) | [18,27) | ...
+  size_t done = std::min<size_t>(num_vars, EQ_SMALL);
+  Fr* cur = c.arena.alloc_n<Fr>((size_t)1 << done);
+  small(0, done, cur);
+  while (done < num_vars) {
+    size_t cnt = std::min<size_t>(num_vars - done, EQ_SMALL);
+    Fr* hi = c.arena.alloc_n<Fr>((size_t)1 << cnt);
+    small(done, cnt, hi);
+    const bool last = done + cnt == num_vars;
+    size_t n = (size_t)1 << (done + cnt);
+    Fr* dst = last ? out : c.arena.alloc_n<Fr>(n);
+    hipLaunchKernelGGL(eq_outer_kernel, grid_for(n), 256, 0, c.stream, cur, (int)done, hi, n, dst);
+    cur = dst;
+    done += cnt;
   }
-  // tmp is released when the scope ends; stream order keeps it valid for the queued kernels,
-  // later arena users are queued behind them on the same stream.
 }
 
 // ------------------------------------------------------------------ linear combination

@@ -50,9 +50,47 @@ __device__ __forceinline__ void publish_flag(uint32_t* flag, uint32_t seq) {
   __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Final cross-workgroup reduction WITHOUT a second launch.  Every workgroup has stored its D partial sums
+// (threads of wave 0, plain stores); it then draws a ticket from a counter that only ever grows (the host
+// knows its value before the launch, so nothing has to be zeroed).  The workgroup that draws the last
+// ticket of the launch re-reads all partials, sums them and publishes the result to the host.
+// Hand-off protocol: cdna_hip_programming.md Guideline 16 (agent-scope release by every producer,
+// agent-scope acquire by the one consumer, never placement-dependent).
+typedef ScFinishArgs ScFinish;
+
+template <int D>
+__device__ __forceinline__ void finish_round(const ScFinish& f, const Fr* __restrict__ partials, Fr* lds) {
+  __shared__ int is_last;
+  if (threadIdx.x < 64) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's partial stores have left
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const uint32_t t = __hip_atomic_fetch_add(f.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = t == f.last_ticket;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      is_last = last;
+    }
+  }
+  __syncthreads();
+  if (!is_last) return;
+  const uint32_t blocks = gridDim.x;
+#pragma unroll
+  for (int x = 0; x < D; x++) {
+    Fr acc = Fr::zero();
+    for (uint32_t i = threadIdx.x; i < blocks; i += blockDim.x) acc = add(acc, partials[(size_t)i * D + x]);
+    acc = block_reduce_sum(acc, lds);
+    if (threadIdx.x == 0) f.out_host[x] = acc;
+  }
+  if (threadIdx.x == 0) publish_flag(f.flag, f.seq);
+}
+
 template <int D, bool BIND>
 __global__ __launch_bounds__(256) void sc_round_kernel(ScArgs a, size_t size, uint32_t tp,
-                                                       Fr* __restrict__ partials, uint32_t* flag, uint32_t seq) {
+                                                       Fr* __restrict__ partials, ScFinish fin) {
   __shared__ Fr lds[4];
   const ScRound& rd = a.rd;
   Fr acc[D];
@@ -117,7 +155,11 @@ __global__ __launch_bounds__(256) void sc_round_kernel(ScArgs a, size_t size, ui
     Fr v = block_reduce_sum(acc[x], lds);
     if (threadIdx.x == 0) partials[(size_t)blockIdx.x * D + x] = v;
   }
-  if (flag && threadIdx.x == 0) publish_flag(flag, seq);  // single-workgroup launch: partials IS the host buffer
+  if (gridDim.x == 1) {  // single workgroup: `partials` IS the host buffer
+    if (threadIdx.x == 0) publish_flag(fin.flag, fin.seq);
+    return;
+  }
+  finish_round<D>(fin, partials, lds);
 }
 
 // ------------------------------------------------------------------ small / medium rounds: LDS-staged
@@ -140,7 +182,7 @@ struct ScLdsArgs {
 
 template <int D, bool BIND>
 __global__ __launch_bounds__(256) void sc_round_lds_kernel(ScLdsArgs g, size_t size, Fr* __restrict__ partials,
-                                                           uint32_t* flag, uint32_t seq) {
+                                                           ScFinish fin) {
   __shared__ Fr vals[LDS_VALS];
   __shared__ Fr red[LDS_ITEMS];
   const ScRound& rd = g.a.rd;
@@ -206,22 +248,23 @@ __global__ __launch_bounds__(256) void sc_round_lds_kernel(ScLdsArgs g, size_t s
     Fr s = Fr::zero();
     for (uint32_t m = 0; m < rd.num_terms; m++) s = add(s, red[m * D + threadIdx.x]);
     partials[(size_t)blockIdx.x * D + threadIdx.x] = s;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    if (gridDim.x == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
   }
-  if (flag) {
+  if (gridDim.x == 1) {  // single workgroup: `partials` IS the host buffer
     __syncthreads();
-    if (threadIdx.x == 0) publish_flag(flag, seq);
+    if (threadIdx.x == 0) publish_flag(fin.flag, fin.seq);
+    return;
   }
+  finish_round<D>(fin, partials, vals);  // vals is free again: 4 slots of it serve as reduction scratch
 }
 
 template <int D>
-static void launch_lds(Ctx& c, const ScLdsArgs& g, bool bind, size_t size, unsigned grid, Fr* partials, uint32_t* flag,
-                       uint32_t seq) {
+static void launch_lds(Ctx& c, const ScLdsArgs& g, bool bind, size_t size, unsigned grid, Fr* partials,
+                       const ScFinish& fin) {
   if (bind)
-    hipLaunchKernelGGL((sc_round_lds_kernel<D, true>), dim3(grid), dim3(256), 0, c.stream, g, size, partials, flag, seq);
+    hipLaunchKernelGGL((sc_round_lds_kernel<D, true>), dim3(grid), dim3(256), 0, c.stream, g, size, partials, fin);
   else
-    hipLaunchKernelGGL((sc_round_lds_kernel<D, false>), dim3(grid), dim3(256), 0, c.stream, g, size, partials, flag,
-                       seq);
+    hipLaunchKernelGGL((sc_round_lds_kernel<D, false>), dim3(grid), dim3(256), 0, c.stream, g, size, partials, fin);
 }
 
 __global__ void sc_reduce_kernel(const Fr* __restrict__ partials, int blocks, int d, Fr* __restrict__ out,
@@ -238,12 +281,11 @@ __global__ void sc_reduce_kernel(const Fr* __restrict__ partials, int blocks, in
 
 template <int D>
 static void launch_round(Ctx& c, const ScArgs& a, bool bind, size_t size, uint32_t tp, unsigned grid, Fr* partials,
-                         uint32_t* flag, uint32_t seq) {
+                         const ScFinish& fin) {
   if (bind)
-    hipLaunchKernelGGL((sc_round_kernel<D, true>), dim3(grid), dim3(256), 0, c.stream, a, size, tp, partials, flag, seq);
+    hipLaunchKernelGGL((sc_round_kernel<D, true>), dim3(grid), dim3(256), 0, c.stream, a, size, tp, partials, fin);
   else
-    hipLaunchKernelGGL((sc_round_kernel<D, false>), dim3(grid), dim3(256), 0, c.stream, a, size, tp, partials, flag,
-                       seq);
+    hipLaunchKernelGGL((sc_round_kernel<D, false>), dim3(grid), dim3(256), 0, c.stream, a, size, tp, partials, fin);
 }
 
 void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, Fr* evals_host) {
@@ -298,23 +340,20 @@ void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, F
     g.P = P;
     size_t grid = (size + P - 1) / P;
     Fr* partials = grid == 1 ? evals_host : c.arena.alloc_n<Fr>(grid * degree);
-    uint32_t* kflag = grid == 1 ? c.flag : nullptr;
+    const ScFinish kflag = c.finish_for((uint32_t)grid, evals_host, seq);
     {
       char name[40];
       snprintf(name, sizeof name, "sc_round<%d,%s>/lds", degree, bind ? "bind" : "first");
       ProfScope ps(c, name, bytes, muls_pair * (double)size, (double)size);
       switch (degree) {
-        case 1: launch_lds<1>(c, g, bind, size, (unsigned)grid, partials, kflag, seq); break;
-        case 2: launch_lds<2>(c, g, bind, size, (unsigned)grid, partials, kflag, seq); break;
-        case 3: launch_lds<3>(c, g, bind, size, (unsigned)grid, partials, kflag, seq); break;
-        case 4: launch_lds<4>(c, g, bind, size, (unsigned)grid, partials, kflag, seq); break;
-        case 5: launch_lds<5>(c, g, bind, size, (unsigned)grid, partials, kflag, seq); break;
-        default: launch_lds<6>(c, g, bind, size, (unsigned)grid, partials, kflag, seq); break;
+        case 1: launch_lds<1>(c, g, bind, size, (unsigned)grid, partials, kflag); break;
+        case 2: launch_lds<2>(c, g, bind, size, (unsigned)grid, partials, kflag); break;
+        case 3: launch_lds<3>(c, g, bind, size, (unsigned)grid, partials, kflag); break;
+        case 4: launch_lds<4>(c, g, bind, size, (unsigned)grid, partials, kflag); break;
+        case 5: launch_lds<5>(c, g, bind, size, (unsigned)grid, partials, kflag); break;
+        default: launch_lds<6>(c, g, bind, size, (unsigned)grid, partials, kflag); break;
       }
     }
-    if (grid > 1)
-      hipLaunchKernelGGL(sc_reduce_kernel, dim3(1), dim3(256), 0, c.stream, partials, (int)grid, degree, evals_host,
-                         c.flag, seq);
     c.wait_flag(seq);
     return;
   }
@@ -330,23 +369,20 @@ void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, F
   size_t cap = (size_t)c.num_cus * 4;
   if (g > cap) g = cap;
   Fr* partials = g == 1 ? evals_host : c.arena.alloc_n<Fr>(g * degree);
-  uint32_t* kflag = g == 1 ? c.flag : nullptr;
+  const ScFinish kflag = c.finish_for((uint32_t)g, evals_host, seq);
   {
     char name[40];
     snprintf(name, sizeof name, "sc_round<%d,%s>%s", degree, bind ? "bind" : "first", tp > 1 ? "/tp" : "");
     ProfScope ps(c, name, bytes, muls_pair * (double)size, (double)size);
     switch (degree) {
-      case 1: launch_round<1>(c, a, bind, size, tp, (unsigned)g, partials, kflag, seq); break;
-      case 2: launch_round<2>(c, a, bind, size, tp, (unsigned)g, partials, kflag, seq); break;
-      case 3: launch_round<3>(c, a, bind, size, tp, (unsigned)g, partials, kflag, seq); break;
-      case 4: launch_round<4>(c, a, bind, size, tp, (unsigned)g, partials, kflag, seq); break;
-      case 5: launch_round<5>(c, a, bind, size, tp, (unsigned)g, partials, kflag, seq); break;
-      default: launch_round<6>(c, a, bind, size, tp, (unsigned)g, partials, kflag, seq); break;
+      case 1: launch_round<1>(c, a, bind, size, tp, (unsigned)g, partials, kflag); break;
+      case 2: launch_round<2>(c, a, bind, size, tp, (unsigned)g, partials, kflag); break;
+      case 3: launch_round<3>(c, a, bind, size, tp, (unsigned)g, partials, kflag); break;
+      case 4: launch_round<4>(c, a, bind, size, tp, (unsigned)g, partials, kflag); break;
+      case 5: launch_round<5>(c, a, bind, size, tp, (unsigned)g, partials, kflag); break;
+      default: launch_round<6>(c, a, bind, size, tp, (unsigned)g, partials, kflag); break;
     }
   }
-  if (g > 1)
-    hipLaunchKernelGGL(sc_reduce_kernel, dim3(1), dim3(256), 0, c.stream, partials, (int)g, degree, evals_host, c.flag,
-                       seq);
   c.wait_flag(seq);
 }
 

@@ -41,6 +41,8 @@ struct MsmJobDev {
   uint32_t c, W;        // window bits, number of windows
   uint32_t key_base;    // first bucket key of this job
   uint32_t entry_base;  // first (key, index) pair of this job: pair of (window w, element i) at w*n + i
+  uint32_t win_stride;  // bucket slots per window (multiple of seg_size)
+  uint32_t is_signed;   // Fr jobs use signed digits: buckets 1..2^(c-1), the sign travels in bit 31 of the index
   uint32_t seg_base;    // first reduce-segment of this job
   uint32_t seg_per_win; // segments per window
   uint32_t seg_size;    // buckets per segment
@@ -65,12 +67,17 @@ __global__ void msm_or_limbs_kernel(MsmPlanDev plan, uint32_t* __restrict__ or_o
 #pragma unroll
     for (int k = 0; k < 8; k++) acc[k] |= s.l[k];
   }
+  __shared__ uint32_t lds_or[8];
+  if (threadIdx.x < 8) lds_or[threadIdx.x] = 0;
+  __syncthreads();
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     uint32_t v = acc[k];
     for (int off = 32; off > 0; off >>= 1) v |= __shfl_xor(v, off, 64);
-    if ((threadIdx.x & 63) == 0 && v) atomicOr(&or_out[blockIdx.y * 8 + k], v);
+    if ((threadIdx.x & 63) == 0 && v) atomicOr(&lds_or[k], v);
   }
+  __syncthreads();
+  if (threadIdx.x < 8 && lds_or[threadIdx.x]) atomicOr(&or_out[blockIdx.y * 8 + threadIdx.x], lds_or[threadIdx.x]);
 }
 
 __global__ void msm_emit_kernel(MsmPlanDev plan, uint32_t sentinel, uint32_t* __restrict__ keys,
@@ -92,10 +99,20 @@ __global__ void msm_emit_kernel(MsmPlanDev plan, uint32_t sentinel, uint32_t* __
     uint64_t buf = 0;
     int have = 0;
     uint32_t w = 0;
-    auto emit = [&](uint32_t d) {
+    uint32_t carry = 0;
+    const uint32_t half = 1u << (c - 1);
+    auto emit = [&](uint32_t raw) {
+      uint32_t d = raw + carry, neg = 0;
+      if (jb.is_signed) {
+        carry = d > half ? 1u : 0u;
+        if (carry) {
+          d = (1u << c) - d;
+          neg = 0x80000000u;
+        }
+      }
       size_t e = (size_t)jb.entry_base + (size_t)w * jb.n + i;
-      keys[e] = d ? jb.key_base + (w << c) + d : sentinel;
-      vals[e] = (uint32_t)i;
+      keys[e] = d ? jb.key_base + w * jb.win_stride + d : sentinel;
+      vals[e] = (uint32_t)i | neg;
     };
 #pragma unroll
     for (int k = 0; k < 8; k++) {
@@ -110,8 +127,9 @@ __global__ void msm_emit_kernel(MsmPlanDev plan, uint32_t sentinel, uint32_t* __
         }
       }
     }
-    if (w < jb.W) {  // top, partial window
+    while (w < jb.W) {  // top, partial window(s): remaining bits, then the final carry
       emit((uint32_t)buf & mask);
+      buf >>= c;
       w++;
     }
   }
@@ -170,7 +188,8 @@ __global__ __launch_bounds__(128) void msm_accumulate0_kernel(MsmPlanDev plan, c
           cur = k;
           bases = job_of_key(plan, cur).bases;
         }
-        acc = add_mixed(acc, bases[sorted_idx[p]]);
+        const uint32_t iv = sorted_idx[p];
+        acc = add_mixed(acc, bases[iv & 0x7fffffffu], (iv >> 31) != 0);
       }
       if (cont) {
         ck = cur;
@@ -239,7 +258,7 @@ __global__ __launch_bounds__(64) void msm_segment_reduce_kernel(MsmPlanDev plan,
     uint32_t local = (uint32_t)(s - jb.seg_base);
     uint32_t w = local / jb.seg_per_win, seg = local % jb.seg_per_win;
     uint32_t d0 = seg * jb.seg_size;
-    const G1Xyzz* b = buckets + jb.key_base + ((size_t)w << jb.c) + d0;
+    const G1Xyzz* b = buckets + jb.key_base + (size_t)w * jb.win_stride + d0;
     G1Xyzz run = G1Xyzz::identity(), acc = G1Xyzz::identity();
     for (int d = (int)jb.seg_size - 1; d >= 0; d--) {
       acc = add(acc, run);
@@ -311,7 +330,7 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
         ArenaScope scope(c.arena);
         uint32_t* d_or = c.arena.alloc_n<uint32_t>(8 * nj);
         LH_HIP(hipMemsetAsync(d_or, 0, 8 * nj * sizeof(uint32_t), c.stream));
-        dim3 g((unsigned)std::min<size_t>((max_n0 + 255) / 256, 1024), (unsigned)nj);
+        dim3 g((unsigned)std::min<size_t>((max_n0 + 255) / 256, 256), (unsigned)nj);
         hipLaunchKernelGGL(msm_or_limbs_kernel, g, dim3(256), 0, c.stream, plan, d_or);
         uint32_t* h_or = (uint32_t*)c.pin(8 * MSM_MAX_JOBS * sizeof(uint32_t));
         LH_HIP(hipMemcpyAsync(h_or, d_or, 8 * nj * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
@@ -333,15 +352,20 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
       uint32_t bits = job_bits[j];
       jd.bases = in.bases;
       jd.c = pick_window(in.n ? in.n : 1, bits ? bits : 1);
-      jd.W = bits ? (bits + jd.c - 1) / jd.c : 0;
+      jd.is_signed = in.scalars_u32 ? 0 : 1;
+      if (jd.is_signed && jd.c < 2) jd.c = 2;
+      // signed digits need one extra bit of head room for the last carry
+      jd.W = bits ? ((jd.is_signed ? bits + 1 : bits) + jd.c - 1) / jd.c : 0;
       if (!in.n) jd.W = 0;
+      const uint32_t nb = jd.is_signed ? (1u << (jd.c - 1)) + 1u : (1u << jd.c);  // bucket indices 0..nb-1
+      jd.seg_size = 16;
+      jd.seg_per_win = (nb + jd.seg_size - 1) / jd.seg_size;
+      jd.win_stride = jd.seg_per_win * jd.seg_size;
       jd.key_base = key;
       jd.entry_base = (uint32_t)max_entries;
-      jd.seg_size = std::min<uint32_t>(16u, 1u << jd.c);
-      jd.seg_per_win = (1u << jd.c) / jd.seg_size;
       jd.seg_base = seg;
       jd.win_base = win;
-      key += jd.W << jd.c;
+      key += jd.W * jd.win_stride;
       seg += jd.W * jd.seg_per_win;
       win += jd.W;
       max_entries += (size_t)jd.n * jd.W;
