@@ -74,6 +74,31 @@ def aggregate(recs):
     return sorted(by.values(), key=lambda a: -a["ms"])
 
 
+def pmc_traffic(profile_name, log_n, table_kind):
+    """HBM bytes of the kernel's largest launch from the committed PMC passes (profiles/r01_pmc_*.json:
+    rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for streaming reads).  Counters cannot be collected from inside this
+    process, so the figure is the recorded one for the same workload, or None."""
+    if table_kind != "range":
+        return None, None
+    path = os.path.join(ROOT, "profiles", "r01_pmc_2p%d.json" % log_n)
+    if not os.path.exists(path):
+        return None, None
+    import re
+    m = re.match(r"sc_round<(\d),(bind|first)>(/lds|/tp)?$", profile_name)
+    if m:
+        kern = "sc_round_%skernel<%s, %s>" % ("lds_" if m.group(3) == "/lds" else "", m.group(1),
+                                              "true" if m.group(2) == "bind" else "false")
+    else:
+        kern = {"msm_accumulate0": "msm_accumulate0_kernel", "msm_bucket_reduce": "msm_segment_reduce_kernel",
+                "msm_accumulate_levels": "msm_accumulate_n_kernel", "lincomb": "lincomb_kernel",
+                "tree_up": "tree_up_kernel"}.get(profile_name)
+    rec = json.load(open(path))["kernels"].get(kern) if kern else None
+    if not rec:
+        return None, None
+    return rec["hbm_bytes_corrected"], "profiles/%s (%s, largest launch)" % (os.path.basename(path), kern)
+
+
 def fr_mul_peak(hl, ctx):
     """measured peak Fr multiplications / s (dependent chains, full occupancy)"""
     n, iters = 1 << 22, 64
@@ -199,8 +224,10 @@ def main():
             dom = aggs[0]
             big = dom["big"]
             ach = big["bytes"] / (big["ms"] * 1e-3) / 1e9 if big["ms"] > 0 else 0.0
+            traffic, traffic_src = pmc_traffic(dom["name"], n, args.table)
             out["roofline"] = {"bound": "hbm", "kernel": dom["name"], "achieved": round(ach, 1), "peak": 8000.0,
-                               "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
+                               "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic,
+                               "traffic_source": traffic_src,
                                "launch": {"ms": round(big["ms"], 4), "bytes": big["bytes"], "items": big["items"]},
                                "share_of_profiled_prove": round(dom["ms"] / tot, 3), "launches": dom["launches"]}
             mul_rate = big["muls"] / (big["ms"] * 1e-3) if big["ms"] > 0 else 0.0
