@@ -530,6 +530,39 @@ def lasso_prove(pp, table, num_vars, dims, transcript):
     _check(pp.ctx.lib.lh_lasso_prove(pp.ctx.h, pp.h, C.byref(t), num_vars, _ptr_array(dims), transcript.p))
 
 
+def attach_comm(ctx, rank, size, all_gather, shard_bit):
+    """Attach a host-side communicator to the context (sharded proving).
+    all_gather(send: bytes) -> bytes of size * len(send), rank-major."""
+    def cb(_user, send, recv, nbytes):
+        try:
+            out = all_gather(C.string_at(send, nbytes))
+            if len(out) != nbytes * size:
+                return _ffi.LH_ERR_ARG
+            C.memmove(recv, out, len(out))
+            return 0
+        except Exception:  # the library turns this into an lh_status
+            return _ffi.LH_ERR_DEVICE
+    comm = _ffi.lh_comm()
+    comm.rank, comm.size, comm.user = rank, size, None
+    comm.all_gather = _ffi._AG_CB(cb)
+    ctx._comm_keepalive = (comm, cb)
+    _check(ctx.lib.lh_ctx_set_comm(ctx.h, C.byref(comm), shard_bit))
+
+
+def detach_comm(ctx):
+    _check(ctx.lib.lh_ctx_set_comm(ctx.h, None, 0))
+    ctx._comm_keepalive = None
+
+
+def lasso_prove_sharded(pp, table, num_vars, dims, transcript):
+    """One proof over the ranks of the attached communicator; same bytes as lasso_prove.
+    dims: the FULL columns on every rank."""
+    if len(dims) != table.c:
+        raise ArgumentError("expected %d dim columns" % table.c)
+    t = table.to_c()
+    _check(pp.ctx.lib.lh_lasso_prove_sharded(pp.ctx.h, pp.h, C.byref(t), num_vars, _ptr_array(dims), transcript.p))
+
+
 def lasso_last_timing(ctx):
     out = (C.c_double * _ffi.LH_LASSO_NUM_PHASES)()
     _check(ctx.lib.lh_lasso_last_timing(ctx.h, out))

@@ -47,6 +47,13 @@ class lh_lasso_table(C.Structure):
                 ("g_factor", (C.c_uint8 * LH_SC_MAX_FACTORS) * LH_LASSO_MAX_TERMS)]
 
 
+_AG_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+class lh_comm(C.Structure):
+    _fields_ = [("rank", C.c_int), ("size", C.c_int), ("user", C.c_void_p), ("all_gather", _AG_CB)]
+
+
 class lh_prof_rec(C.Structure):
     _fields_ = [("name", C.c_char * 40), ("ms", C.c_double), ("bytes", C.c_double), ("muls", C.c_double),
                 ("items", C.c_double)]
@@ -116,6 +123,9 @@ SIGNATURES = {
                                      C.POINTER(lh_evaluation), _SZ, C.POINTER(lh_transcript)]),
     "lh_lasso_prove": (C.c_int, [_P, _P, C.POINTER(lh_lasso_table), _SZ, C.POINTER(_P), C.POINTER(lh_transcript)]),
     "lh_lasso_last_timing": (C.c_int, [_P, C.POINTER(C.c_double)]),
+    "lh_ctx_set_comm": (C.c_int, [_P, C.POINTER(lh_comm), _SZ]),
+    "lh_lasso_prove_sharded": (C.c_int, [_P, _P, C.POINTER(lh_lasso_table), _SZ, C.POINTER(_P),
+                                         C.POINTER(lh_transcript)]),
     "lh_profile_enable": (C.c_int, [_P, C.c_int]),
     "lh_profile_read": (C.c_int, [_P, C.POINTER(lh_prof_rec), _SZ, C.POINTER(_SZ)]),
 }

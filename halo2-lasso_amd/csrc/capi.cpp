@@ -312,6 +312,8 @@ void lh_srs_free(lh_ctx* ctx, lh_srs* srs) {
   if (!srs) return;
   if (ctx) (void)hipStreamSynchronize(ctx->c.stream);
   if (srs->s.d_eqs) (void)hipFree(srs->s.d_eqs);
+  for (G1Affine* p : srs->s.shard_levels)
+    if (p) (void)hipFree(p);
   delete srs;
 }
 
@@ -366,6 +368,33 @@ lh_status lh_lasso_last_timing(lh_ctx* ctx, double* out_ms) {
   LH_TRY NEED(ctx);
   NEED(out_ms);
   memcpy(out_ms, ctx->c.lasso_ms, sizeof(ctx->c.lasso_ms));
+  LH_CATCH
+}
+
+lh_status lh_ctx_set_comm(lh_ctx* ctx, const lh_comm* comm, size_t shard_bit) {
+  LH_TRY NEED(ctx);
+  ctx->c.sync();
+  if (!comm) {
+    ctx->c.has_comm = false;
+    ctx->c.comm = lh_comm{0, 1, nullptr, nullptr};
+  } else {
+    LH_REQUIRE(comm->size >= 1 && (comm->size & (comm->size - 1)) == 0 && comm->rank >= 0 && comm->rank < comm->size,
+               LH_ERR_ARG, "communicator: size must be a power of two and 0 <= rank < size");
+    LH_REQUIRE(comm->size == 1 || comm->all_gather, LH_ERR_ARG, "communicator: all_gather callback missing");
+    ctx->c.comm = *comm;
+    ctx->c.has_comm = true;
+    ctx->c.shard_bit = shard_bit;
+  }
+  LH_CATCH
+}
+lh_status lh_lasso_prove_sharded(lh_ctx* ctx, const lh_srs* srs, const lh_lasso_table* table, size_t num_vars,
+                                 const uint32_t* const* d_dims, lh_transcript* t) {
+  LH_TRY NEED(ctx);
+  NEED(srs);
+  NEED(table);
+  NEED(d_dims);
+  Transcript tr(t);
+  lasso_prove_sharded(ctx->c, srs->s, *table, num_vars, d_dims, tr);
   LH_CATCH
 }
 

@@ -99,6 +99,10 @@ struct Ctx {
   size_t pinned_bytes = 0;
   int num_cus = 256;
   double lasso_ms[LH_LASSO_NUM_PHASES] = {0};
+  // one proof over several GPUs: host-side communicator + position of the shard bits
+  lh_comm comm = {0, 1, nullptr, nullptr};
+  bool has_comm = false;
+  size_t shard_bit = 0;
   bool prof = false;
   std::vector<ProfRec> prof_recs;
   hipEvent_t prof_ev[2] = {nullptr, nullptr};
@@ -190,6 +194,12 @@ struct LassoG {
   const uint32_t* e[LH_LASSO_MAX_MEMORIES];
 };
 void k_lasso_output(Ctx&, const LassoG& g, size_t n, Fr* a);
+
+// ------------------------------------------------------------------ sharding helpers (kernels_poly.hip)
+// local[idx] = global[((idx >> j) << (j + rho)) | (s << j) | (idx & (2^j - 1))], elements of `elem` bytes (4, 32, 64)
+void k_shard_extract(Ctx&, const void* global, size_t n_local, size_t j, size_t rho, size_t s, size_t elem, void* local);
+// out[i] = in[i] * w
+void k_scale(Ctx&, const Fr* in, const Fr& w, size_t n, Fr* out);
 
 // ------------------------------------------------------------------ sum-check round (kernels_sumcheck.hip)
 constexpr int SC_MAX_TABLES = 40;

@@ -88,6 +88,17 @@ struct SumCheckResult {
 SumCheckResult sum_check_prove(Ctx&, int prover_kind, size_t num_vars, const lh_sop& expr, const Fr* const* d_polys,
                                size_t num_polys, const HFr* ys, size_t num_ys, const HFr& sum, Transcript& tr);
 
+// one proof over several GPUs: same messages, tables are this rank's shards
+SumCheckResult sum_check_prove_sharded(Ctx&, int prover_kind, size_t num_vars, const lh_sop& expr,
+                                       const Fr* const* d_polys_local, size_t num_polys, const HFr* ys, size_t num_ys,
+                                       const HFr& sum, Transcript& tr);
+std::vector<HFr> evaluate_polys_sharded(Ctx&, const Fr* const* d_polys_local, size_t count, size_t num_vars,
+                                        const HFr* point);
+void comm_sum_fr(Ctx&, HFr* v, size_t n);
+void comm_sum_points(Ctx&, HG1* pts, size_t n);
+void comm_gather_interleave(Ctx&, const Fr* const* local, size_t count, size_t n_local, Fr* const* out);
+void comm_gather_concat(Ctx&, const Fr* local, size_t n_local, Fr* out);
+
 // ------------------------------------------------------------------ piop::gkr
 struct FracSumCheckResult {
   std::vector<HFr> p_xs, q_xs, x;
@@ -107,6 +118,10 @@ struct Srs {
   G1Affine* d_eqs = nullptr;  // flat: level k at offset 2^k - 1
   size_t num_vars = 0;
   const G1Affine* eq(size_t k) const { return d_eqs + (((size_t)1 << k) - 1); }
+  // this rank's share of the bases of every sharded level (sharded proving; built on first use)
+  mutable std::vector<G1Affine*> shard_levels;
+  mutable int shard_rank = -1;
+  mutable size_t shard_R = 0, shard_j = 0;
 };
 Srs* mkzg_setup(Ctx&, const HFr* ss, size_t num_vars);
 std::vector<HG1> mkzg_batch_commit(Ctx&, const Srs&, const Fr* const* d_polys, size_t num_polys, size_t num_vars);
@@ -120,5 +135,7 @@ void mkzg_batch_open(Ctx&, const Srs&, size_t num_vars, const Fr* const* d_polys
 // ------------------------------------------------------------------ Lasso
 void lasso_prove(Ctx&, const Srs&, const lh_lasso_table& table, size_t num_vars, const uint32_t* const* d_dims,
                  Transcript& tr);
+void lasso_prove_sharded(Ctx&, const Srs&, const lh_lasso_table& table, size_t num_vars,
+                         const uint32_t* const* d_dims, Transcript& tr);
 
 }  // namespace lh

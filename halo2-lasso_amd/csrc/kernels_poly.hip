@@ -270,6 +270,39 @@ void k_eq_xy(Ctx& c, const Fr* y, size_t num_vars, Fr* out) {
   }
 }
 
+// ------------------------------------------------------------------ sharding helpers
+template <class T>
+__global__ void shard_extract_kernel(const T* __restrict__ g, size_t n_local, unsigned j, unsigned rho, size_t s,
+                                     T* __restrict__ local) {
+  const size_t lo_mask = ((size_t)1 << j) - 1;
+  GSTRIDE(i, n_local) local[i] = g[((i >> j) << (j + rho)) | (s << j) | (i & lo_mask)];
+}
+struct alignas(16) Bytes64 {
+  uint4 a, b, c, d;
+};
+void k_shard_extract(Ctx& c, const void* global, size_t n_local, size_t j, size_t rho, size_t s, size_t elem,
+                     void* local) {
+  if (!n_local) return;
+  dim3 g = grid_for(n_local);
+  if (elem == 4)
+    hipLaunchKernelGGL(shard_extract_kernel<uint32_t>, g, 256, 0, c.stream, (const uint32_t*)global, n_local, (unsigned)j,
+                       (unsigned)rho, s, (uint32_t*)local);
+  else if (elem == 32)
+    hipLaunchKernelGGL(shard_extract_kernel<Fr>, g, 256, 0, c.stream, (const Fr*)global, n_local, (unsigned)j,
+                       (unsigned)rho, s, (Fr*)local);
+  else if (elem == 64)
+    hipLaunchKernelGGL(shard_extract_kernel<Bytes64>, g, 256, 0, c.stream, (const Bytes64*)global, n_local, (unsigned)j,
+                       (unsigned)rho, s, (Bytes64*)local);
+  else
+    throw Error(LH_ERR_ARG, "shard_extract: unsupported element size");
+}
+__global__ void scale_kernel(const Fr* __restrict__ in, Fr w, size_t n, Fr* __restrict__ out) {
+  GSTRIDE(i, n) out[i] = mul(in[i], w);
+}
+void k_scale(Ctx& c, const Fr* in, const Fr& w, size_t n, Fr* out) {
+  if (n) hipLaunchKernelGGL(scale_kernel, grid_for(n), 256, 0, c.stream, in, w, n, out);
+}
+
 // ------------------------------------------------------------------ linear combination
 constexpr int LC_MAX = 32;
 struct LcPack {

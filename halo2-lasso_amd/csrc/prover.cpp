@@ -79,18 +79,119 @@ static HFr horner(const std::vector<HFr>& coeffs, const HFr& x) {
   return acc;
 }
 
+// ------------------------------------------------------------------ communicator helpers (sharded proving)
+static void comm_all_gather(Ctx& c, const void* send, void* recv, size_t bytes) {
+  LH_REQUIRE(c.has_comm && c.comm.all_gather, LH_ERR_ARG, "no communicator attached (lh_ctx_set_comm)");
+  int rc = c.comm.all_gather(c.comm.user, send, recv, bytes);
+  if (rc != 0) throw Error(rc < 0 ? rc : LH_ERR_DEVICE, "communicator all_gather failed");
+}
+
+void comm_sum_fr(Ctx& c, HFr* v, size_t n) {
+  const size_t R = (size_t)c.comm.size;
+  std::vector<HFr> all(n * R);
+  comm_all_gather(c, v, all.data(), n * sizeof(HFr));
+  for (size_t i = 0; i < n; i++) {
+    HFr acc = HFr::zero();
+    for (size_t r = 0; r < R; r++) acc += all[r * n + i];
+    v[i] = acc;
+  }
+}
+
+void comm_sum_points(Ctx& c, HG1* pts, size_t n) {
+  const size_t R = (size_t)c.comm.size;
+  std::vector<HG1> all(n * R);
+  comm_all_gather(c, pts, all.data(), n * sizeof(HG1));
+  for (size_t i = 0; i < n; i++) {
+    host::G1Xyzz acc = host::G1Xyzz::identity();
+    for (size_t r = 0; r < R; r++) acc = host::g1_add(acc, host::g1_from_affine(all[r * n + i]));
+    pts[i] = host::g1_to_affine(acc);
+  }
+}
+
+// out[t][hi * R + s] = (rank s).local[t][hi]   (the shard bits have reached bit 0)
+void comm_gather_interleave(Ctx& c, const Fr* const* local, size_t count, size_t n_local, Fr* const* out) {
+  const size_t R = (size_t)c.comm.size;
+  std::vector<HFr> mine(count * n_local), all(count * n_local * R), full(n_local * R);
+  for (size_t t = 0; t < count; t++)
+    LH_HIP(hipMemcpyAsync(mine.data() + t * n_local, local[t], n_local * sizeof(Fr), hipMemcpyDeviceToHost, c.stream));
+  c.sync();
+  comm_all_gather(c, mine.data(), all.data(), count * n_local * sizeof(HFr));
+  for (size_t t = 0; t < count; t++) {
+    for (size_t s = 0; s < R; s++)
+      for (size_t hi = 0; hi < n_local; hi++) full[hi * R + s] = all[(s * count + t) * n_local + hi];
+    LH_HIP(hipMemcpyAsync(out[t], full.data(), n_local * R * sizeof(Fr), hipMemcpyHostToDevice, c.stream));
+    c.sync();  // `full` is reused
+  }
+}
+
+// out[s * n_local + i] = (rank s).local[i]   (the shard bits are the top bits)
+void comm_gather_concat(Ctx& c, const Fr* local, size_t n_local, Fr* out) {
+  const size_t R = (size_t)c.comm.size;
+  std::vector<HFr> mine(n_local), all(n_local * R);
+  LH_HIP(hipMemcpyAsync(mine.data(), local, n_local * sizeof(Fr), hipMemcpyDeviceToHost, c.stream));
+  c.sync();
+  comm_all_gather(c, mine.data(), all.data(), n_local * sizeof(HFr));
+  LH_HIP(hipMemcpyAsync(out, all.data(), n_local * R * sizeof(Fr), hipMemcpyHostToDevice, c.stream));
+  c.sync();
+}
+
+static size_t log2_exact(size_t v) {
+  size_t l = 0;
+  while (((size_t)1 << l) < v) l++;
+  return l;
+}
+
+// local shard of eq_xy(y): drop the shard coordinates, scale by eq_shard(y_shard)[rank]
+static void eq_xy_shard(Ctx& c, const HFr* y, size_t num_vars, Fr* out_local) {
+  const size_t rho = log2_exact((size_t)c.comm.size), j = c.shard_bit;
+  std::vector<HFr> yl;
+  HFr scale = HFr::one();
+  for (size_t i = 0; i < num_vars; i++) {
+    if (i >= j && i < j + rho) {
+      bool bit = ((size_t)c.comm.rank >> (i - j)) & 1;
+      scale *= bit ? y[i] : HFr::one() - y[i];
+    } else {
+      yl.push_back(y[i]);
+    }
+  }
+  const size_t n_local = (size_t)1 << yl.size();
+  k_eq_xy(c, (const Fr*)yl.data(), yl.size(), out_local);
+  k_scale(c, out_local, dev(scale), n_local, out_local);
+}
+
+std::vector<HFr> evaluate_polys_sharded(Ctx& c, const Fr* const* d_polys_local, size_t count, size_t num_vars,
+                                        const HFr* point) {
+  std::vector<HFr> out(count);
+  if (!count) return out;
+  ArenaScope scope(c.arena);
+  const size_t rho = log2_exact((size_t)c.comm.size);
+  const size_t n_local = (size_t)1 << (num_vars - rho);
+  Fr* eq = c.arena.alloc_n<Fr>(n_local);
+  eq_xy_shard(c, point, num_vars, eq);
+  k_inner_products(c, d_polys_local, count, eq, n_local, (Fr*)out.data());
+  comm_sum_fr(c, out.data(), count);
+  return out;
+}
+
 // ------------------------------------------------------------------ ClassicSumCheck::prove
 // reference piop/sum_check/classic.rs:208-240.  Round i: [fused bind with r_{i-1}] + evaluation on the
 // GPU (k_sc_round), message to the transcript, squeeze r_i.  After the last squeeze one more bind gives
 // table[0] of every poly (classic.rs:143-149).
-SumCheckResult sum_check_prove(Ctx& c, int prover_kind, size_t num_vars, const lh_sop& expr,
-                               const Fr* const* d_polys, size_t num_polys, const HFr* ys, size_t num_ys,
-                               const HFr& sum, Transcript& tr) {
+//
+// `sharded`: the tables are this rank's shards.  Rounds 0..shard_bit-1 run on the local
+// shard and the D partial sums of all ranks are added; before round shard_bit the residual tables are
+// bound once more, exchanged (the shard bits have reached bit 0) and the remaining rounds run
+// replicated on every rank.  The transcript sees exactly the single-GPU messages.
+static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_vars, const lh_sop& expr,
+                                           const Fr* const* d_polys, size_t num_polys, const HFr* ys, size_t num_ys,
+                                           const HFr& sum, Transcript& tr, bool sharded) {
   LH_REQUIRE(num_vars > 0, LH_ERR_ARG, "sum-check needs num_vars > 0");  // classic.rs:42 assert
   const size_t T = num_polys + num_ys;
   LH_REQUIRE(T <= (size_t)SC_MAX_TABLES, LH_ERR_ARG, "sum-check: too many tables for one round kernel");
   LH_REQUIRE(expr.num_terms >= 1 && expr.num_terms <= LH_SC_MAX_TERMS, LH_ERR_ARG, "sum-check: bad term count");
   LH_REQUIRE(expr.global_eq < (int)num_ys, LH_ERR_ARG, "sum-check: global_eq out of range");
+  const size_t rho = sharded ? log2_exact((size_t)c.comm.size) : 0, j = c.shard_bit;
+  if (sharded) LH_REQUIRE(j >= 1 && j + rho <= num_vars, LH_ERR_ARG, "sharded sum-check: shard bits outside the table");
 
   // Expression::degree() (expression.rs:171-182): every table is degree 1, products add, sums max
   int degree = 0;
@@ -121,30 +222,53 @@ SumCheckResult sum_check_prove(Ctx& c, int prover_kind, size_t num_vars, const l
     LH_REQUIRE(degree >= 2, LH_ERR_ARG, "EvaluationsProver needs degree >= 2");  // eval.rs:316 debug_assert
 
   ArenaScope scope(c.arena);
-  const size_t n = (size_t)1 << num_vars;
+  size_t len = (size_t)1 << (num_vars - rho);  // current length of every (local) table
   std::vector<const Fr*> cur(T);
   for (size_t i = 0; i < num_polys; i++) cur[i] = d_polys[i];
-  for (size_t j = 0; j < num_ys; j++) {  // ProverState::new: eq_xys (classic.rs:56-60)
-    Fr* eq = c.arena.alloc_n<Fr>(n);
-    k_eq_xy(c, (const Fr*)(ys + j * num_vars), num_vars, eq);
-    cur[num_polys + j] = eq;
+  for (size_t jy = 0; jy < num_ys; jy++) {  // ProverState::new: eq_xys (classic.rs:56-60)
+    Fr* eq = c.arena.alloc_n<Fr>(len);
+    if (sharded) eq_xy_shard(c, ys + jy * num_vars, num_vars, eq);
+    else k_eq_xy(c, (const Fr*)(ys + jy * num_vars), num_vars, eq);
+    cur[num_polys + jy] = eq;
   }
-  // ping-pong targets of the binds: A holds 2^(n-1), B holds 2^(n-2)
+  // ping-pong targets of the binds: A holds len/2, B holds len/4
   std::vector<Fr*> bufA(T), bufB(T);
-  for (size_t i = 0; i < T; i++) {
-    bufA[i] = c.arena.alloc_n<Fr>(std::max<size_t>(n >> 1, 1));
-    bufB[i] = c.arena.alloc_n<Fr>(std::max<size_t>(n >> 2, 1));
-  }
+  auto alloc_bufs = [&](size_t l) {
+    for (size_t i = 0; i < T; i++) {
+      bufA[i] = c.arena.alloc_n<Fr>(std::max<size_t>(l >> 1, 1));
+      bufB[i] = c.arena.alloc_n<Fr>(std::max<size_t>(l >> 2, 1));
+    }
+  };
+  alloc_bufs(len);
+  int flip = 0;  // next bind target: 0 -> A, 1 -> B
   Fr* evals_host = (Fr*)c.pin((16 + SC_MAX_TABLES) * sizeof(Fr));
   static const HFr inv2 = HFr::from_u64(2).inv();
 
   SumCheckResult res;
   HFr claim = sum;
   HFr r_prev = HFr::zero();
+  bool sh = sharded;
   for (size_t round = 0; round < num_vars; round++) {
-    const size_t size = (size_t)1 << (num_vars - round - 1);
-    const bool bind = round > 0;
-    std::vector<Fr*>& dst = (round & 1) ? bufA : bufB;
+    bool bind = round > 0;
+    if (sh && round == j) {
+      // the shard bits are about to become the pair bit: bind once more, exchange, go on replicated
+      std::vector<Fr*>& dst = flip ? bufB : bufA;
+      k_fix_var_multi(c, cur.data(), dst.data(), T, len, dev(r_prev));
+      len >>= 1;
+      std::vector<Fr*> rep(T);
+      const size_t full = len << rho;
+      for (size_t i = 0; i < T; i++) rep[i] = c.arena.alloc_n<Fr>(full);
+      std::vector<const Fr*> bound(dst.begin(), dst.end());
+      comm_gather_interleave(c, bound.data(), T, len, rep.data());
+      for (size_t i = 0; i < T; i++) cur[i] = rep[i];
+      len = full;
+      alloc_bufs(len);
+      flip = 0;
+      sh = false;
+      bind = false;
+    }
+    const size_t size = bind ? len >> 2 : len >> 1;
+    std::vector<Fr*>& dst = flip ? bufB : bufA;
     for (size_t i = 0; i < T; i++) {
       rd.in[i] = cur[i];
       rd.out[i] = dst[i];
@@ -153,14 +277,18 @@ SumCheckResult sum_check_prove(Ctx& c, int prover_kind, size_t num_vars, const l
     if (bind) {
       // tables no term touches are still bound (ProverState::next_round binds every poly)
       for (size_t i = 0; i < T; i++)
-        if (!used[i]) k_fix_var(c, cur[i], size << 2, rd.r, dst[i]);
+        if (!used[i]) k_fix_var(c, cur[i], len, rd.r, dst[i]);
     }
     k_sc_round(c, rd, degree, bind, size, evals_host);
-    if (bind)
+    if (bind) {
       for (size_t i = 0; i < T; i++) cur[i] = dst[i];
+      len >>= 1;
+      flip ^= 1;
+    }
 
     std::vector<HFr> ev(degree + 1);
     for (int x = 1; x <= degree; x++) ev[x] = hst(evals_host[x - 1]);
+    if (sh) comm_sum_fr(c, ev.data() + 1, degree);  // partial sums of the other shards
     ev[0] = claim - ev[1];  // eval.rs:129
     HFr r;
     if (prover_kind == LH_SC_COEFFICIENTS) {
@@ -180,6 +308,7 @@ SumCheckResult sum_check_prove(Ctx& c, int prover_kind, size_t num_vars, const l
     res.challenges.push_back(r);
     r_prev = r;
   }
+  LH_REQUIRE(!sh && len == 2, LH_ERR_ARG, "sum-check: internal size mismatch");
   // into_evals: last bind (2 -> 1 entries) of every poly
   if (num_polys) {
     Fr* out = (Fr*)c.pin((16 + SC_MAX_TABLES) * sizeof(Fr)) + 16;
@@ -188,6 +317,18 @@ SumCheckResult sum_check_prove(Ctx& c, int prover_kind, size_t num_vars, const l
     memcpy(res.evals.data(), out, num_polys * sizeof(Fr));
   }
   return res;
+}
+
+SumCheckResult sum_check_prove(Ctx& c, int prover_kind, size_t num_vars, const lh_sop& expr,
+                               const Fr* const* d_polys, size_t num_polys, const HFr* ys, size_t num_ys,
+                               const HFr& sum, Transcript& tr) {
+  return sum_check_prove_impl(c, prover_kind, num_vars, expr, d_polys, num_polys, ys, num_ys, sum, tr, false);
+}
+
+SumCheckResult sum_check_prove_sharded(Ctx& c, int prover_kind, size_t num_vars, const lh_sop& expr,
+                                       const Fr* const* d_polys_local, size_t num_polys, const HFr* ys, size_t num_ys,
+                                       const HFr& sum, Transcript& tr) {
+  return sum_check_prove_impl(c, prover_kind, num_vars, expr, d_polys_local, num_polys, ys, num_ys, sum, tr, true);
 }
 
 // ------------------------------------------------------------------ prove_fractional_sum_check

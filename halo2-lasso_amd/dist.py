@@ -58,3 +58,25 @@ def job_metrics(elapsed_s, steps, world, lookups_per_proof):
     ms_per_step = elapsed_s * 1e3 / max(steps, 1)
     return {"ms_per_step": ms_per_step, "value_ms_per_proof": ms_per_step / world,
             "lookups_per_s": lookups_per_proof * world / (ms_per_step / 1e3)}
+
+
+def host_all_gather(dist, group=None):
+    """bytes -> bytes all-gather over CPU tensors (gloo), the communicator of a sharded proof.
+    The exchanged data are a few hundred bytes per sum-check round and the residual tables once per
+    sum-check; they live on the host anyway (the Fiat-Shamir transcript is there)."""
+    import torch
+
+    def all_gather(buf):
+        world = dist.get_world_size(group)
+        send = torch.frombuffer(bytearray(buf), dtype=torch.uint8)
+        recv = torch.empty(world * len(buf), dtype=torch.uint8)
+        dist.all_gather_into_tensor(recv, send, group=group)
+        return recv.numpy().tobytes()
+    return all_gather
+
+
+def control_group(dist):
+    """A gloo group for host-side exchanges next to an nccl (RCCL) default group."""
+    if dist.get_backend() == "gloo":
+        return None
+    return dist.new_group(backend="gloo")

@@ -201,6 +201,27 @@ lh_status lh_lasso_prove(lh_ctx*, const lh_srs*, const lh_lasso_table*, size_t n
 #define LH_LASSO_NUM_PHASES 9
 lh_status lh_lasso_last_timing(lh_ctx*, double* out_ms);
 
+/* ---------------------------------------------------------------- e: one proof sharded over 2^rho GPUs
+ * (the reference is single-process, there is nothing to cite.)  Every table of 2^m
+ * entries is split on `rho` index bits [shard_bit, shard_bit + rho): the rank whose id equals those
+ * bits holds the 2^(m-rho) entries (hi || lo).  Sum-check pairs (bit 0) and GKR / quotient halves (top
+ * bit) stay local; per round each rank contributes D partial sums, per MSM one partial point, and when
+ * the shard bits reach bit 0 the residual tables (2^(m-shard_bit) entries) are exchanged once.  The
+ * exchanged data are small and live on the host, so the communicator is a host-side all-gather
+ * supplied by the caller (torch.distributed in halo2-lasso_amd/dist.py; RCCL/gloo underneath). */
+typedef struct lh_comm {
+  int rank, size; /* size = 2^rho */
+  void* user;
+  /* recv holds size * bytes_per_rank bytes, rank-major; returns 0 or a negative lh_status */
+  int (*all_gather)(void* user, const void* send, void* recv, size_t bytes_per_rank);
+} lh_comm;
+/* comm == NULL detaches.  shard_bit >= chunk_bits - rho is required by lh_lasso_prove_sharded. */
+lh_status lh_ctx_set_comm(lh_ctx*, const lh_comm* comm, size_t shard_bit);
+/* Same proof bytes as lh_lasso_prove on one GPU.  d_dims: the FULL columns on every rank (witness
+ * counters are computed redundantly, everything field-sized is sharded). */
+lh_status lh_lasso_prove_sharded(lh_ctx*, const lh_srs*, const lh_lasso_table*, size_t num_vars,
+                                 const uint32_t* const* d_dims, lh_transcript* t);
+
 /* ---------------------------------------------------------------- measurement (bench.py)
  * Per-kernel HIP-event timing on the ctx stream.  While enabled every instrumented launch is
  * synchronised, so whole-prove wall time is NOT representative; use a separate pass. */

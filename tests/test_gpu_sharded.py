@@ -1,0 +1,89 @@
+"""GPU: ONE Lasso proof sharded over 2 / 4 ranks must produce the single-GPU proof bytes.
+The ranks are separate processes that share the one GPU of the test box and talk over gloo (host-side
+communicator); on a multi-GPU node the same code runs one rank per GPU."""
+import array
+import json
+import os
+import random
+import subprocess
+import sys
+import textwrap
+import zlib
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import os, sys, json, array, random
+    sys.path.insert(0, %r)
+    import halo2_lasso_amd as hl
+    from halo2_lasso_amd import dist as hdist
+    cfg = json.loads(sys.argv[1])
+    rank, _, world = hdist.env_rank()
+    d = hdist.init("gloo")
+    ctx = hl.Context(0)                      # every rank on the one GPU of the test box
+    rng = random.Random(cfg["seed"])
+    ss = [rng.randrange(hl.R_MOD) for _ in range(cfg["n"])]
+    dims = [[rng.randrange(1 << cfg["l"]) for _ in range(1 << cfg["n"])] for _ in range(cfg["c"])]
+    pp = hl.MultilinearKzg.setup(ctx, ss)
+    table = hl.LassoTable.range(cfg["c"], cfg["l"]) if cfg["kind"] == "range" else hl.LassoTable.bitwise(
+        hl.SUBTABLE_AND if cfg["kind"] == "and" else hl.SUBTABLE_XOR, cfg["c"], cfg["l"])
+    d_dims = [ctx.upload(array.array("I", col).tobytes()) for col in dims]
+    hl.attach_comm(ctx, rank, world, hdist.host_all_gather(d), cfg["shard_bit"])
+    t = hl.Keccak256Transcript()
+    hl.lasso_prove_sharded(pp, table, cfg["n"], d_dims, t)
+    print(json.dumps({"rank": rank, "proof": t.into_proof().hex()}), flush=True)
+    hdist.barrier(d)
+    d.destroy_process_group()
+""") % ROOT
+
+
+def run_ranks(tmp_path, world, cfg, port):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(r),
+                   LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script), json.dumps(cfg)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-3000:]
+        outs.append(json.loads(o.strip().splitlines()[-1]))
+    return outs
+
+
+CASES = [
+    # world, kind, c, l, n, shard_bit
+    (2, "range", 2, 3, 6, 2),
+    (2, "and", 2, 4, 7, 3),
+    (4, "range", 2, 4, 8, 2),
+    (4, "xor", 3, 4, 7, 3),
+    (2, "range", 2, 3, 9, 5),
+]
+
+
+@pytest.mark.parametrize("world,kind,c,l,n,shard_bit", CASES)
+def test_sharded_proof_equals_single_gpu_and_oracle(tmp_path, world, kind, c, l, n, shard_bit):
+    from oracle.pyref import lasso as o_lasso, kzg as o_kzg
+    from oracle.pyref.field import R_MOD
+    from oracle.pyref.transcript import Keccak256Transcript as OT
+    seed = zlib.crc32(repr((world, kind, c, l, n)).encode())
+    cfg = dict(seed=seed, kind=kind, c=c, l=l, n=n, shard_bit=shard_bit)
+    outs = run_ranks(tmp_path, world, cfg, 29600 + (seed % 300))
+    proofs = {o["proof"] for o in outs}
+    assert len(proofs) == 1, "ranks disagree on the proof"
+    rng = random.Random(seed)
+    ss = [rng.randrange(R_MOD) for _ in range(n)]
+    dims = [[rng.randrange(1 << l) for _ in range(1 << n)] for _ in range(c)]
+    spec = o_lasso.range_table(c, l) if kind == "range" else o_lasso.bitwise_table(
+        o_lasso.SUBTABLE_AND if kind == "and" else o_lasso.SUBTABLE_XOR, c, l)
+    ot = OT()
+    opp = o_kzg.setup(ss)
+    o_lasso.prove(opp, spec, dims, ot)
+    assert proofs.pop() == ot.into_proof().hex()
+    o_lasso.verify(opp, spec, n, OT(ot.into_proof()))
