@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log-n", type=int, default=0, help="force the CPU sample size")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--mode", default="replicas", choices=["replicas", "sharded"],
+                    help="N>1: 'replicas' = one independent proof per GPU (weak scaling, default); 'sharded' = ONE "
+                         "proof of 2^log-n lookups split over the N GPUs (strong scaling, SURVEY.md §8e)")
     return ap.parse_args()
 
 
@@ -165,21 +168,31 @@ def main():
     dist = hdist.init()
 
     import halo2_lasso_amd as hl
-    ctx = hl.Context(local_rank)
+    ctx = hl.Context(int(os.environ.get("LH_DEVICE", local_rank)))  # LH_DEVICE: several ranks on one GPU (tests)
     n = args.log_n
     table, desc = make_table(hl, args.table)
     pp = hl.MultilinearKzg.setup(ctx, trapdoor(max(n, table.l)))
-    d_dims = [ctx.upload(d.tobytes()) for d in gen_dims(table, n, rank)]
+    sharded = args.mode == "sharded" and world > 1
+    # sharded: every rank holds the same full lookup columns (the counters need the global order)
+    d_dims = [ctx.upload(d.tobytes()) for d in gen_dims(table, n, 0 if sharded else rank)]
     ctx.sync()
+    if sharded:
+        rho = world.bit_length() - 1
+        assert 1 << rho == world, "sharded mode needs a power-of-two number of GPUs"
+        shard_bit = max(table.l - rho, min(14, n - rho - 1), 1)
+        hl.attach_comm(ctx, rank, world, hdist.host_all_gather(dist, hdist.control_group(dist)), shard_bit)
 
     def prove(nn=n, bufs=d_dims):
         tr = hl.Keccak256Transcript()
-        hl.lasso_prove(pp, table, nn, bufs, tr)
+        if sharded and nn == n:
+            hl.lasso_prove_sharded(pp, table, nn, bufs, tr)
+        else:
+            hl.lasso_prove(pp, table, nn, bufs, tr)
         return tr
 
     def barrier():
         ctx.sync()
-        if dist is not None:
+        if dist is not None and dist.get_backend() == "nccl":
             import torch
             torch.cuda.synchronize()
         hdist.barrier(dist)
@@ -191,7 +204,7 @@ def main():
     for _ in range(args.steps):
         tr = prove()
     ctx.sync()
-    if dist is not None:
+    if dist is not None and dist.get_backend() == "nccl":
         import torch
         torch.cuda.synchronize()
     elapsed = hdist.max_over_ranks(dist, time.perf_counter() - t0)
@@ -203,17 +216,18 @@ def main():
     out = None
     if rank == 0:
         out = {
-            "metric": "lasso_prove_time_ms", "value": round(ms_per_step / world, 3), "unit": "ms",
+            "metric": "lasso_prove_time_ms", "value": round(ms_per_step / (1 if sharded else world), 3), "unit": "ms",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "u256 (BN254 Fr/Fq, 8x u32 Montgomery)",
+            "higher_is_better": False, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "u256 (BN254 Fr/Fq, 8x u32 Montgomery)",
             "data": "synthetic",
-            "config": {"workload": desc % n, "lookups_per_proof": 1 << n, "proofs_per_step": world,
+            "config": {"workload": desc % n, "lookups_per_proof": 1 << n, "proofs_per_step": 1 if sharded else world,
                        "pcs": "multilinear KZG (BN254)", "proof_bytes": proof_len,
-                       "parallelism": "1 proof per GPU" if world > 1 else "1 GPU"},
-            "lookups_per_s": round((1 << n) * world / (ms_per_step / 1e3)),
+                       "parallelism": ("1 proof sharded over %d GPUs" % world if sharded else
+                                       "1 proof per GPU" if world > 1 else "1 GPU")},
+            "lookups_per_s": round((1 << n) * (1 if sharded else world) / (ms_per_step / 1e3)),
             "phases_ms": {k: round(v, 3) for k, v in phases.items()},
         }
-        if not args.no_profile:
+        if not args.no_profile and not sharded:
             hl.profile_enable(ctx, True)
             prove()
             ctx.sync()
@@ -238,7 +252,7 @@ def main():
                                "GBps_largest": round(a["big"]["bytes"] / (a["big"]["ms"] * 1e-3) / 1e9, 1)
                                if a["big"]["ms"] > 0 else 0.0}
                               for a in aggs[:12]]
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and not sharded:
             def gpu_proof(nn, dims):
                 bufs = [ctx.upload(d.tobytes()) for d in dims]
                 return prove(nn, bufs).into_proof()
