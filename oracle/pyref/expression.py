@@ -1,9 +1,8 @@
 """Expression AST subset used by the sum-check provers.  TEST INFRASTRUCTURE ONLY.
 
-Follows reference plonkish_backend/src/util/expression.rs:60-182.  Only `Rotation::cur()`
-queries and the `EqXY` common polynomial are modelled here (that is all the sum-check /
-GKR / PCS / Lasso paths use: fractional_sum_check.rs:272-281, pcs/multilinear.rs:182-190);
-`Identity`, `Lagrange` and rotations belong to the HyperPlonk zero-check.
+Follows reference plonkish_backend/src/util/expression.rs:14-574: CommonPolynomial
+{Identity, Lagrange(i), EqXY(idx)}, Polynomial(Query{poly, rotation}), Challenge, Negated, Sum,
+Product, Scaled, DistributePowers; `evaluate` (:109-169), `degree` (:171-182), `used_*` (:184-243).
 """
 from .field import R_MOD as P
 
@@ -38,11 +37,26 @@ class EqXY(Expr):
         self.idx = idx
 
 
-class Poly(Expr):
-    """Expression::Polynomial(Query::new(poly, Rotation::cur()))"""
+class Identity(Expr):
+    """CommonPolynomial::Identity"""
 
-    def __init__(self, idx):
-        self.idx = idx
+
+class Lagrange(Expr):
+    """CommonPolynomial::Lagrange(i)"""
+
+    def __init__(self, i):
+        self.i = i
+
+
+class Poly(Expr):
+    """Expression::Polynomial(Query::new(poly, Rotation(rotation)))"""
+
+    def __init__(self, idx, rotation=0):
+        self.idx, self.rotation = idx, rotation
+
+    @property
+    def query(self):
+        return (self.idx, self.rotation)
 
 
 class Challenge(Expr):
@@ -100,8 +114,10 @@ def evaluate(e, constant, common_poly, poly, challenge, negated, sum_, product, 
         return constant(e.v)
     if isinstance(e, EqXY):
         return common_poly(e.idx)
+    if isinstance(e, (Identity, Lagrange)):
+        return common_poly(e)
     if isinstance(e, Poly):
-        return poly(e.idx)
+        return poly(e.idx) if e.rotation == 0 else poly(e)
     if isinstance(e, Challenge):
         return challenge(e.idx)
     if isinstance(e, Negated):
@@ -148,3 +164,55 @@ def evaluate_fe(e, eq_vals, poly_vals, challenges):
         lambda a, b: a * b % P,
         lambda a, s: a * s % P,
     )
+
+
+# ------------------------------------------------------------------ general form (rotations, identity, lagrange)
+def _walk(e, out):
+    if isinstance(e, (Negated,)):
+        _walk(e.a, out)
+    elif isinstance(e, (Sum, Product)):
+        _walk(e.a, out)
+        _walk(e.b, out)
+    elif isinstance(e, Scaled):
+        _walk(e.a, out)
+    elif isinstance(e, DistributePowers):
+        for sub in e.exprs:
+            _walk(sub, out)
+        _walk(e.base, out)
+    else:
+        out.append(e)
+
+
+def leaves(e):
+    out = []
+    _walk(e, out)
+    return out
+
+
+def used_query(e):
+    """expression.rs:194-196: BTreeSet<Query>, ordered by (poly, rotation)"""
+    return sorted({l.query for l in leaves(e) if isinstance(l, Poly)})
+
+
+def used_lagrange(e):
+    return sorted({l.i for l in leaves(e) if isinstance(l, Lagrange)})
+
+
+def used_rotation(e):
+    return sorted({l.rotation for l in leaves(e) if isinstance(l, Poly)})
+
+
+def evaluate_general(e, eq_vals, query_vals, challenges, identity, lagranges):
+    """Field value given eq_xy evals, a {(poly, rotation): value} map, the identity value and a
+    {i: value} map of Lagrange values (piop/sum_check.rs:60-98 `evaluate`)."""
+    def common(x):
+        if isinstance(x, Identity):
+            return identity % P
+        if isinstance(x, Lagrange):
+            return lagranges[x.i] % P
+        return eq_vals[x]
+    return evaluate(
+        e, lambda c: c, common,
+        lambda q: query_vals[q.query] if isinstance(q, Poly) else query_vals[(q, 0)],
+        lambda i: challenges[i], lambda a: (-a) % P, lambda a, b: (a + b) % P,
+        lambda a, b: a * b % P, lambda a, s: a * s % P)

@@ -72,9 +72,15 @@ class Coefficients:
 
 # ---------------------------------------------------------------- prover state
 class ProverState:
-    """classic.rs:25-150 restricted to Rotation::cur() / EqXY (see expression.py)."""
+    """classic.rs:25-150.  Rotated queries, `Identity` and `Lagrange(i)` are materialised as ordinary
+    evaluation tables (rotated[b] = poly[bh.rotate(b, rot)], id[b] = b, l_i = one-hot at bh[i]): the
+    reference reads them through index maps in round 0 (eval.rs:217-266), materialises the rotated
+    copies when it binds round 0 (classic.rs:104-126) and tracks identity / Lagrange values in closed
+    form (classic.rs:92-101) -- all three are the multilinear extensions of exactly these tables, so
+    every round message is the same field element."""
 
     def __init__(self, num_vars, sum_, vp):
+        from .bh import BooleanHypercube
         assert num_vars > 0
         self.num_vars = num_vars
         self.expression = vp.expression
@@ -86,6 +92,20 @@ class ProverState:
         self.round = 0
         for t in self.eq_xys + self.polys:
             assert len(t) == 1 << num_vars
+        bh = BooleanHypercube(num_vars)
+        order = bh.iter()
+        assert all(abs(r) <= num_vars for r in ex.used_rotation(vp.expression))  # classic.rs:42
+        self.rotated = {}
+        for (idx, rot) in ex.used_query(vp.expression):
+            if rot != 0:
+                self.rotated[(idx, rot)] = [self.polys[idx][bh.rotate(b, rot)] for b in range(1 << num_vars)]
+        self.identity = list(range(1 << num_vars)) if any(
+            isinstance(l, ex.Identity) for l in ex.leaves(vp.expression)) else None
+        self.lagranges = {}
+        for i in ex.used_lagrange(vp.expression):
+            t = [0] * (1 << num_vars)
+            t[order[i % (1 << num_vars)]] = 1
+            self.lagranges[i] = t
 
     def size(self):
         return 1 << (self.num_vars - self.round - 1)
@@ -94,11 +114,23 @@ class ProverState:
         self.sum = sum_
         self.eq_xys = [fix_var(t, challenge) for t in self.eq_xys]
         self.polys = [fix_var(t, challenge) for t in self.polys]
+        self.rotated = {k: fix_var(t, challenge) for k, t in self.rotated.items()}
+        self.lagranges = {k: fix_var(t, challenge) for k, t in self.lagranges.items()}
+        if self.identity is not None:
+            self.identity = fix_var(self.identity, challenge)
         self.round += 1
 
     def into_evals(self):
         assert self.round == self.num_vars
         return [p[0] for p in self.polys]
+
+    def pair_values(self, b, which):
+        """values of every leaf at table index 2b + which"""
+        i = 2 * b + which
+        q = {(idx, 0): t[i] for idx, t in enumerate(self.polys)}
+        q.update({k: t[i] for k, t in self.rotated.items()})
+        return ([t[i] for t in self.eq_xys], q, self.identity[i] if self.identity is not None else 0,
+                {k: t[i] for k, t in self.lagranges.items()})
 
 
 class EvaluationsProver:
@@ -115,18 +147,15 @@ class EvaluationsProver:
         d = state.degree
         evals = [0] * (d + 1)
         for b in range(state.size()):
-            eq0 = [t[2 * b] for t in state.eq_xys]
-            eq1 = [t[2 * b + 1] for t in state.eq_xys]
-            p0 = [t[2 * b] for t in state.polys]
-            p1 = [t[2 * b + 1] for t in state.polys]
-            eqv, pv = eq1, p1
-            eqs = [(a - c) % P for a, c in zip(eq1, eq0)]
-            ps = [(a - c) % P for a, c in zip(p1, p0)]
+            eq0, q0, id0, l0 = state.pair_values(b, 0)
+            eq1, q1, id1, l1 = state.pair_values(b, 1)
             for X in range(1, d + 1):
-                if X > 1:
-                    eqv = [(a + s) % P for a, s in zip(eqv, eqs)]
-                    pv = [(a + s) % P for a, s in zip(pv, ps)]
-                evals[X] = (evals[X] + ex.evaluate_fe(state.expression, eqv, pv, state.challenges)) % P
+                lin = lambda v0, v1: (v1 + (X - 1) * (v1 - v0)) % P
+                eqv = [lin(a, c) for a, c in zip(eq0, eq1)]
+                qv = {k: lin(q0[k], q1[k]) for k in q0}
+                lv = {k: lin(l0[k], l1[k]) for k in l0}
+                val = ex.evaluate_general(state.expression, eqv, qv, state.challenges, lin(id0, id1), lv)
+                evals[X] = (evals[X] + val) % P
         evals[0] = (state.sum - evals[1]) % P
         return evals
 
