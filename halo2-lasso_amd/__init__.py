@@ -336,6 +336,20 @@ class ClassicSumCheck:
         return _fr_list(ch, num_vars), _fr_list(ev, len(polys))
 
 
+def sum_check_prove_expression(ctx, num_vars, expression, polys, challenges, ys, sum_, transcript):
+    """ClassicSumCheck::<EvaluationsProver>::prove over VirtualPolynomial{expression, polys, challenges, ys}
+    (piop/sum_check.rs:16-37, classic.rs:208-240) for a general `expression.Expression`
+    (rotations, Identity, Lagrange) -> (challenges x, evals of every poly at x)."""
+    ce, keep = expression.to_c()
+    ys_flat = [v for y in ys for v in y]
+    ch = (lh_fr * max(num_vars, 1))()
+    ev = (lh_fr * max(len(polys), 1))()
+    _check(ctx.lib.lh_sumcheck_prove_expr(ctx.h, num_vars, C.byref(ce), _ptr_array(polys), len(polys),
+                                          _fr_array(challenges), len(challenges), _fr_array(ys_flat), len(ys),
+                                          _fr_array([sum_]), transcript.p, ch, ev))
+    return _fr_list(ch, num_vars), _fr_list(ev, len(polys))
+
+
 # ------------------------------------------------------------------ piop::gkr
 def prove_fractional_sum_check(ctx, claimed_p_0s, claimed_q_0s, ps, qs, transcript):
     """fractional_sum_check.rs:89-190 -> (p_xs, q_xs, x)."""
@@ -581,3 +595,6 @@ def profile_read(ctx):
     arr = (_ffi.lh_prof_rec * max(n.value, 1))()
     _check(ctx.lib.lh_profile_read(ctx.h, arr, n.value, C.byref(n)))
     return [dict(name=r.name.decode(), ms=r.ms, bytes=r.bytes, muls=r.muls, items=r.items) for r in arr[:n.value]]
+
+
+from . import expression  # noqa: E402,F401  (host mirror of util::expression)

@@ -33,6 +33,14 @@ class lh_sop(C.Structure):
                 ("factor", (C.c_uint8 * LH_SC_MAX_FACTORS) * LH_SC_MAX_TERMS)]
 
 
+class lh_expr_node(C.Structure):
+    _fields_ = [("op", C.c_uint32), ("a", C.c_int32), ("b", C.c_int32), ("reserved", C.c_uint32), ("scalar", lh_fr)]
+
+
+class lh_expr(C.Structure):
+    _fields_ = [("nodes", C.POINTER(lh_expr_node)), ("num_nodes", C.c_size_t)]
+
+
 class lh_evaluation(C.Structure):
     _fields_ = [("poly", C.c_uint32), ("point", C.c_uint32), ("value", lh_fr)]
 
@@ -104,6 +112,9 @@ SIGNATURES = {
     "lh_sumcheck_prove": (C.c_int, [_P, C.c_int, _SZ, C.POINTER(lh_sop), C.POINTER(_P), _SZ,
                                     C.POINTER(lh_fr), _SZ, C.POINTER(lh_fr), C.POINTER(lh_transcript),
                                     C.POINTER(lh_fr), C.POINTER(lh_fr)]),
+    "lh_sumcheck_prove_expr": (C.c_int, [_P, _SZ, C.POINTER(lh_expr), C.POINTER(_P), _SZ, C.POINTER(lh_fr), _SZ,
+                                         C.POINTER(lh_fr), _SZ, C.POINTER(lh_fr), C.POINTER(lh_transcript),
+                                         C.POINTER(lh_fr), C.POINTER(lh_fr)]),
     "lh_gkr_fractional_prove": (C.c_int, [_P, _SZ, _SZ, C.POINTER(C.POINTER(lh_fr)), C.POINTER(C.POINTER(lh_fr)),
                                           C.POINTER(_P), C.POINTER(_P), C.POINTER(lh_transcript),
                                           C.POINTER(lh_fr), C.POINTER(lh_fr), C.POINTER(lh_fr)]),

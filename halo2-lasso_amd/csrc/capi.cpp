@@ -226,6 +226,23 @@ lh_status lh_sumcheck_prove(lh_ctx* ctx, int prover_kind, size_t num_vars, const
   LH_CATCH
 }
 
+lh_status lh_sumcheck_prove_expr(lh_ctx* ctx, size_t num_vars, const lh_expr* expr, const lh_fr* const* d_polys,
+                                 size_t num_polys, const lh_fr* challenges, size_t num_challenges, const lh_fr* ys,
+                                 size_t num_ys, const lh_fr* sum, lh_transcript* t, lh_fr* out_challenges,
+                                 lh_fr* out_evals) {
+  LH_TRY NEED(ctx);
+  NEED(expr);
+  NEED(sum);
+  Transcript tr(t);
+  HFr s;
+  memcpy(&s, sum, 32);
+  SumCheckResult r = sum_check_prove_expr(ctx->c, num_vars, *expr, (const Fr* const*)d_polys, num_polys,
+                                          (const HFr*)challenges, num_challenges, (const HFr*)ys, num_ys, s, tr);
+  if (out_challenges) memcpy(out_challenges, r.challenges.data(), r.challenges.size() * 32);
+  if (out_evals) memcpy(out_evals, r.evals.data(), r.evals.size() * 32);
+  LH_CATCH
+}
+
 lh_status lh_gkr_fractional_prove(lh_ctx* ctx, size_t num_batching, size_t num_vars,
                                   const lh_fr* const* claimed_p_0s, const lh_fr* const* claimed_q_0s,
                                   const lh_fr* const* d_ps, const lh_fr* const* d_qs, lh_transcript* t,

@@ -219,6 +219,39 @@ struct ScRound {
 // evals_host[0..degree) receives sum_b expr at X = 1..degree (X = 0 is derived by the caller)
 void k_sc_round(Ctx&, const ScRound& rd, int degree, bool bind, size_t size, Fr* evals_host);
 
+// ------------------------------------------------------------------ general expressions (kernels_expr.hip)
+struct ExtRound {
+  const Fr* in[SC_MAX_TABLES];
+  Fr* out[SC_MAX_TABLES];
+  uint32_t num_tables, num_terms;
+  // device arrays, constant over the rounds of one sum-check
+  const Fr* coeff;          // [num_terms]
+  const uint8_t* is_one;    // [num_terms]
+  const uint32_t* off;      // [num_terms + 1] into fac / store
+  const uint8_t* fac;       // table ids
+  const uint8_t* store;     // first occurrence of a table stores its bound pair
+  Fr r;
+};
+void k_sc_round_ext(Ctx&, const ExtRound& rd, int degree, bool bind, size_t size, Fr* evals_host);
+void k_rotate_gather(Ctx&, const Fr* poly, size_t num_vars, int rot, uint32_t primitive, uint32_t x_inv, Fr* out);
+void k_identity_table(Ctx&, size_t n, Fr* out);
+void k_one_hot_table(Ctx&, size_t n, size_t hot, Fr* out);
+enum { ROWS_ATOM_POLY = 0, ROWS_ATOM_IDENTITY = 1, ROWS_ATOM_LAGRANGE = 2 };
+struct RowsAtom {
+  const Fr* table;
+  int32_t rot;
+  uint32_t kind;
+  uint64_t hot;  // Lagrange: the row where it is 1
+};
+struct RowsExpr {
+  uint32_t num_terms, num_vars, primitive, x_inv;
+  const Fr* coeff;       // device [num_terms]
+  const uint32_t* off;   // device [num_terms + 1]
+  const uint8_t* fac;    // device: atom ids
+  const RowsAtom* atoms; // device
+};
+void k_expr_rows(Ctx&, const RowsExpr& e, size_t n, Fr* out);
+
 // ------------------------------------------------------------------ MSM (msm.hip)
 struct MsmJob {
   const void* scalars;  // Fr (Montgomery) or u32

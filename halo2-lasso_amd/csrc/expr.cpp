@@ -1,0 +1,229 @@
+// General plonkish expressions on the host: symbolic expansion of the reference's `Expression` AST
+// (util/expression.rs:67-169) into a sum of monomials over atoms, which is what the device kernels
+// evaluate (kernels_expr.hip).  Challenges and constants fold into the coefficients; field arithmetic is
+// exact, so the expanded form takes the same value as the AST at every point and every sum-check message
+// is the same field element as the reference's `ExpressionRegistry` evaluation (evaluator.rs:135-323).
+#include <algorithm>
+#include <map>
+#include "host.hpp"
+#include "expr.hpp"
+
+namespace lh {
+
+// BooleanHypercube tables (reference util/arithmetic/bh.rs:5-74)
+static const uint32_t BH_PRIMITIVES[32] = {
+    1, 3, 7, 11, 19, 37, 67, 131, 285, 529, 1033, 2053, 4179, 8219, 16427, 32771, 65581, 131081, 262183, 524327,
+    1048585, 2097157, 4194307, 8388641, 16777243, 33554441, 67108935, 134217767, 268435465, 536870917, 1073741907,
+    2147483657u};
+static const uint32_t BH_X_INVS[32] = {
+    0, 1, 3, 5, 9, 18, 33, 65, 142, 264, 516, 1026, 2089, 4109, 8213, 16385, 32790, 65540, 131091, 262163, 524292,
+    1048578, 2097153, 4194320, 8388621, 16777220, 33554467, 67108883, 134217732, 268435458, 536870953, 1073741828};
+
+uint32_t bh_primitive(size_t num_vars) { return BH_PRIMITIVES[num_vars]; }
+uint32_t bh_x_inv(size_t num_vars) { return BH_X_INVS[num_vars]; }
+size_t bh_next(size_t b, size_t num_vars) {
+  b <<= 1;
+  return b ^ ((b >> num_vars) * BH_PRIMITIVES[num_vars]);
+}
+// bh.iter().nth(i): 0, then 1, x, x^2, ...  (bh.rs:127-133)
+size_t bh_nth(size_t num_vars, size_t i) {
+  if (i == 0) return 0;
+  size_t b = 1;
+  for (size_t k = 1; k < i; k++) b = bh_next(b, num_vars);
+  return b;
+}
+
+// ------------------------------------------------------------------ expansion
+typedef std::map<std::vector<uint16_t>, HFr> PolyMap;  // sorted atom ids -> coefficient
+
+static uint16_t atom_id(ExpandedExpr& out, const ExprAtom& a) {
+  for (size_t i = 0; i < out.atoms.size(); i++)
+    if (out.atoms[i].kind == a.kind && out.atoms[i].a == a.a && out.atoms[i].b == a.b) return (uint16_t)i;
+  out.atoms.push_back(a);
+  return (uint16_t)(out.atoms.size() - 1);
+}
+
+static void add_into(PolyMap& dst, const PolyMap& src, bool negate) {
+  for (auto& kv : src) {
+    HFr v = negate ? -kv.second : kv.second;
+    auto it = dst.find(kv.first);
+    if (it == dst.end()) dst.emplace(kv.first, v);
+    else it->second += v;
+  }
+}
+
+ExpandedExpr expand_expr(const lh_expr& e, const HFr* challenges, size_t num_challenges) {
+  LH_REQUIRE(e.nodes && e.num_nodes >= 1 && e.num_nodes < 100000, LH_ERR_ARG, "expression: empty or too large");
+  ExpandedExpr out;
+  std::vector<PolyMap> val(e.num_nodes);
+  std::vector<int> deg(e.num_nodes, 0);
+  auto child = [&](int32_t idx, size_t self) -> size_t {
+    LH_REQUIRE(idx >= 0 && (size_t)idx < self, LH_ERR_ARG, "expression: node refers to a later node");
+    return (size_t)idx;
+  };
+  for (size_t i = 0; i < e.num_nodes; i++) {
+    const lh_expr_node& nd = e.nodes[i];
+    HFr sc;
+    memcpy(&sc, &nd.scalar, 32);
+    switch (nd.op) {
+      case LH_EX_CONSTANT:
+        val[i].emplace(std::vector<uint16_t>{}, sc);
+        break;
+      case LH_EX_IDENTITY:
+      case LH_EX_LAGRANGE:
+      case LH_EX_EQ_XY:
+      case LH_EX_POLYNOMIAL: {
+        ExprAtom a{(uint8_t)nd.op, nd.op == LH_EX_IDENTITY ? 0 : nd.a, nd.op == LH_EX_POLYNOMIAL ? nd.b : 0};
+        if (nd.op != LH_EX_IDENTITY && nd.op != LH_EX_LAGRANGE) LH_REQUIRE(nd.a >= 0, LH_ERR_ARG, "expression: negative index");
+        val[i].emplace(std::vector<uint16_t>{atom_id(out, a)}, HFr::one());
+        deg[i] = 1;
+        break;
+      }
+      case LH_EX_CHALLENGE:
+        LH_REQUIRE(nd.a >= 0 && (size_t)nd.a < num_challenges, LH_ERR_ARG, "expression: challenge index out of range");
+        val[i].emplace(std::vector<uint16_t>{}, challenges[nd.a]);
+        break;
+      case LH_EX_NEGATED: {
+        size_t a = child(nd.a, i);
+        add_into(val[i], val[a], true);
+        deg[i] = deg[a];
+        break;
+      }
+      case LH_EX_SUM: {
+        size_t a = child(nd.a, i), b = child(nd.b, i);
+        val[i] = val[a];
+        add_into(val[i], val[b], false);
+        deg[i] = std::max(deg[a], deg[b]);
+        break;
+      }
+      case LH_EX_PRODUCT: {
+        size_t a = child(nd.a, i), b = child(nd.b, i);
+        LH_REQUIRE(val[a].size() * val[b].size() < 200000, LH_ERR_ARG, "expression: expansion too large");
+        for (auto& x : val[a])
+          for (auto& y : val[b]) {
+            std::vector<uint16_t> key(x.first);
+            key.insert(key.end(), y.first.begin(), y.first.end());
+            std::sort(key.begin(), key.end());
+            HFr v = x.second * y.second;
+            auto it = val[i].find(key);
+            if (it == val[i].end()) val[i].emplace(std::move(key), v);
+            else it->second += v;
+          }
+        deg[i] = deg[a] + deg[b];
+        break;
+      }
+      case LH_EX_SCALED: {
+        size_t a = child(nd.a, i);
+        for (auto& x : val[a]) val[i].emplace(x.first, x.second * sc);
+        deg[i] = deg[a];
+        break;
+      }
+      default:
+        throw Error(LH_ERR_ARG, "expression: unknown node op");
+    }
+  }
+  out.degree = deg.back();  // Expression::degree() is structural (expression.rs:171-182)
+  for (auto& kv : val.back())
+    if (!kv.second.is_zero()) out.monos.push_back(ExprMono{kv.second, kv.first});
+  return out;
+}
+
+// ------------------------------------------------------------------ ClassicSumCheck<EvaluationsProver> over an Expression
+SumCheckResult sum_check_prove_expr(Ctx& c, size_t num_vars, const lh_expr& expr, const Fr* const* d_polys,
+                                    size_t num_polys, const HFr* challenges, size_t num_challenges, const HFr* ys,
+                                    size_t num_ys, const HFr& sum, Transcript& tr) {
+  LH_REQUIRE(num_vars > 0 && num_vars < 32, LH_ERR_ARG, "sum-check needs 0 < num_vars < 32");  // classic.rs:42, bh.rs:85
+  ExpandedExpr ex = expand_expr(expr, challenges, num_challenges);
+  LH_REQUIRE(ex.degree >= 2 && ex.degree <= 8, LH_ERR_ARG, "EvaluationsProver: degree must be in 2..8");  // eval.rs:316
+  const size_t n = (size_t)1 << num_vars;
+  ArenaScope scope(c.arena);
+
+  // tables: every poly at the current rotation first (all of them are bound and reported), then one
+  // table per remaining atom
+  std::vector<const Fr*> tables(d_polys, d_polys + num_polys);
+  std::vector<int> table_of(ex.atoms.size(), -1);
+  for (size_t a = 0; a < ex.atoms.size(); a++) {
+    const ExprAtom& at = ex.atoms[a];
+    if (at.kind == LH_EX_POLYNOMIAL) {
+      LH_REQUIRE((size_t)at.a < num_polys, LH_ERR_ARG, "expression: poly index out of range");
+      LH_REQUIRE((size_t)std::abs(at.b) <= num_vars, LH_ERR_ARG, "expression: rotation distance > num_vars");  // classic.rs:42
+      if (at.b == 0) {
+        table_of[a] = at.a;
+      } else {
+        Fr* rot = c.arena.alloc_n<Fr>(n);
+        k_rotate_gather(c, d_polys[at.a], num_vars, at.b, bh_primitive(num_vars), bh_x_inv(num_vars), rot);
+        table_of[a] = (int)tables.size();
+        tables.push_back(rot);
+      }
+    } else if (at.kind == LH_EX_EQ_XY) {
+      LH_REQUIRE((size_t)at.a < num_ys, LH_ERR_ARG, "expression: eq_xy index out of range");
+      Fr* eq = c.arena.alloc_n<Fr>(n);
+      k_eq_xy(c, (const Fr*)(ys + (size_t)at.a * num_vars), num_vars, eq);
+      table_of[a] = (int)tables.size();
+      tables.push_back(eq);
+    } else if (at.kind == LH_EX_IDENTITY) {
+      Fr* id = c.arena.alloc_n<Fr>(n);
+      k_identity_table(c, n, id);
+      table_of[a] = (int)tables.size();
+      tables.push_back(id);
+    } else {  // Lagrange(i): 1 on row bh[i mod 2^n] (classic.rs:46-55)
+      long long m = (long long)at.a % (long long)n;
+      if (m < 0) m += (long long)n;
+      Fr* l = c.arena.alloc_n<Fr>(n);
+      k_one_hot_table(c, n, bh_nth(num_vars, (size_t)m), l);
+      table_of[a] = (int)tables.size();
+      tables.push_back(l);
+    }
+  }
+  const size_t T = tables.size();
+  LH_REQUIRE(T <= (size_t)SC_MAX_TABLES, LH_ERR_ARG, "expression: too many tables for one round kernel");
+  LH_REQUIRE(!ex.monos.empty(), LH_ERR_ARG, "expression: identically zero");
+
+  // monomial list -> device
+  const uint32_t M = (uint32_t)ex.monos.size();
+  std::vector<Fr> coeff(M);
+  std::vector<uint8_t> is_one(M), fac, store;
+  std::vector<uint32_t> off(M + 1, 0);
+  std::vector<char> used(T, 0);
+  const HFr one = HFr::one();
+  for (uint32_t m = 0; m < M; m++) {
+    coeff[m] = dev(ex.monos[m].coeff);
+    is_one[m] = ex.monos[m].coeff == one;
+    for (uint16_t a : ex.monos[m].atoms) {
+      int t = table_of[a];
+      fac.push_back((uint8_t)t);
+      store.push_back(used[t] ? 0 : 1);
+      used[t] = 1;
+    }
+    off[m + 1] = (uint32_t)fac.size();
+  }
+  if (fac.empty()) fac.push_back(0), store.push_back(0);
+  Fr* d_coeff = c.arena.alloc_n<Fr>(M);
+  uint8_t* d_is_one = c.arena.alloc_n<uint8_t>(M);
+  uint32_t* d_off = c.arena.alloc_n<uint32_t>(M + 1);
+  uint8_t* d_fac = c.arena.alloc_n<uint8_t>(fac.size());
+  uint8_t* d_store = c.arena.alloc_n<uint8_t>(store.size());
+  LH_HIP(hipMemcpyAsync(d_coeff, coeff.data(), M * sizeof(Fr), hipMemcpyHostToDevice, c.stream));
+  LH_HIP(hipMemcpyAsync(d_is_one, is_one.data(), M, hipMemcpyHostToDevice, c.stream));
+  LH_HIP(hipMemcpyAsync(d_off, off.data(), (M + 1) * 4, hipMemcpyHostToDevice, c.stream));
+  LH_HIP(hipMemcpyAsync(d_fac, fac.data(), fac.size(), hipMemcpyHostToDevice, c.stream));
+  LH_HIP(hipMemcpyAsync(d_store, store.data(), store.size(), hipMemcpyHostToDevice, c.stream));
+  c.sync();  // the host vectors go out of scope before the first round is queued otherwise
+
+  ExtRound rd;
+  memset(&rd, 0, sizeof(rd));
+  rd.num_tables = (uint32_t)T;
+  rd.num_terms = M;
+  rd.coeff = d_coeff, rd.is_one = d_is_one, rd.off = d_off, rd.fac = d_fac, rd.store = d_store;
+  auto round_fn = [&](const Fr* const* in, Fr* const* out, const Fr& r, bool bind, size_t size, Fr* evals_host) {
+    for (size_t i = 0; i < T; i++) {
+      rd.in[i] = in[i];
+      rd.out[i] = out[i];
+    }
+    rd.r = r;
+    k_sc_round_ext(c, rd, ex.degree, bind, size, evals_host);
+  };
+  return sum_check_loop(c, LH_SC_EVALUATIONS, num_vars, ex.degree, tables, used, num_polys, sum, tr, false, round_fn);
+}
+
+}  // namespace lh

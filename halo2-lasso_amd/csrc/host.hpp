@@ -2,6 +2,7 @@
 // (piop::sum_check, piop::gkr, pcs::multilinear::kzg) on top of the device kernels.
 #pragma once
 #include <string.h>
+#include <functional>
 #include <vector>
 #include "dev.hpp"
 #include "ff_host.hpp"
@@ -87,6 +88,16 @@ struct SumCheckResult {
 };
 SumCheckResult sum_check_prove(Ctx&, int prover_kind, size_t num_vars, const lh_sop& expr, const Fr* const* d_polys,
                                size_t num_polys, const HFr* ys, size_t num_ys, const HFr& sum, Transcript& tr);
+
+// the round loop shared by every sum-check front end (prover.cpp)
+typedef std::function<void(const Fr* const*, Fr* const*, const Fr&, bool, size_t, Fr*)> RoundFn;
+SumCheckResult sum_check_loop(Ctx&, int prover_kind, size_t num_vars, int degree, std::vector<const Fr*> cur,
+                              const std::vector<char>& used, size_t num_polys, const HFr& sum, Transcript& tr,
+                              bool sharded, const RoundFn& round_fn);
+// general Expression (util/expression.rs) through EvaluationsProver; evals = every poly at x
+SumCheckResult sum_check_prove_expr(Ctx&, size_t num_vars, const lh_expr& expr, const Fr* const* d_polys,
+                                    size_t num_polys, const HFr* challenges, size_t num_challenges, const HFr* ys,
+                                    size_t num_ys, const HFr& sum, Transcript& tr);
 
 // one proof over several GPUs: same messages, tables are this rank's shards
 SumCheckResult sum_check_prove_sharded(Ctx&, int prover_kind, size_t num_vars, const lh_sop& expr,

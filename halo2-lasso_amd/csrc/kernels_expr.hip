@@ -1,0 +1,236 @@
+// Kernels for general plonkish expressions (reference util/expression.rs) after symbolic expansion
+// into a sum of monomials over "atoms" (a poly at a rotation, eq_xy, identity, Lagrange):
+//   * sc_round_ext_kernel   sum-check round (fused bind + evaluate) with the monomial list in device
+//                           memory: the HyperPlonk zero-check has ~90 monomials of up to 5 factors, too
+//                           many for kernel arguments.  Replaces EvaluationsProver::evals
+//                           (piop/sum_check/classic/eval.rs:102-131, 210-323) + next_round (classic.rs:90-141).
+//   * rotate_gather_kernel  rotated[b] = poly[bh.rotate(b, rot)]: the round-0 index maps of eval.rs:217-226 /
+//                           the materialisation of classic.rs:104-126, done once up front.
+//   * identity / lagrange   the tables whose multilinear extensions the reference tracks in closed form
+//                           (classic.rs:92-101).
+//   * expr_rows_kernel      row-wise evaluation sum_m c_m prod atoms(b): lookup_compressed_poly
+//                           (backend/hyperplonk/prover.rs:79-137).
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include "dev.hpp"
+#include "reduce.cuh"
+
+namespace lh {
+
+#define GSTRIDE(i, n) \
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (size_t)gridDim.x * blockDim.x)
+
+static inline dim3 grid_for(size_t n, int block = 256, size_t cap = 4096) {
+  size_t g = (n + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return dim3((unsigned)g);
+}
+
+// ------------------------------------------------------------------ BooleanHypercube on the device (bh.rs:143-153)
+__device__ __forceinline__ uint32_t bh_rotate(uint32_t b, int rot, uint32_t num_vars, uint32_t primitive, uint32_t x_inv) {
+  for (int i = 0; i < rot; i++) {
+    uint64_t t = (uint64_t)b << 1;
+    b = (uint32_t)(t ^ ((t >> num_vars) * primitive));
+  }
+  for (int i = 0; i > rot; i--) b = (b >> 1) ^ ((b & 1u) * x_inv);
+  return b;
+}
+
+__global__ void rotate_gather_kernel(const Fr* __restrict__ poly, size_t n, int rot, uint32_t num_vars, uint32_t primitive,
+                                     uint32_t x_inv, Fr* __restrict__ out) {
+  GSTRIDE(b, n) out[b] = poly[bh_rotate((uint32_t)b, rot, num_vars, primitive, x_inv)];
+}
+void k_rotate_gather(Ctx& c, const Fr* poly, size_t num_vars, int rot, uint32_t primitive, uint32_t x_inv, Fr* out) {
+  size_t n = (size_t)1 << num_vars;
+  hipLaunchKernelGGL(rotate_gather_kernel, grid_for(n), 256, 0, c.stream, poly, n, rot, (uint32_t)num_vars, primitive,
+                     x_inv, out);
+}
+
+__global__ void identity_table_kernel(size_t n, Fr* __restrict__ out) {
+  GSTRIDE(b, n) out[b] = from_u64<FrParams>(b);
+}
+void k_identity_table(Ctx& c, size_t n, Fr* out) {
+  hipLaunchKernelGGL(identity_table_kernel, grid_for(n), 256, 0, c.stream, n, out);
+}
+__global__ void set_one_at_kernel(Fr* p, size_t idx) { p[idx] = Fr::one(); }
+void k_one_hot_table(Ctx& c, size_t n, size_t hot, Fr* out) {
+  LH_HIP(hipMemsetAsync(out, 0, n * sizeof(Fr), c.stream));
+  hipLaunchKernelGGL(set_one_at_kernel, 1, 1, 0, c.stream, out, hot);
+}
+
+// ------------------------------------------------------------------ sum-check round, monomials in device memory
+template <bool BIND>
+__device__ __forceinline__ void load_pair_ext(const Fr* __restrict__ in, Fr* __restrict__ out, size_t b, const Fr& r,
+                                              bool store, Fr& v0, Fr& v1) {
+  if (BIND) {
+    const Fr* p = in + 4 * b;
+    Fr e0 = p[0], e1 = p[1], e2 = p[2], e3 = p[3];
+    v0 = add(mul(sub(e1, e0), r), e0);
+    v1 = add(mul(sub(e3, e2), r), e2);
+    if (store) {
+      out[2 * b] = v0;
+      out[2 * b + 1] = v1;
+    }
+  } else {
+    v0 = in[2 * b];
+    v1 = in[2 * b + 1];
+  }
+}
+
+__device__ __forceinline__ void publish_flag_ext(uint32_t* flag, uint32_t seq) {
+  __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+template <int D, bool BIND>
+__global__ __launch_bounds__(256) void sc_round_ext_kernel(ExtRound rd, size_t size, uint32_t tp,
+                                                           Fr* __restrict__ partials, ScFinishArgs fin) {
+  __shared__ Fr lds[4];
+  __shared__ int is_last;
+  Fr acc[D];
+#pragma unroll
+  for (int x = 0; x < D; x++) acc[x] = Fr::zero();
+  const size_t items = size * tp;
+  for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < items; w += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = tp == 1 ? w : w / tp;
+    const uint32_t m_lo = tp == 1 ? 0u : (uint32_t)(w % tp);
+    const uint32_t m_hi = tp == 1 ? rd.num_terms : m_lo + 1u;
+    for (uint32_t m = m_lo; m < m_hi; m++) {
+      Fr pm[D];
+      const uint32_t o0 = rd.off[m], nf = rd.off[m + 1] - o0;
+      if (nf == 0) {  // constant monomial
+#pragma unroll
+        for (int x = 0; x < D; x++) pm[x] = rd.coeff[m];
+      }
+      for (uint32_t k = 0; k < nf; k++) {
+        const int t = rd.fac[o0 + k];
+        Fr v0, v1;
+        load_pair_ext<BIND>(rd.in[t], rd.out[t], b, rd.r, rd.store[o0 + k] != 0, v0, v1);
+        if (k == 0) {
+          if (!rd.is_one[m]) {
+            v0 = mul(v0, rd.coeff[m]);
+            v1 = mul(v1, rd.coeff[m]);
+          }
+          Fr step = sub(v1, v0);
+          pm[0] = v1;
+#pragma unroll
+          for (int x = 1; x < D; x++) pm[x] = add(pm[x - 1], step);
+        } else {
+          Fr step = sub(v1, v0);
+          Fr val = v1;
+          pm[0] = mul(pm[0], val);
+#pragma unroll
+          for (int x = 1; x < D; x++) {
+            val = add(val, step);
+            pm[x] = mul(pm[x], val);
+          }
+        }
+      }
+#pragma unroll
+      for (int x = 0; x < D; x++) acc[x] = add(acc[x], pm[x]);
+    }
+  }
+#pragma unroll
+  for (int x = 0; x < D; x++) {
+    Fr v = block_reduce_sum(acc[x], lds);
+    if (threadIdx.x == 0) partials[(size_t)blockIdx.x * D + x] = v;
+  }
+  if (gridDim.x == 1) {
+    if (threadIdx.x == 0) publish_flag_ext(fin.flag, fin.seq);
+    return;
+  }
+  // last-workgroup final reduction (same protocol as kernels_sumcheck.hip::finish_round)
+  if (threadIdx.x < 64) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const uint32_t t = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = t == fin.last_ticket;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      is_last = last;
+    }
+  }
+  __syncthreads();
+  if (!is_last) return;
+  const uint32_t blocks = gridDim.x;
+#pragma unroll
+  for (int x = 0; x < D; x++) {
+    Fr a2 = Fr::zero();
+    for (uint32_t i = threadIdx.x; i < blocks; i += blockDim.x) a2 = add(a2, partials[(size_t)i * D + x]);
+    a2 = block_reduce_sum(a2, lds);
+    if (threadIdx.x == 0) fin.out_host[x] = a2;
+  }
+  if (threadIdx.x == 0) publish_flag_ext(fin.flag, fin.seq);
+}
+
+template <int D>
+static void launch_ext(Ctx& c, const ExtRound& rd, bool bind, size_t size, uint32_t tp, unsigned grid, Fr* partials,
+                       const ScFinishArgs& fin) {
+  if (bind)
+    hipLaunchKernelGGL((sc_round_ext_kernel<D, true>), dim3(grid), dim3(256), 0, c.stream, rd, size, tp, partials, fin);
+  else
+    hipLaunchKernelGGL((sc_round_ext_kernel<D, false>), dim3(grid), dim3(256), 0, c.stream, rd, size, tp, partials, fin);
+}
+
+void k_sc_round_ext(Ctx& c, const ExtRound& rd, int degree, bool bind, size_t size, Fr* evals_host) {
+  LH_REQUIRE(degree >= 2 && degree <= 8, LH_ERR_ARG, "sum-check degree must be in 2..8");
+  LH_REQUIRE(size >= 1, LH_ERR_ARG, "sum-check round over an empty table");
+  const uint32_t seq = c.next_seq();
+  ArenaScope scope(c.arena);
+  // one thread per (pair, monomial) while that still fits a few waves per SIMD, else one thread per pair
+  const uint32_t tp = (rd.num_terms > 1 && size * rd.num_terms <= ((size_t)1 << 19)) ? rd.num_terms : 1u;
+  size_t g = (size * tp + 255) / 256;
+  size_t cap = (size_t)c.num_cus * 8;
+  if (g > cap) g = cap;
+  Fr* partials = g == 1 ? evals_host : c.arena.alloc_n<Fr>(g * degree);
+  const ScFinishArgs fin = c.finish_for((uint32_t)g, evals_host, seq);
+  {
+    char name[40];
+    snprintf(name, sizeof name, "sc_round_ext<%d,%s>%s", degree, bind ? "bind" : "first", tp > 1 ? "/tp" : "");
+    ProfScope ps(c, name, (bind ? 192.0 : 64.0) * (double)size * rd.num_tables, 0, (double)size);
+    switch (degree) {
+      case 2: launch_ext<2>(c, rd, bind, size, tp, (unsigned)g, partials, fin); break;
+      case 3: launch_ext<3>(c, rd, bind, size, tp, (unsigned)g, partials, fin); break;
+      case 4: launch_ext<4>(c, rd, bind, size, tp, (unsigned)g, partials, fin); break;
+      case 5: launch_ext<5>(c, rd, bind, size, tp, (unsigned)g, partials, fin); break;
+      case 6: launch_ext<6>(c, rd, bind, size, tp, (unsigned)g, partials, fin); break;
+      case 7: launch_ext<7>(c, rd, bind, size, tp, (unsigned)g, partials, fin); break;
+      default: launch_ext<8>(c, rd, bind, size, tp, (unsigned)g, partials, fin); break;
+    }
+  }
+  c.wait_flag(seq);
+}
+
+// ------------------------------------------------------------------ row-wise evaluation of a monomial list
+// out[b] = sum_m coeff_m * prod_k atom_{m,k}(b), atoms read at (rotated) row b
+__global__ void expr_rows_kernel(RowsExpr e, size_t n, Fr* __restrict__ out) {
+  GSTRIDE(b, n) {
+    Fr acc = Fr::zero();
+    for (uint32_t m = 0; m < e.num_terms; m++) {
+      Fr v = e.coeff[m];
+      for (uint32_t k = e.off[m]; k < e.off[m + 1]; k++) {
+        const RowsAtom a = e.atoms[e.fac[k]];
+        Fr f;
+        if (a.kind == ROWS_ATOM_POLY) {
+          f = a.table[a.rot == 0 ? b : bh_rotate((uint32_t)b, a.rot, e.num_vars, e.primitive, e.x_inv)];
+        } else if (a.kind == ROWS_ATOM_IDENTITY) {
+          f = from_u64<FrParams>(b);
+        } else {  // Lagrange: 1 on its row
+          f = (b == a.hot) ? Fr::one() : Fr::zero();
+        }
+        v = mul(v, f);
+      }
+      acc = add(acc, v);
+    }
+    out[b] = acc;
+  }
+}
+void k_expr_rows(Ctx& c, const RowsExpr& e, size_t n, Fr* out) {
+  if (n) hipLaunchKernelGGL(expr_rows_kernel, grid_for(n), 256, 0, c.stream, e, n, out);
+}
+
+}  // namespace lh

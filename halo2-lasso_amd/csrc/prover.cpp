@@ -2,6 +2,7 @@
 // Every function cites the reference routine whose transcript schedule it reproduces; all heavy
 // loops run in HIP kernels (dev.hpp), the host keeps the Fiat-Shamir state and O(n) scalars.
 #include <algorithm>
+#include <functional>
 #include "host.hpp"
 
 namespace lh {
@@ -173,6 +174,101 @@ std::vector<HFr> evaluate_polys_sharded(Ctx& c, const Fr* const* d_polys_local, 
   return out;
 }
 
+// ------------------------------------------------------------------ the round loop of ClassicSumCheck::prove
+// (classic.rs:208-240) shared by the sum-of-products and the general-expression front ends.
+// `cur`: current tables (polys first), `used[i]`: the round kernel binds/stores table i itself,
+// `round_fn(in, out, r_prev, bind, size, evals_host)`: launches the round kernel and waits for the
+// D sums at X = 1..D.
+SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degree, std::vector<const Fr*> cur,
+                                     const std::vector<char>& used, size_t num_polys, const HFr& sum, Transcript& tr,
+                                     bool sharded, const RoundFn& round_fn) {
+  const size_t T = cur.size();
+  const size_t rho = sharded ? log2_exact((size_t)c.comm.size) : 0, j = c.shard_bit;
+  size_t len = (size_t)1 << (num_vars - rho);  // current length of every (local) table
+  // ping-pong targets of the binds: A holds len/2, B holds len/4
+  std::vector<Fr*> bufA(T), bufB(T);
+  auto alloc_bufs = [&](size_t l) {
+    for (size_t i = 0; i < T; i++) {
+      bufA[i] = c.arena.alloc_n<Fr>(std::max<size_t>(l >> 1, 1));
+      bufB[i] = c.arena.alloc_n<Fr>(std::max<size_t>(l >> 2, 1));
+    }
+  };
+  alloc_bufs(len);
+  int flip = 0;  // next bind target: 0 -> A, 1 -> B
+  Fr* evals_host = (Fr*)c.pin((16 + SC_MAX_TABLES) * sizeof(Fr));
+  static const HFr inv2 = HFr::from_u64(2).inv();
+
+  SumCheckResult res;
+  HFr claim = sum;
+  HFr r_prev = HFr::zero();
+  bool sh = sharded;
+  for (size_t round = 0; round < num_vars; round++) {
+    bool bind = round > 0;
+    if (sh && round == j) {
+      // the shard bits are about to become the pair bit: bind once more, exchange, go on replicated
+      std::vector<Fr*>& dst = flip ? bufB : bufA;
+      k_fix_var_multi(c, cur.data(), dst.data(), T, len, dev(r_prev));
+      len >>= 1;
+      std::vector<Fr*> rep(T);
+      const size_t full = len << rho;
+      for (size_t i = 0; i < T; i++) rep[i] = c.arena.alloc_n<Fr>(full);
+      std::vector<const Fr*> bound(dst.begin(), dst.end());
+      comm_gather_interleave(c, bound.data(), T, len, rep.data());
+      for (size_t i = 0; i < T; i++) cur[i] = rep[i];
+      len = full;
+      alloc_bufs(len);
+      flip = 0;
+      sh = false;
+      bind = false;
+    }
+    const size_t size = bind ? len >> 2 : len >> 1;
+    std::vector<Fr*>& dst = flip ? bufB : bufA;
+    if (bind) {
+      // tables no term touches are still bound (ProverState::next_round binds every poly)
+      for (size_t i = 0; i < T; i++)
+        if (!used[i]) k_fix_var(c, cur[i], len, dev(r_prev), dst[i]);
+    }
+    round_fn(cur.data(), dst.data(), dev(r_prev), bind, size, evals_host);
+    if (bind) {
+      for (size_t i = 0; i < T; i++) cur[i] = dst[i];
+      len >>= 1;
+      flip ^= 1;
+    }
+
+    std::vector<HFr> ev(degree + 1);
+    for (int x = 1; x <= degree; x++) ev[x] = hst(evals_host[x - 1]);
+    if (sh) comm_sum_fr(c, ev.data() + 1, degree);  // partial sums of the other shards
+    ev[0] = claim - ev[1];  // eval.rs:129
+    HFr r;
+    if (prover_kind == LH_SC_COEFFICIENTS) {
+      // coeff.rs:136-149: c0 = p(0), c2 = leading coefficient, c1 = claim - (2 c0 + c2)
+      std::vector<HFr> co(3);
+      co[0] = ev[0];
+      co[2] = (ev[2] - ev[1].dbl() + ev[0]) * inv2;
+      co[1] = claim - (co[0].dbl() + co[2]);
+      tr.write_field_elements(co);
+      r = tr.squeeze_challenge();
+      claim = horner(co, r);
+    } else {
+      tr.write_field_elements(ev);
+      r = tr.squeeze_challenge();
+      claim = interpolate_evals(ev, r);
+    }
+    res.challenges.push_back(r);
+    r_prev = r;
+  }
+  LH_REQUIRE(!sh && len == 2, LH_ERR_ARG, "sum-check: internal size mismatch");
+  // into_evals: last bind (2 -> 1 entries) of every poly
+  if (num_polys) {
+    LH_REQUIRE(num_polys <= (size_t)SC_MAX_TABLES, LH_ERR_ARG, "sum-check: too many polys");
+    Fr* out = (Fr*)c.pin((16 + SC_MAX_TABLES) * sizeof(Fr)) + 16;
+    k_bind_first(c, cur.data(), num_polys, dev(r_prev), out);
+    res.evals.resize(num_polys);
+    memcpy(res.evals.data(), out, num_polys * sizeof(Fr));
+  }
+  return res;
+}
+
 // ------------------------------------------------------------------ ClassicSumCheck::prove
 // reference piop/sum_check/classic.rs:208-240.  Round i: [fused bind with r_{i-1}] + evaluation on the
 // GPU (k_sc_round), message to the transcript, squeeze r_i.  After the last squeeze one more bind gives
@@ -222,101 +318,24 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
     LH_REQUIRE(degree >= 2, LH_ERR_ARG, "EvaluationsProver needs degree >= 2");  // eval.rs:316 debug_assert
 
   ArenaScope scope(c.arena);
-  size_t len = (size_t)1 << (num_vars - rho);  // current length of every (local) table
+  const size_t len0 = (size_t)1 << (num_vars - rho);
   std::vector<const Fr*> cur(T);
   for (size_t i = 0; i < num_polys; i++) cur[i] = d_polys[i];
   for (size_t jy = 0; jy < num_ys; jy++) {  // ProverState::new: eq_xys (classic.rs:56-60)
-    Fr* eq = c.arena.alloc_n<Fr>(len);
+    Fr* eq = c.arena.alloc_n<Fr>(len0);
     if (sharded) eq_xy_shard(c, ys + jy * num_vars, num_vars, eq);
     else k_eq_xy(c, (const Fr*)(ys + jy * num_vars), num_vars, eq);
     cur[num_polys + jy] = eq;
   }
-  // ping-pong targets of the binds: A holds len/2, B holds len/4
-  std::vector<Fr*> bufA(T), bufB(T);
-  auto alloc_bufs = [&](size_t l) {
+  auto round_fn = [&](const Fr* const* in, Fr* const* out, const Fr& r, bool bind, size_t size, Fr* evals_host) {
     for (size_t i = 0; i < T; i++) {
-      bufA[i] = c.arena.alloc_n<Fr>(std::max<size_t>(l >> 1, 1));
-      bufB[i] = c.arena.alloc_n<Fr>(std::max<size_t>(l >> 2, 1));
+      rd.in[i] = in[i];
+      rd.out[i] = out[i];
     }
-  };
-  alloc_bufs(len);
-  int flip = 0;  // next bind target: 0 -> A, 1 -> B
-  Fr* evals_host = (Fr*)c.pin((16 + SC_MAX_TABLES) * sizeof(Fr));
-  static const HFr inv2 = HFr::from_u64(2).inv();
-
-  SumCheckResult res;
-  HFr claim = sum;
-  HFr r_prev = HFr::zero();
-  bool sh = sharded;
-  for (size_t round = 0; round < num_vars; round++) {
-    bool bind = round > 0;
-    if (sh && round == j) {
-      // the shard bits are about to become the pair bit: bind once more, exchange, go on replicated
-      std::vector<Fr*>& dst = flip ? bufB : bufA;
-      k_fix_var_multi(c, cur.data(), dst.data(), T, len, dev(r_prev));
-      len >>= 1;
-      std::vector<Fr*> rep(T);
-      const size_t full = len << rho;
-      for (size_t i = 0; i < T; i++) rep[i] = c.arena.alloc_n<Fr>(full);
-      std::vector<const Fr*> bound(dst.begin(), dst.end());
-      comm_gather_interleave(c, bound.data(), T, len, rep.data());
-      for (size_t i = 0; i < T; i++) cur[i] = rep[i];
-      len = full;
-      alloc_bufs(len);
-      flip = 0;
-      sh = false;
-      bind = false;
-    }
-    const size_t size = bind ? len >> 2 : len >> 1;
-    std::vector<Fr*>& dst = flip ? bufB : bufA;
-    for (size_t i = 0; i < T; i++) {
-      rd.in[i] = cur[i];
-      rd.out[i] = dst[i];
-    }
-    rd.r = dev(r_prev);
-    if (bind) {
-      // tables no term touches are still bound (ProverState::next_round binds every poly)
-      for (size_t i = 0; i < T; i++)
-        if (!used[i]) k_fix_var(c, cur[i], len, rd.r, dst[i]);
-    }
+    rd.r = r;
     k_sc_round(c, rd, degree, bind, size, evals_host);
-    if (bind) {
-      for (size_t i = 0; i < T; i++) cur[i] = dst[i];
-      len >>= 1;
-      flip ^= 1;
-    }
-
-    std::vector<HFr> ev(degree + 1);
-    for (int x = 1; x <= degree; x++) ev[x] = hst(evals_host[x - 1]);
-    if (sh) comm_sum_fr(c, ev.data() + 1, degree);  // partial sums of the other shards
-    ev[0] = claim - ev[1];  // eval.rs:129
-    HFr r;
-    if (prover_kind == LH_SC_COEFFICIENTS) {
-      // coeff.rs:136-149: c0 = p(0), c2 = leading coefficient, c1 = claim - (2 c0 + c2)
-      std::vector<HFr> co(3);
-      co[0] = ev[0];
-      co[2] = (ev[2] - ev[1].dbl() + ev[0]) * inv2;
-      co[1] = claim - (co[0].dbl() + co[2]);
-      tr.write_field_elements(co);
-      r = tr.squeeze_challenge();
-      claim = horner(co, r);
-    } else {
-      tr.write_field_elements(ev);
-      r = tr.squeeze_challenge();
-      claim = interpolate_evals(ev, r);
-    }
-    res.challenges.push_back(r);
-    r_prev = r;
-  }
-  LH_REQUIRE(!sh && len == 2, LH_ERR_ARG, "sum-check: internal size mismatch");
-  // into_evals: last bind (2 -> 1 entries) of every poly
-  if (num_polys) {
-    Fr* out = (Fr*)c.pin((16 + SC_MAX_TABLES) * sizeof(Fr)) + 16;
-    k_bind_first(c, cur.data(), num_polys, dev(r_prev), out);
-    res.evals.resize(num_polys);
-    memcpy(res.evals.data(), out, num_polys * sizeof(Fr));
-  }
-  return res;
+  };
+  return sum_check_loop(c, prover_kind, num_vars, degree, cur, used, num_polys, sum, tr, sharded, round_fn);
 }
 
 SumCheckResult sum_check_prove(Ctx& c, int prover_kind, size_t num_vars, const lh_sop& expr,

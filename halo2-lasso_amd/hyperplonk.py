@@ -1,0 +1,168 @@
+"""Host mirror of plonkish_backend::backend::hyperplonk (setup / preprocess / prove surface).
+
+`PlonkishCircuitInfo` (backend.rs:46-130), `compose` and the permutation polys of
+backend/hyperplonk/preprocessor.rs:25-203, `HyperPlonk::{preprocess, prove}` (hyperplonk.rs:97-291).
+Host code here is circuit bookkeeping only (expressions, copy cycles); every polynomial operation of
+`prove` runs on the GPU behind `lh_hyperplonk_prove`.
+"""
+import ctypes as C
+
+from . import _ffi
+from . import expression as ex
+from .expression import R_MOD
+
+
+class PlonkishCircuitInfo:
+    """backend.rs:46-73"""
+
+    def __init__(self, k, num_instances, preprocess_polys, num_witness_polys, num_challenges, constraints, lookups,
+                 permutations, max_degree=None):
+        self.k, self.num_instances = k, list(num_instances)
+        self.preprocess_polys = [list(p) for p in preprocess_polys]
+        self.num_witness_polys, self.num_challenges = list(num_witness_polys), list(num_challenges)
+        self.constraints, self.lookups = list(constraints), [list(l) for l in lookups]
+        self.permutations, self.max_degree = [list(c) for c in permutations], max_degree
+
+    def num_poly(self):
+        return len(self.num_instances) + len(self.preprocess_polys) + sum(self.num_witness_polys)
+
+    def permutation_polys(self):
+        return sorted({poly for cycle in self.permutations for poly, _ in cycle})
+
+
+def lookup_constraints(info, beta, gamma):
+    """preprocessor.rs:79-109"""
+    m_offset = info.num_poly() + len(info.permutation_polys())
+    h_offset = m_offset + len(info.lookups)
+    constraints = []
+    for k, lookup in enumerate(info.lookups):
+        m, h = ex.Polynomial(m_offset + k), ex.Polynomial(h_offset + k)
+        inp = ex.distribute_powers([i for i, _ in lookup], beta)
+        tab = ex.distribute_powers([t for _, t in lookup], beta)
+        constraints.append(h * (inp + gamma) * (tab + gamma) - (tab + gamma) + m * (inp + gamma))
+    return constraints, [ex.Polynomial(h_offset + k) for k in range(len(info.lookups))]
+
+
+def max_degree(info, lookup_cs=None):
+    """preprocessor.rs:62-77"""
+    if lookup_cs is None:
+        lookup_cs = lookup_constraints(info, ex.Constant(0), ex.Constant(0))[0]
+    degs = [c.degree() for c in info.constraints] + [c.degree() for c in lookup_cs]
+    if info.max_degree is not None:
+        degs.append(info.max_degree)
+    return max(degs + [2])
+
+
+def permutation_constraints(info, max_deg, beta, gamma, num_builtin_witness_polys):
+    """preprocessor.rs:111-170"""
+    perm_polys = info.permutation_polys()
+    chunk = max_deg - 1
+    num_chunks = -(-len(perm_polys) // chunk) if perm_polys else 0
+    perm_offset = info.num_poly()
+    z_offset = perm_offset + len(perm_polys) + num_builtin_witness_polys
+    polys = [ex.Polynomial(i) for i in perm_polys]
+    ids = [ex.Constant(i << info.k) + ex.Identity() for i in range(len(polys))]
+    perms = [ex.Polynomial(perm_offset + i) for i in range(len(perm_polys))]
+    zs = [ex.Polynomial(z_offset + i) for i in range(num_chunks)]
+    z_0_next = ex.Polynomial(z_offset, 1)
+    constraints = []
+    if zs:
+        constraints.append(ex.Lagrange(1) * (zs[0] - ex.Constant(1)))
+    for c in range(num_chunks):
+        sl = slice(c * chunk, (c + 1) * chunk)
+        z_lhs, z_rhs = zs[c], (zs[c + 1] if c + 1 < num_chunks else z_0_next)
+        lhs = z_lhs * ex.product_exprs([p + beta * i + gamma for p, i in zip(polys[sl], ids[sl])])
+        rhs = z_rhs * ex.product_exprs([p + beta * s + gamma for p, s in zip(polys[sl], perms[sl])])
+        constraints.append(lhs - rhs)
+    return num_chunks, constraints
+
+
+def compose(info):
+    """preprocessor.rs:25-60 -> (num_permutation_z_polys, expression)"""
+    off = sum(info.num_challenges)
+    beta, gamma, alpha = (ex.Challenge(off + i) for i in range(3))
+    lookup_cs, lookup_zero_checks = lookup_constraints(info, beta, gamma)
+    md = max_degree(info, lookup_cs)
+    num_z, perm_cs = permutation_constraints(info, md, beta, gamma, 2 * len(info.lookups))
+    constraints = list(info.constraints) + lookup_cs + perm_cs
+    zero_check_on_every_row = ex.distribute_powers(constraints, alpha) * ex.EqXY(0)
+    return num_z, ex.distribute_powers(lookup_zero_checks + [zero_check_on_every_row], alpha)
+
+
+def permutation_polys(num_vars, perm_polys, cycles):
+    """preprocessor.rs:172-203"""
+    poly_index = {poly: idx for idx, poly in enumerate(perm_polys)}
+    perms = [[((idx << num_vars) + j) % R_MOD for j in range(1 << num_vars)] for idx in range(len(perm_polys))]
+    for cycle in cycles:
+        i0, j0 = cycle[0]
+        last = perms[poly_index[i0]][j0]
+        for (i, j) in (cycle[1:] + cycle[:1]):
+            assert j != 0
+            perms[poly_index[i]][j], last = last, perms[poly_index[i]][j]
+    return perms
+
+
+class HyperPlonkProverParam:
+    """hyperplonk.rs:38-55"""
+
+
+class HyperPlonk:
+    @staticmethod
+    def preprocess(pcs_pp, info):
+        """hyperplonk.rs:97-162 (prover half): preprocess / permutation polys go to the GPU once."""
+        from . import MultilinearPolynomial, MultilinearKzg
+        ctx = pcs_pp.ctx
+        pp = HyperPlonkProverParam()
+        pp.pcs, pp.num_vars, pp.info = pcs_pp, info.k, info
+        pp.preprocess_polys = [MultilinearPolynomial.new(ctx, p) for p in info.preprocess_polys]
+        pp.preprocess_comms = MultilinearKzg.batch_commit(pcs_pp, pp.preprocess_polys)
+        perm = permutation_polys(info.k, info.permutation_polys(), info.permutations)
+        pp.permutation_polys = [MultilinearPolynomial.new(ctx, p) for p in perm]
+        pp.permutation_comms = MultilinearKzg.batch_commit(pcs_pp, pp.permutation_polys)
+        pp.num_permutation_z_polys, pp.expression = compose(info)
+        return pp
+
+    @staticmethod
+    def prove(pp, instances, witness_polys, transcript):
+        """hyperplonk.rs:164-291 for single-phase circuits (`synthesize(0, [])` = witness_polys)."""
+        from . import _check, _ptr_array, _fr_array, lh_fr
+        info, ctx = pp.info, pp.pcs.ctx
+        if len(info.num_witness_polys) != 1:
+            raise NotImplementedError("multi-phase circuits need a synthesize callback")
+        keep = []
+        prm = _ffi.lh_hp_param()
+        prm.num_vars = pp.num_vars
+        prm.num_instance_polys = len(info.num_instances)
+        ni = (C.c_size_t * max(len(info.num_instances), 1))(*info.num_instances)
+        prm.num_instances = ni
+        prm.num_preprocess_polys = len(pp.preprocess_polys)
+        pre = _ptr_array(pp.preprocess_polys)
+        prm.d_preprocess_polys = C.cast(pre, C.POINTER(C.c_void_p))
+        prm.num_witness_polys = info.num_witness_polys[0]
+        prm.num_challenges = info.num_challenges[0]
+        lookups = (_ffi.lh_hp_lookup * max(len(info.lookups), 1))()
+        for k, lookup in enumerate(info.lookups):
+            ins = (_ffi.lh_expr * len(lookup))()
+            tabs = (_ffi.lh_expr * len(lookup))()
+            for w, (i_e, t_e) in enumerate(lookup):
+                ce, ka = i_e.to_c()
+                ins[w] = ce
+                ct, kb = t_e.to_c()
+                tabs[w] = ct
+                keep += [ka, kb]
+            lookups[k].inputs, lookups[k].tables, lookups[k].width = ins, tabs, len(lookup)
+            keep += [ins, tabs]
+        prm.num_lookups, prm.lookups = len(info.lookups), lookups
+        pidx = info.permutation_polys()
+        prm.num_permutation_polys = len(pidx)
+        pi_arr = (C.c_size_t * max(len(pidx), 1))(*pidx)
+        prm.permutation_poly_index = pi_arr
+        perm = _ptr_array(pp.permutation_polys)
+        prm.d_permutation_polys = C.cast(perm, C.POINTER(C.c_void_p))
+        prm.num_permutation_z_polys = pp.num_permutation_z_polys
+        ce, knodes = pp.expression.to_c()
+        prm.expression = ce
+        inst_arrays = [_fr_array(i) for i in instances]
+        inst = (C.POINTER(lh_fr) * max(len(instances), 1))(*[C.cast(a, C.POINTER(lh_fr)) for a in inst_arrays])
+        wit = _ptr_array(witness_polys)
+        _check(ctx.lib.lh_hyperplonk_prove(ctx.h, pp.pcs.h, C.byref(prm), inst, wit, transcript.p))

@@ -129,6 +129,29 @@ lh_status lh_sumcheck_prove(lh_ctx*, int prover_kind, size_t num_vars, const lh_
                             const lh_fr* sum, lh_transcript* t,
                             lh_fr* out_challenges, lh_fr* out_evals);
 
+/* General Expression (util/expression.rs:67-78), flattened: every node refers to EARLIER nodes, the
+ * root is the last one.  DistributePowers(exprs, base) is lowered by the caller exactly as
+ * Expression::evaluate does (expression.rs:155-167): e0 + base*e1 + base^2*e2 + ...            */
+#define LH_EX_CONSTANT 0   /* scalar */
+#define LH_EX_IDENTITY 1   /* CommonPolynomial::Identity */
+#define LH_EX_LAGRANGE 2   /* CommonPolynomial::Lagrange(a) */
+#define LH_EX_EQ_XY 3      /* CommonPolynomial::EqXY(a) */
+#define LH_EX_POLYNOMIAL 4 /* Query { poly: a, rotation: b } */
+#define LH_EX_CHALLENGE 5  /* Challenge(a) */
+#define LH_EX_NEGATED 6    /* -node[a] */
+#define LH_EX_SUM 7        /* node[a] + node[b] */
+#define LH_EX_PRODUCT 8    /* node[a] * node[b] */
+#define LH_EX_SCALED 9     /* node[a] * scalar */
+typedef struct lh_expr_node { uint32_t op; int32_t a, b; uint32_t reserved; lh_fr scalar; } lh_expr_node;
+typedef struct lh_expr { const lh_expr_node* nodes; size_t num_nodes; } lh_expr;
+/* ClassicSumCheck::<EvaluationsProver>::prove over a VirtualPolynomial{expression, polys, challenges, ys}
+ * (piop/sum_check.rs:16-37, classic.rs:208-240) including rotations (BooleanHypercube, util/arithmetic/bh.rs),
+ * Identity and Lagrange.  out_evals: every poly at x (classic.rs:143-149). */
+lh_status lh_sumcheck_prove_expr(lh_ctx*, size_t num_vars, const lh_expr* expr, const lh_fr* const* d_polys,
+                                 size_t num_polys, const lh_fr* challenges, size_t num_challenges,
+                                 const lh_fr* ys, size_t num_ys, const lh_fr* sum, lh_transcript* t,
+                                 lh_fr* out_challenges, lh_fr* out_evals);
+
 /* ---------------------------------------------------------------- a9: piop::gkr
  * prove_fractional_sum_check (piop/gkr/fractional_sum_check.rs:89-190).  claimed_*[b] may be
  * NULL (None => root written) or point to a claim (Some => root only hashed).  Outputs
