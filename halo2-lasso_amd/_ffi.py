@@ -41,6 +41,22 @@ class lh_expr(C.Structure):
     _fields_ = [("nodes", C.POINTER(lh_expr_node)), ("num_nodes", C.c_size_t)]
 
 
+class lh_hp_lookup(C.Structure):
+    _fields_ = [("inputs", C.POINTER(lh_expr)), ("tables", C.POINTER(lh_expr)), ("width", C.c_size_t)]
+
+
+class lh_hp_param(C.Structure):
+    _fields_ = [("num_vars", C.c_size_t),
+                ("num_instance_polys", C.c_size_t), ("num_instances", C.POINTER(C.c_size_t)),
+                ("num_preprocess_polys", C.c_size_t), ("d_preprocess_polys", C.POINTER(C.c_void_p)),
+                ("num_witness_polys", C.c_size_t), ("num_challenges", C.c_size_t),
+                ("num_lookups", C.c_size_t), ("lookups", C.POINTER(lh_hp_lookup)),
+                ("num_permutation_polys", C.c_size_t), ("permutation_poly_index", C.POINTER(C.c_size_t)),
+                ("d_permutation_polys", C.POINTER(C.c_void_p)),
+                ("num_permutation_z_polys", C.c_size_t),
+                ("expression", lh_expr)]
+
+
 class lh_evaluation(C.Structure):
     _fields_ = [("poly", C.c_uint32), ("point", C.c_uint32), ("value", lh_fr)]
 
@@ -137,6 +153,8 @@ SIGNATURES = {
     "lh_ctx_set_comm": (C.c_int, [_P, C.POINTER(lh_comm), _SZ]),
     "lh_lasso_prove_sharded": (C.c_int, [_P, _P, C.POINTER(lh_lasso_table), _SZ, C.POINTER(_P),
                                          C.POINTER(lh_transcript)]),
+    "lh_hyperplonk_prove": (C.c_int, [_P, _P, C.POINTER(lh_hp_param), C.POINTER(C.POINTER(lh_fr)), C.POINTER(_P),
+                                      C.POINTER(lh_transcript)]),
     "lh_profile_enable": (C.c_int, [_P, C.c_int]),
     "lh_profile_read": (C.c_int, [_P, C.POINTER(lh_prof_rec), _SZ, C.POINTER(_SZ)]),
 }

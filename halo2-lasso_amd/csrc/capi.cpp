@@ -415,6 +415,16 @@ lh_status lh_lasso_prove_sharded(lh_ctx* ctx, const lh_srs* srs, const lh_lasso_
   LH_CATCH
 }
 
+lh_status lh_hyperplonk_prove(lh_ctx* ctx, const lh_srs* srs, const lh_hp_param* pp, const lh_fr* const* instances,
+                              const lh_fr* const* d_witness_polys, lh_transcript* t) {
+  LH_TRY NEED(ctx);
+  NEED(srs);
+  NEED(pp);
+  Transcript tr(t);
+  hyperplonk_prove(ctx->c, srs->s, *pp, (const HFr* const*)instances, (const Fr* const*)d_witness_polys, tr);
+  LH_CATCH
+}
+
 lh_status lh_profile_enable(lh_ctx* ctx, int on) {
   LH_TRY NEED(ctx);
   ctx->c.sync();

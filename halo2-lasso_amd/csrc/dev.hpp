@@ -252,6 +252,15 @@ struct RowsExpr {
 };
 void k_expr_rows(Ctx&, const RowsExpr& e, size_t n, Fr* out);
 
+// ------------------------------------------------------------------ HyperPlonk witness polys (kernels_plonk.hip)
+// m[j] = #{i : input[i] == table[j]} on the LAST row j holding that value; false if an input is missing
+bool k_lookup_m(Ctx&, const Fr* input, const Fr* table, size_t n, Fr* m_out);
+void k_lookup_h(Ctx&, const Fr* input, const Fr* table, const Fr* m, const Fr& gamma, size_t n, Fr* h);
+void k_permutation_z(Ctx&, const Fr* const* values, const Fr* const* perms, size_t num_perm, size_t num_chunks,
+                     size_t num_vars, const Fr& beta, const Fr& gamma, const uint32_t* d_order, const uint32_t* d_nth,
+                     Fr* const* z_out);
+void k_scatter_rows(Ctx&, const uint32_t* d_rows, const Fr* d_vals, size_t count, size_t n, Fr* table);
+
 // ------------------------------------------------------------------ MSM (msm.hip)
 struct MsmJob {
   const void* scalars;  // Fr (Montgomery) or u32

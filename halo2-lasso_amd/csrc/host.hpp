@@ -149,4 +149,8 @@ void lasso_prove(Ctx&, const Srs&, const lh_lasso_table& table, size_t num_vars,
 void lasso_prove_sharded(Ctx&, const Srs&, const lh_lasso_table& table, size_t num_vars,
                          const uint32_t* const* d_dims, Transcript& tr);
 
+// ------------------------------------------------------------------ HyperPlonk (hyperplonk.cpp)
+void hyperplonk_prove(Ctx&, const Srs&, const lh_hp_param& pp, const HFr* const* instances,
+                      const Fr* const* d_witness, Transcript& tr);
+
 }  // namespace lh

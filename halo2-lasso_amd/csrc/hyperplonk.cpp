@@ -1,0 +1,272 @@
+// HyperPlonk::prove (reference backend/hyperplonk.rs:164-291) with LogUp lookups and the permutation
+// argument, for single-phase circuits.  Transcript schedule: SURVEY.md §3.1; restated in
+// oracle/pyref/hyperplonk.py, which the tests compare against byte for byte.
+#include <algorithm>
+#include <map>
+#include <set>
+#include "host.hpp"
+#include "expr.hpp"
+
+namespace lh {
+
+// ------------------------------------------------------------------ rotation points (poly/multilinear.rs:477-549)
+static std::vector<size_t> point_pattern(bool next, size_t num_vars, size_t distance) {
+  const size_t rem = next ? bh_primitive(num_vars) : bh_x_inv(num_vars);
+  std::vector<size_t> pat((size_t)1 << distance, 0);
+  for (size_t depth = 0; depth < distance; depth++) {
+    size_t step = (size_t)1 << (distance - depth);
+    for (size_t e = 0; e < pat.size(); e += step) {
+      size_t o = e + step / 2;
+      size_t rot = next ? pat[e] << 1 : pat[e] >> 1;
+      pat[o] = rot ^ rem;
+      pat[e] = rot;
+    }
+  }
+  return pat;
+}
+
+static std::vector<std::vector<HFr>> rotation_eval_points(const std::vector<HFr>& x, int rotation) {
+  if (rotation == 0) return {x};
+  const size_t n = x.size(), distance = (size_t)std::abs(rotation), num_x = n - distance;
+  std::vector<std::vector<HFr>> out;
+  const HFr one = HFr::one(), zero = HFr::zero();
+  auto bit = [](size_t p, size_t i) { return (p >> i) & 1; };
+  if (rotation < 0) {
+    for (size_t p : point_pattern(false, n, distance)) {
+      std::vector<HFr> pt;
+      for (size_t i = 0; i < num_x; i++) pt.push_back(bit(p, i) ? one - x[distance + i] : x[distance + i]);
+      for (size_t i = 0; i < distance; i++) pt.push_back(bit(p, i + num_x) ? one : zero);
+      out.push_back(pt);
+    }
+  } else {
+    for (size_t p : point_pattern(true, n, distance)) {
+      std::vector<HFr> pt;
+      for (size_t i = 0; i < distance; i++) pt.push_back(bit(p, i) ? one : zero);
+      for (size_t i = 0; i < num_x; i++) pt.push_back(bit(p, i + distance) ? one - x[i] : x[i]);
+      out.push_back(pt);
+    }
+  }
+  return out;
+}
+
+// ------------------------------------------------------------------ lookup_compressed_polys (prover.rs:50-137)
+// sum_i beta^i * expr_i as ONE monomial list over row atoms, evaluated row-wise by expr_rows_kernel
+static void compressed_poly(Ctx& c, const lh_expr* exprs, size_t width, const std::vector<HFr>& betas,
+                            const std::vector<const Fr*>& polys, const HFr* challenges, size_t num_challenges,
+                            size_t num_vars, Fr* out) {
+  std::vector<RowsAtom> atoms;
+  std::vector<Fr> coeff;
+  std::vector<uint32_t> off{0};
+  std::vector<uint8_t> fac;
+  const size_t n = (size_t)1 << num_vars;
+  for (size_t w = 0; w < width; w++) {
+    ExpandedExpr ex = expand_expr(exprs[w], challenges, num_challenges);
+    std::vector<int> id(ex.atoms.size());
+    for (size_t a = 0; a < ex.atoms.size(); a++) {
+      const ExprAtom& at = ex.atoms[a];
+      RowsAtom ra;
+      memset(&ra, 0, sizeof(ra));
+      if (at.kind == LH_EX_POLYNOMIAL) {
+        LH_REQUIRE((size_t)at.a < polys.size(), LH_ERR_ARG, "lookup expression: poly index out of range");
+        ra.kind = ROWS_ATOM_POLY, ra.table = polys[at.a], ra.rot = at.b;
+      } else if (at.kind == LH_EX_IDENTITY) {
+        ra.kind = ROWS_ATOM_IDENTITY;
+      } else if (at.kind == LH_EX_LAGRANGE) {
+        long long m = (long long)at.a % (long long)n;
+        if (m < 0) m += (long long)n;
+        ra.kind = ROWS_ATOM_LAGRANGE, ra.hot = bh_nth(num_vars, (size_t)m);
+      } else {
+        throw Error(LH_ERR_ARG, "lookup expression: eq_xy is not allowed here");  // prover.rs:108 unreachable!()
+      }
+      LH_REQUIRE(atoms.size() < 250, LH_ERR_ARG, "lookup expression: too many atoms");
+      id[a] = (int)atoms.size();
+      atoms.push_back(ra);
+    }
+    for (const ExprMono& m : ex.monos) {
+      coeff.push_back(dev(m.coeff * betas[w]));
+      for (uint16_t a : m.atoms) fac.push_back((uint8_t)id[a]);
+      off.push_back((uint32_t)fac.size());
+    }
+  }
+  if (coeff.empty()) {
+    LH_HIP(hipMemsetAsync(out, 0, n * sizeof(Fr), c.stream));
+    return;
+  }
+  if (fac.empty()) fac.push_back(0);
+  if (atoms.empty()) atoms.push_back(RowsAtom{nullptr, 0, ROWS_ATOM_IDENTITY, 0});
+  ArenaScope scope(c.arena);
+  Fr* d_coeff = c.arena.alloc_n<Fr>(coeff.size());
+  uint32_t* d_off = c.arena.alloc_n<uint32_t>(off.size());
+  uint8_t* d_fac = c.arena.alloc_n<uint8_t>(fac.size());
+  RowsAtom* d_atoms = c.arena.alloc_n<RowsAtom>(atoms.size());
+  LH_HIP(hipMemcpyAsync(d_coeff, coeff.data(), coeff.size() * sizeof(Fr), hipMemcpyHostToDevice, c.stream));
+  LH_HIP(hipMemcpyAsync(d_off, off.data(), off.size() * 4, hipMemcpyHostToDevice, c.stream));
+  LH_HIP(hipMemcpyAsync(d_fac, fac.data(), fac.size(), hipMemcpyHostToDevice, c.stream));
+  LH_HIP(hipMemcpyAsync(d_atoms, atoms.data(), atoms.size() * sizeof(RowsAtom), hipMemcpyHostToDevice, c.stream));
+  RowsExpr re;
+  re.num_terms = (uint32_t)coeff.size(), re.num_vars = (uint32_t)num_vars;
+  re.primitive = bh_primitive(num_vars), re.x_inv = bh_x_inv(num_vars);
+  re.coeff = d_coeff, re.off = d_off, re.fac = d_fac, re.atoms = d_atoms;
+  k_expr_rows(c, re, n, out);
+  c.sync();  // host staging vectors die with this frame
+}
+
+// ------------------------------------------------------------------ HyperPlonk::prove
+void hyperplonk_prove(Ctx& c, const Srs& srs, const lh_hp_param& pp, const HFr* const* instances,
+                      const Fr* const* d_witness, Transcript& tr) {
+  const size_t nv = pp.num_vars, n = (size_t)1 << nv;
+  LH_REQUIRE(nv >= 1 && nv < 32, LH_ERR_ARG, "hyperplonk: bad num_vars");
+  if (nv > srs.num_vars) throw Error(LH_ERR_INVALID_PCS_PARAM, "Too many variates of poly to commit");
+  ArenaScope scope(c.arena);
+
+  // BooleanHypercube order / nth_map (bh.rs:127-141), host-generated once per call
+  std::vector<uint32_t> order(n), nth(n);
+  order[0] = 0;
+  {
+    size_t b = 1;
+    for (size_t k = 1; k < n; k++) {
+      order[k] = (uint32_t)b;
+      b = bh_next(b, nv);
+    }
+    for (size_t k = 0; k < n; k++) nth[order[k]] = (uint32_t)k;
+  }
+  uint32_t* d_order = c.arena.alloc_n<uint32_t>(n);
+  uint32_t* d_nth = c.arena.alloc_n<uint32_t>(n);
+  LH_HIP(hipMemcpyAsync(d_order, order.data(), n * 4, hipMemcpyHostToDevice, c.stream));
+  LH_HIP(hipMemcpyAsync(d_nth, nth.data(), n * 4, hipMemcpyHostToDevice, c.stream));
+
+  // instances: hashed, then placed on rows bh[1], bh[2], .. (hyperplonk.rs:170-177,365-369; prover.rs:32-48)
+  std::vector<const Fr*> polys;
+  for (size_t i = 0; i < pp.num_instance_polys; i++) {
+    const size_t cnt = pp.num_instances[i];
+    LH_REQUIRE(cnt <= n, LH_ERR_ARG, "hyperplonk: too many instances");
+    std::vector<uint32_t> rows(cnt);
+    for (size_t k = 0; k < cnt; k++) {
+      tr.common_field_element(instances[i][k]);
+      rows[k] = k + 1 < n ? order[k + 1] : 0;  // row_mapping = bh.iter().skip(1).chain([0])
+    }
+    Fr* tab = c.arena.alloc_n<Fr>(n);
+    uint32_t* d_rows = c.arena.alloc_n<uint32_t>(std::max<size_t>(cnt, 1));
+    Fr* d_vals = c.arena.alloc_n<Fr>(std::max<size_t>(cnt, 1));
+    if (cnt) {
+      LH_HIP(hipMemcpyAsync(d_rows, rows.data(), cnt * 4, hipMemcpyHostToDevice, c.stream));
+      LH_HIP(hipMemcpyAsync(d_vals, instances[i], cnt * sizeof(Fr), hipMemcpyHostToDevice, c.stream));
+    }
+    k_scatter_rows(c, d_rows, d_vals, cnt, n, tab);
+    c.sync();
+    polys.push_back(tab);
+  }
+  for (size_t i = 0; i < pp.num_preprocess_polys; i++) polys.push_back((const Fr*)pp.d_preprocess_polys[i]);
+
+  // round 0: witness commitments (single phase: synthesize(0, []) = d_witness)
+  std::vector<HFr> challenges;
+  {
+    std::vector<HG1> comms = mkzg_batch_commit(c, srs, d_witness, pp.num_witness_polys, nv);
+    tr.write_commitments(comms);
+    for (size_t i = 0; i < pp.num_witness_polys; i++) polys.push_back(d_witness[i]);
+    std::vector<HFr> ch = tr.squeeze_challenges(pp.num_challenges);
+    challenges.insert(challenges.end(), ch.begin(), ch.end());
+  }
+
+  // round n: beta, lookup m polys
+  HFr beta = tr.squeeze_challenge();
+  size_t width = 0;
+  for (size_t k = 0; k < pp.num_lookups; k++) width = std::max(width, pp.lookups[k].width);
+  std::vector<HFr> betas(width);
+  for (size_t i = 0; i < width; i++) betas[i] = i ? betas[i - 1] * beta : HFr::one();
+  std::vector<Fr*> comp_in(pp.num_lookups), comp_tab(pp.num_lookups), m_polys(pp.num_lookups), h_polys(pp.num_lookups);
+  for (size_t k = 0; k < pp.num_lookups; k++) {
+    comp_in[k] = c.arena.alloc_n<Fr>(n);
+    comp_tab[k] = c.arena.alloc_n<Fr>(n);
+    m_polys[k] = c.arena.alloc_n<Fr>(n);
+    h_polys[k] = c.arena.alloc_n<Fr>(n);
+    compressed_poly(c, pp.lookups[k].inputs, pp.lookups[k].width, betas, polys, challenges.data(), challenges.size(), nv,
+                    comp_in[k]);
+    compressed_poly(c, pp.lookups[k].tables, pp.lookups[k].width, betas, polys, challenges.data(), challenges.size(), nv,
+                    comp_tab[k]);
+    if (!k_lookup_m(c, comp_in[k], comp_tab[k], n, m_polys[k]))
+      throw Error(LH_ERR_INVALID_SNARK, "Invalid lookup input");  // prover.rs:176-178
+  }
+  {
+    std::vector<const Fr*> mp(m_polys.begin(), m_polys.end());
+    std::vector<HG1> comms = mkzg_batch_commit(c, srs, mp.data(), mp.size(), nv);
+    tr.write_commitments(comms);
+  }
+
+  // round n+1: gamma, lookup h polys and permutation z polys
+  HFr gamma = tr.squeeze_challenge();
+  for (size_t k = 0; k < pp.num_lookups; k++) k_lookup_h(c, comp_in[k], comp_tab[k], m_polys[k], dev(gamma), n, h_polys[k]);
+  std::vector<Fr*> z_polys(pp.num_permutation_z_polys);
+  for (auto& z : z_polys) z = c.arena.alloc_n<Fr>(n);
+  {
+    std::vector<const Fr*> values(pp.num_permutation_polys), perms(pp.num_permutation_polys);
+    for (size_t k = 0; k < pp.num_permutation_polys; k++) {
+      LH_REQUIRE(pp.permutation_poly_index[k] < polys.size(), LH_ERR_ARG, "hyperplonk: permutation poly out of range");
+      values[k] = polys[pp.permutation_poly_index[k]];
+      perms[k] = (const Fr*)pp.d_permutation_polys[k];
+    }
+    k_permutation_z(c, values.data(), perms.data(), pp.num_permutation_polys, pp.num_permutation_z_polys, nv, dev(beta),
+                    dev(gamma), d_order, d_nth, z_polys.data());
+  }
+  {
+    std::vector<const Fr*> hz(h_polys.begin(), h_polys.end());
+    hz.insert(hz.end(), z_polys.begin(), z_polys.end());
+    std::vector<HG1> comms = mkzg_batch_commit(c, srs, hz.data(), hz.size(), nv);
+    tr.write_commitments(comms);
+  }
+
+  // round n+2: alpha, y, zero-check
+  HFr alpha = tr.squeeze_challenge();
+  std::vector<HFr> y = tr.squeeze_challenges(nv);
+  for (size_t k = 0; k < pp.num_permutation_polys; k++) polys.push_back((const Fr*)pp.d_permutation_polys[k]);
+  for (auto p : m_polys) polys.push_back(p);
+  for (auto p : h_polys) polys.push_back(p);
+  for (auto p : z_polys) polys.push_back(p);
+  challenges.push_back(beta);
+  challenges.push_back(gamma);
+  challenges.push_back(alpha);
+  SumCheckResult sc = sum_check_prove_expr(c, nv, pp.expression, polys.data(), polys.size(), challenges.data(),
+                                           challenges.size(), y.data(), 1, HFr::zero(), tr);
+  const std::vector<HFr>& x = sc.challenges;
+
+  // evaluations in pcs_query order (verifier.rs:147-180, prover.rs:388-406)
+  std::set<std::pair<size_t, int>> query;
+  for (size_t i = 0; i < pp.expression.num_nodes; i++) {
+    const lh_expr_node& nd = pp.expression.nodes[i];
+    if (nd.op == LH_EX_POLYNOMIAL && (size_t)nd.a >= pp.num_instance_polys) query.insert({(size_t)nd.a, nd.b});
+  }
+  std::set<int> rots;
+  for (auto& q : query) rots.insert(q.second);
+  std::map<int, size_t> point_off;
+  std::vector<HFr> points;  // flattened, nv each
+  size_t num_points = 0;
+  std::map<int, std::vector<std::vector<HFr>>> rot_points;
+  for (int r : rots) {
+    point_off[r] = num_points;
+    rot_points[r] = rotation_eval_points(x, r);
+    for (auto& pt : rot_points[r]) points.insert(points.end(), pt.begin(), pt.end());
+    num_points += rot_points[r].size();
+  }
+  std::vector<lh_evaluation> evals;
+  std::vector<HFr> eval_values;
+  for (auto& q : query) {
+    std::vector<HFr> vals;
+    if (q.second == 0) {
+      vals.push_back(sc.evals[q.first]);
+    } else {  // evaluate_for_rotation (multilinear.rs:191-264): the poly at the rotation's points
+      for (auto& pt : rot_points[q.second]) vals.push_back(evaluate_polys(c, &polys[q.first], 1, nv, pt.data())[0]);
+    }
+    for (size_t k = 0; k < vals.size(); k++) {
+      lh_evaluation e;
+      e.poly = (uint32_t)q.first;
+      e.point = (uint32_t)(point_off[q.second] + k);
+      memcpy(&e.value, &vals[k], 32);
+      evals.push_back(e);
+      eval_values.push_back(vals[k]);
+    }
+  }
+  tr.write_field_elements(eval_values);
+  mkzg_batch_open(c, srs, nv, polys.data(), polys.size(), points.data(), num_points, evals.data(), evals.size(), tr);
+}
+
+}  // namespace lh

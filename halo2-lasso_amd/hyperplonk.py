@@ -166,3 +166,25 @@ class HyperPlonk:
         inst = (C.POINTER(lh_fr) * max(len(instances), 1))(*[C.cast(a, C.POINTER(lh_fr)) for a in inst_arrays])
         wit = _ptr_array(witness_polys)
         _check(ctx.lib.lh_hyperplonk_prove(ctx.h, pp.pcs.h, C.byref(prm), inst, wit, transcript.p))
+
+
+# ------------------------------------------------------------------ the reference's sample circuits
+def _vanilla_gate(base):
+    pi, q_l, q_r, q_m, q_o, q_c = (ex.Polynomial(i) for i in range(6))
+    w_l, w_r, w_o = (ex.Polynomial(base + i) for i in range(3))
+    return q_l * w_l + q_r * w_r + q_m * w_l * w_r + q_o * w_o + q_c + pi
+
+
+def vanilla_plonk_circuit_info(num_vars, num_instances, preprocess_polys, permutations):
+    """backend/hyperplonk/util.rs:30-50: polys pi | q_l q_r q_m q_o q_c | w_l w_r w_o"""
+    return PlonkishCircuitInfo(num_vars, [num_instances], preprocess_polys, [3], [0], [_vanilla_gate(6)], [],
+                               permutations, 4)
+
+
+def vanilla_plonk_with_lookup_circuit_info(num_vars, num_instances, preprocess_polys, permutations):
+    """backend/hyperplonk/util.rs:63-86: polys pi | q_l q_r q_m q_o q_c q_lookup t_l t_r t_o | w_l w_r w_o"""
+    q_lookup, t_l, t_r, t_o = (ex.Polynomial(i) for i in range(6, 10))
+    w_l, w_r, w_o = (ex.Polynomial(i) for i in range(10, 13))
+    lookups = [[(q_lookup * w_l, t_l), (q_lookup * w_r, t_r), (q_lookup * w_o, t_o)]]
+    return PlonkishCircuitInfo(num_vars, [num_instances], preprocess_polys, [3], [0], [_vanilla_gate(10)], lookups,
+                               permutations, 4)

@@ -245,6 +245,41 @@ lh_status lh_ctx_set_comm(lh_ctx*, const lh_comm* comm, size_t shard_bit);
 lh_status lh_lasso_prove_sharded(lh_ctx*, const lh_srs*, const lh_lasso_table*, size_t num_vars,
                                  const uint32_t* const* d_dims, lh_transcript* t);
 
+/* ---------------------------------------------------------------- f1: HyperPlonk with LogUp lookups
+ * HyperPlonk::prove (backend/hyperplonk.rs:164-291) for single-phase circuits: instance hashing and
+ * instance polys (hyperplonk.rs:170-177,365-369), witness commit, lookup_compressed_polys /
+ * lookup_m_polys / lookup_h_polys / permutation_z_polys (backend/hyperplonk/prover.rs:50-313), the
+ * zero-check sum-check over the composed expression (prover.rs:330-386, preprocessor.rs:25-60), the
+ * evaluations in pcs_query order (verifier.rs:147-180) and MultilinearKzg::batch_open.
+ * Poly numbering inside expressions is the reference's: instance | preprocess | witness |
+ * permutation | lookup m | lookup h | permutation z.  Challenge numbering: circuit challenges, then
+ * beta, gamma, alpha. */
+typedef struct lh_hp_lookup {
+  const lh_expr* inputs; /* [width] */
+  const lh_expr* tables; /* [width] */
+  size_t width;
+} lh_hp_lookup;
+typedef struct lh_hp_param { /* HyperPlonkProverParam (hyperplonk.rs:38-55), device-resident */
+  size_t num_vars;
+  size_t num_instance_polys;
+  const size_t* num_instances;             /* [num_instance_polys] */
+  size_t num_preprocess_polys;
+  const void* const* d_preprocess_polys;   /* device lh_fr[2^num_vars] each */
+  size_t num_witness_polys;                /* of the single phase */
+  size_t num_challenges;                   /* squeezed after the witness commitments */
+  size_t num_lookups;
+  const lh_hp_lookup* lookups;
+  size_t num_permutation_polys;
+  const size_t* permutation_poly_index;    /* sorted poly indices under the permutation argument */
+  const void* const* d_permutation_polys;  /* device lh_fr[2^num_vars] each (preprocessor.rs:172-203) */
+  size_t num_permutation_z_polys;
+  lh_expr expression;                      /* compose() output (preprocessor.rs:25-60) */
+} lh_hp_param;
+/* instances[i]: host, num_instances[i] elements.  d_witness_polys: device tables of the phase.
+ * LH_ERR_INVALID_SNARK "Invalid lookup input" if an input row is not in its table (prover.rs:176). */
+lh_status lh_hyperplonk_prove(lh_ctx*, const lh_srs*, const lh_hp_param*, const lh_fr* const* instances,
+                              const lh_fr* const* d_witness_polys, lh_transcript* t);
+
 /* ---------------------------------------------------------------- measurement (bench.py)
  * Per-kernel HIP-event timing on the ctx stream.  While enabled every instrumented launch is
  * synchronised, so whole-prove wall time is NOT representative; use a separate pass. */
