@@ -11,7 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from oracle.pyref import gkr, kzg, lasso, sum_check as sc, expression as ex  # noqa: E402
+from oracle.pyref import gkr, kzg, lasso, sum_check as sc, expression as ex, hyperplonk as hp  # noqa: E402
 from oracle.pyref.field import R_MOD as P  # noqa: E402
 from oracle.pyref.poly import evaluate, eq_xy  # noqa: E402
 from oracle.pyref.transcript import Keccak256Transcript as T  # noqa: E402
@@ -88,6 +88,24 @@ def main():
         proof = t.into_proof()
         lasso.verify(pp, spec, n, T(proof))
         out["lasso"].append({"kind": kind, "c": c_, "l": l, "n": n, "dims": dims, "proof": proof.hex()})
+
+    # HyperPlonk proofs of the reference's sample circuits (own rng: earlier vectors stay unchanged)
+    out["hyperplonk"] = []
+    for nv, with_lookup in ((3, False), (3, True), (4, True)):
+        crng = random.Random(1000 + 2 * nv + with_lookup)
+        gen = hp.rand_vanilla_plonk_with_lookup_circuit if with_lookup else hp.rand_vanilla_plonk_circuit
+        info, instances, witness = gen(nv, crng)
+        hpp = hp.preprocess(pp, info)
+        t = T()
+        hp.prove(hpp, instances, lambda rnd, ch: witness, t)
+        proof = t.into_proof()
+        hp.verify(hpp, instances, T(proof))
+        assert not with_lookup or len(proof) == 1024 + 352 * nv
+        out["hyperplonk"].append({"num_vars": nv, "with_lookup": with_lookup,
+                                  "preprocess_polys": [H(a) for a in info.preprocess_polys],
+                                  "permutations": [[list(c) for c in cyc] for cyc in info.permutations],
+                                  "instances": [H(a) for a in instances], "witness": [H(a) for a in witness],
+                                  "proof": proof.hex()})
 
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "vectors.json"), "w") as f:
         json.dump(out, f, indent=0)

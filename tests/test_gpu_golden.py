@@ -75,3 +75,18 @@ def test_golden_lasso(hl, ctx, pp5, idx):
     t = hl.Keccak256Transcript()
     hl.lasso_prove(pp5, table, g["n"], d_dims, t)
     assert t.into_proof().hex() == g["proof"]
+
+
+@pytest.mark.parametrize("idx", range(3))
+def test_golden_hyperplonk(hl, ctx, pp5, idx):
+    from halo2_lasso_amd import hyperplonk as g_hp
+    g = GOLDEN["hyperplonk"][idx]
+    nv = g["num_vars"]
+    mk = g_hp.vanilla_plonk_with_lookup_circuit_info if g["with_lookup"] else g_hp.vanilla_plonk_circuit_info
+    perms = [[tuple(c) for c in cyc] for cyc in g["permutations"]]
+    info = mk(nv, len(g["instances"][0]), [I(a) for a in g["preprocess_polys"]], perms)
+    pp = g_hp.HyperPlonk.preprocess(pp5, info)
+    t = hl.Keccak256Transcript()
+    g_hp.HyperPlonk.prove(pp, [I(a) for a in g["instances"]],
+                          [hl.MultilinearPolynomial.new(ctx, I(w)) for w in g["witness"]], t)
+    assert t.into_proof().hex() == g["proof"]
