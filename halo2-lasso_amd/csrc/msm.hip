@@ -291,12 +291,21 @@ __global__ __launch_bounds__(256) void msm_window_sum_kernel(MsmPlanDev plan, co
 }
 
 // ------------------------------------------------------------------ host driver
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e && *e ? atoi(e) : dflt;
+}
+// tuning knobs (development): window = floor(log2 n) - LH_MSM_C_OFF capped at LH_MSM_C_MAX; LH_MSM_K = entries per
+// accumulate thread (0: by batch size)
+static const int MSM_C_OFF = env_int("LH_MSM_C_OFF", 3), MSM_C_MAX = env_int("LH_MSM_C_MAX", 16),
+                 MSM_K = env_int("LH_MSM_K", 0), MSM_K2 = env_int("LH_MSM_K2", 8);
+
 static uint32_t pick_window(size_t n, uint32_t bits) {
   uint32_t lg = 0;
   while (((size_t)1 << (lg + 1)) <= n) lg++;
-  int c = (int)lg - 3;
+  int c = (int)lg - MSM_C_OFF;
   if (c < 4) c = 4;
-  if (c > 16) c = 16;
+  if (c > MSM_C_MAX) c = MSM_C_MAX;
   if ((uint32_t)c > bits) c = (int)bits;
   return (uint32_t)c;
 }
@@ -410,7 +419,10 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
       }
 
       // segmented accumulate, level 0 then K-fold shrinking continuation lists
-      uint32_t K = max_entries > ((size_t)1 << 23) ? 32 : max_entries > ((size_t)1 << 21) ? 16 : max_entries > ((size_t)1 << 18) ? 8 : 4;
+      // entries per thread: enough chunks to fill the chip, few enough that the continuation list stays small
+      // (measured: tools/msm_sweep.sh; 2^24 lookups 141 -> 132 ms with K 32 -> 128)
+      uint32_t K = max_entries > ((size_t)1 << 26) ? 128 : max_entries > ((size_t)1 << 25) ? 64 : max_entries > ((size_t)1 << 23) ? 32 : max_entries > ((size_t)1 << 21) ? 16 : max_entries > ((size_t)1 << 18) ? 8 : 4;
+      if (MSM_K > 0) K = (uint32_t)MSM_K;
       size_t nchunks = (max_entries + K - 1) / K;
       uint32_t* ckey = c.arena.alloc_n<uint32_t>(nchunks);
       G1Xyzz* cpt = c.arena.alloc_n<G1Xyzz>(nchunks);
@@ -426,7 +438,7 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
                          dim3(128), 0, c.stream, plan, total, skey, sidx, K, buckets, ckey, cpt, nchunks, lvl_cnt);
       }
       size_t n_in = nchunks;
-      const uint32_t K2 = 8;
+      const uint32_t K2 = (uint32_t)MSM_K2;
       {
         ProfScope ps(c, "msm_accumulate_levels", 0, 0, (double)nchunks);
       int lvl = 0;
