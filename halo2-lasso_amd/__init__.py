@@ -102,6 +102,19 @@ def g1_from_bytes(b):
     return None if x == 0 and y == 0 else (x, y)
 
 
+def g2_to_bytes(pt):
+    """((x0, x1), (y0, y1)) or None -> 128 bytes of a Montgomery `bn256::G2Affine` (x.c0 | x.c1 | y.c0 | y.c1)."""
+    if pt is None:
+        return bytes(128)
+    return b"".join((v % Q_MOD * _MONT % Q_MOD).to_bytes(32, "little") for c in pt for v in c)
+
+
+def g2_from_bytes(b):
+    b = bytes(b)
+    v = [int.from_bytes(b[32 * i:32 * i + 32], "little") * _MONT_INV_Q % Q_MOD for i in range(4)]
+    return None if not any(v) else ((v[0], v[1]), (v[2], v[3]))
+
+
 def _fr_array(xs):
     arr = (lh_fr * max(len(xs), 1))()
     C.memmove(arr, frs_to_bytes(xs), 32 * len(xs))
@@ -190,13 +203,42 @@ def _ptr_array(bufs):
 
 # ------------------------------------------------------------------ transcript
 class Keccak256Transcript:
-    """util::transcript::Keccak256Transcript<Cursor<Vec<u8>>> (write side), living in the library."""
+    """util::transcript::Keccak256Transcript<Cursor<Vec<u8>>> living in the library: `Keccak256Transcript()`
+    writes (InMemoryTranscript::new), `Keccak256Transcript.from_proof(bytes)` reads (transcript.rs:110-123)."""
 
-    def __init__(self):
+    def __init__(self, proof=None):
         self.lib = _ffi.load()
         p = C.POINTER(lh_transcript)()
-        _check(self.lib.lh_keccak_transcript_new(C.byref(p)))
+        if proof is None:
+            _check(self.lib.lh_keccak_transcript_new(C.byref(p)))
+        else:
+            _check(self.lib.lh_keccak_transcript_from_proof(bytes(proof), len(proof), C.byref(p)))
         self.p = p
+
+    @classmethod
+    def from_proof(cls, proof):
+        return cls(proof)
+
+    def read_field_element(self):
+        out = lh_fr()
+        _check(self._vt().read_field_element(self._vt().user, C.byref(out)))
+        return fr_from_bytes(bytes(out))
+
+    def read_field_elements(self, n):
+        return [self.read_field_element() for _ in range(n)]
+
+    def read_commitment(self):
+        out = lh_g1()
+        _check(self._vt().read_commitment(self._vt().user, C.byref(out)))
+        return g1_from_bytes(bytes(out))
+
+    def read_commitments(self, n):
+        return [self.read_commitment() for _ in range(n)]
+
+    def remaining(self):
+        n = C.c_size_t()
+        _check(self.lib.lh_keccak_transcript_remaining(self.p, C.byref(n)))
+        return n.value
 
     def _vt(self):
         return self.p.contents
@@ -474,6 +516,10 @@ class MultilinearKzg:
         raw = C.string_at(out, 64 * len(polys))
         return [g1_from_bytes(raw[64 * i:64 * i + 64]) for i in range(len(polys))]
 
+    verify = staticmethod(lambda vp, comm, point, eval_, transcript: mkzg_verify(vp, comm, point, eval_, transcript))
+    batch_verify = staticmethod(lambda vp, num_vars, comms, points, evals, transcript:
+                                mkzg_batch_verify(vp, num_vars, comms, points, evals, transcript))
+
     @staticmethod
     def batch_commit_and_write(pp, polys, transcript):
         comms = MultilinearKzg.batch_commit(pp, polys)
@@ -489,16 +535,116 @@ class MultilinearKzg:
 
     @staticmethod
     def batch_open(pp, num_vars, polys, points, evals, transcript):
-        evs = (lh_evaluation * max(len(evals), 1))()
-        for i, e in enumerate(evals):
-            evs[i].poly, evs[i].point = e.poly, e.point
-            C.memmove(C.byref(evs[i].value), fr_to_bytes(e.value), 32)
+        evs = _evaluations(evals)
         flat = [v for p in points for v in p]
         for p in points:
             if len(p) != num_vars:
                 raise InvalidPcsParam("Invalid point (expect point to have %d variates but got %d)" % (num_vars, len(p)))
         _check(pp.ctx.lib.lh_mkzg_batch_open(pp.ctx.h, pp.h, num_vars, _ptr_array(polys), len(polys), _fr_array(flat),
                                              len(points), evs, len(evals), transcript.p))
+
+
+class MultilinearKzgVerifierParams:
+    """MultilinearKzgVerifierParams (kzg.rs:79-101): g1, g2, ss[i] = s_i * g2.  Host only."""
+
+    def __init__(self, handle):
+        self.lib, self.h = _ffi.load(), handle
+
+    @classmethod
+    def setup(cls, ss):
+        """the verifier half of MultilinearKzg.setup for the same trapdoor"""
+        h = C.c_void_p()
+        _check(_ffi.load().lh_mkzg_vp_setup(_fr_array(ss), len(ss), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def new(cls, g1, g2, ss):
+        h = C.c_void_p()
+        a, b = _ffi.lh_g1(), _ffi.lh_g2()
+        C.memmove(C.byref(a), g1_to_bytes(g1), 64)
+        C.memmove(C.byref(b), g2_to_bytes(g2), 128)
+        arr = (_ffi.lh_g2 * max(len(ss), 1))()
+        C.memmove(arr, b"".join(g2_to_bytes(p) for p in ss), 128 * len(ss))
+        _check(_ffi.load().lh_mkzg_vp_new(C.byref(a), C.byref(b), arr, len(ss), C.byref(h)))
+        return cls(h)
+
+    @property
+    def num_vars(self):
+        return self.lib.lh_mkzg_vp_num_vars(self.h)
+
+    def export(self):
+        """-> (g1, g2, [ss_i])"""
+        n = self.num_vars
+        a, b, arr = _ffi.lh_g1(), _ffi.lh_g2(), (_ffi.lh_g2 * max(n, 1))()
+        _check(self.lib.lh_mkzg_vp_export(self.h, C.byref(a), C.byref(b), arr))
+        raw = C.string_at(arr, 128 * n)
+        return g1_from_bytes(bytes(a)), g2_from_bytes(bytes(b)), [g2_from_bytes(raw[128 * i:128 * i + 128]) for i in range(n)]
+
+    def free(self):
+        if self.h:
+            self.lib.lh_mkzg_vp_free(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def pairings_product_is_identity(pairs):
+    """util/arithmetic.rs:24-33: pairs of (G1 affine, G2 affine)"""
+    n = len(pairs)
+    ps, qs = (_ffi.lh_g1 * max(n, 1))(), (_ffi.lh_g2 * max(n, 1))()
+    C.memmove(ps, b"".join(g1_to_bytes(p) for p, _ in pairs), 64 * n)
+    C.memmove(qs, b"".join(g2_to_bytes(q) for _, q in pairs), 128 * n)
+    out = C.c_int()
+    _check(_ffi.load().lh_pairing_check(ps, qs, n, C.byref(out)))
+    return bool(out.value)
+
+
+def _evaluations(evals):
+    evs = (lh_evaluation * max(len(evals), 1))()
+    for i, e in enumerate(evals):
+        evs[i].poly, evs[i].point = e.poly, e.point
+        C.memmove(C.byref(evs[i].value), fr_to_bytes(e.value), 32)
+    return evs
+
+
+def _g1_array(pts):
+    arr = (lh_g1 * max(len(pts), 1))()
+    C.memmove(arr, b"".join(g1_to_bytes(p) for p in pts), 64 * len(pts))
+    return arr
+
+
+def mkzg_verify(vp, comm, point, eval_, transcript):
+    """MultilinearKzg::verify (kzg.rs:330-361); raises InvalidPcsOpen"""
+    _check(vp.lib.lh_mkzg_verify(vp.h, _g1_array([comm]), _fr_array(point), len(point), _fr_array([eval_]), transcript.p))
+
+
+def mkzg_batch_verify(vp, num_vars, comms, points, evals, transcript):
+    """additive::batch_verify (pcs/multilinear.rs:237-276)"""
+    for p in points:
+        if len(p) != num_vars:
+            raise InvalidPcsParam("Invalid point (expect point to have %d variates but got %d)" % (num_vars, len(p)))
+    flat = [v for p in points for v in p]
+    _check(vp.lib.lh_mkzg_batch_verify(vp.h, num_vars, _g1_array(comms), len(comms), _fr_array(flat), len(points),
+                                       _evaluations(evals), len(evals), transcript.p))
+
+
+def sum_check_verify(prover, num_vars, degree, sum_, transcript):
+    """ClassicSumCheck::<P>::verify (classic.rs:242-272) -> (final claim, challenges)"""
+    ev, ch = lh_fr(), (lh_fr * max(num_vars, 1))()
+    _check(_ffi.load().lh_sumcheck_verify(prover, num_vars, degree, _fr_array([sum_]), transcript.p, C.byref(ev), ch))
+    return fr_from_bytes(bytes(ev)), _fr_list(ch, num_vars)
+
+
+def lasso_verify(vp, table, num_vars, transcript):
+    """Verifier of the Lasso argument (oracle/pyref/lasso.py:219-261).  A Keccak256Transcript must be fully consumed."""
+    t = table.to_c()
+    _check(vp.lib.lh_lasso_verify(vp.h, C.byref(t), num_vars, transcript.p))
+    if isinstance(transcript, Keccak256Transcript) and transcript.remaining():
+        raise InvalidSnark("trailing bytes in proof")
 
 
 # ------------------------------------------------------------------ Lasso

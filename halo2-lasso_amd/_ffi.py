@@ -57,6 +57,16 @@ class lh_hp_param(C.Structure):
                 ("expression", lh_expr)]
 
 
+class lh_hp_vparam(C.Structure):
+    _fields_ = [("num_vars", C.c_size_t),
+                ("num_instance_polys", C.c_size_t), ("num_instances", C.POINTER(C.c_size_t)),
+                ("num_witness_polys", C.c_size_t), ("num_challenges", C.c_size_t),
+                ("num_lookups", C.c_size_t), ("num_permutation_z_polys", C.c_size_t),
+                ("expression", lh_expr),
+                ("num_preprocess_polys", C.c_size_t), ("preprocess_comms", C.POINTER(lh_g1)),
+                ("num_permutation_polys", C.c_size_t), ("permutation_comms", C.POINTER(lh_g1))]
+
+
 class lh_evaluation(C.Structure):
     _fields_ = [("poly", C.c_uint32), ("point", C.c_uint32), ("value", lh_fr)]
 
@@ -91,7 +101,12 @@ class lh_transcript(C.Structure):
     _fields_ = [("user", C.c_void_p),
                 ("write_field_element", _FE_CB), ("common_field_element", _FE_CB),
                 ("squeeze_challenge", _FE_CB),
-                ("write_commitment", _G1_CB), ("common_commitment", _G1_CB)]
+                ("write_commitment", _G1_CB), ("common_commitment", _G1_CB),
+                ("read_field_element", _FE_CB), ("read_commitment", _G1_CB)]
+
+
+class lh_g2(C.Structure):
+    _fields_ = [("x_c0", C.c_uint64 * 4), ("x_c1", C.c_uint64 * 4), ("y_c0", C.c_uint64 * 4), ("y_c1", C.c_uint64 * 4)]
 
 
 _P = C.c_void_p
@@ -155,6 +170,23 @@ SIGNATURES = {
                                          C.POINTER(lh_transcript)]),
     "lh_hyperplonk_prove": (C.c_int, [_P, _P, C.POINTER(lh_hp_param), C.POINTER(C.POINTER(lh_fr)), C.POINTER(_P),
                                       C.POINTER(lh_transcript)]),
+    "lh_keccak_transcript_from_proof": (C.c_int, [C.c_char_p, _SZ, C.POINTER(C.POINTER(lh_transcript))]),
+    "lh_keccak_transcript_remaining": (C.c_int, [C.POINTER(lh_transcript), C.POINTER(_SZ)]),
+    "lh_mkzg_vp_setup": (C.c_int, [C.POINTER(lh_fr), _SZ, C.POINTER(_P)]),
+    "lh_mkzg_vp_new": (C.c_int, [C.POINTER(lh_g1), C.POINTER(lh_g2), C.POINTER(lh_g2), _SZ, C.POINTER(_P)]),
+    "lh_mkzg_vp_export": (C.c_int, [_P, C.POINTER(lh_g1), C.POINTER(lh_g2), C.POINTER(lh_g2)]),
+    "lh_mkzg_vp_num_vars": (_SZ, [_P]),
+    "lh_mkzg_vp_free": (None, [_P]),
+    "lh_pairing_check": (C.c_int, [C.POINTER(lh_g1), C.POINTER(lh_g2), _SZ, C.POINTER(C.c_int)]),
+    "lh_mkzg_verify": (C.c_int, [_P, C.POINTER(lh_g1), C.POINTER(lh_fr), _SZ, C.POINTER(lh_fr),
+                                 C.POINTER(lh_transcript)]),
+    "lh_mkzg_batch_verify": (C.c_int, [_P, _SZ, C.POINTER(lh_g1), _SZ, C.POINTER(lh_fr), _SZ,
+                                       C.POINTER(lh_evaluation), _SZ, C.POINTER(lh_transcript)]),
+    "lh_sumcheck_verify": (C.c_int, [C.c_int, _SZ, _SZ, C.POINTER(lh_fr), C.POINTER(lh_transcript),
+                                     C.POINTER(lh_fr), C.POINTER(lh_fr)]),
+    "lh_lasso_verify": (C.c_int, [_P, C.POINTER(lh_lasso_table), _SZ, C.POINTER(lh_transcript)]),
+    "lh_hyperplonk_verify": (C.c_int, [_P, C.POINTER(lh_hp_vparam), C.POINTER(C.POINTER(lh_fr)),
+                                       C.POINTER(lh_transcript)]),
     "lh_profile_enable": (C.c_int, [_P, C.c_int]),
     "lh_profile_read": (C.c_int, [_P, C.POINTER(lh_prof_rec), _SZ, C.POINTER(_SZ)]),
 }

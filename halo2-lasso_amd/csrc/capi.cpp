@@ -9,6 +9,9 @@ struct lh_ctx {
 struct lh_srs {
   Srs s;
 };
+struct lh_mkzg_vp {
+  VerifierParams* p;
+};
 
 #define LH_TRY try {
 #define LH_CATCH                                  \
@@ -126,6 +129,23 @@ lh_status lh_keccak_transcript_proof(lh_transcript* t, const uint8_t** bytes, si
   KeccakTranscript* k = (KeccakTranscript*)t->user;
   *bytes = k->stream.data();
   *len = k->stream.size();
+  LH_CATCH
+}
+lh_status lh_keccak_transcript_from_proof(const uint8_t* proof, size_t len, lh_transcript** out) {
+  LH_TRY
+  NEED(out);
+  LH_REQUIRE(proof || !len, LH_ERR_ARG, "null argument: proof");
+  KeccakTranscript* t = new KeccakTranscript();
+  t->stream.assign(proof, proof + len);
+  *out = &t->vt;
+  LH_CATCH
+}
+lh_status lh_keccak_transcript_remaining(lh_transcript* t, size_t* out) {
+  LH_TRY
+  NEED(t);
+  NEED(out);
+  KeccakTranscript* k = (KeccakTranscript*)t->user;
+  *out = k->stream.size() - k->pos;
   LH_CATCH
 }
 
@@ -422,6 +442,100 @@ lh_status lh_hyperplonk_prove(lh_ctx* ctx, const lh_srs* srs, const lh_hp_param*
   NEED(pp);
   Transcript tr(t);
   hyperplonk_prove(ctx->c, srs->s, *pp, (const HFr* const*)instances, (const Fr* const*)d_witness_polys, tr);
+  LH_CATCH
+}
+
+// ---------------------------------------------------------------- verifiers (host only)
+lh_status lh_mkzg_vp_setup(const lh_fr* ss, size_t num_vars, lh_mkzg_vp** out) {
+  LH_TRY
+  NEED(out);
+  LH_REQUIRE(ss || !num_vars, LH_ERR_ARG, "null argument: ss");
+  *out = new lh_mkzg_vp{mkzg_vp_setup((const HFr*)ss, num_vars)};
+  LH_CATCH
+}
+lh_status lh_mkzg_vp_new(const lh_g1* g1, const lh_g2* g2, const lh_g2* ss, size_t num_vars, lh_mkzg_vp** out) {
+  LH_TRY
+  NEED(out);
+  NEED(g1);
+  NEED(g2);
+  LH_REQUIRE(ss || !num_vars, LH_ERR_ARG, "null argument: ss");
+  *out = new lh_mkzg_vp{mkzg_vp_new(*g1, *g2, ss, num_vars)};
+  LH_CATCH
+}
+lh_status lh_mkzg_vp_export(const lh_mkzg_vp* vp, lh_g1* g1, lh_g2* g2, lh_g2* ss) {
+  LH_TRY
+  NEED(vp);
+  mkzg_vp_export(*vp->p, g1, g2, ss);
+  LH_CATCH
+}
+size_t lh_mkzg_vp_num_vars(const lh_mkzg_vp* vp) { return vp ? mkzg_vp_num_vars(*vp->p) : 0; }
+void lh_mkzg_vp_free(lh_mkzg_vp* vp) {
+  if (!vp) return;
+  mkzg_vp_free(vp->p);
+  delete vp;
+}
+lh_status lh_pairing_check(const lh_g1* ps, const lh_g2* qs, size_t n, int* out_is_identity) {
+  LH_TRY
+  NEED(out_is_identity);
+  LH_REQUIRE((ps && qs) || !n, LH_ERR_ARG, "null argument: points");
+  *out_is_identity = pairing_check(ps, qs, n) ? 1 : 0;
+  LH_CATCH
+}
+lh_status lh_mkzg_verify(const lh_mkzg_vp* vp, const lh_g1* comm, const lh_fr* point, size_t num_vars,
+                         const lh_fr* eval, lh_transcript* t) {
+  LH_TRY
+  NEED(vp);
+  NEED(comm);
+  NEED(eval);
+  LH_REQUIRE(point || !num_vars, LH_ERR_ARG, "null argument: point");
+  Transcript tr(t);
+  HG1 c;
+  memcpy(&c, comm, sizeof(c));
+  HFr e;
+  memcpy(&e, eval, 32);
+  mkzg_verify(*vp->p, c, (const HFr*)point, num_vars, e, tr);
+  LH_CATCH
+}
+lh_status lh_mkzg_batch_verify(const lh_mkzg_vp* vp, size_t num_vars, const lh_g1* comms, size_t num_comms,
+                               const lh_fr* points, size_t num_points, const lh_evaluation* evals, size_t num_evals,
+                               lh_transcript* t) {
+  LH_TRY
+  NEED(vp);
+  NEED(comms);
+  NEED(points);
+  NEED(evals);
+  Transcript tr(t);
+  mkzg_batch_verify(*vp->p, num_vars, (const HG1*)comms, num_comms, (const HFr*)points, num_points, evals, num_evals,
+                    tr);
+  LH_CATCH
+}
+lh_status lh_sumcheck_verify(int prover_kind, size_t num_vars, size_t degree, const lh_fr* sum, lh_transcript* t,
+                             lh_fr* out_eval, lh_fr* out_x) {
+  LH_TRY
+  NEED(sum);
+  Transcript tr(t);
+  HFr s;
+  memcpy(&s, sum, 32);
+  auto res = sum_check_verify(prover_kind, num_vars, degree, s, tr);
+  if (out_eval) memcpy(out_eval, &res.first, 32);
+  if (out_x) memcpy(out_x, res.second.data(), 32 * res.second.size());
+  LH_CATCH
+}
+lh_status lh_lasso_verify(const lh_mkzg_vp* vp, const lh_lasso_table* table, size_t num_vars, lh_transcript* t) {
+  LH_TRY
+  NEED(vp);
+  NEED(table);
+  Transcript tr(t);
+  lasso_verify(*vp->p, *table, num_vars, tr);
+  LH_CATCH
+}
+lh_status lh_hyperplonk_verify(const lh_mkzg_vp* vp, const lh_hp_vparam* hvp, const lh_fr* const* instances,
+                               lh_transcript* t) {
+  LH_TRY
+  NEED(vp);
+  NEED(hvp);
+  Transcript tr(t);
+  hyperplonk_verify(*vp->p, *hvp, (const HFr* const*)instances, tr);
   LH_CATCH
 }
 

@@ -25,4 +25,8 @@ uint32_t bh_x_inv(size_t num_vars);
 size_t bh_next(size_t b, size_t num_vars);
 size_t bh_nth(size_t num_vars, size_t i);
 
+// rotation helpers of poly/multilinear.rs:477-549 (hyperplonk.cpp)
+std::vector<size_t> rotation_point_pattern(bool next, size_t num_vars, size_t distance);
+std::vector<std::vector<HFr>> rotation_eval_points(const std::vector<HFr>& x, int rotation);
+
 }  // namespace lh

@@ -40,6 +40,7 @@ struct KeccakTranscript {
   lh_transcript vt;  // must stay the first member: lh_transcript* <-> KeccakTranscript*
   Keccak256 hash;
   std::vector<uint8_t> stream;
+  size_t pos = 0;  // read cursor (from_proof transcripts)
   KeccakTranscript();
 };
 
@@ -72,6 +73,30 @@ struct Transcript {
   void write_commitment(const HG1& p) { check(t->write_commitment(t->user, (const lh_g1*)&p)); }
   void write_commitments(const std::vector<HG1>& ps) {
     for (auto& p : ps) write_commitment(p);
+  }
+  void common_commitment(const HG1& p) { check(t->common_commitment(t->user, (const lh_g1*)&p)); }
+  // TranscriptRead (util/transcript.rs:45-97)
+  HFr read_field_element() {
+    LH_REQUIRE(t->read_field_element, LH_ERR_ARG, "transcript cannot read (write-only callback table)");
+    HFr f;
+    check(t->read_field_element(t->user, (lh_fr*)&f));
+    return f;
+  }
+  std::vector<HFr> read_field_elements(size_t n) {
+    std::vector<HFr> v(n);
+    for (auto& f : v) f = read_field_element();
+    return v;
+  }
+  HG1 read_commitment() {
+    LH_REQUIRE(t->read_commitment, LH_ERR_ARG, "transcript cannot read (write-only callback table)");
+    HG1 p;
+    check(t->read_commitment(t->user, (lh_g1*)&p));
+    return p;
+  }
+  std::vector<HG1> read_commitments(size_t n) {
+    std::vector<HG1> v(n);
+    for (auto& p : v) p = read_commitment();
+    return v;
   }
 };
 
@@ -148,6 +173,26 @@ void lasso_prove(Ctx&, const Srs&, const lh_lasso_table& table, size_t num_vars,
                  Transcript& tr);
 void lasso_prove_sharded(Ctx&, const Srs&, const lh_lasso_table& table, size_t num_vars,
                          const uint32_t* const* d_dims, Transcript& tr);
+
+// ------------------------------------------------------------------ verifiers (verifier.cpp; host only)
+HFr interpolate_evals(const std::vector<HFr>& evals, const HFr& x);  // barycentric over 0..d (arithmetic.rs:108-136)
+HFr horner(const std::vector<HFr>& coeffs, const HFr& x);
+struct VerifierParams;  // MultilinearKzgVerifierParams (kzg.rs:79-101)
+VerifierParams* mkzg_vp_setup(const HFr* ss, size_t num_vars);
+VerifierParams* mkzg_vp_new(const lh_g1& g1, const lh_g2& g2, const lh_g2* ss, size_t num_vars);
+void mkzg_vp_export(const VerifierParams&, lh_g1* g1, lh_g2* g2, lh_g2* ss);
+size_t mkzg_vp_num_vars(const VerifierParams&);
+void mkzg_vp_free(VerifierParams*);
+bool pairing_check(const lh_g1* ps, const lh_g2* qs, size_t n);
+void mkzg_verify(const VerifierParams&, const HG1& comm, const HFr* point, size_t num_vars, const HFr& eval,
+                 Transcript& tr);
+void mkzg_batch_verify(const VerifierParams&, size_t num_vars, const HG1* comms, size_t num_comms, const HFr* points,
+                       size_t num_points, const lh_evaluation* evals, size_t num_evals, Transcript& tr);
+// -> (final claim, challenges)
+std::pair<HFr, std::vector<HFr>> sum_check_verify(int prover_kind, size_t num_vars, size_t degree, const HFr& sum,
+                                                  Transcript& tr);
+void lasso_verify(const VerifierParams&, const lh_lasso_table& table, size_t num_vars, Transcript& tr);
+void hyperplonk_verify(const VerifierParams&, const lh_hp_vparam& vp, const HFr* const* instances, Transcript& tr);
 
 // ------------------------------------------------------------------ HyperPlonk (hyperplonk.cpp)
 void hyperplonk_prove(Ctx&, const Srs&, const lh_hp_param& pp, const HFr* const* instances,

@@ -10,7 +10,7 @@
 namespace lh {
 
 // ------------------------------------------------------------------ rotation points (poly/multilinear.rs:477-549)
-static std::vector<size_t> point_pattern(bool next, size_t num_vars, size_t distance) {
+std::vector<size_t> rotation_point_pattern(bool next, size_t num_vars, size_t distance) {
   const size_t rem = next ? bh_primitive(num_vars) : bh_x_inv(num_vars);
   std::vector<size_t> pat((size_t)1 << distance, 0);
   for (size_t depth = 0; depth < distance; depth++) {
@@ -25,21 +25,21 @@ static std::vector<size_t> point_pattern(bool next, size_t num_vars, size_t dist
   return pat;
 }
 
-static std::vector<std::vector<HFr>> rotation_eval_points(const std::vector<HFr>& x, int rotation) {
+std::vector<std::vector<HFr>> rotation_eval_points(const std::vector<HFr>& x, int rotation) {
   if (rotation == 0) return {x};
   const size_t n = x.size(), distance = (size_t)std::abs(rotation), num_x = n - distance;
   std::vector<std::vector<HFr>> out;
   const HFr one = HFr::one(), zero = HFr::zero();
   auto bit = [](size_t p, size_t i) { return (p >> i) & 1; };
   if (rotation < 0) {
-    for (size_t p : point_pattern(false, n, distance)) {
+    for (size_t p : rotation_point_pattern(false, n, distance)) {
       std::vector<HFr> pt;
       for (size_t i = 0; i < num_x; i++) pt.push_back(bit(p, i) ? one - x[distance + i] : x[distance + i]);
       for (size_t i = 0; i < distance; i++) pt.push_back(bit(p, i + num_x) ? one : zero);
       out.push_back(pt);
     }
   } else {
-    for (size_t p : point_pattern(true, n, distance)) {
+    for (size_t p : rotation_point_pattern(true, n, distance)) {
       std::vector<HFr> pt;
       for (size_t i = 0; i < distance; i++) pt.push_back(bit(p, i) ? one : zero);
       for (size_t i = 0; i < num_x; i++) pt.push_back(bit(p, i + distance) ? one - x[i] : x[i]);

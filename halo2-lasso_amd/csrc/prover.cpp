@@ -59,7 +59,7 @@ static const std::vector<HFr>& lagrange_weights(size_t d) {
   return w;
 }
 
-static HFr interpolate_evals(const std::vector<HFr>& evals, const HFr& x) {
+HFr interpolate_evals(const std::vector<HFr>& evals, const HFr& x) {
   const size_t d = evals.size() - 1;
   const std::vector<HFr>& w = lagrange_weights(d);
   // prefix[j] = prod_{i<j} (x - i), suffix[j] = prod_{i>j} (x - i); x in {0..d} is covered as well
@@ -74,7 +74,7 @@ static HFr interpolate_evals(const std::vector<HFr>& evals, const HFr& x) {
   return total;
 }
 
-static HFr horner(const std::vector<HFr>& coeffs, const HFr& x) {
+HFr horner(const std::vector<HFr>& coeffs, const HFr& x) {
   HFr acc = HFr::zero();
   for (size_t i = coeffs.size(); i-- > 0;) acc = acc * x + coeffs[i];
   return acc;

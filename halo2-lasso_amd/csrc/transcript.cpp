@@ -124,6 +124,47 @@ static int kt_write_comm(void* u, const lh_g1* pt) {
   return LH_OK;
 }
 
+// TranscriptRead: the stream holds byte-reversed reprs; a value >= the modulus or a point off the curve is
+// rejected (from_repr_vartime / CurveAffine::from_xy, transcript.rs:138-154,185-210)
+enum ReadStatus { READ_OK, READ_EOF, READ_BAD };
+template <class F>
+static ReadStatus read_repr(KeccakTranscript* t, F* out) {
+  if (t->stream.size() - t->pos < 32) return READ_EOF;
+  uint64_t c[4];
+  uint8_t repr[32];
+  for (int i = 0; i < 32; i++) repr[i] = t->stream[t->pos + 31 - i];
+  t->pos += 32;
+  memcpy(c, repr, 32);
+  if (F::geq_mod(c)) return READ_BAD;
+  *out = F::from_canonical(c);
+  return READ_OK;
+}
+static int read_failed(ReadStatus st, const char* what) {
+  set_last_error(st == READ_EOF ? "failed to fill whole buffer" : what);  // read_exact's UnexpectedEof text
+  return LH_ERR_TRANSCRIPT;
+}
+static int kt_read_fe(void* u, lh_fr* out) {
+  auto* t = (KeccakTranscript*)u;
+  host::Fr f;
+  ReadStatus st = read_repr(t, &f);
+  if (st != READ_OK) return read_failed(st, "Invalid field element encoding in proof");
+  memcpy(out, &f, 32);
+  return kt_common_fe(u, out);
+}
+static int kt_read_comm(void* u, lh_g1* out) {
+  auto* t = (KeccakTranscript*)u;
+  host::G1Affine p;
+  ReadStatus sx = read_repr(t, &p.x);
+  if (sx == READ_EOF) return read_failed(sx, "");
+  ReadStatus sy = read_repr(t, &p.y);
+  if (sy == READ_EOF) return read_failed(sy, "");
+  // on the curve y^2 = x^3 + 3 (the identity has no affine coordinates and cannot be encoded)
+  if (sx != READ_OK || sy != READ_OK || !(p.y.sqr() == p.x.sqr() * p.x + host::Fq::from_u64(3)))
+    return read_failed(READ_BAD, "Invalid elliptic curve point encoding in proof");
+  memcpy(out, &p, 64);
+  return kt_common_comm(u, out);
+}
+
 KeccakTranscript::KeccakTranscript() {
   vt.user = this;
   vt.write_field_element = kt_write_fe;
@@ -131,6 +172,8 @@ KeccakTranscript::KeccakTranscript() {
   vt.squeeze_challenge = kt_squeeze;
   vt.write_commitment = kt_write_comm;
   vt.common_commitment = kt_common_comm;
+  vt.read_field_element = kt_read_fe;
+  vt.read_commitment = kt_read_comm;
 }
 
 }  // namespace lh

@@ -106,10 +106,15 @@ class HyperPlonkProverParam:
     """hyperplonk.rs:38-55"""
 
 
+class HyperPlonkVerifierParam:
+    """hyperplonk.rs:57-74"""
+
+
 class HyperPlonk:
     @staticmethod
-    def preprocess(pcs_pp, info):
-        """hyperplonk.rs:97-162 (prover half): preprocess / permutation polys go to the GPU once."""
+    def preprocess(pcs_pp, info, pcs_vp=None):
+        """hyperplonk.rs:97-162: preprocess / permutation polys go to the GPU once.  Returns the prover param, or
+        (pp, vp) when the PCS verifier param is given."""
         from . import MultilinearPolynomial, MultilinearKzg
         ctx = pcs_pp.ctx
         pp = HyperPlonkProverParam()
@@ -120,7 +125,13 @@ class HyperPlonk:
         pp.permutation_polys = [MultilinearPolynomial.new(ctx, p) for p in perm]
         pp.permutation_comms = MultilinearKzg.batch_commit(pcs_pp, pp.permutation_polys)
         pp.num_permutation_z_polys, pp.expression = compose(info)
-        return pp
+        if pcs_vp is None:
+            return pp
+        vp = HyperPlonkVerifierParam()
+        vp.pcs, vp.num_vars, vp.info = pcs_vp, info.k, info
+        vp.num_permutation_z_polys, vp.expression = pp.num_permutation_z_polys, pp.expression
+        vp.preprocess_comms, vp.permutation_comms = list(pp.preprocess_comms), list(pp.permutation_comms)
+        return pp, vp
 
     @staticmethod
     def prove(pp, instances, witness_polys, transcript):
@@ -166,6 +177,31 @@ class HyperPlonk:
         inst = (C.POINTER(lh_fr) * max(len(instances), 1))(*[C.cast(a, C.POINTER(lh_fr)) for a in inst_arrays])
         wit = _ptr_array(witness_polys)
         _check(ctx.lib.lh_hyperplonk_prove(ctx.h, pp.pcs.h, C.byref(prm), inst, wit, transcript.p))
+
+    @staticmethod
+    def verify(vp, instances, transcript):
+        """hyperplonk.rs:293-362 (host only).  Raises InvalidSumcheck / InvalidSnark / InvalidPcsOpen."""
+        from . import _check, _fr_array, _g1_array, lh_fr
+        info = vp.info
+        if len(info.num_witness_polys) != 1:
+            raise NotImplementedError("multi-phase circuits")
+        if [len(i) for i in instances] != list(info.num_instances):
+            raise AssertionError("instances do not match num_instances")  # assert_eq! hyperplonk.rs:300
+        prm = _ffi.lh_hp_vparam()
+        prm.num_vars = vp.num_vars
+        prm.num_instance_polys = len(info.num_instances)
+        ni = (C.c_size_t * max(len(info.num_instances), 1))(*info.num_instances)
+        prm.num_instances = ni
+        prm.num_witness_polys, prm.num_challenges = info.num_witness_polys[0], info.num_challenges[0]
+        prm.num_lookups, prm.num_permutation_z_polys = len(info.lookups), vp.num_permutation_z_polys
+        ce, knodes = vp.expression.to_c()
+        prm.expression = ce
+        pre, perm = _g1_array(vp.preprocess_comms), _g1_array(vp.permutation_comms)
+        prm.num_preprocess_polys, prm.preprocess_comms = len(vp.preprocess_comms), pre
+        prm.num_permutation_polys, prm.permutation_comms = len(vp.permutation_comms), perm
+        inst_arrays = [_fr_array(i) for i in instances]
+        inst = (C.POINTER(lh_fr) * max(len(instances), 1))(*[C.cast(a, C.POINTER(lh_fr)) for a in inst_arrays])
+        _check(vp.pcs.lib.lh_hyperplonk_verify(vp.pcs.h, C.byref(prm), inst, transcript.p))
 
 
 # ------------------------------------------------------------------ the reference's sample circuits

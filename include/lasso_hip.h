@@ -69,6 +69,9 @@ typedef struct lh_transcript {
   int (*squeeze_challenge)(void* user, lh_fr* out);          /* transcript.rs:126-131 */
   int (*write_commitment)(void* user, const lh_g1* pt);     /* transcript.rs:213-226 */
   int (*common_commitment)(void* user, const lh_g1* pt);    /* transcript.rs:170-183 */
+  /* TranscriptRead half (verifiers only; may be NULL on a write-only transcript) */
+  int (*read_field_element)(void* user, lh_fr* out);         /* transcript.rs:138-154 */
+  int (*read_commitment)(void* user, lh_g1* out);            /* transcript.rs:185-210 */
 } lh_transcript;
 
 /* Built-in Keccak256Transcript<Cursor<Vec<u8>>> (transcript.rs:99-121) */
@@ -76,6 +79,10 @@ lh_status lh_keccak_transcript_new(lh_transcript** out);
 void lh_keccak_transcript_free(lh_transcript* t);
 /* InMemoryTranscript::into_proof (transcript.rs:110-112): pointer valid until the next write */
 lh_status lh_keccak_transcript_proof(lh_transcript* t, const uint8_t** bytes, size_t* len);
+/* InMemoryTranscript::from_proof (transcript.rs:114-123): a reading transcript over a copy of `proof` */
+lh_status lh_keccak_transcript_from_proof(const uint8_t* proof, size_t len, lh_transcript** out);
+/* bytes of the proof not yet read */
+lh_status lh_keccak_transcript_remaining(lh_transcript* t, size_t* out);
 
 /* ---------------------------------------------------------------- a1: Fr arithmetic
  * halo2_curves bn256::Fr ops (via util/arithmetic.rs:15-22) over device vectors. */
@@ -279,6 +286,50 @@ typedef struct lh_hp_param { /* HyperPlonkProverParam (hyperplonk.rs:38-55), dev
  * LH_ERR_INVALID_SNARK "Invalid lookup input" if an input row is not in its table (prover.rs:176). */
 lh_status lh_hyperplonk_prove(lh_ctx*, const lh_srs*, const lh_hp_param*, const lh_fr* const* instances,
                               const lh_fr* const* d_witness_polys, lh_transcript* t);
+
+/* ---------------------------------------------------------------- f1: verifiers (host only, no GPU, no lh_ctx)
+ * The verify half of the trait surface: PolynomialCommitmentScheme::{verify, batch_verify}
+ * (pcs/multilinear/kzg.rs:330-375, pcs/multilinear.rs:237-276), SumCheck::verify (classic.rs:242-272),
+ * PlonkishBackend::verify (backend/hyperplonk.rs:293-362, hyperplonk/verifier.rs:39-182), and the verifier
+ * of the Lasso argument specified in oracle/pyref/lasso.py.  Pairings: BN254 optimal ate
+ * (MultiMillerLoop::pairings_product_is_identity, util/arithmetic.rs:24-33). */
+typedef struct lh_g2 { uint64_t x_c0[4], x_c1[4], y_c0[4], y_c1[4]; } lh_g2; /* bn256::G2Affine, Montgomery; identity = 0 */
+typedef struct lh_mkzg_vp lh_mkzg_vp; /* MultilinearKzgVerifierParams (kzg.rs:79-101): g1, g2, ss[i] = s_i * g2 */
+/* the verifier half of lh_mkzg_setup: same trapdoor, generators (1,2) and the bn256 G2 generator */
+lh_status lh_mkzg_vp_setup(const lh_fr* ss, size_t num_vars, lh_mkzg_vp** out);
+lh_status lh_mkzg_vp_new(const lh_g1* g1, const lh_g2* g2, const lh_g2* ss, size_t num_vars, lh_mkzg_vp** out);
+lh_status lh_mkzg_vp_export(const lh_mkzg_vp*, lh_g1* g1, lh_g2* g2, lh_g2* ss);
+size_t lh_mkzg_vp_num_vars(const lh_mkzg_vp*);
+void lh_mkzg_vp_free(lh_mkzg_vp*);
+/* e(p_i, q_i) product == 1 */
+lh_status lh_pairing_check(const lh_g1* ps, const lh_g2* qs, size_t n, int* out_is_identity);
+/* LH_ERR_INVALID_PCS_OPEN "Invalid multilinear KZG open" on a failed check */
+lh_status lh_mkzg_verify(const lh_mkzg_vp*, const lh_g1* comm, const lh_fr* point, size_t num_vars,
+                         const lh_fr* eval, lh_transcript* t);
+lh_status lh_mkzg_batch_verify(const lh_mkzg_vp*, size_t num_vars, const lh_g1* comms, size_t num_comms,
+                               const lh_fr* points, size_t num_points, const lh_evaluation* evals,
+                               size_t num_evals, lh_transcript* t);
+/* prover_kind selects the round-message type (Evaluations / Coefficients).  Outputs the final claim and
+ * the challenges x[num_vars]; LH_ERR_INVALID_SUMCHECK on an inconsistent round. */
+lh_status lh_sumcheck_verify(int prover_kind, size_t num_vars, size_t degree, const lh_fr* sum,
+                             lh_transcript* t, lh_fr* out_eval, lh_fr* out_x);
+lh_status lh_lasso_verify(const lh_mkzg_vp*, const lh_lasso_table*, size_t num_vars, lh_transcript* t);
+typedef struct lh_hp_vparam { /* HyperPlonkVerifierParam (hyperplonk.rs:57-74) */
+  size_t num_vars;
+  size_t num_instance_polys;
+  const size_t* num_instances;
+  size_t num_witness_polys;
+  size_t num_challenges;
+  size_t num_lookups;
+  size_t num_permutation_z_polys;
+  lh_expr expression;
+  size_t num_preprocess_polys;
+  const lh_g1* preprocess_comms;
+  size_t num_permutation_polys;
+  const lh_g1* permutation_comms;
+} lh_hp_vparam;
+lh_status lh_hyperplonk_verify(const lh_mkzg_vp*, const lh_hp_vparam*, const lh_fr* const* instances,
+                               lh_transcript* t);
 
 /* ---------------------------------------------------------------- measurement (bench.py)
  * Per-kernel HIP-event timing on the ctx stream.  While enabled every instrumented launch is

@@ -31,7 +31,8 @@ def test_struct_layouts(hl):
     assert C.sizeof(_ffi.lh_sop) == 8 + 32 * 48 + 48 + 48 * 4
     assert C.sizeof(_ffi.lh_lasso_table) == 12 + 64 + 64 + 4 + 32 * 16 + 16 + 16 * 4 + 0 \
         or C.sizeof(_ffi.lh_lasso_table) % 8 == 0
-    assert C.sizeof(_ffi.lh_transcript) == 6 * C.sizeof(C.c_void_p)
+    assert C.sizeof(_ffi.lh_transcript) == 8 * C.sizeof(C.c_void_p)
+    assert C.sizeof(_ffi.lh_g2) == 128
 
 
 def test_marshalling(hl):

@@ -1,0 +1,206 @@
+"""CPU: the product's verifiers (host code in liblasso_hip.so, no GPU) against the oracle and the golden proofs.
+
+* BN254 pairing: the C++ tower implementation vs the oracle's flat-extension implementation
+  (oracle/pyref/pairing.py) through `pairings_product_is_identity` (util/arithmetic.rs:24-33), bilinearity.
+* TranscriptRead: reference error behaviour (transcript.rs:138-154,185-210).
+* MultilinearKzg::{verify, batch_verify}, Lasso verify, HyperPlonk::verify: accept the committed golden proofs
+  (tests/golden/vectors.json), reject tampered ones with the reference's error kinds.
+"""
+import json
+import os
+import random
+
+import pytest
+
+from oracle.pyref import curve, kzg as o_kzg, pairing as o_pair
+from oracle.pyref.field import R_MOD as P, Q_MOD
+from oracle.pyref.poly import evaluate
+from oracle.pyref.transcript import Keccak256Transcript as OT
+
+GOLDEN = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "vectors.json")))
+I = lambda xs: [int(x, 16) for x in xs]
+SS = I(GOLDEN["srs"]["ss"])
+
+
+@pytest.fixture(scope="module")
+def vp5(hl):
+    return hl.MultilinearKzgVerifierParams.setup(SS)
+
+
+# ------------------------------------------------------------------ pairing
+def test_verifier_params_match_oracle_g2(hl, vp5):
+    g1, g2, ss = vp5.export()
+    assert g1 == curve.G1_GEN and g2 == o_pair.G2_GEN
+    assert ss[0] == o_pair.g2_mul(o_pair.G2_GEN, SS[0]) and ss[4] == o_pair.g2_mul(o_pair.G2_GEN, SS[4])
+    again = hl.MultilinearKzgVerifierParams.new(g1, g2, ss)
+    assert again.export() == (g1, g2, ss) and again.num_vars == 5
+    with pytest.raises(hl.Error):
+        hl.MultilinearKzgVerifierParams.new(g1, ((1, 2), (3, 4)), ss)  # not on the twist
+
+
+def test_pairing_product_bilinear(hl):
+    rng = random.Random(5)
+    a, b = rng.randrange(P), rng.randrange(P)
+    g1, g2 = curve.G1_GEN, o_pair.G2_GEN
+    ag1, bg2 = curve.mul(g1, a), o_pair.g2_mul(g2, b)
+    abg1 = curve.mul(g1, a * b % P)
+    cases = [([(ag1, bg2), (curve.neg(abg1), g2)], True),
+             ([(ag1, bg2), (curve.neg(ag1), bg2)], True),
+             ([(ag1, bg2), (curve.neg(abg1), bg2)], False),
+             ([(g1, g2)], False),
+             ([(None, g2), (g1, None)], True),
+             ([], True)]
+    for pairs, want in cases:
+        assert hl.pairings_product_is_identity(pairs) is want
+    # the oracle's independent implementation agrees on the non-trivial ones
+    assert o_pair.pairings_product_is_identity(cases[0][0]) and not o_pair.pairings_product_is_identity(cases[2][0])
+
+
+# ------------------------------------------------------------------ TranscriptRead
+def test_transcript_read_side(hl):
+    w = hl.Keccak256Transcript()
+    w.write_field_element(5)
+    w.write_commitment((1, 2))
+    c_w = w.squeeze_challenge()
+    proof = w.into_proof()
+    r = hl.Keccak256Transcript.from_proof(proof)
+    assert r.remaining() == 96
+    assert r.read_field_element() == 5 and r.read_commitment() == (1, 2)
+    assert r.squeeze_challenge() == c_w and r.remaining() == 0
+    with pytest.raises(hl.TranscriptError):  # read_exact past the end
+        r.read_field_element()
+    # non-canonical field element / point off the curve (transcript.rs:146-151,199-206)
+    bad_fe = (P).to_bytes(32, "big")
+    with pytest.raises(hl.TranscriptError, match="Invalid field element encoding in proof"):
+        hl.Keccak256Transcript.from_proof(bad_fe).read_field_element()
+    bad_pt = (1).to_bytes(32, "big") + (3).to_bytes(32, "big")
+    with pytest.raises(hl.TranscriptError, match="Invalid elliptic curve point encoding in proof"):
+        hl.Keccak256Transcript.from_proof(bad_pt).read_commitment()
+    with pytest.raises(hl.TranscriptError, match="Invalid elliptic curve point encoding in proof"):
+        hl.Keccak256Transcript.from_proof(bytes(64)).read_commitment()  # (0, 0)
+    with pytest.raises(hl.TranscriptError, match="Invalid elliptic curve point encoding in proof"):
+        hl.Keccak256Transcript.from_proof((Q_MOD).to_bytes(32, "big") + (2).to_bytes(32, "big")).read_commitment()
+
+
+# ------------------------------------------------------------------ sum-check verify
+@pytest.mark.parametrize("name,kind,degree", [("sum_check_eval", "eval", 3), ("sum_check_coeff", "coeff", 2)])
+def test_sum_check_verify_golden(hl, name, kind, degree):
+    from oracle.pyref import sum_check as o_sc
+    g = GOLDEN[name]
+    nv, claim, proof = g["num_vars"], int(g["claim"], 16), bytes.fromhex(g["proof"])
+    o_cls, g_kind = (o_sc.Evaluations, hl.LH_SC_EVALUATIONS) if kind == "eval" else (o_sc.Coefficients, hl.LH_SC_COEFFICIENTS)
+    want = o_sc.verify(o_cls, nv, degree, claim, OT(proof))
+    got = hl.sum_check_verify(g_kind, nv, degree, claim, hl.Keccak256Transcript.from_proof(proof))
+    assert got == want and got[1] == I(g["x"])
+    with pytest.raises(hl.InvalidSumcheck):
+        hl.sum_check_verify(g_kind, nv, degree, (claim + 1) % P, hl.Keccak256Transcript.from_proof(proof))
+    bad = bytearray(proof)
+    bad[32 * (degree + 1) + 7] ^= 1  # second round message
+    with pytest.raises(hl.InvalidSumcheck, match="Consistency failure at round 1"):
+        hl.sum_check_verify(g_kind, nv, degree, claim, hl.Keccak256Transcript.from_proof(bytes(bad)))
+
+
+# ------------------------------------------------------------------ MultilinearKzg verify
+def test_mkzg_open_verify_round_trip(hl, vp5):
+    """commit/open by the oracle (CPU), verify by the product's pairing check (pcs/multilinear.rs:321-331 shape)"""
+    rng = random.Random(11)
+    pp = o_kzg.setup(SS)
+    for nv in (1, 3, 5):
+        poly = [rng.randrange(P) for _ in range(1 << nv)]
+        point = [rng.randrange(P) for _ in range(nv)]
+        comm = o_kzg.commit(pp.trim(nv), poly)
+        t = OT()
+        o_kzg.open_(pp.trim(nv), poly, point, t)
+        proof, ev = t.into_proof(), evaluate(poly, point)
+        hl.mkzg_verify(vp5, comm, point, ev, hl.Keccak256Transcript.from_proof(proof))
+        with pytest.raises(hl.InvalidPcsOpen, match="Invalid multilinear KZG open"):
+            hl.mkzg_verify(vp5, comm, point, (ev + 1) % P, hl.Keccak256Transcript.from_proof(proof))
+        with pytest.raises(hl.InvalidPcsOpen):
+            hl.mkzg_verify(vp5, curve.add(comm, curve.G1_GEN), point, ev, hl.Keccak256Transcript.from_proof(proof))
+    with pytest.raises(hl.InvalidPcsParam, match="Too many variates"):
+        hl.mkzg_verify(vp5, comm, [1] * 6, 0, hl.Keccak256Transcript.from_proof(bytes(64 * 6)))
+
+
+def test_mkzg_batch_verify_golden(hl, vp5):
+    g = GOLDEN["kzg_batch"]
+    nv = g["num_vars"]
+    t = hl.Keccak256Transcript.from_proof(bytes.fromhex(g["proof"]))
+    comms = t.read_commitments(len(g["polys"]))
+    pts = [t.squeeze_challenges(nv) for _ in range(2)]
+    vals = t.read_field_elements(len(g["pairs"]))
+    evals = [hl.Evaluation(p, q, v) for (p, q), v in zip(g["pairs"], vals)]
+    hl.MultilinearKzg.batch_verify(vp5, nv, comms, pts, evals, t)
+    assert t.remaining() == 0
+    # a wrong claimed evaluation fails in the sum-check or in the final pairing
+    t = hl.Keccak256Transcript.from_proof(bytes.fromhex(g["proof"]))
+    comms = t.read_commitments(len(g["polys"]))
+    pts = [t.squeeze_challenges(nv) for _ in range(2)]
+    vals = t.read_field_elements(len(g["pairs"]))
+    evals = [hl.Evaluation(p, q, v) for (p, q), v in zip(g["pairs"], vals)]
+    evals[1].value = (evals[1].value + 1) % P
+    with pytest.raises((hl.InvalidSumcheck, hl.InvalidPcsOpen)):
+        hl.MultilinearKzg.batch_verify(vp5, nv, comms, pts, evals, t)
+
+
+# ------------------------------------------------------------------ Lasso verify
+def _table(hl, g):
+    return hl.LassoTable.range(g["c"], g["l"]) if g["kind"] == "range" else hl.LassoTable.bitwise(
+        hl.SUBTABLE_AND if g["kind"] == "and" else hl.SUBTABLE_XOR, g["c"], g["l"])
+
+
+@pytest.mark.parametrize("idx", range(3))
+def test_lasso_verify_golden(hl, vp5, idx):
+    g = GOLDEN["lasso"][idx]
+    proof = bytes.fromhex(g["proof"])
+    hl.lasso_verify(vp5, _table(hl, g), g["n"], hl.Keccak256Transcript.from_proof(proof))
+    rng = random.Random(idx)
+    for _ in range(12):
+        bad = bytearray(proof)
+        bad[rng.randrange(len(bad))] ^= 1 << rng.randrange(8)
+        with pytest.raises(hl.Error):
+            hl.lasso_verify(vp5, _table(hl, g), g["n"], hl.Keccak256Transcript.from_proof(bytes(bad)))
+    with pytest.raises(hl.Error):  # truncated
+        hl.lasso_verify(vp5, _table(hl, g), g["n"], hl.Keccak256Transcript.from_proof(proof[:-32]))
+    with pytest.raises(hl.InvalidSnark, match="trailing bytes"):
+        hl.lasso_verify(vp5, _table(hl, g), g["n"], hl.Keccak256Transcript.from_proof(proof + bytes(32)))
+    with pytest.raises(hl.Error):  # a different table
+        other = hl.LassoTable.range(g["c"], g["l"]) if g["kind"] != "range" else hl.LassoTable.bitwise(
+            hl.SUBTABLE_XOR, g["c"], g["l"])
+        hl.lasso_verify(vp5, other, g["n"], hl.Keccak256Transcript.from_proof(proof))
+
+
+# ------------------------------------------------------------------ HyperPlonk verify
+class _FakePcs:
+    """stands in for the GPU prover param: HyperPlonk.verify needs only commitments, which the oracle computes"""
+
+
+@pytest.mark.parametrize("idx", range(3))
+def test_hyperplonk_verify_golden(hl, vp5, idx):
+    from halo2_lasso_amd import hyperplonk as g_hp
+    from oracle.pyref import hyperplonk as o_hp
+    g = GOLDEN["hyperplonk"][idx]
+    nv = g["num_vars"]
+    perms = [[tuple(c) for c in cyc] for cyc in g["permutations"]]
+    pre = [I(a) for a in g["preprocess_polys"]]
+    mk = g_hp.vanilla_plonk_with_lookup_circuit_info if g["with_lookup"] else g_hp.vanilla_plonk_circuit_info
+    info = mk(nv, len(g["instances"][0]), pre, perms)
+    o_mk = o_hp.vanilla_plonk_with_lookup_circuit_info if g["with_lookup"] else o_hp.vanilla_plonk_circuit_info
+    o_pp = o_hp.preprocess(o_kzg.setup(SS), o_mk(nv, len(g["instances"][0]), pre, perms))
+    vp = g_hp.HyperPlonkVerifierParam()
+    vp.pcs, vp.num_vars, vp.info = vp5, nv, info
+    vp.num_permutation_z_polys, vp.expression = g_hp.compose(info)
+    vp.preprocess_comms, vp.permutation_comms = o_pp.preprocess_comms, o_pp.permutation_comms
+    instances, proof = [I(a) for a in g["instances"]], bytes.fromhex(g["proof"])
+    t = hl.Keccak256Transcript.from_proof(proof)
+    g_hp.HyperPlonk.verify(vp, instances, t)
+    assert t.remaining() == 0
+    bad_inst = [list(instances[0])]
+    bad_inst[0][1] = (bad_inst[0][1] + 1) % P
+    with pytest.raises(hl.Error):
+        g_hp.HyperPlonk.verify(vp, bad_inst, hl.Keccak256Transcript.from_proof(proof))
+    rng = random.Random(100 + idx)
+    for _ in range(12):
+        bad = bytearray(proof)
+        bad[rng.randrange(len(bad))] ^= 1 << rng.randrange(8)
+        with pytest.raises(hl.Error):
+            g_hp.HyperPlonk.verify(vp, instances, hl.Keccak256Transcript.from_proof(bytes(bad)))
