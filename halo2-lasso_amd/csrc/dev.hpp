@@ -236,6 +236,20 @@ void k_sc_round_ext(Ctx&, const ExtRound& rd, int degree, bool bind, size_t size
 void k_rotate_gather(Ctx&, const Fr* poly, size_t num_vars, int rot, uint32_t primitive, uint32_t x_inv, Fr* out);
 void k_identity_table(Ctx&, size_t n, Fr* out);
 void k_one_hot_table(Ctx&, size_t n, size_t hot, Fr* out);
+// Straight-line program over tables, constants and a small register file (the device counterpart of the
+// reference's ExpressionRegistry calculations, util/expression/evaluator.rs:135-323): instruction i is
+//   code[2i]   = op | dst << 4 | a_kind << 8 | b_kind << 10        code[2i+1] = a_idx | b_idx << 16
+enum { PROG_ADD = 0, PROG_SUB = 1, PROG_MUL = 2, PROG_NEG = 3, PROG_MOV = 4 };
+enum { PROG_REG = 0, PROG_ATOM = 1, PROG_CONST = 2 };
+constexpr int PROG_MAX_REGS = 8;
+struct ProgRound {
+  const Fr* in[SC_MAX_TABLES];  // tables of 2 * size entries (already bound)
+  uint32_t num_tables, num_instrs, num_regs, result_reg;
+  const uint32_t* code;  // device
+  const Fr* consts;      // device
+};
+// evals_host[0..degree) = sum over pairs of program(tables at X), X = 1..degree
+void k_sc_round_prog(Ctx&, const ProgRound& pr, int degree, size_t size, Fr* evals_host);
 enum { ROWS_ATOM_POLY = 0, ROWS_ATOM_IDENTITY = 1, ROWS_ATOM_LAGRANGE = 2 };
 struct RowsAtom {
   const Fr* table;

@@ -128,6 +128,172 @@ ExpandedExpr expand_expr(const lh_expr& e, const HFr* challenges, size_t num_cha
   return out;
 }
 
+// ------------------------------------------------------------------ expression -> register program
+// Code generation for k_sc_round_prog: constants and challenges fold on the host, leaves are operands (no load
+// instruction), inner nodes are emitted in Sethi-Ullman order so that the register file stays within
+// PROG_MAX_REGS.  The program computes the same field value as the AST at every point.
+struct Program {
+  std::vector<uint32_t> code;
+  std::vector<Fr> consts;
+  uint32_t num_regs = 0, result_reg = 0;
+  bool ok = false;
+};
+namespace {
+struct Opnd {
+  uint32_t kind, idx;
+};
+struct ProgBuilder {
+  const lh_expr& e;
+  std::vector<char> is_const;
+  std::vector<HFr> cval;
+  std::vector<int> need, table;  // table: leaf node -> table index
+  Program prog;
+  std::vector<uint32_t> free_regs;
+  uint32_t regs_in_use = 0;
+  bool failed = false;
+
+  explicit ProgBuilder(const lh_expr& e_) : e(e_) {}
+  uint32_t const_idx(const HFr& v) {
+    Fr d = dev(v);
+    for (size_t i = 0; i < prog.consts.size(); i++)
+      if (memcmp(&prog.consts[i], &d, sizeof(Fr)) == 0) return (uint32_t)i;
+    prog.consts.push_back(d);
+    return (uint32_t)prog.consts.size() - 1;
+  }
+  uint32_t alloc_reg() {
+    if (!free_regs.empty()) {
+      uint32_t r = free_regs.back();
+      free_regs.pop_back();
+      return r;
+    }
+    if (regs_in_use >= (uint32_t)PROG_MAX_REGS) {
+      failed = true;
+      return 0;
+    }
+    prog.num_regs = std::max(prog.num_regs, regs_in_use + 1);
+    return regs_in_use++;
+  }
+  void release(const Opnd& o) {
+    if (o.kind == PROG_REG) free_regs.push_back(o.idx);
+  }
+  void emit(uint32_t op, uint32_t dst, const Opnd& a, const Opnd& b) {
+    if (a.idx > 0xffff || b.idx > 0xffff || prog.code.size() > 2 * 4096) failed = true;
+    prog.code.push_back(op | dst << 4 | a.kind << 8 | b.kind << 10);
+    prog.code.push_back(a.idx | b.idx << 16);
+  }
+  Opnd binary(uint32_t op, const Opnd& a, const Opnd& b) {
+    // reuse an operand register as the destination (the operands are read before the store)
+    uint32_t dst = a.kind == PROG_REG ? a.idx : b.kind == PROG_REG ? b.idx : alloc_reg();
+    emit(op, dst, a, b);
+    if (a.kind == PROG_REG && a.idx != dst) release(a);
+    if (b.kind == PROG_REG && b.idx != dst) release(b);
+    return Opnd{PROG_REG, dst};
+  }
+  Opnd gen(int n) {
+    const lh_expr_node& nd = e.nodes[n];
+    if (is_const[n]) return Opnd{PROG_CONST, const_idx(cval[n])};
+    switch (nd.op) {
+      case LH_EX_IDENTITY:
+      case LH_EX_LAGRANGE:
+      case LH_EX_EQ_XY:
+      case LH_EX_POLYNOMIAL: return Opnd{PROG_ATOM, (uint32_t)table[n]};
+      case LH_EX_NEGATED: {
+        Opnd a = gen(nd.a);
+        uint32_t dst = a.kind == PROG_REG ? a.idx : alloc_reg();
+        emit(PROG_NEG, dst, a, Opnd{PROG_REG, 0});
+        return Opnd{PROG_REG, dst};
+      }
+      case LH_EX_SCALED: {
+        HFr sc;
+        memcpy(&sc, &nd.scalar, 32);
+        Opnd a = gen(nd.a);
+        if (sc == HFr::one()) return a;
+        return binary(PROG_MUL, a, Opnd{PROG_CONST, const_idx(sc)});
+      }
+      default: {  // SUM / PRODUCT
+        int l = nd.a, r = nd.b;
+        uint32_t op = nd.op == LH_EX_SUM ? PROG_ADD : PROG_MUL;
+        if (nd.op == LH_EX_SUM) {
+          if (is_const[l] && cval[l].is_zero()) return gen(r);
+          if (is_const[r] && cval[r].is_zero()) return gen(l);
+          if (!is_const[r] && e.nodes[r].op == LH_EX_NEGATED) {  // a + (-b) -> a - b
+            op = PROG_SUB;
+            r = e.nodes[r].a;
+          }
+        } else {
+          if (is_const[l] && cval[l] == HFr::one()) return gen(r);
+          if (is_const[r] && cval[r] == HFr::one()) return gen(l);
+        }
+        Opnd a, b;
+        if (need[r] > need[l]) {
+          b = gen(r);
+          a = gen(l);
+        } else {
+          a = gen(l);
+          b = gen(r);
+        }
+        return binary(op, a, b);
+      }
+    }
+  }
+};
+}  // namespace
+
+// leaf_table(node index) -> table index of an atom leaf
+static Program compile_program(const lh_expr& e, const HFr* challenges, size_t num_challenges,
+                               const std::function<int(const lh_expr_node&)>& leaf_table) {
+  ProgBuilder pb(e);
+  const size_t N = e.num_nodes;
+  pb.is_const.assign(N, 0);
+  pb.cval.assign(N, HFr::zero());
+  pb.need.assign(N, 0);
+  pb.table.assign(N, -1);
+  for (size_t i = 0; i < N; i++) {
+    const lh_expr_node& nd = e.nodes[i];
+    HFr sc;
+    memcpy(&sc, &nd.scalar, 32);
+    auto both_const = [&]() { return pb.is_const[nd.a] && pb.is_const[nd.b]; };
+    switch (nd.op) {
+      case LH_EX_CONSTANT: pb.is_const[i] = 1, pb.cval[i] = sc; break;
+      case LH_EX_CHALLENGE:
+        LH_REQUIRE(nd.a >= 0 && (size_t)nd.a < num_challenges, LH_ERR_ARG, "expression: challenge index out of range");
+        pb.is_const[i] = 1, pb.cval[i] = challenges[nd.a];
+        break;
+      case LH_EX_NEGATED:
+        if (pb.is_const[nd.a]) pb.is_const[i] = 1, pb.cval[i] = -pb.cval[nd.a];
+        else pb.need[i] = std::max(pb.need[nd.a], 1);
+        break;
+      case LH_EX_SCALED:
+        if (pb.is_const[nd.a]) pb.is_const[i] = 1, pb.cval[i] = pb.cval[nd.a] * sc;
+        else pb.need[i] = std::max(pb.need[nd.a], 1);
+        break;
+      case LH_EX_SUM:
+      case LH_EX_PRODUCT:
+        if (both_const()) {
+          pb.is_const[i] = 1;
+          pb.cval[i] = nd.op == LH_EX_SUM ? pb.cval[nd.a] + pb.cval[nd.b] : pb.cval[nd.a] * pb.cval[nd.b];
+        } else if (nd.op == LH_EX_PRODUCT && ((pb.is_const[nd.a] && pb.cval[nd.a].is_zero()) ||
+                                              (pb.is_const[nd.b] && pb.cval[nd.b].is_zero()))) {
+          pb.is_const[i] = 1, pb.cval[i] = HFr::zero();
+        } else {
+          int na = pb.need[nd.a], nb = pb.need[nd.b];
+          pb.need[i] = na == nb ? na + 1 : std::max(na, nb);
+        }
+        break;
+      default: pb.table[i] = leaf_table(nd);
+    }
+  }
+  Opnd res = pb.gen((int)N - 1);
+  if (res.kind != PROG_REG) {
+    uint32_t dst = pb.alloc_reg();
+    pb.emit(PROG_MOV, dst, res, Opnd{PROG_REG, 0});
+    res = Opnd{PROG_REG, dst};
+  }
+  pb.prog.result_reg = res.idx;
+  pb.prog.ok = !pb.failed && pb.prog.num_regs >= 1;
+  return pb.prog;
+}
+
 // ------------------------------------------------------------------ ClassicSumCheck<EvaluationsProver> over an Expression
 SumCheckResult sum_check_prove_expr(Ctx& c, size_t num_vars, const lh_expr& expr, const Fr* const* d_polys,
                                     size_t num_polys, const HFr* challenges, size_t num_challenges, const HFr* ys,
@@ -209,6 +375,44 @@ SumCheckResult sum_check_prove_expr(Ctx& c, size_t num_vars, const lh_expr& expr
   LH_HIP(hipMemcpyAsync(d_fac, fac.data(), fac.size(), hipMemcpyHostToDevice, c.stream));
   LH_HIP(hipMemcpyAsync(d_store, store.data(), store.size(), hipMemcpyHostToDevice, c.stream));
   c.sync();  // the host vectors go out of scope before the first round is queued otherwise
+
+  // preferred path: the expression as a register program (bind pass + evaluation from the bound tables)
+  static const bool use_prog = !(getenv("LH_EXPR_MONOMIALS") && atoi(getenv("LH_EXPR_MONOMIALS")));
+  if (use_prog) {
+    auto leaf_table = [&](const lh_expr_node& nd) -> int {
+      for (size_t a = 0; a < ex.atoms.size(); a++)
+        if (ex.atoms[a].kind == nd.op && (nd.op == LH_EX_IDENTITY || (ex.atoms[a].a == nd.a &&
+                                                                        (nd.op != LH_EX_POLYNOMIAL || ex.atoms[a].b == nd.b))))
+          return table_of[a];
+      throw Error(LH_ERR_ARG, "expression: leaf without a table");
+    };
+    Program prog = compile_program(expr, challenges, num_challenges, leaf_table);
+    if (prog.ok) {
+      uint32_t* d_code = c.arena.alloc_n<uint32_t>(prog.code.size());
+      Fr* d_consts = c.arena.alloc_n<Fr>(std::max<size_t>(prog.consts.size(), 1));
+      LH_HIP(hipMemcpyAsync(d_code, prog.code.data(), prog.code.size() * 4, hipMemcpyHostToDevice, c.stream));
+      if (!prog.consts.empty())
+        LH_HIP(hipMemcpyAsync(d_consts, prog.consts.data(), prog.consts.size() * sizeof(Fr), hipMemcpyHostToDevice, c.stream));
+      c.sync();
+      ProgRound pr;
+      memset(&pr, 0, sizeof(pr));
+      pr.num_tables = (uint32_t)T;
+      pr.num_instrs = (uint32_t)prog.code.size() / 2, pr.num_regs = prog.num_regs, pr.result_reg = prog.result_reg;
+      pr.code = d_code, pr.consts = d_consts;
+      auto prog_round = [&](const Fr* const* in, Fr* const* out, const Fr& r, bool bind, size_t size, Fr* evals_host) {
+        if (bind) {
+          std::vector<const Fr*> src;
+          std::vector<Fr*> dst;
+          for (size_t i = 0; i < T; i++)
+            if (used[i]) src.push_back(in[i]), dst.push_back(out[i]);
+          k_fix_var_multi(c, src.data(), dst.data(), src.size(), 4 * size, r);
+        }
+        for (size_t i = 0; i < T; i++) pr.in[i] = bind ? out[i] : in[i];
+        k_sc_round_prog(c, pr, ex.degree, size, evals_host);
+      };
+      return sum_check_loop(c, LH_SC_EVALUATIONS, num_vars, ex.degree, tables, used, num_polys, sum, tr, false, prog_round);
+    }
+  }
 
   ExtRound rd;
   memset(&rd, 0, sizeof(rd));

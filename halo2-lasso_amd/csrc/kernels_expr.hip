@@ -205,6 +205,123 @@ void k_sc_round_ext(Ctx& c, const ExtRound& rd, int degree, bool bind, size_t si
   c.wait_flag(seq);
 }
 
+// ------------------------------------------------------------------ sum-check round as a register program
+// One wave per evaluation point X (blockDim = 64 * D), one lane per pair; the register file lives in LDS
+// (word w of register r of thread t at ((r * 8 + w) * blockDim + t): conflict-free), operands are registers,
+// constants or tables read at X: hi + (X - 1)(hi - lo).  ~35 multiplications per point for the vanilla+lookup
+// zero-check instead of ~160 in expanded-monomial form.
+__device__ __forceinline__ Fr prog_reg_load(const uint32_t* regs, uint32_t r, uint32_t nthreads) {
+  Fr v;
+#pragma unroll
+  for (int w = 0; w < 8; w++) v.l[w] = regs[(r * 8 + w) * nthreads + threadIdx.x];
+  return v;
+}
+__device__ __forceinline__ void prog_reg_store(uint32_t* regs, uint32_t r, uint32_t nthreads, const Fr& v) {
+#pragma unroll
+  for (int w = 0; w < 8; w++) regs[(r * 8 + w) * nthreads + threadIdx.x] = v.l[w];
+}
+__device__ __forceinline__ Fr prog_operand(const ProgRound& pr, const uint32_t* regs, uint32_t kind, uint32_t idx,
+                                           size_t b, int xm1, uint32_t nthreads) {
+  if (kind == PROG_REG) return prog_reg_load(regs, idx, nthreads);
+  if (kind == PROG_CONST) return pr.consts[idx];
+  const Fr* t = pr.in[idx];
+  const Fr lo = t[2 * b], hi = t[2 * b + 1];
+  Fr v = hi;
+  if (xm1 > 0) {
+    const Fr step = sub(hi, lo);
+    for (int k = 0; k < xm1; k++) v = add(v, step);
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(512) void sc_round_prog_kernel(ProgRound pr, size_t size, int D, Fr* __restrict__ partials,
+                                                            ScFinishArgs fin) {
+  extern __shared__ uint32_t prog_regs[];
+  __shared__ int is_last;
+  const uint32_t nthreads = blockDim.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;  // wave = X - 1
+  Fr acc = Fr::zero();
+  for (size_t base = (size_t)blockIdx.x * 64; base < size; base += (size_t)gridDim.x * 64) {
+    const size_t b = base + lane;
+    if (b < size) {
+      for (uint32_t i = 0; i < pr.num_instrs; i++) {
+        const uint32_t w0 = pr.code[2 * i], w1 = pr.code[2 * i + 1];
+        const uint32_t op = w0 & 15u, dst = (w0 >> 4) & 15u;
+        const Fr a = prog_operand(pr, prog_regs, (w0 >> 8) & 3u, w1 & 0xffffu, b, wave, nthreads);
+        Fr res;
+        if (op == PROG_NEG) {
+          res = sub(Fr::zero(), a);
+        } else if (op == PROG_MOV) {
+          res = a;
+        } else {
+          const Fr bb = prog_operand(pr, prog_regs, (w0 >> 10) & 3u, w1 >> 16, b, wave, nthreads);
+          res = op == PROG_MUL ? mul(a, bb) : op == PROG_ADD ? add(a, bb) : sub(a, bb);
+        }
+        prog_reg_store(prog_regs, dst, nthreads, res);
+      }
+      acc = add(acc, prog_reg_load(prog_regs, pr.result_reg, nthreads));
+    }
+  }
+  acc = wave_reduce_sum(acc);
+  if (gridDim.x == 1) {
+    if (lane == 0) {
+      fin.out_host[wave] = acc;
+      __threadfence_system();
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) publish_flag_ext(fin.flag, fin.seq);
+    return;
+  }
+  if (lane == 0) {
+    partials[(size_t)blockIdx.x * D + wave] = acc;
+    __threadfence();
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t t = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = t == fin.last_ticket;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  Fr a2 = Fr::zero();
+  for (uint32_t i = lane; i < gridDim.x; i += 64) a2 = add(a2, partials[(size_t)i * D + wave]);
+  a2 = wave_reduce_sum(a2);
+  if (lane == 0) {
+    fin.out_host[wave] = a2;
+    __threadfence_system();
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) publish_flag_ext(fin.flag, fin.seq);
+}
+
+void k_sc_round_prog(Ctx& c, const ProgRound& pr, int degree, size_t size, Fr* evals_host) {
+  LH_REQUIRE(degree >= 2 && degree <= 8, LH_ERR_ARG, "sum-check degree must be in 2..8");
+  LH_REQUIRE(size >= 1 && pr.num_regs >= 1 && pr.num_regs <= PROG_MAX_REGS, LH_ERR_ARG, "sum-check program: bad shape");
+  const uint32_t seq = c.next_seq();
+  ArenaScope scope(c.arena);
+  const unsigned threads = 64u * (unsigned)degree;
+  const size_t lds_bytes = (size_t)pr.num_regs * 32 * threads;
+  static bool attr_set = false;
+  if (!attr_set) {
+    LH_HIP(hipFuncSetAttribute((const void*)sc_round_prog_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    attr_set = true;
+  }
+  size_t g = (size + 63) / 64;
+  const size_t cap = (size_t)c.num_cus * 4;
+  if (g > cap) g = cap;
+  Fr* partials = g == 1 ? evals_host : c.arena.alloc_n<Fr>(g * degree);
+  const ScFinishArgs fin = c.finish_for((uint32_t)g, evals_host, seq);
+  {
+    char name[40];
+    snprintf(name, sizeof name, "sc_round_prog<%d>", degree);
+    ProfScope ps(c, name, 64.0 * (double)size * pr.num_tables, 0, (double)size);
+    hipLaunchKernelGGL(sc_round_prog_kernel, dim3((unsigned)g), dim3(threads), lds_bytes, c.stream, pr, size, degree,
+                       partials, fin);
+  }
+  c.wait_flag(seq);
+}
+
 // ------------------------------------------------------------------ row-wise evaluation of a monomial list
 // out[b] = sum_m coeff_m * prod_k atom_{m,k}(b), atoms read at (rotated) row b
 __global__ void expr_rows_kernel(RowsExpr e, size_t n, Fr* __restrict__ out) {

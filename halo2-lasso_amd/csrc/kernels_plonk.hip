@@ -38,16 +38,22 @@ __global__ void m_probe_kernel(const Fr* __restrict__ input, const Fr* __restric
     const Fr v = input[i];
     const uint64_t k = key_of(v);
     size_t lo = 0, hi = n;
-    while (lo < hi) {
+    while (lo < hi) {  // upper bound: first key > k
       size_t mid = (lo + hi) >> 1;
-      if (skeys[mid] < k) lo = mid + 1;
+      if (skeys[mid] <= k) lo = mid + 1;
       else hi = mid;
     }
-    // among the table rows holding exactly this value the LAST one wins (HashMap::collect, prover.rs:151)
+    // among the table rows holding exactly this value the LAST one wins (HashMap::collect, prover.rs:151).
+    // The sort is stable, so row indices ascend inside a run of equal keys: walking down from the end of the
+    // run, the first full match is that row (one comparison unless two different values share their low 64 bits;
+    // a table padded with many equal rows does not make the probe quadratic).
     long long best = -1;
-    for (size_t p = lo; p < n && skeys[p] == k; p++) {
+    for (size_t p = lo; p-- > 0 && skeys[p] == k;) {
       uint32_t t = sidx[p];
-      if (table[t] == v && (long long)t > best) best = (long long)t;
+      if (table[t] == v) {
+        best = (long long)t;
+        break;
+      }
     }
     if (best < 0) atomicAdd(missing, 1u);  // Error::InvalidSnark("Invalid lookup input") (prover.rs:176-178)
     else atomicAdd(&counts[best], 1u);
