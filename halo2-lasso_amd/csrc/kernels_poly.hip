@@ -491,62 +491,58 @@ __device__ __forceinline__ uint32_t subtable_entry(int kind, uint32_t m, uint32_
   return kind == LH_SUBTABLE_IDENTITY ? m : kind == LH_SUBTABLE_AND ? (x & y) : (x ^ y);
 }
 
-// read_ts[k] = number of earlier lookups of the same address; final_cts[m] = total count.
-// Sort-free: one thread per ADDRESS scans nothing; instead a stable counting pass is required
-// (read_ts depends on lookup order).  Stage 1: per-block LDS-free global histogram of ordered
-// ranks is not associative, so the kernel below serialises per address with a ticket taken in
-// index order: block b handles lookups [b*T, (b+1)*T) and the blocks are chained through
-// `block_base`, which is produced by a histogram+scan over blocks (counting sort, stable).
-constexpr int CNT_TILE = 2048;
-__global__ void lasso_tile_hist_kernel(const uint32_t* __restrict__ dim, size_t n, size_t m,
-                                       uint32_t* __restrict__ tile_hist /* [tiles][m] */) {
-  // each block owns one tile; counts go straight to its private row (global atomics, no sharing)
-  size_t tile = blockIdx.x;
-  uint32_t* row = tile_hist + tile * m;
-  size_t lo = tile * CNT_TILE, hi = lo + CNT_TILE < n ? lo + CNT_TILE : n;
-  for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) atomicAdd(&row[dim[i]], 1u);
-}
-// exclusive scan down the tiles for every address: tile_hist[t][a] <- sum_{t' < t} ; final_cts[a] = total
-__global__ void lasso_tile_scan_kernel(uint32_t* __restrict__ tile_hist, size_t tiles, size_t m,
-                                       uint32_t* __restrict__ final_cts) {
-  GSTRIDE(a, m) {
-    uint32_t run = 0;
-    for (size_t t = 0; t < tiles; t++) {
-      uint32_t v = tile_hist[t * m + a];
-      tile_hist[t * m + a] = run;
-      run += v;
-    }
-    final_cts[a] = run;
+// read_ts[k] = number of earlier lookups of the same address; final_cts[a] = total count of address a.
+// Stable radix sort of (address, lookup index) pairs, then a lookup's rank inside its run of equal addresses is
+// its position minus the run start: O(n) traffic whatever the table size (a tile x address histogram, the
+// obvious counting-sort formulation, moves tiles * m counters - 2 GB per column at 2^24 lookups).
+void sort_pairs_u32(Ctx& c, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
+                    size_t n, unsigned bits);
+__global__ void lasso_iota_kernel(const uint32_t* __restrict__ dim, size_t n, size_t m, uint32_t* __restrict__ out,
+                                  uint32_t* __restrict__ bad) {
+  GSTRIDE(i, n) {
+    out[i] = (uint32_t)i;
+    if (dim[i] >= m) *bad = 1u;  // benign race: every writer stores the same value
   }
 }
-// inside a tile the order is resolved by one thread per lookup counting equal addresses before it
-// in the tile through LDS (tile is small); O(TILE) per thread worst case is avoided by a
-// per-address running counter processed in index order by a single wave-serial loop.
-__global__ void lasso_tile_rank_kernel(const uint32_t* __restrict__ dim, size_t n, size_t m,
-                                       const uint32_t* __restrict__ tile_hist, uint32_t* __restrict__ read_ts) {
-  __shared__ uint32_t keys[CNT_TILE];
-  size_t tile = blockIdx.x;
-  size_t lo = tile * CNT_TILE, hi = lo + CNT_TILE < n ? lo + CNT_TILE : n;
-  int cnt = (int)(hi - lo);
-  for (int i = threadIdx.x; i < cnt; i += blockDim.x) keys[i] = dim[lo + i];
-  __syncthreads();
-  const uint32_t* row = tile_hist + tile * m;
-  for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
-    uint32_t k = keys[i];
-    uint32_t r = 0;
-    for (int j = 0; j < i; j++) r += (keys[j] == k);
-    read_ts[lo + i] = row[k] + r;
+__global__ void lasso_run_start_kernel(const uint32_t* __restrict__ skey, size_t n, size_t m,
+                                       uint32_t* __restrict__ start) {
+  GSTRIDE(i, n) {
+    const uint32_t k = skey[i];
+    if ((i == 0 || skey[i - 1] != k) && k < m) start[k] = (uint32_t)i;
+  }
+}
+__global__ void lasso_rank_kernel(const uint32_t* __restrict__ skey, const uint32_t* __restrict__ sidx, size_t n,
+                                  size_t m, const uint32_t* __restrict__ start, uint32_t* __restrict__ read_ts,
+                                  uint32_t* __restrict__ final_cts) {
+  GSTRIDE(i, n) {
+    const uint32_t k = skey[i];
+    if (k >= m) continue;  // reported through `bad`
+    const uint32_t r = (uint32_t)i - start[k];
+    read_ts[sidx[i]] = r;
+    if (i + 1 == n || skey[i + 1] != k) final_cts[k] = r + 1;
   }
 }
 void k_lasso_counters(Ctx& c, const uint32_t* dim, size_t n, size_t m, uint32_t* read_ts, uint32_t* final_cts) {
   ProfScope ps(c, "lasso_counters", 8.0 * n + 4.0 * m, 0.0, (double)n);
   ArenaScope scope(c.arena);
-  size_t tiles = (n + CNT_TILE - 1) / CNT_TILE;
-  uint32_t* tile_hist = c.arena.alloc_n<uint32_t>(tiles * m);
-  LH_HIP(hipMemsetAsync(tile_hist, 0, tiles * m * sizeof(uint32_t), c.stream));
-  hipLaunchKernelGGL(lasso_tile_hist_kernel, dim3((unsigned)tiles), 256, 0, c.stream, dim, n, m, tile_hist);
-  hipLaunchKernelGGL(lasso_tile_scan_kernel, grid_for(m), 256, 0, c.stream, tile_hist, tiles, m, final_cts);
-  hipLaunchKernelGGL(lasso_tile_rank_kernel, dim3((unsigned)tiles), 256, 0, c.stream, dim, n, m, tile_hist, read_ts);
+  unsigned bits = 1;
+  while (((size_t)1 << bits) < m) bits++;
+  uint32_t* idx = c.arena.alloc_n<uint32_t>(n);
+  uint32_t* skey = c.arena.alloc_n<uint32_t>(n);
+  uint32_t* sidx = c.arena.alloc_n<uint32_t>(n);
+  uint32_t* start = c.arena.alloc_n<uint32_t>(m);
+  uint32_t* bad = c.arena.alloc_n<uint32_t>(1);
+  LH_HIP(hipMemsetAsync(final_cts, 0, m * sizeof(uint32_t), c.stream));
+  LH_HIP(hipMemsetAsync(bad, 0, sizeof(uint32_t), c.stream));
+  if (!n) return;
+  hipLaunchKernelGGL(lasso_iota_kernel, grid_for(n), 256, 0, c.stream, dim, n, m, idx, bad);
+  sort_pairs_u32(c, dim, skey, idx, sidx, n, bits);
+  hipLaunchKernelGGL(lasso_run_start_kernel, grid_for(n), 256, 0, c.stream, skey, n, m, start);
+  hipLaunchKernelGGL(lasso_rank_kernel, grid_for(n), 256, 0, c.stream, skey, sidx, n, m, start, read_ts, final_cts);
+  uint32_t h_bad = 0;
+  LH_HIP(hipMemcpyAsync(&h_bad, bad, sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
+  c.sync();
+  LH_REQUIRE(!h_bad, LH_ERR_ARG, "lasso: chunk index out of range (>= 2^chunk_bits)");
 }
 
 __global__ void lasso_subtable_read_kernel(int kind, uint32_t bits, const uint32_t* __restrict__ dim, size_t n,

@@ -381,3 +381,16 @@ def test_lasso_rejects_bad_arguments(hl, ctx, srs6):
         hl.lasso_prove(pp, hl.LassoTable.range(2, 4), 4, d[:1], hl.Keccak256Transcript())
     with pytest.raises(hl.ArgumentError):  # AND subtable needs an even chunk width
         hl.lasso_prove(pp, hl.LassoTable.bitwise(hl.SUBTABLE_AND, 2, 3), 4, d, hl.Keccak256Transcript())
+
+
+def test_lasso_rejects_out_of_range_chunk_index(hl, ctx, srs6):
+    """a chunk index >= 2^chunk_bits cannot address the subtable: argument error, not memory corruption"""
+    _, _, pp = srs6
+    good = array.array("I", [1, 2, 3, 1] * 4)
+    bad = array.array("I", [1, 2, 16, 1] * 4)  # chunk_bits = 4
+    with pytest.raises(hl.ArgumentError, match="chunk index out of range"):
+        hl.lasso_prove(pp, hl.LassoTable.range(2, 4), 4, [ctx.upload(good.tobytes()), ctx.upload(bad.tobytes())],
+                       hl.Keccak256Transcript())
+    t = hl.Keccak256Transcript()  # the context is still usable afterwards
+    hl.lasso_prove(pp, hl.LassoTable.range(2, 4), 4, [ctx.upload(good.tobytes()), ctx.upload(good.tobytes())], t)
+    assert len(t.into_proof()) > 0
