@@ -62,6 +62,7 @@ void lh_ctx_destroy(lh_ctx* ctx) {
   (void)hipSetDevice(ctx->c.device);
   (void)hipStreamSynchronize(ctx->c.stream);
   if (ctx->c.pinned) (void)hipHostFree(ctx->c.pinned);
+  if (ctx->c.stage) (void)hipHostFree(ctx->c.stage);
   if (ctx->c.flag) (void)hipHostFree(ctx->c.flag);
   if (ctx->c.ticket) (void)hipFree(ctx->c.ticket);
   (void)hipStreamDestroy(ctx->c.stream);

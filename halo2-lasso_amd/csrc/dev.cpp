@@ -1,4 +1,10 @@
 // Device context and workspace arena.
+#include <string.h>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <functional>
 #include "dev.hpp"
 
 namespace lh {
@@ -78,6 +84,92 @@ void* Ctx::pin(size_t bytes) {
     pinned_bytes = want;
   }
   return pinned;
+}
+
+void Ctx::d2h(void* dst, const void* d_src, size_t bytes) {
+  if (!bytes) return;
+  if (bytes > ((size_t)8 << 20)) {  // bulk: let the runtime stream it
+    LH_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, stream));
+    sync();
+    return;
+  }
+  if (bytes > stage_bytes) {
+    if (stage) (void)hipHostFree(stage);
+    size_t want = bytes < ((size_t)1 << 20) ? ((size_t)1 << 20) : bytes;
+    LH_HIP(hipHostMalloc(&stage, want, hipHostMallocCoherent | hipHostMallocMapped));
+    stage_bytes = want;
+  }
+  LH_HIP(hipMemcpyAsync(stage, d_src, bytes, hipMemcpyDeviceToHost, stream));
+  sync();
+  memcpy(dst, stage, bytes);
+}
+
+// ------------------------------------------------------------------ host worker pool
+namespace {
+struct HostPool {
+  std::mutex mu;
+  std::condition_variable cv;
+  uint64_t gen = 0;
+  const std::function<void(size_t)>* fn = nullptr;
+  size_t n = 0;
+  std::atomic<size_t> next{0}, pending{0};
+  std::atomic<int> active{0};  // workers inside run()
+  HostPool() {
+    unsigned hw = std::thread::hardware_concurrency();
+    unsigned workers = hw > 1 ? std::min(15u, hw - 1) : 0;
+    for (unsigned i = 0; i < workers; i++) std::thread([this] { worker(); }).detach();
+  }
+  void run() {
+    size_t i;
+    while ((i = next.fetch_add(1, std::memory_order_relaxed)) < n) {
+      (*fn)(i);
+      pending.fetch_sub(1, std::memory_order_release);
+    }
+  }
+  void worker() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return gen != seen; });
+        seen = gen;
+        active.fetch_add(1, std::memory_order_acq_rel);
+      }
+      run();
+      active.fetch_sub(1, std::memory_order_acq_rel);
+    }
+  }
+  void parallel_for(size_t count, const std::function<void(size_t)>& f) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      fn = &f;
+      n = count;
+      next.store(0, std::memory_order_relaxed);
+      pending.store(count, std::memory_order_release);
+      gen++;
+    }
+    cv.notify_all();
+    run();
+    while (pending.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+    // no worker may still be looking at `fn` / `n` of this generation when the caller's frame goes away
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      n = 0;
+    }
+    while (active.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+  }
+};
+}  // namespace
+
+void host_parallel_for(size_t n, const std::function<void(size_t)>& fn) {
+  if (n <= 1) {
+    for (size_t i = 0; i < n; i++) fn(i);
+    return;
+  }
+  static HostPool* pool = new HostPool();  // never destroyed: workers sleep on the condition variable
+  static std::mutex one_at_a_time;
+  std::lock_guard<std::mutex> lk(one_at_a_time);
+  pool->parallel_for(n, fn);
 }
 
 }  // namespace lh

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <functional>
 #include <string>
 #include <vector>
 #include <stdexcept>
@@ -107,6 +108,11 @@ struct Ctx {
   std::vector<ProfRec> prof_recs;
   hipEvent_t prof_ev[2] = {nullptr, nullptr};
   void* pin(size_t bytes);  // grows the pinned buffer if needed
+  // small device -> host download through a second pinned staging buffer, synchronising: an async copy into
+  // pageable memory makes the runtime pin pages on the fly (hundreds of microseconds for a few KB)
+  void* stage = nullptr;
+  size_t stage_bytes = 0;
+  void d2h(void* dst, const void* d_src, size_t bytes);
   void sync() { LH_HIP(hipStreamSynchronize(stream)); }
   // Round-trip fast path: a kernel publishes its (small) result into pinned memory and then stores a
   // sequence number with system-scope release; the host spins on it instead of going through
@@ -119,6 +125,10 @@ struct Ctx {
   uint32_t next_seq() { return ++flag_seq; }
   void wait_flag(uint32_t seq);
 };
+
+// Persistent host worker threads for the short host-side tails (window combines of an MSM batch): spawning
+// std::threads per call costs ~50 us each, more than the work itself.
+void host_parallel_for(size_t n, const std::function<void(size_t)>& fn);
 
 struct ProfScope {
   Ctx& c;

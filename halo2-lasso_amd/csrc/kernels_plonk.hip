@@ -76,8 +76,7 @@ bool k_lookup_m(Ctx& c, const Fr* input, const Fr* table, size_t n, Fr* m_out) {
   hipLaunchKernelGGL(m_probe_kernel, grid_for(n), 256, 0, c.stream, input, table, skeys, sidx, n, counts, counts + n);
   k_fr_from_u32(c, counts, n, m_out);
   uint32_t missing = 0;
-  LH_HIP(hipMemcpyAsync(&missing, counts + n, 4, hipMemcpyDeviceToHost, c.stream));
-  c.sync();
+  c.d2h(&missing, counts + n, 4);
   return missing == 0;
 }
 

@@ -382,8 +382,7 @@ static void inner_products_impl(Ctx& c, const void* const* polys, size_t count, 
     hipLaunchKernelGGL(inner_products_kernel<U32>, gg, 256, 0, c.stream, pk, weights, n, partials);
     hipLaunchKernelGGL(reduce_rows_kernel, k, 256, 0, c.stream, partials, (int)g.x, d_out + base);
   }
-  LH_HIP(hipMemcpyAsync(out_host, d_out, count * sizeof(Fr), hipMemcpyDeviceToHost, c.stream));
-  c.sync();
+  c.d2h(out_host, d_out, count * sizeof(Fr));
 }
 void k_inner_products(Ctx& c, const Fr* const* polys, size_t count, const Fr* weights, size_t n, Fr* out_host) {
   inner_products_impl<false>(c, (const void* const*)polys, count, weights, n, out_host);
@@ -540,8 +539,7 @@ void k_lasso_counters(Ctx& c, const uint32_t* dim, size_t n, size_t m, uint32_t*
   hipLaunchKernelGGL(lasso_run_start_kernel, grid_for(n), 256, 0, c.stream, skey, n, m, start);
   hipLaunchKernelGGL(lasso_rank_kernel, grid_for(n), 256, 0, c.stream, skey, sidx, n, m, start, read_ts, final_cts);
   uint32_t h_bad = 0;
-  LH_HIP(hipMemcpyAsync(&h_bad, bad, sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
-  c.sync();
+  c.d2h(&h_bad, bad, sizeof(uint32_t));
   LH_REQUIRE(!h_bad, LH_ERR_ARG, "lasso: chunk index out of range (>= 2^chunk_bits)");
 }
 

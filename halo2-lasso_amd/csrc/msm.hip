@@ -270,8 +270,10 @@ __global__ __launch_bounds__(64) void msm_segment_reduce_kernel(MsmPlanDev plan,
 }
 
 // one workgroup per (job, window): sum of its segment partials
+// The window sums go straight into pinned host memory; the workgroup that finishes last publishes the flag the
+// host spins on (same ticket protocol as the sum-check rounds): no device-to-host copy, no stream synchronise.
 __global__ __launch_bounds__(256) void msm_window_sum_kernel(MsmPlanDev plan, const G1Xyzz* __restrict__ seg_out,
-                                                             G1Xyzz* __restrict__ win_out) {
+                                                             G1Xyzz* __restrict__ win_out, ScFinishArgs fin) {
   __shared__ G1Xyzz lds[256];
   int j = 0;
   while (j + 1 < plan.num_jobs && plan.job[j + 1].win_base <= blockIdx.x) j++;
@@ -287,7 +289,13 @@ __global__ __launch_bounds__(256) void msm_window_sum_kernel(MsmPlanDev plan, co
       lds[threadIdx.x] = add(lds[threadIdx.x], lds[threadIdx.x + off]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) win_out[blockIdx.x] = lds[0];
+  if (threadIdx.x == 0) {
+    win_out[blockIdx.x] = lds[0];
+    __threadfence_system();
+    bool last = gridDim.x == 1;
+    if (!last) last = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == fin.last_ticket;
+    if (last) __hip_atomic_store(fin.flag, fin.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // ------------------------------------------------------------------ host driver
@@ -396,7 +404,7 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
       uint32_t* sidx = c.arena.alloc_n<uint32_t>(max_entries);
       G1Xyzz* buckets = c.arena.alloc_n<G1Xyzz>(nbuckets);
       G1Xyzz* seg_out = c.arena.alloc_n<G1Xyzz>(nsegs);
-      G1Xyzz* win_out = c.arena.alloc_n<G1Xyzz>(nwins);
+      G1Xyzz* win_out = (G1Xyzz*)c.pin(nwins * sizeof(G1Xyzz));  // pinned host memory, written by the last kernel
       uint32_t* lvl_cnt = c.arena.alloc_n<uint32_t>(64);
       LH_HIP(hipMemsetAsync(lvl_cnt, 0, 64 * sizeof(uint32_t), c.stream));
       LH_HIP(hipMemsetAsync(buckets, 0, nbuckets * sizeof(G1Xyzz), c.stream));
@@ -428,8 +436,7 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
       G1Xyzz* cpt = c.arena.alloc_n<G1Xyzz>(nchunks);
       uint32_t h_total = 0;
       if (c.prof) {
-        LH_HIP(hipMemcpyAsync(&h_total, total, 4, hipMemcpyDeviceToHost, c.stream));
-        c.sync();
+        c.d2h(&h_total, total, 4);
       }
       {
         // MSM algorithmic bytes: 96 B per point (32 B scalar + 64 B base); a mixed add is 10 Fq muls
@@ -460,10 +467,13 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
         ProfScope ps(c, "msm_bucket_reduce", 128.0 * nbuckets, 14.0 * 2.2 * nbuckets, (double)nbuckets);
       hipLaunchKernelGGL(msm_segment_reduce_kernel, dim3((unsigned)std::min<size_t>((nsegs + 63) / 64, 1 << 16)),
                          dim3(64), 0, c.stream, plan, buckets, seg_out, nsegs);
-      hipLaunchKernelGGL(msm_window_sum_kernel, dim3((unsigned)nwins), dim3(256), 0, c.stream, plan, seg_out, win_out);
+      const uint32_t seq = c.next_seq();
+      const ScFinishArgs fin = c.finish_for((uint32_t)nwins, nullptr, seq);
+      hipLaunchKernelGGL(msm_window_sum_kernel, dim3((unsigned)nwins), dim3(256), 0, c.stream, plan, seg_out, win_out, fin);
+      if (c.prof) c.sync();
+      c.wait_flag(seq);
       }
-      LH_HIP(hipMemcpyAsync(wins.data(), win_out, nwins * sizeof(G1Xyzz), hipMemcpyDeviceToHost, c.stream));
-      c.sync();
+      memcpy(wins.data(), win_out, nwins * sizeof(G1Xyzz));
     }
     // 6: host combine  sum_w 2^(c*w) * win[w]  and normalise
     auto combine = [&](size_t j) {
@@ -476,17 +486,7 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
       host::G1Affine a = host::g1_to_affine(acc);
       memcpy(&out_host[base + j], &a, sizeof(G1Affine));
     };
-    if (nj <= 2) {
-      for (size_t j = 0; j < nj; j++) combine(j);
-    } else {  // ~70 us of dependent doublings per job: spread the jobs over host threads
-      size_t nt = std::min<size_t>(nj, std::max(1u, std::min(16u, std::thread::hardware_concurrency())));
-      std::vector<std::thread> th;
-      for (size_t t = 0; t < nt; t++)
-        th.emplace_back([&, t] {
-          for (size_t j = t; j < nj; j += nt) combine(j);
-        });
-      for (auto& x : th) x.join();
-    }
+    host_parallel_for(nj, combine);  // ~70 us of dependent doublings per job
   }
 }
 

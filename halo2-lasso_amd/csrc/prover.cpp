@@ -352,10 +352,7 @@ SumCheckResult sum_check_prove_sharded(Ctx& c, int prover_kind, size_t num_vars,
 
 // ------------------------------------------------------------------ prove_fractional_sum_check
 // reference piop/gkr/fractional_sum_check.rs:89-190
-static void download(Ctx& c, void* dst, const void* src, size_t bytes) {
-  LH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c.stream));
-  c.sync();
-}
+static void download(Ctx& c, void* dst, const void* src, size_t bytes) { c.d2h(dst, src, bytes); }
 
 FracSumCheckResult prove_fractional_sum_check(Ctx& c, size_t B, size_t num_vars, const HFr* const* claimed_p_0s,
                                               const HFr* const* claimed_q_0s, const Fr* const* d_ps,

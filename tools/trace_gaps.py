@@ -1,0 +1,36 @@
+"""Development aid: timeline of the LAST proof in a rocprofv3 (rocpd sqlite) kernel trace: busy time, idle gaps and
+the kernels around the largest gaps.  usage: python tools/trace_gaps.py <results.db> [proof_ms]"""
+import re
+import sqlite3
+import sys
+
+db = sqlite3.connect(sys.argv[1])
+rows = db.execute("select name, start, end, grid_x, workgroup_x, vgpr_count from kernels order by start").fetchall()
+short = lambda n: re.sub(r"\(.*", "", re.sub(r"^(void )?(lh::|rocprim::\w+::detail::)?", "", n))[:44]
+# the last proof starts at the last lasso iota kernel before which there is a long idle period
+starts = [i for i, r in enumerate(rows) if "lasso_iota_kernel" in r[0]]
+per = 2  # counters columns per proof (range table c = 2)
+i0 = starts[-per]
+ks = rows[i0:]
+t0, t1 = ks[0][1], max(r[2] for r in ks)
+busy = sum(r[2] - r[1] for r in ks)
+print("last proof: %d kernels, span %.2f ms, busy %.2f ms (%.0f%%)" % (len(ks), (t1 - t0) / 1e6, busy / 1e6, 100.0 * busy / (t1 - t0)))
+gaps = []
+for a, b in zip(ks, ks[1:]):
+    gaps.append((b[1] - a[2], short(a[0]), short(b[0]), (a[2] - t0) / 1e6))
+print("gap histogram (us): ", end="")
+for lo, hi in ((0, 5), (5, 10), (10, 20), (20, 50), (50, 200), (200, 1e9)):
+    sel = [g[0] for g in gaps if lo * 1e3 <= g[0] < hi * 1e3]
+    print("[%g,%g): %d = %.2f ms  " % (lo, hi, len(sel), sum(sel) / 1e6), end="")
+print()
+print("largest gaps:")
+for g in sorted(gaps, reverse=True)[:18]:
+    print("  %7.1f us at %6.2f ms  after %-44s before %s" % (g[0] / 1e3, g[3], g[1], g[2]))
+agg = {}
+for r in ks:
+    a = agg.setdefault(short(r[0]), [0, 0])
+    a[0] += 1
+    a[1] += r[2] - r[1]
+print("kernels of the proof:")
+for n, (c, d) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:24]:
+    print("  %-46s %4d  %8.3f ms  avg %7.1f us" % (n, c, d / 1e6, d / c / 1e3))
