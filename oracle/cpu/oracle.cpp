@@ -18,6 +18,7 @@
 //   MultilinearKzg commit/open     pcs/multilinear/kzg.rs:252-302, quotients pcs/multilinear.rs:72-107
 //   additive::batch_open           pcs/multilinear.rs:134-235
 //   Lasso                          no reference code; spec = oracle/pyref/lasso.py
+//   HyperPlonk::prove + LogUp      backend/hyperplonk.rs:164-291, hyperplonk/prover.rs:32-406 (see the section below)
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -28,6 +29,7 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "ff.hpp"
@@ -717,6 +719,435 @@ static void lasso_prove(Transcript& tr, const Srs& s, const LassoTable& tb, size
   batch_open(tr, s, nv, pp, {pad_pt(r), pad_pt(sc.x), pad_pt(r_N), pad_pt(r_M)}, evs);
 }
 
+// ------------------------------------------------------------------ HyperPlonk with LogUp (backend/hyperplonk)
+// Restated: BooleanHypercube util/arithmetic/bh.rs:5-153; Expression::evaluate util/expression.rs:107-169;
+// instance polys hyperplonk.rs:365-369 + prover.rs:32-48; lookup_compressed/m/h polys prover.rs:50-260;
+// permutation_z_polys prover.rs:262-345; EvaluationsProver over a general expression
+// piop/sum_check/classic.rs:41-149 + classic/eval.rs:102-131 (rotated / identity / Lagrange leaves as tables,
+// evaluate THEN bind); evaluations in pcs_query order prover.rs:388-406, verifier.rs:147-180;
+// rotation points poly/multilinear.rs:477-526; HyperPlonk::prove hyperplonk.rs:164-291.
+static const uint32_t BH_PRIM[32] = {
+    1, 3, 7, 11, 19, 37, 67, 131, 285, 529, 1033, 2053, 4179, 8219, 16427, 32771, 65581, 131081, 262183, 524327,
+    1048585, 2097157, 4194307, 8388641, 16777243, 33554441, 67108935, 134217767, 268435465, 536870917, 1073741907,
+    2147483657u};
+static const uint32_t BH_XINV[32] = {
+    0, 1, 3, 5, 9, 18, 33, 65, 142, 264, 516, 1026, 2089, 4109, 8213, 16385, 32790, 65540, 131091, 262163, 524292,
+    1048578, 2097153, 4194320, 8388621, 16777220, 33554467, 67108883, 134217732, 268435458, 536870953, 1073741828};
+struct Hypercube {
+  size_t nv;
+  size_t next(size_t b) const {
+    b <<= 1;
+    return b ^ ((b >> nv) * BH_PRIM[nv]);
+  }
+  size_t prev(size_t b) const { return (b >> 1) ^ ((b & 1) * BH_XINV[nv]); }
+  size_t rotate(size_t b, int rot) const {
+    for (int i = 0; i > rot; i--) b = prev(b);
+    for (int i = 0; i < rot; i++) b = next(b);
+    return b;
+  }
+  std::vector<uint32_t> order() const {  // iter(): 0, 1, x, x^2, ...
+    std::vector<uint32_t> o((size_t)1 << nv);
+    o[0] = 0;
+    size_t b = 1;
+    for (size_t k = 1; k < o.size(); k++) {
+      o[k] = (uint32_t)b;
+      b = next(b);
+    }
+    return o;
+  }
+};
+
+struct ExprNode {  // same layout as lh_expr_node
+  uint32_t op;
+  int32_t a, b;
+  uint32_t reserved;
+  Fr scalar;
+};
+struct Expr {
+  const ExprNode* nodes;
+  size_t n;
+};
+enum { EX_CONSTANT, EX_IDENTITY, EX_LAGRANGE, EX_EQ_XY, EX_POLYNOMIAL, EX_CHALLENGE, EX_NEGATED, EX_SUM, EX_PRODUCT, EX_SCALED };
+
+// Expression::evaluate with the leaves supplied by the caller (constants/challenges are leaves too)
+template <class Leaf>
+static Fr eval_expr(const Expr& e, std::vector<Fr>& scratch, Leaf&& leaf) {
+  scratch.resize(e.n);
+  for (size_t i = 0; i < e.n; i++) {
+    const ExprNode& nd = e.nodes[i];
+    switch (nd.op) {
+      case EX_NEGATED: scratch[i] = Fr::zero() - scratch[nd.a]; break;
+      case EX_SUM: scratch[i] = scratch[nd.a] + scratch[nd.b]; break;
+      case EX_PRODUCT: scratch[i] = scratch[nd.a] * scratch[nd.b]; break;
+      case EX_SCALED: scratch[i] = scratch[nd.a] * nd.scalar; break;
+      default: scratch[i] = leaf(nd);
+    }
+  }
+  return scratch[e.n - 1];
+}
+static size_t expr_degree(const Expr& e) {
+  std::vector<size_t> d(e.n);
+  for (size_t i = 0; i < e.n; i++) {
+    const ExprNode& nd = e.nodes[i];
+    switch (nd.op) {
+      case EX_CONSTANT:
+      case EX_CHALLENGE: d[i] = 0; break;
+      case EX_NEGATED:
+      case EX_SCALED: d[i] = d[nd.a]; break;
+      case EX_SUM: d[i] = std::max(d[nd.a], d[nd.b]); break;
+      case EX_PRODUCT: d[i] = d[nd.a] + d[nd.b]; break;
+      default: d[i] = 1;
+    }
+  }
+  return d[e.n - 1];
+}
+
+static void batch_invert(Poly& v) {  // zero stays zero
+  std::vector<Fr> pre(v.size());
+  Fr acc = Fr::one();
+  for (size_t i = 0; i < v.size(); i++) {
+    pre[i] = acc;
+    if (!v[i].is_zero()) acc = acc * v[i];
+  }
+  Fr inv = acc.inv();
+  for (size_t i = v.size(); i-- > 0;) {
+    if (v[i].is_zero()) continue;
+    Fr x = inv * pre[i];
+    inv = inv * v[i];
+    v[i] = x;
+  }
+}
+static void par_batch_invert(Poly& v) {
+  parallelize(v.size(), [&](size_t a, size_t b) {
+    Poly part(v.begin() + a, v.begin() + b);
+    batch_invert(part);
+    std::copy(part.begin(), part.end(), v.begin() + a);
+  });
+}
+
+struct HpLookup {  // same layout as lh_hp_lookup
+  const Expr* inputs;
+  const Expr* tables;
+  size_t width;
+};
+struct HpParam {  // same layout as lh_hp_param, host pointers
+  size_t num_vars;
+  size_t num_instance_polys;
+  const size_t* num_instances;
+  size_t num_preprocess_polys;
+  const Fr* const* preprocess_polys;
+  size_t num_witness_polys;
+  size_t num_challenges;
+  size_t num_lookups;
+  const HpLookup* lookups;
+  size_t num_permutation_polys;
+  const size_t* permutation_poly_index;
+  const Fr* const* permutation_polys;
+  size_t num_permutation_z_polys;
+  Expr expression;
+};
+
+struct FrHash {
+  size_t operator()(const Fr& f) const { return (size_t)(f.v[0] ^ (f.v[1] * 0x9e3779b97f4a7c15ull) ^ f.v[2] ^ f.v[3]); }
+};
+
+// poly/multilinear.rs:477-549
+static std::vector<size_t> point_pattern(bool nxt, size_t nv, size_t distance) {
+  size_t rem = nxt ? BH_PRIM[nv] : BH_XINV[nv];
+  std::vector<size_t> pat((size_t)1 << distance, 0);
+  for (size_t depth = 0; depth < distance; depth++) {
+    size_t step = (size_t)1 << (distance - depth);
+    for (size_t e = 0; e < pat.size(); e += step) {
+      size_t rot = nxt ? pat[e] << 1 : pat[e] >> 1;
+      pat[e + step / 2] = rot ^ rem;
+      pat[e] = rot;
+    }
+  }
+  return pat;
+}
+static std::vector<std::vector<Fr>> rotation_points(const std::vector<Fr>& x, int rot) {
+  if (rot == 0) return {x};
+  size_t n = x.size(), dist = (size_t)abs(rot), nx = n - dist;
+  std::vector<std::vector<Fr>> out;
+  for (size_t p : point_pattern(rot > 0, n, dist)) {
+    std::vector<Fr> pt;
+    if (rot < 0) {
+      for (size_t i = 0; i < nx; i++) pt.push_back(((p >> i) & 1) ? Fr::one() - x[dist + i] : x[dist + i]);
+      for (size_t i = 0; i < dist; i++) pt.push_back(((p >> (i + nx)) & 1) ? Fr::one() : Fr::zero());
+    } else {
+      for (size_t i = 0; i < dist; i++) pt.push_back(((p >> i) & 1) ? Fr::one() : Fr::zero());
+      for (size_t i = 0; i < nx; i++) pt.push_back(((p >> (i + dist)) & 1) ? Fr::one() - x[i] : x[i]);
+    }
+    out.push_back(pt);
+  }
+  return out;
+}
+
+static void hyperplonk_prove(Transcript& tr, const Srs& srs, const HpParam& pp, const Fr* const* instances,
+                             const Fr* const* witness) {
+  const size_t nv = pp.num_vars, n = (size_t)1 << nv;
+  if (nv == 0 || nv >= 32) throw OracleError("hyperplonk: bad num_vars");
+  Hypercube bh{nv};
+  const std::vector<uint32_t> order = bh.order();
+  std::vector<uint32_t> nth(n);
+  for (size_t k = 0; k < n; k++) nth[order[k]] = (uint32_t)k;
+
+  std::vector<Poly> polys;
+  for (size_t i = 0; i < pp.num_instance_polys; i++) {
+    Poly p(n, Fr::zero());
+    for (size_t k = 0; k < pp.num_instances[i]; k++) {
+      tr.common_fe(instances[i][k]);
+      p[k + 1 < n ? order[k + 1] : 0] = instances[i][k];
+    }
+    polys.push_back(std::move(p));
+  }
+  for (size_t i = 0; i < pp.num_preprocess_polys; i++) polys.emplace_back(pp.preprocess_polys[i], pp.preprocess_polys[i] + n);
+  for (size_t i = 0; i < pp.num_witness_polys; i++) {
+    polys.emplace_back(witness[i], witness[i] + n);
+    tr.write_comm(commit(srs, polys.back()));
+  }
+  std::vector<Fr> challenges = tr.squeeze_n(pp.num_challenges);
+
+  // lookups
+  Fr beta = tr.squeeze();
+  auto row_leaf = [&](size_t b) {
+    return [&, b](const ExprNode& nd) -> Fr {
+      switch (nd.op) {
+        case EX_CONSTANT: return nd.scalar;
+        case EX_IDENTITY: return Fr::from_u64(b);
+        case EX_LAGRANGE: {
+          long long m = (long long)nd.a % (long long)n;
+          if (m < 0) m += (long long)n;
+          return order[(size_t)m] == b ? Fr::one() : Fr::zero();
+        }
+        case EX_POLYNOMIAL: return polys[nd.a][bh.rotate(b, nd.b)];
+        case EX_CHALLENGE: return challenges[nd.a];
+        default: throw OracleError("lookup expression: eq_xy is not allowed");
+      }
+    };
+  };
+  std::vector<Poly> comp_in, comp_tab, m_polys, h_polys;
+  for (size_t k = 0; k < pp.num_lookups; k++) {
+    const HpLookup& lk = pp.lookups[k];
+    Poly ci(n, Fr::zero()), ct(n, Fr::zero());
+    parallelize(n, [&](size_t lo, size_t hi) {
+      std::vector<Fr> scratch;
+      for (size_t b = lo; b < hi; b++) {
+        Fr pw = Fr::one();
+        auto leaf = row_leaf(b);
+        for (size_t w = 0; w < lk.width; w++) {
+          ci[b] = ci[b] + pw * eval_expr(lk.inputs[w], scratch, leaf);
+          ct[b] = ct[b] + pw * eval_expr(lk.tables[w], scratch, leaf);
+          pw = pw * beta;
+        }
+      }
+    });
+    std::unordered_map<Fr, uint32_t, FrHash> index;
+    index.reserve(2 * n);
+    for (size_t b = 0; b < n; b++) index[ct[b]] = (uint32_t)b;  // the last row holding a value wins
+    std::vector<uint64_t> cnt(n, 0);
+    for (size_t b = 0; b < n; b++) {
+      auto it = index.find(ci[b]);
+      if (it == index.end()) throw OracleError("Invalid lookup input");
+      cnt[it->second]++;
+    }
+    Poly m(n);
+    for (size_t b = 0; b < n; b++) m[b] = Fr::from_u64(cnt[b]);
+    comp_in.push_back(std::move(ci));
+    comp_tab.push_back(std::move(ct));
+    m_polys.push_back(std::move(m));
+  }
+  for (auto& m : m_polys) tr.write_comm(commit(srs, m));
+
+  Fr gamma = tr.squeeze();
+  for (size_t k = 0; k < pp.num_lookups; k++) {
+    Poly hi(n), ht(n), h(n);
+    for (size_t b = 0; b < n; b++) hi[b] = gamma + comp_in[k][b], ht[b] = gamma + comp_tab[k][b];
+    par_batch_invert(hi);
+    par_batch_invert(ht);
+    for (size_t b = 0; b < n; b++) h[b] = hi[b] - ht[b] * m_polys[k][b];
+    h_polys.push_back(std::move(h));
+  }
+  // permutation z polys
+  std::vector<Poly> z_polys;
+  const size_t nchunks = pp.num_permutation_z_polys, nperm = pp.num_permutation_polys;
+  if (nperm && nchunks) {
+    const size_t chunk = (nperm + nchunks - 1) / nchunks;
+    std::vector<Poly> products;
+    for (size_t c = 0; c < nchunks; c++) {
+      Poly prod(n, Fr::one());
+      const size_t k0 = c * chunk, k1 = std::min(nperm, k0 + chunk);
+      for (size_t k = k0; k < k1; k++) {
+        const Poly& val = polys[pp.permutation_poly_index[k]];
+        const Fr* perm = pp.permutation_polys[k];
+        parallelize(n, [&](size_t lo, size_t hi) {
+          for (size_t b = lo; b < hi; b++) prod[b] = prod[b] * (beta * perm[b] + gamma + val[b]);
+        });
+      }
+      par_batch_invert(prod);
+      for (size_t k = k0; k < k1; k++) {
+        const Poly& val = polys[pp.permutation_poly_index[k]];
+        const uint64_t off = (uint64_t)k << nv;
+        parallelize(n, [&](size_t lo, size_t hi) {
+          for (size_t b = lo; b < hi; b++) prod[b] = prod[b] * (Fr::from_u64(off + b) * beta + gamma + val[b]);
+        });
+      }
+      products.push_back(std::move(prod));
+    }
+    std::vector<Fr> z(nchunks * n, Fr::zero());
+    Fr state = Fr::one();
+    size_t pos = nchunks;
+    z[pos++] = state;
+    for (size_t k = 1; k < n && pos < z.size(); k++)
+      for (size_t c = 0; c < nchunks && pos < z.size(); c++) {
+        state = state * products[c][order[k]];
+        z[pos++] = state;
+      }
+    for (size_t c = 0; c < nchunks; c++) {
+      Poly zp(n);
+      for (size_t b = 0; b < n; b++) zp[b] = z[c + nchunks * nth[b]];
+      z_polys.push_back(std::move(zp));
+    }
+  }
+  for (auto& h : h_polys) tr.write_comm(commit(srs, h));
+  for (auto& z : z_polys) tr.write_comm(commit(srs, z));
+
+  Fr alpha = tr.squeeze();
+  std::vector<Fr> y = tr.squeeze_n(nv);
+  for (size_t k = 0; k < nperm; k++) polys.emplace_back(pp.permutation_polys[k], pp.permutation_polys[k] + n);
+  for (auto& m : m_polys) polys.push_back(m);
+  for (auto& h : h_polys) polys.push_back(h);
+  for (auto& z : z_polys) polys.push_back(z);
+  challenges.push_back(beta);
+  challenges.push_back(gamma);
+  challenges.push_back(alpha);
+
+  // zero-check: ClassicSumCheck<EvaluationsProver>, claim 0
+  const Expr& E = pp.expression;
+  const size_t degree = expr_degree(E);
+  if (degree < 2) throw OracleError("EvaluationsProver: degree < 2");
+  // leaf tables: every poly (bound each round), plus one table per distinct non-trivial leaf
+  struct Leaf {
+    uint32_t op;
+    int32_t a, b;
+  };
+  std::vector<Leaf> leaves;
+  std::vector<Poly> extra;  // tables of the leaves that are not a poly at rotation 0
+  std::vector<int> leaf_of(E.n, -1);  // node -> index into `polys` (>= 0) or -(1 + index into `extra`)
+  for (size_t i = 0; i < E.n; i++) {
+    const ExprNode& nd = E.nodes[i];
+    if (nd.op < EX_IDENTITY || nd.op > EX_POLYNOMIAL) continue;
+    if (nd.op == EX_POLYNOMIAL && nd.b == 0) {
+      leaf_of[i] = nd.a;
+      continue;
+    }
+    int found = -1;
+    for (size_t k = 0; k < leaves.size(); k++)
+      if (leaves[k].op == nd.op && (nd.op == EX_IDENTITY || (leaves[k].a == nd.a && (nd.op != EX_POLYNOMIAL || leaves[k].b == nd.b))))
+        found = (int)k;
+    if (found < 0) {
+      Poly t(n, Fr::zero());
+      if (nd.op == EX_IDENTITY) {
+        for (size_t b = 0; b < n; b++) t[b] = Fr::from_u64(b);
+      } else if (nd.op == EX_LAGRANGE) {
+        long long m = (long long)nd.a % (long long)n;
+        if (m < 0) m += (long long)n;
+        t[order[(size_t)m]] = Fr::one();
+      } else if (nd.op == EX_EQ_XY) {
+        if (nd.a != 0) throw OracleError("zero-check has a single eq_xy");
+        t = eq_xy(y.data(), nv);
+      } else {
+        for (size_t b = 0; b < n; b++) t[b] = polys[nd.a][bh.rotate(b, nd.b)];
+      }
+      leaves.push_back(Leaf{nd.op, nd.a, nd.b});
+      extra.push_back(std::move(t));
+      found = (int)leaves.size() - 1;
+    }
+    leaf_of[i] = -(1 + found);
+  }
+  Fr claim = Fr::zero();
+  std::vector<Fr> xs;
+  for (size_t round = 0; round < nv; round++) {
+    const size_t size = (size_t)1 << (nv - round - 1);
+    const size_t nt = (size_t)num_threads();
+    const size_t chunk = std::max<size_t>(1, (size + nt - 1) / nt), nchk = (size + chunk - 1) / chunk;
+    std::vector<std::vector<Fr>> partial(nchk, std::vector<Fr>(degree + 1, Fr::zero()));
+    parallelize(nchk, [&](size_t c0, size_t c1) {
+      std::vector<Fr> scratch;
+      for (size_t c = c0; c < c1; c++)
+        for (size_t b = c * chunk; b < std::min(size, (c + 1) * chunk); b++)
+          for (size_t X = 1; X <= degree; X++) {
+            const Fr fx = Fr::from_u64(X);
+            auto leaf = [&](const ExprNode& nd) -> Fr {
+              if (nd.op == EX_CONSTANT) return nd.scalar;
+              if (nd.op == EX_CHALLENGE) return challenges[nd.a];
+              const int id = leaf_of[&nd - E.nodes];
+              const Poly& t = id >= 0 ? polys[id] : extra[-id - 1];
+              return t[2 * b] + (t[2 * b + 1] - t[2 * b]) * fx;
+            };
+            partial[c][X] = partial[c][X] + eval_expr(E, scratch, leaf);
+          }
+    });
+    std::vector<Fr> ev(degree + 1, Fr::zero());
+    for (auto& p : partial)
+      for (size_t X = 1; X <= degree; X++) ev[X] = ev[X] + p[X];
+    ev[0] = claim - ev[1];
+    tr.write_fes(ev);
+    Fr r = tr.squeeze();
+    claim = interpolate(ev, r);
+    xs.push_back(r);
+    for (auto& p : polys) p = fix_var(p, r);
+    for (auto& p : extra) p = fix_var(p, r);
+  }
+  // evaluations, pcs_query order: (poly, rotation) sorted, polys past the instances
+  std::vector<std::pair<size_t, int>> query;
+  for (size_t i = 0; i < E.n; i++)
+    if (E.nodes[i].op == EX_POLYNOMIAL && (size_t)E.nodes[i].a >= pp.num_instance_polys)
+      query.push_back({(size_t)E.nodes[i].a, E.nodes[i].b});
+  std::sort(query.begin(), query.end());
+  query.erase(std::unique(query.begin(), query.end()), query.end());
+  std::vector<int> rots;
+  for (auto& q : query) rots.push_back(q.second);
+  std::sort(rots.begin(), rots.end());
+  rots.erase(std::unique(rots.begin(), rots.end()), rots.end());
+  std::vector<std::vector<Fr>> points;
+  std::vector<size_t> rot_off;
+  for (int r : rots) {
+    rot_off.push_back(points.size());
+    for (auto& pt : rotation_points(xs, r)) points.push_back(pt);
+  }
+  // the full tables are gone after binding: rebuild what the openings need from the inputs
+  std::vector<Poly> full;
+  for (size_t i = 0; i < pp.num_instance_polys; i++) {
+    Poly p(n, Fr::zero());
+    for (size_t k = 0; k < pp.num_instances[i]; k++) p[k + 1 < n ? order[k + 1] : 0] = instances[i][k];
+    full.push_back(std::move(p));
+  }
+  for (size_t i = 0; i < pp.num_preprocess_polys; i++) full.emplace_back(pp.preprocess_polys[i], pp.preprocess_polys[i] + n);
+  for (size_t i = 0; i < pp.num_witness_polys; i++) full.emplace_back(witness[i], witness[i] + n);
+  for (size_t k = 0; k < nperm; k++) full.emplace_back(pp.permutation_polys[k], pp.permutation_polys[k] + n);
+  for (auto& m : m_polys) full.push_back(m);
+  for (auto& h : h_polys) full.push_back(h);
+  for (auto& z : z_polys) full.push_back(z);
+  std::vector<Eval> evals;
+  std::vector<Fr> written;
+  for (auto& q : query) {
+    const size_t ri = std::lower_bound(rots.begin(), rots.end(), q.second) - rots.begin();
+    if (q.second == 0) {
+      evals.push_back(Eval{(uint32_t)q.first, (uint32_t)rot_off[ri], polys[q.first][0]});
+    } else {
+      size_t k = 0;
+      for (auto& pt : rotation_points(xs, q.second))
+        evals.push_back(Eval{(uint32_t)q.first, (uint32_t)(rot_off[ri] + k++), evaluate(full[q.first], pt.data(), nv)});
+    }
+  }
+  for (auto& e : evals) written.push_back(e.value);
+  tr.write_fes(written);
+  std::vector<const Poly*> ptrs;
+  for (auto& p : full) ptrs.push_back(&p);
+  batch_open(tr, srs, nv, ptrs, points, evals);
+}
+
 // ------------------------------------------------------------------ C interface (ctypes)
 static thread_local std::string g_err;
 #define ORC_TRY try {
@@ -840,6 +1271,11 @@ int orc_grand_product_prove(void* t, size_t B, const Fr* const* leaves, const si
   std::copy(o.roots.begin(), o.roots.end(), roots);
   std::copy(o.claims.begin(), o.claims.end(), claims);
   for (size_t b = 0; b < B; b++) points = std::copy(o.points[b].begin(), o.points[b].end(), points);
+  ORC_CATCH
+}
+int orc_hyperplonk_prove(void* t, const Affine* eqs, size_t srs_nv, const HpParam* pp, const Fr* const* instances,
+                         const Fr* const* witness) {
+  ORC_TRY hyperplonk_prove(*(Transcript*)t, Srs{eqs, srs_nv}, *pp, instances, witness);
   ORC_CATCH
 }
 int orc_lasso_prove(void* t, const Affine* eqs, size_t srs_nv, const LassoTable* tb, size_t n,

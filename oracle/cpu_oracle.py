@@ -178,3 +178,124 @@ def lasso_prove(tr, srs, srs_nv, table_struct, n, dims_u32_bytes):
     """dims_u32_bytes: list of bytes objects / buffers holding u32[2^n]."""
     arr, keep = _ptrs(dims_u32_bytes)
     _chk(lib().orc_lasso_prove(tr.h, srs, C.c_size_t(srs_nv), C.byref(table_struct), C.c_size_t(n), arr))
+
+
+# ------------------------------------------------------------------ HyperPlonk (oracle/cpu/oracle.cpp: hyperplonk_prove)
+class _ExprNode(C.Structure):
+    _fields_ = [("op", C.c_uint32), ("a", C.c_int32), ("b", C.c_int32), ("reserved", C.c_uint32), ("scalar", C.c_uint8 * 32)]
+
+
+class _Expr(C.Structure):
+    _fields_ = [("nodes", C.POINTER(_ExprNode)), ("n", C.c_size_t)]
+
+
+class _HpLookup(C.Structure):
+    _fields_ = [("inputs", C.POINTER(_Expr)), ("tables", C.POINTER(_Expr)), ("width", C.c_size_t)]
+
+
+class _HpParam(C.Structure):
+    _fields_ = [("num_vars", C.c_size_t),
+                ("num_instance_polys", C.c_size_t), ("num_instances", C.POINTER(C.c_size_t)),
+                ("num_preprocess_polys", C.c_size_t), ("preprocess_polys", C.POINTER(C.c_void_p)),
+                ("num_witness_polys", C.c_size_t), ("num_challenges", C.c_size_t),
+                ("num_lookups", C.c_size_t), ("lookups", C.POINTER(_HpLookup)),
+                ("num_permutation_polys", C.c_size_t), ("permutation_poly_index", C.POINTER(C.c_size_t)),
+                ("permutation_polys", C.POINTER(C.c_void_p)),
+                ("num_permutation_z_polys", C.c_size_t),
+                ("expression", _Expr)]
+
+
+def flatten_expression(e):
+    """pyref expression -> node tuples (op, a, b, scalar) in topological order, root last; DistributePowers lowered as
+    Expression::evaluate does (expression.rs:155-167)"""
+    from .pyref import expression as ex
+    nodes = []
+
+    def emit(op, a=0, b=0, scalar=0):
+        nodes.append((op, a, b, scalar % R_MOD))
+        return len(nodes) - 1
+
+    def go(x):
+        if isinstance(x, ex.Constant):
+            return emit(0, scalar=x.v)
+        if isinstance(x, ex.Identity):
+            return emit(1)
+        if isinstance(x, ex.Lagrange):
+            return emit(2, x.i)
+        if isinstance(x, ex.EqXY):
+            return emit(3, x.idx)
+        if isinstance(x, ex.Poly):
+            return emit(4, x.idx, x.rotation)
+        if isinstance(x, ex.Challenge):
+            return emit(5, x.idx)
+        if isinstance(x, ex.Negated):
+            return emit(6, go(x.a))
+        if isinstance(x, ex.Sum):
+            a = go(x.a)
+            return emit(7, a, go(x.b))
+        if isinstance(x, ex.Product):
+            a = go(x.a)
+            return emit(8, a, go(x.b))
+        if isinstance(x, ex.Scaled):
+            return emit(9, go(x.a), scalar=x.s)
+        if isinstance(x, ex.DistributePowers):
+            if len(x.exprs) == 1:
+                return go(x.exprs[0])
+            base, acc = go(x.base), go(x.exprs[0])
+            power = base
+            for k, sub in enumerate(x.exprs[1:]):
+                if k:
+                    power = emit(8, power, base)
+                acc = emit(7, acc, emit(8, power, go(sub)))
+            return acc
+        raise TypeError(x)
+
+    go(e)
+    return nodes
+
+
+def _c_expr(nodes, keep):
+    arr = (_ExprNode * len(nodes))()
+    for k, (op, a, b, scalar) in enumerate(nodes):
+        arr[k].op, arr[k].a, arr[k].b = op, a, b
+        C.memmove(C.byref(arr[k], _ExprNode.scalar.offset), fr_bytes([scalar]), 32)
+    keep.append(arr)
+    e = _Expr()
+    e.nodes, e.n = C.cast(arr, C.POINTER(_ExprNode)), len(nodes)
+    return e
+
+
+def _poly_bytes(p):
+    return p if isinstance(p, (bytes, bytearray)) else fr_bytes(p)
+
+
+def hyperplonk_prove(tr, srs, srs_nv, num_vars, num_instances, preprocess_polys, num_witness_polys, num_challenges,
+                     lookups, permutation_poly_index, permutation_polys, num_permutation_z_polys, expression,
+                     instances, witness):
+    """Polys are int lists or Montgomery byte strings (e.g. downloaded from the GPU); expressions are node lists from
+    `flatten_expression`; lookups: list of lists of (input nodes, table nodes)."""
+    keep = []
+    pp = _HpParam()
+    pp.num_vars = num_vars
+    pp.num_instance_polys = len(num_instances)
+    ni = (C.c_size_t * max(len(num_instances), 1))(*num_instances)
+    pp.num_instances = ni
+    pre, k1 = _ptrs([_poly_bytes(p) for p in preprocess_polys])
+    pp.num_preprocess_polys, pp.preprocess_polys = len(preprocess_polys), C.cast(pre, C.POINTER(C.c_void_p))
+    pp.num_witness_polys, pp.num_challenges = num_witness_polys, num_challenges
+    lk = (_HpLookup * max(len(lookups), 1))()
+    for i, lookup in enumerate(lookups):
+        ins = (_Expr * len(lookup))(*[_c_expr(a, keep) for a, _ in lookup])
+        tabs = (_Expr * len(lookup))(*[_c_expr(b, keep) for _, b in lookup])
+        keep += [ins, tabs]
+        lk[i].inputs, lk[i].tables, lk[i].width = ins, tabs, len(lookup)
+    pp.num_lookups, pp.lookups = len(lookups), lk
+    pidx = (C.c_size_t * max(len(permutation_poly_index), 1))(*permutation_poly_index)
+    perm, k2 = _ptrs([_poly_bytes(p) for p in permutation_polys])
+    pp.num_permutation_polys, pp.permutation_poly_index = len(permutation_polys), pidx
+    pp.permutation_polys = C.cast(perm, C.POINTER(C.c_void_p))
+    pp.num_permutation_z_polys = num_permutation_z_polys
+    pp.expression = _c_expr(expression, keep)
+    inst, k3 = _ptrs([fr_bytes(i) if len(i) else bytes(32) for i in instances])
+    wit, k4 = _ptrs([_poly_bytes(w) for w in witness])
+    _chk(lib().orc_hyperplonk_prove(tr.h, srs, C.c_size_t(srs_nv), C.byref(pp), inst, wit))

@@ -157,3 +157,57 @@ def test_open_matches_python_oracle(srs5):
         a, b = co.Transcript(), T()
         assert co.open_(a, srs, 5, poly, pt) == kzg.open_(pp.trim(nv), poly, pt, b) == evaluate(poly, pt)
         assert a.into_proof() == b.into_proof()
+
+
+# ------------------------------------------------------------------ HyperPlonk: C++ oracle vs Python oracle vs golden
+def _cpp_hyperplonk(srs, srs_nv, info, instances, witness):
+    from oracle.pyref import hyperplonk as hp
+    num_z, expression = hp.compose(info)
+    perm_idx = info.permutation_polys()
+    perm = hp.permutation_polys(info.k, perm_idx, info.permutations)
+    lookups = [[(co.flatten_expression(i), co.flatten_expression(t)) for i, t in lk] for lk in info.lookups]
+    t = co.Transcript()
+    co.hyperplonk_prove(t, srs, srs_nv, info.k, info.num_instances, info.preprocess_polys, info.num_witness_polys[0],
+                        info.num_challenges[0], lookups, perm_idx, perm, num_z, co.flatten_expression(expression),
+                        instances, witness)
+    return t.into_proof()
+
+
+@pytest.mark.parametrize("idx", range(3))
+def test_golden_hyperplonk_cpp(srs5, idx):
+    from oracle.pyref import hyperplonk as hp
+    _, srs = srs5
+    g = GOLDEN["hyperplonk"][idx]
+    mk = hp.vanilla_plonk_with_lookup_circuit_info if g["with_lookup"] else hp.vanilla_plonk_circuit_info
+    perms = [[tuple(c) for c in cyc] for cyc in g["permutations"]]
+    info = mk(g["num_vars"], len(g["instances"][0]), [I(a) for a in g["preprocess_polys"]], perms)
+    proof = _cpp_hyperplonk(srs, 5, info, [I(a) for a in g["instances"]], [I(w) for w in g["witness"]])
+    assert proof.hex() == g["proof"]
+
+
+@pytest.mark.parametrize("with_lookup,threads", [(False, 1), (True, 3), (True, 0)])
+def test_hyperplonk_cpp_matches_python(srs5, with_lookup, threads):
+    from oracle.pyref import hyperplonk as hp
+    ss, srs = srs5
+    co.set_threads(threads)
+    try:
+        rng = random.Random(31 + with_lookup)
+        gen = hp.rand_vanilla_plonk_with_lookup_circuit if with_lookup else hp.rand_vanilla_plonk_circuit
+        info, instances, witness = gen(5, rng)
+        t = T()
+        hp.prove(hp.preprocess(kzg.setup(ss), info), instances, lambda r, c: witness, t)
+        assert _cpp_hyperplonk(srs, 5, info, instances, witness) == t.into_proof()
+    finally:
+        co.set_threads(0)
+
+
+def test_hyperplonk_cpp_invalid_lookup(srs5):
+    from oracle.pyref import hyperplonk as hp
+    _, srs = srs5
+    info, instances, witness = hp.rand_vanilla_plonk_with_lookup_circuit(4, random.Random(2))
+    q_lookup = info.preprocess_polys[5]
+    row = next(b for b in range(16) if q_lookup[b] == 1)
+    witness = [list(w) for w in witness]
+    witness[1][row] = (witness[1][row] + 1) % P
+    with pytest.raises(RuntimeError, match="Invalid lookup input"):
+        _cpp_hyperplonk(srs, 5, info, instances, witness)
