@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-n", type=int, default=20, help="log2 of the number of lookups per proof")
     ap.add_argument("--table", default="range", choices=["range", "and", "xor"])
+    ap.add_argument("--workload", default="lasso", choices=["lasso", "hyperplonk"],
+                    help="'lasso' (default, BASELINE metric) or 'hyperplonk': HyperPlonk + LogUp prove of a synthetic "
+                         "vanilla_plonk_with_lookup circuit of 2^log-n rows (SURVEY.md §8d C5 substitute)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log-n", type=int, default=0, help="force the CPU sample size")
     ap.add_argument("--no-profile", action="store_true")
@@ -120,17 +123,7 @@ def fr_mul_peak(hl, ctx):
 
 
 def cpu_baseline(hl, ctx, pp, table, kind, args, gpu_proof_fn):
-    from oracle import cpu_oracle as co
-    # a library tuned for this host if the toolchain is here; else the portable prebuilt one
-    try:
-        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle", "cpu"), "NATIVE=1"], check=True,
-                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
-        native = os.path.join(ROOT, "oracle", "_build", "liboracle_cpu_native.so")
-        if os.path.exists(native):
-            co.LIB_PATH = native
-            co._lib = None
-    except Exception:
-        pass
+    co = use_native_oracle()
     cores = co.num_threads()
     srs_nv = pp.num_vars
     total = (2 << srs_nv) - 1
@@ -161,11 +154,155 @@ def cpu_baseline(hl, ctx, pp, table, kind, args, gpu_proof_fn):
             "sample_log_n": n, "proof_bytes_equal_gpu": bool(same)}
 
 
+def roofline_objects(hl, ctx, aggs, traffic=(None, None)):
+    tot = sum(a["ms"] for a in aggs) or 1.0
+    peak_mul = fr_mul_peak(hl, ctx)
+    dom = aggs[0]
+    big = dom["big"]
+    ach = big["bytes"] / (big["ms"] * 1e-3) / 1e9 if big["ms"] > 0 else 0.0
+    roof = {"bound": "hbm", "kernel": dom["name"], "achieved": round(ach, 1), "peak": 8000.0,
+            "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic[0], "traffic_source": traffic[1],
+            "launch": {"ms": round(big["ms"], 4), "bytes": big["bytes"], "items": big["items"]},
+            "share_of_profiled_prove": round(dom["ms"] / tot, 3), "launches": dom["launches"]}
+    mul_rate = big["muls"] / (big["ms"] * 1e-3) if big["ms"] > 0 else 0.0
+    alu = {"bound": "int32-mul", "kernel": dom["name"], "achieved": round(mul_rate / 1e9, 2),
+           "peak": round(peak_mul / 1e9, 2), "unit": "G Fr-mul/s", "frac": round(mul_rate / peak_mul, 4)}
+    kernels = [{"name": a["name"], "launches": a["launches"], "ms": round(a["ms"], 3),
+                "GBps_all": round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1) if a["ms"] > 0 else 0.0,
+                "GBps_largest": round(a["big"]["bytes"] / (a["big"]["ms"] * 1e-3) / 1e9, 1) if a["big"]["ms"] > 0 else 0.0}
+               for a in aggs[:12]]
+    return roof, alu, kernels
+
+
+def use_native_oracle():
+    from oracle import cpu_oracle as co
+    # a library tuned for this host if the toolchain is here; else the portable prebuilt one
+    try:
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle", "cpu"), "NATIVE=1"], check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+        native = os.path.join(ROOT, "oracle", "_build", "liboracle_cpu_native.so")
+        if os.path.exists(native):
+            co.LIB_PATH = native
+            co._lib = None
+    except Exception:
+        pass
+    return co
+
+
+def hyperplonk_cpu_baseline(hl, ctx, args, trap, gpu_proof_fn):
+    """the C++ oracle's HyperPlonk restatement on the same synthetic circuit (bounded sample), proof bytes compared"""
+    from halo2_lasso_amd import synthetic
+    from oracle.pyref import hyperplonk as o_hp
+    co = use_native_oracle()
+
+    def run(k):
+        circ = synthetic.vanilla_plonk_with_lookup(ctx, k)
+        pp = hl.MultilinearKzg.setup(ctx, trap[:k])
+        srs = C.create_string_buffer(64 * ((2 << k) - 1))
+        hl._check(ctx.lib.lh_srs_download(ctx.h, pp.h, srs))
+        o_info = o_hp.vanilla_plonk_with_lookup_circuit_info(k, 0, [[]] * 9, [[(10, 1)], [(11, 1)], [(12, 1)]])
+        num_z, expression = o_hp.compose(o_info)
+        lookups = [[(co.flatten_expression(i), co.flatten_expression(t)) for i, t in lk] for lk in o_info.lookups]
+        perm = [p.buf.read() for p in circ.d_permutation]
+        tr = co.Transcript()
+        t = time.perf_counter()
+        co.hyperplonk_prove(tr, srs, k, k, [0], [a.tobytes() for a in circ.h_preprocess], 3, 0, lookups, [10, 11, 12],
+                            perm, num_z, co.flatten_expression(expression), [[]], [a.tobytes() for a in circ.h_witness])
+        ms = (time.perf_counter() - t) * 1e3
+        return ms, tr.into_proof() == gpu_proof_fn(pp, circ)
+
+    k = args.cpu_sample_log_n
+    if not k:
+        k = min(14, args.log_n)
+        ms, _ = run(k)
+        while k < args.log_n and ms * 2.2 < 25e3:
+            k += 1
+            ms *= 2.2
+    ms, same = run(k)
+    frac = "the full workload" if k == args.log_n else "1/%d of the workload's rows" % (1 << (args.log_n - k))
+    return {"value": round(ms, 2), "unit": "ms", "cores": co.num_threads(), "kind": "port",
+            "sample": ("one HyperPlonk prove of the same synthetic circuit at 2^%d rows (" + frac + "); C++ oracle = "
+                       "reference algorithms (expression evaluator per point, evaluate-then-bind, Pippenger per thread "
+                       "chunk)") % k,
+            "sample_log_n": k, "proof_bytes_equal_gpu": bool(same)}
+
+
+def main_hyperplonk(args, hdist, dist, rank, local_rank, world):
+    import halo2_lasso_amd as hl
+    from halo2_lasso_amd import hyperplonk as hp, synthetic
+    ctx = hl.Context(int(os.environ.get("LH_DEVICE", local_rank)))
+    k = args.log_n
+    trap = trapdoor(k)
+    pcs_pp = hl.MultilinearKzg.setup(ctx, trap)
+    circ = synthetic.vanilla_plonk_with_lookup(ctx, k, seed=hdist.batch_seed(k, rank) & 0xffffffff)
+    pp = synthetic.prover_param(pcs_pp, circ)
+    ctx.sync()
+
+    def prove(p=pp, c=circ):
+        tr = hl.Keccak256Transcript()
+        hp.HyperPlonk.prove(p, c.instances, c.d_witness, tr)
+        return tr
+
+    def barrier():
+        ctx.sync()
+        if dist is not None and dist.get_backend() == "nccl":
+            import torch
+            torch.cuda.synchronize()
+        hdist.barrier(dist)
+
+    for _ in range(args.warmup):
+        prove()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr = prove()
+    ctx.sync()
+    elapsed = hdist.max_over_ranks(dist, time.perf_counter() - t0)
+    hdist.barrier(dist)
+    ms_per_step = elapsed * 1e3 / max(args.steps, 1)
+    if rank == 0:
+        out = {
+            "metric": "hyperplonk_prove_time_ms", "value": round(ms_per_step / world, 3), "unit": "ms",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u256 (BN254 Fr/Fq, 8x u32 Montgomery)", "data": "synthetic",
+            "config": {"workload": "HyperPlonk + LogUp prove, vanilla_plonk_with_lookup circuit, 2^%d rows (13 polys, one "
+                                   "3-column lookup on 1/4 of the rows, %d copy constraints, degree-5 zero-check)"
+                                   % (k, circ.num_copies),
+                       "rows": 1 << k, "proofs_per_step": world, "pcs": "multilinear KZG (BN254)",
+                       "proof_bytes": len(tr.into_proof()), "parallelism": "1 proof per GPU" if world > 1 else "1 GPU"},
+            "rows_per_s": round((1 << k) * world / (ms_per_step / 1e3)),
+        }
+        if not args.no_profile:
+            hl.profile_enable(ctx, True)
+            prove()
+            ctx.sync()
+            aggs = aggregate(hl.profile_read(ctx))
+            hl.profile_enable(ctx, False)
+            out["roofline"], out["alu"], out["kernels"] = roofline_objects(hl, ctx, aggs)
+        if not args.no_cpu_baseline:
+            def gpu_proof(pcs, c):
+                return prove(synthetic.prover_param(pcs, c), c).into_proof()
+            try:
+                out["cpu_baseline"] = hyperplonk_cpu_baseline(hl, ctx, args, trap, gpu_proof)
+            except Exception as e:
+                if os.environ.get("LH_BENCH_DEBUG"):
+                    raise
+                out["cpu_baseline"] = {"value": None, "unit": "ms", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": "unavailable: %s" % e}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     from halo2_lasso_amd import dist as hdist
     rank, local_rank, world = hdist.env_rank()
     dist = hdist.init()
+    if args.workload == "hyperplonk":
+        return main_hyperplonk(args, hdist, dist, rank, local_rank, world)
 
     import halo2_lasso_amd as hl
     ctx = hl.Context(int(os.environ.get("LH_DEVICE", local_rank)))  # LH_DEVICE: several ranks on one GPU (tests)
@@ -233,25 +370,8 @@ def main():
             ctx.sync()
             aggs = aggregate(hl.profile_read(ctx))
             hl.profile_enable(ctx, False)
-            tot = sum(a["ms"] for a in aggs) or 1.0
-            peak_mul = fr_mul_peak(hl, ctx)
-            dom = aggs[0]
-            big = dom["big"]
-            ach = big["bytes"] / (big["ms"] * 1e-3) / 1e9 if big["ms"] > 0 else 0.0
-            traffic, traffic_src = pmc_traffic(dom["name"], n, args.table)
-            out["roofline"] = {"bound": "hbm", "kernel": dom["name"], "achieved": round(ach, 1), "peak": 8000.0,
-                               "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic,
-                               "traffic_source": traffic_src,
-                               "launch": {"ms": round(big["ms"], 4), "bytes": big["bytes"], "items": big["items"]},
-                               "share_of_profiled_prove": round(dom["ms"] / tot, 3), "launches": dom["launches"]}
-            mul_rate = big["muls"] / (big["ms"] * 1e-3) if big["ms"] > 0 else 0.0
-            out["alu"] = {"bound": "int32-mul", "kernel": dom["name"], "achieved": round(mul_rate / 1e9, 2),
-                          "peak": round(peak_mul / 1e9, 2), "unit": "G Fr-mul/s", "frac": round(mul_rate / peak_mul, 4)}
-            out["kernels"] = [{"name": a["name"], "launches": a["launches"], "ms": round(a["ms"], 3),
-                               "GBps_all": round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1) if a["ms"] > 0 else 0.0,
-                               "GBps_largest": round(a["big"]["bytes"] / (a["big"]["ms"] * 1e-3) / 1e9, 1)
-                               if a["big"]["ms"] > 0 else 0.0}
-                              for a in aggs[:12]]
+            out["roofline"], out["alu"], out["kernels"] = roofline_objects(hl, ctx, aggs,
+                                                                           pmc_traffic(aggs[0]["name"], n, args.table))
         if not args.no_cpu_baseline and not sharded:
             def gpu_proof(nn, dims):
                 bufs = [ctx.upload(d.tobytes()) for d in dims]

@@ -1,0 +1,116 @@
+"""Synthetic circuits for measurement (bench.py --workload hyperplonk, tools/hp_bench.py).
+
+`vanilla_plonk_with_lookup(ctx, k, seed)` builds a satisfied circuit of the reference's
+`vanilla_plonk_with_lookup` shape (backend/hyperplonk/util.rs:63-86,216-316): 13 polys
+(pi | q_l q_r q_m q_o q_c q_lookup t_l t_r t_o | w_l w_r w_o), add / mul gates, one 3-column lookup on a quarter of
+the rows, copy constraints between the two halves of the table, no instances.  Built with numpy and the device
+field ops so that 2^20..2^24 rows take seconds; the reference's generator (a Python loop in the oracle) is used
+for the small parity circuits instead.
+"""
+import numpy as np
+
+from . import hyperplonk as hp
+
+
+class SyntheticCircuit:
+    """host arrays are (2^k, 4) uint64 Montgomery limbs, exactly the bytes the device holds"""
+
+
+def vanilla_plonk_with_lookup(ctx, k, seed=None):
+    import halo2_lasso_amd as hl
+    size = 1 << k
+    lib = ctx.lib
+    rng = np.random.default_rng(k if seed is None else seed)
+
+    def rand_fr(n):
+        a = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+        a[:, 3] &= np.uint64((1 << 60) - 1)  # < 2^252 < r: a uniform-looking field element in Montgomery form
+        return a
+
+    def const_fr(v, n):
+        return np.tile(np.frombuffer(hl.fr_to_bytes(v), dtype=np.uint64), (n, 1))
+
+    def up(a):
+        return hl.MultilinearPolynomial(ctx, ctx.upload(np.ascontiguousarray(a).tobytes()), k)
+
+    def down(p):
+        return np.frombuffer(p.buf.read(), dtype=np.uint64).reshape(size, 4).copy()
+
+    def binop(fn, a, b):
+        out = hl.MultilinearPolynomial(ctx, ctx.alloc(32 * size), k)
+        hl._check(fn(ctx.h, a.ptr, b.ptr, size, out.ptr))
+        return out
+
+    rows = np.arange(size)
+    live = rows < size - 1                     # the reference leaves the last row empty
+    is_add, is_mul = live & (rows % 4 < 2), live & (rows % 4 == 2)
+    is_lookup = live & (rows % 4 == 3)
+    gate = is_add | is_mul
+    zero, one, minus1 = const_fr(0, size), const_fr(1, size), const_fr(hl.R_MOD - 1, size)
+    sel = lambda m, v: np.where(m[:, None], v, zero)
+    q_l = q_r = sel(is_add, one)
+    q_m, q_o, q_c = sel(is_mul, one), sel(gate, minus1), sel(gate, rand_fr(size))
+    q_lookup = sel(is_lookup, one)
+    t_l, t_r, t_o = (sel(rows >= 2, rand_fr(size)) for _ in range(3))
+    t_idx = rng.integers(1, size, size=size)
+    w_l, w_r = sel(gate, rand_fr(size)), sel(gate, rand_fr(size))
+    w_l[is_lookup], w_r[is_lookup] = t_l[t_idx[is_lookup]], t_r[t_idx[is_lookup]]
+    d_ql, d_qm, d_qc = up(q_l), up(q_m), up(q_c)
+
+    def out_column(wl, wr):
+        """w_o = q_l w_l + q_r w_r + q_m w_l w_r + q_c on gate rows (q_o = -1), t_o[t] on lookup rows"""
+        a, b = up(wl), up(wr)
+        lin = binop(lib.lh_fr_mul, d_ql, binop(lib.lh_fr_add, a, b))
+        quad = binop(lib.lh_fr_mul, d_qm, binop(lib.lh_fr_mul, a, b))
+        wo = down(binop(lib.lh_fr_add, binop(lib.lh_fr_add, lin, quad), d_qc))
+        wo[is_lookup] = t_o[t_idx[is_lookup]]
+        return wo
+
+    # copies: gate rows of the second half take w_l from w_o and w_r from w_r of the row half a table earlier
+    w_o = out_column(w_l, w_r)
+    half = size // 2
+    dst = rows[gate & (rows > half)]           # source row = dst - half >= 1
+    src = dst - half
+    w_l[dst], w_r[dst] = w_o[src], w_r[src]
+    w_o = out_column(w_l, w_r)
+    # permutation polys over (w_l, w_r, w_o) = polys 10, 11, 12 (preprocessor.rs:172-203): 2-cycles swap ids
+    ident = lambda p: (np.uint64(p) << np.uint64(k)) + rows.astype(np.uint64)
+    perm = [ident(0), ident(1), ident(2)]
+    perm[0][dst], perm[2][src] = ident(2)[src], ident(0)[dst]      # (w_o, src) <-> (w_l, dst)
+    perm[1][dst], perm[1][src] = ident(1)[src], ident(1)[dst]      # (w_r, src) <-> (w_r, dst)
+    d_perm, h_perm = [], []
+    for p in perm:
+        out = hl.MultilinearPolynomial(ctx, ctx.alloc(32 * size), k)
+        staged = ctx.upload(p.tobytes())
+        hl._check(lib.lh_fr_from_u64(ctx.h, staged.ptr, size, out.ptr))
+        ctx.sync()
+        d_perm.append(out)
+
+    c = SyntheticCircuit()
+    c.k, c.num_copies, c.num_lookups = k, len(dst), int(is_lookup.sum())
+    # nine (device-resident) preprocess polys: compose() only needs their count
+    c.info = hp.vanilla_plonk_with_lookup_circuit_info(k, 0, [[]] * 9, [[(10, 1)], [(11, 1)], [(12, 1)]])
+    c.h_preprocess = [q_l, q_r, q_m, q_o, q_c, q_lookup, t_l, t_r, t_o]
+    c.h_witness = [w_l, w_r, w_o]
+    c.d_preprocess = [up(a) for a in c.h_preprocess]
+    c.d_permutation = d_perm
+    c.d_witness = [up(a) for a in c.h_witness]
+    c.instances = [[]]
+    return c
+
+
+def prover_param(pcs_pp, circuit, pcs_vp=None):
+    """HyperPlonk.preprocess for a SyntheticCircuit whose polys already live on the device -> pp or (pp, vp)"""
+    import halo2_lasso_amd as hl
+    pp = hp.HyperPlonkProverParam()
+    pp.pcs, pp.num_vars, pp.info = pcs_pp, circuit.k, circuit.info
+    pp.preprocess_polys, pp.permutation_polys = circuit.d_preprocess, circuit.d_permutation
+    pp.num_permutation_z_polys, pp.expression = hp.compose(circuit.info)
+    if pcs_vp is None:
+        return pp
+    vp = hp.HyperPlonkVerifierParam()
+    vp.pcs, vp.num_vars, vp.info = pcs_vp, circuit.k, circuit.info
+    vp.num_permutation_z_polys, vp.expression = pp.num_permutation_z_polys, pp.expression
+    vp.preprocess_comms = hl.MultilinearKzg.batch_commit(pcs_pp, pp.preprocess_polys)
+    vp.permutation_comms = hl.MultilinearKzg.batch_commit(pcs_pp, pp.permutation_polys)
+    return pp, vp
