@@ -48,8 +48,10 @@ struct MsmJobDev {
   uint32_t seg_size;    // buckets per segment
   uint32_t win_base;    // first window-sum slot of this job
 };
+constexpr uint32_t KEY_BLOCK_BITS = 10;  // every job's key range starts at a multiple of 2^KEY_BLOCK_BITS
 struct MsmPlanDev {
   int num_jobs;
+  const uint8_t* job_of_block;  // device: job index of the key block key >> KEY_BLOCK_BITS
   MsmJobDev job[MSM_MAX_JOBS];
 };
 
@@ -151,10 +153,10 @@ void sort_pairs_u32(Ctx& c, const uint32_t* keys_in, uint32_t* keys_out, const u
                     size_t n, unsigned bits);
 
 // ------------------------------------------------------------------ 4: segmented accumulate
+// O(1): this runs at every bucket boundary of the accumulate loop, and a wave takes the branch whenever ANY of
+// its lanes crosses a boundary (nearly every iteration), so a linear scan of the job list costs a multiplication.
 __device__ __forceinline__ const MsmJobDev& job_of_key(const MsmPlanDev& plan, uint32_t key) {
-  int j = 0;
-  while (j + 1 < plan.num_jobs && plan.job[j + 1].key_base <= key) j++;
-  return plan.job[j];
+  return plan.job[plan.job_of_block[key >> KEY_BLOCK_BITS]];
 }
 
 // level 0: affine bases, mixed adds
@@ -378,6 +380,7 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
       jd.seg_size = 16;
       jd.seg_per_win = (nb + jd.seg_size - 1) / jd.seg_size;
       jd.win_stride = jd.seg_per_win * jd.seg_size;
+      key = (key + (1u << KEY_BLOCK_BITS) - 1) & ~((1u << KEY_BLOCK_BITS) - 1);
       jd.key_base = key;
       jd.entry_base = (uint32_t)max_entries;
       jd.seg_base = seg;
@@ -404,8 +407,22 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
       uint32_t* sidx = c.arena.alloc_n<uint32_t>(max_entries);
       G1Xyzz* buckets = c.arena.alloc_n<G1Xyzz>(nbuckets);
       G1Xyzz* seg_out = c.arena.alloc_n<G1Xyzz>(nsegs);
-      G1Xyzz* win_out = (G1Xyzz*)c.pin(nwins * sizeof(G1Xyzz));  // pinned host memory, written by the last kernel
+      // pinned host memory: the window sums (written by the last kernel) followed by the key-block table staging
+      const size_t nblocks = (nbuckets >> KEY_BLOCK_BITS) + 1;
+      uint8_t* pin_base = (uint8_t*)c.pin(nwins * sizeof(G1Xyzz) + nblocks);
+      G1Xyzz* win_out = (G1Xyzz*)pin_base;
       uint32_t* lvl_cnt = c.arena.alloc_n<uint32_t>(64);
+      {
+        uint8_t* h_tab = pin_base + nwins * sizeof(G1Xyzz);
+        for (size_t j = 0; j < nj; j++) {
+          const size_t b0 = plan.job[j].key_base >> KEY_BLOCK_BITS;
+          const size_t b1 = j + 1 < nj ? plan.job[j + 1].key_base >> KEY_BLOCK_BITS : nblocks;
+          for (size_t b = b0; b < b1; b++) h_tab[b] = (uint8_t)j;
+        }
+        uint8_t* d_tab = c.arena.alloc_n<uint8_t>(nblocks);
+        LH_HIP(hipMemcpyAsync(d_tab, h_tab, nblocks, hipMemcpyHostToDevice, c.stream));
+        plan.job_of_block = d_tab;
+      }
       LH_HIP(hipMemsetAsync(lvl_cnt, 0, 64 * sizeof(uint32_t), c.stream));
       LH_HIP(hipMemsetAsync(buckets, 0, nbuckets * sizeof(G1Xyzz), c.stream));
       double total_pts = 0, full_pts = 0;
