@@ -88,8 +88,11 @@ __device__ __forceinline__ void finish_round(const ScFinish& f, const Fr* __rest
   if (threadIdx.x == 0) publish_flag(f.flag, f.seq);
 }
 
+#ifndef LH_SC_WAVES_ATTR
+#define LH_SC_WAVES_ATTR
+#endif
 template <int D, bool BIND>
-__global__ __launch_bounds__(256) void sc_round_kernel(ScArgs a, size_t size, uint32_t tp,
+__global__ __launch_bounds__(256) LH_SC_WAVES_ATTR void sc_round_kernel(ScArgs a, size_t size, uint32_t tp,
                                                        Fr* __restrict__ partials, ScFinish fin) {
   __shared__ Fr lds[4];
   const ScRound& rd = a.rd;
