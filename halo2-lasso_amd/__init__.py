@@ -647,6 +647,154 @@ def lasso_verify(vp, table, num_vars, transcript):
         raise InvalidSnark("trailing bytes in proof")
 
 
+# ------------------------------------------------------------------ pcs::multilinear::zeromorph over pcs::univariate::kzg
+class UnivariateKzgParams:
+    """UnivariateKzgParam (pcs/univariate/kzg.rs:38-66): powers_of_s_g1 resident on the device"""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+
+    @property
+    def size(self):
+        return self.ctx.lib.lh_usrs_size(self.h)
+
+    def powers(self):
+        n = self.size
+        out = C.create_string_buffer(64 * n)
+        _check(self.ctx.lib.lh_usrs_download(self.ctx.h, self.h, out))
+        return [g1_from_bytes(out.raw[64 * i:64 * i + 64]) for i in range(n)]
+
+    def free(self):
+        if self.h and self.ctx.h:
+            self.ctx.lib.lh_usrs_free(self.ctx.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class ZeromorphProverParam:
+    """ZeromorphKzgProverParam (zeromorph.rs:29-40) = the device SRS + the trim size"""
+
+    def __init__(self, params, poly_size):
+        self.params, self.poly_size, self.ctx = params, poly_size, params.ctx
+
+
+class ZeromorphVerifierParam:
+    """ZeromorphKzgVerifierParam (zeromorph.rs:42-65), host only"""
+
+    def __init__(self, handle):
+        self.lib, self.h = _ffi.load(), handle
+
+    @classmethod
+    def setup(cls, s, param_size, poly_size):
+        h = C.c_void_p()
+        _check(_ffi.load().lh_zeromorph_vp_setup(_fr_array([s]), param_size, poly_size, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def new(cls, g1, g2, s_g2, s_offset_g2):
+        h, a = C.c_void_p(), _ffi.lh_g1()
+        C.memmove(C.byref(a), g1_to_bytes(g1), 64)
+        gs = []
+        for p in (g2, s_g2, s_offset_g2):
+            b = _ffi.lh_g2()
+            C.memmove(C.byref(b), g2_to_bytes(p), 128)
+            gs.append(b)
+        _check(_ffi.load().lh_zeromorph_vp_new(C.byref(a), C.byref(gs[0]), C.byref(gs[1]), C.byref(gs[2]), C.byref(h)))
+        return cls(h)
+
+    def export(self):
+        a, b, c_, d = _ffi.lh_g1(), _ffi.lh_g2(), _ffi.lh_g2(), _ffi.lh_g2()
+        _check(self.lib.lh_zeromorph_vp_export(self.h, C.byref(a), C.byref(b), C.byref(c_), C.byref(d)))
+        return g1_from_bytes(bytes(a)), g2_from_bytes(bytes(b)), g2_from_bytes(bytes(c_)), g2_from_bytes(bytes(d))
+
+    def free(self):
+        if self.h:
+            self.lib.lh_zeromorph_vp_free(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Zeromorph:
+    """Zeromorph<UnivariateKzg<Bn256>> (pcs/multilinear/zeromorph.rs:67-256)"""
+
+    @staticmethod
+    def setup(ctx, s, poly_size):
+        """UnivariateKzg::setup (univariate/kzg.rs:175-218) with the trapdoor explicit"""
+        h = C.c_void_p()
+        _check(ctx.lib.lh_ukzg_setup(ctx.h, _fr_array([s]), poly_size, C.byref(h)))
+        return UnivariateKzgParams(ctx, h)
+
+    @staticmethod
+    def upload(ctx, powers):
+        h = C.c_void_p()
+        _check(ctx.lib.lh_usrs_upload(ctx.h, b"".join(g1_to_bytes(p) for p in powers), len(powers), C.byref(h)))
+        return UnivariateKzgParams(ctx, h)
+
+    @staticmethod
+    def trim(params, poly_size):
+        """zeromorph.rs:90-108 (prover half)"""
+        if params.size < poly_size:
+            raise InvalidPcsParam("Too large poly_size to trim to (param supports poly_size up to %d but got %d)"
+                                  % (params.size, poly_size))
+        return ZeromorphProverParam(params, poly_size)
+
+    @staticmethod
+    def batch_commit(pp, polys):
+        if not polys:
+            return []
+        out = (lh_g1 * len(polys))()
+        _check(pp.ctx.lib.lh_zeromorph_batch_commit(pp.ctx.h, pp.params.h, pp.poly_size, _ptr_array(polys), len(polys),
+                                                    polys[0].num_vars, out))
+        raw = C.string_at(out, 64 * len(polys))
+        return [g1_from_bytes(raw[64 * i:64 * i + 64]) for i in range(len(polys))]
+
+    @staticmethod
+    def commit(pp, poly):
+        return Zeromorph.batch_commit(pp, [poly])[0]
+
+    @staticmethod
+    def batch_commit_and_write(pp, polys, transcript):
+        comms = Zeromorph.batch_commit(pp, polys)
+        transcript.write_commitments(comms)
+        return comms
+
+    @staticmethod
+    def open(pp, poly, point, transcript):
+        _check(pp.ctx.lib.lh_zeromorph_open(pp.ctx.h, pp.params.h, pp.poly_size, poly.ptr, poly.num_vars,
+                                            _fr_array(point), transcript.p))
+
+    @staticmethod
+    def batch_open(pp, num_vars, polys, points, evals, transcript):
+        for p in points:
+            if len(p) != num_vars:
+                raise InvalidPcsParam("Invalid point (expect point to have %d variates but got %d)" % (num_vars, len(p)))
+        flat = [v for p in points for v in p]
+        _check(pp.ctx.lib.lh_zeromorph_batch_open(pp.ctx.h, pp.params.h, pp.poly_size, num_vars, _ptr_array(polys),
+                                                  len(polys), _fr_array(flat), len(points), _evaluations(evals),
+                                                  len(evals), transcript.p))
+
+    @staticmethod
+    def verify(vp, comm, point, eval_, transcript):
+        _check(vp.lib.lh_zeromorph_verify(vp.h, _g1_array([comm]), _fr_array(point), len(point), _fr_array([eval_]),
+                                          transcript.p))
+
+    @staticmethod
+    def batch_verify(vp, num_vars, comms, points, evals, transcript):
+        flat = [v for p in points for v in p]
+        _check(vp.lib.lh_zeromorph_batch_verify(vp.h, num_vars, _g1_array(comms), len(comms), _fr_array(flat),
+                                                len(points), _evaluations(evals), len(evals), transcript.p))
+
+
 # ------------------------------------------------------------------ Lasso
 class LassoTable:
     """Decomposable table: c chunks of l bits, memories (chunk, subtable), g = sum coeff * prod E_i."""

@@ -187,6 +187,24 @@ SIGNATURES = {
     "lh_lasso_verify": (C.c_int, [_P, C.POINTER(lh_lasso_table), _SZ, C.POINTER(lh_transcript)]),
     "lh_hyperplonk_verify": (C.c_int, [_P, C.POINTER(lh_hp_vparam), C.POINTER(C.POINTER(lh_fr)),
                                        C.POINTER(lh_transcript)]),
+    "lh_ukzg_setup": (C.c_int, [_P, C.POINTER(lh_fr), _SZ, C.POINTER(_P)]),
+    "lh_usrs_upload": (C.c_int, [_P, C.c_char_p, _SZ, C.POINTER(_P)]),
+    "lh_usrs_download": (C.c_int, [_P, _P, C.c_char_p]),
+    "lh_usrs_size": (_SZ, [_P]),
+    "lh_usrs_free": (None, [_P, _P]),
+    "lh_zeromorph_batch_commit": (C.c_int, [_P, _P, _SZ, C.POINTER(_P), _SZ, _SZ, C.POINTER(lh_g1)]),
+    "lh_zeromorph_open": (C.c_int, [_P, _P, _SZ, _P, _SZ, C.POINTER(lh_fr), C.POINTER(lh_transcript)]),
+    "lh_zeromorph_batch_open": (C.c_int, [_P, _P, _SZ, _SZ, C.POINTER(_P), _SZ, C.POINTER(lh_fr), _SZ,
+                                          C.POINTER(lh_evaluation), _SZ, C.POINTER(lh_transcript)]),
+    "lh_zeromorph_vp_setup": (C.c_int, [C.POINTER(lh_fr), _SZ, _SZ, C.POINTER(_P)]),
+    "lh_zeromorph_vp_new": (C.c_int, [C.POINTER(lh_g1), C.POINTER(lh_g2), C.POINTER(lh_g2), C.POINTER(lh_g2),
+                                      C.POINTER(_P)]),
+    "lh_zeromorph_vp_export": (C.c_int, [_P, C.POINTER(lh_g1), C.POINTER(lh_g2), C.POINTER(lh_g2), C.POINTER(lh_g2)]),
+    "lh_zeromorph_vp_free": (None, [_P]),
+    "lh_zeromorph_verify": (C.c_int, [_P, C.POINTER(lh_g1), C.POINTER(lh_fr), _SZ, C.POINTER(lh_fr),
+                                      C.POINTER(lh_transcript)]),
+    "lh_zeromorph_batch_verify": (C.c_int, [_P, _SZ, C.POINTER(lh_g1), _SZ, C.POINTER(lh_fr), _SZ,
+                                            C.POINTER(lh_evaluation), _SZ, C.POINTER(lh_transcript)]),
     "lh_profile_enable": (C.c_int, [_P, C.c_int]),
     "lh_profile_read": (C.c_int, [_P, C.POINTER(lh_prof_rec), _SZ, C.POINTER(_SZ)]),
 }

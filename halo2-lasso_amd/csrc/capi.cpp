@@ -12,6 +12,12 @@ struct lh_srs {
 struct lh_mkzg_vp {
   VerifierParams* p;
 };
+struct lh_usrs {
+  USrs s;
+};
+struct lh_zm_vp {
+  ZmVerifierParams* p;
+};
 
 #define LH_TRY try {
 #define LH_CATCH                                  \
@@ -537,6 +543,138 @@ lh_status lh_hyperplonk_verify(const lh_mkzg_vp* vp, const lh_hp_vparam* hvp, co
   NEED(hvp);
   Transcript tr(t);
   hyperplonk_verify(*vp->p, *hvp, (const HFr* const*)instances, tr);
+  LH_CATCH
+}
+
+// ---------------------------------------------------------------- Zeromorph over univariate KZG
+lh_status lh_ukzg_setup(lh_ctx* ctx, const lh_fr* s, size_t poly_size, lh_usrs** out) {
+  LH_TRY NEED(ctx);
+  NEED(s);
+  NEED(out);
+  HFr sv;
+  memcpy(&sv, s, 32);
+  USrs* u = ukzg_setup(ctx->c, sv, poly_size);
+  *out = new lh_usrs{*u};
+  delete u;
+  LH_CATCH
+}
+lh_status lh_usrs_upload(lh_ctx* ctx, const lh_g1* powers, size_t poly_size, lh_usrs** out) {
+  LH_TRY NEED(ctx);
+  NEED(powers);
+  NEED(out);
+  LH_REQUIRE(poly_size >= 1 && poly_size < ((size_t)1 << 31), LH_ERR_ARG, "univariate srs: bad poly_size");
+  lh_usrs* w = new lh_usrs();
+  w->s.size = poly_size;
+  LH_HIP(hipMalloc((void**)&w->s.d_powers, poly_size * sizeof(G1Affine)));
+  LH_HIP(hipMemcpyAsync(w->s.d_powers, powers, poly_size * sizeof(G1Affine), hipMemcpyHostToDevice, ctx->c.stream));
+  ctx->c.sync();
+  *out = w;
+  LH_CATCH
+}
+lh_status lh_usrs_download(lh_ctx* ctx, const lh_usrs* srs, lh_g1* powers) {
+  LH_TRY NEED(ctx);
+  NEED(srs);
+  NEED(powers);
+  LH_HIP(hipMemcpyAsync(powers, srs->s.d_powers, srs->s.size * sizeof(G1Affine), hipMemcpyDeviceToHost, ctx->c.stream));
+  ctx->c.sync();
+  LH_CATCH
+}
+size_t lh_usrs_size(const lh_usrs* srs) { return srs ? srs->s.size : 0; }
+void lh_usrs_free(lh_ctx* ctx, lh_usrs* srs) {
+  if (!srs) return;
+  if (ctx) (void)hipStreamSynchronize(ctx->c.stream);
+  if (srs->s.d_powers) (void)hipFree(srs->s.d_powers);
+  delete srs;
+}
+lh_status lh_zeromorph_batch_commit(lh_ctx* ctx, const lh_usrs* srs, size_t poly_size, const lh_fr* const* d_polys,
+                                    size_t num_polys, size_t num_vars, lh_g1* out_comms) {
+  LH_TRY NEED(ctx);
+  NEED(srs);
+  LH_REQUIRE((d_polys && out_comms) || !num_polys, LH_ERR_ARG, "null argument: polys");
+  std::vector<HG1> c = zeromorph_batch_commit(ctx->c, srs->s, poly_size, (const Fr* const*)d_polys, num_polys, num_vars);
+  if (num_polys) memcpy(out_comms, c.data(), 64 * num_polys);
+  LH_CATCH
+}
+lh_status lh_zeromorph_open(lh_ctx* ctx, const lh_usrs* srs, size_t poly_size, const lh_fr* d_poly, size_t num_vars,
+                            const lh_fr* point, lh_transcript* t) {
+  LH_TRY NEED(ctx);
+  NEED(srs);
+  NEED(d_poly);
+  NEED(point);
+  Transcript tr(t);
+  zeromorph_open(ctx->c, srs->s, poly_size, (const Fr*)d_poly, num_vars, (const HFr*)point, tr);
+  LH_CATCH
+}
+lh_status lh_zeromorph_batch_open(lh_ctx* ctx, const lh_usrs* srs, size_t poly_size, size_t num_vars,
+                                  const lh_fr* const* d_polys, size_t num_polys, const lh_fr* points,
+                                  size_t num_points, const lh_evaluation* evals, size_t num_evals, lh_transcript* t) {
+  LH_TRY NEED(ctx);
+  NEED(srs);
+  NEED(d_polys);
+  NEED(points);
+  NEED(evals);
+  Transcript tr(t);
+  zeromorph_batch_open(ctx->c, srs->s, poly_size, num_vars, (const Fr* const*)d_polys, num_polys, (const HFr*)points,
+                       num_points, evals, num_evals, tr);
+  LH_CATCH
+}
+lh_status lh_zeromorph_vp_setup(const lh_fr* s, size_t param_size, size_t poly_size, lh_zm_vp** out) {
+  LH_TRY
+  NEED(s);
+  NEED(out);
+  HFr sv;
+  memcpy(&sv, s, 32);
+  *out = new lh_zm_vp{zeromorph_vp_setup(sv, param_size, poly_size)};
+  LH_CATCH
+}
+lh_status lh_zeromorph_vp_new(const lh_g1* g1, const lh_g2* g2, const lh_g2* s_g2, const lh_g2* s_offset_g2,
+                              lh_zm_vp** out) {
+  LH_TRY
+  NEED(g1);
+  NEED(g2);
+  NEED(s_g2);
+  NEED(s_offset_g2);
+  NEED(out);
+  *out = new lh_zm_vp{zeromorph_vp_new(*g1, *g2, *s_g2, *s_offset_g2)};
+  LH_CATCH
+}
+lh_status lh_zeromorph_vp_export(const lh_zm_vp* vp, lh_g1* g1, lh_g2* g2, lh_g2* s_g2, lh_g2* s_offset_g2) {
+  LH_TRY
+  NEED(vp);
+  zeromorph_vp_export(*vp->p, g1, g2, s_g2, s_offset_g2);
+  LH_CATCH
+}
+void lh_zeromorph_vp_free(lh_zm_vp* vp) {
+  if (!vp) return;
+  zeromorph_vp_free(vp->p);
+  delete vp;
+}
+lh_status lh_zeromorph_verify(const lh_zm_vp* vp, const lh_g1* comm, const lh_fr* point, size_t num_vars,
+                              const lh_fr* eval, lh_transcript* t) {
+  LH_TRY
+  NEED(vp);
+  NEED(comm);
+  NEED(eval);
+  LH_REQUIRE(point || !num_vars, LH_ERR_ARG, "null argument: point");
+  Transcript tr(t);
+  HG1 c;
+  memcpy(&c, comm, sizeof(c));
+  HFr e;
+  memcpy(&e, eval, 32);
+  zeromorph_verify(*vp->p, c, (const HFr*)point, num_vars, e, tr);
+  LH_CATCH
+}
+lh_status lh_zeromorph_batch_verify(const lh_zm_vp* vp, size_t num_vars, const lh_g1* comms, size_t num_comms,
+                                    const lh_fr* points, size_t num_points, const lh_evaluation* evals,
+                                    size_t num_evals, lh_transcript* t) {
+  LH_TRY
+  NEED(vp);
+  NEED(comms);
+  NEED(points);
+  NEED(evals);
+  Transcript tr(t);
+  zeromorph_batch_verify(*vp->p, num_vars, (const HG1*)comms, num_comms, (const HFr*)points, num_points, evals,
+                         num_evals, tr);
   LH_CATCH
 }
 

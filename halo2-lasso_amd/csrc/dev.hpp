@@ -285,6 +285,15 @@ void k_permutation_z(Ctx&, const Fr* const* values, const Fr* const* perms, size
                      Fr* const* z_out);
 void k_scatter_rows(Ctx&, const uint32_t* d_rows, const Fr* d_vals, size_t count, size_t n, Fr* table);
 
+// ------------------------------------------------------------------ Zeromorph / univariate KZG (kernels_zm.hip)
+void k_powers(Ctx&, const Fr& s, size_t n, Fr* out);  // out[i] = s^i
+// q: quotients flat (q_k at offset 2^k - 1); ypow / q_scalars: host arrays of num_vars elements
+void k_zm_qhat(Ctx&, const Fr* q, size_t num_vars, const Fr* ypow, Fr* q_hat);
+void k_zm_combine(Ctx&, const Fr* poly, const Fr* q_hat, const Fr* q, size_t num_vars, const Fr& z,
+                  const Fr* q_scalars, Fr* f);
+// out[i] = sum_{j >= i} f_j x^(j - i): out[1..] is the quotient of f by (X - x), out[0] = f(x)
+void k_suffix_horner(Ctx&, const Fr* f, size_t n, const Fr& x, Fr* out);
+
 // ------------------------------------------------------------------ MSM (msm.hip)
 struct MsmJob {
   const void* scalars;  // Fr (Montgomery) or u32

@@ -168,6 +168,37 @@ void mkzg_batch_open(Ctx&, const Srs&, size_t num_vars, const Fr* const* d_polys
                      const HFr* points, size_t num_points, const lh_evaluation* evals, size_t num_evals,
                      Transcript& tr);
 
+void additive_batch_open(Ctx&, size_t num_vars, const Fr* const* d_polys, size_t num_polys, const HFr* points,
+                         size_t num_points, const lh_evaluation* evals, size_t num_evals, Transcript& tr,
+                         const std::function<void(const Fr* g_prime, const HFr* point)>& open);
+
+// ------------------------------------------------------------------ pcs::multilinear::zeromorph over pcs::univariate::kzg
+struct USrs {  // UnivariateKzgParam (univariate/kzg.rs:38-66): powers_of_s_g1 on the device
+  G1Affine* d_powers = nullptr;
+  size_t size = 0;
+};
+USrs* ukzg_setup(Ctx&, const HFr& s, size_t poly_size);
+// poly_size: the trim size (zeromorph.rs:90-108): commits use powers[..poly_size], the final quotient powers[size - poly_size..]
+std::vector<HG1> zeromorph_batch_commit(Ctx&, const USrs&, size_t poly_size, const Fr* const* d_polys, size_t num_polys,
+                                        size_t num_vars);
+void zeromorph_open(Ctx&, const USrs&, size_t poly_size, const Fr* d_poly, size_t num_vars, const HFr* point,
+                    Transcript& tr);
+void zeromorph_batch_open(Ctx&, const USrs&, size_t poly_size, size_t num_vars, const Fr* const* d_polys,
+                          size_t num_polys, const HFr* points, size_t num_points, const lh_evaluation* evals,
+                          size_t num_evals, Transcript& tr);
+// zeromorph.rs:258-296 -> (eval_scalar, q_scalars)
+std::pair<HFr, std::vector<HFr>> zeromorph_scalars(const HFr& y, const HFr& x, const HFr& z, const HFr* u, size_t n);
+struct ZmVerifierParams;  // ZeromorphKzgVerifierParam (zeromorph.rs:42-65)
+ZmVerifierParams* zeromorph_vp_setup(const HFr& s, size_t param_size, size_t poly_size);
+ZmVerifierParams* zeromorph_vp_new(const lh_g1& g1, const lh_g2& g2, const lh_g2& s_g2, const lh_g2& s_offset_g2);
+void zeromorph_vp_export(const ZmVerifierParams&, lh_g1* g1, lh_g2* g2, lh_g2* s_g2, lh_g2* s_offset_g2);
+void zeromorph_vp_free(ZmVerifierParams*);
+void zeromorph_verify(const ZmVerifierParams&, const HG1& comm, const HFr* point, size_t num_vars, const HFr& eval,
+                      Transcript& tr);
+void zeromorph_batch_verify(const ZmVerifierParams&, size_t num_vars, const HG1* comms, size_t num_comms,
+                            const HFr* points, size_t num_points, const lh_evaluation* evals, size_t num_evals,
+                            Transcript& tr);
+
 // ------------------------------------------------------------------ Lasso
 void lasso_prove(Ctx&, const Srs&, const lh_lasso_table& table, size_t num_vars, const uint32_t* const* d_dims,
                  Transcript& tr);

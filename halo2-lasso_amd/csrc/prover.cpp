@@ -644,11 +644,11 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
   return remainder;
 }
 
-// batch_open: pcs/multilinear.rs:134-235
-void mkzg_batch_open(Ctx& c, const Srs& srs, size_t num_vars, const Fr* const* d_polys, size_t num_polys,
-                     const HFr* points, size_t num_points, const lh_evaluation* evals, size_t num_evals,
-                     Transcript& tr) {
-  check_commit_vars(srs, num_vars, "batch open");
+// additive::batch_open (pcs/multilinear.rs:134-235), generic over the PCS: reduce to ONE opening of g' at the
+// sum-check challenges and hand it to `open`
+void additive_batch_open(Ctx& c, size_t num_vars, const Fr* const* d_polys, size_t num_polys, const HFr* points,
+                         size_t num_points, const lh_evaluation* evals, size_t num_evals, Transcript& tr,
+                         const std::function<void(const Fr* g_prime, const HFr* point)>& open) {
   LH_REQUIRE(num_vars >= 1, LH_ERR_ARG, "batch open: num_vars == 0");
   LH_REQUIRE(num_evals >= 2, LH_ERR_ARG,
              "batch open needs >= 2 evaluations (eq_xy of an empty point is the zero poly, multilinear.rs:92-94)");
@@ -705,7 +705,15 @@ void mkzg_batch_open(Ctx& c, const Srs& srs, size_t num_vars, const Fr* const* d
     w[j] = dev(host_eq_xy_eval(sc.challenges.data(), points + j * num_vars, num_vars));
   Fr* g_prime = c.arena.alloc_n<Fr>(n);
   k_lincomb(c, merged.data(), w.data(), num_points, n, g_prime);
-  mkzg_open(c, srs, g_prime, num_vars, sc.challenges.data(), tr);
+  open(g_prime, sc.challenges.data());
+}
+
+void mkzg_batch_open(Ctx& c, const Srs& srs, size_t num_vars, const Fr* const* d_polys, size_t num_polys,
+                     const HFr* points, size_t num_points, const lh_evaluation* evals, size_t num_evals,
+                     Transcript& tr) {
+  check_commit_vars(srs, num_vars, "batch open");
+  additive_batch_open(c, num_vars, d_polys, num_polys, points, num_points, evals, num_evals, tr,
+                      [&](const Fr* g_prime, const HFr* point) { mkzg_open(c, srs, g_prime, num_vars, point, tr); });
 }
 
 }  // namespace lh

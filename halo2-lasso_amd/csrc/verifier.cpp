@@ -124,13 +124,10 @@ void mkzg_verify(const VerifierParams& vp, const HG1& comm, const HFr* point, si
   if (!host::pairings_product_is_identity(pairs)) throw Error(LH_ERR_INVALID_PCS_OPEN, "Invalid multilinear KZG open");
 }
 
-void mkzg_batch_verify(const VerifierParams& vp, size_t num_vars, const HG1* comms, size_t num_comms,
-                       const HFr* points, size_t num_points, const lh_evaluation* evals, size_t num_evals,
-                       Transcript& tr) {
-  if (num_vars > vp.ss.size())
-    throw Error(LH_ERR_INVALID_PCS_PARAM,
-                "Too many variates of poly to batch verify (param supports variates up to " +
-                    std::to_string(vp.ss.size()) + " but got " + std::to_string(num_vars) + ")");
+// additive::batch_verify (pcs/multilinear.rs:237-276), generic over the PCS
+static void additive_batch_verify(size_t num_vars, const HG1* comms, size_t num_comms, const HFr* points,
+                                  size_t num_points, const lh_evaluation* evals, size_t num_evals, Transcript& tr,
+                                  const std::function<void(const HG1&, const HFr*, const HFr&)>& verify) {
   for (size_t i = 0; i < num_evals; i++)
     LH_REQUIRE(evals[i].poly < num_comms && evals[i].point < num_points, LH_ERR_ARG, "batch verify: bad evaluation");
   size_t ell = 0;
@@ -150,7 +147,77 @@ void mkzg_batch_verify(const VerifierParams& vp, size_t num_vars, const HG1* com
   host::G1Xyzz acc = host::G1Xyzz::identity();  // sum_with_scalar (kzg.rs:138-149)
   for (size_t i = 0; i < num_evals; i++)
     acc = host::g1_add(acc, host::g1_mul(host::g1_from_affine(comms[evals[i].poly]), eq_evals[evals[i].point] * eq_xt[i]));
-  mkzg_verify(vp, host::g1_to_affine(acc), x.data(), num_vars, res.first, tr);
+  verify(host::g1_to_affine(acc), x.data(), res.first);
+}
+
+void mkzg_batch_verify(const VerifierParams& vp, size_t num_vars, const HG1* comms, size_t num_comms,
+                       const HFr* points, size_t num_points, const lh_evaluation* evals, size_t num_evals,
+                       Transcript& tr) {
+  if (num_vars > vp.ss.size())
+    throw Error(LH_ERR_INVALID_PCS_PARAM,
+                "Too many variates of poly to batch verify (param supports variates up to " +
+                    std::to_string(vp.ss.size()) + " but got " + std::to_string(num_vars) + ")");
+  additive_batch_verify(num_vars, comms, num_comms, points, num_points, evals, num_evals, tr,
+                        [&](const HG1& comm, const HFr* x, const HFr& eval) { mkzg_verify(vp, comm, x, num_vars, eval, tr); });
+}
+
+// ------------------------------------------------------------------ Zeromorph::verify (zeromorph.rs:215-256)
+struct ZmVerifierParams {
+  HG1 g1;
+  G2Affine g2, s_g2, s_offset_g2;
+};
+ZmVerifierParams* zeromorph_vp_setup(const HFr& s, size_t param_size, size_t poly_size) {
+  LH_REQUIRE(poly_size >= 1 && poly_size <= param_size, LH_ERR_INVALID_PCS_PARAM, "Too large poly_size to trim to");
+  auto* vp = new ZmVerifierParams();
+  vp->g1 = HG1{host::Fq::from_u64(1), host::Fq::from_u64(2)};
+  vp->g2 = host::g2_generator();
+  host::G2Xyzz g = host::g2_from_affine(vp->g2);
+  vp->s_g2 = host::g2_to_affine(host::g2_mul(g, s));
+  HFr so = HFr::one();  // s^(param_size - poly_size)
+  for (size_t i = 0; i < param_size - poly_size; i++) so *= s;
+  vp->s_offset_g2 = host::g2_to_affine(host::g2_mul(g, so));
+  return vp;
+}
+ZmVerifierParams* zeromorph_vp_new(const lh_g1& g1, const lh_g2& g2, const lh_g2& s_g2, const lh_g2& s_offset_g2) {
+  auto* vp = new ZmVerifierParams();
+  memcpy(&vp->g1, &g1, sizeof(HG1));
+  vp->g2 = g2_from_c(g2), vp->s_g2 = g2_from_c(s_g2), vp->s_offset_g2 = g2_from_c(s_offset_g2);
+  if (!host::g2_is_on_curve(vp->g2) || !host::g2_is_on_curve(vp->s_g2) || !host::g2_is_on_curve(vp->s_offset_g2)) {
+    delete vp;
+    throw Error(LH_ERR_SERIALIZATION, "verifier params: G2 point not on the curve");
+  }
+  return vp;
+}
+void zeromorph_vp_export(const ZmVerifierParams& vp, lh_g1* g1, lh_g2* g2, lh_g2* s_g2, lh_g2* s_offset_g2) {
+  if (g1) memcpy(g1, &vp.g1, sizeof(HG1));
+  if (g2) *g2 = g2_to_c(vp.g2);
+  if (s_g2) *s_g2 = g2_to_c(vp.s_g2);
+  if (s_offset_g2) *s_offset_g2 = g2_to_c(vp.s_offset_g2);
+}
+void zeromorph_vp_free(ZmVerifierParams* vp) { delete vp; }
+
+void zeromorph_verify(const ZmVerifierParams& vp, const HG1& comm, const HFr* point, size_t num_vars, const HFr& eval,
+                      Transcript& tr) {
+  std::vector<HG1> q_comms = tr.read_commitments(num_vars);
+  const HFr y = tr.squeeze_challenge();
+  const HG1 q_hat_comm = tr.read_commitment();
+  const HFr x = tr.squeeze_challenge(), z = tr.squeeze_challenge();
+  auto sc = zeromorph_scalars(y, x, z, point, num_vars);
+  host::G1Xyzz c = host::g1_from_affine(q_hat_comm);
+  c = host::g1_add(c, host::g1_mul(host::g1_from_affine(comm), z));
+  c = host::g1_add(c, host::g1_mul(host::g1_from_affine(vp.g1), sc.first * eval));
+  for (size_t k = 0; k < num_vars; k++) c = host::g1_add(c, host::g1_mul(host::g1_from_affine(q_comms[k]), sc.second[k]));
+  const HG1 pi = tr.read_commitment();
+  host::G2Xyzz rhs = host::g2_add(host::g2_from_affine(vp.s_g2), host::g2_mul(host::g2_from_affine(vp.g2), -x));
+  if (!host::pairings_product_is_identity({{host::g1_to_affine(c), host::g2_neg(vp.s_offset_g2)},
+                                            {pi, host::g2_to_affine(rhs)}}))
+    throw Error(LH_ERR_INVALID_PCS_OPEN, "Invalid Zeromorph KZG open");
+}
+void zeromorph_batch_verify(const ZmVerifierParams& vp, size_t num_vars, const HG1* comms, size_t num_comms,
+                            const HFr* points, size_t num_points, const lh_evaluation* evals, size_t num_evals,
+                            Transcript& tr) {
+  additive_batch_verify(num_vars, comms, num_comms, points, num_points, evals, num_evals, tr,
+                        [&](const HG1& comm, const HFr* x, const HFr& eval) { zeromorph_verify(vp, comm, x, num_vars, eval, tr); });
 }
 
 // ------------------------------------------------------------------ expressions on the host

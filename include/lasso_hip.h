@@ -331,6 +331,40 @@ typedef struct lh_hp_vparam { /* HyperPlonkVerifierParam (hyperplonk.rs:57-74) *
 lh_status lh_hyperplonk_verify(const lh_mkzg_vp*, const lh_hp_vparam*, const lh_fr* const* instances,
                                lh_transcript* t);
 
+/* ---------------------------------------------------------------- f3: Zeromorph over univariate KZG
+ * PolynomialCommitmentScheme for Zeromorph<UnivariateKzg<Bn256>> (pcs/multilinear/zeromorph.rs:67-256 on top of
+ * pcs/univariate/kzg.rs:23-36,161-378): a multilinear table of 2^n evaluations is committed as the coefficient
+ * vector of a univariate polynomial against powers_of_s_g1 (2^n points instead of multilinear KZG's 2^(n+1)-1).
+ * `poly_size` is the trim size (zeromorph.rs:90-108): commitments use powers[..poly_size], the final quotient of
+ * an opening powers[size - poly_size..]. */
+typedef struct lh_usrs lh_usrs; /* UnivariateKzgParam: powers_of_s_g1 on the device */
+lh_status lh_ukzg_setup(lh_ctx*, const lh_fr* s, size_t poly_size, lh_usrs** out); /* kzg.rs:175-218, trapdoor explicit */
+lh_status lh_usrs_upload(lh_ctx*, const lh_g1* powers_of_s_g1, size_t poly_size, lh_usrs** out);
+lh_status lh_usrs_download(lh_ctx*, const lh_usrs*, lh_g1* powers_of_s_g1);
+size_t lh_usrs_size(const lh_usrs*);
+void lh_usrs_free(lh_ctx*, lh_usrs*);
+lh_status lh_zeromorph_batch_commit(lh_ctx*, const lh_usrs*, size_t poly_size, const lh_fr* const* d_polys,
+                                    size_t num_polys, size_t num_vars, lh_g1* out_comms);
+/* zeromorph.rs:134-199: writes n quotient commitments, q_hat's commitment and the KZG proof pi */
+lh_status lh_zeromorph_open(lh_ctx*, const lh_usrs*, size_t poly_size, const lh_fr* d_poly, size_t num_vars,
+                            const lh_fr* point, lh_transcript* t);
+lh_status lh_zeromorph_batch_open(lh_ctx*, const lh_usrs*, size_t poly_size, size_t num_vars,
+                                  const lh_fr* const* d_polys, size_t num_polys, const lh_fr* points,
+                                  size_t num_points, const lh_evaluation* evals, size_t num_evals, lh_transcript* t);
+/* verifier half (host only): ZeromorphKzgVerifierParam = (g1, g2, [s]_2, [s^offset]_2) */
+typedef struct lh_zm_vp lh_zm_vp;
+lh_status lh_zeromorph_vp_setup(const lh_fr* s, size_t param_size, size_t poly_size, lh_zm_vp** out);
+lh_status lh_zeromorph_vp_new(const lh_g1* g1, const lh_g2* g2, const lh_g2* s_g2, const lh_g2* s_offset_g2,
+                              lh_zm_vp** out);
+lh_status lh_zeromorph_vp_export(const lh_zm_vp*, lh_g1* g1, lh_g2* g2, lh_g2* s_g2, lh_g2* s_offset_g2);
+void lh_zeromorph_vp_free(lh_zm_vp*);
+/* LH_ERR_INVALID_PCS_OPEN "Invalid Zeromorph KZG open" on a failed pairing check (zeromorph.rs:215-247) */
+lh_status lh_zeromorph_verify(const lh_zm_vp*, const lh_g1* comm, const lh_fr* point, size_t num_vars,
+                              const lh_fr* eval, lh_transcript* t);
+lh_status lh_zeromorph_batch_verify(const lh_zm_vp*, size_t num_vars, const lh_g1* comms, size_t num_comms,
+                                    const lh_fr* points, size_t num_points, const lh_evaluation* evals,
+                                    size_t num_evals, lh_transcript* t);
+
 /* ---------------------------------------------------------------- measurement (bench.py)
  * Per-kernel HIP-event timing on the ctx stream.  While enabled every instrumented launch is
  * synchronised, so whole-prove wall time is NOT representative; use a separate pass. */

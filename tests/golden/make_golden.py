@@ -11,7 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from oracle.pyref import gkr, kzg, lasso, sum_check as sc, expression as ex, hyperplonk as hp  # noqa: E402
+from oracle.pyref import gkr, kzg, lasso, sum_check as sc, expression as ex, hyperplonk as hp, zeromorph as zm  # noqa: E402
 from oracle.pyref.field import R_MOD as P  # noqa: E402
 from oracle.pyref.poly import evaluate, eq_xy  # noqa: E402
 from oracle.pyref.transcript import Keccak256Transcript as T  # noqa: E402
@@ -106,6 +106,27 @@ def main():
                                   "permutations": [[list(c) for c in cyc] for cyc in info.permutations],
                                   "instances": [H(a) for a in instances], "witness": [H(a) for a in witness],
                                   "proof": proof.hex()})
+
+    # Zeromorph over univariate KZG: one opening with a trim offset, one batch opening (own rng)
+    zrng = random.Random(777)
+    s_ = zrng.randrange(1, P)
+    nv = 3
+    zpp, zvp = zm.trim(zm.setup(s_, (1 << nv) + 2), 1 << nv)
+    tabs = [[zrng.randrange(P) for _ in range(1 << nv)] for _ in range(3)]
+    point = [zrng.randrange(P) for _ in range(nv)]
+    t = T()
+    zm.open_(zpp, tabs[0], point, evaluate(tabs[0], point), t)
+    zm.verify(zvp, zm.commit(zpp, tabs[0]), point, evaluate(tabs[0], point), T(t.into_proof()))
+    tb = T()
+    zm.batch_commit_and_write(zpp, tabs, tb)
+    pts = [tb.squeeze_challenges(nv) for _ in range(2)]
+    pairs = [[0, 0], [1, 0], [2, 1], [1, 1]]
+    vals = [evaluate(tabs[p], pts[q]) for p, q in pairs]
+    tb.write_field_elements(vals)
+    zm.batch_open(zpp, nv, tabs, pts, [kzg.Evaluation(p, q, v) for (p, q), v in zip(pairs, vals)], tb)
+    out["zeromorph"] = {"s": hex(s_), "param_size": (1 << nv) + 2, "num_vars": nv, "polys": [H(a) for a in tabs],
+                        "point": H(point), "commitment": [hex(c) for c in zm.commit(zpp, tabs[0])],
+                        "open_proof": t.into_proof().hex(), "pairs": pairs, "batch_proof": tb.into_proof().hex()}
 
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "vectors.json"), "w") as f:
         json.dump(out, f, indent=0)

@@ -90,3 +90,21 @@ def test_golden_hyperplonk(hl, ctx, pp5, idx):
     g_hp.HyperPlonk.prove(pp, [I(a) for a in g["instances"]],
                           [hl.MultilinearPolynomial.new(ctx, I(w)) for w in g["witness"]], t)
     assert t.into_proof().hex() == g["proof"]
+
+
+def test_golden_zeromorph(hl, ctx):
+    g = GOLDEN["zeromorph"]
+    nv, s = g["num_vars"], int(g["s"], 16)
+    pp = hl.Zeromorph.trim(hl.Zeromorph.setup(ctx, s, g["param_size"]), 1 << nv)
+    polys = [hl.MultilinearPolynomial.new(ctx, I(a)) for a in g["polys"]]
+    assert [hex(c) for c in hl.Zeromorph.commit(pp, polys[0])] == g["commitment"]
+    t = hl.Keccak256Transcript()
+    hl.Zeromorph.open(pp, polys[0], I(g["point"]), t)
+    assert t.into_proof().hex() == g["open_proof"]
+    t = hl.Keccak256Transcript()
+    hl.Zeromorph.batch_commit_and_write(pp, polys, t)
+    pts = [t.squeeze_challenges(nv) for _ in range(2)]
+    vals = [polys[p].evaluate(pts[q]) for p, q in g["pairs"]]
+    t.write_field_elements(vals)
+    hl.Zeromorph.batch_open(pp, nv, polys, pts, [hl.Evaluation(p, q, v) for (p, q), v in zip(g["pairs"], vals)], t)
+    assert t.into_proof().hex() == g["batch_proof"]

@@ -204,3 +204,49 @@ def test_hyperplonk_verify_golden(hl, vp5, idx):
         bad[rng.randrange(len(bad))] ^= 1 << rng.randrange(8)
         with pytest.raises(hl.Error):
             g_hp.HyperPlonk.verify(vp, instances, hl.Keccak256Transcript.from_proof(bytes(bad)))
+
+
+# ------------------------------------------------------------------ Zeromorph (oracle proofs, product pairing verifier)
+def test_zeromorph_oracle_round_trip_and_golden():
+    from oracle.pyref import zeromorph as zm
+    g = GOLDEN["zeromorph"]
+    nv, s = g["num_vars"], int(g["s"], 16)
+    pp, vp = zm.trim(zm.setup(s, g["param_size"]), 1 << nv)
+    tabs, point = [I(a) for a in g["polys"]], I(g["point"])
+    assert [hex(c) for c in zm.commit(pp, tabs[0])] == g["commitment"]
+    t = OT()
+    zm.open_(pp, tabs[0], point, evaluate(tabs[0], point), t)
+    assert t.into_proof().hex() == g["open_proof"]
+    zm.verify(vp, zm.commit(pp, tabs[0]), point, evaluate(tabs[0], point), OT(bytes.fromhex(g["open_proof"])))
+    with pytest.raises(o_kzg.PcsError):
+        zm.verify(vp, zm.commit(pp, tabs[1]), point, evaluate(tabs[0], point), OT(bytes.fromhex(g["open_proof"])))
+
+
+def test_zeromorph_product_verifier_on_golden(hl):
+    from oracle.pyref import zeromorph as zm
+    g = GOLDEN["zeromorph"]
+    nv, s = g["num_vars"], int(g["s"], 16)
+    vp = hl.ZeromorphVerifierParam.setup(s, g["param_size"], 1 << nv)
+    g1, g2, s_g2, s_off = vp.export()
+    offset = g["param_size"] - (1 << nv)
+    assert (g1, g2) == (curve.G1_GEN, o_pair.G2_GEN)
+    assert s_g2 == o_pair.g2_mul(o_pair.G2_GEN, s) and s_off == o_pair.g2_mul(o_pair.G2_GEN, pow(s, offset, P))
+    assert hl.ZeromorphVerifierParam.new(g1, g2, s_g2, s_off).export() == (g1, g2, s_g2, s_off)
+    tabs, point = [I(a) for a in g["polys"]], I(g["point"])
+    comm = tuple(int(c, 16) for c in g["commitment"])
+    ev = evaluate(tabs[0], point)
+    proof = bytes.fromhex(g["open_proof"])
+    hl.Zeromorph.verify(vp, comm, point, ev, hl.Keccak256Transcript.from_proof(proof))
+    with pytest.raises(hl.InvalidPcsOpen, match="Invalid Zeromorph KZG open"):
+        hl.Zeromorph.verify(vp, comm, point, (ev + 1) % P, hl.Keccak256Transcript.from_proof(proof))
+    wrong_offset = hl.ZeromorphVerifierParam.setup(s, g["param_size"] + 1, 1 << nv)
+    with pytest.raises(hl.InvalidPcsOpen):
+        hl.Zeromorph.verify(wrong_offset, comm, point, ev, hl.Keccak256Transcript.from_proof(proof))
+    # batch
+    r = hl.Keccak256Transcript.from_proof(bytes.fromhex(g["batch_proof"]))
+    comms = r.read_commitments(3)
+    pts = [r.squeeze_challenges(nv) for _ in range(2)]
+    vals = r.read_field_elements(len(g["pairs"]))
+    assert vals == [evaluate(tabs[p], pts[q]) for p, q in g["pairs"]]
+    hl.Zeromorph.batch_verify(vp, nv, comms, pts, [hl.Evaluation(p, q, v) for (p, q), v in zip(g["pairs"], vals)], r)
+    assert r.remaining() == 0
