@@ -448,7 +448,7 @@ lh_status lh_hyperplonk_prove(lh_ctx* ctx, const lh_srs* srs, const lh_hp_param*
   NEED(srs);
   NEED(pp);
   Transcript tr(t);
-  hyperplonk_prove(ctx->c, srs->s, *pp, (const HFr* const*)instances, (const Fr* const*)d_witness_polys, tr);
+  hyperplonk_prove(ctx->c, mkzg_pcs(ctx->c, srs->s), *pp, (const HFr* const*)instances, (const Fr* const*)d_witness_polys, tr);
   LH_CATCH
 }
 
@@ -542,7 +542,10 @@ lh_status lh_hyperplonk_verify(const lh_mkzg_vp* vp, const lh_hp_vparam* hvp, co
   NEED(vp);
   NEED(hvp);
   Transcript tr(t);
-  hyperplonk_verify(*vp->p, *hvp, (const HFr* const*)instances, tr);
+  const VerifierParams& pcs = *vp->p;
+  hyperplonk_verify([&pcs](size_t nv, const HG1* comms, size_t nc, const HFr* points, size_t np, const lh_evaluation* evals,
+                           size_t ne, Transcript& t2) { mkzg_batch_verify(pcs, nv, comms, nc, points, np, evals, ne, t2); },
+                    *hvp, (const HFr* const*)instances, tr);
   LH_CATCH
 }
 
@@ -675,6 +678,30 @@ lh_status lh_zeromorph_batch_verify(const lh_zm_vp* vp, size_t num_vars, const l
   Transcript tr(t);
   zeromorph_batch_verify(*vp->p, num_vars, (const HG1*)comms, num_comms, (const HFr*)points, num_points, evals,
                          num_evals, tr);
+  LH_CATCH
+}
+
+lh_status lh_hyperplonk_prove_zeromorph(lh_ctx* ctx, const lh_usrs* srs, size_t poly_size, const lh_hp_param* pp,
+                                        const lh_fr* const* instances, const lh_fr* const* d_witness_polys,
+                                        lh_transcript* t) {
+  LH_TRY NEED(ctx);
+  NEED(srs);
+  NEED(pp);
+  Transcript tr(t);
+  hyperplonk_prove(ctx->c, zeromorph_pcs(ctx->c, srs->s, poly_size), *pp, (const HFr* const*)instances,
+                   (const Fr* const*)d_witness_polys, tr);
+  LH_CATCH
+}
+lh_status lh_hyperplonk_verify_zeromorph(const lh_zm_vp* vp, const lh_hp_vparam* hvp, const lh_fr* const* instances,
+                                         lh_transcript* t) {
+  LH_TRY
+  NEED(vp);
+  NEED(hvp);
+  Transcript tr(t);
+  const ZmVerifierParams& pcs = *vp->p;
+  hyperplonk_verify([&pcs](size_t nv, const HG1* comms, size_t nc, const HFr* points, size_t np, const lh_evaluation* evals,
+                           size_t ne, Transcript& t2) { zeromorph_batch_verify(pcs, nv, comms, nc, points, np, evals, ne, t2); },
+                    *hvp, (const HFr* const*)instances, tr);
   LH_CATCH
 }
 

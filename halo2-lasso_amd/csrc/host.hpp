@@ -100,6 +100,11 @@ struct Transcript {
   }
 };
 
+// PolynomialCommitmentScheme::batch_verify of the PCS a backend is generic over
+typedef std::function<void(size_t num_vars, const HG1* comms, size_t num_comms, const HFr* points, size_t num_points,
+                           const lh_evaluation* evals, size_t num_evals, Transcript& tr)>
+    PcsBatchVerify;
+
 // ------------------------------------------------------------------ poly helpers (host side, tiny inputs)
 std::vector<HFr> host_eq_xy(const std::vector<HFr>& y);           // multilinear.rs:91-127
 HFr host_eq_xy_eval(const HFr* x, const HFr* y, size_t n);         // sum_check.rs:112-121
@@ -223,10 +228,20 @@ void mkzg_batch_verify(const VerifierParams&, size_t num_vars, const HG1* comms,
 std::pair<HFr, std::vector<HFr>> sum_check_verify(int prover_kind, size_t num_vars, size_t degree, const HFr& sum,
                                                   Transcript& tr);
 void lasso_verify(const VerifierParams&, const lh_lasso_table& table, size_t num_vars, Transcript& tr);
-void hyperplonk_verify(const VerifierParams&, const lh_hp_vparam& vp, const HFr* const* instances, Transcript& tr);
+void hyperplonk_verify(const PcsBatchVerify& batch_verify, const lh_hp_vparam& vp, const HFr* const* instances,
+                       Transcript& tr);
 
 // ------------------------------------------------------------------ HyperPlonk (hyperplonk.cpp)
-void hyperplonk_prove(Ctx&, const Srs&, const lh_hp_param& pp, const HFr* const* instances,
+// the PolynomialCommitmentScheme the backend is generic over (backend/hyperplonk.rs:76-95)
+struct PcsProver {
+  std::function<std::vector<HG1>(const Fr* const* d_polys, size_t num_polys, size_t num_vars)> batch_commit;
+  std::function<void(size_t num_vars, const Fr* const* d_polys, size_t num_polys, const HFr* points, size_t num_points,
+                     const lh_evaluation* evals, size_t num_evals, Transcript& tr)>
+      batch_open;
+};
+PcsProver mkzg_pcs(Ctx&, const Srs&);
+PcsProver zeromorph_pcs(Ctx&, const USrs&, size_t poly_size);
+void hyperplonk_prove(Ctx&, const PcsProver&, const lh_hp_param& pp, const HFr* const* instances,
                       const Fr* const* d_witness, Transcript& tr);
 
 }  // namespace lh

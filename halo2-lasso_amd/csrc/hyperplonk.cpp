@@ -112,11 +112,31 @@ static void compressed_poly(Ctx& c, const lh_expr* exprs, size_t width, const st
 }
 
 // ------------------------------------------------------------------ HyperPlonk::prove
-void hyperplonk_prove(Ctx& c, const Srs& srs, const lh_hp_param& pp, const HFr* const* instances,
+PcsProver mkzg_pcs(Ctx& c, const Srs& srs) {
+  PcsProver p;
+  p.batch_commit = [&c, &srs](const Fr* const* polys, size_t n, size_t nv) { return mkzg_batch_commit(c, srs, polys, n, nv); };
+  p.batch_open = [&c, &srs](size_t nv, const Fr* const* polys, size_t n, const HFr* points, size_t np,
+                            const lh_evaluation* evals, size_t ne, Transcript& tr) {
+    mkzg_batch_open(c, srs, nv, polys, n, points, np, evals, ne, tr);
+  };
+  return p;
+}
+PcsProver zeromorph_pcs(Ctx& c, const USrs& srs, size_t poly_size) {
+  PcsProver p;
+  p.batch_commit = [&c, &srs, poly_size](const Fr* const* polys, size_t n, size_t nv) {
+    return zeromorph_batch_commit(c, srs, poly_size, polys, n, nv);
+  };
+  p.batch_open = [&c, &srs, poly_size](size_t nv, const Fr* const* polys, size_t n, const HFr* points, size_t np,
+                                       const lh_evaluation* evals, size_t ne, Transcript& tr) {
+    zeromorph_batch_open(c, srs, poly_size, nv, polys, n, points, np, evals, ne, tr);
+  };
+  return p;
+}
+
+void hyperplonk_prove(Ctx& c, const PcsProver& pcs, const lh_hp_param& pp, const HFr* const* instances,
                       const Fr* const* d_witness, Transcript& tr) {
   const size_t nv = pp.num_vars, n = (size_t)1 << nv;
   LH_REQUIRE(nv >= 1 && nv < 32, LH_ERR_ARG, "hyperplonk: bad num_vars");
-  if (nv > srs.num_vars) throw Error(LH_ERR_INVALID_PCS_PARAM, "Too many variates of poly to commit");
   ArenaScope scope(c.arena);
 
   // BooleanHypercube order / nth_map (bh.rs:127-141), host-generated once per call
@@ -161,7 +181,7 @@ void hyperplonk_prove(Ctx& c, const Srs& srs, const lh_hp_param& pp, const HFr* 
   // round 0: witness commitments (single phase: synthesize(0, []) = d_witness)
   std::vector<HFr> challenges;
   {
-    std::vector<HG1> comms = mkzg_batch_commit(c, srs, d_witness, pp.num_witness_polys, nv);
+    std::vector<HG1> comms = pcs.batch_commit(d_witness, pp.num_witness_polys, nv);
     tr.write_commitments(comms);
     for (size_t i = 0; i < pp.num_witness_polys; i++) polys.push_back(d_witness[i]);
     std::vector<HFr> ch = tr.squeeze_challenges(pp.num_challenges);
@@ -189,7 +209,7 @@ void hyperplonk_prove(Ctx& c, const Srs& srs, const lh_hp_param& pp, const HFr* 
   }
   {
     std::vector<const Fr*> mp(m_polys.begin(), m_polys.end());
-    std::vector<HG1> comms = mkzg_batch_commit(c, srs, mp.data(), mp.size(), nv);
+    std::vector<HG1> comms = pcs.batch_commit(mp.data(), mp.size(), nv);
     tr.write_commitments(comms);
   }
 
@@ -211,7 +231,7 @@ void hyperplonk_prove(Ctx& c, const Srs& srs, const lh_hp_param& pp, const HFr* 
   {
     std::vector<const Fr*> hz(h_polys.begin(), h_polys.end());
     hz.insert(hz.end(), z_polys.begin(), z_polys.end());
-    std::vector<HG1> comms = mkzg_batch_commit(c, srs, hz.data(), hz.size(), nv);
+    std::vector<HG1> comms = pcs.batch_commit(hz.data(), hz.size(), nv);
     tr.write_commitments(comms);
   }
 
@@ -266,7 +286,7 @@ void hyperplonk_prove(Ctx& c, const Srs& srs, const lh_hp_param& pp, const HFr* 
     }
   }
   tr.write_field_elements(eval_values);
-  mkzg_batch_open(c, srs, nv, polys.data(), polys.size(), points.data(), num_points, evals.data(), evals.size(), tr);
+  pcs.batch_open(nv, polys.data(), polys.size(), points.data(), num_points, evals.data(), evals.size(), tr);
 }
 
 }  // namespace lh

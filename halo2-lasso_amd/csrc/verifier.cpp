@@ -352,7 +352,7 @@ static HFr rotation_eval(const std::vector<HFr>& x, int rotation, const std::vec
 }
 
 // ------------------------------------------------------------------ HyperPlonk::verify
-void hyperplonk_verify(const VerifierParams& pcs, const lh_hp_vparam& vp, const HFr* const* instances,
+void hyperplonk_verify(const PcsBatchVerify& batch_verify, const lh_hp_vparam& vp, const HFr* const* instances,
                        Transcript& tr) {
   const size_t nv = vp.num_vars;
   LH_REQUIRE(nv >= 1 && nv < 32, LH_ERR_ARG, "hyperplonk: bad num_vars");
@@ -464,7 +464,7 @@ void hyperplonk_verify(const VerifierParams& pcs, const lh_hp_vparam& vp, const 
   }
   comms.insert(comms.end(), m_comms.begin(), m_comms.end());
   comms.insert(comms.end(), hz_comms.begin(), hz_comms.end());
-  mkzg_batch_verify(pcs, nv, comms.data(), comms.size(), points.data(), num_points, evals.data(), evals.size(), tr);
+  batch_verify(nv, comms.data(), comms.size(), points.data(), num_points, evals.data(), evals.size(), tr);
 }
 
 // ------------------------------------------------------------------ Lasso verify (oracle/pyref/lasso.py:219-261)

@@ -106,6 +106,12 @@ class HyperPlonkProverParam:
     """hyperplonk.rs:38-55"""
 
 
+def _pcs_of(pcs_pp):
+    """the PolynomialCommitmentScheme a param belongs to: MultilinearKzg or Zeromorph (backend/hyperplonk.rs:76-95)"""
+    from . import MultilinearKzg, Zeromorph, ZeromorphProverParam
+    return Zeromorph if isinstance(pcs_pp, ZeromorphProverParam) else MultilinearKzg
+
+
 class HyperPlonkVerifierParam:
     """hyperplonk.rs:57-74"""
 
@@ -115,15 +121,16 @@ class HyperPlonk:
     def preprocess(pcs_pp, info, pcs_vp=None):
         """hyperplonk.rs:97-162: preprocess / permutation polys go to the GPU once.  Returns the prover param, or
         (pp, vp) when the PCS verifier param is given."""
-        from . import MultilinearPolynomial, MultilinearKzg
+        from . import MultilinearPolynomial
         ctx = pcs_pp.ctx
+        pcs = _pcs_of(pcs_pp)
         pp = HyperPlonkProverParam()
         pp.pcs, pp.num_vars, pp.info = pcs_pp, info.k, info
         pp.preprocess_polys = [MultilinearPolynomial.new(ctx, p) for p in info.preprocess_polys]
-        pp.preprocess_comms = MultilinearKzg.batch_commit(pcs_pp, pp.preprocess_polys)
+        pp.preprocess_comms = pcs.batch_commit(pcs_pp, pp.preprocess_polys)
         perm = permutation_polys(info.k, info.permutation_polys(), info.permutations)
         pp.permutation_polys = [MultilinearPolynomial.new(ctx, p) for p in perm]
-        pp.permutation_comms = MultilinearKzg.batch_commit(pcs_pp, pp.permutation_polys)
+        pp.permutation_comms = pcs.batch_commit(pcs_pp, pp.permutation_polys)
         pp.num_permutation_z_polys, pp.expression = compose(info)
         if pcs_vp is None:
             return pp
@@ -176,7 +183,12 @@ class HyperPlonk:
         inst_arrays = [_fr_array(i) for i in instances]
         inst = (C.POINTER(lh_fr) * max(len(instances), 1))(*[C.cast(a, C.POINTER(lh_fr)) for a in inst_arrays])
         wit = _ptr_array(witness_polys)
-        _check(ctx.lib.lh_hyperplonk_prove(ctx.h, pp.pcs.h, C.byref(prm), inst, wit, transcript.p))
+        from . import ZeromorphProverParam
+        if isinstance(pp.pcs, ZeromorphProverParam):
+            _check(ctx.lib.lh_hyperplonk_prove_zeromorph(ctx.h, pp.pcs.params.h, pp.pcs.poly_size, C.byref(prm), inst, wit,
+                                                         transcript.p))
+        else:
+            _check(ctx.lib.lh_hyperplonk_prove(ctx.h, pp.pcs.h, C.byref(prm), inst, wit, transcript.p))
 
     @staticmethod
     def verify(vp, instances, transcript):
@@ -201,7 +213,10 @@ class HyperPlonk:
         prm.num_permutation_polys, prm.permutation_comms = len(vp.permutation_comms), perm
         inst_arrays = [_fr_array(i) for i in instances]
         inst = (C.POINTER(lh_fr) * max(len(instances), 1))(*[C.cast(a, C.POINTER(lh_fr)) for a in inst_arrays])
-        _check(vp.pcs.lib.lh_hyperplonk_verify(vp.pcs.h, C.byref(prm), inst, transcript.p))
+        from . import ZeromorphVerifierParam
+        fn = vp.pcs.lib.lh_hyperplonk_verify_zeromorph if isinstance(vp.pcs, ZeromorphVerifierParam) \
+            else vp.pcs.lib.lh_hyperplonk_verify
+        _check(fn(vp.pcs.h, C.byref(prm), inst, transcript.p))
 
 
 # ------------------------------------------------------------------ the reference's sample circuits

@@ -111,6 +111,7 @@ def prover_param(pcs_pp, circuit, pcs_vp=None):
     vp = hp.HyperPlonkVerifierParam()
     vp.pcs, vp.num_vars, vp.info = pcs_vp, circuit.k, circuit.info
     vp.num_permutation_z_polys, vp.expression = pp.num_permutation_z_polys, pp.expression
-    vp.preprocess_comms = hl.MultilinearKzg.batch_commit(pcs_pp, pp.preprocess_polys)
-    vp.permutation_comms = hl.MultilinearKzg.batch_commit(pcs_pp, pp.permutation_polys)
+    pcs = hp._pcs_of(pcs_pp)
+    vp.preprocess_comms = pcs.batch_commit(pcs_pp, pp.preprocess_polys)
+    vp.permutation_comms = pcs.batch_commit(pcs_pp, pp.permutation_polys)
     return pp, vp

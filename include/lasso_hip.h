@@ -365,6 +365,14 @@ lh_status lh_zeromorph_batch_verify(const lh_zm_vp*, size_t num_vars, const lh_g
                                     const lh_fr* points, size_t num_points, const lh_evaluation* evals,
                                     size_t num_evals, lh_transcript* t);
 
+/* HyperPlonk<Zeromorph<UnivariateKzg<Bn256>>> (the reference's second tested backend configuration,
+ * backend/hyperplonk.rs:426): same schedule as lh_hyperplonk_prove / lh_hyperplonk_verify with the other PCS */
+lh_status lh_hyperplonk_prove_zeromorph(lh_ctx*, const lh_usrs*, size_t poly_size, const lh_hp_param*,
+                                        const lh_fr* const* instances, const lh_fr* const* d_witness_polys,
+                                        lh_transcript* t);
+lh_status lh_hyperplonk_verify_zeromorph(const lh_zm_vp*, const lh_hp_vparam*, const lh_fr* const* instances,
+                                         lh_transcript* t);
+
 /* ---------------------------------------------------------------- measurement (bench.py)
  * Per-kernel HIP-event timing on the ctx stream.  While enabled every instrumented launch is
  * synchronised, so whole-prove wall time is NOT representative; use a separate pass. */

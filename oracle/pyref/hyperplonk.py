@@ -360,17 +360,23 @@ class Param:
     pass
 
 
-def preprocess(pcs_pp, info):
-    """hyperplonk.rs:97-162"""
+def preprocess(pcs_pp, info, pcs_mod=None):
+    """hyperplonk.rs:97-162.  pcs_mod: the PolynomialCommitmentScheme the backend is generic over -- `kzg`
+    (multilinear KZG, default; pcs_pp = its Params) or `zeromorph` (pcs_pp = the trimmed (ProverParam, VerifierParam))."""
     pp = Param()
-    pp.pcs, pp.num_vars = pcs_pp.trim(info.k), info.k
+    pp.pcs_mod = pcs_mod or kzg
+    if pp.pcs_mod is kzg:
+        pp.pcs, pp.num_vars = pcs_pp.trim(info.k), info.k
+        pp.pcs_vp = pp.pcs
+    else:
+        (pp.pcs, pp.pcs_vp), pp.num_vars = pcs_pp, info.k
     pp.num_instances, pp.num_witness_polys, pp.num_challenges = info.num_instances, info.num_witness_polys, info.num_challenges
     pp.lookups = info.lookups
     pp.preprocess_polys = info.preprocess_polys
-    pp.preprocess_comms = [kzg.commit(pp.pcs, p) for p in info.preprocess_polys]
+    pp.preprocess_comms = [pp.pcs_mod.commit(pp.pcs, p) for p in info.preprocess_polys]
     perm = permutation_polys(info.k, info.permutation_polys(), info.permutations)
     pp.permutation_polys = list(zip(info.permutation_polys(), perm))
-    pp.permutation_comms = [kzg.commit(pp.pcs, p) for p in perm]
+    pp.permutation_comms = [pp.pcs_mod.commit(pp.pcs, p) for p in perm]
     pp.num_permutation_z_polys, pp.expression = compose(info)
     return pp
 
@@ -385,7 +391,7 @@ def prove(pp, instances, witness_fn, transcript):
     for rnd, (nw, nc) in enumerate(zip(pp.num_witness_polys, pp.num_challenges)):
         polys = witness_fn(rnd, challenges)
         assert len(polys) == nw
-        kzg.batch_commit_and_write(pp.pcs, polys, transcript)
+        pp.pcs_mod.batch_commit_and_write(pp.pcs, polys, transcript)
         witness_polys += polys
         challenges += transcript.squeeze_challenges(nc)
     polys = inst_polys + pp.preprocess_polys + witness_polys
@@ -395,19 +401,19 @@ def prove(pp, instances, witness_fn, transcript):
     betas = [pow(beta, i, P) for i in range(width)]
     compressed = lookup_compressed_polys(pp.lookups, polys, challenges, betas)
     m_polys = [lookup_m_poly(c) for c in compressed]
-    kzg.batch_commit_and_write(pp.pcs, m_polys, transcript)
+    pp.pcs_mod.batch_commit_and_write(pp.pcs, m_polys, transcript)
 
     gamma = transcript.squeeze_challenge()
     h_polys = [lookup_h_poly(c, m, gamma) for c, m in zip(compressed, m_polys)]
     z_polys = permutation_z_polys(pp.num_permutation_z_polys, pp.permutation_polys, polys, beta, gamma)
-    kzg.batch_commit_and_write(pp.pcs, h_polys + z_polys, transcript)
+    pp.pcs_mod.batch_commit_and_write(pp.pcs, h_polys + z_polys, transcript)
 
     alpha = transcript.squeeze_challenge()
     y = transcript.squeeze_challenges(pp.num_vars)
     polys = polys + [p for _, p in pp.permutation_polys] + m_polys + h_polys + z_polys
     challenges = challenges + [beta, gamma, alpha]
     pts, evals = prove_sum_check(len(pp.num_instances), pp.expression, 0, polys, challenges, y, transcript)
-    kzg.batch_open(pp.pcs, pp.num_vars, polys, pts, evals, transcript)
+    pp.pcs_mod.batch_open(pp.pcs, pp.num_vars, polys, pts, evals, transcript)
 
 
 def prove_sum_check(num_instance_poly, expression, sum_, polys, challenges, y, transcript):
@@ -457,7 +463,8 @@ def verify(vp, instances, transcript):
     for (poly, rot), efr in zip(query, evals_for_rotation):
         pcs_evals += [kzg.Evaluation(poly, off[rot] + k, v) for k, v in enumerate(efr)]
     comms = [None] * len(vp.num_instances) + vp.preprocess_comms + witness_comms + vp.permutation_comms + m_comms + hz_comms
-    kzg.batch_verify(vp.pcs, vp.num_vars, comms, points(query, x), pcs_evals, transcript)
+    getattr(vp, 'pcs_mod', kzg).batch_verify(getattr(vp, 'pcs_vp', vp.pcs), vp.num_vars, comms, points(query, x), pcs_evals,
+                                             transcript)
     if transcript.pos != len(transcript.stream):
         raise InvalidSnark("trailing bytes in proof")
 

@@ -110,3 +110,32 @@ def test_hyperplonk_large_proof_verifies(hl, ctx, num_vars, with_lookup):
     bad[-64 * num_vars - 5] ^= 1
     with pytest.raises(Exception):
         o_hp.verify(vp, instances, OT(bytes(bad)))
+
+
+@pytest.mark.parametrize("num_vars,with_lookup", [(3, False), (4, True), (6, True)])
+def test_hyperplonk_over_zeromorph_matches_oracle(hl, ctx, num_vars, with_lookup):
+    """HyperPlonk<Zeromorph<UnivariateKzg<Bn256>>> (backend/hyperplonk.rs:426): same schedule, other PCS"""
+    from halo2_lasso_amd import hyperplonk as g_hp
+    from oracle.pyref import zeromorph as o_zm
+    rng = random.Random(300 + num_vars)
+    s = rng.randrange(1, P)
+    o_info, g_info, instances, witness = _circuit(hl, num_vars, with_lookup, 900 + num_vars)
+    o_pp = o_hp.preprocess(o_zm.trim(o_zm.setup(s, 1 << num_vars), 1 << num_vars), o_info, o_zm)
+    pcs_pp = hl.Zeromorph.trim(hl.Zeromorph.setup(ctx, s, 1 << num_vars), 1 << num_vars)
+    pcs_vp = hl.ZeromorphVerifierParam.setup(s, 1 << num_vars, 1 << num_vars)
+    g_pp, g_vp = g_hp.HyperPlonk.preprocess(pcs_pp, g_info, pcs_vp)
+    assert g_pp.preprocess_comms == o_pp.preprocess_comms and g_pp.permutation_comms == o_pp.permutation_comms
+    ot = OT()
+    o_hp.prove(o_pp, instances, lambda rnd, ch: witness, ot)
+    t = hl.Keccak256Transcript()
+    g_hp.HyperPlonk.prove(g_pp, instances, [hl.MultilinearPolynomial.new(ctx, w) for w in witness], t)
+    proof = t.into_proof()
+    assert proof == ot.into_proof()
+    o_hp.verify(o_pp, instances, OT(proof))
+    r = hl.Keccak256Transcript.from_proof(proof)
+    g_hp.HyperPlonk.verify(g_vp, instances, r)
+    assert r.remaining() == 0
+    bad = bytearray(proof)
+    bad[len(bad) // 2] ^= 2
+    with pytest.raises(hl.Error):
+        g_hp.HyperPlonk.verify(g_vp, instances, hl.Keccak256Transcript.from_proof(bytes(bad)))

@@ -177,3 +177,19 @@ def test_product_compose_matches_oracle(with_lookup):
         hp.permutation_polys(4, o_info.permutation_polys(), o_info.permutations)
     ce, keep = g_expr.to_c()
     assert ce.num_nodes > 0 and keep[ce.num_nodes - 1].op in (7, 8)  # root last: Sum or Product
+
+
+def test_hyperplonk_over_zeromorph_round_trip():
+    """backend/hyperplonk.rs:426 tests!(zeromorph_kzg, Zeromorph<UnivariateKzg<Bn256>>): prove -> verify with the other PCS"""
+    from oracle.pyref import zeromorph as zm
+    rng = random.Random(91)
+    info, instances, witness = hp.rand_vanilla_plonk_with_lookup_circuit(3, rng)
+    pp = hp.preprocess(zm.trim(zm.setup(rng.randrange(1, P), 8), 8), info, zm)
+    t = T()
+    hp.prove(pp, instances, lambda rnd, ch: witness, t)
+    proof = t.into_proof()
+    hp.verify(pp, instances, T(proof))
+    bad = bytearray(proof)
+    bad[100] ^= 1
+    with pytest.raises(Exception):
+        hp.verify(pp, instances, T(bytes(bad)))
