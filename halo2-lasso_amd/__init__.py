@@ -463,6 +463,13 @@ class MultilinearKzgParams:
     def num_vars(self):
         return self.ctx.lib.lh_srs_num_vars(self.h)
 
+    def eqs_bytes(self):
+        """the flat SRS as the device holds it: level k (2^k points of 64 bytes) at offset 2^k - 1"""
+        total = (2 << self.num_vars) - 1
+        out = C.create_string_buffer(64 * total)
+        _check(self.ctx.lib.lh_srs_download(self.ctx.h, self.h, out))
+        return out.raw
+
     def eqs(self):
         """All levels as lists of affine points (level k has 2^k)."""
         n = self.num_vars
@@ -497,8 +504,15 @@ class MultilinearKzg:
     @staticmethod
     def upload(ctx, eqs_levels):
         flat = b"".join(g1_to_bytes(p) for lvl in eqs_levels for p in lvl)
+        return MultilinearKzg.upload_bytes(ctx, flat, len(eqs_levels) - 1)
+
+    @staticmethod
+    def upload_bytes(ctx, eqs_flat, num_vars):
+        """eqs_flat: (2^(num_vars+1) - 1) * 64 bytes in the device layout (e.g. from params_io.read_*)"""
+        if len(eqs_flat) != 64 * ((2 << num_vars) - 1):
+            raise ArgumentError("flat SRS has the wrong length")
         h = C.c_void_p()
-        _check(ctx.lib.lh_srs_upload(ctx.h, flat, len(eqs_levels) - 1, C.byref(h)))
+        _check(ctx.lib.lh_srs_upload(ctx.h, eqs_flat, num_vars, C.byref(h)))
         return MultilinearKzgParams(ctx, h)
 
     @staticmethod
