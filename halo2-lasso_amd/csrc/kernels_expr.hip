@@ -302,11 +302,9 @@ void k_sc_round_prog(Ctx& c, const ProgRound& pr, int degree, size_t size, Fr* e
   ArenaScope scope(c.arena);
   const unsigned threads = 64u * (unsigned)degree;
   const size_t lds_bytes = (size_t)pr.num_regs * 32 * threads;
-  static bool attr_set = false;
-  if (!attr_set) {
-    LH_HIP(hipFuncSetAttribute((const void*)sc_round_prog_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-    attr_set = true;
-  }
+  static const hipError_t attr = hipFuncSetAttribute((const void*)sc_round_prog_kernel,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+  LH_HIP(attr);  // function-local static: set exactly once, thread-safe
   size_t g = (size + 63) / 64;
   const size_t cap = (size_t)c.num_cus * 4;
   if (g > cap) g = cap;

@@ -44,19 +44,22 @@ std::vector<HFr> evaluate_polys(Ctx& c, const Fr* const* d_polys, size_t count, 
 // 1/prod_{i != j}(j - i) depend on d only and are cached: a round costs O(d) multiplications and no
 // inversion on the host (an Fr inversion is ~8 us, and there are hundreds of rounds per proof).
 static const std::vector<HFr>& lagrange_weights(size_t d) {
-  static std::vector<std::vector<HFr>> cache(16);
-  LH_REQUIRE(d < cache.size(), LH_ERR_ARG, "degree too large");
-  std::vector<HFr>& w = cache[d];
-  if (w.empty()) {
-    w.resize(d + 1);
-    for (size_t j = 0; j <= d; j++) {
-      HFr de = HFr::one();
-      for (size_t i = 0; i <= d; i++)
-        if (i != j) de *= HFr::from_u64(j) - HFr::from_u64(i);
-      w[j] = de.inv();
+  // built once, before any use: contexts on different host threads share the table read-only
+  static const std::vector<std::vector<HFr>> cache = [] {
+    std::vector<std::vector<HFr>> c(16);
+    for (size_t deg = 0; deg < c.size(); deg++) {
+      c[deg].resize(deg + 1);
+      for (size_t j = 0; j <= deg; j++) {
+        HFr de = HFr::one();
+        for (size_t i = 0; i <= deg; i++)
+          if (i != j) de *= HFr::from_u64(j) - HFr::from_u64(i);
+        c[deg][j] = de.inv();
+      }
     }
-  }
-  return w;
+    return c;
+  }();
+  LH_REQUIRE(d < cache.size(), LH_ERR_ARG, "degree too large");
+  return cache[d];
 }
 
 HFr interpolate_evals(const std::vector<HFr>& evals, const HFr& x) {
