@@ -160,6 +160,11 @@ __device__ __forceinline__ const MsmJobDev& job_of_key(const MsmPlanDev& plan, u
 }
 
 // level 0: affine bases, mixed adds
+// The sorted (key, index) stream of a thread's chunk is fetched 16 entries at a time with 16-byte loads and parked
+// in a lane-private LDS column: one entry per iteration straight from global memory would touch 64 different
+// cache lines per wave instruction and keep every line alive for 32 iterations (measured: 2.7x the algorithmic
+// fetch traffic).  (Requesting the next base point one iteration ahead was tried and lost 5 %: more registers.)
+constexpr int ACC_GROUP = 16;
 __global__ __launch_bounds__(128) void msm_accumulate0_kernel(MsmPlanDev plan, const uint32_t* __restrict__ total_ptr,
                                                               const uint32_t* __restrict__ sorted_key,
                                                               const uint32_t* __restrict__ sorted_idx, uint32_t K,
@@ -167,6 +172,7 @@ __global__ __launch_bounds__(128) void msm_accumulate0_kernel(MsmPlanDev plan, c
                                                               uint32_t* __restrict__ cont_key,
                                                               G1Xyzz* __restrict__ cont_pt, size_t nchunks,
                                                               uint32_t* __restrict__ cont_count) {
+  __shared__ uint32_t lds_key[ACC_GROUP * 128], lds_idx[ACC_GROUP * 128];
   const size_t total = *total_ptr;
   for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < nchunks; t += (size_t)gridDim.x * blockDim.x) {
     const size_t p0 = t * K < total ? t * K : total, p1 = p0 + K < total ? p0 + K : total;
@@ -176,22 +182,33 @@ __global__ __launch_bounds__(128) void msm_accumulate0_kernel(MsmPlanDev plan, c
       bool cont = p0 > 0 && sorted_key[p0 - 1] == cur;
       const G1Affine* bases = job_of_key(plan, cur).bases;
       G1Xyzz acc = G1Xyzz::identity();
-      for (size_t p = p0; p < p1; p++) {
-        uint32_t k = sorted_key[p];
-        if (k != cur) {
-          if (cont) {
-            ck = cur;
-            cont_pt[t] = acc;
-          } else {
-            buckets[cur] = acc;
-          }
-          cont = false;
-          acc = G1Xyzz::identity();
-          cur = k;
-          bases = job_of_key(plan, cur).bases;
+      for (size_t g0 = p0; g0 < p1; g0 += ACC_GROUP) {
+        // K is a multiple of 4 and the arrays are padded past the last chunk: whole 16-byte loads stay in bounds
+        const uint32_t cnt = (uint32_t)(p1 - g0 < (size_t)ACC_GROUP ? p1 - g0 : (size_t)ACC_GROUP);
+        for (uint32_t q = 0; q < cnt; q += 4) {
+          const uint4 kv = *(const uint4*)(sorted_key + g0 + q), iv4 = *(const uint4*)(sorted_idx + g0 + q);
+          lds_key[(q + 0) * 128 + threadIdx.x] = kv.x, lds_key[(q + 1) * 128 + threadIdx.x] = kv.y;
+          lds_key[(q + 2) * 128 + threadIdx.x] = kv.z, lds_key[(q + 3) * 128 + threadIdx.x] = kv.w;
+          lds_idx[(q + 0) * 128 + threadIdx.x] = iv4.x, lds_idx[(q + 1) * 128 + threadIdx.x] = iv4.y;
+          lds_idx[(q + 2) * 128 + threadIdx.x] = iv4.z, lds_idx[(q + 3) * 128 + threadIdx.x] = iv4.w;
         }
-        const uint32_t iv = sorted_idx[p];
-        acc = add_mixed(acc, bases[iv & 0x7fffffffu], (iv >> 31) != 0);
+        for (uint32_t j = 0; j < cnt; j++) {
+          const uint32_t k = lds_key[j * 128 + threadIdx.x];
+          if (k != cur) {
+            if (cont) {
+              ck = cur;
+              cont_pt[t] = acc;
+            } else {
+              buckets[cur] = acc;
+            }
+            cont = false;
+            acc = G1Xyzz::identity();
+            cur = k;
+            bases = job_of_key(plan, cur).bases;
+          }
+          const uint32_t iv = lds_idx[j * 128 + threadIdx.x];
+          acc = add_mixed(acc, bases[iv & 0x7fffffffu], (iv >> 31) != 0);
+        }
       }
       if (cont) {
         ck = cur;
@@ -403,8 +420,9 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
       uint32_t* total = c.arena.alloc_n<uint32_t>(1);
       uint32_t* ukey = c.arena.alloc_n<uint32_t>(max_entries);
       uint32_t* uidx = c.arena.alloc_n<uint32_t>(max_entries);
-      uint32_t* skey = c.arena.alloc_n<uint32_t>(max_entries);
-      uint32_t* sidx = c.arena.alloc_n<uint32_t>(max_entries);
+      // + 256: accumulate0 reads whole 16-byte groups up to the end of the last (padded) chunk
+      uint32_t* skey = c.arena.alloc_n<uint32_t>(max_entries + 256);
+      uint32_t* sidx = c.arena.alloc_n<uint32_t>(max_entries + 256);
       G1Xyzz* buckets = c.arena.alloc_n<G1Xyzz>(nbuckets);
       G1Xyzz* seg_out = c.arena.alloc_n<G1Xyzz>(nsegs);
       // pinned host memory: the window sums (written by the last kernel) followed by the key-block table staging
