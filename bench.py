@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log-n", type=int, default=0, help="force the CPU sample size")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-inflight", action="store_true",
+                    help="skip the extra throughput figure (two independent proofs in flight on one GPU)")
     ap.add_argument("--mode", default="replicas", choices=["replicas", "sharded"],
                     help="N>1: 'replicas' = one independent proof per GPU (weak scaling, default); 'sharded' = ONE "
                          "proof of 2^log-n lookups split over the N GPUs (strong scaling, SURVEY.md §8e)")
@@ -375,6 +377,29 @@ def main():
             dom_name = max(aggs, key=lambda a: a["big"]["ms"])["name"]
             out["roofline"], out["alu"], out["kernels"] = roofline_objects(hl, ctx, aggs,
                                                                            pmc_traffic(dom_name, n, args.table))
+        if not args.no_inflight and not sharded and world == 1:
+            # throughput with TWO independent proofs in flight on the same GPU (two contexts = two streams, one host
+            # thread each): a single proof leaves the chip idle during its ~250 latency-bound rounds and MSM tails
+            import threading
+            ctx2 = hl.Context(int(os.environ.get("LH_DEVICE", local_rank)))
+            pp2 = hl.MultilinearKzgParams(ctx2, pp.h)  # the SRS is device memory: shared, owned by `pp`
+
+            def worker(p, k):
+                for _ in range(k):
+                    hl.lasso_prove(p, table, n, d_dims, hl.Keccak256Transcript())
+            for k in (1, args.steps):
+                th = [threading.Thread(target=worker, args=(p, k)) for p in (pp, pp2)]
+                ctx.sync(), ctx2.sync()
+                t0 = time.perf_counter()
+                for t in th:
+                    t.start()
+                for t in th:
+                    t.join()
+                ctx.sync(), ctx2.sync()
+                dt = time.perf_counter() - t0
+            pp2.h = None
+            out["two_proofs_in_flight"] = {"ms_per_proof": round(dt * 1e3 / (2 * args.steps), 3),
+                                           "lookups_per_s": round((1 << n) * 2 * args.steps / dt)}
         if not args.no_cpu_baseline and not sharded:
             def gpu_proof(nn, dims):
                 bufs = [ctx.upload(d.tobytes()) for d in dims]

@@ -9,7 +9,8 @@ table = hl.LassoTable.range(2, 16) if kind == "range" else hl.LassoTable.bitwise
     hl.SUBTABLE_AND if kind == "and" else hl.SUBTABLE_XOR, 4, 16)
 rng = np.random.default_rng(1)
 t = time.perf_counter()
-pp = hl.MultilinearKzg.setup(ctx, [int(v) for v in rng.integers(1, 1 << 62, size=n)])
+ss = [int(v) for v in rng.integers(1, 1 << 62, size=n)]
+pp = hl.MultilinearKzg.setup(ctx, ss)
 print("setup %.2fs" % (time.perf_counter() - t), flush=True)
 dims = [ctx.upload(rng.integers(0, 1 << 16, size=1 << n, dtype=np.uint32).tobytes()) for _ in range(table.c)]
 for rep in range(3):
@@ -18,3 +19,7 @@ for rep in range(3):
     hl.lasso_prove(pp, table, n, dims, tr)
     print("%s 2^%d: %.1f ms proof %d B %s" % (kind, n, (time.perf_counter() - t) * 1e3, len(tr.into_proof()),
           {k: round(v, 1) for k, v in hl.lasso_last_timing(ctx).items()}), flush=True)
+if os.environ.get("LH_VERIFY"):
+    t = time.perf_counter()
+    hl.lasso_verify(hl.MultilinearKzgVerifierParams.setup(ss), table, n, hl.Keccak256Transcript.from_proof(tr.into_proof()))
+    print("proof accepted by the host verifier (%.0f ms)" % ((time.perf_counter() - t) * 1e3), flush=True)
