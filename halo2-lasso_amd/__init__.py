@@ -656,7 +656,8 @@ def sum_check_verify(prover, num_vars, degree, sum_, transcript):
 def lasso_verify(vp, table, num_vars, transcript):
     """Verifier of the Lasso argument (oracle/pyref/lasso.py:219-261).  A Keccak256Transcript must be fully consumed."""
     t = table.to_c()
-    _check(vp.lib.lh_lasso_verify(vp.h, C.byref(t), num_vars, transcript.p))
+    fn = vp.lib.lh_lasso_verify_zeromorph if isinstance(vp, ZeromorphVerifierParam) else vp.lib.lh_lasso_verify
+    _check(fn(vp.h, C.byref(t), num_vars, transcript.p))
     if isinstance(transcript, Keccak256Transcript) and transcript.remaining():
         raise InvalidSnark("trailing bytes in proof")
 
@@ -849,6 +850,10 @@ def lasso_prove(pp, table, num_vars, dims, transcript):
             or len(table.g_terms) > _ffi.LH_LASSO_MAX_TERMS:
         raise ArgumentError("table too large")
     t = table.to_c()
+    if isinstance(pp, ZeromorphProverParam):
+        _check(pp.ctx.lib.lh_lasso_prove_zeromorph(pp.ctx.h, pp.params.h, pp.poly_size, C.byref(t), num_vars,
+                                                   _ptr_array(dims), transcript.p))
+        return
     _check(pp.ctx.lib.lh_lasso_prove(pp.ctx.h, pp.h, C.byref(t), num_vars, _ptr_array(dims), transcript.p))
 
 

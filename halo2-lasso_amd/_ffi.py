@@ -205,6 +205,9 @@ SIGNATURES = {
                                       C.POINTER(lh_transcript)]),
     "lh_zeromorph_batch_verify": (C.c_int, [_P, _SZ, C.POINTER(lh_g1), _SZ, C.POINTER(lh_fr), _SZ,
                                             C.POINTER(lh_evaluation), _SZ, C.POINTER(lh_transcript)]),
+    "lh_lasso_prove_zeromorph": (C.c_int, [_P, _P, _SZ, C.POINTER(lh_lasso_table), _SZ, C.POINTER(_P),
+                                           C.POINTER(lh_transcript)]),
+    "lh_lasso_verify_zeromorph": (C.c_int, [_P, C.POINTER(lh_lasso_table), _SZ, C.POINTER(lh_transcript)]),
     "lh_hyperplonk_prove_zeromorph": (C.c_int, [_P, _P, _SZ, C.POINTER(lh_hp_param), C.POINTER(C.POINTER(lh_fr)),
                                                 C.POINTER(_P), C.POINTER(lh_transcript)]),
     "lh_hyperplonk_verify_zeromorph": (C.c_int, [_P, C.POINTER(lh_hp_vparam), C.POINTER(C.POINTER(lh_fr)),

@@ -405,7 +405,7 @@ lh_status lh_lasso_prove(lh_ctx* ctx, const lh_srs* srs, const lh_lasso_table* t
   NEED(table);
   NEED(d_dims);
   Transcript tr(t);
-  lasso_prove(ctx->c, srs->s, *table, num_vars, d_dims, tr);
+  lasso_prove(ctx->c, lasso_mkzg_pcs(ctx->c, srs->s), *table, num_vars, d_dims, tr);
   LH_CATCH
 }
 lh_status lh_lasso_last_timing(lh_ctx* ctx, double* out_ms) {
@@ -533,7 +533,10 @@ lh_status lh_lasso_verify(const lh_mkzg_vp* vp, const lh_lasso_table* table, siz
   NEED(vp);
   NEED(table);
   Transcript tr(t);
-  lasso_verify(*vp->p, *table, num_vars, tr);
+  const VerifierParams& pcs = *vp->p;
+  lasso_verify([&pcs](size_t nv, const HG1* comms, size_t nc, const HFr* points, size_t np, const lh_evaluation* evals,
+                      size_t ne, Transcript& t2) { mkzg_batch_verify(pcs, nv, comms, nc, points, np, evals, ne, t2); },
+               *table, num_vars, tr);
   LH_CATCH
 }
 lh_status lh_hyperplonk_verify(const lh_mkzg_vp* vp, const lh_hp_vparam* hvp, const lh_fr* const* instances,
@@ -681,6 +684,27 @@ lh_status lh_zeromorph_batch_verify(const lh_zm_vp* vp, size_t num_vars, const l
   LH_CATCH
 }
 
+lh_status lh_lasso_prove_zeromorph(lh_ctx* ctx, const lh_usrs* srs, size_t poly_size, const lh_lasso_table* table,
+                                   size_t num_vars, const uint32_t* const* d_dims, lh_transcript* t) {
+  LH_TRY NEED(ctx);
+  NEED(srs);
+  NEED(table);
+  NEED(d_dims);
+  Transcript tr(t);
+  lasso_prove(ctx->c, lasso_zeromorph_pcs(ctx->c, srs->s, poly_size), *table, num_vars, d_dims, tr);
+  LH_CATCH
+}
+lh_status lh_lasso_verify_zeromorph(const lh_zm_vp* vp, const lh_lasso_table* table, size_t num_vars, lh_transcript* t) {
+  LH_TRY
+  NEED(vp);
+  NEED(table);
+  Transcript tr(t);
+  const ZmVerifierParams& pcs = *vp->p;
+  lasso_verify([&pcs](size_t nv, const HG1* comms, size_t nc, const HFr* points, size_t np, const lh_evaluation* evals,
+                      size_t ne, Transcript& t2) { zeromorph_batch_verify(pcs, nv, comms, nc, points, np, evals, ne, t2); },
+               *table, num_vars, tr);
+  LH_CATCH
+}
 lh_status lh_hyperplonk_prove_zeromorph(lh_ctx* ctx, const lh_usrs* srs, size_t poly_size, const lh_hp_param* pp,
                                         const lh_fr* const* instances, const lh_fr* const* d_witness_polys,
                                         lh_transcript* t) {

@@ -205,7 +205,18 @@ void zeromorph_batch_verify(const ZmVerifierParams&, size_t num_vars, const HG1*
                             Transcript& tr);
 
 // ------------------------------------------------------------------ Lasso
-void lasso_prove(Ctx&, const Srs&, const lh_lasso_table& table, size_t num_vars, const uint32_t* const* d_dims,
+// what the Lasso prover needs from its PCS: bases whose first 2^nv points commit a zero-padded table of 2^nv entries
+// (the eq basis of level nv, or the powers of s), the largest nv they cover, and batch_open
+struct LassoPcs {
+  std::function<const G1Affine*(size_t nv)> commit_bases;
+  size_t max_vars;
+  std::function<void(size_t num_vars, const Fr* const* d_polys, size_t num_polys, const HFr* points, size_t num_points,
+                     const lh_evaluation* evals, size_t num_evals, Transcript& tr)>
+      batch_open;
+};
+LassoPcs lasso_mkzg_pcs(Ctx&, const Srs&);
+LassoPcs lasso_zeromorph_pcs(Ctx&, const USrs&, size_t poly_size);
+void lasso_prove(Ctx&, const LassoPcs&, const lh_lasso_table& table, size_t num_vars, const uint32_t* const* d_dims,
                  Transcript& tr);
 void lasso_prove_sharded(Ctx&, const Srs&, const lh_lasso_table& table, size_t num_vars,
                          const uint32_t* const* d_dims, Transcript& tr);
@@ -227,7 +238,7 @@ void mkzg_batch_verify(const VerifierParams&, size_t num_vars, const HG1* comms,
 // -> (final claim, challenges)
 std::pair<HFr, std::vector<HFr>> sum_check_verify(int prover_kind, size_t num_vars, size_t degree, const HFr& sum,
                                                   Transcript& tr);
-void lasso_verify(const VerifierParams&, const lh_lasso_table& table, size_t num_vars, Transcript& tr);
+void lasso_verify(const PcsBatchVerify& batch_verify, const lh_lasso_table& table, size_t num_vars, Transcript& tr);
 void hyperplonk_verify(const PcsBatchVerify& batch_verify, const lh_hp_vparam& vp, const HFr* const* instances,
                        Transcript& tr);
 

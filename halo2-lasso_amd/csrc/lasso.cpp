@@ -12,7 +12,30 @@ static double now_ms() {
   return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
-void lasso_prove(Ctx& c, const Srs& srs, const lh_lasso_table& tb, size_t n, const uint32_t* const* d_dims,
+LassoPcs lasso_mkzg_pcs(Ctx& c, const Srs& srs) {
+  LassoPcs p;
+  p.commit_bases = [&srs](size_t nv) { return srs.eq(nv); };
+  p.max_vars = srs.num_vars;
+  p.batch_open = [&c, &srs](size_t nv, const Fr* const* polys, size_t np, const HFr* points, size_t npts,
+                            const lh_evaluation* evals, size_t ne, Transcript& tr) {
+    mkzg_batch_open(c, srs, nv, polys, np, points, npts, evals, ne, tr);
+  };
+  return p;
+}
+LassoPcs lasso_zeromorph_pcs(Ctx& c, const USrs& srs, size_t poly_size) {
+  LH_REQUIRE(poly_size >= 1 && poly_size <= srs.size, LH_ERR_INVALID_PCS_PARAM, "Too large poly_size to trim to");
+  LassoPcs p;
+  p.commit_bases = [&srs](size_t) { return (const G1Affine*)srs.d_powers; };
+  p.max_vars = 0;
+  while (((size_t)2 << p.max_vars) <= poly_size) p.max_vars++;
+  p.batch_open = [&c, &srs, poly_size](size_t nv, const Fr* const* polys, size_t np, const HFr* points, size_t npts,
+                                       const lh_evaluation* evals, size_t ne, Transcript& tr) {
+    zeromorph_batch_open(c, srs, poly_size, nv, polys, np, points, npts, evals, ne, tr);
+  };
+  return p;
+}
+
+void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n, const uint32_t* const* d_dims,
                  Transcript& tr) {
   const size_t cc = tb.num_chunks, l = tb.chunk_bits, alpha = tb.num_memories;
   LH_REQUIRE(cc >= 1 && cc <= LH_LASSO_MAX_CHUNKS, LH_ERR_ARG, "lasso: bad num_chunks");
@@ -20,7 +43,7 @@ void lasso_prove(Ctx& c, const Srs& srs, const lh_lasso_table& tb, size_t n, con
   LH_REQUIRE(8 * alpha + 1 <= (size_t)SC_MAX_TABLES, LH_ERR_ARG, "lasso: too many memories for one GKR batch");
   LH_REQUIRE(n >= 1 && l >= 1 && l < 31 && n < 31, LH_ERR_ARG, "lasso: need at least one variable");
   LH_REQUIRE(tb.num_terms >= 1 && tb.num_terms <= LH_LASSO_MAX_TERMS, LH_ERR_ARG, "lasso: bad g term count");
-  if (n > srs.num_vars || l > srs.num_vars)
+  if (n > pcs.max_vars || l > pcs.max_vars)
     throw Error(LH_ERR_INVALID_PCS_PARAM, "Too many variates of poly to commit");
   // every committed poly is zero-padded to nv = max(n, l) variables (spec step 1)
   const size_t nv = std::max(n, l), NV = (size_t)1 << nv;
@@ -78,11 +101,11 @@ void lasso_prove(Ctx& c, const Srs& srs, const lh_lasso_table& tb, size_t n, con
   {
     std::vector<MsmJob> jobs;
     // zero padding adds nothing to an MSM: commit the unpadded columns against the first entries of eqs[nv]
-    jobs.push_back(MsmJob{a, false, srs.eq(nv), N});
-    for (size_t j = 0; j < cc; j++) jobs.push_back(MsmJob{d_dims[j], true, srs.eq(nv), N});
-    for (size_t j = 0; j < cc; j++) jobs.push_back(MsmJob{rts[j], true, srs.eq(nv), N});
-    for (size_t i = 0; i < alpha; i++) jobs.push_back(MsmJob{E[i], true, srs.eq(nv), N});
-    for (size_t j = 0; j < cc; j++) jobs.push_back(MsmJob{fcs[j], true, srs.eq(nv), M});
+    jobs.push_back(MsmJob{a, false, pcs.commit_bases(nv), N});
+    for (size_t j = 0; j < cc; j++) jobs.push_back(MsmJob{d_dims[j], true, pcs.commit_bases(nv), N});
+    for (size_t j = 0; j < cc; j++) jobs.push_back(MsmJob{rts[j], true, pcs.commit_bases(nv), N});
+    for (size_t i = 0; i < alpha; i++) jobs.push_back(MsmJob{E[i], true, pcs.commit_bases(nv), N});
+    for (size_t j = 0; j < cc; j++) jobs.push_back(MsmJob{fcs[j], true, pcs.commit_bases(nv), M});
     std::vector<HG1> comms(jobs.size());
     msm_batch(c, jobs.data(), jobs.size(), (G1Affine*)comms.data());
     tr.write_commitments(comms);
@@ -187,7 +210,7 @@ void lasso_prove(Ctx& c, const Srs& srs, const lh_lasso_table& tb, size_t n, con
     for (size_t j = 0; j < cc; j++) push(num_n + j, 3, ev_l[j]);
     std::vector<const Fr*> all(polys_n);
     all.insert(all.end(), polys_l.begin(), polys_l.end());
-    mkzg_batch_open(c, srs, nv, all.data(), all.size(), points.data(), 4, evs.data(), evs.size(), tr);
+    pcs.batch_open(nv, all.data(), all.size(), points.data(), 4, evs.data(), evs.size(), tr);
   }
   lap(6);
   ph[7] = 0;

@@ -533,7 +533,7 @@ static HFr subtable_mle_eval(uint32_t kind, const std::vector<HFr>& point) {  //
   return acc;
 }
 
-void lasso_verify(const VerifierParams& pcs, const lh_lasso_table& tb, size_t n, Transcript& tr) {
+void lasso_verify(const PcsBatchVerify& batch_verify, const lh_lasso_table& tb, size_t n, Transcript& tr) {
   const size_t c = tb.num_chunks, l = tb.chunk_bits, alpha = tb.num_memories;
   LH_REQUIRE(c >= 1 && c <= LH_LASSO_MAX_CHUNKS && alpha >= 1 && alpha <= LH_LASSO_MAX_MEMORIES &&
                  tb.num_terms <= LH_LASSO_MAX_TERMS,
@@ -614,7 +614,7 @@ void lasso_verify(const VerifierParams& pcs, const lh_lasso_table& tb, size_t n,
     points.insert(points.end(), pt->begin(), pt->end());
     points.insert(points.end(), nv - pt->size(), HFr::zero());
   }
-  mkzg_batch_verify(pcs, nv, comms.data(), comms.size(), points.data(), 4, evals.data(), evals.size(), tr);
+  batch_verify(nv, comms.data(), comms.size(), points.data(), 4, evals.data(), evals.size(), tr);
 }
 
 }  // namespace lh

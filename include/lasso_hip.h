@@ -367,6 +367,10 @@ lh_status lh_zeromorph_batch_verify(const lh_zm_vp*, size_t num_vars, const lh_g
 
 /* HyperPlonk<Zeromorph<UnivariateKzg<Bn256>>> (the reference's second tested backend configuration,
  * backend/hyperplonk.rs:426): same schedule as lh_hyperplonk_prove / lh_hyperplonk_verify with the other PCS */
+/* the Lasso argument over Zeromorph (same protocol, oracle/pyref/lasso.py with pcs = zeromorph) */
+lh_status lh_lasso_prove_zeromorph(lh_ctx*, const lh_usrs*, size_t poly_size, const lh_lasso_table*, size_t num_vars,
+                                   const uint32_t* const* d_dims, lh_transcript* t);
+lh_status lh_lasso_verify_zeromorph(const lh_zm_vp*, const lh_lasso_table*, size_t num_vars, lh_transcript* t);
 lh_status lh_hyperplonk_prove_zeromorph(lh_ctx*, const lh_usrs*, size_t poly_size, const lh_hp_param*,
                                         const lh_fr* const* instances, const lh_fr* const* d_witness_polys,
                                         lh_transcript* t);

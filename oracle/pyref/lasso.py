@@ -151,7 +151,12 @@ def _check_shape(spec, n):
 
 
 # ------------------------------------------------------------------ prover
-def prove(pp, spec, dims, transcript):
+def _trim(pcs, p, nv):
+    return p.trim(nv) if pcs is kzg else p
+
+
+def prove(pp, spec, dims, transcript, pcs=kzg):
+    """pcs: `kzg` (pp = its Params) or `zeromorph` (pp = a trimmed ProverParam covering 2^max(n, l) coefficients)"""
     c, l, alpha = spec.c, spec.l, spec.alpha
     N, M = len(dims[0]), 1 << l
     n = N.bit_length() - 1
@@ -161,7 +166,7 @@ def prove(pp, spec, dims, transcript):
     transcript.common_field_elements([n, l, c, alpha])
     nv = max(n, l)
     polys = [_pad(p, nv) for p in [w["a"]] + w["dim"] + w["read_ts"] + w["E"] + w["final_cts"]]
-    kzg.batch_commit_and_write(pp.trim(nv), polys, transcript)
+    pcs.batch_commit_and_write(_trim(pcs, pp, nv), polys, transcript)
 
     r = transcript.squeeze_challenges(n)
     v = evaluate(w["a"], r)
@@ -192,7 +197,7 @@ def prove(pp, spec, dims, transcript):
 
     evals = _evals(spec, v, e_rz, dim_e, rts_e, e_e, fc_e)
     points = [_pad_point(pt, nv) for pt in (r, r_z, r_N, r_M)]
-    kzg.batch_open(pp.trim(nv), nv, polys, points, evals, transcript)
+    pcs.batch_open(_trim(pcs, pp, nv), nv, polys, points, evals, transcript)
     return transcript
 
 
@@ -216,7 +221,7 @@ def _evals(spec, v, e_rz, dim_e, rts_e, e_e, fc_e):
 
 
 # ------------------------------------------------------------------ verifier
-def verify(vp, spec, n, transcript):
+def verify(vp, spec, n, transcript, pcs=kzg):
     c, l, alpha = spec.c, spec.l, spec.alpha
     _check_shape(spec, n)
     transcript.common_field_elements([n, l, c, alpha])
@@ -256,6 +261,6 @@ def verify(vp, spec, n, transcript):
 
     evals = _evals(spec, v, e_rz, dim_e, rts_e, e_e, fc_e)
     points = [_pad_point(pt, nv) for pt in (r, r_z, r_N, r_M)]
-    kzg.batch_verify(vp.trim(nv), nv, comms, points, evals, transcript)
+    pcs.batch_verify(_trim(pcs, vp, nv), nv, comms, points, evals, transcript)
     if transcript.pos != len(transcript.stream):
         raise LassoError("trailing bytes in proof")

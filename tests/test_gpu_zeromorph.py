@@ -107,3 +107,33 @@ def test_zeromorph_large_open_verifies(hl, ctx):
     hl.Zeromorph.verify(vp, comm, point, ev, hl.Keccak256Transcript.from_proof(t.into_proof()))
     with pytest.raises(hl.InvalidPcsOpen):
         hl.Zeromorph.verify(vp, comm, point[::-1], ev, hl.Keccak256Transcript.from_proof(t.into_proof()))
+
+
+@pytest.mark.parametrize("kind,c,l,n", [("range", 2, 3, 4), ("and", 2, 4, 3), ("xor", 2, 4, 6)])
+def test_lasso_over_zeromorph_matches_oracle(hl, ctx, kind, c, l, n):
+    """the Lasso argument with the other PCS: same protocol bytes up to the commitments / opening proof"""
+    import array
+    from oracle.pyref import lasso as o_lasso
+    rng = random.Random(700 + n)
+    s = rng.randrange(1, P)
+    nv = max(n, l)
+    spec = o_lasso.range_table(c, l) if kind == "range" else o_lasso.bitwise_table(
+        o_lasso.SUBTABLE_AND if kind == "and" else o_lasso.SUBTABLE_XOR, c, l)
+    table = hl.LassoTable.range(c, l) if kind == "range" else hl.LassoTable.bitwise(
+        hl.SUBTABLE_AND if kind == "and" else hl.SUBTABLE_XOR, c, l)
+    dims = [[rng.randrange(1 << l) for _ in range(1 << n)] for _ in range(c)]
+    o_pp, o_vp = o_zm.trim(o_zm.setup(s, 1 << nv), 1 << nv)
+    ot = OT()
+    o_lasso.prove(o_pp, spec, dims, ot, pcs=o_zm)
+    pp = hl.Zeromorph.trim(hl.Zeromorph.setup(ctx, s, 1 << nv), 1 << nv)
+    vp = hl.ZeromorphVerifierParam.setup(s, 1 << nv, 1 << nv)
+    t = hl.Keccak256Transcript()
+    hl.lasso_prove(pp, table, n, [ctx.upload(array.array("I", d).tobytes()) for d in dims], t)
+    proof = t.into_proof()
+    assert proof == ot.into_proof()
+    o_lasso.verify(o_vp, spec, n, OT(proof), pcs=o_zm)
+    hl.lasso_verify(vp, table, n, hl.Keccak256Transcript.from_proof(proof))
+    bad = bytearray(proof)
+    bad[len(bad) // 2] ^= 8
+    with pytest.raises(hl.Error):
+        hl.lasso_verify(vp, table, n, hl.Keccak256Transcript.from_proof(bytes(bad)))
