@@ -10,7 +10,9 @@ table = hl.LassoTable.range(2, 16) if kind == "range" else hl.LassoTable.bitwise
 rng = np.random.default_rng(1)
 t = time.perf_counter()
 ss = [int(v) for v in rng.integers(1, 1 << 62, size=n)]
-pp = hl.MultilinearKzg.setup(ctx, ss)
+zm = os.environ.get("LH_PCS") == "zeromorph"
+nv_max = max(n, table.l)
+pp = hl.Zeromorph.trim(hl.Zeromorph.setup(ctx, ss[0], 1 << nv_max), 1 << nv_max) if zm else hl.MultilinearKzg.setup(ctx, ss)
 print("setup %.2fs" % (time.perf_counter() - t), flush=True)
 dims = [ctx.upload(rng.integers(0, 1 << 16, size=1 << n, dtype=np.uint32).tobytes()) for _ in range(table.c)]
 for rep in range(3):
@@ -21,5 +23,6 @@ for rep in range(3):
           {k: round(v, 1) for k, v in hl.lasso_last_timing(ctx).items()}), flush=True)
 if os.environ.get("LH_VERIFY"):
     t = time.perf_counter()
-    hl.lasso_verify(hl.MultilinearKzgVerifierParams.setup(ss), table, n, hl.Keccak256Transcript.from_proof(tr.into_proof()))
+    vp = hl.ZeromorphVerifierParam.setup(ss[0], 1 << nv_max, 1 << nv_max) if zm else hl.MultilinearKzgVerifierParams.setup(ss)
+    hl.lasso_verify(vp, table, n, hl.Keccak256Transcript.from_proof(tr.into_proof()))
     print("proof accepted by the host verifier (%.0f ms)" % ((time.perf_counter() - t) * 1e3), flush=True)
