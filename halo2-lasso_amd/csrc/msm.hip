@@ -508,6 +508,14 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
       if (c.prof) c.sync();
       c.wait_flag(seq);
       }
+      if (getenv("LH_MSM_DEBUG")) {
+        uint32_t h_cnt[16];
+        c.d2h(h_cnt, lvl_cnt, sizeof(h_cnt));
+        fprintf(stderr, "[msm] jobs %zu entries %zu K %u nchunks %zu buckets %zu | continuation counts:", nj, max_entries, K,
+                nchunks, nbuckets);
+        for (int i = 0; i < 10; i++) fprintf(stderr, " %u", h_cnt[i]);
+        fprintf(stderr, "\n");
+      }
       memcpy(wins.data(), win_out, nwins * sizeof(G1Xyzz));
     }
     // 6: host combine  sum_w 2^(c*w) * win[w]  and normalise
