@@ -99,15 +99,42 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
   tr.common_field_element(HFr::from_u64(cc));
   tr.common_field_element(HFr::from_u64(alpha));
   {
+    // zero padding adds nothing to an MSM: commit the unpadded columns against the first entries of the bases.
+    // Commitments are linear, so columns that are linear in others need no MSM of their own (same group elements,
+    // same proof bytes): E_i = dim_j for an identity subtable, and a = sum_m coeff_m E_{f(m)} when g is linear
+    // (range / AND / XOR tables): 4 of 9 column MSMs instead of 9 for the range check.
+    const G1Affine* bases = pcs.commit_bases(nv);
+    bool linear_g = true;
+    for (uint32_t m = 0; m < tb.num_terms; m++) linear_g = linear_g && tb.g_num_factors[m] == 1;
+    const size_t total = 1 + 3 * cc + alpha;
     std::vector<MsmJob> jobs;
-    // zero padding adds nothing to an MSM: commit the unpadded columns against the first entries of eqs[nv]
-    jobs.push_back(MsmJob{a, false, pcs.commit_bases(nv), N});
-    for (size_t j = 0; j < cc; j++) jobs.push_back(MsmJob{d_dims[j], true, pcs.commit_bases(nv), N});
-    for (size_t j = 0; j < cc; j++) jobs.push_back(MsmJob{rts[j], true, pcs.commit_bases(nv), N});
-    for (size_t i = 0; i < alpha; i++) jobs.push_back(MsmJob{E[i], true, pcs.commit_bases(nv), N});
-    for (size_t j = 0; j < cc; j++) jobs.push_back(MsmJob{fcs[j], true, pcs.commit_bases(nv), M});
-    std::vector<HG1> comms(jobs.size());
-    msm_batch(c, jobs.data(), jobs.size(), (G1Affine*)comms.data());
+    std::vector<size_t> slot;  // position of each job's result in `comms`
+    auto add_job = [&](size_t pos, const void* col, bool u32, size_t len) {
+      jobs.push_back(MsmJob{col, u32, bases, len});
+      slot.push_back(pos);
+    };
+    if (!linear_g) add_job(0, a, false, N);
+    for (size_t j = 0; j < cc; j++) add_job(1 + j, d_dims[j], true, N);
+    for (size_t j = 0; j < cc; j++) add_job(1 + cc + j, rts[j], true, N);
+    for (size_t i = 0; i < alpha; i++)
+      if (tb.memory_subtable[i] != LH_SUBTABLE_IDENTITY) add_job(1 + 2 * cc + i, E[i], true, N);
+    for (size_t j = 0; j < cc; j++) add_job(1 + 2 * cc + alpha + j, fcs[j], true, M);
+    std::vector<HG1> part(jobs.size()), comms(total);
+    msm_batch(c, jobs.data(), jobs.size(), (G1Affine*)part.data());
+    for (size_t k = 0; k < jobs.size(); k++) comms[slot[k]] = part[k];
+    for (size_t i = 0; i < alpha; i++)
+      if (tb.memory_subtable[i] == LH_SUBTABLE_IDENTITY) comms[1 + 2 * cc + i] = comms[1 + tb.memory_chunk[i]];
+    if (linear_g) {
+      std::vector<host::G1Xyzz> terms(tb.num_terms);
+      host_parallel_for(tb.num_terms, [&](size_t m) {
+        HFr co;
+        memcpy(&co, &tb.g_coeff[m], 32);
+        terms[m] = host::g1_mul(host::g1_from_affine(comms[1 + 2 * cc + tb.g_factor[m][0]]), co);
+      });
+      host::G1Xyzz acc = host::G1Xyzz::identity();
+      for (auto& t : terms) acc = host::g1_add(acc, t);
+      comms[0] = host::g1_to_affine(acc);
+    }
     tr.write_commitments(comms);
   }
   lap(1);
