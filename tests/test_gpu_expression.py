@@ -115,3 +115,20 @@ def test_zero_check_vanilla_plonk(hl, ctx, num_vars, with_lookup):
     num_z, g_expr = g_hp.compose(g_info)
     assert num_z == 1 and g_expr.degree() == oex.degree(o_expr) == 5
     run(hl, ctx, num_vars, o_expr, g_expr, tables, challenges, [rng.randrange(P) for _ in range(num_vars)])
+
+
+def test_monomial_fallback_path_still_matches_golden():
+    """the expanded-monomial round kernel (used when an expression does not fit the register program) is selected
+    with LH_EXPR_MONOMIALS=1 at library load: run the HyperPlonk golden parity tests in a fresh process with it"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LH_EXPR_MONOMIALS="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_golden.py",
+                        "tests/test_gpu_expression.py", "-k", "hyperplonk or sum_check or zero_check"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    import re
+    m = re.search(r"(\d+) passed", r.stdout)
+    assert m and int(m.group(1)) >= 15, r.stdout[-500:]
