@@ -270,18 +270,6 @@ static void launch_lds(Ctx& c, const ScLdsArgs& g, bool bind, size_t size, unsig
     hipLaunchKernelGGL((sc_round_lds_kernel<D, false>), dim3(grid), dim3(256), 0, c.stream, g, size, partials, fin);
 }
 
-__global__ void sc_reduce_kernel(const Fr* __restrict__ partials, int blocks, int d, Fr* __restrict__ out,
-                                 uint32_t* flag, uint32_t seq) {
-  __shared__ Fr lds[4];
-  for (int x = 0; x < d; x++) {
-    Fr acc = Fr::zero();
-    for (int i = threadIdx.x; i < blocks; i += blockDim.x) acc = add(acc, partials[(size_t)i * d + x]);
-    acc = block_reduce_sum(acc, lds);
-    if (threadIdx.x == 0) out[x] = acc;
-  }
-  if (threadIdx.x == 0) publish_flag(flag, seq);
-}
-
 template <int D>
 static void launch_round(Ctx& c, const ScArgs& a, bool bind, size_t size, uint32_t tp, unsigned grid, Fr* partials,
                          const ScFinish& fin) {
