@@ -245,6 +245,8 @@ struct ExtRound {
 void k_sc_round_ext(Ctx&, const ExtRound& rd, int degree, bool bind, size_t size, Fr* evals_host);
 void k_rotate_gather(Ctx&, const Fr* poly, size_t num_vars, int rot, uint32_t primitive, uint32_t x_inv, Fr* out);
 void k_identity_table(Ctx&, size_t n, Fr* out);
+// BooleanHypercube::iter() order and its inverse (bh.rs:127-141), 2^num_vars entries each
+void k_bh_order(Ctx&, size_t num_vars, uint32_t primitive, uint32_t* order, uint32_t* nth);
 void k_one_hot_table(Ctx&, size_t n, size_t hot, Fr* out);
 // Straight-line program over tables, constants and a small register file (the device counterpart of the
 // reference's ExpressionRegistry calculations, util/expression/evaluator.rs:135-323): instruction i is

@@ -2,6 +2,7 @@
 // argument, for single-phase circuits.  Transcript schedule: SURVEY.md §3.1; restated in
 // oracle/pyref/hyperplonk.py, which the tests compare against byte for byte.
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <set>
 #include "host.hpp"
@@ -133,37 +134,49 @@ PcsProver zeromorph_pcs(Ctx& c, const USrs& srs, size_t poly_size) {
   return p;
 }
 
+namespace {
+struct PhaseTimer {  // LH_HP_DEBUG=1: wall-clock per phase on stderr (development aid)
+  Ctx& c;
+  bool on;
+  double t;
+  static double now() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  }
+  explicit PhaseTimer(Ctx& c_) : c(c_), on(getenv("LH_HP_DEBUG") != nullptr), t(now()) {}
+  void lap(const char* what) {
+    if (!on) return;
+    c.sync();
+    double n = now();
+    fprintf(stderr, "[hyperplonk] %-28s %8.3f ms\n", what, n - t);
+    t = n;
+  }
+};
+}  // namespace
+
 void hyperplonk_prove(Ctx& c, const PcsProver& pcs, const lh_hp_param& pp, const HFr* const* instances,
                       const Fr* const* d_witness, Transcript& tr) {
+  PhaseTimer pt(c);
   const size_t nv = pp.num_vars, n = (size_t)1 << nv;
   LH_REQUIRE(nv >= 1 && nv < 32, LH_ERR_ARG, "hyperplonk: bad num_vars");
   ArenaScope scope(c.arena);
 
-  // BooleanHypercube order / nth_map (bh.rs:127-141), host-generated once per call
-  std::vector<uint32_t> order(n), nth(n);
-  order[0] = 0;
-  {
-    size_t b = 1;
-    for (size_t k = 1; k < n; k++) {
-      order[k] = (uint32_t)b;
-      b = bh_next(b, nv);
-    }
-    for (size_t k = 0; k < n; k++) nth[order[k]] = (uint32_t)k;
-  }
+  // BooleanHypercube order / nth_map (bh.rs:127-141), generated on the device: order[k] = x^(k-1) in GF(2^nv)
   uint32_t* d_order = c.arena.alloc_n<uint32_t>(n);
   uint32_t* d_nth = c.arena.alloc_n<uint32_t>(n);
-  LH_HIP(hipMemcpyAsync(d_order, order.data(), n * 4, hipMemcpyHostToDevice, c.stream));
-  LH_HIP(hipMemcpyAsync(d_nth, nth.data(), n * 4, hipMemcpyHostToDevice, c.stream));
+  k_bh_order(c, nv, bh_primitive(nv), d_order, d_nth);
 
+  pt.lap("hypercube order tables");
   // instances: hashed, then placed on rows bh[1], bh[2], .. (hyperplonk.rs:170-177,365-369; prover.rs:32-48)
   std::vector<const Fr*> polys;
   for (size_t i = 0; i < pp.num_instance_polys; i++) {
     const size_t cnt = pp.num_instances[i];
     LH_REQUIRE(cnt <= n, LH_ERR_ARG, "hyperplonk: too many instances");
     std::vector<uint32_t> rows(cnt);
+    size_t b = 1;  // bh.iter(): 0, 1, x, x^2, ...
     for (size_t k = 0; k < cnt; k++) {
       tr.common_field_element(instances[i][k]);
-      rows[k] = k + 1 < n ? order[k + 1] : 0;  // row_mapping = bh.iter().skip(1).chain([0])
+      rows[k] = k + 1 < n ? (uint32_t)b : 0;  // row_mapping = bh.iter().skip(1).chain([0])
+      b = bh_next(b, nv);
     }
     Fr* tab = c.arena.alloc_n<Fr>(n);
     uint32_t* d_rows = c.arena.alloc_n<uint32_t>(std::max<size_t>(cnt, 1));
@@ -178,6 +191,7 @@ void hyperplonk_prove(Ctx& c, const PcsProver& pcs, const lh_hp_param& pp, const
   }
   for (size_t i = 0; i < pp.num_preprocess_polys; i++) polys.push_back((const Fr*)pp.d_preprocess_polys[i]);
 
+  pt.lap("instance polys");
   // round 0: witness commitments (single phase: synthesize(0, []) = d_witness)
   std::vector<HFr> challenges;
   {
@@ -188,6 +202,7 @@ void hyperplonk_prove(Ctx& c, const PcsProver& pcs, const lh_hp_param& pp, const
     challenges.insert(challenges.end(), ch.begin(), ch.end());
   }
 
+  pt.lap("witness commitments");
   // round n: beta, lookup m polys
   HFr beta = tr.squeeze_challenge();
   size_t width = 0;
@@ -213,6 +228,7 @@ void hyperplonk_prove(Ctx& c, const PcsProver& pcs, const lh_hp_param& pp, const
     tr.write_commitments(comms);
   }
 
+  pt.lap("lookup compressed + m + commit");
   // round n+1: gamma, lookup h polys and permutation z polys
   HFr gamma = tr.squeeze_challenge();
   for (size_t k = 0; k < pp.num_lookups; k++) k_lookup_h(c, comp_in[k], comp_tab[k], m_polys[k], dev(gamma), n, h_polys[k]);
@@ -235,6 +251,7 @@ void hyperplonk_prove(Ctx& c, const PcsProver& pcs, const lh_hp_param& pp, const
     tr.write_commitments(comms);
   }
 
+  pt.lap("h, z polys + commit");
   // round n+2: alpha, y, zero-check
   HFr alpha = tr.squeeze_challenge();
   std::vector<HFr> y = tr.squeeze_challenges(nv);
@@ -249,6 +266,7 @@ void hyperplonk_prove(Ctx& c, const PcsProver& pcs, const lh_hp_param& pp, const
                                            challenges.size(), y.data(), 1, HFr::zero(), tr);
   const std::vector<HFr>& x = sc.challenges;
 
+  pt.lap("zero-check sum-check");
   // evaluations in pcs_query order (verifier.rs:147-180, prover.rs:388-406)
   std::set<std::pair<size_t, int>> query;
   for (size_t i = 0; i < pp.expression.num_nodes; i++) {
@@ -286,7 +304,9 @@ void hyperplonk_prove(Ctx& c, const PcsProver& pcs, const lh_hp_param& pp, const
     }
   }
   tr.write_field_elements(eval_values);
+  pt.lap("rotation evaluations");
   pcs.batch_open(nv, polys.data(), polys.size(), points.data(), num_points, evals.data(), evals.size(), tr);
+  pt.lap("batch open");
 }
 
 }  // namespace lh

@@ -37,12 +37,56 @@ __device__ __forceinline__ uint32_t bh_rotate(uint32_t b, int rot, uint32_t num_
   return b;
 }
 
+// order[k] = bh.iter().nth(k): 0, then x^(k-1) in GF(2)[x] / primitive; nth is the inverse permutation.
+__device__ __forceinline__ uint32_t gf2_mul(uint32_t a, uint32_t b, uint32_t num_vars, uint32_t primitive) {
+  uint64_t r = 0;
+  for (uint32_t i = 0; i < num_vars; i++)
+    if ((b >> i) & 1u) r ^= (uint64_t)a << i;
+  for (int i = 2 * (int)num_vars - 2; i >= (int)num_vars; i--)
+    if ((r >> i) & 1u) r ^= (uint64_t)primitive << (i - (int)num_vars);
+  return (uint32_t)r;
+}
+__global__ void bh_order_kernel(uint32_t num_vars, uint32_t primitive, uint32_t* __restrict__ order,
+                                uint32_t* __restrict__ nth) {
+  const size_t n = (size_t)1 << num_vars, chunks = (n + 63) / 64;
+  GSTRIDE(c, chunks) {
+    // x^(64 c - 1) by square-and-multiply, then 64 steps of "times x"
+    size_t k = c * 64;
+    uint32_t b = 1;
+    if (k > 0) {
+      uint32_t sq = 2u;  // x (a second chunk exists only when num_vars >= 7)
+      for (size_t e = k - 1; e; e >>= 1) {
+        if (e & 1) b = gf2_mul(b, sq, num_vars, primitive);
+        sq = gf2_mul(sq, sq, num_vars, primitive);
+      }
+    }
+    for (size_t j = 0; j < 64 && k + j < n; j++) {
+      const size_t kk = k + j;
+      uint32_t v;
+      if (kk == 0) {
+        v = 0;
+      } else {
+        v = b;
+        uint64_t t = (uint64_t)b << 1;
+        b = (uint32_t)(t ^ ((t >> num_vars) * primitive));
+      }
+      order[kk] = v;
+      nth[v] = (uint32_t)kk;
+    }
+  }
+}
+void k_bh_order(Ctx& c, size_t num_vars, uint32_t primitive, uint32_t* order, uint32_t* nth) {
+  const size_t chunks = (((size_t)1 << num_vars) + 63) / 64;
+  hipLaunchKernelGGL(bh_order_kernel, grid_for(chunks, 64), 64, 0, c.stream, (uint32_t)num_vars, primitive, order, nth);
+}
+
 __global__ void rotate_gather_kernel(const Fr* __restrict__ poly, size_t n, int rot, uint32_t num_vars, uint32_t primitive,
                                      uint32_t x_inv, Fr* __restrict__ out) {
   GSTRIDE(b, n) out[b] = poly[bh_rotate((uint32_t)b, rot, num_vars, primitive, x_inv)];
 }
 void k_rotate_gather(Ctx& c, const Fr* poly, size_t num_vars, int rot, uint32_t primitive, uint32_t x_inv, Fr* out) {
   size_t n = (size_t)1 << num_vars;
+  ProfScope ps(c, "rotate_gather", 64.0 * n, 0.0, (double)n);
   hipLaunchKernelGGL(rotate_gather_kernel, grid_for(n), 256, 0, c.stream, poly, n, rot, (uint32_t)num_vars, primitive,
                      x_inv, out);
 }
@@ -345,6 +389,7 @@ __global__ void expr_rows_kernel(RowsExpr e, size_t n, Fr* __restrict__ out) {
   }
 }
 void k_expr_rows(Ctx& c, const RowsExpr& e, size_t n, Fr* out) {
+  ProfScope ps(c, "expr_rows", 32.0 * n * (e.num_terms + 1), 2.0 * n * e.num_terms, (double)n);
   if (n) hipLaunchKernelGGL(expr_rows_kernel, grid_for(n), 256, 0, c.stream, e, n, out);
 }
 

@@ -55,12 +55,22 @@ __global__ void m_probe_kernel(const Fr* __restrict__ input, const Fr* __restric
         break;
       }
     }
+    // count: lanes of a wave that hit the same table row are combined before the atomic (a selector column that
+    // is zero on most rows sends most inputs to ONE row; unaggregated that is a million atomics on one address)
     if (best < 0) atomicAdd(missing, 1u);  // Error::InvalidSnark("Invalid lookup input") (prover.rs:176-178)
-    else atomicAdd(&counts[best], 1u);
+    unsigned long long todo = __ballot(best >= 0);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const long long v = __shfl(best, leader, 64);
+      const unsigned long long same = __ballot(best == v) & todo;
+      if ((int)(threadIdx.x & 63) == leader) atomicAdd(&counts[v], (uint32_t)__popcll(same));
+      todo &= ~same;
+    }
   }
 }
 
 bool k_lookup_m(Ctx& c, const Fr* input, const Fr* table, size_t n, Fr* m_out) {
+  ProfScope ps(c, "lookup_m", (64.0 + 32.0 + 24.0 * 4) * n, 0.0, (double)n);
   ArenaScope scope(c.arena);
   uint64_t* keys = c.arena.alloc_n<uint64_t>(n);
   uint64_t* skeys = c.arena.alloc_n<uint64_t>(n);
@@ -89,6 +99,7 @@ __global__ void h_final_kernel(const Fr* __restrict__ hi, const Fr* __restrict__
   GSTRIDE(i, n) h[i] = sub(hi[i], mul(ht[i], m[i]));
 }
 void k_lookup_h(Ctx& c, const Fr* input, const Fr* table, const Fr* m, const Fr& gamma, size_t n, Fr* h) {
+  ProfScope ps(c, "lookup_h", (3 * 32.0 + 32.0 + 4 * 64.0) * n, 8.0 * n, (double)n);
   ArenaScope scope(c.arena);
   Fr* a = c.arena.alloc_n<Fr>(n);
   Fr* b = c.arena.alloc_n<Fr>(n);
@@ -232,6 +243,7 @@ static void fr_prefix_product(Ctx& c, const Fr* in, size_t n, Fr* out) {
 void k_permutation_z(Ctx& c, const Fr* const* values, const Fr* const* perms, size_t num_perm, size_t num_chunks,
                      size_t num_vars, const Fr& beta, const Fr& gamma, const uint32_t* d_order, const uint32_t* d_nth,
                      Fr* const* z_out) {
+  ProfScope ps(c, "permutation_z", (2.0 * num_perm + 6.0 * num_chunks) * 32.0 * ((size_t)1 << num_vars), (2.0 * num_perm + 5.0 * num_chunks) * ((size_t)1 << num_vars), (double)((size_t)1 << num_vars));
   if (!num_perm) return;
   LH_REQUIRE(num_chunks >= 1 && num_chunks <= (size_t)PERM_MAX, LH_ERR_ARG, "permutation: too many z polys");
   const size_t n = (size_t)1 << num_vars;
