@@ -387,6 +387,17 @@ SumCheckResult sum_check_prove_expr(Ctx& c, size_t num_vars, const lh_expr& expr
       throw Error(LH_ERR_ARG, "expression: leaf without a table");
     };
     Program prog = compile_program(expr, challenges, num_challenges, leaf_table);
+    if (prog.ok && getenv("LH_HP_DEBUG")) {
+      size_t muls = 0, atoms = 0;
+      for (size_t i = 0; i < prog.code.size(); i += 2) {
+        const uint32_t w0 = prog.code[i];
+        muls += (w0 & 15u) == PROG_MUL;
+        atoms += ((w0 >> 8) & 3u) == PROG_ATOM;
+        atoms += ((w0 & 15u) <= PROG_MUL) && ((w0 >> 10) & 3u) == PROG_ATOM;
+      }
+      fprintf(stderr, "[expr] program: %zu instructions, %zu multiplications, %zu table operands, %u registers, %zu constants, degree %d, %zu tables\n",
+              prog.code.size() / 2, muls, atoms, prog.num_regs, prog.consts.size(), ex.degree, T);
+    }
     if (prog.ok) {
       uint32_t* d_code = c.arena.alloc_n<uint32_t>(prog.code.size());
       Fr* d_consts = c.arena.alloc_n<Fr>(std::max<size_t>(prog.consts.size(), 1));

@@ -284,12 +284,17 @@ __global__ __launch_bounds__(512) void sc_round_prog_kernel(ProgRound pr, size_t
   __shared__ int is_last;
   const uint32_t nthreads = blockDim.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;  // wave = X - 1
+  // the instruction stream lives in LDS behind the register file: a scalar load from global memory per
+  // instruction (~200 ns) would cost as much as the arithmetic it decodes
+  uint32_t* lds_code = prog_regs + (size_t)pr.num_regs * 8 * nthreads;
+  for (uint32_t i = threadIdx.x; i < 2 * pr.num_instrs; i += nthreads) lds_code[i] = pr.code[i];
+  __syncthreads();
   Fr acc = Fr::zero();
   for (size_t base = (size_t)blockIdx.x * 64; base < size; base += (size_t)gridDim.x * 64) {
     const size_t b = base + lane;
     if (b < size) {
       for (uint32_t i = 0; i < pr.num_instrs; i++) {
-        const uint32_t w0 = pr.code[2 * i], w1 = pr.code[2 * i + 1];
+        const uint32_t w0 = lds_code[2 * i], w1 = lds_code[2 * i + 1];
         const uint32_t op = w0 & 15u, dst = (w0 >> 4) & 15u;
         const Fr a = prog_operand(pr, prog_regs, (w0 >> 8) & 3u, w1 & 0xffffu, b, wave, nthreads);
         Fr res;
@@ -345,7 +350,8 @@ void k_sc_round_prog(Ctx& c, const ProgRound& pr, int degree, size_t size, Fr* e
   const uint32_t seq = c.next_seq();
   ArenaScope scope(c.arena);
   const unsigned threads = 64u * (unsigned)degree;
-  const size_t lds_bytes = (size_t)pr.num_regs * 32 * threads;
+  const size_t lds_bytes = (size_t)pr.num_regs * 32 * threads + (size_t)pr.num_instrs * 8;
+  LH_REQUIRE(lds_bytes <= 150 * 1024, LH_ERR_ARG, "sum-check program: too large for LDS");
   static const hipError_t attr = hipFuncSetAttribute((const void*)sc_round_prog_kernel,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
   LH_HIP(attr);  // function-local static: set exactly once, thread-safe
