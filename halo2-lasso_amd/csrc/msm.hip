@@ -380,6 +380,22 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
         }
       }
     }
+    // buckets per reduce thread: the segment kernel is a chain of 2 S additions plus a small-scalar multiplication
+    // per thread.  Few buckets in total = too few threads to fill the chip = pure latency: shorter segments then
+    // (S = 4: ~30 dependent curve operations instead of ~51); many buckets = throughput: S = 16 does least work.
+    uint32_t seg_size = 16;
+    {
+      size_t est = 0;
+      for (size_t j = 0; j < nj; j++) {
+        const MsmJob& in = jobs[base + j];
+        const uint32_t bits = job_bits[j];
+        if (!in.n || !bits) continue;
+        const uint32_t cw = pick_window(in.n, bits);
+        est += ((size_t)(bits + cw) / cw) << (in.scalars_u32 ? cw : cw - 1);
+      }
+      static const int forced = env_int("LH_MSM_SEG", 0);
+      seg_size = forced ? (uint32_t)forced : est <= ((size_t)1 << 18) ? 4u : est <= ((size_t)1 << 20) ? 8u : 16u;
+    }
     uint32_t key = 0, seg = 0, win = 0;
     size_t max_entries = 0, max_n = 0;
     for (size_t j = 0; j < nj; j++) {
@@ -394,7 +410,7 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
       jd.W = bits ? ((jd.is_signed ? bits + 1 : bits) + jd.c - 1) / jd.c : 0;
       if (!in.n) jd.W = 0;
       const uint32_t nb = jd.is_signed ? (1u << (jd.c - 1)) + 1u : (1u << jd.c);  // bucket indices 0..nb-1
-      jd.seg_size = 16;
+      jd.seg_size = seg_size;
       jd.seg_per_win = (nb + jd.seg_size - 1) / jd.seg_size;
       jd.win_stride = jd.seg_per_win * jd.seg_size;
       key = (key + (1u << KEY_BLOCK_BITS) - 1) & ~((1u << KEY_BLOCK_BITS) - 1);
