@@ -212,7 +212,7 @@ void k_shard_extract(Ctx&, const void* global, size_t n_local, size_t j, size_t 
 void k_scale(Ctx&, const Fr* in, const Fr& w, size_t n, Fr* out);
 
 // ------------------------------------------------------------------ sum-check round (kernels_sumcheck.hip)
-constexpr int SC_MAX_TABLES = 40;
+constexpr int SC_MAX_TABLES = 72;  // 32 product trees (8 memories) + eq fit one GKR batch; kernel arguments stay < 4 KB
 struct ScRound {
   // tables of the current round: BIND ? 4*size entries in, 2*size out : 2*size entries in
   const Fr* in[SC_MAX_TABLES];

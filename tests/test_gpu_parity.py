@@ -394,3 +394,22 @@ def test_lasso_rejects_out_of_range_chunk_index(hl, ctx, srs6):
     t = hl.Keccak256Transcript()  # the context is still usable afterwards
     hl.lasso_prove(pp, hl.LassoTable.range(2, 4), 4, [ctx.upload(good.tobytes()), ctx.upload(good.tobytes())], t)
     assert len(t.into_proof()) > 0
+
+
+@pytest.mark.parametrize("kind,c,l,n", [("and", 8, 4, 5), ("xor", 8, 2, 3), ("range", 8, 3, 4)])
+def test_lasso_eight_chunks(hl, ctx, kind, c, l, n):
+    """c = 8 chunks (64-bit operands as 8 x (8+8)-bit chunks in production; tiny chunk width here): 8 memories,
+    32 product trees in one GKR batch, 33 committed columns"""
+    rng = random.Random(1234 + n)
+    ss = [rng.randrange(1, P) for _ in range(max(n, l))]
+    opp, pp = o_kzg.setup(ss), hl.MultilinearKzg.setup(ctx, ss)
+    spec = o_lasso.range_table(c, l) if kind == "range" else o_lasso.bitwise_table(
+        o_lasso.SUBTABLE_AND if kind == "and" else o_lasso.SUBTABLE_XOR, c, l)
+    dims = [[rng.randrange(1 << l) for _ in range(1 << n)] for _ in range(c)]
+    ot = OT()
+    o_lasso.prove(opp, spec, dims, ot)
+    t = hl.Keccak256Transcript()
+    hl.lasso_prove(pp, _table(hl, kind, c, l), n, [ctx.upload(array.array("I", d).tobytes()) for d in dims], t)
+    assert t.into_proof() == ot.into_proof()
+    hl.lasso_verify(hl.MultilinearKzgVerifierParams.setup(ss), _table(hl, kind, c, l), n,
+                    hl.Keccak256Transcript.from_proof(t.into_proof()))

@@ -5,8 +5,9 @@ import numpy as np
 import halo2_lasso_amd as hl
 kind, n = sys.argv[1], int(sys.argv[2])
 ctx = hl.Context(0)
+chunks = 8 if kind.endswith("64") else 4   # and64 / xor64: 64-bit operands as 8 chunks of 8+8 bits
 table = hl.LassoTable.range(2, 16) if kind == "range" else hl.LassoTable.bitwise(
-    hl.SUBTABLE_AND if kind == "and" else hl.SUBTABLE_XOR, 4, 16)
+    hl.SUBTABLE_AND if kind.startswith("and") else hl.SUBTABLE_XOR, chunks, 16)
 rng = np.random.default_rng(1)
 t = time.perf_counter()
 ss = [int(v) for v in rng.integers(1, 1 << 62, size=n)]
