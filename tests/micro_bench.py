@@ -3,7 +3,10 @@
   fractional_sum_check.rs:329  GKR fractional sum-check, 3 batched fractions
 plus the two stream ceilings every roofline in DESIGN.md is priced against (bind GB/s beyond the 256 MiB
 Infinity Cache, Fr multiplications/s).  GPU = HIP path through the C-ABI, CPU = oracle/cpu on all cores.
-Writes one JSON document (stdout)."""
+Writes one JSON document (stdout).
+
+Not a pytest module (a measurement script: `python tests/micro_bench.py 20`); it lives under tests/ because it
+times the oracle next to the GPU path, and only tests/, smoke() and bench.py's cpu_baseline leg may use oracle/."""
 import ctypes as C
 import json
 import os
