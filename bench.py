@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-n", type=int, default=20, help="log2 of the number of lookups per proof")
     ap.add_argument("--table", default="range", choices=["range", "and", "xor"])
+    ap.add_argument("--pcs", default="mkzg", choices=["mkzg", "zeromorph"],
+                    help="polynomial commitment scheme of the Lasso workload: multilinear KZG (default, the metric's "
+                         "configuration) or Zeromorph over univariate KZG")
     ap.add_argument("--workload", default="lasso", choices=["lasso", "hyperplonk"],
                     help="'lasso' (default, BASELINE metric) or 'hyperplonk': HyperPlonk + LogUp prove of a synthetic "
                          "vanilla_plonk_with_lookup circuit of 2^log-n rows (SURVEY.md §8d C5 substitute)")
@@ -127,17 +130,24 @@ def fr_mul_peak(hl, ctx):
 def cpu_baseline(hl, ctx, pp, table, kind, args, gpu_proof_fn):
     co = use_native_oracle()
     cores = co.num_threads()
-    srs_nv = pp.num_vars
-    total = (2 << srs_nv) - 1
-    srs = C.create_string_buffer(64 * total)
-    hl._check(ctx.lib.lh_srs_download(ctx.h, pp.h, srs))
+    zm = isinstance(pp, hl.ZeromorphProverParam)
+    if zm:
+        srs = C.create_string_buffer(64 * pp.params.size)
+        hl._check(ctx.lib.lh_usrs_download(ctx.h, pp.params.h, srs))
+    else:
+        srs_nv = pp.num_vars
+        srs = C.create_string_buffer(64 * ((2 << srs_nv) - 1))
+        hl._check(ctx.lib.lh_srs_download(ctx.h, pp.h, srs))
     tc = table.to_c()
 
     def run(n):
         dims = gen_dims(table, n, 0)
         tr = co.Transcript()
         t = time.perf_counter()
-        co.lasso_prove(tr, srs, srs_nv, tc, n, [d.tobytes() for d in dims])
+        if zm:
+            co.lasso_prove_zm(tr, srs.raw, pp.poly_size, tc, n, [d.tobytes() for d in dims])
+        else:
+            co.lasso_prove(tr, srs, srs_nv, tc, n, [d.tobytes() for d in dims])
         return (time.perf_counter() - t) * 1e3, tr.into_proof(), dims
 
     n = args.cpu_sample_log_n
@@ -312,8 +322,14 @@ def main():
     ctx = hl.Context(int(os.environ.get("LH_DEVICE", local_rank)))  # LH_DEVICE: several ranks on one GPU (tests)
     n = args.log_n
     table, desc = make_table(hl, args.table)
-    pp = hl.MultilinearKzg.setup(ctx, trapdoor(max(n, table.l)))
+    nv_max = max(n, table.l)
+    zm = args.pcs == "zeromorph"
+    if zm:
+        pp = hl.Zeromorph.trim(hl.Zeromorph.setup(ctx, trapdoor(1)[0], 1 << nv_max), 1 << nv_max)
+    else:
+        pp = hl.MultilinearKzg.setup(ctx, trapdoor(nv_max))
     sharded = args.mode == "sharded" and world > 1
+    assert not (zm and sharded), "the sharded mode is implemented for multilinear KZG"
     # sharded: every rank holds the same full lookup columns (the counters need the global order)
     d_dims = [ctx.upload(d.tobytes()) for d in gen_dims(table, n, 0 if sharded else rank)]
     ctx.sync()
@@ -362,7 +378,8 @@ def main():
             "higher_is_better": False, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "u256 (BN254 Fr/Fq, 8x u32 Montgomery)",
             "data": "synthetic",
             "config": {"workload": desc % n, "lookups_per_proof": 1 << n, "proofs_per_step": 1 if sharded else world,
-                       "pcs": "multilinear KZG (BN254)", "proof_bytes": proof_len,
+                       "pcs": "Zeromorph over univariate KZG (BN254)" if zm else "multilinear KZG (BN254)",
+                       "proof_bytes": proof_len,
                        "parallelism": ("1 proof sharded over %d GPUs" % world if sharded else
                                        "1 proof per GPU" if world > 1 else "1 GPU")},
             "lookups_per_s": round((1 << n) * (1 if sharded else world) / (ms_per_step / 1e3)),
@@ -382,7 +399,12 @@ def main():
             # thread each): a single proof leaves the chip idle during its ~250 latency-bound rounds and MSM tails
             import threading
             ctx2 = hl.Context(int(os.environ.get("LH_DEVICE", local_rank)))
-            pp2 = hl.MultilinearKzgParams(ctx2, pp.h)  # the SRS is device memory: shared, owned by `pp`
+            # the SRS is device memory: shared, owned by `pp`
+            if zm:
+                shared = hl.UnivariateKzgParams(ctx2, pp.params.h)
+                pp2 = hl.ZeromorphProverParam(shared, pp.poly_size)
+            else:
+                shared = pp2 = hl.MultilinearKzgParams(ctx2, pp.h)
 
             def worker(p, k):
                 for _ in range(k):
@@ -397,7 +419,7 @@ def main():
                     t.join()
                 ctx.sync(), ctx2.sync()
                 dt = time.perf_counter() - t0
-            pp2.h = None
+            shared.h = None
             out["two_proofs_in_flight"] = {"ms_per_proof": round(dt * 1e3 / (2 * args.steps), 3),
                                            "lookups_per_s": round((1 << n) * 2 * args.steps / dt)}
         if not args.no_cpu_baseline and not sharded:

@@ -558,8 +558,10 @@ struct Eval {  // same layout as lh_evaluation
   uint32_t poly, point;
   Fr value;
 };
-static void batch_open(Transcript& tr, const Srs& s, size_t nv, const std::vector<const Poly*>& polys,
-                       const std::vector<std::vector<Fr>>& points, const std::vector<Eval>& evals) {
+// additive::batch_open (pcs/multilinear.rs:134-235), generic over the PCS through `open`
+static void batch_open_with(Transcript& tr, size_t nv, const std::vector<const Poly*>& polys,
+                            const std::vector<std::vector<Fr>>& points, const std::vector<Eval>& evals,
+                            const std::function<void(const Poly&, const Fr*)>& open) {
   if (evals.size() < 2) throw OracleError("batch open needs >= 2 evaluations");
   size_t ell = 0;
   while (((size_t)1 << ell) < evals.size()) ell++;
@@ -595,7 +597,92 @@ static void batch_open(Transcript& tr, const Srs& s, size_t nv, const std::vecto
       for (size_t k = a; k < b; k++) g[k] = g[k] + w * merged[j][k];
     });
   }
-  kzg_open(tr, s, g, sc.x.data(), nv);
+  open(g, sc.x.data());
+}
+static void batch_open(Transcript& tr, const Srs& s, size_t nv, const std::vector<const Poly*>& polys,
+                       const std::vector<std::vector<Fr>>& points, const std::vector<Eval>& evals) {
+  batch_open_with(tr, nv, polys, points, evals, [&](const Poly& g, const Fr* x) { kzg_open(tr, s, g, x, nv); });
+}
+
+// ------------------------------------------------------------------ Zeromorph over univariate KZG
+// pcs/univariate/kzg.rs:23-36,175-299 and pcs/multilinear/zeromorph.rs:86-213,258-296; spec twin: oracle/pyref/zeromorph.py
+struct USrs {
+  const Affine* powers;  // powers_of_s_g1
+  size_t size, poly_size;  // poly_size: trim size; the opening quotient is committed against powers[size - poly_size..]
+};
+static Affine zm_commit(const USrs& s, const Poly& p) {
+  if (p.size() > s.poly_size) throw OracleError("Too large degree of poly to commit");
+  return msm(p.data(), s.powers, p.size());
+}
+static void zm_scalars(const Fr& y, const Fr& x, const Fr& z, const Fr* u, size_t n, Fr& eval_scalar,
+                       std::vector<Fr>& q_scalars) {  // zeromorph.rs:258-296
+  std::vector<Fr> squares(n + 1), offsets(n), vs(n + 1);
+  squares[0] = x;
+  for (size_t i = 0; i < n; i++) squares[i + 1] = squares[i] * squares[i];
+  Fr state = Fr::one();
+  for (size_t i = n; i-- > 0;) {
+    state = state * squares[i];
+    offsets[i] = state;
+  }
+  const Fr v_numer = squares[n] - Fr::one();
+  for (size_t i = 0; i <= n; i++) vs[i] = v_numer * (squares[i] - Fr::one()).inv();
+  q_scalars.resize(n);
+  Fr py = Fr::one();
+  for (size_t i = 0; i < n; i++) {
+    q_scalars[i] = Fr::zero() - (py * offsets[i] + z * (squares[i] * vs[i + 1] - u[i] * vs[i]));
+    py = py * y;
+  }
+  eval_scalar = Fr::zero() - vs[0] * z;
+}
+static void zm_open(Transcript& tr, const USrs& s, const Poly& poly, const Fr* point, size_t nv) {
+  const size_t n = (size_t)1 << nv;
+  if (n > s.poly_size) throw OracleError("Too large degree of poly to open");
+  Poly rem = poly;
+  std::vector<Poly> qs(nv);
+  for (size_t i = nv; i-- > 0;) {
+    size_t half = (size_t)1 << i;
+    Poly q(half), lo(half);
+    parallelize(half, [&](size_t a, size_t b) {
+      for (size_t k = a; k < b; k++) {
+        q[k] = rem[half + k] - rem[k];
+        lo[k] = rem[k] + q[k] * point[i];
+      }
+    });
+    rem.swap(lo);
+    qs[i] = std::move(q);
+  }
+  for (auto& q : qs) tr.write_comm(msm(q.data(), s.powers, q.size()));
+  const Fr y = tr.squeeze();
+  Poly q_hat(n, Fr::zero());
+  Fr py = Fr::one();
+  for (size_t k = 0; k < nv; k++) {
+    const size_t off = n - ((size_t)1 << k);
+    for (size_t j = 0; j < qs[k].size(); j++) q_hat[off + j] = q_hat[off + j] + py * qs[k][j];
+    py = py * y;
+  }
+  tr.write_comm(msm(q_hat.data(), s.powers, n));
+  const Fr x = tr.squeeze(), z = tr.squeeze();
+  Fr eval_scalar;
+  std::vector<Fr> q_scalars;
+  zm_scalars(y, x, z, point, nv, eval_scalar, q_scalars);
+  Poly f(n);
+  parallelize(n, [&](size_t a, size_t b) {
+    for (size_t j = a; j < b; j++) f[j] = z * poly[j] + q_hat[j];
+  });
+  for (size_t k = 0; k < nv; k++)
+    for (size_t j = 0; j < qs[k].size(); j++) f[j] = f[j] + q_scalars[k] * qs[k][j];
+  // quotient by X - x (the constant term, where eval_scalar * eval would go, does not enter)
+  Poly quot(n - 1);
+  Fr carry = Fr::zero();
+  for (size_t i = n - 1; i >= 1; i--) {
+    carry = f[i] + carry * x;
+    quot[i - 1] = carry;
+  }
+  tr.write_comm(msm(quot.data(), s.powers + (s.size - s.poly_size), n - 1));
+}
+static void zm_batch_open(Transcript& tr, const USrs& s, size_t nv, const std::vector<const Poly*>& polys,
+                          const std::vector<std::vector<Fr>>& points, const std::vector<Eval>& evals) {
+  batch_open_with(tr, nv, polys, points, evals, [&](const Poly& g, const Fr* x) { zm_open(tr, s, g, x, nv); });
 }
 
 // ------------------------------------------------------------------ Lasso (spec: oracle/pyref/lasso.py)
@@ -618,7 +705,13 @@ static Poly to_poly(const std::vector<uint32_t>& v) {
   });
   return p;
 }
-static void lasso_prove(Transcript& tr, const Srs& s, const LassoTable& tb, size_t n, const uint32_t* const* dims) {
+struct LassoPcsFns {
+  std::function<Affine(const Poly&)> commit;
+  std::function<void(size_t, const std::vector<const Poly*>&, const std::vector<std::vector<Fr>>&, const std::vector<Eval>&)>
+      batch_open;
+  size_t max_vars;
+};
+static void lasso_prove(Transcript& tr, const LassoPcsFns& s, const LassoTable& tb, size_t n, const uint32_t* const* dims) {
   const size_t c = tb.c, l = tb.l, alpha = tb.alpha, N = (size_t)1 << n, M = (size_t)1 << l;
   std::vector<std::vector<uint32_t>> rts(c, std::vector<uint32_t>(N)), fcs(c, std::vector<uint32_t>(M, 0));
   for (size_t j = 0; j < c; j++)
@@ -657,7 +750,7 @@ static void lasso_prove(Transcript& tr, const Srs& s, const LassoTable& tb, size
   std::vector<Poly> all;
   for (auto& p : pn) all.push_back(padded(p));
   for (auto& p : pl) all.push_back(padded(p));
-  for (auto& p : all) tr.write_comm(commit(s, p));
+  for (auto& p : all) tr.write_comm(s.commit(p));
 
   std::vector<Fr> r = tr.squeeze_n(n);
   Fr v = evaluate(a, r.data(), n);
@@ -716,7 +809,7 @@ static void lasso_prove(Transcript& tr, const Srs& s, const LassoTable& tb, size
     pt.resize(nv, Fr::zero());
     return pt;
   };
-  batch_open(tr, s, nv, pp, {pad_pt(r), pad_pt(sc.x), pad_pt(r_N), pad_pt(r_M)}, evs);
+  s.batch_open(nv, pp, {pad_pt(r), pad_pt(sc.x), pad_pt(r_N), pad_pt(r_M)}, evs);
 }
 
 // ------------------------------------------------------------------ HyperPlonk with LogUp (backend/hyperplonk)
@@ -1280,7 +1373,82 @@ int orc_hyperplonk_prove(void* t, const Affine* eqs, size_t srs_nv, const HpPara
 }
 int orc_lasso_prove(void* t, const Affine* eqs, size_t srs_nv, const LassoTable* tb, size_t n,
                     const uint32_t* const* dims) {
-  ORC_TRY lasso_prove(*(Transcript*)t, Srs{eqs, srs_nv}, *tb, n, dims);
+  ORC_TRY
+  Transcript& tr = *(Transcript*)t;
+  const Srs s{eqs, srs_nv};
+  LassoPcsFns f;
+  f.commit = [&](const Poly& p) { return commit(s, p); };
+  f.batch_open = [&](size_t nv, const std::vector<const Poly*>& polys, const std::vector<std::vector<Fr>>& pts,
+                     const std::vector<Eval>& evs) { batch_open(tr, s, nv, polys, pts, evs); };
+  f.max_vars = srs_nv;
+  lasso_prove(tr, f, *tb, n, dims);
+  ORC_CATCH
+}
+// powers_of_s_g1[i] = s^i G (univariate/kzg.rs:175-218)
+int orc_usetup(const Fr* s, size_t poly_size, Affine* powers) {
+  ORC_TRY
+  std::vector<Fr> scal(poly_size);
+  Fr p = Fr::one();
+  for (size_t i = 0; i < poly_size; i++) {
+    scal[i] = p;
+    p = p * *s;
+  }
+  std::vector<Affine> tab(32 * 255);
+  Jac off = jac_from_affine(Affine{Fq::from_u64(1), Fq::from_u64(2)});
+  for (int w = 0; w < 32; w++) {
+    Jac acc = off;
+    for (int d = 0; d < 255; d++) {
+      tab[w * 255 + d] = jac_to_affine(acc);
+      acc = jac_add(acc, off);
+    }
+    off = acc;
+  }
+  parallelize(poly_size, [&](size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; i++) {
+      uint64_t c[4];
+      scal[i].to_raw(c);
+      Jac acc = Jac::identity();
+      for (int w = 0; w < 32; w++) {
+        uint32_t d = (c[w / 8] >> (8 * (w % 8))) & 0xff;
+        if (d) acc = jac_add_affine(acc, tab[w * 255 + d - 1]);
+      }
+      powers[i] = jac_to_affine(acc);
+    }
+  });
+  ORC_CATCH
+}
+int orc_zm_commit(const Affine* powers, size_t size, size_t poly_size, const Fr* poly, size_t nv, Affine* out) {
+  ORC_TRY* out = zm_commit(USrs{powers, size, poly_size}, load_poly(poly, (size_t)1 << nv));
+  ORC_CATCH
+}
+int orc_zm_open(void* t, const Affine* powers, size_t size, size_t poly_size, const Fr* poly, size_t nv, const Fr* point) {
+  ORC_TRY zm_open(*(Transcript*)t, USrs{powers, size, poly_size}, load_poly(poly, (size_t)1 << nv), point, nv);
+  ORC_CATCH
+}
+int orc_zm_batch_open(void* t, const Affine* powers, size_t size, size_t poly_size, size_t nv, const Fr* const* polys,
+                      size_t num_polys, const Fr* points, size_t num_points, const Eval* evals, size_t num_evals) {
+  ORC_TRY
+  std::vector<Poly> ps;
+  for (size_t i = 0; i < num_polys; i++) ps.push_back(load_poly(polys[i], (size_t)1 << nv));
+  std::vector<const Poly*> pp;
+  for (auto& p : ps) pp.push_back(&p);
+  std::vector<std::vector<Fr>> pts;
+  for (size_t j = 0; j < num_points; j++) pts.emplace_back(points + j * nv, points + (j + 1) * nv);
+  zm_batch_open(*(Transcript*)t, USrs{powers, size, poly_size}, nv, pp, pts, std::vector<Eval>(evals, evals + num_evals));
+  ORC_CATCH
+}
+int orc_lasso_prove_zm(void* t, const Affine* powers, size_t size, size_t poly_size, const LassoTable* tb, size_t n,
+                       const uint32_t* const* dims) {
+  ORC_TRY
+  Transcript& tr = *(Transcript*)t;
+  const USrs s{powers, size, poly_size};
+  LassoPcsFns f;
+  f.commit = [&](const Poly& p) { return zm_commit(s, p); };
+  f.batch_open = [&](size_t nv, const std::vector<const Poly*>& polys, const std::vector<std::vector<Fr>>& pts,
+                     const std::vector<Eval>& evs) { zm_batch_open(tr, s, nv, polys, pts, evs); };
+  f.max_vars = 0;
+  while (((size_t)2 << f.max_vars) <= poly_size) f.max_vars++;
+  lasso_prove(tr, f, *tb, n, dims);
   ORC_CATCH
 }
 }

@@ -299,3 +299,37 @@ def hyperplonk_prove(tr, srs, srs_nv, num_vars, num_instances, preprocess_polys,
     inst, k3 = _ptrs([fr_bytes(i) if len(i) else bytes(32) for i in instances])
     wit, k4 = _ptrs([_poly_bytes(w) for w in witness])
     _chk(lib().orc_hyperplonk_prove(tr.h, srs, C.c_size_t(srs_nv), C.byref(pp), inst, wit))
+
+
+# ------------------------------------------------------------------ Zeromorph over univariate KZG (oracle.cpp: zm_*)
+def usetup(s, poly_size):
+    """-> powers_of_s_g1 as Montgomery bytes (64 per point)"""
+    out = C.create_string_buffer(64 * poly_size)
+    _chk(lib().orc_usetup(fr_bytes([s]), C.c_size_t(poly_size), out))
+    return out.raw
+
+
+def zm_commit(powers, poly_size, poly):
+    out = C.create_string_buffer(64)
+    nv = len(poly).bit_length() - 1
+    _chk(lib().orc_zm_commit(powers, C.c_size_t(len(powers) // 64), C.c_size_t(poly_size), fr_bytes(poly), C.c_size_t(nv), out))
+    return g1_point(out.raw)
+
+
+def zm_open(tr, powers, poly_size, poly, point):
+    _chk(lib().orc_zm_open(tr.h, powers, C.c_size_t(len(powers) // 64), C.c_size_t(poly_size), fr_bytes(poly),
+                           C.c_size_t(len(point)), fr_bytes(point)))
+
+
+def zm_batch_open(tr, powers, poly_size, nv, polys, points, evals_struct_array, num_evals):
+    arr, keep = _ptrs([fr_bytes(p) for p in polys])
+    flat = fr_bytes([v for p in points for v in p])
+    _chk(lib().orc_zm_batch_open(tr.h, powers, C.c_size_t(len(powers) // 64), C.c_size_t(poly_size), C.c_size_t(nv), arr,
+                                 C.c_size_t(len(polys)), flat, C.c_size_t(len(points)), evals_struct_array,
+                                 C.c_size_t(num_evals)))
+
+
+def lasso_prove_zm(tr, powers, poly_size, table_struct, n, dims_u32_bytes):
+    arr, keep = _ptrs(dims_u32_bytes)
+    _chk(lib().orc_lasso_prove_zm(tr.h, powers, C.c_size_t(len(powers) // 64), C.c_size_t(poly_size),
+                                  C.byref(table_struct), C.c_size_t(n), arr))

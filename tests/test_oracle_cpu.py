@@ -211,3 +211,45 @@ def test_hyperplonk_cpp_invalid_lookup(srs5):
     witness[1][row] = (witness[1][row] + 1) % P
     with pytest.raises(RuntimeError, match="Invalid lookup input"):
         _cpp_hyperplonk(srs, 5, info, instances, witness)
+
+
+# ------------------------------------------------------------------ Zeromorph: C++ oracle vs Python oracle vs golden
+def test_zeromorph_cpp_matches_python_and_golden(ffi):
+    from oracle.pyref import zeromorph as zm
+    g = GOLDEN["zeromorph"]
+    nv, s, size = g["num_vars"], int(g["s"], 16), g["param_size"]
+    powers = co.usetup(s, size)
+    pp, _ = zm.trim(zm.setup(s, size), 1 << nv)
+    assert [co.g1_point(powers[64 * i:64 * i + 64]) for i in range(size)] == zm.setup(s, size).powers_g1
+    tabs, point = [I(a) for a in g["polys"]], I(g["point"])
+    assert [hex(c) for c in co.zm_commit(powers, 1 << nv, tabs[0])] == g["commitment"]
+    t = co.Transcript()
+    co.zm_open(t, powers, 1 << nv, tabs[0], point)
+    assert t.into_proof().hex() == g["open_proof"]
+    tb = co.Transcript()
+    tb.write_commitments([co.zm_commit(powers, 1 << nv, p) for p in tabs])
+    pts = [tb.squeeze_challenges(nv) for _ in range(2)]
+    vals = [evaluate(tabs[p], pts[q]) for p, q in g["pairs"]]
+    tb.write_field_elements(vals)
+    evs = (ffi.lh_evaluation * len(vals))()
+    for i, ((p, q), v) in enumerate(zip(g["pairs"], vals)):
+        evs[i].poly, evs[i].point = p, q
+        C.memmove(C.byref(evs[i].value), co.fr_bytes([v]), 32)
+    co.zm_batch_open(tb, powers, 1 << nv, nv, tabs, pts, evs, len(vals))
+    assert tb.into_proof().hex() == g["batch_proof"]
+
+
+@pytest.mark.parametrize("kind,c,l,n", [("range", 2, 3, 4), ("xor", 2, 4, 3)])
+def test_lasso_over_zeromorph_cpp_matches_python(hl, kind, c, l, n):
+    from oracle.pyref import zeromorph as zm
+    rng = random.Random(17 + n)
+    s, nv = rng.randrange(1, P), max(n, l)
+    spec = lasso.range_table(c, l) if kind == "range" else lasso.bitwise_table(lasso.SUBTABLE_XOR, c, l)
+    table = hl.LassoTable.range(c, l) if kind == "range" else hl.LassoTable.bitwise(hl.SUBTABLE_XOR, c, l)
+    dims = [[rng.randrange(1 << l) for _ in range(1 << n)] for _ in range(c)]
+    pp, _ = zm.trim(zm.setup(s, 1 << nv), 1 << nv)
+    t = T()
+    lasso.prove(pp, spec, dims, t, pcs=zm)
+    ct = co.Transcript()
+    co.lasso_prove_zm(ct, co.usetup(s, 1 << nv), 1 << nv, table.to_c(), n, [array.array("I", d).tobytes() for d in dims])
+    assert ct.into_proof() == t.into_proof()
