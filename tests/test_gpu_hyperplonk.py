@@ -139,3 +139,31 @@ def test_hyperplonk_over_zeromorph_matches_oracle(hl, ctx, num_vars, with_lookup
     bad[len(bad) // 2] ^= 2
     with pytest.raises(hl.Error):
         g_hp.HyperPlonk.verify(g_vp, instances, hl.Keccak256Transcript.from_proof(bytes(bad)))
+
+
+@pytest.mark.parametrize("pcs,k", [("mkzg", 16), ("mkzg", 20), ("zeromorph", 18)])
+def test_hyperplonk_synthetic_circuit_verifies(hl, ctx, pcs, k):
+    """the numpy/device-built circuit of bench.py --workload hyperplonk at its measured sizes: the proof must verify,
+    and a proof for a witness with one wrong cell must not"""
+    import numpy as np
+    from halo2_lasso_amd import hyperplonk as g_hp, synthetic
+    circ = synthetic.vanilla_plonk_with_lookup(ctx, k)
+    ss = [int(v) for v in np.random.default_rng(k).integers(1, 1 << 62, size=k)]
+    if pcs == "mkzg":
+        pcs_pp, pcs_vp = hl.MultilinearKzg.setup(ctx, ss), hl.MultilinearKzgVerifierParams.setup(ss)
+    else:
+        pcs_pp = hl.Zeromorph.trim(hl.Zeromorph.setup(ctx, ss[0], 1 << k), 1 << k)
+        pcs_vp = hl.ZeromorphVerifierParam.setup(ss[0], 1 << k, 1 << k)
+    pp, vp = synthetic.prover_param(pcs_pp, circ, pcs_vp)
+    t = hl.Keccak256Transcript()
+    g_hp.HyperPlonk.prove(pp, circ.instances, circ.d_witness, t)
+    proof = t.into_proof()
+    assert len(proof) == 1024 + 352 * k + (128 if pcs == "zeromorph" else 0)
+    g_hp.HyperPlonk.verify(vp, circ.instances, hl.Keccak256Transcript.from_proof(proof))
+    # break one gate: w_o of row 0 (an add gate)
+    bad = circ.h_witness[2].copy()
+    bad[0, 0] ^= np.uint64(1)
+    t = hl.Keccak256Transcript()
+    g_hp.HyperPlonk.prove(pp, circ.instances, circ.d_witness[:2] + [hl.MultilinearPolynomial(ctx, ctx.upload(bad.tobytes()), k)], t)
+    with pytest.raises(hl.Error):
+        g_hp.HyperPlonk.verify(vp, circ.instances, hl.Keccak256Transcript.from_proof(t.into_proof()))

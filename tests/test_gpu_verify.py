@@ -11,7 +11,7 @@ from oracle.pyref.field import R_MOD as P
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("kind,n", [("range", 10), ("range", 18), ("and", 16), ("xor", 12)])
+@pytest.mark.parametrize("kind,n", [("range", 10), ("range", 18), ("and", 16), ("xor", 12), ("range", 20), ("and", 20)])
 def test_lasso_prove_then_verify(hl, ctx, kind, n):
     rng = np.random.default_rng(n)
     table = hl.LassoTable.range(2, 16) if kind == "range" else hl.LassoTable.bitwise(
