@@ -327,17 +327,40 @@ void lasso_prove_sharded(Ctx& c, const Srs& srs, const lh_lasso_table& tb, size_
   tr.common_field_element(HFr::from_u64(cc));
   tr.common_field_element(HFr::from_u64(alpha));
   {
+    // as in lasso.cpp: columns that are linear in others are committed by linearity (after the partial commitments
+    // of the shards have been summed), not by an MSM of their own
     const G1Affine* bases_l = srs_shard_level(c, srs, n);
+    bool linear_g = true;
+    for (uint32_t m = 0; m < tb.num_terms; m++) linear_g = linear_g && tb.g_num_factors[m] == 1;
+    const size_t total = 1 + 3 * cc + alpha;
     std::vector<MsmJob> jobs;
-    jobs.push_back(MsmJob{a, false, bases_l, NL});
-    for (size_t j = 0; j < cc; j++) jobs.push_back(MsmJob{dim_l[j], true, bases_l, NL});
-    for (size_t j = 0; j < cc; j++) jobs.push_back(MsmJob{rts_l[j], true, bases_l, NL});
-    for (size_t i = 0; i < alpha; i++) jobs.push_back(MsmJob{E_l[i], true, bases_l, NL});
+    std::vector<size_t> slot;
+    auto add_job = [&](size_t pos, const void* col, bool u32, const G1Affine* bases, size_t len) {
+      jobs.push_back(MsmJob{col, u32, bases, len});
+      slot.push_back(pos);
+    };
+    if (!linear_g) add_job(0, a, false, bases_l, NL);
+    for (size_t j = 0; j < cc; j++) add_job(1 + j, dim_l[j], true, bases_l, NL);
+    for (size_t j = 0; j < cc; j++) add_job(1 + cc + j, rts_l[j], true, bases_l, NL);
+    for (size_t i = 0; i < alpha; i++)
+      if (tb.memory_subtable[i] != LH_SUBTABLE_IDENTITY) add_job(1 + 2 * cc + i, E_l[i], true, bases_l, NL);
     const size_t num_sharded = jobs.size();
-    for (size_t j = 0; j < cc; j++) jobs.push_back(MsmJob{fcs[j], true, srs.eq(n), M});
-    std::vector<HG1> comms(jobs.size());
-    msm_batch(c, jobs.data(), jobs.size(), (G1Affine*)comms.data());
-    comm_sum_points(c, comms.data(), num_sharded);
+    for (size_t j = 0; j < cc; j++) add_job(1 + 2 * cc + alpha + j, fcs[j], true, srs.eq(n), M);
+    std::vector<HG1> part(jobs.size()), comms(total);
+    msm_batch(c, jobs.data(), jobs.size(), (G1Affine*)part.data());
+    comm_sum_points(c, part.data(), num_sharded);
+    for (size_t k = 0; k < jobs.size(); k++) comms[slot[k]] = part[k];
+    for (size_t i = 0; i < alpha; i++)
+      if (tb.memory_subtable[i] == LH_SUBTABLE_IDENTITY) comms[1 + 2 * cc + i] = comms[1 + tb.memory_chunk[i]];
+    if (linear_g) {
+      host::G1Xyzz acc = host::G1Xyzz::identity();
+      for (uint32_t m = 0; m < tb.num_terms; m++) {
+        HFr co;
+        memcpy(&co, &tb.g_coeff[m], 32);
+        acc = host::g1_add(acc, host::g1_mul(host::g1_from_affine(comms[1 + 2 * cc + tb.g_factor[m][0]]), co));
+      }
+      comms[0] = host::g1_to_affine(acc);
+    }
     tr.write_commitments(comms);
   }
   lap(1);
