@@ -40,6 +40,24 @@ def test_boolean_hypercube_is_a_full_cycle(num_vars):
     assert all(order[nth[b]] == b for b in range(1 << num_vars))
 
 
+def test_boolean_hypercube_tables_are_consistent():
+    """bh.rs:5-74: X_INVS[k] is 1/X modulo PRIMITIVES[k] for every k the reference tabulates (the property
+    `boolean_hypercube_prev`, bh.rs:171-180, relies on), and the period of X is 2^k - 1 for the sizes a host loop can walk."""
+    from oracle.pyref.bh import PRIMITIVES, X_INVS
+    assert len(PRIMITIVES) == len(X_INVS) == 32
+    for k in range(1, 32):
+        bh = BooleanHypercube(k)
+        assert PRIMITIVES[k] >> k == 1                       # degree exactly k
+        assert bh.next(X_INVS[k]) == 1 and bh.prev(1) == X_INVS[k]
+    for k in range(11, 19):                                  # 1..10 are walked element by element above
+        bh, b, steps = BooleanHypercube(k), 1, 0
+        while True:
+            b, steps = bh.next(b), steps + 1
+            if b == 1:
+                break
+        assert steps == (1 << k) - 1
+
+
 @pytest.mark.parametrize("rotation", [-3, -1, 1, 2])
 def test_rotation_eval_matches_rotated_table(rotation):
     """multilinear.rs:191-264,477-549: evaluating the rotated table at x == combining the 2^|rot| evaluations"""
@@ -193,3 +211,90 @@ def test_hyperplonk_over_zeromorph_round_trip():
     bad[100] ^= 1
     with pytest.raises(Exception):
         hp.verify(pp, instances, T(bytes(bad)))
+
+
+# ------------------------------------------------------------------ the reference's own structural fixtures
+def _o_same(a, b):
+    """structural equality of two oracle expressions (derive(PartialEq) on the reference's enum)"""
+    if type(a) is not type(b):
+        return False
+    if isinstance(a, oex.Constant):
+        return a.v == b.v
+    if isinstance(a, oex.Lagrange):
+        return a.i == b.i
+    if isinstance(a, (oex.EqXY, oex.Challenge)):
+        return a.idx == b.idx
+    if isinstance(a, oex.Poly):
+        return a.query == b.query
+    if isinstance(a, oex.Negated):
+        return _o_same(a.a, b.a)
+    if isinstance(a, (oex.Sum, oex.Product)):
+        return _o_same(a.a, b.a) and _o_same(a.b, b.b)
+    if isinstance(a, oex.Scaled):
+        return a.s == b.s and _o_same(a.a, b.a)
+    if isinstance(a, oex.DistributePowers):
+        return len(a.exprs) == len(b.exprs) and all(_o_same(x, y) for x, y in zip(a.exprs, b.exprs)) \
+            and _o_same(a.base, b.base)
+    return True  # Identity
+
+
+def _literal(ns, with_lookup, num_vars):
+    """The expected expressions the reference's tests spell out (preprocessor.rs:216-302), restated over a namespace
+    of constructors `ns` so the same literal pins the oracle and the product mirror."""
+    P_, Ch, C = ns["Poly"], ns["Challenge"], ns["Constant"]
+    beta, gamma, alpha = Ch(0), Ch(1), Ch(2)
+    ids = [C(idx << num_vars) + ns["Identity"]() for idx in range(3)]
+    l_1, one, eq = ns["Lagrange"](1), C(1), ns["EqXY"](0)
+    dp = ns["distribute_powers"]
+    if not with_lookup:
+        pi, q_l, q_r, q_m, q_o, q_c, w_l, w_r, w_o, s_1, s_2, s_3 = (P_(i, 0) for i in range(12))
+        z, z_next = P_(12, 0), P_(12, 1)
+        constraints = [
+            q_l * w_l + q_r * w_r + q_m * w_l * w_r + q_o * w_o + q_c + pi,
+            l_1 * (z - one),
+            (z * ((w_l + beta * ids[0] + gamma) * (w_r + beta * ids[1] + gamma) * (w_o + beta * ids[2] + gamma)))
+            - (z_next * ((w_l + beta * s_1 + gamma) * (w_r + beta * s_2 + gamma) * (w_o + beta * s_3 + gamma))),
+        ]
+        return dp(constraints, alpha) * eq
+    pi, q_l, q_r, q_m, q_o, q_c, q_lookup, t_l, t_r, t_o, w_l, w_r, w_o, s_1, s_2, s_3 = (P_(i, 0) for i in range(16))
+    lookup_m, lookup_h = P_(16, 0), P_(17, 0)
+    perm_z, perm_z_next = P_(18, 0), P_(18, 1)
+    lookup_input = dp([q_lookup * w for w in (w_l, w_r, w_o)], beta)
+    lookup_table = dp([t_l, t_r, t_o], beta)
+    constraints = [
+        q_l * w_l + q_r * w_r + q_m * w_l * w_r + q_o * w_o + q_c + pi,
+        lookup_h * (lookup_input + gamma) * (lookup_table + gamma) - (lookup_table + gamma)
+        + lookup_m * (lookup_input + gamma),
+        l_1 * (perm_z - one),
+        (perm_z * ((w_l + beta * ids[0] + gamma) * (w_r + beta * ids[1] + gamma) * (w_o + beta * ids[2] + gamma)))
+        - (perm_z_next * ((w_l + beta * s_1 + gamma) * (w_r + beta * s_2 + gamma) * (w_o + beta * s_3 + gamma))),
+    ]
+    zero_check_on_every_row = dp(constraints, alpha) * eq
+    return dp([lookup_h, zero_check_on_every_row], alpha)
+
+
+@pytest.mark.parametrize("with_lookup", [False, True])
+def test_compose_equals_the_reference_literal(with_lookup):
+    """preprocessor.rs:216-251 compose_vanilla_plonk, :253-302 compose_vanilla_plonk_with_lookup at num_vars = 3:
+    the oracle's `compose` and the product's host mirror both produce exactly the tree the reference asserts."""
+    from halo2_lasso_amd import expression as gex, hyperplonk as g_hp
+    num_vars = 3
+    if with_lookup:
+        perms, n_pre = [[(10, 1)], [(11, 1)], [(12, 1)]], 9
+        o_info = hp.vanilla_plonk_with_lookup_circuit_info(num_vars, 0, [[]] * n_pre, perms)
+        g_info = g_hp.vanilla_plonk_with_lookup_circuit_info(num_vars, 0, [[]] * n_pre, perms)
+    else:
+        perms, n_pre = [[(6, 1)], [(7, 1)], [(8, 1)]], 5
+        o_info = hp.vanilla_plonk_circuit_info(num_vars, 0, [[]] * n_pre, perms)
+        g_info = g_hp.vanilla_plonk_circuit_info(num_vars, 0, [[]] * n_pre, perms)
+    o_ns = {k: getattr(oex, k) for k in ("Poly", "Challenge", "Constant", "Identity", "Lagrange", "EqXY",
+                                         "distribute_powers")}
+    g_ns = {"Poly": gex.Polynomial, **{k: getattr(gex, k) for k in ("Challenge", "Constant", "Identity", "Lagrange",
+                                                                    "EqXY", "distribute_powers")}}
+    o_nz, o_expr = hp.compose(o_info)
+    assert o_nz == 1 and _o_same(o_expr, _literal(o_ns, with_lookup, num_vars))
+    g_nz, g_expr = g_hp.compose(g_info)
+    assert g_nz == 1 and _same(_literal(o_ns, with_lookup, num_vars), g_expr)
+    assert _same(o_expr, _literal(g_ns, with_lookup, num_vars))
+    # a deliberately different tree is told apart (the comparison is not vacuous)
+    assert not _o_same(o_expr, _literal(o_ns, with_lookup, num_vars + 1))
