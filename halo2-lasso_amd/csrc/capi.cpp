@@ -55,8 +55,9 @@ lh_status lh_ctx_create(int device_id, lh_ctx** out) {
   LH_HIP(hipGetDeviceProperties(&prop, device_id));
   ctx->c.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   ctx->c.pin(65536);
-  LH_HIP(hipHostMalloc((void**)&ctx->c.flag, 64, hipHostMallocCoherent | hipHostMallocMapped));
-  *ctx->c.flag = 0;
+  // line 0: device -> host sequence flag; lines 1-2: host -> device mailbox of the resident sum-check tail
+  LH_HIP(hipHostMalloc((void**)&ctx->c.flag, 256, hipHostMallocCoherent | hipHostMallocMapped));
+  memset(ctx->c.flag, 0, 256);
   LH_HIP(hipMalloc((void**)&ctx->c.ticket, 64));
   LH_HIP(hipMemset(ctx->c.ticket, 0, 64));
   *out = ctx;

@@ -76,6 +76,14 @@ ScFinishArgs Ctx::finish_for(uint32_t grid, Fr* out_host, uint32_t seq) {
   return f;
 }
 
+void Ctx::mbox_send(const Fr& r, uint32_t seq) {
+  TailMbox* m = mbox();
+  memcpy((void*)&m->r, &r, sizeof(Fr));
+  __atomic_store_n(&m->seq, seq, __ATOMIC_RELEASE);
+}
+
+void Ctx::mbox_abort() { __atomic_store_n(&mbox()->seq, SC_TAIL_ABORT, __ATOMIC_RELEASE); }
+
 void* Ctx::pin(size_t bytes) {
   if (bytes > pinned_bytes) {
     if (pinned) (void)hipHostFree(pinned);

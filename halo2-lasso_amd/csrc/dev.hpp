@@ -123,6 +123,10 @@ struct Ctx {
   uint32_t ticket_base = 0;    // its value before the next launch
   struct ScFinishArgs finish_for(uint32_t grid, Fr* out_host, uint32_t seq);
   uint32_t next_seq() { return ++flag_seq; }
+  // host -> resident kernel mailbox (second cache line of the flag allocation)
+  struct TailMbox* mbox() { return (struct TailMbox*)((char*)flag + 64); }
+  void mbox_send(const Fr& r, uint32_t seq);
+  void mbox_abort();
   void wait_flag(uint32_t seq);
 };
 
@@ -228,6 +232,22 @@ struct ScRound {
 };
 // evals_host[0..degree) receives sum_b expr at X = 1..degree (X = 0 is derived by the caller)
 void k_sc_round(Ctx&, const ScRound& rd, int degree, bool bind, size_t size, Fr* evals_host);
+
+// Resident tail: once the live tables of a sum-check fit the LDS of one CU, ONE launch runs all remaining rounds.
+// Per round the kernel publishes the message (flag = seq0 + i) and polls the mailbox for the challenge, which the host
+// writes after running the transcript; after the last challenge it publishes the final evaluation of the first
+// `num_out` tables (flag = seq0 + rounds).  No launch and no completion latency per round, tables never leave LDS.
+struct TailMbox {   // pinned, written by the host only
+  uint32_t seq;     // seq0 + i once `r` holds the challenge of round i; SC_TAIL_ABORT makes the kernel exit
+  uint32_t pad[7];
+  Fr r;
+};
+constexpr uint32_t SC_TAIL_ABORT = 0xffffffffu;
+// largest resident table length (power of two, 0 = tail not applicable) for this expression
+size_t k_sc_tail_capacity(const ScRound& rd, int degree);
+// rd.in: entry tables; first_bind: they hold 2*n0 entries and are bound with rd.r first.  Returns immediately.
+void k_sc_tail_launch(Ctx&, const ScRound& rd, int degree, size_t n0, bool first_bind, size_t num_out, uint32_t seq0,
+                      Fr* msg_host, Fr* out_host);
 
 // ------------------------------------------------------------------ general expressions (kernels_expr.hip)
 struct ExtRound {

@@ -123,7 +123,7 @@ SumCheckResult sum_check_prove(Ctx&, int prover_kind, size_t num_vars, const lh_
 typedef std::function<void(const Fr* const*, Fr* const*, const Fr&, bool, size_t, Fr*)> RoundFn;
 SumCheckResult sum_check_loop(Ctx&, int prover_kind, size_t num_vars, int degree, std::vector<const Fr*> cur,
                               const std::vector<char>& used, size_t num_polys, const HFr& sum, Transcript& tr,
-                              bool sharded, const RoundFn& round_fn);
+                              bool sharded, const RoundFn& round_fn, const ScRound* tail_rd = nullptr);
 // general Expression (util/expression.rs) through EvaluationsProver; evals = every poly at x
 SumCheckResult sum_check_prove_expr(Ctx&, size_t num_vars, const lh_expr& expr, const Fr* const* d_polys,
                                     size_t num_polys, const HFr* challenges, size_t num_challenges, const HFr* ys,

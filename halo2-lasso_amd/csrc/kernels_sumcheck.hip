@@ -279,6 +279,197 @@ static void launch_round(Ctx& c, const ScArgs& a, bool bind, size_t size, uint32
     hipLaunchKernelGGL((sc_round_kernel<D, false>), dim3(grid), dim3(256), 0, c.stream, a, size, tp, partials, fin);
 }
 
+// ------------------------------------------------------------------ resident tail (dev.hpp: k_sc_tail_*)
+// One workgroup of 8 waves (two per SIMD of a CU: a lone wave leaves a third of the multiplier idle) keeps every live table in LDS and runs ALL remaining rounds:
+//   evaluate: one (term, X, pair) item per lane, segmented butterfly over the pairs of a (term, X) group;
+//   publish the message to pinned memory, flag = seq0 + round;
+//   poll the host's mailbox for the challenge (bounded: ~2 s of the 100 MHz wall clock, or SC_TAIL_ABORT);
+//   bind every table with it, LDS to LDS.
+// The dependent chain per round is 1 (bind) + nfac (+1 eq) + 1 (coefficient) multiplications.
+struct ScTailArgs {
+  ScRound rd;
+  uint32_t n0, first_bind, degree, num_out, seq0, red_off;
+  uint32_t* flag;
+  Fr* msg_host;
+  Fr* out_host;
+  const TailMbox* mbox;
+};
+constexpr uint32_t TAIL_LDS_BYTES = 144 * 1024;      // of the CU's 160 KB (opt-in: hipFuncAttributeMaxDynamicSharedMemorySize)
+constexpr uint32_t TAIL_THREADS = 512;
+constexpr uint32_t TAIL_MAX_ITEMS = 2048;            // (term, X, pair) items of the first resident round: ~2 us per 512 on one CU
+constexpr uint64_t TAIL_POLL_TICKS = 200000000ull;    // 2 s at 100 MHz
+
+__device__ __forceinline__ Fr shfl_xor_fr(const Fr& v, int mask) {
+  Fr o;
+#pragma unroll
+  for (int i = 0; i < 8; i++) o.l[i] = __shfl_xor(v.l[i], mask, 64);
+  return o;
+}
+
+__global__ __launch_bounds__(TAIL_THREADS) void sc_tail_kernel(ScTailArgs a) {
+  extern __shared__ __align__(16) unsigned char tail_lds_raw[];
+  __shared__ Fr r_sh;
+  __shared__ uint32_t stop_sh;
+  Fr* lds = (Fr*)tail_lds_raw;
+  const ScRound& rd = a.rd;
+  const uint32_t T = rd.num_tables, D = a.degree, tid = threadIdx.x, lane = tid & 63u;
+  Fr* cur = lds;               // T * n0 entries
+  Fr* nxt = lds + T * a.n0;    // T * n0 / 2 entries
+  Fr* red = lds + a.red_off;
+  uint32_t n = a.n0, lg = 0;
+  while ((1u << lg) < n) lg++;
+  for (uint32_t e = tid; e < T * n; e += TAIL_THREADS) {
+    const uint32_t t = e >> lg, k = e & (n - 1);
+    Fr v;
+    if (a.first_bind) {
+      const Fr* p = rd.in[t] + 2 * (size_t)k;
+      Fr e0 = p[0], e1 = p[1];
+      v = add(mul(sub(e1, e0), rd.r), e0);
+    } else {
+      v = rd.in[t][k];
+    }
+    cur[e] = v;
+  }
+  if (tid == 0) stop_sh = 0;
+  __syncthreads();
+  const uint32_t rounds = lg, groups = rd.num_terms * D;
+  for (uint32_t i = 0; i < rounds; i++, lg--) {
+    const uint32_t P = n >> 1, lgP = lg - 1, items = groups << lgP;
+    const uint32_t seg = P < 64 ? P : 64, chunks = P < 64 ? 1 : P >> 6;
+    for (uint32_t base = tid & ~63u; base < items; base += TAIL_THREADS) {
+      const uint32_t it = base + lane;
+      const uint32_t pl = it & (P - 1), g = it >> lgP;
+      Fr acc = Fr::zero();
+      if (it < items) {
+        const uint32_t x = g % D, m = g / D;
+        const int nf = rd.nfac[m];
+        for (int k = 0; k <= nf; k++) {
+          int t;
+          if (k < nf) t = rd.fac[m][k];
+          else if (rd.global_eq >= 0) t = rd.global_eq;
+          else break;
+          const Fr* pv = cur + ((uint32_t)t << lg) + 2 * pl;
+          Fr v0 = pv[0], v1 = pv[1];
+          Fr val = v1;
+          if (x > 0) {
+            Fr step = sub(v1, v0);
+            for (uint32_t j = 0; j < x; j++) val = add(val, step);
+          }
+          acc = k == 0 ? val : mul(acc, val);
+        }
+      }
+      for (uint32_t off = 1; off < seg; off <<= 1) acc = add(acc, shfl_xor_fr(acc, (int)off));
+      if (it < items && (lane & (seg - 1)) == 0) red[g * chunks + (pl >> 6)] = acc;
+    }
+    __syncthreads();
+    Fr gs = Fr::zero();
+    if (tid < groups) {
+      for (uint32_t k = 0; k < chunks; k++) gs = add(gs, red[tid * chunks + k]);
+      const uint32_t m = tid / D;
+      if (!rd.coeff_is_one[m]) gs = mul(gs, rd.coeff[m]);
+    }
+    __syncthreads();
+    if (tid < groups) red[tid] = gs;
+    __syncthreads();
+    if (tid < D) {
+      Fr s = Fr::zero();
+      for (uint32_t m = 0; m < rd.num_terms; m++) s = add(s, red[m * D + tid]);
+      a.msg_host[tid] = s;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    }
+    __syncthreads();
+    if (tid == 0) {
+      publish_flag(a.flag, a.seq0 + i);
+      const uint32_t want = a.seq0 + i;
+      const uint64_t t0 = wall_clock64();
+      for (;;) {
+        const uint32_t s = __hip_atomic_load(&a.mbox->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (s == want) break;
+        if (s == SC_TAIL_ABORT || wall_clock64() - t0 > TAIL_POLL_TICKS) {
+          stop_sh = 1;
+          break;
+        }
+      }
+      Fr r;
+#pragma unroll
+      for (int k = 0; k < 8; k++) r.l[k] = __hip_atomic_load(&a.mbox->r.l[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      r_sh = r;
+    }
+    __syncthreads();
+    if (stop_sh) return;  // the host gave up (or went away): leave without publishing anything further
+    const Fr r = r_sh;
+    for (uint32_t e = tid; e < (T << lgP); e += TAIL_THREADS) {
+      const uint32_t t = e >> lgP, k = e & (P - 1);
+      const Fr* pv = cur + (t << lg) + 2 * k;
+      Fr v0 = pv[0], v1 = pv[1];
+      nxt[e] = add(mul(sub(v1, v0), r), v0);
+    }
+    __syncthreads();
+    Fr* tmp = cur;
+    cur = nxt;
+    nxt = tmp;
+    n = P;
+  }
+  if (tid < a.num_out) {
+    a.out_host[tid] = cur[tid];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  }
+  __syncthreads();
+  if (tid == 0) publish_flag(a.flag, a.seq0 + rounds);
+}
+
+static uint32_t tail_red_entries(const ScRound& rd, int degree, size_t n0) {
+  const size_t groups = (size_t)rd.num_terms * degree, P = n0 >> 1;
+  return (uint32_t)std::max(groups, groups * (P < 64 ? 1 : P >> 6));
+}
+
+size_t k_sc_tail_capacity(const ScRound& rd, int degree) {
+  static const int enabled = [] {
+    const char* e = getenv("LH_SC_TAIL");  // LH_SC_TAIL=0: one launch per round all the way down
+    return e ? atoi(e) : 1;
+  }();
+  static const size_t max_len = [] {
+    const char* e = getenv("LH_SC_TAIL_MAX_LEN");
+    return e ? (size_t)atoll(e) : (size_t)512;
+  }();
+  if (!enabled || degree < 1 || degree > 6) return 0;
+  if ((size_t)rd.num_terms * degree > 256 || rd.num_tables == 0) return 0;
+  size_t best = 0;
+  for (size_t n0 = 2; n0 <= max_len; n0 <<= 1) {
+    const size_t fr = (size_t)rd.num_tables * (n0 + n0 / 2) + tail_red_entries(rd, degree, n0);
+    if (fr * sizeof(Fr) > TAIL_LDS_BYTES) break;
+    if (n0 > 2 && (size_t)rd.num_terms * degree * (n0 >> 1) > TAIL_MAX_ITEMS) break;
+    best = n0;
+  }
+  return best;
+}
+
+void k_sc_tail_launch(Ctx& c, const ScRound& rd, int degree, size_t n0, bool first_bind, size_t num_out, uint32_t seq0,
+                      Fr* msg_host, Fr* out_host) {
+  LH_REQUIRE(n0 >= 2 && (n0 & (n0 - 1)) == 0 && n0 <= k_sc_tail_capacity(rd, degree), LH_ERR_ARG,
+             "sum-check tail: tables do not fit");
+  LH_REQUIRE(num_out <= 256, LH_ERR_ARG, "sum-check tail: too many outputs");
+  ScTailArgs a;
+  a.rd = rd;
+  a.n0 = (uint32_t)n0;
+  a.first_bind = first_bind ? 1 : 0;
+  a.degree = (uint32_t)degree;
+  a.num_out = (uint32_t)num_out;
+  a.seq0 = seq0;
+  a.red_off = (uint32_t)((size_t)rd.num_tables * (n0 + n0 / 2));
+  a.flag = c.flag;
+  a.msg_host = msg_host;
+  a.out_host = out_host;
+  a.mbox = c.mbox();
+  __atomic_store_n(&c.mbox()->seq, 0u, __ATOMIC_RELEASE);
+  const size_t lds = ((size_t)a.red_off + tail_red_entries(rd, degree, n0)) * sizeof(Fr);
+  static const hipError_t opt_in =
+      hipFuncSetAttribute((const void*)sc_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TAIL_LDS_BYTES + 2048);
+  LH_HIP(opt_in);
+  hipLaunchKernelGGL(sc_tail_kernel, dim3(1), dim3(TAIL_THREADS), lds, c.stream, a);
+  LH_HIP(hipGetLastError());
+}
+
 void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, Fr* evals_host) {
   LH_REQUIRE(degree >= 1 && degree <= 6, LH_ERR_ARG, "sum-check degree must be in 1..6");
   LH_REQUIRE(size >= 1, LH_ERR_ARG, "sum-check round over an empty table");

@@ -3,6 +3,7 @@
 // loops run in HIP kernels (dev.hpp), the host keeps the Fiat-Shamir state and O(n) scalars.
 #include <algorithm>
 #include <functional>
+#include <chrono>
 #include "host.hpp"
 
 namespace lh {
@@ -184,8 +185,9 @@ std::vector<HFr> evaluate_polys_sharded(Ctx& c, const Fr* const* d_polys_local, 
 // D sums at X = 1..D.
 SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degree, std::vector<const Fr*> cur,
                                      const std::vector<char>& used, size_t num_polys, const HFr& sum, Transcript& tr,
-                                     bool sharded, const RoundFn& round_fn) {
+                                     bool sharded, const RoundFn& round_fn, const ScRound* tail_rd) {
   const size_t T = cur.size();
+  const size_t tail_cap = tail_rd ? k_sc_tail_capacity(*tail_rd, degree) : 0;
   const size_t rho = sharded ? log2_exact((size_t)c.comm.size) : 0, j = c.shard_bit;
   size_t len = (size_t)1 << (num_vars - rho);  // current length of every (local) table
   // ping-pong targets of the binds: A holds len/2, B holds len/4
@@ -205,6 +207,30 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
   HFr claim = sum;
   HFr r_prev = HFr::zero();
   bool sh = sharded;
+  // one round message: device sums at X = 1..degree -> transcript -> challenge, new claim
+  auto message = [&](const Fr* sums) {
+    std::vector<HFr> ev(degree + 1);
+    for (int x = 1; x <= degree; x++) ev[x] = hst(sums[x - 1]);
+    if (sh) comm_sum_fr(c, ev.data() + 1, degree);  // partial sums of the other shards
+    ev[0] = claim - ev[1];  // eval.rs:129
+    HFr r;
+    if (prover_kind == LH_SC_COEFFICIENTS) {
+      // coeff.rs:136-149: c0 = p(0), c2 = leading coefficient, c1 = claim - (2 c0 + c2)
+      std::vector<HFr> co(3);
+      co[0] = ev[0];
+      co[2] = (ev[2] - ev[1].dbl() + ev[0]) * inv2;
+      co[1] = claim - (co[0].dbl() + co[2]);
+      tr.write_field_elements(co);
+      r = tr.squeeze_challenge();
+      claim = horner(co, r);
+    } else {
+      tr.write_field_elements(ev);
+      r = tr.squeeze_challenge();
+      claim = interpolate_evals(ev, r);
+    }
+    res.challenges.push_back(r);
+    return r;
+  };
   for (size_t round = 0; round < num_vars; round++) {
     bool bind = round > 0;
     if (sh && round == j) {
@@ -224,6 +250,46 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
       sh = false;
       bind = false;
     }
+    if (!sh && tail_cap && (bind ? len >> 1 : len) <= tail_cap) {
+      // the rest of the sum-check runs resident on one CU (dev.hpp: k_sc_tail_*): same messages, same order
+      const size_t n0 = bind ? len >> 1 : len, rounds = num_vars - round;
+      LH_REQUIRE(((size_t)1 << rounds) == n0 && num_polys <= T, LH_ERR_ARG, "sum-check: internal size mismatch");
+      ScRound rd = *tail_rd;
+      for (size_t i = 0; i < T; i++) rd.in[i] = cur[i], rd.out[i] = nullptr;
+      rd.r = dev(r_prev);
+      const uint32_t seq0 = c.flag_seq + 1;
+      c.flag_seq += (uint32_t)rounds + 1;
+      static const bool tail_debug = getenv("LH_SC_DEBUG") != nullptr;
+      const auto t_tail = std::chrono::steady_clock::now();
+      ProfScope ps(c, "sc_tail", 0, 0, (double)n0);
+      struct Guard {  // never leave the kernel polling: tell it to go, then wait until it is gone
+        Ctx& c;
+        bool done = false;
+        ~Guard() {
+          if (done) return;
+          c.mbox_abort();
+          (void)hipStreamSynchronize(c.stream);
+        }
+      } guard{c};
+      k_sc_tail_launch(c, rd, degree, n0, bind, num_polys, seq0, evals_host, evals_host + 16);
+      double host_us = 0;
+      for (size_t i = 0; i < rounds; i++) {
+        c.wait_flag(seq0 + (uint32_t)i);
+        const auto t_h = std::chrono::steady_clock::now();
+        const HFr r = message(evals_host);
+        c.mbox_send(dev(r), seq0 + (uint32_t)i);
+        if (tail_debug) host_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_h).count();
+      }
+      c.wait_flag(seq0 + (uint32_t)rounds);
+      guard.done = true;
+      if (tail_debug)
+        fprintf(stderr, "[sc_tail] T %zu terms %u degree %d n0 %zu rounds %zu: %.1f us (host side %.1f us)\n", T,
+                tail_rd->num_terms, degree, n0, rounds,
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_tail).count(), host_us);
+      res.evals.resize(num_polys);
+      memcpy(res.evals.data(), evals_host + 16, num_polys * sizeof(Fr));
+      return res;
+    }
     const size_t size = bind ? len >> 2 : len >> 1;
     std::vector<Fr*>& dst = flip ? bufB : bufA;
     if (bind) {
@@ -238,27 +304,7 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
       flip ^= 1;
     }
 
-    std::vector<HFr> ev(degree + 1);
-    for (int x = 1; x <= degree; x++) ev[x] = hst(evals_host[x - 1]);
-    if (sh) comm_sum_fr(c, ev.data() + 1, degree);  // partial sums of the other shards
-    ev[0] = claim - ev[1];  // eval.rs:129
-    HFr r;
-    if (prover_kind == LH_SC_COEFFICIENTS) {
-      // coeff.rs:136-149: c0 = p(0), c2 = leading coefficient, c1 = claim - (2 c0 + c2)
-      std::vector<HFr> co(3);
-      co[0] = ev[0];
-      co[2] = (ev[2] - ev[1].dbl() + ev[0]) * inv2;
-      co[1] = claim - (co[0].dbl() + co[2]);
-      tr.write_field_elements(co);
-      r = tr.squeeze_challenge();
-      claim = horner(co, r);
-    } else {
-      tr.write_field_elements(ev);
-      r = tr.squeeze_challenge();
-      claim = interpolate_evals(ev, r);
-    }
-    res.challenges.push_back(r);
-    r_prev = r;
+    r_prev = message(evals_host);
   }
   LH_REQUIRE(!sh && len == 2, LH_ERR_ARG, "sum-check: internal size mismatch");
   // into_evals: last bind (2 -> 1 entries) of every poly
@@ -338,7 +384,7 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
     rd.r = r;
     k_sc_round(c, rd, degree, bind, size, evals_host);
   };
-  return sum_check_loop(c, prover_kind, num_vars, degree, cur, used, num_polys, sum, tr, sharded, round_fn);
+  return sum_check_loop(c, prover_kind, num_vars, degree, cur, used, num_polys, sum, tr, sharded, round_fn, &rd);
 }
 
 SumCheckResult sum_check_prove(Ctx& c, int prover_kind, size_t num_vars, const lh_sop& expr,
