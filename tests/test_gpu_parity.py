@@ -7,6 +7,7 @@ prove -> verify round trip.  Sizes are those the oracle finishes in seconds.
 """
 import array
 import random
+import time
 import zlib
 
 import pytest
@@ -230,7 +231,7 @@ def test_batch_commit_open(hl, ctx, srs6, num_vars):
 
 
 # ------------------------------------------------------------------ a5-a8: ClassicSumCheck
-@pytest.mark.parametrize("num_vars", [1, 2, 4, 9])
+@pytest.mark.parametrize("num_vars", [1, 2, 4, 9, 10, 12])
 def test_sum_check_evaluations(hl, ctx, num_vars):
     """eq * (c0*p0*p1 + c1*p2 + c2*p0*p1*p2), degree 4, vs oracle bytes; then verify (sum_check.rs:140-177)."""
     rng = random.Random(20 + num_vars)
@@ -253,7 +254,7 @@ def test_sum_check_evaluations(hl, ctx, num_vars):
     assert vx == x and final == ex.evaluate_fe(expr, [o_kzg.eq_xy_eval(x, y)], ev, [])
 
 
-@pytest.mark.parametrize("num_vars", [1, 3, 8])
+@pytest.mark.parametrize("num_vars", [1, 3, 8, 11])
 def test_sum_check_coefficients(hl, ctx, num_vars):
     """sum_j s_j * eq_j * poly_j (the batch_open expression) through CoefficientsProver."""
     rng = random.Random(30 + num_vars)
@@ -268,6 +269,51 @@ def test_sum_check_coefficients(hl, ctx, num_vars):
     sop = hl.SumOfProducts([(s[j], [3 + j, j]) for j in range(3)])
     t = hl.Keccak256Transcript()
     x, ev = hl.ClassicSumCheck.prove(ctx, hl.CoefficientsProver, num_vars, sop, polys, ys, claim, t)
+    assert (x, ev) == (ox, oev) and t.into_proof() == ot.into_proof()
+
+
+def test_sum_check_transcript_failure_mid_tail(hl, ctx):
+    """The last rounds of a sum-check run inside ONE resident launch that waits for each challenge from the host
+    (csrc/kernels_sumcheck.hip sc_tail_kernel).  A transcript that fails in the middle of it must surface as the
+    transcript's error, release the kernel, and leave the context usable (the next proof has the oracle's bytes)."""
+    import ctypes as C
+    from halo2_lasso_amd import _ffi
+    num_vars = 7
+    rng = random.Random(77)
+    tables = [rand_fr(rng, 1 << num_vars) for _ in range(2)]
+    y = rand_fr(rng, num_vars)
+    polys = [hl.MultilinearPolynomial.new(ctx, t) for t in tables]
+    sop = hl.SumOfProducts([(1, [0, 1])], global_eq=0)
+    claim = sum(e * a * b for e, a, b in zip(eq_xy(y), *tables)) % P
+
+    inner = hl.Keccak256Transcript()
+    vt = inner.p.contents
+    calls = {"n": 0}
+
+    def squeeze(user, out):
+        calls["n"] += 1
+        if calls["n"] == 4:
+            return -6  # LH_ERR_TRANSCRIPT
+        return vt.squeeze_challenge(vt.user, out)
+
+    failing = _ffi.lh_transcript()
+    C.memmove(C.byref(failing), inner.p, C.sizeof(failing))
+    cb = _ffi._FE_CB(squeeze)
+    failing.squeeze_challenge = cb
+
+    class Wrapped:
+        p = C.pointer(failing)
+
+    t0 = time.perf_counter()
+    with pytest.raises(hl.Error):
+        hl.ClassicSumCheck.prove(ctx, hl.EvaluationsProver, num_vars, sop, polys, [y], claim, Wrapped)
+    assert calls["n"] == 4 and time.perf_counter() - t0 < 1.5  # aborted, not timed out
+    # the context is intact: same statement, fresh transcript, oracle bytes
+    expr = ex.EqXY(0) * (ex.Poly(0) * ex.Poly(1))
+    ot = OT()
+    ox, oev = o_sc.prove(o_sc.EvaluationsProver, num_vars, o_sc.VirtualPolynomial(expr, tables, [], [y]), claim, ot)
+    t = hl.Keccak256Transcript()
+    x, ev = hl.ClassicSumCheck.prove(ctx, hl.EvaluationsProver, num_vars, sop, polys, [y], claim, t)
     assert (x, ev) == (ox, oev) and t.into_proof() == ot.into_proof()
 
 
