@@ -203,19 +203,31 @@ __global__ void fr_set_one_kernel(Fr* p) { p[0] = Fr::one(); }
 // first EQ_SMALL levels of an eq table in one workgroup (LDS ping-pong): the GKR calls eq_xy once per layer
 // and most layers are tiny, so one launch instead of num_vars launches is what matters there.
 constexpr int EQ_SMALL = 9;
-struct EqYs {
-  Fr y[EQ_SMALL];
+// out[(hi << lo_bits) | lo] = hi_tab[hi] * lo_tab[lo]: eq tables factor over disjoint variable sets
+__global__ void eq_outer_kernel(const Fr* __restrict__ lo_tab, int lo_bits, const Fr* __restrict__ hi_tab, size_t n,
+                                Fr* __restrict__ out) {
+  const size_t mask = ((size_t)1 << lo_bits) - 1;
+  GSTRIDE(i, n) out[i] = mul(hi_tab[i >> lo_bits], lo_tab[i & mask]);
+}
+
+// every group of <= 9 variables in ONE launch, one workgroup per group
+constexpr int EQ_GROUPS = 4;
+struct EqGroups {
+  Fr y[EQ_GROUPS][EQ_SMALL];  // per group, expanded last-to-first
+  int levels[EQ_GROUPS];
+  Fr* out[EQ_GROUPS];
 };
-__global__ __launch_bounds__(256) void eq_small_kernel(EqYs ys, int levels, Fr* __restrict__ out) {
+__global__ __launch_bounds__(256) void eq_groups_kernel(EqGroups g) {
   __shared__ Fr a[1 << EQ_SMALL];
   __shared__ Fr b[1 << (EQ_SMALL - 1)];
-  Fr* cur = (levels & 1) ? b : a;  // after `levels` flips the result sits in `a`
+  const int levels = g.levels[blockIdx.x];
+  Fr* cur = (levels & 1) ? b : a;
   Fr* nxt = (levels & 1) ? a : b;
   if (threadIdx.x == 0) cur[0] = Fr::one();
   __syncthreads();
   int n = 1;
   for (int i = 0; i < levels; i++) {
-    const Fr yi = ys.y[i];  // ys.y[i] is the variable expanded at step i (caller passes them last-to-first)
+    const Fr yi = g.y[blockIdx.x][i];
     for (int k = threadIdx.x; k < n; k += blockDim.x) {
       Fr e = cur[k];
       Fr hi = mul(e, yi);
@@ -228,45 +240,41 @@ __global__ __launch_bounds__(256) void eq_small_kernel(EqYs ys, int levels, Fr* 
     nxt = t;
     n <<= 1;
   }
+  Fr* out = g.out[blockIdx.x];
   for (int k = threadIdx.x; k < n; k += blockDim.x) out[k] = cur[k];
 }
 
-// out[(hi << lo_bits) | lo] = hi_tab[hi] * lo_tab[lo]: eq tables factor over disjoint variable sets
-__global__ void eq_outer_kernel(const Fr* __restrict__ lo_tab, int lo_bits, const Fr* __restrict__ hi_tab, size_t n,
-                                Fr* __restrict__ out) {
-  const size_t mask = ((size_t)1 << lo_bits) - 1;
-  GSTRIDE(i, n) out[i] = mul(hi_tab[i >> lo_bits], lo_tab[i & mask]);
-}
-
-// eq_xy(y) for any size in at most 5 launches: tables of <= 9 variables come from one workgroup each
-// (eq_small_kernel), larger ones are outer products of those (1 multiplication per entry, as the
-// level-by-level expansion, but without a launch per variable).
+// eq_xy(y) for any size: the variables are split into balanced groups of <= 9 (index bits [0,a) | [a,a+b) | ...),
+// ONE launch builds every group's table (one workgroup each: a chain of <= 9 multiplications), then the table is the
+// outer product of the groups (1 multiplication per entry, as the level-by-level expansion of multilinear.rs:96-121,
+// but without a launch per variable).
 void k_eq_xy(Ctx& c, const Fr* y, size_t num_vars, Fr* out) {
   ProfScope ps(c, "eq_xy", 64.0 * ((size_t)1 << num_vars), 1.0 * ((size_t)1 << num_vars), (double)((size_t)1 << num_vars));
-  auto small = [&](size_t first, size_t cnt, Fr* dst) {  // eq over y[first .. first+cnt), cnt <= EQ_SMALL
-    EqYs ys;
-    for (size_t i = 0; i < cnt; i++) ys.y[i] = y[first + cnt - 1 - i];  // expanded last-to-first (multilinear.rs:103)
-    hipLaunchKernelGGL(eq_small_kernel, dim3(1), dim3(256), 0, c.stream, ys, (int)cnt, dst);
-  };
-  if (num_vars <= (size_t)EQ_SMALL) {
-    small(0, num_vars, out);
-    return;
-  }
+  const size_t ngroups = std::max<size_t>(1, (num_vars + EQ_SMALL - 1) / EQ_SMALL);
+  LH_REQUIRE(ngroups <= (size_t)EQ_GROUPS, LH_ERR_ARG, "eq_xy: too many variables");
   ArenaScope scope(c.arena);
-  // split the variables into groups of <= 9: index bits [0,9) | [9,18) | [18,27) | ...
-  size_t done = std::min<size_t>(num_vars, EQ_SMALL);
-  Fr* cur = c.arena.alloc_n<Fr>((size_t)1 << done);
-  small(0, done, cur);
-  while (done < num_vars) {
-    size_t cnt = std::min<size_t>(num_vars - done, EQ_SMALL);
-    Fr* hi = c.arena.alloc_n<Fr>((size_t)1 << cnt);
-    small(done, cnt, hi);
-    const bool last = done + cnt == num_vars;
-    size_t n = (size_t)1 << (done + cnt);
+  EqGroups g;
+  size_t first[EQ_GROUPS], cnt[EQ_GROUPS];
+  Fr* tab[EQ_GROUPS];
+  for (size_t k = 0, done = 0; k < ngroups; k++) {
+    cnt[k] = (num_vars - done + (ngroups - k) - 1) / (ngroups - k);  // balanced, larger groups first
+    first[k] = done;
+    done += cnt[k];
+    tab[k] = ngroups == 1 ? out : c.arena.alloc_n<Fr>((size_t)1 << cnt[k]);
+    g.levels[k] = (int)cnt[k];
+    g.out[k] = tab[k];
+    for (size_t i = 0; i < cnt[k]; i++) g.y[k][i] = y[first[k] + cnt[k] - 1 - i];  // expanded last-to-first (multilinear.rs:103)
+  }
+  hipLaunchKernelGGL(eq_groups_kernel, dim3((unsigned)ngroups), dim3(256), 0, c.stream, g);
+  Fr* cur = tab[0];
+  size_t done = cnt[0];
+  for (size_t k = 1; k < ngroups; k++) {
+    const bool last = k + 1 == ngroups;
+    const size_t n = (size_t)1 << (done + cnt[k]);
     Fr* dst = last ? out : c.arena.alloc_n<Fr>(n);
-    hipLaunchKernelGGL(eq_outer_kernel, grid_for(n), 256, 0, c.stream, cur, (int)done, hi, n, dst);
+    hipLaunchKernelGGL(eq_outer_kernel, grid_for(n), 256, 0, c.stream, cur, (int)done, tab[k], n, dst);
     cur = dst;
-    done += cnt;
+    done += cnt[k];
   }
 }
 
