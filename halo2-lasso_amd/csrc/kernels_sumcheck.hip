@@ -181,15 +181,19 @@ struct ScLdsArgs {
   uint8_t slot_of[SC_MAX_TABLES];
   uint32_t num_used;
   uint32_t P;                    // pairs per workgroup
+  uint32_t vals_entries;         // LDS carve-up: vals[vals_entries] then red[]
 };
 
 template <int D, bool BIND>
 __global__ __launch_bounds__(256) void sc_round_lds_kernel(ScLdsArgs g, size_t size, Fr* __restrict__ partials,
                                                            ScFinish fin) {
-  __shared__ Fr vals[LDS_VALS];
-  __shared__ Fr red[LDS_ITEMS];
+  // sized by the launch (vals: 2 P entries per used table, at least the 4 reduction slots; red: one slot per item, at
+  // least one per (term, X) group): a fixed 56 KB would cap the CU at two workgroups whatever P is
+  extern __shared__ __align__(16) unsigned char lds_raw[];
   const ScRound& rd = g.a.rd;
   const uint32_t P = g.P, U = g.num_used;
+  Fr* vals = (Fr*)lds_raw;
+  Fr* red = vals + g.vals_entries;
   const size_t b0 = (size_t)blockIdx.x * P;
   // phase 1: entry e = (slot u, local pair pl, which) -> vals[(u*P + pl)*2 + which]
   for (uint32_t e = threadIdx.x; e < U * P * 2; e += blockDim.x) {
@@ -264,10 +268,12 @@ __global__ __launch_bounds__(256) void sc_round_lds_kernel(ScLdsArgs g, size_t s
 template <int D>
 static void launch_lds(Ctx& c, const ScLdsArgs& g, bool bind, size_t size, unsigned grid, Fr* partials,
                        const ScFinish& fin) {
+  const size_t red_entries = std::max<size_t>((size_t)g.a.rd.num_terms * D * g.P, (size_t)g.a.rd.num_terms * D);
+  const size_t lds = ((size_t)g.vals_entries + red_entries) * sizeof(Fr);
   if (bind)
-    hipLaunchKernelGGL((sc_round_lds_kernel<D, true>), dim3(grid), dim3(256), 0, c.stream, g, size, partials, fin);
+    hipLaunchKernelGGL((sc_round_lds_kernel<D, true>), dim3(grid), dim3(256), lds, c.stream, g, size, partials, fin);
   else
-    hipLaunchKernelGGL((sc_round_lds_kernel<D, false>), dim3(grid), dim3(256), 0, c.stream, g, size, partials, fin);
+    hipLaunchKernelGGL((sc_round_lds_kernel<D, false>), dim3(grid), dim3(256), lds, c.stream, g, size, partials, fin);
 }
 
 template <int D>
@@ -520,6 +526,7 @@ void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, F
         g.used[g.num_used++] = (uint8_t)t;
       }
     g.P = P;
+    g.vals_entries = std::max<uint32_t>(g.num_used * P * 2, 8);
     size_t grid = (size + P - 1) / P;
     Fr* partials = grid == 1 ? evals_host : c.arena.alloc_n<Fr>(grid * degree);
     const ScFinish kflag = c.finish_for((uint32_t)grid, evals_host, seq);

@@ -34,3 +34,12 @@ for r in ks:
 print("kernels of the proof:")
 for n, (c, d) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:24]:
     print("  %-46s %4d  %8.3f ms  avg %7.1f us" % (n, c, d / 1e6, d / c / 1e3))
+if len(sys.argv) > 2:  # detail: every launch of the kernels matching the pattern, by grid size
+    pat = re.compile(sys.argv[2])
+    print("launches matching %r (grid workgroups, duration us, gap before us):" % sys.argv[2])
+    prev_end = None
+    for r in ks:
+        if pat.search(r[0]):
+            print("  %-40s grid %6d x %4d  %7.1f us  gap %6.1f" % (short(r[0]), r[3] // max(r[4], 1), r[4], (r[2] - r[1]) / 1e3,
+                                                                 (r[1] - prev_end) / 1e3 if prev_end else 0.0))
+        prev_end = r[2]
