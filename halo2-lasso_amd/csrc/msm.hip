@@ -288,23 +288,30 @@ __global__ __launch_bounds__(64) void msm_segment_reduce_kernel(MsmPlanDev plan,
   }
 }
 
-// one workgroup per (job, window): sum of its segment partials
-// The window sums go straight into pinned host memory; the workgroup that finishes last publishes the flag the
+// `nsplit` workgroups per (job, window): each sums a contiguous share of the window's segment partials (the host adds
+// the nsplit shares: a host addition is ~0.4 us, a device addition on this under-filled launch ~20 us, so a window with
+// 16 K segments must not be 64 dependent additions per thread).
+// The sums go straight into pinned host memory; the workgroup that finishes last publishes the flag the
 // host spins on (same ticket protocol as the sum-check rounds): no device-to-host copy, no stream synchronise.
 __global__ __launch_bounds__(256) void msm_window_sum_kernel(MsmPlanDev plan, const G1Xyzz* __restrict__ seg_out,
-                                                             G1Xyzz* __restrict__ win_out, ScFinishArgs fin) {
+                                                             G1Xyzz* __restrict__ win_out, uint32_t nsplit,
+                                                             ScFinishArgs fin) {
   __shared__ G1Xyzz lds[256];
+  const uint32_t win = blockIdx.x / nsplit, part = blockIdx.x % nsplit;
   int j = 0;
-  while (j + 1 < plan.num_jobs && plan.job[j + 1].win_base <= blockIdx.x) j++;
+  while (j + 1 < plan.num_jobs && plan.job[j + 1].win_base <= win) j++;
   const MsmJobDev& jb = plan.job[j];
-  uint32_t w = blockIdx.x - jb.win_base;
+  uint32_t w = win - jb.win_base;
+  const uint32_t share = (jb.seg_per_win + nsplit - 1) / nsplit;
+  const uint32_t lo = part * share, hi = min(lo + share, jb.seg_per_win);
   const G1Xyzz* src = seg_out + jb.seg_base + (size_t)w * jb.seg_per_win;
   G1Xyzz acc = G1Xyzz::identity();
-  for (uint32_t i = threadIdx.x; i < jb.seg_per_win; i += blockDim.x) acc = add(acc, src[i]);
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) acc = add(acc, src[i]);
   lds[threadIdx.x] = acc;
   __syncthreads();
+  const uint32_t live = hi > lo ? hi - lo : 0;
   for (int off = 128; off > 0; off >>= 1) {
-    if ((int)threadIdx.x < off && (uint32_t)(threadIdx.x + off) < jb.seg_per_win)
+    if ((int)threadIdx.x < off && (uint32_t)(threadIdx.x + off) < live)
       lds[threadIdx.x] = add(lds[threadIdx.x], lds[threadIdx.x + off]);
     __syncthreads();
   }
@@ -428,7 +435,18 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
       max_n = std::max(max_n, in.n);
     }
     const size_t nbuckets = key, nsegs = seg, nwins = win;
-    std::vector<G1Xyzz> wins(nwins);
+    // window-sum shares: enough workgroups that no thread adds more than ~4 segment partials in sequence, few enough
+    // that the host's share of the additions stays in the microseconds
+    uint32_t nsplit = 1;
+    {
+      uint32_t max_spw = 1;
+      for (size_t j = 0; j < nj; j++)
+        if (plan.job[j].W) max_spw = std::max(max_spw, plan.job[j].seg_per_win);
+      static const int forced = env_int("LH_MSM_NSPLIT", 0);
+      while (nsplit < 32 && max_spw / nsplit > 1024 && nwins * nsplit * 2 <= 4096) nsplit *= 2;
+      if (forced > 0) nsplit = (uint32_t)forced;
+    }
+    std::vector<G1Xyzz> wins(nwins * nsplit);
     if (max_entries == 0) {
       for (size_t j = 0; j < nj; j++) memset(&out_host[base + j], 0, sizeof(G1Affine));
       continue;
@@ -445,11 +463,11 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
       G1Xyzz* seg_out = c.arena.alloc_n<G1Xyzz>(nsegs);
       // pinned host memory: the window sums (written by the last kernel) followed by the key-block table staging
       const size_t nblocks = (nbuckets >> KEY_BLOCK_BITS) + 1;
-      uint8_t* pin_base = (uint8_t*)c.pin(nwins * sizeof(G1Xyzz) + nblocks);
+      uint8_t* pin_base = (uint8_t*)c.pin(nwins * nsplit * sizeof(G1Xyzz) + nblocks);
       G1Xyzz* win_out = (G1Xyzz*)pin_base;
       uint32_t* lvl_cnt = c.arena.alloc_n<uint32_t>(64);
       {
-        uint8_t* h_tab = pin_base + nwins * sizeof(G1Xyzz);
+        uint8_t* h_tab = pin_base + nwins * nsplit * sizeof(G1Xyzz);
         for (size_t j = 0; j < nj; j++) {
           const size_t b0 = plan.job[j].key_base >> KEY_BLOCK_BITS;
           const size_t b1 = j + 1 < nj ? plan.job[j + 1].key_base >> KEY_BLOCK_BITS : nblocks;
@@ -521,8 +539,9 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
       hipLaunchKernelGGL(msm_segment_reduce_kernel, dim3((unsigned)std::min<size_t>((nsegs + 63) / 64, 1 << 16)),
                          dim3(64), 0, c.stream, plan, buckets, seg_out, nsegs);
       const uint32_t seq = c.next_seq();
-      const ScFinishArgs fin = c.finish_for((uint32_t)nwins, nullptr, seq);
-      hipLaunchKernelGGL(msm_window_sum_kernel, dim3((unsigned)nwins), dim3(256), 0, c.stream, plan, seg_out, win_out, fin);
+      const ScFinishArgs fin = c.finish_for((uint32_t)(nwins * nsplit), nullptr, seq);
+      hipLaunchKernelGGL(msm_window_sum_kernel, dim3((unsigned)(nwins * nsplit)), dim3(256), 0, c.stream, plan, seg_out,
+                         win_out, nsplit, fin);
       if (c.prof) c.sync();
       c.wait_flag(seq);
       }
@@ -534,7 +553,7 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
         for (int i = 0; i < 10; i++) fprintf(stderr, " %u", h_cnt[i]);
         fprintf(stderr, "\n");
       }
-      memcpy(wins.data(), win_out, nwins * sizeof(G1Xyzz));
+      memcpy(wins.data(), win_out, nwins * nsplit * sizeof(G1Xyzz));
     }
     // 6: host combine  sum_w 2^(c*w) * win[w]  and normalise
     auto combine = [&](size_t j) {
@@ -542,7 +561,8 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
       host::G1Xyzz acc = host::G1Xyzz::identity();
       for (int w = (int)jd.W - 1; w >= 0; w--) {
         for (uint32_t k = 0; k < jd.c; k++) acc = host::g1_dbl(acc);
-        acc = host::g1_add(acc, to_host(wins[jd.win_base + w]));
+        for (uint32_t part = 0; part < nsplit; part++)
+          acc = host::g1_add(acc, to_host(wins[(size_t)(jd.win_base + w) * nsplit + part]));
       }
       host::G1Affine a = host::g1_to_affine(acc);
       memcpy(&out_host[base + j], &a, sizeof(G1Affine));
