@@ -388,14 +388,17 @@ __global__ __launch_bounds__(TAIL_THREADS) void sc_tail_kernel(ScTailArgs a) {
       publish_flag(a.flag, a.seq0 + i);
       const uint32_t want = a.seq0 + i;
       const uint64_t t0 = wall_clock64();
+      // relaxed polls, one acquire at the end: an acquiring load per poll would invalidate the device's caches
+      // (other streams' too) every microsecond
       for (;;) {
-        const uint32_t s = __hip_atomic_load(&a.mbox->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint32_t s = __hip_atomic_load(&a.mbox->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (s == want) break;
         if (s == SC_TAIL_ABORT || wall_clock64() - t0 > TAIL_POLL_TICKS) {
           stop_sh = 1;
           break;
         }
       }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
       Fr r;
 #pragma unroll
       for (int k = 0; k < 8; k++) r.l[k] = __hip_atomic_load(&a.mbox->r.l[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
