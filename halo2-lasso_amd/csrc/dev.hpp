@@ -280,8 +280,14 @@ struct ProgRound {
   const uint32_t* code;  // device
   const Fr* consts;      // device
 };
-// evals_host[0..degree) = sum over pairs of program(tables at X), X = 1..degree
-void k_sc_round_prog(Ctx&, const ProgRound& pr, int degree, size_t size, Fr* evals_host);
+// runtime-compiled form of a program (jit.cpp); nullptr = not compiled (disabled, too small, or compilation failed)
+struct JitKernel;
+bool jit_enabled(size_t num_vars);
+const JitKernel* jit_sc_round(const uint32_t* host_code, size_t num_instrs, uint32_t num_regs, uint32_t result_reg, int degree);
+unsigned jit_blocks_per_cu(const JitKernel*);
+void jit_launch(Ctx&, const JitKernel*, const ProgRound& pr, unsigned grid, size_t size, Fr* partials, const ScFinishArgs& fin);
+// evals_host[0..degree) = sum over pairs of program(tables at X), X = 1..degree; `jit`: run the compiled form
+void k_sc_round_prog(Ctx&, const ProgRound& pr, int degree, size_t size, Fr* evals_host, const JitKernel* jit = nullptr);
 enum { ROWS_ATOM_POLY = 0, ROWS_ATOM_IDENTITY = 1, ROWS_ATOM_LAGRANGE = 2 };
 struct RowsAtom {
   const Fr* table;

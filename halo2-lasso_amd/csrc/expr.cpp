@@ -410,6 +410,9 @@ SumCheckResult sum_check_prove_expr(Ctx& c, size_t num_vars, const lh_expr& expr
       pr.num_tables = (uint32_t)T;
       pr.num_instrs = (uint32_t)prog.code.size() / 2, pr.num_regs = prog.num_regs, pr.result_reg = prog.result_reg;
       pr.code = d_code, pr.consts = d_consts;
+      // large sum-checks run the program as compiled straight-line code (jit.cpp), the rest interpret it
+      const JitKernel* jit =
+          jit_enabled(num_vars) ? jit_sc_round(prog.code.data(), pr.num_instrs, pr.num_regs, pr.result_reg, ex.degree) : nullptr;
       auto prog_round = [&](const Fr* const* in, Fr* const* out, const Fr& r, bool bind, size_t size, Fr* evals_host) {
         if (bind) {
           std::vector<const Fr*> src;
@@ -419,7 +422,7 @@ SumCheckResult sum_check_prove_expr(Ctx& c, size_t num_vars, const lh_expr& expr
           k_fix_var_multi(c, src.data(), dst.data(), src.size(), 4 * size, r);
         }
         for (size_t i = 0; i < T; i++) pr.in[i] = bind ? out[i] : in[i];
-        k_sc_round_prog(c, pr, ex.degree, size, evals_host);
+        k_sc_round_prog(c, pr, ex.degree, size, evals_host, jit);
       };
       return sum_check_loop(c, LH_SC_EVALUATIONS, num_vars, ex.degree, tables, used, num_polys, sum, tr, false, prog_round);
     }

@@ -1,0 +1,226 @@
+// Runtime-compiled sum-check round kernels for general expressions.
+//
+// The register-program interpreter (kernels_expr.hip sc_round_prog_kernel) pays for every instruction a decode, an
+// LDS round trip of its operands and a fresh extrapolation of every table operand; that leaves the multiplier at
+// ~0.4 of its peak.  For large sum-checks the same program is turned into straight-line HIP source here - registers
+// are C++ locals, a table's value at the wave's evaluation point is computed once and reused, the instruction stream
+// is gone - and compiled for gfx950 with hiprtc (the reference's counterpart: the per-expression `indexed_calculations`
+// of util/expression/evaluator.rs:135-323, which the Rust compiler specialises at build time because the expression
+// is a generic parameter there; here it is data, so the specialisation happens when the expression arrives).
+// One module per distinct program (hash of the code words, register count, degree), cached for the process.
+#include <hip/hiprtc.h>
+#include <chrono>
+#include <map>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include "dev.hpp"
+#include "jit_sources.inc"  // JIT_FF_CUH, JIT_REDUCE_CUH: the text of ff.cuh / reduce.cuh (Makefile)
+
+namespace lh {
+
+struct JitKernel {
+  hipModule_t mod = nullptr;
+  hipFunction_t fn = nullptr;
+  unsigned threads = 0, degree = 0;
+  unsigned blocks_per_cu = 1;  // resident workgroups per CU (occupancy API): the grid is sized to one resident wave of them
+  bool failed = false;
+};
+
+namespace {
+struct JitArgs {  // mirrored in the generated source
+  const Fr* in[SC_MAX_TABLES];
+  const Fr* consts;
+  unsigned long long size;
+  Fr* partials;
+  ScFinishArgs fin;
+};
+
+std::string operand(uint32_t kind, uint32_t idx) {
+  std::ostringstream o;
+  if (kind == PROG_REG) o << "r" << idx;
+  else if (kind == PROG_CONST) o << "a.consts[" << idx << "]";
+  else o << "t" << idx;
+  return o.str();
+}
+
+std::string generate(const uint32_t* code, size_t num_instrs, uint32_t num_regs, uint32_t result_reg, int D) {
+  std::ostringstream s;
+  s << "#include \"ff.cuh\"\n#include \"reduce.cuh\"\nusing namespace lh;\n"
+       "struct Fin { unsigned* ticket; unsigned last_ticket; Fr* out_host; unsigned* flag; unsigned seq; };\n"
+       "struct Args { const Fr* in["
+    << SC_MAX_TABLES
+    << "]; const Fr* consts; unsigned long long size; Fr* partials; Fin fin; };\n"
+       "// value of a bound table at the wave's evaluation point X = xm1 + 1: hi + (X - 1)(hi - lo)\n"
+       "static __device__ __forceinline__ Fr at_x(const Fr* __restrict__ t, unsigned long long b, int xm1) {\n"
+       "  const Fr lo = t[2 * b], hi = t[2 * b + 1];\n"
+       "  Fr v = hi;\n"
+       "  if (xm1 > 0) {\n"
+       "    const Fr step = sub(hi, lo);\n"
+       "    for (int k = 0; k < xm1; k++) v = add(v, step);\n"
+       "  }\n"
+       "  return v;\n"
+       "}\n"
+       // Workgroups of 4 waves (one per SIMD) working on 4 different groups of 64 pairs at the same evaluation point
+       // X = blockIdx.x + 1: the straight-line code is several times the instruction cache, and waves that run it in
+       // step fetch it once.  (A workgroup of D waves, one per X, would be limited to one per CU by the registers.)
+       // X is the fast grid dimension so that the D workgroups reading the same pairs run at the same time and share
+       // the tables through L2.
+       "extern \"C\" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void sc_round_jit(Args a) {\n"
+       "  __shared__ int is_last;\n"
+       "  const int D = gridDim.x, NW = 4;\n"
+       "  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wave = blockIdx.x;  // wave = X - 1\n"
+       "  const unsigned long long group = (unsigned long long)blockIdx.y * NW + w, ngroups = (unsigned long long)gridDim.y * NW;\n"
+       "  Fr acc = Fr::zero();\n"
+       "  for (unsigned long long base = group * 64; base < a.size; base += ngroups * 64) {\n"
+       "    const unsigned long long b = base + lane;\n"
+       "    if (b < a.size) {\n";
+  for (uint32_t r = 0; r < num_regs; r++) s << "      Fr r" << r << ";\n";
+  std::map<uint32_t, bool> loaded;
+  auto need = [&](uint32_t kind, uint32_t idx) {
+    if (kind != PROG_ATOM || loaded[idx]) return;
+    loaded[idx] = true;
+    s << "      const Fr t" << idx << " = at_x(a.in[" << idx << "], b, wave);\n";
+  };
+  for (size_t i = 0; i < num_instrs; i++) {
+    const uint32_t w0 = code[2 * i], w1 = code[2 * i + 1];
+    const uint32_t op = w0 & 15u, dst = (w0 >> 4) & 15u, ak = (w0 >> 8) & 3u, bk = (w0 >> 10) & 3u;
+    const uint32_t ai = w1 & 0xffffu, bi = w1 >> 16;
+    need(ak, ai);
+    if (op == PROG_NEG) {
+      s << "      r" << dst << " = sub(Fr::zero(), " << operand(ak, ai) << ");\n";
+    } else if (op == PROG_MOV) {
+      s << "      r" << dst << " = " << operand(ak, ai) << ";\n";
+    } else {
+      need(bk, bi);
+      const char* f = op == PROG_MUL ? "mul" : op == PROG_ADD ? "add" : "sub";
+      s << "      r" << dst << " = " << f << "(" << operand(ak, ai) << ", " << operand(bk, bi) << ");\n";
+    }
+  }
+  s << "      acc = add(acc, r" << result_reg
+    << ");\n"
+       "    }\n"
+       "  }\n"
+       // epilogue: wave sums to global memory, the workgroup that draws the launch's last ticket adds them up per
+       // evaluation point and publishes to pinned memory + flag (the protocol of sc_round_prog_kernel)
+       "  acc = wave_reduce_sum(acc);\n"
+       "  if (lane == 0) {\n"
+       "    a.partials[group * D + wave] = acc;\n"
+       "    __threadfence();\n"
+       "  }\n"
+       "  __syncthreads();\n"
+       "  if (threadIdx.x == 0) {\n"
+       "    const unsigned t = __hip_atomic_fetch_add(a.fin.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);\n"
+       "    is_last = t == a.fin.last_ticket;\n"
+       "  }\n"
+       "  __syncthreads();\n"
+       "  if (!is_last) return;\n"
+       "  __threadfence();\n"
+       "  for (int x = w; x < D; x += NW) {\n"
+       "    Fr a2 = Fr::zero();\n"
+       "    for (unsigned long long i = lane; i < ngroups; i += 64) a2 = add(a2, a.partials[i * D + x]);\n"
+       "    a2 = wave_reduce_sum(a2);\n"
+       "    if (lane == 0) {\n"
+       "      a.fin.out_host[x] = a2;\n"
+       "      __threadfence_system();\n"
+       "    }\n"
+       "  }\n"
+       "  __syncthreads();\n"
+       "  if (threadIdx.x == 0) __hip_atomic_store(a.fin.flag, a.fin.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);\n"
+       "}\n";
+  return s.str();
+}
+
+uint64_t fnv(const void* p, size_t n, uint64_t h) {
+  const unsigned char* b = (const unsigned char*)p;
+  for (size_t i = 0; i < n; i++) h = (h ^ b[i]) * 0x100000001b3ull;
+  return h;
+}
+
+std::mutex g_mu;
+std::map<uint64_t, JitKernel*> g_cache;  // never freed: modules live as long as the process
+}  // namespace
+
+bool jit_enabled(size_t num_vars) {
+  static const int on = [] {
+    const char* e = getenv("LH_EXPR_JIT");  // 0: always interpret
+    return e ? atoi(e) : 1;
+  }();
+  static const size_t min_vars = [] {
+    const char* e = getenv("LH_EXPR_JIT_MIN_VARS");  // smaller sum-checks are not worth seconds of compilation
+    return e ? (size_t)atoll(e) : (size_t)16;
+  }();
+  return on && num_vars >= min_vars;
+}
+
+const JitKernel* jit_sc_round(const uint32_t* code, size_t num_instrs, uint32_t num_regs, uint32_t result_reg, int degree) {
+  uint64_t h = fnv(code, num_instrs * 8, 0xcbf29ce484222325ull);
+  const uint32_t meta[3] = {num_regs, result_reg, (uint32_t)degree};
+  h = fnv(meta, sizeof meta, h);
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  h = fnv(&dev, sizeof dev, h);  // a module belongs to the device it was loaded on
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_cache.find(h);
+  if (it != g_cache.end()) return it->second->failed ? nullptr : it->second;
+  JitKernel* k = new JitKernel();
+  g_cache[h] = k;
+  k->failed = true;
+  const auto t0 = std::chrono::steady_clock::now();
+  const std::string src = generate(code, num_instrs, num_regs, result_reg, degree);
+  hiprtcProgram prog;
+  const char* hdr[] = {JIT_FF_CUH, JIT_REDUCE_CUH};
+  const char* names[] = {"ff.cuh", "reduce.cuh"};
+  if (hiprtcCreateProgram(&prog, src.c_str(), "sc_round_jit.hip", 2, hdr, names) != HIPRTC_SUCCESS) return nullptr;
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+  const hiprtcResult r = hiprtcCompileProgram(prog, 3, opts);
+  if (r != HIPRTC_SUCCESS) {
+    size_t n = 0;
+    (void)hiprtcGetProgramLogSize(prog, &n);
+    std::string log(n + 1, '\0');
+    (void)hiprtcGetProgramLog(prog, &log[0]);
+    fprintf(stderr, "[lasso-hip] runtime compilation of a sum-check program failed (%s), interpreting it instead:\n%.2000s\n",
+            hiprtcGetErrorString(r), log.c_str());
+    (void)hiprtcDestroyProgram(&prog);
+    return nullptr;
+  }
+  size_t n = 0;
+  (void)hiprtcGetCodeSize(prog, &n);
+  std::string bin(n, '\0');
+  (void)hiprtcGetCode(prog, &bin[0]);
+  (void)hiprtcDestroyProgram(&prog);
+  if (hipModuleLoadData(&k->mod, bin.data()) != hipSuccess) return nullptr;
+  if (hipModuleGetFunction(&k->fn, k->mod, "sc_round_jit") != hipSuccess) return nullptr;
+  k->threads = 256u;
+  k->degree = (unsigned)degree;
+  k->failed = false;
+  int per_cu = 0;
+  if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k->fn, (int)k->threads, 0) == hipSuccess && per_cu > 0)
+    k->blocks_per_cu = (unsigned)per_cu;
+  if (getenv("LH_HP_DEBUG")) {
+    int vgprs = 0, scratch = 0;
+    (void)hipFuncGetAttribute(&vgprs, HIP_FUNC_ATTRIBUTE_NUM_REGS, k->fn);
+    (void)hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, k->fn);
+    fprintf(stderr, "[expr] compiled a %zu-instruction program for degree %d in %.2f s (%zu B of code, %d registers, %d B scratch, %u workgroups per CU)\n",
+            num_instrs, degree, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), n, vgprs, scratch,
+            k->blocks_per_cu);
+  }
+  return k;
+}
+
+unsigned jit_blocks_per_cu(const JitKernel* k) { return k->blocks_per_cu; }
+
+void jit_launch(Ctx& c, const JitKernel* k, const ProgRound& pr, unsigned grid, size_t size, Fr* partials,
+                const ScFinishArgs& fin) {
+  JitArgs a;
+  for (int i = 0; i < SC_MAX_TABLES; i++) a.in[i] = pr.in[i];
+  a.consts = pr.consts;
+  a.size = size;
+  a.partials = partials;
+  a.fin = fin;
+  size_t bytes = sizeof(a);
+  void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &bytes, HIP_LAUNCH_PARAM_END};
+  LH_HIP(hipModuleLaunchKernel(k->fn, k->degree, grid, 1, k->threads, 1, 1, 0, c.stream, nullptr, extra));
+}
+
+}  // namespace lh

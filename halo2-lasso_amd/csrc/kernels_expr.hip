@@ -344,7 +344,7 @@ __global__ __launch_bounds__(512) void sc_round_prog_kernel(ProgRound pr, size_t
   if (threadIdx.x == 0) publish_flag_ext(fin.flag, fin.seq);
 }
 
-void k_sc_round_prog(Ctx& c, const ProgRound& pr, int degree, size_t size, Fr* evals_host) {
+void k_sc_round_prog(Ctx& c, const ProgRound& pr, int degree, size_t size, Fr* evals_host, const JitKernel* jit) {
   LH_REQUIRE(degree >= 2 && degree <= 8, LH_ERR_ARG, "sum-check degree must be in 2..8");
   LH_REQUIRE(size >= 1 && pr.num_regs >= 1 && pr.num_regs <= PROG_MAX_REGS, LH_ERR_ARG, "sum-check program: bad shape");
   const uint32_t seq = c.next_seq();
@@ -355,17 +355,37 @@ void k_sc_round_prog(Ctx& c, const ProgRound& pr, int degree, size_t size, Fr* e
   static const hipError_t attr = hipFuncSetAttribute((const void*)sc_round_prog_kernel,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
   LH_HIP(attr);  // function-local static: set exactly once, thread-safe
-  size_t g = (size + 63) / 64;
-  const size_t cap = (size_t)c.num_cus * 4;
+  size_t g = jit ? (size + 255) / 256 : (size + 63) / 64;  // compiled form: 4 groups of 64 pairs per workgroup
+  // one resident set of workgroups (they loop over the pairs): a grid of 4 per CU when only 3 fit runs a second, mostly
+  // empty pass
+  int per_cu = 4;
+  if (jit) {
+    per_cu = (int)jit_blocks_per_cu(jit);
+  } else {
+    static int vm_per_cu[9] = {0};
+    if (!vm_per_cu[degree]) {
+      int n = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sc_round_prog_kernel, (int)threads, lds_bytes) != hipSuccess || n < 1) n = 1;
+      vm_per_cu[degree] = n;
+    }
+    per_cu = vm_per_cu[degree];
+  }
+  static const bool dbg = getenv("LH_HP_DEBUG") != nullptr;
+  if (dbg && size >= ((size_t)1 << 18)) fprintf(stderr, "[expr] round kernel: %d workgroups of %u threads per CU\n", per_cu, threads);
+  // compiled form: one wave per workgroup and a grid of (g, degree) workgroups, all of which draw a ticket
+  const size_t cap = jit ? std::max<size_t>(1, (size_t)c.num_cus * (size_t)per_cu / (size_t)degree) : (size_t)c.num_cus * (size_t)per_cu;
   if (g > cap) g = cap;
-  Fr* partials = g == 1 ? evals_host : c.arena.alloc_n<Fr>(g * degree);
-  const ScFinishArgs fin = c.finish_for((uint32_t)g, evals_host, seq);
+  Fr* partials = (g == 1 && !jit) ? evals_host : c.arena.alloc_n<Fr>(g * degree);
+  const ScFinishArgs fin = c.finish_for((uint32_t)(jit ? g * degree : g), evals_host, seq);
   {
     char name[40];
-    snprintf(name, sizeof name, "sc_round_prog<%d>", degree);
+    snprintf(name, sizeof name, jit ? "sc_round_jit<%d>" : "sc_round_prog<%d>", degree);
     ProfScope ps(c, name, 64.0 * (double)size * pr.num_tables, 0, (double)size);
-    hipLaunchKernelGGL(sc_round_prog_kernel, dim3((unsigned)g), dim3(threads), lds_bytes, c.stream, pr, size, degree,
-                       partials, fin);
+    if (jit)
+      jit_launch(c, jit, pr, (unsigned)g, size, partials, fin);
+    else
+      hipLaunchKernelGGL(sc_round_prog_kernel, dim3((unsigned)g), dim3(threads), lds_bytes, c.stream, pr, size, degree,
+                         partials, fin);
   }
   c.wait_flag(seq);
 }

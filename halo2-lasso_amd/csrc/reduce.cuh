@@ -1,6 +1,8 @@
 // Wave64 / workgroup reductions of field elements (modular sums).
 #pragma once
+#if !defined(__HIPCC_RTC__)  // the runtime compiler (jit.cpp) has the HIP built-ins without headers
 #include <hip/hip_runtime.h>
+#endif
 #include "ff.cuh"
 
 namespace lh {

@@ -126,9 +126,30 @@ def test_monomial_fallback_path_still_matches_golden():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, LH_EXPR_MONOMIALS="1")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_golden.py",
-                        "tests/test_gpu_expression.py", "-k", "hyperplonk or sum_check or zero_check"],
+                        "tests/test_gpu_expression.py", "-k", "(hyperplonk or sum_check or zero_check) and not runtime_compiled"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     import re
     m = re.search(r"(\d+) passed", r.stdout)
     assert m and int(m.group(1)) >= 15, r.stdout[-500:]
+
+
+def test_runtime_compiled_round_kernel_matches_golden():
+    """Large general-expression sum-checks run the register program as straight-line code compiled at run time
+    (csrc/jit.cpp; by default from 2^16 rows).  LH_EXPR_JIT_MIN_VARS=1 selects it for every size: the golden and
+    oracle parity tests of the HyperPlonk path are repeated in a fresh process with it.  (`-k` must not select this
+    test or the fallback test above again.)"""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LH_EXPR_JIT_MIN_VARS="1", LH_HP_DEBUG="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-s", "-m", "gpu", "tests/test_gpu_golden.py",
+                        "tests/test_gpu_expression.py", "tests/test_gpu_hyperplonk.py",
+                        "-k", "(hyperplonk or sum_check or zero_check) and not fallback and not runtime_compiled"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    m = re.search(r"(\d+) passed", r.stdout)
+    assert m and int(m.group(1)) >= 15, r.stdout[-500:]
+    assert "[expr] compiled a" in r.stderr + r.stdout  # the compiled form really ran
