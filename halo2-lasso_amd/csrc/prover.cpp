@@ -273,14 +273,23 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
       } guard{c};
       k_sc_tail_launch(c, rd, degree, n0, bind, num_polys, seq0, evals_host, evals_host + 16);
       double host_us = 0;
+      auto wait = [&](uint32_t seq) {
+        try {
+          c.wait_flag(seq);
+        } catch (const Error& e) {
+          if (e.code != LH_ERR_DEVICE) throw;
+          throw Error(LH_ERR_DEVICE, std::string("resident sum-check rounds ended early (the kernel waits at most 2 s for each "
+                                                 "challenge; LH_SC_TAIL=0 launches every round instead): ") + e.what());
+        }
+      };
       for (size_t i = 0; i < rounds; i++) {
-        c.wait_flag(seq0 + (uint32_t)i);
+        wait(seq0 + (uint32_t)i);
         const auto t_h = std::chrono::steady_clock::now();
         const HFr r = message(evals_host);
         c.mbox_send(dev(r), seq0 + (uint32_t)i);
         if (tail_debug) host_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_h).count();
       }
-      c.wait_flag(seq0 + (uint32_t)rounds);
+      wait(seq0 + (uint32_t)rounds);
       guard.done = true;
       if (tail_debug)
         fprintf(stderr, "[sc_tail] T %zu terms %u degree %d n0 %zu rounds %zu: %.1f us (host side %.1f us)\n", T,

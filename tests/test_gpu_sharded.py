@@ -87,3 +87,31 @@ def test_sharded_proof_equals_single_gpu_and_oracle(tmp_path, world, kind, c, l,
     o_lasso.prove(opp, spec, dims, ot)
     assert proofs.pop() == ot.into_proof().hex()
     o_lasso.verify(opp, spec, n, OT(ot.into_proof()))
+
+
+def test_bench_two_ranks_launched_like_the_driver():
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` exactly as the driver launches it,
+    except that both ranks share GPU 0 (LH_DEVICE) and rendezvous over gloo: one JSON line, from rank 0, whole-job
+    aggregate over both ranks, weak scaling."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, LH_DEVICE="0", LH_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--log-n", "12", "--no-cpu-baseline", "--no-inflight"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["metric"] == "lasso_prove_time_ms" and d["higher_is_better"] is False
+    # two ranks prove one batch each per step: the job's time per proof is half the step time
+    assert abs(d["value"] - d["ms_per_step"] / 2) < 1e-6 * max(1.0, d["ms_per_step"])
+    assert d["config"]["lookups_per_proof"] == 1 << 12 and d["roofline"]["bound"] == "hbm"
