@@ -7,6 +7,9 @@
 //   x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2 ; identity <=> ZZ == 0 (all-zero bytes are the identity,
 //   so hipMemset(0) initialises bucket arrays).  Affine identity is (0,0) as in halo2curves.
 #pragma once
+#if defined(__HIPCC__) && !defined(__HIPCC_RTC__)
+#include <hip/hip_runtime.h>  // threadIdx in the quad-cooperative routines
+#endif
 #include "ff.cuh"
 
 namespace lh {
@@ -121,5 +124,80 @@ LH_HD G1Xyzz add(const G1Xyzz& p, const G1Xyzz& q) {
   r.zzz = mul(mul(p.zzz, q.zzz), ppp);
   return r;
 }
+
+#if defined(__HIPCC__)
+// ------------------------------------------------------------------ quad-cooperative arithmetic (device only)
+// The tails of an MSM (late continuation levels, small bucket reductions) are chains of DEPENDENT additions on
+// launches far below one wave per SIMD: a lone lane multiplies at ~1 us per Montgomery product, so one addition
+// (14 products) costs ~14 us however idle the machine is.  Here the 4 lanes of a quad (lanes 4k..4k+3) hold the
+// SAME operands and share the work: the products of one formula step run in different lanes and are exchanged with
+// DPP quad_perm moves, 4 product-steps per addition and 3 per doubling instead of 14 and 9.  Every lane of the quad
+// returns the full result, so a kernel maps one logical thread to a quad and keeps its control flow (which depends
+// only on the replicated data) unchanged.
+template <int K>
+__device__ __forceinline__ Fq quad_bcast(const Fq& v) {
+  Fq o;
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+    o.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.l[i], K * 0x55, 0xf, 0xf, false);
+  return o;
+}
+
+// lane-dependent operand choice as mask arithmetic: (x & m) | (y & ~m) is one v_bfi_b32 (the ternary form is turned
+// into a branch per limb)
+__device__ __forceinline__ Fq quad_sel(int ql, const Fq& a, const Fq& b, const Fq& c, const Fq& d) {
+  const uint32_t lo = 0u - (uint32_t)(ql & 1), hi = 0u - (uint32_t)((ql >> 1) & 1);
+  Fq o;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const uint32_t t0 = (b.l[i] & lo) | (a.l[i] & ~lo), t1 = (d.l[i] & lo) | (c.l[i] & ~lo);
+    o.l[i] = (t1 & hi) | (t0 & ~hi);
+  }
+  return o;
+}
+
+__device__ __forceinline__ G1Xyzz dbl_quad(const G1Xyzz& p) {
+  if (p.is_identity() || p.y.is_zero()) return G1Xyzz::identity();
+  const int ql = (int)(threadIdx.x & 3u);
+  const Fq u = dbl(p.y);
+  Fq t = quad_sel(ql, u, p.x, u, u);
+  Fq m = mul(t, t);                                              // 0: V = U^2   1: XX = X^2
+  const Fq v = quad_bcast<0>(m), xx = quad_bcast<1>(m);
+  const Fq mm = add(dbl(xx), xx);
+  m = mul(quad_sel(ql, u, p.x, mm, v), quad_sel(ql, v, v, mm, p.zz));   // 0: W = U V  1: S = X V  2: M^2  3: V ZZ
+  const Fq w = quad_bcast<0>(m), s_ = quad_bcast<1>(m), m2 = quad_bcast<2>(m);
+  G1Xyzz r;
+  r.zz = quad_bcast<3>(m);
+  r.x = sub(m2, dbl(s_));
+  m = mul(quad_sel(ql, mm, w, w, w), quad_sel(ql, sub(s_, r.x), p.y, p.zzz, p.zzz));  // 0: M (S - X3)  1: W Y  2: W ZZZ
+  r.y = sub(quad_bcast<0>(m), quad_bcast<1>(m));
+  r.zzz = quad_bcast<2>(m);
+  return r;
+}
+
+__device__ __forceinline__ G1Xyzz add_quad(const G1Xyzz& p, const G1Xyzz& q) {
+  if (p.is_identity()) return q;
+  if (q.is_identity()) return p;
+  const int ql = (int)(threadIdx.x & 3u);
+  Fq m = mul(quad_sel(ql, p.x, q.x, p.y, q.y), quad_sel(ql, q.zz, p.zz, q.zzz, p.zzz));
+  const Fq u1 = quad_bcast<0>(m), u2 = quad_bcast<1>(m), s1 = quad_bcast<2>(m), s2 = quad_bcast<3>(m);
+  const Fq pp_ = sub(u2, u1), r_ = sub(s2, s1);
+  if (pp_.is_zero()) {
+    if (r_.is_zero()) return dbl_quad(p);
+    return G1Xyzz::identity();
+  }
+  m = mul(quad_sel(ql, pp_, r_, p.zz, p.zzz), quad_sel(ql, pp_, r_, q.zz, q.zzz));   // PP, RR, ZZ1 ZZ2, ZZZ1 ZZZ2
+  const Fq pp = quad_bcast<0>(m), rr = quad_bcast<1>(m), zz12 = quad_bcast<2>(m), zzz12 = quad_bcast<3>(m);
+  m = mul(quad_sel(ql, pp_, u1, zz12, zz12), pp);                                        // PPP, Q, ZZ3
+  const Fq ppp = quad_bcast<0>(m), qq = quad_bcast<1>(m);
+  G1Xyzz r;
+  r.zz = quad_bcast<2>(m);
+  r.x = sub(sub(rr, ppp), dbl(qq));
+  m = mul(quad_sel(ql, r_, s1, zzz12, zzz12), quad_sel(ql, sub(qq, r.x), ppp, ppp, ppp));
+  r.y = sub(quad_bcast<0>(m), quad_bcast<1>(m));
+  r.zzz = quad_bcast<2>(m);
+  return r;
+}
+#endif
 
 }  // namespace lh

@@ -258,6 +258,43 @@ __global__ __launch_bounds__(128) void msm_accumulate_n_kernel(const uint32_t* _
   }
 }
 
+// The same level for short lists (ec.cuh, quad-cooperative arithmetic): one QUAD of lanes per entry, 9 us per
+// dependent addition instead of 20.  Used when the list is far too short to fill the chip anyway.
+__global__ __launch_bounds__(128) void msm_accumulate_n_quad_kernel(const uint32_t* __restrict__ in_key,
+                                                                    const G1Xyzz* __restrict__ in_pt, size_t n_in,
+                                                                    uint32_t G, G1Xyzz* __restrict__ buckets,
+                                                                    uint32_t* __restrict__ out_key,
+                                                                    G1Xyzz* __restrict__ out_pt,
+                                                                    const uint32_t* __restrict__ in_count,
+                                                                    uint32_t* __restrict__ out_count) {
+  if (*in_count == 0) return;
+  const bool lead = (threadIdx.x & 3u) == 0;
+  const size_t quads = ((size_t)gridDim.x * blockDim.x) >> 2;
+  for (size_t p = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; p < n_in; p += quads) {
+    const uint32_t k = in_key[p];
+    const bool valid = k != SENTINEL;
+    const bool prev_same = valid && p > 0 && in_key[p - 1] == k;
+    const bool slot_owner = (p % G) == 0;
+    const bool forced = prev_same && slot_owner;
+    uint32_t ok = SENTINEL;
+    if (valid && (!prev_same || forced)) {
+      G1Xyzz acc = in_pt[p];
+      for (size_t q = p + 1; q < n_in && (q % G) != 0 && in_key[q] == k; q++) acc = add_quad(acc, in_pt[q]);
+      if (forced) {
+        ok = k;
+        if (lead) {
+          out_pt[p / G] = acc;
+          atomicAdd(out_count, 1u);
+        }
+      } else {
+        const G1Xyzz sum = add_quad(buckets[k], acc);
+        if (lead) buckets[k] = sum;
+      }
+    }
+    if (slot_owner && lead) out_key[p / G] = ok;
+  }
+}
+
 // ------------------------------------------------------------------ 5: bucket reduce
 __device__ __forceinline__ G1Xyzz mul_small(const G1Xyzz& p, uint32_t k) {
   G1Xyzz acc = G1Xyzz::identity();
@@ -288,16 +325,51 @@ __global__ __launch_bounds__(64) void msm_segment_reduce_kernel(MsmPlanDev plan,
   }
 }
 
+// quad-cooperative form for batches with few segments (latency-bound: the chain is 2 S additions + a small multiple)
+__device__ __forceinline__ G1Xyzz mul_small_quad(const G1Xyzz& p, uint32_t k) {
+  G1Xyzz acc = G1Xyzz::identity();
+  for (int b = 31 - __clz(k | 1u); b >= 0; b--) {
+    acc = dbl_quad(acc);
+    if ((k >> b) & 1u) acc = add_quad(acc, p);
+  }
+  return k ? acc : G1Xyzz::identity();
+}
+
+__global__ __launch_bounds__(64) void msm_segment_reduce_quad_kernel(MsmPlanDev plan, const G1Xyzz* __restrict__ buckets,
+                                                                     G1Xyzz* __restrict__ seg_out, size_t total_segs) {
+  const bool lead = (threadIdx.x & 3u) == 0;
+  const size_t quads = ((size_t)gridDim.x * blockDim.x) >> 2;
+  for (size_t s = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; s < total_segs; s += quads) {
+    int j = 0;
+    while (j + 1 < plan.num_jobs && plan.job[j + 1].seg_base <= s) j++;
+    const MsmJobDev& jb = plan.job[j];
+    uint32_t local = (uint32_t)(s - jb.seg_base);
+    uint32_t w = local / jb.seg_per_win, seg = local % jb.seg_per_win;
+    uint32_t d0 = seg * jb.seg_size;
+    const G1Xyzz* b = buckets + jb.key_base + (size_t)w * jb.win_stride + d0;
+    G1Xyzz run = G1Xyzz::identity(), acc = G1Xyzz::identity();
+    for (int d = (int)jb.seg_size - 1; d >= 0; d--) {
+      acc = add_quad(acc, run);
+      run = add_quad(run, b[d]);
+    }
+    if (d0) acc = add_quad(acc, mul_small_quad(run, d0));
+    if (lead) seg_out[s] = acc;
+  }
+}
+
 // `nsplit` workgroups per (job, window): each sums a contiguous share of the window's segment partials (the host adds
 // the nsplit shares: a host addition is ~0.4 us, a device addition on this under-filled launch ~20 us, so a window with
 // 16 K segments must not be 64 dependent additions per thread).
 // The sums go straight into pinned host memory; the workgroup that finishes last publishes the flag the
 // host spins on (same ticket protocol as the sum-check rounds): no device-to-host copy, no stream synchronise.
-__global__ __launch_bounds__(256) void msm_window_sum_kernel(MsmPlanDev plan, const G1Xyzz* __restrict__ seg_out,
+__global__ __launch_bounds__(512) void msm_window_sum_kernel(MsmPlanDev plan, const G1Xyzz* __restrict__ seg_out,
                                                              G1Xyzz* __restrict__ win_out, uint32_t nsplit,
                                                              ScFinishArgs fin) {
-  __shared__ G1Xyzz lds[256];
+  // 128 quads of lanes (ec.cuh: quad-cooperative additions): a share of <= 1024 partials is 8 + 7 dependent additions
+  __shared__ G1Xyzz lds[128];
   const uint32_t win = blockIdx.x / nsplit, part = blockIdx.x % nsplit;
+  const uint32_t q = threadIdx.x >> 2;
+  const bool lead = (threadIdx.x & 3u) == 0;
   int j = 0;
   while (j + 1 < plan.num_jobs && plan.job[j + 1].win_base <= win) j++;
   const MsmJobDev& jb = plan.job[j];
@@ -306,13 +378,15 @@ __global__ __launch_bounds__(256) void msm_window_sum_kernel(MsmPlanDev plan, co
   const uint32_t lo = part * share, hi = min(lo + share, jb.seg_per_win);
   const G1Xyzz* src = seg_out + jb.seg_base + (size_t)w * jb.seg_per_win;
   G1Xyzz acc = G1Xyzz::identity();
-  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) acc = add(acc, src[i]);
-  lds[threadIdx.x] = acc;
+  for (uint32_t i = lo + q; i < hi; i += 128) acc = add_quad(acc, src[i]);
+  if (lead) lds[q] = acc;
   __syncthreads();
   const uint32_t live = hi > lo ? hi - lo : 0;
-  for (int off = 128; off > 0; off >>= 1) {
-    if ((int)threadIdx.x < off && (uint32_t)(threadIdx.x + off) < live)
-      lds[threadIdx.x] = add(lds[threadIdx.x], lds[threadIdx.x + off]);
+  for (uint32_t off = 64; off > 0; off >>= 1) {
+    if (q < off && q + off < live) {
+      const G1Xyzz v = add_quad(lds[q], lds[q + off]);
+      if (lead) lds[q] = v;
+    }
     __syncthreads();
   }
   if (threadIdx.x == 0) {
@@ -333,6 +407,8 @@ static int env_int(const char* name, int dflt) {
 // accumulate thread (0: by batch size)
 static const int MSM_C_OFF = env_int("LH_MSM_C_OFF", 3), MSM_C_MAX = env_int("LH_MSM_C_MAX", 16),
                  MSM_K = env_int("LH_MSM_K", 0),
+                 MSM_QUAD_MAX = env_int("LH_MSM_QUAD_MAX", 262144),  // lists / segment counts up to which a quad of lanes
+                                                                      // shares one curve addition (0: never)
                  MSM_K2 = env_int("LH_MSM_K2", 4);  // continuation fan-in: a level costs ~K2 dependent additions, there are
                                                     // log_K2(chunks) levels; swept 2..16, 3-4 is best (2^16: 10.1 -> 9.3 ms)
 
@@ -524,9 +600,13 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
         size_t nc = (n_in + K2 - 1) / K2;
         uint32_t* okey = c.arena.alloc_n<uint32_t>(nc);
         G1Xyzz* opt = c.arena.alloc_n<G1Xyzz>(nc);
-        hipLaunchKernelGGL(msm_accumulate_n_kernel, dim3((unsigned)std::min<size_t>((n_in + 127) / 128, 1 << 16)),
-                           dim3(128), 0, c.stream, ckey, cpt, n_in, K2, buckets, okey, opt, lvl_cnt + lvl,
-                           lvl_cnt + lvl + 1);
+        if (n_in <= (size_t)MSM_QUAD_MAX)  // far below one wave per SIMD: a quad of lanes per entry
+          hipLaunchKernelGGL(msm_accumulate_n_quad_kernel, dim3((unsigned)((4 * n_in + 127) / 128)), dim3(128), 0, c.stream,
+                             ckey, cpt, n_in, K2, buckets, okey, opt, lvl_cnt + lvl, lvl_cnt + lvl + 1);
+        else
+          hipLaunchKernelGGL(msm_accumulate_n_kernel, dim3((unsigned)std::min<size_t>((n_in + 127) / 128, 1 << 16)),
+                             dim3(128), 0, c.stream, ckey, cpt, n_in, K2, buckets, okey, opt, lvl_cnt + lvl,
+                             lvl_cnt + lvl + 1);
         lvl++;
         if (n_in <= K2) break;  // a single chunk: no continuation can remain
         ckey = okey;
@@ -536,11 +616,15 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
       }
       {
         ProfScope ps(c, "msm_bucket_reduce", 128.0 * nbuckets, 14.0 * 2.2 * nbuckets, (double)nbuckets);
-      hipLaunchKernelGGL(msm_segment_reduce_kernel, dim3((unsigned)std::min<size_t>((nsegs + 63) / 64, 1 << 16)),
-                         dim3(64), 0, c.stream, plan, buckets, seg_out, nsegs);
+      if (nsegs <= (size_t)MSM_QUAD_MAX / 2)
+        hipLaunchKernelGGL(msm_segment_reduce_quad_kernel, dim3((unsigned)((4 * nsegs + 63) / 64)), dim3(64), 0, c.stream,
+                           plan, buckets, seg_out, nsegs);
+      else
+        hipLaunchKernelGGL(msm_segment_reduce_kernel, dim3((unsigned)std::min<size_t>((nsegs + 63) / 64, 1 << 16)),
+                           dim3(64), 0, c.stream, plan, buckets, seg_out, nsegs);
       const uint32_t seq = c.next_seq();
       const ScFinishArgs fin = c.finish_for((uint32_t)(nwins * nsplit), nullptr, seq);
-      hipLaunchKernelGGL(msm_window_sum_kernel, dim3((unsigned)(nwins * nsplit)), dim3(256), 0, c.stream, plan, seg_out,
+      hipLaunchKernelGGL(msm_window_sum_kernel, dim3((unsigned)(nwins * nsplit)), dim3(512), 0, c.stream, plan, seg_out,
                          win_out, nsplit, fin);
       if (c.prof) c.sync();
       c.wait_flag(seq);
