@@ -60,14 +60,18 @@ struct MsmPlanDev {
 // Fr column holding small values (Lasso's output column) only emits the windows it needs.
 __global__ void msm_or_limbs_kernel(MsmPlanDev plan, uint32_t* __restrict__ or_out /* [jobs][8] */) {
   const MsmJobDev& jb = plan.job[blockIdx.y];
-  if (jb.is_u32) return;
   uint32_t acc[8];
 #pragma unroll
   for (int k = 0; k < 8; k++) acc[k] = 0;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < jb.n; i += (size_t)gridDim.x * blockDim.x) {
-    Fr s = from_mont(((const Fr*)jb.scalars)[i]);
+  if (jb.is_u32) {  // a 32-bit column of 16-bit chunk indices needs one window, not two
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < jb.n; i += (size_t)gridDim.x * blockDim.x)
+      acc[0] |= ((const uint32_t*)jb.scalars)[i];
+  } else {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < jb.n; i += (size_t)gridDim.x * blockDim.x) {
+      Fr s = from_mont(((const Fr*)jb.scalars)[i]);
 #pragma unroll
-    for (int k = 0; k < 8; k++) acc[k] |= s.l[k];
+      for (int k = 0; k < 8; k++) acc[k] |= s.l[k];
+    }
   }
   __shared__ uint32_t lds_or[8];
   if (threadIdx.x < 8) lds_or[threadIdx.x] = 0;
@@ -405,7 +409,7 @@ static int env_int(const char* name, int dflt) {
 }
 // tuning knobs (development): window = floor(log2 n) - LH_MSM_C_OFF capped at LH_MSM_C_MAX; LH_MSM_K = entries per
 // accumulate thread (0: by batch size)
-static const int MSM_C_OFF = env_int("LH_MSM_C_OFF", 3), MSM_C_MAX = env_int("LH_MSM_C_MAX", 16),
+static const int MSM_C_OFF = env_int("LH_MSM_C_OFF", 3), MSM_C_MAX = env_int("LH_MSM_C_MAX", 17),
                  MSM_K = env_int("LH_MSM_K", 0),
                  MSM_QUAD_MAX = env_int("LH_MSM_QUAD_MAX", 262144),  // lists / segment counts up to which a quad of lanes
                                                                       // shares one curve addition (0: never)
@@ -433,7 +437,7 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
     size_t nj = std::min(num_jobs - base, (size_t)MSM_MAX_JOBS);
     MsmPlanDev plan;
     plan.num_jobs = (int)nj;
-    // significant bits of every Fr column (one cheap pass; u32 columns are 32-bit by declaration)
+    // significant bits of every column (one cheap pass)
     std::vector<uint32_t> job_bits(nj, 32);
     {
       bool any_fr = false;
@@ -444,7 +448,7 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
         plan.job[j].scalars = in.scalars;
         plan.job[j].is_u32 = in.scalars_u32 ? 1 : 0;
         plan.job[j].n = (uint32_t)in.n;
-        any_fr |= !in.scalars_u32 && in.n;
+        any_fr |= in.n != 0;
         max_n0 = std::max(max_n0, in.n);
       }
       if (any_fr) {
@@ -457,7 +461,6 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
         LH_HIP(hipMemcpyAsync(h_or, d_or, 8 * nj * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
         c.sync();
         for (size_t j = 0; j < nj; j++) {
-          if (jobs[base + j].scalars_u32) continue;
           uint32_t bits = 0;
           for (int k = 7; k >= 0 && !bits; k--)
             if (h_or[8 * j + k]) bits = 32 * k + (32 - __builtin_clz(h_or[8 * j + k]));
