@@ -409,7 +409,7 @@ static int env_int(const char* name, int dflt) {
 }
 // tuning knobs (development): window = floor(log2 n) - LH_MSM_C_OFF capped at LH_MSM_C_MAX; LH_MSM_K = entries per
 // accumulate thread (0: by batch size)
-static const int MSM_C_OFF = env_int("LH_MSM_C_OFF", 3), MSM_C_MAX = env_int("LH_MSM_C_MAX", 17),
+static const int MSM_C_OFF = env_int("LH_MSM_C_OFF", 4), MSM_C_MAX = env_int("LH_MSM_C_MAX", 17),
                  MSM_K = env_int("LH_MSM_K", 0),
                  MSM_QUAD_MAX = env_int("LH_MSM_QUAD_MAX", 262144),  // lists / segment counts up to which a quad of lanes
                                                                       // shares one curve addition (0: never)
