@@ -113,5 +113,5 @@ def test_bench_two_ranks_launched_like_the_driver():
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
     assert d["metric"] == "lasso_prove_time_ms" and d["higher_is_better"] is False
     # two ranks prove one batch each per step: the job's time per proof is half the step time
-    assert abs(d["value"] - d["ms_per_step"] / 2) < 1e-6 * max(1.0, d["ms_per_step"])
+    assert abs(d["value"] - d["ms_per_step"] / 2) <= 1e-3  # both are printed with three decimals
     assert d["config"]["lookups_per_proof"] == 1 << 12 and d["roofline"]["bound"] == "hbm"
