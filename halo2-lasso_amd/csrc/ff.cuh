@@ -122,7 +122,7 @@ LH_HD uint32_t sub_mod_raw(Fp<P>& r, const Fp<P>& a) {
 }
 
 template <class P>
-LH_HD Fp<P> reduce_once(const Fp<P>& a) {
+LH_HD Fp<P> reduce_once_generic(const Fp<P>& a) {
   Fp<P> t;
   uint32_t bw = sub_mod_raw(t, a);
   Fp<P> r;
@@ -132,14 +132,14 @@ LH_HD Fp<P> reduce_once(const Fp<P>& a) {
 }
 
 template <class P>
-LH_HD Fp<P> add(const Fp<P>& a, const Fp<P>& b) {
+LH_HD Fp<P> add_generic(const Fp<P>& a, const Fp<P>& b) {
   Fp<P> s;
   add_raw(s, a, b);  // a,b < p < 2^254 : no carry out of 256 bits
-  return reduce_once(s);
+  return reduce_once_generic(s);
 }
 
 template <class P>
-LH_HD Fp<P> sub(const Fp<P>& a, const Fp<P>& b) {
+LH_HD Fp<P> sub_generic(const Fp<P>& a, const Fp<P>& b) {
   Fp<P> d;
   uint32_t bw = 0;
 #pragma unroll
@@ -158,6 +158,108 @@ LH_HD Fp<P> sub(const Fp<P>& a, const Fp<P>& b) {
     c = (uint32_t)(s >> 32);
   }
   return r;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// Device forms: the 8-limb carry chains written as the 8 instructions they are (from the C++ above the compiler makes
+// ~100 instructions per modular addition: 64-bit adds on zero-extended register pairs and the moves to build them;
+// these are ~25).  Checked against the generic forms by tools/ubench/mul_forms.hip and by every parity test.
+template <class P>
+__device__ __forceinline__ void add_chain(Fp<P>& s, const Fp<P>& a, const Fp<P>& b) {
+  asm("v_add_co_u32 %0, vcc, %8, %16\n\t"
+      "v_addc_co_u32 %1, vcc, %9, %17, vcc\n\t"
+      "v_addc_co_u32 %2, vcc, %10, %18, vcc\n\t"
+      "v_addc_co_u32 %3, vcc, %11, %19, vcc\n\t"
+      "v_addc_co_u32 %4, vcc, %12, %20, vcc\n\t"
+      "v_addc_co_u32 %5, vcc, %13, %21, vcc\n\t"
+      "v_addc_co_u32 %6, vcc, %14, %22, vcc\n\t"
+      "v_addc_co_u32 %7, vcc, %15, %23, vcc"
+      : "=&v"(s.l[0]), "=&v"(s.l[1]), "=&v"(s.l[2]), "=&v"(s.l[3]), "=&v"(s.l[4]), "=&v"(s.l[5]), "=&v"(s.l[6]),
+        "=&v"(s.l[7])
+      : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]),
+        "v"(b.l[0]), "v"(b.l[1]), "v"(b.l[2]), "v"(b.l[3]), "v"(b.l[4]), "v"(b.l[5]), "v"(b.l[6]), "v"(b.l[7])
+      : "vcc");
+}
+// t = s - p, mask = all ones if that borrowed (s < p)
+template <class P>
+__device__ __forceinline__ uint32_t sub_p_chain(Fp<P>& t, const Fp<P>& s) {
+  uint32_t mask;
+  asm("v_subrev_co_u32 %0, vcc, %17, %9\n\t"
+      "v_subbrev_co_u32 %1, vcc, %18, %10, vcc\n\t"
+      "v_subbrev_co_u32 %2, vcc, %19, %11, vcc\n\t"
+      "v_subbrev_co_u32 %3, vcc, %20, %12, vcc\n\t"
+      "v_subbrev_co_u32 %4, vcc, %21, %13, vcc\n\t"
+      "v_subbrev_co_u32 %5, vcc, %22, %14, vcc\n\t"
+      "v_subbrev_co_u32 %6, vcc, %23, %15, vcc\n\t"
+      "v_subbrev_co_u32 %7, vcc, %24, %16, vcc\n\t"
+      "v_cndmask_b32_e64 %8, 0, -1, vcc"
+      : "=&v"(t.l[0]), "=&v"(t.l[1]), "=&v"(t.l[2]), "=&v"(t.l[3]), "=&v"(t.l[4]), "=&v"(t.l[5]), "=&v"(t.l[6]),
+        "=&v"(t.l[7]), "=&v"(mask)
+      : "v"(s.l[0]), "v"(s.l[1]), "v"(s.l[2]), "v"(s.l[3]), "v"(s.l[4]), "v"(s.l[5]), "v"(s.l[6]), "v"(s.l[7]),
+        // the modulus in VGPRs: an SGPR operand next to the carry-in would be two constant-bus reads
+        "v"(P::mod(0)), "v"(P::mod(1)), "v"(P::mod(2)), "v"(P::mod(3)), "v"(P::mod(4)), "v"(P::mod(5)), "v"(P::mod(6)),
+        "v"(P::mod(7))
+      : "vcc");
+  return mask;
+}
+// d = a - b, mask = all ones if that borrowed (a < b)
+template <class P>
+__device__ __forceinline__ uint32_t sub_chain(Fp<P>& d, const Fp<P>& a, const Fp<P>& b) {
+  uint32_t mask;
+  asm("v_sub_co_u32 %0, vcc, %9, %17\n\t"
+      "v_subb_co_u32 %1, vcc, %10, %18, vcc\n\t"
+      "v_subb_co_u32 %2, vcc, %11, %19, vcc\n\t"
+      "v_subb_co_u32 %3, vcc, %12, %20, vcc\n\t"
+      "v_subb_co_u32 %4, vcc, %13, %21, vcc\n\t"
+      "v_subb_co_u32 %5, vcc, %14, %22, vcc\n\t"
+      "v_subb_co_u32 %6, vcc, %15, %23, vcc\n\t"
+      "v_subb_co_u32 %7, vcc, %16, %24, vcc\n\t"
+      "v_cndmask_b32_e64 %8, 0, -1, vcc"
+      : "=&v"(d.l[0]), "=&v"(d.l[1]), "=&v"(d.l[2]), "=&v"(d.l[3]), "=&v"(d.l[4]), "=&v"(d.l[5]), "=&v"(d.l[6]),
+        "=&v"(d.l[7]), "=&v"(mask)
+      : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]),
+        "v"(b.l[0]), "v"(b.l[1]), "v"(b.l[2]), "v"(b.l[3]), "v"(b.l[4]), "v"(b.l[5]), "v"(b.l[6]), "v"(b.l[7])
+      : "vcc");
+  return mask;
+}
+#endif
+
+template <class P>
+LH_HD Fp<P> reduce_once(const Fp<P>& a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  Fp<P> t, r;
+  const uint32_t keep = sub_p_chain(t, a);  // a < p: keep a
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.l[i] = (a.l[i] & keep) | (t.l[i] & ~keep);
+  return r;
+#else
+  return reduce_once_generic(a);
+#endif
+}
+
+template <class P>
+LH_HD Fp<P> add(const Fp<P>& a, const Fp<P>& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  Fp<P> s;
+  add_chain(s, a, b);  // a, b < p < 2^254: no carry out of 256 bits
+  return reduce_once(s);
+#else
+  return add_generic(a, b);
+#endif
+}
+
+template <class P>
+LH_HD Fp<P> sub(const Fp<P>& a, const Fp<P>& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  Fp<P> d, pm, r;
+  const uint32_t borrowed = sub_chain(d, a, b);
+#pragma unroll
+  for (int i = 0; i < 8; i++) pm.l[i] = P::mod(i) & borrowed;
+  add_chain(r, d, pm);  // wraps back into [0, p)
+  return r;
+#else
+  return sub_generic(a, b);
+#endif
 }
 
 template <class P>

@@ -54,11 +54,29 @@ __device__ __forceinline__ Fp<P> mul_ps(const Fp<P>& a, const Fp<P>& b) {
   return reduce_once(out);  // a, b < p < 2^254: the result is < 2p < 2^255, no ninth word
 }
 
+// additions / subtractions: device forms (ff.cuh add, sub) against the generic C++ forms
+__global__ __launch_bounds__(256) void addsub_check(const Fr* a, const Fr* b, Fr* o0, Fr* o1) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const Fr x = reduce_once_generic(a[i]), y = reduce_once_generic(b[i]);
+  o0[i] = add_generic(sub_generic(add_generic(x, y), sub_generic(y, x)), reduce_once_generic(add_generic(x, x)));
+  o1[i] = add(sub(add(x, y), sub(y, x)), reduce_once(dbl(x)));
+}
+template <int FORM>
+__global__ __launch_bounds__(256) void addsub_chain(const Fr* a, const Fr* b, Fr* o, int iters) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  Fr x = reduce_once_generic(a[i]), y = reduce_once_generic(b[i]);
+  for (int k = 0; k < iters; k++) {
+    x = FORM ? add(x, y) : add_generic(x, y);
+    y = FORM ? sub(y, x) : sub_generic(y, x);
+  }
+  o[i] = FORM ? add(x, y) : add_generic(x, y);
+}
+
 template <int FORM>
 __global__ __launch_bounds__(256) void chain(const Fr* a, const Fr* b, Fr* o, int iters) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   Fr x = a[i], y = b[i];
-  for (int k = 0; k < iters; k++) x = FORM ? mul_ps(x, y) : mul(x, y);
+  for (int k = 0; k < iters; k++) x = FORM ? mul_ps(x, y) : mul_cios(x, y);
   o[i] = x;
 }
 
@@ -106,5 +124,27 @@ int main() {
   const bool same = memcmp(h0.data(), h1.data(), n * sizeof(Fr)) == 0;
   printf("CIOS (C++): %.1f G mul/s   product scanning (mad + addc): %.1f G mul/s   results %s\n",
          n * (double)iters / ms[0] / 1e6, n * (double)iters / ms[1] / 1e6, same ? "identical" : "DIFFER");
-  return same ? 0 : 2;
+  if (!same) return 2;
+  hipLaunchKernelGGL(addsub_check, n / 256, 256, 0, 0, da, db, d0, d1);
+  CK(hipMemcpy(h0.data(), d0, n * sizeof(Fr), hipMemcpyDeviceToHost));
+  CK(hipMemcpy(h1.data(), d1, n * sizeof(Fr), hipMemcpyDeviceToHost));
+  const bool same_as = memcmp(h0.data(), h1.data(), n * sizeof(Fr)) == 0;
+  for (int rep = 0; rep < 3; rep++) {
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(addsub_chain<0>, n / 256, 256, 0, 0, da, db, d0, iters);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms[0], e0, e1));
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(addsub_chain<1>, n / 256, 256, 0, 0, da, db, d1, iters);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms[1], e0, e1));
+  }
+  CK(hipMemcpy(h0.data(), d0, n * sizeof(Fr), hipMemcpyDeviceToHost));
+  CK(hipMemcpy(h1.data(), d1, n * sizeof(Fr), hipMemcpyDeviceToHost));
+  const bool same_chain = memcmp(h0.data(), h1.data(), n * sizeof(Fr)) == 0;
+  printf("modular add + sub pairs: generic C++ %.1f G/s   carry chains %.1f G/s   results %s\n",
+         n * (double)iters / ms[0] / 1e6, n * (double)iters / ms[1] / 1e6, same_as && same_chain ? "identical" : "DIFFER");
+  return same_as && same_chain ? 0 : 3;
 }
