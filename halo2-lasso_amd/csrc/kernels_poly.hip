@@ -61,14 +61,23 @@ void k_fr_binop(Ctx& c, int op, const Fr* a, const Fr* b, size_t n, Fr* out) {
 
 __global__ void fr_mul_chain_kernel(const Fr* __restrict__ a, const Fr* __restrict__ b, size_t n, int iters,
                                     Fr* __restrict__ out) {
-  GSTRIDE(i, n) {
-    Fr x = a[i], y = b[i];
-    for (int k = 0; k < iters; k++) x = mul(x, y);
-    out[i] = x;
+  // two independent chains per thread (elements i and i + half): the measured rate is the multiplier's, not the
+  // latency of one dependent chain at whatever occupancy the launch reaches
+  const size_t half = (n + 1) / 2;
+  GSTRIDE(i, half) {
+    const size_t j = i + half;
+    const bool two = j < n;
+    Fr x0 = a[i], y0 = b[i], x1 = two ? a[j] : x0, y1 = two ? b[j] : y0;
+    for (int k = 0; k < iters; k++) {
+      x0 = mul(x0, y0);
+      x1 = mul(x1, y1);
+    }
+    out[i] = x0;
+    if (two) out[j] = x1;
   }
 }
 void k_fr_mul_chain(Ctx& c, const Fr* a, const Fr* b, size_t n, int iters, Fr* out) {
-  if (n) hipLaunchKernelGGL(fr_mul_chain_kernel, grid_for(n, 256, 1 << 20), 256, 0, c.stream, a, b, n, iters, out);
+  if (n) hipLaunchKernelGGL(fr_mul_chain_kernel, grid_for((n + 1) / 2, 256, 1 << 20), 256, 0, c.stream, a, b, n, iters, out);
 }
 
 // Batch inversion, Montgomery's trick per thread over a strip of CHUNK elements:
