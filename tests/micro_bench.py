@@ -110,6 +110,20 @@ def main():
             hl.prove_fractional_sum_check(ctx, [None] * 3, [None] * 3, polys[:3], polys[3:], gt)
             rec["bytes_equal"] = gt.into_proof() == tr.into_proof()
         out["frac_gkr"].append(rec)
+    # ---- zero-check: ClassicSumCheck<EvaluationsProver> over vanilla_plonk_expression (benches/zero_check.rs:24-42),
+    # random tables (the prover's work does not depend on the claim being true), sum claimed 0 as in the bench
+    from halo2_lasso_amd import hyperplonk as g_hp
+    out["zero_check"] = []
+    for nv in range(20, 24):
+        info = g_hp.vanilla_plonk_circuit_info(nv, 0, [[]] * 5, [[(6, 1)], [(7, 1)], [(8, 1)]])
+        nz, expr = g_hp.compose(info)
+        polys = [hl.MultilinearPolynomial(ctx, ctx.upload(rand_fr_bytes(rng, 1 << nv)), nv) for _ in range(13)]
+        challenges = [int(v) for v in rng.integers(1, 1 << 62, size=3)]
+        ys = [[int(v) for v in rng.integers(1, 1 << 62, size=nv)]]
+        g = gpu_time(ctx, lambda: hl.sum_check_prove_expression(ctx, nv, expr, polys, challenges, ys, 0,
+                                                                hl.Keccak256Transcript()))
+        out["zero_check"].append({"num_vars": nv, "gpu_ms": g, "polys": 13, "degree": expr.degree()})
+        del polys
     print(json.dumps(out, indent=1))
 
 
