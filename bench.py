@@ -423,7 +423,7 @@ def main():
             shared.h = None
             out["two_proofs_in_flight"] = {"ms_per_proof": round(dt * 1e3 / (2 * args.steps), 3),
                                            "lookups_per_s": round((1 << n) * 2 * args.steps / dt)}
-        if not args.no_cpu_baseline and not sharded:
+        if not args.no_cpu_baseline and not sharded and world == 1:  # the contract: rank 0 at N = 1 only
             def gpu_proof(nn, dims):
                 bufs = [ctx.upload(d.tobytes()) for d in dims]
                 return prove(nn, bufs).into_proof()
