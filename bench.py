@@ -295,7 +295,7 @@ def main_hyperplonk(args, hdist, dist, rank, local_rank, world):
             aggs = aggregate(hl.profile_read(ctx))
             hl.profile_enable(ctx, False)
             out["roofline"], out["alu"], out["kernels"] = roofline_objects(hl, ctx, aggs)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
             def gpu_proof(pcs, c):
                 return prove(synthetic.prover_param(pcs, c), c).into_proof()
             try:
