@@ -1,18 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- Lasso prove time on MI355X (BASELINE.json metric), one JSON line on stdout.
 
-Step = one Lasso prove of the workload (BASELINE.json configs[1]: 2^20 range-check lookups, BN254,
-32-bit values as 2 x 16-bit limbs into the identity subtable, multilinear-KZG openings) with the lookup
-indices and the SRS already resident in HBM.  `--gpus N` (launched by torch.distributed.run, one
-rank per GPU): every rank proves its own independent batch of 2^n lookups (weak scaling, no
-data-path collective); time = max over ranks, value = ms per proof over the
-whole job = wall / (N * K).
+Step = one Lasso prove of the workload with the lookup indices and the SRS already resident in HBM.  Default
+workload = BASELINE.json configs[2], the configuration north_star states its target on: 2^24 AND lookups (32-bit
+operands as 4 chunks of 8+8 bits into the 2^16-entry AND subtable, Surge), BN254, multilinear-KZG openings.
+`--log-n 20 --table range` is configs[1].
+
+`--gpus N` (launched by torch.distributed.run, one rank per GPU): ONE proof of the same 2^log-n lookups sharded over
+the N GPUs (tables and SRS split on mid index bits, per-round partial sums and partial commitments
+all-gathered over RCCL on the prover's stream): strong scaling, value = ms per proof.  `--mode replicas` instead
+lets every rank prove its own batch (weak scaling, no data-path collective).
 
 Extra objects on the line:
-  roofline      dominant kernel (the one owning the most expensive single launch of the profiled prove) at that
-                launch shape: algorithmic bytes per launch / HIP-event duration, against 8 TB/s HBM
-  alu           same kernel against the measured Fr-multiplication peak (integer-ALU bound)
-  cpu_baseline  the C++ oracle (reference algorithms, all host cores) on a bounded sample
+  roofline      the kernel with the largest total time in a separately profiled prove: SURVEY.md §8(d) algorithmic
+                bytes / HIP-event time (ctx stream), against 8 TB/s HBM
+  alu           the same launches against the Fr-multiplication peak (the field arithmetic is integer-ALU bound)
+  cpu_baseline  the C++ oracle (reference algorithms, all host cores) on a bounded sample, proof bytes compared
 """
 import argparse
 import ctypes as C
@@ -35,8 +38,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--log-n", type=int, default=20, help="log2 of the number of lookups per proof")
-    ap.add_argument("--table", default="range", choices=["range", "and", "xor"])
+    ap.add_argument("--log-n", type=int, default=0,
+                    help="log2 of the number of lookups per proof (default 24: BASELINE.json configs[2], the config "
+                         "north_star's target is stated on; --log-n 20 --table range is configs[1]; hyperplonk: 20)")
+    ap.add_argument("--table", default="and", choices=["range", "and", "xor"])
     ap.add_argument("--pcs", default="mkzg", choices=["mkzg", "zeromorph"],
                     help="polynomial commitment scheme of the Lasso workload: multilinear KZG (default, the metric's "
                          "configuration) or Zeromorph over univariate KZG")
@@ -48,10 +53,14 @@ def parse():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-inflight", action="store_true",
                     help="skip the extra throughput figure (two independent proofs in flight on one GPU)")
-    ap.add_argument("--mode", default="replicas", choices=["replicas", "sharded"],
-                    help="N>1: 'replicas' = one independent proof per GPU (weak scaling, default); 'sharded' = ONE "
-                         "proof of 2^log-n lookups split over the N GPUs (strong scaling, SURVEY.md §8e)")
-    return ap.parse_args()
+    ap.add_argument("--mode", default="sharded", choices=["replicas", "sharded"],
+                    help="N>1: 'sharded' (default) = ONE proof of 2^log-n lookups split over the N GPUs (strong "
+                         "scaling, SURVEY.md §8e, partial sums over RCCL); 'replicas' = one independent proof per GPU "
+                         "(weak scaling, no data-path collective)")
+    args = ap.parse_args()
+    if not args.log_n:
+        args.log_n = 20 if args.workload == "hyperplonk" else 24
+    return args
 
 
 def make_table(hl, kind):
@@ -75,11 +84,12 @@ def trapdoor(nv):
 def aggregate(recs):
     by = {}
     for r in recs:
-        a = by.setdefault(r["name"], dict(name=r["name"], launches=0, ms=0.0, bytes=0.0, muls=0.0, big=None))
+        a = by.setdefault(r["name"], dict(name=r["name"], launches=0, ms=0.0, bytes=0.0, muls=0.0, items=0.0, big=None))
         a["launches"] += 1
         a["ms"] += r["ms"]
         a["bytes"] += r["bytes"]
         a["muls"] += r["muls"]
+        a["items"] += r["items"]
         if a["big"] is None or r["bytes"] > a["big"]["bytes"]:
             a["big"] = r
     return sorted(by.values(), key=lambda a: -a["ms"])
@@ -167,21 +177,41 @@ def cpu_baseline(hl, ctx, pp, table, kind, args, gpu_proof_fn):
             "sample_log_n": n, "proof_bytes_equal_gpu": bool(same)}
 
 
+# Ceiling of the 32-bit integer multiplier the field arithmetic runs on (csrc/ff.cuh): one Montgomery product is
+# 129 v_mad_u64_u32 (64 operand products + 64 reduction products + 1).  v_mad_u64_u32 issues at a quarter of the
+# full 32-bit VALU rate (128 lanes per CU per cycle): 256 CUs x 128 x 2.4 GHz / 4 = 19.7 T mad/s = 152 G products/s;
+# the measured chain (tools/ubench/mul_forms.hip, lh_fr_mul_chain) reaches 86 % of that.
+MAD_PER_FR_MUL = 129
+MAD_CEILING_PER_S = 256 * 128 * 2.4e9 / 4
+
+
 def roofline_objects(hl, ctx, aggs, traffic=(None, None)):
+    """`roofline`: the kernel with the largest total time in the profiled prove, priced in SURVEY.md §8(d)'s
+    algorithmic bytes (sum over its launches) / its HIP-event time (sum over its launches) against 8 TB/s HBM;
+    `alu`: the same launches against the Fr-multiplication peak (measured, and the quarter-rate ceiling it is
+    derived from)."""
     tot = sum(a["ms"] for a in aggs) or 1.0
     peak_mul = fr_mul_peak(hl, ctx)
-    # dominant kernel = the one owning the single most expensive launch of the proof: a well-defined launch shape
-    # (the round kernels run hundreds of launches from 1 pair to 2^19 pairs; their aggregate has no single roofline)
-    dom = max(aggs, key=lambda a: a["big"]["ms"])
-    big = dom["big"]
-    ach = big["bytes"] / (big["ms"] * 1e-3) / 1e9 if big["ms"] > 0 else 0.0
+    dom = max(aggs, key=lambda a: a["ms"])
+    avg_ms = dom["ms"] / dom["launches"]
+    ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 if dom["ms"] > 0 else 0.0
     roof = {"bound": "hbm", "kernel": dom["name"], "achieved": round(ach, 1), "peak": 8000.0,
             "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic[0], "traffic_source": traffic[1],
-            "launch": {"ms": round(big["ms"], 4), "bytes": big["bytes"], "items": big["items"]},
-            "share_of_profiled_prove": round(dom["ms"] / tot, 3), "launches": dom["launches"]}
-    mul_rate = big["muls"] / (big["ms"] * 1e-3) if big["ms"] > 0 else 0.0
+            "launches": dom["launches"], "avg_launch_ms": round(avg_ms, 4),
+            "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
+            "items_per_launch": dom["items"] / dom["launches"],
+            "share_of_profiled_prove": round(dom["ms"] / tot, 3),
+            "accounting": "SURVEY.md 8(d): MSM 96 B per point with a 32-byte scalar, 68 B with a u32 scalar, summed "
+                          "over the jobs of the batch; sum-check 96 B per bound entry; see DESIGN.md section 3"}
+    mul_rate = dom["muls"] / (dom["ms"] * 1e-3) if dom["ms"] > 0 else 0.0
+    ceiling = MAD_CEILING_PER_S / MAD_PER_FR_MUL
     alu = {"bound": "int32-mul", "kernel": dom["name"], "achieved": round(mul_rate / 1e9, 2),
-           "peak": round(peak_mul / 1e9, 2), "unit": "G Fr-mul/s", "frac": round(mul_rate / peak_mul, 4)}
+           "peak": round(peak_mul / 1e9, 2), "unit": "G Fr-mul/s", "frac": round(mul_rate / peak_mul, 4),
+           "peak_source": "measured (lh_fr_mul_chain: two independent product chains per thread, 256 products per "
+                          "element)",
+           "ceiling": round(ceiling / 1e9, 1), "frac_of_ceiling": round(mul_rate / ceiling, 4),
+           "ceiling_derivation": "256 CU x 128 lanes/cycle x 2.4 GHz / 4 (v_mad_u64_u32 is quarter rate) = 19.7 T mad/s; "
+                                 "/ 129 v_mad_u64_u32 per Montgomery product"}
     kernels = [{"name": a["name"], "launches": a["launches"], "ms": round(a["ms"], 3),
                 "GBps_all": round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1) if a["ms"] > 0 else 0.0,
                 "GBps_largest": round(a["big"]["bytes"] / (a["big"]["ms"] * 1e-3) / 1e9, 1) if a["big"]["ms"] > 0 else 0.0}

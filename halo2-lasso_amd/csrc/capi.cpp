@@ -34,6 +34,27 @@ struct lh_zm_vp {
 
 #define NEED(p) LH_REQUIRE((p) != nullptr, LH_ERR_ARG, "null argument: " #p)
 
+// The current HIP device is a per-host-thread setting: every entry point that takes a ctx makes the ctx's device
+// current for the duration of the call (workspace growth, SRS shards and runtime-compiled modules must land on the
+// device the ctx's stream belongs to, whichever thread calls) and restores the caller's device afterwards.
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) {
+      LH_HIP(hipSetDevice(dev));
+      switched = true;
+    }
+  }
+  ~DeviceGuard() {
+    if (switched && prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+#define NEED_CTX(ctx) \
+  NEED(ctx);          \
+  DeviceGuard device_guard_((ctx)->c.device)
+
 extern "C" {
 
 const char* lh_last_error(void) { return lh::get_last_error(); }
@@ -54,6 +75,9 @@ lh_status lh_ctx_create(int device_id, lh_ctx** out) {
   hipDeviceProp_t prop;
   LH_HIP(hipGetDeviceProperties(&prop, device_id));
   ctx->c.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  int khz = 0;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device_id) == hipSuccess && khz > 0)
+    ctx->c.wall_clock_khz = khz;
   ctx->c.pin(65536);
   // line 0: device -> host sequence flag; lines 1-2: host -> device mailbox of the resident sum-check tail
   LH_HIP(hipHostMalloc((void**)&ctx->c.flag, 256, hipHostMallocCoherent | hipHostMallocMapped));
@@ -78,7 +102,7 @@ void lh_ctx_destroy(lh_ctx* ctx) {
 
 lh_status lh_ctx_sync(lh_ctx* ctx) {
   LH_TRY
-  NEED(ctx);
+  NEED_CTX(ctx);
   ctx->c.sync();
   LH_CATCH
 }
@@ -86,22 +110,21 @@ void* lh_ctx_stream(lh_ctx* ctx) { return ctx ? (void*)ctx->c.stream : nullptr; 
 
 lh_status lh_alloc(lh_ctx* ctx, size_t bytes, void** d_out) {
   LH_TRY
-  NEED(ctx);
+  NEED_CTX(ctx);
   NEED(d_out);
-  LH_HIP(hipSetDevice(ctx->c.device));
   LH_HIP(hipMalloc(d_out, bytes ? bytes : 1));
   LH_CATCH
 }
 lh_status lh_free(lh_ctx* ctx, void* d_ptr) {
   LH_TRY
-  NEED(ctx);
+  NEED_CTX(ctx);
   ctx->c.sync();
   if (d_ptr) LH_HIP(hipFree(d_ptr));
   LH_CATCH
 }
 lh_status lh_upload(lh_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
   LH_TRY
-  NEED(ctx);
+  NEED_CTX(ctx);
   if (bytes) {
     LH_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->c.stream));
     ctx->c.sync();
@@ -110,7 +133,7 @@ lh_status lh_upload(lh_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
 }
 lh_status lh_download(lh_ctx* ctx, void* dst, const void* d_src, size_t bytes) {
   LH_TRY
-  NEED(ctx);
+  NEED_CTX(ctx);
   if (bytes) {
     LH_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->c.stream));
     ctx->c.sync();
@@ -159,47 +182,47 @@ lh_status lh_keccak_transcript_remaining(lh_transcript* t, size_t* out) {
 
 // ---------------------------------------------------------------- Fr vectors
 lh_status lh_fr_from_u64(lh_ctx* ctx, const uint64_t* d_in, size_t n, lh_fr* d_out) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   k_fr_from_u64(ctx->c, d_in, n, (Fr*)d_out);
   LH_CATCH
 }
 lh_status lh_fr_from_u32(lh_ctx* ctx, const uint32_t* d_in, size_t n, lh_fr* d_out) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   k_fr_from_u32(ctx->c, d_in, n, (Fr*)d_out);
   LH_CATCH
 }
 lh_status lh_fr_to_repr(lh_ctx* ctx, const lh_fr* d_in, size_t n, uint8_t* d_out32) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   k_fr_to_repr(ctx->c, (const Fr*)d_in, n, (Fr*)d_out32);
   LH_CATCH
 }
 lh_status lh_fr_from_repr(lh_ctx* ctx, const uint8_t* d_in32, size_t n, lh_fr* d_out) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   k_fr_from_repr(ctx->c, (const Fr*)d_in32, n, (Fr*)d_out);
   LH_CATCH
 }
 lh_status lh_fr_add(lh_ctx* ctx, const lh_fr* a, const lh_fr* b, size_t n, lh_fr* out) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   k_fr_binop(ctx->c, 0, (const Fr*)a, (const Fr*)b, n, (Fr*)out);
   LH_CATCH
 }
 lh_status lh_fr_sub(lh_ctx* ctx, const lh_fr* a, const lh_fr* b, size_t n, lh_fr* out) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   k_fr_binop(ctx->c, 1, (const Fr*)a, (const Fr*)b, n, (Fr*)out);
   LH_CATCH
 }
 lh_status lh_fr_mul(lh_ctx* ctx, const lh_fr* a, const lh_fr* b, size_t n, lh_fr* out) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   k_fr_binop(ctx->c, 2, (const Fr*)a, (const Fr*)b, n, (Fr*)out);
   LH_CATCH
 }
 lh_status lh_fr_mul_chain(lh_ctx* ctx, const lh_fr* a, const lh_fr* b, size_t n, int iters, lh_fr* out) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   k_fr_mul_chain(ctx->c, (const Fr*)a, (const Fr*)b, n, iters, (Fr*)out);
   LH_CATCH
 }
 lh_status lh_fr_batch_invert(lh_ctx* ctx, const lh_fr* d_in, size_t n, lh_fr* d_out) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   k_fr_batch_invert(ctx->c, (const Fr*)d_in, n, (Fr*)d_out);
   LH_CATCH
 }
@@ -208,7 +231,7 @@ lh_status lh_fr_batch_invert(lh_ctx* ctx, const lh_fr* d_in, size_t n, lh_fr* d_
 static bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
 
 lh_status lh_fix_var(lh_ctx* ctx, const lh_fr* d_in, size_t n_in, const lh_fr* x, lh_fr* d_out) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   NEED(x);
   LH_REQUIRE(is_pow2(n_in) && n_in >= 2, LH_ERR_ARG, "fix_var: table must have 2^m >= 2 entries");
   Fr xr;
@@ -217,21 +240,21 @@ lh_status lh_fix_var(lh_ctx* ctx, const lh_fr* d_in, size_t n_in, const lh_fr* x
   LH_CATCH
 }
 lh_status lh_eq_xy(lh_ctx* ctx, const lh_fr* y, size_t num_vars, lh_fr* d_out) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   LH_REQUIRE(num_vars < 32, LH_ERR_ARG, "eq_xy: num_vars too large");
   k_eq_xy(ctx->c, (const Fr*)y, num_vars, (Fr*)d_out);
   LH_CATCH
 }
 lh_status lh_evaluate(lh_ctx* ctx, const lh_fr* const* d_polys, size_t num_polys, size_t num_vars,
                       const lh_fr* point, lh_fr* out_evals) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   std::vector<HFr> ev = evaluate_polys(ctx->c, (const Fr* const*)d_polys, num_polys, num_vars, (const HFr*)point);
   memcpy(out_evals, ev.data(), num_polys * 32);
   LH_CATCH
 }
 lh_status lh_lincomb(lh_ctx* ctx, const lh_fr* const* d_polys, const lh_fr* w, size_t num_polys, size_t n,
                      lh_fr* d_out) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   k_lincomb(ctx->c, (const Fr* const*)d_polys, (const Fr*)w, num_polys, n, (Fr*)d_out);
   LH_CATCH
 }
@@ -240,7 +263,7 @@ lh_status lh_lincomb(lh_ctx* ctx, const lh_fr* const* d_polys, const lh_fr* w, s
 lh_status lh_sumcheck_prove(lh_ctx* ctx, int prover_kind, size_t num_vars, const lh_sop* expr,
                             const lh_fr* const* d_polys, size_t num_polys, const lh_fr* ys, size_t num_ys,
                             const lh_fr* sum, lh_transcript* t, lh_fr* out_challenges, lh_fr* out_evals) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   NEED(expr);
   NEED(sum);
   LH_REQUIRE(prover_kind == LH_SC_EVALUATIONS || prover_kind == LH_SC_COEFFICIENTS, LH_ERR_ARG, "bad prover kind");
@@ -258,7 +281,7 @@ lh_status lh_sumcheck_prove_expr(lh_ctx* ctx, size_t num_vars, const lh_expr* ex
                                  size_t num_polys, const lh_fr* challenges, size_t num_challenges, const lh_fr* ys,
                                  size_t num_ys, const lh_fr* sum, lh_transcript* t, lh_fr* out_challenges,
                                  lh_fr* out_evals) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   NEED(expr);
   NEED(sum);
   Transcript tr(t);
@@ -275,7 +298,7 @@ lh_status lh_gkr_fractional_prove(lh_ctx* ctx, size_t num_batching, size_t num_v
                                   const lh_fr* const* claimed_p_0s, const lh_fr* const* claimed_q_0s,
                                   const lh_fr* const* d_ps, const lh_fr* const* d_qs, lh_transcript* t,
                                   lh_fr* out_p_xs, lh_fr* out_q_xs, lh_fr* out_x) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   Transcript tr(t);
   FracSumCheckResult r =
       prove_fractional_sum_check(ctx->c, num_batching, num_vars, (const HFr* const*)claimed_p_0s,
@@ -288,7 +311,7 @@ lh_status lh_gkr_fractional_prove(lh_ctx* ctx, size_t num_batching, size_t num_v
 
 lh_status lh_grand_product_prove(lh_ctx* ctx, size_t num_trees, const lh_fr* const* d_leaves, const size_t* num_vars,
                                  lh_transcript* t, lh_fr* out_roots, lh_fr* out_claims, lh_fr* out_points) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   NEED(num_vars);
   Transcript tr(t);
   GrandProductResult r = prove_grand_product(ctx->c, num_trees, (const Fr* const*)d_leaves, num_vars, tr);
@@ -306,14 +329,14 @@ lh_status lh_grand_product_prove(lh_ctx* ctx, size_t num_trees, const lh_fr* con
 
 // ---------------------------------------------------------------- MSM
 lh_status lh_msm(lh_ctx* ctx, const lh_fr* d_scalars, const lh_g1* d_bases, size_t n, lh_g1* out) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   NEED(out);
   MsmJob job{d_scalars, false, (const G1Affine*)d_bases, n};
   msm_batch(ctx->c, &job, 1, (G1Affine*)out);
   LH_CATCH
 }
 lh_status lh_msm_u32(lh_ctx* ctx, const uint32_t* d_scalars, const lh_g1* d_bases, size_t n, lh_g1* out) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   NEED(out);
   MsmJob job{d_scalars, true, (const G1Affine*)d_bases, n};
   msm_batch(ctx->c, &job, 1, (G1Affine*)out);
@@ -322,7 +345,7 @@ lh_status lh_msm_u32(lh_ctx* ctx, const uint32_t* d_scalars, const lh_g1* d_base
 
 // ---------------------------------------------------------------- multilinear KZG
 lh_status lh_mkzg_setup(lh_ctx* ctx, const lh_fr* ss, size_t num_vars, lh_srs** out) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   NEED(out);
   Srs* s = mkzg_setup(ctx->c, (const HFr*)ss, num_vars);
   lh_srs* w = new lh_srs();
@@ -332,7 +355,7 @@ lh_status lh_mkzg_setup(lh_ctx* ctx, const lh_fr* ss, size_t num_vars, lh_srs** 
   LH_CATCH
 }
 lh_status lh_srs_upload(lh_ctx* ctx, const lh_g1* eqs_flat, size_t num_vars, lh_srs** out) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   NEED(out);
   LH_REQUIRE(num_vars < 31, LH_ERR_ARG, "srs: num_vars too large");
   lh_srs* w = new lh_srs();
@@ -345,7 +368,7 @@ lh_status lh_srs_upload(lh_ctx* ctx, const lh_g1* eqs_flat, size_t num_vars, lh_
   LH_CATCH
 }
 lh_status lh_srs_download(lh_ctx* ctx, const lh_srs* srs, lh_g1* eqs_flat) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   NEED(srs);
   size_t total = ((size_t)2 << srs->s.num_vars) - 1;
   LH_HIP(hipMemcpyAsync(eqs_flat, srs->s.d_eqs, total * sizeof(G1Affine), hipMemcpyDeviceToHost, ctx->c.stream));
@@ -363,7 +386,7 @@ void lh_srs_free(lh_ctx* ctx, lh_srs* srs) {
 }
 
 lh_status lh_mkzg_commit(lh_ctx* ctx, const lh_srs* srs, const lh_fr* d_poly, size_t num_vars, lh_g1* out) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   NEED(srs);
   const Fr* p = (const Fr*)d_poly;
   std::vector<HG1> c = mkzg_batch_commit(ctx->c, srs->s, &p, 1, num_vars);
@@ -372,7 +395,7 @@ lh_status lh_mkzg_commit(lh_ctx* ctx, const lh_srs* srs, const lh_fr* d_poly, si
 }
 lh_status lh_mkzg_batch_commit(lh_ctx* ctx, const lh_srs* srs, const lh_fr* const* d_polys, size_t num_polys,
                                size_t num_vars, lh_g1* out_comms) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   NEED(srs);
   std::vector<HG1> c = mkzg_batch_commit(ctx->c, srs->s, (const Fr* const*)d_polys, num_polys, num_vars);
   memcpy(out_comms, c.data(), num_polys * 64);
@@ -380,7 +403,7 @@ lh_status lh_mkzg_batch_commit(lh_ctx* ctx, const lh_srs* srs, const lh_fr* cons
 }
 lh_status lh_mkzg_open(lh_ctx* ctx, const lh_srs* srs, const lh_fr* d_poly, size_t num_vars, const lh_fr* point,
                        lh_transcript* t, lh_fr* out_eval) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   NEED(srs);
   Transcript tr(t);
   HFr e = mkzg_open(ctx->c, srs->s, (const Fr*)d_poly, num_vars, (const HFr*)point, tr);
@@ -390,7 +413,7 @@ lh_status lh_mkzg_open(lh_ctx* ctx, const lh_srs* srs, const lh_fr* d_poly, size
 lh_status lh_mkzg_batch_open(lh_ctx* ctx, const lh_srs* srs, size_t num_vars, const lh_fr* const* d_polys,
                              size_t num_polys, const lh_fr* points, size_t num_points, const lh_evaluation* evals,
                              size_t num_evals, lh_transcript* t) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   NEED(srs);
   Transcript tr(t);
   mkzg_batch_open(ctx->c, srs->s, num_vars, (const Fr* const*)d_polys, num_polys, (const HFr*)points, num_points,
@@ -401,7 +424,7 @@ lh_status lh_mkzg_batch_open(lh_ctx* ctx, const lh_srs* srs, size_t num_vars, co
 // ---------------------------------------------------------------- Lasso
 lh_status lh_lasso_prove(lh_ctx* ctx, const lh_srs* srs, const lh_lasso_table* table, size_t num_vars,
                          const uint32_t* const* d_dims, lh_transcript* t) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   NEED(srs);
   NEED(table);
   NEED(d_dims);
@@ -410,14 +433,14 @@ lh_status lh_lasso_prove(lh_ctx* ctx, const lh_srs* srs, const lh_lasso_table* t
   LH_CATCH
 }
 lh_status lh_lasso_last_timing(lh_ctx* ctx, double* out_ms) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   NEED(out_ms);
   memcpy(out_ms, ctx->c.lasso_ms, sizeof(ctx->c.lasso_ms));
   LH_CATCH
 }
 
 lh_status lh_ctx_set_comm(lh_ctx* ctx, const lh_comm* comm, size_t shard_bit) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   ctx->c.sync();
   if (!comm) {
     ctx->c.has_comm = false;
@@ -434,7 +457,7 @@ lh_status lh_ctx_set_comm(lh_ctx* ctx, const lh_comm* comm, size_t shard_bit) {
 }
 lh_status lh_lasso_prove_sharded(lh_ctx* ctx, const lh_srs* srs, const lh_lasso_table* table, size_t num_vars,
                                  const uint32_t* const* d_dims, lh_transcript* t) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   NEED(srs);
   NEED(table);
   NEED(d_dims);
@@ -445,7 +468,7 @@ lh_status lh_lasso_prove_sharded(lh_ctx* ctx, const lh_srs* srs, const lh_lasso_
 
 lh_status lh_hyperplonk_prove(lh_ctx* ctx, const lh_srs* srs, const lh_hp_param* pp, const lh_fr* const* instances,
                               const lh_fr* const* d_witness_polys, lh_transcript* t) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   NEED(srs);
   NEED(pp);
   Transcript tr(t);
@@ -555,7 +578,7 @@ lh_status lh_hyperplonk_verify(const lh_mkzg_vp* vp, const lh_hp_vparam* hvp, co
 
 // ---------------------------------------------------------------- Zeromorph over univariate KZG
 lh_status lh_ukzg_setup(lh_ctx* ctx, const lh_fr* s, size_t poly_size, lh_usrs** out) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   NEED(s);
   NEED(out);
   HFr sv;
@@ -566,7 +589,7 @@ lh_status lh_ukzg_setup(lh_ctx* ctx, const lh_fr* s, size_t poly_size, lh_usrs**
   LH_CATCH
 }
 lh_status lh_usrs_upload(lh_ctx* ctx, const lh_g1* powers, size_t poly_size, lh_usrs** out) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   NEED(powers);
   NEED(out);
   LH_REQUIRE(poly_size >= 1 && poly_size < ((size_t)1 << 31), LH_ERR_ARG, "univariate srs: bad poly_size");
@@ -579,7 +602,7 @@ lh_status lh_usrs_upload(lh_ctx* ctx, const lh_g1* powers, size_t poly_size, lh_
   LH_CATCH
 }
 lh_status lh_usrs_download(lh_ctx* ctx, const lh_usrs* srs, lh_g1* powers) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   NEED(srs);
   NEED(powers);
   LH_HIP(hipMemcpyAsync(powers, srs->s.d_powers, srs->s.size * sizeof(G1Affine), hipMemcpyDeviceToHost, ctx->c.stream));
@@ -595,7 +618,7 @@ void lh_usrs_free(lh_ctx* ctx, lh_usrs* srs) {
 }
 lh_status lh_zeromorph_batch_commit(lh_ctx* ctx, const lh_usrs* srs, size_t poly_size, const lh_fr* const* d_polys,
                                     size_t num_polys, size_t num_vars, lh_g1* out_comms) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   NEED(srs);
   LH_REQUIRE((d_polys && out_comms) || !num_polys, LH_ERR_ARG, "null argument: polys");
   std::vector<HG1> c = zeromorph_batch_commit(ctx->c, srs->s, poly_size, (const Fr* const*)d_polys, num_polys, num_vars);
@@ -604,7 +627,7 @@ lh_status lh_zeromorph_batch_commit(lh_ctx* ctx, const lh_usrs* srs, size_t poly
 }
 lh_status lh_zeromorph_open(lh_ctx* ctx, const lh_usrs* srs, size_t poly_size, const lh_fr* d_poly, size_t num_vars,
                             const lh_fr* point, lh_transcript* t) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   NEED(srs);
   NEED(d_poly);
   NEED(point);
@@ -615,7 +638,7 @@ lh_status lh_zeromorph_open(lh_ctx* ctx, const lh_usrs* srs, size_t poly_size, c
 lh_status lh_zeromorph_batch_open(lh_ctx* ctx, const lh_usrs* srs, size_t poly_size, size_t num_vars,
                                   const lh_fr* const* d_polys, size_t num_polys, const lh_fr* points,
                                   size_t num_points, const lh_evaluation* evals, size_t num_evals, lh_transcript* t) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   NEED(srs);
   NEED(d_polys);
   NEED(points);
@@ -687,7 +710,7 @@ lh_status lh_zeromorph_batch_verify(const lh_zm_vp* vp, size_t num_vars, const l
 
 lh_status lh_lasso_prove_zeromorph(lh_ctx* ctx, const lh_usrs* srs, size_t poly_size, const lh_lasso_table* table,
                                    size_t num_vars, const uint32_t* const* d_dims, lh_transcript* t) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   NEED(srs);
   NEED(table);
   NEED(d_dims);
@@ -709,7 +732,7 @@ lh_status lh_lasso_verify_zeromorph(const lh_zm_vp* vp, const lh_lasso_table* ta
 lh_status lh_hyperplonk_prove_zeromorph(lh_ctx* ctx, const lh_usrs* srs, size_t poly_size, const lh_hp_param* pp,
                                         const lh_fr* const* instances, const lh_fr* const* d_witness_polys,
                                         lh_transcript* t) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   NEED(srs);
   NEED(pp);
   Transcript tr(t);
@@ -731,14 +754,14 @@ lh_status lh_hyperplonk_verify_zeromorph(const lh_zm_vp* vp, const lh_hp_vparam*
 }
 
 lh_status lh_profile_enable(lh_ctx* ctx, int on) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   ctx->c.sync();
   ctx->c.prof = on != 0;
   ctx->c.prof_recs.clear();
   LH_CATCH
 }
 lh_status lh_profile_read(lh_ctx* ctx, lh_prof_rec* out, size_t cap, size_t* count) {
-  LH_TRY NEED(ctx);
+  LH_TRY NEED_CTX(ctx);
   NEED(count);
   static_assert(sizeof(lh_prof_rec) == sizeof(lh::ProfRec), "profile record layout");
   size_t n = ctx->c.prof_recs.size();

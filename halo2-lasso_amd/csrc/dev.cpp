@@ -5,6 +5,7 @@
 #include <mutex>
 #include <thread>
 #include <functional>
+#include <memory>
 #include "dev.hpp"
 
 namespace lh {
@@ -113,58 +114,61 @@ void Ctx::d2h(void* dst, const void* d_src, size_t bytes) {
 }
 
 // ------------------------------------------------------------------ host worker pool
+// Every parallel_for publishes ONE immutable job object (function, item count, its own claim and completion
+// counters).  A worker copies the shared_ptr under the mutex and claims indices only from that job's counter, so a
+// worker that wakes late works on its own (already finished) job and can never draw an index of the next generation.
 namespace {
+struct HostJob {
+  std::function<void(size_t)> fn;
+  size_t n = 0;
+  std::atomic<size_t> next{0}, done{0};
+  void run() {
+    size_t i;
+    while ((i = next.fetch_add(1, std::memory_order_relaxed)) < n) {
+      fn(i);
+      done.fetch_add(1, std::memory_order_release);
+    }
+  }
+};
 struct HostPool {
   std::mutex mu;
   std::condition_variable cv;
   uint64_t gen = 0;
-  const std::function<void(size_t)>* fn = nullptr;
-  size_t n = 0;
-  std::atomic<size_t> next{0}, pending{0};
-  std::atomic<int> active{0};  // workers inside run()
+  std::shared_ptr<HostJob> job;
   HostPool() {
     unsigned hw = std::thread::hardware_concurrency();
     unsigned workers = hw > 1 ? std::min(15u, hw - 1) : 0;
     for (unsigned i = 0; i < workers; i++) std::thread([this] { worker(); }).detach();
   }
-  void run() {
-    size_t i;
-    while ((i = next.fetch_add(1, std::memory_order_relaxed)) < n) {
-      (*fn)(i);
-      pending.fetch_sub(1, std::memory_order_release);
-    }
-  }
   void worker() {
     uint64_t seen = 0;
     for (;;) {
+      std::shared_ptr<HostJob> mine;
       {
         std::unique_lock<std::mutex> lk(mu);
         cv.wait(lk, [&] { return gen != seen; });
         seen = gen;
-        active.fetch_add(1, std::memory_order_acq_rel);
+        mine = job;
       }
-      run();
-      active.fetch_sub(1, std::memory_order_acq_rel);
+      if (mine) mine->run();
     }
   }
   void parallel_for(size_t count, const std::function<void(size_t)>& f) {
+    auto j = std::make_shared<HostJob>();
+    j->fn = f;  // a copy: the job outlives the caller's frame for workers that wake late
+    j->n = count;
     {
       std::lock_guard<std::mutex> lk(mu);
-      fn = &f;
-      n = count;
-      next.store(0, std::memory_order_relaxed);
-      pending.store(count, std::memory_order_release);
+      job = j;
       gen++;
     }
     cv.notify_all();
-    run();
-    while (pending.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
-    // no worker may still be looking at `fn` / `n` of this generation when the caller's frame goes away
+    j->run();
+    while (j->done.load(std::memory_order_acquire) != count) __builtin_ia32_pause();
     {
       std::lock_guard<std::mutex> lk(mu);
-      n = 0;
+      if (job == j) job.reset();
     }
-    while (active.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
   }
 };
 }  // namespace
@@ -175,8 +179,6 @@ void host_parallel_for(size_t n, const std::function<void(size_t)>& fn) {
     return;
   }
   static HostPool* pool = new HostPool();  // never destroyed: workers sleep on the condition variable
-  static std::mutex one_at_a_time;
-  std::lock_guard<std::mutex> lk(one_at_a_time);
   pool->parallel_for(n, fn);
 }
 

@@ -99,6 +99,7 @@ struct Ctx {
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
   int num_cus = 256;
+  int wall_clock_khz = 100000;  // rate of wall_clock64() on the device
   double lasso_ms[LH_LASSO_NUM_PHASES] = {0};
   // one proof over several GPUs: host-side communicator + position of the shard bits
   lh_comm comm = {0, 1, nullptr, nullptr};
@@ -283,7 +284,7 @@ struct ProgRound {
 // runtime-compiled form of a program (jit.cpp); nullptr = not compiled (disabled, too small, or compilation failed)
 struct JitKernel;
 bool jit_enabled(size_t num_vars);
-const JitKernel* jit_sc_round(const uint32_t* host_code, size_t num_instrs, uint32_t num_regs, uint32_t result_reg, int degree);
+const JitKernel* jit_sc_round(const Ctx&, const uint32_t* host_code, size_t num_instrs, uint32_t num_regs, uint32_t result_reg, int degree);
 unsigned jit_blocks_per_cu(const JitKernel*);
 void jit_launch(Ctx&, const JitKernel*, const ProgRound& pr, unsigned grid, size_t size, Fr* partials, const ScFinishArgs& fin);
 // evals_host[0..degree) = sum over pairs of program(tables at X), X = 1..degree; `jit`: run the compiled form

@@ -412,7 +412,7 @@ SumCheckResult sum_check_prove_expr(Ctx& c, size_t num_vars, const lh_expr& expr
       pr.code = d_code, pr.consts = d_consts;
       // large sum-checks run the program as compiled straight-line code (jit.cpp), the rest interpret it
       const JitKernel* jit =
-          jit_enabled(num_vars) ? jit_sc_round(prog.code.data(), pr.num_instrs, pr.num_regs, pr.result_reg, ex.degree) : nullptr;
+          jit_enabled(num_vars) ? jit_sc_round(c, prog.code.data(), pr.num_instrs, pr.num_regs, pr.result_reg, ex.degree) : nullptr;
       auto prog_round = [&](const Fr* const* in, Fr* const* out, const Fr& r, bool bind, size_t size, Fr* evals_host) {
         if (bind) {
           std::vector<const Fr*> src;

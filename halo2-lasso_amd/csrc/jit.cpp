@@ -14,6 +14,7 @@
 #include <mutex>
 #include <sstream>
 #include <string>
+#include <vector>
 #include "dev.hpp"
 #include "jit_sources.inc"  // JIT_FF_CUH, JIT_REDUCE_CUH: the text of ff.cuh / reduce.cuh (Makefile)
 
@@ -131,14 +132,10 @@ std::string generate(const uint32_t* code, size_t num_instrs, uint32_t num_regs,
   return s.str();
 }
 
-uint64_t fnv(const void* p, size_t n, uint64_t h) {
-  const unsigned char* b = (const unsigned char*)p;
-  for (size_t i = 0; i < n; i++) h = (h ^ b[i]) * 0x100000001b3ull;
-  return h;
-}
 
 std::mutex g_mu;
-std::map<uint64_t, JitKernel*> g_cache;  // never freed: modules live as long as the process
+// keyed on the whole program (device, register count, result register, degree, code words): no hash that could collide
+std::map<std::vector<uint32_t>, JitKernel*> g_cache;  // never freed: modules live as long as the process
 }  // namespace
 
 bool jit_enabled(size_t num_vars) {
@@ -153,18 +150,16 @@ bool jit_enabled(size_t num_vars) {
   return on && num_vars >= min_vars;
 }
 
-const JitKernel* jit_sc_round(const uint32_t* code, size_t num_instrs, uint32_t num_regs, uint32_t result_reg, int degree) {
-  uint64_t h = fnv(code, num_instrs * 8, 0xcbf29ce484222325ull);
-  const uint32_t meta[3] = {num_regs, result_reg, (uint32_t)degree};
-  h = fnv(meta, sizeof meta, h);
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  h = fnv(&dev, sizeof dev, h);  // a module belongs to the device it was loaded on
+const JitKernel* jit_sc_round(const Ctx& c, const uint32_t* code, size_t num_instrs, uint32_t num_regs, uint32_t result_reg,
+                              int degree) {
+  // a module belongs to the device it was loaded on: the ctx's (made current by the C-ABI entry point)
+  std::vector<uint32_t> key{(uint32_t)c.device, num_regs, result_reg, (uint32_t)degree};
+  key.insert(key.end(), code, code + 2 * num_instrs);
   std::lock_guard<std::mutex> lk(g_mu);
-  auto it = g_cache.find(h);
+  auto it = g_cache.find(key);
   if (it != g_cache.end()) return it->second->failed ? nullptr : it->second;
   JitKernel* k = new JitKernel();
-  g_cache[h] = k;
+  g_cache[key] = k;
   k->failed = true;
   const auto t0 = std::chrono::steady_clock::now();
   const std::string src = generate(code, num_instrs, num_regs, result_reg, degree);

@@ -299,11 +299,11 @@ struct ScTailArgs {
   Fr* msg_host;
   Fr* out_host;
   const TailMbox* mbox;
+  uint64_t poll_ticks;  // wall_clock64 ticks the kernel waits for one challenge before it leaves
 };
 constexpr uint32_t TAIL_LDS_BYTES = 144 * 1024;      // of the CU's 160 KB (opt-in: hipFuncAttributeMaxDynamicSharedMemorySize)
 constexpr uint32_t TAIL_THREADS = 512;
 constexpr uint32_t TAIL_MAX_ITEMS = 2048;            // (term, X, pair) items of the first resident round: ~2 us per 512 on one CU
-constexpr uint64_t TAIL_POLL_TICKS = 200000000ull;    // 2 s at 100 MHz
 
 __device__ __forceinline__ Fr shfl_xor_fr(const Fr& v, int mask) {
   Fr o;
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void sc_tail_kernel(ScTailArgs a) {
       for (;;) {
         const uint32_t s = __hip_atomic_load(&a.mbox->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (s == want) break;
-        if (s == SC_TAIL_ABORT || wall_clock64() - t0 > TAIL_POLL_TICKS) {
+        if (s == SC_TAIL_ABORT || wall_clock64() - t0 > a.poll_ticks) {
           stop_sh = 1;
           break;
         }
@@ -470,6 +470,11 @@ void k_sc_tail_launch(Ctx& c, const ScRound& rd, int degree, size_t n0, bool fir
   a.msg_host = msg_host;
   a.out_host = out_host;
   a.mbox = c.mbox();
+  // bounded wait per challenge: LH_SC_TAIL_TIMEOUT_MS (default 2000) in ticks of the device's constant-rate counter
+  // (hipDeviceAttributeWallClockRate, 100 MHz on gfx950).  When it expires the host resumes with launched rounds.
+  const char* tmo = getenv("LH_SC_TAIL_TIMEOUT_MS");
+  const double ms = tmo && *tmo ? atof(tmo) : 2000.0;
+  a.poll_ticks = (uint64_t)(ms * (double)c.wall_clock_khz);
   __atomic_store_n(&c.mbox()->seq, 0u, __ATOMIC_RELEASE);
   const size_t lds = ((size_t)a.red_off + tail_red_entries(rd, degree, n0)) * sizeof(Fr);
   static const hipError_t opt_in =

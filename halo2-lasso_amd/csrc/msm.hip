@@ -589,8 +589,9 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
         c.d2h(&h_total, total, 4);
       }
       {
-        // MSM algorithmic bytes: 96 B per point (32 B scalar + 64 B base); a mixed add is 10 Fq muls
-        ProfScope ps(c, "msm_accumulate0", 72.0 * h_total, 10.0 * h_total, (double)h_total);
+        // MSM algorithmic bytes: 96 B per point (32 B scalar + 64 B base), 68 B for a u32 column,
+        // whatever the number of windows; `items` = sorted (point, window) entries, a mixed add is 10 Fq muls
+        ProfScope ps(c, "msm_accumulate0", 96.0 * full_pts + 68.0 * (total_pts - full_pts), 10.0 * h_total, (double)h_total);
       hipLaunchKernelGGL(msm_accumulate0_kernel, dim3((unsigned)std::min<size_t>((nchunks + 127) / 128, 1 << 16)),
                          dim3(128), 0, c.stream, plan, total, skey, sidx, K, buckets, ckey, cpt, nchunks, lvl_cnt);
       }

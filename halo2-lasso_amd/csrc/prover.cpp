@@ -231,6 +231,7 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
     res.challenges.push_back(r);
     return r;
   };
+  bool tail_ok = true;  // cleared when a resident tail ended early: the remaining rounds are launched one by one
   for (size_t round = 0; round < num_vars; round++) {
     bool bind = round > 0;
     if (sh && round == j) {
@@ -250,7 +251,7 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
       sh = false;
       bind = false;
     }
-    if (!sh && tail_cap && (bind ? len >> 1 : len) <= tail_cap) {
+    if (!sh && tail_ok && tail_cap && (bind ? len >> 1 : len) <= tail_cap) {
       // the rest of the sum-check runs resident on one CU (dev.hpp: k_sc_tail_*): same messages, same order
       const size_t n0 = bind ? len >> 1 : len, rounds = num_vars - round;
       LH_REQUIRE(((size_t)1 << rounds) == n0 && num_polys <= T, LH_ERR_ARG, "sum-check: internal size mismatch");
@@ -273,31 +274,60 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
       } guard{c};
       k_sc_tail_launch(c, rd, degree, n0, bind, num_polys, seq0, evals_host, evals_host + 16);
       double host_us = 0;
+      size_t absorbed = 0;  // tail rounds whose message is in the transcript and whose challenge is known
+      bool gave_up = false;
+      // The kernel waits a bounded time for each challenge (LH_SC_TAIL_TIMEOUT_MS, default 2 s): a host thread stalled
+      // past that (debugger, SIGSTOP, a slow transcript callback) finds the kernel gone.  The entry tables are untouched
+      // and the challenges squeezed so far are known, so the sum-check is resumed on the per-round path.
       auto wait = [&](uint32_t seq) {
         try {
           c.wait_flag(seq);
+          return true;
         } catch (const Error& e) {
-          if (e.code != LH_ERR_DEVICE) throw;
-          throw Error(LH_ERR_DEVICE, std::string("resident sum-check rounds ended early (the kernel waits at most 2 s for each "
-                                                 "challenge; LH_SC_TAIL=0 launches every round instead): ") + e.what());
+          if (e.code != LH_ERR_DEVICE || hipStreamQuery(c.stream) != hipSuccess) throw;
+          return false;
         }
       };
-      for (size_t i = 0; i < rounds; i++) {
-        wait(seq0 + (uint32_t)i);
+      for (size_t i = 0; i < rounds && !gave_up; i++) {
+        if (!wait(seq0 + (uint32_t)i)) {
+          gave_up = true;
+          break;
+        }
         const auto t_h = std::chrono::steady_clock::now();
         const HFr r = message(evals_host);
         c.mbox_send(dev(r), seq0 + (uint32_t)i);
+        absorbed = i + 1;
         if (tail_debug) host_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_h).count();
       }
-      wait(seq0 + (uint32_t)rounds);
+      if (!gave_up && !wait(seq0 + (uint32_t)rounds)) gave_up = true;
       guard.done = true;
-      if (tail_debug)
-        fprintf(stderr, "[sc_tail] T %zu terms %u degree %d n0 %zu rounds %zu: %.1f us (host side %.1f us)\n", T,
-                tail_rd->num_terms, degree, n0, rounds,
-                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_tail).count(), host_us);
-      res.evals.resize(num_polys);
-      memcpy(res.evals.data(), evals_host + 16, num_polys * sizeof(Fr));
-      return res;
+      if (!gave_up) {
+        if (tail_debug)
+          fprintf(stderr, "[sc_tail] T %zu terms %u degree %d n0 %zu rounds %zu: %.1f us (host side %.1f us)\n", T,
+                  tail_rd->num_terms, degree, n0, rounds,
+                  std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_tail).count(), host_us);
+        res.evals.resize(num_polys);
+        memcpy(res.evals.data(), evals_host + 16, num_polys * sizeof(Fr));
+        return res;
+      }
+      // resume: replay the binds of the `absorbed` rounds with their known challenges (no evaluation, no transcript
+      // traffic), then go on with launched rounds from round + absorbed
+      if (tail_debug) fprintf(stderr, "[sc_tail] ended early after %zu of %zu rounds: resuming with launched rounds\n", absorbed, rounds);
+      tail_ok = false;
+      const size_t first_ch = res.challenges.size() - absorbed;
+      for (size_t i = 0; i < absorbed; i++) {
+        if (bind) {
+          std::vector<Fr*>& dst = flip ? bufB : bufA;
+          k_fix_var_multi(c, cur.data(), dst.data(), T, len, dev(r_prev));
+          for (size_t t = 0; t < T; t++) cur[t] = dst[t];
+          len >>= 1;
+          flip ^= 1;
+        }
+        r_prev = res.challenges[first_ch + i];
+        bind = true;
+      }
+      round += absorbed;
+      if (round == num_vars) break;  // every message was absorbed: only the final bind is left
     }
     const size_t size = bind ? len >> 2 : len >> 1;
     std::vector<Fr*>& dst = flip ? bufB : bufA;

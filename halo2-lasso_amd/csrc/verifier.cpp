@@ -541,6 +541,9 @@ void lasso_verify(const PcsBatchVerify& batch_verify, const lh_lasso_table& tb, 
   LH_REQUIRE(n >= 1 && l >= 1 && n < 32 && l < 32, LH_ERR_ARG, "lasso: need at least one variable");
   for (size_t i = 0; i < alpha; i++)
     LH_REQUIRE(tb.memory_chunk[i] < c && tb.memory_subtable[i] <= LH_SUBTABLE_XOR, LH_ERR_ARG, "lasso: bad memory");
+  LH_REQUIRE(tb.num_terms >= 1, LH_ERR_ARG, "lasso: bad g term count");
+  for (size_t m = 0; m < tb.num_terms; m++)
+    LH_REQUIRE(tb.g_num_factors[m] >= 1 && tb.g_num_factors[m] <= LH_SC_MAX_FACTORS, LH_ERR_ARG, "lasso: bad g term");
   for (size_t v : {n, l, c, alpha}) tr.common_field_element(HFr::from_u64(v));
   const size_t nv = std::max(n, l);
   std::vector<HG1> comms = tr.read_commitments(1 + 3 * c + alpha);

@@ -317,6 +317,46 @@ def test_sum_check_transcript_failure_mid_tail(hl, ctx):
     assert (x, ev) == (ox, oev) and t.into_proof() == ot.into_proof()
 
 
+def test_sum_check_resumes_after_tail_timeout(hl, ctx, monkeypatch):
+    """A host that stalls longer than the resident tail waits for a challenge (LH_SC_TAIL_TIMEOUT_MS) finds the
+    kernel gone; the prover resumes on the per-round path from the challenges it already has: same bytes."""
+    import ctypes as C
+    from halo2_lasso_amd import _ffi
+    num_vars = 9
+    rng = random.Random(78)
+    tables = [rand_fr(rng, 1 << num_vars) for _ in range(3)]
+    y = rand_fr(rng, num_vars)
+    polys = [hl.MultilinearPolynomial.new(ctx, t) for t in tables]
+    sop = hl.SumOfProducts([(5, [0, 1]), (7, [2])], global_eq=0)
+    eq = eq_xy(y)
+    claim = sum(e * (5 * a * b + 7 * c_) for e, a, b, c_ in zip(eq, *tables)) % P
+    expr = ex.EqXY(0) * (ex.Poly(0) * ex.Poly(1) * 5 + ex.Poly(2) * 7)
+    ot = OT()
+    ox, oev = o_sc.prove(o_sc.EvaluationsProver, num_vars, o_sc.VirtualPolynomial(expr, tables, [], [y]), claim, ot)
+    monkeypatch.setenv("LH_SC_TAIL_TIMEOUT_MS", "20")
+    for stall_at in (1, 3, num_vars):  # first tail round, a middle one, the last challenge
+        inner = hl.Keccak256Transcript()
+        vt = inner.p.contents
+        calls = {"n": 0}
+
+        def squeeze(user, out, calls=calls, vt=vt, stall_at=stall_at):
+            calls["n"] += 1
+            if calls["n"] == stall_at:
+                time.sleep(0.2)
+            return vt.squeeze_challenge(vt.user, out)
+
+        slow = _ffi.lh_transcript()
+        C.memmove(C.byref(slow), inner.p, C.sizeof(slow))
+        cb = _ffi._FE_CB(squeeze)
+        slow.squeeze_challenge = cb
+
+        class Wrapped:
+            p = C.pointer(slow)
+
+        x, ev = hl.ClassicSumCheck.prove(ctx, hl.EvaluationsProver, num_vars, sop, polys, [y], claim, Wrapped)
+        assert (x, ev) == (ox, oev) and inner.into_proof() == ot.into_proof(), stall_at
+
+
 def test_sum_check_rejects_bad_shapes(hl, ctx):
     poly = hl.MultilinearPolynomial.new(ctx, [1, 2])
     with pytest.raises(hl.ArgumentError):  # CoefficientsProver: degree != 2 is unimplemented!() (coeff.rs:143)
