@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-inflight", action="store_true",
                     help="skip the extra throughput figure (two independent proofs in flight on one GPU)")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="N>1: skip the extra objects (configs[3] 2^26 sharded, replicas)")
     ap.add_argument("--mode", default="sharded", choices=["replicas", "sharded"],
                     help="N>1: 'sharded' (default) = ONE proof of 2^log-n lookups split over the N GPUs (strong "
                          "scaling, SURVEY.md §8e, partial sums over RCCL); 'replicas' = one independent proof per GPU "
@@ -95,7 +97,7 @@ def aggregate(recs):
     return sorted(by.values(), key=lambda a: -a["ms"])
 
 
-def pmc_traffic(profile_name, log_n, table_kind):
+def pmc_traffic(profile_name, log_n, table_kind, world=1):
     """HBM bytes of the kernel's largest launch from the committed PMC passes (profiles/r01_pmc_*.json:
     rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for streaming reads).  Counters cannot be collected from inside this
@@ -353,29 +355,41 @@ def main():
     ctx = hl.Context(int(os.environ.get("LH_DEVICE", local_rank)))  # LH_DEVICE: several ranks on one GPU (tests)
     n = args.log_n
     table, desc = make_table(hl, args.table)
-    nv_max = max(n, table.l)
     zm = args.pcs == "zeromorph"
-    if zm:
-        pp = hl.Zeromorph.trim(hl.Zeromorph.setup(ctx, trapdoor(1)[0], 1 << nv_max), 1 << nv_max)
-    else:
-        pp = hl.MultilinearKzg.setup(ctx, trapdoor(nv_max))
     sharded = args.mode == "sharded" and world > 1
     assert not (zm and sharded), "the sharded mode is implemented for multilinear KZG"
-    # sharded: every rank holds the same full lookup columns (the counters need the global order)
-    d_dims = [ctx.upload(d.tobytes()) for d in gen_dims(table, n, 0 if sharded else rank)]
-    ctx.sync()
-    if sharded:
+
+    def setup(nv):
+        if zm:
+            return hl.Zeromorph.trim(hl.Zeromorph.setup(ctx, trapdoor(1)[0], 1 << nv), 1 << nv)
+        return hl.MultilinearKzg.setup(ctx, trapdoor(nv))
+
+    def shard_geometry(tb, nn):
         rho = world.bit_length() - 1
         assert 1 << rho == world, "sharded mode needs a power-of-two number of GPUs"
-        shard_bit = max(table.l - rho, min(14, n - rho - 1), 1)
-        hl.attach_comm(ctx, rank, world, hdist.host_all_gather(dist, hdist.control_group(dist)), shard_bit)
+        return max(tb.l - rho, min(14, nn - rho - 1), 1)
 
-    def prove(nn=n, bufs=d_dims):
+    def load_columns(tb, nn, shard_bit):
+        """device columns of this rank: its shard of the (rank-0 seeded) batch when sharded, else its own batch"""
+        cols = gen_dims(tb, nn, 0 if sharded else rank)
+        if sharded:
+            cols = [hl.shard_of(c, rank, world, shard_bit) for c in cols]
+        return [ctx.upload(c.tobytes()) for c in cols]
+
+    pp = setup(max(n, table.l))
+    transport = None
+    shard_bit = shard_geometry(table, n) if sharded else 0
+    d_dims = load_columns(table, n, shard_bit)
+    ctx.sync()
+    if sharded:
+        transport = hdist.attach_sharded(ctx, dist, shard_bit)
+
+    def prove(nn=n, bufs=None, single=False, p=None, tb=None):
         tr = hl.Keccak256Transcript()
-        if sharded and nn == n:
-            hl.lasso_prove_sharded(pp, table, nn, bufs, tr)
+        if sharded and not single:
+            hl.lasso_prove_sharded(p or pp, tb or table, nn, bufs or d_dims, tr)
         else:
-            hl.lasso_prove(pp, table, nn, bufs, tr)
+            hl.lasso_prove(p or pp, tb or table, nn, bufs or d_dims, tr)
         return tr
 
     def barrier():
@@ -385,49 +399,97 @@ def main():
             torch.cuda.synchronize()
         hdist.barrier(dist)
 
-    for _ in range(args.warmup):
-        prove()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tr = prove()
-    ctx.sync()
-    if dist is not None and dist.get_backend() == "nccl":
-        import torch
-        torch.cuda.synchronize()
-    elapsed = hdist.max_over_ranks(dist, time.perf_counter() - t0)
-    hdist.barrier(dist)
+    def timed(steps, warmup, **kw):
+        for _ in range(warmup):
+            prove(**kw)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tr = prove(**kw)
+        ctx.sync()
+        if dist is not None and dist.get_backend() == "nccl":
+            import torch
+            torch.cuda.synchronize()
+        elapsed = hdist.max_over_ranks(dist, time.perf_counter() - t0)
+        hdist.barrier(dist)
+        return elapsed * 1e3 / max(steps, 1), tr
+
+    ms_per_step, tr = timed(args.steps, args.warmup)
     phases = hl.lasso_last_timing(ctx)
-    ms_per_step = elapsed * 1e3 / max(args.steps, 1)
-    proof_len = len(tr.into_proof())
+    proof = tr.into_proof()
+    proofs_per_step = 1 if sharded else world
 
     out = None
     if rank == 0:
         out = {
-            "metric": "lasso_prove_time_ms", "value": round(ms_per_step / (1 if sharded else world), 3), "unit": "ms",
+            "metric": "lasso_prove_time_ms", "value": round(ms_per_step / proofs_per_step, 3), "unit": "ms",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": False, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "u256 (BN254 Fr/Fq, 8x u32 Montgomery)",
-            "data": "synthetic",
-            "config": {"workload": desc % n, "lookups_per_proof": 1 << n, "proofs_per_step": 1 if sharded else world,
+            "higher_is_better": False, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
+            "dtype": "u256 (BN254 Fr/Fq, 8x u32 Montgomery)", "data": "synthetic",
+            "config": {"workload": desc % n, "lookups_per_proof": 1 << n, "proofs_per_step": proofs_per_step,
                        "pcs": "Zeromorph over univariate KZG (BN254)" if zm else "multilinear KZG (BN254)",
-                       "proof_bytes": proof_len,
-                       "parallelism": ("1 proof sharded over %d GPUs" % world if sharded else
-                                       "1 proof per GPU" if world > 1 else "1 GPU")},
-            "lookups_per_s": round((1 << n) * (1 if sharded else world) / (ms_per_step / 1e3)),
+                       "proof_bytes": len(proof),
+                       "parallelism": ("1 proof sharded over %d GPUs (index bits [%d, %d))" % (world, shard_bit, shard_bit + world.bit_length() - 1)
+                                       if sharded else "1 proof per GPU" if world > 1 else "1 GPU")},
+            "lookups_per_s": round((1 << n) * proofs_per_step / (ms_per_step / 1e3)),
             "phases_ms": {k: round(v, 3) for k, v in phases.items()},
         }
-        if not args.no_profile and not sharded:
+        if sharded:
+            out["config"]["transport"] = transport
+    if not args.no_profile:
+        # a separately profiled prove (every instrumented launch synchronised); sharded: every rank takes part in the
+        # collectives, rank 0 records
+        if rank == 0:
             hl.profile_enable(ctx, True)
+        if sharded or rank == 0:
             prove()
             ctx.sync()
+        if rank == 0:
             aggs = aggregate(hl.profile_read(ctx))
             hl.profile_enable(ctx, False)
-            dom_name = max(aggs, key=lambda a: a["big"]["ms"])["name"]
-            out["roofline"], out["alu"], out["kernels"] = roofline_objects(hl, ctx, aggs,
-                                                                           pmc_traffic(dom_name, n, args.table))
+            dom_name = max(aggs, key=lambda a: a["ms"])["name"]
+            out["roofline"], out["alu"], out["kernels"] = roofline_objects(
+                hl, ctx, aggs, pmc_traffic(dom_name, n, args.table, world))
+    if sharded:
+        # the sharded proof against the single-GPU prover on the same lookups (rank 0 holds the whole batch for it)
+        stats = hl.comm_stats(ctx)
+        if rank == 0:
+            out["comm_collectives_per_run"] = stats
+            if n <= 26:
+                full = [ctx.upload(c.tobytes()) for c in gen_dims(table, n, 0)]
+                out["sharded_proof_equals_single_gpu"] = prove(bufs=full, single=True).into_proof() == proof
+                del full
+    if world > 1 and not args.no_extra:
+        # extra objects next to the headline: BASELINE.json configs[3] (2^26 range-check lookups, one proof sharded over
+        # the N GPUs) and N independent replicas of the headline workload (weak scaling, no data-path collective)
+        extra_steps = max(1, min(args.steps, 3))
+        if sharded and not (n == 26 and args.table == "range") and not zm:
+            t26, _ = make_table(hl, "range")
+            sb26 = shard_geometry(t26, 26)
+            hl.detach_comm(ctx)
+            pp26 = setup(26)
+            cols26 = load_columns(t26, 26, sb26)
+            hdist.attach_sharded(ctx, dist, sb26)
+            ms26, tr26 = timed(extra_steps, 1, nn=26, bufs=cols26, p=pp26, tb=t26)
+            if rank == 0:
+                out["config3_2p26_range_sharded"] = {"ms_per_proof": round(ms26, 3), "steps": extra_steps,
+                                                     "lookups_per_s": round((1 << 26) / (ms26 / 1e3)),
+                                                     "proof_bytes": len(tr26.into_proof())}
+            del cols26, pp26
+            hl.detach_comm(ctx)
+            hdist.attach_sharded(ctx, dist, shard_bit)
+        if sharded:
+            own = [ctx.upload(c.tobytes()) for c in gen_dims(table, n, rank)]
+            msr, _ = timed(extra_steps, 1, bufs=own, single=True)
+            if rank == 0:
+                out["replicas"] = {"ms_per_step": round(msr, 3), "proofs_per_step": world, "scaling": "weak",
+                                   "ms_per_proof": round(msr / world, 3),
+                                   "lookups_per_s": round((1 << n) * world / (msr / 1e3))}
+            del own
+    if rank == 0:
         if not args.no_inflight and not sharded and world == 1:
             # throughput with TWO independent proofs in flight on the same GPU (two contexts = two streams, one host
-            # thread each): a single proof leaves the chip idle during its ~250 latency-bound rounds and MSM tails
+            # thread each): a single proof leaves the chip idle during its latency-bound rounds and MSM tails
             import threading
             ctx2 = hl.Context(int(os.environ.get("LH_DEVICE", local_rank)))
             # the SRS is device memory: shared, owned by `pp`
@@ -463,6 +525,8 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "ms", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "unavailable: %s" % e}
         print(json.dumps(out), flush=True)
+    if sharded:
+        hl.detach_comm(ctx)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

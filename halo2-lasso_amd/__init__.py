@@ -858,8 +858,9 @@ def lasso_prove(pp, table, num_vars, dims, transcript):
 
 
 def attach_comm(ctx, rank, size, all_gather, shard_bit):
-    """Attach a host-side communicator to the context (sharded proving).
-    all_gather(send: bytes) -> bytes of size * len(send), rank-major."""
+    """Attach a caller-supplied communicator to the context (sharded proving): the transport of the
+    CPU / one-GPU tests.  all_gather(send: bytes) -> bytes of size * len(send), rank-major; device-side gathers are
+    staged through it.  A multi-GPU node uses attach_comm_rccl."""
     def cb(_user, send, recv, nbytes):
         try:
             out = all_gather(C.string_at(send, nbytes))
@@ -876,18 +877,48 @@ def attach_comm(ctx, rank, size, all_gather, shard_bit):
     _check(ctx.lib.lh_ctx_set_comm(ctx.h, C.byref(comm), shard_bit))
 
 
+def rccl_unique_id():
+    """ncclGetUniqueId: 128 bytes to hand to every rank's attach_comm_rccl (call on one rank)"""
+    buf = C.create_string_buffer(_ffi.LH_RCCL_UNIQUE_ID_BYTES)
+    _check(_ffi.load().lh_rccl_unique_id(buf))
+    return buf.raw
+
+
+def attach_comm_rccl(ctx, rank, size, unique_id, shard_bit):
+    """RCCL communicator on the ctx's device and stream (collective over the `size` ranks): every exchange of a sharded
+    proof is an ncclAllGather enqueued behind the kernels that produce its input."""
+    if len(unique_id) != _ffi.LH_RCCL_UNIQUE_ID_BYTES:
+        raise ArgumentError("unique id must be %d bytes" % _ffi.LH_RCCL_UNIQUE_ID_BYTES)
+    _check(ctx.lib.lh_ctx_set_comm_rccl(ctx.h, rank, size, unique_id, shard_bit))
+
+
+def comm_stats(ctx):
+    """{"device": collectives issued on the device side (RCCL), "host": through the host callback}"""
+    out = (C.c_uint64 * 2)()
+    _check(ctx.lib.lh_ctx_comm_stats(ctx.h, out))
+    return {"device": int(out[0]), "host": int(out[1])}
+
+
 def detach_comm(ctx):
     _check(ctx.lib.lh_ctx_set_comm(ctx.h, None, 0))
     ctx._comm_keepalive = None
 
 
-def lasso_prove_sharded(pp, table, num_vars, dims, transcript):
+def shard_of(column, rank, size, shard_bit):
+    """This rank's shard of a full column (numpy array of 2^n entries): entries whose index bits
+    [shard_bit, shard_bit + log2 size) equal `rank`, in index order (local index hi || lo)."""
+    rho = size.bit_length() - 1
+    n = len(column)
+    return column.reshape(n >> (shard_bit + rho), size, 1 << shard_bit)[:, rank, :].reshape(-1).copy()
+
+
+def lasso_prove_sharded(pp, table, num_vars, dims_local, transcript):
     """One proof over the ranks of the attached communicator; same bytes as lasso_prove.
-    dims: the FULL columns on every rank."""
-    if len(dims) != table.c:
+    dims_local: THIS RANK'S shard of every chunk column (device u32[2^(num_vars - rho)], see shard_of)."""
+    if len(dims_local) != table.c:
         raise ArgumentError("expected %d dim columns" % table.c)
     t = table.to_c()
-    _check(pp.ctx.lib.lh_lasso_prove_sharded(pp.ctx.h, pp.h, C.byref(t), num_vars, _ptr_array(dims), transcript.p))
+    _check(pp.ctx.lib.lh_lasso_prove_sharded(pp.ctx.h, pp.h, C.byref(t), num_vars, _ptr_array(dims_local), transcript.p))
 
 
 def lasso_last_timing(ctx):

@@ -82,10 +82,13 @@ class lh_lasso_table(C.Structure):
 
 
 _AG_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+_AGD_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+LH_RCCL_UNIQUE_ID_BYTES = 128
 
 
 class lh_comm(C.Structure):
-    _fields_ = [("rank", C.c_int), ("size", C.c_int), ("user", C.c_void_p), ("all_gather", _AG_CB)]
+    _fields_ = [("rank", C.c_int), ("size", C.c_int), ("user", C.c_void_p), ("all_gather", _AG_CB),
+                ("all_gather_device", _AGD_CB)]
 
 
 class lh_prof_rec(C.Structure):
@@ -166,6 +169,9 @@ SIGNATURES = {
     "lh_lasso_prove": (C.c_int, [_P, _P, C.POINTER(lh_lasso_table), _SZ, C.POINTER(_P), C.POINTER(lh_transcript)]),
     "lh_lasso_last_timing": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "lh_ctx_set_comm": (C.c_int, [_P, C.POINTER(lh_comm), _SZ]),
+    "lh_rccl_unique_id": (C.c_int, [C.c_char_p]),
+    "lh_ctx_set_comm_rccl": (C.c_int, [_P, C.c_int, C.c_int, C.c_char_p, _SZ]),
+    "lh_ctx_comm_stats": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "lh_lasso_prove_sharded": (C.c_int, [_P, _P, C.POINTER(lh_lasso_table), _SZ, C.POINTER(_P),
                                          C.POINTER(lh_transcript)]),
     "lh_hyperplonk_prove": (C.c_int, [_P, _P, C.POINTER(lh_hp_param), C.POINTER(C.POINTER(lh_fr)), C.POINTER(_P),

@@ -92,6 +92,11 @@ void lh_ctx_destroy(lh_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->c.device);
   (void)hipStreamSynchronize(ctx->c.stream);
+  try {
+    comm_detach(ctx->c);
+  } catch (...) {
+  }
+  if (ctx->c.comm_stage) (void)hipFree(ctx->c.comm_stage);
   if (ctx->c.pinned) (void)hipHostFree(ctx->c.pinned);
   if (ctx->c.stage) (void)hipHostFree(ctx->c.stage);
   if (ctx->c.flag) (void)hipHostFree(ctx->c.flag);
@@ -442,17 +447,40 @@ lh_status lh_lasso_last_timing(lh_ctx* ctx, double* out_ms) {
 lh_status lh_ctx_set_comm(lh_ctx* ctx, const lh_comm* comm, size_t shard_bit) {
   LH_TRY NEED_CTX(ctx);
   ctx->c.sync();
-  if (!comm) {
-    ctx->c.has_comm = false;
-    ctx->c.comm = lh_comm{0, 1, nullptr, nullptr};
-  } else {
+  comm_detach(ctx->c);
+  if (comm) {
     LH_REQUIRE(comm->size >= 1 && (comm->size & (comm->size - 1)) == 0 && comm->rank >= 0 && comm->rank < comm->size,
                LH_ERR_ARG, "communicator: size must be a power of two and 0 <= rank < size");
-    LH_REQUIRE(comm->size == 1 || comm->all_gather, LH_ERR_ARG, "communicator: all_gather callback missing");
+    LH_REQUIRE(comm->all_gather || comm->all_gather_device, LH_ERR_ARG, "communicator: no all_gather callback");
     ctx->c.comm = *comm;
     ctx->c.has_comm = true;
     ctx->c.shard_bit = shard_bit;
+    ctx->c.comm_stats[0] = ctx->c.comm_stats[1] = 0;
   }
+  LH_CATCH
+}
+lh_status lh_rccl_unique_id(uint8_t out[LH_RCCL_UNIQUE_ID_BYTES]) {
+  LH_TRY
+  NEED(out);
+  rccl_unique_id(out);
+  LH_CATCH
+}
+lh_status lh_ctx_set_comm_rccl(lh_ctx* ctx, int rank, int size, const uint8_t unique_id[LH_RCCL_UNIQUE_ID_BYTES],
+                               size_t shard_bit) {
+  LH_TRY NEED_CTX(ctx);
+  NEED(unique_id);
+  LH_REQUIRE(size >= 1 && (size & (size - 1)) == 0 && rank >= 0 && rank < size, LH_ERR_ARG,
+             "communicator: size must be a power of two and 0 <= rank < size");
+  ctx->c.sync();
+  comm_attach_rccl(ctx->c, rank, size, unique_id, shard_bit);
+  ctx->c.comm_stats[0] = ctx->c.comm_stats[1] = 0;
+  LH_CATCH
+}
+lh_status lh_ctx_comm_stats(lh_ctx* ctx, uint64_t out[2]) {
+  LH_TRY NEED_CTX(ctx);
+  NEED(out);
+  out[0] = ctx->c.comm_stats[0];
+  out[1] = ctx->c.comm_stats[1];
   LH_CATCH
 }
 lh_status lh_lasso_prove_sharded(lh_ctx* ctx, const lh_srs* srs, const lh_lasso_table* table, size_t num_vars,

@@ -1,0 +1,162 @@
+// Communicator of a proof sharded over several GPUs (the reference is single-process, nothing to cite).
+//
+// Two collectives are all the sharded prover needs:
+//   all_gather_dev   device buffers, enqueued on the ctx's stream - per-round partial sums, residual tables when the
+//                    shard bits reach bit 0, tree levels / quotient remainders at the replication point, the u32
+//                    lookup columns of the witness phase;
+//   all_gather_host  a few hundred bytes that live on the host anyway (partial commitments after the host's window
+//                    combine, partial evaluations).
+// Backends:
+//   RCCL (lh_ctx_set_comm_rccl) - one ncclComm per ctx, created from a unique id the caller distributes (the host
+//       side does that over its own control plane: torch.distributed's store / broadcast in halo2-lasso_amd/dist.py).
+//       ncclAllGather runs on the ctx's stream, so a sharded sum-check round is [round kernel -> all-gather -> sum and
+//       publish kernel] without a host round trip in between; host-side gathers are staged through a device buffer.
+//       librccl is loaded with dlopen at the first use (no link-time dependency: a single-GPU host never loads it; a
+//       process that already runs torch's RCCL gets that same instance through the shared soname).
+//   callbacks (lh_ctx_set_comm) - a caller-supplied host all-gather (gloo in the CPU / one-GPU tests) and optionally a
+//       device all-gather; without the latter device gathers are staged through the host.
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and enums only: every function is resolved with dlsym
+#include <mutex>
+#include "host.hpp"
+
+namespace lh {
+
+namespace {
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+const RcclApi& rccl() {
+  static RcclApi api;
+  static std::once_flag once;
+  static std::string err;
+  std::call_once(once, [] {
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+      api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (api.lib) break;
+    }
+    if (!api.lib) {
+      err = std::string("RCCL is not loadable (librccl.so.1): ") + (dlerror() ? dlerror() : "");
+      return;
+    }
+    auto sym = [&](const char* s) {
+      void* p = dlsym(api.lib, s);
+      if (!p && err.empty()) err = std::string("RCCL symbol missing: ") + s;
+      return p;
+    };
+    api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+    api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+    api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
+    api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+  });
+  if (!err.empty()) throw Error(LH_ERR_DEVICE, err);
+  return api;
+}
+
+void rccl_check(ncclResult_t r, const char* what) {
+  if (r == ncclSuccess) return;
+  const RcclApi& api = rccl();
+  throw Error(LH_ERR_DEVICE, std::string(what) + ": " + (api.GetErrorString ? api.GetErrorString(r) : "RCCL error"));
+}
+
+void* comm_device_stage(Ctx& c, size_t bytes) {
+  if (bytes > c.comm_stage_bytes) {
+    if (c.comm_stage) {
+      c.sync();
+      (void)hipFree(c.comm_stage);
+    }
+    size_t want = bytes < ((size_t)1 << 16) ? ((size_t)1 << 16) : bytes;
+    LH_HIP(hipMalloc(&c.comm_stage, want));
+    c.comm_stage_bytes = want;
+  }
+  return c.comm_stage;
+}
+}  // namespace
+
+void rccl_unique_id(uint8_t out[LH_RCCL_UNIQUE_ID_BYTES]) {
+  static_assert(sizeof(ncclUniqueId) == LH_RCCL_UNIQUE_ID_BYTES, "ncclUniqueId size");
+  ncclUniqueId id;
+  rccl_check(rccl().GetUniqueId(&id), "ncclGetUniqueId");
+  memcpy(out, &id, sizeof(id));
+}
+
+void comm_detach(Ctx& c) {
+  if (c.rccl_comm) {
+    (void)hipStreamSynchronize(c.stream);
+    (void)rccl().CommDestroy((ncclComm_t)c.rccl_comm);
+    c.rccl_comm = nullptr;
+  }
+  c.has_comm = false;
+  c.comm = lh_comm{0, 1, nullptr, nullptr, nullptr};
+  c.shard_bit = 0;
+}
+
+void comm_attach_rccl(Ctx& c, int rank, int size, const uint8_t id_bytes[LH_RCCL_UNIQUE_ID_BYTES], size_t shard_bit) {
+  comm_detach(c);
+  ncclUniqueId id;
+  memcpy(&id, id_bytes, sizeof(id));
+  ncclComm_t comm = nullptr;
+  rccl_check(rccl().CommInitRank(&comm, size, id, rank), "ncclCommInitRank");
+  c.rccl_comm = comm;
+  c.comm = lh_comm{rank, size, nullptr, nullptr, nullptr};
+  c.has_comm = true;
+  c.shard_bit = shard_bit;
+}
+
+static void require_comm(const Ctx& c) {
+  LH_REQUIRE(c.has_comm && (c.rccl_comm || c.comm.all_gather || c.comm.all_gather_device), LH_ERR_ARG,
+             "no communicator attached (lh_ctx_set_comm / lh_ctx_set_comm_rccl)");
+}
+
+void comm_all_gather_dev(Ctx& c, const void* d_send, void* d_recv, size_t bytes) {
+  require_comm(c);
+  if (!bytes) return;
+  if (c.rccl_comm) {
+    c.comm_stats[0]++;
+    rccl_check(rccl().AllGather(d_send, d_recv, bytes, ncclUint8, (ncclComm_t)c.rccl_comm, c.stream), "ncclAllGather");
+    return;
+  }
+  if (c.comm.all_gather_device) {
+    c.comm_stats[0]++;
+    int rc = c.comm.all_gather_device(c.comm.user, d_send, d_recv, bytes, (void*)c.stream);
+    if (rc != 0) throw Error(rc < 0 ? rc : LH_ERR_DEVICE, "communicator all_gather_device failed");
+    return;
+  }
+  // staged through the host (tests with several ranks on one GPU, gloo)
+  const size_t R = (size_t)c.comm.size;
+  std::vector<uint8_t> mine(bytes), all(bytes * R);
+  LH_HIP(hipMemcpyAsync(mine.data(), d_send, bytes, hipMemcpyDeviceToHost, c.stream));
+  c.sync();
+  c.comm_stats[1]++;
+  int rc = c.comm.all_gather(c.comm.user, mine.data(), all.data(), bytes);
+  if (rc != 0) throw Error(rc < 0 ? rc : LH_ERR_DEVICE, "communicator all_gather failed");
+  LH_HIP(hipMemcpyAsync(d_recv, all.data(), bytes * R, hipMemcpyHostToDevice, c.stream));
+  c.sync();  // `all` is pageable host memory
+}
+
+void comm_all_gather_host(Ctx& c, const void* send, void* recv, size_t bytes) {
+  require_comm(c);
+  if (!bytes) return;
+  if (c.comm.all_gather && !c.rccl_comm) {
+    c.comm_stats[1]++;
+    int rc = c.comm.all_gather(c.comm.user, send, recv, bytes);
+    if (rc != 0) throw Error(rc < 0 ? rc : LH_ERR_DEVICE, "communicator all_gather failed");
+    return;
+  }
+  // device collective only: stage through a device buffer [send | recv]
+  const size_t R = (size_t)c.comm.size;
+  uint8_t* d = (uint8_t*)comm_device_stage(c, bytes * (R + 1));
+  LH_HIP(hipMemcpyAsync(d, send, bytes, hipMemcpyHostToDevice, c.stream));
+  comm_all_gather_dev(c, d, d + bytes, bytes);
+  c.d2h(recv, d + bytes, bytes * R);
+}
+
+}  // namespace lh

@@ -102,9 +102,16 @@ struct Ctx {
   int wall_clock_khz = 100000;  // rate of wall_clock64() on the device
   double lasso_ms[LH_LASSO_NUM_PHASES] = {0};
   // one proof over several GPUs: host-side communicator + position of the shard bits
-  lh_comm comm = {0, 1, nullptr, nullptr};
+  lh_comm comm = {0, 1, nullptr, nullptr, nullptr};
   bool has_comm = false;
   size_t shard_bit = 0;
+  void* rccl_comm = nullptr;      // ncclComm_t of the built-in RCCL backend (comm.cpp)
+  void* comm_stage = nullptr;     // device staging of host-side gathers over a device-only communicator
+  size_t comm_stage_bytes = 0;
+  uint64_t comm_stats[2] = {0, 0};  // collectives issued: device-side, host callback
+  // sharded sum-check rounds: the round kernel leaves its D sums in this DEVICE buffer (and "publishes" to a device
+  // word) instead of pinned host memory; the all-gather and the sum-and-publish kernel follow on the stream
+  Fr* sc_redirect = nullptr;
   bool prof = false;
   std::vector<ProfRec> prof_recs;
   hipEvent_t prof_ev[2] = {nullptr, nullptr};
@@ -120,7 +127,7 @@ struct Ctx {
   // hipStreamSynchronize (tens of microseconds per call, paid once per sum-check round).
   uint32_t* flag = nullptr;  // pinned, coherent
   uint32_t flag_seq = 0;
-  uint32_t* ticket = nullptr;  // device counter for in-launch final reductions; only ever grows
+  uint32_t* ticket = nullptr;  // device counter for in-launch final reductions; only ever grows (word 8: device flag)
   uint32_t ticket_base = 0;    // its value before the next launch
   struct ScFinishArgs finish_for(uint32_t grid, Fr* out_host, uint32_t seq);
   uint32_t next_seq() { return ++flag_seq; }
@@ -210,7 +217,22 @@ struct LassoG {
 };
 void k_lasso_output(Ctx&, const LassoG& g, size_t n, Fr* a);
 
+// ------------------------------------------------------------------ communicator (comm.cpp)
+void rccl_unique_id(uint8_t out[LH_RCCL_UNIQUE_ID_BYTES]);
+void comm_attach_rccl(Ctx&, int rank, int size, const uint8_t id[LH_RCCL_UNIQUE_ID_BYTES], size_t shard_bit);
+void comm_detach(Ctx&);
+// recv = size * bytes, rank-major.  _dev: device buffers, enqueued on the ctx's stream (staged through the host when
+// the communicator has no device collective); _host: host buffers, synchronous
+void comm_all_gather_dev(Ctx&, const void* d_send, void* d_recv, size_t bytes);
+void comm_all_gather_host(Ctx&, const void* send, void* recv, size_t bytes);
+
 // ------------------------------------------------------------------ sharding helpers (kernels_poly.hip)
+// inverse of k_shard_extract over the all-gathered shards: global[g] = gathered[s(g) * n_local + local(g)]
+void k_shard_merge(Ctx&, const void* gathered, size_t n_local, size_t j, size_t rho, size_t elem, void* global);
+// out[t][hi * R + s] = gathered[(s * count + t) * n_local + hi]  (tables whose shard bits have reached bit 0)
+void k_gather_interleave(Ctx&, const Fr* gathered, size_t count, size_t n_local, size_t R, Fr* const* out);
+// out_host[x] = sum_s all[s * D + x], x < D; then the flag: the closing step of a sharded sum-check round
+void k_sum_publish(Ctx&, const Fr* all, size_t R, size_t D, Fr* out_host, uint32_t seq);
 // local[idx] = global[((idx >> j) << (j + rho)) | (s << j) | (idx & (2^j - 1))], elements of `elem` bytes (4, 32, 64)
 void k_shard_extract(Ctx&, const void* global, size_t n_local, size_t j, size_t rho, size_t s, size_t elem, void* local);
 // out[i] = in[i] * w

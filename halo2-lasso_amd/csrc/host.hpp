@@ -137,7 +137,7 @@ std::vector<HFr> evaluate_polys_sharded(Ctx&, const Fr* const* d_polys_local, si
                                         const HFr* point);
 void comm_sum_fr(Ctx&, HFr* v, size_t n);
 void comm_sum_points(Ctx&, HG1* pts, size_t n);
-void comm_gather_interleave(Ctx&, const Fr* const* local, size_t count, size_t n_local, Fr* const* out);
+void comm_gather_interleave(Ctx&, const Fr* local_block, size_t count, size_t n_local, Fr* const* out);
 void comm_gather_concat(Ctx&, const Fr* local, size_t n_local, Fr* out);
 
 // ------------------------------------------------------------------ piop::gkr

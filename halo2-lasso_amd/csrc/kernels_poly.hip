@@ -313,6 +313,67 @@ void k_shard_extract(Ctx& c, const void* global, size_t n_local, size_t j, size_
   else
     throw Error(LH_ERR_ARG, "shard_extract: unsupported element size");
 }
+// inverse of shard_extract over the all-gathered shards (rank-major): global index (hi, s, lo) <- gathered[s][hi || lo]
+template <class T>
+__global__ void shard_merge_kernel(const T* __restrict__ gathered, size_t n_local, unsigned j, unsigned rho,
+                                   T* __restrict__ global) {
+  const size_t lo_mask = ((size_t)1 << j) - 1, s_mask = ((size_t)1 << rho) - 1;
+  GSTRIDE(g, n_local << rho) {
+    const size_t s = (g >> j) & s_mask, local = ((g >> (j + rho)) << j) | (g & lo_mask);
+    global[g] = gathered[s * n_local + local];
+  }
+}
+void k_shard_merge(Ctx& c, const void* gathered, size_t n_local, size_t j, size_t rho, size_t elem, void* global) {
+  if (!n_local) return;
+  dim3 g = grid_for(n_local << rho);
+  if (elem == 4)
+    hipLaunchKernelGGL(shard_merge_kernel<uint32_t>, g, 256, 0, c.stream, (const uint32_t*)gathered, n_local, (unsigned)j,
+                       (unsigned)rho, (uint32_t*)global);
+  else if (elem == 32)
+    hipLaunchKernelGGL(shard_merge_kernel<Fr>, g, 256, 0, c.stream, (const Fr*)gathered, n_local, (unsigned)j,
+                       (unsigned)rho, (Fr*)global);
+  else
+    throw Error(LH_ERR_ARG, "shard_merge: unsupported element size");
+}
+
+// tables whose shard bits have reached bit 0: out[t][hi * R + s] = gathered[(s * count + t) * n_local + hi]
+struct InterleaveOut {
+  Fr* out[SC_MAX_TABLES];
+};
+__global__ void gather_interleave_kernel(const Fr* __restrict__ gathered, unsigned count, size_t n_local, unsigned R,
+                                         InterleaveOut o) {
+  const size_t full = n_local * R;
+  GSTRIDE(e, full * count) {
+    const size_t t = e / full, k = e % full, hi = k / R, s = k % R;
+    o.out[t][k] = gathered[((size_t)s * count + t) * n_local + hi];
+  }
+}
+void k_gather_interleave(Ctx& c, const Fr* gathered, size_t count, size_t n_local, size_t R, Fr* const* out) {
+  LH_REQUIRE(count <= (size_t)SC_MAX_TABLES, LH_ERR_ARG, "gather_interleave: too many tables");
+  if (!count || !n_local) return;
+  InterleaveOut o;
+  for (size_t t = 0; t < count; t++) o.out[t] = out[t];
+  hipLaunchKernelGGL(gather_interleave_kernel, grid_for(n_local * R * count), 256, 0, c.stream, gathered, (unsigned)count,
+                     n_local, (unsigned)R, o);
+}
+
+// closing step of a sharded sum-check round: the D partial sums of the R ranks (all-gathered, rank-major) are added
+// and published to the host exactly as a single-GPU round kernel publishes its result (pinned buffer, then the flag)
+__global__ void sum_publish_kernel(const Fr* __restrict__ all, unsigned R, unsigned D, Fr* __restrict__ out_host,
+                                   uint32_t* flag, uint32_t seq) {
+  if (threadIdx.x == 0) {
+    for (unsigned x = 0; x < D; x++) {
+      Fr acc = all[x];
+      for (unsigned s = 1; s < R; s++) acc = add(acc, all[(size_t)s * D + x]);
+      out_host[x] = acc;
+    }
+    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+void k_sum_publish(Ctx& c, const Fr* all, size_t R, size_t D, Fr* out_host, uint32_t seq) {
+  hipLaunchKernelGGL(sum_publish_kernel, dim3(1), dim3(64), 0, c.stream, all, (unsigned)R, (unsigned)D, out_host, c.flag, seq);
+}
+
 __global__ void scale_kernel(const Fr* __restrict__ in, Fr w, size_t n, Fr* __restrict__ out) {
   GSTRIDE(i, n) out[i] = mul(in[i], w);
 }

@@ -509,6 +509,14 @@ void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, F
   const double bytes = (bind ? 192.0 : 64.0) * (double)size * (double)tabs;
   const uint32_t seq = c.next_seq();
   ArenaScope scope(c.arena);
+  // sharded rounds (prover.cpp): the D sums stay on the device (all-gather and sum-and-publish follow on the stream)
+  const bool redirect = c.sc_redirect != nullptr;
+  if (redirect) evals_host = c.sc_redirect;
+  auto finish = [&](size_t grid) {
+    ScFinish f = c.finish_for((uint32_t)grid, evals_host, seq);
+    if (redirect) f.flag = c.ticket + 8;  // a device word nobody waits on
+    return f;
+  };
 
   // pairs per workgroup of the LDS-staged kernel
   uint32_t P = (uint32_t)std::min<size_t>(size, 64);
@@ -537,7 +545,7 @@ void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, F
     g.vals_entries = std::max<uint32_t>(g.num_used * P * 2, 8);
     size_t grid = (size + P - 1) / P;
     Fr* partials = grid == 1 ? evals_host : c.arena.alloc_n<Fr>(grid * degree);
-    const ScFinish kflag = c.finish_for((uint32_t)grid, evals_host, seq);
+    const ScFinish kflag = finish(grid);
     {
       char name[40];
       snprintf(name, sizeof name, "sc_round<%d,%s>/lds", degree, bind ? "bind" : "first");
@@ -551,7 +559,7 @@ void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, F
         default: launch_lds<6>(c, g, bind, size, (unsigned)grid, partials, kflag); break;
       }
     }
-    c.wait_flag(seq);
+    if (!redirect) c.wait_flag(seq);
     return;
   }
 
@@ -566,7 +574,7 @@ void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, F
   size_t cap = (size_t)c.num_cus * 4;
   if (g > cap) g = cap;
   Fr* partials = g == 1 ? evals_host : c.arena.alloc_n<Fr>(g * degree);
-  const ScFinish kflag = c.finish_for((uint32_t)g, evals_host, seq);
+  const ScFinish kflag = finish(g);
   {
     char name[40];
     snprintf(name, sizeof name, "sc_round<%d,%s>%s", degree, bind ? "bind" : "first", tp > 1 ? "/tp" : "");
@@ -580,7 +588,7 @@ void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, F
       default: launch_round<6>(c, a, bind, size, tp, (unsigned)g, partials, kflag); break;
     }
   }
-  c.wait_flag(seq);
+  if (!redirect) c.wait_flag(seq);
 }
 
 }  // namespace lh

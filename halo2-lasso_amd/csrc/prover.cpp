@@ -85,16 +85,10 @@ HFr horner(const std::vector<HFr>& coeffs, const HFr& x) {
 }
 
 // ------------------------------------------------------------------ communicator helpers (sharded proving)
-static void comm_all_gather(Ctx& c, const void* send, void* recv, size_t bytes) {
-  LH_REQUIRE(c.has_comm && c.comm.all_gather, LH_ERR_ARG, "no communicator attached (lh_ctx_set_comm)");
-  int rc = c.comm.all_gather(c.comm.user, send, recv, bytes);
-  if (rc != 0) throw Error(rc < 0 ? rc : LH_ERR_DEVICE, "communicator all_gather failed");
-}
-
 void comm_sum_fr(Ctx& c, HFr* v, size_t n) {
   const size_t R = (size_t)c.comm.size;
   std::vector<HFr> all(n * R);
-  comm_all_gather(c, v, all.data(), n * sizeof(HFr));
+  comm_all_gather_host(c, v, all.data(), n * sizeof(HFr));
   for (size_t i = 0; i < n; i++) {
     HFr acc = HFr::zero();
     for (size_t r = 0; r < R; r++) acc += all[r * n + i];
@@ -105,7 +99,7 @@ void comm_sum_fr(Ctx& c, HFr* v, size_t n) {
 void comm_sum_points(Ctx& c, HG1* pts, size_t n) {
   const size_t R = (size_t)c.comm.size;
   std::vector<HG1> all(n * R);
-  comm_all_gather(c, pts, all.data(), n * sizeof(HG1));
+  comm_all_gather_host(c, pts, all.data(), n * sizeof(HG1));
   for (size_t i = 0; i < n; i++) {
     host::G1Xyzz acc = host::G1Xyzz::identity();
     for (size_t r = 0; r < R; r++) acc = host::g1_add(acc, host::g1_from_affine(all[r * n + i]));
@@ -113,31 +107,19 @@ void comm_sum_points(Ctx& c, HG1* pts, size_t n) {
   }
 }
 
-// out[t][hi * R + s] = (rank s).local[t][hi]   (the shard bits have reached bit 0)
-void comm_gather_interleave(Ctx& c, const Fr* const* local, size_t count, size_t n_local, Fr* const* out) {
+// out[t][hi * R + s] = (rank s).local[t][hi]   (the shard bits have reached bit 0).  `local_block`: the `count` local
+// tables back to back (count * n_local entries) - ONE device all-gather, one interleaving pass.
+void comm_gather_interleave(Ctx& c, const Fr* local_block, size_t count, size_t n_local, Fr* const* out) {
   const size_t R = (size_t)c.comm.size;
-  std::vector<HFr> mine(count * n_local), all(count * n_local * R), full(n_local * R);
-  for (size_t t = 0; t < count; t++)
-    LH_HIP(hipMemcpyAsync(mine.data() + t * n_local, local[t], n_local * sizeof(Fr), hipMemcpyDeviceToHost, c.stream));
-  c.sync();
-  comm_all_gather(c, mine.data(), all.data(), count * n_local * sizeof(HFr));
-  for (size_t t = 0; t < count; t++) {
-    for (size_t s = 0; s < R; s++)
-      for (size_t hi = 0; hi < n_local; hi++) full[hi * R + s] = all[(s * count + t) * n_local + hi];
-    LH_HIP(hipMemcpyAsync(out[t], full.data(), n_local * R * sizeof(Fr), hipMemcpyHostToDevice, c.stream));
-    c.sync();  // `full` is reused
-  }
+  ArenaScope scope(c.arena);
+  Fr* gathered = c.arena.alloc_n<Fr>(count * n_local * R);
+  comm_all_gather_dev(c, local_block, gathered, count * n_local * sizeof(Fr));
+  k_gather_interleave(c, gathered, count, n_local, R, out);
 }
 
-// out[s * n_local + i] = (rank s).local[i]   (the shard bits are the top bits)
+// out[s * n_local + i] = (rank s).local[i]   (the shard bits are the top bits): exactly an all-gather
 void comm_gather_concat(Ctx& c, const Fr* local, size_t n_local, Fr* out) {
-  const size_t R = (size_t)c.comm.size;
-  std::vector<HFr> mine(n_local), all(n_local * R);
-  LH_HIP(hipMemcpyAsync(mine.data(), local, n_local * sizeof(Fr), hipMemcpyDeviceToHost, c.stream));
-  c.sync();
-  comm_all_gather(c, mine.data(), all.data(), n_local * sizeof(HFr));
-  LH_HIP(hipMemcpyAsync(out, all.data(), n_local * R * sizeof(Fr), hipMemcpyHostToDevice, c.stream));
-  c.sync();
+  comm_all_gather_dev(c, local, out, n_local * sizeof(Fr));
 }
 
 static size_t log2_exact(size_t v) {
@@ -211,7 +193,6 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
   auto message = [&](const Fr* sums) {
     std::vector<HFr> ev(degree + 1);
     for (int x = 1; x <= degree; x++) ev[x] = hst(sums[x - 1]);
-    if (sh) comm_sum_fr(c, ev.data() + 1, degree);  // partial sums of the other shards
     ev[0] = claim - ev[1];  // eval.rs:129
     HFr r;
     if (prover_kind == LH_SC_COEFFICIENTS) {
@@ -231,19 +212,22 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
     res.challenges.push_back(r);
     return r;
   };
+  Fr *d_part = nullptr, *d_all = nullptr;  // sharded rounds: this rank's D sums, every rank's
   bool tail_ok = true;  // cleared when a resident tail ended early: the remaining rounds are launched one by one
   for (size_t round = 0; round < num_vars; round++) {
     bool bind = round > 0;
     if (sh && round == j) {
       // the shard bits are about to become the pair bit: bind once more, exchange, go on replicated
-      std::vector<Fr*>& dst = flip ? bufB : bufA;
-      k_fix_var_multi(c, cur.data(), dst.data(), T, len, dev(r_prev));
+      // (the T bound tables go into one block: a single all-gather moves them)
       len >>= 1;
+      Fr* block = c.arena.alloc_n<Fr>(T * len);
+      std::vector<Fr*> dst(T);
+      for (size_t i = 0; i < T; i++) dst[i] = block + i * len;
+      k_fix_var_multi(c, cur.data(), dst.data(), T, len << 1, dev(r_prev));
       std::vector<Fr*> rep(T);
       const size_t full = len << rho;
       for (size_t i = 0; i < T; i++) rep[i] = c.arena.alloc_n<Fr>(full);
-      std::vector<const Fr*> bound(dst.begin(), dst.end());
-      comm_gather_interleave(c, bound.data(), T, len, rep.data());
+      comm_gather_interleave(c, block, T, len, rep.data());
       for (size_t i = 0; i < T; i++) cur[i] = rep[i];
       len = full;
       alloc_bufs(len);
@@ -336,7 +320,28 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
       for (size_t i = 0; i < T; i++)
         if (!used[i]) k_fix_var(c, cur[i], len, dev(r_prev), dst[i]);
     }
-    round_fn(cur.data(), dst.data(), dev(r_prev), bind, size, evals_host);
+    if (sh) {
+      // [round kernel -> all-gather of the D partial sums -> sum and publish], all on the ctx's stream
+      const size_t R = (size_t)c.comm.size;
+      if (!d_part) {
+        d_part = c.arena.alloc_n<Fr>(8);
+        d_all = c.arena.alloc_n<Fr>(8 * R);
+      }
+      c.sc_redirect = d_part;
+      try {
+        round_fn(cur.data(), dst.data(), dev(r_prev), bind, size, evals_host);
+      } catch (...) {
+        c.sc_redirect = nullptr;
+        throw;
+      }
+      c.sc_redirect = nullptr;
+      comm_all_gather_dev(c, d_part, d_all, (size_t)degree * sizeof(Fr));
+      const uint32_t seq = c.next_seq();
+      k_sum_publish(c, d_all, R, (size_t)degree, evals_host, seq);
+      c.wait_flag(seq);
+    } else {
+      round_fn(cur.data(), dst.data(), dev(r_prev), bind, size, evals_host);
+    }
     if (bind) {
       for (size_t i = 0; i < T; i++) cur[i] = dst[i];
       len >>= 1;

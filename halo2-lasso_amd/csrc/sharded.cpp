@@ -5,8 +5,9 @@
 // the 2^(m-rho) entries (hi || lo).  Every kernel is index-agnostic over such a local table because
 //   * sum-check pairs are (2b, 2b+1)      -> bit 0, local while it is not a shard bit (rounds 0..j-1),
 //   * product-tree / quotient halves      -> top bit, local while the table has more than j+rho variables.
-// What crosses ranks (host-side all-gather, small): D partial sums per round, one partial point per MSM
-// job, the residual tables of a sum-check when the shard bits reach bit 0 (2^(m-j) entries per table),
+// What crosses ranks (comm.cpp: RCCL all-gathers on the ctx's stream on a multi-GPU node): the u32 lookup columns
+// once (the access counters need the global lookup order), D partial sums per sharded round, one partial point
+// per MSM job, the residual tables of a sum-check when the shard bits reach bit 0 (2^(m-j) entries per table),
 // the tree level / quotient remainder at 2^(j+rho) entries.  Tables of <= j+rho variables (the subtable
 // side of the memory check, the top of every tree) are replicated and computed redundantly.
 #include <algorithm>
@@ -266,11 +267,11 @@ static double now_ms() {
   return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
-void lasso_prove_sharded(Ctx& c, const Srs& srs, const lh_lasso_table& tb, size_t n, const uint32_t* const* d_dims,
-                         Transcript& tr) {
+void lasso_prove_sharded(Ctx& c, const Srs& srs, const lh_lasso_table& tb, size_t n,
+                         const uint32_t* const* d_dims_local, Transcript& tr) {
   LH_REQUIRE(c.has_comm, LH_ERR_ARG, "lasso_prove_sharded: no communicator attached");
   const ShardGeom g(c);
-  LH_REQUIRE(g.R >= 2 && ((size_t)1 << g.rho) == g.R, LH_ERR_ARG, "sharded prove: the number of ranks must be 2^rho >= 2");
+  LH_REQUIRE(g.R >= 1 && ((size_t)1 << g.rho) == g.R, LH_ERR_ARG, "sharded prove: the number of ranks must be a power of two");
   const size_t cc = tb.num_chunks, l = tb.chunk_bits, alpha = tb.num_memories;
   LH_REQUIRE(cc >= 1 && cc <= LH_LASSO_MAX_CHUNKS && alpha >= 1 && alpha <= LH_LASSO_MAX_MEMORIES, LH_ERR_ARG,
              "lasso: bad table shape");
@@ -292,18 +293,32 @@ void lasso_prove_sharded(Ctx& c, const Srs& srs, const lh_lasso_table& tb, size_
     t_prev = t;
   };
   ArenaScope scope(c.arena);
-
-  // ---- witness: counters need the global lookup order -> computed on every rank, then sharded
-  std::vector<uint32_t*> rts_l(cc), dim_l(cc), fcs(cc), E_l(alpha);
+  std::vector<uint32_t*> rts_pre(cc), fcs_pre(cc);
   for (size_t j = 0; j < cc; j++) {
-    uint32_t* rts_full = c.arena.alloc_n<uint32_t>(N);
-    fcs[j] = c.arena.alloc_n<uint32_t>(M);
-    k_lasso_counters(c, d_dims[j], N, M, rts_full, fcs[j]);
-    rts_l[j] = c.arena.alloc_n<uint32_t>(NL);
-    dim_l[j] = c.arena.alloc_n<uint32_t>(NL);
-    k_shard_extract(c, rts_full, NL, g.j, g.rho, g.rank, 4, rts_l[j]);
-    k_shard_extract(c, d_dims[j], NL, g.j, g.rho, g.rank, 4, dim_l[j]);
+    rts_pre[j] = c.arena.alloc_n<uint32_t>(NL);
+    fcs_pre[j] = c.arena.alloc_n<uint32_t>(M);
   }
+
+  // ---- witness: read_ts[k] = number of earlier lookups (global order) of the same address: a stable sort of the
+  // whole column.  The 4-byte columns are all-gathered once (1/8 of a field-sized table) and every rank runs the
+  // counters on the full column (3 % of a 2^24 proof), keeping its own share of read_ts; final_cts is replicated.
+  std::vector<uint32_t*> rts_l(cc), fcs(cc), E_l(alpha);
+  std::vector<const uint32_t*> dim_l(cc);
+  {
+    ArenaScope wscope(c.arena);  // the full columns are only needed here
+    uint32_t* gathered = c.arena.alloc_n<uint32_t>(N);
+    uint32_t* full = c.arena.alloc_n<uint32_t>(N);
+    uint32_t* rts_full = c.arena.alloc_n<uint32_t>(N);
+    // (the outputs rts_pre / fcs_pre were allocated in the outer scope above)
+    for (size_t j = 0; j < cc; j++) {
+      dim_l[j] = d_dims_local[j];
+      comm_all_gather_dev(c, d_dims_local[j], gathered, NL * sizeof(uint32_t));
+      k_shard_merge(c, gathered, NL, g.j, g.rho, 4, full);
+      k_lasso_counters(c, full, N, M, rts_full, fcs_pre[j]);
+      k_shard_extract(c, rts_full, NL, g.j, g.rho, g.rank, 4, rts_pre[j]);
+    }
+  }
+  for (size_t j = 0; j < cc; j++) rts_l[j] = rts_pre[j], fcs[j] = fcs_pre[j];
   LassoG gg;
   memset(&gg, 0, sizeof(gg));
   for (size_t i = 0; i < alpha; i++) {

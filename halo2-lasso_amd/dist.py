@@ -1,9 +1,15 @@
-"""Multi-GPU plumbing (torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" on CPU for tests).
+"""Multi-GPU plumbing: one process per GPU, rendezvous and control plane through torch.distributed (backend "nccl" is
+RCCL on ROCm, "gloo" on CPU for tests).
 
-Round 1 shards the UNITS of work: every rank proves its own independent batch of lookups (its own
-witness, the same SRS), there is no data-path collective; the only exchanges are the barrier and the
-max-over-ranks of the timed region that bench.py's contract asks for.  (Sharding ONE proof across ranks
-- SURVEY.md §8e - needs the partial-sum exchange inside the host prover and is the next row.)
+Two ways to use N GPUs (bench.py --mode):
+* sharded (default): ONE proof split over the ranks (csrc/sharded.cpp).  The data path does not go
+  through torch: `attach_sharded` gives the prover's context its own RCCL communicator (lh_ctx_set_comm_rccl; the
+  128-byte unique id travels over torch.distributed's broadcast) and every exchange is an ncclAllGather on the
+  prover's stream.  With the gloo backend (CPU tests, several ranks on one GPU) the same prover runs over a host
+  all-gather callback instead.
+* replicas: every rank proves its own independent batch (weak scaling, no data-path collective).
+torch.distributed itself only carries the barrier and the max-over-ranks of the timed region that bench.py's
+contract asks for.
 """
 import os
 
@@ -73,6 +79,19 @@ def host_all_gather(dist, group=None):
         dist.all_gather_into_tensor(recv, send, group=group)
         return recv.numpy().tobytes()
     return all_gather
+
+
+def attach_sharded(ctx, dist, shard_bit):
+    """Give `ctx` the communicator of a sharded proof over all ranks of `dist`; returns "rccl" or "host"."""
+    import halo2_lasso_amd as hl
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if dist.get_backend() == "nccl" and os.environ.get("LH_SHARDED_TRANSPORT", "rccl") == "rccl":
+        ids = [hl.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        hl.attach_comm_rccl(ctx, rank, world, ids[0], shard_bit)
+        return "rccl"
+    hl.attach_comm(ctx, rank, world, host_all_gather(dist, control_group(dist)), shard_bit)
+    return "host"
 
 
 def control_group(dist):

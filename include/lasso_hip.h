@@ -236,21 +236,40 @@ lh_status lh_lasso_last_timing(lh_ctx*, double* out_ms);
  * entries is split on `rho` index bits [shard_bit, shard_bit + rho): the rank whose id equals those
  * bits holds the 2^(m-rho) entries (hi || lo).  Sum-check pairs (bit 0) and GKR / quotient halves (top
  * bit) stay local; per round each rank contributes D partial sums, per MSM one partial point, and when
- * the shard bits reach bit 0 the residual tables (2^(m-shard_bit) entries) are exchanged once.  The
- * exchanged data are small and live on the host, so the communicator is a host-side all-gather
- * supplied by the caller (torch.distributed in halo2-lasso_amd/dist.py; RCCL/gloo underneath). */
+ * the shard bits reach bit 0 the residual tables (2^(m-shard_bit) entries) are exchanged once.
+ *
+ * Transport.  On a multi-GPU node the communicator is RCCL over xGMI (lh_ctx_set_comm_rccl): one process per
+ * GPU, one ncclComm per ctx, every device-side exchange is an ncclAllGather enqueued on the ctx's stream (a
+ * sharded sum-check round is [round kernel -> all-gather of the D partial sums -> sum-and-publish kernel],
+ * no host round trip in between).  The 128-byte unique id comes from lh_rccl_unique_id on one rank and reaches
+ * the others over the caller's control plane.  lh_ctx_set_comm takes caller-supplied collectives instead
+ * (tests: gloo through torch.distributed, several ranks on one GPU); device gathers are then staged through
+ * the host unless all_gather_device is given. */
 typedef struct lh_comm {
   int rank, size; /* size = 2^rho */
   void* user;
-  /* recv holds size * bytes_per_rank bytes, rank-major; returns 0 or a negative lh_status */
+  /* host buffers: recv holds size * bytes_per_rank bytes, rank-major; returns 0 or a negative lh_status */
   int (*all_gather)(void* user, const void* send, void* recv, size_t bytes_per_rank);
+  /* optional (may be NULL): the same over DEVICE buffers, enqueued on hip_stream (the ctx's stream) */
+  int (*all_gather_device)(void* user, const void* d_send, void* d_recv, size_t bytes_per_rank, void* hip_stream);
 } lh_comm;
-/* comm == NULL detaches.  shard_bit >= chunk_bits - rho is required by lh_lasso_prove_sharded. */
+/* comm == NULL detaches.  shard_bit + rho >= chunk_bits is required by lh_lasso_prove_sharded. */
 lh_status lh_ctx_set_comm(lh_ctx*, const lh_comm* comm, size_t shard_bit);
-/* Same proof bytes as lh_lasso_prove on one GPU.  d_dims: the FULL columns on every rank (witness
- * counters are computed redundantly, everything field-sized is sharded). */
+#define LH_RCCL_UNIQUE_ID_BYTES 128
+/* ncclGetUniqueId: call on ONE rank, distribute the bytes to every rank */
+lh_status lh_rccl_unique_id(uint8_t out[LH_RCCL_UNIQUE_ID_BYTES]);
+/* ncclCommInitRank on the ctx's device (collective: every rank of the job calls it with the same id) */
+lh_status lh_ctx_set_comm_rccl(lh_ctx*, int rank, int size, const uint8_t unique_id[LH_RCCL_UNIQUE_ID_BYTES],
+                               size_t shard_bit);
+/* collectives issued on this ctx since the communicator was attached: out[0] device-side (RCCL or
+ * all_gather_device), out[1] host callback.  A job on RCCL shows out[1] == 0. */
+lh_status lh_ctx_comm_stats(lh_ctx*, uint64_t out[2]);
+/* Same proof bytes as lh_lasso_prove on one GPU.  d_dims_local[j]: THIS RANK'S shard of chunk column j, device
+ * u32[2^(num_vars - rho)] in the shard layout (local index hi || lo <-> lookup (hi, rank, lo)).  The 4-byte columns
+ * are all-gathered once (the access counters are a stable sort in global lookup order); everything field-sized -
+ * tables, SRS, sum-check, product trees, MSMs, openings - stays sharded. */
 lh_status lh_lasso_prove_sharded(lh_ctx*, const lh_srs*, const lh_lasso_table*, size_t num_vars,
-                                 const uint32_t* const* d_dims, lh_transcript* t);
+                                 const uint32_t* const* d_dims_local, lh_transcript* t);
 
 /* ---------------------------------------------------------------- f1: HyperPlonk with LogUp lookups
  * HyperPlonk::prove (backend/hyperplonk.rs:164-291) for single-phase circuits: instance hashing and

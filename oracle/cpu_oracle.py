@@ -31,6 +31,9 @@ def lib():
 
 
 def fr_bytes(xs):
+    """ints -> Montgomery bytes; byte strings (already Montgomery, e.g. downloaded from the GPU) pass through"""
+    if isinstance(xs, (bytes, bytearray)):
+        return bytes(xs)
     return b"".join((x % R_MOD * MONT_R % R_MOD).to_bytes(32, "little") for x in xs)
 
 
@@ -47,6 +50,11 @@ def g1_point(b):
     x = int.from_bytes(b[:32], "little") * _QI % Q_MOD
     y = int.from_bytes(b[32:64], "little") * _QI % Q_MOD
     return None if x == 0 and y == 0 else (x, y)
+
+
+def _count(p):
+    """number of field elements of an int list or a Montgomery byte string"""
+    return len(p) // 32 if isinstance(p, (bytes, bytearray)) else len(p)
 
 
 def _chk(rc):
@@ -119,13 +127,13 @@ def setup(ss):
 
 def msm(scalars, bases_bytes):
     out = C.create_string_buffer(64)
-    _chk(lib().orc_msm(fr_bytes(scalars), bases_bytes, C.c_size_t(len(scalars)), out))
+    _chk(lib().orc_msm(fr_bytes(scalars), bases_bytes, C.c_size_t(_count(scalars)), out))
     return g1_point(out.raw)
 
 
 def commit(srs, srs_nv, poly):
     out = C.create_string_buffer(64)
-    nv = len(poly).bit_length() - 1
+    nv = _count(poly).bit_length() - 1
     _chk(lib().orc_commit(srs, C.c_size_t(srs_nv), fr_bytes(poly), C.c_size_t(nv), out))
     return g1_point(out.raw)
 
@@ -152,7 +160,7 @@ def sumcheck_prove(tr, kind, nv, sop_struct, polys, ys, claim):
 
 
 def frac_gkr_prove(tr, ps, qs):
-    B, nv = len(ps), len(ps[0]).bit_length() - 1
+    B, nv = len(ps), _count(ps[0]).bit_length() - 1
     pa, k1 = _ptrs([fr_bytes(p) for p in ps])
     qa, k2 = _ptrs([fr_bytes(q) for q in qs])
     px, qx, x = (C.create_string_buffer(32 * B), C.create_string_buffer(32 * B), C.create_string_buffer(32 * nv))
@@ -162,7 +170,7 @@ def frac_gkr_prove(tr, ps, qs):
 
 def grand_product_prove(tr, leaves):
     B = len(leaves)
-    nvs = [len(v).bit_length() - 1 for v in leaves]
+    nvs = [_count(v).bit_length() - 1 for v in leaves]
     la, keep = _ptrs([fr_bytes(v) for v in leaves])
     roots, claims = C.create_string_buffer(32 * B), C.create_string_buffer(32 * B)
     pts = C.create_string_buffer(32 * sum(nvs))
@@ -311,7 +319,7 @@ def usetup(s, poly_size):
 
 def zm_commit(powers, poly_size, poly):
     out = C.create_string_buffer(64)
-    nv = len(poly).bit_length() - 1
+    nv = _count(poly).bit_length() - 1
     _chk(lib().orc_zm_commit(powers, C.c_size_t(len(powers) // 64), C.c_size_t(poly_size), fr_bytes(poly), C.c_size_t(nv), out))
     return g1_point(out.raw)
 

@@ -1,0 +1,295 @@
+"""GPU parity at the sizes where the STREAMING kernels run (round-1 parity tests stop below the thresholds at which
+`sc_round_kernel<D,BIND>` replaces the LDS round kernel, the radix sort takes several passes, MSM windows reach
+13-17 bits with continuation levels, `eq_outer_kernel` runs and the expression rounds are compiled at run time).
+
+The checker is the multithreaded C++ oracle (oracle/cpu: the reference's algorithms, SOS Montgomery on 4 x u64,
+Jacobian points, evaluate-then-bind, Pippenger per thread chunk), which finishes 2^16..2^20 in about a second on the
+GPU box's host cores; it is itself pinned to the Python oracle and the golden vectors by tests/test_oracle_cpu.py.
+Every comparison is on bytes: proof streams, challenges and evaluations as Montgomery limbs, affine points.
+Inputs are uniformly random Montgomery limb patterns below the modulus (a uniform field element), handed unchanged to
+both sides.  The last test proves BASELINE.json configs[2] (2^24 AND lookups) and puts the proof through the verifier.
+"""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+
+from oracle import cpu_oracle as co
+from oracle.pyref.field import R_MOD as P
+
+pytestmark = pytest.mark.gpu
+
+TOP_LIMB = 0x30644E72E131A029  # top 64 bits of r: limb patterns with a smaller top limb are < r
+
+
+def rand_mont(rng, n):
+    a = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(n, 4), dtype=np.uint64)
+    a[:, 3] = rng.integers(0, TOP_LIMB, size=n, dtype=np.uint64)
+    return a.tobytes()
+
+
+def mle(hl, ctx, raw):
+    n = len(raw) // 32
+    return hl.MultilinearPolynomial(ctx, ctx.upload(raw), n.bit_length() - 1)
+
+
+def trapdoor(nv, seed):
+    rng = random.Random(seed)
+    return [rng.randrange(1, P) for _ in range(nv)]
+
+
+@pytest.fixture(scope="module")
+def srs17(hl, ctx):
+    """(ss, GPU params, the C++ oracle's flat SRS) for 17 variables; the two setups must agree on all 2^18 - 1 points"""
+    ss = trapdoor(17, 1700)
+    pp = hl.MultilinearKzg.setup(ctx, ss)
+    flat = co.setup(ss)
+    assert pp.eqs_bytes() == flat, "SRS of the GPU setup differs from the oracle's"
+    return ss, pp, flat
+
+
+# ------------------------------------------------------------------ a': Lasso
+def _dims(rng, table, n, skew):
+    cols = []
+    for j in range(table.c):
+        d = rng.integers(0, 1 << table.l, size=1 << n, dtype=np.uint32)
+        if skew and j == 0:  # a third of the lookups hit one address, another third a handful: long runs for the
+            hot = rng.random(1 << n)  # counters' sort, the MSM's continuation levels and one very hot bucket
+            d[hot < 0.33] = 7
+            d[(hot >= 0.33) & (hot < 0.66)] = rng.integers(0, 5, size=int(((hot >= 0.33) & (hot < 0.66)).sum()), dtype=np.uint32)
+        cols.append(d)
+    return cols
+
+
+@pytest.mark.parametrize("kind,n,skew", [("range", 14, False), ("and", 14, False), ("xor", 14, True),
+                                         ("range", 17, True), ("and", 17, False), ("xor", 17, False)])
+def test_lasso_matches_cpp_oracle(hl, ctx, srs17, kind, n, skew):
+    ss, pp, flat = srs17
+    table = hl.LassoTable.range(2, 16) if kind == "range" else hl.LassoTable.bitwise(
+        hl.SUBTABLE_AND if kind == "and" else hl.SUBTABLE_XOR, 4, 16)
+    rng = np.random.default_rng(1000 + n + len(kind))
+    dims = _dims(rng, table, n, skew)
+    ot = co.Transcript()
+    co.lasso_prove(ot, flat, 17, table.to_c(), n, [d.tobytes() for d in dims])
+    t = hl.Keccak256Transcript()
+    hl.lasso_prove(pp, table, n, [ctx.upload(d.tobytes()) for d in dims], t)
+    proof = t.into_proof()
+    assert proof == ot.into_proof()
+    hl.lasso_verify(hl.MultilinearKzgVerifierParams.setup(ss), table, n, hl.Keccak256Transcript.from_proof(proof))
+
+
+# ------------------------------------------------------------------ a5-a8: both sum-check provers at 2^18
+def _sop_struct(hl, terms, global_eq):
+    return hl.SumOfProducts(terms, global_eq=global_eq).to_c()
+
+
+def test_sum_check_evaluations_2p18(hl, ctx):
+    """eq * (c0 p0 p1 + c1 p2 p3 + c2 p0 p3 p4), degree 4: sc_round_kernel<4,*> from 2^17 pairs down through the
+    LDS kernel and the resident tail; challenges, evaluations and proof bytes against the C++ oracle"""
+    nv = 18
+    rng = np.random.default_rng(18)
+    prng = random.Random(18)
+    tables = [rand_mont(rng, 1 << nv) for _ in range(5)]
+    y = [prng.randrange(P) for _ in range(nv)]
+    c = [prng.randrange(P) for _ in range(3)]
+    claim = prng.randrange(P)  # both provers derive p(0) from the claim: any value gives the same bytes
+    terms = [(c[0], [0, 1]), (c[1], [2, 3]), (c[2], [0, 3, 4])]
+    ot = co.Transcript()
+    ox, oev = co.sumcheck_prove(ot, 0, nv, _sop_struct(hl, terms, 0), tables, [y], claim)
+    t = hl.Keccak256Transcript()
+    x, ev = hl.ClassicSumCheck.prove(ctx, hl.EvaluationsProver, nv, hl.SumOfProducts(terms, global_eq=0),
+                                     [mle(hl, ctx, r) for r in tables], [y], claim, t)
+    assert (x, ev) == (ox, oev) and t.into_proof() == ot.into_proof()
+
+
+def test_sum_check_coefficients_2p18(hl, ctx):
+    """sum_j s_j eq_j poly_j (batch_open's expression) with the true claim; the verifier accepts"""
+    nv = 18
+    rng = np.random.default_rng(19)
+    prng = random.Random(19)
+    tables = [rand_mont(rng, 1 << nv) for _ in range(4)]
+    ys = [[prng.randrange(P) for _ in range(nv)] for _ in range(4)]
+    s = [prng.randrange(P) for _ in range(4)]
+    polys = [mle(hl, ctx, r) for r in tables]
+    claim = sum(sj * p.evaluate(yj) for sj, p, yj in zip(s, polys, ys)) % P
+    terms = [(s[j], [4 + j, j]) for j in range(4)]
+    ot = co.Transcript()
+    ox, oev = co.sumcheck_prove(ot, 1, nv, _sop_struct(hl, terms, -1), tables, ys, claim)
+    t = hl.Keccak256Transcript()
+    x, ev = hl.ClassicSumCheck.prove(ctx, hl.CoefficientsProver, nv, hl.SumOfProducts(terms), polys, ys, claim, t)
+    assert (x, ev) == (ox, oev) and t.into_proof() == ot.into_proof()
+    from oracle.pyref import kzg as o_kzg
+    final, vx = hl.sum_check_verify(hl.CoefficientsProver, nv, 2, claim, hl.Keccak256Transcript.from_proof(t.into_proof()))
+    assert vx == x and final == sum(s[j] * o_kzg.eq_xy_eval(x, ys[j]) * ev[j] for j in range(4)) % P
+
+
+# ------------------------------------------------------------------ a9: GKR
+def test_fractional_sum_check_x3_2p16(hl, ctx):
+    """the reference's GKR test shape (fractional_sum_check.rs:327-370: three batched fractions) at 16 variables"""
+    nv = 16
+    rng = np.random.default_rng(16)
+    ps = [rand_mont(rng, 1 << nv) for _ in range(3)]
+    qs = [rand_mont(rng, 1 << nv) for _ in range(3)]
+    ot = co.Transcript()
+    o = co.frac_gkr_prove(ot, ps, qs)
+    t = hl.Keccak256Transcript()
+    g = hl.prove_fractional_sum_check(ctx, [None] * 3, [None] * 3, [mle(hl, ctx, r) for r in ps],
+                                      [mle(hl, ctx, r) for r in qs], t)
+    assert tuple(g) == tuple(o) and t.into_proof() == ot.into_proof()
+
+
+def test_grand_product_mixed_depth_large(hl, ctx):
+    """the Lasso memory-check shape: trees of 2^18, 2^18, 2^12, 2^16 leaves in one batch"""
+    rng = np.random.default_rng(17)
+    leaves = [rand_mont(rng, 1 << nv) for nv in (18, 18, 12, 16)]
+    ot = co.Transcript()
+    o_roots, o_claims = co.grand_product_prove(ot, leaves)
+    t = hl.Keccak256Transcript()
+    roots, claims = hl.prove_grand_product(ctx, [mle(hl, ctx, r) for r in leaves], t)
+    assert roots == o_roots and claims == o_claims and t.into_proof() == ot.into_proof()
+
+
+# ------------------------------------------------------------------ a10: variable_base_msm
+@pytest.fixture(scope="module")
+def bases20(hl, ctx):
+    pp = hl.MultilinearKzg.setup(ctx, trapdoor(20, 2000))
+    flat = pp.eqs_bytes()
+    off = 64 * ((1 << 20) - 1)  # level 20 of the flat layout
+    raw = flat[off:off + 64 * (1 << 20)]
+    return ctx.upload(raw), raw
+
+
+@pytest.mark.parametrize("n", [1 << 16, (1 << 20) - 3])
+def test_msm_fr_large(hl, ctx, bases20, n):
+    d_bases, raw = bases20
+    rng = np.random.default_rng(n)
+    scalars = rand_mont(rng, n)
+    got = hl.variable_base_msm(ctx, ctx.upload(scalars), d_bases, n)
+    assert got == co.msm(scalars, raw[:64 * n])
+
+
+def _fr_of_u32(hl, ctx, vals):
+    src, out = ctx.upload(vals.tobytes()), ctx.alloc(32 * len(vals))
+    hl._check(ctx.lib.lh_fr_from_u32(ctx.h, src.ptr, len(vals), out.ptr))
+    ctx.sync()
+    return src, out.read()
+
+
+@pytest.mark.parametrize("shape", ["uniform16", "uniform32", "skewed"])
+def test_msm_u32_large(hl, ctx, bases20, shape):
+    """32-bit columns (Lasso's dim / read_ts / final_cts / E): one or two windows; `skewed`: 60 % of the scalars are
+    the same value and another 30 % come from eight values (hot buckets cut into continuation chunks), zeros present"""
+    d_bases, raw = bases20
+    n = 1 << 20
+    rng = np.random.default_rng(len(shape))
+    if shape == "uniform16":
+        v = rng.integers(0, 1 << 16, size=n, dtype=np.uint32)
+    elif shape == "uniform32":
+        v = rng.integers(0, 1 << 32, size=n, dtype=np.uint32)
+    else:
+        v = rng.integers(0, 1 << 20, size=n, dtype=np.uint32)
+        u = rng.random(n)
+        v[u < 0.6] = 12345
+        v[(u >= 0.6) & (u < 0.9)] = rng.integers(1, 9, size=int(((u >= 0.6) & (u < 0.9)).sum()), dtype=np.uint32)
+        v[u > 0.99] = 0
+    src, as_fr = _fr_of_u32(hl, ctx, v)
+    got = hl.variable_base_msm_u32(ctx, src, d_bases, n)
+    assert got == co.msm(as_fr, raw)
+    # the same column as full field elements goes through the signed-digit path
+    assert hl.variable_base_msm(ctx, ctx.upload(as_fr), d_bases, n) == got
+
+
+def test_msm_fr_skewed_large(hl, ctx, bases20):
+    """full-width scalars with heavy repetition: every window has one very hot bucket"""
+    d_bases, raw = bases20
+    n = 1 << 18
+    rng = np.random.default_rng(5)
+    a = np.frombuffer(rand_mont(rng, n), dtype=np.uint64).reshape(n, 4).copy()
+    a[rng.random(n) < 0.5] = a[0]
+    scalars = a.tobytes()
+    assert hl.variable_base_msm(ctx, ctx.upload(scalars), d_bases, n) == co.msm(scalars, raw[:64 * n])
+
+
+# ------------------------------------------------------------------ a16: HyperPlonk at 2^16 (runtime-compiled rounds)
+@pytest.mark.parametrize("with_lookup", [False, True])
+def test_hyperplonk_2p16_matches_cpp_oracle(hl, ctx, with_lookup):
+    """the reference's sample circuits (backend/hyperplonk/util.rs) at 16 variables: the zero-check runs the
+    expression compiled at run time (csrc/jit.cpp, from 2^16 rows), LogUp's sort-merge join and the permutation
+    prefix product run at scale; proof bytes against the C++ oracle, then the host verifier"""
+    from halo2_lasso_amd import hyperplonk as g_hp
+    from oracle.pyref import hyperplonk as o_hp
+    k = 16
+    ss = trapdoor(k, 1600 + with_lookup)
+    gen = o_hp.rand_vanilla_plonk_with_lookup_circuit if with_lookup else o_hp.rand_vanilla_plonk_circuit
+    o_info, instances, witness = gen(k, random.Random(160 + with_lookup))
+    mk = g_hp.vanilla_plonk_with_lookup_circuit_info if with_lookup else g_hp.vanilla_plonk_circuit_info
+    g_info = mk(k, len(instances[0]), o_info.preprocess_polys, o_info.permutations)
+    pcs = hl.MultilinearKzg.setup(ctx, ss)
+    pp, vp = g_hp.HyperPlonk.preprocess(pcs, g_info, hl.MultilinearKzgVerifierParams.setup(ss))
+    t = hl.Keccak256Transcript()
+    g_hp.HyperPlonk.prove(pp, instances, [hl.MultilinearPolynomial.new(ctx, w) for w in witness], t)
+    proof = t.into_proof()
+    # C++ oracle on the same circuit
+    num_z, expression = o_hp.compose(o_info)
+    perm_idx = o_info.permutation_polys()
+    perm = o_hp.permutation_polys(o_info.k, perm_idx, o_info.permutations)
+    lookups = [[(co.flatten_expression(i), co.flatten_expression(tb)) for i, tb in lk] for lk in o_info.lookups]
+    ot = co.Transcript()
+    co.hyperplonk_prove(ot, pcs.eqs_bytes(), k, k, o_info.num_instances, o_info.preprocess_polys,
+                        o_info.num_witness_polys[0], o_info.num_challenges[0], lookups, perm_idx, perm, num_z,
+                        co.flatten_expression(expression), instances, witness)
+    assert proof == ot.into_proof()
+    g_hp.HyperPlonk.verify(vp, instances, hl.Keccak256Transcript.from_proof(proof))
+
+
+# ------------------------------------------------------------------ f3: Zeromorph at 2^16
+def test_zeromorph_commit_open_2p16(hl, ctx):
+    nv = 16
+    prng = random.Random(316)
+    s = prng.randrange(1, P)
+    size = (1 << nv) + 5
+    powers = co.usetup(s, size)
+    params = hl.Zeromorph.setup(ctx, s, size)
+    buf = C.create_string_buffer(64 * size)
+    hl._check(ctx.lib.lh_usrs_download(ctx.h, params.h, buf))
+    assert buf.raw == powers, "powers of s differ from the oracle's"
+    pp = hl.Zeromorph.trim(params, 1 << nv)
+    raw = rand_mont(np.random.default_rng(316), 1 << nv)
+    poly = mle(hl, ctx, raw)
+    assert hl.Zeromorph.commit(pp, poly) == co.zm_commit(powers, 1 << nv, raw)
+    point = [prng.randrange(P) for _ in range(nv)]
+    ot = co.Transcript()
+    co.zm_open(ot, powers, 1 << nv, raw, point)
+    t = hl.Keccak256Transcript()
+    hl.Zeromorph.open(pp, poly, point, t)
+    assert t.into_proof() == ot.into_proof()
+    vp = hl.ZeromorphVerifierParam.setup(s, size, 1 << nv)
+    hl.Zeromorph.verify(vp, hl.Zeromorph.commit(pp, poly), point, poly.evaluate(point),
+                        hl.Keccak256Transcript.from_proof(t.into_proof()))
+
+
+# ------------------------------------------------------------------ BASELINE.json configs[2]
+def test_lasso_2p24_and_prove_verify(hl, ctx):
+    """2^24 AND lookups (32-bit operands, 4 chunks of 8+8 bits) on one GPU: the proof verifies, is deterministic, and a
+    flipped lookup index changes it.  (Bytes against the oracle at this size are checked by bench.py's cpu_baseline
+    on the largest sample that fits its time bound.)"""
+    n = 24
+    table = hl.LassoTable.bitwise(hl.SUBTABLE_AND, 4, 16)
+    ss = trapdoor(n, 2400)
+    pp = hl.MultilinearKzg.setup(ctx, ss)
+    rng = np.random.default_rng(24)
+    dims = [rng.integers(0, 1 << 16, size=1 << n, dtype=np.uint32) for _ in range(4)]
+    bufs = [ctx.upload(d.tobytes()) for d in dims]
+    proofs = []
+    for _ in range(2):
+        t = hl.Keccak256Transcript()
+        hl.lasso_prove(pp, table, n, bufs, t)
+        proofs.append(t.into_proof())
+    assert proofs[0] == proofs[1]
+    hl.lasso_verify(hl.MultilinearKzgVerifierParams.setup(ss), table, n, hl.Keccak256Transcript.from_proof(proofs[0]))
+    dims[2][12345] ^= 1
+    bufs[2] = ctx.upload(dims[2].tobytes())
+    t = hl.Keccak256Transcript()
+    hl.lasso_prove(pp, table, n, bufs, t)
+    assert t.into_proof() != proofs[0]

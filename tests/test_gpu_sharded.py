@@ -1,6 +1,8 @@
 """GPU: ONE Lasso proof sharded over 2 / 4 ranks must produce the single-GPU proof bytes.
-The ranks are separate processes that share the one GPU of the test box and talk over gloo (host-side
-communicator); on a multi-GPU node the same code runs one rank per GPU."""
+The ranks are separate processes that share the one GPU of the test box and talk over gloo (host all-gather
+callback: RCCL refuses two ranks on one device); the RCCL transport itself is exercised by a world-1 job on the one
+GPU (same code path: ncclAllGather on the prover's stream, sum-and-publish kernel) and by a two-GPU job that runs
+when the box has two devices."""
 import array
 import json
 import os
@@ -18,6 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = textwrap.dedent("""
     import os, sys, json, array, random
     sys.path.insert(0, %r)
+    import numpy as np
     import halo2_lasso_amd as hl
     from halo2_lasso_amd import dist as hdist
     cfg = json.loads(sys.argv[1])
@@ -30,11 +33,13 @@ WORKER = textwrap.dedent("""
     pp = hl.MultilinearKzg.setup(ctx, ss)
     table = hl.LassoTable.range(cfg["c"], cfg["l"]) if cfg["kind"] == "range" else hl.LassoTable.bitwise(
         hl.SUBTABLE_AND if cfg["kind"] == "and" else hl.SUBTABLE_XOR, cfg["c"], cfg["l"])
-    d_dims = [ctx.upload(array.array("I", col).tobytes()) for col in dims]
+    # every rank holds only its shard of the lookup columns
+    d_dims = [ctx.upload(hl.shard_of(np.array(col, dtype=np.uint32), rank, world, cfg["shard_bit"]).tobytes())
+              for col in dims]
     hl.attach_comm(ctx, rank, world, hdist.host_all_gather(d), cfg["shard_bit"])
     t = hl.Keccak256Transcript()
     hl.lasso_prove_sharded(pp, table, cfg["n"], d_dims, t)
-    print(json.dumps({"rank": rank, "proof": t.into_proof().hex()}), flush=True)
+    print(json.dumps({"rank": rank, "proof": t.into_proof().hex(), "stats": hl.comm_stats(ctx)}), flush=True)
     hdist.barrier(d)
     d.destroy_process_group()
 """) % ROOT
@@ -89,29 +94,132 @@ def test_sharded_proof_equals_single_gpu_and_oracle(tmp_path, world, kind, c, l,
     o_lasso.verify(opp, spec, n, OT(ot.into_proof()))
 
 
+LARGE = [
+    # world, kind, c, l, n, shard_bit: the streaming kernels on shards, checked against the C++ oracle
+    (2, "range", 2, 16, 18, 15),
+    (4, "and", 4, 16, 18, 14),
+]
+
+
+@pytest.mark.parametrize("world,kind,c,l,n,shard_bit", LARGE)
+def test_sharded_proof_large_vs_cpp_oracle(tmp_path, world, kind, c, l, n, shard_bit):
+    import numpy as np
+    import halo2_lasso_amd as hl
+    from oracle import cpu_oracle as co
+    seed = zlib.crc32(repr((world, kind, c, l, n)).encode())
+    cfg = dict(seed=seed, kind=kind, c=c, l=l, n=n, shard_bit=shard_bit)
+    outs = run_ranks(tmp_path, world, cfg, 29900 + (seed % 90))
+    proofs = {o["proof"] for o in outs}
+    assert len(proofs) == 1, "ranks disagree on the proof"
+    assert all(o["stats"]["host"] > 0 for o in outs)
+    rng = random.Random(seed)
+    ss = [rng.randrange(hl.R_MOD) for _ in range(n)]
+    dims = [[rng.randrange(1 << l) for _ in range(1 << n)] for _ in range(c)]
+    table = hl.LassoTable.range(c, l) if kind == "range" else hl.LassoTable.bitwise(
+        hl.SUBTABLE_AND if kind == "and" else hl.SUBTABLE_XOR, c, l)
+    ot = co.Transcript()
+    co.lasso_prove(ot, co.setup(ss), n, table.to_c(), n, [np.array(d, dtype=np.uint32).tobytes() for d in dims])
+    assert proofs.pop() == ot.into_proof().hex()
+
+
+def test_sharded_world1_over_rccl(hl, ctx):
+    """The RCCL transport on the one GPU of the test box: a world of ONE rank runs the whole sharded prover - every
+    exchange an ncclAllGather on the prover's stream followed by the sum-and-publish kernel - and must give the bytes
+    of lasso_prove.  Asserts that the device-side path was taken and nothing went through a host callback."""
+    import numpy as np
+    n, shard_bit = 17, 16
+    table = hl.LassoTable.bitwise(hl.SUBTABLE_XOR, 4, 16)
+    rng = np.random.default_rng(171)
+    prng = random.Random(171)
+    pp = hl.MultilinearKzg.setup(ctx, [prng.randrange(1, hl.R_MOD) for _ in range(n)])
+    dims = [ctx.upload(rng.integers(0, 1 << 16, size=1 << n, dtype=np.uint32).tobytes()) for _ in range(4)]
+    single = hl.Keccak256Transcript()
+    hl.lasso_prove(pp, table, n, dims, single)
+    hl.attach_comm_rccl(ctx, 0, 1, hl.rccl_unique_id(), shard_bit)
+    try:
+        t = hl.Keccak256Transcript()
+        hl.lasso_prove_sharded(pp, table, n, dims, t)
+        stats = hl.comm_stats(ctx)
+    finally:
+        hl.detach_comm(ctx)
+    assert t.into_proof() == single.into_proof()
+    assert stats["device"] > 50 and stats["host"] == 0, stats
+
+
+RCCL_WORKER = textwrap.dedent("""
+    import os, sys, json
+    sys.path.insert(0, %r)
+    import numpy as np
+    import halo2_lasso_amd as hl
+    from halo2_lasso_amd import dist as hdist
+    rank, local_rank, world = hdist.env_rank()
+    d = hdist.init("nccl")
+    ctx = hl.Context(local_rank)             # one rank per GPU
+    n, shard_bit = 18, 15
+    table = hl.LassoTable.range(2, 16)
+    rng = np.random.default_rng(5)
+    import random
+    prng = random.Random(5)
+    pp = hl.MultilinearKzg.setup(ctx, [prng.randrange(1, hl.R_MOD) for _ in range(n)])
+    cols = [rng.integers(0, 1 << 16, size=1 << n, dtype=np.uint32) for _ in range(2)]
+    single = hl.Keccak256Transcript()
+    hl.lasso_prove(pp, table, n, [ctx.upload(c.tobytes()) for c in cols], single)
+    assert hdist.attach_sharded(ctx, d, shard_bit) == "rccl"
+    t = hl.Keccak256Transcript()
+    hl.lasso_prove_sharded(pp, table, n, [ctx.upload(hl.shard_of(c, rank, world, shard_bit).tobytes()) for c in cols], t)
+    print(json.dumps({"rank": rank, "same": t.into_proof() == single.into_proof(), "stats": hl.comm_stats(ctx)}), flush=True)
+    hl.detach_comm(ctx)
+    hdist.barrier(d)
+    d.destroy_process_group()
+""") % ROOT
+
+
+def test_sharded_two_gpus_over_rccl(tmp_path):
+    """two ranks, two GPUs, RCCL over xGMI (skipped on a one-GPU box): bytes of the single-GPU proof, no host callback"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29871", WORLD_SIZE="2", RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        o, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-3000:]
+        out = json.loads(o.strip().splitlines()[-1])
+        assert out["same"] and out["stats"]["device"] > 50 and out["stats"]["host"] == 0, out
+
+
 def test_bench_two_ranks_launched_like_the_driver():
     """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` exactly as the driver launches it,
-    except that both ranks share GPU 0 (LH_DEVICE) and rendezvous over gloo: one JSON line, from rank 0, whole-job
-    aggregate over both ranks, weak scaling."""
-    import json
+    except that both ranks share GPU 0 (LH_DEVICE) and rendezvous over gloo: one JSON line, from rank 0; by default
+    the two ranks prove ONE sharded proof (strong scaling), `--mode replicas` proves one batch per rank."""
     import socket
-    import subprocess
-    import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    env = dict(os.environ, LH_DEVICE="0", LH_DIST_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--log-n", "12", "--no-cpu-baseline", "--no-inflight"]
-    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-1500:]
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+
+    def run(extra):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        env = dict(os.environ, LH_DEVICE="0", LH_DIST_BACKEND="gloo")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1",
+               "--log-n", "17", "--table", "range", "--no-cpu-baseline", "--no-inflight", "--no-extra"] + extra
+        r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-1500:]
+        return json.loads(lines[0])
+
+    d = run([])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "strong"
     assert d["metric"] == "lasso_prove_time_ms" and d["higher_is_better"] is False
-    # two ranks prove one batch each per step: the job's time per proof is half the step time
-    assert abs(d["value"] - d["ms_per_step"] / 2) <= 1e-3  # both are printed with three decimals
-    assert d["config"]["lookups_per_proof"] == 1 << 12 and d["roofline"]["bound"] == "hbm"
+    assert abs(d["value"] - d["ms_per_step"]) <= 1e-3          # one proof per step, whatever the number of ranks
+    assert d["config"]["lookups_per_proof"] == 1 << 17 and d["config"]["proofs_per_step"] == 1
+    assert d["config"]["transport"] == "host" and d["sharded_proof_equals_single_gpu"] is True
+    d = run(["--mode", "replicas"])
+    assert d["scaling"] == "weak" and d["config"]["proofs_per_step"] == 2
+    assert abs(d["value"] - d["ms_per_step"] / 2) <= 1e-3       # two proofs per step
