@@ -216,6 +216,9 @@ struct LassoPcs {
 };
 LassoPcs lasso_mkzg_pcs(Ctx&, const Srs&);
 LassoPcs lasso_zeromorph_pcs(Ctx&, const USrs&, size_t poly_size);
+// commitment framing of the Lasso argument: identity mask as one field element, then the non-identity commitments
+void lasso_write_commitments(Transcript& tr, const std::vector<HG1>& comms);
+std::vector<HG1> lasso_read_commitments(Transcript& tr, size_t count);
 void lasso_prove(Ctx&, const LassoPcs&, const lh_lasso_table& table, size_t num_vars, const uint32_t* const* d_dims,
                  Transcript& tr);
 void lasso_prove_sharded(Ctx&, const Srs&, const lh_lasso_table& table, size_t num_vars,

@@ -35,6 +35,34 @@ LassoPcs lasso_zeromorph_pcs(Ctx& c, const USrs& srs, size_t poly_size) {
   return p;
 }
 
+// Commitment framing of the Lasso argument (oracle/pyref/lasso.py write_commitments / read_commitments).  A committed
+// column that is identically zero commits to the identity - the high-limb dim of a 32-bit range check whose values are
+// all below 2^16, read_ts when the indices are pairwise distinct - and the reference's transcript cannot encode the
+// identity (util/transcript.rs:172-179,216-219).  So: ONE field element whose bit i says that commitment i is the
+// identity, then the other commitments in order; only calls every TranscriptWrite / TranscriptRead offers.
+void lasso_write_commitments(Transcript& tr, const std::vector<HG1>& comms) {
+  LH_REQUIRE(comms.size() < 64, LH_ERR_ARG, "lasso: too many commitments for the identity mask");
+  uint64_t mask = 0;
+  for (size_t i = 0; i < comms.size(); i++)
+    if (comms[i].is_identity()) mask |= (uint64_t)1 << i;
+  tr.write_field_element(HFr::from_u64(mask));
+  for (const HG1& cm : comms)
+    if (!cm.is_identity()) tr.write_commitment(cm);
+}
+
+std::vector<HG1> lasso_read_commitments(Transcript& tr, size_t count) {
+  LH_REQUIRE(count < 64, LH_ERR_ARG, "lasso: too many commitments for the identity mask");
+  const HFr m = tr.read_field_element();
+  uint64_t canon[4];
+  m.to_canonical(canon);
+  if (canon[1] || canon[2] || canon[3] || (canon[0] >> count))
+    throw Error(LH_ERR_INVALID_SNARK, "lasso: commitment mask out of range");
+  std::vector<HG1> comms(count);
+  for (size_t i = 0; i < count; i++)
+    comms[i] = (canon[0] >> i) & 1 ? HG1{host::Fq::zero(), host::Fq::zero()} : tr.read_commitment();
+  return comms;
+}
+
 void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n, const uint32_t* const* d_dims,
                  Transcript& tr) {
   const size_t cc = tb.num_chunks, l = tb.chunk_bits, alpha = tb.num_memories;
@@ -135,7 +163,7 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
       for (auto& t : terms) acc = host::g1_add(acc, t);
       comms[0] = host::g1_to_affine(acc);
     }
-    tr.write_commitments(comms);
+    lasso_write_commitments(tr, comms);
   }
   lap(1);
 

@@ -376,7 +376,7 @@ void lasso_prove_sharded(Ctx& c, const Srs& srs, const lh_lasso_table& tb, size_
       }
       comms[0] = host::g1_to_affine(acc);
     }
-    tr.write_commitments(comms);
+    lasso_write_commitments(tr, comms);
   }
   lap(1);
 

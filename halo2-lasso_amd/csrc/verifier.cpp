@@ -546,7 +546,7 @@ void lasso_verify(const PcsBatchVerify& batch_verify, const lh_lasso_table& tb, 
     LH_REQUIRE(tb.g_num_factors[m] >= 1 && tb.g_num_factors[m] <= LH_SC_MAX_FACTORS, LH_ERR_ARG, "lasso: bad g term");
   for (size_t v : {n, l, c, alpha}) tr.common_field_element(HFr::from_u64(v));
   const size_t nv = std::max(n, l);
-  std::vector<HG1> comms = tr.read_commitments(1 + 3 * c + alpha);
+  std::vector<HG1> comms = lasso_read_commitments(tr, 1 + 3 * c + alpha);
 
   auto g_eval = [&](const std::vector<HFr>& vals) {
     HFr acc = HFr::zero();

@@ -750,7 +750,18 @@ static void lasso_prove(Transcript& tr, const LassoPcsFns& s, const LassoTable& 
   std::vector<Poly> all;
   for (auto& p : pn) all.push_back(padded(p));
   for (auto& p : pl) all.push_back(padded(p));
-  for (auto& p : all) tr.write_comm(s.commit(p));
+  {
+    // commitment framing of the Lasso argument (oracle/pyref/lasso.py write_commitments): a mask of the identity
+    // commitments (identically zero columns) as one field element, then the other commitments in order
+    std::vector<Affine> comms;
+    for (auto& p : all) comms.push_back(s.commit(p));
+    uint64_t mask = 0;
+    for (size_t i = 0; i < comms.size(); i++)
+      if (comms[i].is_identity()) mask |= (uint64_t)1 << i;
+    tr.write_fe(Fr::from_u64(mask));
+    for (auto& cm : comms)
+      if (!cm.is_identity()) tr.write_comm(cm);
+  }
 
   std::vector<Fr> r = tr.squeeze_n(n);
   Fr v = evaluate(a, r.data(), n);

@@ -150,6 +150,26 @@ def _check_shape(spec, n):
         raise LassoError("need at least one variable")
 
 
+# ------------------------------------------------------------------ commitment framing
+# A committed column that is identically zero commits to the group identity: the high-limb `dim` of a 32-bit range
+# check whose values are all below 2^16, `read_ts` when the indices are pairwise distinct, `E` of an AND whose operands
+# never share a bit.  The reference's transcript cannot encode the identity (write_commitment fails on it,
+# util/transcript.rs:172-179,216-219), and valid witnesses must stay provable, so the Lasso argument frames its
+# commitments itself, with calls every TranscriptWrite offers: ONE field element whose bit i says that commitment i is
+# the identity, then the other commitments in order.
+def write_commitments(transcript, comms):
+    mask = sum(1 << i for i, cm in enumerate(comms) if cm is None)
+    transcript.write_field_element(mask)
+    transcript.write_commitments([cm for cm in comms if cm is not None])
+
+
+def read_commitments(transcript, count):
+    mask = transcript.read_field_element()
+    if mask >> count:
+        raise LassoError("commitment mask out of range")
+    return [None if (mask >> i) & 1 else transcript.read_commitment() for i in range(count)]
+
+
 # ------------------------------------------------------------------ prover
 def _trim(pcs, p, nv):
     return p.trim(nv) if pcs is kzg else p
@@ -166,7 +186,7 @@ def prove(pp, spec, dims, transcript, pcs=kzg):
     transcript.common_field_elements([n, l, c, alpha])
     nv = max(n, l)
     polys = [_pad(p, nv) for p in [w["a"]] + w["dim"] + w["read_ts"] + w["E"] + w["final_cts"]]
-    pcs.batch_commit_and_write(_trim(pcs, pp, nv), polys, transcript)
+    write_commitments(transcript, [pcs.commit(_trim(pcs, pp, nv), p) for p in polys])
 
     r = transcript.squeeze_challenges(n)
     v = evaluate(w["a"], r)
@@ -226,7 +246,7 @@ def verify(vp, spec, n, transcript, pcs=kzg):
     _check_shape(spec, n)
     transcript.common_field_elements([n, l, c, alpha])
     nv = max(n, l)
-    comms = transcript.read_commitments(1 + 3 * c + alpha)
+    comms = read_commitments(transcript, 1 + 3 * c + alpha)
 
     r = transcript.squeeze_challenges(n)
     v = transcript.read_field_element()

@@ -88,6 +88,20 @@ def main():
         proof = t.into_proof()
         lasso.verify(pp, spec, n, T(proof))
         out["lasso"].append({"kind": kind, "c": c_, "l": l, "n": n, "dims": dims, "proof": proof.hex()})
+    # identically zero columns commit to the identity (lasso.py write_commitments): an all-zero high limb (dim_1 = E_1
+    # = 0), pairwise distinct indices (read_ts_0 = 0); own rng: the vectors above stay unchanged
+    lrng = random.Random(4242)
+    perm = list(range(16))
+    lrng.shuffle(perm)
+    for c_, l, n, dims in ((2, 3, 4, [[lrng.randrange(8) for _ in range(16)], [0] * 16]),
+                           (2, 4, 4, [perm, [lrng.randrange(16) for _ in range(16)]])):
+        spec = lasso.range_table(c_, l)
+        t = T()
+        lasso.prove(pp, spec, dims, t)
+        proof = t.into_proof()
+        lasso.verify(pp, spec, n, T(proof))
+        assert int.from_bytes(proof[:32], "big") != 0  # the identity mask is not empty
+        out["lasso"].append({"kind": "range", "c": c_, "l": l, "n": n, "dims": dims, "proof": proof.hex()})
 
     # HyperPlonk proofs of the reference's sample circuits (own rng: earlier vectors stay unchanged)
     out["hyperplonk"] = []

@@ -445,17 +445,37 @@ def test_lasso_proof_bytes(hl, ctx, srs6, kind, c, l, n):
     o_lasso.verify(opp, spec, n, OT(proof))
 
 
-def test_lasso_all_distinct_lookups_is_transcript_error(hl, ctx, srs6):
-    """read_ts == 0 everywhere commits to the identity, which the reference transcript rejects
-    (transcript.rs:172-179); oracle and HIP path fail the same way."""
-    _, opp, pp = srs6
-    dims = [list(range(8)), list(range(7, -1, -1))]
-    with pytest.raises(Exception) as e:
-        o_lasso.prove(opp, o_lasso.range_table(2, 3), dims, OT())
-    assert "Invalid elliptic curve point" in str(e.value)
-    d_dims = [ctx.upload(array.array("I", d).tobytes()) for d in dims]
-    with pytest.raises(hl.TranscriptError):
-        hl.lasso_prove(pp, hl.LassoTable.range(2, 3), 3, d_dims, hl.Keccak256Transcript())
+ZERO_COLUMN_CASES = {
+    # identically zero committed columns commit to the identity, which the reference's transcript cannot encode
+    # (transcript.rs:172-179): the Lasso argument frames its commitments with an identity mask (lasso.py)
+    "distinct_indices": ("range", 2, 3, 3, lambda rng: [list(range(8)), list(range(7, -1, -1))]),          # read_ts = 0
+    "zero_high_limb": ("range", 2, 4, 5, lambda rng: [[rng.randrange(16) for _ in range(32)], [0] * 32]),  # dim_1 = E_1 = 0
+    "and_disjoint_bits": ("and", 2, 4, 4, lambda rng: [[0b0110] * 16, [rng.choice([0b0100, 0b0001, 0b1000]) for _ in range(16)]]),
+    "all_zero_lookups": ("xor", 2, 4, 4, lambda rng: [[0] * 16, [0] * 16]),                                # a = dim = E = 0
+}
+
+
+@pytest.mark.parametrize("name", sorted(ZERO_COLUMN_CASES))
+def test_lasso_zero_columns_are_provable(hl, ctx, srs6, name):
+    ss, opp, pp = srs6
+    kind, c, l, n, make = ZERO_COLUMN_CASES[name]
+    dims = make(random.Random(len(name)))
+    spec = _spec(kind, c, l)
+    ot = OT()
+    o_lasso.prove(opp, spec, dims, ot)
+    t = hl.Keccak256Transcript()
+    hl.lasso_prove(pp, _table(hl, kind, c, l), n, [ctx.upload(array.array("I", d).tobytes()) for d in dims], t)
+    proof = t.into_proof()
+    assert proof == ot.into_proof()
+    assert int.from_bytes(proof[:32], "big") != 0  # some commitment is the identity
+    o_lasso.verify(opp, spec, n, OT(proof))
+    hl.lasso_verify(hl.MultilinearKzgVerifierParams.setup(ss), _table(hl, kind, c, l), n,
+                    hl.Keccak256Transcript.from_proof(proof))
+    bad = bytearray(proof)
+    bad[31] ^= 1 << 1  # claim that one more / one fewer commitment is the identity
+    with pytest.raises(hl.Error):
+        hl.lasso_verify(hl.MultilinearKzgVerifierParams.setup(ss), _table(hl, kind, c, l), n,
+                        hl.Keccak256Transcript.from_proof(bytes(bad)))
 
 
 def test_lasso_rejects_bad_arguments(hl, ctx, srs6):

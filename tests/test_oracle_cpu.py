@@ -124,7 +124,7 @@ def _table(hl, g):
         hl.SUBTABLE_AND if g["kind"] == "and" else hl.SUBTABLE_XOR, g["c"], g["l"])).to_c()
 
 
-@pytest.mark.parametrize("idx", range(3))
+@pytest.mark.parametrize("idx", range(5))  # 3, 4: identically zero columns (identity commitments)
 def test_golden_lasso(hl, srs5, idx):
     _, srs = srs5
     g = GOLDEN["lasso"][idx]

@@ -148,7 +148,7 @@ def _table(hl, g):
         hl.SUBTABLE_AND if g["kind"] == "and" else hl.SUBTABLE_XOR, g["c"], g["l"])
 
 
-@pytest.mark.parametrize("idx", range(3))
+@pytest.mark.parametrize("idx", range(5))
 def test_lasso_verify_golden(hl, vp5, idx):
     g = GOLDEN["lasso"][idx]
     proof = bytes.fromhex(g["proof"])
