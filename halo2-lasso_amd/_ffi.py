@@ -57,6 +57,13 @@ class lh_hp_param(C.Structure):
                 ("expression", lh_expr)]
 
 
+_SYNTH_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.POINTER(lh_fr), C.c_size_t, C.POINTER(C.c_void_p), C.c_size_t)
+
+
+class lh_hp_circuit(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("synthesize", _SYNTH_CB)]
+
+
 class lh_hp_vparam(C.Structure):
     _fields_ = [("num_vars", C.c_size_t),
                 ("num_instance_polys", C.c_size_t), ("num_instances", C.POINTER(C.c_size_t)),
@@ -176,6 +183,11 @@ SIGNATURES = {
                                          C.POINTER(lh_transcript)]),
     "lh_hyperplonk_prove": (C.c_int, [_P, _P, C.POINTER(lh_hp_param), C.POINTER(C.POINTER(lh_fr)), C.POINTER(_P),
                                       C.POINTER(lh_transcript)]),
+    "lh_hyperplonk_prove_phases": (C.c_int, [_P, _P, C.POINTER(lh_hp_param), _SZ, C.POINTER(_SZ), C.POINTER(_SZ),
+                                             C.POINTER(C.POINTER(lh_fr)), C.POINTER(lh_hp_circuit),
+                                             C.POINTER(lh_transcript)]),
+    "lh_hyperplonk_verify_phases": (C.c_int, [_P, C.POINTER(lh_hp_vparam), _SZ, C.POINTER(_SZ), C.POINTER(_SZ),
+                                              C.POINTER(C.POINTER(lh_fr)), C.POINTER(lh_transcript)]),
     "lh_keccak_transcript_from_proof": (C.c_int, [C.c_char_p, _SZ, C.POINTER(C.POINTER(lh_transcript))]),
     "lh_keccak_transcript_remaining": (C.c_int, [C.POINTER(lh_transcript), C.POINTER(_SZ)]),
     "lh_mkzg_vp_setup": (C.c_int, [C.POINTER(lh_fr), _SZ, C.POINTER(_P)]),

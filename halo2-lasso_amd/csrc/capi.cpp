@@ -494,6 +494,39 @@ lh_status lh_lasso_prove_sharded(lh_ctx* ctx, const lh_srs* srs, const lh_lasso_
   LH_CATCH
 }
 
+lh_status lh_hyperplonk_prove_phases(lh_ctx* ctx, const lh_srs* srs, const lh_hp_param* pp, size_t num_phases,
+                                     const size_t* num_witness_polys, const size_t* num_challenges,
+                                     const lh_fr* const* instances, const lh_hp_circuit* circuit, lh_transcript* t) {
+  LH_TRY NEED_CTX(ctx);
+  NEED(srs);
+  NEED(pp);
+  NEED(circuit);
+  LH_REQUIRE(circuit->synthesize, LH_ERR_ARG, "circuit: synthesize callback missing");
+  LH_REQUIRE(num_phases == 0 || (num_witness_polys && num_challenges), LH_ERR_ARG, "null argument: phases");
+  Transcript tr(t);
+  HpPhases ph;
+  ph.num_witness_polys.assign(num_witness_polys, num_witness_polys + num_phases);
+  ph.num_challenges.assign(num_challenges, num_challenges + num_phases);
+  size_t tw = 0, tc = 0;
+  for (size_t r = 0; r < num_phases; r++) tw += num_witness_polys[r], tc += num_challenges[r];
+  LH_REQUIRE(tw == pp->num_witness_polys && tc == pp->num_challenges, LH_ERR_ARG,
+             "hyperplonk: phases do not add up to num_witness_polys / num_challenges");
+  ph.synthesize = [&](size_t round, const std::vector<HFr>& challenges) {
+    std::vector<const void*> out(ph.num_witness_polys[round], nullptr);
+    int rc = circuit->synthesize(circuit->user, round, (const lh_fr*)challenges.data(), challenges.size(), out.data(),
+                                 out.size());
+    if (rc != LH_OK) throw lh::Error(rc < 0 ? rc : LH_ERR_INVALID_SNARK, "circuit synthesize callback failed");
+    std::vector<const Fr*> w;
+    for (const void* p : out) {
+      LH_REQUIRE(p != nullptr, LH_ERR_ARG, "circuit synthesize left a witness poly unset");
+      w.push_back((const Fr*)p);
+    }
+    return w;
+  };
+  hyperplonk_prove_phases(ctx->c, mkzg_pcs(ctx->c, srs->s), *pp, ph, (const HFr* const*)instances, tr);
+  LH_CATCH
+}
+
 lh_status lh_hyperplonk_prove(lh_ctx* ctx, const lh_srs* srs, const lh_hp_param* pp, const lh_fr* const* instances,
                               const lh_fr* const* d_witness_polys, lh_transcript* t) {
   LH_TRY NEED_CTX(ctx);
@@ -601,6 +634,22 @@ lh_status lh_hyperplonk_verify(const lh_mkzg_vp* vp, const lh_hp_vparam* hvp, co
   hyperplonk_verify([&pcs](size_t nv, const HG1* comms, size_t nc, const HFr* points, size_t np, const lh_evaluation* evals,
                            size_t ne, Transcript& t2) { mkzg_batch_verify(pcs, nv, comms, nc, points, np, evals, ne, t2); },
                     *hvp, (const HFr* const*)instances, tr);
+  LH_CATCH
+}
+lh_status lh_hyperplonk_verify_phases(const lh_mkzg_vp* vp, const lh_hp_vparam* hvp, size_t num_phases,
+                                      const size_t* num_witness_polys, const size_t* num_challenges,
+                                      const lh_fr* const* instances, lh_transcript* t) {
+  LH_TRY
+  NEED(vp);
+  NEED(hvp);
+  LH_REQUIRE(num_phases == 0 || (num_witness_polys && num_challenges), LH_ERR_ARG, "null argument: phases");
+  Transcript tr(t);
+  const VerifierParams& pcs = *vp->p;
+  hyperplonk_verify_phases(
+      [&pcs](size_t nv, const HG1* comms, size_t nc, const HFr* points, size_t np, const lh_evaluation* evals, size_t ne,
+             Transcript& t2) { mkzg_batch_verify(pcs, nv, comms, nc, points, np, evals, ne, t2); },
+      *hvp, std::vector<size_t>(num_witness_polys, num_witness_polys + num_phases),
+      std::vector<size_t>(num_challenges, num_challenges + num_phases), (const HFr* const*)instances, tr);
   LH_CATCH
 }
 

@@ -244,6 +244,9 @@ std::pair<HFr, std::vector<HFr>> sum_check_verify(int prover_kind, size_t num_va
 void lasso_verify(const PcsBatchVerify& batch_verify, const lh_lasso_table& table, size_t num_vars, Transcript& tr);
 void hyperplonk_verify(const PcsBatchVerify& batch_verify, const lh_hp_vparam& vp, const HFr* const* instances,
                        Transcript& tr);
+void hyperplonk_verify_phases(const PcsBatchVerify& batch_verify, const lh_hp_vparam& vp,
+                              const std::vector<size_t>& num_witness_polys, const std::vector<size_t>& num_challenges,
+                              const HFr* const* instances, Transcript& tr);
 
 // ------------------------------------------------------------------ HyperPlonk (hyperplonk.cpp)
 // the PolynomialCommitmentScheme the backend is generic over (backend/hyperplonk.rs:76-95)
@@ -257,5 +260,13 @@ PcsProver mkzg_pcs(Ctx&, const Srs&);
 PcsProver zeromorph_pcs(Ctx&, const USrs&, size_t poly_size);
 void hyperplonk_prove(Ctx&, const PcsProver&, const lh_hp_param& pp, const HFr* const* instances,
                       const Fr* const* d_witness, Transcript& tr);
+// multi-phase circuits (hyperplonk.rs:185-205): phase r synthesizes num_witness_polys[r] device tables from the
+// challenges of the earlier phases (PlonkishCircuit::synthesize, backend.rs:139), then num_challenges[r] are squeezed
+struct HpPhases {
+  std::vector<size_t> num_witness_polys, num_challenges;
+  std::function<std::vector<const Fr*>(size_t round, const std::vector<HFr>& challenges)> synthesize;
+};
+void hyperplonk_prove_phases(Ctx&, const PcsProver&, const lh_hp_param& pp, const HpPhases& phases,
+                             const HFr* const* instances, Transcript& tr);
 
 }  // namespace lh

@@ -1,5 +1,5 @@
 // HyperPlonk::prove (reference backend/hyperplonk.rs:164-291) with LogUp lookups and the permutation
-// argument, for single-phase circuits.  Transcript schedule: SURVEY.md §3.1; restated in
+// argument, single- and multi-phase circuits (the phase loop of hyperplonk.rs:185-205).  Transcript schedule: SURVEY.md §3.1; restated in
 // oracle/pyref/hyperplonk.py, which the tests compare against byte for byte.
 #include <algorithm>
 #include <chrono>
@@ -155,7 +155,21 @@ struct PhaseTimer {  // LH_HP_DEBUG=1: wall-clock per phase on stderr (developme
 
 void hyperplonk_prove(Ctx& c, const PcsProver& pcs, const lh_hp_param& pp, const HFr* const* instances,
                       const Fr* const* d_witness, Transcript& tr) {
+  // single phase: synthesize(0, []) = d_witness
+  HpPhases ph;
+  ph.num_witness_polys = {pp.num_witness_polys};
+  ph.num_challenges = {pp.num_challenges};
+  ph.synthesize = [&](size_t, const std::vector<HFr>&) {
+    return std::vector<const Fr*>(d_witness, d_witness + pp.num_witness_polys);
+  };
+  hyperplonk_prove_phases(c, pcs, pp, ph, instances, tr);
+}
+
+void hyperplonk_prove_phases(Ctx& c, const PcsProver& pcs, const lh_hp_param& pp, const HpPhases& ph,
+                             const HFr* const* instances, Transcript& tr) {
   PhaseTimer pt(c);
+  LH_REQUIRE(ph.num_witness_polys.size() == ph.num_challenges.size() && ph.synthesize, LH_ERR_ARG,
+             "hyperplonk: phases are malformed");  // zip_eq, hyperplonk.rs:186-190
   const size_t nv = pp.num_vars, n = (size_t)1 << nv;
   LH_REQUIRE(nv >= 1 && nv < 32, LH_ERR_ARG, "hyperplonk: bad num_vars");
   ArenaScope scope(c.arena);
@@ -192,13 +206,16 @@ void hyperplonk_prove(Ctx& c, const PcsProver& pcs, const lh_hp_param& pp, const
   for (size_t i = 0; i < pp.num_preprocess_polys; i++) polys.push_back((const Fr*)pp.d_preprocess_polys[i]);
 
   pt.lap("instance polys");
-  // round 0: witness commitments (single phase: synthesize(0, []) = d_witness)
+  // rounds 0..n (hyperplonk.rs:185-205): per phase synthesize from the challenges so far, commit, squeeze
   std::vector<HFr> challenges;
-  {
-    std::vector<HG1> comms = pcs.batch_commit(d_witness, pp.num_witness_polys, nv);
+  for (size_t round = 0; round < ph.num_witness_polys.size(); round++) {
+    std::vector<const Fr*> w = ph.synthesize(round, challenges);
+    LH_REQUIRE(w.size() == ph.num_witness_polys[round], LH_ERR_ARG,
+               "hyperplonk: synthesize returned the wrong number of witness polys");  // assert_eq hyperplonk.rs:198
+    std::vector<HG1> comms = pcs.batch_commit(w.data(), w.size(), nv);
     tr.write_commitments(comms);
-    for (size_t i = 0; i < pp.num_witness_polys; i++) polys.push_back(d_witness[i]);
-    std::vector<HFr> ch = tr.squeeze_challenges(pp.num_challenges);
+    polys.insert(polys.end(), w.begin(), w.end());
+    std::vector<HFr> ch = tr.squeeze_challenges(ph.num_challenges[round]);
     challenges.insert(challenges.end(), ch.begin(), ch.end());
   }
 

@@ -354,13 +354,34 @@ static HFr rotation_eval(const std::vector<HFr>& x, int rotation, const std::vec
 // ------------------------------------------------------------------ HyperPlonk::verify
 void hyperplonk_verify(const PcsBatchVerify& batch_verify, const lh_hp_vparam& vp, const HFr* const* instances,
                        Transcript& tr) {
+  hyperplonk_verify_phases(batch_verify, vp, {vp.num_witness_polys}, {vp.num_challenges}, instances, tr);
+}
+
+void hyperplonk_verify_phases(const PcsBatchVerify& batch_verify, const lh_hp_vparam& vp,
+                              const std::vector<size_t>& phase_witness_polys, const std::vector<size_t>& phase_challenges,
+                              const HFr* const* instances, Transcript& tr) {
   const size_t nv = vp.num_vars;
+  LH_REQUIRE(phase_witness_polys.size() == phase_challenges.size(), LH_ERR_ARG, "hyperplonk: phases are malformed");
+  {
+    size_t w = 0, ch = 0;
+    for (size_t v : phase_witness_polys) w += v;
+    for (size_t v : phase_challenges) ch += v;
+    LH_REQUIRE(w == vp.num_witness_polys && ch == vp.num_challenges, LH_ERR_ARG,
+               "hyperplonk: phases do not add up to num_witness_polys / num_challenges");
+  }
   LH_REQUIRE(nv >= 1 && nv < 32, LH_ERR_ARG, "hyperplonk: bad num_vars");
   check_expr(vp.expression);
   for (size_t i = 0; i < vp.num_instance_polys; i++)
     for (size_t k = 0; k < vp.num_instances[i]; k++) tr.common_field_element(instances[i][k]);
-  std::vector<HG1> witness_comms = tr.read_commitments(vp.num_witness_polys);
-  std::vector<HFr> challenges = tr.squeeze_challenges(vp.num_challenges);
+  // rounds 0..n (hyperplonk.rs:309-316): per phase read the witness commitments, squeeze the phase's challenges
+  std::vector<HG1> witness_comms;
+  std::vector<HFr> challenges;
+  for (size_t r = 0; r < phase_witness_polys.size(); r++) {
+    std::vector<HG1> cm = tr.read_commitments(phase_witness_polys[r]);
+    witness_comms.insert(witness_comms.end(), cm.begin(), cm.end());
+    std::vector<HFr> ch = tr.squeeze_challenges(phase_challenges[r]);
+    challenges.insert(challenges.end(), ch.begin(), ch.end());
+  }
   HFr beta = tr.squeeze_challenge();
   std::vector<HG1> m_comms = tr.read_commitments(vp.num_lookups);
   HFr gamma = tr.squeeze_challenge();

@@ -142,11 +142,14 @@ class HyperPlonk:
 
     @staticmethod
     def prove(pp, instances, witness_polys, transcript):
-        """hyperplonk.rs:164-291 for single-phase circuits (`synthesize(0, [])` = witness_polys)."""
-        from . import _check, _ptr_array, _fr_array, lh_fr
+        """hyperplonk.rs:164-291.  `witness_polys`: the device tables of a single-phase circuit (`synthesize(0, [])`),
+        or a callable synthesize(round, challenges) -> list of MultilinearPolynomial (PlonkishCircuit::synthesize,
+        backend.rs:139) which the phase loop of hyperplonk.rs:185-205 calls once per phase."""
+        from . import _check, _ptr_array, _fr_array, lh_fr, ArgumentError
         info, ctx = pp.info, pp.pcs.ctx
-        if len(info.num_witness_polys) != 1:
-            raise NotImplementedError("multi-phase circuits need a synthesize callback")
+        multi = callable(witness_polys)
+        if len(info.num_witness_polys) != 1 and not multi:
+            raise ArgumentError("multi-phase circuits need a synthesize(round, challenges) callable")
         keep = []
         prm = _ffi.lh_hp_param()
         prm.num_vars = pp.num_vars
@@ -156,8 +159,8 @@ class HyperPlonk:
         prm.num_preprocess_polys = len(pp.preprocess_polys)
         pre = _ptr_array(pp.preprocess_polys)
         prm.d_preprocess_polys = C.cast(pre, C.POINTER(C.c_void_p))
-        prm.num_witness_polys = info.num_witness_polys[0]
-        prm.num_challenges = info.num_challenges[0]
+        prm.num_witness_polys = sum(info.num_witness_polys)
+        prm.num_challenges = sum(info.num_challenges)
         lookups = (_ffi.lh_hp_lookup * max(len(info.lookups), 1))()
         for k, lookup in enumerate(info.lookups):
             ins = (_ffi.lh_expr * len(lookup))()
@@ -182,8 +185,38 @@ class HyperPlonk:
         prm.expression = ce
         inst_arrays = [_fr_array(i) for i in instances]
         inst = (C.POINTER(lh_fr) * max(len(instances), 1))(*[C.cast(a, C.POINTER(lh_fr)) for a in inst_arrays])
-        wit = _ptr_array(witness_polys)
         from . import ZeromorphProverParam
+        if multi:
+            if isinstance(pp.pcs, ZeromorphProverParam):
+                raise NotImplementedError("multi-phase circuits are wired for multilinear KZG")
+            from . import fr_from_bytes
+            alive, failure = [], []
+
+            def synth(_user, rnd, challenges, num_ch, d_out, num_out):
+                try:
+                    ch = [fr_from_bytes(bytes(challenges[i])) for i in range(num_ch)]
+                    polys = list(witness_polys(rnd, ch))
+                    if len(polys) != num_out:
+                        return _ffi.LH_ERR_ARG
+                    alive.append(polys)  # the tables must outlive the prove
+                    for i, p in enumerate(polys):
+                        d_out[i] = p.ptr
+                    return 0
+                except Exception as e:  # surfaces as the prove's error
+                    failure.append(e)
+                    return _ffi.LH_ERR_INVALID_SNARK
+            circ = _ffi.lh_hp_circuit()
+            circ.user, circ.synthesize = None, _ffi._SYNTH_CB(synth)
+            nph = len(info.num_witness_polys)
+            nw = (C.c_size_t * max(nph, 1))(*info.num_witness_polys)
+            nc = (C.c_size_t * max(nph, 1))(*info.num_challenges)
+            rc = ctx.lib.lh_hyperplonk_prove_phases(ctx.h, pp.pcs.h, C.byref(prm), nph, nw, nc, inst, C.byref(circ),
+                                                    transcript.p)
+            if failure:
+                raise failure[0]
+            _check(rc)
+            return
+        wit = _ptr_array(witness_polys)
         if isinstance(pp.pcs, ZeromorphProverParam):
             _check(ctx.lib.lh_hyperplonk_prove_zeromorph(ctx.h, pp.pcs.params.h, pp.pcs.poly_size, C.byref(prm), inst, wit,
                                                          transcript.p))
@@ -195,8 +228,6 @@ class HyperPlonk:
         """hyperplonk.rs:293-362 (host only).  Raises InvalidSumcheck / InvalidSnark / InvalidPcsOpen."""
         from . import _check, _fr_array, _g1_array, lh_fr
         info = vp.info
-        if len(info.num_witness_polys) != 1:
-            raise NotImplementedError("multi-phase circuits")
         if [len(i) for i in instances] != list(info.num_instances):
             raise AssertionError("instances do not match num_instances")  # assert_eq! hyperplonk.rs:300
         prm = _ffi.lh_hp_vparam()
@@ -204,7 +235,7 @@ class HyperPlonk:
         prm.num_instance_polys = len(info.num_instances)
         ni = (C.c_size_t * max(len(info.num_instances), 1))(*info.num_instances)
         prm.num_instances = ni
-        prm.num_witness_polys, prm.num_challenges = info.num_witness_polys[0], info.num_challenges[0]
+        prm.num_witness_polys, prm.num_challenges = sum(info.num_witness_polys), sum(info.num_challenges)
         prm.num_lookups, prm.num_permutation_z_polys = len(info.lookups), vp.num_permutation_z_polys
         ce, knodes = vp.expression.to_c()
         prm.expression = ce
@@ -214,6 +245,14 @@ class HyperPlonk:
         inst_arrays = [_fr_array(i) for i in instances]
         inst = (C.POINTER(lh_fr) * max(len(instances), 1))(*[C.cast(a, C.POINTER(lh_fr)) for a in inst_arrays])
         from . import ZeromorphVerifierParam
+        if len(info.num_witness_polys) != 1:
+            if isinstance(vp.pcs, ZeromorphVerifierParam):
+                raise NotImplementedError("multi-phase circuits are wired for multilinear KZG")
+            nph = len(info.num_witness_polys)
+            nw = (C.c_size_t * max(nph, 1))(*info.num_witness_polys)
+            nc = (C.c_size_t * max(nph, 1))(*info.num_challenges)
+            _check(vp.pcs.lib.lh_hyperplonk_verify_phases(vp.pcs.h, C.byref(prm), nph, nw, nc, inst, transcript.p))
+            return
         fn = vp.pcs.lib.lh_hyperplonk_verify_zeromorph if isinstance(vp.pcs, ZeromorphVerifierParam) \
             else vp.pcs.lib.lh_hyperplonk_verify
         _check(fn(vp.pcs.h, C.byref(prm), inst, transcript.p))

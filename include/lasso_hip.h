@@ -272,7 +272,8 @@ lh_status lh_lasso_prove_sharded(lh_ctx*, const lh_srs*, const lh_lasso_table*, 
                                  const uint32_t* const* d_dims_local, lh_transcript* t);
 
 /* ---------------------------------------------------------------- f1: HyperPlonk with LogUp lookups
- * HyperPlonk::prove (backend/hyperplonk.rs:164-291) for single-phase circuits: instance hashing and
+ * HyperPlonk::prove (backend/hyperplonk.rs:164-291), single-phase form (lh_hyperplonk_prove_phases below runs the
+ * phase loop with a synthesize callback): instance hashing and
  * instance polys (hyperplonk.rs:170-177,365-369), witness commit, lookup_compressed_polys /
  * lookup_m_polys / lookup_h_polys / permutation_z_polys (backend/hyperplonk/prover.rs:50-313), the
  * zero-check sum-check over the composed expression (prover.rs:330-386, preprocessor.rs:25-60), the
@@ -305,6 +306,21 @@ typedef struct lh_hp_param { /* HyperPlonkProverParam (hyperplonk.rs:38-55), dev
  * LH_ERR_INVALID_SNARK "Invalid lookup input" if an input row is not in its table (prover.rs:176). */
 lh_status lh_hyperplonk_prove(lh_ctx*, const lh_srs*, const lh_hp_param*, const lh_fr* const* instances,
                               const lh_fr* const* d_witness_polys, lh_transcript* t);
+
+/* Multi-phase circuits: the phase loop of HyperPlonk::prove (backend/hyperplonk.rs:185-205).  Phase r calls
+ * PlonkishCircuit::synthesize(r, challenges so far) (backend.rs:139) for num_witness_polys[r] polys, commits them and
+ * squeezes num_challenges[r] challenges; Challenge(i) in expressions indexes the concatenation, then beta, gamma, alpha.
+ * The param's num_witness_polys / num_challenges hold the totals over the phases. */
+typedef struct lh_hp_circuit { /* the witness half of `&impl PlonkishCircuit<F>` */
+  void* user;
+  /* fills d_out_polys[0 .. num_out) with DEVICE pointers to 2^num_vars lh_fr tables that stay valid until the prove
+   * returns; `challenges` are those of the earlier phases; returns 0 or a negative lh_status */
+  int (*synthesize)(void* user, size_t round, const lh_fr* challenges, size_t num_challenges,
+                    const void** d_out_polys, size_t num_out);
+} lh_hp_circuit;
+lh_status lh_hyperplonk_prove_phases(lh_ctx*, const lh_srs*, const lh_hp_param*, size_t num_phases,
+                                     const size_t* num_witness_polys, const size_t* num_challenges,
+                                     const lh_fr* const* instances, const lh_hp_circuit* circuit, lh_transcript* t);
 
 /* ---------------------------------------------------------------- f1: verifiers (host only, no GPU, no lh_ctx)
  * The verify half of the trait surface: PolynomialCommitmentScheme::{verify, batch_verify}
@@ -349,6 +365,10 @@ typedef struct lh_hp_vparam { /* HyperPlonkVerifierParam (hyperplonk.rs:57-74) *
 } lh_hp_vparam;
 lh_status lh_hyperplonk_verify(const lh_mkzg_vp*, const lh_hp_vparam*, const lh_fr* const* instances,
                                lh_transcript* t);
+/* multi-phase (hyperplonk.rs:309-316): per phase num_witness_polys[r] commitments are read, num_challenges[r] squeezed */
+lh_status lh_hyperplonk_verify_phases(const lh_mkzg_vp*, const lh_hp_vparam*, size_t num_phases,
+                                      const size_t* num_witness_polys, const size_t* num_challenges,
+                                      const lh_fr* const* instances, lh_transcript* t);
 
 /* ---------------------------------------------------------------- f3: Zeromorph over univariate KZG
  * PolynomialCommitmentScheme for Zeromorph<UnivariateKzg<Bn256>> (pcs/multilinear/zeromorph.rs:67-256 on top of

@@ -167,3 +167,80 @@ def test_hyperplonk_synthetic_circuit_verifies(hl, ctx, pcs, k):
     g_hp.HyperPlonk.prove(pp, circ.instances, circ.d_witness[:2] + [hl.MultilinearPolynomial(ctx, ctx.upload(bad.tobytes()), k)], t)
     with pytest.raises(hl.Error):
         g_hp.HyperPlonk.verify(vp, circ.instances, hl.Keccak256Transcript.from_proof(t.into_proof()))
+
+
+# ------------------------------------------------------------------ multi-phase circuits (hyperplonk.rs:185-205)
+def _two_phase_circuit(mod_ex, mk_info, k, rng, theta_of):
+    """pi | q, q_inst | phase 0: w0, w1 -> challenge theta | phase 1: w2 = w0 + theta * w1 -> challenge (used as a
+    constraint separator).  Constraints: q (w2 - w0 - theta w1), ch1 (w2 - w0 - theta w1) w1, q_inst (w0 - pi); one copy
+    constraint between (w0, row a) and (w2, row b)."""
+    from oracle.pyref import hyperplonk as o_hp
+    n = 1 << k
+    rows = o_hp.row_mapping(k)
+    num_inst = 3
+    instances = [[rng.randrange(P) for _ in range(num_inst)]]
+    q = [rng.randrange(2) for _ in range(n)]
+    q_inst = [0] * n
+    w0 = [rng.randrange(P) for _ in range(n)]
+    w1 = [rng.randrange(P) for _ in range(n)]
+    for i in range(num_inst):
+        q_inst[rows[i]] = 1
+        w0[rows[i]] = instances[0][i]
+    a, b = rows[num_inst], rows[num_inst + 1]   # rows outside the instance rows, never row 0
+    w1[b], w0[b] = 0, w0[a]                      # then w2[b] = w0[b] = w0[a]: the copy holds
+    E = mod_ex
+    pi, pq, pqi, pw0, pw1, pw2 = (E.Polynomial(i) if hasattr(E, "Polynomial") else E.Poly(i) for i in range(6))
+    theta, sep = E.Challenge(0), E.Challenge(1)
+    gate = pw2 - pw0 - theta * pw1
+    constraints = [pq * gate, sep * gate * pw1, pqi * (pw0 - pi)]
+    info = mk_info(k, [num_inst], [q, q_inst], [2, 1], [1, 1], constraints, [], [[(3, a), (5, b)]], None)
+
+    def synthesize(rnd, challenges):
+        if rnd == 0:
+            assert challenges == []
+            return [w0, w1]
+        assert len(challenges) == 1
+        return [[(x + challenges[0] * y) % P for x, y in zip(w0, w1)]]
+    return info, instances, synthesize
+
+
+@pytest.mark.parametrize("num_vars", [3, 5, 9])
+def test_hyperplonk_two_phase_circuit(hl, ctx, num_vars):
+    """the phase loop: synthesize(round, challenges) is called per phase through the C-ABI callback, the second phase's
+    witness depends on the first phase's challenge; bytes equal the oracle's, both verifiers accept, a witness that
+    ignores the challenge is rejected"""
+    from halo2_lasso_amd import hyperplonk as g_hp, expression as g_ex
+    from oracle.pyref import expression as o_ex
+    o_pcs, g_pcs = _setup(hl, ctx, num_vars, 900 + num_vars)
+    o_info, instances, o_synth = _two_phase_circuit(o_ex, o_hp.CircuitInfo, num_vars, random.Random(num_vars), None)
+    g_info, instances2, _ = _two_phase_circuit(g_ex, g_hp.PlonkishCircuitInfo, num_vars, random.Random(num_vars), None)
+    assert instances == instances2
+    o_pp = o_hp.preprocess(o_pcs, o_info)
+    ot = OT()
+    o_hp.prove(o_pp, instances, o_synth, ot)
+    rng = random.Random(900 + num_vars)
+    ss = [rng.randrange(1, P) for _ in range(num_vars)]
+    g_pp, g_vp = g_hp.HyperPlonk.preprocess(g_pcs, g_info, hl.MultilinearKzgVerifierParams.setup(ss))
+    calls = []
+
+    def synth(rnd, challenges):
+        calls.append((rnd, list(challenges)))
+        return [hl.MultilinearPolynomial.new(ctx, w) for w in o_synth(rnd, challenges)]
+    t = hl.Keccak256Transcript()
+    g_hp.HyperPlonk.prove(g_pp, instances, synth, t)
+    proof = t.into_proof()
+    assert [c[0] for c in calls] == [0, 1] and calls[0][1] == [] and len(calls[1][1]) == 1
+    assert proof == ot.into_proof()
+    o_hp.verify(o_pp, instances, OT(proof))
+    g_hp.HyperPlonk.verify(g_vp, instances, hl.Keccak256Transcript.from_proof(proof))
+
+    # a second-phase witness computed with the wrong challenge does not satisfy the circuit
+    def cheat(rnd, challenges):
+        return [hl.MultilinearPolynomial.new(ctx, w) for w in o_synth(rnd, [c + 1 for c in challenges])]
+    t = hl.Keccak256Transcript()
+    g_hp.HyperPlonk.prove(g_pp, instances, cheat, t)
+    with pytest.raises(hl.Error):
+        g_hp.HyperPlonk.verify(g_vp, instances, hl.Keccak256Transcript.from_proof(t.into_proof()))
+    # a synthesize that returns the wrong number of polys is the reference's assert_eq (hyperplonk.rs:198)
+    with pytest.raises(hl.Error):
+        g_hp.HyperPlonk.prove(g_pp, instances, lambda r, ch: [], hl.Keccak256Transcript())

@@ -250,3 +250,31 @@ def test_zeromorph_product_verifier_on_golden(hl):
     assert vals == [evaluate(tabs[p], pts[q]) for p, q in g["pairs"]]
     hl.Zeromorph.batch_verify(vp, nv, comms, pts, [hl.Evaluation(p, q, v) for (p, q), v in zip(g["pairs"], vals)], r)
     assert r.remaining() == 0
+
+
+@pytest.mark.parametrize("num_vars", [3, 5])
+def test_hyperplonk_verify_two_phase_circuit(hl, num_vars):
+    """multi-phase circuits (hyperplonk.rs:309-316): the oracle proves a two-phase circuit whose second-phase witness
+    depends on the first phase's challenge; lh_hyperplonk_verify_phases accepts it and rejects a tampered proof"""
+    from halo2_lasso_amd import hyperplonk as g_hp, expression as g_ex
+    from oracle.pyref import hyperplonk as o_hp, expression as o_ex
+    from test_gpu_hyperplonk import _two_phase_circuit
+    rng = random.Random(900 + num_vars)
+    ss = [rng.randrange(1, P) for _ in range(num_vars)]
+    o_info, instances, synth = _two_phase_circuit(o_ex, o_hp.CircuitInfo, num_vars, random.Random(num_vars), None)
+    o_pp = o_hp.preprocess(o_kzg.setup(ss), o_info)
+    t = OT()
+    o_hp.prove(o_pp, instances, synth, t)
+    proof = t.into_proof()
+    g_info, _, _ = _two_phase_circuit(g_ex, g_hp.PlonkishCircuitInfo, num_vars, random.Random(num_vars), None)
+    vp = g_hp.HyperPlonkVerifierParam()
+    vp.pcs, vp.num_vars, vp.info = hl.MultilinearKzgVerifierParams.setup(ss), num_vars, g_info
+    vp.num_permutation_z_polys, vp.expression = g_hp.compose(g_info)
+    vp.preprocess_comms, vp.permutation_comms = o_pp.preprocess_comms, o_pp.permutation_comms
+    g_hp.HyperPlonk.verify(vp, instances, hl.Keccak256Transcript.from_proof(proof))
+    bad = bytearray(proof)
+    bad[3 * 64 + 40] ^= 1  # inside the m / h / z commitments or the first round message
+    with pytest.raises(hl.Error):
+        g_hp.HyperPlonk.verify(vp, instances, hl.Keccak256Transcript.from_proof(bytes(bad)))
+    with pytest.raises(hl.Error):
+        g_hp.HyperPlonk.verify(vp, [[v + 1 for v in instances[0]]], hl.Keccak256Transcript.from_proof(proof))
