@@ -41,6 +41,20 @@ class lh_expr(C.Structure):
     _fields_ = [("nodes", C.POINTER(lh_expr_node)), ("num_nodes", C.c_size_t)]
 
 
+class lh_lasso_table(C.Structure):
+    _fields_ = [("num_chunks", C.c_uint32), ("chunk_bits", C.c_uint32), ("num_memories", C.c_uint32),
+                ("memory_chunk", C.c_uint32 * LH_LASSO_MAX_MEMORIES),
+                ("memory_subtable", C.c_uint32 * LH_LASSO_MAX_MEMORIES),
+                ("num_terms", C.c_uint32),
+                ("g_coeff", lh_fr * LH_LASSO_MAX_TERMS),
+                ("g_num_factors", C.c_uint8 * LH_LASSO_MAX_TERMS),
+                ("g_factor", (C.c_uint8 * LH_SC_MAX_FACTORS) * LH_LASSO_MAX_TERMS)]
+
+
+class lh_hp_lasso_lookup(C.Structure):
+    _fields_ = [("table", lh_lasso_table), ("output_poly", C.c_size_t), ("chunk_polys", C.c_size_t * LH_LASSO_MAX_CHUNKS)]
+
+
 class lh_hp_lookup(C.Structure):
     _fields_ = [("inputs", C.POINTER(lh_expr)), ("tables", C.POINTER(lh_expr)), ("width", C.c_size_t)]
 
@@ -54,7 +68,8 @@ class lh_hp_param(C.Structure):
                 ("num_permutation_polys", C.c_size_t), ("permutation_poly_index", C.POINTER(C.c_size_t)),
                 ("d_permutation_polys", C.POINTER(C.c_void_p)),
                 ("num_permutation_z_polys", C.c_size_t),
-                ("expression", lh_expr)]
+                ("expression", lh_expr),
+                ("num_lasso_lookups", C.c_size_t), ("lasso_lookups", C.POINTER(lh_hp_lasso_lookup))]
 
 
 _SYNTH_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.POINTER(lh_fr), C.c_size_t, C.POINTER(C.c_void_p), C.c_size_t)
@@ -71,21 +86,12 @@ class lh_hp_vparam(C.Structure):
                 ("num_lookups", C.c_size_t), ("num_permutation_z_polys", C.c_size_t),
                 ("expression", lh_expr),
                 ("num_preprocess_polys", C.c_size_t), ("preprocess_comms", C.POINTER(lh_g1)),
-                ("num_permutation_polys", C.c_size_t), ("permutation_comms", C.POINTER(lh_g1))]
+                ("num_permutation_polys", C.c_size_t), ("permutation_comms", C.POINTER(lh_g1)),
+                ("num_lasso_lookups", C.c_size_t), ("lasso_lookups", C.POINTER(lh_hp_lasso_lookup))]
 
 
 class lh_evaluation(C.Structure):
     _fields_ = [("poly", C.c_uint32), ("point", C.c_uint32), ("value", lh_fr)]
-
-
-class lh_lasso_table(C.Structure):
-    _fields_ = [("num_chunks", C.c_uint32), ("chunk_bits", C.c_uint32), ("num_memories", C.c_uint32),
-                ("memory_chunk", C.c_uint32 * LH_LASSO_MAX_MEMORIES),
-                ("memory_subtable", C.c_uint32 * LH_LASSO_MAX_MEMORIES),
-                ("num_terms", C.c_uint32),
-                ("g_coeff", lh_fr * LH_LASSO_MAX_TERMS),
-                ("g_num_factors", C.c_uint8 * LH_LASSO_MAX_TERMS),
-                ("g_factor", (C.c_uint8 * LH_SC_MAX_FACTORS) * LH_LASSO_MAX_TERMS)]
 
 
 _AG_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)

@@ -216,6 +216,10 @@ struct LassoG {
   const uint32_t* e[LH_LASSO_MAX_MEMORIES];
 };
 void k_lasso_output(Ctx&, const LassoG& g, size_t n, Fr* a);
+// canonical value of every entry as u32; false if an entry is not below 2^bits
+bool k_fr_to_index(Ctx&, const Fr* in, size_t n, uint32_t bits, uint32_t* out);
+// both tables hold Montgomery residues in [0, r): equal values have equal limbs
+bool k_fr_tables_equal(Ctx&, const Fr* a, const Fr* b, size_t n);
 
 // ------------------------------------------------------------------ communicator (comm.cpp)
 void rccl_unique_id(uint8_t out[LH_RCCL_UNIQUE_ID_BYTES]);

@@ -216,6 +216,22 @@ struct LassoPcs {
 };
 LassoPcs lasso_mkzg_pcs(Ctx&, const Srs&);
 LassoPcs lasso_zeromorph_pcs(Ctx&, const USrs&, size_t poly_size);
+// pieces of the argument shared by the standalone prover (lasso.cpp) and HyperPlonk's Lasso lookups (hyperplonk.cpp)
+struct LassoColumns {  // small-valued witness columns as u32 (arena memory of the caller's scope)
+  std::vector<uint32_t*> rts, fcs, E;
+};
+struct LassoClaims {  // points and claimed evaluations that remain to be opened
+  std::vector<HFr> r, r_z, r_N, r_M;
+  HFr v;                  // a(r)
+  std::vector<HFr> e_rz;  // E_i(r_z)
+  std::vector<HFr> ev_n;  // dim_j | read_ts_j | E_i at r_N
+  std::vector<HFr> ev_l;  // final_cts_j at r_M
+};
+void lasso_check_table(const lh_lasso_table& tb);
+LassoColumns lasso_witness_columns(Ctx&, const lh_lasso_table&, size_t n, const uint32_t* const* d_dims, Fr** a_out);
+LassoClaims lasso_argue(Ctx&, const lh_lasso_table&, size_t n, const LassoColumns& w, const uint32_t* const* d_dims,
+                        const Fr* a, const Fr* const* dim_fr, const Fr* const* rts_fr, const Fr* const* E_fr,
+                        const Fr* const* fcs_fr, Transcript& tr, const std::function<void(int)>& lap = nullptr);
 // commitment framing of the Lasso argument: identity mask as one field element, then the non-identity commitments
 void lasso_write_commitments(Transcript& tr, const std::vector<HG1>& comms);
 std::vector<HG1> lasso_read_commitments(Transcript& tr, size_t count);
@@ -242,6 +258,8 @@ void mkzg_batch_verify(const VerifierParams&, size_t num_vars, const HG1* comms,
 std::pair<HFr, std::vector<HFr>> sum_check_verify(int prover_kind, size_t num_vars, size_t degree, const HFr& sum,
                                                   Transcript& tr);
 void lasso_verify(const PcsBatchVerify& batch_verify, const lh_lasso_table& table, size_t num_vars, Transcript& tr);
+// the verifier's side of lasso_argue: Surge and memory-checking identities; claims left to check against commitments
+LassoClaims lasso_check(const lh_lasso_table& table, size_t num_vars, Transcript& tr);
 void hyperplonk_verify(const PcsBatchVerify& batch_verify, const lh_hp_vparam& vp, const HFr* const* instances,
                        Transcript& tr);
 void hyperplonk_verify_phases(const PcsBatchVerify& batch_verify, const lh_hp_vparam& vp,
@@ -252,6 +270,9 @@ void hyperplonk_verify_phases(const PcsBatchVerify& batch_verify, const lh_hp_vp
 // the PolynomialCommitmentScheme the backend is generic over (backend/hyperplonk.rs:76-95)
 struct PcsProver {
   std::function<std::vector<HG1>(const Fr* const* d_polys, size_t num_polys, size_t num_vars)> batch_commit;
+  // bases whose first 2^nv points commit a (zero-padded) table of 2^nv entries: the small-valued Lasso columns are
+  // committed as u32 MSMs against them
+  std::function<const G1Affine*(size_t nv)> commit_bases;
   std::function<void(size_t num_vars, const Fr* const* d_polys, size_t num_polys, const HFr* points, size_t num_points,
                      const lh_evaluation* evals, size_t num_evals, Transcript& tr)>
       batch_open;

@@ -116,6 +116,10 @@ static void compressed_poly(Ctx& c, const lh_expr* exprs, size_t width, const st
 PcsProver mkzg_pcs(Ctx& c, const Srs& srs) {
   PcsProver p;
   p.batch_commit = [&c, &srs](const Fr* const* polys, size_t n, size_t nv) { return mkzg_batch_commit(c, srs, polys, n, nv); };
+  p.commit_bases = [&srs](size_t nv) {
+    LH_REQUIRE(nv <= srs.num_vars, LH_ERR_INVALID_PCS_PARAM, "Too many variates of poly to commit");
+    return srs.eq(nv);
+  };
   p.batch_open = [&c, &srs](size_t nv, const Fr* const* polys, size_t n, const HFr* points, size_t np,
                             const lh_evaluation* evals, size_t ne, Transcript& tr) {
     mkzg_batch_open(c, srs, nv, polys, n, points, np, evals, ne, tr);
@@ -126,6 +130,10 @@ PcsProver zeromorph_pcs(Ctx& c, const USrs& srs, size_t poly_size) {
   PcsProver p;
   p.batch_commit = [&c, &srs, poly_size](const Fr* const* polys, size_t n, size_t nv) {
     return zeromorph_batch_commit(c, srs, poly_size, polys, n, nv);
+  };
+  p.commit_bases = [&srs, poly_size](size_t nv) {
+    LH_REQUIRE(((size_t)1 << nv) <= poly_size, LH_ERR_INVALID_PCS_PARAM, "Too many variates of poly to commit");
+    return (const G1Affine*)srs.d_powers;
   };
   p.batch_open = [&c, &srs, poly_size](size_t nv, const Fr* const* polys, size_t n, const HFr* points, size_t np,
                                        const lh_evaluation* evals, size_t ne, Transcript& tr) {
@@ -244,6 +252,56 @@ void hyperplonk_prove_phases(Ctx& c, const PcsProver& pcs, const lh_hp_param& pp
     std::vector<HG1> comms = pcs.batch_commit(mp.data(), mp.size(), nv);
     tr.write_commitments(comms);
   }
+  // Lasso lookups (oracle/pyref/hyperplonk.py LassoLookup): witness columns from the circuit's chunk polys, the
+  // small-valued columns committed as u32 MSMs, framed with the identity mask
+  struct LassoState {
+    const lh_hp_lasso_lookup* lk;
+    std::vector<uint32_t*> dims;
+    LassoColumns cols;
+    std::vector<const Fr*> dim_fr, rts_fr, E_fr, fcs_fr;  // fcs_fr: 2^nv entries (zero padded), read as l-variable tables too
+  };
+  std::vector<LassoState> lasso(pp.num_lasso_lookups);
+  if (pp.num_lasso_lookups) {
+    LH_REQUIRE(pp.lasso_lookups != nullptr, LH_ERR_ARG, "hyperplonk: lasso_lookups is null");
+    const G1Affine* bases = pcs.commit_bases(nv);
+    std::vector<MsmJob> jobs;
+    for (size_t k = 0; k < pp.num_lasso_lookups; k++) {
+      LassoState& st = lasso[k];
+      st.lk = &pp.lasso_lookups[k];
+      const lh_lasso_table& tb = st.lk->table;
+      lasso_check_table(tb);
+      const size_t cc = tb.num_chunks, l = tb.chunk_bits, alpha = tb.num_memories, M = (size_t)1 << l;
+      if (l > nv) throw Error(LH_ERR_INVALID_SNARK, "Lasso subtable larger than the circuit");
+      LH_REQUIRE(st.lk->output_poly < polys.size(), LH_ERR_ARG, "hyperplonk: lasso output poly out of range");
+      st.dims.resize(cc);
+      for (size_t j = 0; j < cc; j++) {
+        LH_REQUIRE(st.lk->chunk_polys[j] < polys.size(), LH_ERR_ARG, "hyperplonk: lasso chunk poly out of range");
+        st.dim_fr.push_back(polys[st.lk->chunk_polys[j]]);
+        st.dims[j] = c.arena.alloc_n<uint32_t>(n);
+        if (!k_fr_to_index(c, st.dim_fr[j], n, (uint32_t)l, st.dims[j]))
+          throw Error(LH_ERR_INVALID_SNARK, "Invalid lookup input");
+      }
+      Fr* a = nullptr;
+      st.cols = lasso_witness_columns(c, tb, nv, st.dims.data(), &a);
+      if (!k_fr_tables_equal(c, a, polys[st.lk->output_poly], n))
+        throw Error(LH_ERR_INVALID_SNARK, "Invalid lookup input");
+      auto fr_view = [&](const uint32_t* src, size_t len) {
+        Fr* d = c.arena.alloc_n<Fr>(n);
+        k_fr_from_u32(c, src, len, d);
+        if (len < n) LH_HIP(hipMemsetAsync(d + len, 0, (n - len) * sizeof(Fr), c.stream));
+        return (const Fr*)d;
+      };
+      for (size_t j = 0; j < cc; j++) st.rts_fr.push_back(fr_view(st.cols.rts[j], n));
+      for (size_t i = 0; i < alpha; i++) st.E_fr.push_back(fr_view(st.cols.E[i], n));
+      for (size_t j = 0; j < cc; j++) st.fcs_fr.push_back(fr_view(st.cols.fcs[j], M));
+      for (size_t j = 0; j < cc; j++) jobs.push_back(MsmJob{st.cols.rts[j], true, bases, n});
+      for (size_t i = 0; i < alpha; i++) jobs.push_back(MsmJob{st.cols.E[i], true, bases, n});
+      for (size_t j = 0; j < cc; j++) jobs.push_back(MsmJob{st.cols.fcs[j], true, bases, M});
+    }
+    std::vector<HG1> comms(jobs.size());
+    msm_batch(c, jobs.data(), jobs.size(), (G1Affine*)comms.data());
+    lasso_write_commitments(tr, comms);
+  }
 
   pt.lap("lookup compressed + m + commit");
   // round n+1: gamma, lookup h polys and permutation z polys
@@ -322,6 +380,39 @@ void hyperplonk_prove_phases(Ctx& c, const PcsProver& pcs, const lh_hp_param& pp
   }
   tr.write_field_elements(eval_values);
   pt.lap("rotation evaluations");
+  // Lasso lookups: the argument itself, then its claims join the one batch opening
+  for (LassoState& st : lasso) {
+    const lh_lasso_table& tb = st.lk->table;
+    const size_t cc = tb.num_chunks, l = tb.chunk_bits, alpha = tb.num_memories;
+    tr.common_field_element(HFr::from_u64(nv));
+    tr.common_field_element(HFr::from_u64(l));
+    tr.common_field_element(HFr::from_u64(cc));
+    tr.common_field_element(HFr::from_u64(alpha));
+    LassoClaims cl = lasso_argue(c, tb, nv, st.cols, st.dims.data(), polys[st.lk->output_poly], st.dim_fr.data(),
+                                 st.rts_fr.data(), st.E_fr.data(), st.fcs_fr.data(), tr);
+    const size_t base = polys.size(), p0 = num_points;
+    for (const Fr* p : st.rts_fr) polys.push_back(p);
+    for (const Fr* p : st.E_fr) polys.push_back(p);
+    for (const Fr* p : st.fcs_fr) polys.push_back(p);
+    for (const std::vector<HFr>* ptv : {&cl.r, &cl.r_z, &cl.r_N, &cl.r_M}) {
+      points.insert(points.end(), ptv->begin(), ptv->end());
+      points.insert(points.end(), nv - ptv->size(), HFr::zero());
+    }
+    num_points += 4;
+    auto push = [&](size_t poly, size_t point, const HFr& val) {
+      lh_evaluation e;
+      e.poly = (uint32_t)poly, e.point = (uint32_t)point;
+      memcpy(&e.value, &val, 32);
+      evals.push_back(e);
+    };
+    push(st.lk->output_poly, p0, cl.v);
+    for (size_t i = 0; i < alpha; i++) push(base + cc + i, p0 + 1, cl.e_rz[i]);
+    for (size_t j = 0; j < cc; j++) push(st.lk->chunk_polys[j], p0 + 2, cl.ev_n[j]);
+    for (size_t j = 0; j < cc; j++) push(base + j, p0 + 2, cl.ev_n[cc + j]);
+    for (size_t i = 0; i < alpha; i++) push(base + cc + i, p0 + 2, cl.ev_n[2 * cc + i]);
+    for (size_t j = 0; j < cc; j++) push(base + cc + alpha + j, p0 + 3, cl.ev_l[j]);
+  }
+  if (!lasso.empty()) pt.lap("lasso lookups");
   pcs.batch_open(nv, polys.data(), polys.size(), points.data(), num_points, evals.data(), evals.size(), tr);
   pt.lap("batch open");
 }

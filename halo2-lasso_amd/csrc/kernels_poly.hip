@@ -629,6 +629,48 @@ void k_lasso_subtable_read(Ctx& c, int subtable, uint32_t chunk_bits, const uint
   if (n) hipLaunchKernelGGL(lasso_subtable_read_kernel, grid_for(n), 256, 0, c.stream, subtable, chunk_bits, dim, n, e);
 }
 
+// HyperPlonk's Lasso lookups take their chunk columns from the circuit's (field-element) polys: canonical value of
+// every entry as u32; `bad` is raised by an entry that is not an index of the 2^bits-entry subtable
+__global__ void fr_to_index_kernel(const Fr* __restrict__ in, size_t n, uint32_t bits, uint32_t* __restrict__ out,
+                                   uint32_t* __restrict__ bad) {
+  GSTRIDE(i, n) {
+    const Fr v = from_mont(in[i]);
+    uint32_t hi = 0;
+#pragma unroll
+    for (int k = 1; k < 8; k++) hi |= v.l[k];
+    if (hi || (bits < 32 && (v.l[0] >> bits))) atomicOr(bad, 1u);
+    out[i] = v.l[0];
+  }
+}
+bool k_fr_to_index(Ctx& c, const Fr* in, size_t n, uint32_t bits, uint32_t* out) {
+  ArenaScope scope(c.arena);
+  uint32_t* bad = c.arena.alloc_n<uint32_t>(1);
+  LH_HIP(hipMemsetAsync(bad, 0, 4, c.stream));
+  if (n) hipLaunchKernelGGL(fr_to_index_kernel, grid_for(n), 256, 0, c.stream, in, n, bits, out, bad);
+  uint32_t h = 0;
+  c.d2h(&h, bad, 4);
+  return h == 0;
+}
+__global__ void fr_tables_equal_kernel(const Fr* __restrict__ a, const Fr* __restrict__ b, size_t n,
+                                       uint32_t* __restrict__ bad) {
+  GSTRIDE(i, n) {
+    const Fr x = a[i], y = b[i];
+    uint32_t d = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) d |= x.l[k] ^ y.l[k];
+    if (d) atomicOr(bad, 1u);
+  }
+}
+bool k_fr_tables_equal(Ctx& c, const Fr* a, const Fr* b, size_t n) {
+  ArenaScope scope(c.arena);
+  uint32_t* bad = c.arena.alloc_n<uint32_t>(1);
+  LH_HIP(hipMemsetAsync(bad, 0, 4, c.stream));
+  if (n) hipLaunchKernelGGL(fr_tables_equal_kernel, grid_for(n), 256, 0, c.stream, a, b, n, bad);
+  uint32_t h = 0;
+  c.d2h(&h, bad, 4);
+  return h == 0;
+}
+
 __global__ void lasso_output_kernel(LassoG g, size_t n, Fr* __restrict__ a) {
   GSTRIDE(i, n) {
     Fr acc = Fr::zero();

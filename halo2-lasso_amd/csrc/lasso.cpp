@@ -63,18 +63,13 @@ std::vector<HG1> lasso_read_commitments(Transcript& tr, size_t count) {
   return comms;
 }
 
-void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n, const uint32_t* const* d_dims,
-                 Transcript& tr) {
+void lasso_check_table(const lh_lasso_table& tb) {
   const size_t cc = tb.num_chunks, l = tb.chunk_bits, alpha = tb.num_memories;
   LH_REQUIRE(cc >= 1 && cc <= LH_LASSO_MAX_CHUNKS, LH_ERR_ARG, "lasso: bad num_chunks");
   LH_REQUIRE(alpha >= 1 && alpha <= LH_LASSO_MAX_MEMORIES, LH_ERR_ARG, "lasso: bad num_memories");
   LH_REQUIRE(8 * alpha + 1 <= (size_t)SC_MAX_TABLES, LH_ERR_ARG, "lasso: too many memories for one GKR batch");
-  LH_REQUIRE(n >= 1 && l >= 1 && l < 31 && n < 31, LH_ERR_ARG, "lasso: need at least one variable");
+  LH_REQUIRE(l >= 1 && l < 31, LH_ERR_ARG, "lasso: need at least one variable");
   LH_REQUIRE(tb.num_terms >= 1 && tb.num_terms <= LH_LASSO_MAX_TERMS, LH_ERR_ARG, "lasso: bad g term count");
-  if (n > pcs.max_vars || l > pcs.max_vars)
-    throw Error(LH_ERR_INVALID_PCS_PARAM, "Too many variates of poly to commit");
-  // every committed poly is zero-padded to nv = max(n, l) variables (spec step 1)
-  const size_t nv = std::max(n, l), NV = (size_t)1 << nv;
   for (size_t i = 0; i < alpha; i++) {
     LH_REQUIRE(tb.memory_chunk[i] < cc, LH_ERR_ARG, "lasso: memory chunk out of range");
     LH_REQUIRE(tb.memory_subtable[i] <= LH_SUBTABLE_XOR, LH_ERR_ARG, "lasso: unknown subtable");
@@ -86,6 +81,116 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
     for (int k = 0; k < tb.g_num_factors[m]; k++)
       LH_REQUIRE(tb.g_factor[m][k] < alpha, LH_ERR_ARG, "lasso: g factor out of range");
   }
+}
+
+// witness: access counters, subtable reads and (optionally) the lookup outputs a = g(E); arena memory of the caller's scope
+LassoColumns lasso_witness_columns(Ctx& c, const lh_lasso_table& tb, size_t n, const uint32_t* const* d_dims, Fr** a_out) {
+  const size_t cc = tb.num_chunks, l = tb.chunk_bits, alpha = tb.num_memories;
+  const size_t N = (size_t)1 << n, M = (size_t)1 << l;
+  LassoColumns w;
+  w.rts.resize(cc), w.fcs.resize(cc), w.E.resize(alpha);
+  for (size_t j = 0; j < cc; j++) {
+    w.rts[j] = c.arena.alloc_n<uint32_t>(N);
+    w.fcs[j] = c.arena.alloc_n<uint32_t>(M);
+    k_lasso_counters(c, d_dims[j], N, M, w.rts[j], w.fcs[j]);
+  }
+  LassoG g;
+  memset(&g, 0, sizeof(g));
+  for (size_t i = 0; i < alpha; i++) {
+    w.E[i] = c.arena.alloc_n<uint32_t>(N);
+    k_lasso_subtable_read(c, (int)tb.memory_subtable[i], (uint32_t)l, d_dims[tb.memory_chunk[i]], N, w.E[i]);
+    g.e[i] = w.E[i];
+  }
+  if (a_out) {
+    g.num_terms = tb.num_terms;
+    for (uint32_t m = 0; m < tb.num_terms; m++) {
+      memcpy(&g.coeff[m], &tb.g_coeff[m], 32);
+      g.nfac[m] = tb.g_num_factors[m];
+      for (int k = 0; k < LH_SC_MAX_FACTORS; k++) g.fac[m][k] = tb.g_factor[m][k];
+    }
+    *a_out = c.arena.alloc_n<Fr>(N);
+    k_lasso_output(c, g, N, *a_out);
+  }
+  return w;
+}
+
+// Steps 2-7 of the argument (oracle/pyref/lasso.py argue): Surge sum-check, memory-checking grand products,
+// evaluations.  The Fr tables hold at least 2^n (fcs_fr: 2^l) entries; `lap` (optional) receives phase boundaries.
+LassoClaims lasso_argue(Ctx& c, const lh_lasso_table& tb, size_t n, const LassoColumns& w, const uint32_t* const* d_dims,
+                        const Fr* a, const Fr* const* dim_fr, const Fr* const* rts_fr, const Fr* const* E_fr,
+                        const Fr* const* fcs_fr, Transcript& tr, const std::function<void(int)>& lap) {
+  const size_t cc = tb.num_chunks, l = tb.chunk_bits, alpha = tb.num_memories;
+  const size_t N = (size_t)1 << n, M = (size_t)1 << l;
+  LassoClaims cl;
+  // ---- 2-4: Surge primary sum-check
+  cl.r = tr.squeeze_challenges(n);
+  cl.v = evaluate_polys(c, &a, 1, n, cl.r.data())[0];
+  tr.write_field_element(cl.v);
+  lh_sop surge;
+  memset(&surge, 0, sizeof(surge));
+  surge.global_eq = 0;
+  surge.num_terms = tb.num_terms;
+  for (uint32_t m = 0; m < tb.num_terms; m++) {
+    surge.coeff[m] = tb.g_coeff[m];
+    surge.num_factors[m] = tb.g_num_factors[m];
+    for (int k = 0; k < LH_SC_MAX_FACTORS; k++) surge.factor[m][k] = tb.g_factor[m][k];
+  }
+  SumCheckResult sc = sum_check_prove(c, LH_SC_EVALUATIONS, n, surge, E_fr, alpha, cl.r.data(), 1, cl.v, tr);
+  cl.r_z = sc.challenges;
+  cl.e_rz = sc.evals;
+  tr.write_field_elements(sc.evals);
+  if (lap) lap(2);
+
+  // ---- 5/6: memory-checking fingerprints and product trees
+  HFr gamma = tr.squeeze_challenge();
+  HFr tau = tr.squeeze_challenge();
+  HFr gamma2 = gamma * gamma;
+  {
+    ArenaScope scope(c.arena);
+    std::vector<const Fr*> leaves(4 * alpha);
+    std::vector<size_t> depths(4 * alpha);
+    for (size_t i = 0; i < alpha; i++) {
+      size_t j = tb.memory_chunk[i];
+      Fr* rs = c.arena.alloc_n<Fr>(N);
+      Fr* ws = c.arena.alloc_n<Fr>(N);
+      Fr* in = c.arena.alloc_n<Fr>(M);
+      Fr* fi = c.arena.alloc_n<Fr>(M);
+      k_lasso_rw_leaves(c, d_dims[j], w.E[i], w.rts[j], N, dev(gamma), dev(gamma2), dev(tau), rs, ws);
+      k_lasso_if_leaves(c, (int)tb.memory_subtable[i], (uint32_t)l, w.fcs[j], M, dev(gamma), dev(gamma2), dev(tau), in, fi);
+      leaves[2 * i] = rs, leaves[2 * i + 1] = ws;
+      leaves[2 * alpha + 2 * i] = in, leaves[2 * alpha + 2 * i + 1] = fi;
+      depths[2 * i] = depths[2 * i + 1] = n;
+      depths[2 * alpha + 2 * i] = depths[2 * alpha + 2 * i + 1] = l;
+    }
+    if (lap) lap(3);
+    GrandProductResult gp = prove_grand_product(c, 4 * alpha, leaves.data(), depths.data(), tr);
+    cl.r_N = gp.points[0];
+    cl.r_M = gp.points[2 * alpha];
+  }
+  if (lap) lap(4);
+
+  // ---- 7: evaluations at r_N / r_M: dim | read_ts | E, then final_cts
+  std::vector<const Fr*> at_n;
+  for (size_t j = 0; j < cc; j++) at_n.push_back(dim_fr[j]);
+  for (size_t j = 0; j < cc; j++) at_n.push_back(rts_fr[j]);
+  for (size_t i = 0; i < alpha; i++) at_n.push_back(E_fr[i]);
+  cl.ev_n = evaluate_polys(c, at_n.data(), at_n.size(), n, cl.r_N.data());
+  cl.ev_l = evaluate_polys(c, fcs_fr, cc, l, cl.r_M.data());
+  tr.write_field_elements(cl.ev_n);
+  tr.write_field_elements(cl.ev_l);
+  if (lap) lap(5);
+  return cl;
+}
+
+void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n, const uint32_t* const* d_dims,
+                 Transcript& tr) {
+  lasso_check_table(tb);
+  const size_t cc = tb.num_chunks, l = tb.chunk_bits, alpha = tb.num_memories;
+  LH_REQUIRE(n >= 1 && n < 31, LH_ERR_ARG, "lasso: need at least one variable");
+  if (n > pcs.max_vars || l > pcs.max_vars)
+    throw Error(LH_ERR_INVALID_PCS_PARAM, "Too many variates of poly to commit");
+  // every committed poly is zero-padded to nv = max(n, l) variables (spec step 1)
+  const size_t nv = std::max(n, l), NV = (size_t)1 << nv;
   const size_t N = (size_t)1 << n, M = (size_t)1 << l;
   double t0 = now_ms(), t_prev = t0;
   double* ph = c.lasso_ms;
@@ -98,29 +203,10 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
 
   ArenaScope scope(c.arena);
   // ---- witness: counters, subtable reads, lookup outputs
-  std::vector<uint32_t*> rts(cc), fcs(cc), E(alpha);
-  for (size_t j = 0; j < cc; j++) {
-    rts[j] = c.arena.alloc_n<uint32_t>(N);
-    fcs[j] = c.arena.alloc_n<uint32_t>(M);
-    k_lasso_counters(c, d_dims[j], N, M, rts[j], fcs[j]);
-  }
-  LassoG g;
-  memset(&g, 0, sizeof(g));
-  for (size_t i = 0; i < alpha; i++) {
-    E[i] = c.arena.alloc_n<uint32_t>(N);
-    k_lasso_subtable_read(c, (int)tb.memory_subtable[i], (uint32_t)l, d_dims[tb.memory_chunk[i]], N, E[i]);
-    g.e[i] = E[i];
-  }
-  g.num_terms = tb.num_terms;
-  for (uint32_t m = 0; m < tb.num_terms; m++) {
-    memcpy(&g.coeff[m], &tb.g_coeff[m], 32);
-    g.nfac[m] = tb.g_num_factors[m];
-    for (int k = 0; k < LH_SC_MAX_FACTORS; k++) g.fac[m][k] = tb.g_factor[m][k];
-  }
-  Fr* a = c.arena.alloc_n<Fr>(N);
-  k_lasso_output(c, g, N, a);
+  Fr* a = nullptr;
+  LassoColumns w = lasso_witness_columns(c, tb, n, d_dims, &a);
+  std::vector<uint32_t*>&rts = w.rts, &fcs = w.fcs, &E = w.E;
   lap(0);
-
   // ---- 0/1: domain separation + commitments (one batched MSM)
   tr.common_field_element(HFr::from_u64(n));
   tr.common_field_element(HFr::from_u64(l));
@@ -192,55 +278,11 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
   for (size_t i = 0; i < alpha; i++) polys_n[1 + 2 * cc + i] = fr_view(E[i], N);
   const Fr* const* E_fr = polys_n.data() + 1 + 2 * cc;
 
-  // ---- 2-4: Surge primary sum-check
-  std::vector<HFr> r = tr.squeeze_challenges(n);
-  HFr v = evaluate_polys(c, &polys_n[0], 1, n, r.data())[0];
-  tr.write_field_element(v);
-  lh_sop surge;
-  memset(&surge, 0, sizeof(surge));
-  surge.global_eq = 0;
-  surge.num_terms = tb.num_terms;
-  for (uint32_t m = 0; m < tb.num_terms; m++) {
-    surge.coeff[m] = tb.g_coeff[m];
-    surge.num_factors[m] = tb.g_num_factors[m];
-    for (int k = 0; k < LH_SC_MAX_FACTORS; k++) surge.factor[m][k] = tb.g_factor[m][k];
-  }
-  SumCheckResult sc = sum_check_prove(c, LH_SC_EVALUATIONS, n, surge, E_fr, alpha, r.data(), 1, v, tr);
-  const std::vector<HFr>& r_z = sc.challenges;
-  tr.write_field_elements(sc.evals);
-  lap(2);
-
-  // ---- 5/6: memory-checking fingerprints and product trees
-  HFr gamma = tr.squeeze_challenge();
-  HFr tau = tr.squeeze_challenge();
-  HFr gamma2 = gamma * gamma;
-  std::vector<const Fr*> leaves(4 * alpha);
-  std::vector<size_t> depths(4 * alpha);
-  for (size_t i = 0; i < alpha; i++) {
-    size_t j = tb.memory_chunk[i];
-    Fr* rs = c.arena.alloc_n<Fr>(N);
-    Fr* ws = c.arena.alloc_n<Fr>(N);
-    Fr* in = c.arena.alloc_n<Fr>(M);
-    Fr* fi = c.arena.alloc_n<Fr>(M);
-    k_lasso_rw_leaves(c, d_dims[j], E[i], rts[j], N, dev(gamma), dev(gamma2), dev(tau), rs, ws);
-    k_lasso_if_leaves(c, (int)tb.memory_subtable[i], (uint32_t)l, fcs[j], M, dev(gamma), dev(gamma2), dev(tau), in, fi);
-    leaves[2 * i] = rs, leaves[2 * i + 1] = ws;
-    leaves[2 * alpha + 2 * i] = in, leaves[2 * alpha + 2 * i + 1] = fi;
-    depths[2 * i] = depths[2 * i + 1] = n;
-    depths[2 * alpha + 2 * i] = depths[2 * alpha + 2 * i + 1] = l;
-  }
-  lap(3);
-  GrandProductResult gp = prove_grand_product(c, 4 * alpha, leaves.data(), depths.data(), tr);
-  const std::vector<HFr>& r_N = gp.points[0];
-  const std::vector<HFr>& r_M = gp.points[2 * alpha];
-  lap(4);
-
-  // ---- 7: evaluations at r_N / r_M
-  std::vector<HFr> ev_n = evaluate_polys(c, polys_n.data() + 1, 2 * cc + alpha, n, r_N.data());  // dim | rts | E
-  std::vector<HFr> ev_l = evaluate_polys(c, polys_l.data(), cc, l, r_M.data());
-  tr.write_field_elements(ev_n);
-  tr.write_field_elements(ev_l);
-  lap(5);
+  // ---- 2-7: Surge, memory checking, evaluations
+  LassoClaims cl = lasso_argue(c, tb, n, w, d_dims, polys_n[0], polys_n.data() + 1, polys_n.data() + 1 + cc, E_fr,
+                               polys_l.data(), tr, lap);
+  const std::vector<HFr>&r = cl.r, &r_z = cl.r_z, &r_N = cl.r_N, &r_M = cl.r_M, &ev_n = cl.ev_n, &ev_l = cl.ev_l;
+  const HFr& v = cl.v;
 
   // ---- 8: ONE batch opening of all committed polys (nv variables) at r, r_z, r_N, r_M (zero-padded)
   {
@@ -258,7 +300,7 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
       evs.push_back(e);
     };
     push(0, 0, v);
-    for (size_t i = 0; i < alpha; i++) push(1 + 2 * cc + i, 1, sc.evals[i]);
+    for (size_t i = 0; i < alpha; i++) push(1 + 2 * cc + i, 1, cl.e_rz[i]);
     for (size_t j = 0; j < cc; j++) push(1 + j, 2, ev_n[j]);
     for (size_t j = 0; j < cc; j++) push(1 + cc + j, 2, ev_n[cc + j]);
     for (size_t i = 0; i < alpha; i++) push(1 + 2 * cc + i, 2, ev_n[2 * cc + i]);

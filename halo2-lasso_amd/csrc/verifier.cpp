@@ -352,6 +352,8 @@ static HFr rotation_eval(const std::vector<HFr>& x, int rotation, const std::vec
 }
 
 // ------------------------------------------------------------------ HyperPlonk::verify
+static void lasso_verify_check_table(const lh_lasso_table& tb, size_t n);
+
 void hyperplonk_verify(const PcsBatchVerify& batch_verify, const lh_hp_vparam& vp, const HFr* const* instances,
                        Transcript& tr) {
   hyperplonk_verify_phases(batch_verify, vp, {vp.num_witness_polys}, {vp.num_challenges}, instances, tr);
@@ -384,6 +386,19 @@ void hyperplonk_verify_phases(const PcsBatchVerify& batch_verify, const lh_hp_vp
   }
   HFr beta = tr.squeeze_challenge();
   std::vector<HG1> m_comms = tr.read_commitments(vp.num_lookups);
+  // Lasso lookups (oracle/pyref/hyperplonk.py LassoLookup): read_ts | E | final_cts per lookup, identity-mask framing
+  std::vector<HG1> lasso_comms;
+  if (vp.num_lasso_lookups) {
+    LH_REQUIRE(vp.lasso_lookups != nullptr, LH_ERR_ARG, "hyperplonk: lasso_lookups is null");
+    size_t count = 0;
+    for (size_t k = 0; k < vp.num_lasso_lookups; k++) {
+      const lh_hp_lasso_lookup& lk = vp.lasso_lookups[k];
+      lasso_verify_check_table(lk.table, nv);
+      if (lk.table.chunk_bits > nv) throw Error(LH_ERR_INVALID_SNARK, "Lasso subtable larger than the circuit");
+      count += 2 * lk.table.num_chunks + lk.table.num_memories;
+    }
+    lasso_comms = lasso_read_commitments(tr, count);
+  }
   HFr gamma = tr.squeeze_challenge();
   std::vector<HG1> hz_comms = tr.read_commitments(vp.num_lookups + vp.num_permutation_z_polys);
   HFr alpha = tr.squeeze_challenge();
@@ -485,6 +500,40 @@ void hyperplonk_verify_phases(const PcsBatchVerify& batch_verify, const lh_hp_vp
   }
   comms.insert(comms.end(), m_comms.begin(), m_comms.end());
   comms.insert(comms.end(), hz_comms.begin(), hz_comms.end());
+  // Lasso lookups: the argument's checks, then its claims join the one batch verification
+  size_t base = comms.size();
+  comms.insert(comms.end(), lasso_comms.begin(), lasso_comms.end());
+  for (size_t k = 0; k < vp.num_lasso_lookups; k++) {
+    const lh_hp_lasso_lookup& lk = vp.lasso_lookups[k];
+    const lh_lasso_table& tb = lk.table;
+    const size_t cc = tb.num_chunks, l = tb.chunk_bits, alpha = tb.num_memories;
+    const size_t first_committed = vp.num_instance_polys;  // instance polys have no commitment to open
+    LH_REQUIRE(lk.output_poly >= first_committed && lk.output_poly < base, LH_ERR_ARG, "hyperplonk: lasso output poly out of range");
+    for (size_t j = 0; j < cc; j++)
+      LH_REQUIRE(lk.chunk_polys[j] >= first_committed && lk.chunk_polys[j] < base, LH_ERR_ARG,
+                 "hyperplonk: lasso chunk poly out of range");
+    for (size_t v : {nv, l, cc, alpha}) tr.common_field_element(HFr::from_u64(v));
+    LassoClaims cl = lasso_check(tb, nv, tr);
+    const size_t p0 = num_points;
+    for (const std::vector<HFr>* ptv : {&cl.r, &cl.r_z, &cl.r_N, &cl.r_M}) {
+      points.insert(points.end(), ptv->begin(), ptv->end());
+      points.insert(points.end(), nv - ptv->size(), HFr::zero());
+    }
+    num_points += 4;
+    auto push = [&](size_t poly, size_t point, const HFr& val) {
+      lh_evaluation e;
+      e.poly = (uint32_t)poly, e.point = (uint32_t)point;
+      memcpy(&e.value, &val, 32);
+      evals.push_back(e);
+    };
+    push(lk.output_poly, p0, cl.v);
+    for (size_t i = 0; i < alpha; i++) push(base + cc + i, p0 + 1, cl.e_rz[i]);
+    for (size_t j = 0; j < cc; j++) push(lk.chunk_polys[j], p0 + 2, cl.ev_n[j]);
+    for (size_t j = 0; j < cc; j++) push(base + j, p0 + 2, cl.ev_n[cc + j]);
+    for (size_t i = 0; i < alpha; i++) push(base + cc + i, p0 + 2, cl.ev_n[2 * cc + i]);
+    for (size_t j = 0; j < cc; j++) push(base + cc + alpha + j, p0 + 3, cl.ev_l[j]);
+    base += 2 * cc + alpha;
+  }
   batch_verify(nv, comms.data(), comms.size(), points.data(), num_points, evals.data(), evals.size(), tr);
 }
 
@@ -554,7 +603,7 @@ static HFr subtable_mle_eval(uint32_t kind, const std::vector<HFr>& point) {  //
   return acc;
 }
 
-void lasso_verify(const PcsBatchVerify& batch_verify, const lh_lasso_table& tb, size_t n, Transcript& tr) {
+static void lasso_verify_check_table(const lh_lasso_table& tb, size_t n) {
   const size_t c = tb.num_chunks, l = tb.chunk_bits, alpha = tb.num_memories;
   LH_REQUIRE(c >= 1 && c <= LH_LASSO_MAX_CHUNKS && alpha >= 1 && alpha <= LH_LASSO_MAX_MEMORIES &&
                  tb.num_terms <= LH_LASSO_MAX_TERMS,
@@ -565,10 +614,12 @@ void lasso_verify(const PcsBatchVerify& batch_verify, const lh_lasso_table& tb, 
   LH_REQUIRE(tb.num_terms >= 1, LH_ERR_ARG, "lasso: bad g term count");
   for (size_t m = 0; m < tb.num_terms; m++)
     LH_REQUIRE(tb.g_num_factors[m] >= 1 && tb.g_num_factors[m] <= LH_SC_MAX_FACTORS, LH_ERR_ARG, "lasso: bad g term");
-  for (size_t v : {n, l, c, alpha}) tr.common_field_element(HFr::from_u64(v));
-  const size_t nv = std::max(n, l);
-  std::vector<HG1> comms = lasso_read_commitments(tr, 1 + 3 * c + alpha);
+}
 
+// the verifier's side of lasso_argue (oracle/pyref/lasso.py check): reads the messages, checks Surge and the
+// memory-checking identities, returns the points and claimed evaluations left to check against the commitments
+LassoClaims lasso_check(const lh_lasso_table& tb, size_t n, Transcript& tr) {
+  const size_t c = tb.num_chunks, l = tb.chunk_bits, alpha = tb.num_memories;
   auto g_eval = [&](const std::vector<HFr>& vals) {
     HFr acc = HFr::zero();
     for (size_t m = 0; m < tb.num_terms; m++) {
@@ -585,12 +636,13 @@ void lasso_verify(const PcsBatchVerify& batch_verify, const lh_lasso_table& tb, 
   size_t g_degree = 0;
   for (size_t m = 0; m < tb.num_terms; m++) g_degree = std::max<size_t>(g_degree, tb.g_num_factors[m]);
 
-  std::vector<HFr> r = tr.squeeze_challenges(n);
-  HFr v = tr.read_field_element();
-  auto surge = sum_check_verify(LH_SC_EVALUATIONS, n, g_degree + 1, v, tr);
-  const std::vector<HFr>& r_z = surge.second;
-  std::vector<HFr> e_rz = tr.read_field_elements(alpha);
-  if (surge.first != host_eq_xy_eval(r_z.data(), r.data(), n) * g_eval(e_rz))
+  LassoClaims cl;
+  cl.r = tr.squeeze_challenges(n);
+  cl.v = tr.read_field_element();
+  auto surge = sum_check_verify(LH_SC_EVALUATIONS, n, g_degree + 1, cl.v, tr);
+  cl.r_z = surge.second;
+  cl.e_rz = tr.read_field_elements(alpha);
+  if (surge.first != host_eq_xy_eval(cl.r_z.data(), cl.r.data(), n) * g_eval(cl.e_rz))
     throw Error(LH_ERR_INVALID_SNARK, "Surge sum-check final evaluation mismatch");
 
   HFr gamma = tr.squeeze_challenge(), tau = tr.squeeze_challenge();
@@ -604,20 +656,33 @@ void lasso_verify(const PcsBatchVerify& batch_verify, const lh_lasso_table& tb, 
     if (init * ws != rs * fin)
       throw Error(LH_ERR_INVALID_SNARK, "memory " + std::to_string(i) + ": Init*WS != RS*Final");
   }
-  const std::vector<HFr>&r_N = claims[0].point, &r_M = claims[2 * alpha].point;
+  cl.r_N = claims[0].point, cl.r_M = claims[2 * alpha].point;
 
   std::vector<HFr> vals = tr.read_field_elements(3 * c + alpha);
   const HFr *dim_e = &vals[0], *rts_e = &vals[c], *e_e = &vals[2 * c], *fc_e = &vals[2 * c + alpha];
   auto fingerprint = [&](const HFr& a, const HFr& val, const HFr& t) { return a * gamma * gamma + val * gamma + t - tau; };
-  const HFr id_M = identity_eval(r_M), one = HFr::one();
+  const HFr id_M = identity_eval(cl.r_M), one = HFr::one();
   for (size_t i = 0; i < alpha; i++) {
     const size_t j = tb.memory_chunk[i];
     HFr rs = fingerprint(dim_e[j], e_e[i], rts_e[j]);
-    HFr init = fingerprint(id_M, subtable_mle_eval(tb.memory_subtable[i], r_M), HFr::zero());
+    HFr init = fingerprint(id_M, subtable_mle_eval(tb.memory_subtable[i], cl.r_M), HFr::zero());
     if (claims[2 * i].claim != rs || claims[2 * i + 1].claim != rs + one || claims[2 * alpha + 2 * i].claim != init ||
         claims[2 * alpha + 2 * i + 1].claim != init + fc_e[j])
       throw Error(LH_ERR_INVALID_SNARK, "memory " + std::to_string(i) + ": leaf claim mismatch");
   }
+  cl.ev_n.assign(vals.begin(), vals.begin() + 2 * c + alpha);
+  cl.ev_l.assign(vals.begin() + 2 * c + alpha, vals.end());
+  return cl;
+}
+
+void lasso_verify(const PcsBatchVerify& batch_verify, const lh_lasso_table& tb, size_t n, Transcript& tr) {
+  lasso_verify_check_table(tb, n);
+  const size_t c = tb.num_chunks, l = tb.chunk_bits, alpha = tb.num_memories;
+  for (size_t v : {n, l, c, alpha}) tr.common_field_element(HFr::from_u64(v));
+  const size_t nv = std::max(n, l);
+  std::vector<HG1> comms = lasso_read_commitments(tr, 1 + 3 * c + alpha);
+  LassoClaims cl = lasso_check(tb, n, tr);
+  const HFr *dim_e = &cl.ev_n[0], *rts_e = &cl.ev_n[c], *e_e = &cl.ev_n[2 * c], *fc_e = &cl.ev_l[0];
 
   std::vector<lh_evaluation> evals;
   auto push = [&](size_t poly, size_t point, const HFr& val) {
@@ -626,14 +691,14 @@ void lasso_verify(const PcsBatchVerify& batch_verify, const lh_lasso_table& tb, 
     memcpy(&e.value, &val, 32);
     evals.push_back(e);
   };
-  push(0, 0, v);
-  for (size_t i = 0; i < alpha; i++) push(1 + 2 * c + i, 1, e_rz[i]);
+  push(0, 0, cl.v);
+  for (size_t i = 0; i < alpha; i++) push(1 + 2 * c + i, 1, cl.e_rz[i]);
   for (size_t j = 0; j < c; j++) push(1 + j, 2, dim_e[j]);
   for (size_t j = 0; j < c; j++) push(1 + c + j, 2, rts_e[j]);
   for (size_t i = 0; i < alpha; i++) push(1 + 2 * c + i, 2, e_e[i]);
   for (size_t j = 0; j < c; j++) push(1 + 2 * c + alpha + j, 3, fc_e[j]);
   std::vector<HFr> points;
-  const std::vector<HFr>* pts[4] = {&r, &r_z, &r_N, &r_M};
+  const std::vector<HFr>* pts[4] = {&cl.r, &cl.r_z, &cl.r_N, &cl.r_M};
   for (const std::vector<HFr>* pt : pts) {
     points.insert(points.end(), pt->begin(), pt->end());
     points.insert(points.end(), nv - pt->size(), HFr::zero());

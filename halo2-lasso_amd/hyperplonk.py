@@ -22,12 +22,34 @@ class PlonkishCircuitInfo:
         self.num_witness_polys, self.num_challenges = list(num_witness_polys), list(num_challenges)
         self.constraints, self.lookups = list(constraints), [list(l) for l in lookups]
         self.permutations, self.max_degree = [list(c) for c in permutations], max_degree
+        self.lasso_lookups = []  # LassoLookup: lookups proven by the Lasso argument instead of LogUp
 
     def num_poly(self):
         return len(self.num_instances) + len(self.preprocess_polys) + sum(self.num_witness_polys)
 
     def permutation_polys(self):
         return sorted({poly for cycle in self.permutations for poly, _ in cycle})
+
+
+class LassoLookup:
+    """A lookup into a decomposable table (`LassoTable`) proven by the Lasso argument inside HyperPlonk::prove in place of
+    LogUp (include/lasso_hip.h lh_hp_lasso_lookup; specification: oracle/pyref/hyperplonk.py).  On every row the circuit
+    poly `output_poly` holds g(T[dim_0], ..) and `chunk_polys[j]` the chunk index dim_j < 2^l."""
+
+    def __init__(self, table, output_poly, chunk_polys):
+        if len(chunk_polys) != table.c:
+            raise ValueError("expected %d chunk polys" % table.c)
+        self.table, self.output_poly, self.chunk_polys = table, output_poly, list(chunk_polys)
+
+
+def _lasso_lookups_c(info):
+    arr = (_ffi.lh_hp_lasso_lookup * max(len(info.lasso_lookups), 1))()
+    for k, lk in enumerate(info.lasso_lookups):
+        arr[k].table = lk.table.to_c()
+        arr[k].output_poly = lk.output_poly
+        for j, p in enumerate(lk.chunk_polys):
+            arr[k].chunk_polys[j] = p
+    return arr
 
 
 def lookup_constraints(info, beta, gamma):
@@ -183,6 +205,8 @@ class HyperPlonk:
         prm.num_permutation_z_polys = pp.num_permutation_z_polys
         ce, knodes = pp.expression.to_c()
         prm.expression = ce
+        lasso_arr = _lasso_lookups_c(info)
+        prm.num_lasso_lookups, prm.lasso_lookups = len(info.lasso_lookups), lasso_arr
         inst_arrays = [_fr_array(i) for i in instances]
         inst = (C.POINTER(lh_fr) * max(len(instances), 1))(*[C.cast(a, C.POINTER(lh_fr)) for a in inst_arrays])
         from . import ZeromorphProverParam
@@ -239,6 +263,8 @@ class HyperPlonk:
         prm.num_lookups, prm.num_permutation_z_polys = len(info.lookups), vp.num_permutation_z_polys
         ce, knodes = vp.expression.to_c()
         prm.expression = ce
+        lasso_arr = _lasso_lookups_c(info)
+        prm.num_lasso_lookups, prm.lasso_lookups = len(info.lasso_lookups), lasso_arr
         pre, perm = _g1_array(vp.preprocess_comms), _g1_array(vp.permutation_comms)
         prm.num_preprocess_polys, prm.preprocess_comms = len(vp.preprocess_comms), pre
         prm.num_permutation_polys, prm.permutation_comms = len(vp.permutation_comms), perm
@@ -278,3 +304,16 @@ def vanilla_plonk_with_lookup_circuit_info(num_vars, num_instances, preprocess_p
     lookups = [[(q_lookup * w_l, t_l), (q_lookup * w_r, t_r), (q_lookup * w_o, t_o)]]
     return PlonkishCircuitInfo(num_vars, [num_instances], preprocess_polys, [3], [0], [_vanilla_gate(10)], lookups,
                                permutations, 4)
+
+
+def vanilla_plonk_with_lasso_circuit_info(num_vars, num_instances, preprocess_polys, permutations, table):
+    """The BASELINE.json configs[4] stand-in (the reference has no Keccak-f circuit and no Lasso): vanilla gates plus ONE
+    lookup into a decomposable `LassoTable` proven by Lasso.  polys pi | q_l q_r q_m q_o q_c q_lookup | w_l w_r w_o
+    d_0..d_{c-1} a; constraints: the vanilla gate and q_lookup * (w_o - a)."""
+    c = table.c
+    q_lookup = ex.Polynomial(6)
+    w_o, a = ex.Polynomial(9), ex.Polynomial(10 + c)
+    info = PlonkishCircuitInfo(num_vars, [num_instances], preprocess_polys, [4 + c], [0],
+                               [_vanilla_gate(7), q_lookup * (w_o - a)], [], permutations, 4)
+    info.lasso_lookups = [LassoLookup(table, 10 + c, [10 + j for j in range(c)])]
+    return info

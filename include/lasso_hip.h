@@ -286,6 +286,20 @@ typedef struct lh_hp_lookup {
   const lh_expr* tables; /* [width] */
   size_t width;
 } lh_hp_lookup;
+/* A lookup proven by the Lasso argument INSIDE HyperPlonk::prove, in place of LogUp's m / h polys and constraint
+ * (hyperplonk.rs:211-252, preprocessor.rs:79-109) - north_star's "hyperplonk::prover Lasso/Surge memory-check".  The
+ * reference snapshot has no Lasso code; the schedule is specified in oracle/pyref/hyperplonk.py (LassoLookup).
+ * On every row k the circuit poly `output_poly` holds a[k] = g(T_1[dim_1[k]], ..) and `chunk_polys[j]` the chunk
+ * index dim_j[k] < 2^chunk_bits (ordinary circuit polys, normally witness columns tied to the circuit by its own gates;
+ * not instance polys).  The argument adds committed polys read_ts_j | E_i | final_cts_j, numbered after the
+ * permutation z polys; they are committed in round n after the LogUp m commitments (identity-mask framing), the
+ * argument runs after the zero-check, and ONE batch_open serves the zero-check's queries and every Lasso claim.
+ * Requires chunk_bits <= num_vars. */
+typedef struct lh_hp_lasso_lookup {
+  lh_lasso_table table;
+  size_t output_poly;
+  size_t chunk_polys[LH_LASSO_MAX_CHUNKS];
+} lh_hp_lasso_lookup;
 typedef struct lh_hp_param { /* HyperPlonkProverParam (hyperplonk.rs:38-55), device-resident */
   size_t num_vars;
   size_t num_instance_polys;
@@ -301,9 +315,12 @@ typedef struct lh_hp_param { /* HyperPlonkProverParam (hyperplonk.rs:38-55), dev
   const void* const* d_permutation_polys;  /* device lh_fr[2^num_vars] each (preprocessor.rs:172-203) */
   size_t num_permutation_z_polys;
   lh_expr expression;                      /* compose() output (preprocessor.rs:25-60) */
+  size_t num_lasso_lookups;                /* lookups proven by Lasso instead of LogUp (0: none) */
+  const lh_hp_lasso_lookup* lasso_lookups;
 } lh_hp_param;
 /* instances[i]: host, num_instances[i] elements.  d_witness_polys: device tables of the phase.
- * LH_ERR_INVALID_SNARK "Invalid lookup input" if an input row is not in its table (prover.rs:176). */
+ * LH_ERR_INVALID_SNARK "Invalid lookup input" if an input row is not in its table (prover.rs:176), or if a Lasso
+ * lookup's chunk column holds a value >= 2^chunk_bits or its output column is not the table's value. */
 lh_status lh_hyperplonk_prove(lh_ctx*, const lh_srs*, const lh_hp_param*, const lh_fr* const* instances,
                               const lh_fr* const* d_witness_polys, lh_transcript* t);
 
@@ -362,6 +379,8 @@ typedef struct lh_hp_vparam { /* HyperPlonkVerifierParam (hyperplonk.rs:57-74) *
   const lh_g1* preprocess_comms;
   size_t num_permutation_polys;
   const lh_g1* permutation_comms;
+  size_t num_lasso_lookups;
+  const lh_hp_lasso_lookup* lasso_lookups;
 } lh_hp_vparam;
 lh_status lh_hyperplonk_verify(const lh_mkzg_vp*, const lh_hp_vparam*, const lh_fr* const* instances,
                                lh_transcript* t);

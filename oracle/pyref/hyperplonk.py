@@ -12,6 +12,7 @@ from .field import R_MOD as P, batch_invert
 from . import expression as ex
 from . import sum_check as sc
 from . import kzg
+from . import lasso
 from .bh import BooleanHypercube
 from .poly import evaluate as mle_evaluate
 
@@ -29,12 +30,68 @@ class CircuitInfo:
         self.num_witness_polys, self.num_challenges = list(num_witness_polys), list(num_challenges)
         self.constraints, self.lookups = list(constraints), [list(l) for l in lookups]
         self.permutations, self.max_degree = [list(c) for c in permutations], max_degree
+        self.lasso_lookups = []  # LassoLookup: lookups proven by the Lasso argument instead of LogUp (see below)
 
     def num_poly(self):
         return len(self.num_instances) + len(self.preprocess_polys) + sum(self.num_witness_polys)
 
     def permutation_polys(self):
         return sorted({poly for cycle in self.permutations for poly, _ in cycle})
+
+
+class LassoLookup:
+    """A lookup into a decomposable table proven by the Lasso argument (oracle/pyref/lasso.py) inside HyperPlonk::prove,
+    in place of the LogUp m / h polys and constraint of hyperplonk.rs:211-252, preprocessor.rs:79-109 (the reference
+    snapshot has no Lasso code: this schedule is the build's own).  On EVERY row k the circuit's poly `output_poly`
+    holds a[k] = g(T_1[dim_1[k]], ..), the polys `chunk_polys[j]` hold the chunk indices dim_j[k] < 2^l.  These are
+    ordinary circuit polys (normally witness columns, tied to the rest of the circuit by its own gates); the argument
+    adds committed polys read_ts_j, E_i (2^num_vars entries) and final_cts_j (2^l <= 2^num_vars entries, zero padded),
+    numbered after the permutation z polys: per lookup read_ts | E | final_cts.
+
+    Schedule inside prove (hyperplonk.py): the Lasso polys are committed in round n right after the LogUp m
+    commitments, framed with lasso.write_commitments (an identically zero read_ts is a valid witness); after the
+    zero-check and its evaluations each lookup absorbs (num_vars, l, c, alpha) and runs lasso.argue; ONE batch_open
+    then serves the zero-check's queries and every Lasso claim."""
+
+    def __init__(self, spec, output_poly, chunk_polys):
+        assert len(chunk_polys) == spec.c
+        self.spec, self.output_poly, self.chunk_polys = spec, output_poly, list(chunk_polys)
+
+
+def lasso_witnesses(lookups, polys, num_vars):
+    """chunk columns -> Lasso witnesses; a chunk value outside the subtable or an output that is not the table's value
+    is the reference's Error::InvalidSnark("Invalid lookup input") (prover.rs:176-178)"""
+    out = []
+    for lk in lookups:
+        if lk.spec.l > num_vars:
+            raise InvalidSnark("Lasso subtable larger than the circuit")
+        dims = [polys[p] for p in lk.chunk_polys]
+        if any(d >= 1 << lk.spec.l for col in dims for d in col):
+            raise InvalidSnark("Invalid lookup input")
+        w = lasso.witness(lk.spec, dims)
+        if w["a"] != [v % P for v in polys[lk.output_poly]]:
+            raise InvalidSnark("Invalid lookup input")
+        out.append(w)
+    return out
+
+
+def lasso_poly_list(w, num_vars):
+    pad = lambda t: list(t) + [0] * ((1 << num_vars) - len(t))
+    return [pad(t) for t in w["read_ts"] + w["E"] + w["final_cts"]]
+
+
+def lasso_evaluations(lk, base, point_base, vals):
+    """Evaluation claims of one Lasso lookup: polys numbered from `base` (read_ts | E | final_cts), points numbered from
+    `point_base` (r, r_z, r_N, r_M)"""
+    v, e_rz, dim_e, rts_e, e_e, fc_e = vals
+    c, alpha = lk.spec.c, lk.spec.alpha
+    out = [kzg.Evaluation(lk.output_poly, point_base, v)]
+    out += [kzg.Evaluation(base + c + i, point_base + 1, e_rz[i]) for i in range(alpha)]
+    out += [kzg.Evaluation(lk.chunk_polys[j], point_base + 2, dim_e[j]) for j in range(c)]
+    out += [kzg.Evaluation(base + j, point_base + 2, rts_e[j]) for j in range(c)]
+    out += [kzg.Evaluation(base + c + i, point_base + 2, e_e[i]) for i in range(alpha)]
+    out += [kzg.Evaluation(base + c + alpha + j, point_base + 3, fc_e[j]) for j in range(c)]
+    return out
 
 
 def row_mapping(k):
@@ -372,6 +429,7 @@ def preprocess(pcs_pp, info, pcs_mod=None):
         (pp.pcs, pp.pcs_vp), pp.num_vars = pcs_pp, info.k
     pp.num_instances, pp.num_witness_polys, pp.num_challenges = info.num_instances, info.num_witness_polys, info.num_challenges
     pp.lookups = info.lookups
+    pp.lasso_lookups = getattr(info, "lasso_lookups", [])
     pp.preprocess_polys = info.preprocess_polys
     pp.preprocess_comms = [pp.pcs_mod.commit(pp.pcs, p) for p in info.preprocess_polys]
     perm = permutation_polys(info.k, info.permutation_polys(), info.permutations)
@@ -402,6 +460,10 @@ def prove(pp, instances, witness_fn, transcript):
     compressed = lookup_compressed_polys(pp.lookups, polys, challenges, betas)
     m_polys = [lookup_m_poly(c) for c in compressed]
     pp.pcs_mod.batch_commit_and_write(pp.pcs, m_polys, transcript)
+    lasso_w = lasso_witnesses(pp.lasso_lookups, polys, pp.num_vars)
+    lasso_polys = [p for w in lasso_w for p in lasso_poly_list(w, pp.num_vars)]
+    if pp.lasso_lookups:
+        lasso.write_commitments(transcript, [pp.pcs_mod.commit(pp.pcs, p) for p in lasso_polys])
 
     gamma = transcript.squeeze_challenge()
     h_polys = [lookup_h_poly(c, m, gamma) for c, m in zip(compressed, m_polys)]
@@ -413,6 +475,15 @@ def prove(pp, instances, witness_fn, transcript):
     polys = polys + [p for _, p in pp.permutation_polys] + m_polys + h_polys + z_polys
     challenges = challenges + [beta, gamma, alpha]
     pts, evals = prove_sum_check(len(pp.num_instances), pp.expression, 0, polys, challenges, y, transcript)
+    base = len(polys)
+    polys = polys + lasso_polys
+    pad_pt = lambda pt: list(pt) + [0] * (pp.num_vars - len(pt))
+    for lk, w in zip(pp.lasso_lookups, lasso_w):
+        transcript.common_field_elements([pp.num_vars, lk.spec.l, lk.spec.c, lk.spec.alpha])
+        lpts, vals = lasso.argue(lk.spec, w, transcript)
+        evals += lasso_evaluations(lk, base, len(pts), vals)
+        pts += [pad_pt(pt) for pt in lpts]
+        base += 2 * lk.spec.c + lk.spec.alpha
     pp.pcs_mod.batch_open(pp.pcs, pp.num_vars, polys, pts, evals, transcript)
 
 
@@ -442,6 +513,9 @@ def verify(vp, instances, transcript):
         challenges += transcript.squeeze_challenges(nc)
     beta = transcript.squeeze_challenge()
     m_comms = transcript.read_commitments(len(vp.lookups))
+    lasso_lookups = getattr(vp, "lasso_lookups", [])
+    lasso_comms = lasso.read_commitments(transcript, sum(2 * lk.spec.c + lk.spec.alpha for lk in lasso_lookups)) \
+        if lasso_lookups else []
     gamma = transcript.squeeze_challenge()
     hz_comms = transcript.read_commitments(len(vp.lookups) + vp.num_permutation_z_polys)
     alpha = transcript.squeeze_challenge()
@@ -463,7 +537,24 @@ def verify(vp, instances, transcript):
     for (poly, rot), efr in zip(query, evals_for_rotation):
         pcs_evals += [kzg.Evaluation(poly, off[rot] + k, v) for k, v in enumerate(efr)]
     comms = [None] * len(vp.num_instances) + vp.preprocess_comms + witness_comms + vp.permutation_comms + m_comms + hz_comms
-    getattr(vp, 'pcs_mod', kzg).batch_verify(getattr(vp, 'pcs_vp', vp.pcs), vp.num_vars, comms, points(query, x), pcs_evals,
+    pts = points(query, x)
+    base = len(comms)
+    comms = comms + lasso_comms
+    pad_pt = lambda pt: list(pt) + [0] * (vp.num_vars - len(pt))
+    for lk in lasso_lookups:
+        if lk.spec.l > vp.num_vars:
+            raise InvalidSnark("Lasso subtable larger than the circuit")
+        if lk.output_poly < len(vp.num_instances) or any(p < len(vp.num_instances) for p in lk.chunk_polys):
+            raise InvalidSnark("Lasso lookups over instance polys are not supported")  # they have no commitment
+        transcript.common_field_elements([vp.num_vars, lk.spec.l, lk.spec.c, lk.spec.alpha])
+        try:
+            lpts, vals = lasso.check(lk.spec, vp.num_vars, transcript)
+        except lasso.LassoError as e:
+            raise InvalidSnark(str(e))
+        pcs_evals += lasso_evaluations(lk, base, len(pts), vals)
+        pts += [pad_pt(pt) for pt in lpts]
+        base += 2 * lk.spec.c + lk.spec.alpha
+    getattr(vp, 'pcs_mod', kzg).batch_verify(getattr(vp, 'pcs_vp', vp.pcs), vp.num_vars, comms, pts, pcs_evals,
                                              transcript)
     if transcript.pos != len(transcript.stream):
         raise InvalidSnark("trailing bytes in proof")
@@ -577,3 +668,53 @@ def rand_vanilla_plonk_circuit(num_vars, rng):
             polys[poly][idx] = v
     info = vanilla_plonk_circuit_info(num_vars, len(instances), polys[1:6], perm.into_cycles())
     return info, [instances], polys[6:9]
+
+
+def vanilla_plonk_with_lasso_circuit_info(num_vars, num_instances, preprocess_polys, permutations, spec):
+    """The configs[4] stand-in: vanilla gates plus ONE lookup into a decomposable table proven by Lasso.
+    polys pi | q_l q_r q_m q_o q_c q_lookup | w_l w_r w_o d_0..d_{c-1} a; constraints: the vanilla gate and
+    q_lookup * (w_o - a); the Lasso lookup ties a to the chunk columns d_j on every row."""
+    c = spec.c
+    q_lookup = ex.Poly(6)
+    w_o, a = ex.Poly(9), ex.Poly(10 + c)
+    info = CircuitInfo(num_vars, [num_instances], preprocess_polys, [4 + c], [0],
+                       [_vanilla_gate(7), q_lookup * (w_o - a)], [], permutations, 4)
+    info.lasso_lookups = [LassoLookup(spec, 10 + c, [10 + j for j in range(c)])]
+    return info
+
+
+def rand_vanilla_plonk_with_lasso_circuit(num_vars, rng, spec):
+    """-> (CircuitInfo, instances, witness tables [w_l, w_r, w_o, d_0.., a]); about half of the rows are lookups"""
+    size, c = 1 << num_vars, spec.c
+    rf = lambda: rng.randrange(P)
+    polys = [[0] * size for _ in range(11 + c)]
+    instances = [rf() for _ in range(num_vars)]
+    polys[0] = instance_polys(num_vars, [instances])[0]
+    instance_rows = set(BooleanHypercube(num_vars).iter()[:num_vars + 1])
+    perm = _Permutation()
+    for poly in (7, 8, 9):
+        perm.copy((poly, 1), (poly, 1))
+    for idx in range(size - 1):
+        use_copy = rng.getrandbits(1) == 0 and idx > 1
+        if use_copy:
+            l_copy = (rng.randrange(7, 10), rng.randrange(1, idx))
+            r_copy = (rng.randrange(7, 10), rng.randrange(1, idx))
+            perm.copy(l_copy, (7, idx))
+            perm.copy(r_copy, (8, idx))
+            w_l, w_r = polys[l_copy[0]][l_copy[1]], polys[r_copy[0]][r_copy[1]]
+        else:
+            w_l, w_r = rf(), rf()
+        q_c = rf()
+        if use_copy or idx in instance_rows or rng.getrandbits(1) == 0:
+            if rng.getrandbits(1) == 0:
+                vals = [(1, 1), (2, 1), (4, P - 1), (5, q_c), (7, w_l), (8, w_r), (9, (w_l + w_r + q_c + polys[0][idx]) % P)]
+            else:
+                vals = [(3, 1), (4, P - 1), (5, q_c), (7, w_l), (8, w_r), (9, (w_l * w_r + q_c + polys[0][idx]) % P)]
+        else:  # a lookup row: w_o is the table's value at the chunk indices
+            dims = [rng.randrange(1 << spec.l) for _ in range(c)]
+            out = spec.g_eval([lasso.subtable_entry(kind, dims[j], spec.l) for j, kind in spec.memories])
+            vals = [(6, 1), (7, w_l), (8, w_r), (9, out), (10 + c, out)] + [(10 + j, dims[j]) for j in range(c)]
+        for poly, v in vals:
+            polys[poly][idx] = v
+    info = vanilla_plonk_with_lasso_circuit_info(num_vars, len(instances), polys[1:7], perm.into_cycles(), spec)
+    return info, [instances], polys[7:]

@@ -175,19 +175,14 @@ def _trim(pcs, p, nv):
     return p.trim(nv) if pcs is kzg else p
 
 
-def prove(pp, spec, dims, transcript, pcs=kzg):
-    """pcs: `kzg` (pp = its Params) or `zeromorph` (pp = a trimmed ProverParam covering 2^max(n, l) coefficients)"""
+def argue(spec, w, transcript):
+    """Steps 2-7 of the argument, everything between the commitments and the opening: Surge sum-check, memory-checking
+    grand products, evaluations.  `w`: the witness dict (a, dim, read_ts, E, final_cts; unpadded).  Returns the four
+    points and the claimed evaluations; the caller opens them (standalone: `prove`; inside HyperPlonk:
+    oracle/pyref/hyperplonk.py, where a and dim are witness columns of the circuit)."""
     c, l, alpha = spec.c, spec.l, spec.alpha
-    N, M = len(dims[0]), 1 << l
+    N, M = len(w["a"]), 1 << l
     n = N.bit_length() - 1
-    assert N == 1 << n and all(len(d) == N for d in dims) and len(dims) == c
-    _check_shape(spec, n)
-    w = witness(spec, dims)
-    transcript.common_field_elements([n, l, c, alpha])
-    nv = max(n, l)
-    polys = [_pad(p, nv) for p in [w["a"]] + w["dim"] + w["read_ts"] + w["E"] + w["final_cts"]]
-    write_commitments(transcript, [pcs.commit(_trim(pcs, pp, nv), p) for p in polys])
-
     r = transcript.squeeze_challenges(n)
     v = evaluate(w["a"], r)
     transcript.write_field_element(v)
@@ -214,9 +209,25 @@ def prove(pp, spec, dims, transcript, pcs=kzg):
     e_e = [evaluate(t, r_N) for t in w["E"]]
     fc_e = [evaluate(t, r_M) for t in w["final_cts"]]
     transcript.write_field_elements(dim_e + rts_e + e_e + fc_e)
+    return (r, r_z, r_N, r_M), (v, e_rz, dim_e, rts_e, e_e, fc_e)
 
-    evals = _evals(spec, v, e_rz, dim_e, rts_e, e_e, fc_e)
-    points = [_pad_point(pt, nv) for pt in (r, r_z, r_N, r_M)]
+
+def prove(pp, spec, dims, transcript, pcs=kzg):
+    """pcs: `kzg` (pp = its Params) or `zeromorph` (pp = a trimmed ProverParam covering 2^max(n, l) coefficients)"""
+    c, l, alpha = spec.c, spec.l, spec.alpha
+    N = len(dims[0])
+    n = N.bit_length() - 1
+    assert N == 1 << n and all(len(d) == N for d in dims) and len(dims) == c
+    _check_shape(spec, n)
+    w = witness(spec, dims)
+    transcript.common_field_elements([n, l, c, alpha])
+    nv = max(n, l)
+    polys = [_pad(p, nv) for p in [w["a"]] + w["dim"] + w["read_ts"] + w["E"] + w["final_cts"]]
+    write_commitments(transcript, [pcs.commit(_trim(pcs, pp, nv), p) for p in polys])
+
+    pts, vals = argue(spec, w, transcript)
+    evals = _evals(spec, *vals)
+    points = [_pad_point(pt, nv) for pt in pts]
     pcs.batch_open(_trim(pcs, pp, nv), nv, polys, points, evals, transcript)
     return transcript
 
@@ -241,13 +252,10 @@ def _evals(spec, v, e_rz, dim_e, rts_e, e_e, fc_e):
 
 
 # ------------------------------------------------------------------ verifier
-def verify(vp, spec, n, transcript, pcs=kzg):
+def check(spec, n, transcript):
+    """The verifier's side of `argue`: reads the messages, checks Surge and the memory-checking identities, returns the
+    four points and the claimed evaluations that remain to be checked against the commitments."""
     c, l, alpha = spec.c, spec.l, spec.alpha
-    _check_shape(spec, n)
-    transcript.common_field_elements([n, l, c, alpha])
-    nv = max(n, l)
-    comms = read_commitments(transcript, 1 + 3 * c + alpha)
-
     r = transcript.squeeze_challenges(n)
     v = transcript.read_field_element()
     surge = ex.EqXY(0) * spec.g_expression()
@@ -278,9 +286,18 @@ def verify(vp, spec, n, transcript, pcs=kzg):
                claims[2 * alpha + 2 * i][0], claims[2 * alpha + 2 * i + 1][0]]
         if want != got:
             raise LassoError("memory %d: leaf claim mismatch" % i)
+    return (r, r_z, r_N, r_M), (v, e_rz, dim_e, rts_e, e_e, fc_e)
 
-    evals = _evals(spec, v, e_rz, dim_e, rts_e, e_e, fc_e)
-    points = [_pad_point(pt, nv) for pt in (r, r_z, r_N, r_M)]
+
+def verify(vp, spec, n, transcript, pcs=kzg):
+    c, l, alpha = spec.c, spec.l, spec.alpha
+    _check_shape(spec, n)
+    transcript.common_field_elements([n, l, c, alpha])
+    nv = max(n, l)
+    comms = read_commitments(transcript, 1 + 3 * c + alpha)
+    pts, vals = check(spec, n, transcript)
+    evals = _evals(spec, *vals)
+    points = [_pad_point(pt, nv) for pt in pts]
     pcs.batch_verify(_trim(pcs, vp, nv), nv, comms, points, evals, transcript)
     if transcript.pos != len(transcript.stream):
         raise LassoError("trailing bytes in proof")

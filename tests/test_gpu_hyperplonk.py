@@ -244,3 +244,37 @@ def test_hyperplonk_two_phase_circuit(hl, ctx, num_vars):
     # a synthesize that returns the wrong number of polys is the reference's assert_eq (hyperplonk.rs:198)
     with pytest.raises(hl.Error):
         g_hp.HyperPlonk.prove(g_pp, instances, lambda r, ch: [], hl.Keccak256Transcript())
+
+
+# ------------------------------------------------------------------ Lasso as HyperPlonk's lookup argument
+@pytest.mark.parametrize("kind,c,l,num_vars", [("range", 2, 2, 4), ("and", 2, 4, 5), ("xor", 2, 4, 4), ("range", 2, 4, 4),
+                                               ("and", 4, 4, 7)])
+def test_hyperplonk_with_lasso_lookup(hl, ctx, kind, c, l, num_vars):
+    """north_star's "hyperplonk::prover Lasso/Surge memory-check" (BASELINE.json configs[4] stand-in: vanilla gates plus
+    one lookup into a decomposable table proven by Lasso inside HyperPlonk::prove; specification
+    oracle/pyref/hyperplonk.py LassoLookup): proof bytes equal the oracle's, both verifiers accept, a chunk value outside
+    the subtable or a wrong output is the reference's "Invalid lookup input"."""
+    from halo2_lasso_amd import hyperplonk as g_hp
+    from test_verifier import _lasso_circuit
+    o_pcs, g_pcs = _setup(hl, ctx, num_vars, 300 + num_vars)
+    o_info, g_info, instances, witness = _lasso_circuit(hl, kind, c, l, num_vars, 31 + num_vars)
+    o_pp = o_hp.preprocess(o_pcs, o_info)
+    ot = OT()
+    o_hp.prove(o_pp, instances, lambda r, ch: witness, ot)
+    rng = random.Random(300 + num_vars)
+    ss = [rng.randrange(1, P) for _ in range(num_vars)]
+    g_pp, g_vp = g_hp.HyperPlonk.preprocess(g_pcs, g_info, hl.MultilinearKzgVerifierParams.setup(ss))
+    t = hl.Keccak256Transcript()
+    g_hp.HyperPlonk.prove(g_pp, instances, [hl.MultilinearPolynomial.new(ctx, w) for w in witness], t)
+    proof = t.into_proof()
+    assert proof == ot.into_proof()
+    o_hp.verify(o_pp, instances, OT(proof))
+    g_hp.HyperPlonk.verify(g_vp, instances, hl.Keccak256Transcript.from_proof(proof))
+    # a chunk index outside the subtable / an output that is not the table's value
+    row = [i for i in range(1 << num_vars) if o_info.preprocess_polys[5][i] == 1][0]
+    for col, val in ((3, 1 << l), (len(witness) - 1, (witness[-1][row] + 1) % P)):
+        bad = [list(w) for w in witness]
+        bad[col][row] = val
+        with pytest.raises(hl.InvalidSnark, match="Invalid lookup input"):
+            g_hp.HyperPlonk.prove(g_pp, instances, [hl.MultilinearPolynomial.new(ctx, w) for w in bad],
+                                  hl.Keccak256Transcript())

@@ -45,6 +45,29 @@ WORKER = textwrap.dedent("""
 """) % ROOT
 
 
+def _wait_all(procs, timeout):
+    """Wait for every rank; as soon as one fails the others are stopped (a dead rank leaves its peers in a collective
+    for gloo's 30-minute timeout) and ITS output is reported."""
+    import time
+    deadline = time.time() + timeout
+    while True:
+        codes = [p.poll() for p in procs]
+        failed = [i for i, c in enumerate(codes) if c not in (None, 0)]
+        if failed or all(c == 0 for c in codes) or time.time() > deadline:
+            break
+        time.sleep(0.2)
+    outs = []
+    for i, p in enumerate(procs):
+        if p.poll() is None:
+            p.kill()
+        o, err = p.communicate()
+        outs.append((p.returncode, o, err))
+    for i in failed:
+        raise AssertionError("rank %d failed (rc %s):\n%s" % (i, outs[i][0], outs[i][2][-3000:]))
+    assert all(rc == 0 for rc, _, _ in outs), "timeout: " + " | ".join(e[-600:] for _, _, e in outs)
+    return [json.loads(o.strip().splitlines()[-1]) for _, o, _ in outs]
+
+
 def run_ranks(tmp_path, world, cfg, port):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
@@ -54,12 +77,7 @@ def run_ranks(tmp_path, world, cfg, port):
                    LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, str(script), json.dumps(cfg)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
-    outs = []
-    for p in procs:
-        o, err = p.communicate(timeout=600)
-        assert p.returncode == 0, err[-3000:]
-        outs.append(json.loads(o.strip().splitlines()[-1]))
-    return outs
+    return _wait_all(procs, 600)
 
 
 CASES = [
@@ -186,10 +204,7 @@ def test_sharded_two_gpus_over_rccl(tmp_path):
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29871", WORLD_SIZE="2", RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
-    for p in procs:
-        o, err = p.communicate(timeout=600)
-        assert p.returncode == 0, err[-3000:]
-        out = json.loads(o.strip().splitlines()[-1])
+    for out in _wait_all(procs, 600):
         assert out["same"] and out["stats"]["device"] > 50 and out["stats"]["host"] == 0, out
 
 

@@ -278,3 +278,46 @@ def test_hyperplonk_verify_two_phase_circuit(hl, num_vars):
         g_hp.HyperPlonk.verify(vp, instances, hl.Keccak256Transcript.from_proof(bytes(bad)))
     with pytest.raises(hl.Error):
         g_hp.HyperPlonk.verify(vp, [[v + 1 for v in instances[0]]], hl.Keccak256Transcript.from_proof(proof))
+
+
+LASSO_CIRCUITS = [("range", 2, 2, 4), ("and", 2, 4, 5), ("xor", 2, 4, 4)]
+
+
+def _lasso_circuit(hl, kind, c, l, num_vars, seed):
+    """the configs[4] stand-in circuit (vanilla gates + one Lasso lookup) in the oracle's and the product's description"""
+    from halo2_lasso_amd import hyperplonk as g_hp
+    from oracle.pyref import hyperplonk as o_hp, lasso as o_lasso
+    spec = o_lasso.range_table(c, l) if kind == "range" else o_lasso.bitwise_table(
+        o_lasso.SUBTABLE_AND if kind == "and" else o_lasso.SUBTABLE_XOR, c, l)
+    table = hl.LassoTable.range(c, l) if kind == "range" else hl.LassoTable.bitwise(
+        hl.SUBTABLE_AND if kind == "and" else hl.SUBTABLE_XOR, c, l)
+    o_info, instances, witness = o_hp.rand_vanilla_plonk_with_lasso_circuit(num_vars, random.Random(seed), spec)
+    g_info = g_hp.vanilla_plonk_with_lasso_circuit_info(num_vars, len(instances[0]), o_info.preprocess_polys,
+                                                        o_info.permutations, table)
+    return o_info, g_info, instances, witness
+
+
+@pytest.mark.parametrize("kind,c,l,num_vars", LASSO_CIRCUITS)
+def test_hyperplonk_verify_lasso_lookup(hl, kind, c, l, num_vars):
+    """Lasso as HyperPlonk's lookup argument (specification: oracle/pyref/hyperplonk.py LassoLookup): a proof made by the
+    oracle is accepted by lh_hyperplonk_verify, tampered proofs and wrong instances are rejected"""
+    from halo2_lasso_amd import hyperplonk as g_hp
+    from oracle.pyref import hyperplonk as o_hp
+    rng = random.Random(70 + num_vars)
+    ss = [rng.randrange(1, P) for _ in range(num_vars)]
+    o_info, g_info, instances, witness = _lasso_circuit(hl, kind, c, l, num_vars, 7 + num_vars)
+    o_pp = o_hp.preprocess(o_kzg.setup(ss), o_info)
+    t = OT()
+    o_hp.prove(o_pp, instances, lambda r, ch: witness, t)
+    proof = t.into_proof()
+    o_hp.verify(o_pp, instances, OT(proof))
+    vp = g_hp.HyperPlonkVerifierParam()
+    vp.pcs, vp.num_vars, vp.info = hl.MultilinearKzgVerifierParams.setup(ss), num_vars, g_info
+    vp.num_permutation_z_polys, vp.expression = g_hp.compose(g_info)
+    vp.preprocess_comms, vp.permutation_comms = o_pp.preprocess_comms, o_pp.permutation_comms
+    g_hp.HyperPlonk.verify(vp, instances, hl.Keccak256Transcript.from_proof(proof))
+    for pos in (len(proof) // 3, len(proof) // 2, len(proof) - 40):
+        bad = bytearray(proof)
+        bad[pos] ^= 1
+        with pytest.raises(hl.Error):
+            g_hp.HyperPlonk.verify(vp, instances, hl.Keccak256Transcript.from_proof(bytes(bad)))
