@@ -711,33 +711,120 @@ struct LassoPcsFns {
       batch_open;
   size_t max_vars;
 };
-static void lasso_prove(Transcript& tr, const LassoPcsFns& s, const LassoTable& tb, size_t n, const uint32_t* const* dims) {
+// witness of the argument: access counters in lookup order and the subtable reads (oracle/pyref/lasso.py witness)
+struct LassoW {
+  std::vector<std::vector<uint32_t>> rts, fcs, E;
+};
+static LassoW lasso_witness(const LassoTable& tb, size_t n, const uint32_t* const* dims) {
   const size_t c = tb.c, l = tb.l, alpha = tb.alpha, N = (size_t)1 << n, M = (size_t)1 << l;
-  std::vector<std::vector<uint32_t>> rts(c, std::vector<uint32_t>(N)), fcs(c, std::vector<uint32_t>(M, 0));
+  LassoW w;
+  w.rts.assign(c, std::vector<uint32_t>(N));
+  w.fcs.assign(c, std::vector<uint32_t>(M, 0));
+  w.E.assign(alpha, std::vector<uint32_t>(N));
   for (size_t j = 0; j < c; j++)
-    for (size_t k = 0; k < N; k++) rts[j][k] = fcs[j][dims[j][k]]++;
-  std::vector<std::vector<uint32_t>> E(alpha, std::vector<uint32_t>(N));
+    for (size_t k = 0; k < N; k++) w.rts[j][k] = w.fcs[j][dims[j][k]]++;
   for (size_t i = 0; i < alpha; i++)
-    for (size_t k = 0; k < N; k++) E[i][k] = subtable_entry(tb.mem_sub[i], dims[tb.mem_chunk[i]][k], (uint32_t)l);
+    for (size_t k = 0; k < N; k++) w.E[i][k] = subtable_entry(tb.mem_sub[i], dims[tb.mem_chunk[i]][k], (uint32_t)l);
+  return w;
+}
+static Poly lasso_output(const LassoTable& tb, const LassoW& w, size_t N) {
   Poly a(N);
   parallelize(N, [&](size_t lo, size_t hi) {
     for (size_t k = lo; k < hi; k++) {
       Fr acc = Fr::zero();
       for (uint32_t m = 0; m < tb.num_terms; m++) {
         Fr v = tb.g_coeff[m];
-        for (int f = 0; f < tb.g_nfac[m]; f++) v = v * Fr::from_u64(E[tb.g_fac[m][f]][k]);
+        for (int f = 0; f < tb.g_nfac[m]; f++) v = v * Fr::from_u64(w.E[tb.g_fac[m][f]][k]);
         acc = acc + v;
       }
       a[k] = acc;
     }
   });
+  return a;
+}
+// steps 2-7 of the argument (oracle/pyref/lasso.py argue): Surge, memory-checking grand products, evaluations.
+// a, dim, rts, E: tables of >= 2^n entries; fc: >= 2^l entries
+struct LassoCl {
+  std::vector<Fr> r, r_z, r_N, r_M, e_rz, ev_n, ev_l;
+  Fr v;
+};
+static LassoCl lasso_argue(Transcript& tr, const LassoTable& tb, size_t n, const Poly& a, const std::vector<const Poly*>& dimp,
+                           const std::vector<const Poly*>& tsp, const std::vector<const Poly*>& ep,
+                           const std::vector<const Poly*>& fcp) {
+  const size_t l = tb.l, alpha = tb.alpha, N = (size_t)1 << n, M = (size_t)1 << l;
+  LassoCl cl;
+  cl.r = tr.squeeze_n(n);
+  cl.v = evaluate(Poly(a.begin(), a.begin() + N), cl.r.data(), n);
+  tr.write_fe(cl.v);
+  Sop surge;
+  memset(&surge, 0, sizeof surge);
+  surge.global_eq = 0;
+  surge.num_terms = tb.num_terms;
+  for (uint32_t m = 0; m < tb.num_terms; m++) {
+    surge.coeff[m] = tb.g_coeff[m];
+    surge.num_factors[m] = tb.g_nfac[m];
+    memcpy(surge.factor[m], tb.g_fac[m], 4);
+  }
+  std::vector<Poly> Ep;
+  for (auto* p : ep) Ep.emplace_back(p->begin(), p->begin() + N);
+  ScOut sc = sum_check_prove(tr, 0, n, surge, Ep, {cl.r}, cl.v);
+  cl.r_z = sc.x;
+  cl.e_rz = sc.evals;
+  tr.write_fes(sc.evals);
+
+  Fr gamma = tr.squeeze(), tau = tr.squeeze(), g2 = gamma * gamma, one = Fr::one();
+  std::vector<Poly> leaves(4 * alpha);
+  for (size_t i = 0; i < alpha; i++) {
+    size_t j = tb.mem_chunk[i];
+    Poly rs(N), ws(N), in(M), fi(M);
+    const Poly &dp = *dimp[j], &epi = *ep[i], &tp = *tsp[j], &fp = *fcp[j];
+    parallelize(N, [&](size_t lo, size_t hi) {
+      for (size_t k = lo; k < hi; k++) {
+        rs[k] = dp[k] * g2 + epi[k] * gamma + tp[k] - tau;
+        ws[k] = rs[k] + one;
+      }
+    });
+    parallelize(M, [&](size_t lo, size_t hi) {
+      for (size_t m = lo; m < hi; m++) {
+        in[m] = Fr::from_u64(m) * g2 + Fr::from_u64(subtable_entry(tb.mem_sub[i], (uint32_t)m, (uint32_t)l)) * gamma - tau;
+        fi[m] = in[m] + fp[m];
+      }
+    });
+    leaves[2 * i] = rs, leaves[2 * i + 1] = ws;
+    leaves[2 * alpha + 2 * i] = in, leaves[2 * alpha + 2 * i + 1] = fi;
+  }
+  GpOut gp = grand_product_prove(tr, leaves);
+  cl.r_N = gp.points[0], cl.r_M = gp.points[2 * alpha];
+  auto head = [](const Poly& p, size_t len) { return Poly(p.begin(), p.begin() + len); };
+  for (auto* p : dimp) cl.ev_n.push_back(evaluate(head(*p, N), cl.r_N.data(), n));
+  for (auto* p : tsp) cl.ev_n.push_back(evaluate(head(*p, N), cl.r_N.data(), n));
+  for (auto* p : ep) cl.ev_n.push_back(evaluate(head(*p, N), cl.r_N.data(), n));
+  for (auto* p : fcp) cl.ev_l.push_back(evaluate(head(*p, M), cl.r_M.data(), l));
+  tr.write_fes(cl.ev_n), tr.write_fes(cl.ev_l);
+  return cl;
+}
+// commitment framing (oracle/pyref/lasso.py write_commitments): a mask of the identity commitments (identically zero
+// columns) as one field element, then the other commitments in order
+static void lasso_write_comms(Transcript& tr, const std::vector<Affine>& comms) {
+  uint64_t mask = 0;
+  for (size_t i = 0; i < comms.size(); i++)
+    if (comms[i].is_identity()) mask |= (uint64_t)1 << i;
+  tr.write_fe(Fr::from_u64(mask));
+  for (auto& cm : comms)
+    if (!cm.is_identity()) tr.write_comm(cm);
+}
+
+static void lasso_prove(Transcript& tr, const LassoPcsFns& s, const LassoTable& tb, size_t n, const uint32_t* const* dims) {
+  const size_t c = tb.c, l = tb.l, alpha = tb.alpha, N = (size_t)1 << n;
+  LassoW w = lasso_witness(tb, n, dims);
+  Poly a = lasso_output(tb, w, N);
   std::vector<Poly> pn;  // a | dim | read_ts | E
   pn.push_back(a);
   for (size_t j = 0; j < c; j++) pn.push_back(to_poly(std::vector<uint32_t>(dims[j], dims[j] + N)));
-  for (size_t j = 0; j < c; j++) pn.push_back(to_poly(rts[j]));
-  for (size_t i = 0; i < alpha; i++) pn.push_back(to_poly(E[i]));
+  for (size_t j = 0; j < c; j++) pn.push_back(to_poly(w.rts[j]));
+  for (size_t i = 0; i < alpha; i++) pn.push_back(to_poly(w.E[i]));
   std::vector<Poly> pl;
-  for (size_t j = 0; j < c; j++) pl.push_back(to_poly(fcs[j]));
+  for (size_t j = 0; j < c; j++) pl.push_back(to_poly(w.fcs[j]));
 
   tr.common_fe(Fr::from_u64(n)), tr.common_fe(Fr::from_u64(l)), tr.common_fe(Fr::from_u64(c)), tr.common_fe(Fr::from_u64(alpha));
   // every committed poly is zero-padded to nv = max(n, l) variables (one batch_open serves all)
@@ -751,76 +838,29 @@ static void lasso_prove(Transcript& tr, const LassoPcsFns& s, const LassoTable& 
   for (auto& p : pn) all.push_back(padded(p));
   for (auto& p : pl) all.push_back(padded(p));
   {
-    // commitment framing of the Lasso argument (oracle/pyref/lasso.py write_commitments): a mask of the identity
-    // commitments (identically zero columns) as one field element, then the other commitments in order
     std::vector<Affine> comms;
     for (auto& p : all) comms.push_back(s.commit(p));
-    uint64_t mask = 0;
-    for (size_t i = 0; i < comms.size(); i++)
-      if (comms[i].is_identity()) mask |= (uint64_t)1 << i;
-    tr.write_fe(Fr::from_u64(mask));
-    for (auto& cm : comms)
-      if (!cm.is_identity()) tr.write_comm(cm);
+    lasso_write_comms(tr, comms);
   }
-
-  std::vector<Fr> r = tr.squeeze_n(n);
-  Fr v = evaluate(a, r.data(), n);
-  tr.write_fe(v);
-  Sop surge;
-  memset(&surge, 0, sizeof surge);
-  surge.global_eq = 0;
-  surge.num_terms = tb.num_terms;
-  for (uint32_t m = 0; m < tb.num_terms; m++) {
-    surge.coeff[m] = tb.g_coeff[m];
-    surge.num_factors[m] = tb.g_nfac[m];
-    memcpy(surge.factor[m], tb.g_fac[m], 4);
-  }
-  std::vector<Poly> Ep(pn.begin() + 1 + 2 * c, pn.end());
-  ScOut sc = sum_check_prove(tr, 0, n, surge, Ep, {r}, v);
-  tr.write_fes(sc.evals);
-
-  Fr gamma = tr.squeeze(), tau = tr.squeeze(), g2 = gamma * gamma, one = Fr::one();
-  std::vector<Poly> leaves(4 * alpha);
-  for (size_t i = 0; i < alpha; i++) {
-    size_t j = tb.mem_chunk[i];
-    Poly rs(N), ws(N), in(M), fi(M);
-    const Poly &dimp = pn[1 + j], &ep = pn[1 + 2 * c + i], &tsp = pn[1 + c + j], &fcp = pl[j];
-    parallelize(N, [&](size_t lo, size_t hi) {
-      for (size_t k = lo; k < hi; k++) {
-        rs[k] = dimp[k] * g2 + ep[k] * gamma + tsp[k] - tau;
-        ws[k] = rs[k] + one;
-      }
-    });
-    parallelize(M, [&](size_t lo, size_t hi) {
-      for (size_t m = lo; m < hi; m++) {
-        in[m] = Fr::from_u64(m) * g2 + Fr::from_u64(subtable_entry(tb.mem_sub[i], (uint32_t)m, (uint32_t)l)) * gamma - tau;
-        fi[m] = in[m] + fcp[m];
-      }
-    });
-    leaves[2 * i] = rs, leaves[2 * i + 1] = ws;
-    leaves[2 * alpha + 2 * i] = in, leaves[2 * alpha + 2 * i + 1] = fi;
-  }
-  GpOut gp = grand_product_prove(tr, leaves);
-  const std::vector<Fr>&r_N = gp.points[0], &r_M = gp.points[2 * alpha];
-  std::vector<Fr> ev_n, ev_l;
-  for (size_t k = 1; k < pn.size(); k++) ev_n.push_back(evaluate(pn[k], r_N.data(), n));
-  for (auto& p : pl) ev_l.push_back(evaluate(p, r_M.data(), l));
-  tr.write_fes(ev_n), tr.write_fes(ev_l);
+  std::vector<const Poly*> dimp, tsp, ep, fcp;
+  for (size_t j = 0; j < c; j++) dimp.push_back(&pn[1 + j]), tsp.push_back(&pn[1 + c + j]), fcp.push_back(&pl[j]);
+  for (size_t i = 0; i < alpha; i++) ep.push_back(&pn[1 + 2 * c + i]);
+  LassoCl cl = lasso_argue(tr, tb, n, pn[0], dimp, tsp, ep, fcp);
 
   std::vector<Eval> evs;
-  evs.push_back(Eval{0, 0, v});
-  for (size_t i = 0; i < alpha; i++) evs.push_back(Eval{(uint32_t)(1 + 2 * c + i), 1, sc.evals[i]});
-  for (size_t j = 0; j < c; j++) evs.push_back(Eval{(uint32_t)(1 + j), 2, ev_n[j]});
-  for (size_t j = 0; j < c; j++) evs.push_back(Eval{(uint32_t)(1 + c + j), 2, ev_n[c + j]});
-  for (size_t i = 0; i < alpha; i++) evs.push_back(Eval{(uint32_t)(1 + 2 * c + i), 2, ev_n[2 * c + i]});
-  for (size_t j = 0; j < c; j++) evs.push_back(Eval{(uint32_t)(1 + 2 * c + alpha + j), 3, ev_l[j]});
+  evs.push_back(Eval{0, 0, cl.v});
+  for (size_t i = 0; i < alpha; i++) evs.push_back(Eval{(uint32_t)(1 + 2 * c + i), 1, cl.e_rz[i]});
+  for (size_t j = 0; j < c; j++) evs.push_back(Eval{(uint32_t)(1 + j), 2, cl.ev_n[j]});
+  for (size_t j = 0; j < c; j++) evs.push_back(Eval{(uint32_t)(1 + c + j), 2, cl.ev_n[c + j]});
+  for (size_t i = 0; i < alpha; i++) evs.push_back(Eval{(uint32_t)(1 + 2 * c + i), 2, cl.ev_n[2 * c + i]});
+  for (size_t j = 0; j < c; j++) evs.push_back(Eval{(uint32_t)(1 + 2 * c + alpha + j), 3, cl.ev_l[j]});
   std::vector<const Poly*> pp;
   for (auto& p : all) pp.push_back(&p);
   auto pad_pt = [&](std::vector<Fr> pt) {
     pt.resize(nv, Fr::zero());
     return pt;
   };
-  s.batch_open(nv, pp, {pad_pt(r), pad_pt(sc.x), pad_pt(r_N), pad_pt(r_M)}, evs);
+  s.batch_open(nv, pp, {pad_pt(cl.r), pad_pt(cl.r_z), pad_pt(cl.r_N), pad_pt(cl.r_M)}, evs);
 }
 
 // ------------------------------------------------------------------ HyperPlonk with LogUp (backend/hyperplonk)
@@ -949,6 +989,13 @@ struct HpParam {  // same layout as lh_hp_param, host pointers
   const Fr* const* permutation_polys;
   size_t num_permutation_z_polys;
   Expr expression;
+  size_t num_lasso_lookups;  // lookups proven by Lasso (oracle/pyref/hyperplonk.py LassoLookup)
+  const struct HpLassoLookup* lasso_lookups;
+};
+struct HpLassoLookup {  // same layout as lh_hp_lasso_lookup
+  LassoTable table;
+  size_t output_poly;
+  size_t chunk_polys[8];
 };
 
 struct FrHash {
@@ -1062,6 +1109,51 @@ static void hyperplonk_prove(Transcript& tr, const Srs& srs, const HpParam& pp, 
     m_polys.push_back(std::move(m));
   }
   for (auto& m : m_polys) tr.write_comm(commit(srs, m));
+  // Lasso lookups: witnesses from the circuit's chunk columns, commitments with the identity-mask framing
+  struct LassoSt {
+    const HpLassoLookup* lk;
+    std::vector<std::vector<uint32_t>> dims;
+    LassoW w;
+    std::vector<Poly> rts, E, fcs;  // 2^nv entries each (final_cts zero padded)
+  };
+  std::vector<LassoSt> lasso(pp.num_lasso_lookups);
+  if (pp.num_lasso_lookups) {
+    std::vector<Affine> comms;
+    for (size_t k = 0; k < pp.num_lasso_lookups; k++) {
+      LassoSt& st = lasso[k];
+      st.lk = &pp.lasso_lookups[k];
+      const LassoTable& tb = st.lk->table;
+      if (tb.l > nv) throw OracleError("Lasso subtable larger than the circuit");
+      st.dims.assign(tb.c, std::vector<uint32_t>(n));
+      std::vector<const uint32_t*> dptr;
+      for (size_t j = 0; j < tb.c; j++) {
+        const Poly& col = polys.at(st.lk->chunk_polys[j]);
+        for (size_t b = 0; b < n; b++) {
+          uint64_t canon[4];
+          col[b].to_raw(canon);
+          if (canon[1] || canon[2] || canon[3] || (canon[0] >> tb.l)) throw OracleError("Invalid lookup input");
+          st.dims[j][b] = (uint32_t)canon[0];
+        }
+        dptr.push_back(st.dims[j].data());
+      }
+      st.w = lasso_witness(tb, nv, dptr.data());
+      Poly a = lasso_output(tb, st.w, n);
+      const Poly& out = polys.at(st.lk->output_poly);
+      for (size_t b = 0; b < n; b++)
+        if (!(a[b] == out[b])) throw OracleError("Invalid lookup input");
+      for (size_t j = 0; j < tb.c; j++) st.rts.push_back(to_poly(st.w.rts[j]));
+      for (size_t i = 0; i < tb.alpha; i++) st.E.push_back(to_poly(st.w.E[i]));
+      for (size_t j = 0; j < tb.c; j++) {
+        Poly f = to_poly(st.w.fcs[j]);
+        f.resize(n, Fr::zero());
+        st.fcs.push_back(std::move(f));
+      }
+      for (auto& p : st.rts) comms.push_back(commit(srs, p));
+      for (auto& p : st.E) comms.push_back(commit(srs, p));
+      for (auto& p : st.fcs) comms.push_back(commit(srs, p));
+    }
+    lasso_write_comms(tr, comms);
+  }
 
   Fr gamma = tr.squeeze();
   for (size_t k = 0; k < pp.num_lookups; k++) {
@@ -1247,6 +1339,31 @@ static void hyperplonk_prove(Transcript& tr, const Srs& srs, const HpParam& pp, 
   }
   for (auto& e : evals) written.push_back(e.value);
   tr.write_fes(written);
+  // Lasso lookups: the argument, then its claims join the one batch opening
+  for (LassoSt& st : lasso) {
+    const LassoTable& tb = st.lk->table;
+    const size_t c = tb.c, l = tb.l, alpha = tb.alpha;
+    tr.common_fe(Fr::from_u64(nv)), tr.common_fe(Fr::from_u64(l)), tr.common_fe(Fr::from_u64(c)), tr.common_fe(Fr::from_u64(alpha));
+    std::vector<const Poly*> dimp, tsp, ep, fcp;
+    for (size_t j = 0; j < c; j++) dimp.push_back(&full.at(st.lk->chunk_polys[j])), tsp.push_back(&st.rts[j]), fcp.push_back(&st.fcs[j]);
+    for (size_t i = 0; i < alpha; i++) ep.push_back(&st.E[i]);
+    LassoCl cl = lasso_argue(tr, tb, nv, full.at(st.lk->output_poly), dimp, tsp, ep, fcp);
+    const uint32_t base = (uint32_t)full.size(), p0 = (uint32_t)points.size();
+    for (auto& p : st.rts) full.push_back(p);
+    for (auto& p : st.E) full.push_back(p);
+    for (auto& p : st.fcs) full.push_back(p);
+    for (const std::vector<Fr>* pt : {&cl.r, &cl.r_z, &cl.r_N, &cl.r_M}) {
+      std::vector<Fr> q = *pt;
+      q.resize(nv, Fr::zero());
+      points.push_back(q);
+    }
+    evals.push_back(Eval{(uint32_t)st.lk->output_poly, p0, cl.v});
+    for (size_t i = 0; i < alpha; i++) evals.push_back(Eval{(uint32_t)(base + c + i), p0 + 1, cl.e_rz[i]});
+    for (size_t j = 0; j < c; j++) evals.push_back(Eval{(uint32_t)st.lk->chunk_polys[j], p0 + 2, cl.ev_n[j]});
+    for (size_t j = 0; j < c; j++) evals.push_back(Eval{(uint32_t)(base + j), p0 + 2, cl.ev_n[c + j]});
+    for (size_t i = 0; i < alpha; i++) evals.push_back(Eval{(uint32_t)(base + c + i), p0 + 2, cl.ev_n[2 * c + i]});
+    for (size_t j = 0; j < c; j++) evals.push_back(Eval{(uint32_t)(base + c + alpha + j), p0 + 3, cl.ev_l[j]});
+  }
   std::vector<const Poly*> ptrs;
   for (auto& p : full) ptrs.push_back(&p);
   batch_open(tr, srs, nv, ptrs, points, evals);

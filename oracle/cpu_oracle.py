@@ -210,7 +210,8 @@ class _HpParam(C.Structure):
                 ("num_permutation_polys", C.c_size_t), ("permutation_poly_index", C.POINTER(C.c_size_t)),
                 ("permutation_polys", C.POINTER(C.c_void_p)),
                 ("num_permutation_z_polys", C.c_size_t),
-                ("expression", _Expr)]
+                ("expression", _Expr),
+                ("num_lasso_lookups", C.c_size_t), ("lasso_lookups", C.c_void_p)]
 
 
 def flatten_expression(e):
@@ -279,9 +280,11 @@ def _poly_bytes(p):
 
 def hyperplonk_prove(tr, srs, srs_nv, num_vars, num_instances, preprocess_polys, num_witness_polys, num_challenges,
                      lookups, permutation_poly_index, permutation_polys, num_permutation_z_polys, expression,
-                     instances, witness):
+                     instances, witness, lasso_lookups=()):
     """Polys are int lists or Montgomery byte strings (e.g. downloaded from the GPU); expressions are node lists from
-    `flatten_expression`; lookups: list of lists of (input nodes, table nodes)."""
+    `flatten_expression`; lookups: list of lists of (input nodes, table nodes); lasso_lookups: list of
+    (lh_lasso_table-layout ctypes struct, output_poly, chunk_polys) - lookups proven by the Lasso argument
+    (oracle/pyref/hyperplonk.py LassoLookup)."""
     keep = []
     pp = _HpParam()
     pp.num_vars = num_vars
@@ -304,6 +307,16 @@ def hyperplonk_prove(tr, srs, srs_nv, num_vars, num_instances, preprocess_polys,
     pp.permutation_polys = C.cast(perm, C.POINTER(C.c_void_p))
     pp.num_permutation_z_polys = num_permutation_z_polys
     pp.expression = _c_expr(expression, keep)
+    if lasso_lookups:
+        tsize = C.sizeof(lasso_lookups[0][0])
+        stride = tsize + 8 + 8 * 8  # table | output_poly | chunk_polys[8]: the layout of lh_hp_lasso_lookup
+        buf = C.create_string_buffer(stride * len(lasso_lookups))
+        for k, (table, out_poly, chunk_polys) in enumerate(lasso_lookups):
+            C.memmove(C.addressof(buf) + k * stride, C.byref(table), tsize)
+            tail = (C.c_size_t * 9)(out_poly, *(list(chunk_polys) + [0] * (8 - len(chunk_polys))))
+            C.memmove(C.addressof(buf) + k * stride + tsize, tail, 72)
+        keep.append(buf)
+        pp.num_lasso_lookups, pp.lasso_lookups = len(lasso_lookups), C.cast(buf, C.c_void_p)
     inst, k3 = _ptrs([fr_bytes(i) if len(i) else bytes(32) for i in instances])
     wit, k4 = _ptrs([_poly_bytes(w) for w in witness])
     _chk(lib().orc_hyperplonk_prove(tr.h, srs, C.c_size_t(srs_nv), C.byref(pp), inst, wit))

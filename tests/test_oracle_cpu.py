@@ -253,3 +253,33 @@ def test_lasso_over_zeromorph_cpp_matches_python(hl, kind, c, l, n):
     ct = co.Transcript()
     co.lasso_prove_zm(ct, co.usetup(s, 1 << nv), 1 << nv, table.to_c(), n, [array.array("I", d).tobytes() for d in dims])
     assert ct.into_proof() == t.into_proof()
+
+
+@pytest.mark.parametrize("kind,c,l,num_vars", [("range", 2, 2, 4), ("and", 2, 4, 5), ("xor", 2, 4, 4)])
+def test_hyperplonk_with_lasso_lookup_cpp_matches_python(hl, kind, c, l, num_vars):
+    """Lasso as HyperPlonk's lookup argument (oracle/pyref/hyperplonk.py LassoLookup): the C++ oracle reproduces the
+    Python specification's bytes; a chunk value outside the subtable is "Invalid lookup input" """
+    from oracle.pyref import hyperplonk as hp
+    from test_verifier import _lasso_circuit
+    rng = random.Random(num_vars)
+    ss = [rng.randrange(1, P) for _ in range(num_vars)]
+    o_info, g_info, instances, witness = _lasso_circuit(hl, kind, c, l, num_vars, 5 + num_vars)
+    t = T()
+    hp.prove(hp.preprocess(kzg.setup(ss), o_info), instances, lambda r, ch: witness, t)
+    num_z, expression = hp.compose(o_info)
+    perm_idx = o_info.permutation_polys()
+    perm = hp.permutation_polys(o_info.k, perm_idx, o_info.permutations)
+    lk = g_info.lasso_lookups[0]
+
+    def cpp(wit):
+        ct = co.Transcript()
+        co.hyperplonk_prove(ct, co.setup(ss), num_vars, num_vars, o_info.num_instances, o_info.preprocess_polys,
+                            o_info.num_witness_polys[0], o_info.num_challenges[0], [], perm_idx, perm, num_z,
+                            co.flatten_expression(expression), instances, wit,
+                            lasso_lookups=[(lk.table.to_c(), lk.output_poly, lk.chunk_polys)])
+        return ct.into_proof()
+    assert cpp(witness) == t.into_proof()
+    bad = [list(w) for w in witness]
+    bad[3][1] = 1 << l
+    with pytest.raises(RuntimeError, match="Invalid lookup input"):
+        cpp(bad)
