@@ -121,6 +121,30 @@ def main():
                                   "instances": [H(a) for a in instances], "witness": [H(a) for a in witness],
                                   "proof": proof.hex()})
 
+    # Lasso as HyperPlonk's lookup argument (hyperplonk.py LassoLookup): vanilla gates + one AND lookup proven by Lasso
+    out["hyperplonk_lasso"] = []
+    for nv, kind, c_, l in ((4, "range", 2, 2), (5, "and", 2, 4)):
+        spec = lasso.range_table(c_, l) if kind == "range" else lasso.bitwise_table(lasso.SUBTABLE_AND, c_, l)
+        seed = 2000 + nv
+        while True:  # a tiny circuit can have an identically zero witness column: the reference's transcript rejects
+            crng = random.Random(seed)  # the identity commitment (transcript.rs:172-179); take the next seed then
+            info, instances, witness = hp.rand_vanilla_plonk_with_lasso_circuit(nv, crng, spec)
+            hpp = hp.preprocess(pp, info)
+            t = T()
+            try:
+                hp.prove(hpp, instances, lambda rnd, ch: witness, t)
+                break
+            except Exception as e:
+                assert "Invalid elliptic curve point" in str(e)
+                seed += 100
+        proof = t.into_proof()
+        hp.verify(hpp, instances, T(proof))
+        out["hyperplonk_lasso"].append({"num_vars": nv, "kind": kind, "c": c_, "l": l,
+                                        "preprocess_polys": [H(a) for a in info.preprocess_polys],
+                                        "permutations": [[list(c) for c in cyc] for cyc in info.permutations],
+                                        "instances": [H(a) for a in instances], "witness": [H(a) for a in witness],
+                                        "proof": proof.hex()})
+
     # Zeromorph over univariate KZG: one opening with a trim offset, one batch opening (own rng)
     zrng = random.Random(777)
     s_ = zrng.randrange(1, P)

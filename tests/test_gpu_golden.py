@@ -92,6 +92,24 @@ def test_golden_hyperplonk(hl, ctx, pp5, idx):
     assert t.into_proof().hex() == g["proof"]
 
 
+@pytest.mark.parametrize("idx", range(2))
+def test_golden_hyperplonk_lasso(hl, ctx, pp5, idx):
+    """Lasso as HyperPlonk's lookup argument against the committed proof of the specification"""
+    from halo2_lasso_amd import hyperplonk as g_hp
+    g = GOLDEN["hyperplonk_lasso"][idx]
+    nv = g["num_vars"]
+    table = hl.LassoTable.range(g["c"], g["l"]) if g["kind"] == "range" else hl.LassoTable.bitwise(
+        hl.SUBTABLE_AND, g["c"], g["l"])
+    perms = [[tuple(c) for c in cyc] for cyc in g["permutations"]]
+    info = g_hp.vanilla_plonk_with_lasso_circuit_info(nv, len(g["instances"][0]), [I(a) for a in g["preprocess_polys"]],
+                                                      perms, table)
+    pp = g_hp.HyperPlonk.preprocess(pp5, info)
+    t = hl.Keccak256Transcript()
+    g_hp.HyperPlonk.prove(pp, [I(a) for a in g["instances"]],
+                          [hl.MultilinearPolynomial.new(ctx, I(w)) for w in g["witness"]], t)
+    assert t.into_proof().hex() == g["proof"]
+
+
 def test_golden_zeromorph(hl, ctx):
     g = GOLDEN["zeromorph"]
     nv, s = g["num_vars"], int(g["s"], 16)

@@ -321,3 +321,28 @@ def test_hyperplonk_verify_lasso_lookup(hl, kind, c, l, num_vars):
         bad[pos] ^= 1
         with pytest.raises(hl.Error):
             g_hp.HyperPlonk.verify(vp, instances, hl.Keccak256Transcript.from_proof(bytes(bad)))
+
+
+@pytest.mark.parametrize("idx", range(2))
+def test_hyperplonk_lasso_verify_golden(hl, vp5, idx):
+    """the committed HyperPlonk + Lasso proofs through the host verifier (needs the preprocess / permutation commitments:
+    recomputed with the oracle's commit)"""
+    from halo2_lasso_amd import hyperplonk as g_hp
+    from oracle.pyref import hyperplonk as o_hp, lasso as o_lasso
+    g = GOLDEN["hyperplonk_lasso"][idx]
+    nv = g["num_vars"]
+    I = lambda xs: [int(x, 16) for x in xs]
+    spec = o_lasso.range_table(g["c"], g["l"]) if g["kind"] == "range" else o_lasso.bitwise_table(
+        o_lasso.SUBTABLE_AND, g["c"], g["l"])
+    table = hl.LassoTable.range(g["c"], g["l"]) if g["kind"] == "range" else hl.LassoTable.bitwise(
+        hl.SUBTABLE_AND, g["c"], g["l"])
+    perms = [[tuple(c) for c in cyc] for cyc in g["permutations"]]
+    pre = [I(a) for a in g["preprocess_polys"]]
+    instances = [I(a) for a in g["instances"]]
+    o_pp = o_hp.preprocess(o_kzg.setup(SS), o_hp.vanilla_plonk_with_lasso_circuit_info(nv, len(instances[0]), pre, perms, spec))
+    g_info = g_hp.vanilla_plonk_with_lasso_circuit_info(nv, len(instances[0]), pre, perms, table)
+    vp = g_hp.HyperPlonkVerifierParam()
+    vp.pcs, vp.num_vars, vp.info = vp5, nv, g_info
+    vp.num_permutation_z_polys, vp.expression = g_hp.compose(g_info)
+    vp.preprocess_comms, vp.permutation_comms = o_pp.preprocess_comms, o_pp.permutation_comms
+    g_hp.HyperPlonk.verify(vp, instances, hl.Keccak256Transcript.from_proof(bytes.fromhex(g["proof"])))
