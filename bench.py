@@ -48,6 +48,10 @@ def parse():
     ap.add_argument("--workload", default="lasso", choices=["lasso", "hyperplonk"],
                     help="'lasso' (default, BASELINE metric) or 'hyperplonk': HyperPlonk + LogUp prove of a synthetic "
                          "vanilla_plonk_with_lookup circuit of 2^log-n rows (SURVEY.md §8d C5 substitute)")
+    ap.add_argument("--lookup", default="logup", choices=["logup", "lasso"],
+                    help="--workload hyperplonk: the circuit's lookup argument: 'logup' (the reference's, a 3-column "
+                         "vanilla_plonk_with_lookup circuit) or 'lasso' (north_star's HyperPlonk + Lasso: vanilla gates + "
+                         "a 32-bit --table lookup proven by Lasso inside HyperPlonk::prove, the configs[4] stand-in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log-n", type=int, default=0, help="force the CPU sample size")
     ap.add_argument("--no-profile", action="store_true")
@@ -236,6 +240,13 @@ def use_native_oracle():
     return co
 
 
+def make_hp_circuit(ctx, k, args, seed=None):
+    from halo2_lasso_amd import synthetic
+    if args.lookup == "lasso":
+        return synthetic.vanilla_plonk_with_lasso(ctx, k, kind=args.table, seed=seed)
+    return synthetic.vanilla_plonk_with_lookup(ctx, k, seed=seed)
+
+
 def hyperplonk_cpu_baseline(hl, ctx, args, trap, gpu_proof_fn):
     """the C++ oracle's HyperPlonk restatement on the same synthetic circuit (bounded sample), proof bytes compared"""
     from halo2_lasso_amd import synthetic
@@ -243,18 +254,28 @@ def hyperplonk_cpu_baseline(hl, ctx, args, trap, gpu_proof_fn):
     co = use_native_oracle()
 
     def run(k):
-        circ = synthetic.vanilla_plonk_with_lookup(ctx, k)
+        circ = make_hp_circuit(ctx, k, args)
         pp = hl.MultilinearKzg.setup(ctx, trap[:k])
         srs = C.create_string_buffer(64 * ((2 << k) - 1))
         hl._check(ctx.lib.lh_srs_download(ctx.h, pp.h, srs))
-        o_info = o_hp.vanilla_plonk_with_lookup_circuit_info(k, 0, [[]] * 9, [[(10, 1)], [(11, 1)], [(12, 1)]])
+        if args.lookup == "lasso":
+            from oracle.pyref import lasso as o_lasso
+            spec = o_lasso.range_table(2, 16) if args.table == "range" else o_lasso.bitwise_table(
+                o_lasso.SUBTABLE_AND if args.table == "and" else o_lasso.SUBTABLE_XOR, 4, 16)
+            o_info = o_hp.vanilla_plonk_with_lasso_circuit_info(k, 0, [[]] * 6, [[(7, 1)], [(8, 1)], [(9, 1)]], spec)
+            lk = circ.info.lasso_lookups[0]
+            lasso_lookups, perm_idx = [(lk.table.to_c(), lk.output_poly, lk.chunk_polys)], [7, 8, 9]
+        else:
+            o_info = o_hp.vanilla_plonk_with_lookup_circuit_info(k, 0, [[]] * 9, [[(10, 1)], [(11, 1)], [(12, 1)]])
+            lasso_lookups, perm_idx = [], [10, 11, 12]
         num_z, expression = o_hp.compose(o_info)
         lookups = [[(co.flatten_expression(i), co.flatten_expression(t)) for i, t in lk] for lk in o_info.lookups]
         perm = [p.buf.read() for p in circ.d_permutation]
         tr = co.Transcript()
         t = time.perf_counter()
-        co.hyperplonk_prove(tr, srs, k, k, [0], [a.tobytes() for a in circ.h_preprocess], 3, 0, lookups, [10, 11, 12],
-                            perm, num_z, co.flatten_expression(expression), [[]], [a.tobytes() for a in circ.h_witness])
+        co.hyperplonk_prove(tr, srs, k, k, [0], [a.tobytes() for a in circ.h_preprocess], len(circ.h_witness), 0, lookups,
+                            perm_idx, perm, num_z, co.flatten_expression(expression), [[]],
+                            [a.tobytes() for a in circ.h_witness], lasso_lookups=lasso_lookups)
         ms = (time.perf_counter() - t) * 1e3
         return ms, tr.into_proof() == gpu_proof_fn(pp, circ)
 
@@ -281,7 +302,7 @@ def main_hyperplonk(args, hdist, dist, rank, local_rank, world):
     k = args.log_n
     trap = trapdoor(k)
     pcs_pp = hl.MultilinearKzg.setup(ctx, trap)
-    circ = synthetic.vanilla_plonk_with_lookup(ctx, k, seed=hdist.batch_seed(k, rank) & 0xffffffff)
+    circ = make_hp_circuit(ctx, k, args, seed=hdist.batch_seed(k, rank) & 0xffffffff)
     pp = synthetic.prover_param(pcs_pp, circ)
     ctx.sync()
 
@@ -313,9 +334,14 @@ def main_hyperplonk(args, hdist, dist, rank, local_rank, world):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
             "dtype": "u256 (BN254 Fr/Fq, 8x u32 Montgomery)", "data": "synthetic",
-            "config": {"workload": "HyperPlonk + LogUp prove, vanilla_plonk_with_lookup circuit, 2^%d rows (13 polys, one "
-                                   "3-column lookup on 1/4 of the rows, %d copy constraints, degree-5 zero-check)"
-                                   % (k, circ.num_copies),
+            "config": {"workload": ("HyperPlonk + Lasso prove (BASELINE configs[4] stand-in), 2^%d rows: vanilla gates on "
+                                    "half of the rows, a 32-bit %s lookup proven by Lasso inside HyperPlonk::prove on "
+                                    "the other half (%d polys, %d copy constraints)"
+                                    % (k, args.table.upper(), 7 + len(circ.h_witness), circ.num_copies))
+                       if args.lookup == "lasso" else
+                       ("HyperPlonk + LogUp prove, vanilla_plonk_with_lookup circuit, 2^%d rows (13 polys, one "
+                        "3-column lookup on 1/4 of the rows, %d copy constraints, degree-5 zero-check)"
+                        % (k, circ.num_copies)),
                        "rows": 1 << k, "proofs_per_step": world, "pcs": "multilinear KZG (BN254)",
                        "proof_bytes": len(tr.into_proof()), "parallelism": "1 proof per GPU" if world > 1 else "1 GPU"},
             "rows_per_s": round((1 << k) * world / (ms_per_step / 1e3)),

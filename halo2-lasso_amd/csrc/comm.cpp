@@ -37,10 +37,16 @@ const RcclApi& rccl() {
   static std::once_flag once;
   static std::string err;
   std::call_once(once, [] {
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // an instance the process already runs (torch ships its own librccl.so) is reused; otherwise the ROCm one is loaded.
+    // RTLD_LOCAL: a second copy loaded later by someone else must not bind to this one's symbols.
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
-      api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
       if (api.lib) break;
+    }
+    for (const char* n : names) {
+      if (api.lib) break;
+      api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
     }
     if (!api.lib) {
       err = std::string("RCCL is not loadable (librccl.so.1): ") + (dlerror() ? dlerror() : "");
@@ -111,6 +117,13 @@ void comm_attach_rccl(Ctx& c, int rank, int size, const uint8_t id_bytes[LH_RCCL
   c.shard_bit = shard_bit;
 }
 
+static const bool COMM_DEBUG = getenv("LH_COMM_DEBUG") != nullptr;  // one stderr line per collective (development)
+static void comm_trace(const Ctx& c, const char* what, size_t bytes) {
+  if (COMM_DEBUG)
+    fprintf(stderr, "[comm %d/%d] #%llu %s %zu B\n", c.comm.rank, c.comm.size,
+            (unsigned long long)(c.comm_stats[0] + c.comm_stats[1]), what, bytes);
+}
+
 static void require_comm(const Ctx& c) {
   LH_REQUIRE(c.has_comm && (c.rccl_comm || c.comm.all_gather || c.comm.all_gather_device), LH_ERR_ARG,
              "no communicator attached (lh_ctx_set_comm / lh_ctx_set_comm_rccl)");
@@ -119,6 +132,7 @@ static void require_comm(const Ctx& c) {
 void comm_all_gather_dev(Ctx& c, const void* d_send, void* d_recv, size_t bytes) {
   require_comm(c);
   if (!bytes) return;
+  comm_trace(c, "all_gather_dev", bytes);
   if (c.rccl_comm) {
     c.comm_stats[0]++;
     rccl_check(rccl().AllGather(d_send, d_recv, bytes, ncclUint8, (ncclComm_t)c.rccl_comm, c.stream), "ncclAllGather");
@@ -145,6 +159,7 @@ void comm_all_gather_dev(Ctx& c, const void* d_send, void* d_recv, size_t bytes)
 void comm_all_gather_host(Ctx& c, const void* send, void* recv, size_t bytes) {
   require_comm(c);
   if (!bytes) return;
+  comm_trace(c, "all_gather_host", bytes);
   if (c.comm.all_gather && !c.rccl_comm) {
     c.comm_stats[1]++;
     int rc = c.comm.all_gather(c.comm.user, send, recv, bytes);

@@ -25,7 +25,9 @@ static size_t lg(size_t v) {
 struct ShardGeom {
   size_t rho, j, rank, R;
   explicit ShardGeom(const Ctx& c) : rho(lg((size_t)c.comm.size)), j(c.shard_bit), rank((size_t)c.comm.rank), R((size_t)c.comm.size) {}
-  bool sharded(size_t num_vars) const { return num_vars >= j + rho + 1; }
+  // a table of num_vars variables is held in shards (a single rank, rho = 0, goes through the same code paths: its
+  // "exchange" round still needs one round before it)
+  bool sharded(size_t num_vars) const { return num_vars >= j + (rho ? rho : 1) + 1; }
 };
 
 // ------------------------------------------------------------------ grand product

@@ -99,6 +99,101 @@ def vanilla_plonk_with_lookup(ctx, k, seed=None):
     return c
 
 
+def vanilla_plonk_with_lasso(ctx, k, kind="and", seed=None):
+    """The BASELINE.json configs[4] stand-in at scale (hyperplonk.vanilla_plonk_with_lasso_circuit_info): vanilla add / mul
+    gates on half of the rows, a 32-bit AND / XOR / range lookup proven by Lasso on the other half (w_o = a on lookup rows),
+    copy constraints between the two halves of the table, no instances.  16 polys for the bitwise tables:
+    pi | q_l q_r q_m q_o q_c q_lookup | w_l w_r w_o d_0..d_3 a."""
+    import halo2_lasso_amd as hl
+    size = 1 << k
+    lib = ctx.lib
+    rng = np.random.default_rng(1000 + k if seed is None else seed)
+    table = hl.LassoTable.range(2, 16) if kind == "range" else hl.LassoTable.bitwise(
+        hl.SUBTABLE_AND if kind == "and" else hl.SUBTABLE_XOR, 4, 16)
+    c = table.c
+
+    def rand_fr(n):
+        a = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+        a[:, 3] &= np.uint64((1 << 60) - 1)
+        return a
+
+    def const_fr(v, n):
+        return np.tile(np.frombuffer(hl.fr_to_bytes(v), dtype=np.uint64), (n, 1))
+
+    def up(a):
+        return hl.MultilinearPolynomial(ctx, ctx.upload(np.ascontiguousarray(a).tobytes()), k)
+
+    def down(p):
+        return np.frombuffer(p.buf.read(), dtype=np.uint64).reshape(size, 4).copy()
+
+    def binop(fn, a, b):
+        out = hl.MultilinearPolynomial(ctx, ctx.alloc(32 * size), k)
+        hl._check(fn(ctx.h, a.ptr, b.ptr, size, out.ptr))
+        return out
+
+    def fr_of_u64(v):
+        out = hl.MultilinearPolynomial(ctx, ctx.alloc(32 * size), k)
+        staged = ctx.upload(np.ascontiguousarray(v, dtype=np.uint64).tobytes())
+        hl._check(lib.lh_fr_from_u64(ctx.h, staged.ptr, size, out.ptr))
+        ctx.sync()
+        return out
+
+    rows = np.arange(size)
+    live = rows < size - 1
+    is_add, is_mul = live & (rows % 4 == 0), live & (rows % 4 == 1)
+    is_lookup = live & (rows % 4 >= 2)
+    gate = is_add | is_mul
+    zero, one, minus1 = const_fr(0, size), const_fr(1, size), const_fr(hl.R_MOD - 1, size)
+    sel = lambda m, v: np.where(m[:, None], v, zero)
+    q_l = q_r = sel(is_add, one)
+    q_m, q_o, q_c = sel(is_mul, one), sel(gate, minus1), sel(gate, rand_fr(size))
+    q_lookup = sel(is_lookup, one)
+    # chunk columns: indices on lookup rows, 0 elsewhere (T[0] = 0 for range / AND / XOR: a = 0 there)
+    dims = [np.where(is_lookup, rng.integers(0, 1 << table.l, size=size, dtype=np.uint64), 0).astype(np.uint64)
+            for _ in range(c)]
+    if kind == "range":
+        out = sum(d << np.uint64(16 * j) for j, d in enumerate(dims))
+    else:
+        x, y = [d >> np.uint64(8) for d in dims], [d & np.uint64(0xff) for d in dims]
+        out = sum(((xj & yj) if kind == "and" else (xj ^ yj)) << np.uint64(8 * j) for j, (xj, yj) in enumerate(zip(x, y)))
+    d_dims = [fr_of_u64(d) for d in dims]
+    d_a = fr_of_u64(out)
+    a_host = down(d_a)
+    w_l, w_r = sel(live, rand_fr(size)), sel(live, rand_fr(size))
+    d_ql, d_qm, d_qc = up(q_l), up(q_m), up(q_c)
+
+    def out_column(wl, wr):
+        al, ar = up(wl), up(wr)
+        lin = binop(lib.lh_fr_mul, d_ql, binop(lib.lh_fr_add, al, ar))
+        quad = binop(lib.lh_fr_mul, d_qm, binop(lib.lh_fr_mul, al, ar))
+        wo = down(binop(lib.lh_fr_add, binop(lib.lh_fr_add, lin, quad), d_qc))
+        wo[is_lookup] = a_host[is_lookup]
+        return wo
+
+    w_o = out_column(w_l, w_r)
+    half = size // 2
+    dst = rows[gate & (rows > half)]
+    src = dst - half
+    w_l[dst], w_r[dst] = w_o[src], w_r[src]
+    w_o = out_column(w_l, w_r)
+    ident = lambda p: (np.uint64(p) << np.uint64(k)) + rows.astype(np.uint64)
+    perm = [ident(0), ident(1), ident(2)]
+    perm[0][dst], perm[2][src] = ident(2)[src], ident(0)[dst]
+    perm[1][dst], perm[1][src] = ident(1)[src], ident(1)[dst]
+    d_perm = [fr_of_u64(p) for p in perm]
+
+    circ = SyntheticCircuit()
+    circ.k, circ.num_copies, circ.num_lookups, circ.table, circ.kind = k, len(dst), int(is_lookup.sum()), table, kind
+    circ.info = hp.vanilla_plonk_with_lasso_circuit_info(k, 0, [[]] * 6, [[(7, 1)], [(8, 1)], [(9, 1)]], table)
+    circ.h_preprocess = [q_l, q_r, q_m, q_o, q_c, q_lookup]
+    circ.h_witness = [w_l, w_r, w_o] + [down(d) for d in d_dims] + [a_host]
+    circ.d_preprocess = [up(a) for a in circ.h_preprocess]
+    circ.d_permutation = d_perm
+    circ.d_witness = [up(w_l), up(w_r), up(w_o)] + d_dims + [d_a]
+    circ.instances = [[]]
+    return circ
+
+
 def prover_param(pcs_pp, circuit, pcs_vp=None):
     """HyperPlonk.preprocess for a SyntheticCircuit whose polys already live on the device -> pp or (pp, vp)"""
     import halo2_lasso_amd as hl
