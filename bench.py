@@ -281,7 +281,7 @@ def hyperplonk_cpu_baseline(hl, ctx, args, trap, gpu_proof_fn):
 
     k = args.cpu_sample_log_n
     if not k:
-        k = min(14, args.log_n)
+        k = min(16 if args.lookup == "lasso" else 14, args.log_n)  # a Lasso circuit has at least 2^16 rows (the subtable)
         ms, _ = run(k)
         while k < args.log_n and ms * 2.2 < 25e3:
             k += 1

@@ -355,6 +355,14 @@ struct MsmJob {
   bool scalars_u32;
   const G1Affine* bases;
   size_t n;
+  // Optional: this column is a table of another column of the batch, scalars[i] = table[parent.scalars[i]] (Lasso's
+  // E = T[dim]).  When the parent ends up with ONE window whose bucket index is the parent's value, this job's buckets
+  // are sums of the PARENT'S buckets (S_v = sum of B_d over T[d] = v) and no pass over its n points is made: 2^in_bits
+  // bucket additions instead of n point additions.  Otherwise the job runs as an ordinary u32 column.
+  int derived_parent = -1;             // index of the parent job in the same batch
+  const uint32_t* d_table = nullptr;   // device: T[d], d < 2^table_in_bits; T[0] must be 0
+  const uint32_t* d_order = nullptr;   // device: 0 .. 2^table_in_bits - 1 sorted by T (any order inside equal T)
+  uint32_t table_in_bits = 0, table_out_bits = 0;
 };
 // Runs all jobs as one batched Pippenger; out[j] is the affine sum (identity = (0,0)).
 void msm_batch(Ctx&, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host);

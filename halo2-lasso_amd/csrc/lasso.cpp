@@ -63,6 +63,36 @@ std::vector<HG1> lasso_read_commitments(Transcript& tr, size_t count) {
   return comms;
 }
 
+// T[d] and the d's sorted by T[d] for the bitwise subtables, on the device (arena memory of the caller's scope; the host
+// staging lives as long as this object, i.e. past the msm_batch that consumes them)
+struct SubtableOrders {
+  Ctx& c;
+  size_t l;
+  std::vector<uint32_t> h_tab[3], h_ord[3];
+  uint32_t *d_tab[3] = {nullptr, nullptr, nullptr}, *d_ord[3] = {nullptr, nullptr, nullptr};
+  SubtableOrders(Ctx& c_, size_t l_) : c(c_), l(l_) {}
+  void get(int kind, const uint32_t** table, const uint32_t** order) {
+    if (!d_tab[kind]) {
+      const size_t M = (size_t)1 << l, h = l / 2, V = (size_t)1 << h;
+      std::vector<uint32_t>&tab = h_tab[kind], &ord = h_ord[kind];
+      tab.resize(M), ord.resize(M);
+      std::vector<uint32_t> start(V + 1, 0);
+      for (size_t d = 0; d < M; d++) {
+        const uint32_t x = (uint32_t)(d >> h), y = (uint32_t)(d & (V - 1));
+        tab[d] = kind == LH_SUBTABLE_AND ? (x & y) : (x ^ y);
+        start[tab[d] + 1]++;
+      }
+      for (size_t v = 0; v < V; v++) start[v + 1] += start[v];
+      for (size_t d = 0; d < M; d++) ord[start[tab[d]]++] = (uint32_t)d;  // counting sort by T
+      d_tab[kind] = c.arena.alloc_n<uint32_t>(M);
+      d_ord[kind] = c.arena.alloc_n<uint32_t>(M);
+      LH_HIP(hipMemcpyAsync(d_tab[kind], tab.data(), M * 4, hipMemcpyHostToDevice, c.stream));
+      LH_HIP(hipMemcpyAsync(d_ord[kind], ord.data(), M * 4, hipMemcpyHostToDevice, c.stream));
+    }
+    *table = d_tab[kind], *order = d_ord[kind];
+  }
+};
+
 void lasso_check_table(const lh_lasso_table& tb) {
   const size_t cc = tb.num_chunks, l = tb.chunk_bits, alpha = tb.num_memories;
   LH_REQUIRE(cc >= 1 && cc <= LH_LASSO_MAX_CHUNKS, LH_ERR_ARG, "lasso: bad num_chunks");
@@ -228,10 +258,23 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
       slot.push_back(pos);
     };
     if (!linear_g) add_job(0, a, false, N);
-    for (size_t j = 0; j < cc; j++) add_job(1 + j, d_dims[j], true, N);
+    std::vector<size_t> dim_job(cc);
+    for (size_t j = 0; j < cc; j++) dim_job[j] = jobs.size(), add_job(1 + j, d_dims[j], true, N);
     for (size_t j = 0; j < cc; j++) add_job(1 + cc + j, rts[j], true, N);
+    // E_i = T[dim_j]: commit(E_i) = sum_d T[d] * B_d over the BUCKET sums B_d of dim_j's commitment - no second pass
+    // over the N points (msm.hip, MsmJob::derived_parent; falls back to an ordinary column when the window shape of
+    // dim_j does not allow it)
+    SubtableOrders orders(c, l);
     for (size_t i = 0; i < alpha; i++)
-      if (tb.memory_subtable[i] != LH_SUBTABLE_IDENTITY) add_job(1 + 2 * cc + i, E[i], true, N);
+      if (tb.memory_subtable[i] != LH_SUBTABLE_IDENTITY) {
+        add_job(1 + 2 * cc + i, E[i], true, N);
+        if (l <= 20) {
+          MsmJob& jb = jobs.back();
+          jb.derived_parent = (int)dim_job[tb.memory_chunk[i]];
+          orders.get((int)tb.memory_subtable[i], &jb.d_table, &jb.d_order);
+          jb.table_in_bits = (uint32_t)l, jb.table_out_bits = (uint32_t)(l / 2);
+        }
+      }
     for (size_t j = 0; j < cc; j++) add_job(1 + 2 * cc + alpha + j, fcs[j], true, M);
     std::vector<HG1> part(jobs.size()), comms(total);
     msm_batch(c, jobs.data(), jobs.size(), (G1Affine*)part.data());

@@ -402,6 +402,32 @@ __global__ __launch_bounds__(512) void msm_window_sum_kernel(MsmPlanDev plan, co
   }
 }
 
+// ------------------------------------------------------------------ derived jobs (MsmJob::derived_parent)
+// list entry p of derived job j: (key_base_j + T[order[p]], parent bucket order[p]); sorted by key because `order` is
+// sorted by T.  The continuation-level kernels then sum the runs into the derived job's buckets.
+constexpr int MSM_MAX_DERIVED = 16;
+struct MsmDerivedDev {
+  uint32_t count;
+  uint32_t off[MSM_MAX_DERIVED + 1];  // list offsets
+  uint32_t key_base[MSM_MAX_DERIVED], parent_key_base[MSM_MAX_DERIVED];
+  const uint32_t* table[MSM_MAX_DERIVED];
+  const uint32_t* order[MSM_MAX_DERIVED];
+};
+__global__ void msm_derived_gather_kernel(MsmDerivedDev dd, const G1Xyzz* __restrict__ buckets,
+                                          uint32_t* __restrict__ out_key, G1Xyzz* __restrict__ out_pt) {
+  const uint32_t total = dd.off[dd.count];
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < total; p += gridDim.x * blockDim.x) {
+    uint32_t j = 0;
+    while (j + 1 < dd.count && dd.off[j + 1] <= p) j++;
+    const uint32_t d = dd.order[j][p - dd.off[j]];
+    const uint32_t v = dd.table[j][d];
+    // no sentinels (they would split a run into several "first" segments): an empty parent bucket is the identity,
+    // and T[d] = 0 lands in the derived job's bucket 0, which the reduction weighs with 0
+    out_key[p] = dd.key_base[j] + v;
+    out_pt[p] = buckets[dd.parent_key_base[j] + d];
+  }
+}
+
 // ------------------------------------------------------------------ host driver
 static int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
@@ -468,6 +494,24 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
         }
       }
     }
+    // derived jobs (MsmJob::derived_parent): usable when the parent is a u32 column of the same points whose single
+    // window is indexed by its value (window bits == significant bits <= the table's input bits)
+    std::vector<char> derived(nj, 0);
+    size_t num_derived = 0;
+    for (size_t j = 0; j < nj; j++) {
+      const MsmJob& in = jobs[base + j];
+      const long p = (long)in.derived_parent - (long)base;
+      if (in.derived_parent < 0 || p < 0 || p >= (long)nj || !in.d_table || !in.d_order) continue;
+      const MsmJob& par = jobs[base + p];
+      const uint32_t pb = job_bits[p];
+      if (!in.scalars_u32 || !par.scalars_u32 || par.n != in.n || par.bases != in.bases || par.derived_parent >= 0) continue;
+      if (!pb || pb > in.table_in_bits || in.table_in_bits > 20 || pick_window(par.n, pb) != pb) continue;
+      if (!in.table_out_bits || num_derived == (size_t)MSM_MAX_DERIVED) continue;
+      derived[j] = 1;
+      num_derived++;
+      job_bits[j] = std::min(job_bits[j], in.table_out_bits);  // (0 stays 0: an all-zero column)
+      if (!job_bits[j] || pick_window(in.n, job_bits[j]) != job_bits[j]) derived[j] = 0, num_derived--;
+    }
     // buckets per reduce thread: the segment kernel is a chain of 2 S additions plus a small-scalar multiplication
     // per thread.  Few buckets in total = too few threads to fill the chip = pure latency: shorter segments then
     // (S = 4: ~30 dependent curve operations instead of ~51); many buckets = throughput: S = 16 does least work.
@@ -491,6 +535,7 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
       MsmJobDev& jd = plan.job[j];
       uint32_t bits = job_bits[j];
       jd.bases = in.bases;
+      if (derived[j]) jd.n = 0;  // emits no (point, window) entries: its buckets are filled from the parent's
       jd.c = pick_window(in.n ? in.n : 1, bits ? bits : 1);
       jd.is_signed = in.scalars_u32 ? 0 : 1;
       if (jd.is_signed && jd.c < 2) jd.c = 2;
@@ -617,6 +662,48 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
         cpt = opt;
         n_in = nc;
       }
+      }
+      if (num_derived) {
+        // derived jobs: (key, parent bucket) lists sorted by key, summed into the derived buckets by the same
+        // continuation levels (a run shrinks K2-fold per level)
+        MsmDerivedDev dd;
+        memset(&dd, 0, sizeof(dd));
+        for (size_t j = 0; j < nj; j++) {
+          if (!derived[j]) continue;
+          const MsmJob& in = jobs[base + j];
+          const uint32_t k = dd.count++;
+          dd.off[k + 1] = dd.off[k] + (1u << in.table_in_bits);
+          dd.key_base[k] = plan.job[j].key_base;
+          dd.parent_key_base[k] = plan.job[(size_t)in.derived_parent - base].key_base;
+          dd.table[k] = in.d_table, dd.order[k] = in.d_order;
+        }
+        const size_t nd = dd.off[dd.count];
+        ProfScope ps(c, "msm_derived", 132.0 * nd, 14.0 * nd, (double)nd);
+        uint32_t* dkey = c.arena.alloc_n<uint32_t>(nd);
+        G1Xyzz* dpt = c.arena.alloc_n<G1Xyzz>(nd);
+        hipLaunchKernelGGL(msm_derived_gather_kernel, dim3((unsigned)std::min<size_t>((nd + 255) / 256, 1024)), dim3(256), 0,
+                           c.stream, dd, buckets, dkey, dpt);
+        uint32_t* dcnt = lvl_cnt + 32;
+        LH_HIP(hipMemsetAsync(dcnt, 1, sizeof(uint32_t), c.stream));  // "something continued into level 0"
+        size_t n_in2 = nd;
+        int lvl = 0;
+        while (true) {
+          size_t nc = (n_in2 + K2 - 1) / K2;
+          uint32_t* okey = c.arena.alloc_n<uint32_t>(nc);
+          G1Xyzz* opt = c.arena.alloc_n<G1Xyzz>(nc);
+          if (n_in2 <= (size_t)MSM_QUAD_MAX)
+            hipLaunchKernelGGL(msm_accumulate_n_quad_kernel, dim3((unsigned)((4 * n_in2 + 127) / 128)), dim3(128), 0, c.stream,
+                               dkey, dpt, n_in2, K2, buckets, okey, opt, dcnt + lvl, dcnt + lvl + 1);
+          else
+            hipLaunchKernelGGL(msm_accumulate_n_kernel, dim3((unsigned)std::min<size_t>((n_in2 + 127) / 128, 1 << 16)),
+                               dim3(128), 0, c.stream, dkey, dpt, n_in2, K2, buckets, okey, opt, dcnt + lvl, dcnt + lvl + 1);
+          lvl++;
+          LH_REQUIRE(lvl < 30, LH_ERR_ARG, "msm: derived list too long");
+          if (n_in2 <= K2) break;
+          dkey = okey;
+          dpt = opt;
+          n_in2 = nc;
+        }
       }
       {
         ProfScope ps(c, "msm_bucket_reduce", 128.0 * nbuckets, 14.0 * 2.2 * nbuckets, (double)nbuckets);
