@@ -94,6 +94,9 @@ def prove_fractional_sum_check(claimed_p_0s, claimed_q_0s, ps, qs, transcript):
         mu = transcript.squeeze_challenge()
         claimed_p, claimed_q = _frac_down(evals, mu)
         y = x + [mu]
+    # the reference's `sanity-check` feature (fractional_sum_check.rs:184-187): the final claims are the inputs at x
+    from .poly import evaluate as _evaluate
+    assert all(_evaluate(t, y) == v for t, v in zip(list(ps) + list(qs), claimed_p + claimed_q))
     return claimed_p, claimed_q, y
 
 

@@ -241,7 +241,9 @@ def lookup_h_poly(compressed, m_poly, gamma):
     inp, table = compressed
     hi = batch_invert([(gamma + v) % P for v in inp])
     ht = batch_invert([(gamma + v) % P for v in table])
-    return [(a - b * m) % P for a, b, m in zip(hi, ht, m_poly)]
+    h = [(a - b * m) % P for a, b, m in zip(hi, ht, m_poly)]
+    assert sum(h) % P == 0  # the reference's `sanity-check` feature (prover.rs:245-247): the LogUp identity closes
+    return h
 
 
 def permutation_z_polys(num_chunks, perm_polys, polys, beta, gamma):
@@ -272,6 +274,8 @@ def permutation_z_polys(num_chunks, perm_polys, polys, beta, gamma):
             state = state * products[c][b] % P
             z.append(state)
     z = z[:num_chunks << num_vars]
+    # the reference's `sanity-check` feature (prover.rs:325-331): the running product closes to one on the last row
+    assert z[-1] * products[-1][order[-1]] % P == 1
     nth = BooleanHypercube(num_vars).nth_map()
     return [[z[offset + num_chunks * nth[b]] for b in range(n)] for offset in range(num_chunks)]
 

@@ -46,11 +46,14 @@ def keccak_f(a):
 
 
 class Keccak256:
-    """Streaming hasher with `finalize_reset`, as `sha3::Keccak256`."""
+    """Streaming hasher with `finalize_reset`, as `sha3::Keccak256`.  `pad`: the domain byte - 0x01 is legacy Keccak
+    (what the reference hashes with); 0x06 turns the same sponge into FIPS-202 SHA3-256, which tests/test_oracle.py
+    compares with hashlib on messages of every length around the block boundaries (pins permutation, rate, padding)."""
 
-    def __init__(self):
+    def __init__(self, pad=0x01):
         self.buf = bytearray()
         self.state = [0] * 25
+        self.pad = pad
 
     def _absorb_block(self, block):
         for i in range(RATE // 8):
@@ -65,7 +68,7 @@ class Keccak256:
 
     def finalize_reset(self):
         pad = bytearray(self.buf)
-        pad.append(0x01)
+        pad.append(self.pad)
         pad += b"\x00" * (RATE - len(pad))
         pad[-1] |= 0x80
         self._absorb_block(pad)

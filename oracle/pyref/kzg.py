@@ -81,6 +81,9 @@ def open_(pp, evals, point, transcript):
     """kzg.rs:276-302: writes pi_0..pi_{n-1}, pi_i = commit(q_i) with eqs[i]."""
     qs, rem = quotients(evals, point)
     comms = [curve.msm(q, pp.eqs[i]) for i, q in enumerate(qs)]
+    # the reference's `sanity-check` feature (kzg.rs:286-297): the remainder of the quotients is the evaluation
+    from .poly import evaluate as _evaluate
+    assert rem == _evaluate(evals, point)
     transcript.write_commitments(comms)  # identity -> TranscriptError, as transcript.rs:216-219
     return rem
 

@@ -133,6 +133,28 @@ def test_msm_edge_cases(hl, ctx, bases_pool):
     assert _msm_case(hl, ctx, s, b) == curve.msm(s, b)
 
 
+def test_g1_public_vectors(hl, ctx):
+    """a2 (Fq arithmetic, G1 mixed addition / doubling / normalisation on the device) against the public alt_bn128
+    values of EIP-196: 2G, 3G, (r-1) G = -G, G + (-G) = O, through one-, two- and three-point MSMs (every curve
+    operation of csrc/ec.cuh is on that path: add_mixed with equal, opposite and distinct operands, dbl, the window
+    sums, the host's normalisation)"""
+    G = (1, 2)
+    two_g = (1368015179489954701390400359078579693043519447331113978918064868415326638035,
+             9918110051302171585080402603319702774565515993150576347155970296011118125764)
+    three_g = (3353031288059533942658390886683067124040920775575537747144343083137631628272,
+               19321533766552368860946552437480515441416830039777911637913418824951667761761)
+    neg = lambda pt: (pt[0], (-pt[1]) % curve.P)
+    assert _msm_case(hl, ctx, [1], [G]) == G
+    assert _msm_case(hl, ctx, [2], [G]) == two_g                      # doubling through the window combine
+    assert _msm_case(hl, ctx, [1, 1], [G, G]) == two_g                # doubling inside a bucket (equal operands)
+    assert _msm_case(hl, ctx, [1, 1], [two_g, G]) == three_g          # mixed addition, distinct operands
+    assert _msm_case(hl, ctx, [3], [G]) == three_g
+    assert _msm_case(hl, ctx, [1, 1, 1], [G, G, G]) == three_g
+    assert _msm_case(hl, ctx, [P - 1], [G]) == neg(G)                 # (r - 1) G = -G: a full-width scalar
+    assert _msm_case(hl, ctx, [1, 1], [G, neg(G)]) is None            # opposite operands: the identity
+    assert _msm_case(hl, ctx, [P - 2, 1], [G, three_g]) == G          # -2 G + 3 G
+
+
 def test_msm_u32(hl, ctx, bases_pool):
     rng = random.Random(6)
     n = 512

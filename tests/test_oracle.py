@@ -267,3 +267,37 @@ def test_golden_lasso(pp5, idx):
     lasso.prove(pp5, spec, g["dims"], t)
     assert t.into_proof().hex() == g["proof"]
     lasso.verify(pp5, spec, g["n"], T(bytes.fromhex(g["proof"])))
+
+
+# ------------------------------------------------------------------ public vectors that pin the primitives
+def test_keccak_sponge_against_hashlib_sha3():
+    """The oracle's sponge with the FIPS-202 domain byte IS SHA3-256: hashlib pins the permutation, the rate and the
+    multi-block absorb/pad logic on every message length around the 136-byte block boundaries and on a long message;
+    the legacy-Keccak domain byte (0x01) the reference uses is pinned by the published Keccak-256 vectors."""
+    import hashlib
+    from oracle.pyref.keccak import Keccak256, keccak256
+    rng = random.Random(5)
+    for n in list(range(0, 300)) + [407, 408, 409, 1000, 10_000]:
+        msg = bytes(rng.randrange(256) for _ in range(n))
+        h = Keccak256(pad=0x06)
+        h.update(msg[:n // 3])
+        h.update(msg[n // 3:])
+        assert h.finalize_reset() == hashlib.sha3_256(msg).digest(), n
+    assert keccak256(b"").hex() == "c5d2460186f7233c927e7db2dcc703c0e500b653ca82273b7bfad8045d85a470"
+    assert keccak256(b"abc").hex() == "4e03657aea45a94fc7d47ba826c8d667c0d1e6e33a64a036ec44f58fa12d6c45"
+    assert keccak256(b"The quick brown fox jumps over the lazy dog").hex() == \
+        "4d741b6f1eb29cb2a9b9911c82f56fa8d73b04959d3d9d222895df6c0b28aa15"
+
+
+def test_bn254_public_points():
+    """alt_bn128 (EIP-196 / EIP-197) public values: 2G, 3G, the order of G1, the G2 generator on its twist, and the
+    precompile's canonical pairing checks e(P, Q) e(-P, Q) = 1 and e(aP, bQ) = e(abP, Q)"""
+    G = curve.G1_GEN
+    two_g = (1368015179489954701390400359078579693043519447331113978918064868415326638035,
+             9918110051302171585080402603319702774565515993150576347155970296011118125764)
+    three_g = (3353031288059533942658390886683067124040920775575537747144343083137631628272,
+               19321533766552368860946552437480515441416830039777911637913418824951667761761)
+    assert curve.add(G, G) == curve.mul(G, 2) == two_g
+    assert curve.add(two_g, G) == curve.mul(G, 3) == three_g
+    assert curve.mul(G, field.R_MOD) is None and curve.mul(G, field.R_MOD - 1) == curve.neg(G)
+    assert curve.msm([5, field.R_MOD - 2], [G, two_g]) == G  # 5 G - 2 (2 G)
