@@ -256,9 +256,27 @@ struct ScRound {
   uint8_t nfac[LH_SC_MAX_TERMS];
   uint8_t fac[LH_SC_MAX_TERMS][LH_SC_MAX_FACTORS];
   Fr r;  // challenge of the previous round (BIND only)
+  // "eq factoring" (prover.cpp): when set, global_eq is -1 and the eq factor of the expression is eq_level[b], the eq
+  // table over the variables AFTER this round's; the kernel returns q(X) = sum_b eq_level[b] * g(X, b)
+  const Fr* eq_level;
 };
 // evals_host[0..degree) receives sum_b expr at X = 1..degree (X = 0 is derived by the caller)
 void k_sc_round(Ctx&, const ScRound& rd, int degree, bool bind, size_t size, Fr* evals_host);
+// true when k_sc_round would run the streaming one-thread-per-pair kernel for this shape (not the LDS-staged one)
+bool k_sc_round_streams(const ScRound& rd, int degree, size_t size);
+// out[i] = in[2 i] + in[2 i + 1]: the eq table over one variable less (eq factoring)
+void k_pair_sums(Ctx&, const Fr* in, size_t n_out, Fr* out);
+// Batch-opening shape sum_m eq_m * poly_m with every eq factored: per term q_m(0) = sum_b E_m[b] v0, q_m(1) = sum_b E_m[b] v1
+constexpr int SC_OPEN_MAX_TERMS = 6;
+struct ScOpenRound {
+  const Fr* in[SC_OPEN_MAX_TERMS];
+  Fr* out[SC_OPEN_MAX_TERMS];
+  const Fr* eq_level[SC_OPEN_MAX_TERMS];
+  uint32_t num_terms;
+  Fr r;
+};
+// out_host[2 m], out_host[2 m + 1] = q_m(0), q_m(1)
+void k_sc_round_open(Ctx&, const ScOpenRound& rd, bool bind, size_t size, Fr* out_host);
 
 // Resident tail: once the live tables of a sum-check fit the LDS of one CU, ONE launch runs all remaining rounds.
 // Per round the kernel publishes the message (flag = seq0 + i) and polls the mailbox for the challenge, which the host

@@ -121,9 +121,34 @@ SumCheckResult sum_check_prove(Ctx&, int prover_kind, size_t num_vars, const lh_
 
 // the round loop shared by every sum-check front end (prover.cpp)
 typedef std::function<void(const Fr* const*, Fr* const*, const Fr&, bool, size_t, Fr*)> RoundFn;
+// Eq factoring of the streaming rounds.  eq(y, x) = prod_i eq(y_i, x_i), so in round j (prefix bound to rho):
+//   eq(y, (rho, X, b)) = S_j * eq(y_j, X) * E_j[b],   S_j = prod_{i<j} eq(y_i, rho_i),   E_j = eq table over variables > j.
+// The round polynomial of  eq * g  is therefore  p(X) = S_j eq(y_j, X) q(X)  with  q(X) = sum_b E_j[b] g(rho, X, b)  of one
+// degree less: the device evaluates q at one point fewer, reads ONE eq entry per pair instead of streaming and binding a
+// whole eq table, and the host rebuilds exactly the reference's message p(0..D) (field arithmetic is exact: same bytes).
+// q(0) follows from the claim:  claim / S_j = (1 - y_j) q(0) + y_j q(1).  When the rounds leave the streaming kernel the eq
+// table is materialised once in its "previous round" form  S_{j-1} * E_{j-2}  and the standard path continues.
+struct EqFactoring {
+  struct One {
+    size_t table;                    // index of the eq table in `cur` (filled at the switch)
+    const HFr* y;                    // the eq point (num_vars coordinates)
+    std::vector<const Fr*> level;    // level[j] = E_j, 2^(num_vars - 1 - j) entries on the device
+    HFr S, S_prev;                   // S_j, S_{j-1}
+    std::vector<HFr> q;              // q(0..) of the current round
+  };
+  std::vector<One> eqs;    // global-eq shape: one entry; per-term shape (sum_m eq_m * poly_m): one per term, in term order
+  bool per_term = false;
+  std::vector<HFr> inv_1my;  // global-eq shape: (1 - y_j)^-1 for every round
+  HFr c;                     // global-eq shape: claim / S_j
+  // would this round run the streaming kernel (else the eq tables are materialised and the standard path takes over)
+  std::function<bool(bool bind, size_t size)> streams;
+  // launches the factored round; device output: q(1..D-1) (global-eq shape) or q_m(0), q_m(1) per term
+  std::function<void(const Fr* const* in, Fr* const* out, const Fr& r, bool bind, size_t size, size_t round, Fr* out_host)> round;
+};
 SumCheckResult sum_check_loop(Ctx&, int prover_kind, size_t num_vars, int degree, std::vector<const Fr*> cur,
                               const std::vector<char>& used, size_t num_polys, const HFr& sum, Transcript& tr,
-                              bool sharded, const RoundFn& round_fn, const ScRound* tail_rd = nullptr);
+                              bool sharded, const RoundFn& round_fn, const ScRound* tail_rd = nullptr,
+                              EqFactoring* ef = nullptr);
 // general Expression (util/expression.rs) through EvaluationsProver; evals = every poly at x
 SumCheckResult sum_check_prove_expr(Ctx&, size_t num_vars, const lh_expr& expr, const Fr* const* d_polys,
                                     size_t num_polys, const HFr* challenges, size_t num_challenges, const HFr* ys,

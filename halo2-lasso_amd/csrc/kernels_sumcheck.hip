@@ -138,7 +138,11 @@ __global__ __launch_bounds__(256) LH_SC_WAVES_ATTR void sc_round_kernel(ScArgs a
 #pragma unroll
       for (int x = 0; x < D; x++) s[x] = add(s[x], pm[x]);
     }
-    if (rd.global_eq >= 0) {
+    if (rd.eq_level) {  // eq factoring: one entry per pair, the same at every X
+      const Fr e = rd.eq_level[b];
+#pragma unroll
+      for (int x = 0; x < D; x++) s[x] = mul(s[x], e);
+    } else if (rd.global_eq >= 0) {
       Fr v0, v1;
       load_pair<BIND>(rd.in[rd.global_eq], rd.out[rd.global_eq], b, rd.r, m_lo == 0, v0, v1);
       Fr step = sub(v1, v0);
@@ -484,6 +488,110 @@ void k_sc_tail_launch(Ctx& c, const ScRound& rd, int degree, size_t n0, bool fir
   LH_HIP(hipGetLastError());
 }
 
+static size_t sc_lds_max_items() {
+  static const size_t lds_max = [] {
+    const char* e = getenv("LH_SC_LDS_MAX_ITEMS");  // tuning knob: (pairs * terms) up to which the LDS kernel is used
+    return e ? (size_t)atoll(e) : ((size_t)1 << 16);
+  }();
+  return lds_max;
+}
+bool k_sc_round_streams(const ScRound& rd, int degree, size_t size) {
+  return !(rd.num_terms * (uint32_t)degree <= 256 && size * rd.num_terms <= sc_lds_max_items());
+}
+
+__global__ void pair_sums_kernel(const Fr* __restrict__ in, size_t n_out, Fr* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_out; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = add(in[2 * i], in[2 * i + 1]);
+}
+void k_pair_sums(Ctx& c, const Fr* in, size_t n_out, Fr* out) {
+  if (!n_out) return;
+  hipLaunchKernelGGL(pair_sums_kernel, dim3((unsigned)std::min<size_t>((n_out + 255) / 256, 4096)), dim3(256), 0, c.stream, in,
+                     n_out, out);
+}
+
+// ------------------------------------------------------------------ batch-opening rounds with factored eq tables
+// expression sum_m eq_m(x) * poly_m(x) (pcs/multilinear.rs:182-190): per term and pair one bind (2 multiplications),
+// two products with the term's eq-level entry; the eq tables are neither read in full nor bound (prover.cpp).
+template <bool BIND>
+__global__ __launch_bounds__(256) void sc_round_open_kernel(ScOpenRound rd, size_t size, Fr* __restrict__ partials,
+                                                            ScFinish fin) {
+  __shared__ Fr lds[4];
+  constexpr int MAXQ = 2 * SC_OPEN_MAX_TERMS;
+  Fr acc[MAXQ];
+#pragma unroll
+  for (int k = 0; k < MAXQ; k++) acc[k] = Fr::zero();
+  for (size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x; b < size; b += (size_t)gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int m = 0; m < SC_OPEN_MAX_TERMS; m++) {
+      if (m < (int)rd.num_terms) {
+        Fr v0, v1;
+        load_pair<BIND>(rd.in[m], rd.out[m], b, rd.r, true, v0, v1);
+        const Fr e = rd.eq_level[m][b];
+        acc[2 * m] = add(acc[2 * m], mul(e, v0));
+        acc[2 * m + 1] = add(acc[2 * m + 1], mul(e, v1));
+      }
+    }
+  }
+  const int nq = 2 * (int)rd.num_terms;
+#pragma unroll
+  for (int k = 0; k < MAXQ; k++) {
+    if (k < nq) {
+      Fr v = block_reduce_sum(acc[k], lds);
+      if (threadIdx.x == 0) partials[(size_t)blockIdx.x * nq + k] = v;
+    }
+  }
+  if (gridDim.x == 1) {
+    if (threadIdx.x == 0) publish_flag(fin.flag, fin.seq);
+    return;
+  }
+  // final cross-workgroup reduction (same ticket protocol as finish_round, with a run-time count)
+  __shared__ int is_last;
+  if (threadIdx.x < 64) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const uint32_t t = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = t == fin.last_ticket;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      is_last = last;
+    }
+  }
+  __syncthreads();
+  if (!is_last) return;
+  const uint32_t blocks = gridDim.x;
+  for (int k = 0; k < nq; k++) {
+    Fr a = Fr::zero();
+    for (uint32_t i = threadIdx.x; i < blocks; i += blockDim.x) a = add(a, partials[(size_t)i * nq + k]);
+    a = block_reduce_sum(a, lds);
+    if (threadIdx.x == 0) fin.out_host[k] = a;
+  }
+  if (threadIdx.x == 0) publish_flag(fin.flag, fin.seq);
+}
+
+void k_sc_round_open(Ctx& c, const ScOpenRound& rd, bool bind, size_t size, Fr* out_host) {
+  LH_REQUIRE(rd.num_terms >= 1 && rd.num_terms <= (uint32_t)SC_OPEN_MAX_TERMS && size >= 1, LH_ERR_ARG, "sc_round_open: bad shape");
+  const uint32_t seq = c.next_seq();
+  ArenaScope scope(c.arena);
+  size_t g = std::min<size_t>((size + 255) / 256, (size_t)c.num_cus * 4);
+  const int nq = 2 * (int)rd.num_terms;
+  Fr* partials = g == 1 ? out_host : c.arena.alloc_n<Fr>(g * nq);
+  const ScFinish fin = c.finish_for((uint32_t)g, out_host, seq);
+  {
+    // algorithmic bytes: 96 B per bound entry of the polys (192 B per pair and term) + the eq-level entry
+    ProfScope ps(c, bind ? "sc_round_open<bind>" : "sc_round_open<first>", ((bind ? 192.0 : 64.0) + 32.0) * (double)size * rd.num_terms,
+                 (bind ? 4.0 : 2.0) * (double)size * rd.num_terms, (double)size);
+    if (bind)
+      hipLaunchKernelGGL((sc_round_open_kernel<true>), dim3((unsigned)g), dim3(256), 0, c.stream, rd, size, partials, fin);
+    else
+      hipLaunchKernelGGL((sc_round_open_kernel<false>), dim3((unsigned)g), dim3(256), 0, c.stream, rd, size, partials, fin);
+  }
+  c.wait_flag(seq);
+}
+
 void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, Fr* evals_host) {
   LH_REQUIRE(degree >= 1 && degree <= 6, LH_ERR_ARG, "sum-check degree must be in 1..6");
   LH_REQUIRE(size >= 1, LH_ERR_ARG, "sum-check round over an empty table");
@@ -502,11 +610,11 @@ void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, F
   for (int t = 0; t < SC_MAX_TABLES; t++) tabs += seen[t] ? 1 : 0;
   double nfac = 0, ncoef = 0;
   for (uint32_t m = 0; m < rd.num_terms; m++) nfac += rd.nfac[m], ncoef += rd.coeff_is_one[m] ? 0 : 2;
-  const double muls_pair = (nfac - rd.num_terms) * degree + ncoef + (rd.global_eq >= 0 ? degree : 0) +
+  const double muls_pair = (nfac - rd.num_terms) * degree + ncoef + (rd.global_eq >= 0 || rd.eq_level ? degree : 0) +
                            (bind ? 2.0 * (nfac + (rd.global_eq >= 0 ? 1 : 0)) : 0.0);
   // algorithmic bytes: fused round = bind bytes only, 96 B per bound entry = 192 B per pair
   // and table; the unfused first round reads 64 B per pair and table.
-  const double bytes = (bind ? 192.0 : 64.0) * (double)size * (double)tabs;
+  const double bytes = (bind ? 192.0 : 64.0) * (double)size * (double)tabs + (rd.eq_level ? 32.0 * (double)size : 0.0);
   const uint32_t seq = c.next_seq();
   ArenaScope scope(c.arena);
   // sharded rounds (prover.cpp): the D sums stay on the device (all-gather and sum-and-publish follow on the stream)
@@ -522,11 +630,7 @@ void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, F
   uint32_t P = (uint32_t)std::min<size_t>(size, 64);
   P = std::min<uint32_t>(P, LDS_VALS / (2 * (uint32_t)tabs));
   P = std::min<uint32_t>(P, LDS_ITEMS / (rd.num_terms * degree));
-  static const size_t lds_max = [] {
-    const char* e = getenv("LH_SC_LDS_MAX_ITEMS");  // tuning knob: (pairs * terms) up to which the LDS kernel is used
-    return e ? (size_t)atoll(e) : ((size_t)1 << 16);
-  }();
-  const bool use_lds = P >= 1 && rd.num_terms * degree <= 256 && size * rd.num_terms <= lds_max;
+  const bool use_lds = P >= 1 && !rd.eq_level && !k_sc_round_streams(rd, degree, size);
   if (use_lds) {
     // fill a workgroup's 256 threads in the item phase when there are pairs enough
     // ... and keep the bind phase at one entry per thread

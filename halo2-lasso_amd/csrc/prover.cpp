@@ -167,8 +167,9 @@ std::vector<HFr> evaluate_polys_sharded(Ctx& c, const Fr* const* d_polys_local, 
 // D sums at X = 1..D.
 SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degree, std::vector<const Fr*> cur,
                                      const std::vector<char>& used, size_t num_polys, const HFr& sum, Transcript& tr,
-                                     bool sharded, const RoundFn& round_fn, const ScRound* tail_rd) {
+                                     bool sharded, const RoundFn& round_fn, const ScRound* tail_rd, EqFactoring* ef) {
   const size_t T = cur.size();
+  bool ef_on = ef != nullptr && !sharded;
   const size_t tail_cap = tail_rd ? k_sc_tail_capacity(*tail_rd, degree) : 0;
   const size_t rho = sharded ? log2_exact((size_t)c.comm.size) : 0, j = c.shard_bit;
   size_t len = (size_t)1 << (num_vars - rho);  // current length of every (local) table
@@ -234,6 +235,17 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
       flip = 0;
       sh = false;
       bind = false;
+    }
+    if (ef_on && !ef->streams(bind, bind ? len >> 2 : len >> 1)) {
+      // the rounds leave the streaming kernel: materialise every factored eq table in the form the standard path
+      // expects (the tables of the previous round, pending their bind with r_prev): S_{round-1} * E_{round-2}
+      LH_REQUIRE(round >= 2 && bind, LH_ERR_ARG, "sum-check: eq factoring ended before it began");
+      for (EqFactoring::One& one : ef->eqs) {
+        Fr* tab = c.arena.alloc_n<Fr>(len);
+        k_scale(c, one.level[round - 2], dev(one.S_prev), len, tab);
+        cur[one.table] = tab;
+      }
+      ef_on = false;
     }
     if (!sh && tail_ok && tail_cap && (bind ? len >> 1 : len) <= tail_cap) {
       // the rest of the sum-check runs resident on one CU (dev.hpp: k_sc_tail_*): same messages, same order
@@ -339,6 +351,8 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
       const uint32_t seq = c.next_seq();
       k_sum_publish(c, d_all, R, (size_t)degree, evals_host, seq);
       c.wait_flag(seq);
+    } else if (ef_on) {
+      ef->round(cur.data(), dst.data(), dev(r_prev), bind, size, round, evals_host);
     } else {
       round_fn(cur.data(), dst.data(), dev(r_prev), bind, size, evals_host);
     }
@@ -346,6 +360,47 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
       for (size_t i = 0; i < T; i++) cur[i] = dst[i];
       len >>= 1;
       flip ^= 1;
+    }
+    if (ef_on) {
+      // rebuild the reference's round message p(1..D) from the factored sums (host.hpp EqFactoring)
+      Fr std_sums[16];
+      const HFr one = HFr::one();
+      auto eq_at = [&](const HFr& yj, const HFr& x) { return (one - yj) * (one - x) + yj * x; };  // eq(y_j, x)
+      if (!ef->per_term) {
+        EqFactoring::One& e = ef->eqs[0];
+        const HFr yj = e.y[round];
+        e.q.assign(degree, HFr::zero());  // q has degree D - 1: D values q(0..D-1)
+        for (int x = 1; x < degree; x++) e.q[x] = hst(evals_host[x - 1]);
+        e.q[0] = (ef->c - yj * e.q[1]) * ef->inv_1my[round];
+        for (int x = 1; x <= degree; x++) {
+          const HFr fx = HFr::from_u64((uint64_t)x);
+          const HFr qx = x < degree ? e.q[x] : interpolate_evals(e.q, fx);
+          std_sums[x - 1] = dev(e.S * eq_at(yj, fx) * qx);
+        }
+        const HFr r = message(std_sums);
+        ef->c = interpolate_evals(e.q, r);
+        e.S_prev = e.S;
+        e.S = e.S * eq_at(yj, r);
+        r_prev = r;
+      } else {
+        HFr p1 = HFr::zero(), p2 = HFr::zero();
+        const HFr two = HFr::from_u64(2);
+        for (size_t m = 0; m < ef->eqs.size(); m++) {
+          EqFactoring::One& e = ef->eqs[m];
+          const HFr yj = e.y[round];
+          e.q = {hst(evals_host[2 * m]), hst(evals_host[2 * m + 1])};
+          p1 += e.S * yj * e.q[1];                                         // eq(y_j, 1) = y_j
+          p2 += e.S * eq_at(yj, two) * (e.q[1].dbl() - e.q[0]);          // q(2) of a line
+        }
+        std_sums[0] = dev(p1), std_sums[1] = dev(p2);
+        const HFr r = message(std_sums);
+        for (EqFactoring::One& e : ef->eqs) {
+          e.S_prev = e.S;
+          e.S = e.S * eq_at(e.y[round], r);
+        }
+        r_prev = r;
+      }
+      continue;
     }
 
     r_prev = message(evals_host);
@@ -414,12 +469,6 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
   const size_t len0 = (size_t)1 << (num_vars - rho);
   std::vector<const Fr*> cur(T);
   for (size_t i = 0; i < num_polys; i++) cur[i] = d_polys[i];
-  for (size_t jy = 0; jy < num_ys; jy++) {  // ProverState::new: eq_xys (classic.rs:56-60)
-    Fr* eq = c.arena.alloc_n<Fr>(len0);
-    if (sharded) eq_xy_shard(c, ys + jy * num_vars, num_vars, eq);
-    else k_eq_xy(c, (const Fr*)(ys + jy * num_vars), num_vars, eq);
-    cur[num_polys + jy] = eq;
-  }
   auto round_fn = [&](const Fr* const* in, Fr* const* out, const Fr& r, bool bind, size_t size, Fr* evals_host) {
     for (size_t i = 0; i < T; i++) {
       rd.in[i] = in[i];
@@ -428,7 +477,119 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
     rd.r = r;
     k_sc_round(c, rd, degree, bind, size, evals_host);
   };
-  return sum_check_loop(c, prover_kind, num_vars, degree, cur, used, num_polys, sum, tr, sharded, round_fn, &rd);
+
+  // ---- eq factoring of the streaming rounds (host.hpp EqFactoring)
+  static const bool ef_enabled = [] {
+    const char* e = getenv("LH_SC_EQ_FACTORING");  // 0: every round streams and binds its eq tables (A/B measurements)
+    return !e || atoi(e) != 0;
+  }();
+  EqFactoring ef;
+  bool use_ef = false;
+  std::vector<size_t> term_poly;  // per-term shape: the poly of term m
+  if (ef_enabled && !sharded && num_vars >= 3 && k_sc_round_streams(rd, degree, (size_t)1 << (num_vars - 1)) &&
+      k_sc_round_streams(rd, degree, (size_t)1 << (num_vars - 2))) {
+    if (rd.global_eq >= 0 && prover_kind == LH_SC_EVALUATIONS) {
+      // shape A: eq(ys[global_eq]) times a sum of products that does not use that eq table as a factor
+      bool ok = true;
+      for (uint32_t m = 0; m < rd.num_terms && ok; m++)
+        for (int k = 0; k < rd.nfac[m]; k++) ok = ok && rd.fac[m][k] != rd.global_eq;
+      const HFr* y = ys + (size_t)expr.global_eq * num_vars;
+      std::vector<HFr> d(num_vars);
+      for (size_t i = 0; i < num_vars && ok; i++) {
+        d[i] = HFr::one() - y[i];
+        ok = !d[i].is_zero();
+      }
+      if (ok) {
+        // (1 - y_j)^-1 for all rounds with one inversion
+        std::vector<HFr> pre(num_vars + 1);
+        pre[0] = HFr::one();
+        for (size_t i = 0; i < num_vars; i++) pre[i + 1] = pre[i] * d[i];
+        HFr inv = pre[num_vars].inv();
+        ef.inv_1my.resize(num_vars);
+        for (size_t i = num_vars; i-- > 0;) {
+          ef.inv_1my[i] = inv * pre[i];
+          inv = inv * d[i];
+        }
+        ef.per_term = false;
+        ef.c = sum;
+        EqFactoring::One one;
+        one.table = (size_t)rd.global_eq, one.y = y, one.S = one.S_prev = HFr::one();
+        ef.eqs.push_back(one);
+        use_ef = true;
+      }
+    } else if (rd.global_eq < 0 && prover_kind == LH_SC_COEFFICIENTS && rd.num_terms <= (uint32_t)SC_OPEN_MAX_TERMS &&
+               T == 2 * (size_t)rd.num_terms) {
+      // shape B (batch opening): sum_m eq_m * poly_m, coefficient one, every table in exactly one term
+      bool ok = true;
+      std::vector<char> seen(T, 0);
+      for (uint32_t m = 0; m < rd.num_terms && ok; m++) {
+        ok = rd.nfac[m] == 2 && rd.coeff_is_one[m];
+        if (!ok) break;
+        size_t a = rd.fac[m][0], b = rd.fac[m][1];
+        if (a < num_polys) std::swap(a, b);  // a: the eq table, b: the poly
+        ok = a >= num_polys && b < num_polys && !seen[a] && !seen[b];
+        if (!ok) break;
+        seen[a] = seen[b] = 1;
+        EqFactoring::One one;
+        one.table = a, one.y = ys + (a - num_polys) * num_vars, one.S = one.S_prev = HFr::one();
+        ef.eqs.push_back(one);
+        term_poly.push_back(b);
+      }
+      ef.per_term = true;
+      use_ef = ok;
+    }
+  }
+  if (use_ef) {
+    const size_t half = (size_t)1 << (num_vars - 1);
+    for (EqFactoring::One& one : ef.eqs) {
+      // level j at offset (2^(n-1) - 2^(n-1-j)) * 2 ... simply: consecutive blocks of halving size in one buffer
+      Fr* buf = c.arena.alloc_n<Fr>(2 * half);
+      one.level.resize(num_vars);
+      size_t off = 0;
+      for (size_t jl = 0; jl < num_vars; jl++) {
+        one.level[jl] = buf + off;
+        off += half >> jl;
+      }
+      k_eq_xy(c, (const Fr*)(one.y + 1), num_vars - 1, buf);  // E_0: the eq table over variables 1..n-1
+    }
+    ef.streams = [&](bool, size_t size) { return k_sc_round_streams(rd, degree, size); };
+    ef.round = [&](const Fr* const* in, Fr* const* out, const Fr& r, bool bind, size_t size, size_t round, Fr* out_host) {
+      if (round > 0)  // E_round from E_{round-1}: the two entries that differ in variable `round` add up
+        for (EqFactoring::One& one : ef.eqs)
+          k_pair_sums(c, one.level[round - 1], size, (Fr*)one.level[round]);
+      if (!ef.per_term) {
+        ScRound g = rd;
+        for (size_t i = 0; i < T; i++) g.in[i] = in[i], g.out[i] = out[i];
+        g.r = r;
+        g.global_eq = -1;
+        g.eq_level = ef.eqs[0].level[round];
+        k_sc_round(c, g, degree - 1, bind, size, out_host);
+      } else {
+        ScOpenRound g;
+        g.num_terms = rd.num_terms;
+        g.r = r;
+        for (uint32_t m = 0; m < rd.num_terms; m++) {
+          g.in[m] = in[term_poly[m]], g.out[m] = out[term_poly[m]];
+          g.eq_level[m] = ef.eqs[m].level[round];
+        }
+        k_sc_round_open(c, g, bind, size, out_host);
+      }
+    };
+  }
+  // ProverState::new: eq_xys (classic.rs:56-60); a factored eq table is not built - its slot is filled when the rounds
+  // leave the streaming kernel
+  for (size_t jy = 0; jy < num_ys; jy++) {
+    bool factored = false;
+    if (use_ef)
+      for (const EqFactoring::One& one : ef.eqs) factored = factored || one.table == num_polys + jy;
+    if (factored) continue;
+    Fr* eq = c.arena.alloc_n<Fr>(len0);
+    if (sharded) eq_xy_shard(c, ys + jy * num_vars, num_vars, eq);
+    else k_eq_xy(c, (const Fr*)(ys + jy * num_vars), num_vars, eq);
+    cur[num_polys + jy] = eq;
+  }
+  return sum_check_loop(c, prover_kind, num_vars, degree, cur, used, num_polys, sum, tr, sharded, round_fn, &rd,
+                        use_ef ? &ef : nullptr);
 }
 
 SumCheckResult sum_check_prove(Ctx& c, int prover_kind, size_t num_vars, const lh_sop& expr,
