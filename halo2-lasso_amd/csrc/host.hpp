@@ -142,8 +142,11 @@ struct EqFactoring {
   HFr c;                     // global-eq shape: claim / S_j
   // would this round run the streaming kernel (else the eq tables are materialised and the standard path takes over)
   std::function<bool(bool bind, size_t size)> streams;
-  // launches the factored round; device output: q(1..D-1) (global-eq shape) or q_m(0), q_m(1) per term
-  std::function<void(const Fr* const* in, Fr* const* out, const Fr& r, bool bind, size_t size, size_t round, Fr* out_host)> round;
+  // launches the factored round; device output: q(1..points) (global-eq shape; points = D - 1, or D in round 0 where the
+  // claim is checked rather than trusted) or q_m(0), q_m(1) per term
+  std::function<void(const Fr* const* in, Fr* const* out, const Fr& r, bool bind, size_t size, size_t round, int points,
+                     Fr* out_host)>
+      round;
 };
 SumCheckResult sum_check_loop(Ctx&, int prover_kind, size_t num_vars, int degree, std::vector<const Fr*> cur,
                               const std::vector<char>& used, size_t num_polys, const HFr& sum, Transcript& tr,

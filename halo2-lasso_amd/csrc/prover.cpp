@@ -213,6 +213,7 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
     res.challenges.push_back(r);
     return r;
   };
+  bool factored_round = false;
   Fr *d_part = nullptr, *d_all = nullptr;  // sharded rounds: this rank's D sums, every rank's
   bool tail_ok = true;  // cleared when a resident tail ended early: the remaining rounds are launched one by one
   for (size_t round = 0; round < num_vars; round++) {
@@ -327,6 +328,7 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
     }
     const size_t size = bind ? len >> 2 : len >> 1;
     std::vector<Fr*>& dst = flip ? bufB : bufA;
+    factored_round = false;
     if (bind) {
       // tables no term touches are still bound (ProverState::next_round binds every poly)
       for (size_t i = 0; i < T; i++)
@@ -352,7 +354,32 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
       k_sum_publish(c, d_all, R, (size_t)degree, evals_host, seq);
       c.wait_flag(seq);
     } else if (ef_on) {
-      ef->round(cur.data(), dst.data(), dev(r_prev), bind, size, round, evals_host);
+      // global-eq shape, round 0: one point more (q at 1..D determines q(0) too), so that the claim can be CHECKED instead
+      // of trusted: with a claim that is not the true sum the reference still sends the true p(1..D), and so must we
+      const bool check_claim = !ef->per_term && round == 0;
+      ef->round(cur.data(), dst.data(), dev(r_prev), bind, size, round, check_claim ? degree : degree - 1, evals_host);
+      factored_round = true;
+      if (check_claim) {
+        EqFactoring::One& e = ef->eqs[0];
+        std::vector<HFr> shifted(degree);  // t -> q(t + 1), t = 0..D-1
+        for (int x = 0; x < degree; x++) shifted[x] = hst(evals_host[x]);
+        const HFr q0 = interpolate_evals(shifted, HFr::zero() - HFr::one());
+        const HFr y0 = e.y[0];
+        if ((HFr::one() - y0) * q0 + y0 * shifted[0] != ef->c) {
+          // not the true sum: every round takes the standard path (eq tables built in full)
+          for (EqFactoring::One& one : ef->eqs) {
+            Fr* tab = c.arena.alloc_n<Fr>(len);
+            k_eq_xy(c, (const Fr*)one.y, num_vars, tab);
+            cur[one.table] = tab;
+          }
+          ef_on = factored_round = false;
+          round_fn(cur.data(), dst.data(), dev(r_prev), bind, size, evals_host);
+        } else {
+          e.q.assign(degree, HFr::zero());
+          e.q[0] = q0;
+          for (int x = 1; x < degree; x++) e.q[x] = shifted[x - 1];
+        }
+      }
     } else {
       round_fn(cur.data(), dst.data(), dev(r_prev), bind, size, evals_host);
     }
@@ -361,7 +388,7 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
       len >>= 1;
       flip ^= 1;
     }
-    if (ef_on) {
+    if (factored_round) {
       // rebuild the reference's round message p(1..D) from the factored sums (host.hpp EqFactoring)
       Fr std_sums[16];
       const HFr one = HFr::one();
@@ -369,9 +396,11 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
       if (!ef->per_term) {
         EqFactoring::One& e = ef->eqs[0];
         const HFr yj = e.y[round];
-        e.q.assign(degree, HFr::zero());  // q has degree D - 1: D values q(0..D-1)
-        for (int x = 1; x < degree; x++) e.q[x] = hst(evals_host[x - 1]);
-        e.q[0] = (ef->c - yj * e.q[1]) * ef->inv_1my[round];
+        if (round > 0) {
+          e.q.assign(degree, HFr::zero());  // q has degree D - 1: D values q(0..D-1)
+          for (int x = 1; x < degree; x++) e.q[x] = hst(evals_host[x - 1]);
+          e.q[0] = (ef->c - yj * e.q[1]) * ef->inv_1my[round];
+        }
         for (int x = 1; x <= degree; x++) {
           const HFr fx = HFr::from_u64((uint64_t)x);
           const HFr qx = x < degree ? e.q[x] : interpolate_evals(e.q, fx);
@@ -553,7 +582,8 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
       k_eq_xy(c, (const Fr*)(one.y + 1), num_vars - 1, buf);  // E_0: the eq table over variables 1..n-1
     }
     ef.streams = [&](bool, size_t size) { return k_sc_round_streams(rd, degree, size); };
-    ef.round = [&](const Fr* const* in, Fr* const* out, const Fr& r, bool bind, size_t size, size_t round, Fr* out_host) {
+    ef.round = [&](const Fr* const* in, Fr* const* out, const Fr& r, bool bind, size_t size, size_t round, int points,
+                   Fr* out_host) {
       if (round > 0)  // E_round from E_{round-1}: the two entries that differ in variable `round` add up
         for (EqFactoring::One& one : ef.eqs)
           k_pair_sums(c, one.level[round - 1], size, (Fr*)one.level[round]);
@@ -563,7 +593,7 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
         g.r = r;
         g.global_eq = -1;
         g.eq_level = ef.eqs[0].level[round];
-        k_sc_round(c, g, degree - 1, bind, size, out_host);
+        k_sc_round(c, g, points, bind, size, out_host);
       } else {
         ScOpenRound g;
         g.num_terms = rd.num_terms;
