@@ -101,29 +101,41 @@ def aggregate(recs):
     return sorted(by.values(), key=lambda a: -a["ms"])
 
 
-def pmc_traffic(profile_name, log_n, table_kind, world=1):
-    """HBM bytes of the kernel's largest launch from the committed PMC passes (profiles/r01_pmc_*.json:
-    rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for streaming reads).  Counters cannot be collected from inside this
-    process, so the figure is the recorded one for the same workload, or None."""
-    if table_kind != "range":
+PMC_KERNEL_NAMES = {"msm_accumulate0": "msm_accumulate0_kernel", "msm_bucket_reduce": "msm_segment_reduce_kernel",
+                    "msm_accumulate_levels": "msm_accumulate_n_kernel", "lincomb": "lincomb_kernel",
+                    "tree_up": "tree_up_kernel", "sc_round_open<bind>": "sc_round_open_kernel<true>",
+                    "sc_round_open<first>": "sc_round_open_kernel<false>"}
+
+
+def pmc_traffic(profile_name, log_n, table_kind, world=1, launches_per_proof=None):
+    """HBM bytes per launch of the kernel (average over its launches, like `achieved`) from the PMC passes committed under
+    profiles/ (tools/pmc_extract.py: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of the same
+    workload, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for streaming reads).  Counters cannot be collected
+    from inside this process, so the figure is the recorded one; it is used only when the record is of THIS workload
+    and the kernel's number of launches per proof matches this run's (a changed launch structure means a stale
+    record: null then)."""
+    if world != 1:
         return None, None
-    path = os.path.join(ROOT, "profiles", "r01_pmc_2p%d.json" % log_n)
-    if not os.path.exists(path):
-        return None, None
+    import glob
     import re
     m = re.match(r"sc_round<(\d),(bind|first)>(/lds|/tp)?$", profile_name)
     if m:
         kern = "sc_round_%skernel<%s, %s>" % ("lds_" if m.group(3) == "/lds" else "", m.group(1),
                                               "true" if m.group(2) == "bind" else "false")
     else:
-        kern = {"msm_accumulate0": "msm_accumulate0_kernel", "msm_bucket_reduce": "msm_segment_reduce_kernel",
-                "msm_accumulate_levels": "msm_accumulate_n_kernel", "lincomb": "lincomb_kernel",
-                "tree_up": "tree_up_kernel"}.get(profile_name)
-    rec = json.load(open(path))["kernels"].get(kern) if kern else None
-    if not rec:
+        kern = PMC_KERNEL_NAMES.get(profile_name)
+    if not kern:
         return None, None
-    return rec["hbm_bytes_corrected"], "profiles/%s (%s, largest launch)" % (os.path.basename(path), kern)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s_2p%d*.json" % (table_kind, log_n))), reverse=True):
+        rec = json.load(open(path))["kernels"].get(kern)
+        if not rec or "hbm_bytes_per_launch_avg" not in rec:
+            continue
+        if launches_per_proof is not None and abs(rec["launches_per_proof"] - launches_per_proof) > 1e-9:
+            continue
+        note = "" if rec.get("calibrated", True) else "; gather kernel: counter uncalibrated for this access shape"
+        return rec["hbm_bytes_per_launch_avg"], "profiles/%s (%s, average over %d launches%s)" % (
+            os.path.basename(path), kern, rec["launches_in_run"], note)
+    return None, None
 
 
 def fr_mul_peak(hl, ctx):
@@ -473,9 +485,9 @@ def main():
         if rank == 0:
             aggs = aggregate(hl.profile_read(ctx))
             hl.profile_enable(ctx, False)
-            dom_name = max(aggs, key=lambda a: a["ms"])["name"]
+            dom = max(aggs, key=lambda a: a["ms"])
             out["roofline"], out["alu"], out["kernels"] = roofline_objects(
-                hl, ctx, aggs, pmc_traffic(dom_name, n, args.table, world))
+                hl, ctx, aggs, pmc_traffic(dom["name"], n, args.table, world, dom["launches"]))
     if sharded:
         # the sharded proof against the single-GPU prover on the same lookups (rank 0 holds the whole batch for it)
         stats = hl.comm_stats(ctx)

@@ -1,35 +1,51 @@
-"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE counter_collection.csv (two separate passes) -> JSON of
-per-kernel HBM traffic at the largest launch.  Corrections per MI355X_MICROARCH.md §HBM: counters are in
-KB; on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced streaming read, WRITE_SIZE
-is exact for 16-B-per-lane streaming stores (other access shapes are uncalibrated: gathers are flagged)."""
-import csv, json, re, sys, collections
+"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE counter_collection.csv (two separate passes over the same program) -> JSON of
+per-kernel HBM traffic: per-launch average (what bench.py's roofline.traffic reports next to the per-launch `achieved`),
+total over the run, and the largest launch.  Corrections per MI355X_MICROARCH.md §HBM: counters are in KB; on gfx950
+FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced streaming read (16 B per lane), WRITE_SIZE is exact for
+16-B-per-lane streaming stores.  Other access shapes are uncalibrated and flagged: a gather kernel such as
+msm_accumulate0 (64-byte random reads pulling 128-byte lines) is listed with the same formula for comparison only.
+
+usage: pmc_extract.py FETCH.csv WRITE.csv "workload description" proofs_in_run OUT.json"""
+import collections
+import csv
+import json
+import re
+import sys
+
 
 def short(name):
     m = re.match(r"(?:void )?(?:lh::)?([A-Za-z0-9_]+)(<[^>]*>)?", name)
     return (m.group(1) + (m.group(2) or "")) if m else name[:40]
 
+
 def load(path, counter):
-    best = collections.defaultdict(lambda: (-1.0, 0, 0))
+    acc = collections.defaultdict(lambda: dict(n=0, total=0.0, big=0.0, grid=0))
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        k = short(r["Kernel_Name"])
+        a = acc[short(r["Kernel_Name"])]
         v = float(r["Counter_Value"])
-        cnt = best[k][2] + 1
-        if v > best[k][0]:
-            best[k] = (v, int(r["Grid_Size"]), cnt)
-        else:
-            best[k] = (best[k][0], best[k][1], cnt)
-    return best
+        a["n"] += 1
+        a["total"] += v
+        if v > a["big"]:
+            a["big"], a["grid"] = v, int(r["Grid_Size"])
+    return acc
 
+
+GATHER = {"msm_accumulate0_kernel", "msm_derived_gather_kernel", "rotate_gather_kernel"}
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+proofs = int(sys.argv[4])
 out = {}
 for k in sorted(set(fetch) | set(write)):
-    f, g, n = fetch.get(k, (0.0, 0, 0))
-    w = write.get(k, (0.0, 0, 0))[0]
-    out[k] = {"launches": n, "largest_grid_threads": g, "FETCH_SIZE_KB_raw": f, "WRITE_SIZE_KB": w,
-              "hbm_bytes_corrected": int((2.0 * f + w) * 1024)}
-json.dump({"note": "largest launch per kernel; hbm_bytes_corrected = (2*FETCH_SIZE + WRITE_SIZE) KB "
-                   "(streaming-read correction of MI355X_MICROARCH.md; gather kernels such as msm_accumulate0 are "
-                   "uncalibrated)", "workload": sys.argv[3], "kernels": out}, open(sys.argv[4], "w"), indent=1)
-print("wrote", sys.argv[4], len(out), "kernels")
+    f, w = fetch.get(k, dict(n=0, total=0.0, big=0.0, grid=0)), write.get(k, dict(n=0, total=0.0, big=0.0, grid=0))
+    n = max(f["n"], w["n"])
+    out[k] = {"launches_in_run": n, "launches_per_proof": n / proofs,
+              "hbm_bytes_per_launch_avg": int((2.0 * f["total"] + w["total"]) * 1024 / max(n, 1)),
+              "hbm_bytes_per_proof": int((2.0 * f["total"] + w["total"]) * 1024 / proofs),
+              "largest_launch": {"grid_threads": f["grid"] or w["grid"], "FETCH_SIZE_KB_raw": f["big"],
+                                 "WRITE_SIZE_KB": w["big"], "hbm_bytes_corrected": int((2.0 * f["big"] + w["big"]) * 1024)},
+              "calibrated": k not in GATHER}
+json.dump({"note": "hbm bytes = (2 * FETCH_SIZE + WRITE_SIZE) KB, the streaming-read correction of MI355X_MICROARCH.md; "
+                   "calibrated = false marks gather kernels, for which the counter is uncalibrated",
+           "workload": sys.argv[3], "proofs_in_run": proofs, "kernels": out}, open(sys.argv[5], "w"), indent=1)
+print("wrote", sys.argv[5], len(out), "kernels")
