@@ -189,6 +189,11 @@ void k_inner_products(Ctx&, const Fr* const* polys, size_t count, const Fr* weig
 // same with u32-valued polys
 void k_inner_products_u32(Ctx&, const uint32_t* const* polys, size_t count, const Fr* weights, size_t n,
                           Fr* out_host);
+// small-valued columns without their field-element views: 8 multiply-adds per term into a wide accumulator
+void k_inner_products_small(Ctx&, const uint32_t* const* polys, size_t count, const Fr* weights, size_t n, Fr* out_host);
+// out[i] = sum_k wfr[k] fr[k][i] + sum_k wsm[k] sm[k][i], i < n; u32 column k has sm_len[k] entries (zero beyond)
+void k_lincomb_mixed(Ctx&, const Fr* const* fr, const Fr* wfr, size_t num_fr, const uint32_t* const* sm,
+                     const size_t* sm_len, const Fr* wsm, size_t num_sm, size_t n, Fr* out);
 // product tree level: out[i] = in[i] * in[half + i]
 void k_tree_up(Ctx&, const Fr* in, size_t half, Fr* out);
 // every level above level H[i] (2^(H+1) nodes at in[i], H <= 9) of `count` product trees, one launch:

@@ -197,13 +197,20 @@ std::vector<HG1> mkzg_batch_commit(Ctx&, const Srs&, const Fr* const* d_polys, s
 std::vector<HG1> mkzg_batch_commit_u32(Ctx&, const Srs&, const uint32_t* const* d_polys, size_t num_polys,
                                        size_t num_vars);
 HFr mkzg_open(Ctx&, const Srs&, const Fr* d_poly, size_t num_vars, const HFr* point, Transcript& tr);
+// a poly handed over as its small-valued u32 column (`len` entries, zero beyond): Lasso's dim / read_ts / E / final_cts
+// reach the batch opening without a field-element view (d_polys[i] may then be null)
+struct SmallPoly {
+  const uint32_t* ptr = nullptr;
+  size_t len = 0;
+};
 void mkzg_batch_open(Ctx&, const Srs&, size_t num_vars, const Fr* const* d_polys, size_t num_polys,
                      const HFr* points, size_t num_points, const lh_evaluation* evals, size_t num_evals,
-                     Transcript& tr);
+                     Transcript& tr, const SmallPoly* small = nullptr);
 
 void additive_batch_open(Ctx&, size_t num_vars, const Fr* const* d_polys, size_t num_polys, const HFr* points,
                          size_t num_points, const lh_evaluation* evals, size_t num_evals, Transcript& tr,
-                         const std::function<void(const Fr* g_prime, const HFr* point)>& open);
+                         const std::function<void(const Fr* g_prime, const HFr* point)>& open,
+                         const SmallPoly* small = nullptr);
 
 // ------------------------------------------------------------------ pcs::multilinear::zeromorph over pcs::univariate::kzg
 struct USrs {  // UnivariateKzgParam (univariate/kzg.rs:38-66): powers_of_s_g1 on the device
@@ -218,7 +225,7 @@ void zeromorph_open(Ctx&, const USrs&, size_t poly_size, const Fr* d_poly, size_
                     Transcript& tr);
 void zeromorph_batch_open(Ctx&, const USrs&, size_t poly_size, size_t num_vars, const Fr* const* d_polys,
                           size_t num_polys, const HFr* points, size_t num_points, const lh_evaluation* evals,
-                          size_t num_evals, Transcript& tr);
+                          size_t num_evals, Transcript& tr, const SmallPoly* small = nullptr);
 // zeromorph.rs:258-296 -> (eval_scalar, q_scalars)
 std::pair<HFr, std::vector<HFr>> zeromorph_scalars(const HFr& y, const HFr& x, const HFr& z, const HFr* u, size_t n);
 struct ZmVerifierParams;  // ZeromorphKzgVerifierParam (zeromorph.rs:42-65)
@@ -239,7 +246,7 @@ struct LassoPcs {
   std::function<const G1Affine*(size_t nv)> commit_bases;
   size_t max_vars;
   std::function<void(size_t num_vars, const Fr* const* d_polys, size_t num_polys, const HFr* points, size_t num_points,
-                     const lh_evaluation* evals, size_t num_evals, Transcript& tr)>
+                     const lh_evaluation* evals, size_t num_evals, Transcript& tr, const SmallPoly* small)>
       batch_open;
 };
 LassoPcs lasso_mkzg_pcs(Ctx&, const Srs&);
@@ -258,8 +265,8 @@ struct LassoClaims {  // points and claimed evaluations that remain to be opened
 void lasso_check_table(const lh_lasso_table& tb);
 LassoColumns lasso_witness_columns(Ctx&, const lh_lasso_table&, size_t n, const uint32_t* const* d_dims, Fr** a_out);
 LassoClaims lasso_argue(Ctx&, const lh_lasso_table&, size_t n, const LassoColumns& w, const uint32_t* const* d_dims,
-                        const Fr* a, const Fr* const* dim_fr, const Fr* const* rts_fr, const Fr* const* E_fr,
-                        const Fr* const* fcs_fr, Transcript& tr, const std::function<void(int)>& lap = nullptr);
+                        const Fr* a, const Fr* const* E_fr, Transcript& tr,
+                        const std::function<void(int)>& lap = nullptr);
 // commitment framing of the Lasso argument: identity mask as one field element, then the non-identity commitments
 void lasso_write_commitments(Transcript& tr, const std::vector<HG1>& comms);
 std::vector<HG1> lasso_read_commitments(Transcript& tr, size_t count);

@@ -388,8 +388,7 @@ void hyperplonk_prove_phases(Ctx& c, const PcsProver& pcs, const lh_hp_param& pp
     tr.common_field_element(HFr::from_u64(l));
     tr.common_field_element(HFr::from_u64(cc));
     tr.common_field_element(HFr::from_u64(alpha));
-    LassoClaims cl = lasso_argue(c, tb, nv, st.cols, st.dims.data(), polys[st.lk->output_poly], st.dim_fr.data(),
-                                 st.rts_fr.data(), st.E_fr.data(), st.fcs_fr.data(), tr);
+    LassoClaims cl = lasso_argue(c, tb, nv, st.cols, st.dims.data(), polys[st.lk->output_poly], st.E_fr.data(), tr);
     const size_t base = polys.size(), p0 = num_points;
     for (const Fr* p : st.rts_fr) polys.push_back(p);
     for (const Fr* p : st.E_fr) polys.push_back(p);

@@ -2,6 +2,7 @@
 // All are HBM- or integer-ALU-bound streams: 256-thread blocks, grid-stride, 16-B vector
 // accesses (an Fr is two dwordx4), no LDS except for block reductions.
 #include <hip/hip_runtime.h>
+#include <string.h>
 #include <algorithm>
 #include "dev.hpp"
 #include "reduce.cuh"
@@ -470,6 +471,128 @@ void k_inner_products_u32(Ctx& c, const uint32_t* const* polys, size_t count, co
   inner_products_impl<true>(c, (const void* const*)polys, count, weights, n, out_host);
 }
 
+// ------------------------------------------------------------------ small-valued columns (Lasso's dim / read_ts / E / final_cts)
+// A Montgomery residue W = w R mod r times a 32-bit integer v is 8 multiply-adds into a 10-limb integer accumulator
+// (no reduction); a sum T of such products is reduced ONCE:  T mod r = mont(T_lo, R mod r) + (T_hi R mod r)  - the
+// Montgomery product with the residue of one reduces any 256-bit integer, the high limbs re-enter as Fr::from(T_hi).
+// A term costs 8 v_mad_u64_u32 instead of the 129 + 129 of from_u64 followed by mul.
+struct Wide {
+  uint32_t l[10];
+  __device__ __forceinline__ static Wide zero() {
+    Wide w;
+#pragma unroll
+    for (int k = 0; k < 10; k++) w.l[k] = 0;
+    return w;
+  }
+};
+__device__ __forceinline__ void wide_mac(Wide& acc, const Fr& w, uint32_t v) {
+  uint64_t carry = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const uint64_t t = (uint64_t)w.l[k] * v + acc.l[k] + carry;  // < 2^64: (2^32-1)^2 + 2 (2^32-1)
+    acc.l[k] = (uint32_t)t;
+    carry = t >> 32;
+  }
+  const uint64_t t = (uint64_t)acc.l[8] + carry;
+  acc.l[8] = (uint32_t)t;
+  acc.l[9] += (uint32_t)(t >> 32);
+}
+__device__ __forceinline__ Fr wide_reduce(const Wide& acc) {
+  Fr lo;
+#pragma unroll
+  for (int k = 0; k < 8; k++) lo.l[k] = acc.l[k];
+  const Fr one = from_u64<FrParams>(1);  // R mod r
+  const uint64_t hi = (uint64_t)acc.l[8] | ((uint64_t)acc.l[9] << 32);
+  Fr r = mul(lo, one);  // lo < 2^256, one < r: the product-scanning multiplication stays below 2 r (ff.cuh)
+  if (hi) r = add(r, from_u64<FrParams>(hi));
+  return r;
+}
+
+// out[i] = sum_k w_k fr_k[i] + sum_k w'_k u32_k[i]  (u32 columns of their own lengths, zero beyond)
+constexpr int LCM_MAX_FR = 8, LCM_MAX_SMALL = 24;
+struct LcMixed {
+  const Fr* fr[LCM_MAX_FR];
+  Fr wfr[LCM_MAX_FR];
+  const uint32_t* sm[LCM_MAX_SMALL];
+  uint64_t sm_len[LCM_MAX_SMALL];
+  Fr wsm[LCM_MAX_SMALL];
+  int num_fr, num_sm;
+};
+__global__ void lincomb_mixed_kernel(const LcMixed* __restrict__ pkp, size_t n, Fr* __restrict__ out) {
+  const LcMixed& pk = *pkp;
+  GSTRIDE(i, n) {
+    Wide t = Wide::zero();
+    for (int k = 0; k < pk.num_sm; k++)
+      if (i < pk.sm_len[k]) wide_mac(t, pk.wsm[k], pk.sm[k][i]);
+    Fr acc = pk.num_sm ? wide_reduce(t) : Fr::zero();
+    for (int k = 0; k < pk.num_fr; k++) acc = add(acc, mul(pk.fr[k][i], pk.wfr[k]));
+    out[i] = acc;
+  }
+}
+void k_lincomb_mixed(Ctx& c, const Fr* const* fr, const Fr* wfr, size_t num_fr, const uint32_t* const* sm,
+                     const size_t* sm_len, const Fr* wsm, size_t num_sm, size_t n, Fr* out) {
+  LH_REQUIRE(num_fr <= (size_t)LCM_MAX_FR && num_sm <= (size_t)LCM_MAX_SMALL, LH_ERR_ARG, "lincomb_mixed: too many inputs");
+  ProfScope ps(c, "lincomb", 32.0 * n * (num_fr + 1) + 4.0 * n * num_sm, 1.0 * n * num_fr + 0.07 * n * num_sm + 2.0 * n, (double)n);
+  if (!n) return;
+  LcMixed pk;
+  memset(&pk, 0, sizeof(pk));
+  pk.num_fr = (int)num_fr, pk.num_sm = (int)num_sm;
+  for (size_t k = 0; k < num_fr; k++) pk.fr[k] = fr[k], pk.wfr[k] = wfr[k];
+  for (size_t k = 0; k < num_sm; k++) pk.sm[k] = sm[k], pk.sm_len[k] = sm_len[k], pk.wsm[k] = wsm[k];
+  ArenaScope scope(c.arena);  // the argument block exceeds the 4 KB of kernel arguments: it travels through memory
+  LcMixed* d_pk = (LcMixed*)c.arena.alloc(sizeof(LcMixed));
+  LcMixed* h_pk = (LcMixed*)c.pin(65536);
+  memcpy(h_pk, &pk, sizeof(pk));
+  LH_HIP(hipMemcpyAsync(d_pk, h_pk, sizeof(pk), hipMemcpyHostToDevice, c.stream));
+  hipLaunchKernelGGL(lincomb_mixed_kernel, grid_for(n), 256, 0, c.stream, d_pk, n, out);
+  c.sync();  // the pinned staging block is reused by the next caller
+}
+
+// out[k] = <u32 column k, weights> for up to IPS_GROUP columns per launch row: the weight is loaded once per entry
+constexpr int IPS_GROUP = 6;
+struct IpSmallPack {
+  const uint32_t* p[IPS_GROUP];
+  int count;
+};
+__global__ __launch_bounds__(256) void inner_products_small_kernel(IpSmallPack pk, const Fr* __restrict__ w, size_t n,
+                                                                   Fr* __restrict__ partials) {
+  __shared__ Fr lds[4];
+  Wide acc[IPS_GROUP];
+#pragma unroll
+  for (int k = 0; k < IPS_GROUP; k++) acc[k] = Wide::zero();
+  GSTRIDE(i, n) {
+    const Fr wi = w[i];
+#pragma unroll
+    for (int k = 0; k < IPS_GROUP; k++)
+      if (k < pk.count) wide_mac(acc[k], wi, pk.p[k][i]);
+  }
+#pragma unroll
+  for (int k = 0; k < IPS_GROUP; k++) {
+    if (k < pk.count) {
+      Fr v = block_reduce_sum(wide_reduce(acc[k]), lds);
+      if (threadIdx.x == 0) partials[(size_t)k * gridDim.x + blockIdx.x] = v;
+    }
+  }
+}
+void k_inner_products_small(Ctx& c, const uint32_t* const* polys, size_t count, const Fr* weights, size_t n,
+                            Fr* out_host) {
+  ProfScope ps(c, "inner_products", 4.0 * n * count + 32.0 * n * ((count + IPS_GROUP - 1) / IPS_GROUP), 0.07 * n * count, (double)n);
+  if (!count) return;
+  ArenaScope scope(c.arena);
+  // a thread's 10-limb accumulator holds up to 2^34 terms of 2^286: the grid-stride share of any n < 2^31 fits
+  dim3 g = grid_for(n, 256, 1024);
+  Fr* partials = c.arena.alloc_n<Fr>((size_t)g.x * IPS_GROUP);
+  Fr* d_out = c.arena.alloc_n<Fr>(count);
+  for (size_t base = 0; base < count; base += IPS_GROUP) {
+    IpSmallPack pk;
+    pk.count = (int)std::min<size_t>(IPS_GROUP, count - base);
+    for (int i = 0; i < IPS_GROUP; i++) pk.p[i] = i < pk.count ? polys[base + i] : nullptr;
+    hipLaunchKernelGGL(inner_products_small_kernel, g, 256, 0, c.stream, pk, weights, n, partials);
+    hipLaunchKernelGGL(reduce_rows_kernel, pk.count, 256, 0, c.stream, partials, (int)g.x, d_out + base);
+  }
+  c.d2h(out_host, d_out, count * sizeof(Fr));
+}
+
 // ------------------------------------------------------------------ GKR layer-up
 // product tree (Lasso memory check): out[i] = in[i] * in[half+i]
 __global__ void tree_up_kernel(const Fr* __restrict__ in, size_t half, Fr* __restrict__ out) {
@@ -693,10 +816,12 @@ __global__ void lasso_rw_leaves_kernel(const uint32_t* __restrict__ dim, const u
                                        Fr* __restrict__ rs, Fr* __restrict__ ws) {
   const Fr one = Fr::one();
   GSTRIDE(i, n) {
-    Fr a = mul(from_u64<FrParams>(dim[i]), gamma2);
-    Fr v = mul(from_u64<FrParams>(e[i]), gamma);
-    Fr t = from_u64<FrParams>(ts[i]);
-    Fr h = sub(add(add(a, v), t), tau);
+    // three residue-times-small-integer products into one wide accumulator, one reduction (see `Wide` above)
+    Wide t = Wide::zero();
+    wide_mac(t, gamma2, dim[i]);
+    wide_mac(t, gamma, e[i]);
+    wide_mac(t, one, ts[i]);
+    Fr h = sub(wide_reduce(t), tau);
     rs[i] = h;
     ws[i] = add(h, one);
   }

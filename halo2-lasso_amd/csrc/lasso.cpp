@@ -17,8 +17,8 @@ LassoPcs lasso_mkzg_pcs(Ctx& c, const Srs& srs) {
   p.commit_bases = [&srs](size_t nv) { return srs.eq(nv); };
   p.max_vars = srs.num_vars;
   p.batch_open = [&c, &srs](size_t nv, const Fr* const* polys, size_t np, const HFr* points, size_t npts,
-                            const lh_evaluation* evals, size_t ne, Transcript& tr) {
-    mkzg_batch_open(c, srs, nv, polys, np, points, npts, evals, ne, tr);
+                            const lh_evaluation* evals, size_t ne, Transcript& tr, const SmallPoly* small) {
+    mkzg_batch_open(c, srs, nv, polys, np, points, npts, evals, ne, tr, small);
   };
   return p;
 }
@@ -29,8 +29,8 @@ LassoPcs lasso_zeromorph_pcs(Ctx& c, const USrs& srs, size_t poly_size) {
   p.max_vars = 0;
   while (((size_t)2 << p.max_vars) <= poly_size) p.max_vars++;
   p.batch_open = [&c, &srs, poly_size](size_t nv, const Fr* const* polys, size_t np, const HFr* points, size_t npts,
-                                       const lh_evaluation* evals, size_t ne, Transcript& tr) {
-    zeromorph_batch_open(c, srs, poly_size, nv, polys, np, points, npts, evals, ne, tr);
+                                       const lh_evaluation* evals, size_t ne, Transcript& tr, const SmallPoly* small) {
+    zeromorph_batch_open(c, srs, poly_size, nv, polys, np, points, npts, evals, ne, tr, small);
   };
   return p;
 }
@@ -147,8 +147,7 @@ LassoColumns lasso_witness_columns(Ctx& c, const lh_lasso_table& tb, size_t n, c
 // Steps 2-7 of the argument (oracle/pyref/lasso.py argue): Surge sum-check, memory-checking grand products,
 // evaluations.  The Fr tables hold at least 2^n (fcs_fr: 2^l) entries; `lap` (optional) receives phase boundaries.
 LassoClaims lasso_argue(Ctx& c, const lh_lasso_table& tb, size_t n, const LassoColumns& w, const uint32_t* const* d_dims,
-                        const Fr* a, const Fr* const* dim_fr, const Fr* const* rts_fr, const Fr* const* E_fr,
-                        const Fr* const* fcs_fr, Transcript& tr, const std::function<void(int)>& lap) {
+                        const Fr* a, const Fr* const* E_fr, Transcript& tr, const std::function<void(int)>& lap) {
   const size_t cc = tb.num_chunks, l = tb.chunk_bits, alpha = tb.num_memories;
   const size_t N = (size_t)1 << n, M = (size_t)1 << l;
   LassoClaims cl;
@@ -199,13 +198,23 @@ LassoClaims lasso_argue(Ctx& c, const lh_lasso_table& tb, size_t n, const LassoC
   }
   if (lap) lap(4);
 
-  // ---- 7: evaluations at r_N / r_M: dim | read_ts | E, then final_cts
-  std::vector<const Fr*> at_n;
-  for (size_t j = 0; j < cc; j++) at_n.push_back(dim_fr[j]);
-  for (size_t j = 0; j < cc; j++) at_n.push_back(rts_fr[j]);
-  for (size_t i = 0; i < alpha; i++) at_n.push_back(E_fr[i]);
-  cl.ev_n = evaluate_polys(c, at_n.data(), at_n.size(), n, cl.r_N.data());
-  cl.ev_l = evaluate_polys(c, fcs_fr, cc, l, cl.r_M.data());
+  // ---- 7: evaluations at r_N / r_M: dim | read_ts | E, then final_cts - straight from the u32 columns (no
+  // field-element views: 4 bytes read and 8 multiply-adds per entry)
+  {
+    ArenaScope scope(c.arena);
+    std::vector<const uint32_t*> at_n;
+    for (size_t j = 0; j < cc; j++) at_n.push_back(d_dims[j]);
+    for (size_t j = 0; j < cc; j++) at_n.push_back(w.rts[j]);
+    for (size_t i = 0; i < alpha; i++) at_n.push_back(w.E[i]);
+    Fr* eq = c.arena.alloc_n<Fr>(std::max(N, M));
+    cl.ev_n.resize(at_n.size());
+    k_eq_xy(c, (const Fr*)cl.r_N.data(), n, eq);
+    k_inner_products_small(c, at_n.data(), at_n.size(), eq, N, (Fr*)cl.ev_n.data());
+    std::vector<const uint32_t*> at_l(w.fcs.begin(), w.fcs.end());
+    cl.ev_l.resize(cc);
+    k_eq_xy(c, (const Fr*)cl.r_M.data(), l, eq);
+    k_inner_products_small(c, at_l.data(), cc, eq, M, (Fr*)cl.ev_l.data());
+  }
   tr.write_field_elements(cl.ev_n);
   tr.write_field_elements(cl.ev_l);
   if (lap) lap(5);
@@ -296,9 +305,11 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
   }
   lap(1);
 
-  // ---- field-element views of the small-valued columns (sum-check / openings work on Fr tables)
+  // ---- field-element views only where a sum-check needs tables (E for Surge); dim / read_ts / final_cts stay u32
+  // all the way: fingerprints, evaluations and the batch opening's merge read the 4-byte columns
   const size_t num_n = 1 + 2 * cc + alpha;
-  std::vector<const Fr*> polys_n(num_n), polys_l(cc);
+  std::vector<const Fr*> polys_n(num_n, nullptr), polys_l(cc, nullptr);
+  std::vector<SmallPoly> small(num_n + cc);
   auto fr_view = [&](const uint32_t* src, size_t len) {
     Fr* d = c.arena.alloc_n<Fr>(NV);
     k_fr_from_u32(c, src, len, d);
@@ -314,16 +325,18 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
     polys_n[0] = a;
   }
   for (size_t j = 0; j < cc; j++) {
-    polys_n[1 + j] = fr_view(d_dims[j], N);
-    polys_n[1 + cc + j] = fr_view(rts[j], N);
-    polys_l[j] = fr_view(fcs[j], M);
+    small[1 + j] = SmallPoly{d_dims[j], N};
+    small[1 + cc + j] = SmallPoly{rts[j], N};
+    small[num_n + j] = SmallPoly{fcs[j], M};
   }
-  for (size_t i = 0; i < alpha; i++) polys_n[1 + 2 * cc + i] = fr_view(E[i], N);
+  for (size_t i = 0; i < alpha; i++) {
+    polys_n[1 + 2 * cc + i] = fr_view(E[i], N);
+    small[1 + 2 * cc + i] = SmallPoly{E[i], N};
+  }
   const Fr* const* E_fr = polys_n.data() + 1 + 2 * cc;
 
   // ---- 2-7: Surge, memory checking, evaluations
-  LassoClaims cl = lasso_argue(c, tb, n, w, d_dims, polys_n[0], polys_n.data() + 1, polys_n.data() + 1 + cc, E_fr,
-                               polys_l.data(), tr, lap);
+  LassoClaims cl = lasso_argue(c, tb, n, w, d_dims, polys_n[0], E_fr, tr, lap);
   const std::vector<HFr>&r = cl.r, &r_z = cl.r_z, &r_N = cl.r_N, &r_M = cl.r_M, &ev_n = cl.ev_n, &ev_l = cl.ev_l;
   const HFr& v = cl.v;
 
@@ -350,7 +363,7 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
     for (size_t j = 0; j < cc; j++) push(num_n + j, 3, ev_l[j]);
     std::vector<const Fr*> all(polys_n);
     all.insert(all.end(), polys_l.begin(), polys_l.end());
-    pcs.batch_open(nv, all.data(), all.size(), points.data(), 4, evs.data(), evs.size(), tr);
+    pcs.batch_open(nv, all.data(), all.size(), points.data(), 4, evs.data(), evs.size(), tr, small.data());
   }
   lap(6);
   ph[7] = 0;

@@ -932,7 +932,7 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
 // sum-check challenges and hand it to `open`
 void additive_batch_open(Ctx& c, size_t num_vars, const Fr* const* d_polys, size_t num_polys, const HFr* points,
                          size_t num_points, const lh_evaluation* evals, size_t num_evals, Transcript& tr,
-                         const std::function<void(const Fr* g_prime, const HFr* point)>& open) {
+                         const std::function<void(const Fr* g_prime, const HFr* point)>& open, const SmallPoly* small) {
   LH_REQUIRE(num_vars >= 1, LH_ERR_ARG, "batch open: num_vars == 0");
   LH_REQUIRE(num_evals >= 2, LH_ERR_ARG,
              "batch open needs >= 2 evaluations (eq_xy of an empty point is the zero poly, multilinear.rs:92-94)");
@@ -953,15 +953,25 @@ void additive_batch_open(Ctx& c, size_t num_vars, const Fr* const* d_polys, size
   std::vector<const Fr*> merged(num_points);
   for (size_t j = 0; j < num_points; j++) {
     std::vector<const Fr*> src;
-    std::vector<Fr> w;
+    std::vector<Fr> w, wsm;
+    std::vector<const uint32_t*> sm;
+    std::vector<size_t> sm_len;
     for (size_t i = 0; i < num_evals; i++)
       if (evals[i].point == j) {
-        src.push_back(d_polys[evals[i].poly]);
-        w.push_back(dev(eq_xt[i]));
+        const size_t pi = evals[i].poly;
+        if (small && small[pi].ptr) {  // a small-valued column: 8 multiply-adds per term, 4 bytes read instead of 32
+          sm.push_back(small[pi].ptr);
+          sm_len.push_back(std::min(small[pi].len, n));
+          wsm.push_back(dev(eq_xt[i]));
+        } else {
+          src.push_back(d_polys[pi]);
+          w.push_back(dev(eq_xt[i]));
+        }
       }
-    LH_REQUIRE(!src.empty(), LH_ERR_ARG, "batch open: a point without evaluations");
+    LH_REQUIRE(!src.empty() || !sm.empty(), LH_ERR_ARG, "batch open: a point without evaluations");
     Fr* m = c.arena.alloc_n<Fr>(n);
-    k_lincomb(c, src.data(), w.data(), src.size(), n, m);
+    if (sm.empty()) k_lincomb(c, src.data(), w.data(), src.size(), n, m);
+    else k_lincomb_mixed(c, src.data(), w.data(), src.size(), sm.data(), sm_len.data(), wsm.data(), sm.size(), n, m);
     merged[j] = m;
   }
   lh_sop expr;
@@ -994,10 +1004,10 @@ void additive_batch_open(Ctx& c, size_t num_vars, const Fr* const* d_polys, size
 
 void mkzg_batch_open(Ctx& c, const Srs& srs, size_t num_vars, const Fr* const* d_polys, size_t num_polys,
                      const HFr* points, size_t num_points, const lh_evaluation* evals, size_t num_evals,
-                     Transcript& tr) {
+                     Transcript& tr, const SmallPoly* small) {
   check_commit_vars(srs, num_vars, "batch open");
   additive_batch_open(c, num_vars, d_polys, num_polys, points, num_points, evals, num_evals, tr,
-                      [&](const Fr* g_prime, const HFr* point) { mkzg_open(c, srs, g_prime, num_vars, point, tr); });
+                      [&](const Fr* g_prime, const HFr* point) { mkzg_open(c, srs, g_prime, num_vars, point, tr); }, small);
 }
 
 }  // namespace lh

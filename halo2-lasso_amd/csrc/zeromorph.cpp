@@ -114,12 +114,11 @@ void zeromorph_open(Ctx& c, const USrs& srs, size_t poly_size, const Fr* d_poly,
 
 void zeromorph_batch_open(Ctx& c, const USrs& srs, size_t poly_size, size_t num_vars, const Fr* const* d_polys,
                           size_t num_polys, const HFr* points, size_t num_points, const lh_evaluation* evals,
-                          size_t num_evals, Transcript& tr) {
+                          size_t num_evals, Transcript& tr, const SmallPoly* small) {
   check_degree(srs, poly_size, num_vars, "open");
-  additive_batch_open(c, num_vars, d_polys, num_polys, points, num_points, evals, num_evals, tr,
-                      [&](const Fr* g_prime, const HFr* point) {
-                        zeromorph_open(c, srs, poly_size, g_prime, num_vars, point, tr);
-                      });
+  additive_batch_open(
+      c, num_vars, d_polys, num_polys, points, num_points, evals, num_evals, tr,
+      [&](const Fr* g_prime, const HFr* point) { zeromorph_open(c, srs, poly_size, g_prime, num_vars, point, tr); }, small);
 }
 
 }  // namespace lh
