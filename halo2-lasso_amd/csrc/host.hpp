@@ -116,8 +116,11 @@ struct SumCheckResult {
   std::vector<HFr> challenges;  // x
   std::vector<HFr> evals;       // every poly at x (classic.rs:143-149)
 };
+// `sum_is_exact`: the caller computed `sum` from these very tables (the provers' internal sum-checks: Surge, the GKR
+// layers): eq factoring then trusts it from round 0 on; a claim from outside (the C-ABI) is checked first (EqFactoring)
 SumCheckResult sum_check_prove(Ctx&, int prover_kind, size_t num_vars, const lh_sop& expr, const Fr* const* d_polys,
-                               size_t num_polys, const HFr* ys, size_t num_ys, const HFr& sum, Transcript& tr);
+                               size_t num_polys, const HFr* ys, size_t num_ys, const HFr& sum, Transcript& tr,
+                               bool sum_is_exact = false);
 
 // the round loop shared by every sum-check front end (prover.cpp)
 typedef std::function<void(const Fr* const*, Fr* const*, const Fr&, bool, size_t, Fr*)> RoundFn;
@@ -138,6 +141,7 @@ struct EqFactoring {
   };
   std::vector<One> eqs;    // global-eq shape: one entry; per-term shape (sum_m eq_m * poly_m): one per term, in term order
   bool per_term = false;
+  bool trusted_claim = false;  // the claim is known to be the true sum: no check (and no extra point) in round 0
   std::vector<HFr> inv_1my;  // global-eq shape: (1 - y_j)^-1 for every round
   HFr c;                     // global-eq shape: claim / S_j
   // would this round run the streaming kernel (else the eq tables are materialised and the standard path takes over)

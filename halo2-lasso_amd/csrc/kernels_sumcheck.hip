@@ -512,64 +512,44 @@ void k_pair_sums(Ctx& c, const Fr* in, size_t n_out, Fr* out) {
 // ------------------------------------------------------------------ batch-opening rounds with factored eq tables
 // expression sum_m eq_m(x) * poly_m(x) (pcs/multilinear.rs:182-190): per term and pair one bind (2 multiplications),
 // two products with the term's eq-level entry; the eq tables are neither read in full nor bound (prover.cpp).
-template <bool BIND>
-__global__ __launch_bounds__(256) void sc_round_open_kernel(ScOpenRound rd, size_t size, Fr* __restrict__ partials,
+// (the number of terms is a template parameter: an accumulator array indexed by a run-time term count lives in scratch
+// memory - 400 B per lane of spills doubled the kernel's HBM writes)
+template <int M, bool BIND>
+__global__ __launch_bounds__(256) LH_SC_WAVES_ATTR void sc_round_open_kernel(ScOpenRound rd, size_t size, Fr* __restrict__ partials,
                                                             ScFinish fin) {
   __shared__ Fr lds[4];
-  constexpr int MAXQ = 2 * SC_OPEN_MAX_TERMS;
-  Fr acc[MAXQ];
+  constexpr int NQ = 2 * M;
+  Fr acc[NQ];
 #pragma unroll
-  for (int k = 0; k < MAXQ; k++) acc[k] = Fr::zero();
+  for (int k = 0; k < NQ; k++) acc[k] = Fr::zero();
   for (size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x; b < size; b += (size_t)gridDim.x * blockDim.x) {
 #pragma unroll
-    for (int m = 0; m < SC_OPEN_MAX_TERMS; m++) {
-      if (m < (int)rd.num_terms) {
-        Fr v0, v1;
-        load_pair<BIND>(rd.in[m], rd.out[m], b, rd.r, true, v0, v1);
-        const Fr e = rd.eq_level[m][b];
-        acc[2 * m] = add(acc[2 * m], mul(e, v0));
-        acc[2 * m + 1] = add(acc[2 * m + 1], mul(e, v1));
-      }
+    for (int m = 0; m < M; m++) {
+      Fr v0, v1;
+      load_pair<BIND>(rd.in[m], rd.out[m], b, rd.r, true, v0, v1);
+      const Fr e = rd.eq_level[m][b];
+      acc[2 * m] = add(acc[2 * m], mul(e, v0));
+      acc[2 * m + 1] = add(acc[2 * m + 1], mul(e, v1));
     }
   }
-  const int nq = 2 * (int)rd.num_terms;
 #pragma unroll
-  for (int k = 0; k < MAXQ; k++) {
-    if (k < nq) {
-      Fr v = block_reduce_sum(acc[k], lds);
-      if (threadIdx.x == 0) partials[(size_t)blockIdx.x * nq + k] = v;
-    }
+  for (int k = 0; k < NQ; k++) {
+    Fr v = block_reduce_sum(acc[k], lds);
+    if (threadIdx.x == 0) partials[(size_t)blockIdx.x * NQ + k] = v;
   }
   if (gridDim.x == 1) {
     if (threadIdx.x == 0) publish_flag(fin.flag, fin.seq);
     return;
   }
-  // final cross-workgroup reduction (same ticket protocol as finish_round, with a run-time count)
-  __shared__ int is_last;
-  if (threadIdx.x < 64) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const uint32_t t = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = t == fin.last_ticket;
-      if (last) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      is_last = last;
-    }
-  }
-  __syncthreads();
-  if (!is_last) return;
-  const uint32_t blocks = gridDim.x;
-  for (int k = 0; k < nq; k++) {
-    Fr a = Fr::zero();
-    for (uint32_t i = threadIdx.x; i < blocks; i += blockDim.x) a = add(a, partials[(size_t)i * nq + k]);
-    a = block_reduce_sum(a, lds);
-    if (threadIdx.x == 0) fin.out_host[k] = a;
-  }
-  if (threadIdx.x == 0) publish_flag(fin.flag, fin.seq);
+  finish_round<NQ>(fin, partials, lds);
+}
+
+template <int M>
+static void launch_open(Ctx& c, const ScOpenRound& rd, bool bind, size_t size, unsigned g, Fr* partials, const ScFinish& fin) {
+  if (bind)
+    hipLaunchKernelGGL((sc_round_open_kernel<M, true>), dim3(g), dim3(256), 0, c.stream, rd, size, partials, fin);
+  else
+    hipLaunchKernelGGL((sc_round_open_kernel<M, false>), dim3(g), dim3(256), 0, c.stream, rd, size, partials, fin);
 }
 
 void k_sc_round_open(Ctx& c, const ScOpenRound& rd, bool bind, size_t size, Fr* out_host) {
@@ -584,10 +564,14 @@ void k_sc_round_open(Ctx& c, const ScOpenRound& rd, bool bind, size_t size, Fr* 
     // algorithmic bytes: 96 B per bound entry of the polys (192 B per pair and term) + the eq-level entry
     ProfScope ps(c, bind ? "sc_round_open<bind>" : "sc_round_open<first>", ((bind ? 192.0 : 64.0) + 32.0) * (double)size * rd.num_terms,
                  (bind ? 4.0 : 2.0) * (double)size * rd.num_terms, (double)size);
-    if (bind)
-      hipLaunchKernelGGL((sc_round_open_kernel<true>), dim3((unsigned)g), dim3(256), 0, c.stream, rd, size, partials, fin);
-    else
-      hipLaunchKernelGGL((sc_round_open_kernel<false>), dim3((unsigned)g), dim3(256), 0, c.stream, rd, size, partials, fin);
+    switch (rd.num_terms) {
+      case 1: launch_open<1>(c, rd, bind, size, (unsigned)g, partials, fin); break;
+      case 2: launch_open<2>(c, rd, bind, size, (unsigned)g, partials, fin); break;
+      case 3: launch_open<3>(c, rd, bind, size, (unsigned)g, partials, fin); break;
+      case 4: launch_open<4>(c, rd, bind, size, (unsigned)g, partials, fin); break;
+      case 5: launch_open<5>(c, rd, bind, size, (unsigned)g, partials, fin); break;
+      default: launch_open<6>(c, rd, bind, size, (unsigned)g, partials, fin); break;
+    }
   }
   c.wait_flag(seq);
 }

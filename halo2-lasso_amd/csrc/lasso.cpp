@@ -164,7 +164,7 @@ LassoClaims lasso_argue(Ctx& c, const lh_lasso_table& tb, size_t n, const LassoC
     surge.num_factors[m] = tb.g_num_factors[m];
     for (int k = 0; k < LH_SC_MAX_FACTORS; k++) surge.factor[m][k] = tb.g_factor[m][k];
   }
-  SumCheckResult sc = sum_check_prove(c, LH_SC_EVALUATIONS, n, surge, E_fr, alpha, cl.r.data(), 1, cl.v, tr);
+  SumCheckResult sc = sum_check_prove(c, LH_SC_EVALUATIONS, n, surge, E_fr, alpha, cl.r.data(), 1, cl.v, tr, true);
   cl.r_z = sc.challenges;
   cl.e_rz = sc.evals;
   tr.write_field_elements(sc.evals);

@@ -356,7 +356,7 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
     } else if (ef_on) {
       // global-eq shape, round 0: one point more (q at 1..D determines q(0) too), so that the claim can be CHECKED instead
       // of trusted: with a claim that is not the true sum the reference still sends the true p(1..D), and so must we
-      const bool check_claim = !ef->per_term && round == 0;
+      const bool check_claim = !ef->per_term && round == 0 && !ef->trusted_claim;
       ef->round(cur.data(), dst.data(), dev(r_prev), bind, size, round, check_claim ? degree : degree - 1, evals_host);
       factored_round = true;
       if (check_claim) {
@@ -396,7 +396,7 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
       if (!ef->per_term) {
         EqFactoring::One& e = ef->eqs[0];
         const HFr yj = e.y[round];
-        if (round > 0) {
+        if (round > 0 || ef->trusted_claim) {
           e.q.assign(degree, HFr::zero());  // q has degree D - 1: D values q(0..D-1)
           for (int x = 1; x < degree; x++) e.q[x] = hst(evals_host[x - 1]);
           e.q[0] = (ef->c - yj * e.q[1]) * ef->inv_1my[round];
@@ -457,7 +457,7 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
 // replicated on every rank.  The transcript sees exactly the single-GPU messages.
 static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_vars, const lh_sop& expr,
                                            const Fr* const* d_polys, size_t num_polys, const HFr* ys, size_t num_ys,
-                                           const HFr& sum, Transcript& tr, bool sharded) {
+                                           const HFr& sum, Transcript& tr, bool sharded, bool sum_is_exact = false) {
   LH_REQUIRE(num_vars > 0, LH_ERR_ARG, "sum-check needs num_vars > 0");  // classic.rs:42 assert
   const size_t T = num_polys + num_ys;
   LH_REQUIRE(T <= (size_t)SC_MAX_TABLES, LH_ERR_ARG, "sum-check: too many tables for one round kernel");
@@ -540,6 +540,7 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
           inv = inv * d[i];
         }
         ef.per_term = false;
+        ef.trusted_claim = sum_is_exact;
         ef.c = sum;
         EqFactoring::One one;
         one.table = (size_t)rd.global_eq, one.y = y, one.S = one.S_prev = HFr::one();
@@ -624,8 +625,8 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
 
 SumCheckResult sum_check_prove(Ctx& c, int prover_kind, size_t num_vars, const lh_sop& expr,
                                const Fr* const* d_polys, size_t num_polys, const HFr* ys, size_t num_ys,
-                               const HFr& sum, Transcript& tr) {
-  return sum_check_prove_impl(c, prover_kind, num_vars, expr, d_polys, num_polys, ys, num_ys, sum, tr, false);
+                               const HFr& sum, Transcript& tr, bool sum_is_exact) {
+  return sum_check_prove_impl(c, prover_kind, num_vars, expr, d_polys, num_polys, ys, num_ys, sum, tr, false, sum_is_exact);
 }
 
 SumCheckResult sum_check_prove_sharded(Ctx& c, int prover_kind, size_t num_vars, const lh_sop& expr,
@@ -726,7 +727,7 @@ FracSumCheckResult prove_fractional_sum_check(Ctx& c, size_t B, size_t num_vars,
         polys.push_back(lq[h][b] + half);
       }
       SumCheckResult sc = sum_check_prove(c, LH_SC_EVALUATIONS, nv, expr, polys.data(), polys.size(), y.data(), 1,
-                                          claim, tr);
+                                          claim, tr, true);
       x = sc.challenges;
       evals = sc.evals;
     }
@@ -829,7 +830,7 @@ GrandProductResult prove_grand_product(Ctx& c, size_t B, const Fr* const* d_leav
       }
       expr.num_terms = (uint32_t)active.size();
       SumCheckResult sc =
-          sum_check_prove(c, LH_SC_EVALUATIONS, h, expr, polys.data(), polys.size(), y.data(), 1, claim, tr);
+          sum_check_prove(c, LH_SC_EVALUATIONS, h, expr, polys.data(), polys.size(), y.data(), 1, claim, tr, true);
       x = sc.challenges;
       evals = sc.evals;
     }
