@@ -5,8 +5,12 @@
 // (SURVEY.md §3.4), so window size / bucket scheme are chosen for the GPU:
 //
 //  1. digits     every scalar -> canonical -> c-bit digits -> (bucket key, point index) pairs at fixed
-//                positions (coalesced, no atomics; zero digits get a sentinel key that sorts last)
-//  2. sort       device radix sort of the pairs by key (order inside a bucket is free)
+//                positions (coalesced, no atomics); digit d > 0 goes to bucket d - 1 of its (job, window) slab, a
+//                zero digit keeps a valid key and carries the SKIP index (nothing is added for it)
+//  2. sort       radix sort of the pairs by key (order inside a bucket is free).  The pairs leave step 1 grouped by
+//                (job, window) and a slab's bucket range starts at a multiple of 2^(digit bits), so a big slab only
+//                needs its <= 16 digit bits sorted (2 radix passes instead of 3 over the 21-23-bit global key);
+//                the slabs of small jobs are sorted together by the full key
 //  3. accumulate load-balanced segmented sum: every thread owns ~K CONSECUTIVE sorted entries whatever
 //                the bucket sizes are (Lasso's read_ts / final_cts / dim columns are heavily skewed - a
 //                thread-per-bucket scheme would serialise on the hot buckets).  Chunk boundaries snap to
@@ -31,7 +35,8 @@
 namespace lh {
 
 constexpr int MSM_MAX_JOBS = 48;
-constexpr uint32_t SENTINEL = 0xffffffffu;
+constexpr uint32_t SENTINEL = 0xffffffffu;   // continuation lists: "no entry"
+constexpr uint32_t SKIP_IDX = 0x7fffffffu;   // sorted entries: a zero digit (nothing to add)
 
 struct MsmJobDev {
   const void* scalars;
@@ -86,8 +91,7 @@ __global__ void msm_or_limbs_kernel(MsmPlanDev plan, uint32_t* __restrict__ or_o
   if (threadIdx.x < 8 && lds_or[threadIdx.x]) atomicOr(&or_out[blockIdx.y * 8 + threadIdx.x], lds_or[threadIdx.x]);
 }
 
-__global__ void msm_emit_kernel(MsmPlanDev plan, uint32_t sentinel, uint32_t* __restrict__ keys,
-                                uint32_t* __restrict__ vals) {
+__global__ void msm_emit_kernel(MsmPlanDev plan, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
   const MsmJobDev& jb = plan.job[blockIdx.y];
   const uint32_t c = jb.c, mask = (1u << c) - 1u;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < jb.n; i += (size_t)gridDim.x * blockDim.x) {
@@ -117,8 +121,8 @@ __global__ void msm_emit_kernel(MsmPlanDev plan, uint32_t sentinel, uint32_t* __
         }
       }
       size_t e = (size_t)jb.entry_base + (size_t)w * jb.n + i;
-      keys[e] = d ? jb.key_base + w * jb.win_stride + d : sentinel;
-      vals[e] = (uint32_t)i | neg;
+      keys[e] = jb.key_base + w * jb.win_stride + (d ? d - 1u : 0u);  // bucket index = digit - 1
+      vals[e] = d ? ((uint32_t)i | neg) : SKIP_IDX;
     };
 #pragma unroll
     for (int k = 0; k < 8; k++) {
@@ -141,20 +145,11 @@ __global__ void msm_emit_kernel(MsmPlanDev plan, uint32_t sentinel, uint32_t* __
   }
 }
 
-// number of valid (non-sentinel) pairs = first index whose sorted key is the sentinel
-__global__ void msm_find_total_kernel(const uint32_t* __restrict__ sorted_key, uint32_t n, uint32_t sentinel,
-                                      uint32_t* __restrict__ total) {
-  uint32_t lo = 0, hi = n;
-  while (lo < hi) {
-    uint32_t mid = (lo + hi) >> 1;
-    if (sorted_key[mid] >= sentinel) hi = mid;
-    else lo = mid + 1;
-  }
-  *total = lo;
-}
-
 void sort_pairs_u32(Ctx& c, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
                     size_t n, unsigned bits);
+size_t sort_pairs_u32_temp_bytes(size_t n, unsigned bits);
+void sort_pairs_u32_with(Ctx& c, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
+                         uint32_t* vals_out, size_t n, unsigned bits, void* temp, size_t temp_bytes);
 
 // ------------------------------------------------------------------ 4: segmented accumulate
 // O(1): this runs at every bucket boundary of the accumulate loop, and a wave takes the branch whenever ANY of
@@ -169,7 +164,7 @@ __device__ __forceinline__ const MsmJobDev& job_of_key(const MsmPlanDev& plan, u
 // cache lines per wave instruction and keep every line alive for 32 iterations (measured: 2.7x the algorithmic
 // fetch traffic).  (Requesting the next base point one iteration ahead was tried and lost 5 %: more registers.)
 constexpr int ACC_GROUP = 16;
-__global__ __launch_bounds__(128) void msm_accumulate0_kernel(MsmPlanDev plan, const uint32_t* __restrict__ total_ptr,
+__global__ __launch_bounds__(128) void msm_accumulate0_kernel(MsmPlanDev plan, size_t total,
                                                               const uint32_t* __restrict__ sorted_key,
                                                               const uint32_t* __restrict__ sorted_idx, uint32_t K,
                                                               G1Xyzz* __restrict__ buckets,
@@ -177,7 +172,6 @@ __global__ __launch_bounds__(128) void msm_accumulate0_kernel(MsmPlanDev plan, c
                                                               G1Xyzz* __restrict__ cont_pt, size_t nchunks,
                                                               uint32_t* __restrict__ cont_count) {
   __shared__ uint32_t lds_key[ACC_GROUP * 128], lds_idx[ACC_GROUP * 128];
-  const size_t total = *total_ptr;
   for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < nchunks; t += (size_t)gridDim.x * blockDim.x) {
     const size_t p0 = t * K < total ? t * K : total, p1 = p0 + K < total ? p0 + K : total;
     uint32_t ck = SENTINEL;
@@ -211,7 +205,7 @@ __global__ __launch_bounds__(128) void msm_accumulate0_kernel(MsmPlanDev plan, c
             bases = job_of_key(plan, cur).bases;
           }
           const uint32_t iv = lds_idx[j * 128 + threadIdx.x];
-          acc = add_mixed(acc, bases[iv & 0x7fffffffu], (iv >> 31) != 0);
+          if (iv != SKIP_IDX) acc = add_mixed(acc, bases[iv & 0x7fffffffu], (iv >> 31) != 0);
         }
       }
       if (cont) {
@@ -324,7 +318,7 @@ __global__ __launch_bounds__(64) void msm_segment_reduce_kernel(MsmPlanDev plan,
       acc = add(acc, run);
       run = add(run, b[d]);
     }
-    if (d0) acc = add(acc, mul_small(run, d0));
+    acc = add(acc, mul_small(run, d0 + 1));  // bucket index b holds digit b + 1
     seg_out[s] = acc;
   }
 }
@@ -356,7 +350,7 @@ __global__ __launch_bounds__(64) void msm_segment_reduce_quad_kernel(MsmPlanDev 
       acc = add_quad(acc, run);
       run = add_quad(run, b[d]);
     }
-    if (d0) acc = add_quad(acc, mul_small_quad(run, d0));
+    acc = add_quad(acc, mul_small_quad(run, d0 + 1));  // bucket index b holds digit b + 1
     if (lead) seg_out[s] = acc;
   }
 }
@@ -423,8 +417,9 @@ __global__ void msm_derived_gather_kernel(MsmDerivedDev dd, const G1Xyzz* __rest
     const uint32_t v = dd.table[j][d];
     // no sentinels (they would split a run into several "first" segments): an empty parent bucket is the identity,
     // and T[d] = 0 lands in the derived job's bucket 0, which the reduction weighs with 0
-    out_key[p] = dd.key_base[j] + v;
-    out_pt[p] = buckets[dd.parent_key_base[j] + d];
+    // (bucket index = value - 1; a zero value has no bucket)
+    out_key[p] = dd.key_base[j] + (v ? v - 1u : 0u);
+    out_pt[p] = (v && d) ? buckets[dd.parent_key_base[j] + d - 1u] : G1Xyzz::identity();
   }
 }
 
@@ -530,6 +525,10 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
     }
     uint32_t key = 0, seg = 0, win = 0;
     size_t max_entries = 0, max_n = 0;
+    // a job of >= 2^LH_MSM_SLAB_LOG points sorts each of its (window) slabs by the digit bits alone
+    static const int slab_log = env_int("LH_MSM_SLAB_LOG", 20);
+    std::vector<char> slab(nj, 0);
+    std::vector<uint32_t> sort_bits(nj, 0);
     for (size_t j = 0; j < nj; j++) {
       const MsmJob& in = jobs[base + j];
       MsmJobDev& jd = plan.job[j];
@@ -542,22 +541,35 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
       // signed digits need one extra bit of head room for the last carry
       jd.W = bits ? ((jd.is_signed ? bits + 1 : bits) + jd.c - 1) / jd.c : 0;
       if (!in.n) jd.W = 0;
-      const uint32_t nb = jd.is_signed ? (1u << (jd.c - 1)) + 1u : (1u << jd.c);  // bucket indices 0..nb-1
+      // digit d > 0 lives in bucket d - 1: signed digits 1 .. 2^(c-1), unsigned 1 .. 2^c - 1
+      sort_bits[j] = jd.is_signed ? jd.c - 1 : jd.c;
+      const uint32_t nb = 1u << sort_bits[j];
       jd.seg_size = seg_size;
       jd.seg_per_win = (nb + jd.seg_size - 1) / jd.seg_size;
       jd.win_stride = jd.seg_per_win * jd.seg_size;
-      key = (key + (1u << KEY_BLOCK_BITS) - 1) & ~((1u << KEY_BLOCK_BITS) - 1);
+      slab[j] = jd.n >= (1u << slab_log) && jd.W > 0 && nb >= jd.seg_size && sort_bits[j] <= 16;
+      // a slab-sorted job's bucket ranges start at multiples of 2^sort_bits: the low bits of a key are the bucket index
+      const uint32_t align_bits = slab[j] ? std::max<uint32_t>(KEY_BLOCK_BITS, sort_bits[j]) : KEY_BLOCK_BITS;
+      key = (key + (1u << align_bits) - 1) & ~((1u << align_bits) - 1);
       jd.key_base = key;
-      jd.entry_base = (uint32_t)max_entries;
       jd.seg_base = seg;
       jd.win_base = win;
       key += jd.W * jd.win_stride;
       seg += jd.W * jd.seg_per_win;
       win += jd.W;
-      max_entries += (size_t)jd.n * jd.W;
-      LH_REQUIRE(max_entries < ((size_t)1 << 32), LH_ERR_ARG, "msm: batch too large for 32-bit entry indices");
+      LH_REQUIRE(in.n < 0x7fffffffu, LH_ERR_ARG, "msm: too many points");
       max_n = std::max(max_n, in.n);
     }
+    // entry layout: the slabs of the small jobs first (one global sort), then the big jobs' slabs
+    size_t small_entries = 0;
+    for (int pass = 0; pass < 2; pass++)
+      for (size_t j = 0; j < nj; j++) {
+        if ((int)slab[j] != pass) continue;
+        plan.job[j].entry_base = (uint32_t)max_entries;
+        max_entries += (size_t)plan.job[j].n * plan.job[j].W;
+        LH_REQUIRE(max_entries < ((size_t)1 << 32), LH_ERR_ARG, "msm: batch too large for 32-bit entry indices");
+        if (!pass) small_entries = max_entries;
+      }
     const size_t nbuckets = key, nsegs = seg, nwins = win;
     // window-sum shares: enough workgroups that no thread adds more than ~4 segment partials in sequence, few enough
     // that the host's share of the additions stays in the microseconds
@@ -577,7 +589,6 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
     }
     {
       ArenaScope scope(c.arena);
-      uint32_t* total = c.arena.alloc_n<uint32_t>(1);
       uint32_t* ukey = c.arena.alloc_n<uint32_t>(max_entries);
       uint32_t* uidx = c.arena.alloc_n<uint32_t>(max_entries);
       // + 256: accumulate0 reads whole 16-byte groups up to the end of the last (padded) chunk
@@ -605,20 +616,30 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
       LH_HIP(hipMemsetAsync(buckets, 0, nbuckets * sizeof(G1Xyzz), c.stream));
       double total_pts = 0, full_pts = 0;
       for (size_t j = 0; j < nj; j++) total_pts += plan.job[j].n, full_pts += plan.job[j].is_u32 ? 0 : plan.job[j].n;
-      const uint32_t sentinel = (uint32_t)nbuckets;  // > every valid key: sorts last
       unsigned key_bits = 1;
       while (((size_t)1 << key_bits) <= nbuckets) key_bits++;
       {
         ProfScope ps(c, "msm_digits", 32.0 * full_pts + 4.0 * (total_pts - full_pts) + 8.0 * max_entries, full_pts,
                      total_pts);
         dim3 g((unsigned)std::min<size_t>((max_n + 255) / 256, 2048), (unsigned)nj);
-        hipLaunchKernelGGL(msm_emit_kernel, g, dim3(256), 0, c.stream, plan, sentinel, ukey, uidx);
+        hipLaunchKernelGGL(msm_emit_kernel, g, dim3(256), 0, c.stream, plan, ukey, uidx);
       }
       {
         ProfScope ps(c, "msm_sort", 32.0 * max_entries, 0, (double)max_entries);
-        sort_pairs_u32(c, ukey, skey, uidx, sidx, max_entries, key_bits);
-        hipLaunchKernelGGL(msm_find_total_kernel, dim3(1), dim3(1), 0, c.stream, skey, (uint32_t)max_entries, sentinel,
-                           total);
+        // small jobs: one sort by the whole key; big jobs: every (job, window) slab by its digit bits only
+        if (small_entries) sort_pairs_u32(c, ukey, skey, uidx, sidx, small_entries, key_bits);
+        size_t temp_bytes = 0;
+        for (size_t j = 0; j < nj; j++)
+          if (slab[j]) temp_bytes = std::max(temp_bytes, sort_pairs_u32_temp_bytes(plan.job[j].n, sort_bits[j]));
+        void* temp = temp_bytes ? c.arena.alloc(temp_bytes) : nullptr;  // the calls run one after another on the stream
+        for (size_t j = 0; j < nj; j++) {
+          if (!slab[j]) continue;
+          const MsmJobDev& jd = plan.job[j];
+          for (uint32_t w = 0; w < jd.W; w++) {
+            const size_t e = (size_t)jd.entry_base + (size_t)w * jd.n;
+            sort_pairs_u32_with(c, ukey + e, skey + e, uidx + e, sidx + e, jd.n, sort_bits[j], temp, temp_bytes);
+          }
+        }
       }
 
       // segmented accumulate, level 0 then K-fold shrinking continuation lists
@@ -629,16 +650,13 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
       size_t nchunks = (max_entries + K - 1) / K;
       uint32_t* ckey = c.arena.alloc_n<uint32_t>(nchunks);
       G1Xyzz* cpt = c.arena.alloc_n<G1Xyzz>(nchunks);
-      uint32_t h_total = 0;
-      if (c.prof) {
-        c.d2h(&h_total, total, 4);
-      }
+      const size_t h_total = max_entries;  // (point, window) entries, zero digits included
       {
         // MSM algorithmic bytes: 96 B per point (32 B scalar + 64 B base), 68 B for a u32 column,
         // whatever the number of windows; `items` = sorted (point, window) entries, a mixed add is 10 Fq muls
         ProfScope ps(c, "msm_accumulate0", 96.0 * full_pts + 68.0 * (total_pts - full_pts), 10.0 * h_total, (double)h_total);
       hipLaunchKernelGGL(msm_accumulate0_kernel, dim3((unsigned)std::min<size_t>((nchunks + 127) / 128, 1 << 16)),
-                         dim3(128), 0, c.stream, plan, total, skey, sidx, K, buckets, ckey, cpt, nchunks, lvl_cnt);
+                         dim3(128), 0, c.stream, plan, max_entries, skey, sidx, K, buckets, ckey, cpt, nchunks, lvl_cnt);
       }
       size_t n_in = nchunks;
       const uint32_t K2 = (uint32_t)MSM_K2;
