@@ -526,7 +526,7 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
     uint32_t key = 0, seg = 0, win = 0;
     size_t max_entries = 0, max_n = 0;
     // a job of >= 2^LH_MSM_SLAB_LOG points sorts each of its (window) slabs by the digit bits alone
-    static const int slab_log = env_int("LH_MSM_SLAB_LOG", 20);
+    static const int slab_log = env_int("LH_MSM_SLAB_LOG", 23);
     std::vector<char> slab(nj, 0);
     std::vector<uint32_t> sort_bits(nj, 0);
     for (size_t j = 0; j < nj; j++) {
