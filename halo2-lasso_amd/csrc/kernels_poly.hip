@@ -549,30 +549,33 @@ void k_lincomb_mixed(Ctx& c, const Fr* const* fr, const Fr* wfr, size_t num_fr, 
 }
 
 // out[k] = <u32 column k, weights> for up to IPS_GROUP columns per launch row: the weight is loaded once per entry
-constexpr int IPS_GROUP = 6;
+constexpr int IPS_GROUP = 4;  // 6 accumulators of 10 limbs spill (256 B of scratch per lane); 4 keep 4 waves per SIMD
 struct IpSmallPack {
   const uint32_t* p[IPS_GROUP];
   int count;
 };
+// (the group size is a template parameter: accumulators indexed by a run-time count end up in scratch memory)
+template <int G>
 __global__ __launch_bounds__(256) void inner_products_small_kernel(IpSmallPack pk, const Fr* __restrict__ w, size_t n,
                                                                    Fr* __restrict__ partials) {
   __shared__ Fr lds[4];
-  Wide acc[IPS_GROUP];
+  Wide acc[G];
 #pragma unroll
-  for (int k = 0; k < IPS_GROUP; k++) acc[k] = Wide::zero();
+  for (int k = 0; k < G; k++) acc[k] = Wide::zero();
   GSTRIDE(i, n) {
     const Fr wi = w[i];
 #pragma unroll
-    for (int k = 0; k < IPS_GROUP; k++)
-      if (k < pk.count) wide_mac(acc[k], wi, pk.p[k][i]);
+    for (int k = 0; k < G; k++) wide_mac(acc[k], wi, pk.p[k][i]);
   }
 #pragma unroll
-  for (int k = 0; k < IPS_GROUP; k++) {
-    if (k < pk.count) {
-      Fr v = block_reduce_sum(wide_reduce(acc[k]), lds);
-      if (threadIdx.x == 0) partials[(size_t)k * gridDim.x + blockIdx.x] = v;
-    }
+  for (int k = 0; k < G; k++) {
+    Fr v = block_reduce_sum(wide_reduce(acc[k]), lds);
+    if (threadIdx.x == 0) partials[(size_t)k * gridDim.x + blockIdx.x] = v;
   }
+}
+template <int G>
+static void launch_ips(Ctx& c, dim3 g, const IpSmallPack& pk, const Fr* w, size_t n, Fr* partials) {
+  hipLaunchKernelGGL(inner_products_small_kernel<G>, g, 256, 0, c.stream, pk, w, n, partials);
 }
 void k_inner_products_small(Ctx& c, const uint32_t* const* polys, size_t count, const Fr* weights, size_t n,
                             Fr* out_host) {
@@ -587,7 +590,12 @@ void k_inner_products_small(Ctx& c, const uint32_t* const* polys, size_t count, 
     IpSmallPack pk;
     pk.count = (int)std::min<size_t>(IPS_GROUP, count - base);
     for (int i = 0; i < IPS_GROUP; i++) pk.p[i] = i < pk.count ? polys[base + i] : nullptr;
-    hipLaunchKernelGGL(inner_products_small_kernel, g, 256, 0, c.stream, pk, weights, n, partials);
+    switch (pk.count) {
+      case 1: launch_ips<1>(c, g, pk, weights, n, partials); break;
+      case 2: launch_ips<2>(c, g, pk, weights, n, partials); break;
+      case 3: launch_ips<3>(c, g, pk, weights, n, partials); break;
+      default: launch_ips<4>(c, g, pk, weights, n, partials); break;
+    }
     hipLaunchKernelGGL(reduce_rows_kernel, pk.count, 256, 0, c.stream, partials, (int)g.x, d_out + base);
   }
   c.d2h(out_host, d_out, count * sizeof(Fr));
