@@ -226,7 +226,8 @@ def test_bench_two_ranks_launched_like_the_driver():
         env = dict(os.environ, LH_DEVICE="0", LH_DIST_BACKEND="gloo")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1",
-               "--log-n", "17", "--table", "range", "--no-cpu-baseline", "--no-inflight", "--no-extra"] + extra
+               "--log-n", "17", "--table", "range", "--no-cpu-baseline", "--no-inflight"] + \
+            ([] if "--extra" in extra else ["--no-extra"]) + [e for e in extra if e != "--extra"]
         r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -234,6 +235,7 @@ def test_bench_two_ranks_launched_like_the_driver():
         return json.loads(lines[0])
 
     d = run([])
+    assert "replicas" not in d
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "strong"
     assert d["metric"] == "lasso_prove_time_ms" and d["higher_is_better"] is False
     assert abs(d["value"] - d["ms_per_step"]) <= 1e-3          # one proof per step, whatever the number of ranks
@@ -242,3 +244,11 @@ def test_bench_two_ranks_launched_like_the_driver():
     d = run(["--mode", "replicas"])
     assert d["scaling"] == "weak" and d["config"]["proofs_per_step"] == 2
     assert abs(d["value"] - d["ms_per_step"] / 2) <= 1e-3       # two proofs per step
+    # the default N > 1 line with its extra objects: configs[3] (here 2^18 instead of 2^26) sharded, and replicas
+    os.environ["LH_BENCH_CONFIG3_LOG_N"] = "18"
+    try:
+        d = run(["--extra"])
+    finally:
+        del os.environ["LH_BENCH_CONFIG3_LOG_N"]
+    assert d["scaling"] == "strong" and d["sharded_proof_equals_single_gpu"] is True
+    assert d["config3_2p26_range_sharded"]["ms_per_proof"] > 0 and d["replicas"]["proofs_per_step"] == 2
