@@ -18,6 +18,13 @@
  *    `prove` from one thread and fans out on rayon, util/parallel.rs:9-46).
  *  - There is NO CPU fallback: without a usable HIP device lh_ctx_create fails with
  *    LH_ERR_DEVICE and nothing else can be called.
+ *  - Every entry point that takes an lh_ctx makes the ctx's HIP device current for the duration of the
+ *    call (and restores the caller's): a ctx may be used from any host thread, one call at a time.
+ *  - The last rounds of a sum-check run inside ONE resident kernel that exchanges message and challenge
+ *    with the calling thread through pinned memory while the lh_* call is in progress.  The kernel waits a
+ *    bounded time for each challenge (environment LH_SC_TAIL_TIMEOUT_MS, default 2000); when the calling
+ *    thread stalls longer (debugger, SIGSTOP, slow transcript callback) the prover resumes with launched
+ *    rounds - same proof bytes, no error.  LH_SC_TAIL=0 disables the resident rounds.
  */
 #ifndef LASSO_HIP_H
 #define LASSO_HIP_H
