@@ -278,3 +278,47 @@ def test_hyperplonk_with_lasso_lookup(hl, ctx, kind, c, l, num_vars):
         with pytest.raises(hl.InvalidSnark, match="Invalid lookup input"):
             g_hp.HyperPlonk.prove(g_pp, instances, [hl.MultilinearPolynomial.new(ctx, w) for w in bad],
                                   hl.Keccak256Transcript())
+
+
+def test_hyperplonk_lasso_zero_columns_and_two_lookups(hl, ctx):
+    """two Lasso lookups in one circuit (a range and an XOR table over different columns), one of them with pairwise
+    distinct chunk indices (read_ts identically zero: an identity commitment inside the Lasso group, framed by the
+    mask): bytes against the specification, both verifiers"""
+    from halo2_lasso_amd import hyperplonk as g_hp, expression as g_ex
+    from oracle.pyref import expression as o_ex, lasso as o_lasso
+    k = 4
+    n = 1 << k
+    rng = random.Random(77)
+    specs = [o_lasso.range_table(2, 2), o_lasso.bitwise_table(o_lasso.SUBTABLE_XOR, 1, 4)]
+    tables = [hl.LassoTable.range(2, 2), hl.LassoTable.bitwise(hl.SUBTABLE_XOR, 1, 4)]
+    # witness columns: lookup 0: d0, d1, a0 (range over 2 x 2-bit limbs); lookup 1: e0 (a permutation of 0..15), a1
+    d0, d1 = [rng.randrange(4) for _ in range(n)], [rng.randrange(4) for _ in range(n)]
+    a0 = [x + 4 * y for x, y in zip(d0, d1)]
+    e0 = list(range(n))
+    rng.shuffle(e0)
+    a1 = [(v >> 2) ^ (v & 3) for v in e0]
+    w = [rng.randrange(P) for _ in range(n)]
+    witness = [w, d0, d1, a0, e0, a1]          # polys 2..7 (pi = 0, q = 1)
+    q = [rng.randrange(2) for _ in range(n)]
+
+    def info(E, Info, Lk, tabs):
+        pw, pa0 = (E.Polynomial(i) if hasattr(E, "Polynomial") else E.Poly(i) for i in (2, 5))
+        pq = E.Polynomial(1) if hasattr(E, "Polynomial") else E.Poly(1)
+        i = Info(k, [0], [q], [6], [0], [pq * (pw - pw) + pq * pa0 - pq * pa0], [], [], None)
+        i.lasso_lookups = [Lk(tabs[0], 5, [3, 4]), Lk(tabs[1], 7, [6])]
+        return i
+    o_info = info(o_ex, o_hp.CircuitInfo, o_hp.LassoLookup, specs)
+    g_info = info(g_ex, g_hp.PlonkishCircuitInfo, g_hp.LassoLookup, tables)
+    o_pcs, g_pcs = _setup(hl, ctx, k, 771)
+    o_pp = o_hp.preprocess(o_pcs, o_info)
+    ot = OT()
+    o_hp.prove(o_pp, [[]], lambda r, ch: witness, ot)
+    prng = random.Random(771)
+    ss = [prng.randrange(1, P) for _ in range(k)]
+    g_pp, g_vp = g_hp.HyperPlonk.preprocess(g_pcs, g_info, hl.MultilinearKzgVerifierParams.setup(ss))
+    t = hl.Keccak256Transcript()
+    g_hp.HyperPlonk.prove(g_pp, [[]], [hl.MultilinearPolynomial.new(ctx, x) for x in witness], t)
+    proof = t.into_proof()
+    assert proof == ot.into_proof()
+    o_hp.verify(o_pp, [[]], OT(proof))
+    g_hp.HyperPlonk.verify(g_vp, [[]], hl.Keccak256Transcript.from_proof(proof))

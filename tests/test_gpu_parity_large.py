@@ -93,7 +93,9 @@ def test_sum_check_evaluations_2p18(hl, ctx):
     tables = [rand_mont(rng, 1 << nv) for _ in range(5)]
     y = [prng.randrange(P) for _ in range(nv)]
     c = [prng.randrange(P) for _ in range(3)]
-    claim = prng.randrange(P)  # both provers derive p(0) from the claim: any value gives the same bytes
+    # a claim that is NOT the true sum: the reference still sends the true p(1..D) with p(0) = claim - p(1); the device
+    # path's eq factoring derives q(0) from the claim, so it must notice in round 0 and take the standard path
+    claim = prng.randrange(P)
     terms = [(c[0], [0, 1]), (c[1], [2, 3]), (c[2], [0, 3, 4])]
     ot = co.Transcript()
     ox, oev = co.sumcheck_prove(ot, 0, nv, _sop_struct(hl, terms, 0), tables, [y], claim)
@@ -293,3 +295,55 @@ def test_lasso_2p24_and_prove_verify(hl, ctx):
     t = hl.Keccak256Transcript()
     hl.lasso_prove(pp, table, n, bufs, t)
     assert t.into_proof() != proofs[0]
+
+
+# ------------------------------------------------------------------ Lasso inside HyperPlonk at scale (configs[4] stand-in)
+@pytest.mark.parametrize("kind", ["and", "range"])
+def test_hyperplonk_lasso_2p17_matches_cpp_oracle(hl, ctx, kind):
+    """vanilla gates + a 32-bit lookup (4 x (8+8)-bit AND chunks / 2 x 16-bit range limbs: the production subtable size)
+    proven by Lasso inside HyperPlonk::prove, 2^17 rows: proof bytes against the C++ oracle's restatement of the
+    specification (oracle/pyref/hyperplonk.py LassoLookup), then the host verifier"""
+    from halo2_lasso_amd import hyperplonk as g_hp, synthetic
+    from oracle.pyref import hyperplonk as o_hp, lasso as o_lasso
+    k = 17
+    ss = trapdoor(k, 1717)
+    pcs = hl.MultilinearKzg.setup(ctx, ss)
+    circ = synthetic.vanilla_plonk_with_lasso(ctx, k, kind=kind, seed=17)
+    pp, vp = synthetic.prover_param(pcs, circ, hl.MultilinearKzgVerifierParams.setup(ss))
+    t = hl.Keccak256Transcript()
+    g_hp.HyperPlonk.prove(pp, circ.instances, circ.d_witness, t)
+    proof = t.into_proof()
+    spec = o_lasso.range_table(2, 16) if kind == "range" else o_lasso.bitwise_table(o_lasso.SUBTABLE_AND, 4, 16)
+    o_info = o_hp.vanilla_plonk_with_lasso_circuit_info(k, 0, [[]] * 6, [[(7, 1)], [(8, 1)], [(9, 1)]], spec)
+    num_z, expression = o_hp.compose(o_info)
+    lk = circ.info.lasso_lookups[0]
+    ot = co.Transcript()
+    co.hyperplonk_prove(ot, pcs.eqs_bytes(), k, k, [0], [a.tobytes() for a in circ.h_preprocess], len(circ.h_witness), 0, [],
+                        [7, 8, 9], [p.buf.read() for p in circ.d_permutation], num_z, co.flatten_expression(expression),
+                        [[]], [a.tobytes() for a in circ.h_witness],
+                        lasso_lookups=[(lk.table.to_c(), lk.output_poly, lk.chunk_polys)])
+    assert proof == ot.into_proof()
+    g_hp.HyperPlonk.verify(vp, circ.instances, hl.Keccak256Transcript.from_proof(proof))
+
+
+def test_context_used_from_another_thread(hl, ctx):
+    """the current HIP device is a per-thread setting: every entry point makes the ctx's device current, so a ctx created
+    on one host thread proves from another (device guard)"""
+    import threading
+    n = 14
+    table = hl.LassoTable.range(2, 16)
+    pp = hl.MultilinearKzg.setup(ctx, trapdoor(16, 99))
+    rng = np.random.default_rng(99)
+    dims = [ctx.upload(rng.integers(0, 1 << 16, size=1 << n, dtype=np.uint32).tobytes()) for _ in range(2)]
+    t0 = hl.Keccak256Transcript()
+    hl.lasso_prove(pp, table, n, dims, t0)
+    out = {}
+
+    def worker():
+        t = hl.Keccak256Transcript()
+        hl.lasso_prove(pp, table, n, dims, t)
+        out["proof"] = t.into_proof()
+    th = threading.Thread(target=worker)
+    th.start()
+    th.join()
+    assert out["proof"] == t0.into_proof()
