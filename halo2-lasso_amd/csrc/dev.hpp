@@ -221,6 +221,13 @@ struct LassoG {
   const uint32_t* e[LH_LASSO_MAX_MEMORIES];
 };
 void k_lasso_output(Ctx&, const LassoG& g, size_t n, Fr* a);
+struct LassoGSmall {  // g = sum_t coeff[t] * E_{fac[t]} with 32-bit coefficients and a value that fits 32 bits
+  uint32_t num_terms;
+  uint32_t coeff[LH_LASSO_MAX_TERMS];
+  uint8_t fac[LH_LASSO_MAX_TERMS];
+  const uint32_t* e[LH_LASSO_MAX_MEMORIES];
+};
+void k_lasso_output_small(Ctx&, const LassoGSmall& g, size_t n, uint32_t* a);
 // canonical value of every entry as u32; false if an entry is not below 2^bits
 bool k_fr_to_index(Ctx&, const Fr* in, size_t n, uint32_t bits, uint32_t* out);
 // both tables hold Montgomery residues in [0, r): equal values have equal limbs

@@ -267,10 +267,14 @@ struct LassoClaims {  // points and claimed evaluations that remain to be opened
   std::vector<HFr> ev_l;  // final_cts_j at r_M
 };
 void lasso_check_table(const lh_lasso_table& tb);
-LassoColumns lasso_witness_columns(Ctx&, const lh_lasso_table&, size_t n, const uint32_t* const* d_dims, Fr** a_out);
+// a_out (optional): the output column a = g(E) as field elements; a_small_out (optional): the same as a 32-bit column
+// when g is linear with small coefficients and the value fits (then *a_out stays null)
+LassoColumns lasso_witness_columns(Ctx&, const lh_lasso_table&, size_t n, const uint32_t* const* d_dims, Fr** a_out,
+                                   uint32_t** a_small_out = nullptr);
+// `a`: the output column as field elements, or null with `a_small` given
 LassoClaims lasso_argue(Ctx&, const lh_lasso_table&, size_t n, const LassoColumns& w, const uint32_t* const* d_dims,
                         const Fr* a, const Fr* const* E_fr, Transcript& tr,
-                        const std::function<void(int)>& lap = nullptr);
+                        const std::function<void(int)>& lap = nullptr, const uint32_t* a_small = nullptr);
 // commitment framing of the Lasso argument: identity mask as one field element, then the non-identity commitments
 void lasso_write_commitments(Transcript& tr, const std::vector<HG1>& comms);
 std::vector<HG1> lasso_read_commitments(Transcript& tr, size_t count);

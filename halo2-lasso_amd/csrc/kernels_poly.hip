@@ -813,6 +813,19 @@ __global__ void lasso_output_kernel(LassoG g, size_t n, Fr* __restrict__ a) {
     a[i] = acc;
   }
 }
+// the same as a 32-bit column when g is linear with small coefficients and the value fits (range / AND / XOR tables of
+// <= 32-bit operands): no field arithmetic, 4 bytes written instead of 32
+__global__ void lasso_output_small_kernel(LassoGSmall g, size_t n, uint32_t* __restrict__ a) {
+  GSTRIDE(i, n) {
+    uint32_t acc = 0;
+    for (uint32_t t = 0; t < g.num_terms; t++) acc += g.coeff[t] * g.e[g.fac[t]][i];
+    a[i] = acc;
+  }
+}
+void k_lasso_output_small(Ctx& c, const LassoGSmall& g, size_t n, uint32_t* a) {
+  ProfScope ps(c, "lasso_output", 4.0 * n * (g.num_terms + 1), 0.0, (double)n);
+  if (n) hipLaunchKernelGGL(lasso_output_small_kernel, grid_for(n), 256, 0, c.stream, g, n, a);
+}
 void k_lasso_output(Ctx& c, const LassoG& g, size_t n, Fr* a) {
   ProfScope ps(c, "lasso_output", 36.0 * n, 2.0 * n, (double)n);
   if (n) hipLaunchKernelGGL(lasso_output_kernel, grid_for(n), 256, 0, c.stream, g, n, a);

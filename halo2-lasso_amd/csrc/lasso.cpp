@@ -114,7 +114,8 @@ void lasso_check_table(const lh_lasso_table& tb) {
 }
 
 // witness: access counters, subtable reads and (optionally) the lookup outputs a = g(E); arena memory of the caller's scope
-LassoColumns lasso_witness_columns(Ctx& c, const lh_lasso_table& tb, size_t n, const uint32_t* const* d_dims, Fr** a_out) {
+LassoColumns lasso_witness_columns(Ctx& c, const lh_lasso_table& tb, size_t n, const uint32_t* const* d_dims, Fr** a_out,
+                                   uint32_t** a_small_out) {
   const size_t cc = tb.num_chunks, l = tb.chunk_bits, alpha = tb.num_memories;
   const size_t N = (size_t)1 << n, M = (size_t)1 << l;
   LassoColumns w;
@@ -130,6 +131,36 @@ LassoColumns lasso_witness_columns(Ctx& c, const lh_lasso_table& tb, size_t n, c
     w.E[i] = c.arena.alloc_n<uint32_t>(N);
     k_lasso_subtable_read(c, (int)tb.memory_subtable[i], (uint32_t)l, d_dims[tb.memory_chunk[i]], N, w.E[i]);
     g.e[i] = w.E[i];
+  }
+  if (a_small_out) {
+    // a 32-bit output column when g = sum coeff_t E_t with small coefficients and the largest value fits 32 bits
+    *a_small_out = nullptr;
+    LassoGSmall gs;
+    memset(&gs, 0, sizeof(gs));
+    gs.num_terms = tb.num_terms;
+    bool ok = true;
+    uint64_t max_val = 0;
+    for (uint32_t m = 0; m < tb.num_terms && ok; m++) {
+      HFr co;
+      memcpy(&co, &tb.g_coeff[m], 32);
+      uint64_t canon[4];
+      co.to_canonical(canon);
+      const size_t i = tb.g_factor[m][0];
+      const size_t ebits = tb.memory_subtable[i] == LH_SUBTABLE_IDENTITY ? l : l / 2;
+      ok = tb.g_num_factors[m] == 1 && !canon[1] && !canon[2] && !canon[3] && canon[0] <= 0xffffffffull && ebits <= 32;
+      if (!ok) break;
+      max_val += canon[0] * (((uint64_t)1 << ebits) - 1);
+      ok = max_val <= 0xffffffffull;
+      gs.coeff[m] = (uint32_t)canon[0];
+      gs.fac[m] = (uint8_t)i;
+    }
+    if (ok) {
+      for (size_t i = 0; i < alpha; i++) gs.e[i] = w.E[i];
+      *a_small_out = c.arena.alloc_n<uint32_t>(N);
+      k_lasso_output_small(c, gs, N, *a_small_out);
+      if (a_out) *a_out = nullptr;
+      return w;
+    }
   }
   if (a_out) {
     g.num_terms = tb.num_terms;
@@ -147,13 +178,21 @@ LassoColumns lasso_witness_columns(Ctx& c, const lh_lasso_table& tb, size_t n, c
 // Steps 2-7 of the argument (oracle/pyref/lasso.py argue): Surge sum-check, memory-checking grand products,
 // evaluations.  The Fr tables hold at least 2^n (fcs_fr: 2^l) entries; `lap` (optional) receives phase boundaries.
 LassoClaims lasso_argue(Ctx& c, const lh_lasso_table& tb, size_t n, const LassoColumns& w, const uint32_t* const* d_dims,
-                        const Fr* a, const Fr* const* E_fr, Transcript& tr, const std::function<void(int)>& lap) {
+                        const Fr* a, const Fr* const* E_fr, Transcript& tr, const std::function<void(int)>& lap,
+                        const uint32_t* a_small) {
   const size_t cc = tb.num_chunks, l = tb.chunk_bits, alpha = tb.num_memories;
   const size_t N = (size_t)1 << n, M = (size_t)1 << l;
   LassoClaims cl;
   // ---- 2-4: Surge primary sum-check
   cl.r = tr.squeeze_challenges(n);
-  cl.v = evaluate_polys(c, &a, 1, n, cl.r.data())[0];
+  if (a_small) {
+    ArenaScope scope(c.arena);
+    Fr* eq = c.arena.alloc_n<Fr>(N);
+    k_eq_xy(c, (const Fr*)cl.r.data(), n, eq);
+    k_inner_products_small(c, &a_small, 1, eq, N, (Fr*)&cl.v);
+  } else {
+    cl.v = evaluate_polys(c, &a, 1, n, cl.r.data())[0];
+  }
   tr.write_field_element(cl.v);
   lh_sop surge;
   memset(&surge, 0, sizeof(surge));
@@ -243,7 +282,8 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
   ArenaScope scope(c.arena);
   // ---- witness: counters, subtable reads, lookup outputs
   Fr* a = nullptr;
-  LassoColumns w = lasso_witness_columns(c, tb, n, d_dims, &a);
+  uint32_t* a_small = nullptr;
+  LassoColumns w = lasso_witness_columns(c, tb, n, d_dims, &a, &a_small);
   std::vector<uint32_t*>&rts = w.rts, &fcs = w.fcs, &E = w.E;
   lap(0);
   // ---- 0/1: domain separation + commitments (one batched MSM)
@@ -316,7 +356,9 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
     if (len < NV) LH_HIP(hipMemsetAsync(d + len, 0, (NV - len) * sizeof(Fr), c.stream));
     return d;
   };
-  if (N < NV) {  // l > n: the output column needs the padding too
+  if (a_small) {
+    small[0] = SmallPoly{a_small, N};
+  } else if (N < NV) {  // l > n: the output column needs the padding too
     Fr* ap = c.arena.alloc_n<Fr>(NV);
     LH_HIP(hipMemcpyAsync(ap, a, N * sizeof(Fr), hipMemcpyDeviceToDevice, c.stream));
     LH_HIP(hipMemsetAsync(ap + N, 0, (NV - N) * sizeof(Fr), c.stream));
@@ -336,7 +378,7 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
   const Fr* const* E_fr = polys_n.data() + 1 + 2 * cc;
 
   // ---- 2-7: Surge, memory checking, evaluations
-  LassoClaims cl = lasso_argue(c, tb, n, w, d_dims, polys_n[0], E_fr, tr, lap);
+  LassoClaims cl = lasso_argue(c, tb, n, w, d_dims, polys_n[0], E_fr, tr, lap, a_small);
   const std::vector<HFr>&r = cl.r, &r_z = cl.r_z, &r_N = cl.r_N, &r_M = cl.r_M, &ev_n = cl.ev_n, &ev_l = cl.ev_l;
   const HFr& v = cl.v;
 

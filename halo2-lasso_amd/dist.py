@@ -12,6 +12,7 @@ torch.distributed itself only carries the barrier and the max-over-ranks of the 
 contract asks for.
 """
 import os
+import sys
 
 SEED_BASE = 0x4C4153534F00  # SURVEY.md §8d
 
@@ -86,16 +87,40 @@ def attach_sharded(ctx, dist, shard_bit):
     import halo2_lasso_amd as hl
     rank, world = dist.get_rank(), dist.get_world_size()
     if dist.get_backend() == "nccl" and os.environ.get("LH_SHARDED_TRANSPORT", "rccl") == "rccl":
-        ids = [hl.rccl_unique_id() if rank == 0 else None]
+        import torch
+        ok = 1
+        try:
+            ids = [hl.rccl_unique_id() if rank == 0 else None]
+        except hl.Error:
+            ids, ok = [None], 0
         dist.broadcast_object_list(ids, src=0)
-        hl.attach_comm_rccl(ctx, rank, world, ids[0], shard_bit)
-        return "rccl"
+        if ids[0] is not None:
+            try:
+                hl.attach_comm_rccl(ctx, rank, world, ids[0], shard_bit)
+            except hl.Error as e:  # e.g. no peer access between the devices of this job
+                sys.stderr.write("[lasso-hip] RCCL communicator failed on rank %d (%s); falling back to the host transport\n"
+                                 % (rank, e))
+                ok = 0
+        else:
+            ok = 0
+        # every rank must end up on the same transport
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            return "rccl"
+        hl.detach_comm(ctx)
     hl.attach_comm(ctx, rank, world, host_all_gather(dist, control_group(dist)), shard_bit)
     return "host"
 
 
+_control = None
+
+
 def control_group(dist):
-    """A gloo group for host-side exchanges next to an nccl (RCCL) default group."""
+    """A gloo group for host-side exchanges next to an nccl (RCCL) default group (created once: new_group is collective)."""
+    global _control
     if dist.get_backend() == "gloo":
         return None
-    return dist.new_group(backend="gloo")
+    if _control is None:
+        _control = dist.new_group(backend="gloo")
+    return _control

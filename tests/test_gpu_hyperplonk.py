@@ -302,9 +302,9 @@ def test_hyperplonk_lasso_zero_columns_and_two_lookups(hl, ctx):
     q = [rng.randrange(2) for _ in range(n)]
 
     def info(E, Info, Lk, tabs):
-        pw, pa0 = (E.Polynomial(i) if hasattr(E, "Polynomial") else E.Poly(i) for i in (2, 5))
-        pq = E.Polynomial(1) if hasattr(E, "Polynomial") else E.Poly(1)
-        i = Info(k, [0], [q], [6], [0], [pq * (pw - pw) + pq * pa0 - pq * pa0], [], [], None)
+        mk = E.Polynomial if hasattr(E, "Polynomial") else E.Poly
+        pq, pd0, pd1, pa0 = mk(1), mk(3), mk(4), mk(5)
+        i = Info(k, [0], [q], [6], [0], [pq * (pa0 - pd0 - pd1 * 4)], [], [], None)  # a0 recomposes its limbs
         i.lasso_lookups = [Lk(tabs[0], 5, [3, 4]), Lk(tabs[1], 7, [6])]
         return i
     o_info = info(o_ex, o_hp.CircuitInfo, o_hp.LassoLookup, specs)
