@@ -6,6 +6,7 @@
 #include <thread>
 #include <functional>
 #include <memory>
+#include <emmintrin.h>
 #include "dev.hpp"
 
 namespace lh {
@@ -77,13 +78,54 @@ ScFinishArgs Ctx::finish_for(uint32_t grid, Fr* out_host, uint32_t seq) {
   return f;
 }
 
-void Ctx::mbox_send(const Fr& r, uint32_t seq) {
-  TailMbox* m = mbox();
-  memcpy((void*)&m->r, &r, sizeof(Fr));
-  __atomic_store_n(&m->seq, seq, __ATOMIC_RELEASE);
+// one 16-byte store per chunk (aligned SSE stores are single-copy atomic on every x86-64 with AVX)
+static inline void store_chunk(TailChunk* dst, uint32_t a, uint32_t b, uint32_t c_, uint32_t d) {
+  _mm_store_si128((__m128i*)dst, _mm_set_epi32((int)d, (int)c_, (int)b, (int)a));
+}
+static inline void load_chunk(const TailChunk* src, uint32_t w[4]) {
+  _mm_store_si128((__m128i*)w, _mm_load_si128((const __m128i*)src));
 }
 
-void Ctx::mbox_abort() { __atomic_store_n(&mbox()->seq, SC_TAIL_ABORT, __ATOMIC_RELEASE); }
+void Ctx::mbox_send(const Fr& r, uint32_t seq) {
+  TailMbox* m = mbox();
+  store_chunk(&m->c[0], seq, r.l[0], r.l[1], r.l[2]);
+  store_chunk(&m->c[1], seq, r.l[3], r.l[4], r.l[5]);
+  store_chunk(&m->c[2], seq, r.l[6], r.l[7], 0);
+}
+
+void Ctx::mbox_abort() {
+  TailMbox* m = mbox();
+  for (int j = 0; j < 3; j++) store_chunk(&m->c[j], SC_TAIL_ABORT, 0, 0, 0);
+}
+
+void Ctx::wait_chunks(const TailChunk* chunks, size_t count, uint32_t seq, Fr* out) {
+  alignas(16) uint32_t w[4];
+  size_t have = 0;  // chunks 0..have-1 carry `seq` and are copied out
+  bool gone = false;
+  for (uint64_t spin = 0;; spin++) {
+    while (have < count) {
+      load_chunk(chunks + have, w);
+      if (w[0] != seq) break;
+      Fr& f = out[have / 3];
+      const size_t j = have % 3;
+      f.l[3 * j] = w[1], f.l[3 * j + 1] = w[2];
+      if (j < 2) f.l[3 * j + 2] = w[3];
+      have++;
+    }
+    if (have == count) return;
+    __builtin_ia32_pause();
+    if ((spin & 0xfffff) == 0xfffff) {
+      hipError_t e = hipStreamQuery(stream);
+      if (e == hipSuccess) {
+        if (gone) throw Error(LH_ERR_DEVICE, "kernel finished without publishing its result");
+        gone = true;  // one more look at the chunks: they may have landed between the last look and the query
+        spin = 0xffffe;
+        continue;
+      }
+      if (e != hipErrorNotReady) throw Error(LH_ERR_DEVICE, std::string("stream error: ") + hipGetErrorString(e));
+    }
+  }
+}
 
 void* Ctx::pin(size_t bytes) {
   if (bytes > pinned_bytes) {

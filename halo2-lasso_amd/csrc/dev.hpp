@@ -112,6 +112,7 @@ struct Ctx {
   // sharded sum-check rounds: the round kernel leaves its D sums in this DEVICE buffer (and "publishes" to a device
   // word) instead of pinned host memory; the all-gather and the sum-and-publish kernel follow on the stream
   Fr* sc_redirect = nullptr;
+  uint64_t* tail_trace = nullptr;  // development: device stamps of the last resident tail (LH_SC_TAIL_TRACE)
   bool prof = false;
   std::vector<ProfRec> prof_recs;
   hipEvent_t prof_ev[2] = {nullptr, nullptr};
@@ -136,6 +137,8 @@ struct Ctx {
   void mbox_send(const Fr& r, uint32_t seq);
   void mbox_abort();
   void wait_flag(uint32_t seq);
+  // message of a resident tail round: `count` chunks that all carry `seq` -> `count` / 3 field elements
+  void wait_chunks(const struct TailChunk* chunks, size_t count, uint32_t seq, Fr* out);
 };
 
 // Persistent host worker threads for the short host-side tails (window combines of an MSM batch): spawning
@@ -290,21 +293,33 @@ struct ScOpenRound {
 // out_host[2 m], out_host[2 m + 1] = q_m(0), q_m(1)
 void k_sc_round_open(Ctx&, const ScOpenRound& rd, bool bind, size_t size, Fr* out_host);
 
-// Resident tail: once the live tables of a sum-check fit the LDS of one CU, ONE launch runs all remaining rounds.
-// Per round the kernel publishes the message (flag = seq0 + i) and polls the mailbox for the challenge, which the host
-// writes after running the transcript; after the last challenge it publishes the final evaluation of the first
-// `num_out` tables (flag = seq0 + rounds).  No launch and no completion latency per round, tables never leave LDS.
-struct TailMbox {   // pinned, written by the host only
-  uint32_t seq;     // seq0 + i once `r` holds the challenge of round i; SC_TAIL_ABORT makes the kernel exit
-  uint32_t pad[7];
-  Fr r;
+// Resident tail: once the live tables of a sum-check fit the LDS of a few CUs, ONE launch runs all remaining rounds.
+// G workgroups each keep a contiguous slice of every table in LDS (binding never crosses a slice); per round every
+// workgroup leaves its D partial sums in device memory and draws a ticket, the one that draws the last ticket adds
+// them up and sends the message to the host; when a slice is down to one entry the slices are handed (through device
+// memory, same ticket protocol) to the workgroup that arrives last, which runs the remaining log2(G) rounds alone.
+// Host <-> kernel traffic is self-validating 16-byte chunks {seq, 3 limbs} (TailChunk): a chunk is written with ONE
+// 16-byte store and read with ONE 16-byte load on either side, so a message needs no flag and no fence (one PCIe
+// crossing per direction and round instead of two).  After the last challenge the kernel publishes the final
+// evaluation of the first `num_out` tables (plain values, flag = seq0 + rounds).
+// No launch and no completion latency per round, tables never leave LDS.
+struct TailChunk {
+  uint32_t w[4];  // {seq, limb 3j, limb 3j+1, limb 3j+2} (chunk j = 0..2 of a field element; the last holds two limbs)
+};
+struct TailMbox {      // pinned, written by the host only: the challenge of round i carries seq0 + i in every chunk;
+  TailChunk c[3];      // SC_TAIL_ABORT makes the kernel exit
+  uint32_t pad[4];
 };
 constexpr uint32_t SC_TAIL_ABORT = 0xffffffffu;
+constexpr int SC_TAIL_MAX_DEGREE = 6;
 // largest resident table length (power of two, 0 = tail not applicable) for this expression
 size_t k_sc_tail_capacity(const ScRound& rd, int degree);
 // rd.in: entry tables; first_bind: they hold 2*n0 entries and are bound with rd.r first.  Returns immediately.
+// msg_host: 3 * degree chunks (value x at chunks 3x..3x+2), out_host: num_out field elements.
 void k_sc_tail_launch(Ctx&, const ScRound& rd, int degree, size_t n0, bool first_bind, size_t num_out, uint32_t seq0,
-                      Fr* msg_host, Fr* out_host);
+                      TailChunk* msg_host, Fr* out_host);
+// after a tail that ended early: the ticket counter is wherever the workgroups left it
+void k_sc_tail_resync(Ctx&);
 
 // ------------------------------------------------------------------ general expressions (kernels_expr.hip)
 struct ExtRound {

@@ -290,24 +290,38 @@ static void launch_round(Ctx& c, const ScArgs& a, bool bind, size_t size, uint32
 }
 
 // ------------------------------------------------------------------ resident tail (dev.hpp: k_sc_tail_*)
-// One workgroup of 8 waves (two per SIMD of a CU: a lone wave leaves a third of the multiplier idle) keeps every live table in LDS and runs ALL remaining rounds:
+// G workgroups (a power of two, 1 for short tables), each with a contiguous slice of every live table in LDS, run ALL
+// remaining rounds:
 //   evaluate: one (term, X, pair) item per lane, segmented butterfly over the pairs of a (term, X) group;
-//   publish the message to pinned memory, flag = seq0 + round;
-//   poll the host's mailbox for the challenge (bounded: ~2 s of the 100 MHz wall clock, or SC_TAIL_ABORT);
-//   bind every table with it, LDS to LDS.
-// The dependent chain per round is 1 (bind) + nfac (+1 eq) + 1 (coefficient) multiplications.
+//   G > 1: the D sums of the slice go to device memory, a ticket is drawn, the workgroup with the last ticket adds the
+//          G partials (finish_round's hand-off protocol);
+//   the message goes to pinned memory as self-validating chunks (dev.hpp TailChunk);
+//   every workgroup polls the host's mailbox for the challenge (bounded: ~2 s of the 100 MHz wall clock, or
+//   SC_TAIL_ABORT) and binds its slice with it, LDS to LDS;
+//   a slice that is down to one pair is bound into device memory instead, and the workgroup that arrives last
+//   collects the G entries of every table and goes on alone.
+// The dependent chain per round is 1 (bind) + nfac (+1 eq) + 1 (coefficient) multiplications; a workgroup of G > 1
+// runs 4 waves (one per SIMD: a second wave on a SIMD doubles the time of every multiplication of the chain).
 struct ScTailArgs {
   ScRound rd;
   uint32_t n0, first_bind, degree, num_out, seq0, red_off;
+  uint32_t G, lgG, cap;    // workgroups; LDS carve-up: cur[T * cap], nxt[T * cap / 2], red[]
+  uint32_t ticket_base;    // value of *ticket before this launch
+  uint32_t* ticket;
+  Fr* part;                // device scratch: [2][G][8] partial sums of the even / odd rounds, then hand[T][G]
+  TailChunk* bcast;        // device: the challenge, relayed by the workgroup that talks to the host (G > 1)
   uint32_t* flag;
-  Fr* msg_host;
+  TailChunk* msg_host;
   Fr* out_host;
   const TailMbox* mbox;
   uint64_t poll_ticks;  // wall_clock64 ticks the kernel waits for one challenge before it leaves
+  uint64_t* trace;      // development (LH_SC_TAIL_TRACE): [round][8] wall-clock stamps of workgroup 0 / the last workgroup
 };
 constexpr uint32_t TAIL_LDS_BYTES = 144 * 1024;      // of the CU's 160 KB (opt-in: hipFuncAttributeMaxDynamicSharedMemorySize)
-constexpr uint32_t TAIL_THREADS = 512;
-constexpr uint32_t TAIL_MAX_ITEMS = 2048;            // (term, X, pair) items of the first resident round: ~2 us per 512 on one CU
+constexpr uint32_t TAIL_THREADS = 512;               // single workgroup
+constexpr uint32_t TAIL_THREADS_MULTI = 256;         // G > 1
+constexpr uint32_t TAIL_MAX_ITEMS = 2048;            // (term, X, pair) items of a workgroup's first round: ~2 us per 512 on one CU
+constexpr uint32_t TAIL_MAX_G = 64;
 
 __device__ __forceinline__ Fr shfl_xor_fr(const Fr& v, int mask) {
   Fr o;
@@ -316,37 +330,74 @@ __device__ __forceinline__ Fr shfl_xor_fr(const Fr& v, int mask) {
   return o;
 }
 
+// 16-byte system-scope accesses: one request to host memory each
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 load_sys_x4(const void* p) {
+  u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void store_sys_x4(void* p, u32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void tail_send(TailChunk* msg, uint32_t x, const Fr& s, uint32_t seq) {
+  store_sys_x4(&msg[3 * x + 0], u32x4{seq, s.l[0], s.l[1], s.l[2]});
+  store_sys_x4(&msg[3 * x + 1], u32x4{seq, s.l[3], s.l[4], s.l[5]});
+  store_sys_x4(&msg[3 * x + 2], u32x4{seq, s.l[6], s.l[7], 0u});
+}
+
+// wave 0, thread 0 of a workgroup: release this workgroup's stores (all of wave 0), draw a ticket; true when it is
+// the last of its batch (then every other workgroup's stores are visible to this CU)
+__device__ __forceinline__ bool tail_ticket(uint32_t* ticket, uint32_t last_ticket) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const bool last = t == last_ticket;
+  if (last) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  return last;
+}
+
 __global__ __launch_bounds__(TAIL_THREADS) void sc_tail_kernel(ScTailArgs a) {
   extern __shared__ __align__(16) unsigned char tail_lds_raw[];
   __shared__ Fr r_sh;
-  __shared__ uint32_t stop_sh;
+  __shared__ uint32_t stop_sh, last_sh;
   Fr* lds = (Fr*)tail_lds_raw;
   const ScRound& rd = a.rd;
-  const uint32_t T = rd.num_tables, D = a.degree, tid = threadIdx.x, lane = tid & 63u;
-  Fr* cur = lds;               // T * n0 entries
-  Fr* nxt = lds + T * a.n0;    // T * n0 / 2 entries
+  const uint32_t T = rd.num_tables, D = a.degree, tid = threadIdx.x, lane = tid & 63u, nthr = blockDim.x;
+  const uint32_t G = a.G, wg = blockIdx.x;
+  Fr* cur = lds;                          // T * n entries
+  Fr* nxt = lds + T * a.cap;              // T * n / 2 entries
   Fr* red = lds + a.red_off;
-  uint32_t n = a.n0, lg = 0;
+  Fr* hand = a.part + 2 * G * 8;
+  bool multi = G > 1;
+  uint32_t n = a.n0 >> a.lgG, lg = 0;     // this workgroup's slice: entries [wg * n, (wg + 1) * n) of every table
   while ((1u << lg) < n) lg++;
-  for (uint32_t e = tid; e < T * n; e += TAIL_THREADS) {
+  for (uint32_t e = tid; e < T * n; e += nthr) {
     const uint32_t t = e >> lg, k = e & (n - 1);
+    const size_t gk = (size_t)wg * n + k;
     Fr v;
     if (a.first_bind) {
-      const Fr* p = rd.in[t] + 2 * (size_t)k;
+      const Fr* p = rd.in[t] + 2 * gk;
       Fr e0 = p[0], e1 = p[1];
       v = add(mul(sub(e1, e0), rd.r), e0);
     } else {
-      v = rd.in[t][k];
+      v = rd.in[t][gk];
     }
     cur[e] = v;
   }
   if (tid == 0) stop_sh = 0;
   __syncthreads();
-  const uint32_t rounds = lg, groups = rd.num_terms * D;
+  uint32_t rounds = lg + a.lgG, batch = 0;
+  const uint32_t groups = rd.num_terms * D;
   for (uint32_t i = 0; i < rounds; i++, lg--) {
     const uint32_t P = n >> 1, lgP = lg - 1, items = groups << lgP;
     const uint32_t seg = P < 64 ? P : 64, chunks = P < 64 ? 1 : P >> 6;
-    for (uint32_t base = tid & ~63u; base < items; base += TAIL_THREADS) {
+    const bool tr0 = a.trace && tid == 0 && (wg == 0 || !multi);
+    if (tr0) a.trace[i * 8 + 0] = wall_clock64();
+    for (uint32_t base = tid & ~63u; base < items; base += nthr) {
       const uint32_t it = base + lane;
       const uint32_t pl = it & (P - 1), g = it >> lgP;
       Fr acc = Fr::zero();
@@ -381,37 +432,92 @@ __global__ __launch_bounds__(TAIL_THREADS) void sc_tail_kernel(ScTailArgs a) {
     __syncthreads();
     if (tid < groups) red[tid] = gs;
     __syncthreads();
-    if (tid < D) {
-      Fr s = Fr::zero();
-      for (uint32_t m = 0; m < rd.num_terms; m++) s = add(s, red[m * D + tid]);
-      a.msg_host[tid] = s;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    if (tr0) a.trace[i * 8 + 1] = wall_clock64();
+    const uint32_t seq = a.seq0 + i;
+    if (!multi) {
+      if (tid < D) {
+        Fr s = Fr::zero();
+        for (uint32_t m = 0; m < rd.num_terms; m++) s = add(s, red[m * D + tid]);
+        tail_send(a.msg_host, tid, s, seq);
+      }
+    } else {
+      // partial sums of this slice -> device memory, ticket; the last workgroup adds the G partials (one wave per X,
+      // butterfly over the workgroups) and sends the message
+      Fr* part = a.part + (size_t)(i & 1u) * G * 8;
+      if (tid < 64) {
+        if (tid < D) {
+          Fr s = Fr::zero();
+          for (uint32_t m = 0; m < rd.num_terms; m++) s = add(s, red[m * D + tid]);
+          part[wg * 8 + tid] = s;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) last_sh = tail_ticket(a.ticket, a.ticket_base + batch * G + G - 1) ? 1u : 0u;
+      }
+      batch++;
+      __syncthreads();
+      if (tr0) a.trace[i * 8 + 2] = wall_clock64();
+      if (last_sh && a.trace && tid == 0) a.trace[i * 8 + 3] = wall_clock64();
+      if (last_sh) {
+        for (uint32_t x = tid >> 6; x < D; x += nthr >> 6) {
+          Fr v = lane < G ? part[lane * 8 + x] : Fr::zero();
+          for (uint32_t off = 1; off < 64 && off < G; off <<= 1) v = add(v, shfl_xor_fr(v, (int)off));
+          if (lane == 0) tail_send(a.msg_host, x, v, seq);
+        }
+      }
     }
-    __syncthreads();
-    if (tid == 0) {
-      publish_flag(a.flag, a.seq0 + i);
-      const uint32_t want = a.seq0 + i;
+    if (a.trace && tid == 0 && (multi ? last_sh != 0 : true)) a.trace[i * 8 + 4] = wall_clock64();
+    if (tid < 64) {
+      // lanes 0..2 fetch one chunk of the mailbox each; the challenge is there when all three carry this round's seq.
+      // G > 1: only the workgroup that sent the message asks the host (dozens of pollers queue up on the PCIe link:
+      // measured 4 us of skew between workgroups); it relays the chunks through device memory to the others.
+      const bool relay = multi && last_sh;
+      const TailChunk* box = multi && !last_sh ? a.bcast : a.mbox->c;
       const uint64_t t0 = wall_clock64();
-      // relaxed polls, one acquire at the end: an acquiring load per poll would invalidate the device's caches
-      // (other streams' too) every microsecond
+      uint32_t stop = 0;
+      u32x4 v = {0u, 0u, 0u, 0u};
       for (;;) {
-        const uint32_t s = __hip_atomic_load(&a.mbox->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (s == want) break;
-        if (s == SC_TAIL_ABORT || wall_clock64() - t0 > a.poll_ticks) {
-          stop_sh = 1;
+        if (lane < 3) v = load_sys_x4(&box[lane]);
+        const uint64_t ok = __ballot(lane >= 3 || v.x == seq);
+        if (ok == ~0ull) break;
+        const uint64_t ab = __ballot(lane < 3 && v.x == SC_TAIL_ABORT);
+        if (ab || wall_clock64() - t0 > a.poll_ticks) {
+          stop = 1;
           break;
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-      Fr r;
-#pragma unroll
-      for (int k = 0; k < 8; k++) r.l[k] = __hip_atomic_load(&a.mbox->r.l[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      r_sh = r;
+      if (relay && lane < 3) store_sys_x4((void*)&a.bcast[lane], stop ? u32x4{SC_TAIL_ABORT, 0u, 0u, 0u} : v);
+      if (lane < 3) {
+        r_sh.l[3 * lane] = v.y, r_sh.l[3 * lane + 1] = v.z;
+        if (lane < 2) r_sh.l[3 * lane + 2] = v.w;
+      }
+      if (lane == 0) stop_sh = stop;
     }
     __syncthreads();
     if (stop_sh) return;  // the host gave up (or went away): leave without publishing anything further
+    if (tr0) a.trace[i * 8 + 5] = wall_clock64();
     const Fr r = r_sh;
-    for (uint32_t e = tid; e < (T << lgP); e += TAIL_THREADS) {
+    if (multi && P == 1) {
+      // hand-over: one bound entry per table and workgroup -> device memory; the last arrival goes on alone with
+      // tables of G entries
+      if (tid < 64) {
+        for (uint32_t t = tid; t < T; t += 64) {
+          const Fr v0 = cur[2 * t], v1 = cur[2 * t + 1];
+          hand[(size_t)t * G + wg] = add(mul(sub(v1, v0), r), v0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) last_sh = tail_ticket(a.ticket, a.ticket_base + batch * G + G - 1) ? 1u : 0u;
+      }
+      __syncthreads();
+      if (!last_sh) return;
+      cur = lds, nxt = lds + T * a.cap;  // (the slice may sit in the smaller of the two regions by now)
+      for (uint32_t e = tid; e < T * G; e += nthr) cur[e] = hand[e];
+      __syncthreads();
+      multi = false;
+      n = G;
+      lg = a.lgG + 1;  // (the loop header takes one off)
+      continue;
+    }
+    for (uint32_t e = tid; e < (T << lgP); e += nthr) {
       const uint32_t t = e >> lgP, k = e & (P - 1);
       const Fr* pv = cur + (t << lg) + 2 * k;
       Fr v0 = pv[0], v1 = pv[1];
@@ -431,9 +537,32 @@ __global__ __launch_bounds__(TAIL_THREADS) void sc_tail_kernel(ScTailArgs a) {
   if (tid == 0) publish_flag(a.flag, a.seq0 + rounds);
 }
 
-static uint32_t tail_red_entries(const ScRound& rd, int degree, size_t n0) {
-  const size_t groups = (size_t)rd.num_terms * degree, P = n0 >> 1;
+static uint32_t tail_red_entries(const ScRound& rd, int degree, size_t n) {
+  const size_t groups = (size_t)rd.num_terms * degree, P = n >> 1;
   return (uint32_t)std::max(groups, groups * (P < 64 ? 1 : P >> 6));
+}
+
+// workgroups of a resident tail over tables of n0 entries: slices of ~32 entries (about one multiplication per lane and
+// round), at most TAIL_MAX_G
+static uint32_t tail_workgroups(size_t n0) {
+  static const int forced = [] {
+    const char* e = getenv("LH_SC_TAIL_G");  // development: 1 = always a single workgroup
+    return e ? atoi(e) : 0;
+  }();
+  uint32_t G = 1;
+  while (G < TAIL_MAX_G && (size_t)G * 64 <= n0) G <<= 1;
+  if (forced > 0) {
+    G = 1;
+    while (G < (uint32_t)forced && (size_t)G * 4 <= n0) G <<= 1;
+  }
+  return G;
+}
+
+static bool tail_fits(const ScRound& rd, int degree, size_t n0, uint32_t G) {
+  const size_t s0 = n0 / G, cap = std::max<size_t>(s0, G);
+  const size_t fr = (size_t)rd.num_tables * (cap + cap / 2) + tail_red_entries(rd, degree, cap);
+  if (fr * sizeof(Fr) > TAIL_LDS_BYTES) return false;
+  return cap <= 2 || (size_t)rd.num_terms * degree * (cap >> 1) <= TAIL_MAX_ITEMS;
 }
 
 size_t k_sc_tail_capacity(const ScRound& rd, int degree) {
@@ -443,24 +572,23 @@ size_t k_sc_tail_capacity(const ScRound& rd, int degree) {
   }();
   static const size_t max_len = [] {
     const char* e = getenv("LH_SC_TAIL_MAX_LEN");
-    return e ? (size_t)atoll(e) : (size_t)512;
+    return e ? (size_t)atoll(e) : (size_t)8192;
   }();
-  if (!enabled || degree < 1 || degree > 6) return 0;
+  if (!enabled || degree < 1 || degree > SC_TAIL_MAX_DEGREE) return 0;
   if ((size_t)rd.num_terms * degree > 256 || rd.num_tables == 0) return 0;
   size_t best = 0;
   for (size_t n0 = 2; n0 <= max_len; n0 <<= 1) {
-    const size_t fr = (size_t)rd.num_tables * (n0 + n0 / 2) + tail_red_entries(rd, degree, n0);
-    if (fr * sizeof(Fr) > TAIL_LDS_BYTES) break;
-    if (n0 > 2 && (size_t)rd.num_terms * degree * (n0 >> 1) > TAIL_MAX_ITEMS) break;
+    if (!tail_fits(rd, degree, n0, tail_workgroups(n0))) break;
     best = n0;
   }
   return best;
 }
 
 void k_sc_tail_launch(Ctx& c, const ScRound& rd, int degree, size_t n0, bool first_bind, size_t num_out, uint32_t seq0,
-                      Fr* msg_host, Fr* out_host) {
-  LH_REQUIRE(n0 >= 2 && (n0 & (n0 - 1)) == 0 && n0 <= k_sc_tail_capacity(rd, degree), LH_ERR_ARG,
-             "sum-check tail: tables do not fit");
+                      TailChunk* msg_host, Fr* out_host) {
+  const uint32_t G = tail_workgroups(n0);
+  LH_REQUIRE(n0 >= 2 && (n0 & (n0 - 1)) == 0 && n0 <= k_sc_tail_capacity(rd, degree) && tail_fits(rd, degree, n0, G),
+             LH_ERR_ARG, "sum-check tail: tables do not fit");
   LH_REQUIRE(num_out <= 256, LH_ERR_ARG, "sum-check tail: too many outputs");
   ScTailArgs a;
   a.rd = rd;
@@ -469,7 +597,24 @@ void k_sc_tail_launch(Ctx& c, const ScRound& rd, int degree, size_t n0, bool fir
   a.degree = (uint32_t)degree;
   a.num_out = (uint32_t)num_out;
   a.seq0 = seq0;
-  a.red_off = (uint32_t)((size_t)rd.num_tables * (n0 + n0 / 2));
+  a.G = G;
+  a.lgG = 0;
+  while ((1u << a.lgG) < G) a.lgG++;
+  a.cap = (uint32_t)std::max<size_t>(n0 / G, G);
+  a.red_off = (uint32_t)((size_t)rd.num_tables * (a.cap + a.cap / 2));
+  a.ticket = c.ticket;
+  a.ticket_base = c.ticket_base;
+  a.part = nullptr;
+  a.bcast = nullptr;
+  if (G > 1) {
+    // one batch of G tickets per distributed round, one for the hand-over
+    uint32_t rounds_a = 0;
+    while (((size_t)G << (rounds_a + 1)) <= n0) rounds_a++;
+    c.ticket_base += (rounds_a + 1) * G;
+    a.part = c.arena.alloc_n<Fr>((size_t)2 * G * 8 + (size_t)rd.num_tables * G);
+    a.bcast = (TailChunk*)c.arena.alloc(4 * sizeof(TailChunk));
+    LH_HIP(hipMemsetAsync(a.bcast, 0, 4 * sizeof(TailChunk), c.stream));
+  }
   a.flag = c.flag;
   a.msg_host = msg_host;
   a.out_host = out_host;
@@ -479,13 +624,26 @@ void k_sc_tail_launch(Ctx& c, const ScRound& rd, int degree, size_t n0, bool fir
   const char* tmo = getenv("LH_SC_TAIL_TIMEOUT_MS");
   const double ms = tmo && *tmo ? atof(tmo) : 2000.0;
   a.poll_ticks = (uint64_t)(ms * (double)c.wall_clock_khz);
-  __atomic_store_n(&c.mbox()->seq, 0u, __ATOMIC_RELEASE);
-  const size_t lds = ((size_t)a.red_off + tail_red_entries(rd, degree, n0)) * sizeof(Fr);
+  static const bool trace_on = getenv("LH_SC_TAIL_TRACE") != nullptr;
+  a.trace = nullptr;
+  if (trace_on) {
+    a.trace = (uint64_t*)c.arena.alloc(32 * 8 * sizeof(uint64_t));
+    LH_HIP(hipMemsetAsync(a.trace, 0, 32 * 8 * sizeof(uint64_t), c.stream));
+    c.tail_trace = a.trace;
+  }
+  c.mbox_send(Fr::zero(), 0u);
+  const size_t lds = ((size_t)a.red_off + tail_red_entries(rd, degree, a.cap)) * sizeof(Fr);
   static const hipError_t opt_in =
       hipFuncSetAttribute((const void*)sc_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TAIL_LDS_BYTES + 2048);
   LH_HIP(opt_in);
-  hipLaunchKernelGGL(sc_tail_kernel, dim3(1), dim3(TAIL_THREADS), lds, c.stream, a);
+  hipLaunchKernelGGL(sc_tail_kernel, dim3(G), dim3(G > 1 ? TAIL_THREADS_MULTI : TAIL_THREADS), lds, c.stream, a);
   LH_HIP(hipGetLastError());
+}
+
+void k_sc_tail_resync(Ctx& c) {
+  uint32_t v = 0;
+  c.d2h(&v, c.ticket, sizeof(v));
+  c.ticket_base = v;
 }
 
 static size_t sc_lds_max_items() {

@@ -269,16 +269,21 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
           (void)hipStreamSynchronize(c.stream);
         }
       } guard{c};
-      k_sc_tail_launch(c, rd, degree, n0, bind, num_polys, seq0, evals_host, evals_host + 16);
+      // the round messages arrive as 3 * degree self-validating chunks in the first 512 bytes of the pinned block
+      TailChunk* chunks = (TailChunk*)evals_host;
+      memset((void*)chunks, 0, 3 * SC_TAIL_MAX_DEGREE * sizeof(TailChunk));
+      k_sc_tail_launch(c, rd, degree, n0, bind, num_polys, seq0, chunks, evals_host + 16);
       double host_us = 0;
       size_t absorbed = 0;  // tail rounds whose message is in the transcript and whose challenge is known
       bool gave_up = false;
       // The kernel waits a bounded time for each challenge (LH_SC_TAIL_TIMEOUT_MS, default 2 s): a host thread stalled
       // past that (debugger, SIGSTOP, a slow transcript callback) finds the kernel gone.  The entry tables are untouched
       // and the challenges squeezed so far are known, so the sum-check is resumed on the per-round path.
-      auto wait = [&](uint32_t seq) {
+      Fr sums[SC_TAIL_MAX_DEGREE];
+      auto wait = [&](uint32_t seq, bool msg) {
         try {
-          c.wait_flag(seq);
+          if (msg) c.wait_chunks(chunks, 3 * (size_t)degree, seq, sums);
+          else c.wait_flag(seq);
           return true;
         } catch (const Error& e) {
           if (e.code != LH_ERR_DEVICE || hipStreamQuery(c.stream) != hipSuccess) throw;
@@ -286,18 +291,34 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
         }
       };
       for (size_t i = 0; i < rounds && !gave_up; i++) {
-        if (!wait(seq0 + (uint32_t)i)) {
+        if (!wait(seq0 + (uint32_t)i, true)) {
           gave_up = true;
           break;
         }
         const auto t_h = std::chrono::steady_clock::now();
-        const HFr r = message(evals_host);
+        const HFr r = message(sums);
         c.mbox_send(dev(r), seq0 + (uint32_t)i);
         absorbed = i + 1;
         if (tail_debug) host_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_h).count();
       }
-      if (!gave_up && !wait(seq0 + (uint32_t)rounds)) gave_up = true;
+      if (!gave_up && !wait(seq0 + (uint32_t)rounds, false)) gave_up = true;
       guard.done = true;
+      if (!gave_up && c.tail_trace) {
+        // development: per round, in us since the round began on workgroup 0: evaluated, ticket drawn, (last workgroup,
+        // absolute) partials visible, message sent, challenge seen
+        std::vector<uint64_t> st(rounds * 8);
+        c.d2h(st.data(), c.tail_trace, st.size() * sizeof(uint64_t));
+        c.tail_trace = nullptr;
+        const double tick_us = 1e3 / (double)c.wall_clock_khz;
+        fprintf(stderr, "[sc_tail trace] T %zu degree %d n0 %zu\n", T, degree, n0);
+        for (size_t i = 0; i < rounds; i++) {
+          const uint64_t* s8 = &st[i * 8];
+          auto rel = [&](int k) { return s8[k] ? (double)(int64_t)(s8[k] - s8[0]) * tick_us : -1.0; };
+          fprintf(stderr, "  round %2zu: eval %.2f ticket %.2f last-sees %.2f sent %.2f challenge %.2f | next round starts %.2f\n", i,
+                  rel(1), rel(2), rel(3), rel(4), rel(5),
+                  i + 1 < rounds && st[(i + 1) * 8] ? (double)(int64_t)(st[(i + 1) * 8] - s8[0]) * tick_us : -1.0);
+        }
+      }
       if (!gave_up) {
         if (tail_debug)
           fprintf(stderr, "[sc_tail] T %zu terms %u degree %d n0 %zu rounds %zu: %.1f us (host side %.1f us)\n", T,
@@ -311,6 +332,7 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
       // traffic), then go on with launched rounds from round + absorbed
       if (tail_debug) fprintf(stderr, "[sc_tail] ended early after %zu of %zu rounds: resuming with launched rounds\n", absorbed, rounds);
       tail_ok = false;
+      k_sc_tail_resync(c);
       const size_t first_ch = res.challenges.size() - absorbed;
       for (size_t i = 0; i < absorbed; i++) {
         if (bind) {
