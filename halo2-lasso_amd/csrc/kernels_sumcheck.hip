@@ -88,11 +88,16 @@ __device__ __forceinline__ void finish_round(const ScFinish& f, const Fr* __rest
   if (threadIdx.x == 0) publish_flag(f.flag, f.seq);
 }
 
-#ifndef LH_SC_WAVES_ATTR
-#define LH_SC_WAVES_ATTR
+// Occupancy of the streaming round kernels: the degree-2 instantiations (GKR layers, Surge, the batch opening: the
+// ones that run at 2^24) are asked for 4 waves per SIMD instead of the 3 the register allocator settles on by itself
+// (measured 2^24 AND proof: -0.9 ms, tools/ab_waves.sh); higher degrees would spill heavily and keep the default.
+#ifndef LH_SC_WAVES_D2
+#define LH_SC_WAVES_D2 4
 #endif
+#define LH_SC_WAVES_ATTR(D) \
+  __attribute__((amdgpu_waves_per_eu((D) <= 2 && LH_SC_WAVES_D2 ? LH_SC_WAVES_D2 : 1, (D) <= 2 && LH_SC_WAVES_D2 ? LH_SC_WAVES_D2 : 8)))
 template <int D, bool BIND>
-__global__ __launch_bounds__(256) LH_SC_WAVES_ATTR void sc_round_kernel(ScArgs a, size_t size, uint32_t tp,
+__global__ __launch_bounds__(256) LH_SC_WAVES_ATTR(D) void sc_round_kernel(ScArgs a, size_t size, uint32_t tp,
                                                        Fr* __restrict__ partials, ScFinish fin) {
   __shared__ Fr lds[4];
   const ScRound& rd = a.rd;
@@ -673,7 +678,7 @@ void k_pair_sums(Ctx& c, const Fr* in, size_t n_out, Fr* out) {
 // (the number of terms is a template parameter: an accumulator array indexed by a run-time term count lives in scratch
 // memory - 400 B per lane of spills doubled the kernel's HBM writes)
 template <int M, bool BIND>
-__global__ __launch_bounds__(256) LH_SC_WAVES_ATTR void sc_round_open_kernel(ScOpenRound rd, size_t size, Fr* __restrict__ partials,
+__global__ __launch_bounds__(256) LH_SC_WAVES_ATTR(M <= 4 ? 2 : 3) void sc_round_open_kernel(ScOpenRound rd, size_t size, Fr* __restrict__ partials,
                                                             ScFinish fin) {
   __shared__ Fr lds[4];
   constexpr int NQ = 2 * M;
