@@ -213,7 +213,9 @@ void k_lasso_rw_leaves(Ctx&, const uint32_t* dim, const uint32_t* e, const uint3
 void k_lasso_if_leaves(Ctx&, int subtable, uint32_t chunk_bits, const uint32_t* final_cts, size_t m,
                        const Fr& gamma, const Fr& gamma2, const Fr& tau, Fr* init, Fr* fin);
 // Lasso witness: counters and subtable reads
-void k_lasso_counters(Ctx&, const uint32_t* dim, size_t n, size_t m, uint32_t* read_ts, uint32_t* final_cts);
+// keep_sorted / keep_index (optional, n entries each): the column sorted by value and the positions it came from
+void k_lasso_counters(Ctx&, const uint32_t* dim, size_t n, size_t m, uint32_t* read_ts, uint32_t* final_cts,
+                      uint32_t* keep_sorted = nullptr, uint32_t* keep_index = nullptr);
 void k_lasso_subtable_read(Ctx&, int subtable, uint32_t chunk_bits, const uint32_t* dim, size_t n, uint32_t* e);
 // a[k] = g(E_0[k],..): small-integer evaluation into Fr
 struct LassoG {
@@ -408,9 +410,15 @@ struct MsmJob {
   const uint32_t* d_table = nullptr;   // device: T[d], d < 2^table_in_bits; T[0] must be 0
   const uint32_t* d_order = nullptr;   // device: 0 .. 2^table_in_bits - 1 sorted by T (any order inside equal T)
   uint32_t table_in_bits = 0, table_out_bits = 0;
+  // Optional (u32 columns): the column's values in ascending order and the positions they came from (Lasso's access
+  // counters sort every dim column anyway).  A job that ends up with one window per (job, window) slab takes its sorted
+  // entry stream from these instead of emitting and sorting it again.
+  const uint32_t* sorted_scalars = nullptr;
+  const uint32_t* sorted_index = nullptr;
 };
 // Runs all jobs as one batched Pippenger; out[j] is the affine sum (identity = (0,0)).
 void msm_batch(Ctx&, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host);
+int msm_slab_log();  // jobs of >= 2^this points are sorted slab by slab (and can take MsmJob::sorted_*)
 // out[i] = scalars[i] * G (fixed-base), normalised to affine; all on device
 void k_fixed_base_mul_g(Ctx&, const Fr* scalars, size_t n, G1Affine* out);
 

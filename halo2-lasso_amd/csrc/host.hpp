@@ -258,6 +258,7 @@ LassoPcs lasso_zeromorph_pcs(Ctx&, const USrs&, size_t poly_size);
 // pieces of the argument shared by the standalone prover (lasso.cpp) and HyperPlonk's Lasso lookups (hyperplonk.cpp)
 struct LassoColumns {  // small-valued witness columns as u32 (arena memory of the caller's scope)
   std::vector<uint32_t*> rts, fcs, E;
+  std::vector<uint32_t*> dim_sorted, dim_index;  // (keep_sorted) every dim column sorted by value + source positions
 };
 struct LassoClaims {  // points and claimed evaluations that remain to be opened
   std::vector<HFr> r, r_z, r_N, r_M;
@@ -270,7 +271,7 @@ void lasso_check_table(const lh_lasso_table& tb);
 // a_out (optional): the output column a = g(E) as field elements; a_small_out (optional): the same as a 32-bit column
 // when g is linear with small coefficients and the value fits (then *a_out stays null)
 LassoColumns lasso_witness_columns(Ctx&, const lh_lasso_table&, size_t n, const uint32_t* const* d_dims, Fr** a_out,
-                                   uint32_t** a_small_out = nullptr);
+                                   uint32_t** a_small_out = nullptr, bool keep_sorted = false);
 // `a`: the output column as field elements, or null with `a_small` given
 LassoClaims lasso_argue(Ctx&, const lh_lasso_table&, size_t n, const LassoColumns& w, const uint32_t* const* d_dims,
                         const Fr* a, const Fr* const* E_fr, Transcript& tr,

@@ -730,14 +730,15 @@ __global__ void lasso_rank_kernel(const uint32_t* __restrict__ skey, const uint3
     if (i + 1 == n || skey[i + 1] != k) final_cts[k] = r + 1;
   }
 }
-void k_lasso_counters(Ctx& c, const uint32_t* dim, size_t n, size_t m, uint32_t* read_ts, uint32_t* final_cts) {
+void k_lasso_counters(Ctx& c, const uint32_t* dim, size_t n, size_t m, uint32_t* read_ts, uint32_t* final_cts,
+                      uint32_t* keep_sorted, uint32_t* keep_index) {
   ProfScope ps(c, "lasso_counters", 8.0 * n + 4.0 * m, 0.0, (double)n);
   ArenaScope scope(c.arena);
   unsigned bits = 1;
   while (((size_t)1 << bits) < m) bits++;
   uint32_t* idx = c.arena.alloc_n<uint32_t>(n);
-  uint32_t* skey = c.arena.alloc_n<uint32_t>(n);
-  uint32_t* sidx = c.arena.alloc_n<uint32_t>(n);
+  uint32_t* skey = keep_sorted ? keep_sorted : c.arena.alloc_n<uint32_t>(n);
+  uint32_t* sidx = keep_index ? keep_index : c.arena.alloc_n<uint32_t>(n);
   uint32_t* start = c.arena.alloc_n<uint32_t>(m);
   uint32_t* bad = c.arena.alloc_n<uint32_t>(1);
   LH_HIP(hipMemsetAsync(final_cts, 0, m * sizeof(uint32_t), c.stream));

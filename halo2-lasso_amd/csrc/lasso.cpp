@@ -115,7 +115,7 @@ void lasso_check_table(const lh_lasso_table& tb) {
 
 // witness: access counters, subtable reads and (optionally) the lookup outputs a = g(E); arena memory of the caller's scope
 LassoColumns lasso_witness_columns(Ctx& c, const lh_lasso_table& tb, size_t n, const uint32_t* const* d_dims, Fr** a_out,
-                                   uint32_t** a_small_out) {
+                                   uint32_t** a_small_out, bool keep_sorted) {
   const size_t cc = tb.num_chunks, l = tb.chunk_bits, alpha = tb.num_memories;
   const size_t N = (size_t)1 << n, M = (size_t)1 << l;
   LassoColumns w;
@@ -123,7 +123,13 @@ LassoColumns lasso_witness_columns(Ctx& c, const lh_lasso_table& tb, size_t n, c
   for (size_t j = 0; j < cc; j++) {
     w.rts[j] = c.arena.alloc_n<uint32_t>(N);
     w.fcs[j] = c.arena.alloc_n<uint32_t>(M);
-    k_lasso_counters(c, d_dims[j], N, M, w.rts[j], w.fcs[j]);
+    if (keep_sorted) {
+      w.dim_sorted.push_back(c.arena.alloc_n<uint32_t>(N));
+      w.dim_index.push_back(c.arena.alloc_n<uint32_t>(N));
+      k_lasso_counters(c, d_dims[j], N, M, w.rts[j], w.fcs[j], w.dim_sorted[j], w.dim_index[j]);
+    } else {
+      k_lasso_counters(c, d_dims[j], N, M, w.rts[j], w.fcs[j]);
+    }
   }
   LassoG g;
   memset(&g, 0, sizeof(g));
@@ -283,7 +289,8 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
   // ---- witness: counters, subtable reads, lookup outputs
   Fr* a = nullptr;
   uint32_t* a_small = nullptr;
-  LassoColumns w = lasso_witness_columns(c, tb, n, d_dims, &a, &a_small);
+  // (the sorted dim columns only pay off where the MSM sorts slab by slab: msm.hip LH_MSM_SLAB_LOG)
+  LassoColumns w = lasso_witness_columns(c, tb, n, d_dims, &a, &a_small, (int)n >= msm_slab_log());
   std::vector<uint32_t*>&rts = w.rts, &fcs = w.fcs, &E = w.E;
   lap(0);
   // ---- 0/1: domain separation + commitments (one batched MSM)
@@ -308,7 +315,10 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
     };
     if (!linear_g) add_job(0, a, false, N);
     std::vector<size_t> dim_job(cc);
-    for (size_t j = 0; j < cc; j++) dim_job[j] = jobs.size(), add_job(1 + j, d_dims[j], true, N);
+    for (size_t j = 0; j < cc; j++) {
+      dim_job[j] = jobs.size(), add_job(1 + j, d_dims[j], true, N);
+      if (!w.dim_sorted.empty()) jobs.back().sorted_scalars = w.dim_sorted[j], jobs.back().sorted_index = w.dim_index[j];
+    }
     for (size_t j = 0; j < cc; j++) add_job(1 + cc + j, rts[j], true, N);
     // E_i = T[dim_j]: commit(E_i) = sum_d T[d] * B_d over the BUCKET sums B_d of dim_j's commitment - no second pass
     // over the N points (msm.hip, MsmJob::derived_parent; falls back to an ordinary column when the window shape of

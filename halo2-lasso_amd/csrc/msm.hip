@@ -52,6 +52,7 @@ struct MsmJobDev {
   uint32_t seg_per_win; // segments per window
   uint32_t seg_size;    // buckets per segment
   uint32_t win_base;    // first window-sum slot of this job
+  uint32_t presorted;   // the sorted entries of its single slab come from MsmJob::sorted_scalars / sorted_index
 };
 constexpr uint32_t KEY_BLOCK_BITS = 10;  // every job's key range starts at a multiple of 2^KEY_BLOCK_BITS
 struct MsmPlanDev {
@@ -91,8 +92,20 @@ __global__ void msm_or_limbs_kernel(MsmPlanDev plan, uint32_t* __restrict__ or_o
   if (threadIdx.x < 8 && lds_or[threadIdx.x]) atomicOr(&or_out[blockIdx.y * 8 + threadIdx.x], lds_or[threadIdx.x]);
 }
 
+// a column that arrives sorted by value (single unsigned window: digit = value): the sorted entry stream directly
+__global__ void msm_presorted_kernel(uint32_t key_base, const uint32_t* __restrict__ sorted_scalars,
+                                     const uint32_t* __restrict__ sorted_index, size_t n, uint32_t* __restrict__ skey,
+                                     uint32_t* __restrict__ sidx) {
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t d = sorted_scalars[p];
+    skey[p] = key_base + (d ? d - 1u : 0u);
+    sidx[p] = d ? sorted_index[p] : SKIP_IDX;
+  }
+}
+
 __global__ void msm_emit_kernel(MsmPlanDev plan, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
   const MsmJobDev& jb = plan.job[blockIdx.y];
+  if (jb.presorted) return;
   const uint32_t c = jb.c, mask = (1u << c) - 1u;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < jb.n; i += (size_t)gridDim.x * blockDim.x) {
     uint32_t limb[8];
@@ -437,6 +450,11 @@ static const int MSM_C_OFF = env_int("LH_MSM_C_OFF", 4), MSM_C_MAX = env_int("LH
                  MSM_K2 = env_int("LH_MSM_K2", 4);  // continuation fan-in: a level costs ~K2 dependent additions, there are
                                                     // log_K2(chunks) levels; swept 2..16, 3-4 is best (2^16: 10.1 -> 9.3 ms)
 
+int msm_slab_log() {
+  static const int v = env_int("LH_MSM_SLAB_LOG", 23);
+  return v;
+}
+
 static uint32_t pick_window(size_t n, uint32_t bits) {
   uint32_t lg = 0;
   while (((size_t)1 << (lg + 1)) <= n) lg++;
@@ -526,7 +544,7 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
     uint32_t key = 0, seg = 0, win = 0;
     size_t max_entries = 0, max_n = 0;
     // a job of >= 2^LH_MSM_SLAB_LOG points sorts each of its (window) slabs by the digit bits alone
-    static const int slab_log = env_int("LH_MSM_SLAB_LOG", 23);
+    static const int slab_log = msm_slab_log();
     std::vector<char> slab(nj, 0);
     std::vector<uint32_t> sort_bits(nj, 0);
     for (size_t j = 0; j < nj; j++) {
@@ -548,6 +566,7 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
       jd.seg_per_win = (nb + jd.seg_size - 1) / jd.seg_size;
       jd.win_stride = jd.seg_per_win * jd.seg_size;
       slab[j] = jd.n >= (1u << slab_log) && jd.W > 0 && nb >= jd.seg_size && sort_bits[j] <= 16;
+      jd.presorted = slab[j] && jd.W == 1 && in.scalars_u32 && in.sorted_scalars && in.sorted_index && !derived[j];
       // a slab-sorted job's bucket ranges start at multiples of 2^sort_bits: the low bits of a key are the bucket index
       const uint32_t align_bits = slab[j] ? std::max<uint32_t>(KEY_BLOCK_BITS, sort_bits[j]) : KEY_BLOCK_BITS;
       key = (key + (1u << align_bits) - 1) & ~((1u << align_bits) - 1);
@@ -635,6 +654,13 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
         for (size_t j = 0; j < nj; j++) {
           if (!slab[j]) continue;
           const MsmJobDev& jd = plan.job[j];
+          if (jd.presorted) {
+            const MsmJob& in = jobs[base + j];
+            hipLaunchKernelGGL(msm_presorted_kernel, dim3((unsigned)std::min<size_t>((jd.n + 255) / 256, 4096)), dim3(256), 0,
+                               c.stream, jd.key_base, in.sorted_scalars, in.sorted_index, (size_t)jd.n, skey + jd.entry_base,
+                               sidx + jd.entry_base);
+            continue;
+          }
           for (uint32_t w = 0; w < jd.W; w++) {
             const size_t e = (size_t)jd.entry_base + (size_t)w * jd.n;
             sort_pairs_u32_with(c, ukey + e, skey + e, uidx + e, sidx + e, jd.n, sort_bits[j], temp, temp_bytes);
