@@ -339,12 +339,14 @@ def test_sum_check_transcript_failure_mid_tail(hl, ctx):
     assert (x, ev) == (ox, oev) and t.into_proof() == ot.into_proof()
 
 
-def test_sum_check_resumes_after_tail_timeout(hl, ctx, monkeypatch):
+@pytest.mark.parametrize("num_vars", [9, 13])
+def test_sum_check_resumes_after_tail_timeout(hl, ctx, monkeypatch, num_vars):
     """A host that stalls longer than the resident tail waits for a challenge (LH_SC_TAIL_TIMEOUT_MS) finds the
-    kernel gone; the prover resumes on the per-round path from the challenges it already has: same bytes."""
+    kernel gone; the prover resumes on the per-round path from the challenges it already has: same bytes.
+    2^9 entries: 8 workgroups; 2^13: 64 workgroups, hand-over to one after round 6 (the ticket counter is re-read
+    after every early exit - a stale one would break the next proof's in-launch reductions)."""
     import ctypes as C
     from halo2_lasso_amd import _ffi
-    num_vars = 9
     rng = random.Random(78)
     tables = [rand_fr(rng, 1 << num_vars) for _ in range(3)]
     y = rand_fr(rng, num_vars)
@@ -356,7 +358,8 @@ def test_sum_check_resumes_after_tail_timeout(hl, ctx, monkeypatch):
     ot = OT()
     ox, oev = o_sc.prove(o_sc.EvaluationsProver, num_vars, o_sc.VirtualPolynomial(expr, tables, [], [y]), claim, ot)
     monkeypatch.setenv("LH_SC_TAIL_TIMEOUT_MS", "20")
-    for stall_at in (1, 3, num_vars):  # first tail round, a middle one, the last challenge
+    # first tail round, middle ones (2^13: the last distributed round and the first one after the hand-over), the last
+    for stall_at in sorted({1, 3, 7, 8, num_vars} - ({7, 8} if num_vars < 13 else set())):
         inner = hl.Keccak256Transcript()
         vt = inner.p.contents
         calls = {"n": 0}

@@ -347,3 +347,20 @@ def test_context_used_from_another_thread(hl, ctx):
     th.start()
     th.join()
     assert out["proof"] == t0.into_proof()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"LH_SC_TAIL_G": "64"}, {"LH_SC_TAIL_G": "2", "LH_SC_TAIL_MAX_LEN": "16384"},
+                                 {"LH_SC_TAIL": "0"}, {"LH_MSM_SLAB_LOG": "14"}])
+def test_small_parity_suite_under_forced_shapes(env):
+    """The byte-parity tests of test_gpu_parity.py / test_gpu_golden.py again in a child process with the shape
+    knobs forced (they are read once per process): 64 workgroups with slices of two entries (hand-over right after
+    the first resident round), two workgroups with the longest resident tables, no resident tail at all, and every
+    MSM job >= 2^14 points on the slab path (per-slab sorts, the dim columns' entry streams taken from the access
+    counters' sorts)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "tests/test_gpu_golden.py", "-m", "gpu",
+                          "-x", "-q", "-k", "sum_check or grand_product or fractional or lasso or batch_open or golden"],
+                         cwd=root, env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
