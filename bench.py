@@ -474,6 +474,8 @@ def main():
         }
         if sharded:
             out["config"]["transport"] = transport
+        if os.environ.get("LH_BENCH_MODE_FALLBACK"):
+            out["mode_fallback"] = {"ran": "replicas", "sharded_error": os.environ["LH_BENCH_MODE_FALLBACK"]}
     if not args.no_profile:
         # a separately profiled prove (every instrumented launch synchronised); sharded: every rank takes part in the
         # collectives, rank 0 records
@@ -502,31 +504,41 @@ def main():
         # the N GPUs) and N independent replicas of the headline workload (weak scaling, no data-path collective)
         extra_steps = max(1, min(args.steps, 3))
         n3 = int(os.environ.get("LH_BENCH_CONFIG3_LOG_N", "26"))  # (smaller in the tests)
+        # (an extra that fails the same way on every rank - out of memory, an SRS too small - is reported in its object and
+        # must not take the headline with it)
         if sharded and not (n == n3 and args.table == "range") and not zm:
-            t26, _ = make_table(hl, "range")
-            sb26 = shard_geometry(t26, n3)
-            hl.detach_comm(ctx)
-            pp26 = setup(n3)
-            cols26 = load_columns(t26, n3, sb26)
-            hdist.attach_sharded(ctx, dist, sb26)
-            ms26, tr26 = timed(extra_steps, 1, nn=n3, bufs=cols26, p=pp26, tb=t26)
-            if rank == 0:
-                out["config3_2p26_range_sharded"] = {"workload": "2^%d range-check Lasso lookup, one proof sharded over %d GPUs"
-                                                                 % (n3, world),
-                                                     "ms_per_proof": round(ms26, 3), "steps": extra_steps,
-                                                     "lookups_per_s": round((1 << n3) / (ms26 / 1e3)),
-                                                     "proof_bytes": len(tr26.into_proof())}
-            del cols26, pp26
+            try:
+                t26, _ = make_table(hl, "range")
+                sb26 = shard_geometry(t26, n3)
+                hl.detach_comm(ctx)
+                pp26 = setup(n3)
+                cols26 = load_columns(t26, n3, sb26)
+                hdist.attach_sharded(ctx, dist, sb26)
+                ms26, tr26 = timed(extra_steps, 1, nn=n3, bufs=cols26, p=pp26, tb=t26)
+                if rank == 0:
+                    out["config3_2p26_range_sharded"] = {"workload": "2^%d range-check Lasso lookup, one proof sharded over %d GPUs"
+                                                                     % (n3, world),
+                                                         "ms_per_proof": round(ms26, 3), "steps": extra_steps,
+                                                         "lookups_per_s": round((1 << n3) / (ms26 / 1e3)),
+                                                         "proof_bytes": len(tr26.into_proof())}
+                del cols26, pp26
+            except Exception as e:
+                if rank == 0:
+                    out["config3_2p26_range_sharded"] = {"error": "%s: %s" % (type(e).__name__, e)}
             hl.detach_comm(ctx)
             hdist.attach_sharded(ctx, dist, shard_bit)
         if sharded:
-            own = [ctx.upload(c.tobytes()) for c in gen_dims(table, n, rank)]
-            msr, _ = timed(extra_steps, 1, bufs=own, single=True)
-            if rank == 0:
-                out["replicas"] = {"ms_per_step": round(msr, 3), "proofs_per_step": world, "scaling": "weak",
-                                   "ms_per_proof": round(msr / world, 3),
-                                   "lookups_per_s": round((1 << n) * world / (msr / 1e3))}
-            del own
+            try:
+                own = [ctx.upload(c.tobytes()) for c in gen_dims(table, n, rank)]
+                msr, _ = timed(extra_steps, 1, bufs=own, single=True)
+                if rank == 0:
+                    out["replicas"] = {"ms_per_step": round(msr, 3), "proofs_per_step": world, "scaling": "weak",
+                                       "ms_per_proof": round(msr / world, 3),
+                                       "lookups_per_s": round((1 << n) * world / (msr / 1e3))}
+                del own
+            except Exception as e:
+                if rank == 0:
+                    out["replicas"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         if not args.no_inflight and not sharded and world == 1:
             # throughput with TWO independent proofs in flight on the same GPU (two contexts = two streams, one host
@@ -574,4 +586,18 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except Exception as e:
+        # N > 1: a sharded run that fails the same way on every rank (an exception, not a hang) is re-run as N independent
+        # replicas, and the line says so; anything else is fatal
+        _args = parse()
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1 and _args.mode == "sharded" and _args.workload == "lasso" \
+                and "LH_BENCH_MODE_FALLBACK" not in os.environ:
+            import traceback
+            traceback.print_exc()
+            os.environ["LH_BENCH_MODE_FALLBACK"] = "%s: %s" % (type(e).__name__, e)
+            sys.argv += ["--mode", "replicas"]
+            main()
+        else:
+            raise
