@@ -24,7 +24,10 @@
  *    with the calling thread through pinned memory while the lh_* call is in progress.  The kernel waits a
  *    bounded time for each challenge (environment LH_SC_TAIL_TIMEOUT_MS, default 2000); when the calling
  *    thread stalls longer (debugger, SIGSTOP, slow transcript callback) the prover resumes with launched
- *    rounds - same proof bytes, no error.  LH_SC_TAIL=0 disables the resident rounds.
+ *    rounds - same proof bytes, no error.  LH_SC_TAIL=0 disables the resident rounds.  (The kernel is at most 64
+ *    workgroups that wait for the host only, never for one another or for another kernel; messages and challenges
+ *    cross as 16-byte chunks that carry their own sequence number, written with single 16-byte stores: the host
+ *    side is x86-64 with SSE2.)
  */
 #ifndef LASSO_HIP_H
 #define LASSO_HIP_H
