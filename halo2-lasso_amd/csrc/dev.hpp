@@ -209,6 +209,9 @@ void k_quotient_step(Ctx&, const Fr* rem, size_t half, const Fr& x, Fr* q, Fr* r
 // Lasso fingerprints: rs = dim*g2 + e*g + ts - tau ; ws = rs + 1
 void k_lasso_rw_leaves(Ctx&, const uint32_t* dim, const uint32_t* e, const uint32_t* ts, size_t n,
                        const Fr& gamma, const Fr& gamma2, const Fr& tau, Fr* rs, Fr* ws);
+// the same plus the level above the leaves of both trees (rs_up[i] = rs[i] * rs[i + n/2], n/2 entries each)
+void k_lasso_rw_leaves_up(Ctx&, const uint32_t* dim, const uint32_t* e, const uint32_t* ts, size_t n, const Fr& gamma,
+                          const Fr& gamma2, const Fr& tau, Fr* rs, Fr* ws, Fr* rs_up, Fr* ws_up);
 // init = m*g2 + T[m]*g - tau ; fin = init + final_cts[m]
 void k_lasso_if_leaves(Ctx&, int subtable, uint32_t chunk_bits, const uint32_t* final_cts, size_t m,
                        const Fr& gamma, const Fr& gamma2, const Fr& tau, Fr* init, Fr* fin);

@@ -183,8 +183,10 @@ struct GrandProductResult {
   std::vector<HFr> roots, claims;
   std::vector<std::vector<HFr>> points;
 };
+// d_level_up (optional): per tree the level above the leaves (2^(num_vars-1) nodes, node i = leaf[i] * leaf[i + half]) when
+// the caller made it together with the leaves, else null
 GrandProductResult prove_grand_product(Ctx&, size_t num_trees, const Fr* const* d_leaves, const size_t* num_vars,
-                                       Transcript& tr);
+                                       Transcript& tr, const Fr* const* d_level_up = nullptr);
 
 // ------------------------------------------------------------------ pcs::multilinear::kzg
 struct Srs {

@@ -221,7 +221,7 @@ LassoClaims lasso_argue(Ctx& c, const lh_lasso_table& tb, size_t n, const LassoC
   HFr gamma2 = gamma * gamma;
   {
     ArenaScope scope(c.arena);
-    std::vector<const Fr*> leaves(4 * alpha);
+    std::vector<const Fr*> leaves(4 * alpha), level_up(4 * alpha, nullptr);
     std::vector<size_t> depths(4 * alpha);
     for (size_t i = 0; i < alpha; i++) {
       size_t j = tb.memory_chunk[i];
@@ -229,7 +229,14 @@ LassoClaims lasso_argue(Ctx& c, const lh_lasso_table& tb, size_t n, const LassoC
       Fr* ws = c.arena.alloc_n<Fr>(N);
       Fr* in = c.arena.alloc_n<Fr>(M);
       Fr* fi = c.arena.alloc_n<Fr>(M);
-      k_lasso_rw_leaves(c, d_dims[j], w.E[i], w.rts[j], N, dev(gamma), dev(gamma2), dev(tau), rs, ws);
+      if (n >= 12) {  // the level above the leaves comes with them (no tree_up pass over the largest level)
+        Fr* rs_up = c.arena.alloc_n<Fr>(N / 2);
+        Fr* ws_up = c.arena.alloc_n<Fr>(N / 2);
+        k_lasso_rw_leaves_up(c, d_dims[j], w.E[i], w.rts[j], N, dev(gamma), dev(gamma2), dev(tau), rs, ws, rs_up, ws_up);
+        level_up[2 * i] = rs_up, level_up[2 * i + 1] = ws_up;
+      } else {
+        k_lasso_rw_leaves(c, d_dims[j], w.E[i], w.rts[j], N, dev(gamma), dev(gamma2), dev(tau), rs, ws);
+      }
       k_lasso_if_leaves(c, (int)tb.memory_subtable[i], (uint32_t)l, w.fcs[j], M, dev(gamma), dev(gamma2), dev(tau), in, fi);
       leaves[2 * i] = rs, leaves[2 * i + 1] = ws;
       leaves[2 * alpha + 2 * i] = in, leaves[2 * alpha + 2 * i + 1] = fi;
@@ -237,7 +244,7 @@ LassoClaims lasso_argue(Ctx& c, const lh_lasso_table& tb, size_t n, const LassoC
       depths[2 * alpha + 2 * i] = depths[2 * alpha + 2 * i + 1] = l;
     }
     if (lap) lap(3);
-    GrandProductResult gp = prove_grand_product(c, 4 * alpha, leaves.data(), depths.data(), tr);
+    GrandProductResult gp = prove_grand_product(c, 4 * alpha, leaves.data(), depths.data(), tr, level_up.data());
     cl.r_N = gp.points[0];
     cl.r_M = gp.points[2 * alpha];
   }

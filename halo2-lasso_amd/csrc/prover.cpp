@@ -769,7 +769,7 @@ FracSumCheckResult prove_fractional_sum_check(Ctx& c, size_t B, size_t num_vars,
 // ------------------------------------------------------------------ grand product (Lasso memory check)
 // Product-only layered circuit; schedule in oracle/pyref/gkr.py::prove_grand_product.
 GrandProductResult prove_grand_product(Ctx& c, size_t B, const Fr* const* d_leaves, const size_t* num_vars,
-                                       Transcript& tr) {
+                                       Transcript& tr, const Fr* const* d_level_up) {
   LH_REQUIRE(B != 0, LH_ERR_ARG, "grand product: no trees");
   size_t max_depth = 0;
   for (size_t b = 0; b < B; b++) {
@@ -790,6 +790,10 @@ GrandProductResult prove_grand_product(Ctx& c, size_t B, const Fr* const* d_leav
       level[b].resize(num_vars[b]);
       level[b][num_vars[b] - 1] = d_leaves[b];
       size_t h = num_vars[b] - 1;  // current lowest computed level
+      if (d_level_up && d_level_up[b] && h > SMALL) {
+        level[b][h - 1] = d_level_up[b];
+        h--;
+      }
       for (; h > SMALL; h--) {
         size_t half = (size_t)1 << h;
         Fr* up = c.arena.alloc_n<Fr>(half);
