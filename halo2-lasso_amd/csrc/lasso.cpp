@@ -200,16 +200,47 @@ LassoClaims lasso_argue(Ctx& c, const lh_lasso_table& tb, size_t n, const LassoC
     cl.v = evaluate_polys(c, &a, 1, n, cl.r.data())[0];
   }
   tr.write_field_element(cl.v);
-  lh_sop surge;
-  memset(&surge, 0, sizeof(surge));
-  surge.global_eq = 0;
-  surge.num_terms = tb.num_terms;
-  for (uint32_t m = 0; m < tb.num_terms; m++) {
-    surge.coeff[m] = tb.g_coeff[m];
-    surge.num_factors[m] = tb.g_num_factors[m];
-    for (int k = 0; k < LH_SC_MAX_FACTORS; k++) surge.factor[m][k] = tb.g_factor[m][k];
+  bool linear_g = true;
+  for (uint32_t m = 0; m < tb.num_terms; m++) linear_g = linear_g && tb.g_num_factors[m] == 1;
+  SumCheckResult sc;
+  if (linear_g) {
+    // g linear (range / AND / XOR): the summand eq * sum_m coeff_m E_m IS eq * a entry by entry, and binding is linear
+    // too, so the round messages of the sum-check over the alpha subtable-read columns are those of the sum-check over
+    // the single output column a.  One table instead of alpha in every round; the evaluations E_i(r_z) the transcript
+    // wants next are inner products of the 32-bit columns with eq(r_z).
+    ArenaScope scope(c.arena);
+    const Fr* a_tab = a;
+    if (!a_tab) {
+      Fr* view = c.arena.alloc_n<Fr>(N);
+      k_fr_from_u32(c, a_small, N, view);
+      a_tab = view;
+    }
+    lh_sop one_term;
+    memset(&one_term, 0, sizeof(one_term));
+    one_term.global_eq = 0;
+    one_term.num_terms = 1;
+    const HFr one = HFr::one();
+    memcpy(&one_term.coeff[0], &one, 32);
+    one_term.num_factors[0] = 1;
+    one_term.factor[0][0] = 0;
+    sc = sum_check_prove(c, LH_SC_EVALUATIONS, n, one_term, &a_tab, 1, cl.r.data(), 1, cl.v, tr, true);
+    Fr* eq = c.arena.alloc_n<Fr>(N);
+    k_eq_xy(c, (const Fr*)sc.challenges.data(), n, eq);
+    std::vector<const uint32_t*> cols(w.E.begin(), w.E.end());
+    sc.evals.assign(alpha, HFr::zero());
+    k_inner_products_small(c, cols.data(), alpha, eq, N, (Fr*)sc.evals.data());
+  } else {
+    lh_sop surge;
+    memset(&surge, 0, sizeof(surge));
+    surge.global_eq = 0;
+    surge.num_terms = tb.num_terms;
+    for (uint32_t m = 0; m < tb.num_terms; m++) {
+      surge.coeff[m] = tb.g_coeff[m];
+      surge.num_factors[m] = tb.g_num_factors[m];
+      for (int k = 0; k < LH_SC_MAX_FACTORS; k++) surge.factor[m][k] = tb.g_factor[m][k];
+    }
+    sc = sum_check_prove(c, LH_SC_EVALUATIONS, n, surge, E_fr, alpha, cl.r.data(), 1, cl.v, tr, true);
   }
-  SumCheckResult sc = sum_check_prove(c, LH_SC_EVALUATIONS, n, surge, E_fr, alpha, cl.r.data(), 1, cl.v, tr, true);
   cl.r_z = sc.challenges;
   cl.e_rz = sc.evals;
   tr.write_field_elements(sc.evals);
@@ -362,8 +393,9 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
   }
   lap(1);
 
-  // ---- field-element views only where a sum-check needs tables (E for Surge); dim / read_ts / final_cts stay u32
-  // all the way: fingerprints, evaluations and the batch opening's merge read the 4-byte columns
+  // ---- field-element views only where a sum-check needs tables (E for Surge when g is not linear); dim / read_ts /
+  // final_cts (and E under a linear g) stay u32 all the way: fingerprints, evaluations and the batch opening's merge
+  // read the 4-byte columns
   const size_t num_n = 1 + 2 * cc + alpha;
   std::vector<const Fr*> polys_n(num_n, nullptr), polys_l(cc, nullptr);
   std::vector<SmallPoly> small(num_n + cc);
@@ -388,8 +420,10 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
     small[1 + cc + j] = SmallPoly{rts[j], N};
     small[num_n + j] = SmallPoly{fcs[j], M};
   }
+  bool linear_surge = true;  // (lasso_argue: the Surge sum-check then runs over the output column alone)
+  for (uint32_t m = 0; m < tb.num_terms; m++) linear_surge = linear_surge && tb.g_num_factors[m] == 1;
   for (size_t i = 0; i < alpha; i++) {
-    polys_n[1 + 2 * cc + i] = fr_view(E[i], N);
+    if (!linear_surge) polys_n[1 + 2 * cc + i] = fr_view(E[i], N);
     small[1 + 2 * cc + i] = SmallPoly{E[i], N};
   }
   const Fr* const* E_fr = polys_n.data() + 1 + 2 * cc;
