@@ -298,6 +298,25 @@ struct ScOpenRound {
 // out_host[2 m], out_host[2 m + 1] = q_m(0), q_m(1)
 void k_sc_round_open(Ctx&, const ScOpenRound& rd, bool bind, size_t size, Fr* out_host);
 
+// Streaming round of a grand-product layer whose trees come in pairs (A_i, A_i + 1) - Lasso's read set and write set at
+// the leaf level, write = read + 1 entry by entry, and binding keeps the "+ 1".  With cs_i = c_A + c_B, k_i = c_B / cs_i:
+//   c_A l r + c_B (l + 1)(r + 1) = cs_i (l + k_i)(r + k_i) + const_i
+// so only the A tables are read and bound and a pair of trees costs one product per point.  Factored eq (eq_level as in
+// ScRound); out_host[x - 1] = sum_b eq_level[b] * sum_i cs_i (l_i + k_i)(r_i + k_i) at X = x, x = 1, 2 (the caller adds
+// the constants).
+constexpr int SC_RW_MAX_PAIRS = 8;
+struct ScRwRound {
+  const Fr* l[SC_RW_MAX_PAIRS];
+  const Fr* r[SC_RW_MAX_PAIRS];
+  Fr* lo[SC_RW_MAX_PAIRS];
+  Fr* ro[SC_RW_MAX_PAIRS];
+  Fr cs[SC_RW_MAX_PAIRS], k[SC_RW_MAX_PAIRS];
+  const Fr* eq_level;
+  Fr rchal;
+  uint32_t num_pairs;
+};
+void k_sc_round_rw(Ctx&, const ScRwRound& rd, bool bind, size_t size, Fr* out_host);
+
 // Resident tail: once the live tables of a sum-check fit the LDS of a few CUs, ONE launch runs all remaining rounds.
 // G workgroups each keep a contiguous slice of every table in LDS (binding never crosses a slice); per round every
 // workgroup leaves its D partial sums in device memory and draws a ticket, the one that draws the last ticket adds

@@ -118,9 +118,16 @@ struct SumCheckResult {
 };
 // `sum_is_exact`: the caller computed `sum` from these very tables (the provers' internal sum-checks: Surge, the GKR
 // layers): eq factoring then trusts it from round 0 on; a claim from outside (the C-ABI) is checked first (EqFactoring)
+// `rw` (optional): the expression is a grand-product layer over (A_i, A_i + 1) tree pairs written over the A tables
+// alone (dev.hpp ScRwRound; polys = l_0, r_0, l_1, r_1, ...): its streaming rounds run the dedicated kernel
+struct ScRwPairs {
+  uint32_t num_pairs;
+  HFr cs[SC_RW_MAX_PAIRS], k[SC_RW_MAX_PAIRS];
+  HFr const_total;  // sum of the constants the factorisation leaves behind: added to q at every point
+};
 SumCheckResult sum_check_prove(Ctx&, int prover_kind, size_t num_vars, const lh_sop& expr, const Fr* const* d_polys,
                                size_t num_polys, const HFr* ys, size_t num_ys, const HFr& sum, Transcript& tr,
-                               bool sum_is_exact = false);
+                               bool sum_is_exact = false, const ScRwPairs* rw = nullptr);
 
 // the round loop shared by every sum-check front end (prover.cpp)
 typedef std::function<void(const Fr* const*, Fr* const*, const Fr&, bool, size_t, Fr*)> RoundFn;
@@ -185,8 +192,12 @@ struct GrandProductResult {
 };
 // d_level_up (optional): per tree the level above the leaves (2^(num_vars-1) nodes, node i = leaf[i] * leaf[i + half]) when
 // the caller made it together with the leaves, else null
+// plus_one (optional): plus_one[b] != 0 says that tree b's leaves are tree (b - 1)'s leaves + 1, entry by entry (same
+// depth; Lasso's write set over its read set).  The leaf layer of such a pair then runs over tree (b - 1)'s tables
+// alone (dev.hpp ScRwRound) and d_leaves[b] is never read (it may be null; d_level_up[b] must be given).
 GrandProductResult prove_grand_product(Ctx&, size_t num_trees, const Fr* const* d_leaves, const size_t* num_vars,
-                                       Transcript& tr, const Fr* const* d_level_up = nullptr);
+                                       Transcript& tr, const Fr* const* d_level_up = nullptr,
+                                       const uint8_t* plus_one = nullptr);
 
 // ------------------------------------------------------------------ pcs::multilinear::kzg
 struct Srs {

@@ -869,15 +869,17 @@ __global__ void lasso_rw_leaves_up_kernel(const uint32_t* __restrict__ dim, cons
       rs[j] = h[k];
     }
     const Fr w0 = add(h[0], one), w1 = add(h[1], one);
-    ws[i] = w0;
-    ws[i + half] = w1;
+    if (ws) {  // (null: the caller's leaf layer runs over the read set alone)
+      ws[i] = w0;
+      ws[i + half] = w1;
+    }
     rs_up[i] = mul(h[0], h[1]);
     ws_up[i] = mul(w0, w1);
   }
 }
 void k_lasso_rw_leaves_up(Ctx& c, const uint32_t* dim, const uint32_t* e, const uint32_t* ts, size_t n, const Fr& gamma,
                           const Fr& gamma2, const Fr& tau, Fr* rs, Fr* ws, Fr* rs_up, Fr* ws_up) {
-  ProfScope ps(c, "lasso_rw_leaves", (12.0 + 64.0 + 32.0) * n, 6.0 * n, (double)n);
+  ProfScope ps(c, "lasso_rw_leaves", (12.0 + (ws ? 64.0 : 32.0) + 32.0) * n, 6.0 * n, (double)n);
   if (n >= 2)
     hipLaunchKernelGGL(lasso_rw_leaves_up_kernel, grid_for(n / 2), 256, 0, c.stream, dim, e, ts, n / 2, gamma, gamma2, tau,
                        rs, ws, rs_up, ws_up);

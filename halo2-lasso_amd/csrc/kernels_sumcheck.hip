@@ -116,6 +116,10 @@ __global__ __launch_bounds__(256) LH_SC_WAVES_ATTR(D) void sc_round_kernel(ScArg
     for (uint32_t m = m_lo; m < m_hi; m++) {
       Fr pm[D];
       const int nf = rd.nfac[m];
+      if (nf == 0) {  // a constant (times the eq factor below)
+#pragma unroll
+        for (int x = 0; x < D; x++) pm[x] = rd.coeff_is_one[m] ? Fr::one() : rd.coeff[m];
+      }
       for (int k = 0; k < nf; k++) {
         const int t = rd.fac[m][k];
         Fr v0, v1;
@@ -739,6 +743,76 @@ void k_sc_round_open(Ctx& c, const ScOpenRound& rd, bool bind, size_t size, Fr* 
   c.wait_flag(seq);
 }
 
+// ------------------------------------------------------------------ grand-product layer over (A, A + 1) tree pairs
+template <int P, bool BIND>
+__global__ __launch_bounds__(256) LH_SC_WAVES_ATTR(2) void sc_round_rw_kernel(ScRwRound rd, size_t size,
+                                                                              Fr* __restrict__ partials, ScFinish fin) {
+  __shared__ Fr lds[4];
+  Fr acc0 = Fr::zero(), acc1 = Fr::zero();
+  for (size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x; b < size; b += (size_t)gridDim.x * blockDim.x) {
+    Fr s0 = Fr::zero(), s1 = Fr::zero();
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+      Fr v0, v1, w0, w1;
+      load_pair<BIND>(rd.l[i], rd.lo[i], b, rd.rchal, true, v0, v1);
+      load_pair<BIND>(rd.r[i], rd.ro[i], b, rd.rchal, true, w0, w1);
+      const Fr sl = sub(v1, v0), sr = sub(w1, w0);
+      const Fr a1 = add(v1, rd.k[i]), b1 = add(w1, rd.k[i]);   // X = 1
+      const Fr a2 = add(a1, sl), b2 = add(b1, sr);             // X = 2
+      s0 = add(s0, mul(mul(a1, b1), rd.cs[i]));
+      s1 = add(s1, mul(mul(a2, b2), rd.cs[i]));
+    }
+    const Fr e = rd.eq_level[b];
+    acc0 = add(acc0, mul(s0, e));
+    acc1 = add(acc1, mul(s1, e));
+  }
+  Fr v = block_reduce_sum(acc0, lds);
+  if (threadIdx.x == 0) partials[(size_t)blockIdx.x * 2] = v;
+  v = block_reduce_sum(acc1, lds);
+  if (threadIdx.x == 0) partials[(size_t)blockIdx.x * 2 + 1] = v;
+  if (gridDim.x == 1) {
+    if (threadIdx.x == 0) publish_flag(fin.flag, fin.seq);
+    return;
+  }
+  finish_round<2>(fin, partials, lds);
+}
+
+template <int P>
+static void launch_rw(Ctx& c, const ScRwRound& rd, bool bind, size_t size, unsigned g, Fr* partials, const ScFinish& fin) {
+  if (bind)
+    hipLaunchKernelGGL((sc_round_rw_kernel<P, true>), dim3(g), dim3(256), 0, c.stream, rd, size, partials, fin);
+  else
+    hipLaunchKernelGGL((sc_round_rw_kernel<P, false>), dim3(g), dim3(256), 0, c.stream, rd, size, partials, fin);
+}
+
+void k_sc_round_rw(Ctx& c, const ScRwRound& rd, bool bind, size_t size, Fr* out_host) {
+  LH_REQUIRE(rd.num_pairs >= 1 && rd.num_pairs <= (uint32_t)SC_RW_MAX_PAIRS && size >= 1 && rd.eq_level, LH_ERR_ARG,
+             "sc_round_rw: bad shape");
+  const uint32_t seq = c.next_seq();
+  ArenaScope scope(c.arena);
+  size_t g = std::min<size_t>((size + 255) / 256, (size_t)c.num_cus * 4);
+  Fr* partials = g == 1 ? out_host : c.arena.alloc_n<Fr>(g * 2);
+  const ScFinish fin = c.finish_for((uint32_t)g, out_host, seq);
+  {
+    // algorithmic bytes: 96 B per bound entry of the 2 P tables read (192 B per pair and table) + the eq-level entry;
+    // products per pair: 4 per tree pair (+ 4 binds), 2 for the eq factor
+    const double P = (double)rd.num_pairs;
+    ProfScope ps(c, bind ? "sc_round_rw<bind>" : "sc_round_rw<first>", ((bind ? 192.0 : 64.0) * 2.0 * P + 32.0) * (double)size,
+                 ((bind ? 8.0 : 4.0) * P + 2.0) * (double)size, (double)size);
+    switch (rd.num_pairs) {
+      case 1: launch_rw<1>(c, rd, bind, size, (unsigned)g, partials, fin); break;
+      case 2: launch_rw<2>(c, rd, bind, size, (unsigned)g, partials, fin); break;
+      case 3: launch_rw<3>(c, rd, bind, size, (unsigned)g, partials, fin); break;
+      case 4: launch_rw<4>(c, rd, bind, size, (unsigned)g, partials, fin); break;
+      case 5: launch_rw<5>(c, rd, bind, size, (unsigned)g, partials, fin); break;
+      case 6: launch_rw<6>(c, rd, bind, size, (unsigned)g, partials, fin); break;
+      case 7: launch_rw<7>(c, rd, bind, size, (unsigned)g, partials, fin); break;
+      default: launch_rw<8>(c, rd, bind, size, (unsigned)g, partials, fin); break;
+    }
+  }
+  c.wait_flag(seq);
+}
+
 void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, Fr* evals_host) {
   LH_REQUIRE(degree >= 1 && degree <= 6, LH_ERR_ARG, "sum-check degree must be in 1..6");
   LH_REQUIRE(size >= 1, LH_ERR_ARG, "sum-check round over an empty table");
@@ -757,7 +831,7 @@ void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, F
   for (int t = 0; t < SC_MAX_TABLES; t++) tabs += seen[t] ? 1 : 0;
   double nfac = 0, ncoef = 0;
   for (uint32_t m = 0; m < rd.num_terms; m++) nfac += rd.nfac[m], ncoef += rd.coeff_is_one[m] ? 0 : 2;
-  const double muls_pair = (nfac - rd.num_terms) * degree + ncoef + (rd.global_eq >= 0 || rd.eq_level ? degree : 0) +
+  const double muls_pair = std::max(0.0, nfac - rd.num_terms) * degree + ncoef + (rd.global_eq >= 0 || rd.eq_level ? degree : 0) +
                            (bind ? 2.0 * (nfac + (rd.global_eq >= 0 ? 1 : 0)) : 0.0);
   // algorithmic bytes: fused round = bind bytes only, 96 B per bound entry = 192 B per pair
   // and table; the unfused first round reads 64 B per pair and table.

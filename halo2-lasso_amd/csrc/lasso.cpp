@@ -254,13 +254,17 @@ LassoClaims lasso_argue(Ctx& c, const lh_lasso_table& tb, size_t n, const LassoC
     ArenaScope scope(c.arena);
     std::vector<const Fr*> leaves(4 * alpha), level_up(4 * alpha, nullptr);
     std::vector<size_t> depths(4 * alpha);
+    std::vector<uint8_t> plus_one(4 * alpha, 0);
+    // write leaf = read leaf + 1: when the n-variable trees are alone at their leaf layer (n > l) that layer runs over the
+    // read-set tables only (prove_grand_product: plus_one) and the write-set leaves are never stored
+    const bool fused_up = n >= 12, ws_implicit = fused_up && n > l;
     for (size_t i = 0; i < alpha; i++) {
       size_t j = tb.memory_chunk[i];
       Fr* rs = c.arena.alloc_n<Fr>(N);
-      Fr* ws = c.arena.alloc_n<Fr>(N);
+      Fr* ws = ws_implicit ? nullptr : c.arena.alloc_n<Fr>(N);
       Fr* in = c.arena.alloc_n<Fr>(M);
       Fr* fi = c.arena.alloc_n<Fr>(M);
-      if (n >= 12) {  // the level above the leaves comes with them (no tree_up pass over the largest level)
+      if (fused_up) {  // the level above the leaves comes with them (no tree_up pass over the largest level)
         Fr* rs_up = c.arena.alloc_n<Fr>(N / 2);
         Fr* ws_up = c.arena.alloc_n<Fr>(N / 2);
         k_lasso_rw_leaves_up(c, d_dims[j], w.E[i], w.rts[j], N, dev(gamma), dev(gamma2), dev(tau), rs, ws, rs_up, ws_up);
@@ -270,12 +274,13 @@ LassoClaims lasso_argue(Ctx& c, const lh_lasso_table& tb, size_t n, const LassoC
       }
       k_lasso_if_leaves(c, (int)tb.memory_subtable[i], (uint32_t)l, w.fcs[j], M, dev(gamma), dev(gamma2), dev(tau), in, fi);
       leaves[2 * i] = rs, leaves[2 * i + 1] = ws;
+      plus_one[2 * i + 1] = 1;
       leaves[2 * alpha + 2 * i] = in, leaves[2 * alpha + 2 * i + 1] = fi;
       depths[2 * i] = depths[2 * i + 1] = n;
       depths[2 * alpha + 2 * i] = depths[2 * alpha + 2 * i + 1] = l;
     }
     if (lap) lap(3);
-    GrandProductResult gp = prove_grand_product(c, 4 * alpha, leaves.data(), depths.data(), tr, level_up.data());
+    GrandProductResult gp = prove_grand_product(c, 4 * alpha, leaves.data(), depths.data(), tr, level_up.data(), plus_one.data());
     cl.r_N = gp.points[0];
     cl.r_M = gp.points[2 * alpha];
   }

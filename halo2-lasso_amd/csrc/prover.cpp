@@ -479,7 +479,8 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
 // replicated on every rank.  The transcript sees exactly the single-GPU messages.
 static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_vars, const lh_sop& expr,
                                            const Fr* const* d_polys, size_t num_polys, const HFr* ys, size_t num_ys,
-                                           const HFr& sum, Transcript& tr, bool sharded, bool sum_is_exact = false) {
+                                           const HFr& sum, Transcript& tr, bool sharded, bool sum_is_exact = false,
+                                           const ScRwPairs* rw = nullptr) {
   LH_REQUIRE(num_vars > 0, LH_ERR_ARG, "sum-check needs num_vars > 0");  // classic.rs:42 assert
   const size_t T = num_polys + num_ys;
   LH_REQUIRE(T <= (size_t)SC_MAX_TABLES, LH_ERR_ARG, "sum-check: too many tables for one round kernel");
@@ -500,7 +501,9 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
   if (rd.global_eq >= 0) used[rd.global_eq] = 1;
   for (uint32_t m = 0; m < expr.num_terms; m++) {
     int nf = expr.num_factors[m];
-    LH_REQUIRE(nf >= 1 && nf <= LH_SC_MAX_FACTORS, LH_ERR_ARG, "sum-check: bad factor count");
+    // (no factor at all: a constant times the global eq - the prover's own layer expressions use it)
+    LH_REQUIRE((nf >= 1 || (nf == 0 && expr.global_eq >= 0)) && nf <= LH_SC_MAX_FACTORS, LH_ERR_ARG,
+               "sum-check: bad factor count");
     degree = std::max(degree, nf + (expr.global_eq >= 0 ? 1 : 0));
     memcpy(&rd.coeff[m], &expr.coeff[m], 32);
     rd.coeff_is_one[m] = (memcmp(&expr.coeff[m], &one, 32) == 0);
@@ -610,7 +613,20 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
       if (round > 0)  // E_round from E_{round-1}: the two entries that differ in variable `round` add up
         for (EqFactoring::One& one : ef.eqs)
           k_pair_sums(c, one.level[round - 1], size, (Fr*)one.level[round]);
-      if (!ef.per_term) {
+      if (!ef.per_term && rw && points == 2) {
+        ScRwRound g;
+        memset(&g, 0, sizeof(g));
+        g.num_pairs = rw->num_pairs;
+        for (uint32_t i = 0; i < rw->num_pairs; i++) {
+          g.l[i] = in[2 * i], g.r[i] = in[2 * i + 1];
+          g.lo[i] = out[2 * i], g.ro[i] = out[2 * i + 1];
+          g.cs[i] = dev(rw->cs[i]), g.k[i] = dev(rw->k[i]);
+        }
+        g.eq_level = ef.eqs[0].level[round];
+        g.rchal = r;
+        k_sc_round_rw(c, g, bind, size, out_host);
+        for (int x = 0; x < 2; x++) out_host[x] = dev(hst(out_host[x]) + rw->const_total);  // (the suffix eq sums to one)
+      } else if (!ef.per_term) {
         ScRound g = rd;
         for (size_t i = 0; i < T; i++) g.in[i] = in[i], g.out[i] = out[i];
         g.r = r;
@@ -647,8 +663,13 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
 
 SumCheckResult sum_check_prove(Ctx& c, int prover_kind, size_t num_vars, const lh_sop& expr,
                                const Fr* const* d_polys, size_t num_polys, const HFr* ys, size_t num_ys,
-                               const HFr& sum, Transcript& tr, bool sum_is_exact) {
-  return sum_check_prove_impl(c, prover_kind, num_vars, expr, d_polys, num_polys, ys, num_ys, sum, tr, false, sum_is_exact);
+                               const HFr& sum, Transcript& tr, bool sum_is_exact, const ScRwPairs* rw) {
+  if (rw)
+    LH_REQUIRE(rw->num_pairs >= 1 && rw->num_pairs <= (uint32_t)SC_RW_MAX_PAIRS && num_polys == 2 * (size_t)rw->num_pairs &&
+                   expr.global_eq >= 0 && sum_is_exact,
+               LH_ERR_ARG, "sum-check: tree-pair rounds over the wrong shape");
+  return sum_check_prove_impl(c, prover_kind, num_vars, expr, d_polys, num_polys, ys, num_ys, sum, tr, false, sum_is_exact,
+                              rw);
 }
 
 SumCheckResult sum_check_prove_sharded(Ctx& c, int prover_kind, size_t num_vars, const lh_sop& expr,
@@ -769,7 +790,7 @@ FracSumCheckResult prove_fractional_sum_check(Ctx& c, size_t B, size_t num_vars,
 // ------------------------------------------------------------------ grand product (Lasso memory check)
 // Product-only layered circuit; schedule in oracle/pyref/gkr.py::prove_grand_product.
 GrandProductResult prove_grand_product(Ctx& c, size_t B, const Fr* const* d_leaves, const size_t* num_vars,
-                                       Transcript& tr, const Fr* const* d_level_up) {
+                                       Transcript& tr, const Fr* const* d_level_up, const uint8_t* plus_one) {
   LH_REQUIRE(B != 0, LH_ERR_ARG, "grand product: no trees");
   size_t max_depth = 0;
   for (size_t b = 0; b < B; b++) {
@@ -843,8 +864,55 @@ GrandProductResult prove_grand_product(Ctx& c, size_t B, const Fr* const* d_leav
       memset(&expr, 0, sizeof(expr));
       expr.global_eq = 0;
       std::vector<const Fr*> polys;
+      // leaf layer of (A, A + 1) tree pairs (`plus_one`): every active tree is at its leaf level and they pair up
+      bool pairs = plus_one != nullptr && active.size() % 2 == 0 && active.size() / 2 <= (size_t)SC_RW_MAX_PAIRS;
+      for (size_t k = 0; k < active.size() && pairs; k++) {
+        const size_t b = active[k];
+        pairs = num_vars[b] == h + 1 && (k % 2 == 0 ? !plus_one[b] : (plus_one[b] && active[k - 1] + 1 == b));
+      }
+      if (pairs) {
+        // c_A l r + c_B (l + 1)(r + 1) = cs (l + k)(r + k) + c_B (1 - k),  cs = c_A + c_B, k = c_B / cs: only the A tables
+        // are read and bound (dev.hpp ScRwRound); the same expression written out as products over the A tables, with its
+        // constant term, serves the small rounds (LDS kernel, resident tail) and the degenerate cs = 0
+        const size_t P = active.size() / 2;
+        ScRwPairs rw;
+        rw.num_pairs = (uint32_t)P;
+        rw.const_total = HFr::zero();
+        HFr cw_sum = HFr::zero();
+        bool degenerate = false;
+        uint32_t t = 0;
+        for (size_t i = 0; i < P; i++) {
+          const size_t a = active[2 * i], bb = active[2 * i + 1];
+          const HFr c_a = power, c_b = power * lam;
+          claim += claims[a] * c_a + claims[bb] * c_b;
+          power = c_b * lam;
+          const HFr cs = c_a + c_b;
+          degenerate = degenerate || cs.is_zero();
+          rw.cs[i] = cs;
+          rw.k[i] = cs.is_zero() ? HFr::zero() : c_b * cs.inv();
+          rw.const_total += c_b * (HFr::one() - rw.k[i]);
+          cw_sum += c_b;
+          const uint8_t li = (uint8_t)(2 * i), ri = (uint8_t)(2 * i + 1);
+          memcpy(&expr.coeff[t], &cs, 32), expr.num_factors[t] = 2, expr.factor[t][0] = li, expr.factor[t][1] = ri, t++;
+          memcpy(&expr.coeff[t], &c_b, 32), expr.num_factors[t] = 1, expr.factor[t][0] = li, t++;
+          memcpy(&expr.coeff[t], &c_b, 32), expr.num_factors[t] = 1, expr.factor[t][0] = ri, t++;
+          polys.push_back(level[a][h]);
+          polys.push_back(level[a][h] + half);
+        }
+        memcpy(&expr.coeff[t], &cw_sum, 32), expr.num_factors[t] = 0, t++;
+        expr.num_terms = t;
+        SumCheckResult sc = sum_check_prove(c, LH_SC_EVALUATIONS, h, expr, polys.data(), polys.size(), y.data(), 1, claim, tr,
+                                            true, degenerate ? nullptr : &rw);
+        x = sc.challenges;
+        for (size_t i = 0; i < P; i++) {  // evaluations of the B tables: those of the A tables + 1
+          const HFr l = sc.evals[2 * i], r = sc.evals[2 * i + 1];
+          evals.push_back(l), evals.push_back(r);
+          evals.push_back(l + HFr::one()), evals.push_back(r + HFr::one());
+        }
+      } else {
       for (size_t k = 0; k < active.size(); k++) {
         size_t b = active[k];
+        LH_REQUIRE(level[b][h] != nullptr, LH_ERR_ARG, "grand product: a tree given without leaves is not at a paired leaf layer");
         claim += claims[b] * power;
         memcpy(&expr.coeff[k], &power, 32);
         expr.num_factors[k] = 2;
@@ -859,6 +927,7 @@ GrandProductResult prove_grand_product(Ctx& c, size_t B, const Fr* const* d_leav
           sum_check_prove(c, LH_SC_EVALUATIONS, h, expr, polys.data(), polys.size(), y.data(), 1, claim, tr, true);
       x = sc.challenges;
       evals = sc.evals;
+      }
     }
     tr.write_field_elements(evals);
     HFr mu = tr.squeeze_challenge();
