@@ -421,7 +421,25 @@ void lasso_prove_sharded(Ctx& c, const Srs& srs, const lh_lasso_table& tb, size_
     surge.num_factors[m] = tb.g_num_factors[m];
     for (int k = 0; k < LH_SC_MAX_FACTORS; k++) surge.factor[m][k] = tb.g_factor[m][k];
   }
-  SumCheckResult sc = sum_check_prove_sharded(c, LH_SC_EVALUATIONS, n, surge, E_fr, alpha, r.data(), 1, v, tr);
+  bool linear_g = true;
+  for (uint32_t m = 0; m < tb.num_terms; m++) linear_g = linear_g && tb.g_num_factors[m] == 1;
+  SumCheckResult sc;
+  if (linear_g) {
+    // g linear: eq * g(E) is eq * a entry by entry and binding is linear (lasso.cpp lasso_argue): the rounds run over the
+    // output column's shard alone; E_i(r_z) by sharded inner products
+    lh_sop one_term;
+    memset(&one_term, 0, sizeof(one_term));
+    one_term.global_eq = 0;
+    one_term.num_terms = 1;
+    const HFr one = HFr::one();
+    memcpy(&one_term.coeff[0], &one, 32);
+    one_term.num_factors[0] = 1;
+    one_term.factor[0][0] = 0;
+    sc = sum_check_prove_sharded(c, LH_SC_EVALUATIONS, n, one_term, &polys_n[0], 1, r.data(), 1, v, tr);
+    sc.evals = evaluate_polys_sharded(c, E_fr, alpha, n, sc.challenges.data());
+  } else {
+    sc = sum_check_prove_sharded(c, LH_SC_EVALUATIONS, n, surge, E_fr, alpha, r.data(), 1, v, tr);
+  }
   const std::vector<HFr>& r_z = sc.challenges;
   tr.write_field_elements(sc.evals);
   lap(2);
