@@ -217,6 +217,10 @@ void k_lasso_if_leaves(Ctx&, int subtable, uint32_t chunk_bits, const uint32_t* 
                        const Fr& gamma, const Fr& gamma2, const Fr& tau, Fr* init, Fr* fin);
 // Lasso witness: counters and subtable reads
 // keep_sorted / keep_index (optional, n entries each): the column sorted by value and the positions it came from
+// OR of all entries of every column (its bit length bounds the values); synchronises
+void k_or_u32(Ctx&, const uint32_t* const* cols, size_t count, size_t n, uint32_t* out_host);
+// out[i] = a[i] | b[i] << shift
+void k_pack_u32(Ctx&, const uint32_t* a, const uint32_t* b, uint32_t shift, size_t n, uint32_t* out);
 void k_lasso_counters(Ctx&, const uint32_t* dim, size_t n, size_t m, uint32_t* read_ts, uint32_t* final_cts,
                       uint32_t* keep_sorted = nullptr, uint32_t* keep_index = nullptr);
 void k_lasso_subtable_read(Ctx&, int subtable, uint32_t chunk_bits, const uint32_t* dim, size_t n, uint32_t* e);
@@ -437,7 +441,13 @@ struct MsmJob {
   // entry stream from these instead of emitting and sorting it again.
   const uint32_t* sorted_scalars = nullptr;
   const uint32_t* sorted_index = nullptr;
+  // Optional (u32 columns): TWO small-valued columns over the same bases packed into one, scalars[i] = s1[i] | s2[i] <<
+  // pack_shift (4 <= pack_shift, at most MSM_PACK_MAX_BITS significant bits together).  One pass over the points fills one
+  // bucket set indexed by the packed value; the reduction weighs it twice: out[j] = sum s1[i] B_i, *out_second = sum s2[i] B_i.
+  uint32_t pack_shift = 0;
+  G1Affine* out_second = nullptr;  // host
 };
+constexpr uint32_t MSM_PACK_MAX_BITS = 20;
 // Runs all jobs as one batched Pippenger; out[j] is the affine sum (identity = (0,0)).
 void msm_batch(Ctx&, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host);
 int msm_slab_log();  // jobs of >= 2^this points are sorted slab by slab (and can take MsmJob::sorted_*)

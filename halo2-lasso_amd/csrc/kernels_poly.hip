@@ -832,6 +832,35 @@ void k_lasso_output(Ctx& c, const LassoG& g, size_t n, Fr* a) {
   if (n) hipLaunchKernelGGL(lasso_output_kernel, grid_for(n), 256, 0, c.stream, g, n, a);
 }
 
+__global__ void or_u32_kernel(const uint32_t* const* __restrict__ cols, size_t n, uint32_t* __restrict__ out) {
+  const uint32_t* col = cols[blockIdx.y];
+  uint32_t acc = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc |= col[i];
+  for (int off = 32; off > 0; off >>= 1) acc |= __shfl_xor(acc, off, 64);
+  if ((threadIdx.x & 63) == 0 && acc) atomicOr(&out[blockIdx.y], acc);
+}
+void k_or_u32(Ctx& c, const uint32_t* const* cols, size_t count, size_t n, uint32_t* out_host) {
+  if (!count) return;
+  ArenaScope scope(c.arena);
+  const uint32_t** d_cols = (const uint32_t**)c.arena.alloc(count * sizeof(uint32_t*));
+  uint32_t* d_out = c.arena.alloc_n<uint32_t>(count);
+  void* stage = c.pin(count * sizeof(uint32_t*));
+  memcpy(stage, cols, count * sizeof(uint32_t*));
+  LH_HIP(hipMemcpyAsync(d_cols, stage, count * sizeof(uint32_t*), hipMemcpyHostToDevice, c.stream));
+  LH_HIP(hipMemsetAsync(d_out, 0, count * sizeof(uint32_t), c.stream));
+  if (n)
+    hipLaunchKernelGGL(or_u32_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 256), (unsigned)count), dim3(256), 0,
+                       c.stream, d_cols, n, d_out);
+  c.d2h(out_host, d_out, count * sizeof(uint32_t));
+}
+__global__ void pack_u32_kernel(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint32_t shift, size_t n,
+                                uint32_t* __restrict__ out) {
+  GSTRIDE(i, n) out[i] = a[i] | (b[i] << shift);
+}
+void k_pack_u32(Ctx& c, const uint32_t* a, const uint32_t* b, uint32_t shift, size_t n, uint32_t* out) {
+  if (n) hipLaunchKernelGGL(pack_u32_kernel, grid_for(n), 256, 0, c.stream, a, b, shift, n, out);
+}
+
 // fingerprint h(a, v, t) = a*gamma^2 + v*gamma + t - tau
 __global__ void lasso_rw_leaves_kernel(const uint32_t* __restrict__ dim, const uint32_t* __restrict__ e,
                                        const uint32_t* __restrict__ ts, size_t n, Fr gamma, Fr gamma2, Fr tau,

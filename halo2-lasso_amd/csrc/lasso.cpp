@@ -362,7 +362,34 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
       dim_job[j] = jobs.size(), add_job(1 + j, d_dims[j], true, N);
       if (!w.dim_sorted.empty()) jobs.back().sorted_scalars = w.dim_sorted[j], jobs.back().sorted_index = w.dim_index[j];
     }
-    for (size_t j = 0; j < cc; j++) add_job(1 + cc + j, rts[j], true, N);
+    // read_ts columns are small (a cell's access count): two of them share one pass over the points when their bit
+    // lengths allow (MsmJob::pack_shift; the access counts bound the timestamps)
+    std::vector<HG1> second(cc);
+    std::vector<size_t> second_of;  // chunks whose commitment comes back through `second`
+    {
+      std::vector<uint32_t> ors(cc, 0);
+      std::vector<const uint32_t*> cols(fcs.begin(), fcs.end());
+      static const bool pack_on = [] {
+        const char* e = getenv("LH_LASSO_PACK_TS");  // 0: one MSM pass per read_ts column (A/B measurements)
+        return !e || atoi(e) != 0;
+      }();
+      if (pack_on && cc >= 2 && N >= ((size_t)1 << 12)) k_or_u32(c, cols.data(), cc, M, ors.data());
+      auto bits_of = [](uint32_t v) { return v ? 32u - (uint32_t)__builtin_clz(v) : 0u; };
+      for (size_t j = 0; j < cc; j++) {
+        const uint32_t b0 = std::max(bits_of(ors[j]), 4u), b1 = j + 1 < cc ? bits_of(ors[j + 1]) : 0;
+        if (ors[j] && j + 1 < cc && ors[j + 1] && b0 + b1 <= MSM_PACK_MAX_BITS) {
+          uint32_t* packed = c.arena.alloc_n<uint32_t>(N);
+          k_pack_u32(c, rts[j], rts[j + 1], b0, N, packed);
+          add_job(1 + cc + j, packed, true, N);
+          jobs.back().pack_shift = b0;
+          jobs.back().out_second = (G1Affine*)&second[j + 1];
+          second_of.push_back(j + 1);
+          j++;
+        } else {
+          add_job(1 + cc + j, rts[j], true, N);
+        }
+      }
+    }
     // E_i = T[dim_j]: commit(E_i) = sum_d T[d] * B_d over the BUCKET sums B_d of dim_j's commitment - no second pass
     // over the N points (msm.hip, MsmJob::derived_parent; falls back to an ordinary column when the window shape of
     // dim_j does not allow it)
@@ -381,6 +408,7 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
     std::vector<HG1> part(jobs.size()), comms(total);
     msm_batch(c, jobs.data(), jobs.size(), (G1Affine*)part.data());
     for (size_t k = 0; k < jobs.size(); k++) comms[slot[k]] = part[k];
+    for (size_t j : second_of) comms[1 + cc + j] = second[j];
     for (size_t i = 0; i < alpha; i++)
       if (tb.memory_subtable[i] == LH_SUBTABLE_IDENTITY) comms[1 + 2 * cc + i] = comms[1 + tb.memory_chunk[i]];
     if (linear_g) {

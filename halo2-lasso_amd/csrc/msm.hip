@@ -53,6 +53,9 @@ struct MsmJobDev {
   uint32_t seg_size;    // buckets per segment
   uint32_t win_base;    // first window-sum slot of this job
   uint32_t presorted;   // the sorted entries of its single slab come from MsmJob::sorted_scalars / sorted_index
+  uint32_t pack_shift;  // != 0: two columns packed into one (MsmJob::pack_shift): one window whose bucket index IS the
+                        // packed value, reduced twice (red_W = 2 "windows" over the same buckets: low part, high part)
+  uint32_t red_W;       // windows of the reduction (= W except for packed jobs)
 };
 constexpr uint32_t KEY_BLOCK_BITS = 10;  // every job's key range starts at a multiple of 2^KEY_BLOCK_BITS
 struct MsmPlanDev {
@@ -134,7 +137,8 @@ __global__ void msm_emit_kernel(MsmPlanDev plan, uint32_t* __restrict__ keys, ui
         }
       }
       size_t e = (size_t)jb.entry_base + (size_t)w * jb.n + i;
-      keys[e] = jb.key_base + w * jb.win_stride + (d ? d - 1u : 0u);  // bucket index = digit - 1
+      // bucket index = digit - 1 (packed jobs: = digit, so that a reduce segment never straddles a change of the high part)
+      keys[e] = jb.key_base + w * jb.win_stride + (jb.pack_shift ? d : (d ? d - 1u : 0u));
       vals[e] = d ? ((uint32_t)i | neg) : SKIP_IDX;
     };
 #pragma unroll
@@ -325,13 +329,20 @@ __global__ __launch_bounds__(64) void msm_segment_reduce_kernel(MsmPlanDev plan,
     uint32_t local = (uint32_t)(s - jb.seg_base);
     uint32_t w = local / jb.seg_per_win, seg = local % jb.seg_per_win;
     uint32_t d0 = seg * jb.seg_size;
-    const G1Xyzz* b = buckets + jb.key_base + (size_t)w * jb.win_stride + d0;
+    const G1Xyzz* b = buckets + jb.key_base + (jb.pack_shift ? 0 : (size_t)w * jb.win_stride) + d0;
     G1Xyzz run = G1Xyzz::identity(), acc = G1Xyzz::identity();
     for (int d = (int)jb.seg_size - 1; d >= 0; d--) {
       acc = add(acc, run);
       run = add(run, b[d]);
     }
-    acc = add(acc, mul_small(run, d0 + 1));  // bucket index b holds digit b + 1
+    if (jb.pack_shift) {
+      // bucket index = packed value: "window" 0 weighs it with its low part (linear inside the aligned segment), 1 with
+      // its high part (constant inside it)
+      const uint32_t lo = d0 & ((1u << jb.pack_shift) - 1u), hi = d0 >> jb.pack_shift;
+      acc = w == 0 ? add(acc, mul_small(run, lo)) : mul_small(run, hi);
+    } else {
+      acc = add(acc, mul_small(run, d0 + 1));  // bucket index b holds digit b + 1
+    }
     seg_out[s] = acc;
   }
 }
@@ -357,13 +368,18 @@ __global__ __launch_bounds__(64) void msm_segment_reduce_quad_kernel(MsmPlanDev 
     uint32_t local = (uint32_t)(s - jb.seg_base);
     uint32_t w = local / jb.seg_per_win, seg = local % jb.seg_per_win;
     uint32_t d0 = seg * jb.seg_size;
-    const G1Xyzz* b = buckets + jb.key_base + (size_t)w * jb.win_stride + d0;
+    const G1Xyzz* b = buckets + jb.key_base + (jb.pack_shift ? 0 : (size_t)w * jb.win_stride) + d0;
     G1Xyzz run = G1Xyzz::identity(), acc = G1Xyzz::identity();
     for (int d = (int)jb.seg_size - 1; d >= 0; d--) {
       acc = add_quad(acc, run);
       run = add_quad(run, b[d]);
     }
-    acc = add_quad(acc, mul_small_quad(run, d0 + 1));  // bucket index b holds digit b + 1
+    if (jb.pack_shift) {
+      const uint32_t lo = d0 & ((1u << jb.pack_shift) - 1u), hi = d0 >> jb.pack_shift;
+      acc = w == 0 ? add_quad(acc, mul_small_quad(run, lo)) : mul_small_quad(run, hi);
+    } else {
+      acc = add_quad(acc, mul_small_quad(run, d0 + 1));  // bucket index b holds digit b + 1
+    }
     if (lead) seg_out[s] = acc;
   }
 }
@@ -554,6 +570,13 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
       jd.bases = in.bases;
       if (derived[j]) jd.n = 0;  // emits no (point, window) entries: its buckets are filled from the parent's
       jd.c = pick_window(in.n ? in.n : 1, bits ? bits : 1);
+      jd.pack_shift = 0;
+      if (in.pack_shift) {
+        LH_REQUIRE(in.scalars_u32 && in.out_second && in.pack_shift >= 4 && bits <= MSM_PACK_MAX_BITS && !derived[j],
+                   LH_ERR_ARG, "msm: bad packed job");
+        jd.pack_shift = in.pack_shift;
+        jd.c = std::max<uint32_t>(bits, 4);  // one window: the bucket index is the packed value
+      }
       jd.is_signed = in.scalars_u32 ? 0 : 1;
       if (jd.is_signed && jd.c < 2) jd.c = 2;
       // signed digits need one extra bit of head room for the last carry
@@ -562,10 +585,12 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
       // digit d > 0 lives in bucket d - 1: signed digits 1 .. 2^(c-1), unsigned 1 .. 2^c - 1
       sort_bits[j] = jd.is_signed ? jd.c - 1 : jd.c;
       const uint32_t nb = 1u << sort_bits[j];
+      jd.red_W = jd.pack_shift && jd.W ? 2 : jd.W;
       jd.seg_size = seg_size;
       jd.seg_per_win = (nb + jd.seg_size - 1) / jd.seg_size;
       jd.win_stride = jd.seg_per_win * jd.seg_size;
-      slab[j] = jd.n >= (1u << slab_log) && jd.W > 0 && nb >= jd.seg_size && sort_bits[j] <= 16;
+      slab[j] = jd.n >= (1u << slab_log) && jd.W > 0 && nb >= jd.seg_size &&
+                sort_bits[j] <= (jd.pack_shift ? MSM_PACK_MAX_BITS : 16u);
       jd.presorted = slab[j] && jd.W == 1 && in.scalars_u32 && in.sorted_scalars && in.sorted_index && !derived[j];
       // a slab-sorted job's bucket ranges start at multiples of 2^sort_bits: the low bits of a key are the bucket index
       const uint32_t align_bits = slab[j] ? std::max<uint32_t>(KEY_BLOCK_BITS, sort_bits[j]) : KEY_BLOCK_BITS;
@@ -574,8 +599,8 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
       jd.seg_base = seg;
       jd.win_base = win;
       key += jd.W * jd.win_stride;
-      seg += jd.W * jd.seg_per_win;
-      win += jd.W;
+      seg += jd.red_W * jd.seg_per_win;
+      win += jd.red_W;
       LH_REQUIRE(in.n < 0x7fffffffu, LH_ERR_ARG, "msm: too many points");
       max_n = std::max(max_n, in.n);
     }
@@ -603,7 +628,10 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
     }
     std::vector<G1Xyzz> wins(nwins * nsplit);
     if (max_entries == 0) {
-      for (size_t j = 0; j < nj; j++) memset(&out_host[base + j], 0, sizeof(G1Affine));
+      for (size_t j = 0; j < nj; j++) {
+        memset(&out_host[base + j], 0, sizeof(G1Affine));
+        if (jobs[base + j].out_second) memset(jobs[base + j].out_second, 0, sizeof(G1Affine));
+      }
       continue;
     }
     {
@@ -777,6 +805,17 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
     // 6: host combine  sum_w 2^(c*w) * win[w]  and normalise
     auto combine = [&](size_t j) {
       const MsmJobDev& jd = plan.job[j];
+      if (jd.pack_shift) {  // the two "windows" are the two results
+        for (uint32_t v = 0; v < 2; v++) {
+          host::G1Xyzz acc = host::G1Xyzz::identity();
+          if (jd.red_W)
+            for (uint32_t part = 0; part < nsplit; part++)
+              acc = host::g1_add(acc, to_host(wins[(size_t)(jd.win_base + v) * nsplit + part]));
+          host::G1Affine a = host::g1_to_affine(acc);
+          memcpy(v == 0 ? &out_host[base + j] : jobs[base + j].out_second, &a, sizeof(G1Affine));
+        }
+        return;
+      }
       host::G1Xyzz acc = host::G1Xyzz::identity();
       for (int w = (int)jd.W - 1; w >= 0; w--) {
         for (uint32_t k = 0; k < jd.c; k++) acc = host::g1_dbl(acc);
