@@ -219,8 +219,12 @@ void k_lasso_if_leaves(Ctx&, int subtable, uint32_t chunk_bits, const uint32_t* 
 // keep_sorted / keep_index (optional, n entries each): the column sorted by value and the positions it came from
 // OR of all entries of every column (its bit length bounds the values); synchronises
 void k_or_u32(Ctx&, const uint32_t* const* cols, size_t count, size_t n, uint32_t* out_host);
+void k_fill_u32(Ctx&, uint32_t* out, uint32_t value, size_t n);
 // out[i] = a[i] | b[i] << shift
 void k_pack_u32(Ctx&, const uint32_t* a, const uint32_t* b, uint32_t shift, size_t n, uint32_t* out);
+// v = col[i + half] - col[i] + offset (entries beyond `len` are zero; 0 < v < 2^33): out_lo[i] = v, or with out_hi:
+// out_lo[i] = v & 0xffff, out_hi[i] = v >> 16
+void k_delta_u32(Ctx&, const uint32_t* col, size_t len, size_t half, uint64_t offset, uint32_t* out_lo, uint32_t* out_hi);
 void k_lasso_counters(Ctx&, const uint32_t* dim, size_t n, size_t m, uint32_t* read_ts, uint32_t* final_cts,
                       uint32_t* keep_sorted = nullptr, uint32_t* keep_index = nullptr);
 void k_lasso_subtable_read(Ctx&, int subtable, uint32_t chunk_bits, const uint32_t* dim, size_t n, uint32_t* e);

@@ -3,6 +3,8 @@
 #pragma once
 #include <string.h>
 #include <functional>
+#include <map>
+#include <mutex>
 #include <vector>
 #include "dev.hpp"
 #include "ff_host.hpp"
@@ -208,26 +210,40 @@ struct Srs {
   mutable std::vector<G1Affine*> shard_levels;
   mutable int shard_rank = -1;
   mutable size_t shard_R = 0, shard_j = 0;
+  // sum of all bases of a level (mkzg_open over small-valued columns), computed on first use
+  mutable std::map<size_t, HG1> level_sums;  // (guarded by one process-wide mutex in prover.cpp)
 };
 Srs* mkzg_setup(Ctx&, const HFr* ss, size_t num_vars);
 std::vector<HG1> mkzg_batch_commit(Ctx&, const Srs&, const Fr* const* d_polys, size_t num_polys, size_t num_vars);
 std::vector<HG1> mkzg_batch_commit_u32(Ctx&, const Srs&, const uint32_t* const* d_polys, size_t num_polys,
                                        size_t num_vars);
-HFr mkzg_open(Ctx&, const Srs&, const Fr* d_poly, size_t num_vars, const HFr* point, Transcript& tr);
+struct SmallOpen;
+// small (optional): d_poly = sum_k coef[k] * cols[k] with small-valued columns: the largest quotient is then committed
+// column by column from 32-bit differences (prover.cpp)
+HFr mkzg_open(Ctx&, const Srs&, const Fr* d_poly, size_t num_vars, const HFr* point, Transcript& tr,
+              const SmallOpen* small = nullptr);
 // a poly handed over as its small-valued u32 column (`len` entries, zero beyond): Lasso's dim / read_ts / E / final_cts
 // reach the batch opening without a field-element view (d_polys[i] may then be null)
 struct SmallPoly {
   const uint32_t* ptr = nullptr;
   size_t len = 0;
+  uint32_t bits = 0;  // every entry < 2^bits when the caller knows (0: unknown)
 };
 void mkzg_batch_open(Ctx&, const Srs&, size_t num_vars, const Fr* const* d_polys, size_t num_polys,
                      const HFr* points, size_t num_points, const lh_evaluation* evals, size_t num_evals,
                      Transcript& tr, const SmallPoly* small = nullptr);
 
+// g' of a batch opening whose polys are ALL small-valued columns: g' = sum_k coef[k] * cols[k] (scalar coefficients)
+struct SmallOpen {
+  std::vector<SmallPoly> cols;
+  std::vector<HFr> coef;
+};
+// `open_small` (optional) is called instead of `open` when every opened poly came as a small-valued column
 void additive_batch_open(Ctx&, size_t num_vars, const Fr* const* d_polys, size_t num_polys, const HFr* points,
                          size_t num_points, const lh_evaluation* evals, size_t num_evals, Transcript& tr,
                          const std::function<void(const Fr* g_prime, const HFr* point)>& open,
-                         const SmallPoly* small = nullptr);
+                         const SmallPoly* small = nullptr,
+                         const std::function<void(const Fr* g_prime, const HFr* point, const SmallOpen&)>& open_small = nullptr);
 
 // ------------------------------------------------------------------ pcs::multilinear::zeromorph over pcs::univariate::kzg
 struct USrs {  // UnivariateKzgParam (univariate/kzg.rs:38-66): powers_of_s_g1 on the device

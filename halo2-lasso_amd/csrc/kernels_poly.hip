@@ -683,7 +683,7 @@ __global__ void quotient_step_kernel(const Fr* __restrict__ rem, size_t half, Fr
   GSTRIDE(i, half) {
     Fr lo = rem[i], hi = rem[half + i];
     Fr d = sub(hi, lo);
-    q[i] = d;
+    if (q) q[i] = d;  // (null: the caller commits this quotient another way)
     rem_out[i] = add(lo, mul(d, x));
   }
 }
@@ -852,6 +852,29 @@ void k_or_u32(Ctx& c, const uint32_t* const* cols, size_t count, size_t n, uint3
     hipLaunchKernelGGL(or_u32_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 256), (unsigned)count), dim3(256), 0,
                        c.stream, d_cols, n, d_out);
   c.d2h(out_host, d_out, count * sizeof(uint32_t));
+}
+__global__ void fill_u32_kernel(uint32_t* __restrict__ out, uint32_t value, size_t n) {
+  GSTRIDE(i, n) out[i] = value;
+}
+void k_fill_u32(Ctx& c, uint32_t* out, uint32_t value, size_t n) {
+  if (n) hipLaunchKernelGGL(fill_u32_kernel, grid_for(n), 256, 0, c.stream, out, value, n);
+}
+__global__ void delta_u32_kernel(const uint32_t* __restrict__ col, size_t len, size_t half, uint64_t offset,
+                                 uint32_t* __restrict__ out_lo, uint32_t* __restrict__ out_hi) {
+  GSTRIDE(i, half) {
+    const uint64_t lo = i < len ? col[i] : 0u, hi = i + half < len ? col[i + half] : 0u;
+    const uint64_t v = hi + offset - lo;
+    if (out_hi) {
+      out_lo[i] = (uint32_t)(v & 0xffffu);
+      out_hi[i] = (uint32_t)(v >> 16);
+    } else {
+      out_lo[i] = (uint32_t)v;
+    }
+  }
+}
+void k_delta_u32(Ctx& c, const uint32_t* col, size_t len, size_t half, uint64_t offset, uint32_t* out_lo, uint32_t* out_hi) {
+  if (half)
+    hipLaunchKernelGGL(delta_u32_kernel, grid_for(half), 256, 0, c.stream, col, len, half, offset, out_lo, out_hi);
 }
 __global__ void pack_u32_kernel(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint32_t shift, size_t n,
                                 uint32_t* __restrict__ out) {

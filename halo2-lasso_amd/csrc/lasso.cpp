@@ -329,6 +329,7 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
   };
 
   ArenaScope scope(c.arena);
+  std::vector<uint32_t> count_ors(cc, 0);  // OR of every final_cts column (bounds its read_ts column) when computed
   // ---- witness: counters, subtable reads, lookup outputs
   Fr* a = nullptr;
   uint32_t* a_small = nullptr;
@@ -367,7 +368,7 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
     std::vector<HG1> second(cc);
     std::vector<size_t> second_of;  // chunks whose commitment comes back through `second`
     {
-      std::vector<uint32_t> ors(cc, 0);
+      std::vector<uint32_t>& ors = count_ors;
       std::vector<const uint32_t*> cols(fcs.begin(), fcs.end());
       static const bool pack_on = [] {
         const char* e = getenv("LH_LASSO_PACK_TS");  // 0: one MSM pass per read_ts column (A/B measurements)
@@ -439,7 +440,7 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
     return d;
   };
   if (a_small) {
-    small[0] = SmallPoly{a_small, N};
+    small[0] = SmallPoly{a_small, N, 0};
   } else if (N < NV) {  // l > n: the output column needs the padding too
     Fr* ap = c.arena.alloc_n<Fr>(NV);
     LH_HIP(hipMemcpyAsync(ap, a, N * sizeof(Fr), hipMemcpyDeviceToDevice, c.stream));
@@ -449,15 +450,15 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
     polys_n[0] = a;
   }
   for (size_t j = 0; j < cc; j++) {
-    small[1 + j] = SmallPoly{d_dims[j], N};
-    small[1 + cc + j] = SmallPoly{rts[j], N};
-    small[num_n + j] = SmallPoly{fcs[j], M};
+    small[1 + j] = SmallPoly{d_dims[j], N, (uint32_t)l};
+    small[1 + cc + j] = SmallPoly{rts[j], N, count_ors[j] ? 32u - (uint32_t)__builtin_clz(count_ors[j]) : 0u};
+    small[num_n + j] = SmallPoly{fcs[j], M, 0};
   }
   bool linear_surge = true;  // (lasso_argue: the Surge sum-check then runs over the output column alone)
   for (uint32_t m = 0; m < tb.num_terms; m++) linear_surge = linear_surge && tb.g_num_factors[m] == 1;
   for (size_t i = 0; i < alpha; i++) {
     if (!linear_surge) polys_n[1 + 2 * cc + i] = fr_view(E[i], N);
-    small[1 + 2 * cc + i] = SmallPoly{E[i], N};
+    small[1 + 2 * cc + i] = SmallPoly{E[i], N, (uint32_t)(tb.memory_subtable[i] == LH_SUBTABLE_IDENTITY ? l : l / 2)};
   }
   const Fr* const* E_fr = polys_n.data() + 1 + 2 * cc;
 

@@ -328,6 +328,7 @@ __global__ __launch_bounds__(64) void msm_segment_reduce_kernel(MsmPlanDev plan,
     const MsmJobDev& jb = plan.job[j];
     uint32_t local = (uint32_t)(s - jb.seg_base);
     uint32_t w = local / jb.seg_per_win, seg = local % jb.seg_per_win;
+    if (jb.pack_shift && w) continue;  // (written by the thread of "window" 0)
     uint32_t d0 = seg * jb.seg_size;
     const G1Xyzz* b = buckets + jb.key_base + (jb.pack_shift ? 0 : (size_t)w * jb.win_stride) + d0;
     G1Xyzz run = G1Xyzz::identity(), acc = G1Xyzz::identity();
@@ -337,9 +338,10 @@ __global__ __launch_bounds__(64) void msm_segment_reduce_kernel(MsmPlanDev plan,
     }
     if (jb.pack_shift) {
       // bucket index = packed value: "window" 0 weighs it with its low part (linear inside the aligned segment), 1 with
-      // its high part (constant inside it)
+      // its high part (constant inside it); the thread of window 0 writes both
       const uint32_t lo = d0 & ((1u << jb.pack_shift) - 1u), hi = d0 >> jb.pack_shift;
-      acc = w == 0 ? add(acc, mul_small(run, lo)) : mul_small(run, hi);
+      seg_out[s + jb.seg_per_win] = mul_small(run, hi);
+      acc = add(acc, mul_small(run, lo));
     } else {
       acc = add(acc, mul_small(run, d0 + 1));  // bucket index b holds digit b + 1
     }
@@ -367,6 +369,7 @@ __global__ __launch_bounds__(64) void msm_segment_reduce_quad_kernel(MsmPlanDev 
     const MsmJobDev& jb = plan.job[j];
     uint32_t local = (uint32_t)(s - jb.seg_base);
     uint32_t w = local / jb.seg_per_win, seg = local % jb.seg_per_win;
+    if (jb.pack_shift && w) continue;  // (written by the thread of "window" 0)
     uint32_t d0 = seg * jb.seg_size;
     const G1Xyzz* b = buckets + jb.key_base + (jb.pack_shift ? 0 : (size_t)w * jb.win_stride) + d0;
     G1Xyzz run = G1Xyzz::identity(), acc = G1Xyzz::identity();
@@ -376,7 +379,9 @@ __global__ __launch_bounds__(64) void msm_segment_reduce_quad_kernel(MsmPlanDev 
     }
     if (jb.pack_shift) {
       const uint32_t lo = d0 & ((1u << jb.pack_shift) - 1u), hi = d0 >> jb.pack_shift;
-      acc = w == 0 ? add_quad(acc, mul_small_quad(run, lo)) : mul_small_quad(run, hi);
+      const G1Xyzz high = mul_small_quad(run, hi);
+      if (lead) seg_out[s + jb.seg_per_win] = high;
+      acc = add_quad(acc, mul_small_quad(run, lo));
     } else {
       acc = add_quad(acc, mul_small_quad(run, d0 + 1));  // bucket index b holds digit b + 1
     }

@@ -993,8 +993,23 @@ std::vector<HG1> mkzg_batch_commit_u32(Ctx& c, const Srs& srs, const uint32_t* c
 
 // open: kzg.rs:276-302 + quotients pcs/multilinear.rs:72-107.  The n quotient polynomials are laid out
 // back to back (q_i at offset 2^i - 1, exactly the flat SRS layout) and committed as ONE batched MSM.
-HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const HFr* point, Transcript& tr) {
+//
+// `small`: the opened poly is a scalar combination of small-valued columns, g' = sum_k coef_k col_k (a Lasso batch opening
+// under a linear g).  The quotient operator is linear and the LARGEST quotient (half of all quotient entries) is a plain
+// difference of halves, q_top = sum_k coef_k (hi_k - lo_k): its commitment is sum_k coef_k C(hi_k - lo_k) with 17-33-bit
+// differences - one or two windows per column, pairs of narrow columns in one pass (MsmJob::pack_shift) - instead of 15
+// windows over 2^(n-1) full-size scalars.  Differences are made non-negative by an offset 2^bits; the offsets cost one
+// multiple of the level's base sum (Srs::level_sums, computed once).  The lower quotients come from the folded
+// remainder as before.
+static std::mutex level_sums_mu;
+HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const HFr* point, Transcript& tr,
+              const SmallOpen* small) {
   check_commit_vars(srs, num_vars, "open");
+  static const size_t small_min_vars = [] {
+    const char* e = getenv("LH_OPEN_SMALL_MIN_VARS");  // smallest opening that takes the column route (64: never)
+    return e ? (size_t)atoll(e) : (size_t)21;
+  }();
+  if (small && (num_vars < small_min_vars || num_vars < 2 || small->cols.empty())) small = nullptr;
   ArenaScope scope(c.arena);
   const size_t n = (size_t)1 << num_vars;
   Fr* q = c.arena.alloc_n<Fr>(n);  // n - 1 used
@@ -1004,7 +1019,7 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
   for (size_t i = num_vars; i-- > 0;) {
     size_t half = (size_t)1 << i;
     Fr* dst = ((num_vars - i) & 1) ? remA : remB;
-    k_quotient_step(c, rem, half, dev(point[i]), q + (half - 1), dst);
+    k_quotient_step(c, rem, half, dev(point[i]), small && i + 1 == num_vars ? nullptr : q + (half - 1), dst);
     rem = dst;
   }
   HFr remainder;
@@ -1012,13 +1027,151 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
     download(c, &remainder, d_poly, sizeof(Fr));
     return remainder;
   }
-  std::vector<MsmJob> jobs(num_vars);
-  for (size_t i = 0; i < num_vars; i++) {
+  const size_t plain = small ? num_vars - 1 : num_vars;
+  std::vector<MsmJob> jobs(plain);
+  for (size_t i = 0; i < plain; i++) {
     size_t half = (size_t)1 << i;
     jobs[i] = MsmJob{q + (half - 1), false, srs.eq(i), half};
   }
-  std::vector<HG1> comms(num_vars);
-  msm_batch(c, jobs.data(), num_vars, (G1Affine*)comms.data());
+  // ---- the top quotient, column by column
+  struct Term {     // result of job `job` (or its second output), times `scale`, goes into the commitment
+    size_t job;
+    bool second;
+    HFr scale;
+  };
+  std::vector<Term> terms;
+  std::vector<HG1> seconds;
+  HFr offset_total = HFr::zero();  // sum_k coef_k * offset_k: times the level's base sum, subtracted
+  bool need_sum = false;
+  if (small) {
+    const size_t top = num_vars - 1, half = (size_t)1 << top;
+    const G1Affine* bases = srs.eq(top);
+    const size_t K = small->cols.size();
+    // bit lengths of the full columns (one pass)
+    std::vector<uint32_t> ors(K, 0);
+    {
+      std::map<size_t, std::vector<size_t>> by_len;  // one OR pass per column length (normally a single one)
+      for (size_t k = 0; k < K; k++) {
+        if (small->cols[k].len <= half || small->coef[k].is_zero()) continue;
+        if (small->cols[k].bits) ors[k] = small->cols[k].bits >= 32 ? 0xffffffffu : (1u << small->cols[k].bits) - 1u;  // known bound
+        else by_len[small->cols[k].len].push_back(k);
+      }
+      for (const auto& grp : by_len) {
+        std::vector<const uint32_t*> ptrs;
+        for (size_t k : grp.second) ptrs.push_back(small->cols[k].ptr);
+        std::vector<uint32_t> o(ptrs.size(), 0);
+        k_or_u32(c, ptrs.data(), ptrs.size(), grp.first, o.data());
+        for (size_t f = 0; f < ptrs.size(); f++) ors[grp.second[f]] = o[f];
+      }
+    }
+    auto bits_of = [](uint32_t v) { return v ? 32u - (uint32_t)__builtin_clz(v) : 0u; };
+    struct Narrow {
+      size_t k;
+      uint32_t bits;  // of the shifted difference
+      uint32_t* col;
+    };
+    std::vector<Narrow> narrow;
+    seconds.resize(K);
+    for (size_t k = 0; k < K; k++) {
+      const SmallPoly& sp = small->cols[k];
+      const HFr& co = small->coef[k];
+      if (co.is_zero() || !sp.len) continue;
+      if (sp.len <= half) {  // only the low half is populated: hi - lo = -lo, no offset
+        jobs.push_back(MsmJob{sp.ptr, true, bases, sp.len});
+        terms.push_back(Term{jobs.size() - 1, false, HFr::zero() - co});
+        continue;
+      }
+      const uint32_t b = bits_of(ors[k]);
+      if (!b) continue;  // an all-zero column
+      const uint64_t off = (uint64_t)1 << b;
+      offset_total += co * HFr::from_u64(off);
+      need_sum = true;
+      if (b + 1 > 32) {  // 33-bit shifted differences: a 16-bit limb and a 17-bit limb
+        uint32_t* lo = c.arena.alloc_n<uint32_t>(half);
+        uint32_t* hi = c.arena.alloc_n<uint32_t>(half);
+        k_delta_u32(c, sp.ptr, sp.len, half, off, lo, hi);
+        jobs.push_back(MsmJob{lo, true, bases, half});
+        terms.push_back(Term{jobs.size() - 1, false, co});
+        jobs.push_back(MsmJob{hi, true, bases, half});
+        terms.push_back(Term{jobs.size() - 1, false, co * HFr::from_u64(65536)});
+        continue;
+      }
+      uint32_t* d = c.arena.alloc_n<uint32_t>(half);
+      k_delta_u32(c, sp.ptr, sp.len, half, off, d, nullptr);
+      if (b + 1 <= MSM_PACK_MAX_BITS - 4) {
+        narrow.push_back(Narrow{k, b + 1, d});
+      } else {
+        jobs.push_back(MsmJob{d, true, bases, half});
+        terms.push_back(Term{jobs.size() - 1, false, co});
+      }
+    }
+    // narrow columns two by two (narrowest first) while the packed value stays within MSM_PACK_MAX_BITS
+    std::sort(narrow.begin(), narrow.end(), [](const Narrow& a, const Narrow& b) { return a.bits < b.bits; });
+    for (size_t i = 0; i < narrow.size(); i++) {
+      const Narrow& a = narrow[i];
+      const uint32_t shift = std::max(a.bits, 4u);
+      if (i + 1 < narrow.size() && shift + narrow[i + 1].bits <= MSM_PACK_MAX_BITS) {
+        const Narrow& b2 = narrow[i + 1];
+        uint32_t* packed = c.arena.alloc_n<uint32_t>(half);
+        k_pack_u32(c, a.col, b2.col, shift, half, packed);
+        MsmJob jb{packed, true, bases, half};
+        jb.pack_shift = shift;
+        jb.out_second = (G1Affine*)&seconds[b2.k];
+        jobs.push_back(jb);
+        terms.push_back(Term{jobs.size() - 1, false, small->coef[a.k]});
+        terms.push_back(Term{jobs.size() - 1, true, small->coef[b2.k]});
+        i++;
+      } else {
+        jobs.push_back(MsmJob{a.col, true, bases, half});
+        terms.push_back(Term{jobs.size() - 1, false, small->coef[a.k]});
+      }
+    }
+  }
+  // the level's base sum (an MSM with all-one scalars, once per SRS and level)
+  HG1 base_sum;
+  size_t sum_job = (size_t)-1;
+  if (need_sum) {
+    const size_t top = num_vars - 1;
+    std::lock_guard<std::mutex> lock(level_sums_mu);
+    auto it = srs.level_sums.find(top);
+    if (it != srs.level_sums.end()) {
+      base_sum = it->second;
+    } else {
+      const size_t half = (size_t)1 << top;
+      uint32_t* ones = c.arena.alloc_n<uint32_t>(half);
+      k_fill_u32(c, ones, 1u, half);
+      jobs.push_back(MsmJob{ones, true, srs.eq(top), half});
+      sum_job = jobs.size() - 1;
+    }
+  }
+  std::vector<HG1> out(jobs.size());
+  msm_batch(c, jobs.data(), jobs.size(), (G1Affine*)out.data());
+  std::vector<HG1> comms(out.begin(), out.begin() + plain);
+  if (small) {
+    if (sum_job != (size_t)-1) {
+      base_sum = out[sum_job];
+      std::lock_guard<std::mutex> lock(level_sums_mu);
+      srs.level_sums[num_vars - 1] = base_sum;
+    }
+    // commitment = sum_t scale_t * result_t - offset_total * base sum  (scalar multiplications on the host's threads)
+    std::vector<HG1> pts(terms.size() + 1);
+    std::vector<HFr> scal(terms.size() + 1);
+    for (size_t t = 0; t < terms.size(); t++) {
+      const Term& tm = terms[t];
+      if (tm.second) memcpy(&pts[t], jobs[tm.job].out_second, sizeof(HG1));
+      else pts[t] = out[tm.job];
+      scal[t] = tm.scale;
+    }
+    pts[terms.size()] = need_sum ? base_sum : HG1{host::Fq::zero(), host::Fq::zero()};
+    scal[terms.size()] = HFr::zero() - offset_total;
+    std::vector<host::G1Xyzz> parts(pts.size(), host::G1Xyzz::identity());
+    host_parallel_for(pts.size(), [&](size_t t) {
+      if (!pts[t].is_identity() && !scal[t].is_zero()) parts[t] = host::g1_mul(host::g1_from_affine(pts[t]), scal[t]);
+    });
+    host::G1Xyzz acc = host::G1Xyzz::identity();
+    for (const host::G1Xyzz& pt : parts) acc = host::g1_add(acc, pt);
+    comms.push_back(host::g1_to_affine(acc));
+  }
   download(c, &remainder, rem, sizeof(Fr));
   tr.write_commitments(comms);  // identity -> Error::Transcript (transcript.rs:172-179,216-219)
   return remainder;
@@ -1028,7 +1181,8 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
 // sum-check challenges and hand it to `open`
 void additive_batch_open(Ctx& c, size_t num_vars, const Fr* const* d_polys, size_t num_polys, const HFr* points,
                          size_t num_points, const lh_evaluation* evals, size_t num_evals, Transcript& tr,
-                         const std::function<void(const Fr* g_prime, const HFr* point)>& open, const SmallPoly* small) {
+                         const std::function<void(const Fr* g_prime, const HFr* point)>& open, const SmallPoly* small,
+                         const std::function<void(const Fr* g_prime, const HFr* point, const SmallOpen&)>& open_small) {
   LH_REQUIRE(num_vars >= 1, LH_ERR_ARG, "batch open: num_vars == 0");
   LH_REQUIRE(num_evals >= 2, LH_ERR_ARG,
              "batch open needs >= 2 evaluations (eq_xy of an empty point is the zero poly, multilinear.rs:92-94)");
@@ -1095,6 +1249,23 @@ void additive_batch_open(Ctx& c, size_t num_vars, const Fr* const* d_polys, size
     w[j] = dev(host_eq_xy_eval(sc.challenges.data(), points + j * num_vars, num_vars));
   Fr* g_prime = c.arena.alloc_n<Fr>(n);
   k_lincomb(c, merged.data(), w.data(), num_points, n, g_prime);
+  // every opened poly a small-valued column: g' = sum_p coef_p col_p with coef_p = sum_{i: poly(i) = p} eq_xt[i] w[point(i)]
+  bool all_small = open_small != nullptr && small != nullptr;
+  for (size_t i = 0; i < num_evals && all_small; i++) all_small = small[evals[i].poly].ptr != nullptr;
+  if (all_small) {
+    std::vector<HFr> coef(num_polys, HFr::zero());
+    std::vector<char> used(num_polys, 0);
+    for (size_t i = 0; i < num_evals; i++) {
+      coef[evals[i].poly] += eq_xt[i] * hst(w[evals[i].point]);
+      used[evals[i].poly] = 1;
+    }
+    SmallOpen so;
+    for (size_t pi = 0; pi < num_polys; pi++)
+      if (used[pi])
+        so.cols.push_back(SmallPoly{small[pi].ptr, std::min(small[pi].len, n), small[pi].bits}), so.coef.push_back(coef[pi]);
+    open_small(g_prime, sc.challenges.data(), so);
+    return;
+  }
   open(g_prime, sc.challenges.data());
 }
 
@@ -1102,8 +1273,10 @@ void mkzg_batch_open(Ctx& c, const Srs& srs, size_t num_vars, const Fr* const* d
                      const HFr* points, size_t num_points, const lh_evaluation* evals, size_t num_evals,
                      Transcript& tr, const SmallPoly* small) {
   check_commit_vars(srs, num_vars, "batch open");
-  additive_batch_open(c, num_vars, d_polys, num_polys, points, num_points, evals, num_evals, tr,
-                      [&](const Fr* g_prime, const HFr* point) { mkzg_open(c, srs, g_prime, num_vars, point, tr); }, small);
+  additive_batch_open(
+      c, num_vars, d_polys, num_polys, points, num_points, evals, num_evals, tr,
+      [&](const Fr* g_prime, const HFr* point) { mkzg_open(c, srs, g_prime, num_vars, point, tr); }, small,
+      [&](const Fr* g_prime, const HFr* point, const SmallOpen& so) { mkzg_open(c, srs, g_prime, num_vars, point, tr, &so); });
 }
 
 }  // namespace lh
