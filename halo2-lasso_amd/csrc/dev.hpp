@@ -199,6 +199,7 @@ void k_lincomb_mixed(Ctx&, const Fr* const* fr, const Fr* wfr, size_t num_fr, co
                      const size_t* sm_len, const Fr* wsm, size_t num_sm, size_t n, Fr* out);
 // product tree level: out[i] = in[i] * in[half + i]
 void k_tree_up(Ctx&, const Fr* in, size_t half, Fr* out);
+void k_tree_up_multi(Ctx&, const Fr* const* in, Fr* const* out, size_t count, size_t half);
 // every level above level H[i] (2^(H+1) nodes at in[i], H <= 9) of `count` product trees, one launch:
 // level h < H lands at out[i] + (2^(h+1) - 2)
 void k_tree_tops(Ctx&, const Fr* const* in, Fr* const* out, const int* H, size_t count);

@@ -606,6 +606,27 @@ void k_inner_products_small(Ctx& c, const uint32_t* const* polys, size_t count, 
 __global__ void tree_up_kernel(const Fr* __restrict__ in, size_t half, Fr* __restrict__ out) {
   GSTRIDE(i, half) out[i] = mul(in[i], in[half + i]);
 }
+// the same level of several trees of equal size in one launch (a level of a small tree is launch-bound)
+__global__ void tree_up_multi_kernel(PtrPack p, size_t half) {
+  const Fr* __restrict__ in = p.in[blockIdx.y];
+  Fr* __restrict__ out = p.out[blockIdx.y];
+  GSTRIDE(i, half) out[i] = mul(in[i], in[half + i]);
+}
+void k_tree_up_multi(Ctx& c, const Fr* const* in, Fr* const* out, size_t count, size_t half) {
+  ProfScope ps(c, "tree_up", 96.0 * half * count, 1.0 * half * count, (double)half * count);
+  if (!half) return;
+  for (size_t base = 0; base < count; base += SC_MAX_TABLES) {
+    size_t k = count - base < (size_t)SC_MAX_TABLES ? count - base : (size_t)SC_MAX_TABLES;
+    PtrPack p;
+    for (size_t i = 0; i < k; i++) {
+      p.in[i] = in[base + i];
+      p.out[i] = out[base + i];
+    }
+    dim3 g = grid_for(half);
+    g.y = (unsigned)k;
+    hipLaunchKernelGGL(tree_up_multi_kernel, g, 256, 0, c.stream, p, half);
+  }
+}
 void k_tree_up(Ctx& c, const Fr* in, size_t half, Fr* out) {
   ProfScope ps(c, "tree_up", 96.0 * half, 1.0 * half, (double)half);
   if (half) hipLaunchKernelGGL(tree_up_kernel, grid_for(half), 256, 0, c.stream, in, half, out);

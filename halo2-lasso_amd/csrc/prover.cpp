@@ -807,20 +807,36 @@ GrandProductResult prove_grand_product(Ctx& c, size_t B, const Fr* const* d_leav
     std::vector<const Fr*> top_in(B);
     std::vector<Fr*> top_out(B);
     std::vector<int> top_H(B);
+    std::vector<size_t> cur_h(B);  // lowest computed level of every tree
+    size_t max_h = 0;
     for (size_t b = 0; b < B; b++) {
       level[b].resize(num_vars[b]);
       level[b][num_vars[b] - 1] = d_leaves[b];
-      size_t h = num_vars[b] - 1;  // current lowest computed level
+      size_t h = num_vars[b] - 1;
       if (d_level_up && d_level_up[b] && h > SMALL) {
         level[b][h - 1] = d_level_up[b];
         h--;
       }
-      for (; h > SMALL; h--) {
-        size_t half = (size_t)1 << h;
+      cur_h[b] = h;
+      max_h = std::max(max_h, h);
+    }
+    // level by level, the trees of equal size in one launch
+    for (size_t h = max_h; h > SMALL; h--) {
+      std::vector<const Fr*> ins;
+      std::vector<Fr*> outs;
+      const size_t half = (size_t)1 << h;
+      for (size_t b = 0; b < B; b++) {
+        if (cur_h[b] != h) continue;
         Fr* up = c.arena.alloc_n<Fr>(half);
-        k_tree_up(c, level[b][h], half, up);
+        ins.push_back(level[b][h]);
+        outs.push_back(up);
         level[b][h - 1] = up;
+        cur_h[b] = h - 1;
       }
+      if (!ins.empty()) k_tree_up_multi(c, ins.data(), outs.data(), ins.size(), half);
+    }
+    for (size_t b = 0; b < B; b++) {
+      const size_t h = cur_h[b];
       // h <= SMALL: levels h-1 .. 0 in one go
       Fr* tops = c.arena.alloc_n<Fr>(((size_t)2 << h));
       top_in[b] = level[b][h];
