@@ -296,6 +296,36 @@ struct LassoClaims {  // points and claimed evaluations that remain to be opened
   std::vector<HFr> ev_n;  // dim_j | read_ts_j | E_i at r_N
   std::vector<HFr> ev_l;  // final_cts_j at r_M
 };
+// T[d] and the d's sorted by T[d] for the bitwise subtables, on the device (arena memory of the caller's scope; the host
+// staging lives as long as this object, i.e. past the msm_batch that consumes them)
+struct SubtableOrders {
+  Ctx& c;
+  size_t l;
+  std::vector<uint32_t> h_tab[3], h_ord[3];
+  uint32_t *d_tab[3] = {nullptr, nullptr, nullptr}, *d_ord[3] = {nullptr, nullptr, nullptr};
+  SubtableOrders(Ctx& c_, size_t l_) : c(c_), l(l_) {}
+  void get(int kind, const uint32_t** table, const uint32_t** order) {
+    if (!d_tab[kind]) {
+      const size_t M = (size_t)1 << l, h = l / 2, V = (size_t)1 << h;
+      std::vector<uint32_t>&tab = h_tab[kind], &ord = h_ord[kind];
+      tab.resize(M), ord.resize(M);
+      std::vector<uint32_t> start(V + 1, 0);
+      for (size_t d = 0; d < M; d++) {
+        const uint32_t x = (uint32_t)(d >> h), y = (uint32_t)(d & (V - 1));
+        tab[d] = kind == LH_SUBTABLE_AND ? (x & y) : (x ^ y);
+        start[tab[d] + 1]++;
+      }
+      for (size_t v = 0; v < V; v++) start[v + 1] += start[v];
+      for (size_t d = 0; d < M; d++) ord[start[tab[d]]++] = (uint32_t)d;  // counting sort by T
+      d_tab[kind] = c.arena.alloc_n<uint32_t>(M);
+      d_ord[kind] = c.arena.alloc_n<uint32_t>(M);
+      LH_HIP(hipMemcpyAsync(d_tab[kind], tab.data(), M * 4, hipMemcpyHostToDevice, c.stream));
+      LH_HIP(hipMemcpyAsync(d_ord[kind], ord.data(), M * 4, hipMemcpyHostToDevice, c.stream));
+    }
+    *table = d_tab[kind], *order = d_ord[kind];
+  }
+};
+
 void lasso_check_table(const lh_lasso_table& tb);
 // a_out (optional): the output column a = g(E) as field elements; a_small_out (optional): the same as a 32-bit column
 // when g is linear with small coefficients and the value fits (then *a_out stays null)

@@ -357,15 +357,56 @@ void lasso_prove_sharded(Ctx& c, const Srs& srs, const lh_lasso_table& tb, size_
       slot.push_back(pos);
     };
     if (!linear_g) add_job(0, a, false, bases_l, NL);
-    for (size_t j = 0; j < cc; j++) add_job(1 + j, dim_l[j], true, bases_l, NL);
-    for (size_t j = 0; j < cc; j++) add_job(1 + cc + j, rts_l[j], true, bases_l, NL);
+    std::vector<size_t> dim_job(cc);
+    for (size_t j = 0; j < cc; j++) dim_job[j] = jobs.size(), add_job(1 + j, dim_l[j], true, bases_l, NL);
+    // read_ts columns in packed pairs, E = T[dim] from dim's bucket sums: as in lasso.cpp, on this rank's shards (the
+    // replicated final_cts bound every shard's read_ts)
+    std::vector<HG1> second(cc);
+    std::vector<size_t> second_of;
+    {
+      std::vector<uint32_t> ors(cc, 0);
+      std::vector<const uint32_t*> cols(fcs.begin(), fcs.end());
+      if (cc >= 2 && NL >= ((size_t)1 << 12)) k_or_u32(c, cols.data(), cc, M, ors.data());
+      auto bits_of = [](uint32_t v) { return v ? 32u - (uint32_t)__builtin_clz(v) : 0u; };
+      for (size_t j = 0; j < cc; j++) {
+        const uint32_t b0 = std::max(bits_of(ors[j]), 4u), b1 = j + 1 < cc ? bits_of(ors[j + 1]) : 0;
+        if (ors[j] && j + 1 < cc && ors[j + 1] && b0 + b1 <= MSM_PACK_MAX_BITS) {
+          uint32_t* packed = c.arena.alloc_n<uint32_t>(NL);
+          k_pack_u32(c, rts_l[j], rts_l[j + 1], b0, NL, packed);
+          add_job(1 + cc + j, packed, true, bases_l, NL);
+          jobs.back().pack_shift = b0;
+          jobs.back().out_second = (G1Affine*)&second[j + 1];
+          second_of.push_back(j + 1);
+          j++;
+        } else {
+          add_job(1 + cc + j, rts_l[j], true, bases_l, NL);
+        }
+      }
+    }
+    SubtableOrders orders(c, l);
     for (size_t i = 0; i < alpha; i++)
-      if (tb.memory_subtable[i] != LH_SUBTABLE_IDENTITY) add_job(1 + 2 * cc + i, E_l[i], true, bases_l, NL);
+      if (tb.memory_subtable[i] != LH_SUBTABLE_IDENTITY) {
+        add_job(1 + 2 * cc + i, E_l[i], true, bases_l, NL);
+        if (l <= 20) {
+          MsmJob& jb = jobs.back();
+          jb.derived_parent = (int)dim_job[tb.memory_chunk[i]];
+          orders.get((int)tb.memory_subtable[i], &jb.d_table, &jb.d_order);
+          jb.table_in_bits = (uint32_t)l, jb.table_out_bits = (uint32_t)(l / 2);
+        }
+      }
     const size_t num_sharded = jobs.size();
     for (size_t j = 0; j < cc; j++) add_job(1 + 2 * cc + alpha + j, fcs[j], true, srs.eq(n), M);
     std::vector<HG1> part(jobs.size()), comms(total);
     msm_batch(c, jobs.data(), jobs.size(), (G1Affine*)part.data());
-    comm_sum_points(c, part.data(), num_sharded);
+    {
+      // partial commitments of the shards (the second outputs of packed jobs included) -> their sums
+      std::vector<HG1> sums(part.begin(), part.begin() + num_sharded);
+      for (size_t j : second_of) sums.push_back(second[j]);
+      comm_sum_points(c, sums.data(), sums.size());
+      for (size_t k = 0; k < num_sharded; k++) part[k] = sums[k];
+      for (size_t q = 0; q < second_of.size(); q++) second[second_of[q]] = sums[num_sharded + q];
+    }
+    for (size_t j : second_of) comms[1 + cc + j] = second[j];
     for (size_t k = 0; k < jobs.size(); k++) comms[slot[k]] = part[k];
     for (size_t i = 0; i < alpha; i++)
       if (tb.memory_subtable[i] == LH_SUBTABLE_IDENTITY) comms[1 + 2 * cc + i] = comms[1 + tb.memory_chunk[i]];
