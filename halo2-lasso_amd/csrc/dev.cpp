@@ -55,6 +55,13 @@ void Arena::release(Mark m) {
   blocks_[cur_].used = m.used;
 }
 
+void Ctx::opt_in_lds(const void* fn, int bytes) {
+  for (const void* f : lds_opted)
+    if (f == fn) return;
+  LH_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  lds_opted.push_back(fn);
+}
+
 void Ctx::wait_flag(uint32_t seq) {
   volatile uint32_t* f = flag;
   for (uint64_t spin = 0;; spin++) {

@@ -137,6 +137,9 @@ struct Ctx {
   void mbox_send(const Fr& r, uint32_t seq);
   void mbox_abort();
   void wait_flag(uint32_t seq);
+  // more than 64 KB of dynamic LDS for `fn` on this ctx's device (the attribute is per device: once per ctx and kernel)
+  std::vector<const void*> lds_opted;
+  void opt_in_lds(const void* fn, int bytes);
   // message of a resident tail round: `count` chunks that all carry `seq` -> `count` / 3 field elements
   void wait_chunks(const struct TailChunk* chunks, size_t count, uint32_t seq, Fr* out);
 };

@@ -352,9 +352,7 @@ void k_sc_round_prog(Ctx& c, const ProgRound& pr, int degree, size_t size, Fr* e
   const unsigned threads = 64u * (unsigned)degree;
   const size_t lds_bytes = (size_t)pr.num_regs * 32 * threads + (size_t)pr.num_instrs * 8;
   LH_REQUIRE(lds_bytes <= 150 * 1024, LH_ERR_ARG, "sum-check program: too large for LDS");
-  static const hipError_t attr = hipFuncSetAttribute((const void*)sc_round_prog_kernel,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-  LH_HIP(attr);  // function-local static: set exactly once, thread-safe
+  c.opt_in_lds((const void*)sc_round_prog_kernel, 160 * 1024 - 64);
   size_t g = jit ? (size + 255) / 256 : (size + 63) / 64;  // compiled form: 4 groups of 64 pairs per workgroup
   // one resident set of workgroups (they loop over the pairs): a grid of 4 per CU when only 3 fit runs a second, mostly
   // empty pass

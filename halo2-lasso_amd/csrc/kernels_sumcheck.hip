@@ -642,9 +642,7 @@ void k_sc_tail_launch(Ctx& c, const ScRound& rd, int degree, size_t n0, bool fir
   }
   c.mbox_send(Fr::zero(), 0u);
   const size_t lds = ((size_t)a.red_off + tail_red_entries(rd, degree, a.cap)) * sizeof(Fr);
-  static const hipError_t opt_in =
-      hipFuncSetAttribute((const void*)sc_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TAIL_LDS_BYTES + 2048);
-  LH_HIP(opt_in);
+  c.opt_in_lds((const void*)sc_tail_kernel, (int)TAIL_LDS_BYTES + 2048);
   hipLaunchKernelGGL(sc_tail_kernel, dim3(G), dim3(G > 1 ? TAIL_THREADS_MULTI : TAIL_THREADS), lds, c.stream, a);
   LH_HIP(hipGetLastError());
 }
