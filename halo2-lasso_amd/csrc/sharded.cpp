@@ -34,6 +34,7 @@ struct ShardGeom {
 struct ShardedLeaves {
   const Fr* ptr;    // local shard (2^(nv-rho)) when sharded, the full table otherwise
   size_t num_vars;  // global
+  bool plus_one = false;  // its leaves are the previous tree's leaves + 1 (prover.cpp prove_grand_product: plus_one)
 };
 
 static GrandProductResult prove_grand_product_sharded(Ctx& c, const std::vector<ShardedLeaves>& trees, Transcript& tr) {
@@ -106,6 +107,42 @@ static GrandProductResult prove_grand_product_sharded(Ctx& c, const std::vector<
       memset(&expr, 0, sizeof(expr));
       expr.global_eq = 0;
       std::vector<const Fr*> polys;
+      // leaf layer of (A, A + 1) tree pairs: c_A l r + c_B (l + 1)(r + 1) written out over the A tables alone, constant
+      // term included (prover.cpp prove_grand_product): half the tables in every round and in the residual exchange
+      bool pairs = active.size() % 2 == 0;
+      for (size_t k = 0; k < active.size() && pairs; k++) {
+        const size_t b = active[k];
+        pairs = trees[b].num_vars == h + 1 && (k % 2 == 0 ? !trees[b].plus_one : (trees[b].plus_one && active[k - 1] + 1 == b));
+      }
+      SumCheckResult sc;
+      if (pairs && 3 * (active.size() / 2) + 1 <= (size_t)LH_SC_MAX_TERMS) {
+        const size_t P = active.size() / 2;
+        HFr cw_sum = HFr::zero();
+        uint32_t t = 0;
+        for (size_t i = 0; i < P; i++) {
+          const size_t a = active[2 * i], bb = active[2 * i + 1];
+          const HFr c_a = power, c_b = power * lam, cs = c_a + c_b;
+          claim += claims[a] * c_a + claims[bb] * c_b;
+          power = c_b * lam;
+          cw_sum += c_b;
+          const uint8_t li = (uint8_t)(2 * i), ri = (uint8_t)(2 * i + 1);
+          memcpy(&expr.coeff[t], &cs, 32), expr.num_factors[t] = 2, expr.factor[t][0] = li, expr.factor[t][1] = ri, t++;
+          memcpy(&expr.coeff[t], &c_b, 32), expr.num_factors[t] = 1, expr.factor[t][0] = li, t++;
+          memcpy(&expr.coeff[t], &c_b, 32), expr.num_factors[t] = 1, expr.factor[t][0] = ri, t++;
+          polys.push_back(level[a][h]);
+          polys.push_back(level[a][h] + half);
+        }
+        memcpy(&expr.coeff[t], &cw_sum, 32), expr.num_factors[t] = 0, t++;
+        expr.num_terms = t;
+        sc = sh ? sum_check_prove_sharded(c, LH_SC_EVALUATIONS, h, expr, polys.data(), polys.size(), y.data(), 1, claim, tr)
+                : sum_check_prove(c, LH_SC_EVALUATIONS, h, expr, polys.data(), polys.size(), y.data(), 1, claim, tr);
+        x = sc.challenges;
+        for (size_t i = 0; i < P; i++) {
+          const HFr l = sc.evals[2 * i], r = sc.evals[2 * i + 1];
+          evals.push_back(l), evals.push_back(r);
+          evals.push_back(l + HFr::one()), evals.push_back(r + HFr::one());
+        }
+      } else {
       for (size_t k = 0; k < active.size(); k++) {
         size_t b = active[k];
         claim += claims[b] * power;
@@ -118,12 +155,13 @@ static GrandProductResult prove_grand_product_sharded(Ctx& c, const std::vector<
         polys.push_back(level[b][h] + half);
       }
       expr.num_terms = (uint32_t)active.size();
-      SumCheckResult sc = sh ? sum_check_prove_sharded(c, LH_SC_EVALUATIONS, h, expr, polys.data(), polys.size(),
+      sc = sh ? sum_check_prove_sharded(c, LH_SC_EVALUATIONS, h, expr, polys.data(), polys.size(),
                                                        y.data(), 1, claim, tr)
                              : sum_check_prove(c, LH_SC_EVALUATIONS, h, expr, polys.data(), polys.size(), y.data(), 1,
                                                claim, tr);
       x = sc.challenges;
       evals = sc.evals;
+      }
     }
     tr.write_field_elements(evals);
     HFr mu = tr.squeeze_challenge();
@@ -499,7 +537,7 @@ void lasso_prove_sharded(Ctx& c, const Srs& srs, const lh_lasso_table& tb, size_
     k_lasso_rw_leaves(c, dim_l[j], E_l[i], rts_l[j], NL, dev(gamma), dev(gamma2), dev(tau), rs, ws);
     k_lasso_if_leaves(c, (int)tb.memory_subtable[i], (uint32_t)l, fcs[j], M, dev(gamma), dev(gamma2), dev(tau), in, fi);
     trees[2 * i] = ShardedLeaves{rs, n};
-    trees[2 * i + 1] = ShardedLeaves{ws, n};
+    trees[2 * i + 1] = ShardedLeaves{ws, n, true};
     trees[2 * alpha + 2 * i] = ShardedLeaves{in, l};
     trees[2 * alpha + 2 * i + 1] = ShardedLeaves{fi, l};
   }
