@@ -5,6 +5,7 @@
 #include <string.h>
 #include <algorithm>
 #include "dev.hpp"
+#include "ff_host.hpp"
 #include "reduce.cuh"
 
 namespace lh {
@@ -508,6 +509,52 @@ __device__ __forceinline__ Fr wide_reduce(const Wide& acc) {
   return r;
 }
 
+// The same sum with weights given TIMES R (w R^2 in memory, prescale_r on the host): one Montgomery REDUCTION of the
+// 10-limb accumulator (72 multiply-adds) returns sum_k w_k v_k in Montgomery form, instead of the two full
+// multiplications of wide_reduce (258).  acc < 2^320, so the result is below 2^64 + r < 2 r: one conditional subtraction.
+__device__ __forceinline__ Fr wide_redc(const Wide& acc) {
+  uint32_t a[18];
+#pragma unroll
+  for (int k = 0; k < 10; k++) a[k] = acc.l[k];
+#pragma unroll
+  for (int k = 10; k < 18; k++) a[k] = 0u;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const uint32_t m = a[i] * FrParams::INV;
+    uint64_t carry = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const uint64_t t = (uint64_t)m * FrParams::mod(j) + a[i + j] + carry;
+      a[i + j] = (uint32_t)t;
+      carry = t >> 32;
+    }
+#pragma unroll
+    for (int j = i + 8; j < 18; j++) {
+      const uint64_t t = (uint64_t)a[j] + carry;
+      a[j] = (uint32_t)t;
+      carry = t >> 32;
+    }
+  }
+  Fr r;
+#pragma unroll
+  for (int k = 0; k < 8; k++) r.l[k] = a[8 + k];
+  return reduce_once(r);
+}
+// host: w (Montgomery form) -> w R (Montgomery form), the weight wide_redc expects
+static Fr prescale_r(const Fr& w) {
+  static const host::Fr scale = [] {
+    uint64_t c[4];
+    for (int k = 0; k < 4; k++) c[k] = (uint64_t)FrParams::r1(2 * k) | ((uint64_t)FrParams::r1(2 * k + 1) << 32);
+    return host::Fr::from_canonical(c);  // the field element R mod r
+  }();
+  host::Fr h;
+  memcpy(&h, &w, sizeof(h));
+  h = h * scale;
+  Fr out;
+  memcpy(&out, &h, sizeof(out));
+  return out;
+}
+
 // out[i] = sum_k w_k fr_k[i] + sum_k w'_k u32_k[i]  (u32 columns of their own lengths, zero beyond)
 constexpr int LCM_MAX_FR = 8, LCM_MAX_SMALL = 24;
 struct LcMixed {
@@ -524,7 +571,7 @@ __global__ void lincomb_mixed_kernel(const LcMixed* __restrict__ pkp, size_t n, 
     Wide t = Wide::zero();
     for (int k = 0; k < pk.num_sm; k++)
       if (i < pk.sm_len[k]) wide_mac(t, pk.wsm[k], pk.sm[k][i]);
-    Fr acc = pk.num_sm ? wide_reduce(t) : Fr::zero();
+    Fr acc = pk.num_sm ? wide_redc(t) : Fr::zero();  // (wsm holds the weights times R)
     for (int k = 0; k < pk.num_fr; k++) acc = add(acc, mul(pk.fr[k][i], pk.wfr[k]));
     out[i] = acc;
   }
@@ -538,7 +585,7 @@ void k_lincomb_mixed(Ctx& c, const Fr* const* fr, const Fr* wfr, size_t num_fr, 
   memset(&pk, 0, sizeof(pk));
   pk.num_fr = (int)num_fr, pk.num_sm = (int)num_sm;
   for (size_t k = 0; k < num_fr; k++) pk.fr[k] = fr[k], pk.wfr[k] = wfr[k];
-  for (size_t k = 0; k < num_sm; k++) pk.sm[k] = sm[k], pk.sm_len[k] = sm_len[k], pk.wsm[k] = wsm[k];
+  for (size_t k = 0; k < num_sm; k++) pk.sm[k] = sm[k], pk.sm_len[k] = sm_len[k], pk.wsm[k] = prescale_r(wsm[k]);
   ArenaScope scope(c.arena);  // the argument block exceeds the 4 KB of kernel arguments: it travels through memory
   LcMixed* d_pk = (LcMixed*)c.arena.alloc(sizeof(LcMixed));
   LcMixed* h_pk = (LcMixed*)c.pin(65536);
@@ -906,17 +953,18 @@ void k_pack_u32(Ctx& c, const uint32_t* a, const uint32_t* b, uint32_t shift, si
 }
 
 // fingerprint h(a, v, t) = a*gamma^2 + v*gamma + t - tau
+// (gamma_r, gamma2_r, one_r: the weights times R, prescale_r - one Montgomery reduction per leaf, wide_redc)
 __global__ void lasso_rw_leaves_kernel(const uint32_t* __restrict__ dim, const uint32_t* __restrict__ e,
-                                       const uint32_t* __restrict__ ts, size_t n, Fr gamma, Fr gamma2, Fr tau,
+                                       const uint32_t* __restrict__ ts, size_t n, Fr gamma_r, Fr gamma2_r, Fr one_r, Fr tau,
                                        Fr* __restrict__ rs, Fr* __restrict__ ws) {
   const Fr one = Fr::one();
   GSTRIDE(i, n) {
     // three residue-times-small-integer products into one wide accumulator, one reduction (see `Wide` above)
     Wide t = Wide::zero();
-    wide_mac(t, gamma2, dim[i]);
-    wide_mac(t, gamma, e[i]);
-    wide_mac(t, one, ts[i]);
-    Fr h = sub(wide_reduce(t), tau);
+    wide_mac(t, gamma2_r, dim[i]);
+    wide_mac(t, gamma_r, e[i]);
+    wide_mac(t, one_r, ts[i]);
+    Fr h = sub(wide_redc(t), tau);
     rs[i] = h;
     ws[i] = add(h, one);
   }
@@ -925,8 +973,8 @@ __global__ void lasso_rw_leaves_kernel(const uint32_t* __restrict__ dim, const u
 // leaf[i] * leaf[i + n/2] (the trees split on the top bit), so the thread that makes both leaves also makes their
 // product - the level is not read back from HBM by a tree_up pass (2 x 32 B per leaf saved)
 __global__ void lasso_rw_leaves_up_kernel(const uint32_t* __restrict__ dim, const uint32_t* __restrict__ e,
-                                          const uint32_t* __restrict__ ts, size_t half, Fr gamma, Fr gamma2, Fr tau,
-                                          Fr* __restrict__ rs, Fr* __restrict__ ws, Fr* __restrict__ rs_up,
+                                          const uint32_t* __restrict__ ts, size_t half, Fr gamma_r, Fr gamma2_r, Fr one_r,
+                                          Fr tau, Fr* __restrict__ rs, Fr* __restrict__ ws, Fr* __restrict__ rs_up,
                                           Fr* __restrict__ ws_up) {
   const Fr one = Fr::one();
   GSTRIDE(i, half) {
@@ -935,10 +983,10 @@ __global__ void lasso_rw_leaves_up_kernel(const uint32_t* __restrict__ dim, cons
     for (int k = 0; k < 2; k++) {
       const size_t j = i + (k ? half : 0);
       Wide t = Wide::zero();
-      wide_mac(t, gamma2, dim[j]);
-      wide_mac(t, gamma, e[j]);
-      wide_mac(t, one, ts[j]);
-      h[k] = sub(wide_reduce(t), tau);
+      wide_mac(t, gamma2_r, dim[j]);
+      wide_mac(t, gamma_r, e[j]);
+      wide_mac(t, one_r, ts[j]);
+      h[k] = sub(wide_redc(t), tau);
       rs[j] = h[k];
     }
     const Fr w0 = add(h[0], one), w1 = add(h[1], one);
@@ -954,15 +1002,15 @@ void k_lasso_rw_leaves_up(Ctx& c, const uint32_t* dim, const uint32_t* e, const 
                           const Fr& gamma2, const Fr& tau, Fr* rs, Fr* ws, Fr* rs_up, Fr* ws_up) {
   ProfScope ps(c, "lasso_rw_leaves", (12.0 + (ws ? 64.0 : 32.0) + 32.0) * n, 6.0 * n, (double)n);
   if (n >= 2)
-    hipLaunchKernelGGL(lasso_rw_leaves_up_kernel, grid_for(n / 2), 256, 0, c.stream, dim, e, ts, n / 2, gamma, gamma2, tau,
-                       rs, ws, rs_up, ws_up);
+    hipLaunchKernelGGL(lasso_rw_leaves_up_kernel, grid_for(n / 2), 256, 0, c.stream, dim, e, ts, n / 2, prescale_r(gamma),
+                       prescale_r(gamma2), prescale_r(Fr::one()), tau, rs, ws, rs_up, ws_up);
 }
 void k_lasso_rw_leaves(Ctx& c, const uint32_t* dim, const uint32_t* e, const uint32_t* ts, size_t n, const Fr& gamma,
                        const Fr& gamma2, const Fr& tau, Fr* rs, Fr* ws) {
   ProfScope ps(c, "lasso_rw_leaves", (12.0 + 64.0) * n, 5.0 * n, (double)n);
   if (n)
-    hipLaunchKernelGGL(lasso_rw_leaves_kernel, grid_for(n), 256, 0, c.stream, dim, e, ts, n, gamma, gamma2, tau, rs,
-                       ws);
+    hipLaunchKernelGGL(lasso_rw_leaves_kernel, grid_for(n), 256, 0, c.stream, dim, e, ts, n, prescale_r(gamma),
+                       prescale_r(gamma2), prescale_r(Fr::one()), tau, rs, ws);
 }
 __global__ void lasso_if_leaves_kernel(int kind, uint32_t bits, const uint32_t* __restrict__ final_cts, size_t m,
                                        Fr gamma, Fr gamma2, Fr tau, Fr* __restrict__ init, Fr* __restrict__ fin) {
