@@ -104,8 +104,13 @@ LassoColumns lasso_witness_columns(Ctx& c, const lh_lasso_table& tb, size_t n, c
   LassoG g;
   memset(&g, 0, sizeof(g));
   for (size_t i = 0; i < alpha; i++) {
-    w.E[i] = c.arena.alloc_n<uint32_t>(N);
-    k_lasso_subtable_read(c, (int)tb.memory_subtable[i], (uint32_t)l, d_dims[tb.memory_chunk[i]], N, w.E[i]);
+    if (tb.memory_subtable[i] == LH_SUBTABLE_IDENTITY) {
+      // E = dim entry by entry: the same column (read-only everywhere; the batch opening merges columns it is handed twice)
+      w.E[i] = const_cast<uint32_t*>(d_dims[tb.memory_chunk[i]]);
+    } else {
+      w.E[i] = c.arena.alloc_n<uint32_t>(N);
+      k_lasso_subtable_read(c, (int)tb.memory_subtable[i], (uint32_t)l, d_dims[tb.memory_chunk[i]], N, w.E[i]);
+    }
     g.e[i] = w.E[i];
   }
   if (a_small_out) {

@@ -1276,9 +1276,18 @@ void additive_batch_open(Ctx& c, size_t num_vars, const Fr* const* d_polys, size
       used[evals[i].poly] = 1;
     }
     SmallOpen so;
-    for (size_t pi = 0; pi < num_polys; pi++)
-      if (used[pi])
-        so.cols.push_back(SmallPoly{small[pi].ptr, std::min(small[pi].len, n), small[pi].bits}), so.coef.push_back(coef[pi]);
+    for (size_t pi = 0; pi < num_polys; pi++) {
+      if (!used[pi]) continue;
+      const SmallPoly sp{small[pi].ptr, std::min(small[pi].len, n), small[pi].bits};
+      size_t k = 0;  // the same column under two names (Lasso's E = dim for an identity subtable): one coefficient
+      while (k < so.cols.size() && !(so.cols[k].ptr == sp.ptr && so.cols[k].len == sp.len)) k++;
+      if (k < so.cols.size()) {
+        so.coef[k] += coef[pi];
+        so.cols[k].bits = so.cols[k].bits && sp.bits ? std::max(so.cols[k].bits, sp.bits) : 0;
+      } else {
+        so.cols.push_back(sp), so.coef.push_back(coef[pi]);
+      }
+    }
     open_small(g_prime, sc.challenges.data(), so);
     return;
   }
