@@ -224,10 +224,17 @@ HFr mkzg_open(Ctx&, const Srs&, const Fr* d_poly, size_t num_vars, const HFr* po
               const SmallOpen* small = nullptr);
 // a poly handed over as its small-valued u32 column (`len` entries, zero beyond): Lasso's dim / read_ts / E / final_cts
 // reach the batch opening without a field-element view (d_polys[i] may then be null)
+struct SmallLinear {  // column = sum_k coeff[k] * (the column of poly[k]) entry by entry (poly: indices of the same opening)
+  std::vector<size_t> poly;
+  std::vector<HFr> coeff;
+};
 struct SmallPoly {
   const uint32_t* ptr = nullptr;
   size_t len = 0;
   uint32_t bits = 0;  // every entry < 2^bits when the caller knows (0: unknown)
+  // optional: this column is an exact linear combination of other columns of the opening (Lasso's output a = g(E) under a
+  // linear g): the small-column opening then folds its coefficient into theirs and never touches it
+  const SmallLinear* linear = nullptr;
 };
 void mkzg_batch_open(Ctx&, const Srs&, size_t num_vars, const Fr* const* d_polys, size_t num_polys,
                      const HFr* points, size_t num_points, const lh_evaluation* evals, size_t num_evals,

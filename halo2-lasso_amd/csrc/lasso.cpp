@@ -414,8 +414,15 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
     if (len < NV) LH_HIP(hipMemsetAsync(d + len, 0, (NV - len) * sizeof(Fr), c.stream));
     return d;
   };
+  SmallLinear a_linear;  // a = sum_m coeff_m E_{f(m)} entry by entry (linear g)
   if (a_small) {
-    small[0] = SmallPoly{a_small, N, 0};
+    for (uint32_t m = 0; m < tb.num_terms; m++) {
+      HFr co;
+      memcpy(&co, &tb.g_coeff[m], 32);
+      a_linear.poly.push_back(1 + 2 * cc + tb.g_factor[m][0]);
+      a_linear.coeff.push_back(co);
+    }
+    small[0] = SmallPoly{a_small, N, 0, &a_linear};
   } else if (N < NV) {  // l > n: the output column needs the padding too
     Fr* ap = c.arena.alloc_n<Fr>(NV);
     LH_HIP(hipMemcpyAsync(ap, a, N * sizeof(Fr), hipMemcpyDeviceToDevice, c.stream));

@@ -1275,6 +1275,17 @@ void additive_batch_open(Ctx& c, size_t num_vars, const Fr* const* d_polys, size
       coef[evals[i].poly] += eq_xt[i] * hst(w[evals[i].point]);
       used[evals[i].poly] = 1;
     }
+    // a column that is a linear combination of other opened columns hands its coefficient over to them
+    for (size_t pi = 0; pi < num_polys; pi++) {
+      const SmallLinear* lin = small[pi].linear;
+      if (!used[pi] || !lin) continue;
+      bool ok = !lin->poly.empty() && lin->poly.size() == lin->coeff.size();
+      for (size_t k = 0; k < lin->poly.size() && ok; k++) ok = lin->poly[k] < num_polys && lin->poly[k] != pi && used[lin->poly[k]];
+      if (!ok) continue;
+      for (size_t k = 0; k < lin->poly.size(); k++) coef[lin->poly[k]] += coef[pi] * lin->coeff[k];
+      coef[pi] = HFr::zero();
+      used[pi] = 0;
+    }
     SmallOpen so;
     for (size_t pi = 0; pi < num_polys; pi++) {
       if (!used[pi]) continue;
