@@ -190,6 +190,8 @@ void k_bind_first(Ctx&, const Fr* const* in, size_t count, const Fr& x, Fr* out_
 // out_host (pinned) [i*k + j] = in[i][j], j < k ; synchronises
 void k_gather_heads(Ctx&, const Fr* const* in, size_t count, int k, Fr* out_host);
 void k_lincomb(Ctx&, const Fr* const* polys, const Fr* w, size_t count, size_t n, Fr* out);
+// out[b] = lo + x (hi - lo), lo = sum_k w_k p_k[b], hi = sum_k w_k p_k[b + half]
+void k_lincomb_fold(Ctx&, const Fr* const* polys, const Fr* w, size_t count, size_t half, const Fr& x, Fr* out);
 // out[i] = <polys[i], weights>, i < count ; result on host
 void k_inner_products(Ctx&, const Fr* const* polys, size_t count, const Fr* weights, size_t n, Fr* out_host);
 // same with u32-valued polys

@@ -244,6 +244,10 @@ void mkzg_batch_open(Ctx&, const Srs&, size_t num_vars, const Fr* const* d_polys
 struct SmallOpen {
   std::vector<SmallPoly> cols;
   std::vector<HFr> coef;
+  // the same g' as a combination of field-element tables (the merged polys of the batch opening): when the opening is
+  // handed a null g', it forms what it needs from these (the first fold directly, g' itself only on the plain route)
+  std::vector<const Fr*> merged;
+  std::vector<Fr> merged_w;
 };
 // `open_small` (optional) is called instead of `open` when every opened poly came as a small-valued column
 void additive_batch_open(Ctx&, size_t num_vars, const Fr* const* d_polys, size_t num_polys, const HFr* points,

@@ -396,6 +396,26 @@ __global__ void lincomb_kernel(LcPack pk, int count, size_t n, Fr* __restrict__ 
     out[i] = acc;
   }
 }
+// first step of an mKZG opening of g = sum_k w_k p_k without forming g: out[b] = lo + x (hi - lo) with lo = g[b],
+// hi = g[b + half] (the quotient hi - lo itself is committed another way: prover.cpp mkzg_open, SmallOpen)
+__global__ void lincomb_fold_kernel(LcPack pk, int count, size_t half, Fr x, Fr* __restrict__ out) {
+  GSTRIDE(i, half) {
+    Fr lo = Fr::zero(), hi = Fr::zero();
+    for (int k = 0; k < count; k++) {
+      lo = add(lo, mul(pk.p[k][i], pk.w[k]));
+      hi = add(hi, mul(pk.p[k][half + i], pk.w[k]));
+    }
+    out[i] = add(lo, mul(sub(hi, lo), x));
+  }
+}
+void k_lincomb_fold(Ctx& c, const Fr* const* polys, const Fr* w, size_t count, size_t half, const Fr& x, Fr* out) {
+  LH_REQUIRE(count >= 1 && count <= (size_t)LC_MAX, LH_ERR_ARG, "lincomb_fold: bad input count");
+  ProfScope ps(c, "lincomb", 32.0 * half * (2 * count + 1), (2.0 * count + 1.0) * half, (double)half);
+  if (!half) return;
+  LcPack pk;
+  for (size_t i = 0; i < count; i++) pk.p[i] = polys[i], pk.w[i] = w[i];
+  hipLaunchKernelGGL(lincomb_fold_kernel, grid_for(half), 256, 0, c.stream, pk, (int)count, half, x, out);
+}
 void k_lincomb(Ctx& c, const Fr* const* polys, const Fr* w, size_t count, size_t n, Fr* out) {
   ProfScope ps(c, "lincomb", 32.0 * n * (count + 1), 1.0 * n * count, (double)n);
   if (!n) return;

@@ -1025,9 +1025,18 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
     const char* e = getenv("LH_OPEN_SMALL_MIN_VARS");  // smallest opening that takes the column route (64: never)
     return e ? (size_t)atoll(e) : (size_t)21;
   }();
+  const SmallOpen* given = small;
   if (small && (num_vars < small_min_vars || num_vars < 2 || small->cols.empty())) small = nullptr;
   ArenaScope scope(c.arena);
   const size_t n = (size_t)1 << num_vars;
+  if (!d_poly) {
+    LH_REQUIRE(given && !given->merged.empty(), LH_ERR_ARG, "open: no polynomial");
+    if (!small) {  // the plain route needs g' itself
+      Fr* g = c.arena.alloc_n<Fr>(n);
+      k_lincomb(c, given->merged.data(), given->merged_w.data(), given->merged.size(), n, g);
+      d_poly = g;
+    }
+  }
   Fr* q = c.arena.alloc_n<Fr>(n);  // n - 1 used
   Fr* remA = c.arena.alloc_n<Fr>(std::max<size_t>(n >> 1, 1));
   Fr* remB = c.arena.alloc_n<Fr>(std::max<size_t>(n >> 2, 1));
@@ -1035,7 +1044,10 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
   for (size_t i = num_vars; i-- > 0;) {
     size_t half = (size_t)1 << i;
     Fr* dst = ((num_vars - i) & 1) ? remA : remB;
-    k_quotient_step(c, rem, half, dev(point[i]), small && i + 1 == num_vars ? nullptr : q + (half - 1), dst);
+    if (!rem)  // first step of the column route straight from the merged tables (g' is never formed)
+      k_lincomb_fold(c, small->merged.data(), small->merged_w.data(), small->merged.size(), half, dev(point[i]), dst);
+    else
+      k_quotient_step(c, rem, half, dev(point[i]), small && i + 1 == num_vars ? nullptr : q + (half - 1), dst);
     rem = dst;
   }
   HFr remainder;
@@ -1263,8 +1275,6 @@ void additive_batch_open(Ctx& c, size_t num_vars, const Fr* const* d_polys, size
   std::vector<Fr> w(num_points);
   for (size_t j = 0; j < num_points; j++)
     w[j] = dev(host_eq_xy_eval(sc.challenges.data(), points + j * num_vars, num_vars));
-  Fr* g_prime = c.arena.alloc_n<Fr>(n);
-  k_lincomb(c, merged.data(), w.data(), num_points, n, g_prime);
   // every opened poly a small-valued column: g' = sum_p coef_p col_p with coef_p = sum_{i: poly(i) = p} eq_xt[i] w[point(i)]
   bool all_small = open_small != nullptr && small != nullptr;
   for (size_t i = 0; i < num_evals && all_small; i++) all_small = small[evals[i].poly].ptr != nullptr;
@@ -1299,9 +1309,13 @@ void additive_batch_open(Ctx& c, size_t num_vars, const Fr* const* d_polys, size
         so.cols.push_back(sp), so.coef.push_back(coef[pi]);
       }
     }
-    open_small(g_prime, sc.challenges.data(), so);
+    so.merged = merged;
+    so.merged_w = w;
+    open_small(nullptr, sc.challenges.data(), so);  // (g' is formed by the opening if it needs it)
     return;
   }
+  Fr* g_prime = c.arena.alloc_n<Fr>(n);
+  k_lincomb(c, merged.data(), w.data(), num_points, n, g_prime);
   open(g_prime, sc.challenges.data());
 }
 
