@@ -456,6 +456,9 @@ struct MsmJob {
   // bucket set indexed by the packed value; the reduction weighs it twice: out[j] = sum s1[i] B_i, *out_second = sum s2[i] B_i.
   uint32_t pack_shift = 0;
   G1Affine* out_second = nullptr;  // host
+  // Optional: every scalar < 2^known_bits, promised by the caller (0: measured by a pass over the scalars - a column
+  // that happens to be narrower then gets fewer windows; a promise that is too small loses the upper bits)
+  uint32_t known_bits = 0;
 };
 constexpr uint32_t MSM_PACK_MAX_BITS = 20;
 // Runs all jobs as one batched Pippenger; out[j] is the affine sum (identity = (0,0)).

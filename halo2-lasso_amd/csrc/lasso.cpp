@@ -336,6 +336,7 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
     std::vector<size_t> dim_job(cc);
     for (size_t j = 0; j < cc; j++) {
       dim_job[j] = jobs.size(), add_job(1 + j, d_dims[j], true, N);
+      jobs.back().known_bits = (uint32_t)l;  // (the access counters rejected any index >= 2^l)
       if (!w.dim_sorted.empty()) jobs.back().sorted_scalars = w.dim_sorted[j], jobs.back().sorted_index = w.dim_index[j];
     }
     // read_ts columns are small (a cell's access count): two of them share one pass over the points when their bit
@@ -357,12 +358,14 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
           uint32_t* packed = c.arena.alloc_n<uint32_t>(N);
           k_pack_u32(c, rts[j], rts[j + 1], b0, N, packed);
           add_job(1 + cc + j, packed, true, N);
+          jobs.back().known_bits = b0 + b1;
           jobs.back().pack_shift = b0;
           jobs.back().out_second = (G1Affine*)&second[j + 1];
           second_of.push_back(j + 1);
           j++;
         } else {
           add_job(1 + cc + j, rts[j], true, N);
+          jobs.back().known_bits = bits_of(ors[j]);  // (0 when the counts were not looked at: measured then)
         }
       }
     }
@@ -379,8 +382,12 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
           orders.get((int)tb.memory_subtable[i], &jb.d_table, &jb.d_order);
           jb.table_in_bits = (uint32_t)l, jb.table_out_bits = (uint32_t)(l / 2);
         }
+        jobs.back().known_bits = (uint32_t)(l / 2);  // AND / XOR of two (l/2)-bit halves
       }
-    for (size_t j = 0; j < cc; j++) add_job(1 + 2 * cc + alpha + j, fcs[j], true, M);
+    for (size_t j = 0; j < cc; j++) {
+      add_job(1 + 2 * cc + alpha + j, fcs[j], true, M);
+      jobs.back().known_bits = count_ors[j] ? 32u - (uint32_t)__builtin_clz(count_ors[j]) : 0u;
+    }
     std::vector<HG1> part(jobs.size()), comms(total);
     msm_batch(c, jobs.data(), jobs.size(), (G1Affine*)part.data());
     for (size_t k = 0; k < jobs.size(); k++) comms[slot[k]] = part[k];

@@ -511,12 +511,18 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
         any_fr |= in.n != 0;
         max_n0 = std::max(max_n0, in.n);
       }
-      if (any_fr) {
+      bool any_unknown = false;
+      MsmPlanDev or_plan = plan;  // (jobs whose width the caller promises take no part in the pass)
+      for (size_t j = 0; j < nj; j++) {
+        if (jobs[base + j].known_bits) or_plan.job[j].n = 0;
+        else any_unknown |= jobs[base + j].n != 0;
+      }
+      if (any_fr && any_unknown) {
         ArenaScope scope(c.arena);
         uint32_t* d_or = c.arena.alloc_n<uint32_t>(8 * nj);
         LH_HIP(hipMemsetAsync(d_or, 0, 8 * nj * sizeof(uint32_t), c.stream));
         dim3 g((unsigned)std::min<size_t>((max_n0 + 255) / 256, 256), (unsigned)nj);
-        hipLaunchKernelGGL(msm_or_limbs_kernel, g, dim3(256), 0, c.stream, plan, d_or);
+        hipLaunchKernelGGL(msm_or_limbs_kernel, g, dim3(256), 0, c.stream, or_plan, d_or);
         uint32_t* h_or = (uint32_t*)c.pin(8 * MSM_MAX_JOBS * sizeof(uint32_t));
         LH_HIP(hipMemcpyAsync(h_or, d_or, 8 * nj * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
         c.sync();
@@ -527,6 +533,8 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
           job_bits[j] = bits;  // 0: all-zero column
         }
       }
+      for (size_t j = 0; j < nj; j++)
+        if (jobs[base + j].known_bits) job_bits[j] = jobs[base + j].n ? std::min<uint32_t>(jobs[base + j].known_bits, jobs[base + j].scalars_u32 ? 32u : 254u) : 0;
     }
     // derived jobs (MsmJob::derived_parent): usable when the parent is a u32 column of the same points whose single
     // window is indexed by its value (window bits == significant bits <= the table's input bits)

@@ -1060,6 +1060,7 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
   for (size_t i = 0; i < plain; i++) {
     size_t half = (size_t)1 << i;
     jobs[i] = MsmJob{q + (half - 1), false, srs.eq(i), half};
+    if (small) jobs[i].known_bits = 254;  // quotients of a random combination: full-size scalars, nothing to measure
   }
   // ---- the top quotient, column by column
   struct Term {     // result of job `job` (or its second output), times `scale`, goes into the commitment
@@ -1119,8 +1120,10 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
         uint32_t* hi = c.arena.alloc_n<uint32_t>(half);
         k_delta_u32(c, sp.ptr, sp.len, half, off, lo, hi);
         jobs.push_back(MsmJob{lo, true, bases, half});
+        jobs.back().known_bits = 16;
         terms.push_back(Term{jobs.size() - 1, false, co});
         jobs.push_back(MsmJob{hi, true, bases, half});
+        jobs.back().known_bits = b + 1 - 16;
         terms.push_back(Term{jobs.size() - 1, false, co * HFr::from_u64(65536)});
         continue;
       }
@@ -1130,6 +1133,7 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
         narrow.push_back(Narrow{k, b + 1, d});
       } else {
         jobs.push_back(MsmJob{d, true, bases, half});
+        jobs.back().known_bits = b + 1;
         terms.push_back(Term{jobs.size() - 1, false, co});
       }
     }
@@ -1144,6 +1148,7 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
         k_pack_u32(c, a.col, b2.col, shift, half, packed);
         MsmJob jb{packed, true, bases, half};
         jb.pack_shift = shift;
+        jb.known_bits = shift + b2.bits;
         jb.out_second = (G1Affine*)&seconds[b2.k];
         jobs.push_back(jb);
         terms.push_back(Term{jobs.size() - 1, false, small->coef[a.k]});
@@ -1151,6 +1156,7 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
         i++;
       } else {
         jobs.push_back(MsmJob{a.col, true, bases, half});
+        jobs.back().known_bits = a.bits;
         terms.push_back(Term{jobs.size() - 1, false, small->coef[a.k]});
       }
     }
@@ -1169,6 +1175,7 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
       uint32_t* ones = c.arena.alloc_n<uint32_t>(half);
       k_fill_u32(c, ones, 1u, half);
       jobs.push_back(MsmJob{ones, true, srs.eq(top), half});
+      jobs.back().known_bits = 1;
       sum_job = jobs.size() - 1;
     }
   }
