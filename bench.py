@@ -467,7 +467,7 @@ def main():
         # N independent replicas first (no data-path collective: nothing in it can wait for another rank's GPU) - the extra
         # object of the sharded line, and the line itself if the sharded proof does not come back: a collective that never
         # completes cannot be caught as an exception, so a timer prints the replicas line and ends the process
-        # (LH_BENCH_SHARDED_TIMEOUT seconds, default 600; the sharded proof has never run on more than one GPU)
+        # (LH_BENCH_SHARDED_TIMEOUT seconds, default 240; the sharded proof has never run on more than one GPU)
         if not args.no_extra:
             extra_steps = max(1, min(args.steps, 3))
             own = [ctx.upload(c.tobytes()) for c in gen_dims(table, n, rank)]
@@ -498,7 +498,7 @@ def main():
                                           "LH_BENCH_SHARDED_TIMEOUT seconds"}}), flush=True)
                 os._exit(0)
             import threading
-            watchdog = threading.Timer(float(os.environ.get("LH_BENCH_SHARDED_TIMEOUT", "600")), give_up)
+            watchdog = threading.Timer(float(os.environ.get("LH_BENCH_SHARDED_TIMEOUT", "240")), give_up)
             watchdog.daemon = True
             watchdog.start()
         transport = hdist.attach_sharded(ctx, dist, shard_bit)
