@@ -1026,7 +1026,15 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
     return e ? (size_t)atoll(e) : (size_t)21;
   }();
   const SmallOpen* given = small;
-  if (small && (num_vars < small_min_vars || num_vars < 2 || small->cols.empty())) small = nullptr;
+  if (small && num_vars < small_min_vars) {
+    // below the general threshold the route still pays when only a few columns take part (the range check: two dim
+    // and two read_ts columns - 2^20 lookups 11.7 -> 11.0 ms; the AND table's twelve columns lose there)
+    size_t full = 0;
+    for (size_t k = 0; k < small->cols.size(); k++)
+      full += small->cols[k].len > ((size_t)1 << (num_vars - 1)) && !small->coef[k].is_zero();
+    if (!(num_vars >= 17 && full <= 4 && !getenv("LH_OPEN_SMALL_MIN_VARS"))) small = nullptr;
+  }
+  if (small && (num_vars < 2 || small->cols.empty())) small = nullptr;
   ArenaScope scope(c.arena);
   const size_t n = (size_t)1 << num_vars;
   if (!d_poly) {
