@@ -1045,6 +1045,51 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
       d_poly = g;
     }
   }
+  // ---- which quotient levels go column by column: the largest always; the second largest too when few columns take
+  // part.  After d folds the remainder is sum_s w_s g'[s 2^(n-d) + .] over the 2^d settings s of the top d index bits
+  // (w_s = the product of x_j or 1 - x_j over those bits), so the quotient of level n-1-d is the same kind of sum of
+  // 2^d differences of sub-columns per column: 2^d times the passes of the top level, against ~15 windows.
+  auto bits_of = [](uint32_t v) { return v ? 32u - (uint32_t)__builtin_clz(v) : 0u; };
+  size_t depth = 0;
+  std::vector<uint32_t> ors;
+  if (small) {
+    const size_t K = small->cols.size(), half_top = (size_t)1 << (num_vars - 1);
+    ors.assign(K, 0);
+    std::map<size_t, std::vector<size_t>> by_len;  // one OR pass per column length (normally none: the widths are known)
+    for (size_t k = 0; k < K; k++) {
+      // (every column that can reach past the low half of a sub-column at either depth needs its width)
+      if (small->cols[k].len <= (half_top >> 1) || small->coef[k].is_zero()) continue;
+      if (small->cols[k].bits) ors[k] = small->cols[k].bits >= 32 ? 0xffffffffu : (1u << small->cols[k].bits) - 1u;  // known bound
+      else by_len[small->cols[k].len].push_back(k);
+    }
+    for (const auto& grp : by_len) {
+      std::vector<const uint32_t*> ptrs;
+      for (size_t k : grp.second) ptrs.push_back(small->cols[k].ptr);
+      std::vector<uint32_t> o(ptrs.size(), 0);
+      k_or_u32(c, ptrs.data(), ptrs.size(), grp.first, o.data());
+      for (size_t f = 0; f < ptrs.size(); f++) ors[grp.second[f]] = o[f];
+    }
+    size_t passes = 0, narrow_cols = 0;
+    for (size_t k = 0; k < K; k++) {
+      if (small->cols[k].len <= half_top || small->coef[k].is_zero() || !ors[k]) continue;
+      const uint32_t b1 = bits_of(ors[k]) + 1;
+      if (b1 > 32) passes += 2;
+      else if (b1 <= MSM_PACK_MAX_BITS - 4) narrow_cols++;
+      else passes += 1;
+    }
+    passes += (narrow_cols + 1) / 2;
+    static const int forced_depth = [] {
+      const char* e = getenv("LH_OPEN_SMALL_DEPTH");  // development: 1 or 2 levels column by column, whatever the shape
+      return e ? atoi(e) : 0;
+    }();
+    depth = 1;
+    if (num_vars >= 3 && (forced_depth ? forced_depth >= 2 : 2 * passes <= 10)) depth = 2;
+  }
+  // development (LH_OPEN_SMALL_CHECK): the column-wise levels whose quotient exists are committed the plain way too and
+  // compared (stderr)
+  static const bool self_check_env = getenv("LH_OPEN_SMALL_CHECK") != nullptr;
+  const bool self_check = self_check_env && small;
+  const size_t check_from = d_poly ? 0 : 1;  // (the first fold of a lazy g' leaves no quotient to compare with)
   Fr* q = c.arena.alloc_n<Fr>(n);  // n - 1 used
   Fr* remA = c.arena.alloc_n<Fr>(std::max<size_t>(n >> 1, 1));
   Fr* remB = c.arena.alloc_n<Fr>(std::max<size_t>(n >> 2, 1));
@@ -1055,7 +1100,7 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
     if (!rem)  // first step of the column route straight from the merged tables (g' is never formed)
       k_lincomb_fold(c, small->merged.data(), small->merged_w.data(), small->merged.size(), half, dev(point[i]), dst);
     else
-      k_quotient_step(c, rem, half, dev(point[i]), small && i + 1 == num_vars ? nullptr : q + (half - 1), dst);
+      k_quotient_step(c, rem, half, dev(point[i]), i + depth >= num_vars && !self_check ? nullptr : q + (half - 1), dst);
     rem = dst;
   }
   HFr remainder;
@@ -1063,150 +1108,159 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
     download(c, &remainder, d_poly, sizeof(Fr));
     return remainder;
   }
-  const size_t plain = small ? num_vars - 1 : num_vars;
+  const size_t plain = num_vars - depth;
   std::vector<MsmJob> jobs(plain);
   for (size_t i = 0; i < plain; i++) {
     size_t half = (size_t)1 << i;
     jobs[i] = MsmJob{q + (half - 1), false, srs.eq(i), half};
     if (small) jobs[i].known_bits = 254;  // quotients of a random combination: full-size scalars, nothing to measure
   }
-  // ---- the top quotient, column by column
+  // ---- the column-wise levels
   struct Term {     // result of job `job` (or its second output), times `scale`, goes into the commitment
     size_t job;
     bool second;
     HFr scale;
   };
-  std::vector<Term> terms;
+  struct ColumnLevel {
+    size_t level = 0;             // quotient level (number of variables)
+    std::vector<Term> terms;
+    HFr offset_total;             // sum coef * offset: times the level's base sum, subtracted
+    bool need_sum = false;
+    size_t sum_job = (size_t)-1;  // the all-ones MSM when the level's base sum is not cached yet
+    HG1 base_sum;
+  };
+  std::vector<ColumnLevel> col_levels(depth);
   std::vector<HG1> seconds;
-  HFr offset_total = HFr::zero();  // sum_k coef_k * offset_k: times the level's base sum, subtracted
-  bool need_sum = false;
-  if (small) {
-    const size_t top = num_vars - 1, half = (size_t)1 << top;
-    const G1Affine* bases = srs.eq(top);
-    const size_t K = small->cols.size();
-    // bit lengths of the full columns (one pass)
-    std::vector<uint32_t> ors(K, 0);
-    {
-      std::map<size_t, std::vector<size_t>> by_len;  // one OR pass per column length (normally a single one)
-      for (size_t k = 0; k < K; k++) {
-        if (small->cols[k].len <= half || small->coef[k].is_zero()) continue;
-        if (small->cols[k].bits) ors[k] = small->cols[k].bits >= 32 ? 0xffffffffu : (1u << small->cols[k].bits) - 1u;  // known bound
-        else by_len[small->cols[k].len].push_back(k);
-      }
-      for (const auto& grp : by_len) {
-        std::vector<const uint32_t*> ptrs;
-        for (size_t k : grp.second) ptrs.push_back(small->cols[k].ptr);
-        std::vector<uint32_t> o(ptrs.size(), 0);
-        k_or_u32(c, ptrs.data(), ptrs.size(), grp.first, o.data());
-        for (size_t f = 0; f < ptrs.size(); f++) ors[grp.second[f]] = o[f];
-      }
-    }
-    auto bits_of = [](uint32_t v) { return v ? 32u - (uint32_t)__builtin_clz(v) : 0u; };
+  seconds.reserve(64);
+  size_t num_seconds = 0;
+  for (size_t d = 0; d < depth; d++) num_seconds += small->cols.size() << d;
+  seconds.resize(num_seconds);
+  size_t next_second = 0;
+  for (size_t d = 0; d < depth; d++) {
+    ColumnLevel& cl = col_levels[d];
+    cl.level = num_vars - 1 - d;
+    cl.offset_total = HFr::zero();
+    const size_t half = (size_t)1 << cl.level;
+    const G1Affine* bases = srs.eq(cl.level);
     struct Narrow {
-      size_t k;
       uint32_t bits;  // of the shifted difference
       uint32_t* col;
+      HFr coef;
     };
     std::vector<Narrow> narrow;
-    seconds.resize(K);
-    for (size_t k = 0; k < K; k++) {
-      const SmallPoly& sp = small->cols[k];
-      const HFr& co = small->coef[k];
-      if (co.is_zero() || !sp.len) continue;
-      if (sp.len <= half) {  // only the low half is populated: hi - lo = -lo, no offset
-        jobs.push_back(MsmJob{sp.ptr, true, bases, sp.len});
-        terms.push_back(Term{jobs.size() - 1, false, HFr::zero() - co});
-        continue;
+    for (size_t sidx = 0; sidx < ((size_t)1 << d); sidx++) {
+      // weight of this setting of the top d index bits (bit n-1-j of the index is bit d-1-j of sidx)
+      HFr w_s = HFr::one();
+      for (size_t j = 0; j < d; j++) {
+        const HFr& xj = point[num_vars - 1 - j];
+        w_s *= ((sidx >> (d - 1 - j)) & 1) ? xj : HFr::one() - xj;
       }
-      const uint32_t b = bits_of(ors[k]);
-      if (!b) continue;  // an all-zero column
-      const uint64_t off = (uint64_t)1 << b;
-      offset_total += co * HFr::from_u64(off);
-      need_sum = true;
-      if (b + 1 > 32) {  // 33-bit shifted differences: a 16-bit limb and a 17-bit limb
-        uint32_t* lo = c.arena.alloc_n<uint32_t>(half);
-        uint32_t* hi = c.arena.alloc_n<uint32_t>(half);
-        k_delta_u32(c, sp.ptr, sp.len, half, off, lo, hi);
-        jobs.push_back(MsmJob{lo, true, bases, half});
-        jobs.back().known_bits = 16;
-        terms.push_back(Term{jobs.size() - 1, false, co});
-        jobs.push_back(MsmJob{hi, true, bases, half});
-        jobs.back().known_bits = b + 1 - 16;
-        terms.push_back(Term{jobs.size() - 1, false, co * HFr::from_u64(65536)});
-        continue;
-      }
-      uint32_t* d = c.arena.alloc_n<uint32_t>(half);
-      k_delta_u32(c, sp.ptr, sp.len, half, off, d, nullptr);
-      if (b + 1 <= MSM_PACK_MAX_BITS - 4) {
-        narrow.push_back(Narrow{k, b + 1, d});
-      } else {
-        jobs.push_back(MsmJob{d, true, bases, half});
-        jobs.back().known_bits = b + 1;
-        terms.push_back(Term{jobs.size() - 1, false, co});
+      const size_t off_idx = sidx << (cl.level + 1);
+      for (size_t k = 0; k < small->cols.size(); k++) {
+        const SmallPoly& sp = small->cols[k];
+        if (small->coef[k].is_zero() || sp.len <= off_idx) continue;
+        const HFr co = small->coef[k] * w_s;
+        const uint32_t* sub = sp.ptr + off_idx;
+        const size_t sub_len = std::min(sp.len - off_idx, half << 1);
+        if (sub_len <= half) {  // only the low half is populated: hi - lo = -lo, no offset
+          jobs.push_back(MsmJob{sub, true, bases, sub_len});
+          if (sp.bits) jobs.back().known_bits = sp.bits;
+          cl.terms.push_back(Term{jobs.size() - 1, false, HFr::zero() - co});
+          continue;
+        }
+        const uint32_t b = bits_of(ors[k]);
+        if (!b) continue;  // an all-zero column
+        const uint64_t off = (uint64_t)1 << b;
+        cl.offset_total += co * HFr::from_u64(off);
+        cl.need_sum = true;
+        if (b + 1 > 32) {  // 33-bit shifted differences: a 16-bit limb and a 17-bit limb
+          uint32_t* lo = c.arena.alloc_n<uint32_t>(half);
+          uint32_t* hi = c.arena.alloc_n<uint32_t>(half);
+          k_delta_u32(c, sub, sub_len, half, off, lo, hi);
+          jobs.push_back(MsmJob{lo, true, bases, half});
+          jobs.back().known_bits = 16;
+          cl.terms.push_back(Term{jobs.size() - 1, false, co});
+          jobs.push_back(MsmJob{hi, true, bases, half});
+          jobs.back().known_bits = b + 1 - 16;
+          cl.terms.push_back(Term{jobs.size() - 1, false, co * HFr::from_u64(65536)});
+          continue;
+        }
+        uint32_t* dcol = c.arena.alloc_n<uint32_t>(half);
+        k_delta_u32(c, sub, sub_len, half, off, dcol, nullptr);
+        if (b + 1 <= MSM_PACK_MAX_BITS - 4) {
+          narrow.push_back(Narrow{b + 1, dcol, co});
+        } else {
+          jobs.push_back(MsmJob{dcol, true, bases, half});
+          jobs.back().known_bits = b + 1;
+          cl.terms.push_back(Term{jobs.size() - 1, false, co});
+        }
       }
     }
     // narrow columns two by two (narrowest first) while the packed value stays within MSM_PACK_MAX_BITS
-    std::sort(narrow.begin(), narrow.end(), [](const Narrow& a, const Narrow& b) { return a.bits < b.bits; });
+    std::stable_sort(narrow.begin(), narrow.end(), [](const Narrow& x, const Narrow& y) { return x.bits < y.bits; });
     for (size_t i = 0; i < narrow.size(); i++) {
-      const Narrow& a = narrow[i];
-      const uint32_t shift = std::max(a.bits, 4u);
+      const Narrow& x = narrow[i];
+      const uint32_t shift = std::max(x.bits, 4u);
       if (i + 1 < narrow.size() && shift + narrow[i + 1].bits <= MSM_PACK_MAX_BITS) {
-        const Narrow& b2 = narrow[i + 1];
+        const Narrow& y = narrow[i + 1];
         uint32_t* packed = c.arena.alloc_n<uint32_t>(half);
-        k_pack_u32(c, a.col, b2.col, shift, half, packed);
+        k_pack_u32(c, x.col, y.col, shift, half, packed);
         MsmJob jb{packed, true, bases, half};
         jb.pack_shift = shift;
-        jb.known_bits = shift + b2.bits;
-        jb.out_second = (G1Affine*)&seconds[b2.k];
+        jb.known_bits = shift + y.bits;
+        jb.out_second = (G1Affine*)&seconds[next_second++];
         jobs.push_back(jb);
-        terms.push_back(Term{jobs.size() - 1, false, small->coef[a.k]});
-        terms.push_back(Term{jobs.size() - 1, true, small->coef[b2.k]});
+        cl.terms.push_back(Term{jobs.size() - 1, false, x.coef});
+        cl.terms.push_back(Term{jobs.size() - 1, true, y.coef});
         i++;
       } else {
-        jobs.push_back(MsmJob{a.col, true, bases, half});
-        jobs.back().known_bits = a.bits;
-        terms.push_back(Term{jobs.size() - 1, false, small->coef[a.k]});
+        jobs.push_back(MsmJob{x.col, true, bases, half});
+        jobs.back().known_bits = x.bits;
+        cl.terms.push_back(Term{jobs.size() - 1, false, x.coef});
+      }
+    }
+    // the level's base sum (an MSM with all-one scalars, once per SRS and level)
+    if (cl.need_sum) {
+      std::lock_guard<std::mutex> lock(level_sums_mu);
+      auto it = srs.level_sums.find(cl.level);
+      if (it != srs.level_sums.end()) {
+        cl.base_sum = it->second;
+      } else {
+        uint32_t* ones = c.arena.alloc_n<uint32_t>(half);
+        k_fill_u32(c, ones, 1u, half);
+        jobs.push_back(MsmJob{ones, true, bases, half});
+        jobs.back().known_bits = 1;
+        cl.sum_job = jobs.size() - 1;
       }
     }
   }
-  // the level's base sum (an MSM with all-one scalars, once per SRS and level)
-  HG1 base_sum;
-  size_t sum_job = (size_t)-1;
-  if (need_sum) {
-    const size_t top = num_vars - 1;
-    std::lock_guard<std::mutex> lock(level_sums_mu);
-    auto it = srs.level_sums.find(top);
-    if (it != srs.level_sums.end()) {
-      base_sum = it->second;
-    } else {
-      const size_t half = (size_t)1 << top;
-      uint32_t* ones = c.arena.alloc_n<uint32_t>(half);
-      k_fill_u32(c, ones, 1u, half);
-      jobs.push_back(MsmJob{ones, true, srs.eq(top), half});
-      jobs.back().known_bits = 1;
-      sum_job = jobs.size() - 1;
+  const size_t check_base = jobs.size();
+  if (self_check)
+    for (size_t d = check_from; d < depth; d++) {
+      const size_t lvl = num_vars - 1 - d, half = (size_t)1 << lvl;
+      jobs.push_back(MsmJob{q + (half - 1), false, srs.eq(lvl), half});
     }
-  }
   std::vector<HG1> out(jobs.size());
   msm_batch(c, jobs.data(), jobs.size(), (G1Affine*)out.data());
   std::vector<HG1> comms(out.begin(), out.begin() + plain);
-  if (small) {
-    if (sum_job != (size_t)-1) {
-      base_sum = out[sum_job];
+  for (size_t d = depth; d-- > 0;) {  // levels in ascending order after the plain ones
+    ColumnLevel& cl = col_levels[d];
+    if (cl.sum_job != (size_t)-1) {
+      cl.base_sum = out[cl.sum_job];
       std::lock_guard<std::mutex> lock(level_sums_mu);
-      srs.level_sums[num_vars - 1] = base_sum;
+      srs.level_sums[cl.level] = cl.base_sum;
     }
     // commitment = sum_t scale_t * result_t - offset_total * base sum  (scalar multiplications on the host's threads)
-    std::vector<HG1> pts(terms.size() + 1);
-    std::vector<HFr> scal(terms.size() + 1);
-    for (size_t t = 0; t < terms.size(); t++) {
-      const Term& tm = terms[t];
+    std::vector<HG1> pts(cl.terms.size() + 1);
+    std::vector<HFr> scal(cl.terms.size() + 1);
+    for (size_t t = 0; t < cl.terms.size(); t++) {
+      const Term& tm = cl.terms[t];
       if (tm.second) memcpy(&pts[t], jobs[tm.job].out_second, sizeof(HG1));
       else pts[t] = out[tm.job];
       scal[t] = tm.scale;
     }
-    pts[terms.size()] = need_sum ? base_sum : HG1{host::Fq::zero(), host::Fq::zero()};
-    scal[terms.size()] = HFr::zero() - offset_total;
+    pts[cl.terms.size()] = cl.need_sum ? cl.base_sum : HG1{host::Fq::zero(), host::Fq::zero()};
+    scal[cl.terms.size()] = HFr::zero() - cl.offset_total;
     std::vector<host::G1Xyzz> parts(pts.size(), host::G1Xyzz::identity());
     host_parallel_for(pts.size(), [&](size_t t) {
       if (!pts[t].is_identity() && !scal[t].is_zero()) parts[t] = host::g1_mul(host::g1_from_affine(pts[t]), scal[t]);
@@ -1214,6 +1268,8 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
     host::G1Xyzz acc = host::G1Xyzz::identity();
     for (const host::G1Xyzz& pt : parts) acc = host::g1_add(acc, pt);
     comms.push_back(host::g1_to_affine(acc));
+    if (self_check && d >= check_from && memcmp(&comms.back(), &out[check_base + d - check_from], sizeof(HG1)) != 0)
+      fprintf(stderr, "[open] column-wise commitment of level %zu (depth %zu of %zu) differs from the plain one\n", cl.level, d, depth);
   }
   download(c, &remainder, rem, sizeof(Fr));
   tr.write_commitments(comms);  // identity -> Error::Transcript (transcript.rs:172-179,216-219)

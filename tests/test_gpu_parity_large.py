@@ -352,7 +352,8 @@ def test_context_used_from_another_thread(hl, ctx):
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"LH_SC_TAIL_G": "64"}, {"LH_SC_TAIL_G": "2", "LH_SC_TAIL_MAX_LEN": "16384"},
                                  {"LH_SC_TAIL": "0"}, {"LH_MSM_SLAB_LOG": "14"},
-                                 {"LH_OPEN_SMALL_MIN_VARS": "2", "LH_MSM_SLAB_LOG": "12"}, {"LH_LASSO_PACK_TS": "0"}])
+                                 {"LH_OPEN_SMALL_MIN_VARS": "2", "LH_MSM_SLAB_LOG": "12"}, {"LH_LASSO_PACK_TS": "0"},
+                                 {"LH_OPEN_SMALL_MIN_VARS": "2", "LH_OPEN_SMALL_DEPTH": "2", "LH_OPEN_SMALL_CHECK": "1"}])
 def test_small_parity_suite_under_forced_shapes(env):
     """The byte-parity tests of test_gpu_parity.py / test_gpu_golden.py again in a child process with the shape
     knobs forced (they are read once per process): 64 workgroups with slices of two entries (hand-over right after
@@ -360,7 +361,8 @@ def test_small_parity_suite_under_forced_shapes(env):
     MSM job >= 2^14 points on the slab path (per-slab sorts, the dim columns' entry streams taken from the access
     counters' sorts), every Lasso batch opening through the small-column route for its largest quotient (32-bit
     differences, packed column pairs, base-sum offsets: by default only from 2^21 lookups on), read_ts columns
-    committed one by one instead of in packed pairs."""
+    committed one by one instead of in packed pairs, and the two largest quotients column by column whatever the table
+    (with the route's own comparison against the plain commitments switched on)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "tests/test_gpu_golden.py", "-m", "gpu",
