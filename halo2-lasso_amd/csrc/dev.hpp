@@ -113,6 +113,13 @@ struct Ctx {
   // word) instead of pinned host memory; the all-gather and the sum-and-publish kernel follow on the stream
   Fr* sc_redirect = nullptr;
   uint64_t* tail_trace = nullptr;  // development: device stamps of the last resident tail (LH_SC_TAIL_TRACE)
+  // eq tables of point tails y[1..n) built during one proof (prover.cpp eq_half_*): an evaluation, a sum-check and the batch
+  // opening at the same point share one table.  Arena memory of the proof's scope: the proof clears the list (EqHalfScope).
+  struct EqHalfEntry {
+    std::vector<uint8_t> key;  // the bytes of y[1..n)
+    const Fr* table;
+  };
+  std::vector<EqHalfEntry> eq_half_cache;
   bool prof = false;
   std::vector<ProfRec> prof_recs;
   hipEvent_t prof_ev[2] = {nullptr, nullptr};
@@ -199,6 +206,9 @@ void k_inner_products_u32(Ctx&, const uint32_t* const* polys, size_t count, cons
                           Fr* out_host);
 // small-valued columns without their field-element views: 8 multiply-adds per term into a wide accumulator
 void k_inner_products_small(Ctx&, const uint32_t* const* polys, size_t count, const Fr* weights, size_t n, Fr* out_host);
+// the same against eq(y) given as the eq table of y[1..] (`half` entries) and y0
+void k_inner_products_small_half(Ctx&, const uint32_t* const* polys, size_t count, const Fr* eq_half, size_t half,
+                                 const Fr& y0, Fr* out_host);
 // out[i] = sum_k wfr[k] fr[k][i] + sum_k wsm[k] sm[k][i], i < n; u32 column k has sm_len[k] entries (zero beyond)
 void k_lincomb_mixed(Ctx&, const Fr* const* fr, const Fr* wfr, size_t num_fr, const uint32_t* const* sm,
                      const size_t* sm_len, const Fr* wsm, size_t num_sm, size_t n, Fr* out);

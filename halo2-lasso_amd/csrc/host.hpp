@@ -131,6 +131,16 @@ SumCheckResult sum_check_prove(Ctx&, int prover_kind, size_t num_vars, const lh_
                                size_t num_polys, const HFr* ys, size_t num_ys, const HFr& sum, Transcript& tr,
                                bool sum_is_exact = false, const ScRwPairs* rw = nullptr);
 
+// eq table of y[1..num_vars) (2^(num_vars-1) entries), shared through Ctx::eq_half_cache within one proof
+const Fr* eq_half_lookup(Ctx&, const HFr* y, size_t num_vars);
+const Fr* eq_half_get(Ctx&, const HFr* y, size_t num_vars);  // built (in the arena, at the caller's depth) when absent
+struct EqHalfScope {  // forgets, on exit, what was cached after its creation
+  Ctx& c;
+  size_t mark;
+  explicit EqHalfScope(Ctx& c_) : c(c_), mark(c_.eq_half_cache.size()) {}
+  ~EqHalfScope() { c.eq_half_cache.resize(mark); }
+};
+
 // the round loop shared by every sum-check front end (prover.cpp)
 typedef std::function<void(const Fr* const*, Fr* const*, const Fr&, bool, size_t, Fr*)> RoundFn;
 // Eq factoring of the streaming rounds.  eq(y, x) = prod_i eq(y_i, x_i), so in round j (prefix bound to rho):

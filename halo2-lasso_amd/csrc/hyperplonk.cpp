@@ -181,6 +181,7 @@ void hyperplonk_prove_phases(Ctx& c, const PcsProver& pcs, const lh_hp_param& pp
   const size_t nv = pp.num_vars, n = (size_t)1 << nv;
   LH_REQUIRE(nv >= 1 && nv < 32, LH_ERR_ARG, "hyperplonk: bad num_vars");
   ArenaScope scope(c.arena);
+  EqHalfScope eq_scope(c);  // (lasso_argue shares eq tables of its points: arena memory of this scope)
 
   // BooleanHypercube order / nth_map (bh.rs:127-141), generated on the device: order[k] = x^(k-1) in GF(2^nv)
   uint32_t* d_order = c.arena.alloc_n<uint32_t>(n);

@@ -620,6 +620,7 @@ constexpr int IPS_GROUP = 4;  // 6 accumulators of 10 limbs spill (256 B of scra
 struct IpSmallPack {
   const uint32_t* p[IPS_GROUP];
   int count;
+  uint32_t stride, off[IPS_GROUP];  // entry i of pseudo-column k is p[k][i * stride + off[k]] (the even / odd halves of a column)
 };
 // (the group size is a template parameter: accumulators indexed by a run-time count end up in scratch memory)
 template <int G>
@@ -632,7 +633,7 @@ __global__ __launch_bounds__(256) void inner_products_small_kernel(IpSmallPack p
   GSTRIDE(i, n) {
     const Fr wi = w[i];
 #pragma unroll
-    for (int k = 0; k < G; k++) wide_mac(acc[k], wi, pk.p[k][i]);
+    for (int k = 0; k < G; k++) wide_mac(acc[k], wi, pk.p[k][i * pk.stride + pk.off[k]]);
   }
 #pragma unroll
   for (int k = 0; k < G; k++) {
@@ -644,8 +645,8 @@ template <int G>
 static void launch_ips(Ctx& c, dim3 g, const IpSmallPack& pk, const Fr* w, size_t n, Fr* partials) {
   hipLaunchKernelGGL(inner_products_small_kernel<G>, g, 256, 0, c.stream, pk, w, n, partials);
 }
-void k_inner_products_small(Ctx& c, const uint32_t* const* polys, size_t count, const Fr* weights, size_t n,
-                            Fr* out_host) {
+static void inner_products_small_strided(Ctx& c, const uint32_t* const* polys, const uint32_t* offs, size_t count,
+                                         uint32_t stride, const Fr* weights, size_t n, Fr* out_host) {
   ProfScope ps(c, "inner_products", 4.0 * n * count + 32.0 * n * ((count + IPS_GROUP - 1) / IPS_GROUP), 0.07 * n * count, (double)n);
   if (!count) return;
   ArenaScope scope(c.arena);
@@ -656,7 +657,11 @@ void k_inner_products_small(Ctx& c, const uint32_t* const* polys, size_t count, 
   for (size_t base = 0; base < count; base += IPS_GROUP) {
     IpSmallPack pk;
     pk.count = (int)std::min<size_t>(IPS_GROUP, count - base);
-    for (int i = 0; i < IPS_GROUP; i++) pk.p[i] = i < pk.count ? polys[base + i] : nullptr;
+    pk.stride = stride;
+    for (int i = 0; i < IPS_GROUP; i++) {
+      pk.p[i] = i < pk.count ? polys[base + i] : nullptr;
+      pk.off[i] = i < pk.count && offs ? offs[base + i] : 0u;
+    }
     switch (pk.count) {
       case 1: launch_ips<1>(c, g, pk, weights, n, partials); break;
       case 2: launch_ips<2>(c, g, pk, weights, n, partials); break;
@@ -666,6 +671,30 @@ void k_inner_products_small(Ctx& c, const uint32_t* const* polys, size_t count, 
     hipLaunchKernelGGL(reduce_rows_kernel, pk.count, 256, 0, c.stream, partials, (int)g.x, d_out + base);
   }
   c.d2h(out_host, d_out, count * sizeof(Fr));
+}
+void k_inner_products_small(Ctx& c, const uint32_t* const* polys, size_t count, const Fr* weights, size_t n,
+                            Fr* out_host) {
+  inner_products_small_strided(c, polys, nullptr, count, 1, weights, n, out_host);
+}
+// <column, eq(y)> from the eq table of y[1..] alone (half the entries): eq(y, 2b + e) = (e ? y0 : 1 - y0) * half[b], so the
+// even and the odd entries of a column are two strided pseudo-columns against the same weights
+void k_inner_products_small_half(Ctx& c, const uint32_t* const* polys, size_t count, const Fr* eq_half, size_t half,
+                                 const Fr& y0, Fr* out_host) {
+  if (!count) return;
+  std::vector<const uint32_t*> p2(2 * count);
+  std::vector<uint32_t> off(2 * count);
+  for (size_t k = 0; k < count; k++) p2[2 * k] = p2[2 * k + 1] = polys[k], off[2 * k] = 0, off[2 * k + 1] = 1;
+  std::vector<Fr> eo(2 * count);
+  inner_products_small_strided(c, p2.data(), off.data(), 2 * count, 2, eq_half, half, eo.data());
+  host::Fr y, one = host::Fr::one();
+  memcpy(&y, &y0, sizeof(y));
+  for (size_t k = 0; k < count; k++) {
+    host::Fr e, o;
+    memcpy(&e, &eo[2 * k], sizeof(e));
+    memcpy(&o, &eo[2 * k + 1], sizeof(o));
+    const host::Fr r = (one - y) * e + y * o;
+    memcpy(&out_host[k], &r, sizeof(r));
+  }
 }
 
 // ------------------------------------------------------------------ GKR layer-up

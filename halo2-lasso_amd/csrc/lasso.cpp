@@ -166,7 +166,11 @@ LassoClaims lasso_argue(Ctx& c, const lh_lasso_table& tb, size_t n, const LassoC
   LassoClaims cl;
   // ---- 2-4: Surge primary sum-check
   cl.r = tr.squeeze_challenges(n);
-  if (a_small) {
+  if (a_small && n >= 2) {
+    // against the eq table of r[1..] (half the entries), which the Surge sum-check and the batch opening at r use as well
+    const Fr* eq_half = eq_half_get(c, cl.r.data(), n);
+    k_inner_products_small_half(c, &a_small, 1, eq_half, N / 2, dev(cl.r[0]), (Fr*)&cl.v);
+  } else if (a_small) {
     ArenaScope scope(c.arena);
     Fr* eq = c.arena.alloc_n<Fr>(N);
     k_eq_xy(c, (const Fr*)cl.r.data(), n, eq);
@@ -183,27 +187,35 @@ LassoClaims lasso_argue(Ctx& c, const lh_lasso_table& tb, size_t n, const LassoC
     // too, so the round messages of the sum-check over the alpha subtable-read columns are those of the sum-check over
     // the single output column a.  One table instead of alpha in every round; the evaluations E_i(r_z) the transcript
     // wants next are inner products of the 32-bit columns with eq(r_z).
-    ArenaScope scope(c.arena);
-    const Fr* a_tab = a;
-    if (!a_tab) {
-      Fr* view = c.arena.alloc_n<Fr>(N);
-      k_fr_from_u32(c, a_small, N, view);
-      a_tab = view;
+    {
+      ArenaScope scope(c.arena);
+      const Fr* a_tab = a;
+      if (!a_tab) {
+        Fr* view = c.arena.alloc_n<Fr>(N);
+        k_fr_from_u32(c, a_small, N, view);
+        a_tab = view;
+      }
+      lh_sop one_term;
+      memset(&one_term, 0, sizeof(one_term));
+      one_term.global_eq = 0;
+      one_term.num_terms = 1;
+      const HFr one = HFr::one();
+      memcpy(&one_term.coeff[0], &one, 32);
+      one_term.num_factors[0] = 1;
+      one_term.factor[0][0] = 0;
+      sc = sum_check_prove(c, LH_SC_EVALUATIONS, n, one_term, &a_tab, 1, cl.r.data(), 1, cl.v, tr, true);
     }
-    lh_sop one_term;
-    memset(&one_term, 0, sizeof(one_term));
-    one_term.global_eq = 0;
-    one_term.num_terms = 1;
-    const HFr one = HFr::one();
-    memcpy(&one_term.coeff[0], &one, 32);
-    one_term.num_factors[0] = 1;
-    one_term.factor[0][0] = 0;
-    sc = sum_check_prove(c, LH_SC_EVALUATIONS, n, one_term, &a_tab, 1, cl.r.data(), 1, cl.v, tr, true);
-    Fr* eq = c.arena.alloc_n<Fr>(N);
-    k_eq_xy(c, (const Fr*)sc.challenges.data(), n, eq);
     std::vector<const uint32_t*> cols(w.E.begin(), w.E.end());
     sc.evals.assign(alpha, HFr::zero());
-    k_inner_products_small(c, cols.data(), alpha, eq, N, (Fr*)sc.evals.data());
+    if (n >= 2) {  // (the table of r_z[1..] stays for the batch opening at r_z)
+      const Fr* eq_half = eq_half_get(c, sc.challenges.data(), n);
+      k_inner_products_small_half(c, cols.data(), alpha, eq_half, N / 2, dev(sc.challenges[0]), (Fr*)sc.evals.data());
+    } else {
+      ArenaScope scope(c.arena);
+      Fr* eq = c.arena.alloc_n<Fr>(N);
+      k_eq_xy(c, (const Fr*)sc.challenges.data(), n, eq);
+      k_inner_products_small(c, cols.data(), alpha, eq, N, (Fr*)sc.evals.data());
+    }
   } else {
     lh_sop surge;
     memset(&surge, 0, sizeof(surge));
@@ -262,17 +274,23 @@ LassoClaims lasso_argue(Ctx& c, const lh_lasso_table& tb, size_t n, const LassoC
   if (lap) lap(4);
 
   // ---- 7: evaluations at r_N / r_M: dim | read_ts | E, then final_cts - straight from the u32 columns (no
-  // field-element views: 4 bytes read and 8 multiply-adds per entry)
+  // field-element views: 4 bytes read and 8 multiply-adds per entry); at r_N against the eq table of r_N[1..], which the
+  // batch opening at r_N uses as well
+  const Fr* eq_half_n = n >= 2 ? eq_half_get(c, cl.r_N.data(), n) : nullptr;
   {
     ArenaScope scope(c.arena);
     std::vector<const uint32_t*> at_n;
     for (size_t j = 0; j < cc; j++) at_n.push_back(d_dims[j]);
     for (size_t j = 0; j < cc; j++) at_n.push_back(w.rts[j]);
     for (size_t i = 0; i < alpha; i++) at_n.push_back(w.E[i]);
-    Fr* eq = c.arena.alloc_n<Fr>(std::max(N, M));
     cl.ev_n.resize(at_n.size());
-    k_eq_xy(c, (const Fr*)cl.r_N.data(), n, eq);
-    k_inner_products_small(c, at_n.data(), at_n.size(), eq, N, (Fr*)cl.ev_n.data());
+    Fr* eq = c.arena.alloc_n<Fr>(eq_half_n ? M : std::max(N, M));
+    if (eq_half_n) {
+      k_inner_products_small_half(c, at_n.data(), at_n.size(), eq_half_n, N / 2, dev(cl.r_N[0]), (Fr*)cl.ev_n.data());
+    } else {
+      k_eq_xy(c, (const Fr*)cl.r_N.data(), n, eq);
+      k_inner_products_small(c, at_n.data(), at_n.size(), eq, N, (Fr*)cl.ev_n.data());
+    }
     std::vector<const uint32_t*> at_l(w.fcs.begin(), w.fcs.end());
     cl.ev_l.resize(cc);
     k_eq_xy(c, (const Fr*)cl.r_M.data(), l, eq);
@@ -304,6 +322,7 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
   };
 
   ArenaScope scope(c.arena);
+  EqHalfScope eq_scope(c);  // (the shared eq tables are arena memory of this scope)
   std::vector<uint32_t> count_ors(cc, 0);  // OR of every final_cts column (bounds its read_ts column) when computed
   // ---- witness: counters, subtable reads, lookup outputs
   Fr* a = nullptr;

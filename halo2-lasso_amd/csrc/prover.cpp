@@ -160,6 +160,26 @@ std::vector<HFr> evaluate_polys_sharded(Ctx& c, const Fr* const* d_polys_local, 
   return out;
 }
 
+// ------------------------------------------------------------------ shared eq tables of point tails (host.hpp)
+const Fr* eq_half_lookup(Ctx& c, const HFr* y, size_t num_vars) {
+  if (num_vars < 2) return nullptr;
+  const size_t bytes = (num_vars - 1) * sizeof(HFr);
+  for (const Ctx::EqHalfEntry& e : c.eq_half_cache)
+    if (e.key.size() == bytes && memcmp(e.key.data(), y + 1, bytes) == 0) return e.table;
+  return nullptr;
+}
+const Fr* eq_half_get(Ctx& c, const HFr* y, size_t num_vars) {
+  if (const Fr* t = eq_half_lookup(c, y, num_vars)) return t;
+  LH_REQUIRE(num_vars >= 2, LH_ERR_ARG, "eq_half: needs two variables");
+  Fr* t = c.arena.alloc_n<Fr>((size_t)1 << (num_vars - 1));
+  k_eq_xy(c, (const Fr*)(y + 1), num_vars - 1, t);
+  Ctx::EqHalfEntry e;
+  e.key.assign((const uint8_t*)(y + 1), (const uint8_t*)(y + 1) + (num_vars - 1) * sizeof(HFr));
+  e.table = t;
+  c.eq_half_cache.push_back(std::move(e));
+  return t;
+}
+
 // ------------------------------------------------------------------ the round loop of ClassicSumCheck::prove
 // (classic.rs:208-240) shared by the sum-of-products and the general-expression front ends.
 // `cur`: current tables (polys first), `used[i]`: the round kernel binds/stores table i itself,
@@ -597,15 +617,21 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
   if (use_ef) {
     const size_t half = (size_t)1 << (num_vars - 1);
     for (EqFactoring::One& one : ef.eqs) {
-      // level j at offset (2^(n-1) - 2^(n-1-j)) * 2 ... simply: consecutive blocks of halving size in one buffer
-      Fr* buf = c.arena.alloc_n<Fr>(2 * half);
+      // consecutive blocks of halving size in one buffer; E_0 (the eq table over variables 1..n-1) comes from the proof's
+      // shared tables when an evaluation at the same point built it already
+      const Fr* shared = eq_half_lookup(c, one.y, num_vars);
+      Fr* buf = c.arena.alloc_n<Fr>(shared ? half : 2 * half);
       one.level.resize(num_vars);
       size_t off = 0;
       for (size_t jl = 0; jl < num_vars; jl++) {
+        if (jl == 0 && shared) {
+          one.level[0] = const_cast<Fr*>(shared);
+          continue;
+        }
         one.level[jl] = buf + off;
         off += half >> jl;
       }
-      k_eq_xy(c, (const Fr*)(one.y + 1), num_vars - 1, buf);  // E_0: the eq table over variables 1..n-1
+      if (!shared) k_eq_xy(c, (const Fr*)(one.y + 1), num_vars - 1, buf);
     }
     ef.streams = [&](bool, size_t size) { return k_sc_round_streams(rd, degree, size); };
     ef.round = [&](const Fr* const* in, Fr* const* out, const Fr& r, bool bind, size_t size, size_t round, int points,
