@@ -56,6 +56,8 @@ struct MsmJobDev {
   uint32_t pack_shift;  // != 0: two columns packed into one (MsmJob::pack_shift): one window whose bucket index IS the
                         // packed value, reduced twice (red_W = 2 "windows" over the same buckets: low part, high part)
   uint32_t red_W;       // windows of the reduction (= W except for packed jobs)
+  uint32_t nsplit;      // workgroups (shares) per window in the window-sum kernel
+  uint32_t share_base;  // first share (workgroup / output slot) of this job
 };
 constexpr uint32_t KEY_BLOCK_BITS = 10;  // every job's key range starts at a multiple of 2^KEY_BLOCK_BITS
 struct MsmPlanDev {
@@ -389,23 +391,23 @@ __global__ __launch_bounds__(64) void msm_segment_reduce_quad_kernel(MsmPlanDev 
   }
 }
 
-// `nsplit` workgroups per (job, window): each sums a contiguous share of the window's segment partials (the host adds
+// `nsplit` workgroups per window of a job: each sums a contiguous share of the window's segment partials (the host adds
 // the nsplit shares: a host addition is ~0.4 us, a device addition on this under-filled launch ~20 us, so a window with
-// 16 K segments must not be 64 dependent additions per thread).
+// 16 K segments must not be 64 dependent additions per thread).  Per job: the few very wide windows (packed column
+// pairs: 2^16 segments) take 32 shares without multiplying the host's additions for the hundreds of ordinary ones.
 // The sums go straight into pinned host memory; the workgroup that finishes last publishes the flag the
 // host spins on (same ticket protocol as the sum-check rounds): no device-to-host copy, no stream synchronise.
 __global__ __launch_bounds__(512) void msm_window_sum_kernel(MsmPlanDev plan, const G1Xyzz* __restrict__ seg_out,
-                                                             G1Xyzz* __restrict__ win_out, uint32_t nsplit,
-                                                             ScFinishArgs fin) {
+                                                             G1Xyzz* __restrict__ win_out, ScFinishArgs fin) {
   // 128 quads of lanes (ec.cuh: quad-cooperative additions): a share of <= 1024 partials is 8 + 7 dependent additions
   __shared__ G1Xyzz lds[128];
-  const uint32_t win = blockIdx.x / nsplit, part = blockIdx.x % nsplit;
+  int j = 0;
+  while (j + 1 < plan.num_jobs && plan.job[j + 1].share_base <= blockIdx.x) j++;
+  const MsmJobDev& jb = plan.job[j];
+  const uint32_t nsplit = jb.nsplit;
+  const uint32_t w = (blockIdx.x - jb.share_base) / nsplit, part = (blockIdx.x - jb.share_base) % nsplit;
   const uint32_t q = threadIdx.x >> 2;
   const bool lead = (threadIdx.x & 3u) == 0;
-  int j = 0;
-  while (j + 1 < plan.num_jobs && plan.job[j + 1].win_base <= win) j++;
-  const MsmJobDev& jb = plan.job[j];
-  uint32_t w = win - jb.win_base;
   const uint32_t share = (jb.seg_per_win + nsplit - 1) / nsplit;
   const uint32_t lo = part * share, hi = min(lo + share, jb.seg_per_win);
   const G1Xyzz* src = seg_out + jb.seg_base + (size_t)w * jb.seg_per_win;
@@ -634,12 +636,19 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
     {
       uint32_t max_spw = 1;
       for (size_t j = 0; j < nj; j++)
-        if (plan.job[j].W) max_spw = std::max(max_spw, plan.job[j].seg_per_win);
+        if (plan.job[j].W && plan.job[j].seg_per_win < 16384) max_spw = std::max(max_spw, plan.job[j].seg_per_win);
       static const int forced = env_int("LH_MSM_NSPLIT", 0);
       while (nsplit < 32 && max_spw / nsplit > 1024 && nwins * nsplit * 2 <= 4096) nsplit *= 2;
       if (forced > 0) nsplit = (uint32_t)forced;
     }
-    std::vector<G1Xyzz> wins(nwins * nsplit);
+    uint32_t nshares = 0;
+    for (size_t j = 0; j < nj; j++) {
+      MsmJobDev& jd = plan.job[j];
+      jd.nsplit = jd.seg_per_win >= 16384 ? std::max<uint32_t>(nsplit, 32u) : nsplit;
+      jd.share_base = nshares;
+      nshares += jd.red_W * jd.nsplit;
+    }
+    std::vector<G1Xyzz> wins(nshares);
     if (max_entries == 0) {
       for (size_t j = 0; j < nj; j++) {
         memset(&out_host[base + j], 0, sizeof(G1Affine));
@@ -658,11 +667,11 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
       G1Xyzz* seg_out = c.arena.alloc_n<G1Xyzz>(nsegs);
       // pinned host memory: the window sums (written by the last kernel) followed by the key-block table staging
       const size_t nblocks = (nbuckets >> KEY_BLOCK_BITS) + 1;
-      uint8_t* pin_base = (uint8_t*)c.pin(nwins * nsplit * sizeof(G1Xyzz) + nblocks);
+      uint8_t* pin_base = (uint8_t*)c.pin(nshares * sizeof(G1Xyzz) + nblocks);
       G1Xyzz* win_out = (G1Xyzz*)pin_base;
       uint32_t* lvl_cnt = c.arena.alloc_n<uint32_t>(64);
       {
-        uint8_t* h_tab = pin_base + nwins * nsplit * sizeof(G1Xyzz);
+        uint8_t* h_tab = pin_base + nshares * sizeof(G1Xyzz);
         for (size_t j = 0; j < nj; j++) {
           const size_t b0 = plan.job[j].key_base >> KEY_BLOCK_BITS;
           const size_t b1 = j + 1 < nj ? plan.job[j + 1].key_base >> KEY_BLOCK_BITS : nblocks;
@@ -799,9 +808,8 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
         hipLaunchKernelGGL(msm_segment_reduce_kernel, dim3((unsigned)std::min<size_t>((nsegs + 63) / 64, 1 << 16)),
                            dim3(64), 0, c.stream, plan, buckets, seg_out, nsegs);
       const uint32_t seq = c.next_seq();
-      const ScFinishArgs fin = c.finish_for((uint32_t)(nwins * nsplit), nullptr, seq);
-      hipLaunchKernelGGL(msm_window_sum_kernel, dim3((unsigned)(nwins * nsplit)), dim3(512), 0, c.stream, plan, seg_out,
-                         win_out, nsplit, fin);
+      const ScFinishArgs fin = c.finish_for(nshares, nullptr, seq);
+      hipLaunchKernelGGL(msm_window_sum_kernel, dim3(nshares), dim3(512), 0, c.stream, plan, seg_out, win_out, fin);
       if (c.prof) c.sync();
       c.wait_flag(seq);
       }
@@ -813,7 +821,7 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
         for (int i = 0; i < 10; i++) fprintf(stderr, " %u", h_cnt[i]);
         fprintf(stderr, "\n");
       }
-      memcpy(wins.data(), win_out, nwins * nsplit * sizeof(G1Xyzz));
+      memcpy(wins.data(), win_out, nshares * sizeof(G1Xyzz));
     }
     // 6: host combine  sum_w 2^(c*w) * win[w]  and normalise
     auto combine = [&](size_t j) {
@@ -822,8 +830,8 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
         for (uint32_t v = 0; v < 2; v++) {
           host::G1Xyzz acc = host::G1Xyzz::identity();
           if (jd.red_W)
-            for (uint32_t part = 0; part < nsplit; part++)
-              acc = host::g1_add(acc, to_host(wins[(size_t)(jd.win_base + v) * nsplit + part]));
+            for (uint32_t part = 0; part < jd.nsplit; part++)
+              acc = host::g1_add(acc, to_host(wins[(size_t)jd.share_base + (size_t)v * jd.nsplit + part]));
           host::G1Affine a = host::g1_to_affine(acc);
           memcpy(v == 0 ? &out_host[base + j] : jobs[base + j].out_second, &a, sizeof(G1Affine));
         }
@@ -832,8 +840,8 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
       host::G1Xyzz acc = host::G1Xyzz::identity();
       for (int w = (int)jd.W - 1; w >= 0; w--) {
         for (uint32_t k = 0; k < jd.c; k++) acc = host::g1_dbl(acc);
-        for (uint32_t part = 0; part < nsplit; part++)
-          acc = host::g1_add(acc, to_host(wins[(size_t)(jd.win_base + w) * nsplit + part]));
+        for (uint32_t part = 0; part < jd.nsplit; part++)
+          acc = host::g1_add(acc, to_host(wins[(size_t)jd.share_base + (size_t)w * jd.nsplit + part]));
       }
       host::G1Affine a = host::g1_to_affine(acc);
       memcpy(&out_host[base + j], &a, sizeof(G1Affine));
