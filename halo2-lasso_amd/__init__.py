@@ -928,6 +928,29 @@ def lasso_last_timing(ctx):
     return dict(zip(names, list(out)))
 
 
+ROUTE_FIELDS = ["open_small_depth", "open_small_passes", "eq_factored_rounds", "standard_rounds", "rw_leaf_rounds",
+                "resident_tails", "resident_rounds", "packed_ts_pairs", "derived_commitments", "sorted_dim_reuse",
+                "sharded_rounds", "shard_exchanges"]
+
+
+def lasso_last_route(ctx):
+    """lh_lasso_last_route: which routes the last Lasso prove on `ctx` took (include/lasso_hip.h lh_lasso_route)"""
+    out = (C.c_uint32 * 16)()
+    _check(ctx.lib.lh_lasso_last_route(ctx.h, out))
+    return dict(zip(ROUTE_FIELDS, [int(v) for v in out]))
+
+
+def set_option(ctx, name, value):
+    """lh_ctx_set_option: a route switch of the prover (include/lasso_hip.h lists them)"""
+    _check(ctx.lib.lh_ctx_set_option(ctx.h, name.encode(), int(value)))
+
+
+def get_option(ctx, name):
+    out = C.c_int64(0)
+    _check(ctx.lib.lh_ctx_get_option(ctx.h, name.encode(), C.byref(out)))
+    return int(out.value)
+
+
 def profile_enable(ctx, on=True):
     _check(ctx.lib.lh_profile_enable(ctx.h, 1 if on else 0))
 

@@ -181,6 +181,9 @@ SIGNATURES = {
                                      C.POINTER(lh_evaluation), _SZ, C.POINTER(lh_transcript)]),
     "lh_lasso_prove": (C.c_int, [_P, _P, C.POINTER(lh_lasso_table), _SZ, C.POINTER(_P), C.POINTER(lh_transcript)]),
     "lh_lasso_last_timing": (C.c_int, [_P, C.POINTER(C.c_double)]),
+    "lh_ctx_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
+    "lh_ctx_get_option": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int64)]),
+    "lh_lasso_last_route": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
     "lh_ctx_set_comm": (C.c_int, [_P, C.POINTER(lh_comm), _SZ]),
     "lh_rccl_unique_id": (C.c_int, [C.c_char_p]),
     "lh_ctx_set_comm_rccl": (C.c_int, [_P, C.c_int, C.c_int, C.c_char_p, _SZ]),

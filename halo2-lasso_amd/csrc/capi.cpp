@@ -444,6 +444,30 @@ lh_status lh_lasso_last_timing(lh_ctx* ctx, double* out_ms) {
   LH_CATCH
 }
 
+lh_status lh_ctx_set_option(lh_ctx* ctx, const char* name, int64_t value) {
+  LH_TRY NEED_CTX(ctx);
+  int64_t* slot = ctx->c.opt.find(name);
+  LH_REQUIRE(slot != nullptr, LH_ERR_ARG, std::string("unknown option: ") + (name ? name : "(null)"));
+  *slot = value;
+  if (slot == &ctx->c.opt.open_small_min_vars) ctx->c.opt.open_small_min_vars_forced = true;
+  LH_CATCH
+}
+lh_status lh_ctx_get_option(lh_ctx* ctx, const char* name, int64_t* out) {
+  LH_TRY NEED_CTX(ctx);
+  NEED(out);
+  int64_t* slot = ctx->c.opt.find(name);
+  LH_REQUIRE(slot != nullptr, LH_ERR_ARG, std::string("unknown option: ") + (name ? name : "(null)"));
+  *out = *slot;
+  LH_CATCH
+}
+lh_status lh_lasso_last_route(lh_ctx* ctx, lh_lasso_route* out) {
+  LH_TRY NEED_CTX(ctx);
+  NEED(out);
+  static_assert(sizeof(lh_lasso_route) == sizeof(uint32_t) * LH_LASSO_ROUTE_WORDS, "lh_lasso_route layout");
+  memcpy(out, ctx->c.route.v, sizeof(*out));
+  LH_CATCH
+}
+
 lh_status lh_ctx_set_comm(lh_ctx* ctx, const lh_comm* comm, size_t shard_bit) {
   LH_TRY NEED_CTX(ctx);
   ctx->c.sync();

@@ -1,5 +1,6 @@
 // Device context and workspace arena.
 #include <string.h>
+#include <ctype.h>
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
@@ -62,6 +63,34 @@ void Ctx::opt_in_lds(const void* fn, int bytes) {
   lds_opted.push_back(fn);
 }
 
+static const struct {
+  const char* name;
+  int64_t Options::*field;
+} OPTION_TABLE[] = {
+    {"open_small_min_vars", &Options::open_small_min_vars}, {"open_small_depth", &Options::open_small_depth},
+    {"sc_eq_factoring", &Options::sc_eq_factoring},         {"lasso_pack_ts", &Options::lasso_pack_ts},
+    {"sc_tail", &Options::sc_tail},                         {"sc_tail_max_len", &Options::sc_tail_max_len},
+    {"shard_exchange_log", &Options::shard_exchange_log},   {"shard_allreduce", &Options::shard_allreduce},
+};
+
+int64_t* Options::find(const char* name) {
+  if (!name) return nullptr;
+  for (const auto& o : OPTION_TABLE)
+    if (strcmp(o.name, name) == 0) return &(this->*o.field);
+  return nullptr;
+}
+
+Options::Options() {
+  for (const auto& o : OPTION_TABLE) {
+    std::string env = "LH_";
+    for (const char* p = o.name; *p; p++) env.push_back((char)toupper((unsigned char)*p));
+    const char* e = getenv(env.c_str());
+    if (!e || !*e) continue;
+    this->*o.field = (int64_t)atoll(e);
+    if (o.field == &Options::open_small_min_vars) open_small_min_vars_forced = true;
+  }
+}
+
 void Ctx::wait_flag(uint32_t seq) {
   volatile uint32_t* f = flag;
   for (uint64_t spin = 0;; spin++) {
@@ -81,6 +110,7 @@ void Ctx::wait_flag(uint32_t seq) {
 
 ScFinishArgs Ctx::finish_for(uint32_t grid, Fr* out_host, uint32_t seq) {
   ScFinishArgs f{ticket, (uint32_t)(ticket_base + grid - 1), out_host, flag, seq};
+  if (sc_redirect) f.out_host = sc_redirect, f.flag = ticket + 8;  // sharded round: a device word nobody waits on
   if (grid > 1) ticket_base += grid;  // single-workgroup launches draw no ticket
   return f;
 }

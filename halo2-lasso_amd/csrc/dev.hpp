@@ -90,8 +90,33 @@ struct ScFinishArgs {
   uint32_t seq;
 };
 
+// ------------------------------------------------------------------ route options and the route a proof took
+// The switches that decide WHICH code proves (not how fast a kernel runs).  Per ctx: set through lh_ctx_set_option
+// (include/lasso_hip.h lists them), initialised at ctx creation from the environment variable of the same name in upper
+// case with an LH_ prefix (LH_OPEN_SMALL_MIN_VARS, ...).  Proof bytes never depend on them.
+struct Options {
+  int64_t open_small_min_vars = 21;    // smallest opening whose largest quotient(s) are committed column by column (64: never)
+  bool open_small_min_vars_forced = false;  // set explicitly: no automatic "few columns" exception below the threshold
+  int64_t open_small_depth = 0;        // 1 / 2: that many column-wise quotient levels whatever the shape (0: by cost)
+  int64_t sc_eq_factoring = 1;         // 0: every sum-check round streams and binds its eq tables
+  int64_t lasso_pack_ts = 1;           // 0: one MSM pass per read_ts column
+  int64_t sc_tail = 1;                 // 0: one launch per sum-check round all the way down (no resident tail)
+  int64_t sc_tail_max_len = 8192;      // longest table that enters the resident tail
+  int64_t shard_exchange_log = 17;     // sharded sum-check: the residual tables travel once they hold <= 2^this entries
+  int64_t shard_allreduce = 0;         // sharded rounds: 1 = ncclAllReduce(sum) over u64 lanes of 32-bit limbs
+  Options();                           // environment defaults (dev.cpp)
+  int64_t* find(const char* name);
+};
+struct RouteStats {  // lh_lasso_route (include/lasso_hip.h): counters of the last Lasso prove on the ctx
+  uint32_t v[LH_LASSO_ROUTE_WORDS] = {0};
+  enum { OPEN_DEPTH, OPEN_PASSES, EF_ROUNDS, STD_ROUNDS, RW_ROUNDS, TAILS, TAIL_ROUNDS, PACKED_TS, DERIVED, SORTED_REUSE,
+         SHARDED_ROUNDS, SHARD_EXCHANGES };
+};
+
 // ------------------------------------------------------------------ context
 struct Ctx {
+  Options opt;
+  RouteStats route;
   int device = 0;
   hipStream_t stream = nullptr;
   Arena arena;
@@ -105,6 +130,9 @@ struct Ctx {
   lh_comm comm = {0, 1, nullptr, nullptr, nullptr};
   bool has_comm = false;
   size_t shard_bit = 0;
+  // a sharded proof is running on this ctx (set for the duration of lh_lasso_prove_sharded): every routine of the prover
+  // then takes its tables as this rank's shards (struct Shard below); otherwise an attached communicator is ignored
+  bool shard_active = false;
   void* rccl_comm = nullptr;      // ncclComm_t of the built-in RCCL backend (comm.cpp)
   void* comm_stage = nullptr;     // device staging of host-side gathers over a device-only communicator
   size_t comm_stage_bytes = 0;
@@ -112,12 +140,17 @@ struct Ctx {
   // sharded sum-check rounds: the round kernel leaves its D sums in this DEVICE buffer (and "publishes" to a device
   // word) instead of pinned host memory; the all-gather and the sum-and-publish kernel follow on the stream
   Fr* sc_redirect = nullptr;
+  Fr* round_out(Fr* out_host) const { return sc_redirect ? sc_redirect : out_host; }
+  void wait_round(uint32_t seq) {  // the host's wait for a round kernel's sums (nothing to wait for when they stay on the device)
+    if (!sc_redirect) wait_flag(seq);
+  }
   uint64_t* tail_trace = nullptr;  // development: device stamps of the last resident tail (LH_SC_TAIL_TRACE)
   // eq tables of point tails y[1..n) built during one proof (prover.cpp eq_half_*): an evaluation, a sum-check and the batch
   // opening at the same point share one table.  Arena memory of the proof's scope: the proof clears the list (EqHalfScope).
   struct EqHalfEntry {
     std::vector<uint8_t> key;  // the bytes of y[1..n)
     const Fr* table;
+    bool sharded = false;  // this rank's shard of the table (sharded proofs)
   };
   std::vector<EqHalfEntry> eq_half_cache;
   bool prof = false;
@@ -149,6 +182,27 @@ struct Ctx {
   void opt_in_lds(const void* fn, int bytes);
   // message of a resident tail round: `count` chunks that all carry `seq` -> `count` / 3 field elements
   void wait_chunks(const struct TailChunk* chunks, size_t count, uint32_t seq, Fr* out);
+};
+
+// Geometry of a proof sharded over R = 2^rho ranks.  A table of 2^m entries is split on the index bits
+// [j, j + rho): rank s holds the 2^(m - rho) entries (hi || lo) <-> global index (hi, s, lo).  Every kernel is
+// index-agnostic over such a local table because
+//   * sum-check pairs are (2b, 2b+1): bit 0, local while it is not a shard bit (rounds 0..j-1);
+//   * product-tree / quotient halves are split on the top bit, local while the table has more than j + rho variables.
+// `on` false (no sharded proof running): rho = 0 and nothing is sharded - the single-GPU prover is the world of one.
+struct Shard {
+  bool on = false;
+  size_t rho = 0, j = 0, rank = 0, R = 1;
+  explicit Shard(const Ctx& c) {
+    if (!c.shard_active) return;
+    on = true, j = c.shard_bit, rank = (size_t)c.comm.rank, R = (size_t)c.comm.size;
+    while (((size_t)1 << rho) < R) rho++;
+  }
+  // is a table of `num_vars` variables held in shards?  Smaller ones are replicated and worked on redundantly.  (A
+  // communicator of ONE rank goes through the same code paths - its "exchange" round still needs one round before it.)
+  bool sharded(size_t num_vars) const { return on && num_vars >= j + (rho ? rho : 1) + 1; }
+  size_t local_vars(size_t num_vars) const { return sharded(num_vars) ? num_vars - rho : num_vars; }
+  size_t local_len(size_t num_vars) const { return (size_t)1 << local_vars(num_vars); }
 };
 
 // Persistent host worker threads for the short host-side tails (window combines of an MSM batch): spawning
@@ -277,8 +331,10 @@ void comm_all_gather_host(Ctx&, const void* send, void* recv, size_t bytes);
 // ------------------------------------------------------------------ sharding helpers (kernels_poly.hip)
 // inverse of k_shard_extract over the all-gathered shards: global[g] = gathered[s(g) * n_local + local(g)]
 void k_shard_merge(Ctx&, const void* gathered, size_t n_local, size_t j, size_t rho, size_t elem, void* global);
-// out[t][hi * R + s] = gathered[(s * count + t) * n_local + hi]  (tables whose shard bits have reached bit 0)
-void k_gather_interleave(Ctx&, const Fr* gathered, size_t count, size_t n_local, size_t R, Fr* const* out);
+// out[t][(hi * R + s) * block + lo] = gathered[(s * count + t) * n_local + hi * block + lo]: the residual tables of a
+// sharded sum-check (block = 1 once the shard bits have reached bit 0) or tree levels / remainders at the replication
+// point (block = n_local: concatenation)
+void k_gather_interleave(Ctx&, const Fr* gathered, size_t count, size_t n_local, size_t R, size_t block, Fr* const* out);
 // out_host[x] = sum_s all[s * D + x], x < D; then the flag: the closing step of a sharded sum-check round
 void k_sum_publish(Ctx&, const Fr* all, size_t R, size_t D, Fr* out_host, uint32_t seq);
 // local[idx] = global[((idx >> j) << (j + rho)) | (s << j) | (idx & (2^j - 1))], elements of `elem` bytes (4, 32, 64)
@@ -361,7 +417,7 @@ struct TailMbox {      // pinned, written by the host only: the challenge of rou
 constexpr uint32_t SC_TAIL_ABORT = 0xffffffffu;
 constexpr int SC_TAIL_MAX_DEGREE = 6;
 // largest resident table length (power of two, 0 = tail not applicable) for this expression
-size_t k_sc_tail_capacity(const ScRound& rd, int degree);
+size_t k_sc_tail_capacity(const Ctx&, const ScRound& rd, int degree);
 // rd.in: entry tables; first_bind: they hold 2*n0 entries and are bound with rd.r first.  Returns immediately.
 // msg_host: 3 * degree chunks (value x at chunks 3x..3x+2), out_host: num_out field elements.
 void k_sc_tail_launch(Ctx&, const ScRound& rd, int degree, size_t n0, bool first_bind, size_t num_out, uint32_t seq0,

@@ -129,11 +129,14 @@ struct ScRwPairs {
 };
 SumCheckResult sum_check_prove(Ctx&, int prover_kind, size_t num_vars, const lh_sop& expr, const Fr* const* d_polys,
                                size_t num_polys, const HFr* ys, size_t num_ys, const HFr& sum, Transcript& tr,
-                               bool sum_is_exact = false, const ScRwPairs* rw = nullptr);
+                               bool sum_is_exact = false, const ScRwPairs* rw = nullptr, bool sharded = false);
+// `sharded` (inside a sharded proof, dev.hpp Shard): d_polys are this rank's shards of num_vars-variable tables; same
+// messages, same result on every rank
 
-// eq table of y[1..num_vars) (2^(num_vars-1) entries), shared through Ctx::eq_half_cache within one proof
-const Fr* eq_half_lookup(Ctx&, const HFr* y, size_t num_vars);
-const Fr* eq_half_get(Ctx&, const HFr* y, size_t num_vars);  // built (in the arena, at the caller's depth) when absent
+// eq table of y[1..num_vars) (2^(num_vars-1) entries), shared through Ctx::eq_half_cache within one proof; `sharded`: this
+// rank's shard of it with the rank's factor of the shard coordinates multiplied in
+const Fr* eq_half_lookup(Ctx&, const HFr* y, size_t num_vars, bool sharded = false);
+const Fr* eq_half_get(Ctx&, const HFr* y, size_t num_vars, bool sharded = false);  // built (in the arena, at the caller's depth) when absent
 struct EqHalfScope {  // forgets, on exit, what was cached after its creation
   Ctx& c;
   size_t mark;
@@ -163,6 +166,7 @@ struct EqFactoring {
   bool trusted_claim = false;  // the claim is known to be the true sum: no check (and no extra point) in round 0
   std::vector<HFr> inv_1my;  // global-eq shape: (1 - y_j)^-1 for every round
   HFr c;                     // global-eq shape: claim / S_j
+  HFr add_const;             // set by `round`: a constant the kernel left out of every q value (ScRwPairs::const_total)
   // would this round run the streaming kernel (else the eq tables are materialised and the standard path takes over)
   std::function<bool(bool bind, size_t size)> streams;
   // launches the factored round; device output: q(1..points) (global-eq shape; points = D - 1, or D in round 0 where the
@@ -180,15 +184,11 @@ SumCheckResult sum_check_prove_expr(Ctx&, size_t num_vars, const lh_expr& expr, 
                                     size_t num_polys, const HFr* challenges, size_t num_challenges, const HFr* ys,
                                     size_t num_ys, const HFr& sum, Transcript& tr);
 
-// one proof over several GPUs: same messages, tables are this rank's shards
-SumCheckResult sum_check_prove_sharded(Ctx&, int prover_kind, size_t num_vars, const lh_sop& expr,
-                                       const Fr* const* d_polys_local, size_t num_polys, const HFr* ys, size_t num_ys,
-                                       const HFr& sum, Transcript& tr);
-std::vector<HFr> evaluate_polys_sharded(Ctx&, const Fr* const* d_polys_local, size_t count, size_t num_vars,
-                                        const HFr* point);
+// one proof over several GPUs (dev.hpp Shard): tables are this rank's shards, results are global
+std::vector<HFr> evaluate_polys(Ctx&, const Fr* const* d_polys, size_t count, size_t num_vars, const HFr* point, bool sharded);
 void comm_sum_fr(Ctx&, HFr* v, size_t n);
 void comm_sum_points(Ctx&, HG1* pts, size_t n);
-void comm_gather_interleave(Ctx&, const Fr* local_block, size_t count, size_t n_local, Fr* const* out);
+void comm_gather_tables(Ctx&, const Fr* local_block, size_t count, size_t n_local, size_t block, Fr* const* out);
 void comm_gather_concat(Ctx&, const Fr* local, size_t n_local, Fr* out);
 
 // ------------------------------------------------------------------ piop::gkr
@@ -222,7 +222,9 @@ struct Srs {
   mutable size_t shard_R = 0, shard_j = 0;
   // sum of all bases of a level (mkzg_open over small-valued columns), computed on first use
   mutable std::map<size_t, HG1> level_sums;  // (guarded by one process-wide mutex in prover.cpp)
+  mutable std::map<size_t, HG1> shard_level_sums;  // the same over this rank's share of a sharded level
 };
+const G1Affine* srs_shard_level(Ctx&, const Srs&, size_t level);  // this rank's share of a level's bases (sharded proofs)
 Srs* mkzg_setup(Ctx&, const HFr* ss, size_t num_vars);
 std::vector<HG1> mkzg_batch_commit(Ctx&, const Srs&, const Fr* const* d_polys, size_t num_polys, size_t num_vars);
 std::vector<HG1> mkzg_batch_commit_u32(Ctx&, const Srs&, const uint32_t* const* d_polys, size_t num_polys,
@@ -298,6 +300,7 @@ void zeromorph_batch_verify(const ZmVerifierParams&, size_t num_vars, const HG1*
 // (the eq basis of level nv, or the powers of s), the largest nv they cover, and batch_open
 struct LassoPcs {
   std::function<const G1Affine*(size_t nv)> commit_bases;
+  std::function<const G1Affine*(size_t nv)> shard_bases;  // this rank's share of them (sharded proofs; null: unsupported)
   size_t max_vars;
   std::function<void(size_t num_vars, const Fr* const* d_polys, size_t num_polys, const HFr* points, size_t num_points,
                      const lh_evaluation* evals, size_t num_evals, Transcript& tr, const SmallPoly* small)>

@@ -338,25 +338,28 @@ void k_shard_merge(Ctx& c, const void* gathered, size_t n_local, size_t j, size_
     throw Error(LH_ERR_ARG, "shard_merge: unsupported element size");
 }
 
-// tables whose shard bits have reached bit 0: out[t][hi * R + s] = gathered[(s * count + t) * n_local + hi]
+// residual tables of a sharded sum-check, gathered rank-major: with `block` = 2^(shard_bit - rounds bound) entries of
+// every rank still contiguous,  out[t][(hi * R + s) * block + lo] = gathered[(s * count + t) * n_local + hi * block + lo]
+// (block = 1: the shard bits have reached bit 0; block = n_local: the shard bits are the top bits, a plain concatenation)
 struct InterleaveOut {
   Fr* out[SC_MAX_TABLES];
 };
 __global__ void gather_interleave_kernel(const Fr* __restrict__ gathered, unsigned count, size_t n_local, unsigned R,
-                                         InterleaveOut o) {
+                                         size_t block, InterleaveOut o) {
   const size_t full = n_local * R;
   GSTRIDE(e, full * count) {
-    const size_t t = e / full, k = e % full, hi = k / R, s = k % R;
-    o.out[t][k] = gathered[((size_t)s * count + t) * n_local + hi];
+    const size_t t = e / full, k = e % full, lo = k % block, q = k / block, hi = q / R, s = q % R;
+    o.out[t][k] = gathered[((size_t)s * count + t) * n_local + hi * block + lo];
   }
 }
-void k_gather_interleave(Ctx& c, const Fr* gathered, size_t count, size_t n_local, size_t R, Fr* const* out) {
+void k_gather_interleave(Ctx& c, const Fr* gathered, size_t count, size_t n_local, size_t R, size_t block, Fr* const* out) {
   LH_REQUIRE(count <= (size_t)SC_MAX_TABLES, LH_ERR_ARG, "gather_interleave: too many tables");
+  LH_REQUIRE(block >= 1 && n_local % block == 0, LH_ERR_ARG, "gather_interleave: bad block size");
   if (!count || !n_local) return;
   InterleaveOut o;
   for (size_t t = 0; t < count; t++) o.out[t] = out[t];
   hipLaunchKernelGGL(gather_interleave_kernel, grid_for(n_local * R * count), 256, 0, c.stream, gathered, (unsigned)count,
-                     n_local, (unsigned)R, o);
+                     n_local, (unsigned)R, block, o);
 }
 
 // closing step of a sharded sum-check round: the D partial sums of the R ranks (all-gathered, rank-major) are added

@@ -574,15 +574,9 @@ static bool tail_fits(const ScRound& rd, int degree, size_t n0, uint32_t G) {
   return cap <= 2 || (size_t)rd.num_terms * degree * (cap >> 1) <= TAIL_MAX_ITEMS;
 }
 
-size_t k_sc_tail_capacity(const ScRound& rd, int degree) {
-  static const int enabled = [] {
-    const char* e = getenv("LH_SC_TAIL");  // LH_SC_TAIL=0: one launch per round all the way down
-    return e ? atoi(e) : 1;
-  }();
-  static const size_t max_len = [] {
-    const char* e = getenv("LH_SC_TAIL_MAX_LEN");
-    return e ? (size_t)atoll(e) : (size_t)8192;
-  }();
+size_t k_sc_tail_capacity(const Ctx& c, const ScRound& rd, int degree) {
+  const bool enabled = c.opt.sc_tail != 0;  // 0: one launch per round all the way down
+  const size_t max_len = (size_t)c.opt.sc_tail_max_len;
   if (!enabled || degree < 1 || degree > SC_TAIL_MAX_DEGREE) return 0;
   if ((size_t)rd.num_terms * degree > 256 || rd.num_tables == 0) return 0;
   size_t best = 0;
@@ -596,7 +590,7 @@ size_t k_sc_tail_capacity(const ScRound& rd, int degree) {
 void k_sc_tail_launch(Ctx& c, const ScRound& rd, int degree, size_t n0, bool first_bind, size_t num_out, uint32_t seq0,
                       TailChunk* msg_host, Fr* out_host) {
   const uint32_t G = tail_workgroups(n0);
-  LH_REQUIRE(n0 >= 2 && (n0 & (n0 - 1)) == 0 && n0 <= k_sc_tail_capacity(rd, degree) && tail_fits(rd, degree, n0, G),
+  LH_REQUIRE(n0 >= 2 && (n0 & (n0 - 1)) == 0 && n0 <= k_sc_tail_capacity(c, rd, degree) && tail_fits(rd, degree, n0, G),
              LH_ERR_ARG, "sum-check tail: tables do not fit");
   LH_REQUIRE(num_out <= 256, LH_ERR_ARG, "sum-check tail: too many outputs");
   ScTailArgs a;
@@ -721,6 +715,7 @@ void k_sc_round_open(Ctx& c, const ScOpenRound& rd, bool bind, size_t size, Fr* 
   LH_REQUIRE(rd.num_terms >= 1 && rd.num_terms <= (uint32_t)SC_OPEN_MAX_TERMS && size >= 1, LH_ERR_ARG, "sc_round_open: bad shape");
   const uint32_t seq = c.next_seq();
   ArenaScope scope(c.arena);
+  out_host = c.round_out(out_host);  // (sharded rounds: the sums stay on the device, prover.cpp)
   size_t g = std::min<size_t>((size + 255) / 256, (size_t)c.num_cus * 4);
   const int nq = 2 * (int)rd.num_terms;
   Fr* partials = g == 1 ? out_host : c.arena.alloc_n<Fr>(g * nq);
@@ -738,7 +733,7 @@ void k_sc_round_open(Ctx& c, const ScOpenRound& rd, bool bind, size_t size, Fr* 
       default: launch_open<6>(c, rd, bind, size, (unsigned)g, partials, fin); break;
     }
   }
-  c.wait_flag(seq);
+  c.wait_round(seq);
 }
 
 // ------------------------------------------------------------------ grand-product layer over (A, A + 1) tree pairs
@@ -788,6 +783,7 @@ void k_sc_round_rw(Ctx& c, const ScRwRound& rd, bool bind, size_t size, Fr* out_
              "sc_round_rw: bad shape");
   const uint32_t seq = c.next_seq();
   ArenaScope scope(c.arena);
+  out_host = c.round_out(out_host);
   size_t g = std::min<size_t>((size + 255) / 256, (size_t)c.num_cus * 4);
   Fr* partials = g == 1 ? out_host : c.arena.alloc_n<Fr>(g * 2);
   const ScFinish fin = c.finish_for((uint32_t)g, out_host, seq);
@@ -808,7 +804,7 @@ void k_sc_round_rw(Ctx& c, const ScRwRound& rd, bool bind, size_t size, Fr* out_
       default: launch_rw<8>(c, rd, bind, size, (unsigned)g, partials, fin); break;
     }
   }
-  c.wait_flag(seq);
+  c.wait_round(seq);
 }
 
 void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, Fr* evals_host) {
@@ -837,13 +833,8 @@ void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, F
   const uint32_t seq = c.next_seq();
   ArenaScope scope(c.arena);
   // sharded rounds (prover.cpp): the D sums stay on the device (all-gather and sum-and-publish follow on the stream)
-  const bool redirect = c.sc_redirect != nullptr;
-  if (redirect) evals_host = c.sc_redirect;
-  auto finish = [&](size_t grid) {
-    ScFinish f = c.finish_for((uint32_t)grid, evals_host, seq);
-    if (redirect) f.flag = c.ticket + 8;  // a device word nobody waits on
-    return f;
-  };
+  evals_host = c.round_out(evals_host);
+  auto finish = [&](size_t grid) { return c.finish_for((uint32_t)grid, evals_host, seq); };
 
   // pairs per workgroup of the LDS-staged kernel
   uint32_t P = (uint32_t)std::min<size_t>(size, 64);
@@ -882,7 +873,7 @@ void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, F
         default: launch_lds<6>(c, g, bind, size, (unsigned)grid, partials, kflag); break;
       }
     }
-    if (!redirect) c.wait_flag(seq);
+    c.wait_round(seq);
     return;
   }
 
@@ -911,7 +902,7 @@ void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, F
       default: launch_round<6>(c, a, bind, size, tp, (unsigned)g, partials, kflag); break;
     }
   }
-  if (!redirect) c.wait_flag(seq);
+  c.wait_round(seq);
 }
 
 }  // namespace lh

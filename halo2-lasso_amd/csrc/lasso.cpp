@@ -15,6 +15,7 @@ static double now_ms() {
 LassoPcs lasso_mkzg_pcs(Ctx& c, const Srs& srs) {
   LassoPcs p;
   p.commit_bases = [&srs](size_t nv) { return srs.eq(nv); };
+  p.shard_bases = [&c, &srs](size_t nv) { return srs_shard_level(c, srs, nv); };
   p.max_vars = srs.num_vars;
   p.batch_open = [&c, &srs](size_t nv, const Fr* const* polys, size_t np, const HFr* points, size_t npts,
                             const lh_evaluation* evals, size_t ne, Transcript& tr, const SmallPoly* small) {
@@ -83,22 +84,48 @@ void lasso_check_table(const lh_lasso_table& tb) {
   }
 }
 
-// witness: access counters, subtable reads and (optionally) the lookup outputs a = g(E); arena memory of the caller's scope
+// Access counters of a sharded proof: read_ts[k] = number of earlier lookups - in the GLOBAL lookup order - of the same
+// address, final_cts[a] = number of lookups of a.  rts[j]: this rank's shard (2^(n - rho)), fcs[j]: replicated (2^l).
+static void lasso_counters_sharded(Ctx& c, const Shard& sh, const uint32_t* const* d_dims_local, size_t cc, size_t n, size_t l,
+                                   uint32_t* const* rts, uint32_t* const* fcs) {
+  const size_t N = (size_t)1 << n, M = (size_t)1 << l, NL = N >> sh.rho;
+  ArenaScope wscope(c.arena);  // the full columns are only needed here
+  uint32_t* gathered = c.arena.alloc_n<uint32_t>(N);
+  uint32_t* full = c.arena.alloc_n<uint32_t>(N);
+  uint32_t* rts_full = c.arena.alloc_n<uint32_t>(N);
+  for (size_t j = 0; j < cc; j++) {
+    comm_all_gather_dev(c, d_dims_local[j], gathered, NL * sizeof(uint32_t));
+    k_shard_merge(c, gathered, NL, sh.j, sh.rho, 4, full);
+    k_lasso_counters(c, full, N, M, rts_full, fcs[j]);
+    k_shard_extract(c, rts_full, NL, sh.j, sh.rho, sh.rank, 4, rts[j]);
+  }
+}
+
+// witness: access counters, subtable reads and (optionally) the lookup outputs a = g(E); arena memory of the caller's scope.
+// Inside a sharded proof d_dims are this rank's shards of the lookup columns and so are read_ts / E / a; final_cts (2^l
+// entries, l <= shard_bit + rho) is replicated.
 LassoColumns lasso_witness_columns(Ctx& c, const lh_lasso_table& tb, size_t n, const uint32_t* const* d_dims, Fr** a_out,
                                    uint32_t** a_small_out, bool keep_sorted) {
   const size_t cc = tb.num_chunks, l = tb.chunk_bits, alpha = tb.num_memories;
-  const size_t N = (size_t)1 << n, M = (size_t)1 << l;
+  const Shard sh(c);
+  const size_t N = (size_t)1 << (n - sh.rho), M = (size_t)1 << l;  // N: entries of this rank's columns
   LassoColumns w;
   w.rts.resize(cc), w.fcs.resize(cc), w.E.resize(alpha);
   for (size_t j = 0; j < cc; j++) {
     w.rts[j] = c.arena.alloc_n<uint32_t>(N);
     w.fcs[j] = c.arena.alloc_n<uint32_t>(M);
-    if (keep_sorted) {
-      w.dim_sorted.push_back(c.arena.alloc_n<uint32_t>(N));
-      w.dim_index.push_back(c.arena.alloc_n<uint32_t>(N));
-      k_lasso_counters(c, d_dims[j], N, M, w.rts[j], w.fcs[j], w.dim_sorted[j], w.dim_index[j]);
-    } else {
-      k_lasso_counters(c, d_dims[j], N, M, w.rts[j], w.fcs[j]);
+  }
+  if (sh.on) {
+    lasso_counters_sharded(c, sh, d_dims, cc, n, l, w.rts.data(), w.fcs.data());
+  } else {
+    for (size_t j = 0; j < cc; j++) {
+      if (keep_sorted) {
+        w.dim_sorted.push_back(c.arena.alloc_n<uint32_t>(N));
+        w.dim_index.push_back(c.arena.alloc_n<uint32_t>(N));
+        k_lasso_counters(c, d_dims[j], N, M, w.rts[j], w.fcs[j], w.dim_sorted[j], w.dim_index[j]);
+      } else {
+        k_lasso_counters(c, d_dims[j], N, M, w.rts[j], w.fcs[j]);
+      }
     }
   }
   LassoG g;
@@ -162,21 +189,30 @@ LassoClaims lasso_argue(Ctx& c, const lh_lasso_table& tb, size_t n, const LassoC
                         const Fr* a, const Fr* const* E_fr, Transcript& tr, const std::function<void(int)>& lap,
                         const uint32_t* a_small) {
   const size_t cc = tb.num_chunks, l = tb.chunk_bits, alpha = tb.num_memories;
-  const size_t N = (size_t)1 << n, M = (size_t)1 << l;
+  // inside a sharded proof (dev.hpp Shard) every n-variable column is this rank's shard (N entries); sums over a column -
+  // evaluations, round messages - are partial sums added over the ranks; the 2^l-entry subtable side is replicated
+  const Shard sh(c);
+  const bool shn = sh.on;
+  if (shn) LH_REQUIRE(sh.sharded(n) && l <= sh.j + sh.rho, LH_ERR_ARG, "lasso: shard geometry does not fit the table");
+  const size_t N = (size_t)1 << (n - sh.rho), M = (size_t)1 << l;
+  auto sum_ranks = [&](HFr* v, size_t count) {
+    if (shn) comm_sum_fr(c, v, count);
+  };
   LassoClaims cl;
   // ---- 2-4: Surge primary sum-check
   cl.r = tr.squeeze_challenges(n);
   if (a_small && n >= 2) {
     // against the eq table of r[1..] (half the entries), which the Surge sum-check and the batch opening at r use as well
-    const Fr* eq_half = eq_half_get(c, cl.r.data(), n);
+    const Fr* eq_half = eq_half_get(c, cl.r.data(), n, shn);
     k_inner_products_small_half(c, &a_small, 1, eq_half, N / 2, dev(cl.r[0]), (Fr*)&cl.v);
+    sum_ranks(&cl.v, 1);
   } else if (a_small) {
     ArenaScope scope(c.arena);
     Fr* eq = c.arena.alloc_n<Fr>(N);
     k_eq_xy(c, (const Fr*)cl.r.data(), n, eq);
     k_inner_products_small(c, &a_small, 1, eq, N, (Fr*)&cl.v);
   } else {
-    cl.v = evaluate_polys(c, &a, 1, n, cl.r.data())[0];
+    cl.v = evaluate_polys(c, &a, 1, n, cl.r.data(), shn)[0];
   }
   tr.write_field_element(cl.v);
   bool linear_g = true;
@@ -203,13 +239,14 @@ LassoClaims lasso_argue(Ctx& c, const lh_lasso_table& tb, size_t n, const LassoC
       memcpy(&one_term.coeff[0], &one, 32);
       one_term.num_factors[0] = 1;
       one_term.factor[0][0] = 0;
-      sc = sum_check_prove(c, LH_SC_EVALUATIONS, n, one_term, &a_tab, 1, cl.r.data(), 1, cl.v, tr, true);
+      sc = sum_check_prove(c, LH_SC_EVALUATIONS, n, one_term, &a_tab, 1, cl.r.data(), 1, cl.v, tr, true, nullptr, shn);
     }
     std::vector<const uint32_t*> cols(w.E.begin(), w.E.end());
     sc.evals.assign(alpha, HFr::zero());
     if (n >= 2) {  // (the table of r_z[1..] stays for the batch opening at r_z)
-      const Fr* eq_half = eq_half_get(c, sc.challenges.data(), n);
+      const Fr* eq_half = eq_half_get(c, sc.challenges.data(), n, shn);
       k_inner_products_small_half(c, cols.data(), alpha, eq_half, N / 2, dev(sc.challenges[0]), (Fr*)sc.evals.data());
+      sum_ranks(sc.evals.data(), alpha);
     } else {
       ArenaScope scope(c.arena);
       Fr* eq = c.arena.alloc_n<Fr>(N);
@@ -226,7 +263,7 @@ LassoClaims lasso_argue(Ctx& c, const lh_lasso_table& tb, size_t n, const LassoC
       surge.num_factors[m] = tb.g_num_factors[m];
       for (int k = 0; k < LH_SC_MAX_FACTORS; k++) surge.factor[m][k] = tb.g_factor[m][k];
     }
-    sc = sum_check_prove(c, LH_SC_EVALUATIONS, n, surge, E_fr, alpha, cl.r.data(), 1, cl.v, tr, true);
+    sc = sum_check_prove(c, LH_SC_EVALUATIONS, n, surge, E_fr, alpha, cl.r.data(), 1, cl.v, tr, true, nullptr, shn);
   }
   cl.r_z = sc.challenges;
   cl.e_rz = sc.evals;
@@ -244,7 +281,8 @@ LassoClaims lasso_argue(Ctx& c, const lh_lasso_table& tb, size_t n, const LassoC
     std::vector<uint8_t> plus_one(4 * alpha, 0);
     // write leaf = read leaf + 1: when the n-variable trees are alone at their leaf layer (n > l) that layer runs over the
     // read-set tables only (prove_grand_product: plus_one) and the write-set leaves are never stored
-    const bool fused_up = n >= 12, ws_implicit = fused_up && n > l;
+    // (sharded: the level above the leaves must itself be held in shards, else it is exchanged by the tree builder)
+    const bool fused_up = n >= 12 && (!shn || sh.sharded(n - 1)), ws_implicit = fused_up && n > l;
     for (size_t i = 0; i < alpha; i++) {
       size_t j = tb.memory_chunk[i];
       Fr* rs = c.arena.alloc_n<Fr>(N);
@@ -276,7 +314,7 @@ LassoClaims lasso_argue(Ctx& c, const lh_lasso_table& tb, size_t n, const LassoC
   // ---- 7: evaluations at r_N / r_M: dim | read_ts | E, then final_cts - straight from the u32 columns (no
   // field-element views: 4 bytes read and 8 multiply-adds per entry); at r_N against the eq table of r_N[1..], which the
   // batch opening at r_N uses as well
-  const Fr* eq_half_n = n >= 2 ? eq_half_get(c, cl.r_N.data(), n) : nullptr;
+  const Fr* eq_half_n = n >= 2 ? eq_half_get(c, cl.r_N.data(), n, shn) : nullptr;
   {
     ArenaScope scope(c.arena);
     std::vector<const uint32_t*> at_n;
@@ -287,6 +325,7 @@ LassoClaims lasso_argue(Ctx& c, const lh_lasso_table& tb, size_t n, const LassoC
     Fr* eq = c.arena.alloc_n<Fr>(eq_half_n ? M : std::max(N, M));
     if (eq_half_n) {
       k_inner_products_small_half(c, at_n.data(), at_n.size(), eq_half_n, N / 2, dev(cl.r_N[0]), (Fr*)cl.ev_n.data());
+      sum_ranks(cl.ev_n.data(), cl.ev_n.size());
     } else {
       k_eq_xy(c, (const Fr*)cl.r_N.data(), n, eq);
       k_inner_products_small(c, at_n.data(), at_n.size(), eq, N, (Fr*)cl.ev_n.data());
@@ -310,8 +349,19 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
   if (n > pcs.max_vars || l > pcs.max_vars)
     throw Error(LH_ERR_INVALID_PCS_PARAM, "Too many variates of poly to commit");
   // every committed poly is zero-padded to nv = max(n, l) variables (spec step 1)
-  const size_t nv = std::max(n, l), NV = (size_t)1 << nv;
-  const size_t N = (size_t)1 << n, M = (size_t)1 << l;
+  // Inside a sharded proof (dev.hpp Shard, lasso_prove_sharded below) d_dims are this rank's shards of the lookup columns
+  // and every n-variable column below is a shard of N = 2^(n - rho) entries; what crosses ranks: the access counters'
+  // exchange, partial commitments, partial sums per round, residual tables (prover.cpp).  World of one: nothing.
+  const Shard sh(c);
+  const bool shn = sh.on;
+  if (shn) {
+    LH_REQUIRE(pcs.shard_bases != nullptr, LH_ERR_ARG, "sharded prove: implemented for multilinear KZG");
+    LH_REQUIRE(sh.j >= 1 && l <= sh.j + sh.rho, LH_ERR_ARG,
+               "sharded prove: need shard_bit + rho >= chunk_bits (subtables replicated)");
+    LH_REQUIRE(sh.sharded(n) && n >= l, LH_ERR_ARG, "sharded prove: 2^num_vars lookups are too few to shard");
+  }
+  const size_t nv = std::max(n, l), NV = (size_t)1 << (nv - sh.rho);
+  const size_t N = (size_t)1 << (n - sh.rho), M = (size_t)1 << l;
   double t0 = now_ms(), t_prev = t0;
   double* ph = c.lasso_ms;
   auto lap = [&](int idx) {
@@ -323,12 +373,13 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
 
   ArenaScope scope(c.arena);
   EqHalfScope eq_scope(c);  // (the shared eq tables are arena memory of this scope)
+  c.route = RouteStats();
   std::vector<uint32_t> count_ors(cc, 0);  // OR of every final_cts column (bounds its read_ts column) when computed
   // ---- witness: counters, subtable reads, lookup outputs
   Fr* a = nullptr;
   uint32_t* a_small = nullptr;
   // (the sorted dim columns only pay off where the MSM sorts slab by slab: msm.hip LH_MSM_SLAB_LOG)
-  LassoColumns w = lasso_witness_columns(c, tb, n, d_dims, &a, &a_small, (int)n >= msm_slab_log());
+  LassoColumns w = lasso_witness_columns(c, tb, n, d_dims, &a, &a_small, !shn && (int)n >= msm_slab_log());
   std::vector<uint32_t*>&rts = w.rts, &fcs = w.fcs, &E = w.E;
   lap(0);
   // ---- 0/1: domain separation + commitments (one batched MSM)
@@ -341,7 +392,9 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
     // Commitments are linear, so columns that are linear in others need no MSM of their own (same group elements,
     // same proof bytes): E_i = dim_j for an identity subtable, and a = sum_m coeff_m E_{f(m)} when g is linear
     // (range / AND / XOR tables): 4 of 9 column MSMs instead of 9 for the range check.
-    const G1Affine* bases = pcs.commit_bases(nv);
+    // (sharded: this rank's share of the bases; every MSM below is the commitment of a shard - the chunk-split-then-sum
+    // of util/arithmetic/msm.rs:101-114 with the shards as chunks - and the partial commitments are added at the end)
+    const G1Affine* bases = shn ? pcs.shard_bases(nv) : pcs.commit_bases(nv);
     bool linear_g = true;
     for (uint32_t m = 0; m < tb.num_terms; m++) linear_g = linear_g && tb.g_num_factors[m] == 1;
     const size_t total = 1 + 3 * cc + alpha;
@@ -356,7 +409,10 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
     for (size_t j = 0; j < cc; j++) {
       dim_job[j] = jobs.size(), add_job(1 + j, d_dims[j], true, N);
       jobs.back().known_bits = (uint32_t)l;  // (the access counters rejected any index >= 2^l)
-      if (!w.dim_sorted.empty()) jobs.back().sorted_scalars = w.dim_sorted[j], jobs.back().sorted_index = w.dim_index[j];
+      if (!w.dim_sorted.empty()) {
+        jobs.back().sorted_scalars = w.dim_sorted[j], jobs.back().sorted_index = w.dim_index[j];
+        c.route.v[RouteStats::SORTED_REUSE]++;
+      }
     }
     // read_ts columns are small (a cell's access count): two of them share one pass over the points when their bit
     // lengths allow (MsmJob::pack_shift; the access counts bound the timestamps)
@@ -365,10 +421,7 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
     {
       std::vector<uint32_t>& ors = count_ors;
       std::vector<const uint32_t*> cols(fcs.begin(), fcs.end());
-      static const bool pack_on = [] {
-        const char* e = getenv("LH_LASSO_PACK_TS");  // 0: one MSM pass per read_ts column (A/B measurements)
-        return !e || atoi(e) != 0;
-      }();
+      const bool pack_on = c.opt.lasso_pack_ts != 0;  // 0: one MSM pass per read_ts column (A/B measurements)
       if (pack_on && cc >= 2 && N >= ((size_t)1 << 12)) k_or_u32(c, cols.data(), cc, M, ors.data());
       auto bits_of = [](uint32_t v) { return v ? 32u - (uint32_t)__builtin_clz(v) : 0u; };
       for (size_t j = 0; j < cc; j++) {
@@ -381,6 +434,7 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
           jobs.back().pack_shift = b0;
           jobs.back().out_second = (G1Affine*)&second[j + 1];
           second_of.push_back(j + 1);
+          c.route.v[RouteStats::PACKED_TS]++;
           j++;
         } else {
           add_job(1 + cc + j, rts[j], true, N);
@@ -400,15 +454,26 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
           jb.derived_parent = (int)dim_job[tb.memory_chunk[i]];
           orders.get((int)tb.memory_subtable[i], &jb.d_table, &jb.d_order);
           jb.table_in_bits = (uint32_t)l, jb.table_out_bits = (uint32_t)(l / 2);
+          c.route.v[RouteStats::DERIVED]++;
         }
         jobs.back().known_bits = (uint32_t)(l / 2);  // AND / XOR of two (l/2)-bit halves
       }
-    for (size_t j = 0; j < cc; j++) {
+    const size_t num_sharded = jobs.size();
+    for (size_t j = 0; j < cc; j++) {  // (final_cts is replicated: committed in full on every rank)
       add_job(1 + 2 * cc + alpha + j, fcs[j], true, M);
+      jobs.back().bases = pcs.commit_bases(nv);
       jobs.back().known_bits = count_ors[j] ? 32u - (uint32_t)__builtin_clz(count_ors[j]) : 0u;
     }
     std::vector<HG1> part(jobs.size()), comms(total);
     msm_batch(c, jobs.data(), jobs.size(), (G1Affine*)part.data());
+    if (shn) {
+      // partial commitments of the shards (the second outputs of packed jobs included) -> their sums, one exchange
+      std::vector<HG1> sums(part.begin(), part.begin() + num_sharded);
+      for (size_t j : second_of) sums.push_back(second[j]);
+      comm_sum_points(c, sums.data(), sums.size());
+      for (size_t k = 0; k < num_sharded; k++) part[k] = sums[k];
+      for (size_t q = 0; q < second_of.size(); q++) second[second_of[q]] = sums[num_sharded + q];
+    }
     for (size_t k = 0; k < jobs.size(); k++) comms[slot[k]] = part[k];
     for (size_t j : second_of) comms[1 + cc + j] = second[j];
     for (size_t i = 0; i < alpha; i++)
@@ -461,6 +526,12 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
     small[1 + j] = SmallPoly{d_dims[j], N, (uint32_t)l};
     small[1 + cc + j] = SmallPoly{rts[j], N, count_ors[j] ? 32u - (uint32_t)__builtin_clz(count_ors[j]) : 0u};
     small[num_n + j] = SmallPoly{fcs[j], M, 0};
+    if (shn) {
+      // the zero-padded n-variable final_cts column lives in the index range [0, 2^l), l <= shard_bit + rho: this rank's
+      // shard of it is the slice [rank * 2^shard_bit, (rank + 1) * 2^shard_bit) at its local indices [0, 2^shard_bit)
+      const size_t first = sh.rank << sh.j;
+      small[num_n + j] = first < M ? SmallPoly{fcs[j] + first, std::min(M - first, (size_t)1 << sh.j), 0} : SmallPoly{fcs[j], 0, 0};
+    }
   }
   bool linear_surge = true;  // (lasso_argue: the Surge sum-check then runs over the output column alone)
   for (uint32_t m = 0; m < tb.num_terms; m++) linear_surge = linear_surge && tb.g_num_factors[m] == 1;
@@ -503,6 +574,21 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
   lap(6);
   ph[7] = 0;
   ph[8] = now_ms() - t0;
+}
+
+// ONE proof over the 2^rho ranks of the ctx's communicator: the same prover, with every table a shard
+// (dev.hpp Shard).  Same transcript, same proof bytes on every rank as lasso_prove on one GPU.
+void lasso_prove_sharded(Ctx& c, const Srs& srs, const lh_lasso_table& tb, size_t n, const uint32_t* const* d_dims_local,
+                         Transcript& tr) {
+  LH_REQUIRE(c.has_comm, LH_ERR_ARG, "lasso_prove_sharded: no communicator attached");
+  const size_t R = (size_t)c.comm.size;
+  LH_REQUIRE(R >= 1 && (R & (R - 1)) == 0, LH_ERR_ARG, "sharded prove: the number of ranks must be a power of two");
+  struct Active {
+    Ctx& c;
+    explicit Active(Ctx& c_) : c(c_) { c.shard_active = true; }
+    ~Active() { c.shard_active = false; }
+  } active(c);
+  lasso_prove(c, lasso_mkzg_pcs(c, srs), tb, n, d_dims_local, tr);
 }
 
 }  // namespace lh

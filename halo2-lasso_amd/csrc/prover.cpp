@@ -107,14 +107,16 @@ void comm_sum_points(Ctx& c, HG1* pts, size_t n) {
   }
 }
 
-// out[t][hi * R + s] = (rank s).local[t][hi]   (the shard bits have reached bit 0).  `local_block`: the `count` local
-// tables back to back (count * n_local entries) - ONE device all-gather, one interleaving pass.
-void comm_gather_interleave(Ctx& c, const Fr* local_block, size_t count, size_t n_local, Fr* const* out) {
+// `count` local tables back to back (count * n_local entries) -> the full tables on every rank: ONE device all-gather and
+// one rearranging pass.  `block`: entries of a rank that are still contiguous in the global order - 2^(shard_bit - rounds
+// bound) for the residual tables of a sum-check (1 once the shard bits have reached bit 0), n_local when the shard bits
+// are the top bits (tree levels and quotient remainders at the replication point: a plain concatenation).
+void comm_gather_tables(Ctx& c, const Fr* local_block, size_t count, size_t n_local, size_t block, Fr* const* out) {
   const size_t R = (size_t)c.comm.size;
   ArenaScope scope(c.arena);
   Fr* gathered = c.arena.alloc_n<Fr>(count * n_local * R);
   comm_all_gather_dev(c, local_block, gathered, count * n_local * sizeof(Fr));
-  k_gather_interleave(c, gathered, count, n_local, R, out);
+  k_gather_interleave(c, gathered, count, n_local, R, block, out);
 }
 
 // out[s * n_local + i] = (rank s).local[i]   (the shard bits are the top bits): exactly an all-gather
@@ -128,14 +130,13 @@ static size_t log2_exact(size_t v) {
   return l;
 }
 
-// local shard of eq_xy(y): drop the shard coordinates, scale by eq_shard(y_shard)[rank]
-static void eq_xy_shard(Ctx& c, const HFr* y, size_t num_vars, Fr* out_local) {
-  const size_t rho = log2_exact((size_t)c.comm.size), j = c.shard_bit;
+// local shard of eq_xy(y[first..num_vars)): drop the shard coordinates, scale by eq_shard(y_shard)[rank]
+static void eq_xy_shard(Ctx& c, const Shard& sh, const HFr* y, size_t num_vars, size_t first, Fr* out_local) {
   std::vector<HFr> yl;
   HFr scale = HFr::one();
-  for (size_t i = 0; i < num_vars; i++) {
-    if (i >= j && i < j + rho) {
-      bool bit = ((size_t)c.comm.rank >> (i - j)) & 1;
+  for (size_t i = first; i < num_vars; i++) {
+    if (i >= sh.j && i < sh.j + sh.rho) {
+      bool bit = (sh.rank >> (i - sh.j)) & 1;
       scale *= bit ? y[i] : HFr::one() - y[i];
     } else {
       yl.push_back(y[i]);
@@ -143,39 +144,51 @@ static void eq_xy_shard(Ctx& c, const HFr* y, size_t num_vars, Fr* out_local) {
   }
   const size_t n_local = (size_t)1 << yl.size();
   k_eq_xy(c, (const Fr*)yl.data(), yl.size(), out_local);
-  k_scale(c, out_local, dev(scale), n_local, out_local);
+  if (sh.rho) k_scale(c, out_local, dev(scale), n_local, out_local);
 }
 
-std::vector<HFr> evaluate_polys_sharded(Ctx& c, const Fr* const* d_polys_local, size_t count, size_t num_vars,
-                                        const HFr* point) {
+// evaluations of tables at a point; `sharded`: the tables are this rank's shards of num_vars-variable tables - partial
+// inner products against the local shard of eq(point), summed over the ranks
+std::vector<HFr> evaluate_polys(Ctx& c, const Fr* const* d_polys, size_t count, size_t num_vars, const HFr* point, bool sharded) {
+  if (!sharded) return evaluate_polys(c, d_polys, count, num_vars, point);
   std::vector<HFr> out(count);
   if (!count) return out;
+  const Shard sh(c);
   ArenaScope scope(c.arena);
-  const size_t rho = log2_exact((size_t)c.comm.size);
-  const size_t n_local = (size_t)1 << (num_vars - rho);
+  const size_t n_local = (size_t)1 << (num_vars - sh.rho);
   Fr* eq = c.arena.alloc_n<Fr>(n_local);
-  eq_xy_shard(c, point, num_vars, eq);
-  k_inner_products(c, d_polys_local, count, eq, n_local, (Fr*)out.data());
+  eq_xy_shard(c, sh, point, num_vars, 0, eq);
+  k_inner_products(c, d_polys, count, eq, n_local, (Fr*)out.data());
   comm_sum_fr(c, out.data(), count);
   return out;
 }
 
 // ------------------------------------------------------------------ shared eq tables of point tails (host.hpp)
-const Fr* eq_half_lookup(Ctx& c, const HFr* y, size_t num_vars) {
+// `sharded`: this rank's shard of the table (the shard coordinates dropped, the rank's factor multiplied in) - its entries
+// then weigh the local shards of n-variable columns, and the partial sums of the ranks add up
+const Fr* eq_half_lookup(Ctx& c, const HFr* y, size_t num_vars, bool sharded) {
   if (num_vars < 2) return nullptr;
   const size_t bytes = (num_vars - 1) * sizeof(HFr);
   for (const Ctx::EqHalfEntry& e : c.eq_half_cache)
-    if (e.key.size() == bytes && memcmp(e.key.data(), y + 1, bytes) == 0) return e.table;
+    if (e.sharded == sharded && e.key.size() == bytes && memcmp(e.key.data(), y + 1, bytes) == 0) return e.table;
   return nullptr;
 }
-const Fr* eq_half_get(Ctx& c, const HFr* y, size_t num_vars) {
-  if (const Fr* t = eq_half_lookup(c, y, num_vars)) return t;
+const Fr* eq_half_get(Ctx& c, const HFr* y, size_t num_vars, bool sharded) {
+  if (const Fr* t = eq_half_lookup(c, y, num_vars, sharded)) return t;
   LH_REQUIRE(num_vars >= 2, LH_ERR_ARG, "eq_half: needs two variables");
-  Fr* t = c.arena.alloc_n<Fr>((size_t)1 << (num_vars - 1));
-  k_eq_xy(c, (const Fr*)(y + 1), num_vars - 1, t);
+  Fr* t;
+  if (sharded) {
+    const Shard sh(c);
+    t = c.arena.alloc_n<Fr>((size_t)1 << (num_vars - sh.rho - 1));
+    eq_xy_shard(c, sh, y, num_vars, 1, t);  // (shard_bit >= 1: coordinate 0 is never a shard coordinate)
+  } else {
+    t = c.arena.alloc_n<Fr>((size_t)1 << (num_vars - 1));
+    k_eq_xy(c, (const Fr*)(y + 1), num_vars - 1, t);
+  }
   Ctx::EqHalfEntry e;
   e.key.assign((const uint8_t*)(y + 1), (const uint8_t*)(y + 1) + (num_vars - 1) * sizeof(HFr));
   e.table = t;
+  e.sharded = sharded;
   c.eq_half_cache.push_back(std::move(e));
   return t;
 }
@@ -189,10 +202,21 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
                                      const std::vector<char>& used, size_t num_polys, const HFr& sum, Transcript& tr,
                                      bool sharded, const RoundFn& round_fn, const ScRound* tail_rd, EqFactoring* ef) {
   const size_t T = cur.size();
-  bool ef_on = ef != nullptr && !sharded;
-  const size_t tail_cap = tail_rd ? k_sc_tail_capacity(*tail_rd, degree) : 0;
+  bool ef_on = ef != nullptr;
+  const size_t tail_cap = tail_rd ? k_sc_tail_capacity(c, *tail_rd, degree) : 0;
   const size_t rho = sharded ? log2_exact((size_t)c.comm.size) : 0, j = c.shard_bit;
   size_t len = (size_t)1 << (num_vars - rho);  // current length of every (local) table
+  // sharded: the round before which the residual tables are exchanged and the sum-check goes on replicated - as soon as
+  // they are small enough for one all-gather (Ctx::shard_exchange_log), at the latest when the shard bits reach bit 0
+  size_t x_round = 0;
+  if (sharded) {
+    x_round = j;
+    for (size_t r = 1; r < j; r++)
+      if ((T << (num_vars - r)) <= ((size_t)1 << c.opt.shard_exchange_log)) {
+        x_round = r;
+        break;
+      }
+  }
   // ping-pong targets of the binds: A holds len/2, B holds len/4
   std::vector<Fr*> bufA(T), bufB(T);
   auto alloc_bufs = [&](size_t l) {
@@ -238,26 +262,45 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
   bool tail_ok = true;  // cleared when a resident tail ended early: the remaining rounds are launched one by one
   for (size_t round = 0; round < num_vars; round++) {
     bool bind = round > 0;
-    if (sh && round == j) {
-      // the shard bits are about to become the pair bit: bind once more, exchange, go on replicated
-      // (the T bound tables go into one block: a single all-gather moves them)
+    if (sh && round == x_round) {
+      // bind once more, exchange, go on replicated (the bound tables go into one block: a single all-gather moves them).
+      // A factored eq table does not travel: bound through round - 1 it is S_round * eq(y[round..]) on every rank.
       len >>= 1;
-      Fr* block = c.arena.alloc_n<Fr>(T * len);
-      std::vector<Fr*> dst(T);
-      for (size_t i = 0; i < T; i++) dst[i] = block + i * len;
-      k_fix_var_multi(c, cur.data(), dst.data(), T, len << 1, dev(r_prev));
-      std::vector<Fr*> rep(T);
+      std::vector<size_t> live;
+      for (size_t i = 0; i < T; i++) {
+        bool factored = false;
+        if (ef_on)
+          for (const EqFactoring::One& one : ef->eqs) factored = factored || one.table == i;
+        if (!factored) live.push_back(i);
+      }
+      const size_t L = live.size();
+      Fr* block = c.arena.alloc_n<Fr>(L * len);
+      std::vector<const Fr*> src(L);
+      std::vector<Fr*> dst(L), rep(L);
+      for (size_t k = 0; k < L; k++) src[k] = cur[live[k]], dst[k] = block + k * len;
+      k_fix_var_multi(c, src.data(), dst.data(), L, len << 1, dev(r_prev));
       const size_t full = len << rho;
-      for (size_t i = 0; i < T; i++) rep[i] = c.arena.alloc_n<Fr>(full);
-      comm_gather_interleave(c, block, T, len, rep.data());
-      for (size_t i = 0; i < T; i++) cur[i] = rep[i];
+      for (size_t k = 0; k < L; k++) rep[k] = c.arena.alloc_n<Fr>(full);
+      comm_gather_tables(c, block, L, len, (size_t)1 << (j - round), rep.data());
+      c.route.v[RouteStats::SHARD_EXCHANGES]++;
+      for (size_t k = 0; k < L; k++) cur[live[k]] = rep[k];
+      if (ef_on) {
+        for (EqFactoring::One& one : ef->eqs) {
+          Fr* tab = c.arena.alloc_n<Fr>(full);
+          k_eq_xy(c, (const Fr*)(one.y + round), num_vars - round, tab);
+          k_scale(c, tab, dev(one.S), full, tab);
+          cur[one.table] = tab;
+        }
+        ef_on = false;
+      }
       len = full;
       alloc_bufs(len);
       flip = 0;
       sh = false;
       bind = false;
     }
-    if (ef_on && !ef->streams(bind, bind ? len >> 2 : len >> 1)) {
+    const bool tail_now = !sh && tail_ok && tail_cap && (bind ? len >> 1 : len) <= tail_cap;
+    if (ef_on && (tail_now || !ef->streams(bind, bind ? len >> 2 : len >> 1))) {
       // the rounds leave the streaming kernel: materialise every factored eq table in the form the standard path
       // expects (the tables of the previous round, pending their bind with r_prev): S_{round-1} * E_{round-2}
       LH_REQUIRE(round >= 2 && bind, LH_ERR_ARG, "sum-check: eq factoring ended before it began");
@@ -268,7 +311,7 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
       }
       ef_on = false;
     }
-    if (!sh && tail_ok && tail_cap && (bind ? len >> 1 : len) <= tail_cap) {
+    if (tail_now) {
       // the rest of the sum-check runs resident on one CU (dev.hpp: k_sc_tail_*): same messages, same order
       const size_t n0 = bind ? len >> 1 : len, rounds = num_vars - round;
       LH_REQUIRE(((size_t)1 << rounds) == n0 && num_polys <= T, LH_ERR_ARG, "sum-check: internal size mismatch");
@@ -287,12 +330,19 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
           if (done) return;
           c.mbox_abort();
           (void)hipStreamSynchronize(c.stream);
+          // the workgroups left having drawn fewer tickets than the launch reserved: later launches must count from
+          // where the device counter really is
+          try {
+            k_sc_tail_resync(c);
+          } catch (...) {
+          }
         }
       } guard{c};
       // the round messages arrive as 3 * degree self-validating chunks in the first 512 bytes of the pinned block
       TailChunk* chunks = (TailChunk*)evals_host;
       memset((void*)chunks, 0, 3 * SC_TAIL_MAX_DEGREE * sizeof(TailChunk));
       k_sc_tail_launch(c, rd, degree, n0, bind, num_polys, seq0, chunks, evals_host + 16);
+      c.route.v[RouteStats::TAILS]++;
       double host_us = 0;
       size_t absorbed = 0;  // tail rounds whose message is in the transcript and whose challenge is known
       bool gave_up = false;
@@ -319,6 +369,7 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
         const HFr r = message(sums);
         c.mbox_send(dev(r), seq0 + (uint32_t)i);
         absorbed = i + 1;
+        c.route.v[RouteStats::TAIL_ROUNDS]++;
         if (tail_debug) host_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_h).count();
       }
       if (!gave_up && !wait(seq0 + (uint32_t)rounds, false)) gave_up = true;
@@ -377,30 +428,48 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
         if (!used[i]) k_fix_var(c, cur[i], len, dev(r_prev), dst[i]);
     }
     if (sh) {
-      // [round kernel -> all-gather of the D partial sums -> sum and publish], all on the ctx's stream
+      // [round kernel -> all-gather of the partial sums -> sum and publish], all on the ctx's stream.  With factored eq
+      // tables the partial sums are those of q (this rank's eq-level entries carry its factor of the shard coordinates).
       const size_t R = (size_t)c.comm.size;
       if (!d_part) {
-        d_part = c.arena.alloc_n<Fr>(8);
-        d_all = c.arena.alloc_n<Fr>(8 * R);
+        d_part = c.arena.alloc_n<Fr>(16);
+        d_all = c.arena.alloc_n<Fr>(16 * R);
       }
+      size_t nvals = (size_t)degree;
       c.sc_redirect = d_part;
       try {
-        round_fn(cur.data(), dst.data(), dev(r_prev), bind, size, evals_host);
+        if (ef_on) {
+          nvals = ef->per_term ? 2 * ef->eqs.size() : (size_t)degree - 1;
+          ef->add_const = HFr::zero();
+          ef->round(cur.data(), dst.data(), dev(r_prev), bind, size, round, (int)nvals, evals_host);
+          factored_round = true;
+        } else {
+          round_fn(cur.data(), dst.data(), dev(r_prev), bind, size, evals_host);
+        }
       } catch (...) {
         c.sc_redirect = nullptr;
         throw;
       }
       c.sc_redirect = nullptr;
-      comm_all_gather_dev(c, d_part, d_all, (size_t)degree * sizeof(Fr));
+      c.route.v[RouteStats::SHARDED_ROUNDS]++;
+      c.route.v[factored_round ? RouteStats::EF_ROUNDS : RouteStats::STD_ROUNDS]++;
+      LH_REQUIRE(nvals <= 16, LH_ERR_ARG, "sharded sum-check: too many partial sums per round");
+      comm_all_gather_dev(c, d_part, d_all, nvals * sizeof(Fr));
       const uint32_t seq = c.next_seq();
-      k_sum_publish(c, d_all, R, (size_t)degree, evals_host, seq);
+      k_sum_publish(c, d_all, R, nvals, evals_host, seq);
       c.wait_flag(seq);
+      if (factored_round && !ef->per_term)  // (constants the factored kernel leaves to the host: the eq level sums to one)
+        for (size_t x = 0; x < nvals; x++) evals_host[x] = dev(hst(evals_host[x]) + ef->add_const);
     } else if (ef_on) {
       // global-eq shape, round 0: one point more (q at 1..D determines q(0) too), so that the claim can be CHECKED instead
       // of trusted: with a claim that is not the true sum the reference still sends the true p(1..D), and so must we
       const bool check_claim = !ef->per_term && round == 0 && !ef->trusted_claim;
+      ef->add_const = HFr::zero();
       ef->round(cur.data(), dst.data(), dev(r_prev), bind, size, round, check_claim ? degree : degree - 1, evals_host);
       factored_round = true;
+      c.route.v[RouteStats::EF_ROUNDS]++;
+      if (!ef->add_const.is_zero())
+        for (int x = 0; x < degree - 1; x++) evals_host[x] = dev(hst(evals_host[x]) + ef->add_const);
       if (check_claim) {
         EqFactoring::One& e = ef->eqs[0];
         std::vector<HFr> shifted(degree);  // t -> q(t + 1), t = 0..D-1
@@ -415,6 +484,7 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
             cur[one.table] = tab;
           }
           ef_on = factored_round = false;
+          c.route.v[RouteStats::EF_ROUNDS]--, c.route.v[RouteStats::STD_ROUNDS]++;
           round_fn(cur.data(), dst.data(), dev(r_prev), bind, size, evals_host);
         } else {
           e.q.assign(degree, HFr::zero());
@@ -424,6 +494,7 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
       }
     } else {
       round_fn(cur.data(), dst.data(), dev(r_prev), bind, size, evals_host);
+      c.route.v[RouteStats::STD_ROUNDS]++;
     }
     if (bind) {
       for (size_t i = 0; i < T; i++) cur[i] = dst[i];
@@ -493,10 +564,11 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
 // GPU (k_sc_round), message to the transcript, squeeze r_i.  After the last squeeze one more bind gives
 // table[0] of every poly (classic.rs:143-149).
 //
-// `sharded`: the tables are this rank's shards.  Rounds 0..shard_bit-1 run on the local
-// shard and the D partial sums of all ranks are added; before round shard_bit the residual tables are
-// bound once more, exchanged (the shard bits have reached bit 0) and the remaining rounds run
-// replicated on every rank.  The transcript sees exactly the single-GPU messages.
+// `sharded`: the tables are this rank's shards (dev.hpp Shard; this is ProverState::next_round, classic.rs:90-141, over a
+// shard).  The first rounds run the very same kernels on the local shard - eq factoring included - and the partial sums
+// of all ranks are added; once the residual tables are small (at the latest before round shard_bit, when the shard bits
+// would become the pair bit) they are bound once more, exchanged, and the remaining rounds run replicated on every rank.
+// The transcript sees exactly the single-GPU messages.
 static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_vars, const lh_sop& expr,
                                            const Fr* const* d_polys, size_t num_polys, const HFr* ys, size_t num_ys,
                                            const HFr& sum, Transcript& tr, bool sharded, bool sum_is_exact = false,
@@ -553,16 +625,15 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
   };
 
   // ---- eq factoring of the streaming rounds (host.hpp EqFactoring)
-  static const bool ef_enabled = [] {
-    const char* e = getenv("LH_SC_EQ_FACTORING");  // 0: every round streams and binds its eq tables (A/B measurements)
-    return !e || atoi(e) != 0;
-  }();
+  const bool ef_enabled = c.opt.sc_eq_factoring != 0;  // 0: every round streams and binds its eq tables (A/B measurements)
   EqFactoring ef;
   bool use_ef = false;
   std::vector<size_t> term_poly;  // per-term shape: the poly of term m
-  if (ef_enabled && !sharded && num_vars >= 3 && k_sc_round_streams(rd, degree, (size_t)1 << (num_vars - 1)) &&
-      k_sc_round_streams(rd, degree, (size_t)1 << (num_vars - 2))) {
-    if (rd.global_eq >= 0 && prover_kind == LH_SC_EVALUATIONS) {
+  const size_t nvl = num_vars - rho;  // variables of the local tables
+  // (sharded: the first two rounds must be local ones, and the claim is not checked against partial sums)
+  if (ef_enabled && nvl >= 3 && (!sharded || j >= 2) && k_sc_round_streams(rd, degree, (size_t)1 << (nvl - 1)) &&
+      k_sc_round_streams(rd, degree, (size_t)1 << (nvl - 2))) {
+    if (rd.global_eq >= 0 && prover_kind == LH_SC_EVALUATIONS && degree >= 2 && (!sharded || sum_is_exact)) {
       // shape A: eq(ys[global_eq]) times a sum of products that does not use that eq table as a factor
       bool ok = true;
       for (uint32_t m = 0; m < rd.num_terms && ok; m++)
@@ -615,15 +686,16 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
     }
   }
   if (use_ef) {
-    const size_t half = (size_t)1 << (num_vars - 1);
+    const Shard shg(c);
+    const size_t half = (size_t)1 << (nvl - 1);
     for (EqFactoring::One& one : ef.eqs) {
-      // consecutive blocks of halving size in one buffer; E_0 (the eq table over variables 1..n-1) comes from the proof's
-      // shared tables when an evaluation at the same point built it already
-      const Fr* shared = eq_half_lookup(c, one.y, num_vars);
+      // consecutive blocks of halving size in one buffer; E_0 (the eq table over variables 1..n-1; sharded: this rank's
+      // shard of it) comes from the proof's shared tables when an evaluation at the same point built it already
+      const Fr* shared = eq_half_lookup(c, one.y, num_vars, sharded);
       Fr* buf = c.arena.alloc_n<Fr>(shared ? half : 2 * half);
       one.level.resize(num_vars);
       size_t off = 0;
-      for (size_t jl = 0; jl < num_vars; jl++) {
+      for (size_t jl = 0; jl < nvl; jl++) {
         if (jl == 0 && shared) {
           one.level[0] = const_cast<Fr*>(shared);
           continue;
@@ -631,7 +703,9 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
         one.level[jl] = buf + off;
         off += half >> jl;
       }
-      if (!shared) k_eq_xy(c, (const Fr*)(one.y + 1), num_vars - 1, buf);
+      if (shared) continue;
+      if (sharded) eq_xy_shard(c, shg, one.y, num_vars, 1, buf);
+      else k_eq_xy(c, (const Fr*)(one.y + 1), num_vars - 1, buf);
     }
     ef.streams = [&](bool, size_t size) { return k_sc_round_streams(rd, degree, size); };
     ef.round = [&](const Fr* const* in, Fr* const* out, const Fr& r, bool bind, size_t size, size_t round, int points,
@@ -651,7 +725,8 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
         g.eq_level = ef.eqs[0].level[round];
         g.rchal = r;
         k_sc_round_rw(c, g, bind, size, out_host);
-        for (int x = 0; x < 2; x++) out_host[x] = dev(hst(out_host[x]) + rw->const_total);  // (the suffix eq sums to one)
+        c.route.v[RouteStats::RW_ROUNDS]++;
+        ef.add_const = rw->const_total;  // added to q(1), q(2) by the round loop (the suffix eq sums to one - over all ranks)
       } else if (!ef.per_term) {
         ScRound g = rd;
         for (size_t i = 0; i < T; i++) g.in[i] = in[i], g.out[i] = out[i];
@@ -679,7 +754,7 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
       for (const EqFactoring::One& one : ef.eqs) factored = factored || one.table == num_polys + jy;
     if (factored) continue;
     Fr* eq = c.arena.alloc_n<Fr>(len0);
-    if (sharded) eq_xy_shard(c, ys + jy * num_vars, num_vars, eq);
+    if (sharded) eq_xy_shard(c, Shard(c), ys + jy * num_vars, num_vars, 0, eq);
     else k_eq_xy(c, (const Fr*)(ys + jy * num_vars), num_vars, eq);
     cur[num_polys + jy] = eq;
   }
@@ -689,19 +764,14 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
 
 SumCheckResult sum_check_prove(Ctx& c, int prover_kind, size_t num_vars, const lh_sop& expr,
                                const Fr* const* d_polys, size_t num_polys, const HFr* ys, size_t num_ys,
-                               const HFr& sum, Transcript& tr, bool sum_is_exact, const ScRwPairs* rw) {
+                               const HFr& sum, Transcript& tr, bool sum_is_exact, const ScRwPairs* rw, bool sharded) {
   if (rw)
     LH_REQUIRE(rw->num_pairs >= 1 && rw->num_pairs <= (uint32_t)SC_RW_MAX_PAIRS && num_polys == 2 * (size_t)rw->num_pairs &&
                    expr.global_eq >= 0 && sum_is_exact,
                LH_ERR_ARG, "sum-check: tree-pair rounds over the wrong shape");
-  return sum_check_prove_impl(c, prover_kind, num_vars, expr, d_polys, num_polys, ys, num_ys, sum, tr, false, sum_is_exact,
+  if (sharded) LH_REQUIRE(c.shard_active && c.has_comm, LH_ERR_ARG, "sharded sum-check outside a sharded proof");
+  return sum_check_prove_impl(c, prover_kind, num_vars, expr, d_polys, num_polys, ys, num_ys, sum, tr, sharded, sum_is_exact,
                               rw);
-}
-
-SumCheckResult sum_check_prove_sharded(Ctx& c, int prover_kind, size_t num_vars, const lh_sop& expr,
-                                       const Fr* const* d_polys_local, size_t num_polys, const HFr* ys, size_t num_ys,
-                                       const HFr& sum, Transcript& tr) {
-  return sum_check_prove_impl(c, prover_kind, num_vars, expr, d_polys_local, num_polys, ys, num_ys, sum, tr, true);
 }
 
 // ------------------------------------------------------------------ prove_fractional_sum_check
@@ -826,6 +896,11 @@ GrandProductResult prove_grand_product(Ctx& c, size_t B, const Fr* const* d_leav
   LH_REQUIRE(2 * B + 1 <= (size_t)SC_MAX_TABLES && B <= LH_SC_MAX_TERMS, LH_ERR_ARG,
              "grand product: too many trees for one round kernel");
   ArenaScope scope(c.arena);
+  // Inside a sharded proof (dev.hpp Shard) a level of 2^(h+1) nodes is held in shards while it has more than
+  // shard_bit + rho variables: Layer::up (fractional_sum_check.rs:62-85; here v = l * r) pairs node i with node i + half,
+  // the top index bit, which is local to a shard.  At the replication point the level is exchanged once (the shard bits
+  // have become its top bits: a concatenation) and everything above is computed redundantly on every rank.
+  const Shard sh(c);
   // level[b][h]: array with 2^(h+1) nodes, h = 0 (top, two nodes) .. depth-1 (the leaves)
   std::vector<std::vector<const Fr*>> level(B);
   {
@@ -839,7 +914,7 @@ GrandProductResult prove_grand_product(Ctx& c, size_t B, const Fr* const* d_leav
       level[b].resize(num_vars[b]);
       level[b][num_vars[b] - 1] = d_leaves[b];
       size_t h = num_vars[b] - 1;
-      if (d_level_up && d_level_up[b] && h > SMALL) {
+      if (d_level_up && d_level_up[b] && h > SMALL && (!sh.on || sh.sharded(h))) {
         level[b][h - 1] = d_level_up[b];
         h--;
       }
@@ -847,23 +922,43 @@ GrandProductResult prove_grand_product(Ctx& c, size_t B, const Fr* const* d_leav
       max_h = std::max(max_h, h);
     }
     // level by level, the trees of equal size in one launch
-    for (size_t h = max_h; h > SMALL; h--) {
+    for (size_t h = max_h; h >= 1 && (h > SMALL || sh.sharded(h + 1)); h--) {
       std::vector<const Fr*> ins;
       std::vector<Fr*> outs;
-      const size_t half = (size_t)1 << h;
+      std::vector<size_t> who;
+      const bool in_sh = sh.sharded(h + 1), out_sh = sh.sharded(h);
+      const size_t half = (size_t)1 << (in_sh ? h - sh.rho : h);
       for (size_t b = 0; b < B; b++) {
         if (cur_h[b] != h) continue;
-        Fr* up = c.arena.alloc_n<Fr>(half);
         ins.push_back(level[b][h]);
-        outs.push_back(up);
-        level[b][h - 1] = up;
+        who.push_back(b);
         cur_h[b] = h - 1;
       }
-      if (!ins.empty()) k_tree_up_multi(c, ins.data(), outs.data(), ins.size(), half);
+      if (ins.empty()) continue;
+      if (in_sh && !out_sh) {
+        // replication point: the products of all trees into one block, one all-gather
+        Fr* block = c.arena.alloc_n<Fr>(ins.size() * half);
+        std::vector<Fr*> rep(ins.size());
+        for (size_t k = 0; k < ins.size(); k++) {
+          outs.push_back(block + k * half);
+          rep[k] = c.arena.alloc_n<Fr>((size_t)1 << h);
+        }
+        k_tree_up_multi(c, ins.data(), outs.data(), ins.size(), half);
+        comm_gather_tables(c, block, ins.size(), half, half, rep.data());
+        c.route.v[RouteStats::SHARD_EXCHANGES]++;
+        for (size_t k = 0; k < ins.size(); k++) level[who[k]][h - 1] = rep[k];
+      } else {
+        for (size_t k = 0; k < ins.size(); k++) {
+          outs.push_back(c.arena.alloc_n<Fr>(half));
+          level[who[k]][h - 1] = outs.back();
+        }
+        k_tree_up_multi(c, ins.data(), outs.data(), ins.size(), half);
+      }
     }
     for (size_t b = 0; b < B; b++) {
       const size_t h = cur_h[b];
       // h <= SMALL: levels h-1 .. 0 in one go
+      LH_REQUIRE(h <= SMALL && !sh.sharded(h + 1), LH_ERR_ARG, "grand product: internal level mismatch");
       Fr* tops = c.arena.alloc_n<Fr>(((size_t)2 << h));
       top_in[b] = level[b][h];
       top_out[b] = tops;
@@ -892,7 +987,8 @@ GrandProductResult prove_grand_product(Ctx& c, size_t B, const Fr* const* d_leav
     std::vector<size_t> active;
     for (size_t b = 0; b < B; b++)
       if (num_vars[b] > h) active.push_back(b);
-    const size_t half = (size_t)1 << h;
+    const bool layer_sh = sh.sharded(h + 1);  // this layer's tables (h variables each) are shards
+    const size_t half = (size_t)1 << (layer_sh ? h - sh.rho : h);
     std::vector<HFr> x, evals;
     if (h == 0) {
       for (size_t b : active) {
@@ -944,7 +1040,7 @@ GrandProductResult prove_grand_product(Ctx& c, size_t B, const Fr* const* d_leav
         memcpy(&expr.coeff[t], &cw_sum, 32), expr.num_factors[t] = 0, t++;
         expr.num_terms = t;
         SumCheckResult sc = sum_check_prove(c, LH_SC_EVALUATIONS, h, expr, polys.data(), polys.size(), y.data(), 1, claim, tr,
-                                            true, degenerate ? nullptr : &rw);
+                                            true, degenerate ? nullptr : &rw, layer_sh);
         x = sc.challenges;
         for (size_t i = 0; i < P; i++) {  // evaluations of the B tables: those of the A tables + 1
           const HFr l = sc.evals[2 * i], r = sc.evals[2 * i + 1];
@@ -965,8 +1061,8 @@ GrandProductResult prove_grand_product(Ctx& c, size_t B, const Fr* const* d_leav
         polys.push_back(level[b][h] + half);
       }
       expr.num_terms = (uint32_t)active.size();
-      SumCheckResult sc =
-          sum_check_prove(c, LH_SC_EVALUATIONS, h, expr, polys.data(), polys.size(), y.data(), 1, claim, tr, true);
+      SumCheckResult sc = sum_check_prove(c, LH_SC_EVALUATIONS, h, expr, polys.data(), polys.size(), y.data(), 1, claim, tr,
+                                          true, nullptr, layer_sh);
       x = sc.challenges;
       evals = sc.evals;
       }
@@ -1044,25 +1140,58 @@ std::vector<HG1> mkzg_batch_commit_u32(Ctx& c, const Srs& srs, const uint32_t* c
 // multiple of the level's base sum (Srs::level_sums, computed once).  The lower quotients come from the folded
 // remainder as before.
 static std::mutex level_sums_mu;
+
+// bases of level `lvl` that belong to this rank (same index split as the tables); built on first use
+const G1Affine* srs_shard_level(Ctx& c, const Srs& srs, size_t lvl) {
+  const Shard g(c);
+  LH_REQUIRE(g.on, LH_ERR_ARG, "srs shard: no sharded proof is running");
+  std::lock_guard<std::mutex> lock(level_sums_mu);
+  if (srs.shard_rank != (int)g.rank || srs.shard_R != g.R || srs.shard_j != g.j) {
+    for (G1Affine* p : srs.shard_levels)
+      if (p) (void)hipFree(p);
+    srs.shard_levels.assign(srs.num_vars + 1, nullptr);
+    srs.shard_level_sums.clear();
+    srs.shard_rank = (int)g.rank, srs.shard_R = g.R, srs.shard_j = g.j;
+  }
+  LH_REQUIRE(lvl <= srs.num_vars && lvl >= g.j + g.rho, LH_ERR_ARG, "srs shard: level is not sharded");
+  if (!srs.shard_levels[lvl]) {
+    const size_t n_local = (size_t)1 << (lvl - g.rho);
+    G1Affine* p = nullptr;
+    LH_HIP(hipMalloc((void**)&p, n_local * sizeof(G1Affine)));
+    k_shard_extract(c, srs.eq(lvl), n_local, g.j, g.rho, g.rank, sizeof(G1Affine), p);
+    c.sync();
+    srs.shard_levels[lvl] = p;
+  }
+  return srs.shard_levels[lvl];
+}
+
+// Inside a sharded proof (dev.hpp Shard) `d_poly` / the small columns are this rank's shards.  The quotient of level i
+// is a difference of halves - the top index bit, local to a shard while i >= shard_bit + rho: those levels are computed
+// and committed shard by shard against this rank's share of the level's bases (the chunk-split-then-sum of
+// util/arithmetic/msm.rs:101-114, the chunks being the shards) and the partial commitments are added; the remainder at
+// the replication point is exchanged once (2^(shard_bit + rho) entries) and the small levels run on every rank.
 HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const HFr* point, Transcript& tr,
               const SmallOpen* small) {
   check_commit_vars(srs, num_vars, "open");
-  static const size_t small_min_vars = [] {
-    const char* e = getenv("LH_OPEN_SMALL_MIN_VARS");  // smallest opening that takes the column route (64: never)
-    return e ? (size_t)atoll(e) : (size_t)21;
-  }();
+  const Shard sh(c);
+  const bool sharded = sh.sharded(num_vars);
+  const size_t cut = sharded ? sh.j + sh.rho : 0;  // quotient levels >= cut are held in shards
+  const size_t small_min_vars = (size_t)c.opt.open_small_min_vars;  // smallest opening that takes the column route (64: never)
   const SmallOpen* given = small;
-  if (small && num_vars < small_min_vars) {
+  const size_t lsh = sharded ? sh.rho : 0;        // local length of level i: 2^(i - lsh), i >= cut
+  const size_t n = (size_t)1 << (num_vars - lsh);  // entries of the (local) table
+  // (which route an opening takes is decided per rank on its local sizes: every route yields the commitment of the rank's
+  // shard of each quotient, so ranks may even differ)
+  if (small && num_vars - lsh < small_min_vars) {
     // below the general threshold the route still pays when only a few columns take part (the range check: two dim
     // and two read_ts columns - 2^20 lookups 11.7 -> 11.0 ms; the AND table's twelve columns lose there)
     size_t full = 0;
-    for (size_t k = 0; k < small->cols.size(); k++)
-      full += small->cols[k].len > ((size_t)1 << (num_vars - 1)) && !small->coef[k].is_zero();
-    if (!(num_vars >= 17 && full <= 4 && !getenv("LH_OPEN_SMALL_MIN_VARS"))) small = nullptr;
+    for (size_t k = 0; k < small->cols.size(); k++) full += small->cols[k].len > (n >> 1) && !small->coef[k].is_zero();
+    if (!(num_vars - lsh >= 17 && full <= 4 && !c.opt.open_small_min_vars_forced)) small = nullptr;
   }
   if (small && (num_vars < 2 || small->cols.empty())) small = nullptr;
+  if (small && sharded && num_vars < cut + 2) small = nullptr;  // (the column-wise levels must be sharded ones)
   ArenaScope scope(c.arena);
-  const size_t n = (size_t)1 << num_vars;
   if (!d_poly) {
     LH_REQUIRE(given && !given->merged.empty(), LH_ERR_ARG, "open: no polynomial");
     if (!small) {  // the plain route needs g' itself
@@ -1079,7 +1208,7 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
   size_t depth = 0;
   std::vector<uint32_t> ors;
   if (small) {
-    const size_t K = small->cols.size(), half_top = (size_t)1 << (num_vars - 1);
+    const size_t K = small->cols.size(), half_top = n >> 1;
     ors.assign(K, 0);
     std::map<size_t, std::vector<size_t>> by_len;  // one OR pass per column length (normally none: the widths are known)
     for (size_t k = 0; k < K; k++) {
@@ -1104,41 +1233,65 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
       else passes += 1;
     }
     passes += (narrow_cols + 1) / 2;
-    static const int forced_depth = [] {
-      const char* e = getenv("LH_OPEN_SMALL_DEPTH");  // development: 1 or 2 levels column by column, whatever the shape
-      return e ? atoi(e) : 0;
-    }();
+    const int forced_depth = (int)c.opt.open_small_depth;  // 1 or 2 levels column by column, whatever the shape
     depth = 1;
-    if (num_vars >= 3 && (forced_depth ? forced_depth >= 2 : 2 * passes <= 10)) depth = 2;
+    if (num_vars >= cut + 3 && (forced_depth ? forced_depth >= 2 : 2 * passes <= 10)) depth = 2;
   }
   // development (LH_OPEN_SMALL_CHECK): the column-wise levels whose quotient exists are committed the plain way too and
   // compared (stderr)
   static const bool self_check_env = getenv("LH_OPEN_SMALL_CHECK") != nullptr;
   const bool self_check = self_check_env && small;
   const size_t check_from = d_poly ? 0 : 1;  // (the first fold of a lazy g' leaves no quotient to compare with)
+  // quotients back to back: the sharded levels (local halves) from the top down, then - replicated - the flat layout of
+  // the small levels (q_i at offset 2^i - 1)
   Fr* q = c.arena.alloc_n<Fr>(n);  // n - 1 used
   Fr* remA = c.arena.alloc_n<Fr>(std::max<size_t>(n >> 1, 1));
   Fr* remB = c.arena.alloc_n<Fr>(std::max<size_t>(n >> 2, 1));
+  std::vector<const Fr*> q_of(num_vars, nullptr);
   const Fr* rem = d_poly;
-  for (size_t i = num_vars; i-- > 0;) {
-    size_t half = (size_t)1 << i;
+  size_t q_off = 0;
+  for (size_t i = num_vars; i-- > cut;) {
+    size_t half = (size_t)1 << (i - lsh);
     Fr* dst = ((num_vars - i) & 1) ? remA : remB;
+    const bool keep_q = !(i + depth >= num_vars && !self_check);
     if (!rem)  // first step of the column route straight from the merged tables (g' is never formed)
       k_lincomb_fold(c, small->merged.data(), small->merged_w.data(), small->merged.size(), half, dev(point[i]), dst);
     else
-      k_quotient_step(c, rem, half, dev(point[i]), i + depth >= num_vars && !self_check ? nullptr : q + (half - 1), dst);
+      k_quotient_step(c, rem, half, dev(point[i]), keep_q ? q + q_off : nullptr, dst);
+    if (keep_q && rem) q_of[i] = q + q_off;
+    q_off += half;
     rem = dst;
+  }
+  if (sharded) {
+    // remainder: 2^cut entries globally, the shard bits on top -> replicate and finish as on one GPU
+    const size_t n_rep = (size_t)1 << cut;
+    Fr* rep = c.arena.alloc_n<Fr>(n_rep);
+    comm_gather_concat(c, rem, (size_t)1 << sh.j, rep);
+    c.route.v[RouteStats::SHARD_EXCHANGES]++;
+    Fr* q_rep = c.arena.alloc_n<Fr>(n_rep);
+    Fr* repA = c.arena.alloc_n<Fr>(std::max<size_t>(n_rep >> 1, 1));
+    Fr* repB = c.arena.alloc_n<Fr>(std::max<size_t>(n_rep >> 2, 1));
+    rem = rep;
+    for (size_t i = cut; i-- > 0;) {
+      const size_t half = (size_t)1 << i;
+      Fr* dst = ((cut - i) & 1) ? repA : repB;
+      k_quotient_step(c, rem, half, dev(point[i]), q_rep + (half - 1), dst);
+      q_of[i] = q_rep + (half - 1);
+      rem = dst;
+    }
   }
   HFr remainder;
   if (num_vars == 0) {
     download(c, &remainder, d_poly, sizeof(Fr));
     return remainder;
   }
+  // bases of a level: this rank's share of a sharded level
+  auto level_bases = [&](size_t lvl) { return lvl >= cut && sharded ? srs_shard_level(c, srs, lvl) : srs.eq(lvl); };
   const size_t plain = num_vars - depth;
   std::vector<MsmJob> jobs(plain);
   for (size_t i = 0; i < plain; i++) {
-    size_t half = (size_t)1 << i;
-    jobs[i] = MsmJob{q + (half - 1), false, srs.eq(i), half};
+    size_t half = (size_t)1 << (i >= cut ? i - lsh : i);
+    jobs[i] = MsmJob{q_of[i], false, level_bases(i), half};
     if (small) jobs[i].known_bits = 254;  // quotients of a random combination: full-size scalars, nothing to measure
   }
   // ---- the column-wise levels
@@ -1166,8 +1319,8 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
     ColumnLevel& cl = col_levels[d];
     cl.level = num_vars - 1 - d;
     cl.offset_total = HFr::zero();
-    const size_t half = (size_t)1 << cl.level;
-    const G1Affine* bases = srs.eq(cl.level);
+    const size_t half = (size_t)1 << (cl.level - lsh);
+    const G1Affine* bases = level_bases(cl.level);
     struct Narrow {
       uint32_t bits;  // of the shifted difference
       uint32_t* col;
@@ -1181,7 +1334,7 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
         const HFr& xj = point[num_vars - 1 - j];
         w_s *= ((sidx >> (d - 1 - j)) & 1) ? xj : HFr::one() - xj;
       }
-      const size_t off_idx = sidx << (cl.level + 1);
+      const size_t off_idx = sidx << (cl.level + 1 - lsh);
       for (size_t k = 0; k < small->cols.size(); k++) {
         const SmallPoly& sp = small->cols[k];
         if (small->coef[k].is_zero() || sp.len <= off_idx) continue;
@@ -1248,8 +1401,9 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
     // the level's base sum (an MSM with all-one scalars, once per SRS and level)
     if (cl.need_sum) {
       std::lock_guard<std::mutex> lock(level_sums_mu);
-      auto it = srs.level_sums.find(cl.level);
-      if (it != srs.level_sums.end()) {
+      std::map<size_t, HG1>& sums = sharded ? srs.shard_level_sums : srs.level_sums;  // (sharded: of this rank's share)
+      auto it = sums.find(cl.level);
+      if (it != sums.end()) {
         cl.base_sum = it->second;
       } else {
         uint32_t* ones = c.arena.alloc_n<uint32_t>(half);
@@ -1260,11 +1414,13 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
       }
     }
   }
+  c.route.v[RouteStats::OPEN_DEPTH] = (uint32_t)depth;
+  c.route.v[RouteStats::OPEN_PASSES] = (uint32_t)(jobs.size() - plain);
   const size_t check_base = jobs.size();
   if (self_check)
     for (size_t d = check_from; d < depth; d++) {
-      const size_t lvl = num_vars - 1 - d, half = (size_t)1 << lvl;
-      jobs.push_back(MsmJob{q + (half - 1), false, srs.eq(lvl), half});
+      const size_t lvl = num_vars - 1 - d, half = (size_t)1 << (lvl - lsh);
+      jobs.push_back(MsmJob{q_of[lvl], false, level_bases(lvl), half});
     }
   std::vector<HG1> out(jobs.size());
   msm_batch(c, jobs.data(), jobs.size(), (G1Affine*)out.data());
@@ -1274,7 +1430,7 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
     if (cl.sum_job != (size_t)-1) {
       cl.base_sum = out[cl.sum_job];
       std::lock_guard<std::mutex> lock(level_sums_mu);
-      srs.level_sums[cl.level] = cl.base_sum;
+      (sharded ? srs.shard_level_sums : srs.level_sums)[cl.level] = cl.base_sum;
     }
     // commitment = sum_t scale_t * result_t - offset_total * base sum  (scalar multiplications on the host's threads)
     std::vector<HG1> pts(cl.terms.size() + 1);
@@ -1298,6 +1454,9 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
       fprintf(stderr, "[open] column-wise commitment of level %zu (depth %zu of %zu) differs from the plain one\n", cl.level, d, depth);
   }
   download(c, &remainder, rem, sizeof(Fr));
+  // sharded levels: what every rank holds is the commitment of its shard (column-wise levels: of its share of the columns,
+  // offset term included - everything above is linear in the bases) -> their sums, one exchange
+  if (sharded) comm_sum_points(c, comms.data() + cut, num_vars - cut);
   tr.write_commitments(comms);  // identity -> Error::Transcript (transcript.rs:172-179,216-219)
   return remainder;
 }
@@ -1322,7 +1481,12 @@ void additive_batch_open(Ctx& c, size_t num_vars, const Fr* const* d_polys, size
   std::vector<HFr> eq_xt = host_eq_xy(t);
 
   ArenaScope scope(c.arena);
-  const size_t n = (size_t)1 << num_vars;
+  // inside a sharded proof (dev.hpp Shard) every poly is this rank's shard: the merges and g' are entry-wise, the
+  // sum-check and the opening know about shards
+  const Shard sh(c);
+  const bool sharded = sh.on;
+  if (sharded) LH_REQUIRE(sh.sharded(num_vars), LH_ERR_ARG, "batch open: too few variables for this shard geometry");
+  const size_t n = (size_t)1 << (num_vars - (sharded ? sh.rho : 0));
   // merged_j = sum_{i : point(i) = j} eq_xt[i] * poly_i  (:155-170; the lazy first scalar there is a
   // representation detail, every field value below is the same)
   std::vector<const Fr*> merged(num_points);
@@ -1367,7 +1531,7 @@ void additive_batch_open(Ctx& c, size_t num_vars, const Fr* const* d_polys, size
     tilde_gs_sum += v * eq_xt[i];
   }
   SumCheckResult sc = sum_check_prove(c, LH_SC_COEFFICIENTS, num_vars, expr, merged.data(), num_points, points,
-                                      num_points, tilde_gs_sum, tr);
+                                      num_points, tilde_gs_sum, tr, false, nullptr, sharded);
   // g' = sum_j eq_xy_eval(challenges, z_j) * merged_j  (:200-213)
   std::vector<Fr> w(num_points);
   for (size_t j = 0; j < num_points; j++)

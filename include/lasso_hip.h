@@ -241,6 +241,47 @@ lh_status lh_lasso_prove(lh_ctx*, const lh_srs*, const lh_lasso_table*, size_t n
 #define LH_LASSO_NUM_PHASES 9
 lh_status lh_lasso_last_timing(lh_ctx*, double* out_ms);
 
+/* ---------------------------------------------------------------- route options
+ * The switches that decide WHICH code proves (never which bytes: every route yields the reference's transcript).  They
+ * are per ctx; at lh_ctx_create each takes the value of the environment variable LH_<NAME IN UPPER CASE> when that is
+ * set (LH_OPEN_SMALL_MIN_VARS=64 ...), else its default.  lh_ctx_set_option returns LH_ERR_ARG for an unknown name.
+ *   open_small_min_vars  21   smallest batch opening (variables) whose largest quotient(s) are committed column by column
+ *                             from 32-bit differences of the small-valued Lasso columns instead of from full-size
+ *                             scalars (mkzg_open's column route; 64: never; below it an opening of at most four full
+ *                             columns of >= 17 variables still takes it unless the option was set explicitly)
+ *   open_small_depth     0    1 / 2: exactly that many column-wise quotient levels (0: chosen by cost)
+ *   sc_eq_factoring      1    0: every sum-check round streams and binds its eq tables (the reference's shape) instead
+ *                             of the factored form eq(y, x) = S_j eq(y_j, X) E_j[b]
+ *   lasso_pack_ts        1    0: one MSM pass per read_ts column instead of packed pairs
+ *   sc_tail              1    0: one kernel launch per sum-check round all the way down (no resident tail kernel)
+ *   sc_tail_max_len      8192 longest table (entries) that enters the resident tail
+ *   shard_exchange_log   17   sharded proofs: a sum-check goes on replicated once its residual tables hold <= 2^this
+ *                             entries together (one all-gather), at the latest when the shard bits reach bit 0
+ *   shard_allreduce      0    sharded proofs over RCCL: 1 = a round's partial sums are combined by ONE
+ *                             ncclAllReduce(sum) over u64 lanes of 32-bit limbs (the host reduces mod r) instead of
+ *                             ncclAllGather + a sum kernel
+ * lh_lasso_last_route reports which of these routes the last Lasso prove on the ctx actually took, so that a byte
+ * mismatch in the field can be bisected from the outside. */
+lh_status lh_ctx_set_option(lh_ctx*, const char* name, int64_t value);
+lh_status lh_ctx_get_option(lh_ctx*, const char* name, int64_t* out);
+#define LH_LASSO_ROUTE_WORDS 16
+typedef struct lh_lasso_route {
+  uint32_t open_small_depth;    /* column-wise quotient levels of the opening (0: plain route) */
+  uint32_t open_small_passes;   /* column passes (MSM jobs) of those levels */
+  uint32_t eq_factored_rounds;  /* launched sum-check rounds with factored eq tables */
+  uint32_t standard_rounds;     /* launched rounds on the standard path (eq tables streamed and bound) */
+  uint32_t rw_leaf_rounds;      /* of the factored rounds: the read/write leaf-layer kernel (sc_round_rw) */
+  uint32_t resident_tails;      /* resident tail launches */
+  uint32_t resident_rounds;     /* rounds that ran inside them */
+  uint32_t packed_ts_pairs;     /* read_ts columns committed two to a pass */
+  uint32_t derived_commitments; /* E columns committed from their dim column's buckets */
+  uint32_t sorted_dim_reuse;    /* dim columns whose MSM entry stream came from the access counters' sort */
+  uint32_t sharded_rounds;      /* rounds that carried a collective (sharded proofs) */
+  uint32_t shard_exchanges;     /* residual-table / tree-level / remainder exchanges (sharded proofs) */
+  uint32_t reserved[4];
+} lh_lasso_route;
+lh_status lh_lasso_last_route(lh_ctx*, lh_lasso_route* out);
+
 /* ---------------------------------------------------------------- e: one proof sharded over 2^rho GPUs
  * (the reference is single-process, there is nothing to cite.)  Every table of 2^m
  * entries is split on `rho` index bits [shard_bit, shard_bit + rho): the rank whose id equals those

@@ -335,8 +335,25 @@ def test_sum_check_transcript_failure_mid_tail(hl, ctx):
     ot = OT()
     ox, oev = o_sc.prove(o_sc.EvaluationsProver, num_vars, o_sc.VirtualPolynomial(expr, tables, [], [y]), claim, ot)
     t = hl.Keccak256Transcript()
+    t1 = time.perf_counter()
     x, ev = hl.ClassicSumCheck.prove(ctx, hl.EvaluationsProver, num_vars, sop, polys, [y], claim, t)
+    # (an aborted multi-workgroup tail leaves the device's ticket counter behind the host's: without the resync the next
+    # tail only comes back through its 2 s timeout)
+    assert time.perf_counter() - t1 < 1.0
     assert (x, ev) == (ox, oev) and t.into_proof() == ot.into_proof()
+    # ... and a sum-check large enough for multi-workgroup launched rounds (in-launch final reduction by ticket) after it
+    nv2 = 14
+    big = [rand_fr(rng, 1 << nv2) for _ in range(2)]
+    y2 = rand_fr(rng, nv2)
+    claim2 = sum(e * a * b for e, a, b in zip(eq_xy(y2), *big)) % P
+    ot2 = OT()
+    o2 = o_sc.prove(o_sc.EvaluationsProver, nv2, o_sc.VirtualPolynomial(expr, big, [], [y2]), claim2, ot2)
+    t2 = hl.Keccak256Transcript()
+    t1 = time.perf_counter()
+    r2 = hl.ClassicSumCheck.prove(ctx, hl.EvaluationsProver, nv2, sop, [hl.MultilinearPolynomial.new(ctx, b) for b in big],
+                                  [y2], claim2, t2)
+    assert time.perf_counter() - t1 < 1.0
+    assert r2 == o2 and t2.into_proof() == ot2.into_proof()
 
 
 @pytest.mark.parametrize("num_vars", [9, 13])

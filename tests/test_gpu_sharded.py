@@ -38,11 +38,14 @@ WORKER = textwrap.dedent("""
     d_dims = [ctx.upload(hl.shard_of(np.array(col, dtype=np.uint32), rank, world, cfg["shard_bit"]).tobytes())
               for col in dims]
     hl.attach_comm(ctx, rank, world, hdist.host_all_gather(d), cfg["shard_bit"])
+    if "xlog" in cfg:                        # when the residual tables of a sharded sum-check travel (0: at the last moment)
+        hl.set_option(ctx, "shard_exchange_log", cfg["xlog"])
     t = hl.Keccak256Transcript()
     hl.lasso_prove_sharded(pp, table, cfg["n"], d_dims, t)
     # (to a file: a proof of this size does not fit a pipe's buffer, and the parent reads the pipes only at the end)
     with open(sys.argv[2] + ".%%d" %% rank, "w") as f:
-        json.dump({"rank": rank, "proof": t.into_proof().hex(), "stats": hl.comm_stats(ctx)}, f)
+        json.dump({"rank": rank, "proof": t.into_proof().hex(), "stats": hl.comm_stats(ctx),
+                   "route": hl.lasso_last_route(ctx)}, f)
     hdist.barrier(d)
     d.destroy_process_group()
 """) % ROOT
@@ -84,22 +87,27 @@ def run_ranks(tmp_path, world, cfg, port):
 
 
 CASES = [
-    # world, kind, c, l, n, shard_bit
-    (2, "range", 2, 3, 6, 2),
-    (2, "and", 2, 4, 7, 3),
-    (4, "range", 2, 4, 8, 2),
-    (4, "xor", 3, 4, 7, 3),
-    (2, "range", 2, 3, 9, 5),
+    # world, kind, c, l, n, shard_bit, xlog (None: default - these tiny tables travel before round 1; 0: every sum-check
+    # keeps its rounds sharded until the shard bits reach bit 0)
+    (2, "range", 2, 3, 6, 2, 0),
+    (2, "and", 2, 4, 7, 3, None),
+    (4, "range", 2, 4, 8, 2, 0),
+    (4, "xor", 3, 4, 7, 3, 0),
+    (2, "range", 2, 3, 9, 5, 0),
+    (8, "and", 2, 4, 9, 2, 0),
+    (2, "xor", 2, 4, 9, 4, 5),
 ]
 
 
-@pytest.mark.parametrize("world,kind,c,l,n,shard_bit", CASES)
-def test_sharded_proof_equals_single_gpu_and_oracle(tmp_path, world, kind, c, l, n, shard_bit):
+@pytest.mark.parametrize("world,kind,c,l,n,shard_bit,xlog", CASES)
+def test_sharded_proof_equals_single_gpu_and_oracle(tmp_path, world, kind, c, l, n, shard_bit, xlog):
     from oracle.pyref import lasso as o_lasso, kzg as o_kzg
     from oracle.pyref.field import R_MOD
     from oracle.pyref.transcript import Keccak256Transcript as OT
     seed = zlib.crc32(repr((world, kind, c, l, n)).encode())
     cfg = dict(seed=seed, kind=kind, c=c, l=l, n=n, shard_bit=shard_bit)
+    if xlog is not None:
+        cfg["xlog"] = xlog
     outs = run_ranks(tmp_path, world, cfg, 29600 + (seed % 300))
     proofs = {o["proof"] for o in outs}
     assert len(proofs) == 1, "ranks disagree on the proof"
@@ -116,23 +124,37 @@ def test_sharded_proof_equals_single_gpu_and_oracle(tmp_path, world, kind, c, l,
 
 
 LARGE = [
-    # world, kind, c, l, n, shard_bit: the streaming kernels on shards, checked against the C++ oracle
-    (2, "range", 2, 16, 18, 15),
-    (4, "and", 4, 16, 18, 14),
+    # world, kind, c, l, n, shard_bit, xlog: the streaming kernels on shards - eq-factored rounds, the read/write leaf
+    # kernel, packed and derived commitments, the column-wise top quotient - checked against the C++ oracle
+    (2, "range", 2, 16, 18, 15, None),
+    (4, "and", 4, 16, 18, 14, None),
+    (8, "and", 4, 16, 20, 13, None),
+    (8, "xor", 4, 16, 20, 13, 0),
+    (8, "range", 2, 16, 21, 13, None),
 ]
 
 
-@pytest.mark.parametrize("world,kind,c,l,n,shard_bit", LARGE)
-def test_sharded_proof_large_vs_cpp_oracle(tmp_path, world, kind, c, l, n, shard_bit):
+@pytest.mark.parametrize("world,kind,c,l,n,shard_bit,xlog", LARGE)
+def test_sharded_proof_large_vs_cpp_oracle(tmp_path, world, kind, c, l, n, shard_bit, xlog):
     import numpy as np
     import halo2_lasso_amd as hl
     from oracle import cpu_oracle as co
     seed = zlib.crc32(repr((world, kind, c, l, n)).encode())
     cfg = dict(seed=seed, kind=kind, c=c, l=l, n=n, shard_bit=shard_bit)
+    if xlog is not None:
+        cfg["xlog"] = xlog
     outs = run_ranks(tmp_path, world, cfg, 29900 + (seed % 90))
     proofs = {o["proof"] for o in outs}
     assert len(proofs) == 1, "ranks disagree on the proof"
     assert all(o["stats"]["host"] > 0 for o in outs)
+    # the shards ran the single-GPU prover's routes: factored rounds (with collectives), the leaf-layer kernel, derived
+    # commitments for the bitwise tables
+    for o in outs:
+        r = o["route"]
+        assert r["sharded_rounds"] > 0 and r["eq_factored_rounds"] > 0 and r["rw_leaf_rounds"] > 0, r
+        assert r["shard_exchanges"] > 0, r
+        if kind != "range":
+            assert r["derived_commitments"] == c, r
     rng = random.Random(seed)
     ss = [rng.randrange(hl.R_MOD) for _ in range(n)]
     dims = [[rng.randrange(1 << l) for _ in range(1 << n)] for _ in range(c)]
