@@ -170,7 +170,7 @@ def test_sharded_world1_over_rccl(hl, ctx):
     exchange an ncclAllGather on the prover's stream followed by the sum-and-publish kernel - and must give the bytes
     of lasso_prove.  Asserts that the device-side path was taken and nothing went through a host callback."""
     import numpy as np
-    n, shard_bit = 17, 16
+    n, shard_bit = 18, 16  # (a world of one: rho = 0, the replicated subtables need shard_bit >= 16, the tables two more variables)
     table = hl.LassoTable.bitwise(hl.SUBTABLE_XOR, 4, 16)
     rng = np.random.default_rng(171)
     prng = random.Random(171)
