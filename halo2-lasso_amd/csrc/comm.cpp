@@ -16,6 +16,7 @@
 //   callbacks (lh_ctx_set_comm) - a caller-supplied host all-gather (gloo in the CPU / one-GPU tests) and optionally a
 //       device all-gather; without the latter device gathers are staged through the host.
 #include <dlfcn.h>
+#include <algorithm>
 #include <rccl/rccl.h>  // types and enums only: every function is resolved with dlsym
 #include <mutex>
 #include "host.hpp"
@@ -29,6 +30,11 @@ struct RcclApi {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -61,6 +67,11 @@ const RcclApi& rccl() {
     api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
     api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
     api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
+    api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
+    api.Send = (decltype(api.Send))sym("ncclSend");
+    api.Recv = (decltype(api.Recv))sym("ncclRecv");
+    api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+    api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
     api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
   });
   if (!err.empty()) throw Error(LH_ERR_DEVICE, err);
@@ -172,6 +183,55 @@ void comm_all_gather_host(Ctx& c, const void* send, void* recv, size_t bytes) {
   LH_HIP(hipMemcpyAsync(d, send, bytes, hipMemcpyHostToDevice, c.stream));
   comm_all_gather_dev(c, d, d + bytes, bytes);
   c.d2h(recv, d + bytes, bytes * R);
+}
+
+// Personalised exchange (the sharded access counters: lookups to their address owners and the ranks back).  RCCL:
+// grouped ncclSend / ncclRecv on the ctx's stream - on xGMI's full mesh every pair of GPUs has its own link, so an
+// all-to-all costs each link 1/(R-1) of a rank's traffic.  Callback transports have no point-to-point primitive: every
+// rank's whole send buffer is all-gathered and the segments meant for this rank are picked out (tests only).
+void comm_all_to_all_v(Ctx& c, const void* d_send, const size_t* send_off, const size_t* send_cnt, void* d_recv,
+                       const size_t* recv_off, const size_t* recv_cnt, const size_t* peer_off, size_t send_span, size_t elem) {
+  require_comm(c);
+  const size_t R = (size_t)c.comm.size, me = (size_t)c.comm.rank;
+  size_t total = 0;
+  for (size_t p = 0; p < R; p++) total += send_cnt[p] + recv_cnt[p];
+  comm_trace(c, "all_to_all_v", total * elem);
+  if (c.rccl_comm) {
+    const RcclApi& api = rccl();
+    c.comm_stats[0]++;
+    // (the segment a rank keeps for itself is a device copy: no self-send)
+    if (send_cnt[me])
+      LH_HIP(hipMemcpyAsync((char*)d_recv + recv_off[me] * elem, (const char*)d_send + send_off[me] * elem, send_cnt[me] * elem,
+                            hipMemcpyDeviceToDevice, c.stream));
+    if (R > 1) {
+      rccl_check(api.GroupStart(), "ncclGroupStart");
+      for (size_t p = 0; p < R; p++) {
+        if (p == me) continue;
+        if (send_cnt[p])
+          rccl_check(api.Send((const char*)d_send + send_off[p] * elem, send_cnt[p] * elem, ncclUint8, (int)p,
+                              (ncclComm_t)c.rccl_comm, c.stream), "ncclSend");
+        if (recv_cnt[p])
+          rccl_check(api.Recv((char*)d_recv + recv_off[p] * elem, recv_cnt[p] * elem, ncclUint8, (int)p,
+                              (ncclComm_t)c.rccl_comm, c.stream), "ncclRecv");
+      }
+      rccl_check(api.GroupEnd(), "ncclGroupEnd");
+    }
+    return;
+  }
+  ArenaScope scope(c.arena);
+  char* all = (char*)c.arena.alloc(std::max<size_t>(send_span * elem * R, 256));
+  comm_all_gather_dev(c, d_send, all, send_span * elem);
+  for (size_t p = 0; p < R; p++)
+    if (recv_cnt[p])
+      LH_HIP(hipMemcpyAsync((char*)d_recv + recv_off[p] * elem, all + (p * send_span + peer_off[p]) * elem, recv_cnt[p] * elem,
+                            hipMemcpyDeviceToDevice, c.stream));
+  c.sync();  // (`all` is released with the scope)
+}
+
+// closing steps of a sharded sum-check round: all-gather of every rank's partial sums, then the sum-and-publish kernel
+void comm_sum_publish(Ctx& c, const Fr* d_part, Fr* d_scratch, size_t count, Fr* out_host, uint32_t seq) {
+  comm_all_gather_dev(c, d_part, d_scratch, count * sizeof(Fr));
+  k_sum_publish(c, d_scratch, (size_t)c.comm.size, count, out_host, seq);
 }
 
 }  // namespace lh

@@ -297,6 +297,15 @@ void k_pack_u32(Ctx&, const uint32_t* a, const uint32_t* b, uint32_t shift, size
 void k_delta_u32(Ctx&, const uint32_t* col, size_t len, size_t half, uint64_t offset, uint32_t* out_lo, uint32_t* out_hi);
 void k_lasso_counters(Ctx&, const uint32_t* dim, size_t n, size_t m, uint32_t* read_ts, uint32_t* final_cts,
                       uint32_t* keep_sorted = nullptr, uint32_t* keep_index = nullptr);
+// the sharded counters' steps (lasso.cpp lasso_counters_sharded): partition the local lookups by address owner (sidx: local
+// indices in send order; send: (address on the owner) << n_bits | global index; start_host[o]: first send position of
+// owner o, R + 1 entries), rank the received lookups on the owner, scatter the returned ranks, assemble final_cts
+void k_cs_partition(Ctx&, const uint32_t* dim, size_t n, size_t m, unsigned rho, unsigned j, uint32_t rank, unsigned n_bits,
+                    uint32_t* sidx, uint64_t* send, uint32_t* start_host);
+void k_cs_rank(Ctx&, const uint64_t* recv, size_t n, unsigned n_bits, unsigned a_bits, size_t m_loc, uint32_t* ret,
+               uint32_t* counts);
+void k_cs_scatter(Ctx&, const uint32_t* back, const uint32_t* sidx, size_t n, uint32_t* read_ts);
+void k_cs_final(Ctx&, const uint32_t* all_counts, size_t m, unsigned rho, size_t m_loc, uint32_t* final_cts);
 void k_lasso_subtable_read(Ctx&, int subtable, uint32_t chunk_bits, const uint32_t* dim, size_t n, uint32_t* e);
 // a[k] = g(E_0[k],..): small-integer evaluation into Fr
 struct LassoG {
@@ -327,6 +336,15 @@ void comm_detach(Ctx&);
 // the communicator has no device collective); _host: host buffers, synchronous
 void comm_all_gather_dev(Ctx&, const void* d_send, void* d_recv, size_t bytes);
 void comm_all_gather_host(Ctx&, const void* send, void* recv, size_t bytes);
+// personalised exchange of device buffers (elements of `elem` bytes): this rank sends send_cnt[p] elements from
+// d_send + send_off[p] to every peer p and receives recv_cnt[p] from it at d_recv + recv_off[p].  peer_off[p]: where,
+// inside p's send buffer, the segment for this rank starts; send_span: elements every rank's send buffer spans at least
+// (equal on all ranks) - both only used by transports without point-to-point sends (staged through an all-gather).
+void comm_all_to_all_v(Ctx&, const void* d_send, const size_t* send_off, const size_t* send_cnt, void* d_recv,
+                       const size_t* recv_off, const size_t* recv_cnt, const size_t* peer_off, size_t send_span, size_t elem);
+// v[i] = sum over the ranks of v[i], `count` field elements in a device buffer the ctx's stream owns; the sums are left in
+// out_host (pinned) followed by the flag `seq` (the closing steps of a sharded sum-check round)
+void comm_sum_publish(Ctx&, const Fr* d_part, Fr* d_scratch, size_t count, Fr* out_host, uint32_t seq);
 
 // ------------------------------------------------------------------ sharding helpers (kernels_poly.hip)
 // inverse of k_shard_extract over the all-gathered shards: global[g] = gathered[s(g) * n_local + local(g)]

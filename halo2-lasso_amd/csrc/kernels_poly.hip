@@ -873,6 +873,123 @@ void k_lasso_counters(Ctx& c, const uint32_t* dim, size_t n, size_t m, uint32_t*
   LH_REQUIRE(!h_bad, LH_ERR_ARG, "lasso: chunk index out of range (>= 2^chunk_bits)");
 }
 
+// ---- access counters of a sharded proof (dev.hpp Shard): the lookups of a column are repartitioned by ADDRESS (owner =
+// address mod R), the owner ranks every lookup of its addresses in the global lookup order, the ranks travel back.
+void sort_pairs_u64(Ctx& c, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
+                    size_t n, unsigned bits);
+__global__ void cs_owner_keys_kernel(const uint32_t* __restrict__ dim, size_t n, size_t m, uint32_t owner_mask,
+                                     uint32_t* __restrict__ okey, uint32_t* __restrict__ idx, uint32_t* __restrict__ bad) {
+  GSTRIDE(i, n) {
+    const uint32_t a = dim[i];
+    okey[i] = a & owner_mask;
+    idx[i] = (uint32_t)i;
+    if (a >= m) *bad = 1u;
+  }
+}
+// start[o] = first position of owner o in the owner-sorted list (left at `n` for owners that do not occur)
+__global__ void cs_owner_starts_kernel(const uint32_t* __restrict__ sown, size_t n, uint32_t* __restrict__ start) {
+  GSTRIDE(p, n)
+    if (p == 0 || sown[p - 1] != sown[p]) start[sown[p]] = (uint32_t)p;
+}
+// send[p] = (address on its owner) << n_bits | global lookup index, in owner-sorted order (stable: within an owner the
+// lookups stay in local = global order)
+__global__ void cs_send_keys_kernel(const uint32_t* __restrict__ dim, const uint32_t* __restrict__ sidx, size_t n,
+                                    unsigned rho, unsigned j, uint32_t rank, unsigned n_bits, uint64_t* __restrict__ send) {
+  const uint64_t lo_mask = ((uint64_t)1 << j) - 1;
+  GSTRIDE(p, n) {
+    const uint32_t li = sidx[p];
+    const uint64_t g = (((uint64_t)li >> j) << (j + rho)) | ((uint64_t)rank << j) | ((uint64_t)li & lo_mask);
+    send[p] = ((uint64_t)(dim[li] >> rho) << n_bits) | g;
+  }
+}
+__global__ void cs_iota_kernel(uint32_t* __restrict__ out, size_t n) {
+  GSTRIDE(i, n) out[i] = (uint32_t)i;
+}
+__global__ void cs_run_start_kernel(const uint64_t* __restrict__ skey, size_t n, unsigned n_bits, uint32_t* __restrict__ start) {
+  GSTRIDE(i, n) {
+    const uint64_t a = skey[i] >> n_bits;
+    if (i == 0 || (skey[i - 1] >> n_bits) != a) start[a] = (uint32_t)i;
+  }
+}
+// ret[position in the receive buffer] = rank of the lookup among the lookups of its address; counts[a] = run length
+__global__ void cs_rank_kernel(const uint64_t* __restrict__ skey, const uint32_t* __restrict__ spos, size_t n, unsigned n_bits,
+                               const uint32_t* __restrict__ start, uint32_t* __restrict__ ret, uint32_t* __restrict__ counts) {
+  GSTRIDE(i, n) {
+    const uint64_t a = skey[i] >> n_bits;
+    const uint32_t r = (uint32_t)i - start[a];
+    ret[spos[i]] = r;
+    if (i + 1 == n || (skey[i + 1] >> n_bits) != a) counts[a] = r + 1;
+  }
+}
+__global__ void cs_scatter_kernel(const uint32_t* __restrict__ back, const uint32_t* __restrict__ sidx, size_t n,
+                                  uint32_t* __restrict__ read_ts) {
+  GSTRIDE(p, n) read_ts[sidx[p]] = back[p];
+}
+// final_cts[a] = (owner a mod R).counts[a >> rho]
+__global__ void cs_final_kernel(const uint32_t* __restrict__ all_counts, size_t m, unsigned rho, size_t m_loc,
+                                uint32_t* __restrict__ final_cts) {
+  const uint32_t mask = (1u << rho) - 1u;
+  GSTRIDE(a, m) final_cts[a] = all_counts[(size_t)(a & mask) * m_loc + (a >> rho)];
+}
+
+void k_cs_partition(Ctx& c, const uint32_t* dim, size_t n, size_t m, unsigned rho, unsigned j, uint32_t rank, unsigned n_bits,
+                    uint32_t* sidx, uint64_t* send, uint32_t* start_host) {
+  ProfScope ps(c, "lasso_counters/partition", 24.0 * n, 0.0, (double)n);
+  ArenaScope scope(c.arena);
+  const size_t R = (size_t)1 << rho;
+  uint32_t* okey = c.arena.alloc_n<uint32_t>(n);
+  uint32_t* idx = c.arena.alloc_n<uint32_t>(n);
+  uint32_t* sown = c.arena.alloc_n<uint32_t>(n);
+  uint32_t* start = c.arena.alloc_n<uint32_t>(R + 1);
+  uint32_t* bad = start + R;
+  std::vector<uint32_t> init(R + 1, (uint32_t)n);
+  init[R] = 0;
+  LH_HIP(hipMemcpyAsync(start, init.data(), (R + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
+  hipLaunchKernelGGL(cs_owner_keys_kernel, grid_for(n), 256, 0, c.stream, dim, n, m, (uint32_t)(R - 1), okey, idx, bad);
+  if (rho) {
+    sort_pairs_u32(c, okey, sown, idx, sidx, n, rho);
+  } else {
+    LH_HIP(hipMemcpyAsync(sown, okey, n * 4, hipMemcpyDeviceToDevice, c.stream));
+    LH_HIP(hipMemcpyAsync(sidx, idx, n * 4, hipMemcpyDeviceToDevice, c.stream));
+  }
+  hipLaunchKernelGGL(cs_owner_starts_kernel, grid_for(n), 256, 0, c.stream, sown, n, start);
+  hipLaunchKernelGGL(cs_send_keys_kernel, grid_for(n), 256, 0, c.stream, dim, sidx, n, rho, j, rank, n_bits, send);
+  std::vector<uint32_t> h(R + 1);
+  c.d2h(h.data(), start, (R + 1) * sizeof(uint32_t));  // (synchronises: `init` may go)
+  LH_REQUIRE(!h[R], LH_ERR_ARG, "lasso: chunk index out of range (>= 2^chunk_bits)");
+  // owners that do not occur start where the next one does
+  uint32_t next = (uint32_t)n;
+  for (size_t o = R; o-- > 0;) {
+    if (h[o] == (uint32_t)n) h[o] = next;
+    next = h[o];
+  }
+  for (size_t o = 0; o < R; o++) start_host[o] = h[o];
+  start_host[R] = (uint32_t)n;
+}
+
+void k_cs_rank(Ctx& c, const uint64_t* recv, size_t n, unsigned n_bits, unsigned a_bits, size_t m_loc, uint32_t* ret,
+               uint32_t* counts) {
+  ProfScope ps(c, "lasso_counters/rank", 28.0 * n, 0.0, (double)n);
+  ArenaScope scope(c.arena);
+  LH_HIP(hipMemsetAsync(counts, 0, m_loc * sizeof(uint32_t), c.stream));
+  if (!n) return;
+  uint32_t* pos = c.arena.alloc_n<uint32_t>(n);
+  uint32_t* spos = c.arena.alloc_n<uint32_t>(n);
+  uint64_t* skey = c.arena.alloc_n<uint64_t>(n);
+  uint32_t* start = c.arena.alloc_n<uint32_t>(m_loc);
+  hipLaunchKernelGGL(cs_iota_kernel, grid_for(n), 256, 0, c.stream, pos, n);
+  sort_pairs_u64(c, recv, skey, pos, spos, n, n_bits + a_bits);
+  hipLaunchKernelGGL(cs_run_start_kernel, grid_for(n), 256, 0, c.stream, skey, n, n_bits, start);
+  hipLaunchKernelGGL(cs_rank_kernel, grid_for(n), 256, 0, c.stream, skey, spos, n, n_bits, start, ret, counts);
+}
+
+void k_cs_scatter(Ctx& c, const uint32_t* back, const uint32_t* sidx, size_t n, uint32_t* read_ts) {
+  if (n) hipLaunchKernelGGL(cs_scatter_kernel, grid_for(n), 256, 0, c.stream, back, sidx, n, read_ts);
+}
+void k_cs_final(Ctx& c, const uint32_t* all_counts, size_t m, unsigned rho, size_t m_loc, uint32_t* final_cts) {
+  if (m) hipLaunchKernelGGL(cs_final_kernel, grid_for(m), 256, 0, c.stream, all_counts, m, rho, m_loc, final_cts);
+}
+
 __global__ void lasso_subtable_read_kernel(int kind, uint32_t bits, const uint32_t* __restrict__ dim, size_t n,
                                            uint32_t* __restrict__ e) {
   GSTRIDE(i, n) e[i] = subtable_entry(kind, dim[i], bits);

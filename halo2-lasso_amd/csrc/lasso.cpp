@@ -86,19 +86,61 @@ void lasso_check_table(const lh_lasso_table& tb) {
 
 // Access counters of a sharded proof: read_ts[k] = number of earlier lookups - in the GLOBAL lookup order - of the same
 // address, final_cts[a] = number of lookups of a.  rts[j]: this rank's shard (2^(n - rho)), fcs[j]: replicated (2^l).
+// No rank ever holds a whole column: the lookups are repartitioned by address (owner = address mod R), the owner sorts
+// its (address, global index) pairs and ranks every lookup inside its address run, the ranks travel back the same way;
+// per column two personalised exchanges of ~2^(n - rho) entries per rank (8 B out, 4 B back) and one all-gather of the
+// 2^l / R counts of every owner.  Work and traffic per rank shrink with R (a column that hits one address only
+// degenerates to the single-GPU sort on that address's owner).
 static void lasso_counters_sharded(Ctx& c, const Shard& sh, const uint32_t* const* d_dims_local, size_t cc, size_t n, size_t l,
                                    uint32_t* const* rts, uint32_t* const* fcs) {
-  const size_t N = (size_t)1 << n, M = (size_t)1 << l, NL = N >> sh.rho;
-  ArenaScope wscope(c.arena);  // the full columns are only needed here
-  uint32_t* gathered = c.arena.alloc_n<uint32_t>(N);
-  uint32_t* full = c.arena.alloc_n<uint32_t>(N);
-  uint32_t* rts_full = c.arena.alloc_n<uint32_t>(N);
-  for (size_t j = 0; j < cc; j++) {
-    comm_all_gather_dev(c, d_dims_local[j], gathered, NL * sizeof(uint32_t));
-    k_shard_merge(c, gathered, NL, sh.j, sh.rho, 4, full);
-    k_lasso_counters(c, full, N, M, rts_full, fcs[j]);
-    k_shard_extract(c, rts_full, NL, sh.j, sh.rho, sh.rank, 4, rts[j]);
+  const size_t R = sh.R, me = sh.rank, M = (size_t)1 << l, NL = (size_t)1 << (n - sh.rho);
+  const size_t m_loc = std::max<size_t>(M >> sh.rho, 1);
+  unsigned a_bits = 0;
+  while (((size_t)1 << a_bits) < m_loc) a_bits++;
+  for (size_t col = 0; col < cc; col++) {
+    ArenaScope scope(c.arena);
+    uint32_t* sidx = c.arena.alloc_n<uint32_t>(NL);
+    uint64_t* send = c.arena.alloc_n<uint64_t>(NL);
+    std::vector<uint32_t> start(R + 1);
+    k_cs_partition(c, d_dims_local[col], NL, M, (unsigned)sh.rho, (unsigned)sh.j, (uint32_t)me, (unsigned)n, sidx, send,
+                   start.data());
+    // everybody's segment boundaries: starts[s][o] = where, in rank s's send buffer, the lookups for owner o begin
+    std::vector<uint32_t> starts((R + 1) * R);
+    comm_all_gather_host(c, start.data(), starts.data(), (R + 1) * sizeof(uint32_t));
+    auto seg = [&](size_t s, size_t o) { return (size_t)(starts[s * (R + 1) + o + 1] - starts[s * (R + 1) + o]); };
+    std::vector<size_t> s_off(R), s_cnt(R), r_off(R), r_cnt(R), peer_off(R);
+    size_t recv_total = 0, recv_max = 0;
+    for (size_t p = 0; p < R; p++) {
+      s_off[p] = start[p], s_cnt[p] = seg(me, p);
+      r_off[p] = recv_total, r_cnt[p] = seg(p, me), peer_off[p] = starts[p * (R + 1) + me];
+      recv_total += r_cnt[p];
+    }
+    for (size_t o = 0; o < R; o++) {  // (the largest receive buffer of any owner: the span of the way back)
+      size_t t = 0;
+      for (size_t s = 0; s < R; s++) t += seg(s, o);
+      recv_max = std::max(recv_max, t);
+    }
+    uint64_t* recv = c.arena.alloc_n<uint64_t>(std::max<size_t>(recv_total, 1));
+    comm_all_to_all_v(c, send, s_off.data(), s_cnt.data(), recv, r_off.data(), r_cnt.data(), peer_off.data(), NL, sizeof(uint64_t));
+    // the owner's side: rank inside the address run, per-address totals
+    uint32_t* ret = c.arena.alloc_n<uint32_t>(std::max<size_t>(recv_max, 1));
+    uint32_t* counts = c.arena.alloc_n<uint32_t>(m_loc);
+    k_cs_rank(c, recv, recv_total, (unsigned)n, a_bits, m_loc, ret, counts);
+    // the ranks go back along the same segments (the send side of the way back is this rank's receive layout)
+    uint32_t* back = c.arena.alloc_n<uint32_t>(NL);
+    // (where, in owner p's return buffer, the segment for this rank begins: the lookups of ranks 0..me-1 come first)
+    std::vector<size_t> back_peer_off(R, 0);
+    for (size_t p = 0; p < R; p++)
+      for (size_t s = 0; s < me; s++) back_peer_off[p] += seg(s, p);
+    comm_all_to_all_v(c, ret, r_off.data(), r_cnt.data(), back, s_off.data(), s_cnt.data(), back_peer_off.data(), recv_max,
+                      sizeof(uint32_t));
+    k_cs_scatter(c, back, sidx, NL, rts[col]);
+    uint32_t* all_counts = c.arena.alloc_n<uint32_t>(m_loc * R);
+    comm_all_gather_dev(c, counts, all_counts, m_loc * sizeof(uint32_t));
+    k_cs_final(c, all_counts, M, (unsigned)sh.rho, m_loc, fcs[col]);
+    c.sync();  // (the scope's buffers are released)
   }
+  c.route.v[RouteStats::SHARD_EXCHANGES] += (uint32_t)(3 * cc);
 }
 
 // witness: access counters, subtable reads and (optionally) the lookup outputs a = g(E); arena memory of the caller's scope.

@@ -454,9 +454,8 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
       c.route.v[RouteStats::SHARDED_ROUNDS]++;
       c.route.v[factored_round ? RouteStats::EF_ROUNDS : RouteStats::STD_ROUNDS]++;
       LH_REQUIRE(nvals <= 16, LH_ERR_ARG, "sharded sum-check: too many partial sums per round");
-      comm_all_gather_dev(c, d_part, d_all, nvals * sizeof(Fr));
       const uint32_t seq = c.next_seq();
-      k_sum_publish(c, d_all, R, nvals, evals_host, seq);
+      comm_sum_publish(c, d_part, d_all, nvals, evals_host, seq);
       c.wait_flag(seq);
       if (factored_round && !ef->per_term)  // (constants the factored kernel leaves to the host: the eq level sums to one)
         for (size_t x = 0; x < nvals; x++) evals_host[x] = dev(hst(evals_host[x]) + ef->add_const);
