@@ -6,10 +6,12 @@ workload = BASELINE.json configs[2], the configuration north_star states its tar
 operands as 4 chunks of 8+8 bits into the 2^16-entry AND subtable, Surge), BN254, multilinear-KZG openings.
 `--log-n 20 --table range` is configs[1].
 
-`--gpus N` (launched by torch.distributed.run, one rank per GPU): ONE proof of the same 2^log-n lookups sharded over
-the N GPUs (tables and SRS split on mid index bits, per-round partial sums and partial commitments
-all-gathered over RCCL on the prover's stream): strong scaling, value = ms per proof.  `--mode replicas` instead
-lets every rank prove its own batch (weak scaling, no data-path collective).
+`--gpus N` (one rank per GPU: launched by torch.distributed.run as the driver does, or - when WORLD_SIZE is not set -
+bench.py starts the N ranks itself before anything touches a GPU and relays rank 0's line): ONE proof of the same
+2^log-n lookups sharded over the N GPUs (tables and SRS split on mid index bits; the same prover as on
+one GPU runs on every shard, per-round partial sums and partial commitments cross over RCCL on the prover's stream):
+strong scaling, value = ms per proof.  `--mode replicas` instead lets every rank prove its own batch (weak scaling, no
+data-path collective).
 
 Extra objects on the line:
   roofline      the kernel with the largest total time in a separately profiled prove: SURVEY.md §8(d) algorithmic
@@ -63,6 +65,9 @@ def parse():
                     help="N>1: 'sharded' (default) = ONE proof of 2^log-n lookups split over the N GPUs (strong "
                          "scaling, SURVEY.md §8e, partial sums over RCCL); 'replicas' = one independent proof per GPU "
                          "(weak scaling, no data-path collective)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="start the ranks, form the process group, add up the ranks and print {n_gpus, sum} - no GPU work "
+                         "(tests/test_dist.py: the launch path of --gpus N on a CPU-only machine)")
     args = ap.parse_args()
     if not args.log_n:
         args.log_n = 20 if args.workload == "hyperplonk" else 24
@@ -397,6 +402,14 @@ def main():
     from halo2_lasso_amd import dist as hdist
     rank, local_rank, world = hdist.env_rank()
     dist = hdist.init()
+    if args.rendezvous_only:
+        total = hdist.max_over_ranks(dist, float(rank))
+        if rank == 0:
+            print(json.dumps({"n_gpus": world, "max_rank": int(total), "rendezvous": "ok"}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if args.workload == "hyperplonk":
         return main_hyperplonk(args, hdist, dist, rank, local_rank, world)
 
@@ -416,7 +429,10 @@ def main():
     def shard_geometry(tb, nn):
         rho = world.bit_length() - 1
         assert 1 << rho == world, "sharded mode needs a power-of-two number of GPUs"
-        return max(tb.l - rho, min(14, nn - rho - 1), 1)
+        # the lowest shard bit the replicated subtables allow (2^l <= 2^(shard_bit + rho)): everything with more than
+        # shard_bit + rho variables - tree levels, quotient levels - then stays sharded; when a sum-check's residual
+        # tables travel is decided by their size (option shard_exchange_log), not by shard_bit
+        return max(tb.l - rho, min(10, nn - rho - 1), 1)
 
     def load_columns(tb, nn, shard_bit):
         """device columns of this rank: its shard of the (rank-0 seeded) batch when sharded, else its own batch"""
@@ -463,11 +479,10 @@ def main():
 
     replicas = None
     watchdog = None
+    headline = {}  # rank 0: the sharded line once it exists (the extras that follow run collectives too)
     if sharded:
         # N independent replicas first (no data-path collective: nothing in it can wait for another rank's GPU) - the extra
-        # object of the sharded line, and the line itself if the sharded proof does not come back: a collective that never
-        # completes cannot be caught as an exception, so a timer prints the replicas line and ends the process
-        # (LH_BENCH_SHARDED_TIMEOUT seconds, default 240; the sharded proof has never run on more than one GPU)
+        # object of the sharded line
         if not args.no_extra:
             extra_steps = max(1, min(args.steps, 3))
             own = [ctx.upload(c.tobytes()) for c in gen_dims(table, n, rank)]
@@ -476,31 +491,21 @@ def main():
             replicas = {"ms_per_step": round(msr, 3), "proofs_per_step": world, "scaling": "weak",
                         "ms_per_proof": round(msr / world, 3), "lookups_per_s": round((1 << n) * world / (msr / 1e3))}
 
-            headline = {}  # rank 0: the sharded line once it exists (the extras that follow run collectives too)
-
-            def give_up():
-                if rank == 0 and headline.get("line"):
-                    late = dict(headline["line"])
-                    late["extras_error"] = "an extra object did not complete within LH_BENCH_SHARDED_TIMEOUT seconds"
-                    late.setdefault("replicas", replicas)
-                    print(json.dumps(late), flush=True)
-                elif rank == 0:
-                    print(json.dumps({
-                        "metric": "lasso_prove_time_ms", "value": replicas["ms_per_proof"], "unit": "ms", "n_gpus": world,
-                        "steps": extra_steps, "warmup": 1, "ms_per_step": replicas["ms_per_step"],
-                        "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
-                        "dtype": "u256 (BN254 Fr/Fq, 8x u32 Montgomery)", "data": "synthetic",
-                        "config": {"workload": desc % n, "lookups_per_proof": 1 << n, "proofs_per_step": world,
-                                   "pcs": "multilinear KZG (BN254)", "proof_bytes": len(trr.into_proof()),
-                                   "parallelism": "1 proof per GPU"},
-                        "lookups_per_s": replicas["lookups_per_s"],
-                        "mode_fallback": {"ran": "replicas", "sharded_error": "the sharded proof did not complete within "
-                                          "LH_BENCH_SHARDED_TIMEOUT seconds"}}), flush=True)
-                os._exit(0)
-            import threading
-            watchdog = threading.Timer(float(os.environ.get("LH_BENCH_SHARDED_TIMEOUT", "240")), give_up)
-            watchdog.daemon = True
-            watchdog.start()
+        def give_up():
+            # a collective that never completes cannot be caught as an exception: after LH_BENCH_SHARDED_TIMEOUT seconds
+            # (default 240) say what is known on stderr and FAIL the run (the other ranks sit in the same collective;
+            # their timers do the same).  A process with a kernel stuck on the GPU must not report numbers.
+            if rank == 0:
+                sys.stderr.write(json.dumps({
+                    "error": "the sharded proof (or an extra object after it) did not complete within "
+                             "LH_BENCH_SHARDED_TIMEOUT seconds", "headline_line_before_the_hang": headline.get("line"),
+                    "replicas_measured_before": replicas}) + "\n")
+                sys.stderr.flush()
+            os._exit(3)
+        import threading
+        watchdog = threading.Timer(float(os.environ.get("LH_BENCH_SHARDED_TIMEOUT", "240")), give_up)
+        watchdog.daemon = True
+        watchdog.start()
         transport = hdist.attach_sharded(ctx, dist, shard_bit)
 
     ms_per_step, tr = timed(args.steps, args.warmup)
@@ -630,19 +635,59 @@ def main():
         dist.destroy_process_group()
 
 
+def spawn_ranks(n, argv, extra_env=None):
+    """start the n ranks of a job as child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run
+    sets them; rank 0's stdout is this process's stdout) and return the first non-zero exit code, else 0.  The caller has
+    not touched a GPU - or is on its way out."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    while procs:
+        for p in list(procs):
+            code = p.poll()
+            if code is None:
+                continue
+            procs.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in procs:  # a dead rank leaves its peers in a collective: stop them (exact PIDs we started)
+                    q.terminate()
+        time.sleep(0.1)
+    return rc
+
+
+def replicas_fallback(err):
+    """A sharded run that failed the same way on every rank (an exception, not a hang) is re-run as N independent
+    replicas in FRESH processes - this one has live contexts and a process group in an unknown state - and the line says
+    so.  Every rank starts its own successor (same RANK / WORLD_SIZE, the rendezvous one port up) and leaves with its
+    exit code."""
+    import traceback
+    traceback.print_exc()
+    env = dict(os.environ, LH_BENCH_MODE_FALLBACK="%s: %s" % (type(err).__name__, err),
+               MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29533")) + 17))
+    argv = [a for a in sys.argv[1:]] + ["--mode", "replicas"]
+    return subprocess.call([sys.executable, os.path.abspath(__file__)] + argv, env=env)
+
+
 if __name__ == "__main__":
+    _args = parse()
+    if _args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process only starts the ranks (no GPU call before this point)
+        sys.exit(spawn_ranks(_args.gpus, sys.argv[1:]))
     try:
         main()
     except Exception as e:
-        # N > 1: a sharded run that fails the same way on every rank (an exception, not a hang) is re-run as N independent
-        # replicas, and the line says so; anything else is fatal
-        _args = parse()
         if int(os.environ.get("WORLD_SIZE", "1")) > 1 and _args.mode == "sharded" and _args.workload == "lasso" \
                 and "LH_BENCH_MODE_FALLBACK" not in os.environ:
-            import traceback
-            traceback.print_exc()
-            os.environ["LH_BENCH_MODE_FALLBACK"] = "%s: %s" % (type(e).__name__, e)
-            sys.argv += ["--mode", "replicas"]
-            main()
-        else:
-            raise
+            sys.stdout.flush()
+            os._exit(replicas_fallback(e))  # (no teardown of this process's half-finished job: the successor spoke for it)
+        raise

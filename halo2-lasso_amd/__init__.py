@@ -899,6 +899,11 @@ def comm_stats(ctx):
     return {"device": int(out[0]), "host": int(out[1])}
 
 
+def attach_comm_loopback(ctx, rank, size, shard_bit):
+    """lh_ctx_set_comm_loopback: measurement aid - every peer is a copy of this rank (the transcript is not a valid proof)"""
+    _check(ctx.lib.lh_ctx_set_comm_loopback(ctx.h, rank, size, shard_bit))
+
+
 def detach_comm(ctx):
     _check(ctx.lib.lh_ctx_set_comm(ctx.h, None, 0))
     ctx._comm_keepalive = None

@@ -187,6 +187,7 @@ SIGNATURES = {
     "lh_ctx_set_comm": (C.c_int, [_P, C.POINTER(lh_comm), _SZ]),
     "lh_rccl_unique_id": (C.c_int, [C.c_char_p]),
     "lh_ctx_set_comm_rccl": (C.c_int, [_P, C.c_int, C.c_int, C.c_char_p, _SZ]),
+    "lh_ctx_set_comm_loopback": (C.c_int, [_P, C.c_int, C.c_int, _SZ]),
     "lh_ctx_comm_stats": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "lh_lasso_prove_sharded": (C.c_int, [_P, _P, C.POINTER(lh_lasso_table), _SZ, C.POINTER(_P),
                                          C.POINTER(lh_transcript)]),

@@ -500,6 +500,15 @@ lh_status lh_ctx_set_comm_rccl(lh_ctx* ctx, int rank, int size, const uint8_t un
   ctx->c.comm_stats[0] = ctx->c.comm_stats[1] = 0;
   LH_CATCH
 }
+lh_status lh_ctx_set_comm_loopback(lh_ctx* ctx, int rank, int size, size_t shard_bit) {
+  LH_TRY NEED_CTX(ctx);
+  LH_REQUIRE(size >= 1 && (size & (size - 1)) == 0 && rank >= 0 && rank < size, LH_ERR_ARG,
+             "communicator: size must be a power of two and 0 <= rank < size");
+  ctx->c.sync();
+  comm_attach_loopback(ctx->c, rank, size, shard_bit);
+  ctx->c.comm_stats[0] = ctx->c.comm_stats[1] = 0;
+  LH_CATCH
+}
 lh_status lh_ctx_comm_stats(lh_ctx* ctx, uint64_t out[2]) {
   LH_TRY NEED_CTX(ctx);
   NEED(out);

@@ -112,6 +112,7 @@ void comm_detach(Ctx& c) {
     c.rccl_comm = nullptr;
   }
   c.has_comm = false;
+  c.comm_loopback = false;
   c.comm = lh_comm{0, 1, nullptr, nullptr, nullptr};
   c.shard_bit = 0;
 }
@@ -128,6 +129,18 @@ void comm_attach_rccl(Ctx& c, int rank, int size, const uint8_t id_bytes[LH_RCCL
   c.shard_bit = shard_bit;
 }
 
+// Measurement aid (lh_ctx_set_comm_loopback): every peer is a copy of this rank.  Rank `rank` of a `size`-rank proof then
+// runs alone on its GPU with exactly the kernels, sizes and exchange volumes it has in the real job - the compute half of
+// a scaling curve without the other GPUs.  Sums and gathered tables are NOT those of a real job: the transcript it
+// produces is not a valid proof.
+void comm_attach_loopback(Ctx& c, int rank, int size, size_t shard_bit) {
+  comm_detach(c);
+  c.comm = lh_comm{rank, size, nullptr, nullptr, nullptr};
+  c.comm_loopback = true;
+  c.has_comm = true;
+  c.shard_bit = shard_bit;
+}
+
 static const bool COMM_DEBUG = getenv("LH_COMM_DEBUG") != nullptr;  // one stderr line per collective (development)
 static void comm_trace(const Ctx& c, const char* what, size_t bytes) {
   if (COMM_DEBUG)
@@ -136,7 +149,7 @@ static void comm_trace(const Ctx& c, const char* what, size_t bytes) {
 }
 
 static void require_comm(const Ctx& c) {
-  LH_REQUIRE(c.has_comm && (c.rccl_comm || c.comm.all_gather || c.comm.all_gather_device), LH_ERR_ARG,
+  LH_REQUIRE(c.has_comm && (c.rccl_comm || c.comm_loopback || c.comm.all_gather || c.comm.all_gather_device), LH_ERR_ARG,
              "no communicator attached (lh_ctx_set_comm / lh_ctx_set_comm_rccl)");
 }
 
@@ -144,6 +157,12 @@ void comm_all_gather_dev(Ctx& c, const void* d_send, void* d_recv, size_t bytes)
   require_comm(c);
   if (!bytes) return;
   comm_trace(c, "all_gather_dev", bytes);
+  if (c.comm_loopback) {
+    c.comm_stats[0]++;
+    for (size_t s = 0; s < (size_t)c.comm.size; s++)
+      LH_HIP(hipMemcpyAsync((char*)d_recv + s * bytes, d_send, bytes, hipMemcpyDeviceToDevice, c.stream));
+    return;
+  }
   if (c.rccl_comm) {
     c.comm_stats[0]++;
     rccl_check(rccl().AllGather(d_send, d_recv, bytes, ncclUint8, (ncclComm_t)c.rccl_comm, c.stream), "ncclAllGather");
@@ -171,6 +190,11 @@ void comm_all_gather_host(Ctx& c, const void* send, void* recv, size_t bytes) {
   require_comm(c);
   if (!bytes) return;
   comm_trace(c, "all_gather_host", bytes);
+  if (c.comm_loopback) {
+    c.comm_stats[1]++;
+    for (size_t s = 0; s < (size_t)c.comm.size; s++) memcpy((char*)recv + s * bytes, send, bytes);
+    return;
+  }
   if (c.comm.all_gather && !c.rccl_comm) {
     c.comm_stats[1]++;
     int rc = c.comm.all_gather(c.comm.user, send, recv, bytes);

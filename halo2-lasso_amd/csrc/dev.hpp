@@ -129,6 +129,7 @@ struct Ctx {
   // one proof over several GPUs: host-side communicator + position of the shard bits
   lh_comm comm = {0, 1, nullptr, nullptr, nullptr};
   bool has_comm = false;
+  bool comm_loopback = false;  // measurement aid: every peer is a copy of this rank (comm.cpp comm_attach_loopback)
   size_t shard_bit = 0;
   // a sharded proof is running on this ctx (set for the duration of lh_lasso_prove_sharded): every routine of the prover
   // then takes its tables as this rank's shards (struct Shard below); otherwise an attached communicator is ignored
@@ -331,6 +332,7 @@ bool k_fr_tables_equal(Ctx&, const Fr* a, const Fr* b, size_t n);
 // ------------------------------------------------------------------ communicator (comm.cpp)
 void rccl_unique_id(uint8_t out[LH_RCCL_UNIQUE_ID_BYTES]);
 void comm_attach_rccl(Ctx&, int rank, int size, const uint8_t id[LH_RCCL_UNIQUE_ID_BYTES], size_t shard_bit);
+void comm_attach_loopback(Ctx&, int rank, int size, size_t shard_bit);
 void comm_detach(Ctx&);
 // recv = size * bytes, rank-major.  _dev: device buffers, enqueued on the ctx's stream (staged through the host when
 // the communicator has no device collective); _host: host buffers, synchronous

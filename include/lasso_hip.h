@@ -312,13 +312,20 @@ lh_status lh_rccl_unique_id(uint8_t out[LH_RCCL_UNIQUE_ID_BYTES]);
 /* ncclCommInitRank on the ctx's device (collective: every rank of the job calls it with the same id) */
 lh_status lh_ctx_set_comm_rccl(lh_ctx*, int rank, int size, const uint8_t unique_id[LH_RCCL_UNIQUE_ID_BYTES],
                                size_t shard_bit);
+/* MEASUREMENT AID, not a transport: every peer is a copy of this rank (device gathers are device copies, nothing leaves
+ * the GPU).  Rank `rank` of a `size`-rank sharded proof then runs alone with exactly the kernels, sizes and exchange
+ * volumes it has in the real job - the compute half of a scaling curve on one GPU (tools/sharded_rank_profile.py).  The
+ * transcript lh_lasso_prove_sharded produces over it is NOT a valid proof (the sums are R times this rank's share). */
+lh_status lh_ctx_set_comm_loopback(lh_ctx*, int rank, int size, size_t shard_bit);
 /* collectives issued on this ctx since the communicator was attached: out[0] device-side (RCCL or
  * all_gather_device), out[1] host callback.  A job on RCCL shows out[1] == 0. */
 lh_status lh_ctx_comm_stats(lh_ctx*, uint64_t out[2]);
-/* Same proof bytes as lh_lasso_prove on one GPU.  d_dims_local[j]: THIS RANK'S shard of chunk column j, device
- * u32[2^(num_vars - rho)] in the shard layout (local index hi || lo <-> lookup (hi, rank, lo)).  The 4-byte columns
- * are all-gathered once (the access counters are a stable sort in global lookup order); everything field-sized -
- * tables, SRS, sum-check, product trees, MSMs, openings - stays sharded. */
+/* Same proof bytes as lh_lasso_prove on one GPU - it IS lh_lasso_prove with every table a shard: the same kernels (eq-
+ * factored rounds, leaf-layer kernel, derived / packed commitments, column-wise top quotient) run on the shards, with a
+ * collective where a round's partial sums or an MSM's partial commitments are added.  d_dims_local[j]: THIS RANK'S shard
+ * of chunk column j, device u32[2^(num_vars - rho)] in the shard layout (local index hi || lo <-> lookup (hi, rank, lo)).
+ * The access counters (a rank in the global lookup order per address) repartition the lookups by address owner with
+ * one personalised exchange per column and direction; no rank ever holds a whole column.  Multilinear KZG only. */
 lh_status lh_lasso_prove_sharded(lh_ctx*, const lh_srs*, const lh_lasso_table*, size_t num_vars,
                                  const uint32_t* const* d_dims_local, lh_transcript* t);
 

@@ -55,3 +55,23 @@ def test_single_process_is_a_noop():
     assert hdist.init() is None
     assert hdist.max_over_ranks(None, 1.5) == 1.5
     assert hdist.job_metrics(2.0, 4, 1, 1 << 20)["value_ms_per_proof"] == 500.0
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher (no WORLD_SIZE): bench.py itself starts the two ranks before any GPU
+    call, rank 0's line comes back on stdout, the exit code is the ranks'.  (--rendezvous-only: process group over gloo
+    and one all-reduce, no GPU work - the launch path on this CPU-only machine.)"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["LH_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only"], env=env,
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d == {"n_gpus": 2, "max_rank": 1, "rendezvous": "ok"}
+    # a rank that fails takes the job's exit code with it
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only"],
+                       env=dict(env, LH_DIST_BACKEND="no-such-backend"), capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -165,6 +165,72 @@ def test_sharded_proof_large_vs_cpp_oracle(tmp_path, world, kind, c, l, n, shard
     assert proofs.pop() == ot.into_proof().hex()
 
 
+BIG_WORKER = textwrap.dedent("""
+    import os, sys, json, hashlib, faulthandler
+    faulthandler.dump_traceback_later(840, exit=True)
+    sys.path.insert(0, %r)
+    import numpy as np
+    import halo2_lasso_amd as hl
+    from halo2_lasso_amd import dist as hdist
+    import bench
+    cfg = json.loads(sys.argv[1])
+    rank, _, world = hdist.env_rank()
+    d = hdist.init("gloo")
+    ctx = hl.Context(0)                      # every rank on the one GPU of the test box
+    table, _ = bench.make_table(hl, cfg["kind"])
+    n = cfg["n"]
+    pp = hl.MultilinearKzg.setup(ctx, bench.trapdoor(n))
+    d_dims = [ctx.upload(hl.shard_of(col, rank, world, cfg["shard_bit"]).tobytes()) for col in bench.gen_dims(table, n, 0)]
+    hl.attach_comm(ctx, rank, world, hdist.host_all_gather(d), cfg["shard_bit"])
+    t = hl.Keccak256Transcript()
+    hl.lasso_prove_sharded(pp, table, n, d_dims, t)
+    proof = t.into_proof()
+    with open(sys.argv[2] + ".%%d" %% rank, "w") as f:
+        json.dump({"rank": rank, "sha256": hashlib.sha256(proof).hexdigest(), "bytes": len(proof), "stats": hl.comm_stats(ctx),
+                   "route": hl.lasso_last_route(ctx), "phases": hl.lasso_last_timing(ctx)}, f)
+    hdist.barrier(d)
+    d.destroy_process_group()
+""") % ROOT
+
+
+def run_big(tmp_path, world, cfg, port):
+    script = tmp_path / "big_worker.py"
+    script.write_text(BIG_WORKER)
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(r),
+                   LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script), json.dumps(cfg), str(tmp_path / "out")], env=env,
+                                      stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True))
+    return _wait_all(procs, 900, str(tmp_path / "out"))
+
+
+@pytest.mark.parametrize("world,kind,n", [(8, "range", 26), (4, "and", 24)])
+def test_full_size_configs_sharded_on_one_gpu(tmp_path, hl, ctx, world, kind, n):
+    """BASELINE.json configs[3] at FULL size - 2^26 range-check lookups, one proof sharded over 8 ranks - and configs[2]
+    (2^24 AND) over 4 ranks, the ranks sharing the one GPU of the test box over gloo: every rank's proof is byte for byte
+    the single-GPU prover's proof of the same lookups (which test_gpu_verify / test_gpu_parity_large tie to the verifier
+    and the C++ oracle).  Exercises the sharded code at the real sizes: the repartitioned access counters on 2^23-entry
+    shards, eq-factored sharded rounds, the column-wise top quotients on shards, SRS shards of 2^23 points."""
+    import hashlib
+    import bench
+    table, _ = bench.make_table(hl, kind)
+    rho = world.bit_length() - 1
+    shard_bit = max(table.l - rho, 10)
+    pp = hl.MultilinearKzg.setup(ctx, bench.trapdoor(n))
+    full = [ctx.upload(c.tobytes()) for c in bench.gen_dims(table, n, 0)]
+    t = hl.Keccak256Transcript()
+    hl.lasso_prove(pp, table, n, full, t)
+    single = t.into_proof()
+    del full, pp
+    outs = run_big(tmp_path, world, dict(kind=kind, n=n, shard_bit=shard_bit), 29480 + world + n)
+    want = hashlib.sha256(single).hexdigest()
+    for o in outs:
+        assert o["bytes"] == len(single) and o["sha256"] == want, "rank %d: the sharded proof differs" % o["rank"]
+        r = o["route"]
+        assert r["sharded_rounds"] > 0 and r["eq_factored_rounds"] > 0 and r["rw_leaf_rounds"] > 0 and r["open_small_depth"] >= 1, r
+
+
 def test_sharded_world1_over_rccl(hl, ctx):
     """The RCCL transport on the one GPU of the test box: a world of ONE rank runs the whole sharded prover - every
     exchange an ncclAllGather on the prover's stream followed by the sum-and-publish kernel - and must give the bytes
@@ -232,6 +298,23 @@ def test_sharded_two_gpus_over_rccl(tmp_path):
                                       stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True))
     for out in _wait_all(procs, 600, str(tmp_path / "out")):
         assert out["same"] and out["stats"]["device"] > 20 and out["stats"]["host"] == 0, out
+
+
+def test_bench_gpus_2_without_a_launcher():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: bench.py starts the two ranks itself (both on GPU 0
+    here, rendezvous over gloo) and relays rank 0's line: n_gpus == 2, one sharded proof per step."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(LH_DEVICE="0", LH_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--log-n", "17", "--table",
+                        "range", "--no-cpu-baseline", "--no-inflight", "--no-extra", "--no-profile"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["proofs_per_step"] == 1
+    assert d["sharded_proof_equals_single_gpu"] is True
 
 
 def test_bench_two_ranks_launched_like_the_driver():

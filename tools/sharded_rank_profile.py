@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""The compute half of the scaling curve, measured on ONE GPU (profiles/r03_sharded_rank_ms.json).
+
+For world = 1, 2, 4, 8 and every rank of that world, the rank proves alone on the GPU over the loopback communicator
+(lh_ctx_set_comm_loopback: every peer is a copy of this rank, device gathers are device copies): exactly the kernels,
+sizes and exchange volumes the rank has in the real sharded job, no other process on the GPU, no link.  Recorded per rank:
+  wall_ms   wall-clock of lh_lasso_prove_sharded (median of `--steps`): a rank's time with every collective free
+  busy_ms   sum of the HIP-event durations of the instrumented launches of one separately profiled prove
+  collectives, the route counters (lh_lasso_last_route), the largest kernels
+and for world = 1 the plain lh_lasso_prove next to it.  What is NOT in these numbers: link time (RCCL over xGMI) and
+waiting for slower peers.  The transcripts of loopback runs are not valid proofs (byte equality of the real sharded
+prover is tests/test_gpu_sharded.py's business).
+
+usage: python tools/sharded_rank_profile.py [--configs and24,range26] [--worlds 1,2,4,8] [--out FILE]
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", default="and24,range26")
+    ap.add_argument("--worlds", default="1,2,4,8")
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--all-ranks", action="store_true", help="every rank of each world (default: ranks 0 and R-1)")
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r03_sharded_rank_ms.json"))
+    args = ap.parse_args()
+    import halo2_lasso_amd as hl
+    import bench
+    ctx = hl.Context(0)
+    result = {"note": __doc__.split("\n\n")[1].replace("\n", " "), "configs": {}}
+    for cfg in args.configs.split(","):
+        kind, n = cfg.rstrip("0123456789"), int(cfg[len(cfg.rstrip("0123456789")):])
+        table, desc = bench.make_table(hl, kind)
+        pp = hl.MultilinearKzg.setup(ctx, bench.trapdoor(n))
+        cols = bench.gen_dims(table, n, 0)
+        entry = {"workload": desc % n, "worlds": {}}
+        # the single-GPU prover
+        full = [ctx.upload(c.tobytes()) for c in cols]
+        for _ in range(2):
+            hl.lasso_prove(pp, table, n, full, hl.Keccak256Transcript())
+        ts = []
+        for _ in range(args.steps):
+            ctx.sync()
+            t0 = time.perf_counter()
+            hl.lasso_prove(pp, table, n, full, hl.Keccak256Transcript())
+            ctx.sync()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        hl.profile_enable(ctx, True)
+        hl.lasso_prove(pp, table, n, full, hl.Keccak256Transcript())
+        ctx.sync()
+        aggs = bench.aggregate(hl.profile_read(ctx))
+        hl.profile_enable(ctx, False)
+        single = {"wall_ms": round(statistics.median(ts), 3), "busy_ms": round(sum(a["ms"] for a in aggs), 3),
+                  "route": hl.lasso_last_route(ctx)}
+        entry["single_gpu_lasso_prove"] = single
+        del full
+        for world in [int(w) for w in args.worlds.split(",")]:
+            rho = world.bit_length() - 1
+            shard_bit = max(table.l - rho, min(10, n - rho - 1), 1)
+            if world == 1:
+                shard_bit = max(shard_bit, table.l)
+            ranks = list(range(world)) if args.all_ranks else sorted({0, world - 1})
+            per_rank = []
+            for rank in ranks:
+                d_dims = [ctx.upload(hl.shard_of(c, rank, world, shard_bit).tobytes()) for c in cols]
+                hl.attach_comm_loopback(ctx, rank, world, shard_bit)
+                try:
+                    for _ in range(2):
+                        hl.lasso_prove_sharded(pp, table, n, d_dims, hl.Keccak256Transcript())
+                    ts = []
+                    for _ in range(args.steps):
+                        ctx.sync()
+                        t0 = time.perf_counter()
+                        hl.lasso_prove_sharded(pp, table, n, d_dims, hl.Keccak256Transcript())
+                        ctx.sync()
+                        ts.append((time.perf_counter() - t0) * 1e3)
+                    phases = hl.lasso_last_timing(ctx)
+                    stats0 = hl.comm_stats(ctx)
+                    hl.profile_enable(ctx, True)
+                    hl.lasso_prove_sharded(pp, table, n, d_dims, hl.Keccak256Transcript())
+                    ctx.sync()
+                    aggs = bench.aggregate(hl.profile_read(ctx))
+                    hl.profile_enable(ctx, False)
+                    stats1 = hl.comm_stats(ctx)
+                finally:
+                    hl.detach_comm(ctx)
+                del d_dims
+                per_rank.append({
+                    "rank": rank, "wall_ms": round(statistics.median(ts), 3),
+                    "busy_ms": round(sum(a["ms"] for a in aggs), 3),
+                    "collectives_per_proof": {k: stats1[k] - stats0[k] for k in stats0},
+                    "phases_ms": {k: round(v, 3) for k, v in phases.items()},
+                    "route": hl.lasso_last_route(ctx),
+                    "top_kernels": [{"name": a["name"], "launches": a["launches"], "ms": round(a["ms"], 3)} for a in aggs[:8]]})
+            worst_wall = max(r["wall_ms"] for r in per_rank)
+            worst_busy = max(r["busy_ms"] for r in per_rank)
+            entry["worlds"][str(world)] = {
+                "shard_bit": shard_bit, "ranks": per_rank, "max_rank_wall_ms": worst_wall, "max_rank_busy_ms": worst_busy,
+                "ideal_ms": round(single["wall_ms"] / world, 3),
+                "wall_over_ideal": round(worst_wall / (single["wall_ms"] / world), 3),
+                "busy_over_ideal": round(worst_busy / (single["busy_ms"] / world), 3),
+                "compute_speedup_vs_single_gpu": round(single["wall_ms"] / worst_wall, 3)}
+            print("%s world %d: max rank wall %.2f ms, busy %.2f ms (single GPU %.2f / %.2f)" % (
+                cfg, world, worst_wall, worst_busy, single["wall_ms"], single["busy_ms"]), file=sys.stderr, flush=True)
+        result["configs"][cfg] = entry
+        del pp
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    with open(args.out, "w") as f:
+        json.dump(result, f, indent=1)
+    print(json.dumps({k: {w: (v["worlds"][w]["max_rank_wall_ms"], v["worlds"][w]["max_rank_busy_ms"]) for w in v["worlds"]}
+                      for k, v in result["configs"].items()}))
+
+
+if __name__ == "__main__":
+    main()
