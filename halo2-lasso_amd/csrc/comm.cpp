@@ -158,9 +158,17 @@ void comm_all_gather_dev(Ctx& c, const void* d_send, void* d_recv, size_t bytes)
   if (!bytes) return;
   comm_trace(c, "all_gather_dev", bytes);
   if (c.comm_loopback) {
+    // peer s's data = this rank's rotated by 32 s bytes (whole field elements): the same volume, but not R identical
+    // blocks - identical halves of a gathered table would make a quotient identically zero, and its commitment, the
+    // identity, cannot be written to the transcript
     c.comm_stats[0]++;
-    for (size_t s = 0; s < (size_t)c.comm.size; s++)
-      LH_HIP(hipMemcpyAsync((char*)d_recv + s * bytes, d_send, bytes, hipMemcpyDeviceToDevice, c.stream));
+    const size_t R = (size_t)c.comm.size;
+    for (size_t s = 0; s < R; s++) {
+      const size_t rot = bytes % 32 == 0 && bytes >= 64 * R ? 32 * s : 0;
+      char* dst = (char*)d_recv + s * bytes;
+      LH_HIP(hipMemcpyAsync(dst, (const char*)d_send + rot, bytes - rot, hipMemcpyDeviceToDevice, c.stream));
+      if (rot) LH_HIP(hipMemcpyAsync(dst + bytes - rot, d_send, rot, hipMemcpyDeviceToDevice, c.stream));
+    }
     return;
   }
   if (c.rccl_comm) {

@@ -128,9 +128,7 @@ LARGE = [
     # kernel, packed and derived commitments, the column-wise top quotient - checked against the C++ oracle
     (2, "range", 2, 16, 18, 15, None),
     (4, "and", 4, 16, 18, 14, None),
-    (8, "and", 4, 16, 20, 13, None),
     (8, "xor", 4, 16, 20, 13, 0),
-    (8, "range", 2, 16, 21, 13, None),
 ]
 
 
