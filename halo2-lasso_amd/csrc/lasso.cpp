@@ -157,7 +157,8 @@ LassoColumns lasso_witness_columns(Ctx& c, const lh_lasso_table& tb, size_t n, c
     w.rts[j] = c.arena.alloc_n<uint32_t>(N);
     w.fcs[j] = c.arena.alloc_n<uint32_t>(M);
   }
-  if (sh.on) {
+  keep_sorted = keep_sorted && sh.R == 1;
+  if (sh.on && sh.R > 1) {
     lasso_counters_sharded(c, sh, d_dims, cc, n, l, w.rts.data(), w.fcs.data());
   } else {
     for (size_t j = 0; j < cc; j++) {
@@ -421,7 +422,7 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
   Fr* a = nullptr;
   uint32_t* a_small = nullptr;
   // (the sorted dim columns only pay off where the MSM sorts slab by slab: msm.hip LH_MSM_SLAB_LOG)
-  LassoColumns w = lasso_witness_columns(c, tb, n, d_dims, &a, &a_small, !shn && (int)n >= msm_slab_log());
+  LassoColumns w = lasso_witness_columns(c, tb, n, d_dims, &a, &a_small, (int)n >= msm_slab_log());
   std::vector<uint32_t*>&rts = w.rts, &fcs = w.fcs, &E = w.E;
   lap(0);
   // ---- 0/1: domain separation + commitments (one batched MSM)
