@@ -264,6 +264,14 @@ void hyperplonk_prove_phases(Ctx& c, const PcsProver& pcs, const lh_hp_param& pp
   std::vector<LassoState> lasso(pp.num_lasso_lookups);
   if (pp.num_lasso_lookups) {
     LH_REQUIRE(pp.lasso_lookups != nullptr, LH_ERR_ARG, "hyperplonk: lasso_lookups is null");
+    {
+      // all Lasso commitments of a proof share ONE identity mask (a field element read as 63 bits, lasso.cpp)
+      size_t total = 0;
+      for (size_t k = 0; k < pp.num_lasso_lookups; k++)
+        total += 2 * (size_t)pp.lasso_lookups[k].table.num_chunks + pp.lasso_lookups[k].table.num_memories;
+      LH_REQUIRE(total <= LH_HP_LASSO_MAX_COMMITMENTS, LH_ERR_ARG,
+                 "hyperplonk: the Lasso lookups of one circuit commit to more than 63 polys (sum of 2 * chunks + memories)");
+    }
     const G1Affine* bases = pcs.commit_bases(nv);
     std::vector<MsmJob> jobs;
     for (size_t k = 0; k < pp.num_lasso_lookups; k++) {
@@ -273,10 +281,14 @@ void hyperplonk_prove_phases(Ctx& c, const PcsProver& pcs, const lh_hp_param& pp
       lasso_check_table(tb);
       const size_t cc = tb.num_chunks, l = tb.chunk_bits, alpha = tb.num_memories, M = (size_t)1 << l;
       if (l > nv) throw Error(LH_ERR_INVALID_SNARK, "Lasso subtable larger than the circuit");
-      LH_REQUIRE(st.lk->output_poly < polys.size(), LH_ERR_ARG, "hyperplonk: lasso output poly out of range");
+      // (the same range on the verifier's side, verifier.cpp: preprocess and witness polys - committed, and known before
+      // the lookup argument starts)
+      LH_REQUIRE(st.lk->output_poly >= pp.num_instance_polys && st.lk->output_poly < polys.size(), LH_ERR_ARG,
+                 "hyperplonk: lasso output poly out of range");
       st.dims.resize(cc);
       for (size_t j = 0; j < cc; j++) {
-        LH_REQUIRE(st.lk->chunk_polys[j] < polys.size(), LH_ERR_ARG, "hyperplonk: lasso chunk poly out of range");
+        LH_REQUIRE(st.lk->chunk_polys[j] >= pp.num_instance_polys && st.lk->chunk_polys[j] < polys.size(), LH_ERR_ARG,
+                   "hyperplonk: lasso chunk poly out of range");
         st.dim_fr.push_back(polys[st.lk->chunk_polys[j]]);
         st.dims[j] = c.arena.alloc_n<uint32_t>(n);
         if (!k_fr_to_index(c, st.dim_fr[j], n, (uint32_t)l, st.dims[j]))

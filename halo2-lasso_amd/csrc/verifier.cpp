@@ -507,10 +507,13 @@ void hyperplonk_verify_phases(const PcsBatchVerify& batch_verify, const lh_hp_vp
     const lh_hp_lasso_lookup& lk = vp.lasso_lookups[k];
     const lh_lasso_table& tb = lk.table;
     const size_t cc = tb.num_chunks, l = tb.chunk_bits, alpha = tb.num_memories;
-    const size_t first_committed = vp.num_instance_polys;  // instance polys have no commitment to open
-    LH_REQUIRE(lk.output_poly >= first_committed && lk.output_poly < base, LH_ERR_ARG, "hyperplonk: lasso output poly out of range");
+    // the prover's range (hyperplonk.cpp): preprocess and witness polys - instance polys have no commitment to open, the
+    // polys after the witness do not exist yet when the lookup's columns are read
+    const size_t first_committed = vp.num_instance_polys;
+    const size_t end_committed = vp.num_instance_polys + vp.num_preprocess_polys + witness_comms.size();
+    LH_REQUIRE(lk.output_poly >= first_committed && lk.output_poly < end_committed, LH_ERR_ARG, "hyperplonk: lasso output poly out of range");
     for (size_t j = 0; j < cc; j++)
-      LH_REQUIRE(lk.chunk_polys[j] >= first_committed && lk.chunk_polys[j] < base, LH_ERR_ARG,
+      LH_REQUIRE(lk.chunk_polys[j] >= first_committed && lk.chunk_polys[j] < end_committed, LH_ERR_ARG,
                  "hyperplonk: lasso chunk poly out of range");
     for (size_t v : {nv, l, cc, alpha}) tr.common_field_element(HFr::from_u64(v));
     LassoClaims cl = lasso_check(tb, nv, tr);

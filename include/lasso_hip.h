@@ -352,7 +352,11 @@ typedef struct lh_hp_lookup {
  * not instance polys).  The argument adds committed polys read_ts_j | E_i | final_cts_j, numbered after the
  * permutation z polys; they are committed in round n after the LogUp m commitments (identity-mask framing), the
  * argument runs after the zero-check, and ONE batch_open serves the zero-check's queries and every Lasso claim.
- * Requires chunk_bits <= num_vars. */
+ * Requires chunk_bits <= num_vars; output_poly and chunk_polys must be preprocess or witness polys (index >=
+ * num_instance_polys and < num_instance_polys + num_preprocess_polys + witness polys - prover and verifier check the same
+ * range); all Lasso commitments of one proof share one identity mask of 63 bits, so the lookups of a circuit may commit
+ * to at most LH_HP_LASSO_MAX_COMMITMENTS polys together (sum over the lookups of 2 * num_chunks + num_memories). */
+#define LH_HP_LASSO_MAX_COMMITMENTS 63
 typedef struct lh_hp_lasso_lookup {
   lh_lasso_table table;
   size_t output_poly;

@@ -27,6 +27,8 @@
 #include <algorithm>
 #include <functional>
 #include <stdexcept>
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -45,17 +47,89 @@ static int num_threads() {
   }
   return g_threads;
 }
-// parallelize (parallel.rs:27-46): contiguous chunks, serial when chunk_size < num_threads
+// parallelize (parallel.rs:27-46): contiguous chunks, serial when chunk_size < num_threads.  The chunks run on a
+// persistent pool (rayon keeps its workers alive too: spawning std::threads per call cost more than the work of the
+// small calls - thousands per proof - and put the CPU baseline at a disadvantage it does not have in the reference).
+namespace {
+struct Pool {
+  std::vector<std::thread> workers;
+  std::mutex mu;
+  std::condition_variable cv_work, cv_done;
+  const std::function<void(size_t, size_t)>* fn = nullptr;
+  size_t n = 0, chunk = 0, next = 0, pending = 0;
+  uint64_t generation = 0;
+  bool stop = false;
+  static thread_local bool inside;
+  explicit Pool(size_t nt) {
+    for (size_t i = 0; i + 1 < nt; i++) workers.emplace_back([this] { run(); });
+  }
+  ~Pool() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv_work.notify_all();
+    for (auto& t : workers) t.join();
+  }
+  bool take(size_t& s, size_t& e) {  // (mu held)
+    if (!fn || next >= n) return false;
+    s = next, e = std::min(n, next + chunk);
+    next = e;
+    return true;
+  }
+  void run() {
+    inside = true;
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      size_t s, e;
+      if (take(s, e)) {
+        const auto* f = fn;
+        lk.unlock();
+        (*f)(s, e);
+        lk.lock();
+        if (--pending == 0) cv_done.notify_all();
+        continue;
+      }
+      if (stop) return;
+      cv_work.wait(lk);
+    }
+  }
+  void parallel(size_t n_, size_t chunk_, const std::function<void(size_t, size_t)>& f) {
+    std::unique_lock<std::mutex> lk(mu);
+    fn = &f, n = n_, chunk = chunk_, next = 0, pending = (n_ + chunk_ - 1) / chunk_;
+    generation++;
+    cv_work.notify_all();
+    // the caller works too
+    size_t s, e;
+    while (take(s, e)) {
+      lk.unlock();
+      f(s, e);
+      lk.lock();
+      --pending;
+    }
+    cv_done.wait(lk, [this] { return pending == 0; });
+    fn = nullptr;
+  }
+};
+thread_local bool Pool::inside = false;
+}  // namespace
 static void parallelize(size_t n, const std::function<void(size_t, size_t)>& f) {
   size_t nt = (size_t)num_threads();
   size_t chunk = (n + nt - 1) / nt;
-  if (nt == 1 || chunk < nt) {
+  if (nt == 1 || chunk < nt || Pool::inside) {  // (a chunk that parallelizes again runs that part inline)
     f(0, n);
     return;
   }
-  std::vector<std::thread> th;
-  for (size_t s = 0; s < n; s += chunk) th.emplace_back(f, s, std::min(n, s + chunk));
-  for (auto& t : th) t.join();
+  static Pool* pool = nullptr;
+  static size_t pool_threads = 0;
+  static std::mutex pool_mu;  // one parallel region at a time (the oracle is driven from one thread)
+  std::lock_guard<std::mutex> guard(pool_mu);
+  if (!pool || pool_threads != nt) {
+    delete pool;
+    pool = new Pool(nt);
+    pool_threads = nt;
+  }
+  pool->parallel(n, chunk, f);
 }
 
 // ------------------------------------------------------------------ Keccak-256 (sha3 0.10.6 Keccak256)

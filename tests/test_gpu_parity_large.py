@@ -271,6 +271,39 @@ def test_zeromorph_commit_open_2p16(hl, ctx):
                         hl.Keccak256Transcript.from_proof(t.into_proof()))
 
 
+# ------------------------------------------------------------------ the headline config's REAL route, byte for byte
+@pytest.fixture(scope="module")
+def srs22(hl, ctx):
+    """GPU params for 22 variables and their flat SRS for the C++ oracle (srs17 above ties the GPU setup to the oracle's)"""
+    ss = trapdoor(22, 2200)
+    pp = hl.MultilinearKzg.setup(ctx, ss)
+    return ss, pp, pp.eqs_bytes()
+
+
+@pytest.mark.parametrize("kind,n", [("and", 21), ("xor", 21), ("range", 22)])
+def test_lasso_default_route_at_2p21_matches_cpp_oracle(hl, ctx, srs22, kind, n):
+    """The route the 2^24 headline proof takes switches on at 2^21 lookups: the largest quotient(s) of the opening are
+    committed column by column (mkzg_open's column route: packed pairs with 2^18-2^20 buckets, 32-share window sums, the
+    lazy first fold; TWO column-wise levels for the range check), E columns come from their dim column's buckets, read_ts
+    columns go in packed pairs.  A passing pairing check does not pin the n quotient commitments one by one; the C++
+    oracle's bytes do.  Default options, nothing forced."""
+    ss, pp, flat = srs22
+    table = hl.LassoTable.range(2, 16) if kind == "range" else hl.LassoTable.bitwise(
+        hl.SUBTABLE_AND if kind == "and" else hl.SUBTABLE_XOR, 4, 16)
+    rng = np.random.default_rng(2100 + n + len(kind))
+    dims = _dims(rng, table, n, kind == "xor")
+    ot = co.Transcript()
+    co.lasso_prove(ot, flat, 22, table.to_c(), n, [d.tobytes() for d in dims])
+    t = hl.Keccak256Transcript()
+    hl.lasso_prove(pp, table, n, [ctx.upload(d.tobytes()) for d in dims], t)
+    assert t.into_proof() == ot.into_proof()
+    route = hl.lasso_last_route(ctx)
+    assert route["open_small_depth"] == (2 if kind == "range" else 1) and route["open_small_passes"] >= 3, route
+    assert route["eq_factored_rounds"] > 0 and route["rw_leaf_rounds"] > 0, route
+    if kind != "range":
+        assert route["derived_commitments"] == 4 and route["packed_ts_pairs"] == 2, route
+
+
 # ------------------------------------------------------------------ BASELINE.json configs[2]
 def test_lasso_2p24_and_prove_verify(hl, ctx):
     """2^24 AND lookups (32-bit operands, 4 chunks of 8+8 bits) on one GPU: the proof verifies, is deterministic, and a

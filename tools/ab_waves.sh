@@ -9,3 +9,7 @@ make 2>> ../../gpurun_out/r02_ab.err | tail -1
 cd ../..
 python bench.py --no-inflight --no-cpu-baseline --steps 8 > gpurun_out/r02_ab_base.json 2>> gpurun_out/r02_ab.err
 python -m pytest tests/test_gpu_parity_large.py -m gpu -q -k "sum_check or lasso" 2>&1 | tail -2
+# restore the default build: the tree's library must never stay the variant (later bench / profile lines would be
+# measured on the wrong build)
+touch halo2-lasso_amd/csrc/kernels_sumcheck.hip
+make -C halo2-lasso_amd/csrc 2>> gpurun_out/r02_ab.err | tail -1
