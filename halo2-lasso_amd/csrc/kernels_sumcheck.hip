@@ -178,6 +178,76 @@ __global__ __launch_bounds__(256) LH_SC_WAVES_ATTR(D) void sc_round_kernel(ScArg
   finish_round<D>(fin, partials, lds);
 }
 
+// ------------------------------------------------------------------ one lane per BOUND ENTRY (the degree-2 factored rounds)
+// The streaming kernel above gives a lane a whole pair: in BIND mode it reads 4 consecutive entries (128 B) per table, so
+// every dwordx4 of a wave touches 64 different cache lines - the rounds moved exactly their algorithmic bytes (PMC) at
+// 2.3-3.7 TB/s while the plain bind kernel, one lane per output entry (64 B per lane), streams at 5.2-6.2 TB/s.  Here lane
+// i owns bound entry i = (pair i / 2, side i & 1): it reads in[2i], in[2i+1], binds and stores out[i] exactly like the
+// bind kernel, and evaluates ONE point of q: the odd lane holds v1 = the pair's value at X = 1 as it is; the even lane
+// holds v0 and takes v1 from its neighbour (8 DPP moves per table) for the value at X = 2, 2 v1 - v0.  Same products per
+// pair as before, spread over two lanes; half the registers per lane.
+__device__ __forceinline__ Fr dpp_xor1(const Fr& v) {  // the value of lane ^ 1 (quad_perm [1,0,3,2])
+  Fr o;
+#pragma unroll
+  for (int i = 0; i < 8; i++) o.l[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)v.l[i], 0xB1, 0xF, 0xF, true);
+  return o;
+}
+template <bool BIND>
+__device__ __forceinline__ Fr load_entry(const Fr* __restrict__ in, Fr* __restrict__ out, size_t i, const Fr& r, bool store) {
+  if (BIND) {
+    const Fr e0 = in[2 * i], e1 = in[2 * i + 1];
+    const Fr v = add(mul(sub(e1, e0), r), e0);
+    if (store) out[i] = v;
+    return v;
+  }
+  return in[i];
+}
+// the pair's value at this lane's point: X = 1 on odd lanes (v1), X = 2 on even lanes (2 v1 - v0)
+__device__ __forceinline__ Fr at_lane_point(const Fr& v, bool odd) {
+  const Fr o = dpp_xor1(v);
+  return odd ? v : sub(dbl(o), v);
+}
+// masked block reductions: even lanes' sum, then odd lanes' sum
+__device__ __forceinline__ void reduce_by_parity(const Fr& acc, bool odd, Fr* lds, Fr& even_sum, Fr& odd_sum) {
+  even_sum = block_reduce_sum(odd ? Fr::zero() : acc, lds);
+  odd_sum = block_reduce_sum(odd ? acc : Fr::zero(), lds);
+}
+
+// q(1), q(2) of  sum_b eq_level[b] * sum_m coeff_m prod_k table_{m,k}  (ScRound with eq_level): partials[.][0] = q(1)
+template <bool BIND>
+__global__ __launch_bounds__(256) void sc_round_e2_kernel(ScArgs a, size_t size, Fr* __restrict__ partials, ScFinish fin) {
+  __shared__ Fr lds[4];
+  const ScRound& rd = a.rd;
+  Fr acc = Fr::zero();
+  const size_t items = 2 * size;
+  const bool odd = threadIdx.x & 1;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < items; i += (size_t)gridDim.x * blockDim.x) {
+    Fr s = Fr::zero();
+    for (uint32_t m = 0; m < rd.num_terms; m++) {
+      const int nf = rd.nfac[m];
+      Fr pm = rd.coeff_is_one[m] ? Fr::one() : rd.coeff[m];  // (nf == 0: a constant)
+      for (int k = 0; k < nf; k++) {
+        const int t = rd.fac[m][k];
+        const Fr val = at_lane_point(load_entry<BIND>(rd.in[t], rd.out[t], i, rd.r, a.store[m][k] != 0), odd);
+        pm = k == 0 ? (rd.coeff_is_one[m] ? val : mul(val, rd.coeff[m])) : mul(pm, val);
+      }
+      s = add(s, pm);
+    }
+    acc = add(acc, mul(s, rd.eq_level[i >> 1]));
+  }
+  Fr q2, q1;
+  reduce_by_parity(acc, odd, lds, q2, q1);
+  if (threadIdx.x == 0) {
+    partials[(size_t)blockIdx.x * 2] = q1;
+    partials[(size_t)blockIdx.x * 2 + 1] = q2;
+  }
+  if (gridDim.x == 1) {
+    if (threadIdx.x == 0) publish_flag(fin.flag, fin.seq);
+    return;
+  }
+  finish_round<2>(fin, partials, lds);
+}
+
 // ------------------------------------------------------------------ small / medium rounds: LDS-staged
 // The late rounds of every sum-check (and whole GKR layers near the root) are latency-bound: few pairs,
 // but one thread walking a whole term is a chain of ~15 dependent field multiplications (~1 us each
@@ -668,33 +738,46 @@ void k_pair_sums(Ctx& c, const Fr* in, size_t n_out, Fr* out) {
                      n_out, out);
 }
 
+// workgroups per CU of the entry-per-lane round kernels (grid-stride loops; tuning knob LH_SC_ENTRY_BLOCKS)
+static size_t sc_entry_blocks_per_cu() {
+  static const size_t v = [] {
+    const char* e = getenv("LH_SC_ENTRY_BLOCKS");
+    return e && atoi(e) > 0 ? (size_t)atoi(e) : (size_t)8;
+  }();
+  return v;
+}
+
 // ------------------------------------------------------------------ batch-opening rounds with factored eq tables
 // expression sum_m eq_m(x) * poly_m(x) (pcs/multilinear.rs:182-190): per term and pair one bind (2 multiplications),
 // two products with the term's eq-level entry; the eq tables are neither read in full nor bound (prover.cpp).
 // (the number of terms is a template parameter: an accumulator array indexed by a run-time term count lives in scratch
 // memory - 400 B per lane of spills doubled the kernel's HBM writes)
 template <int M, bool BIND>
-__global__ __launch_bounds__(256) LH_SC_WAVES_ATTR(M <= 4 ? 2 : 3) void sc_round_open_kernel(ScOpenRound rd, size_t size, Fr* __restrict__ partials,
-                                                            ScFinish fin) {
+__global__ __launch_bounds__(256) void sc_round_open_kernel(ScOpenRound rd, size_t size, Fr* __restrict__ partials, ScFinish fin) {
+  // one lane per bound entry (see sc_round_e2_kernel): q_m(0) = sum_b E_m[b] v0 comes from the even lanes, q_m(1) from the
+  // odd ones - no exchange between lanes at all
   __shared__ Fr lds[4];
   constexpr int NQ = 2 * M;
-  Fr acc[NQ];
+  Fr acc[M];
 #pragma unroll
-  for (int k = 0; k < NQ; k++) acc[k] = Fr::zero();
-  for (size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x; b < size; b += (size_t)gridDim.x * blockDim.x) {
+  for (int m = 0; m < M; m++) acc[m] = Fr::zero();
+  const size_t items = 2 * size;
+  const bool odd = threadIdx.x & 1;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < items; i += (size_t)gridDim.x * blockDim.x) {
 #pragma unroll
     for (int m = 0; m < M; m++) {
-      Fr v0, v1;
-      load_pair<BIND>(rd.in[m], rd.out[m], b, rd.r, true, v0, v1);
-      const Fr e = rd.eq_level[m][b];
-      acc[2 * m] = add(acc[2 * m], mul(e, v0));
-      acc[2 * m + 1] = add(acc[2 * m + 1], mul(e, v1));
+      const Fr v = load_entry<BIND>(rd.in[m], rd.out[m], i, rd.r, true);
+      acc[m] = add(acc[m], mul(rd.eq_level[m][i >> 1], v));
     }
   }
 #pragma unroll
-  for (int k = 0; k < NQ; k++) {
-    Fr v = block_reduce_sum(acc[k], lds);
-    if (threadIdx.x == 0) partials[(size_t)blockIdx.x * NQ + k] = v;
+  for (int m = 0; m < M; m++) {
+    Fr q0, q1;
+    reduce_by_parity(acc[m], odd, lds, q0, q1);
+    if (threadIdx.x == 0) {
+      partials[(size_t)blockIdx.x * NQ + 2 * m] = q0;
+      partials[(size_t)blockIdx.x * NQ + 2 * m + 1] = q1;
+    }
   }
   if (gridDim.x == 1) {
     if (threadIdx.x == 0) publish_flag(fin.flag, fin.seq);
@@ -716,7 +799,7 @@ void k_sc_round_open(Ctx& c, const ScOpenRound& rd, bool bind, size_t size, Fr* 
   const uint32_t seq = c.next_seq();
   ArenaScope scope(c.arena);
   out_host = c.round_out(out_host);  // (sharded rounds: the sums stay on the device, prover.cpp)
-  size_t g = std::min<size_t>((size + 255) / 256, (size_t)c.num_cus * 4);
+  size_t g = std::min<size_t>((2 * size + 255) / 256, (size_t)c.num_cus * sc_entry_blocks_per_cu());
   const int nq = 2 * (int)rd.num_terms;
   Fr* partials = g == 1 ? out_host : c.arena.alloc_n<Fr>(g * nq);
   const ScFinish fin = c.finish_for((uint32_t)g, out_host, seq);
@@ -738,31 +821,28 @@ void k_sc_round_open(Ctx& c, const ScOpenRound& rd, bool bind, size_t size, Fr* 
 
 // ------------------------------------------------------------------ grand-product layer over (A, A + 1) tree pairs
 template <int P, bool BIND>
-__global__ __launch_bounds__(256) LH_SC_WAVES_ATTR(2) void sc_round_rw_kernel(ScRwRound rd, size_t size,
-                                                                              Fr* __restrict__ partials, ScFinish fin) {
+__global__ __launch_bounds__(256) void sc_round_rw_kernel(ScRwRound rd, size_t size, Fr* __restrict__ partials, ScFinish fin) {
+  // one lane per bound entry (see sc_round_e2_kernel): odd lanes evaluate X = 1, even lanes X = 2
   __shared__ Fr lds[4];
-  Fr acc0 = Fr::zero(), acc1 = Fr::zero();
-  for (size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x; b < size; b += (size_t)gridDim.x * blockDim.x) {
-    Fr s0 = Fr::zero(), s1 = Fr::zero();
+  Fr acc = Fr::zero();
+  const size_t items = 2 * size;
+  const bool odd = threadIdx.x & 1;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < items; i += (size_t)gridDim.x * blockDim.x) {
+    Fr s = Fr::zero();
 #pragma unroll
-    for (int i = 0; i < P; i++) {
-      Fr v0, v1, w0, w1;
-      load_pair<BIND>(rd.l[i], rd.lo[i], b, rd.rchal, true, v0, v1);
-      load_pair<BIND>(rd.r[i], rd.ro[i], b, rd.rchal, true, w0, w1);
-      const Fr sl = sub(v1, v0), sr = sub(w1, w0);
-      const Fr a1 = add(v1, rd.k[i]), b1 = add(w1, rd.k[i]);   // X = 1
-      const Fr a2 = add(a1, sl), b2 = add(b1, sr);             // X = 2
-      s0 = add(s0, mul(mul(a1, b1), rd.cs[i]));
-      s1 = add(s1, mul(mul(a2, b2), rd.cs[i]));
+    for (int p = 0; p < P; p++) {
+      const Fr a = add(at_lane_point(load_entry<BIND>(rd.l[p], rd.lo[p], i, rd.rchal, true), odd), rd.k[p]);
+      const Fr b = add(at_lane_point(load_entry<BIND>(rd.r[p], rd.ro[p], i, rd.rchal, true), odd), rd.k[p]);
+      s = add(s, mul(mul(a, b), rd.cs[p]));
     }
-    const Fr e = rd.eq_level[b];
-    acc0 = add(acc0, mul(s0, e));
-    acc1 = add(acc1, mul(s1, e));
+    acc = add(acc, mul(s, rd.eq_level[i >> 1]));
   }
-  Fr v = block_reduce_sum(acc0, lds);
-  if (threadIdx.x == 0) partials[(size_t)blockIdx.x * 2] = v;
-  v = block_reduce_sum(acc1, lds);
-  if (threadIdx.x == 0) partials[(size_t)blockIdx.x * 2 + 1] = v;
+  Fr q2, q1;
+  reduce_by_parity(acc, odd, lds, q2, q1);
+  if (threadIdx.x == 0) {
+    partials[(size_t)blockIdx.x * 2] = q1;
+    partials[(size_t)blockIdx.x * 2 + 1] = q2;
+  }
   if (gridDim.x == 1) {
     if (threadIdx.x == 0) publish_flag(fin.flag, fin.seq);
     return;
@@ -784,7 +864,7 @@ void k_sc_round_rw(Ctx& c, const ScRwRound& rd, bool bind, size_t size, Fr* out_
   const uint32_t seq = c.next_seq();
   ArenaScope scope(c.arena);
   out_host = c.round_out(out_host);
-  size_t g = std::min<size_t>((size + 255) / 256, (size_t)c.num_cus * 4);
+  size_t g = std::min<size_t>((2 * size + 255) / 256, (size_t)c.num_cus * sc_entry_blocks_per_cu());
   Fr* partials = g == 1 ? out_host : c.arena.alloc_n<Fr>(g * 2);
   const ScFinish fin = c.finish_for((uint32_t)g, out_host, seq);
   {
@@ -884,6 +964,19 @@ void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, F
     return e ? (size_t)atoll(e) : ((size_t)1 << 17);
   }();
   const uint32_t tp = (rd.num_terms > 1 && size * rd.num_terms <= tp_max) ? rd.num_terms : 1u;
+  if (degree == 2 && rd.eq_level && tp == 1) {
+    // the factored degree-2 rounds (GKR layers, Surge over one table): one lane per bound entry
+    size_t g2 = std::min<size_t>((2 * size + 255) / 256, (size_t)c.num_cus * sc_entry_blocks_per_cu());
+    Fr* partials = g2 == 1 ? evals_host : c.arena.alloc_n<Fr>(g2 * 2);
+    const ScFinish kflag = finish(g2);
+    {
+      ProfScope ps(c, bind ? "sc_round<2,bind>" : "sc_round<2,first>", bytes, muls_pair * (double)size, (double)size);
+      if (bind) hipLaunchKernelGGL((sc_round_e2_kernel<true>), dim3((unsigned)g2), dim3(256), 0, c.stream, a, size, partials, kflag);
+      else hipLaunchKernelGGL((sc_round_e2_kernel<false>), dim3((unsigned)g2), dim3(256), 0, c.stream, a, size, partials, kflag);
+    }
+    c.wait_round(seq);
+    return;
+  }
   size_t g = (size * tp + 255) / 256;
   size_t cap = (size_t)c.num_cus * 4;
   if (g > cap) g = cap;

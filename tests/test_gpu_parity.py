@@ -155,6 +155,15 @@ def test_g1_public_vectors(hl, ctx):
     assert _msm_case(hl, ctx, [P - 2, 1], [G, three_g]) == G          # -2 G + 3 G
 
 
+def test_g1_precompile_vectors_on_the_device(hl, ctx):
+    """EIP-196 ECADD / ECMUL known answers (tests/golden/alt_bn128_vectors.py: points that are not multiples this build
+    computed) through the device MSM: A + B, k P with a 61-bit k (several windows, doublings in the window combine)"""
+    from tests.golden import alt_bn128_vectors as v
+    assert _msm_case(hl, ctx, [1, 1], [v.ECADD_A, v.ECADD_B]) == v.ECADD_C
+    assert _msm_case(hl, ctx, [v.ECMUL_K], [v.ECMUL_P]) == v.ECMUL_Q
+    assert _msm_case(hl, ctx, [v.ECMUL_K, 1, 1], [v.ECMUL_P, v.ECADD_A, v.ECADD_B]) == curve.add(v.ECMUL_Q, v.ECADD_C)
+
+
 def test_msm_u32(hl, ctx, bases_pool):
     rng = random.Random(6)
     n = 512

@@ -56,6 +56,25 @@ def test_pairing_product_bilinear(hl):
     assert o_pair.pairings_product_is_identity(cases[0][0]) and not o_pair.pairings_product_is_identity(cases[2][0])
 
 
+def test_pairing_public_precompile_vectors(hl):
+    """EIP-196 / EIP-197 known answers (tests/golden/alt_bn128_vectors.py) against BOTH pairing implementations - the
+    product's 2-3-2 tower (csrc/pairing.hpp, through lh_pairing_check) and the oracle's flat extension: a positive pairing
+    check over a G2 point that is not the generator, its negative (one G1 point negated; one G2 point replaced), and the
+    ECADD / ECMUL vectors on the oracle's G1 (the device's G1 takes them in test_gpu_parity.py)."""
+    from tests.golden import alt_bn128_vectors as v
+    assert curve.is_on_curve(v.PAIRING_P1) and curve.is_on_curve(v.PAIRING_P2)
+    assert o_pair.g2_is_on_curve(v.PAIRING_Q1) and v.PAIRING_Q2 == o_pair.G2_GEN and v.PAIRING_Q1 != o_pair.G2_GEN
+    good = [(v.PAIRING_P1, v.PAIRING_Q1), (v.PAIRING_P2, v.PAIRING_Q2)]
+    bad_g1 = [(v.PAIRING_P1, v.PAIRING_Q1), (curve.neg(v.PAIRING_P2), v.PAIRING_Q2)]
+    bad_g2 = [(v.PAIRING_P1, v.PAIRING_Q2), (v.PAIRING_P2, v.PAIRING_Q2)]
+    for impl in (hl.pairings_product_is_identity, o_pair.pairings_product_is_identity):
+        assert impl(good) is True
+        assert impl(bad_g1) is False and impl(bad_g2) is False
+    assert curve.add(v.ECADD_A, v.ECADD_B) == v.ECADD_C
+    assert curve.mul(v.ECMUL_P, v.ECMUL_K) == v.ECMUL_Q
+    assert curve.msm([1, 1], [v.ECADD_A, v.ECADD_B]) == v.ECADD_C
+
+
 # ------------------------------------------------------------------ TranscriptRead
 def test_transcript_read_side(hl):
     w = hl.Keccak256Transcript()
