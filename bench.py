@@ -54,6 +54,10 @@ def parse():
                     help="--workload hyperplonk: the circuit's lookup argument: 'logup' (the reference's, a 3-column "
                          "vanilla_plonk_with_lookup circuit) or 'lasso' (north_star's HyperPlonk + Lasso: vanilla gates + "
                          "a 32-bit --table lookup proven by Lasso inside HyperPlonk::prove, the configs[4] stand-in)")
+    ap.add_argument("--circuit", default="vanilla", choices=["vanilla", "keccak"],
+                    help="--workload hyperplonk --lookup lasso: 'keccak' = BASELINE.json configs[4]: Keccak-f[1600] "
+                         "permutations (35013 rows each) packed into 2^log-n rows, every byte XOR / AND a Lasso lookup "
+                         "(halo2-lasso_amd/keccak_circuit.py); 'vanilla' = vanilla gates + one 32-bit --table lookup")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log-n", type=int, default=0, help="force the CPU sample size")
     ap.add_argument("--no-profile", action="store_true")
@@ -273,6 +277,8 @@ def use_native_oracle():
 
 def make_hp_circuit(ctx, k, args, seed=None):
     from halo2_lasso_amd import synthetic
+    if args.lookup == "lasso" and args.circuit == "keccak":
+        return synthetic.keccak_f(ctx, k, seed=seed)
     if args.lookup == "lasso":
         return synthetic.vanilla_plonk_with_lasso(ctx, k, kind=args.table, seed=seed)
     return synthetic.vanilla_plonk_with_lookup(ctx, k, seed=seed)
@@ -289,7 +295,14 @@ def hyperplonk_cpu_baseline(hl, ctx, args, trap, gpu_proof_fn):
         pp = hl.MultilinearKzg.setup(ctx, trap[:k])
         srs = C.create_string_buffer(64 * ((2 << k) - 1))
         hl._check(ctx.lib.lh_srs_download(ctx.h, pp.h, srs))
-        if args.lookup == "lasso":
+        if args.lookup == "lasso" and args.circuit == "keccak":
+            from oracle.pyref import lasso as o_lasso
+            o_info = o_hp.keccak_circuit_info(k, [[]] * 7, [[(8, 1)], [(9, 1)], [(10, 1)]],
+                                              o_lasso.bitwise_table(o_lasso.SUBTABLE_XOR, 1, 16),
+                                              o_lasso.bitwise_table(o_lasso.SUBTABLE_AND, 1, 16))
+            lasso_lookups = [(lk.table.to_c(), lk.output_poly, lk.chunk_polys) for lk in circ.info.lasso_lookups]
+            perm_idx = [8, 9, 10]
+        elif args.lookup == "lasso":
             from oracle.pyref import lasso as o_lasso
             spec = o_lasso.range_table(2, 16) if args.table == "range" else o_lasso.bitwise_table(
                 o_lasso.SUBTABLE_AND if args.table == "and" else o_lasso.SUBTABLE_XOR, 4, 16)
@@ -365,7 +378,12 @@ def main_hyperplonk(args, hdist, dist, rank, local_rank, world):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
             "dtype": "u256 (BN254 Fr/Fq, 8x u32 Montgomery)", "data": "synthetic",
-            "config": {"workload": ("HyperPlonk + Lasso prove (BASELINE configs[4] stand-in), 2^%d rows: vanilla gates on "
+            "config": {"workload": ("HyperPlonk + Lasso prove of a Keccak-f[1600] circuit (BASELINE configs[4]), 2^%d rows: %d "
+                                    "permutations of 24 rounds, 35013 byte-operation rows each, every XOR / AND a Lasso "
+                                    "lookup into a 2^16-entry subtable (15 polys, %d copy constraints)"
+                                    % (k, circ.num_permutations, circ.num_copies))
+                       if args.lookup == "lasso" and args.circuit == "keccak" else
+                       ("HyperPlonk + Lasso prove (BASELINE configs[4] stand-in), 2^%d rows: vanilla gates on "
                                     "half of the rows, a 32-bit %s lookup proven by Lasso inside HyperPlonk::prove on "
                                     "the other half (%d polys, %d copy constraints)"
                                     % (k, args.table.upper(), 7 + len(circ.h_witness), circ.num_copies))

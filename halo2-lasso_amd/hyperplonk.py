@@ -317,3 +317,18 @@ def vanilla_plonk_with_lasso_circuit_info(num_vars, num_instances, preprocess_po
                                [_vanilla_gate(7), q_lookup * (w_o - a)], [], permutations, 4)
     info.lasso_lookups = [LassoLookup(table, 10 + c, [10 + j for j in range(c)])]
     return info
+
+
+def keccak_circuit_info(num_vars, preprocess_polys, permutations, table_xor, table_and):
+    """Keccak-f as a PLONKish circuit whose bitwise operations are Lasso lookups (BASELINE.json configs[4]); layout and
+    row kinds: halo2-lasso_amd/keccak_circuit.py.  polys pi | q_xor q_and q_lin c_x s_x c_y s_y | x y o d_X a_X d_A a_A;
+    two Lasso lookups (one chunk of 2 ub bits each): a_X = T_xor[d_X], a_A = T_and[d_A] on every row."""
+    q_xor, q_and, q_lin, c_x, s_x, c_y, s_y = (ex.Polynomial(1 + i) for i in range(7))
+    x, y, o, d_x, a_x, d_a, a_a = (ex.Polynomial(8 + i) for i in range(7))
+    u, v = c_x + s_x * x, c_y + s_y * y
+    unit = 1 << (table_xor.l // 2)
+    constraints = [q_xor * (d_x - u * unit - v), q_xor * (o - a_x), q_and * (d_a - u * unit - v), q_and * (o - a_a),
+                   q_lin * (o - u - v)]
+    info = PlonkishCircuitInfo(num_vars, [0], preprocess_polys, [7], [0], constraints, [], permutations, 4)
+    info.lasso_lookups = [LassoLookup(table_xor, 12, [11]), LassoLookup(table_and, 14, [13])]
+    return info

@@ -194,6 +194,81 @@ def vanilla_plonk_with_lasso(ctx, k, kind="and", seed=None):
     return circ
 
 
+def keccak_f(ctx, k, w=64, ub=8, rounds=None, seed=None, instances=None, states=None):
+    """BASELINE.json configs[4]: Keccak-f[25 w] permutations (default Keccak-f[1600], 35013 rows each) packed into a
+    circuit of 2^k rows, every XOR / AND of the permutation a Lasso lookup proven inside HyperPlonk::prove
+    (keccak_circuit.py: layout; hyperplonk.keccak_circuit_info: gates).  Random input states; `outputs` holds the
+    permuted states.  15 polys, two Lasso lookups (XOR and AND over units of `ub` bits), ~2 copy constraints per row."""
+    import halo2_lasso_amd as hl
+    from . import keccak_circuit as kc
+    size = 1 << k
+    lib = ctx.lib
+    prog = kc.keccak_program(w, ub, rounds)
+    fit = (size - 2) // prog.num_rows
+    if fit < 1:
+        raise ValueError("a Keccak-f[%d] of %d rounds needs %d rows: 2^%d is too small" % (25 * w, prog.rounds, prog.num_rows, k))
+    B = fit if instances is None else instances
+    rng = np.random.default_rng(4000 + k if seed is None else seed)
+    if states is not None:  # the caller's input states, (B, 25) lanes in FIPS-202 order
+        states = np.asarray(states, dtype=np.uint64)
+        B = states.shape[0]
+    else:
+        states = rng.integers(0, 1 << min(w, 63), size=(B, 25), dtype=np.uint64)
+        if w == 64:
+            states = states * np.uint64(2) + rng.integers(0, 2, size=(B, 25), dtype=np.uint64)
+    col = kc.build_columns(prog, k, states)
+
+    def up(a):
+        return hl.MultilinearPolynomial(ctx, ctx.upload(np.ascontiguousarray(a).tobytes()), k)
+
+    def down(p):
+        return np.frombuffer(p.buf.read(), dtype=np.uint64).reshape(size, 4).copy()
+
+    def fr_of_u64(v):
+        out = hl.MultilinearPolynomial(ctx, ctx.alloc(32 * size), k)
+        staged = ctx.upload(np.ascontiguousarray(v, dtype=np.uint64).tobytes())
+        hl._check(lib.lh_fr_from_u64(ctx.h, staged.ptr, size, out.ptr))
+        ctx.sync()
+        return out
+
+    def fr_of_values(vals):
+        """a column of few distinct field values (python ints mod r) -> host Montgomery limbs"""
+        vals = np.asarray(vals, dtype=object)
+        distinct = sorted(set(int(v) % hl.R_MOD for v in vals))
+        table = np.stack([np.frombuffer(hl.fr_to_bytes(v), dtype=np.uint64) for v in distinct])
+        index = {v: i for i, v in enumerate(distinct)}
+        return table[np.fromiter((index[int(v) % hl.R_MOD] for v in vals), dtype=np.int64, count=len(vals))]
+
+    lin = col.q_lin == 1
+    inv2 = pow(2, hl.R_MOD - 2, hl.R_MOD)
+    s_x = np.where(lin, 0, col.sx).astype(object)
+    s_y = np.where(lin, 0, col.sy).astype(object)
+    for shl in np.unique(col.lin_shl[lin]):
+        s_x[lin & (col.lin_shl == shl)] = 1 << int(shl)
+    for shr in np.unique(col.lin_shr[lin]):
+        s_y[lin & (col.lin_shr == shr)] = pow(inv2, int(shr), hl.R_MOD)
+    h_pre = [fr_of_values(c) for c in (col.q_xor, col.q_and, col.q_lin, col.cx, s_x, col.cy, s_y)]
+    d_wit = [fr_of_u64(c) for c in (col.x, col.y, col.o, col.d_xor, col.a_xor, col.d_and, col.a_and)]
+    d_perm = [fr_of_u64((col.perm_col[c].astype(np.uint64) << np.uint64(k)) + col.perm_row[c].astype(np.uint64)) for c in range(3)]
+    unit_bits = 2 * ub
+    t_xor, t_and = hl.LassoTable.bitwise(hl.SUBTABLE_XOR, 1, unit_bits), hl.LassoTable.bitwise(hl.SUBTABLE_AND, 1, unit_bits)
+
+    circ = SyntheticCircuit()
+    circ.k, circ.columns, circ.program, circ.states, circ.outputs = k, col, prog, states, col.outputs
+    circ.num_copies = int(sum(((col.perm_row[c] != np.arange(size)) | (col.perm_col[c] != c)).sum() for c in range(3)))
+    circ.num_lookups = int(col.q_xor.sum() + col.q_and.sum())
+    circ.num_permutations, circ.rows_per_permutation, circ.lane_bits, circ.unit_bits = B, prog.num_rows, w, ub
+    circ.tables = (t_xor, t_and)
+    circ.info = hp.keccak_circuit_info(k, [[]] * 7, [[(8, 1)], [(9, 1)], [(10, 1)]], t_xor, t_and)
+    circ.h_preprocess = h_pre
+    circ.d_preprocess = [up(a) for a in h_pre]
+    circ.d_permutation = d_perm
+    circ.d_witness = d_wit
+    circ.h_witness = [down(d) for d in d_wit]
+    circ.instances = [[]]
+    return circ
+
+
 def prover_param(pcs_pp, circuit, pcs_vp=None):
     """HyperPlonk.preprocess for a SyntheticCircuit whose polys already live on the device -> pp or (pp, vp)"""
     import halo2_lasso_amd as hl

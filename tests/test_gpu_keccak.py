@@ -1,0 +1,90 @@
+"""GPU: BASELINE.json configs[4] - Keccak-f as a HyperPlonk circuit whose XOR / AND operations are Lasso lookups
+(halo2-lasso_amd/keccak_circuit.py; gates: hyperplonk.keccak_circuit_info; specification of Lasso inside HyperPlonk:
+oracle/pyref/hyperplonk.py).  Proof bytes against the Python specification at a small size and against the C++ oracle for
+one full Keccak-f[1600] (35013 rows, 2^16-row circuit), then the host verifier."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle.pyref import hyperplonk as o_hp, kzg as o_kzg, lasso as o_lasso
+from oracle.pyref.field import R_MOD as P
+from oracle.pyref.transcript import Keccak256Transcript as OT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("w,ub,rounds,k", [(4, 4, 1, 8), (8, 4, 2, 10)])
+def test_small_keccak_circuit_matches_the_specification(hl, ctx, w, ub, rounds, k):
+    from halo2_lasso_amd import hyperplonk as g_hp, keccak_circuit as kc
+    prog = kc.keccak_program(w, ub, rounds)
+    rng = np.random.default_rng(k)
+    col = kc.build_columns(prog, k, rng.integers(0, 1 << w, size=((1 << k) // prog.num_rows, 25), dtype=np.uint64))
+    pre, wit = kc.field_columns(col)
+    cycles = kc.copy_cycles(col)
+    o_info = o_hp.keccak_circuit_info(k, pre, cycles, o_lasso.bitwise_table(o_lasso.SUBTABLE_XOR, 1, 2 * ub),
+                                      o_lasso.bitwise_table(o_lasso.SUBTABLE_AND, 1, 2 * ub))
+    g_info = g_hp.keccak_circuit_info(k, pre, cycles, hl.LassoTable.bitwise(hl.SUBTABLE_XOR, 1, 2 * ub),
+                                      hl.LassoTable.bitwise(hl.SUBTABLE_AND, 1, 2 * ub))
+    prng = random.Random(900 + k)
+    ss = [prng.randrange(1, P) for _ in range(k)]
+    o_pp = o_hp.preprocess(o_kzg.setup(ss), o_info)
+    ot = OT()
+    o_hp.prove(o_pp, [[]], lambda r, ch: wit, ot)
+    g_pp, g_vp = g_hp.HyperPlonk.preprocess(hl.MultilinearKzg.setup(ctx, ss), g_info, hl.MultilinearKzgVerifierParams.setup(ss))
+    t = hl.Keccak256Transcript()
+    g_hp.HyperPlonk.prove(g_pp, [[]], [hl.MultilinearPolynomial.new(ctx, x) for x in wit], t)
+    proof = t.into_proof()
+    assert proof == ot.into_proof()
+    o_hp.verify(o_pp, [[]], OT(proof))
+    g_hp.HyperPlonk.verify(g_vp, [[]], hl.Keccak256Transcript.from_proof(proof))
+    # a result unit that is not the table's value (result cell and lookup output flipped together: the gate still holds)
+    bad = [list(x) for x in wit]
+    row = int(np.nonzero(col.q_xor)[0][7])
+    bad[2][row] ^= 1
+    bad[4][row] ^= 1
+    with pytest.raises(hl.InvalidSnark, match="Invalid lookup input"):
+        g_hp.HyperPlonk.prove(g_pp, [[]], [hl.MultilinearPolynomial.new(ctx, x) for x in bad], hl.Keccak256Transcript())
+
+
+def test_keccak_f_1600_circuit_matches_cpp_oracle(hl, ctx):
+    """one full Keccak-f[1600] - 24 rounds, 35013 rows of byte operations: 17536 XOR and 17477 AND / rotation rows, two
+    Lasso lookups into the 2^16-entry XOR and AND subtables - in a 2^16-row circuit built on the device
+    (synthetic.keccak_f): proof bytes against the C++ oracle, the permuted state against hashlib's SHA3-256, the host
+    verifier."""
+    import ctypes as C
+    import hashlib
+    from halo2_lasso_amd import hyperplonk as g_hp, synthetic
+    from oracle import cpu_oracle as co
+    k = 16
+    prng = random.Random(1600)
+    ss = [prng.randrange(1, P) for _ in range(k)]
+    pcs = hl.MultilinearKzg.setup(ctx, ss)
+    circ = synthetic.keccak_f(ctx, k, seed=16)
+    assert circ.num_permutations == 1 and circ.rows_per_permutation == 35013
+    # the circuit's permutation is the one SHA-3 uses: absorb a message into a state by hand and compare the digest
+    msg = bytes(range(100))
+    block = bytearray(msg + b"\x06" + bytes(136 - len(msg) - 2) + b"\x80")
+    state = np.zeros((1, 25), dtype=np.uint64)
+    for i in range(17):
+        state[0, i] = int.from_bytes(block[8 * i:8 * i + 8], "little")
+    sha = synthetic.keccak_f(ctx, k, seed=16, states=state)
+    digest = b"".join(int(v).to_bytes(8, "little") for v in sha.outputs[0][:4])
+    assert digest == hashlib.sha3_256(msg).digest()
+    pp, vp = synthetic.prover_param(pcs, circ, hl.MultilinearKzgVerifierParams.setup(ss))
+    t = hl.Keccak256Transcript()
+    g_hp.HyperPlonk.prove(pp, circ.instances, circ.d_witness, t)
+    proof = t.into_proof()
+    g_hp.HyperPlonk.verify(vp, circ.instances, hl.Keccak256Transcript.from_proof(proof))
+    # the C++ oracle on the same polys
+    srs = C.create_string_buffer(64 * ((2 << k) - 1))
+    hl._check(ctx.lib.lh_srs_download(ctx.h, pcs.h, srs))
+    o_info = o_hp.keccak_circuit_info(k, [[]] * 7, [[(8, 1)], [(9, 1)], [(10, 1)]],
+                                      o_lasso.bitwise_table(o_lasso.SUBTABLE_XOR, 1, 16), o_lasso.bitwise_table(o_lasso.SUBTABLE_AND, 1, 16))
+    num_z, expression = o_hp.compose(o_info)
+    lasso_lookups = [(lk.table.to_c(), lk.output_poly, lk.chunk_polys) for lk in circ.info.lasso_lookups]
+    ot = co.Transcript()
+    co.hyperplonk_prove(ot, srs, k, k, [0], [a.tobytes() for a in circ.h_preprocess], len(circ.h_witness), 0, [], [8, 9, 10],
+                        [p.buf.read() for p in circ.d_permutation], num_z, co.flatten_expression(expression), [[]],
+                        [a.tobytes() for a in circ.h_witness], lasso_lookups=lasso_lookups)
+    assert proof == ot.into_proof()
