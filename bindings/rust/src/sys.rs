@@ -149,6 +149,25 @@ pub struct lh_hp_circuit {
     pub synthesize: Option<unsafe extern "C" fn(*mut c_void, usize, *const Fr, usize, *mut *const c_void, usize) -> c_int>,
 }
 
+/// lh_lasso_route (include/lasso_hip.h): which routes the last Lasso prove on a ctx took
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct lh_lasso_route {
+    pub open_small_depth: u32,
+    pub open_small_passes: u32,
+    pub eq_factored_rounds: u32,
+    pub standard_rounds: u32,
+    pub rw_leaf_rounds: u32,
+    pub resident_tails: u32,
+    pub resident_rounds: u32,
+    pub packed_ts_pairs: u32,
+    pub derived_commitments: u32,
+    pub sorted_dim_reuse: u32,
+    pub sharded_rounds: u32,
+    pub shard_exchanges: u32,
+    pub reserved: [u32; 4],
+}
+
 extern "C" {
     pub fn lh_last_error() -> *const c_char;
     pub fn lh_version() -> *const c_char;
@@ -216,7 +235,12 @@ extern "C" {
     pub fn lh_ctx_set_comm(ctx: *mut lh_ctx, comm: *const lh_comm, shard_bit: usize) -> lh_status;
     pub fn lh_rccl_unique_id(out: *mut u8) -> lh_status;
     pub fn lh_ctx_set_comm_rccl(ctx: *mut lh_ctx, rank: c_int, size: c_int, unique_id: *const u8, shard_bit: usize) -> lh_status;
+    pub fn lh_ctx_set_comm_loopback(ctx: *mut lh_ctx, rank: c_int, size: c_int, shard_bit: usize) -> lh_status;
     pub fn lh_ctx_comm_stats(ctx: *mut lh_ctx, out: *mut u64) -> lh_status;
+    // route options (include/lasso_hip.h lists the names) and the route the last Lasso prove took
+    pub fn lh_ctx_set_option(ctx: *mut lh_ctx, name: *const c_char, value: i64) -> lh_status;
+    pub fn lh_ctx_get_option(ctx: *mut lh_ctx, name: *const c_char, out: *mut i64) -> lh_status;
+    pub fn lh_lasso_last_route(ctx: *mut lh_ctx, out: *mut lh_lasso_route) -> lh_status;
     pub fn lh_lasso_prove_sharded(ctx: *mut lh_ctx, srs: *const lh_srs, table: *const lh_lasso_table, num_vars: usize,
                                   d_dims_local: *const *const u32, t: *mut lh_transcript) -> lh_status;
     // HyperPlonk
