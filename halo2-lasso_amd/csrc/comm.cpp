@@ -16,6 +16,7 @@
 //   callbacks (lh_ctx_set_comm) - a caller-supplied host all-gather (gloo in the CPU / one-GPU tests) and optionally a
 //       device all-gather; without the latter device gathers are staged through the host.
 #include <dlfcn.h>
+#include <string.h>
 #include <algorithm>
 #include <rccl/rccl.h>  // types and enums only: every function is resolved with dlsym
 #include <mutex>
@@ -228,7 +229,13 @@ void comm_all_to_all_v(Ctx& c, const void* d_send, const size_t* send_off, const
   size_t total = 0;
   for (size_t p = 0; p < R; p++) total += send_cnt[p] + recv_cnt[p];
   comm_trace(c, "all_to_all_v", total * elem);
-  if (c.rccl_comm) {
+  // LH_COMM_A2A=allgather: stage the personalised exchange through ncclAllGather under RCCL as well (a fallback should
+  // grouped send / recv misbehave on some fabric; R times the traffic)
+  static const bool a2a_by_gather = [] {
+    const char* e = getenv("LH_COMM_A2A");
+    return e && strcmp(e, "allgather") == 0;
+  }();
+  if (c.rccl_comm && !a2a_by_gather) {
     const RcclApi& api = rccl();
     c.comm_stats[0]++;
     // (the segment a rank keeps for itself is a device copy: no self-send)
