@@ -514,14 +514,32 @@ def main():
 
         def give_up():
             # a collective that never completes cannot be caught as an exception: after LH_BENCH_SHARDED_TIMEOUT seconds
-            # (default 240) say what is known on stderr and FAIL the run (the other ranks sit in the same collective;
-            # their timers do the same).  A process with a kernel stuck on the GPU must not report numbers.
+            # (default 240) say what is known and FAIL the run with exit code 3 (the other ranks sit in the same
+            # collective; their timers do the same).  A process with a kernel stuck on the GPU is not trusted with new
+            # measurements: what goes out is the replicas figure taken BEFORE the sharded proof started, marked as a
+            # fallback, next to the error.
             if rank == 0:
-                sys.stderr.write(json.dumps({
-                    "error": "the sharded proof (or an extra object after it) did not complete within "
-                             "LH_BENCH_SHARDED_TIMEOUT seconds", "headline_line_before_the_hang": headline.get("line"),
-                    "replicas_measured_before": replicas}) + "\n")
+                err = ("the sharded proof (or an extra object after it) did not complete within LH_BENCH_SHARDED_TIMEOUT "
+                       "seconds; exit code 3")
+                sys.stderr.write(json.dumps({"error": err, "headline_line_before_the_hang": headline.get("line"),
+                                             "replicas_measured_before": replicas}) + "\n")
                 sys.stderr.flush()
+                if headline.get("line"):
+                    late = dict(headline["line"])
+                    late["extras_error"] = err
+                    late.setdefault("replicas", replicas)
+                    print(json.dumps(late), flush=True)
+                elif replicas is not None:
+                    print(json.dumps({
+                        "metric": "lasso_prove_time_ms", "value": replicas["ms_per_proof"], "unit": "ms", "n_gpus": world,
+                        "steps": max(1, min(args.steps, 3)), "warmup": 1, "ms_per_step": replicas["ms_per_step"],
+                        "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
+                        "dtype": "u256 (BN254 Fr/Fq, 8x u32 Montgomery)", "data": "synthetic",
+                        "config": {"workload": desc % n, "lookups_per_proof": 1 << n, "proofs_per_step": world,
+                                   "pcs": "multilinear KZG (BN254)", "parallelism": "1 proof per GPU"},
+                        "lookups_per_s": replicas["lookups_per_s"],
+                        "mode_fallback": {"ran": "replicas (measured before the sharded proof was started)",
+                                          "sharded_error": err}}), flush=True)
             os._exit(3)
         import threading
         watchdog = threading.Timer(float(os.environ.get("LH_BENCH_SHARDED_TIMEOUT", "240")), give_up)
