@@ -2,7 +2,8 @@
 RCCL on ROCm, "gloo" on CPU for tests).
 
 Two ways to use N GPUs (bench.py --mode):
-* sharded (default): ONE proof split over the ranks (csrc/sharded.cpp).  The data path does not go
+* sharded (default): ONE proof split over the ranks (the single-GPU prover with every table a shard,
+  csrc/lasso.cpp lasso_prove_sharded).  The data path does not go
   through torch: `attach_sharded` gives the prover's context its own RCCL communicator (lh_ctx_set_comm_rccl; the
   128-byte unique id travels over torch.distributed's broadcast) and every exchange is an ncclAllGather on the
   prover's stream.  With the gloo backend (CPU tests, several ranks on one GPU) the same prover runs over a host
