@@ -70,7 +70,7 @@ static const struct {
     {"open_small_min_vars", &Options::open_small_min_vars}, {"open_small_depth", &Options::open_small_depth},
     {"sc_eq_factoring", &Options::sc_eq_factoring},         {"lasso_pack_ts", &Options::lasso_pack_ts},
     {"sc_tail", &Options::sc_tail},                         {"sc_tail_max_len", &Options::sc_tail_max_len},
-    {"shard_exchange_log", &Options::shard_exchange_log},   {"shard_allreduce", &Options::shard_allreduce},
+    {"shard_exchange_log", &Options::shard_exchange_log},
 };
 
 int64_t* Options::find(const char* name) {

@@ -103,7 +103,6 @@ struct Options {
   int64_t sc_tail = 1;                 // 0: one launch per sum-check round all the way down (no resident tail)
   int64_t sc_tail_max_len = 8192;      // longest table that enters the resident tail
   int64_t shard_exchange_log = 17;     // sharded sum-check: the residual tables travel once they hold <= 2^this entries
-  int64_t shard_allreduce = 0;         // sharded rounds: 1 = ncclAllReduce(sum) over u64 lanes of 32-bit limbs
   Options();                           // environment defaults (dev.cpp)
   int64_t* find(const char* name);
 };

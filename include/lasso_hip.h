@@ -257,9 +257,6 @@ lh_status lh_lasso_last_timing(lh_ctx*, double* out_ms);
  *   sc_tail_max_len      8192 longest table (entries) that enters the resident tail
  *   shard_exchange_log   17   sharded proofs: a sum-check goes on replicated once its residual tables hold <= 2^this
  *                             entries together (one all-gather), at the latest when the shard bits reach bit 0
- *   shard_allreduce      0    sharded proofs over RCCL: 1 = a round's partial sums are combined by ONE
- *                             ncclAllReduce(sum) over u64 lanes of 32-bit limbs (the host reduces mod r) instead of
- *                             ncclAllGather + a sum kernel
  * lh_lasso_last_route reports which of these routes the last Lasso prove on the ctx actually took, so that a byte
  * mismatch in the field can be bisected from the outside. */
 lh_status lh_ctx_set_option(lh_ctx*, const char* name, int64_t value);
