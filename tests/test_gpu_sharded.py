@@ -127,8 +127,7 @@ LARGE = [
     # world, kind, c, l, n, shard_bit, xlog: the streaming kernels on shards - eq-factored rounds, the read/write leaf
     # kernel, packed and derived commitments, the column-wise top quotient - checked against the C++ oracle
     (2, "range", 2, 16, 18, 15, None),
-    (4, "and", 4, 16, 18, 14, None),
-    (8, "xor", 4, 16, 20, 13, 0),
+    (8, "xor", 4, 16, 19, 13, 0),
 ]
 
 
