@@ -75,3 +75,86 @@ def test_bench_gpus_n_starts_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only"],
                        env=dict(env, LH_DIST_BACKEND="no-such-backend"), capture_output=True, text=True, timeout=240)
     assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+COUNTERS_WORKER = textwrap.dedent("""
+    # A numpy restatement of the sharded access counters (csrc/lasso.cpp lasso_counters_sharded: partition by address
+    # owner, personalised exchange staged through an all-gather as the callback transports do, rank inside the address
+    # run on the owner, ranks back along the same segments, final counts all-gathered) over gloo, 2 ranks, CPU only.
+    import os, sys, json
+    sys.path.insert(0, %r)
+    import numpy as np
+    import torch
+    from halo2_lasso_amd import dist as hdist
+    rank, _, world = hdist.env_rank()
+    d = hdist.init("gloo")
+    n, l, j = 12, 6, 3
+    rho = world.bit_length() - 1
+    N, M, NL = 1 << n, 1 << l, (1 << n) >> rho
+    rng = np.random.default_rng(12)
+    col = rng.integers(0, M, size=N, dtype=np.int64)
+    col[rng.random(N) < 0.3] = 5                                   # a hot address
+    # reference: the sequential definition (oracle/pyref/lasso.py witness)
+    cnt = np.zeros(M, dtype=np.int64); rts = np.zeros(N, dtype=np.int64)
+    for k, a in enumerate(col):
+        rts[k] = cnt[a]; cnt[a] += 1
+    def shard(v, s):                                               # local index (hi || lo) <-> global (hi, s, lo)
+        return v.reshape(N >> (j + rho), world, 1 << j)[:, s, :].reshape(-1)
+    mine = shard(col, rank)
+    def gather(arr):                                               # rank-major all-gather of equal-size int64 arrays
+        out = [torch.empty(len(arr), dtype=torch.int64) for _ in range(world)]
+        d.all_gather(out, torch.from_numpy(np.ascontiguousarray(arr)))
+        return [o.numpy() for o in out]
+    # k_cs_partition: stable sort by owner = address mod R; send key = (address >> rho) << n | global index
+    li = np.arange(NL, dtype=np.int64)
+    gidx = ((li >> j) << (j + rho)) | (rank << j) | (li & ((1 << j) - 1))
+    owner = mine & (world - 1)
+    sidx = np.argsort(owner, kind="stable")
+    send = ((mine[sidx] >> rho) << n) | gidx[sidx]
+    start = np.searchsorted(owner[sidx], np.arange(world + 1))    # start[o] .. start[o + 1]: the segment for owner o
+    starts = gather(start.astype(np.int64))
+    seg = lambda s, o: int(starts[s][o + 1] - starts[s][o])
+    # forward exchange staged through an all-gather of the whole send buffers
+    all_send = gather(send)
+    recv = np.concatenate([all_send[p][starts[p][rank]:starts[p][rank + 1]] for p in range(world)])
+    # k_cs_rank on the owner: sort by (address, global index); rank inside the run; per-address totals
+    order = np.argsort(recv, kind="stable")
+    skey = recv[order]
+    addr = skey >> n
+    first = np.ones(len(skey), dtype=bool); first[1:] = addr[1:] != addr[:-1]
+    run_start = np.maximum.accumulate(np.where(first, np.arange(len(skey)), 0))
+    ret = np.empty(len(skey), dtype=np.int64)
+    ret[order] = np.arange(len(skey)) - run_start
+    m_loc = max(M >> rho, 1)
+    counts = np.bincount(addr, minlength=m_loc).astype(np.int64)
+    # the way back: owner p's return buffer holds the lookups of ranks 0..me-1 first (recv_max = the common span)
+    recv_max = max(sum(seg(s, o) for s in range(world)) for o in range(world))
+    padded = np.zeros(recv_max, dtype=np.int64); padded[:len(ret)] = ret
+    all_ret = gather(padded)
+    back = np.concatenate([all_ret[p][sum(seg(s, p) for s in range(rank)):][:seg(rank, p)] for p in range(world)])
+    my_rts = np.empty(NL, dtype=np.int64)
+    my_rts[sidx] = back
+    all_counts = np.concatenate(gather(counts))
+    a = np.arange(M)
+    fcs = all_counts[(a & (world - 1)) * m_loc + (a >> rho)]
+    ok = bool((my_rts == shard(rts, rank)).all() and (fcs == cnt).all())
+    print(json.dumps({"rank": rank, "ok": ok}), flush=True)
+    hdist.barrier(d)
+    d.destroy_process_group()
+""") % ROOT
+
+
+def test_sharded_access_counters_algorithm_two_ranks_gloo(tmp_path):
+    """the N > 1 data path's one non-local step - read_ts in the GLOBAL lookup order without any rank holding a whole
+    column - restated in numpy over gloo (CPU, world 2) with the formulas of the device code (global index of a local
+    entry, owner = address mod R, segment offsets of both exchange directions) against the sequential definition"""
+    import json
+    script = tmp_path / "counters_worker.py"
+    script.write_text(COUNTERS_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29583", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    for p in procs:
+        o, err = p.communicate(timeout=240)
+        assert p.returncode == 0, err[-3000:]
+        assert json.loads(o.strip().splitlines()[-1])["ok"] is True
