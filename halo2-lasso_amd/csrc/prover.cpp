@@ -435,11 +435,12 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
         d_part = c.arena.alloc_n<Fr>(16);
         d_all = c.arena.alloc_n<Fr>(16 * R);
       }
-      size_t nvals = (size_t)degree;
+      // (the device buffers hold 16 sums: degree <= 6, at most SC_OPEN_MAX_TERMS = 6 factored terms)
+      const size_t nvals = !ef_on ? (size_t)degree : ef->per_term ? 2 * ef->eqs.size() : (size_t)degree - 1;
+      LH_REQUIRE(nvals >= 1 && nvals <= 16, LH_ERR_ARG, "sharded sum-check: too many partial sums per round");
       c.sc_redirect = d_part;
       try {
         if (ef_on) {
-          nvals = ef->per_term ? 2 * ef->eqs.size() : (size_t)degree - 1;
           ef->add_const = HFr::zero();
           ef->round(cur.data(), dst.data(), dev(r_prev), bind, size, round, (int)nvals, evals_host);
           factored_round = true;
@@ -453,7 +454,6 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
       c.sc_redirect = nullptr;
       c.route.v[RouteStats::SHARDED_ROUNDS]++;
       c.route.v[factored_round ? RouteStats::EF_ROUNDS : RouteStats::STD_ROUNDS]++;
-      LH_REQUIRE(nvals <= 16, LH_ERR_ARG, "sharded sum-check: too many partial sums per round");
       const uint32_t seq = c.next_seq();
       comm_sum_publish(c, d_part, d_all, nvals, evals_host, seq);
       c.wait_flag(seq);
