@@ -496,6 +496,36 @@ def test_lasso_proof_bytes(hl, ctx, srs6, kind, c, l, n):
     o_lasso.verify(opp, spec, n, OT(proof))
 
 
+def _nonlinear_tables(hl, c, l):
+    """a decomposable table whose g is NOT linear in the subtable reads (products of two and three reads, a read used in
+    two terms, a large coefficient): the output column is a field-sized column committed by its own MSM, Surge runs over
+    the alpha read columns with the multi-factor expression, nothing is derived by linearity.
+    memories: identity on every chunk, then XOR and AND on chunk 0 and chunk c - 1."""
+    I, X, A = o_lasso.SUBTABLE_IDENTITY, o_lasso.SUBTABLE_XOR, o_lasso.SUBTABLE_AND
+    memories = [(j, I) for j in range(c)] + [(0, X), (c - 1, A)]
+    g = [(1, (0, c)), (P - 5, (c + 1, 1 % c, 0)), (7, (c,)), (1 << 40, (c - 1, c + 1))]
+    return (o_lasso.TableSpec("nonlinear", c, l, memories, g),
+            hl.LassoTable(c, l, [(j, {I: hl.SUBTABLE_IDENTITY, X: hl.SUBTABLE_XOR, A: hl.SUBTABLE_AND}[k]) for j, k in memories],
+                          [(co, list(f)) for co, f in g]))
+
+
+@pytest.mark.parametrize("c,l,n", [(2, 4, 5), (3, 4, 7), (2, 2, 1), (2, 6, 4)])
+def test_lasso_nonlinear_g_proof_bytes(hl, ctx, srs6, c, l, n):
+    """g with product terms (the shape of Lasso's comparison / equality tables): the branches that linear tables never
+    take - the output column's own commitment, Surge over the read columns, field-element views in the opening"""
+    _, opp, pp = srs6
+    rng = random.Random(zlib.crc32(repr(("nonlinear", c, l, n)).encode()))
+    spec, table = _nonlinear_tables(hl, c, l)
+    dims = [[rng.randrange(1 << l) for _ in range(1 << n)] for _ in range(c)]
+    ot = OT()
+    o_lasso.prove(opp, spec, dims, ot)
+    t = hl.Keccak256Transcript()
+    hl.lasso_prove(pp, table, n, [ctx.upload(array.array("I", d).tobytes()) for d in dims], t)
+    proof = t.into_proof()
+    assert proof == ot.into_proof()
+    o_lasso.verify(opp, spec, n, OT(proof))
+
+
 ZERO_COLUMN_CASES = {
     # identically zero committed columns commit to the identity, which the reference's transcript cannot encode
     # (transcript.rs:172-179): the Lasso argument frames its commitments with an identity mask (lasso.py)

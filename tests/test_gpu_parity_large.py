@@ -79,6 +79,24 @@ def test_lasso_matches_cpp_oracle(hl, ctx, srs17, kind, n, skew):
     hl.lasso_verify(hl.MultilinearKzgVerifierParams.setup(ss), table, n, hl.Keccak256Transcript.from_proof(proof))
 
 
+@pytest.mark.parametrize("n", [14, 17])
+def test_lasso_nonlinear_g_matches_cpp_oracle(hl, ctx, srs17, n):
+    """a table whose g has product terms (test_gpu_parity._nonlinear_tables) at streaming sizes: the output column's
+    full-width MSM, the degree-4 Surge rounds over six read columns, the opening over field-element views"""
+    from test_gpu_parity import _nonlinear_tables
+    ss, pp, flat = srs17
+    spec, table = _nonlinear_tables(hl, 4, 16)
+    rng = np.random.default_rng(1700 + n)
+    dims = _dims(rng, table, n, n == 17)
+    ot = co.Transcript()
+    co.lasso_prove(ot, flat, 17, table.to_c(), n, [d.tobytes() for d in dims])
+    t = hl.Keccak256Transcript()
+    hl.lasso_prove(pp, table, n, [ctx.upload(d.tobytes()) for d in dims], t)
+    proof = t.into_proof()
+    assert proof == ot.into_proof()
+    hl.lasso_verify(hl.MultilinearKzgVerifierParams.setup(ss), table, n, hl.Keccak256Transcript.from_proof(proof))
+
+
 # ------------------------------------------------------------------ a5-a8: both sum-check provers at 2^18
 def _sop_struct(hl, terms, global_eq):
     return hl.SumOfProducts(terms, global_eq=global_eq).to_c()

@@ -32,8 +32,13 @@ WORKER = textwrap.dedent("""
     ss = [rng.randrange(hl.R_MOD) for _ in range(cfg["n"])]
     dims = [[rng.randrange(1 << cfg["l"]) for _ in range(1 << cfg["n"])] for _ in range(cfg["c"])]
     pp = hl.MultilinearKzg.setup(ctx, ss)
-    table = hl.LassoTable.range(cfg["c"], cfg["l"]) if cfg["kind"] == "range" else hl.LassoTable.bitwise(
-        hl.SUBTABLE_AND if cfg["kind"] == "and" else hl.SUBTABLE_XOR, cfg["c"], cfg["l"])
+    if cfg["kind"] == "nonlinear":           # g with product terms (tests/test_gpu_parity.py _nonlinear_tables)
+        sys.path.insert(0, os.path.join(%r, "tests"))
+        from test_gpu_parity import _nonlinear_tables
+        table = _nonlinear_tables(hl, cfg["c"], cfg["l"])[1]
+    else:
+        table = hl.LassoTable.range(cfg["c"], cfg["l"]) if cfg["kind"] == "range" else hl.LassoTable.bitwise(
+            hl.SUBTABLE_AND if cfg["kind"] == "and" else hl.SUBTABLE_XOR, cfg["c"], cfg["l"])
     # every rank holds only its shard of the lookup columns
     d_dims = [ctx.upload(hl.shard_of(np.array(col, dtype=np.uint32), rank, world, cfg["shard_bit"]).tobytes())
               for col in dims]
@@ -48,7 +53,7 @@ WORKER = textwrap.dedent("""
                    "route": hl.lasso_last_route(ctx)}, f)
     hdist.barrier(d)
     d.destroy_process_group()
-""") % ROOT
+""") % (ROOT, ROOT)
 
 
 def _wait_all(procs, timeout, out_prefix):
@@ -96,6 +101,8 @@ CASES = [
     (2, "range", 2, 3, 9, 5, 0),
     (8, "and", 2, 4, 9, 2, 0),
     (2, "xor", 2, 4, 9, 4, 5),
+    (4, "nonlinear", 2, 4, 8, 2, 0),
+    (2, "nonlinear", 3, 4, 9, 3, None),
 ]
 
 
@@ -114,8 +121,13 @@ def test_sharded_proof_equals_single_gpu_and_oracle(tmp_path, world, kind, c, l,
     rng = random.Random(seed)
     ss = [rng.randrange(R_MOD) for _ in range(n)]
     dims = [[rng.randrange(1 << l) for _ in range(1 << n)] for _ in range(c)]
-    spec = o_lasso.range_table(c, l) if kind == "range" else o_lasso.bitwise_table(
-        o_lasso.SUBTABLE_AND if kind == "and" else o_lasso.SUBTABLE_XOR, c, l)
+    if kind == "nonlinear":
+        import halo2_lasso_amd as hl
+        from test_gpu_parity import _nonlinear_tables
+        spec = _nonlinear_tables(hl, c, l)[0]
+    else:
+        spec = o_lasso.range_table(c, l) if kind == "range" else o_lasso.bitwise_table(
+            o_lasso.SUBTABLE_AND if kind == "and" else o_lasso.SUBTABLE_XOR, c, l)
     ot = OT()
     opp = o_kzg.setup(ss)
     o_lasso.prove(opp, spec, dims, ot)
