@@ -97,6 +97,45 @@ def test_lasso_nonlinear_g_matches_cpp_oracle(hl, ctx, srs17, n):
     hl.lasso_verify(hl.MultilinearKzgVerifierParams.setup(ss), table, n, hl.Keccak256Transcript.from_proof(proof))
 
 
+def test_route_options_change_the_route_not_the_bytes(hl, srs17):
+    """lh_ctx_set_option / lh_lasso_last_route (include/lasso_hip.h): every route switch yields the same proof bytes and
+    the route report shows that the other code ran; unknown names are LH_ERR_ARG"""
+    ss, pp0, flat = srs17
+    n = 17
+    table = hl.LassoTable.range(2, 16)
+    rng = np.random.default_rng(1717)
+    dims = _dims(rng, table, n, False)
+    ot = co.Transcript()
+    co.lasso_prove(ot, flat, 17, table.to_c(), n, [d.tobytes() for d in dims])
+    want = ot.into_proof()
+    ctx = hl.Context(0)                       # options are per ctx: a fresh one, sharing the session SRS (device memory)
+    pp = hl.MultilinearKzgParams(ctx, pp0.h)
+    try:
+        bufs = [ctx.upload(d.tobytes()) for d in dims]
+
+        def prove():
+            t = hl.Keccak256Transcript()
+            hl.lasso_prove(pp, table, n, bufs, t)
+            return t.into_proof(), hl.lasso_last_route(ctx)
+        proof, route = prove()
+        assert proof == want and route["open_small_depth"] >= 1 and route["eq_factored_rounds"] > 0 and route["resident_tails"] > 0
+        assert hl.get_option(ctx, "open_small_min_vars") == 21 and hl.get_option(ctx, "sc_eq_factoring") == 1
+        hl.set_option(ctx, "open_small_min_vars", 64)
+        proof, route = prove()
+        assert proof == want and route["open_small_depth"] == 0 and route["open_small_passes"] == 0
+        hl.set_option(ctx, "sc_eq_factoring", 0)
+        proof, route = prove()
+        assert proof == want and route["eq_factored_rounds"] == 0 and route["rw_leaf_rounds"] == 0 and route["standard_rounds"] > 0
+        hl.set_option(ctx, "sc_tail", 0)
+        hl.set_option(ctx, "lasso_pack_ts", 0)
+        proof, route = prove()
+        assert proof == want and route["resident_tails"] == 0 and route["packed_ts_pairs"] == 0
+        with pytest.raises(hl.Error):
+            hl.set_option(ctx, "no_such_option", 1)
+    finally:
+        pp.h = None                            # the SRS belongs to the session fixture
+
+
 # ------------------------------------------------------------------ a5-a8: both sum-check provers at 2^18
 def _sop_struct(hl, terms, global_eq):
     return hl.SumOfProducts(terms, global_eq=global_eq).to_c()
