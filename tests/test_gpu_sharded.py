@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = textwrap.dedent("""
     import os, sys, json, array, random, faulthandler
-    faulthandler.dump_traceback_later(240, exit=True)   # a hung rank reports where it sits instead of timing the test out
+    faulthandler.dump_traceback_later(900, exit=True)   # a hung rank reports where it sits instead of timing the test out
     sys.path.insert(0, %r)
     import numpy as np
     import halo2_lasso_amd as hl
@@ -88,7 +88,7 @@ def run_ranks(tmp_path, world, cfg, port):
                    LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, str(script), json.dumps(cfg), str(tmp_path / "out")], env=env,
                                       stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True))
-    return _wait_all(procs, 600, str(tmp_path / "out"))
+    return _wait_all(procs, 1000, str(tmp_path / "out"))
 
 
 CASES = [
@@ -176,7 +176,7 @@ def test_sharded_proof_large_vs_cpp_oracle(tmp_path, world, kind, c, l, n, shard
 
 BIG_WORKER = textwrap.dedent("""
     import os, sys, json, hashlib, faulthandler
-    faulthandler.dump_traceback_later(840, exit=True)
+    faulthandler.dump_traceback_later(1700, exit=True)
     sys.path.insert(0, %r)
     import numpy as np
     import halo2_lasso_amd as hl
@@ -211,7 +211,7 @@ def run_big(tmp_path, world, cfg, port):
                    LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, str(script), json.dumps(cfg), str(tmp_path / "out")], env=env,
                                       stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True))
-    return _wait_all(procs, 900, str(tmp_path / "out"))
+    return _wait_all(procs, 1800, str(tmp_path / "out"))
 
 
 @pytest.mark.parametrize("world,kind,n", [(8, "range", 26), (4, "and", 24)])
