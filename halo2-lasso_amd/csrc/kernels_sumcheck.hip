@@ -214,8 +214,19 @@ __device__ __forceinline__ void reduce_by_parity(const Fr& acc, bool odd, Fr* ld
 }
 
 // q(1), q(2) of  sum_b eq_level[b] * sum_m coeff_m prod_k table_{m,k}  (ScRound with eq_level): partials[.][0] = q(1)
+// occupancy hints of the entry-per-lane kernels (waves per SIMD; 0 = the register allocator's choice): A/B knobs at build time
+#ifndef LH_E_WAVES_E2
+#define LH_E_WAVES_E2 0
+#endif
+#ifndef LH_E_WAVES_OPEN
+#define LH_E_WAVES_OPEN 0
+#endif
+#ifndef LH_E_WAVES_RW
+#define LH_E_WAVES_RW 0
+#endif
+#define LH_E_WAVES_ATTR(W) __attribute__((amdgpu_waves_per_eu((W) ? (W) : 1, (W) ? (W) : 8)))
 template <bool BIND>
-__global__ __launch_bounds__(256) void sc_round_e2_kernel(ScArgs a, size_t size, Fr* __restrict__ partials, ScFinish fin) {
+__global__ __launch_bounds__(256) LH_E_WAVES_ATTR(LH_E_WAVES_E2) void sc_round_e2_kernel(ScArgs a, size_t size, Fr* __restrict__ partials, ScFinish fin) {
   __shared__ Fr lds[4];
   const ScRound& rd = a.rd;
   Fr acc = Fr::zero();
@@ -753,7 +764,7 @@ static size_t sc_entry_blocks_per_cu() {
 // (the number of terms is a template parameter: an accumulator array indexed by a run-time term count lives in scratch
 // memory - 400 B per lane of spills doubled the kernel's HBM writes)
 template <int M, bool BIND>
-__global__ __launch_bounds__(256) void sc_round_open_kernel(ScOpenRound rd, size_t size, Fr* __restrict__ partials, ScFinish fin) {
+__global__ __launch_bounds__(256) LH_E_WAVES_ATTR(LH_E_WAVES_OPEN) void sc_round_open_kernel(ScOpenRound rd, size_t size, Fr* __restrict__ partials, ScFinish fin) {
   // one lane per bound entry (see sc_round_e2_kernel): q_m(0) = sum_b E_m[b] v0 comes from the even lanes, q_m(1) from the
   // odd ones - no exchange between lanes at all
   __shared__ Fr lds[4];
@@ -821,7 +832,7 @@ void k_sc_round_open(Ctx& c, const ScOpenRound& rd, bool bind, size_t size, Fr* 
 
 // ------------------------------------------------------------------ grand-product layer over (A, A + 1) tree pairs
 template <int P, bool BIND>
-__global__ __launch_bounds__(256) void sc_round_rw_kernel(ScRwRound rd, size_t size, Fr* __restrict__ partials, ScFinish fin) {
+__global__ __launch_bounds__(256) LH_E_WAVES_ATTR(LH_E_WAVES_RW) void sc_round_rw_kernel(ScRwRound rd, size_t size, Fr* __restrict__ partials, ScFinish fin) {
   // one lane per bound entry (see sc_round_e2_kernel): odd lanes evaluate X = 1, even lanes X = 2
   __shared__ Fr lds[4];
   Fr acc = Fr::zero();
