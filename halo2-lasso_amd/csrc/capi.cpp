@@ -99,6 +99,8 @@ void lh_ctx_destroy(lh_ctx* ctx) {
   if (ctx->c.comm_stage) (void)hipFree(ctx->c.comm_stage);
   if (ctx->c.pinned) (void)hipHostFree(ctx->c.pinned);
   if (ctx->c.stage) (void)hipHostFree(ctx->c.stage);
+  if (ctx->c.sort_stage) (void)hipHostFree(ctx->c.sort_stage);
+  if (ctx->c.sort_ev) (void)hipEventDestroy(ctx->c.sort_ev);
   if (ctx->c.flag) (void)hipHostFree(ctx->c.flag);
   if (ctx->c.ticket) (void)hipFree(ctx->c.ticket);
   (void)hipStreamDestroy(ctx->c.stream);

@@ -161,6 +161,14 @@ struct Ctx {
   // pageable memory makes the runtime pin pages on the fly (hundreds of microseconds for a few KB)
   void* stage = nullptr;
   size_t stage_bytes = 0;
+  // pinned staging of the radix sort's slab descriptors (sort.hip) and the event after their last upload
+  void* sort_stage = nullptr;
+  size_t sort_stage_bytes = 0;
+  hipEvent_t sort_ev = nullptr;
+  hipEvent_t sort_stage_done() {
+    if (!sort_ev) LH_HIP(hipEventCreateWithFlags(&sort_ev, hipEventDisableTiming));
+    return sort_ev;
+  }
   void d2h(void* dst, const void* d_src, size_t bytes);
   void sync() { LH_HIP(hipStreamSynchronize(stream)); }
   // Round-trip fast path: a kernel publishes its (small) result into pinned memory and then stores a
@@ -516,6 +524,23 @@ void k_zm_combine(Ctx&, const Fr* poly, const Fr* q_hat, const Fr* q, size_t num
                   const Fr* q_scalars, Fr* f);
 // out[i] = sum_{j >= i} f_j x^(j - i): out[1..] is the quotient of f by (X - x), out[0] = f(x)
 void k_suffix_horner(Ctx&, const Fr* f, size_t n, const Fr& x, Fr* out);
+
+// ------------------------------------------------------------------ radix sort (sort.hip)
+// stable sort of (u32 key, u32 value) pairs by the low `bits` bits of the key; inputs are preserved
+struct SortSlab {
+  const uint32_t* keys_in;
+  uint32_t* keys_out;
+  const uint32_t* vals_in;
+  uint32_t* vals_out;
+  size_t n;
+  unsigned bits;
+};
+void sort_pairs_u32(Ctx&, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, size_t n,
+                    unsigned bits);
+// `count` independent sorts as ONE launch set per radix pass (temporary storage from the arena: the caller's ArenaScope)
+void sort_pairs_u32_batched(Ctx&, const SortSlab* slabs, size_t count);
+void sort_pairs_u64(Ctx&, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, size_t n,
+                    unsigned bits);
 
 // ------------------------------------------------------------------ MSM (msm.hip)
 struct MsmJob {

@@ -5,7 +5,6 @@
 //                                                               BooleanHypercube order, remap)
 #include <hip/hip_runtime.h>
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
 #include "dev.hpp"
 
 namespace lh {
@@ -79,10 +78,7 @@ bool k_lookup_m(Ctx& c, const Fr* input, const Fr* table, size_t n, Fr* m_out) {
   uint32_t* counts = c.arena.alloc_n<uint32_t>(n + 1);
   LH_HIP(hipMemsetAsync(counts, 0, (n + 1) * sizeof(uint32_t), c.stream));
   hipLaunchKernelGGL(m_keys_kernel, grid_for(n), 256, 0, c.stream, table, n, keys, idx);
-  size_t temp_bytes = 0;
-  LH_HIP(rocprim::radix_sort_pairs(nullptr, temp_bytes, keys, skeys, idx, sidx, n, 0u, 64u, c.stream));
-  void* temp = c.arena.alloc(temp_bytes ? temp_bytes : 256);
-  LH_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keys, skeys, idx, sidx, n, 0u, 64u, c.stream));
+  sort_pairs_u64(c, keys, skeys, idx, sidx, n, 64);  // stable: equal values keep their row order (prover.rs:151)
   hipLaunchKernelGGL(m_probe_kernel, grid_for(n), 256, 0, c.stream, input, table, skeys, sidx, n, counts, counts + n);
   k_fr_from_u32(c, counts, n, m_out);
   uint32_t missing = 0;

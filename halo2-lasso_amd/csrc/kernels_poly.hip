@@ -823,8 +823,6 @@ __device__ __forceinline__ uint32_t subtable_entry(int kind, uint32_t m, uint32_
 // Stable radix sort of (address, lookup index) pairs, then a lookup's rank inside its run of equal addresses is
 // its position minus the run start: O(n) traffic whatever the table size (a tile x address histogram, the
 // obvious counting-sort formulation, moves tiles * m counters - 2 GB per column at 2^24 lookups).
-void sort_pairs_u32(Ctx& c, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
-                    size_t n, unsigned bits);
 __global__ void lasso_iota_kernel(const uint32_t* __restrict__ dim, size_t n, size_t m, uint32_t* __restrict__ out,
                                   uint32_t* __restrict__ bad) {
   GSTRIDE(i, n) {
@@ -875,8 +873,6 @@ void k_lasso_counters(Ctx& c, const uint32_t* dim, size_t n, size_t m, uint32_t*
 
 // ---- access counters of a sharded proof (dev.hpp Shard): the lookups of a column are repartitioned by ADDRESS (owner =
 // address mod R), the owner ranks every lookup of its addresses in the global lookup order, the ranks travel back.
-void sort_pairs_u64(Ctx& c, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
-                    size_t n, unsigned bits);
 __global__ void cs_owner_keys_kernel(const uint32_t* __restrict__ dim, size_t n, size_t m, uint32_t owner_mask,
                                      uint32_t* __restrict__ okey, uint32_t* __restrict__ idx, uint32_t* __restrict__ bad) {
   GSTRIDE(i, n) {

@@ -164,11 +164,6 @@ __global__ void msm_emit_kernel(MsmPlanDev plan, uint32_t* __restrict__ keys, ui
   }
 }
 
-void sort_pairs_u32(Ctx& c, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
-                    size_t n, unsigned bits);
-size_t sort_pairs_u32_temp_bytes(size_t n, unsigned bits);
-void sort_pairs_u32_with(Ctx& c, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
-                         uint32_t* vals_out, size_t n, unsigned bits, void* temp, size_t temp_bytes);
 
 // ------------------------------------------------------------------ 4: segmented accumulate
 // O(1): this runs at every bucket boundary of the accumulate loop, and a wave takes the branch whenever ANY of
@@ -474,7 +469,9 @@ static const int MSM_C_OFF = env_int("LH_MSM_C_OFF", 4), MSM_C_MAX = env_int("LH
                                                     // log_K2(chunks) levels; swept 2..16, 3-4 is best (2^16: 10.1 -> 9.3 ms)
 
 int msm_slab_log() {
-  static const int v = env_int("LH_MSM_SLAB_LOG", 23);
+  // (2^23 while every slab was a library call of its own; the batched sort has no per-slab cost: 2^16, tools sweep in
+  // profiles/README.md round 3)
+  static const int v = env_int("LH_MSM_SLAB_LOG", 16);
   return v;
 }
 
@@ -695,12 +692,10 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
       }
       {
         ProfScope ps(c, "msm_sort", 32.0 * max_entries, 0, (double)max_entries);
-        // small jobs: one sort by the whole key; big jobs: every (job, window) slab by its digit bits only
-        if (small_entries) sort_pairs_u32(c, ukey, skey, uidx, sidx, small_entries, key_bits);
-        size_t temp_bytes = 0;
-        for (size_t j = 0; j < nj; j++)
-          if (slab[j]) temp_bytes = std::max(temp_bytes, sort_pairs_u32_temp_bytes(plan.job[j].n, sort_bits[j]));
-        void* temp = temp_bytes ? c.arena.alloc(temp_bytes) : nullptr;  // the calls run one after another on the stream
+        // small jobs: one sort by the whole key; big jobs: every (job, window) slab by its digit bits only - all of them
+        // as ONE batch of the radix sort (sort.hip): three launches per pass for the whole MSM batch
+        std::vector<SortSlab> sorts;
+        if (small_entries) sorts.push_back(SortSlab{ukey, skey, uidx, sidx, small_entries, key_bits});
         for (size_t j = 0; j < nj; j++) {
           if (!slab[j]) continue;
           const MsmJobDev& jd = plan.job[j];
@@ -713,9 +708,10 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
           }
           for (uint32_t w = 0; w < jd.W; w++) {
             const size_t e = (size_t)jd.entry_base + (size_t)w * jd.n;
-            sort_pairs_u32_with(c, ukey + e, skey + e, uidx + e, sidx + e, jd.n, sort_bits[j], temp, temp_bytes);
+            sorts.push_back(SortSlab{ukey + e, skey + e, uidx + e, sidx + e, jd.n, sort_bits[j]});
           }
         }
+        if (!sorts.empty()) sort_pairs_u32_batched(c, sorts.data(), sorts.size());
       }
 
       // segmented accumulate, level 0 then K-fold shrinking continuation lists
