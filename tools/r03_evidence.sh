@@ -12,6 +12,9 @@ python3 bench.py --log-n 24 --table range --steps 10 --warmup 3 --no-cpu-baselin
 python3 bench.py --log-n 24 --table xor --steps 10 --warmup 3 --no-cpu-baseline --no-inflight > $O/r03_bench_xor_2p24.json 2>> $O/r03_bench.err
 python3 bench.py --workload hyperplonk --log-n 20 > $O/r03_bench_hyperplonk_2p20.json 2>> $O/r03_bench.err
 python3 bench.py --workload hyperplonk --lookup lasso --log-n 20 > $O/r03_bench_hyperplonk_lasso_2p20.json 2>> $O/r03_bench.err
+python3 bench.py --workload hyperplonk --lookup lasso --circuit keccak --log-n 20 > $O/r03_bench_hyperplonk_keccak_2p20.json 2>> $O/r03_bench.err
+for n in 18 22 26; do python3 bench.py --log-n $n --table range --steps 5 --warmup 2 --no-cpu-baseline --no-inflight > $O/r03_bench_range_2p$n.json 2>> $O/r03_bench.err; done
+python3 tools/sharded_rank_profile.py --configs and24,range26 --worlds 1,2,4,8 --out $O/r03_sharded_rank_ms.json > $O/r03_rank.log 2>&1
 # rocprofv3 kernel trace + stats of the default command (the program itself after --: no env / shell hop)
 rm -rf $O/r03_prof_stats
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r03_prof_stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-inflight > $O/r03_prof_stats.log 2>&1
@@ -24,13 +27,9 @@ F=$(find $O/r03_pmcf -name "*counter_collection.csv" | head -1)
 W=$(find $O/r03_pmcw -name "*counter_collection.csv" | head -1)
 python3 tools/pmc_extract.py "$F" "$W" "tools/big_run.py and 24 (setup + 3 Lasso proofs of 2^24 AND lookups)" 3 $O/r03_pmc_and_2p24.json > $O/r03_pmc_extract.log 2>&1
 rm -rf $O/r03_pmcf $O/r03_pmcw $O/r03_prof_stats   # (raw traces are large; the summaries stay)
-# when a sharded sum-check's residual tables travel: per-rank time at world 8
-for x in 15 19; do
-  LH_SHARD_EXCHANGE_LOG=$x python3 tools/sharded_rank_profile.py --configs and24 --worlds 8 --out $O/r03_rank_x$x.json > $O/r03_rank_x$x.log 2>&1
-done
-tail -2 $O/r03_rank_x15.log $O/r03_rank_x19.log
-for f in r03_bench_and_2p24 r03_bench_2p20 r03_bench_2p16 r03_bench_range_2p24 r03_bench_xor_2p24 r03_bench_hyperplonk_2p20 r03_bench_hyperplonk_lasso_2p20; do
+for f in r03_bench_and_2p24 r03_bench_2p20 r03_bench_2p16 r03_bench_range_2p18 r03_bench_range_2p22 r03_bench_range_2p24 r03_bench_range_2p26 r03_bench_xor_2p24 r03_bench_hyperplonk_2p20 r03_bench_hyperplonk_lasso_2p20 r03_bench_hyperplonk_keccak_2p20; do
   python3 -c "import json,sys; d=json.load(open('$O/$f.json')); print('$f', d['value'], d.get('cpu_baseline',{}).get('value'), d.get('cpu_baseline',{}).get('proof_bytes_equal_gpu'))"
 done
 head -5 $O/r03_rocprof_kernel_stats.csv
 tail -3 $O/r03_pmc_extract.log
+tail -n 9 $O/r03_rank.log
