@@ -99,8 +99,16 @@ void lh_ctx_destroy(lh_ctx* ctx) {
   if (ctx->c.comm_stage) (void)hipFree(ctx->c.comm_stage);
   if (ctx->c.pinned) (void)hipHostFree(ctx->c.pinned);
   if (ctx->c.stage) (void)hipHostFree(ctx->c.stage);
-  if (ctx->c.sort_stage) (void)hipHostFree(ctx->c.sort_stage);
-  if (ctx->c.sort_ev) (void)hipEventDestroy(ctx->c.sort_ev);
+  for (int k = 0; k < 2; k++) {
+    if (ctx->c.sort_stage[k]) (void)hipHostFree(ctx->c.sort_stage[k]);
+    if (ctx->c.sort_ev[k]) (void)hipEventDestroy(ctx->c.sort_ev[k]);
+  }
+  if (ctx->c.stream2) {
+    (void)hipStreamSynchronize(ctx->c.stream2);
+    (void)hipStreamDestroy(ctx->c.stream2);
+    (void)hipEventDestroy(ctx->c.fork_ev);
+    (void)hipEventDestroy(ctx->c.join_ev);
+  }
   if (ctx->c.flag) (void)hipHostFree(ctx->c.flag);
   if (ctx->c.ticket) (void)hipFree(ctx->c.ticket);
   (void)hipStreamDestroy(ctx->c.stream);

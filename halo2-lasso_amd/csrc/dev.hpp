@@ -162,12 +162,24 @@ struct Ctx {
   void* stage = nullptr;
   size_t stage_bytes = 0;
   // pinned staging of the radix sort's slab descriptors (sort.hip) and the event after their last upload
-  void* sort_stage = nullptr;
-  size_t sort_stage_bytes = 0;
-  hipEvent_t sort_ev = nullptr;
-  hipEvent_t sort_stage_done() {
-    if (!sort_ev) LH_HIP(hipEventCreateWithFlags(&sort_ev, hipEventDisableTiming));
-    return sort_ev;
+  void* sort_stage[2] = {nullptr, nullptr};
+  size_t sort_stage_bytes[2] = {0, 0};
+  hipEvent_t sort_ev[2] = {nullptr, nullptr};
+  hipEvent_t sort_stage_done(int side) {
+    if (!sort_ev[side]) LH_HIP(hipEventCreateWithFlags(&sort_ev[side], hipEventDisableTiming));
+    return sort_ev[side];
+  }
+  // second stream + fork / join events: memory-bound work of an MSM batch (the sort of the slabs it accumulates last)
+  // beside the ALU-bound accumulation on the main stream (msm.hip)
+  hipStream_t stream2 = nullptr;
+  hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+  hipStream_t second_stream() {
+    if (!stream2) {
+      LH_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+      LH_HIP(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
+      LH_HIP(hipEventCreateWithFlags(&join_ev, hipEventDisableTiming));
+    }
+    return stream2;
   }
   void d2h(void* dst, const void* d_src, size_t bytes);
   void sync() { LH_HIP(hipStreamSynchronize(stream)); }
@@ -538,7 +550,7 @@ struct SortSlab {
 void sort_pairs_u32(Ctx&, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, size_t n,
                     unsigned bits);
 // `count` independent sorts as ONE launch set per radix pass (temporary storage from the arena: the caller's ArenaScope)
-void sort_pairs_u32_batched(Ctx&, const SortSlab* slabs, size_t count);
+void sort_pairs_u32_batched(Ctx&, const SortSlab* slabs, size_t count, int side = 0);  // side 1: on the ctx's second stream
 void sort_pairs_u64(Ctx&, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, size_t n,
                     unsigned bits);
 

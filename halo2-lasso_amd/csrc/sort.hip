@@ -282,9 +282,12 @@ size_t rs_batch_bytes(const RsJob* slabs, size_t count, size_t key_bytes) {
   for (size_t i = 0; i < count; i++) bytes += rs_plan(slabs[i].n, slabs[i].bits, key_bytes).bytes;
   return bytes;
 }
+// `side` (0 / 1): 0 = the ctx's stream; 1 = the ctx's second stream (an MSM batch sorts the slabs it accumulates last on
+// it, beside the accumulation of the first ones); each side has its own pinned descriptor staging
 template <class K>
-void rs_sort_batch(Ctx& c, const RsJob* slabs, size_t count, void* temp) {
+void rs_sort_batch(Ctx& c, const RsJob* slabs, size_t count, void* temp, int side = 0) {
   const size_t key_bytes = sizeof(K);
+  hipStream_t stream = side ? c.second_stream() : c.stream;
   std::vector<RsSlab> host;
   char* cur = (char*)(((uintptr_t)temp + 255) & ~(uintptr_t)255);
   RsSlab* d_slabs = (RsSlab*)cur;
@@ -310,41 +313,41 @@ void rs_sort_batch(Ctx& c, const RsJob* slabs, size_t count, void* temp) {
   // (the descriptors go up through a pinned staging buffer of their own - Ctx::pin holds round messages and MSM tables that
   // may still be in flight; an async copy out of pageable memory would pin pages on the fly)
   const size_t stage_bytes = host.size() * sizeof(RsSlab);
-  if (stage_bytes > c.sort_stage_bytes) {
-    if (c.sort_stage) {
-      LH_HIP(hipStreamSynchronize(c.stream));
-      (void)hipHostFree(c.sort_stage);
-      c.sort_stage = nullptr;
+  if (stage_bytes > c.sort_stage_bytes[side]) {
+    if (c.sort_stage[side]) {
+      LH_HIP(hipStreamSynchronize(stream));
+      (void)hipHostFree(c.sort_stage[side]);
+      c.sort_stage[side] = nullptr;
     }
-    c.sort_stage_bytes = std::max<size_t>(stage_bytes, 16384);
-    LH_HIP(hipHostMalloc(&c.sort_stage, c.sort_stage_bytes, hipHostMallocDefault));
+    c.sort_stage_bytes[side] = std::max<size_t>(stage_bytes, 16384);
+    LH_HIP(hipHostMalloc(&c.sort_stage[side], c.sort_stage_bytes[side], hipHostMallocDefault));
   }
-  RsSlab* stage = (RsSlab*)c.sort_stage;
-  LH_HIP(hipEventSynchronize(c.sort_stage_done()));  // (the previous batch's upload; long done in practice)
+  RsSlab* stage = (RsSlab*)c.sort_stage[side];
+  LH_HIP(hipEventSynchronize(c.sort_stage_done(side)));  // (the previous batch's upload; long done in practice)
   memcpy(stage, host.data(), stage_bytes);
-  LH_HIP(hipMemcpyAsync(d_slabs, stage, host.size() * sizeof(RsSlab), hipMemcpyHostToDevice, c.stream));
+  LH_HIP(hipMemcpyAsync(d_slabs, stage, host.size() * sizeof(RsSlab), hipMemcpyHostToDevice, stream));
   c.opt_in_lds((const void*)rs_scatter_kernel<K>, (int)rs_lds_bytes(8, key_bytes));
   const uint32_t ns = (uint32_t)host.size();
   for (unsigned q = 0; q < max_passes; q++) {
     unsigned rb_max = 1;
     for (const RsSlab& s : host)
       if (q < s.passes) rb_max = std::max(rb_max, s.rb[q]);
-    hipLaunchKernelGGL(rs_hist_kernel<K>, dim3(tiles), dim3(RS_BS), 0, c.stream, d_slabs, ns, q);
-    hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1u << rb_max, ns), dim3(256), 0, c.stream, d_slabs, q);
-    hipLaunchKernelGGL(rs_scatter_kernel<K>, dim3(tiles), dim3(RS_BS), rs_lds_bytes(rb_max, key_bytes), c.stream, d_slabs, ns, q);
+    hipLaunchKernelGGL(rs_hist_kernel<K>, dim3(tiles), dim3(RS_BS), 0, stream, d_slabs, ns, q);
+    hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1u << rb_max, ns), dim3(256), 0, stream, d_slabs, q);
+    hipLaunchKernelGGL(rs_scatter_kernel<K>, dim3(tiles), dim3(RS_BS), rs_lds_bytes(rb_max, key_bytes), stream, d_slabs, ns, q);
   }
   LH_HIP(hipGetLastError());
   // `stage` is reused by the next batch: its copy must have been consumed by then (the sorts themselves stay queued)
-  LH_HIP(hipEventRecord(c.sort_stage_done(), c.stream));
+  LH_HIP(hipEventRecord(c.sort_stage_done(side), stream));
 }
 }  // namespace
 
-void sort_pairs_u32_batched(Ctx& c, const SortSlab* slabs, size_t count) {
+void sort_pairs_u32_batched(Ctx& c, const SortSlab* slabs, size_t count, int side) {
   std::vector<RsJob> jobs(count);
   for (size_t i = 0; i < count; i++)
     jobs[i] = RsJob{slabs[i].keys_in, slabs[i].keys_out, slabs[i].vals_in, slabs[i].vals_out, slabs[i].n, slabs[i].bits};
   void* temp = c.arena.alloc(rs_batch_bytes(jobs.data(), count, 4));  // caller's ArenaScope releases it
-  rs_sort_batch<uint32_t>(c, jobs.data(), count, temp);
+  rs_sort_batch<uint32_t>(c, jobs.data(), count, temp, side);
 }
 
 void sort_pairs_u32(Ctx& c, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
