@@ -8,6 +8,8 @@
 #include <functional>
 #include <memory>
 #include <emmintrin.h>
+#include <hip/hip_ext.h>
+#include <vector>
 #include "dev.hpp"
 
 namespace lh {
@@ -106,6 +108,24 @@ void Ctx::wait_flag(uint32_t seq) {
       if (e != hipErrorNotReady) throw Error(LH_ERR_DEVICE, std::string("stream error: ") + hipGetErrorString(e));
     }
   }
+}
+
+hipStream_t Ctx::second_stream(int cu_share) {
+  if (!stream2) {
+    if (cu_share > 1) {
+      const int words = (num_cus + 31) / 32;
+      std::vector<uint32_t> ma(words, 0), mb(words, 0);
+      for (int cu = 0; cu < num_cus; cu++) (cu % cu_share == 0 ? mb : ma)[cu / 32] |= 1u << (cu % 32);
+      LH_HIP(hipExtStreamCreateWithCUMask(&stream2, words, mb.data()));
+      LH_HIP(hipExtStreamCreateWithCUMask(&stream3, words, ma.data()));
+      LH_HIP(hipEventCreateWithFlags(&join3_ev, hipEventDisableTiming));
+    } else {
+      LH_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+    }
+    LH_HIP(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
+    LH_HIP(hipEventCreateWithFlags(&join_ev, hipEventDisableTiming));
+  }
+  return stream2;
 }
 
 ScFinishArgs Ctx::finish_for(uint32_t grid, Fr* out_host, uint32_t seq) {

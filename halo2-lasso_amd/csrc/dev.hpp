@@ -171,16 +171,10 @@ struct Ctx {
   }
   // second stream + fork / join events: memory-bound work of an MSM batch (the sort of the slabs it accumulates last)
   // beside the ALU-bound accumulation on the main stream (msm.hip)
-  hipStream_t stream2 = nullptr;
-  hipEvent_t fork_ev = nullptr, join_ev = nullptr;
-  hipStream_t second_stream() {
-    if (!stream2) {
-      LH_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
-      LH_HIP(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
-      LH_HIP(hipEventCreateWithFlags(&join_ev, hipEventDisableTiming));
-    }
-    return stream2;
-  }
+  hipStream_t stream2 = nullptr, stream3 = nullptr;  // stream3: the complement CU mask of a masked stream2 (else null)
+  hipEvent_t fork_ev = nullptr, join_ev = nullptr, join3_ev = nullptr;
+  // cu_share > 0: stream2 gets every cu_share-th CU, stream3 the others (hipExtStreamCreateWithCUMask)
+  hipStream_t second_stream(int cu_share = 0);
   void d2h(void* dst, const void* d_src, size_t bytes);
   void sync() { LH_HIP(hipStreamSynchronize(stream)); }
   // Round-trip fast path: a kernel publishes its (small) result into pinned memory and then stores a

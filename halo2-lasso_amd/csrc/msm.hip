@@ -718,7 +718,8 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
         // perfectly (tools/ubench/overlap_mask.hip).  The entries the accumulation reaches first - everything before
         // `e_split`, a slab boundary about 30 % into the stream - are sorted on the main stream; the remaining slabs sort
         // on the ctx's second stream while the first accumulate launch runs, the second launch waits for them.
-        static const bool pipe_on = env_int("LH_MSM_PIPELINE", 1) != 0;
+        static const int pipe_mode = env_int("LH_MSM_PIPELINE", 0);  // 1: two plain streams; k >= 2: every k-th CU for the sorts
+        const bool pipe_on = pipe_mode != 0;
         size_t first_group = sorts.size();
         if (pipe_on && !c.prof && max_entries >= ((size_t)1 << 22)) {
           for (size_t k = 0; k < sorts.size(); k++)
@@ -729,7 +730,7 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
         }
         if (first_group < sorts.size()) {
           e_split = (size_t)(sorts[first_group].keys_in - ukey);
-          hipStream_t s2 = c.second_stream();
+          hipStream_t s2 = c.second_stream(pipe_mode);
           LH_HIP(hipEventRecord(c.fork_ev, c.stream));  // (after the emit and the pre-sorted copies)
           LH_HIP(hipStreamWaitEvent(s2, c.fork_ev, 0));
           sort_pairs_u32_batched(c, sorts.data() + first_group, sorts.size() - first_group, 1);
@@ -753,9 +754,20 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
         ProfScope ps(c, "msm_accumulate0", 96.0 * full_pts + 68.0 * (total_pts - full_pts), 10.0 * h_total, (double)h_total);
       // (two launches when the tail of the stream is still being sorted: chunks that end before e_split first)
       const size_t c1 = e_split ? e_split / K : 0;
-      if (c1)
-        hipLaunchKernelGGL(msm_accumulate0_kernel, dim3((unsigned)std::min<size_t>((c1 + 127) / 128, 1 << 16)), dim3(128), 0,
-                           c.stream, plan, max_entries, skey, sidx, K, buckets, ckey, cpt, (size_t)0, c1, lvl_cnt);
+      if (c1) {
+        // (with CU masks: the first launch on the stream that owns the CUs the sorts do not)
+        hipStream_t sa = c.stream3 ? c.stream3 : c.stream;
+        if (c.stream3) {
+          LH_HIP(hipEventRecord(c.join3_ev, c.stream));
+          LH_HIP(hipStreamWaitEvent(sa, c.join3_ev, 0));
+        }
+        hipLaunchKernelGGL(msm_accumulate0_kernel, dim3((unsigned)std::min<size_t>((c1 + 127) / 128, 1 << 16)), dim3(128), 0, sa,
+                           plan, max_entries, skey, sidx, K, buckets, ckey, cpt, (size_t)0, c1, lvl_cnt);
+        if (c.stream3) {
+          LH_HIP(hipEventRecord(c.join3_ev, sa));
+          LH_HIP(hipStreamWaitEvent(c.stream, c.join3_ev, 0));
+        }
+      }
       if (e_split) LH_HIP(hipStreamWaitEvent(c.stream, c.join_ev, 0));
       hipLaunchKernelGGL(msm_accumulate0_kernel, dim3((unsigned)std::min<size_t>((nchunks - c1 + 127) / 128, 1 << 16)),
                          dim3(128), 0, c.stream, plan, max_entries, skey, sidx, K, buckets, ckey, cpt, c1, nchunks, lvl_cnt);
