@@ -441,8 +441,8 @@ def test_context_used_from_another_thread(hl, ctx):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"LH_SC_TAIL_G": "64"}, {"LH_SC_TAIL_G": "2", "LH_SC_TAIL_MAX_LEN": "16384"},
-                                 {"LH_SC_TAIL": "0"}, {"LH_MSM_SLAB_LOG": "14"},
-                                 {"LH_OPEN_SMALL_MIN_VARS": "2", "LH_MSM_SLAB_LOG": "12"}, {"LH_LASSO_PACK_TS": "0"},
+                                 {"LH_SC_TAIL": "0", "LH_LASSO_PACK_TS": "0", "LH_MSM_SLAB_LOG": "31"},
+                                 {"LH_OPEN_SMALL_MIN_VARS": "2", "LH_MSM_SLAB_LOG": "4", "LH_MSM_PIPELINE": "1"},
                                  {"LH_OPEN_SMALL_MIN_VARS": "2", "LH_OPEN_SMALL_DEPTH": "2", "LH_OPEN_SMALL_CHECK": "1"}])
 def test_small_parity_suite_under_forced_shapes(env):
     """The byte-parity tests of test_gpu_parity.py / test_gpu_golden.py again in a child process with the shape

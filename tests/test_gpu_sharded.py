@@ -139,7 +139,7 @@ LARGE = [
     # world, kind, c, l, n, shard_bit, xlog: the streaming kernels on shards - eq-factored rounds, the read/write leaf
     # kernel, packed and derived commitments, the column-wise top quotient - checked against the C++ oracle
     (2, "range", 2, 16, 18, 15, None),
-    (8, "xor", 4, 16, 19, 13, 0),
+    (4, "xor", 4, 16, 18, 14, 0),
 ]
 
 
@@ -175,6 +175,8 @@ def test_sharded_proof_large_vs_cpp_oracle(tmp_path, world, kind, c, l, n, shard
 
 
 BIG_WORKER = textwrap.dedent("""
+    import time
+    T0 = time.time()
     import os, sys, json, hashlib, faulthandler
     faulthandler.dump_traceback_later(1700, exit=True)
     sys.path.insert(0, %r)
@@ -190,13 +192,16 @@ BIG_WORKER = textwrap.dedent("""
     n = cfg["n"]
     pp = hl.MultilinearKzg.setup(ctx, bench.trapdoor(n))
     d_dims = [ctx.upload(hl.shard_of(col, rank, world, cfg["shard_bit"]).tobytes()) for col in bench.gen_dims(table, n, 0)]
+    import time
+    t_ready = time.time()
     hl.attach_comm(ctx, rank, world, hdist.host_all_gather(d), cfg["shard_bit"])
     t = hl.Keccak256Transcript()
     hl.lasso_prove_sharded(pp, table, n, d_dims, t)
     proof = t.into_proof()
     with open(sys.argv[2] + ".%%d" %% rank, "w") as f:
         json.dump({"rank": rank, "sha256": hashlib.sha256(proof).hexdigest(), "bytes": len(proof), "stats": hl.comm_stats(ctx),
-                   "route": hl.lasso_last_route(ctx), "phases": hl.lasso_last_timing(ctx)}, f)
+                   "route": hl.lasso_last_route(ctx), "phases": hl.lasso_last_timing(ctx),
+                   "seconds": {"start_to_ready": t_ready - T0, "prove": time.time() - t_ready}}, f)
     hdist.barrier(d)
     d.destroy_process_group()
 """) % ROOT
@@ -234,6 +239,7 @@ def test_full_size_configs_sharded_on_one_gpu(tmp_path, hl, ctx, world, kind, n)
     del full, pp
     outs = run_big(tmp_path, world, dict(kind=kind, n=n, shard_bit=shard_bit), 29480 + world + n)
     want = hashlib.sha256(single).hexdigest()
+    print("ranks: seconds", outs[0]["seconds"], "phases ms", {k: round(v) for k, v in outs[0]["phases"].items()})
     for o in outs:
         assert o["bytes"] == len(single) and o["sha256"] == want, "rank %d: the sharded proof differs" % o["rank"]
         r = o["route"]
