@@ -195,6 +195,8 @@ BIG_WORKER = textwrap.dedent("""
     import time
     t_ready = time.time()
     hl.attach_comm(ctx, rank, world, hdist.host_all_gather(d), cfg["shard_bit"])
+    if "xlog" in cfg:
+        hl.set_option(ctx, "shard_exchange_log", cfg["xlog"])
     t = hl.Keccak256Transcript()
     hl.lasso_prove_sharded(pp, table, n, d_dims, t)
     proof = t.into_proof()
@@ -237,7 +239,9 @@ def test_full_size_configs_sharded_on_one_gpu(tmp_path, hl, ctx, world, kind, n)
     hl.lasso_prove(pp, table, n, full, t)
     single = t.into_proof()
     del full, pp
-    outs = run_big(tmp_path, world, dict(kind=kind, n=n, shard_bit=shard_bit), 29480 + world + n)
+    # (ranks that share one GPU pay ~0.5 s of GPU process switching per collective: the residual tables travel a little
+    # earlier than by default - fewer sharded rounds - which changes no byte)
+    outs = run_big(tmp_path, world, dict(kind=kind, n=n, shard_bit=shard_bit, xlog=20), 29480 + world + n)
     want = hashlib.sha256(single).hexdigest()
     print("ranks: seconds", outs[0]["seconds"], "phases ms", {k: round(v) for k, v in outs[0]["phases"].items()})
     for o in outs:
