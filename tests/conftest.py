@@ -1,5 +1,6 @@
 import os
 import sys
+import time
 
 import pytest
 
@@ -8,8 +9,50 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The round-end GPU run gives the whole `-m gpu` suite 1200 s and boxes differ (the same suite took 370 s on one box
+# and several times that on another, the multi-process tests - N ranks sharing the one GPU - most of all).  Tests
+# marked `heavy(est=seconds on a normal box)` run LAST, cheapest first, and skip themselves - with the reason - when the
+# time already spent plus their own estimate, scaled by how much slower than estimated the heavy tests before them ran,
+# would not fit LH_TEST_BUDGET_S (default 900 s; 0 disables the check).  On a normal box nothing is skipped.
+SESSION_T0 = time.time()
+BUDGET_S = float(os.environ.get("LH_TEST_BUDGET_S", "900"))
+_ratios = []
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "heavy(est): a long test (est = seconds on a normal box): runs last, skips when "
+                                       "the session's time budget (LH_TEST_BUDGET_S) would be exceeded")
+
+
+def _est(item):
+    m = item.get_closest_marker("heavy")
+    return None if m is None else float(m.kwargs.get("est", m.args[0] if m.args else 60))
+
+
+def pytest_collection_modifyitems(config, items):
+    items.sort(key=lambda it: (0, 0.0) if _est(it) is None else (1, _est(it)))  # stable: everything else keeps its order
+
+
+def slow_factor():
+    """How much slower than estimated the last heavy tests ran (>= 1)."""
+    return max([1.0] + _ratios[-4:])
+
+
+@pytest.fixture(autouse=True)
+def _time_budget(request):
+    est = _est(request.node)
+    if est is None:
+        yield
+        return
+    elapsed = time.time() - SESSION_T0
+    want = est * slow_factor() * 1.25
+    if BUDGET_S > 0 and elapsed + want > BUDGET_S:
+        pytest.skip("time budget: %.0f s into the session, this test needs ~%.0f s here (estimate %.0f s x %.1f), budget "
+                    "%.0f s (LH_TEST_BUDGET_S)" % (elapsed, want, est, slow_factor(), BUDGET_S))
+    t0 = time.time()
+    yield
+    _ratios.append(min(max((time.time() - t0) / est, 0.25), 20.0))
 
 
 @pytest.fixture(scope="session")

@@ -134,6 +134,7 @@ def test_monomial_fallback_path_still_matches_golden():
     assert m and int(m.group(1)) >= 15, r.stdout[-500:]
 
 
+@pytest.mark.heavy(est=45)
 def test_runtime_compiled_round_kernel_matches_golden():
     """Large general-expression sum-checks run the register program as straight-line code compiled at run time
     (csrc/jit.cpp; by default from 2^16 rows).  LH_EXPR_JIT_MIN_VARS=1 selects it for every size: the golden and

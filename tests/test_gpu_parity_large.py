@@ -337,6 +337,7 @@ def srs22(hl, ctx):
     return ss, pp, pp.eqs_bytes()
 
 
+@pytest.mark.heavy(est=10)
 @pytest.mark.parametrize("kind,n", [("and", 21), ("xor", 21), ("range", 22)])
 def test_lasso_default_route_at_2p21_matches_cpp_oracle(hl, ctx, srs22, kind, n):
     """The route the 2^24 headline proof takes switches on at 2^21 lookups: the largest quotient(s) of the opening are
@@ -362,16 +363,22 @@ def test_lasso_default_route_at_2p21_matches_cpp_oracle(hl, ctx, srs22, kind, n)
 
 
 # ------------------------------------------------------------------ BASELINE.json configs[2]
-def test_lasso_2p24_and_prove_verify(hl, ctx):
-    """2^24 AND lookups (32-bit operands, 4 chunks of 8+8 bits) on one GPU: the proof verifies, is deterministic, and a
-    flipped lookup index changes it.  (Bytes against the oracle at this size are checked by bench.py's cpu_baseline
-    on the largest sample that fits its time bound.)"""
+@pytest.mark.parametrize("kind", ["and", pytest.param("xor", marks=pytest.mark.heavy(est=8))])
+def test_lasso_2p24_and_prove_verify(hl, ctx, kind):
+    """2^24 AND / XOR lookups (32-bit operands, 4 chunks of 8+8 bits) on one GPU: the proof verifies, is deterministic,
+    and a flipped lookup index changes it.  (Bytes against the oracle at this size are checked by bench.py's cpu_baseline
+    on the largest sample that fits its time bound; the XOR columns are skewed - a quarter of the lookups hit 16 cells -
+    so the access counts are wide and the packed read_ts pairs take their large-bucket shape.)"""
     n = 24
-    table = hl.LassoTable.bitwise(hl.SUBTABLE_AND, 4, 16)
+    table = hl.LassoTable.bitwise(hl.SUBTABLE_AND if kind == "and" else hl.SUBTABLE_XOR, 4, 16)
     ss = trapdoor(n, 2400)
     pp = hl.MultilinearKzg.setup(ctx, ss)
     rng = np.random.default_rng(24)
     dims = [rng.integers(0, 1 << 16, size=1 << n, dtype=np.uint32) for _ in range(4)]
+    if kind == "xor":
+        for d in dims:
+            hot = rng.random(1 << n) < 0.25
+            d[hot] = rng.integers(0, 16, size=int(hot.sum()), dtype=np.uint32) * 4099 % (1 << 16)
     bufs = [ctx.upload(d.tobytes()) for d in dims]
     proofs = []
     for _ in range(2):
@@ -440,6 +447,7 @@ def test_context_used_from_another_thread(hl, ctx):
 
 
 @pytest.mark.gpu
+@pytest.mark.heavy(est=7)
 @pytest.mark.parametrize("env", [{"LH_SC_TAIL_G": "64"}, {"LH_SC_TAIL_G": "2", "LH_SC_TAIL_MAX_LEN": "16384"},
                                  {"LH_SC_TAIL": "0", "LH_LASSO_PACK_TS": "0", "LH_MSM_SLAB_LOG": "31"},
                                  {"LH_OPEN_SMALL_MIN_VARS": "2", "LH_MSM_SLAB_LOG": "4", "LH_MSM_PIPELINE": "1"},

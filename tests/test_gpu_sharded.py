@@ -138,8 +138,8 @@ def test_sharded_proof_equals_single_gpu_and_oracle(tmp_path, world, kind, c, l,
 LARGE = [
     # world, kind, c, l, n, shard_bit, xlog: the streaming kernels on shards - eq-factored rounds, the read/write leaf
     # kernel, packed and derived commitments, the column-wise top quotient - checked against the C++ oracle
-    (2, "range", 2, 16, 18, 15, None),
-    (4, "xor", 4, 16, 18, 14, 0),
+    pytest.param(2, "range", 2, 16, 18, 15, None, marks=pytest.mark.heavy(est=8)),
+    pytest.param(4, "xor", 4, 16, 18, 14, 0, marks=pytest.mark.heavy(est=25)),
 ]
 
 
@@ -221,7 +221,8 @@ def run_big(tmp_path, world, cfg, port):
     return _wait_all(procs, 1800, str(tmp_path / "out"))
 
 
-@pytest.mark.parametrize("world,kind,n", [(8, "range", 26), (4, "and", 24)])
+@pytest.mark.parametrize("world,kind,n", [pytest.param(8, "range", 26, marks=pytest.mark.heavy(est=95)),
+                                           pytest.param(4, "and", 24, marks=pytest.mark.heavy(est=30))])
 def test_full_size_configs_sharded_on_one_gpu(tmp_path, hl, ctx, world, kind, n):
     """BASELINE.json configs[3] at FULL size - 2^26 range-check lookups, one proof sharded over 8 ranks - and configs[2]
     (2^24 AND) over 4 ranks, the ranks sharing the one GPU of the test box over gloo: every rank's proof is byte for byte
@@ -319,6 +320,7 @@ def test_sharded_two_gpus_over_rccl(tmp_path):
         assert out["same"] and out["stats"]["device"] > 20 and out["stats"]["host"] == 0, out
 
 
+@pytest.mark.heavy(est=10)
 def test_bench_gpus_2_without_a_launcher():
     """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: bench.py starts the two ranks itself (both on GPU 0
     here, rendezvous over gloo) and relays rank 0's line: n_gpus == 2, one sharded proof per step."""
@@ -336,6 +338,7 @@ def test_bench_gpus_2_without_a_launcher():
     assert d["sharded_proof_equals_single_gpu"] is True
 
 
+@pytest.mark.heavy(est=10)
 def test_bench_two_ranks_launched_like_the_driver():
     """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` exactly as the driver launches it,
     except that both ranks share GPU 0 (LH_DEVICE) and rendezvous over gloo: one JSON line, from rank 0; by default
