@@ -165,7 +165,8 @@ pub struct lh_lasso_route {
     pub sorted_dim_reuse: u32,
     pub sharded_rounds: u32,
     pub shard_exchanges: u32,
-    pub reserved: [u32; 4],
+    pub window_table_jobs: u32,
+    pub reserved: [u32; 3],
 }
 
 extern "C" {

@@ -399,6 +399,8 @@ void lh_srs_free(lh_ctx* ctx, lh_srs* srs) {
   if (srs->s.d_eqs) (void)hipFree(srs->s.d_eqs);
   for (G1Affine* p : srs->s.shard_levels)
     if (p) (void)hipFree(p);
+  for (auto& kv : srs->s.win_tables)
+    if (kv.second.d) (void)hipFree(kv.second.d);
   delete srs;
 }
 

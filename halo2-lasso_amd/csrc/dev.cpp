@@ -72,7 +72,7 @@ static const struct {
     {"open_small_min_vars", &Options::open_small_min_vars}, {"open_small_depth", &Options::open_small_depth},
     {"sc_eq_factoring", &Options::sc_eq_factoring},         {"lasso_pack_ts", &Options::lasso_pack_ts},
     {"sc_tail", &Options::sc_tail},                         {"sc_tail_max_len", &Options::sc_tail_max_len},
-    {"shard_exchange_log", &Options::shard_exchange_log},
+    {"shard_exchange_log", &Options::shard_exchange_log},   {"msm_window_tables", &Options::msm_window_tables},
 };
 
 int64_t* Options::find(const char* name) {

@@ -103,13 +103,15 @@ struct Options {
   int64_t sc_tail = 1;                 // 0: one launch per sum-check round all the way down (no resident tail)
   int64_t sc_tail_max_len = 8192;      // longest table that enters the resident tail
   int64_t shard_exchange_log = 17;     // sharded sum-check: the residual tables travel once they hold <= 2^this entries
+  int64_t msm_window_tables = 0;       // SRS levels of <= 2^this points get a window table (MsmJob::win_table) on first use:
+                                       // full-width columns over them reduce ONE bucket set (0: no tables)
   Options();                           // environment defaults (dev.cpp)
   int64_t* find(const char* name);
 };
 struct RouteStats {  // lh_lasso_route (include/lasso_hip.h): counters of the last Lasso prove on the ctx
   uint32_t v[LH_LASSO_ROUTE_WORDS] = {0};
   enum { OPEN_DEPTH, OPEN_PASSES, EF_ROUNDS, STD_ROUNDS, RW_ROUNDS, TAILS, TAIL_ROUNDS, PACKED_TS, DERIVED, SORTED_REUSE,
-         SHARDED_ROUNDS, SHARD_EXCHANGES };
+         SHARDED_ROUNDS, SHARD_EXCHANGES, WIN_TABLE_JOBS };
 };
 
 // ------------------------------------------------------------------ context
@@ -575,8 +577,15 @@ struct MsmJob {
   // Optional: every scalar < 2^known_bits, promised by the caller (0: measured by a pass over the scalars - a column
   // that happens to be narrower then gets fewer windows; a promise that is too small loses the upper bits)
   uint32_t known_bits = 0;
+  // Optional (Fr columns): the window table of `bases` (k_msm_window_table: entry w * n + i = 2^(win_table_c w) * bases[i],
+  // w < win_table_W).  A column that needs 2 .. win_table_W windows of win_table_c bits then files all of them into one
+  // bucket set (one bucket reduction, no doublings) - same sum, W-fold fewer buckets.
+  const G1Affine* win_table = nullptr;
+  uint32_t win_table_c = 0, win_table_W = 0;
 };
 constexpr uint32_t MSM_PACK_MAX_BITS = 20;
+uint32_t msm_window_bits(size_t n);  // window width msm_batch picks for a full-width (254-bit) column of n points
+void k_msm_window_table(Ctx&, const G1Affine* bases, size_t n, uint32_t cbits, uint32_t W, G1Affine* out);
 // Runs all jobs as one batched Pippenger; out[j] is the affine sum (identity = (0,0)).
 void msm_batch(Ctx&, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host);
 int msm_slab_log();  // jobs of >= 2^this points are sorted slab by slab (and can take MsmJob::sorted_*)

@@ -223,7 +223,15 @@ struct Srs {
   // sum of all bases of a level (mkzg_open over small-valued columns), computed on first use
   mutable std::map<size_t, HG1> level_sums;  // (guarded by one process-wide mutex in prover.cpp)
   mutable std::map<size_t, HG1> shard_level_sums;  // the same over this rank's share of a sharded level
+  // window tables of whole levels (dev.hpp MsmJob::win_table; Options::msm_window_tables), built on first use
+  struct WinTable {
+    G1Affine* d = nullptr;
+    uint32_t c = 0, W = 0;
+  };
+  mutable std::map<size_t, WinTable> win_tables;
 };
+// the window table of a level (nullptr: tables are off for this level - Options::msm_window_tables - or do not fit)
+const Srs::WinTable* srs_window_table(Ctx&, const Srs&, size_t level);
 const G1Affine* srs_shard_level(Ctx&, const Srs&, size_t level);  // this rank's share of a level's bases (sharded proofs)
 Srs* mkzg_setup(Ctx&, const HFr* ss, size_t num_vars);
 std::vector<HG1> mkzg_batch_commit(Ctx&, const Srs&, const Fr* const* d_polys, size_t num_polys, size_t num_vars);

@@ -58,6 +58,8 @@ struct MsmJobDev {
   uint32_t red_W;       // windows of the reduction (= W except for packed jobs)
   uint32_t nsplit;      // workgroups (shares) per window in the window-sum kernel
   uint32_t share_base;  // first share (workgroup / output slot) of this job
+  uint32_t merged;      // `bases` is a window table (MsmJob::win_table: entry w * n + i = 2^(c w) * base i): all W windows
+                        // fill ONE bucket set (red_W = 1), the entry's index carries the window
 };
 constexpr uint32_t KEY_BLOCK_BITS = 10;  // every job's key range starts at a multiple of 2^KEY_BLOCK_BITS
 struct MsmPlanDev {
@@ -140,8 +142,8 @@ __global__ void msm_emit_kernel(MsmPlanDev plan, uint32_t* __restrict__ keys, ui
       }
       size_t e = (size_t)jb.entry_base + (size_t)w * jb.n + i;
       // bucket index = digit - 1 (packed jobs: = digit, so that a reduce segment never straddles a change of the high part)
-      keys[e] = jb.key_base + w * jb.win_stride + (jb.pack_shift ? d : (d ? d - 1u : 0u));
-      vals[e] = d ? ((uint32_t)i | neg) : SKIP_IDX;
+      keys[e] = jb.key_base + (jb.merged ? 0u : w * jb.win_stride) + (jb.pack_shift ? d : (d ? d - 1u : 0u));
+      vals[e] = d ? (((uint32_t)i + (jb.merged ? w * jb.n : 0u)) | neg) : SKIP_IDX;
     };
 #pragma unroll
     for (int k = 0; k < 8; k++) {
@@ -595,10 +597,22 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
       // signed digits need one extra bit of head room for the last carry
       jd.W = bits ? ((jd.is_signed ? bits + 1 : bits) + jd.c - 1) / jd.c : 0;
       if (!in.n) jd.W = 0;
+      // window table (MsmJob::win_table): the windows of the table's width share one bucket set
+      jd.merged = 0;
+      if (in.win_table && jd.is_signed && !derived[j] && in.n && in.win_table_c >= 2) {
+        const uint32_t Wt = (bits + 1 + in.win_table_c - 1) / in.win_table_c;
+        if (Wt >= 2 && Wt <= in.win_table_W && (size_t)Wt * in.n < ((size_t)1 << 31)) {
+          jd.merged = 1;
+          c.route.v[RouteStats::WIN_TABLE_JOBS]++;
+          jd.c = in.win_table_c;
+          jd.W = Wt;
+          jd.bases = in.win_table;
+        }
+      }
       // digit d > 0 lives in bucket d - 1: signed digits 1 .. 2^(c-1), unsigned 1 .. 2^c - 1
       sort_bits[j] = jd.is_signed ? jd.c - 1 : jd.c;
       const uint32_t nb = 1u << sort_bits[j];
-      jd.red_W = jd.pack_shift && jd.W ? 2 : jd.W;
+      jd.red_W = jd.pack_shift && jd.W ? 2 : jd.merged ? 1 : jd.W;
       jd.seg_size = seg_size;
       jd.seg_per_win = (nb + jd.seg_size - 1) / jd.seg_size;
       jd.win_stride = jd.seg_per_win * jd.seg_size;
@@ -611,7 +625,7 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
       jd.key_base = key;
       jd.seg_base = seg;
       jd.win_base = win;
-      key += jd.W * jd.win_stride;
+      key += (jd.merged ? 1 : jd.W) * jd.win_stride;
       seg += jd.red_W * jd.seg_per_win;
       win += jd.red_W;
       LH_REQUIRE(in.n < 0x7fffffffu, LH_ERR_ARG, "msm: too many points");
@@ -707,6 +721,11 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
             hipLaunchKernelGGL(msm_presorted_kernel, dim3((unsigned)std::min<size_t>((jd.n + 255) / 256, 4096)), dim3(256), 0,
                                c.stream, jd.key_base, in.sorted_scalars, in.sorted_index, (size_t)jd.n, skey + jd.entry_base,
                                sidx + jd.entry_base);
+            continue;
+          }
+          if (jd.merged) {  // one bucket set: the entries of all windows are one slab
+            const size_t e = jd.entry_base;
+            sorts.push_back(SortSlab{ukey + e, skey + e, uidx + e, sidx + e, (size_t)jd.n * jd.W, sort_bits[j]});
             continue;
           }
           for (uint32_t w = 0; w < jd.W; w++) {
@@ -876,8 +895,8 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
         return;
       }
       host::G1Xyzz acc = host::G1Xyzz::identity();
-      for (int w = (int)jd.W - 1; w >= 0; w--) {
-        for (uint32_t k = 0; k < jd.c; k++) acc = host::g1_dbl(acc);
+      for (int w = (int)jd.red_W - 1; w >= 0; w--) {  // (a window table's job has one "window": no doublings)
+        for (uint32_t k = 0; k < jd.c && !jd.merged; k++) acc = host::g1_dbl(acc);
         for (uint32_t part = 0; part < jd.nsplit; part++)
           acc = host::g1_add(acc, to_host(wins[(size_t)jd.share_base + (size_t)w * jd.nsplit + part]));
       }
@@ -886,6 +905,41 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
     };
     host_parallel_for(nj, combine);  // ~70 us of dependent doublings per job
   }
+}
+
+// ------------------------------------------------------------------ window tables (MsmJob::win_table)
+// out[w * n + i] = 2^(c w) * bases[i], affine, w < W.  Built once per SRS level (prover.cpp srs_window_table): with the
+// multiples at hand the W windows of a full-width scalar file into ONE bucket set - the bucket reduction, the window sums
+// and the host's doublings of that job shrink W-fold, the additions of the accumulation stay what they were.
+__global__ __launch_bounds__(128) void msm_window_table_kernel(const G1Affine* __restrict__ bases, size_t n, uint32_t cbits,
+                                                               uint32_t W, G1Affine* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const G1Affine b = bases[i];
+    out[i] = b;
+    G1Xyzz p = G1Xyzz::from_affine(b);
+    for (uint32_t w = 1; w < W; w++) {
+      for (uint32_t k = 0; k < cbits; k++) p = dbl(p);
+      G1Affine r;
+      if (p.is_identity()) {
+        r.x = Fq::zero();
+        r.y = Fq::zero();
+      } else {
+        const Fq i2 = inv(mul(p.zz, p.zzz));
+        r.x = mul(p.x, mul(i2, p.zzz));
+        r.y = mul(p.y, mul(i2, p.zz));
+      }
+      out[(size_t)w * n + i] = r;
+      p = G1Xyzz::from_affine(r);  // (keeps the next doublings on a normalised point: zz = zzz = 1)
+    }
+  }
+}
+
+uint32_t msm_window_bits(size_t n) { return pick_window(n ? n : 1, 254); }
+
+void k_msm_window_table(Ctx& c, const G1Affine* bases, size_t n, uint32_t cbits, uint32_t W, G1Affine* out) {
+  if (!n || !W) return;
+  hipLaunchKernelGGL(msm_window_table_kernel, dim3((unsigned)std::min<size_t>((n + 127) / 128, 1 << 16)), dim3(128), 0,
+                     c.stream, bases, n, cbits, W, out);
 }
 
 // ------------------------------------------------------------------ fixed-base multiples of G (SRS setup)

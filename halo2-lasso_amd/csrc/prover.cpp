@@ -1123,8 +1123,11 @@ std::vector<HG1> mkzg_batch_commit(Ctx& c, const Srs& srs, const Fr* const* d_po
                                    size_t num_vars) {
   check_commit_vars(srs, num_vars, "batch commit");
   std::vector<MsmJob> jobs(num_polys);
-  for (size_t i = 0; i < num_polys; i++)
+  const Srs::WinTable* wt = srs_window_table(c, srs, num_vars);
+  for (size_t i = 0; i < num_polys; i++) {
     jobs[i] = MsmJob{d_polys[i], false, srs.eq(num_vars), (size_t)1 << num_vars};
+    if (wt) jobs[i].win_table = wt->d, jobs[i].win_table_c = wt->c, jobs[i].win_table_W = wt->W;
+  }
   std::vector<HG1> out(num_polys);
   msm_batch(c, jobs.data(), num_polys, (G1Affine*)out.data());
   return out;
@@ -1175,6 +1178,33 @@ const G1Affine* srs_shard_level(Ctx& c, const Srs& srs, size_t lvl) {
     srs.shard_levels[lvl] = p;
   }
   return srs.shard_levels[lvl];
+}
+
+// window table of a whole level (MsmJob::win_table), built on first use by the ctx that asks (the table belongs to the
+// SRS: every ctx of the process sees it afterwards).  Levels above Options::msm_window_tables, levels too small to matter
+// and levels whose table does not fit the device's free memory have none.
+const Srs::WinTable* srs_window_table(Ctx& c, const Srs& srs, size_t lvl) {
+  if (c.opt.msm_window_tables <= 0 || (int64_t)lvl > c.opt.msm_window_tables || lvl > srs.num_vars || lvl < 6) return nullptr;
+  std::lock_guard<std::mutex> lock(level_sums_mu);
+  auto it = srs.win_tables.find(lvl);
+  if (it != srs.win_tables.end()) return it->second.d ? &it->second : nullptr;
+  Srs::WinTable t;
+  const size_t n = (size_t)1 << lvl;
+  t.c = msm_window_bits(n);
+  t.W = (255 + t.c - 1) / t.c;  // (254 bits + the head room of the signed digits)
+  const size_t bytes = (size_t)t.W * n * sizeof(G1Affine);
+  size_t free_b = 0, total_b = 0;
+  if ((size_t)t.W * n >= ((size_t)1 << 31) || hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > free_b / 4 ||
+      hipMalloc((void**)&t.d, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    t.d = nullptr;
+    srs.win_tables[lvl] = t;  // (remembered: not asked again)
+    return nullptr;
+  }
+  k_msm_window_table(c, srs.eq(lvl), n, t.c, t.W, t.d);
+  c.sync();
+  srs.win_tables[lvl] = t;
+  return &srs.win_tables[lvl];
 }
 
 // Inside a sharded proof (dev.hpp Shard) `d_poly` / the small columns are this rank's shards.  The quotient of level i
@@ -1305,6 +1335,9 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
     size_t half = (size_t)1 << (i >= cut ? i - lsh : i);
     jobs[i] = MsmJob{q_of[i], false, level_bases(i), half};
     if (small) jobs[i].known_bits = 254;  // quotients of a random combination: full-size scalars, nothing to measure
+    if (!(i >= cut && sharded))           // (a rank's share of a sharded level has no window table)
+      if (const Srs::WinTable* wt = srs_window_table(c, srs, i))
+        jobs[i].win_table = wt->d, jobs[i].win_table_c = wt->c, jobs[i].win_table_W = wt->W;
   }
   // ---- the column-wise levels
   struct Term {     // result of job `job` (or its second output), times `scale`, goes into the commitment

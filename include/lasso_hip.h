@@ -257,6 +257,10 @@ lh_status lh_lasso_last_timing(lh_ctx*, double* out_ms);
  *   sc_tail_max_len      8192 longest table (entries) that enters the resident tail
  *   shard_exchange_log   17   sharded proofs: a sum-check goes on replicated once its residual tables hold <= 2^this
  *                             entries together (one all-gather), at the latest when the shard bits reach bit 0
+ *   msm_window_tables    0    SRS levels of <= 2^this points get a window table on first use (2^(c w) multiples of every
+ *                             base, W-fold the level's memory): the W windows of a full-width column then fill ONE
+ *                             bucket set - one bucket reduction, no doublings.  Measured neutral at 2^24 lookups (shorter
+ *                             reduction, longer bucket runs): off by default
  * lh_lasso_last_route reports which of these routes the last Lasso prove on the ctx actually took, so that a byte
  * mismatch in the field can be bisected from the outside. */
 lh_status lh_ctx_set_option(lh_ctx*, const char* name, int64_t value);
@@ -275,7 +279,8 @@ typedef struct lh_lasso_route {
   uint32_t sorted_dim_reuse;    /* dim columns whose MSM entry stream came from the access counters' sort */
   uint32_t sharded_rounds;      /* rounds that carried a collective (sharded proofs) */
   uint32_t shard_exchanges;     /* residual-table / tree-level / remainder exchanges (sharded proofs) */
-  uint32_t reserved[4];
+  uint32_t window_table_jobs;   /* MSM jobs that ran over a window table (msm_window_tables) */
+  uint32_t reserved[3];
 } lh_lasso_route;
 lh_status lh_lasso_last_route(lh_ctx*, lh_lasso_route* out);
 

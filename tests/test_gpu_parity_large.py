@@ -130,6 +130,10 @@ def test_route_options_change_the_route_not_the_bytes(hl, srs17):
         hl.set_option(ctx, "lasso_pack_ts", 0)
         proof, route = prove()
         assert proof == want and route["resident_tails"] == 0 and route["packed_ts_pairs"] == 0
+        assert route["window_table_jobs"] == 0
+        hl.set_option(ctx, "msm_window_tables", 17)   # window tables of the SRS levels: one bucket set per quotient job
+        proof, route = prove()
+        assert proof == want and route["window_table_jobs"] >= 10, route
         with pytest.raises(hl.Error):
             hl.set_option(ctx, "no_such_option", 1)
     finally:
@@ -451,7 +455,8 @@ def test_context_used_from_another_thread(hl, ctx):
 @pytest.mark.parametrize("env", [{"LH_SC_TAIL_G": "64"}, {"LH_SC_TAIL_G": "2", "LH_SC_TAIL_MAX_LEN": "16384"},
                                  {"LH_SC_TAIL": "0", "LH_LASSO_PACK_TS": "0", "LH_MSM_SLAB_LOG": "31"},
                                  {"LH_OPEN_SMALL_MIN_VARS": "2", "LH_MSM_SLAB_LOG": "4", "LH_MSM_PIPELINE": "1"},
-                                 {"LH_OPEN_SMALL_MIN_VARS": "2", "LH_OPEN_SMALL_DEPTH": "2", "LH_OPEN_SMALL_CHECK": "1"}])
+                                 {"LH_OPEN_SMALL_MIN_VARS": "2", "LH_OPEN_SMALL_DEPTH": "2", "LH_OPEN_SMALL_CHECK": "1"},
+                                 {"LH_MSM_WINDOW_TABLES": "24", "LH_MSM_SLAB_LOG": "6"}])
 def test_small_parity_suite_under_forced_shapes(env):
     """The byte-parity tests of test_gpu_parity.py / test_gpu_golden.py again in a child process with the shape
     knobs forced (they are read once per process): 64 workgroups with slices of two entries (hand-over right after
@@ -460,7 +465,8 @@ def test_small_parity_suite_under_forced_shapes(env):
     counters' sorts), every Lasso batch opening through the small-column route for its largest quotient (32-bit
     differences, packed column pairs, base-sum offsets: by default only from 2^21 lookups on), read_ts columns
     committed one by one instead of in packed pairs, and the two largest quotients column by column whatever the table
-    (with the route's own comparison against the plain commitments switched on)."""
+    (with the route's own comparison against the plain commitments switched on), and every full-width MSM job over a
+    window table of its SRS level (one bucket set for all windows)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "tests/test_gpu_golden.py", "-m", "gpu",
