@@ -401,6 +401,7 @@ void k_sc_round(Ctx&, const ScRound& rd, int degree, bool bind, size_t size, Fr*
 bool k_sc_round_streams(const ScRound& rd, int degree, size_t size);
 // out[i] = in[2 i] + in[2 i + 1]: the eq table over one variable less (eq factoring)
 void k_pair_sums(Ctx&, const Fr* in, size_t n_out, Fr* out);
+void k_pair_sums_multi(Ctx&, const Fr* const* in, Fr* const* out, size_t count, size_t n_out);  // <= 8 per launch
 // Batch-opening shape sum_m eq_m * poly_m with every eq factored: per term q_m(0) = sum_b E_m[b] v0, q_m(1) = sum_b E_m[b] v1
 constexpr int SC_OPEN_MAX_TERMS = 6;
 struct ScOpenRound {

@@ -748,6 +748,27 @@ void k_pair_sums(Ctx& c, const Fr* in, size_t n_out, Fr* out) {
   hipLaunchKernelGGL(pair_sums_kernel, dim3((unsigned)std::min<size_t>((n_out + 255) / 256, 4096)), dim3(256), 0, c.stream, in,
                      n_out, out);
 }
+// the same for up to 8 tables of one length in one launch (the eq levels of a batch opening's terms)
+struct PairSumsPack {
+  const Fr* in[8];
+  Fr* out[8];
+};
+__global__ void pair_sums_multi_kernel(PairSumsPack pk, size_t n_out) {
+  const Fr* __restrict__ in = pk.in[blockIdx.y];
+  Fr* __restrict__ out = pk.out[blockIdx.y];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_out; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = add(in[2 * i], in[2 * i + 1]);
+}
+void k_pair_sums_multi(Ctx& c, const Fr* const* in, Fr* const* out, size_t count, size_t n_out) {
+  if (!n_out) return;
+  for (size_t base = 0; base < count; base += 8) {
+    const size_t k = std::min<size_t>(8, count - base);
+    PairSumsPack pk;
+    for (size_t i = 0; i < k; i++) pk.in[i] = in[base + i], pk.out[i] = out[base + i];
+    hipLaunchKernelGGL(pair_sums_multi_kernel, dim3((unsigned)std::min<size_t>((n_out + 255) / 256, 4096), (unsigned)k),
+                       dim3(256), 0, c.stream, pk, n_out);
+  }
+}
 
 // workgroups per CU of the entry-per-lane round kernels (grid-stride loops; tuning knob LH_SC_ENTRY_BLOCKS)
 static size_t sc_entry_blocks_per_cu() {

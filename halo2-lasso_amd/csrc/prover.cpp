@@ -722,9 +722,17 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
     ef.streams = [&](bool, size_t size) { return k_sc_round_streams(rd, degree, size); };
     ef.round = [&](const Fr* const* in, Fr* const* out, const Fr& r, bool bind, size_t size, size_t round, int points,
                    Fr* out_host) {
-      if (round > 0)  // E_round from E_{round-1}: the two entries that differ in variable `round` add up
-        for (EqFactoring::One& one : ef.eqs)
-          k_pair_sums(c, one.level[round - 1], size, (Fr*)one.level[round]);
+      // E_round from E_{round-1}: the two entries that differ in variable `round` add up (all terms' tables in one launch).
+      // (Queueing the level of round + 1 right behind this round's kernel, so that it runs while the host turns the
+      // message around, was measured: no difference - profiles/README.md round 3.)
+      auto next_level = [&](size_t lvl, size_t n_out) {
+        const Fr* ins[LH_SC_MAX_TERMS];
+        Fr* outs[LH_SC_MAX_TERMS];
+        size_t k = 0;
+        for (EqFactoring::One& one : ef.eqs) ins[k] = one.level[lvl - 1], outs[k] = (Fr*)one.level[lvl], k++;
+        k_pair_sums_multi(c, ins, outs, k, n_out);
+      };
+      if (round > 0) next_level(round, size);
       if (!ef.per_term && rw && points == 2) {
         ScRwRound g;
         memset(&g, 0, sizeof(g));
