@@ -400,8 +400,9 @@ void k_sc_round(Ctx&, const ScRound& rd, int degree, bool bind, size_t size, Fr*
 // true when k_sc_round would run the streaming one-thread-per-pair kernel for this shape (not the LDS-staged one)
 bool k_sc_round_streams(const ScRound& rd, int degree, size_t size);
 // out[i] = in[2 i] + in[2 i + 1]: the eq table over one variable less (eq factoring)
-void k_pair_sums(Ctx&, const Fr* in, size_t n_out, Fr* out);
-void k_pair_sums_multi(Ctx&, const Fr* const* in, Fr* const* out, size_t count, size_t n_out);  // <= 8 per launch
+// levels[k] = pair sums of levels[k - 1] (levels[-1] = `in`, n_in entries, a power of two), k < nlev: the levels of a
+// factored eq table (host.hpp EqFactoring), 9 per launch
+void k_eq_levels(Ctx&, const Fr* in, size_t n_in, Fr* const* levels, size_t nlev);
 // Batch-opening shape sum_m eq_m * poly_m with every eq factored: per term q_m(0) = sum_b E_m[b] v0, q_m(1) = sum_b E_m[b] v1
 constexpr int SC_OPEN_MAX_TERMS = 6;
 struct ScOpenRound {

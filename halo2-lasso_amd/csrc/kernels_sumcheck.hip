@@ -739,34 +739,64 @@ bool k_sc_round_streams(const ScRound& rd, int degree, size_t size) {
   return !(rd.num_terms * (uint32_t)degree <= 256 && size * rd.num_terms <= sc_lds_max_items());
 }
 
-__global__ void pair_sums_kernel(const Fr* __restrict__ in, size_t n_out, Fr* __restrict__ out) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_out; i += (size_t)gridDim.x * blockDim.x)
-    out[i] = add(in[2 * i], in[2 * i + 1]);
-}
-void k_pair_sums(Ctx& c, const Fr* in, size_t n_out, Fr* out) {
-  if (!n_out) return;
-  hipLaunchKernelGGL(pair_sums_kernel, dim3((unsigned)std::min<size_t>((n_out + 255) / 256, 4096)), dim3(256), 0, c.stream, in,
-                     n_out, out);
-}
-// the same for up to 8 tables of one length in one launch (the eq levels of a batch opening's terms)
-struct PairSumsPack {
-  const Fr* in[8];
-  Fr* out[8];
+// Every level of a factored eq table (host.hpp EqFactoring: E_{j+1}[b] = E_j[2b] + E_j[2b+1]) in a few launches instead of
+// one per round: a thread takes 8 consecutive entries through three levels, its wave six more by lane shuffles - one
+// launch makes 9 levels, the next one starts from the last level of the first.  (One launch per round, in front of the
+// round's kernel: 76 launches and ~1.3 ms of a 2^24 AND proof.)
+struct EqLevelsPack {
+  const Fr* in;
+  Fr* out[9];
 };
-__global__ void pair_sums_multi_kernel(PairSumsPack pk, size_t n_out) {
-  const Fr* __restrict__ in = pk.in[blockIdx.y];
-  Fr* __restrict__ out = pk.out[blockIdx.y];
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_out; i += (size_t)gridDim.x * blockDim.x)
-    out[i] = add(in[2 * i], in[2 * i + 1]);
+__global__ __launch_bounds__(256) void eq_levels_kernel(EqLevelsPack pk, size_t n_in, int nlev) {
+  const int lane = threadIdx.x & 63;
+  const size_t threads = (size_t)gridDim.x * blockDim.x, tiles = (n_in + 7) / 8;
+  // (whole waves enter and leave the loop together: the shuffles below need every lane)
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t - lane < tiles; t += threads) {
+    Fr e[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) e[k] = t * 8 + k < n_in ? pk.in[t * 8 + k] : Fr::zero();
+    Fr v = Fr::zero();
+#pragma unroll
+    for (int lv = 0; lv < 3; lv++) {  // levels 1..3 of this launch: 4, 2, 1 entries per thread
+      const int cnt = 4 >> lv;
+#pragma unroll
+      for (int k = 0; k < cnt; k++) e[k] = add(e[2 * k], e[2 * k + 1]);
+      if (lv < nlev) {
+        const size_t n_out = n_in >> (lv + 1);
+#pragma unroll
+        for (int k = 0; k < cnt; k++)
+          if (t * cnt + k < n_out) pk.out[lv][t * cnt + k] = e[k];
+      }
+    }
+    v = e[0];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {  // levels 4..9: pairs, quads, ... of lanes
+      Fr o;
+#pragma unroll
+      for (int q = 0; q < 8; q++) o.l[q] = __shfl_xor(v.l[q], 1 << k, 64);
+      v = add(v, o);
+      const int lv = 3 + k;
+      if (lv < nlev && (lane & ((2 << k) - 1)) == 0) {
+        const size_t idx = t >> (k + 1), n_out = n_in >> (lv + 1);
+        if (idx < n_out) pk.out[lv][idx] = v;
+      }
+    }
+  }
 }
-void k_pair_sums_multi(Ctx& c, const Fr* const* in, Fr* const* out, size_t count, size_t n_out) {
-  if (!n_out) return;
-  for (size_t base = 0; base < count; base += 8) {
-    const size_t k = std::min<size_t>(8, count - base);
-    PairSumsPack pk;
-    for (size_t i = 0; i < k; i++) pk.in[i] = in[base + i], pk.out[i] = out[base + i];
-    hipLaunchKernelGGL(pair_sums_multi_kernel, dim3((unsigned)std::min<size_t>((n_out + 255) / 256, 4096), (unsigned)k),
-                       dim3(256), 0, c.stream, pk, n_out);
+// levels[k] (k < nlev) = the pair sums of levels[k - 1], levels[-1] = `in` of n_in entries (a power of two)
+void k_eq_levels(Ctx& c, const Fr* in, size_t n_in, Fr* const* levels, size_t nlev) {
+  size_t done = 0;
+  while (done < nlev && n_in >= 2) {
+    const size_t k = std::min<size_t>(9, nlev - done);
+    EqLevelsPack pk;
+    pk.in = in;
+    for (size_t i = 0; i < 9; i++) pk.out[i] = i < k ? levels[done + i] : nullptr;
+    const size_t waves = (n_in + 511) / 512;
+    hipLaunchKernelGGL(eq_levels_kernel, dim3((unsigned)std::min<size_t>((waves + 3) / 4, 8192)), dim3(256), 0, c.stream, pk,
+                       n_in, (int)k);
+    in = levels[done + k - 1];
+    n_in >>= k;
+    done += k;
   }
 }
 

@@ -700,6 +700,7 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
   if (use_ef) {
     const Shard shg(c);
     const size_t half = (size_t)1 << (nvl - 1);
+    static const bool eq_levels_ahead = !(getenv("LH_SC_EQ_LEVELS_AHEAD") && atoi(getenv("LH_SC_EQ_LEVELS_AHEAD")) == 0);
     for (EqFactoring::One& one : ef.eqs) {
       // consecutive blocks of halving size in one buffer; E_0 (the eq table over variables 1..n-1; sharded: this rank's
       // shard of it) comes from the proof's shared tables when an evaluation at the same point built it already
@@ -715,24 +716,25 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
         one.level[jl] = buf + off;
         off += half >> jl;
       }
-      if (shared) continue;
-      if (sharded) eq_xy_shard(c, shg, one.y, num_vars, 1, buf);
-      else k_eq_xy(c, (const Fr*)(one.y + 1), num_vars - 1, buf);
+      if (!shared) {
+        if (sharded) eq_xy_shard(c, shg, one.y, num_vars, 1, buf);
+        else k_eq_xy(c, (const Fr*)(one.y + 1), num_vars - 1, buf);
+      }
+      // E_{j+1} from E_j: the two entries that differ in variable j + 1 add up.  No level depends on a challenge: all of
+      // them now, nine per launch (one launch per round in front of the round's kernel was 76 launches per 2^24 proof)
+      std::vector<Fr*> lower;
+      for (size_t jl = 1; jl < nvl; jl++) lower.push_back((Fr*)one.level[jl]);
+      if (eq_levels_ahead) k_eq_levels(c, one.level[0], half, lower.data(), lower.size());
     }
     ef.streams = [&](bool, size_t size) { return k_sc_round_streams(rd, degree, size); };
     ef.round = [&](const Fr* const* in, Fr* const* out, const Fr& r, bool bind, size_t size, size_t round, int points,
                    Fr* out_host) {
-      // E_round from E_{round-1}: the two entries that differ in variable `round` add up (all terms' tables in one launch).
-      // (Queueing the level of round + 1 right behind this round's kernel, so that it runs while the host turns the
-      // message around, was measured: no difference - profiles/README.md round 3.)
-      auto next_level = [&](size_t lvl, size_t n_out) {
-        const Fr* ins[LH_SC_MAX_TERMS];
-        Fr* outs[LH_SC_MAX_TERMS];
-        size_t k = 0;
-        for (EqFactoring::One& one : ef.eqs) ins[k] = one.level[lvl - 1], outs[k] = (Fr*)one.level[lvl], k++;
-        k_pair_sums_multi(c, ins, outs, k, n_out);
-      };
-      if (round > 0) next_level(round, size);
+      static const bool eq_levels_ahead = !(getenv("LH_SC_EQ_LEVELS_AHEAD") && atoi(getenv("LH_SC_EQ_LEVELS_AHEAD")) == 0);
+      if (!eq_levels_ahead && round > 0)  // (A/B: one level per round, in front of the round's kernel, as before)
+        for (EqFactoring::One& one : ef.eqs) {
+          Fr* lvl = (Fr*)one.level[round];
+          k_eq_levels(c, one.level[round - 1], 2 * size, &lvl, 1);
+        }
       if (!ef.per_term && rw && points == 2) {
         ScRwRound g;
         memset(&g, 0, sizeof(g));
