@@ -545,6 +545,7 @@ struct SortSlab {
   size_t n;
   unsigned bits;
 };
+// (vals_in == nullptr: the values are the positions 0 .. n - 1)
 void sort_pairs_u32(Ctx&, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, size_t n,
                     unsigned bits);
 // `count` independent sorts as ONE launch set per radix pass (temporary storage from the arena: the caller's ArenaScope)

@@ -823,18 +823,12 @@ __device__ __forceinline__ uint32_t subtable_entry(int kind, uint32_t m, uint32_
 // Stable radix sort of (address, lookup index) pairs, then a lookup's rank inside its run of equal addresses is
 // its position minus the run start: O(n) traffic whatever the table size (a tile x address histogram, the
 // obvious counting-sort formulation, moves tiles * m counters - 2 GB per column at 2^24 lookups).
-__global__ void lasso_iota_kernel(const uint32_t* __restrict__ dim, size_t n, size_t m, uint32_t* __restrict__ out,
-                                  uint32_t* __restrict__ bad) {
-  GSTRIDE(i, n) {
-    out[i] = (uint32_t)i;
-    if (dim[i] >= m) *bad = 1u;  // benign race: every writer stores the same value
-  }
-}
 __global__ void lasso_run_start_kernel(const uint32_t* __restrict__ skey, size_t n, size_t m,
-                                       uint32_t* __restrict__ start) {
+                                       uint32_t* __restrict__ start, uint32_t* __restrict__ bad) {
   GSTRIDE(i, n) {
     const uint32_t k = skey[i];
-    if ((i == 0 || skey[i - 1] != k) && k < m) start[k] = (uint32_t)i;
+    if (k >= m) *bad = 1u;  // benign race: every writer stores the same value
+    else if (i == 0 || skey[i - 1] != k) start[k] = (uint32_t)i;
   }
 }
 __global__ void lasso_rank_kernel(const uint32_t* __restrict__ skey, const uint32_t* __restrict__ sidx, size_t n,
@@ -854,7 +848,6 @@ void k_lasso_counters(Ctx& c, const uint32_t* dim, size_t n, size_t m, uint32_t*
   ArenaScope scope(c.arena);
   unsigned bits = 1;
   while (((size_t)1 << bits) < m) bits++;
-  uint32_t* idx = c.arena.alloc_n<uint32_t>(n);
   uint32_t* skey = keep_sorted ? keep_sorted : c.arena.alloc_n<uint32_t>(n);
   uint32_t* sidx = keep_index ? keep_index : c.arena.alloc_n<uint32_t>(n);
   uint32_t* start = c.arena.alloc_n<uint32_t>(m);
@@ -862,9 +855,8 @@ void k_lasso_counters(Ctx& c, const uint32_t* dim, size_t n, size_t m, uint32_t*
   LH_HIP(hipMemsetAsync(final_cts, 0, m * sizeof(uint32_t), c.stream));
   LH_HIP(hipMemsetAsync(bad, 0, sizeof(uint32_t), c.stream));
   if (!n) return;
-  hipLaunchKernelGGL(lasso_iota_kernel, grid_for(n), 256, 0, c.stream, dim, n, m, idx, bad);
-  sort_pairs_u32(c, dim, skey, idx, sidx, n, bits);
-  hipLaunchKernelGGL(lasso_run_start_kernel, grid_for(n), 256, 0, c.stream, skey, n, m, start);
+  sort_pairs_u32(c, dim, skey, nullptr, sidx, n, bits);  // (address, lookup index) pairs: the index is the position
+  hipLaunchKernelGGL(lasso_run_start_kernel, grid_for(n), 256, 0, c.stream, skey, n, m, start, bad);
   hipLaunchKernelGGL(lasso_rank_kernel, grid_for(n), 256, 0, c.stream, skey, sidx, n, m, start, read_ts, final_cts);
   uint32_t h_bad = 0;
   c.d2h(&h_bad, bad, sizeof(uint32_t));

@@ -740,46 +740,47 @@ bool k_sc_round_streams(const ScRound& rd, int degree, size_t size) {
 }
 
 // Every level of a factored eq table (host.hpp EqFactoring: E_{j+1}[b] = E_j[2b] + E_j[2b+1]) in a few launches instead of
-// one per round: a thread takes 8 consecutive entries through three levels, its wave six more by lane shuffles - one
-// launch makes 9 levels, the next one starts from the last level of the first.  (One launch per round, in front of the
-// round's kernel: 76 launches and ~1.3 ms of a 2^24 AND proof.)
+// one per round.  A wave takes a tile of 512 entries as four rows of 128: a lane loads one pair per row (64 contiguous
+// bytes per lane: the plain bind kernel's access pattern), adds it (level 1), six rounds of lane shuffles make levels 2..7
+// of every row, the four row totals levels 8 and 9 - one launch makes 9 levels, the next one starts from the last level of
+// the first.  (One launch per round, in front of the round's kernel: 76 launches and ~1.3 ms of a 2^24 AND proof.)
 struct EqLevelsPack {
   const Fr* in;
   Fr* out[9];
 };
 __global__ __launch_bounds__(256) void eq_levels_kernel(EqLevelsPack pk, size_t n_in, int nlev) {
   const int lane = threadIdx.x & 63;
-  const size_t threads = (size_t)gridDim.x * blockDim.x, tiles = (n_in + 7) / 8;
-  // (whole waves enter and leave the loop together: the shuffles below need every lane)
-  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t - lane < tiles; t += threads) {
-    Fr e[8];
+  const size_t waves = ((size_t)gridDim.x * blockDim.x) >> 6, tiles = (n_in + 511) / 512;
+  for (size_t tile = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; tile < tiles; tile += waves) {
+    Fr v[4];
 #pragma unroll
-    for (int k = 0; k < 8; k++) e[k] = t * 8 + k < n_in ? pk.in[t * 8 + k] : Fr::zero();
-    Fr v = Fr::zero();
+    for (int r = 0; r < 4; r++) {
+      const size_t i = tile * 512 + (size_t)r * 128 + 2 * (size_t)lane;
+      v[r] = i + 1 < n_in ? add(pk.in[i], pk.in[i + 1]) : Fr::zero();
+      if (nlev > 0 && (i >> 1) < (n_in >> 1)) pk.out[0][i >> 1] = v[r];
+    }
 #pragma unroll
-    for (int lv = 0; lv < 3; lv++) {  // levels 1..3 of this launch: 4, 2, 1 entries per thread
-      const int cnt = 4 >> lv;
+    for (int k = 0; k < 6; k++) {  // levels 2..7: pairs, quads, ... of lanes inside a row
+      const int lv = 1 + k;
 #pragma unroll
-      for (int k = 0; k < cnt; k++) e[k] = add(e[2 * k], e[2 * k + 1]);
-      if (lv < nlev) {
-        const size_t n_out = n_in >> (lv + 1);
+      for (int r = 0; r < 4; r++) {
+        Fr o;
 #pragma unroll
-        for (int k = 0; k < cnt; k++)
-          if (t * cnt + k < n_out) pk.out[lv][t * cnt + k] = e[k];
+        for (int q = 0; q < 8; q++) o.l[q] = __shfl_xor(v[r].l[q], 1 << k, 64);
+        v[r] = add(v[r], o);
+        if (lv < nlev && (lane & ((2 << k) - 1)) == 0) {
+          const size_t idx = (tile * 256 + (size_t)r * 64 + (size_t)lane) >> (k + 1);
+          if (idx < (n_in >> (lv + 1))) pk.out[lv][idx] = v[r];
+        }
       }
     }
-    v = e[0];
-#pragma unroll
-    for (int k = 0; k < 6; k++) {  // levels 4..9: pairs, quads, ... of lanes
-      Fr o;
-#pragma unroll
-      for (int q = 0; q < 8; q++) o.l[q] = __shfl_xor(v.l[q], 1 << k, 64);
-      v = add(v, o);
-      const int lv = 3 + k;
-      if (lv < nlev && (lane & ((2 << k) - 1)) == 0) {
-        const size_t idx = t >> (k + 1), n_out = n_in >> (lv + 1);
-        if (idx < n_out) pk.out[lv][idx] = v;
+    if (lane == 0) {  // the row totals: levels 8 and 9
+      const Fr w0 = add(v[0], v[1]), w1 = add(v[2], v[3]);
+      if (nlev > 7) {
+        if (tile * 2 < (n_in >> 8)) pk.out[7][tile * 2] = w0;
+        if (tile * 2 + 1 < (n_in >> 8)) pk.out[7][tile * 2 + 1] = w1;
       }
+      if (nlev > 8 && tile < (n_in >> 9)) pk.out[8][tile] = add(w0, w1);
     }
   }
 }

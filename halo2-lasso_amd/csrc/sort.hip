@@ -163,7 +163,7 @@ __global__ __launch_bounds__(RS_BS) void rs_scatter_kernel(const RsSlab* __restr
   for (int i = 0; i < RS_IPT; i++) {
     const size_t k = base + (size_t)i * RS_BS + threadIdx.x;
     key[i] = k < n ? keys_in[k] : (K)0;
-    val[i] = k < n ? vals_in[k] : 0u;
+    val[i] = k < n ? (vals_in ? vals_in[k] : (uint32_t)k) : 0u;  // (no values given: the pair's position)
   }
   // global bases: exclusive scan of the bin totals (256 values: the first four waves), plus this tile's offset in its bin
   if (threadIdx.x < 256) {
