@@ -4,7 +4,7 @@
 //
 // Hand-written since round 3 (tools/ubench/radix_own.hip holds the development harness and the comparison with rocPRIM's
 // onesweep, which this replaced on the Lasso path): a stable LSD sort, <= 8 bits per pass, three launches per pass -
-//   hist     per-tile digit histogram (LDS atomics), written bin-major
+//   hist     per-tile digit histogram (LDS atomics; 512 threads x 8 keys), written bin-major
 //   scan     exclusive scan of every bin's row over the tiles, and the bin totals
 //   scatter  a tile of 4096 pairs is ranked by wave-level digit matching (ballots), reordered through LDS and written out as
 //            one run per digit: coalesced stores whatever the digit distribution; two workgroups share a CU's LDS so that one
@@ -65,8 +65,10 @@ __device__ __forceinline__ uint32_t rs_find_slab(const RsSlab* __restrict__ slab
   return lo;
 }
 
-template <class K>
-__global__ __launch_bounds__(RS_BS) void rs_hist_kernel(const RsSlab* __restrict__ slabs, uint32_t count, unsigned q) {
+// (512 threads x 8 keys, all loads first: with the scatter kernel's 1024 x 4 shape the histogram pass ran at the latency
+// of two workgroups per CU - per launch 111 us on average in a 2^24 AND proof; 128 / 256 / 512 threads: 72 / 70 / 66 us)
+template <class K, int RS_HIST_BS>
+__global__ __launch_bounds__(RS_HIST_BS) void rs_hist_kernel(const RsSlab* __restrict__ slabs, uint32_t count, unsigned q) {
   __shared__ uint32_t h[256];
   const RsSlab& sl = slabs[rs_find_slab(slabs, count, blockIdx.x)];
   if (q >= sl.passes) return;
@@ -80,16 +82,22 @@ __global__ __launch_bounds__(RS_BS) void rs_hist_kernel(const RsSlab* __restrict
   rs_buffers<K>(sl, q, keys, vi_, ko_, vo_);
   uint32_t* hist = sl.hist;
   const uint32_t radix = 1u << rb, mask = radix - 1u;
-  if (threadIdx.x < radix) h[threadIdx.x] = 0;
+  for (uint32_t b = threadIdx.x; b < radix; b += RS_HIST_BS) h[b] = 0;
   __syncthreads();
   const size_t base = (size_t)tile * RS_TILE;
+  K kk[RS_TILE / RS_HIST_BS];
 #pragma unroll
-  for (int i = 0; i < RS_IPT; i++) {
-    const size_t k = base + (size_t)i * RS_BS + threadIdx.x;
-    if (k < n) atomicAdd(&h[(uint32_t)(keys[k] >> shift) & mask], 1u);
+  for (int i = 0; i < RS_TILE / RS_HIST_BS; i++) {  // (all loads first)
+    const size_t k = base + (size_t)i * RS_HIST_BS + threadIdx.x;
+    kk[i] = k < n ? keys[k] : (K)0;
+  }
+#pragma unroll
+  for (int i = 0; i < RS_TILE / RS_HIST_BS; i++) {
+    const size_t k = base + (size_t)i * RS_HIST_BS + threadIdx.x;
+    if (k < n) atomicAdd(&h[(uint32_t)(kk[i] >> shift) & mask], 1u);
   }
   __syncthreads();
-  if (threadIdx.x < radix) hist[(size_t)threadIdx.x * ntiles + tile] = h[threadIdx.x];
+  for (uint32_t b = threadIdx.x; b < radix; b += RS_HIST_BS) hist[(size_t)b * ntiles + tile] = h[b];
 }
 
 // one workgroup per (bin, slab): exclusive scan of the bin's row (the tiles in order: stability across tiles), and its total
@@ -332,7 +340,13 @@ void rs_sort_batch(Ctx& c, const RsJob* slabs, size_t count, void* temp, int sid
     unsigned rb_max = 1;
     for (const RsSlab& s : host)
       if (q < s.passes) rb_max = std::max(rb_max, s.rb[q]);
-    hipLaunchKernelGGL(rs_hist_kernel<K>, dim3(tiles), dim3(RS_BS), 0, stream, d_slabs, ns, q);
+    static const int hist_bs = [] {  // development: LH_RS_HIST_BS = 128 / 256 / 512 threads per histogram workgroup
+      const char* e = getenv("LH_RS_HIST_BS");
+      return e && *e ? atoi(e) : 512;
+    }();
+    if (hist_bs == 128) hipLaunchKernelGGL((rs_hist_kernel<K, 128>), dim3(tiles), dim3(128), 0, stream, d_slabs, ns, q);
+    else if (hist_bs == 256) hipLaunchKernelGGL((rs_hist_kernel<K, 256>), dim3(tiles), dim3(256), 0, stream, d_slabs, ns, q);
+    else hipLaunchKernelGGL((rs_hist_kernel<K, 512>), dim3(tiles), dim3(512), 0, stream, d_slabs, ns, q);
     hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1u << rb_max, ns), dim3(256), 0, stream, d_slabs, q);
     hipLaunchKernelGGL(rs_scatter_kernel<K>, dim3(tiles), dim3(RS_BS), rs_lds_bytes(rb_max, key_bytes), stream, d_slabs, ns, q);
   }
