@@ -545,9 +545,9 @@ struct SortSlab {
   size_t n;
   unsigned bits;
 };
-// (vals_in == nullptr: the values are the positions 0 .. n - 1)
+// (vals_in == nullptr: the values are the positions 0 .. n - 1; the sort is by the key bits [first_bit, first_bit + bits))
 void sort_pairs_u32(Ctx&, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, size_t n,
-                    unsigned bits);
+                    unsigned bits, unsigned first_bit = 0);
 // `count` independent sorts as ONE launch set per radix pass (temporary storage from the arena: the caller's ArenaScope)
 void sort_pairs_u32_batched(Ctx&, const SortSlab* slabs, size_t count, int side = 0);  // side 1: on the ctx's second stream
 void sort_pairs_u64(Ctx&, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, size_t n,

@@ -842,6 +842,43 @@ __global__ void lasso_rank_kernel(const uint32_t* __restrict__ skey, const uint3
     if (i + 1 == n || skey[i + 1] != k) final_cts[k] = r + 1;
   }
 }
+// Large columns: the scatter read_ts[sidx[i]] = rank above drags a whole line through the caches for every 4 bytes.  Here
+// the ranks stay in sorted order (`ranks`, coalesced), the (lookup index, rank) pairs are partitioned by the top bits of the
+// index (one or two passes of the radix sort) and every window of 2^15 consecutive read_ts entries is assembled in LDS and
+// written out as whole lines.
+__global__ void lasso_rank_sorted_kernel(const uint32_t* __restrict__ skey, size_t n, size_t m,
+                                         const uint32_t* __restrict__ start, uint32_t* __restrict__ ranks,
+                                         uint32_t* __restrict__ final_cts) {
+  GSTRIDE(i, n) {
+    const uint32_t k = skey[i];
+    uint32_t r = 0;
+    if (k < m) {
+      r = (uint32_t)i - start[k];
+      if (i + 1 == n || skey[i + 1] != k) final_cts[k] = r + 1;
+    }
+    ranks[i] = r;
+  }
+}
+constexpr uint32_t UNPERM_WINDOW_LOG = 15;  // read_ts entries per workgroup: 128 KB of LDS
+// pairs (idx, rank) grouped by idx >> group_log (group g = positions [g << group_log, (g + 1) << group_log), idx a
+// permutation); workgroup (g, h) assembles window h of group g
+__global__ __launch_bounds__(1024) void lasso_unpermute_kernel(const uint32_t* __restrict__ pidx,
+                                                               const uint32_t* __restrict__ prank, unsigned group_log,
+                                                               uint32_t* __restrict__ read_ts) {
+  extern __shared__ uint32_t win[];
+  const unsigned parts_log = group_log - UNPERM_WINDOW_LOG;
+  const size_t g = blockIdx.x >> parts_log;
+  const uint32_t h = blockIdx.x & ((1u << parts_log) - 1u);
+  const size_t p0 = g << group_log, cnt = (size_t)1 << group_log;
+  const uint32_t wmask = (1u << UNPERM_WINDOW_LOG) - 1u;
+  for (size_t q = threadIdx.x; q < cnt; q += blockDim.x) {
+    const uint32_t idx = pidx[p0 + q];
+    if (((idx >> UNPERM_WINDOW_LOG) & ((1u << parts_log) - 1u)) == h) win[idx & wmask] = prank[p0 + q];
+  }
+  __syncthreads();
+  uint32_t* out = read_ts + (g << group_log) + ((size_t)h << UNPERM_WINDOW_LOG);
+  for (uint32_t q = threadIdx.x; q <= wmask; q += blockDim.x) out[q] = win[q];
+}
 void k_lasso_counters(Ctx& c, const uint32_t* dim, size_t n, size_t m, uint32_t* read_ts, uint32_t* final_cts,
                       uint32_t* keep_sorted, uint32_t* keep_index) {
   ProfScope ps(c, "lasso_counters", 8.0 * n + 4.0 * m, 0.0, (double)n);
@@ -857,7 +894,26 @@ void k_lasso_counters(Ctx& c, const uint32_t* dim, size_t n, size_t m, uint32_t*
   if (!n) return;
   sort_pairs_u32(c, dim, skey, nullptr, sidx, n, bits);  // (address, lookup index) pairs: the index is the position
   hipLaunchKernelGGL(lasso_run_start_kernel, grid_for(n), 256, 0, c.stream, skey, n, m, start, bad);
-  hipLaunchKernelGGL(lasso_rank_kernel, grid_for(n), 256, 0, c.stream, skey, sidx, n, m, start, read_ts, final_cts);
+  unsigned lg = 0;
+  while (((size_t)1 << lg) < n) lg++;
+  static const bool two_step = !(getenv("LH_LASSO_UNPERMUTE") && atoi(getenv("LH_LASSO_UNPERMUTE")) == 0);  // (A/B)
+  // (2^17 .. 2^24 lookups: one partition pass; beyond, the second pass costs what the scatter did - 2^26: 5.3 -> 5.8 ms)
+  if (two_step && lg >= 17 && lg <= UNPERM_WINDOW_LOG + 9 && n == ((size_t)1 << lg)) {
+    uint32_t* ranks = c.arena.alloc_n<uint32_t>(n);
+    uint32_t* pidx = c.arena.alloc_n<uint32_t>(n);
+    uint32_t* prank = c.arena.alloc_n<uint32_t>(n);
+    hipLaunchKernelGGL(lasso_rank_sorted_kernel, grid_for(n), 256, 0, c.stream, skey, n, m, start, ranks, final_cts);
+    // groups of 2^15 (one window per workgroup) when that takes one pass of <= 8 bits, 2^16 (two windows, the pairs read
+    // twice) at 2^24
+    const unsigned top = lg - UNPERM_WINDOW_LOG;
+    const unsigned pbits = top == 9 ? 8 : top, group_log = lg - pbits;
+    sort_pairs_u32(c, sidx, pidx, ranks, prank, n, pbits, group_log);
+    c.opt_in_lds((const void*)lasso_unpermute_kernel, (int)(4u << UNPERM_WINDOW_LOG));
+    hipLaunchKernelGGL(lasso_unpermute_kernel, dim3((unsigned)(n >> UNPERM_WINDOW_LOG)), dim3(1024), 4u << UNPERM_WINDOW_LOG,
+                       c.stream, pidx, prank, group_log, read_ts);
+  } else {
+    hipLaunchKernelGGL(lasso_rank_kernel, grid_for(n), 256, 0, c.stream, skey, sidx, n, m, start, read_ts, final_cts);
+  }
   uint32_t h_bad = 0;
   c.d2h(&h_bad, bad, sizeof(uint32_t));
   LH_REQUIRE(!h_bad, LH_ERR_ARG, "lasso: chunk index out of range (>= 2^chunk_bits)");

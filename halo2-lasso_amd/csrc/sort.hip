@@ -41,6 +41,7 @@ struct RsSlab {
   uint64_t n;
   uint32_t ntiles, tile0;     // tiles of this slab, index of its first tile in the batch's flattened tile list
   uint32_t passes, rb[8];
+  uint32_t shift0;            // first key bit of the sort (the passes cover bits [shift0, shift0 + sum rb))
 };
 // the buffers of pass q: (in) -> (out); the last pass lands in (kout, vout)
 template <class K>
@@ -50,7 +51,7 @@ __device__ __forceinline__ void rs_buffers(const RsSlab& s, unsigned q, const K*
   ki = (const K*)(q == 0 ? s.kin : in_is_tmp ? s.ktmp : s.kout), vi = q == 0 ? s.vin : in_is_tmp ? s.vtmp : s.vout;
 }
 __device__ __forceinline__ unsigned rs_shift(const RsSlab& s, unsigned q) {
-  unsigned sh = 0;
+  unsigned sh = s.shift0;
   for (unsigned i = 0; i < q; i++) sh += s.rb[i];
   return sh;
 }
@@ -284,6 +285,7 @@ struct RsJob {  // one sort of a batch, keys of the batch's type
   uint32_t* vals_out;
   size_t n;
   unsigned bits;
+  unsigned first_bit = 0;
 };
 size_t rs_batch_bytes(const RsJob* slabs, size_t count, size_t key_bytes) {
   size_t bytes = 256 + ((count * sizeof(RsSlab) + 255) & ~(size_t)255);
@@ -313,6 +315,7 @@ void rs_sort_batch(Ctx& c, const RsJob* slabs, size_t count, void* temp, int sid
     cur += p.bytes & ~(size_t)255;
     s.n = slabs[i].n, s.ntiles = (uint32_t)p.ntiles, s.tile0 = tiles, s.passes = p.passes;
     for (int k = 0; k < 8; k++) s.rb[k] = p.rb[k];
+    s.shift0 = slabs[i].first_bit;
     tiles += s.ntiles;
     max_passes = std::max(max_passes, p.passes);
     host.push_back(s);
@@ -365,9 +368,11 @@ void sort_pairs_u32_batched(Ctx& c, const SortSlab* slabs, size_t count, int sid
 }
 
 void sort_pairs_u32(Ctx& c, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
-                    size_t n, unsigned bits) {
-  const SortSlab one{keys_in, keys_out, vals_in, vals_out, n, bits};
-  sort_pairs_u32_batched(c, &one, 1);
+                    size_t n, unsigned bits, unsigned first_bit) {
+  RsJob one{keys_in, keys_out, vals_in, vals_out, n, bits};
+  one.first_bit = first_bit;
+  void* temp = c.arena.alloc(rs_batch_bytes(&one, 1, 4));  // caller's ArenaScope releases it
+  rs_sort_batch<uint32_t>(c, &one, 1, temp);
 }
 
 // 64-bit keys (the sharded access counters sort (address, global lookup index) on the address owner: 37-45 bits)
