@@ -82,8 +82,8 @@ lh_status lh_ctx_create(int device_id, lh_ctx** out) {
   // line 0: device -> host sequence flag; lines 1-2: host -> device mailbox of the resident sum-check tail
   LH_HIP(hipHostMalloc((void**)&ctx->c.flag, 256, hipHostMallocCoherent | hipHostMallocMapped));
   memset(ctx->c.flag, 0, 256);
-  LH_HIP(hipMalloc((void**)&ctx->c.ticket, 64));
-  LH_HIP(hipMemset(ctx->c.ticket, 0, 64));
+  LH_HIP(hipMalloc((void**)&ctx->c.ticket, 256));  // word 0: ticket, word 8: device flag, words 32..47: the tail's relay chunks
+  LH_HIP(hipMemset(ctx->c.ticket, 0, 256));
   *out = ctx;
   LH_CATCH
 }

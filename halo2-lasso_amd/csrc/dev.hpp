@@ -184,7 +184,8 @@ struct Ctx {
   // hipStreamSynchronize (tens of microseconds per call, paid once per sum-check round).
   uint32_t* flag = nullptr;  // pinned, coherent
   uint32_t flag_seq = 0;
-  uint32_t* ticket = nullptr;  // device counter for in-launch final reductions; only ever grows (word 8: device flag)
+  uint32_t* ticket = nullptr;  // device counter for in-launch final reductions; only ever grows (word 8: device flag;
+                               // words 32..47: the resident tail's relay chunks)
   uint32_t ticket_base = 0;    // its value before the next launch
   struct ScFinishArgs finish_for(uint32_t grid, Fr* out_host, uint32_t seq);
   uint32_t next_seq() { return ++flag_seq; }

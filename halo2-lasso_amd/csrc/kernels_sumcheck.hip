@@ -696,8 +696,9 @@ void k_sc_tail_launch(Ctx& c, const ScRound& rd, int degree, size_t n0, bool fir
     while (((size_t)G << (rounds_a + 1)) <= n0) rounds_a++;
     c.ticket_base += (rounds_a + 1) * G;
     a.part = c.arena.alloc_n<Fr>((size_t)2 * G * 8 + (size_t)rd.num_tables * G);
-    a.bcast = (TailChunk*)c.arena.alloc(4 * sizeof(TailChunk));
-    LH_HIP(hipMemsetAsync(a.bcast, 0, 4 * sizeof(TailChunk), c.stream));
+    // (the ctx's own relay chunks: every round's sequence number is new, so they are never cleared between tails - only
+    // after an aborted one, whose abort marker would stop the next tail: k_sc_tail_resync)
+    a.bcast = (TailChunk*)(c.ticket + 32);
   }
   a.flag = c.flag;
   a.msg_host = msg_host;
@@ -723,6 +724,7 @@ void k_sc_tail_launch(Ctx& c, const ScRound& rd, int degree, size_t n0, bool fir
 }
 
 void k_sc_tail_resync(Ctx& c) {
+  LH_HIP(hipMemsetAsync(c.ticket + 32, 0, 4 * sizeof(TailChunk), c.stream));  // the relay chunks (an abort marker may sit there)
   uint32_t v = 0;
   c.d2h(&v, c.ticket, sizeof(v));
   c.ticket_base = v;
