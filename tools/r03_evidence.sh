@@ -33,3 +33,11 @@ done
 head -5 $O/r03_rocprof_kernel_stats.csv
 tail -3 $O/r03_pmc_extract.log
 tail -n 9 $O/r03_rank.log
+# kernel stats of configs[1] (2^20 range) and configs[4] (Keccak-f circuit) as well
+for cfg in "2p20:--log-n 20 --table range" "keccak:--workload hyperplonk --lookup lasso --circuit keccak --log-n 20"; do
+  tag=${cfg%%:*}; flags=${cfg#*:}
+  rm -rf $O/r03_prof_$tag
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/r03_prof_$tag -- python3 bench.py $flags --steps 5 --warmup 2 --no-cpu-baseline --no-inflight > $O/r03_prof_$tag.log 2>&1
+  find $O/r03_prof_$tag -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/r03_rocprof_kernel_stats_$tag.csv
+  rm -rf $O/r03_prof_$tag
+done
