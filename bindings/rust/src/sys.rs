@@ -166,7 +166,8 @@ pub struct lh_lasso_route {
     pub sharded_rounds: u32,
     pub shard_exchanges: u32,
     pub window_table_jobs: u32,
-    pub reserved: [u32; 3],
+    pub open_precommit: u32,
+    pub reserved: [u32; 2],
 }
 
 extern "C" {

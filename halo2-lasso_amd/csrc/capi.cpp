@@ -88,9 +88,31 @@ lh_status lh_ctx_create(int device_id, lh_ctx** out) {
   LH_CATCH
 }
 
+}  // extern "C"
+namespace lh {
+Ctx& ctx_helper(Ctx& c) {
+  if (!c.helper) {
+    lh_ctx* h = nullptr;
+    if (lh_ctx_create(c.device, &h) != LH_OK || !h) throw Error(LH_ERR_DEVICE, std::string("helper ctx: ") + get_last_error());
+    c.helper_handle = h;
+    c.helper = &h->c;
+  }
+  return *c.helper;
+}
+}  // namespace lh
+extern "C" {
+
 void lh_ctx_destroy(lh_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->c.device);
+  try {
+    open_precommit_cancel(ctx->c);
+  } catch (...) {
+  }
+  if (ctx->c.helper_handle) {
+    lh_ctx_destroy((lh_ctx*)ctx->c.helper_handle);
+    ctx->c.helper_handle = nullptr, ctx->c.helper = nullptr;
+  }
   (void)hipStreamSynchronize(ctx->c.stream);
   try {
     comm_detach(ctx->c);

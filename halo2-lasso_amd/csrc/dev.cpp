@@ -73,6 +73,7 @@ static const struct {
     {"sc_eq_factoring", &Options::sc_eq_factoring},         {"lasso_pack_ts", &Options::lasso_pack_ts},
     {"sc_tail", &Options::sc_tail},                         {"sc_tail_max_len", &Options::sc_tail_max_len},
     {"shard_exchange_log", &Options::shard_exchange_log},   {"msm_window_tables", &Options::msm_window_tables},
+    {"open_precommit", &Options::open_precommit},
 };
 
 int64_t* Options::find(const char* name) {

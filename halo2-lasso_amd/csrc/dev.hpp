@@ -103,6 +103,8 @@ struct Options {
   int64_t sc_tail = 1;                 // 0: one launch per sum-check round all the way down (no resident tail)
   int64_t sc_tail_max_len = 8192;      // longest table that enters the resident tail
   int64_t shard_exchange_log = 17;     // sharded sum-check: the residual tables travel once they hold <= 2^this entries
+  int64_t open_precommit = 1;          // 1: the challenge-free half of the opening's column route (the MSMs over differences of
+                                       // witness columns) runs on a helper ctx beside the sum-checks of a Lasso prove
   int64_t msm_window_tables = 0;       // SRS levels of <= 2^this points get a window table (MsmJob::win_table) on first use:
                                        // full-width columns over them reduce ONE bucket set (0: no tables)
   Options();                           // environment defaults (dev.cpp)
@@ -111,7 +113,7 @@ struct Options {
 struct RouteStats {  // lh_lasso_route (include/lasso_hip.h): counters of the last Lasso prove on the ctx
   uint32_t v[LH_LASSO_ROUTE_WORDS] = {0};
   enum { OPEN_DEPTH, OPEN_PASSES, EF_ROUNDS, STD_ROUNDS, RW_ROUNDS, TAILS, TAIL_ROUNDS, PACKED_TS, DERIVED, SORTED_REUSE,
-         SHARDED_ROUNDS, SHARD_EXCHANGES, WIN_TABLE_JOBS };
+         SHARDED_ROUNDS, SHARD_EXCHANGES, WIN_TABLE_JOBS, OPEN_PRECOMMIT };
 };
 
 // ------------------------------------------------------------------ context
@@ -157,6 +159,11 @@ struct Ctx {
   std::vector<EqHalfEntry> eq_half_cache;
   bool prof = false;
   std::vector<ProfRec> prof_recs;
+  // helper ctx (same device, own stream / arena / pinned blocks; capi.cpp ctx_helper) and what it is committing ahead of
+  // the opening (prover.cpp open_precommit_*): both owned by this ctx
+  Ctx* helper = nullptr;
+  void* helper_handle = nullptr;
+  void* precommit = nullptr;
   hipEvent_t prof_ev[2] = {nullptr, nullptr};
   void* pin(size_t bytes);  // grows the pinned buffer if needed
   // small device -> host download through a second pinned staging buffer, synchronising: an async copy into
@@ -588,6 +595,8 @@ struct MsmJob {
   uint32_t win_table_c = 0, win_table_W = 0;
 };
 constexpr uint32_t MSM_PACK_MAX_BITS = 20;
+Ctx& ctx_helper(Ctx&);            // the ctx's helper ctx (created on first use, destroyed with the ctx)
+void open_precommit_cancel(Ctx&);  // waits for a running precommit and drops it (prover.cpp)
 uint32_t msm_window_bits(size_t n);  // window width msm_batch picks for a full-width (254-bit) column of n points
 void k_msm_window_table(Ctx&, const G1Affine* bases, size_t n, uint32_t cbits, uint32_t W, G1Affine* out);
 // Runs all jobs as one batched Pippenger; out[j] is the affine sum (identity = (0,0)).

@@ -269,6 +269,11 @@ struct SmallOpen {
   std::vector<const Fr*> merged;
   std::vector<Fr> merged_w;
 };
+// Options::open_precommit: commit the challenge-free half of the coming batch opening's column route on the ctx's helper
+// ctx, starting now (the opening's polys, their small columns and the (poly, point) pairs as mkzg_batch_open will get them;
+// the evaluations' values are not used).  mkzg_open picks the results up when they fit, and commits as before when not.
+void open_precommit_start(Ctx&, const Srs&, size_t num_vars, const SmallPoly* small, size_t num_polys,
+                          const lh_evaluation* evals, size_t num_evals);
 // `open_small` (optional) is called instead of `open` when every opened poly came as a small-valued column
 void additive_batch_open(Ctx&, size_t num_vars, const Fr* const* d_polys, size_t num_polys, const HFr* points,
                          size_t num_points, const lh_evaluation* evals, size_t num_evals, Transcript& tr,
@@ -313,6 +318,9 @@ struct LassoPcs {
   std::function<void(size_t num_vars, const Fr* const* d_polys, size_t num_polys, const HFr* points, size_t num_points,
                      const lh_evaluation* evals, size_t num_evals, Transcript& tr, const SmallPoly* small)>
       batch_open;
+  // optional (multilinear KZG): start committing the challenge-free half of that batch opening now (open_precommit_start)
+  std::function<void(size_t num_vars, const SmallPoly* small, size_t num_polys, const lh_evaluation* evals, size_t num_evals)>
+      precommit;
 };
 LassoPcs lasso_mkzg_pcs(Ctx&, const Srs&);
 LassoPcs lasso_zeromorph_pcs(Ctx&, const USrs&, size_t poly_size);

@@ -21,6 +21,9 @@ LassoPcs lasso_mkzg_pcs(Ctx& c, const Srs& srs) {
                             const lh_evaluation* evals, size_t ne, Transcript& tr, const SmallPoly* small) {
     mkzg_batch_open(c, srs, nv, polys, np, points, npts, evals, ne, tr, small);
   };
+  p.precommit = [&c, &srs](size_t nv, const SmallPoly* small, size_t np, const lh_evaluation* evals, size_t ne) {
+    open_precommit_start(c, srs, nv, small, np, evals, ne);
+  };
   return p;
 }
 LassoPcs lasso_zeromorph_pcs(Ctx& c, const USrs& srs, size_t poly_size) {
@@ -584,6 +587,31 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
   }
   const Fr* const* E_fr = polys_n.data() + 1 + 2 * cc;
 
+  // (poly, point) pairs of the batch opening at the end (step 8): r, r_z, r_N, r_M are points 0..3
+  std::vector<lh_evaluation> evs;
+  {
+    auto push = [&](size_t poly, size_t point) {
+      lh_evaluation e;
+      memset(&e, 0, sizeof(e));
+      e.poly = (uint32_t)poly;
+      e.point = (uint32_t)point;
+      evs.push_back(e);
+    };
+    push(0, 0);
+    for (size_t i = 0; i < alpha; i++) push(1 + 2 * cc + i, 1);
+    for (size_t j = 0; j < cc; j++) push(1 + j, 2);
+    for (size_t j = 0; j < cc; j++) push(1 + cc + j, 2);
+    for (size_t i = 0; i < alpha; i++) push(1 + 2 * cc + i, 2);
+    for (size_t j = 0; j < cc; j++) push(num_n + j, 3);
+  }
+  // the opening's column-wise commitments depend on the witness columns alone: on the helper ctx from here on, beside
+  // the sum-checks (Options::open_precommit)
+  struct PrecommitGuard {  // (a prove that fails on the way drops what was started)
+    Ctx& c;
+    ~PrecommitGuard() { open_precommit_cancel(c); }
+  } precommit_guard{c};
+  if (pcs.precommit && !shn) pcs.precommit(nv, small.data(), small.size(), evs.data(), evs.size());
+
   // ---- 2-7: Surge, memory checking, evaluations
   LassoClaims cl = lasso_argue(c, tb, n, w, d_dims, polys_n[0], E_fr, tr, lap, a_small);
   const std::vector<HFr>&r = cl.r, &r_z = cl.r_z, &r_N = cl.r_N, &r_M = cl.r_M, &ev_n = cl.ev_n, &ev_l = cl.ev_l;
@@ -596,20 +624,15 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
     std::copy(r_z.begin(), r_z.end(), points.begin() + nv);
     std::copy(r_N.begin(), r_N.end(), points.begin() + 2 * nv);
     std::copy(r_M.begin(), r_M.end(), points.begin() + 3 * nv);
-    std::vector<lh_evaluation> evs;
-    auto push = [&](size_t poly, size_t point, const HFr& val) {
-      lh_evaluation e;
-      e.poly = (uint32_t)poly;
-      e.point = (uint32_t)point;
-      memcpy(&e.value, &val, 32);
-      evs.push_back(e);
-    };
-    push(0, 0, v);
-    for (size_t i = 0; i < alpha; i++) push(1 + 2 * cc + i, 1, cl.e_rz[i]);
-    for (size_t j = 0; j < cc; j++) push(1 + j, 2, ev_n[j]);
-    for (size_t j = 0; j < cc; j++) push(1 + cc + j, 2, ev_n[cc + j]);
-    for (size_t i = 0; i < alpha; i++) push(1 + 2 * cc + i, 2, ev_n[2 * cc + i]);
-    for (size_t j = 0; j < cc; j++) push(num_n + j, 3, ev_l[j]);
+    size_t next = 0;
+    auto value = [&](const HFr& val) { memcpy(&evs[next++].value, &val, 32); };  // (in the order the pairs were listed)
+    value(v);
+    for (size_t i = 0; i < alpha; i++) value(cl.e_rz[i]);
+    for (size_t j = 0; j < cc; j++) value(ev_n[j]);
+    for (size_t j = 0; j < cc; j++) value(ev_n[cc + j]);
+    for (size_t i = 0; i < alpha; i++) value(ev_n[2 * cc + i]);
+    for (size_t j = 0; j < cc; j++) value(ev_l[j]);
+    LH_REQUIRE(next == evs.size(), LH_ERR_ARG, "lasso: evaluation list out of step");
     std::vector<const Fr*> all(polys_n);
     all.insert(all.end(), polys_l.begin(), polys_l.end());
     pcs.batch_open(nv, all.data(), all.size(), points.data(), 4, evs.data(), evs.size(), tr, small.data());

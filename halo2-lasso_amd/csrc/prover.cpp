@@ -4,6 +4,8 @@
 #include <algorithm>
 #include <functional>
 #include <chrono>
+#include <memory>
+#include <thread>
 #include "host.hpp"
 
 namespace lh {
@@ -1217,6 +1219,323 @@ const Srs::WinTable* srs_window_table(Ctx& c, const Srs& srs, size_t lvl) {
   return &srs.win_tables[lvl];
 }
 
+// ------------------------------------------------------------------ the challenge-free half of the column route
+// Which columns take part, how wide their differences are, how many levels go column by column and the MSM jobs that
+// commit them depend on the witness columns alone; only the linear combination of the jobs' results uses the batch
+// opening's coefficients and the fold weights.  mkzg_open builds this plan itself - or finds it already committed by
+// open_precommit_start (a helper ctx on its own stream and host thread, beside the GKR phase).
+struct ColTerm {  // result of job `job` (or its second output) times coef[k] * w(sidx) * factor goes into the commitment
+  size_t job;
+  bool second;
+  size_t k, sidx;
+  int factor;  // -1: only the low half is populated (hi - lo = -lo); 1; 65536: the high limb of a 33-bit difference
+};
+struct ColOffset {  // coef[k] * w(sidx) * off: times the level's base sum, subtracted
+  size_t k, sidx;
+  uint64_t off;
+};
+struct ColLevel {
+  size_t level = 0;  // quotient level (number of variables)
+  std::vector<ColTerm> terms;
+  std::vector<ColOffset> offsets;
+  bool need_sum = false;
+  size_t sum_job = (size_t)-1;  // the all-ones MSM when the level's base sum is not cached yet
+  HG1 base_sum;
+};
+struct ColumnPlan {
+  std::vector<uint32_t> ors;  // per column: OR of its entries (a bound when the caller knows the width)
+  size_t depth = 0;           // quotient levels that go column by column
+  std::vector<MsmJob> jobs;
+  std::vector<ColLevel> levels;
+  std::vector<HG1> seconds;   // second outputs of packed jobs (MsmJob::out_second points in here: sized before the jobs)
+};
+static inline uint32_t bits_of_u32(uint32_t v) { return v ? 32u - (uint32_t)__builtin_clz(v) : 0u; }
+
+// ---- which quotient levels go column by column: the largest always; the second largest too when few columns take
+// part.  After d folds the remainder is sum_s w_s g'[s 2^(n-d) + .] over the 2^d settings s of the top d index bits
+// (w_s = the product of x_j or 1 - x_j over those bits), so the quotient of level n-1-d is the same kind of sum of
+// 2^d differences of sub-columns per column: 2^d times the passes of the top level, against ~15 windows.
+static void column_shape(Ctx& c, const std::vector<SmallPoly>& cols, const std::vector<char>& zero, size_t n,
+                         size_t num_vars, size_t cut, ColumnPlan& plan) {
+  const size_t K = cols.size(), half_top = n >> 1;
+  std::vector<uint32_t>& ors = plan.ors;
+  ors.assign(K, 0);
+  std::map<size_t, std::vector<size_t>> by_len;  // one OR pass per column length (normally none: the widths are known)
+  for (size_t k = 0; k < K; k++) {
+    // (every column that can reach past the low half of a sub-column at either depth needs its width)
+    if (cols[k].len <= (half_top >> 1) || zero[k]) continue;
+    if (cols[k].bits) ors[k] = cols[k].bits >= 32 ? 0xffffffffu : (1u << cols[k].bits) - 1u;  // known bound
+    else by_len[cols[k].len].push_back(k);
+  }
+  for (const auto& grp : by_len) {
+    std::vector<const uint32_t*> ptrs;
+    for (size_t k : grp.second) ptrs.push_back(cols[k].ptr);
+    std::vector<uint32_t> o(ptrs.size(), 0);
+    k_or_u32(c, ptrs.data(), ptrs.size(), grp.first, o.data());
+    for (size_t f = 0; f < ptrs.size(); f++) ors[grp.second[f]] = o[f];
+  }
+  size_t passes = 0, narrow_cols = 0;
+  for (size_t k = 0; k < K; k++) {
+    if (cols[k].len <= half_top || zero[k] || !ors[k]) continue;
+    const uint32_t b1 = bits_of_u32(ors[k]) + 1;
+    if (b1 > 32) passes += 2;
+    else if (b1 <= MSM_PACK_MAX_BITS - 4) narrow_cols++;
+    else passes += 1;
+  }
+  passes += (narrow_cols + 1) / 2;
+  const int forced_depth = (int)c.opt.open_small_depth;  // 1 or 2 levels column by column, whatever the shape
+  plan.depth = 1;
+  if (num_vars >= cut + 3 && (forced_depth ? forced_depth >= 2 : 2 * passes <= 10)) plan.depth = 2;
+}
+
+// the MSM jobs of the column-wise levels (difference columns, limbs, packed pairs, the levels' base sums); temporaries
+// from c's arena, kernels on c's stream
+static void column_jobs(Ctx& c, const Srs& srs, const std::vector<SmallPoly>& cols, const std::vector<char>& zero,
+                        size_t num_vars, size_t lsh, bool sharded, const std::function<const G1Affine*(size_t)>& level_bases,
+                        ColumnPlan& plan) {
+  const size_t depth = plan.depth;
+  const std::vector<uint32_t>& ors = plan.ors;
+  std::vector<MsmJob>& jobs = plan.jobs;
+  plan.levels.assign(depth, ColLevel());
+  size_t num_seconds = 0;
+  for (size_t d = 0; d < depth; d++) num_seconds += cols.size() << d;
+  plan.seconds.assign(num_seconds, HG1());
+  size_t next_second = 0;
+  for (size_t d = 0; d < depth; d++) {
+    ColLevel& cl = plan.levels[d];
+    cl.level = num_vars - 1 - d;
+    const size_t half = (size_t)1 << (cl.level - lsh);
+    const G1Affine* bases = level_bases(cl.level);
+    struct Narrow {
+      uint32_t bits;  // of the shifted difference
+      uint32_t* col;
+      size_t k, sidx;
+    };
+    std::vector<Narrow> narrow;
+    for (size_t sidx = 0; sidx < ((size_t)1 << d); sidx++) {
+      const size_t off_idx = sidx << (cl.level + 1 - lsh);
+      for (size_t k = 0; k < cols.size(); k++) {
+        const SmallPoly& sp = cols[k];
+        if (zero[k] || sp.len <= off_idx) continue;
+        const uint32_t* sub = sp.ptr + off_idx;
+        const size_t sub_len = std::min(sp.len - off_idx, half << 1);
+        if (sub_len <= half) {  // only the low half is populated: hi - lo = -lo, no offset
+          jobs.push_back(MsmJob{sub, true, bases, sub_len});
+          if (sp.bits) jobs.back().known_bits = sp.bits;
+          cl.terms.push_back(ColTerm{jobs.size() - 1, false, k, sidx, -1});
+          continue;
+        }
+        const uint32_t b = bits_of_u32(ors[k]);
+        if (!b) continue;  // an all-zero column
+        const uint64_t off = (uint64_t)1 << b;
+        cl.offsets.push_back(ColOffset{k, sidx, off});
+        cl.need_sum = true;
+        if (b + 1 > 32) {  // 33-bit shifted differences: a 16-bit limb and a 17-bit limb
+          uint32_t* lo = c.arena.alloc_n<uint32_t>(half);
+          uint32_t* hi = c.arena.alloc_n<uint32_t>(half);
+          k_delta_u32(c, sub, sub_len, half, off, lo, hi);
+          jobs.push_back(MsmJob{lo, true, bases, half});
+          jobs.back().known_bits = 16;
+          cl.terms.push_back(ColTerm{jobs.size() - 1, false, k, sidx, 1});
+          jobs.push_back(MsmJob{hi, true, bases, half});
+          jobs.back().known_bits = b + 1 - 16;
+          cl.terms.push_back(ColTerm{jobs.size() - 1, false, k, sidx, 65536});
+          continue;
+        }
+        uint32_t* dcol = c.arena.alloc_n<uint32_t>(half);
+        k_delta_u32(c, sub, sub_len, half, off, dcol, nullptr);
+        if (b + 1 <= MSM_PACK_MAX_BITS - 4) {
+          narrow.push_back(Narrow{b + 1, dcol, k, sidx});
+        } else {
+          jobs.push_back(MsmJob{dcol, true, bases, half});
+          jobs.back().known_bits = b + 1;
+          cl.terms.push_back(ColTerm{jobs.size() - 1, false, k, sidx, 1});
+        }
+      }
+    }
+    // narrow columns two by two (narrowest first) while the packed value stays within MSM_PACK_MAX_BITS
+    std::stable_sort(narrow.begin(), narrow.end(), [](const Narrow& x, const Narrow& y) { return x.bits < y.bits; });
+    for (size_t i = 0; i < narrow.size(); i++) {
+      const Narrow& x = narrow[i];
+      const uint32_t shift = std::max(x.bits, 4u);
+      if (i + 1 < narrow.size() && shift + narrow[i + 1].bits <= MSM_PACK_MAX_BITS) {
+        const Narrow& y = narrow[i + 1];
+        uint32_t* packed = c.arena.alloc_n<uint32_t>(half);
+        k_pack_u32(c, x.col, y.col, shift, half, packed);
+        MsmJob jb{packed, true, bases, half};
+        jb.pack_shift = shift;
+        jb.known_bits = shift + y.bits;
+        jb.out_second = (G1Affine*)&plan.seconds[next_second++];
+        jobs.push_back(jb);
+        cl.terms.push_back(ColTerm{jobs.size() - 1, false, x.k, x.sidx, 1});
+        cl.terms.push_back(ColTerm{jobs.size() - 1, true, y.k, y.sidx, 1});
+        i++;
+      } else {
+        jobs.push_back(MsmJob{x.col, true, bases, half});
+        jobs.back().known_bits = x.bits;
+        cl.terms.push_back(ColTerm{jobs.size() - 1, false, x.k, x.sidx, 1});
+      }
+    }
+    // the level's base sum (an MSM with all-one scalars, once per SRS and level)
+    if (cl.need_sum) {
+      std::lock_guard<std::mutex> lock(level_sums_mu);
+      std::map<size_t, HG1>& sums = sharded ? srs.shard_level_sums : srs.level_sums;  // (sharded: of this rank's share)
+      auto it = sums.find(cl.level);
+      if (it != sums.end()) {
+        cl.base_sum = it->second;
+      } else {
+        uint32_t* ones = c.arena.alloc_n<uint32_t>(half);
+        k_fill_u32(c, ones, 1u, half);
+        jobs.push_back(MsmJob{ones, true, bases, half});
+        jobs.back().known_bits = 1;
+        cl.sum_job = jobs.size() - 1;
+      }
+    }
+  }
+}
+// after the jobs ran: the levels' base sums that were computed go into the SRS's cache
+static void column_sums_store(const Srs& srs, bool sharded, ColumnPlan& plan, const HG1* out) {
+  for (ColLevel& cl : plan.levels)
+    if (cl.sum_job != (size_t)-1) {
+      cl.base_sum = out[cl.sum_job];
+      std::lock_guard<std::mutex> lock(level_sums_mu);
+      (sharded ? srs.shard_level_sums : srs.level_sums)[cl.level] = cl.base_sum;
+    }
+}
+
+// does an opening over these columns take the column route (mkzg_open's gating, on the local sizes)
+static bool column_route_on(const Ctx& c, const std::vector<SmallPoly>& cols, const std::vector<char>& zero, size_t num_vars,
+                            size_t lsh, size_t n, bool sharded, size_t cut) {
+  if (num_vars - lsh < (size_t)c.opt.open_small_min_vars) {
+    // below the general threshold the route still pays when only a few columns take part (the range check: two dim
+    // and two read_ts columns - 2^20 lookups 11.7 -> 11.0 ms; the AND table's twelve columns lose there)
+    size_t full = 0;
+    for (size_t k = 0; k < cols.size(); k++) full += cols[k].len > (n >> 1) && !zero[k];
+    if (!(num_vars - lsh >= 17 && full <= 4 && !c.opt.open_small_min_vars_forced)) return false;
+  }
+  if (num_vars < 2 || cols.empty()) return false;
+  if (sharded && num_vars < cut + 2) return false;  // (the column-wise levels must be sharded ones)
+  return true;
+}
+
+// ---- the plan committed ahead (Options::open_precommit): the helper ctx builds the same plan from the same columns and
+// runs its jobs on its own stream, driven by its own host thread, while the ctx goes through the sum-checks.  mkzg_open
+// takes the results only if columns, widths and depth are what it arrives at itself; otherwise it commits as before.
+struct OpenPrecommit {
+  std::thread th;
+  const Srs* srs = nullptr;
+  size_t num_vars = 0;
+  std::vector<SmallPoly> cols;
+  std::vector<char> zero;
+  ColumnPlan plan;
+  std::vector<HG1> out;
+  bool ok = false;
+  std::string err;
+  ~OpenPrecommit() {
+    if (th.joinable()) th.join();
+  }
+};
+void open_precommit_cancel(Ctx& c) {
+  if (!c.precommit) return;
+  delete (OpenPrecommit*)c.precommit;  // (joins)
+  c.precommit = nullptr;
+}
+// the columns of a batch opening whose polys are all small-valued columns: `used` polys, a linear column's coefficient
+// handed to the columns it combines, the same column under two names merged.  coef == nullptr: the structure alone
+// (every column that survives gets coefficient one)
+static bool small_open_columns(const SmallPoly* small, size_t num_polys, const lh_evaluation* evals, size_t num_evals,
+                               size_t n, const HFr* coef_in, SmallOpen& so) {
+  for (size_t i = 0; i < num_evals; i++)
+    if (evals[i].poly >= num_polys || !small[evals[i].poly].ptr) return false;
+  std::vector<HFr> coef(num_polys, HFr::zero());
+  std::vector<char> used(num_polys, 0);
+  for (size_t i = 0; i < num_evals; i++) {
+    coef[evals[i].poly] = coef_in ? coef_in[evals[i].poly] : HFr::one();
+    used[evals[i].poly] = 1;
+  }
+  // a column that is a linear combination of other opened columns hands its coefficient over to them
+  for (size_t pi = 0; pi < num_polys; pi++) {
+    const SmallLinear* lin = small[pi].linear;
+    if (!used[pi] || !lin) continue;
+    bool ok = !lin->poly.empty() && lin->poly.size() == lin->coeff.size();
+    for (size_t k = 0; k < lin->poly.size() && ok; k++) ok = lin->poly[k] < num_polys && lin->poly[k] != pi && used[lin->poly[k]];
+    if (!ok) continue;
+    if (coef_in)
+      for (size_t k = 0; k < lin->poly.size(); k++) coef[lin->poly[k]] += coef[pi] * lin->coeff[k];
+    coef[pi] = HFr::zero();
+    used[pi] = 0;
+  }
+  for (size_t pi = 0; pi < num_polys; pi++) {
+    if (!used[pi]) continue;
+    const SmallPoly sp{small[pi].ptr, std::min(small[pi].len, n), small[pi].bits};
+    size_t k = 0;  // the same column under two names (Lasso's E = dim for an identity subtable): one coefficient
+    while (k < so.cols.size() && !(so.cols[k].ptr == sp.ptr && so.cols[k].len == sp.len)) k++;
+    if (k < so.cols.size()) {
+      if (coef_in) so.coef[k] += coef[pi];
+      so.cols[k].bits = so.cols[k].bits && sp.bits ? std::max(so.cols[k].bits, sp.bits) : 0;
+    } else {
+      so.cols.push_back(sp), so.coef.push_back(coef[pi]);
+    }
+  }
+  return true;
+}
+void open_precommit_start(Ctx& c, const Srs& srs, size_t num_vars, const SmallPoly* small, size_t num_polys,
+                          const lh_evaluation* evals, size_t num_evals) {
+  open_precommit_cancel(c);
+  if (!c.opt.open_precommit || c.shard_active || !small || num_vars > srs.num_vars) return;
+  const size_t n = (size_t)1 << num_vars;
+  SmallOpen so;
+  if (!small_open_columns(small, num_polys, evals, num_evals, n, nullptr, so)) return;
+  std::vector<char> zero(so.cols.size(), 0);
+  if (!column_route_on(c, so.cols, zero, num_vars, 0, n, false, 0)) return;
+  Ctx& h = ctx_helper(c);
+  h.opt = c.opt;
+  h.prof = c.prof;
+  h.prof_recs.clear();
+  OpenPrecommit* pc = new OpenPrecommit();
+  pc->srs = &srs, pc->num_vars = num_vars, pc->cols = so.cols, pc->zero = zero;
+  c.precommit = pc;
+  c.sync();  // the witness columns are written by kernels queued on this ctx's stream: the helper's stream reads them
+  const int device = c.device;
+  pc->th = std::thread([pc, &h, &srs, num_vars, n, device] {
+    try {
+      LH_HIP(hipSetDevice(device));
+      ArenaScope scope(h.arena);
+      column_shape(h, pc->cols, pc->zero, n, num_vars, 0, pc->plan);
+      column_jobs(h, srs, pc->cols, pc->zero, num_vars, 0, false, [&srs](size_t lvl) { return srs.eq(lvl); }, pc->plan);
+      pc->out.resize(pc->plan.jobs.size());
+      if (!pc->plan.jobs.empty()) msm_batch(h, pc->plan.jobs.data(), pc->plan.jobs.size(), (G1Affine*)pc->out.data());
+      h.sync();
+      column_sums_store(srs, false, pc->plan, pc->out.data());
+      pc->ok = true;
+    } catch (const std::exception& e) {
+      pc->err = e.what();
+    } catch (...) {
+      pc->err = "unknown error";
+    }
+  });
+  if (c.prof) pc->th.join();  // a profiled prove keeps its kernels one at a time (the records are merged when taken)
+}
+// the precommitted plan if it is the plan this opening would build (same SRS, columns, zero pattern, widths, depth)
+static std::unique_ptr<OpenPrecommit> open_precommit_take(Ctx& c, const Srs& srs, size_t num_vars,
+                                                          const std::vector<SmallPoly>& cols, const std::vector<char>& zero,
+                                                          const ColumnPlan& own) {
+  std::unique_ptr<OpenPrecommit> pc((OpenPrecommit*)c.precommit);
+  c.precommit = nullptr;
+  if (!pc) return nullptr;
+  if (pc->th.joinable()) pc->th.join();
+  if (c.prof && c.helper) {
+    c.prof_recs.insert(c.prof_recs.end(), c.helper->prof_recs.begin(), c.helper->prof_recs.end());
+    c.helper->prof_recs.clear();
+  }
+  bool same = pc->ok && pc->srs == &srs && pc->num_vars == num_vars && pc->cols.size() == cols.size() && pc->zero == zero &&
+              pc->plan.depth == own.depth && pc->plan.ors == own.ors;
+  for (size_t k = 0; same && k < cols.size(); k++)
+    same = pc->cols[k].ptr == cols[k].ptr && pc->cols[k].len == cols[k].len && pc->cols[k].bits == cols[k].bits;
+  if (!same) return nullptr;
+  return pc;
+}
+
 // Inside a sharded proof (dev.hpp Shard) `d_poly` / the small columns are this rank's shards.  The quotient of level i
 // is a difference of halves - the top index bit, local to a shard while i >= shard_bit + rho: those levels are computed
 // and committed shard by shard against this rank's share of the level's bases (the chunk-split-then-sum of
@@ -1228,21 +1547,17 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
   const Shard sh(c);
   const bool sharded = sh.sharded(num_vars);
   const size_t cut = sharded ? sh.j + sh.rho : 0;  // quotient levels >= cut are held in shards
-  const size_t small_min_vars = (size_t)c.opt.open_small_min_vars;  // smallest opening that takes the column route (64: never)
   const SmallOpen* given = small;
   const size_t lsh = sharded ? sh.rho : 0;        // local length of level i: 2^(i - lsh), i >= cut
   const size_t n = (size_t)1 << (num_vars - lsh);  // entries of the (local) table
   // (which route an opening takes is decided per rank on its local sizes: every route yields the commitment of the rank's
   // shard of each quotient, so ranks may even differ)
-  if (small && num_vars - lsh < small_min_vars) {
-    // below the general threshold the route still pays when only a few columns take part (the range check: two dim
-    // and two read_ts columns - 2^20 lookups 11.7 -> 11.0 ms; the AND table's twelve columns lose there)
-    size_t full = 0;
-    for (size_t k = 0; k < small->cols.size(); k++) full += small->cols[k].len > (n >> 1) && !small->coef[k].is_zero();
-    if (!(num_vars - lsh >= 17 && full <= 4 && !c.opt.open_small_min_vars_forced)) small = nullptr;
+  if (small) {
+    std::vector<char> z(small->cols.size());
+    for (size_t k = 0; k < z.size(); k++) z[k] = small->coef[k].is_zero();
+    if (!column_route_on(c, small->cols, z, num_vars, lsh, n, sharded, cut)) small = nullptr;
   }
-  if (small && (num_vars < 2 || small->cols.empty())) small = nullptr;
-  if (small && sharded && num_vars < cut + 2) small = nullptr;  // (the column-wise levels must be sharded ones)
+  if (!small) open_precommit_cancel(c);  // (whatever was committed ahead is not what this opening needs)
   ArenaScope scope(c.arena);
   if (!d_poly) {
     LH_REQUIRE(given && !given->merged.empty(), LH_ERR_ARG, "open: no polynomial");
@@ -1252,42 +1567,15 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
       d_poly = g;
     }
   }
-  // ---- which quotient levels go column by column: the largest always; the second largest too when few columns take
-  // part.  After d folds the remainder is sum_s w_s g'[s 2^(n-d) + .] over the 2^d settings s of the top d index bits
-  // (w_s = the product of x_j or 1 - x_j over those bits), so the quotient of level n-1-d is the same kind of sum of
-  // 2^d differences of sub-columns per column: 2^d times the passes of the top level, against ~15 windows.
-  auto bits_of = [](uint32_t v) { return v ? 32u - (uint32_t)__builtin_clz(v) : 0u; };
+  // ---- the challenge-free half of the column route (column_shape / column_jobs above)
   size_t depth = 0;
-  std::vector<uint32_t> ors;
+  ColumnPlan own;
+  std::vector<char> zero;
   if (small) {
-    const size_t K = small->cols.size(), half_top = n >> 1;
-    ors.assign(K, 0);
-    std::map<size_t, std::vector<size_t>> by_len;  // one OR pass per column length (normally none: the widths are known)
-    for (size_t k = 0; k < K; k++) {
-      // (every column that can reach past the low half of a sub-column at either depth needs its width)
-      if (small->cols[k].len <= (half_top >> 1) || small->coef[k].is_zero()) continue;
-      if (small->cols[k].bits) ors[k] = small->cols[k].bits >= 32 ? 0xffffffffu : (1u << small->cols[k].bits) - 1u;  // known bound
-      else by_len[small->cols[k].len].push_back(k);
-    }
-    for (const auto& grp : by_len) {
-      std::vector<const uint32_t*> ptrs;
-      for (size_t k : grp.second) ptrs.push_back(small->cols[k].ptr);
-      std::vector<uint32_t> o(ptrs.size(), 0);
-      k_or_u32(c, ptrs.data(), ptrs.size(), grp.first, o.data());
-      for (size_t f = 0; f < ptrs.size(); f++) ors[grp.second[f]] = o[f];
-    }
-    size_t passes = 0, narrow_cols = 0;
-    for (size_t k = 0; k < K; k++) {
-      if (small->cols[k].len <= half_top || small->coef[k].is_zero() || !ors[k]) continue;
-      const uint32_t b1 = bits_of(ors[k]) + 1;
-      if (b1 > 32) passes += 2;
-      else if (b1 <= MSM_PACK_MAX_BITS - 4) narrow_cols++;
-      else passes += 1;
-    }
-    passes += (narrow_cols + 1) / 2;
-    const int forced_depth = (int)c.opt.open_small_depth;  // 1 or 2 levels column by column, whatever the shape
-    depth = 1;
-    if (num_vars >= cut + 3 && (forced_depth ? forced_depth >= 2 : 2 * passes <= 10)) depth = 2;
+    zero.resize(small->cols.size());
+    for (size_t k = 0; k < zero.size(); k++) zero[k] = small->coef[k].is_zero();
+    column_shape(c, small->cols, zero, n, num_vars, cut, own);
+    depth = own.depth;
   }
   // development (LH_OPEN_SMALL_CHECK): the column-wise levels whose quotient exists are committed the plain way too and
   // compared (stderr)
@@ -1349,128 +1637,24 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
       if (const Srs::WinTable* wt = srs_window_table(c, srs, i))
         jobs[i].win_table = wt->d, jobs[i].win_table_c = wt->c, jobs[i].win_table_W = wt->W;
   }
-  // ---- the column-wise levels
-  struct Term {     // result of job `job` (or its second output), times `scale`, goes into the commitment
-    size_t job;
-    bool second;
-    HFr scale;
-  };
-  struct ColumnLevel {
-    size_t level = 0;             // quotient level (number of variables)
-    std::vector<Term> terms;
-    HFr offset_total;             // sum coef * offset: times the level's base sum, subtracted
-    bool need_sum = false;
-    size_t sum_job = (size_t)-1;  // the all-ones MSM when the level's base sum is not cached yet
-    HG1 base_sum;
-  };
-  std::vector<ColumnLevel> col_levels(depth);
-  std::vector<HG1> seconds;
-  seconds.reserve(64);
-  size_t num_seconds = 0;
-  for (size_t d = 0; d < depth; d++) num_seconds += small->cols.size() << d;
-  seconds.resize(num_seconds);
-  size_t next_second = 0;
-  for (size_t d = 0; d < depth; d++) {
-    ColumnLevel& cl = col_levels[d];
-    cl.level = num_vars - 1 - d;
-    cl.offset_total = HFr::zero();
-    const size_t half = (size_t)1 << (cl.level - lsh);
-    const G1Affine* bases = level_bases(cl.level);
-    struct Narrow {
-      uint32_t bits;  // of the shifted difference
-      uint32_t* col;
-      HFr coef;
-    };
-    std::vector<Narrow> narrow;
-    for (size_t sidx = 0; sidx < ((size_t)1 << d); sidx++) {
-      // weight of this setting of the top d index bits (bit n-1-j of the index is bit d-1-j of sidx)
-      HFr w_s = HFr::one();
-      for (size_t j = 0; j < d; j++) {
-        const HFr& xj = point[num_vars - 1 - j];
-        w_s *= ((sidx >> (d - 1 - j)) & 1) ? xj : HFr::one() - xj;
-      }
-      const size_t off_idx = sidx << (cl.level + 1 - lsh);
-      for (size_t k = 0; k < small->cols.size(); k++) {
-        const SmallPoly& sp = small->cols[k];
-        if (small->coef[k].is_zero() || sp.len <= off_idx) continue;
-        const HFr co = small->coef[k] * w_s;
-        const uint32_t* sub = sp.ptr + off_idx;
-        const size_t sub_len = std::min(sp.len - off_idx, half << 1);
-        if (sub_len <= half) {  // only the low half is populated: hi - lo = -lo, no offset
-          jobs.push_back(MsmJob{sub, true, bases, sub_len});
-          if (sp.bits) jobs.back().known_bits = sp.bits;
-          cl.terms.push_back(Term{jobs.size() - 1, false, HFr::zero() - co});
-          continue;
-        }
-        const uint32_t b = bits_of(ors[k]);
-        if (!b) continue;  // an all-zero column
-        const uint64_t off = (uint64_t)1 << b;
-        cl.offset_total += co * HFr::from_u64(off);
-        cl.need_sum = true;
-        if (b + 1 > 32) {  // 33-bit shifted differences: a 16-bit limb and a 17-bit limb
-          uint32_t* lo = c.arena.alloc_n<uint32_t>(half);
-          uint32_t* hi = c.arena.alloc_n<uint32_t>(half);
-          k_delta_u32(c, sub, sub_len, half, off, lo, hi);
-          jobs.push_back(MsmJob{lo, true, bases, half});
-          jobs.back().known_bits = 16;
-          cl.terms.push_back(Term{jobs.size() - 1, false, co});
-          jobs.push_back(MsmJob{hi, true, bases, half});
-          jobs.back().known_bits = b + 1 - 16;
-          cl.terms.push_back(Term{jobs.size() - 1, false, co * HFr::from_u64(65536)});
-          continue;
-        }
-        uint32_t* dcol = c.arena.alloc_n<uint32_t>(half);
-        k_delta_u32(c, sub, sub_len, half, off, dcol, nullptr);
-        if (b + 1 <= MSM_PACK_MAX_BITS - 4) {
-          narrow.push_back(Narrow{b + 1, dcol, co});
-        } else {
-          jobs.push_back(MsmJob{dcol, true, bases, half});
-          jobs.back().known_bits = b + 1;
-          cl.terms.push_back(Term{jobs.size() - 1, false, co});
-        }
-      }
-    }
-    // narrow columns two by two (narrowest first) while the packed value stays within MSM_PACK_MAX_BITS
-    std::stable_sort(narrow.begin(), narrow.end(), [](const Narrow& x, const Narrow& y) { return x.bits < y.bits; });
-    for (size_t i = 0; i < narrow.size(); i++) {
-      const Narrow& x = narrow[i];
-      const uint32_t shift = std::max(x.bits, 4u);
-      if (i + 1 < narrow.size() && shift + narrow[i + 1].bits <= MSM_PACK_MAX_BITS) {
-        const Narrow& y = narrow[i + 1];
-        uint32_t* packed = c.arena.alloc_n<uint32_t>(half);
-        k_pack_u32(c, x.col, y.col, shift, half, packed);
-        MsmJob jb{packed, true, bases, half};
-        jb.pack_shift = shift;
-        jb.known_bits = shift + y.bits;
-        jb.out_second = (G1Affine*)&seconds[next_second++];
-        jobs.push_back(jb);
-        cl.terms.push_back(Term{jobs.size() - 1, false, x.coef});
-        cl.terms.push_back(Term{jobs.size() - 1, true, y.coef});
-        i++;
-      } else {
-        jobs.push_back(MsmJob{x.col, true, bases, half});
-        jobs.back().known_bits = x.bits;
-        cl.terms.push_back(Term{jobs.size() - 1, false, x.coef});
-      }
-    }
-    // the level's base sum (an MSM with all-one scalars, once per SRS and level)
-    if (cl.need_sum) {
-      std::lock_guard<std::mutex> lock(level_sums_mu);
-      std::map<size_t, HG1>& sums = sharded ? srs.shard_level_sums : srs.level_sums;  // (sharded: of this rank's share)
-      auto it = sums.find(cl.level);
-      if (it != sums.end()) {
-        cl.base_sum = it->second;
-      } else {
-        uint32_t* ones = c.arena.alloc_n<uint32_t>(half);
-        k_fill_u32(c, ones, 1u, half);
-        jobs.push_back(MsmJob{ones, true, bases, half});
-        jobs.back().known_bits = 1;
-        cl.sum_job = jobs.size() - 1;
-      }
+  // ---- the column-wise levels: committed ahead by open_precommit_start (same columns, widths and depth), or here
+  const ColumnPlan* plan = nullptr;
+  const std::vector<HG1>* pre_out = nullptr;
+  std::unique_ptr<OpenPrecommit> pre;
+  if (small) {
+    pre = open_precommit_take(c, srs, num_vars, small->cols, zero, own);
+    if (pre) {
+      plan = &pre->plan, pre_out = &pre->out;
+    } else {
+      column_jobs(c, srs, small->cols, zero, num_vars, lsh, sharded, level_bases, own);
+      plan = &own;
     }
   }
+  const size_t col_base = jobs.size();  // (index of the plan's first job in this batch, when it runs here)
+  if (plan && !pre_out) jobs.insert(jobs.end(), plan->jobs.begin(), plan->jobs.end());
   c.route.v[RouteStats::OPEN_DEPTH] = (uint32_t)depth;
-  c.route.v[RouteStats::OPEN_PASSES] = (uint32_t)(jobs.size() - plain);
+  c.route.v[RouteStats::OPEN_PASSES] = (uint32_t)(plan ? plan->jobs.size() : 0);
+  c.route.v[RouteStats::OPEN_PRECOMMIT] = pre_out ? 1u : 0u;
   const size_t check_base = jobs.size();
   if (self_check)
     for (size_t d = check_from; d < depth; d++) {
@@ -1480,24 +1664,30 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
   std::vector<HG1> out(jobs.size());
   msm_batch(c, jobs.data(), jobs.size(), (G1Affine*)out.data());
   std::vector<HG1> comms(out.begin(), out.begin() + plain);
+  if (plan && !pre_out) column_sums_store(srs, sharded, own, out.data() + col_base);
   for (size_t d = depth; d-- > 0;) {  // levels in ascending order after the plain ones
-    ColumnLevel& cl = col_levels[d];
-    if (cl.sum_job != (size_t)-1) {
-      cl.base_sum = out[cl.sum_job];
-      std::lock_guard<std::mutex> lock(level_sums_mu);
-      (sharded ? srs.shard_level_sums : srs.level_sums)[cl.level] = cl.base_sum;
-    }
+    const ColLevel& cl = plan->levels[d];
+    // weights of the settings of the top d index bits (bit n-1-j of the index is bit d-1-j of sidx)
+    std::vector<HFr> w_s((size_t)1 << d, HFr::one());
+    for (size_t sidx = 0; sidx < w_s.size(); sidx++)
+      for (size_t j = 0; j < d; j++) {
+        const HFr& xj = point[num_vars - 1 - j];
+        w_s[sidx] *= ((sidx >> (d - 1 - j)) & 1) ? xj : HFr::one() - xj;
+      }
     // commitment = sum_t scale_t * result_t - offset_total * base sum  (scalar multiplications on the host's threads)
     std::vector<HG1> pts(cl.terms.size() + 1);
     std::vector<HFr> scal(cl.terms.size() + 1);
     for (size_t t = 0; t < cl.terms.size(); t++) {
-      const Term& tm = cl.terms[t];
-      if (tm.second) memcpy(&pts[t], jobs[tm.job].out_second, sizeof(HG1));
-      else pts[t] = out[tm.job];
-      scal[t] = tm.scale;
+      const ColTerm& tm = cl.terms[t];
+      if (tm.second) memcpy(&pts[t], plan->jobs[tm.job].out_second, sizeof(HG1));
+      else pts[t] = pre_out ? (*pre_out)[tm.job] : out[col_base + tm.job];
+      const HFr co = small->coef[tm.k] * w_s[tm.sidx];
+      scal[t] = tm.factor == -1 ? HFr::zero() - co : tm.factor == 1 ? co : co * HFr::from_u64((uint64_t)tm.factor);
     }
+    HFr offset_total = HFr::zero();
+    for (const ColOffset& o : cl.offsets) offset_total += small->coef[o.k] * w_s[o.sidx] * HFr::from_u64(o.off);
     pts[cl.terms.size()] = cl.need_sum ? cl.base_sum : HG1{host::Fq::zero(), host::Fq::zero()};
-    scal[cl.terms.size()] = HFr::zero() - cl.offset_total;
+    scal[cl.terms.size()] = HFr::zero() - offset_total;
     std::vector<host::G1Xyzz> parts(pts.size(), host::G1Xyzz::identity());
     host_parallel_for(pts.size(), [&](size_t t) {
       if (!pts[t].is_identity() && !scal[t].is_zero()) parts[t] = host::g1_mul(host::g1_from_affine(pts[t]), scal[t]);
@@ -1592,43 +1782,16 @@ void additive_batch_open(Ctx& c, size_t num_vars, const Fr* const* d_polys, size
   for (size_t j = 0; j < num_points; j++)
     w[j] = dev(host_eq_xy_eval(sc.challenges.data(), points + j * num_vars, num_vars));
   // every opened poly a small-valued column: g' = sum_p coef_p col_p with coef_p = sum_{i: poly(i) = p} eq_xt[i] w[point(i)]
-  bool all_small = open_small != nullptr && small != nullptr;
-  for (size_t i = 0; i < num_evals && all_small; i++) all_small = small[evals[i].poly].ptr != nullptr;
-  if (all_small) {
+  if (open_small != nullptr && small != nullptr) {
     std::vector<HFr> coef(num_polys, HFr::zero());
-    std::vector<char> used(num_polys, 0);
-    for (size_t i = 0; i < num_evals; i++) {
-      coef[evals[i].poly] += eq_xt[i] * hst(w[evals[i].point]);
-      used[evals[i].poly] = 1;
-    }
-    // a column that is a linear combination of other opened columns hands its coefficient over to them
-    for (size_t pi = 0; pi < num_polys; pi++) {
-      const SmallLinear* lin = small[pi].linear;
-      if (!used[pi] || !lin) continue;
-      bool ok = !lin->poly.empty() && lin->poly.size() == lin->coeff.size();
-      for (size_t k = 0; k < lin->poly.size() && ok; k++) ok = lin->poly[k] < num_polys && lin->poly[k] != pi && used[lin->poly[k]];
-      if (!ok) continue;
-      for (size_t k = 0; k < lin->poly.size(); k++) coef[lin->poly[k]] += coef[pi] * lin->coeff[k];
-      coef[pi] = HFr::zero();
-      used[pi] = 0;
-    }
+    for (size_t i = 0; i < num_evals; i++) coef[evals[i].poly] += eq_xt[i] * hst(w[evals[i].point]);
     SmallOpen so;
-    for (size_t pi = 0; pi < num_polys; pi++) {
-      if (!used[pi]) continue;
-      const SmallPoly sp{small[pi].ptr, std::min(small[pi].len, n), small[pi].bits};
-      size_t k = 0;  // the same column under two names (Lasso's E = dim for an identity subtable): one coefficient
-      while (k < so.cols.size() && !(so.cols[k].ptr == sp.ptr && so.cols[k].len == sp.len)) k++;
-      if (k < so.cols.size()) {
-        so.coef[k] += coef[pi];
-        so.cols[k].bits = so.cols[k].bits && sp.bits ? std::max(so.cols[k].bits, sp.bits) : 0;
-      } else {
-        so.cols.push_back(sp), so.coef.push_back(coef[pi]);
-      }
+    if (small_open_columns(small, num_polys, evals, num_evals, n, coef.data(), so)) {
+      so.merged = merged;
+      so.merged_w = w;
+      open_small(nullptr, sc.challenges.data(), so);  // (g' is formed by the opening if it needs it)
+      return;
     }
-    so.merged = merged;
-    so.merged_w = w;
-    open_small(nullptr, sc.challenges.data(), so);  // (g' is formed by the opening if it needs it)
-    return;
   }
   Fr* g_prime = c.arena.alloc_n<Fr>(n);
   k_lincomb(c, merged.data(), w.data(), num_points, n, g_prime);

@@ -257,6 +257,9 @@ lh_status lh_lasso_last_timing(lh_ctx*, double* out_ms);
  *   sc_tail_max_len      8192 longest table (entries) that enters the resident tail
  *   shard_exchange_log   17   sharded proofs: a sum-check goes on replicated once its residual tables hold <= 2^this
  *                             entries together (one all-gather), at the latest when the shard bits reach bit 0
+ *   open_precommit       1    1: the column-wise quotient commitments of a Lasso proof's opening - MSMs over differences of
+ *                             witness columns, challenge-free - run on a helper ctx (own stream and host thread) beside the
+ *                             Surge and memory-checking sum-checks; the opening then only combines their results
  *   msm_window_tables    0    SRS levels of <= 2^this points get a window table on first use (2^(c w) multiples of every
  *                             base, W-fold the level's memory): the W windows of a full-width column then fill ONE
  *                             bucket set - one bucket reduction, no doublings.  Measured neutral at 2^24 lookups (shorter
@@ -280,7 +283,8 @@ typedef struct lh_lasso_route {
   uint32_t sharded_rounds;      /* rounds that carried a collective (sharded proofs) */
   uint32_t shard_exchanges;     /* residual-table / tree-level / remainder exchanges (sharded proofs) */
   uint32_t window_table_jobs;   /* MSM jobs that ran over a window table (msm_window_tables) */
-  uint32_t reserved[3];
+  uint32_t open_precommit;      /* 1: the opening's column-wise commitments were taken from the helper ctx (open_precommit) */
+  uint32_t reserved[2];
 } lh_lasso_route;
 lh_status lh_lasso_last_route(lh_ctx*, lh_lasso_route* out);
 

@@ -119,7 +119,12 @@ def test_route_options_change_the_route_not_the_bytes(hl, srs17):
             return t.into_proof(), hl.lasso_last_route(ctx)
         proof, route = prove()
         assert proof == want and route["open_small_depth"] >= 1 and route["eq_factored_rounds"] > 0 and route["resident_tails"] > 0
+        assert route["open_precommit"] == 1      # the column-wise commitments came from the helper ctx, beside the sum-checks
         assert hl.get_option(ctx, "open_small_min_vars") == 21 and hl.get_option(ctx, "sc_eq_factoring") == 1
+        hl.set_option(ctx, "open_precommit", 0)
+        proof, route = prove()
+        assert proof == want and route["open_precommit"] == 0 and route["open_small_depth"] >= 1
+        hl.set_option(ctx, "open_precommit", 1)
         hl.set_option(ctx, "open_small_min_vars", 64)
         proof, route = prove()
         assert proof == want and route["open_small_depth"] == 0 and route["open_small_passes"] == 0
@@ -362,6 +367,7 @@ def test_lasso_default_route_at_2p21_matches_cpp_oracle(hl, ctx, srs22, kind, n)
     route = hl.lasso_last_route(ctx)
     assert route["open_small_depth"] == (2 if kind == "range" else 1) and route["open_small_passes"] >= 3, route
     assert route["eq_factored_rounds"] > 0 and route["rw_leaf_rounds"] > 0, route
+    assert route["open_precommit"] == 1, route  # (those column-wise commitments ran on the helper ctx, beside the sum-checks)
     if kind != "range":
         assert route["derived_commitments"] == 4 and route["packed_ts_pairs"] >= 1, route  # (a skewed column has wide counts)
 
