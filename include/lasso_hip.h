@@ -15,7 +15,9 @@
  *    plonkish_backend::Error (plonkish_backend/src/lib.rs:12-20).  lh_last_error() gives the
  *    message of the last failure on the calling thread.
  *  - One ctx per process per GPU; calls on one ctx are not re-entrant (the reference calls
- *    `prove` from one thread and fans out on rayon, util/parallel.rs:9-46).
+ *    `prove` from one thread and fans out on rayon, util/parallel.rs:9-46).  A ctx may start host threads of its own and a
+ *    helper ctx on the same device (second stream, own arena and pinned blocks: lh_lasso_prove commits the challenge-free
+ *    part of its opening there, option open_precommit); both end with the call that started them / with lh_ctx_destroy.
  *  - There is NO CPU fallback: without a usable HIP device lh_ctx_create fails with
  *    LH_ERR_DEVICE and nothing else can be called.
  *  - Every entry point that takes an lh_ctx makes the ctx's HIP device current for the duration of the
