@@ -164,6 +164,9 @@ struct Ctx {
   Ctx* helper = nullptr;
   void* helper_handle = nullptr;
   void* precommit = nullptr;
+  // called once (and cleared) when a grand-product argument has built its trees and starts its layer sum-checks: the
+  // latency-bound stretch of a Lasso prove, where lasso_prove starts the opening's precommit
+  std::function<void()> gkr_hook;
   hipEvent_t prof_ev[2] = {nullptr, nullptr};
   void* pin(size_t bytes);  // grows the pinned buffer if needed
   // small device -> host download through a second pinned staging buffer, synchronising: an async copy into

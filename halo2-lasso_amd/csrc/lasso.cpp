@@ -608,9 +608,15 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
   // the sum-checks (Options::open_precommit)
   struct PrecommitGuard {  // (a prove that fails on the way drops what was started)
     Ctx& c;
-    ~PrecommitGuard() { open_precommit_cancel(c); }
+    ~PrecommitGuard() {
+      c.gkr_hook = nullptr;
+      open_precommit_cancel(c);
+    }
   } precommit_guard{c};
-  if (pcs.precommit && !shn) pcs.precommit(nv, small.data(), small.size(), evs.data(), evs.size());
+  // (started when the memory-checking argument has built its product trees - Ctx::gkr_hook: beside the Surge rounds and the
+  // tree kernels, which stream at the HBM bound, the helper's sorts only get in the way: tree_up 1.2 -> 5.0 ms per proof)
+  if (pcs.precommit && !shn)
+    c.gkr_hook = [&] { pcs.precommit(nv, small.data(), small.size(), evs.data(), evs.size()); };
 
   // ---- 2-7: Surge, memory checking, evaluations
   LassoClaims cl = lasso_argue(c, tb, n, w, d_dims, polys_n[0], E_fr, tr, lap, a_small);

@@ -1007,6 +1007,11 @@ GrandProductResult prove_grand_product(Ctx& c, size_t B, const Fr* const* d_leav
   tr.write_field_elements(res.roots);
 
   std::vector<HFr> claims = res.roots, y;
+  if (c.gkr_hook) {  // (the trees are built: from here on the small layers leave most of the chip idle)
+    std::function<void()> hook;
+    hook.swap(c.gkr_hook);
+    hook();
+  }
   for (size_t h = 0; h < max_depth; h++) {
     std::vector<size_t> active;
     for (size_t b = 0; b < B; b++)
