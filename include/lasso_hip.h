@@ -259,9 +259,10 @@ lh_status lh_lasso_last_timing(lh_ctx*, double* out_ms);
  *   sc_tail_max_len      8192 longest table (entries) that enters the resident tail
  *   shard_exchange_log   17   sharded proofs: a sum-check goes on replicated once its residual tables hold <= 2^this
  *                             entries together (one all-gather), at the latest when the shard bits reach bit 0
- *   open_precommit       1    1: the column-wise quotient commitments of a Lasso proof's opening - MSMs over differences of
- *                             witness columns, challenge-free - run on a helper ctx (own stream and host thread) beside the
- *                             Surge and memory-checking sum-checks; the opening then only combines their results
+ *   open_precommit       20   Lasso proofs of >= 2^this lookups (0: never, 1: always) run the column-wise quotient
+ *                             commitments of their opening - MSMs over differences of witness columns, challenge-free - on
+ *                             a helper ctx (own stream and host thread) beside the memory-checking sum-checks; the opening
+ *                             then only combines their results
  *   msm_window_tables    0    SRS levels of <= 2^this points get a window table on first use (2^(c w) multiples of every
  *                             base, W-fold the level's memory): the W windows of a full-width column then fill ONE
  *                             bucket set - one bucket reduction, no doublings.  Measured neutral at 2^24 lookups (shorter
