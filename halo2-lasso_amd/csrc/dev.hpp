@@ -103,7 +103,7 @@ struct Options {
   int64_t sc_tail = 1;                 // 0: one launch per sum-check round all the way down (no resident tail)
   int64_t sc_tail_max_len = 8192;      // longest table that enters the resident tail
   int64_t shard_exchange_log = 17;     // sharded sum-check: the residual tables travel once they hold <= 2^this entries
-  int64_t open_precommit = 20;         // proofs of >= 2^this lookups run the challenge-free half of the opening's column route
+  int64_t open_precommit = 1;          // proofs of >= 2^this lookups run the challenge-free half of the opening's column route
                                        // (the MSMs over differences of witness columns) on a helper ctx beside the sum-checks of
                                        // a Lasso prove (0: never; 1: always)
   int64_t msm_window_tables = 0;       // SRS levels of <= 2^this points get a window table (MsmJob::win_table) on first use:

@@ -1487,7 +1487,8 @@ static bool small_open_columns(const SmallPoly* small, size_t num_polys, const l
 void open_precommit_start(Ctx& c, const Srs& srs, size_t num_vars, const SmallPoly* small, size_t num_polys,
                           const lh_evaluation* evals, size_t num_evals) {
   open_precommit_cancel(c);
-  // (from 2^20 lookups on by default: a 2^18 proof is too short for the helper's thread and stream to pay - 7.4 -> 11.3 ms)
+  // (the option is the smallest proof that does it; default 1: every proof that takes the column route - 2^17..2^19 range
+  // lookups gain too: 7.0 -> 6.4-6.9, 8.1-9.1 -> 7.3-7.7, 9.7-9.9 -> 9.3-9.4 ms)
   if (c.opt.open_precommit <= 0 || (int64_t)num_vars < c.opt.open_precommit || c.shard_active || !small || num_vars > srs.num_vars) return;
   const size_t n = (size_t)1 << num_vars;
   SmallOpen so;

@@ -259,7 +259,7 @@ lh_status lh_lasso_last_timing(lh_ctx*, double* out_ms);
  *   sc_tail_max_len      8192 longest table (entries) that enters the resident tail
  *   shard_exchange_log   17   sharded proofs: a sum-check goes on replicated once its residual tables hold <= 2^this
  *                             entries together (one all-gather), at the latest when the shard bits reach bit 0
- *   open_precommit       20   Lasso proofs of >= 2^this lookups (0: never, 1: always) run the column-wise quotient
+ *   open_precommit       1    Lasso proofs of >= 2^this lookups (0: never, 1: always) run the column-wise quotient
  *                             commitments of their opening - MSMs over differences of witness columns, challenge-free - on
  *                             a helper ctx (own stream and host thread) beside the memory-checking sum-checks; the opening
  *                             then only combines their results

@@ -119,13 +119,13 @@ def test_route_options_change_the_route_not_the_bytes(hl, srs17):
             return t.into_proof(), hl.lasso_last_route(ctx)
         proof, route = prove()
         assert proof == want and route["open_small_depth"] >= 1 and route["eq_factored_rounds"] > 0 and route["resident_tails"] > 0
-        assert route["open_precommit"] == 0      # (by default only from 2^20 lookups on)
+        assert route["open_precommit"] == 1      # the column-wise commitments came from the helper ctx, beside the sum-checks
         assert hl.get_option(ctx, "open_small_min_vars") == 21 and hl.get_option(ctx, "sc_eq_factoring") == 1
-        assert hl.get_option(ctx, "open_precommit") == 20
-        hl.set_option(ctx, "open_precommit", 1)   # always: the column-wise commitments come from the helper ctx
-        proof, route = prove()
-        assert proof == want and route["open_precommit"] == 1 and route["open_small_depth"] >= 1
-        hl.set_option(ctx, "open_precommit", 20)
+        for smallest in (0, 18):                  # never / only proofs of >= 2^18 lookups: this one commits in the opening
+            hl.set_option(ctx, "open_precommit", smallest)
+            proof, route = prove()
+            assert proof == want and route["open_precommit"] == 0 and route["open_small_depth"] >= 1
+        hl.set_option(ctx, "open_precommit", 1)
         hl.set_option(ctx, "open_small_min_vars", 64)
         proof, route = prove()
         assert proof == want and route["open_small_depth"] == 0 and route["open_small_passes"] == 0
