@@ -899,6 +899,14 @@ def comm_stats(ctx):
     return {"device": int(out[0]), "host": int(out[1])}
 
 
+def comm_phase_stats(ctx, reset=False):
+    """collectives and bytes (this rank's contribution) by phase of the Lasso prove that issued them"""
+    out = (C.c_uint64 * 16)()
+    _check(ctx.lib.lh_ctx_comm_phase_stats(ctx.h, out, 1 if reset else 0))
+    names = ["witness", "commit", "surge", "leaves", "gkr", "evals", "open", "outside"]
+    return {nm: {"collectives": int(out[2 * i]), "bytes": int(out[2 * i + 1])} for i, nm in enumerate(names) if out[2 * i]}
+
+
 def attach_comm_loopback(ctx, rank, size, shard_bit):
     """lh_ctx_set_comm_loopback: measurement aid - every peer is a copy of this rank (the transcript is not a valid proof)"""
     _check(ctx.lib.lh_ctx_set_comm_loopback(ctx.h, rank, size, shard_bit))

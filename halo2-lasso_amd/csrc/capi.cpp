@@ -113,6 +113,11 @@ void lh_ctx_destroy(lh_ctx* ctx) {
     lh_ctx_destroy((lh_ctx*)ctx->c.helper_handle);
     ctx->c.helper_handle = nullptr, ctx->c.helper = nullptr;
   }
+  delete ctx->c.worker;  // (joins; after the precommit it may still be running was cancelled above)
+  ctx->c.worker = nullptr;
+  if (ctx->c.handoff_ev) (void)hipEventDestroy(ctx->c.handoff_ev);
+  for (hipEvent_t& ev : ctx->c.phase_ev)
+    if (ev) (void)hipEventDestroy(ev), ev = nullptr;
   (void)hipStreamSynchronize(ctx->c.stream);
   try {
     comm_detach(ctx->c);
@@ -484,6 +489,7 @@ lh_status lh_ctx_set_option(lh_ctx* ctx, const char* name, int64_t value) {
   LH_TRY NEED_CTX(ctx);
   int64_t* slot = ctx->c.opt.find(name);
   LH_REQUIRE(slot != nullptr, LH_ERR_ARG, std::string("unknown option: ") + (name ? name : "(null)"));
+  LH_REQUIRE(Options::in_range(name, value), LH_ERR_ARG, std::string("option value out of range: ") + name);
   *slot = value;
   if (slot == &ctx->c.opt.open_small_min_vars) ctx->c.opt.open_small_min_vars_forced = true;
   LH_CATCH
@@ -550,6 +556,16 @@ lh_status lh_ctx_comm_stats(lh_ctx* ctx, uint64_t out[2]) {
   NEED(out);
   out[0] = ctx->c.comm_stats[0];
   out[1] = ctx->c.comm_stats[1];
+  LH_CATCH
+}
+lh_status lh_ctx_comm_phase_stats(lh_ctx* ctx, uint64_t out[16], int reset) {
+  LH_TRY NEED_CTX(ctx);
+  NEED(out);
+  for (int p = 0; p < 8; p++) {
+    out[2 * p] = ctx->c.comm_phase_stats[p][0];
+    out[2 * p + 1] = ctx->c.comm_phase_stats[p][1];
+    if (reset) ctx->c.comm_phase_stats[p][0] = ctx->c.comm_phase_stats[p][1] = 0;
+  }
   LH_CATCH
 }
 lh_status lh_lasso_prove_sharded(lh_ctx* ctx, const lh_srs* srs, const lh_lasso_table* table, size_t num_vars,

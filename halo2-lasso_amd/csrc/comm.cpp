@@ -143,7 +143,9 @@ void comm_attach_loopback(Ctx& c, int rank, int size, size_t shard_bit) {
 }
 
 static const bool COMM_DEBUG = getenv("LH_COMM_DEBUG") != nullptr;  // one stderr line per collective (development)
-static void comm_trace(const Ctx& c, const char* what, size_t bytes) {
+static void comm_trace(Ctx& c, const char* what, size_t bytes) {
+  c.comm_phase_stats[c.comm_phase & 7][0]++;
+  c.comm_phase_stats[c.comm_phase & 7][1] += bytes;
   if (COMM_DEBUG)
     fprintf(stderr, "[comm %d/%d] #%llu %s %zu B\n", c.comm.rank, c.comm.size,
             (unsigned long long)(c.comm_stats[0] + c.comm_stats[1]), what, bytes);

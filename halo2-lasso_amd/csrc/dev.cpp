@@ -68,12 +68,13 @@ void Ctx::opt_in_lds(const void* fn, int bytes) {
 static const struct {
   const char* name;
   int64_t Options::*field;
+  int64_t lo, hi;  // accepted range (shift counts stay below 64, lengths are never negative)
 } OPTION_TABLE[] = {
-    {"open_small_min_vars", &Options::open_small_min_vars}, {"open_small_depth", &Options::open_small_depth},
-    {"sc_eq_factoring", &Options::sc_eq_factoring},         {"lasso_pack_ts", &Options::lasso_pack_ts},
-    {"sc_tail", &Options::sc_tail},                         {"sc_tail_max_len", &Options::sc_tail_max_len},
-    {"shard_exchange_log", &Options::shard_exchange_log},   {"msm_window_tables", &Options::msm_window_tables},
-    {"open_precommit", &Options::open_precommit},
+    {"open_small_min_vars", &Options::open_small_min_vars, 0, 64}, {"open_small_depth", &Options::open_small_depth, 0, 2},
+    {"sc_eq_factoring", &Options::sc_eq_factoring, 0, 1},          {"lasso_pack_ts", &Options::lasso_pack_ts, 0, 1},
+    {"sc_tail", &Options::sc_tail, 0, 1},                          {"sc_tail_max_len", &Options::sc_tail_max_len, 0, (int64_t)1 << 20},
+    {"shard_exchange_log", &Options::shard_exchange_log, 0, 40},   {"msm_window_tables", &Options::msm_window_tables, 0, 40},
+    {"open_precommit", &Options::open_precommit, 0, 64},           {"gkr_resident", &Options::gkr_resident, 0, 1},
 };
 
 int64_t* Options::find(const char* name) {
@@ -82,6 +83,12 @@ int64_t* Options::find(const char* name) {
     if (strcmp(o.name, name) == 0) return &(this->*o.field);
   return nullptr;
 }
+bool Options::in_range(const char* name, int64_t value) {
+  if (!name) return false;
+  for (const auto& o : OPTION_TABLE)
+    if (strcmp(o.name, name) == 0) return value >= o.lo && value <= o.hi;
+  return false;
+}
 
 Options::Options() {
   for (const auto& o : OPTION_TABLE) {
@@ -89,7 +96,12 @@ Options::Options() {
     for (const char* p = o.name; *p; p++) env.push_back((char)toupper((unsigned char)*p));
     const char* e = getenv(env.c_str());
     if (!e || !*e) continue;
-    this->*o.field = (int64_t)atoll(e);
+    const int64_t v = (int64_t)atoll(e);
+    if (v < o.lo || v > o.hi) {  // (an environment default out of range is ignored, loudly: nobody is there to take an error)
+      fprintf(stderr, "[lasso-hip] %s=%s is outside [%lld, %lld]: ignored\n", env.c_str(), e, (long long)o.lo, (long long)o.hi);
+      continue;
+    }
+    this->*o.field = v;
     if (o.field == &Options::open_small_min_vars) open_small_min_vars_forced = true;
   }
 }
@@ -211,6 +223,72 @@ void Ctx::d2h(void* dst, const void* d_src, size_t bytes) {
   LH_HIP(hipMemcpyAsync(stage, d_src, bytes, hipMemcpyDeviceToHost, stream));
   sync();
   memcpy(dst, stage, bytes);
+}
+
+// ------------------------------------------------------------------ HostWorker
+struct HostWorker::Impl {
+  std::mutex mu;
+  std::condition_variable cv, idle_cv;
+  std::vector<std::function<void()>> queue;
+  size_t head = 0;
+  bool busy = false, stop = false;
+  std::thread th;
+  void loop() {
+    for (;;) {
+      std::function<void()> fn;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return stop || head < queue.size(); });
+        if (head >= queue.size()) return;  // (stop, and nothing left)
+        fn = std::move(queue[head++]);
+        if (head == queue.size()) queue.clear(), head = 0;
+        busy = true;
+      }
+      try {
+        fn();
+      } catch (...) {  // (tasks report their own errors; nothing may escape a thread)
+      }
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        busy = false;
+      }
+      idle_cv.notify_all();
+    }
+  }
+};
+HostWorker::HostWorker() : impl_(new Impl()) { impl_->th = std::thread([this] { impl_->loop(); }); }
+HostWorker::~HostWorker() {
+  {
+    std::lock_guard<std::mutex> lk(impl_->mu);
+    impl_->stop = true;
+  }
+  impl_->cv.notify_all();
+  if (impl_->th.joinable()) impl_->th.join();
+  delete impl_;
+}
+void HostWorker::submit(std::function<void()> fn) {
+  {
+    std::lock_guard<std::mutex> lk(impl_->mu);
+    impl_->queue.push_back(std::move(fn));
+  }
+  impl_->cv.notify_one();
+}
+void HostWorker::wait() {
+  std::unique_lock<std::mutex> lk(impl_->mu);
+  impl_->idle_cv.wait(lk, [&] { return !impl_->busy && impl_->head >= impl_->queue.size(); });
+}
+
+void Ctx::phase_times_resolve() {
+  if (!phase_ev_pending) return;
+  phase_ev_pending = false;
+  // ev[0] = start of the prove, ev[k + 1] = end of phase k (k = 0..6); [7] stays 0, [8] (total) is the host's wall clock
+  if (!phase_ev[0]) return;
+  LH_HIP(hipEventSynchronize(phase_ev[7]));
+  for (int k = 0; k < 7; k++) {
+    float ms = 0;
+    LH_HIP(hipEventElapsedTime(&ms, phase_ev[k], phase_ev[k + 1]));
+    lasso_ms[k] = (double)ms;
+  }
 }
 
 // ------------------------------------------------------------------ host worker pool

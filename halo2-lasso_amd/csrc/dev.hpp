@@ -108,13 +108,30 @@ struct Options {
                                        // a Lasso prove (0: never; 1: always)
   int64_t msm_window_tables = 0;       // SRS levels of <= 2^this points get a window table (MsmJob::win_table) on first use:
                                        // full-width columns over them reduce ONE bucket set (0: no tables)
+  int64_t gkr_resident = 1;            // the layers of a grand-product argument whose tables fit the resident kernel run in ONE
+                                       // launch (layer loop, eq tables and rounds inside; 0: one sum-check per layer)
   Options();                           // environment defaults (dev.cpp)
   int64_t* find(const char* name);
+  static bool in_range(const char* name, int64_t value);  // the range lh_ctx_set_option accepts
 };
 struct RouteStats {  // lh_lasso_route (include/lasso_hip.h): counters of the last Lasso prove on the ctx
   uint32_t v[LH_LASSO_ROUTE_WORDS] = {0};
   enum { OPEN_DEPTH, OPEN_PASSES, EF_ROUNDS, STD_ROUNDS, RW_ROUNDS, TAILS, TAIL_ROUNDS, PACKED_TS, DERIVED, SORTED_REUSE,
          SHARDED_ROUNDS, SHARD_EXCHANGES, WIN_TABLE_JOBS, OPEN_PRECOMMIT };
+};
+
+// ------------------------------------------------------------------ a long-lived host thread (dev.cpp)
+// Runs submitted tasks one after the other: the driver of a helper ctx (prover.cpp open_precommit_*) - starting a
+// std::thread per proof costs tens of microseconds on the prover's critical path, a condition variable costs two.
+class HostWorker {
+ public:
+  HostWorker();
+  ~HostWorker();  // finishes what was submitted, then joins
+  void submit(std::function<void()> fn);
+  void wait();    // until every submitted task has finished
+ private:
+  struct Impl;
+  Impl* impl_;
 };
 
 // ------------------------------------------------------------------ context
@@ -142,6 +159,10 @@ struct Ctx {
   void* comm_stage = nullptr;     // device staging of host-side gathers over a device-only communicator
   size_t comm_stage_bytes = 0;
   uint64_t comm_stats[2] = {0, 0};  // collectives issued: device-side, host callback
+  // the same by phase of the Lasso prove that issued them (index = the phase in progress: witness, commit, surge, leaves,
+  // gkr, evals, open; 7 = outside a Lasso prove): [phase][0] collectives, [phase][1] bytes this rank contributed
+  uint64_t comm_phase_stats[8][2] = {};
+  int comm_phase = 7;
   // sharded sum-check rounds: the round kernel leaves its D sums in this DEVICE buffer (and "publishes" to a device
   // word) instead of pinned host memory; the all-gather and the sum-and-publish kernel follow on the stream
   Fr* sc_redirect = nullptr;
@@ -165,6 +186,12 @@ struct Ctx {
   Ctx* helper = nullptr;
   void* helper_handle = nullptr;
   void* precommit = nullptr;
+  HostWorker* worker = nullptr;   // the host thread that drives THIS ctx when it is somebody's helper (created on first use)
+  hipEvent_t handoff_ev = nullptr;  // recorded on this ctx's stream where a helper's stream may start reading its columns
+  // phase boundaries of the last Lasso prove as events on the stream (no host sync at a boundary: lasso.cpp lap)
+  hipEvent_t phase_ev[LH_LASSO_NUM_PHASES] = {};
+  bool phase_ev_pending = false;
+  void phase_times_resolve();  // events -> lasso_ms (waits for the last one)
   // called once (and cleared) when a grand-product argument has built its trees and starts its layer sum-checks: the
   // latency-bound stretch of a Lasso prove, where lasso_prove starts the opening's precommit
   std::function<void()> gkr_hook;
@@ -329,7 +356,7 @@ void k_lasso_counters(Ctx&, const uint32_t* dim, size_t n, size_t m, uint32_t* r
 // indices in send order; send: (address on the owner) << n_bits | global index; start_host[o]: first send position of
 // owner o, R + 1 entries), rank the received lookups on the owner, scatter the returned ranks, assemble final_cts
 void k_cs_partition(Ctx&, const uint32_t* dim, size_t n, size_t m, unsigned rho, unsigned j, uint32_t rank, unsigned n_bits,
-                    uint32_t* sidx, uint64_t* send, uint32_t* start_host);
+                    uint32_t* sidx, uint64_t* send, uint32_t* start_host, bool* bad_out);
 void k_cs_rank(Ctx&, const uint64_t* recv, size_t n, unsigned n_bits, unsigned a_bits, size_t m_loc, uint32_t* ret,
                uint32_t* counts);
 void k_cs_scatter(Ctx&, const uint32_t* back, const uint32_t* sidx, size_t n, uint32_t* read_ts);

@@ -977,7 +977,7 @@ __global__ void cs_final_kernel(const uint32_t* __restrict__ all_counts, size_t 
 }
 
 void k_cs_partition(Ctx& c, const uint32_t* dim, size_t n, size_t m, unsigned rho, unsigned j, uint32_t rank, unsigned n_bits,
-                    uint32_t* sidx, uint64_t* send, uint32_t* start_host) {
+                    uint32_t* sidx, uint64_t* send, uint32_t* start_host, bool* bad_out) {
   ProfScope ps(c, "lasso_counters/partition", 24.0 * n, 0.0, (double)n);
   ArenaScope scope(c.arena);
   const size_t R = (size_t)1 << rho;
@@ -1000,7 +1000,9 @@ void k_cs_partition(Ctx& c, const uint32_t* dim, size_t n, size_t m, unsigned rh
   hipLaunchKernelGGL(cs_send_keys_kernel, grid_for(n), 256, 0, c.stream, dim, sidx, n, rho, j, rank, n_bits, send);
   std::vector<uint32_t> h(R + 1);
   c.d2h(h.data(), start, (R + 1) * sizeof(uint32_t));  // (synchronises: `init` may go)
-  LH_REQUIRE(!h[R], LH_ERR_ARG, "lasso: chunk index out of range (>= 2^chunk_bits)");
+  // (an index >= 2^chunk_bits: NOT raised here - this rank's peers are about to enter a collective and would wait forever;
+  // the caller lets the verdict travel with the segment boundaries and raises on every rank)
+  *bad_out = h[R] != 0;
   // owners that do not occur start where the next one does
   uint32_t next = (uint32_t)n;
   for (size_t o = R; o-- > 0;) {

@@ -104,18 +104,25 @@ static void lasso_counters_sharded(Ctx& c, const Shard& sh, const uint32_t* cons
     ArenaScope scope(c.arena);
     uint32_t* sidx = c.arena.alloc_n<uint32_t>(NL);
     uint64_t* send = c.arena.alloc_n<uint64_t>(NL);
-    std::vector<uint32_t> start(R + 1);
+    std::vector<uint32_t> start(R + 2);
+    bool bad = false;
     k_cs_partition(c, d_dims_local[col], NL, M, (unsigned)sh.rho, (unsigned)sh.j, (uint32_t)me, (unsigned)n, sidx, send,
-                   start.data());
-    // everybody's segment boundaries: starts[s][o] = where, in rank s's send buffer, the lookups for owner o begin
-    std::vector<uint32_t> starts((R + 1) * R);
-    comm_all_gather_host(c, start.data(), starts.data(), (R + 1) * sizeof(uint32_t));
-    auto seg = [&](size_t s, size_t o) { return (size_t)(starts[s * (R + 1) + o + 1] - starts[s * (R + 1) + o]); };
+                   start.data(), &bad);
+    start[R + 1] = bad ? 1u : 0u;
+    // everybody's segment boundaries: starts[s][o] = where, in rank s's send buffer, the lookups for owner o begin - and
+    // everybody's verdict on its own shard: an index out of range on ANY rank fails the prove on EVERY rank, after the
+    // exchange (a rank that threw on its own would leave its peers waiting in this collective)
+    const size_t W = R + 2;
+    std::vector<uint32_t> starts(W * R);
+    comm_all_gather_host(c, start.data(), starts.data(), W * sizeof(uint32_t));
+    for (size_t s = 0; s < R; s++)
+      LH_REQUIRE(!starts[s * W + R + 1], LH_ERR_ARG, "lasso: chunk index out of range (>= 2^chunk_bits)");
+    auto seg = [&](size_t s, size_t o) { return (size_t)(starts[s * W + o + 1] - starts[s * W + o]); };
     std::vector<size_t> s_off(R), s_cnt(R), r_off(R), r_cnt(R), peer_off(R);
     size_t recv_total = 0, recv_max = 0;
     for (size_t p = 0; p < R; p++) {
       s_off[p] = start[p], s_cnt[p] = seg(me, p);
-      r_off[p] = recv_total, r_cnt[p] = seg(p, me), peer_off[p] = starts[p * (R + 1) + me];
+      r_off[p] = recv_total, r_cnt[p] = seg(p, me), peer_off[p] = starts[p * W + me];
       recv_total += r_cnt[p];
     }
     for (size_t o = 0; o < R; o++) {  // (the largest receive buffer of any owner: the span of the way back)
@@ -408,13 +415,23 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
   }
   const size_t nv = std::max(n, l), NV = (size_t)1 << (nv - sh.rho);
   const size_t N = (size_t)1 << (n - sh.rho), M = (size_t)1 << l;
-  double t0 = now_ms(), t_prev = t0;
+  // phase boundaries are EVENTS on the prover's stream (a hipStreamSynchronize at each of them drained the queue seven
+  // times per proof for the sake of a number nobody reads in production): lh_lasso_last_timing turns them into phase
+  // times when asked (Ctx::phase_times_resolve); lasso_ms[8], the total, is the host's wall clock
+  const double t0 = now_ms();
   double* ph = c.lasso_ms;
+  for (int k = 0; k < 8; k++)
+    if (!c.phase_ev[k]) LH_HIP(hipEventCreate(&c.phase_ev[k]));
+  c.phase_ev_pending = false;
+  LH_HIP(hipEventRecord(c.phase_ev[0], c.stream));
+  c.comm_phase = 0;
+  struct PhaseGuard {  // (collectives issued after the prove - or after it failed - count as outside)
+    Ctx& c;
+    ~PhaseGuard() { c.comm_phase = 7; }
+  } phase_guard{c};
   auto lap = [&](int idx) {
-    c.sync();
-    double t = now_ms();
-    ph[idx] = t - t_prev;
-    t_prev = t;
+    LH_HIP(hipEventRecord(c.phase_ev[idx + 1], c.stream));
+    c.comm_phase = idx + 1;
   };
 
   ArenaScope scope(c.arena);
@@ -646,6 +663,7 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
   lap(6);
   ph[7] = 0;
   ph[8] = now_ms() - t0;
+  c.phase_ev_pending = true;
 }
 
 // ONE proof over the 2^rho ranks of the ctx's communicator: the same prover, with every table a shard

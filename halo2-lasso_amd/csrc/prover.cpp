@@ -1427,7 +1427,7 @@ static bool column_route_on(const Ctx& c, const std::vector<SmallPoly>& cols, co
 // runs its jobs on its own stream, driven by its own host thread, while the ctx goes through the sum-checks.  mkzg_open
 // takes the results only if columns, widths and depth are what it arrives at itself; otherwise it commits as before.
 struct OpenPrecommit {
-  std::thread th;
+  HostWorker* worker = nullptr;  // the helper ctx's host thread, busy with this plan until wait() returns
   const Srs* srs = nullptr;
   size_t num_vars = 0;
   std::vector<SmallPoly> cols;
@@ -1436,9 +1436,11 @@ struct OpenPrecommit {
   std::vector<HG1> out;
   bool ok = false;
   std::string err;
-  ~OpenPrecommit() {
-    if (th.joinable()) th.join();
+  void join() {
+    if (worker) worker->wait();
+    worker = nullptr;
   }
+  ~OpenPrecommit() { join(); }
 };
 void open_precommit_cancel(Ctx& c) {
   if (!c.precommit) return;
@@ -1502,11 +1504,18 @@ void open_precommit_start(Ctx& c, const Srs& srs, size_t num_vars, const SmallPo
   OpenPrecommit* pc = new OpenPrecommit();
   pc->srs = &srs, pc->num_vars = num_vars, pc->cols = so.cols, pc->zero = zero;
   c.precommit = pc;
-  c.sync();  // the witness columns are written by kernels queued on this ctx's stream: the helper's stream reads them
+  // the witness columns are written by kernels queued on this ctx's stream and read by the helper's: an event between the
+  // streams (not a host sync), and the helper's long-lived host thread (not a thread per proof)
+  if (!c.handoff_ev) LH_HIP(hipEventCreateWithFlags(&c.handoff_ev, hipEventDisableTiming));
+  LH_HIP(hipEventRecord(c.handoff_ev, c.stream));
+  hipEvent_t handoff = c.handoff_ev;
   const int device = c.device;
-  pc->th = std::thread([pc, &h, &srs, num_vars, n, device] {
+  if (!h.worker) h.worker = new HostWorker();
+  pc->worker = h.worker;
+  h.worker->submit([pc, &h, &srs, num_vars, n, device, handoff] {
     try {
       LH_HIP(hipSetDevice(device));
+      LH_HIP(hipStreamWaitEvent(h.stream, handoff, 0));
       ArenaScope scope(h.arena);
       column_shape(h, pc->cols, pc->zero, n, num_vars, 0, pc->plan);
       column_jobs(h, srs, pc->cols, pc->zero, num_vars, 0, false, [&srs](size_t lvl) { return srs.eq(lvl); }, pc->plan);
@@ -1521,7 +1530,7 @@ void open_precommit_start(Ctx& c, const Srs& srs, size_t num_vars, const SmallPo
       pc->err = "unknown error";
     }
   });
-  if (c.prof) pc->th.join();  // a profiled prove keeps its kernels one at a time (the records are merged when taken)
+  if (c.prof) pc->join();  // a profiled prove keeps its kernels one at a time (the records are merged when taken)
 }
 // the precommitted plan if it is the plan this opening would build (same SRS, columns, zero pattern, widths, depth)
 static std::unique_ptr<OpenPrecommit> open_precommit_take(Ctx& c, const Srs& srs, size_t num_vars,
@@ -1530,7 +1539,7 @@ static std::unique_ptr<OpenPrecommit> open_precommit_take(Ctx& c, const Srs& srs
   std::unique_ptr<OpenPrecommit> pc((OpenPrecommit*)c.precommit);
   c.precommit = nullptr;
   if (!pc) return nullptr;
-  if (pc->th.joinable()) pc->th.join();
+  pc->join();
   if (c.prof && c.helper) {
     c.prof_recs.insert(c.prof_recs.end(), c.helper->prof_recs.begin(), c.helper->prof_recs.end());
     c.helper->prof_recs.clear();

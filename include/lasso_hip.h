@@ -329,6 +329,11 @@ lh_status lh_ctx_set_comm_loopback(lh_ctx*, int rank, int size, size_t shard_bit
 /* collectives issued on this ctx since the communicator was attached: out[0] device-side (RCCL or
  * all_gather_device), out[1] host callback.  A job on RCCL shows out[1] == 0. */
 lh_status lh_ctx_comm_stats(lh_ctx*, uint64_t out[2]);
+/* the same by phase of the Lasso prove in progress when the collective was issued: out[2 p] collectives, out[2 p + 1]
+ * bytes this rank contributed, p = 0..6 for witness (the access counters' exchange), commit, surge, leaves, gkr, evals,
+ * open; p = 7: outside a Lasso prove.  reset != 0 clears the counters after reading.  (bench.py prints them next to
+ * the N > 1 line so that a measured scaling curve can be read against the per-rank compute profile.) */
+lh_status lh_ctx_comm_phase_stats(lh_ctx*, uint64_t out[16], int reset);
 /* Same proof bytes as lh_lasso_prove on one GPU - it IS lh_lasso_prove with every table a shard: the same kernels (eq-
  * factored rounds, leaf-layer kernel, derived / packed commitments, column-wise top quotient) run on the shards, with a
  * collective where a round's partial sums or an MSM's partial commitments are added.  d_dims_local[j]: THIS RANK'S shard

@@ -99,13 +99,29 @@ struct Pool {
     fn = &f, n = n_, chunk = chunk_, next = 0, pending = (n_ + chunk_ - 1) / chunk_;
     generation++;
     cv_work.notify_all();
-    // the caller works too
+    // the caller works too - as an insider: a chunk that parallelizes again must run that part inline (the region's
+    // mutex is not recursive); a chunk that throws on this thread must not leave workers with a dangling `fn`
+    struct Inside {
+      bool was = inside;
+      Inside() { inside = true; }
+      ~Inside() { inside = was; }
+    } mark;
     size_t s, e;
-    while (take(s, e)) {
-      lk.unlock();
-      f(s, e);
-      lk.lock();
-      --pending;
+    try {
+      while (take(s, e)) {
+        lk.unlock();
+        f(s, e);
+        lk.lock();
+        --pending;
+      }
+    } catch (...) {
+      if (!lk.owns_lock()) lk.lock();
+      --pending;                 // the chunk that threw
+      pending -= (n - next + chunk - 1) / chunk;  // chunks nobody has taken: withdrawn
+      next = n;
+      cv_done.wait(lk, [this] { return pending == 0; });  // chunks in flight on workers finish first
+      fn = nullptr;
+      throw;
     }
     cv_done.wait(lk, [this] { return pending == 0; });
     fn = nullptr;

@@ -77,6 +77,37 @@ def test_bench_gpus_n_starts_its_own_ranks():
     assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 
+def test_sharded_fallback_chain_under_torchrun():
+    """a sharded run that raises on every rank is re-run in fresh processes - first sharded again with the
+    personalised exchange staged through all-gathers, then as replicas.  Launched by torch.distributed.run (as the driver
+    does) every worker inherits TORCHELASTIC_USE_AGENT_STORE=True, under which even rank 0 is only a CLIENT of the
+    agent's store: the successors must drop it or nobody listens on their new port.  (--rendezvous-only over gloo: the
+    whole chain without a GPU; LH_BENCH_TEST_RAISE names the attempts that fail.)"""
+    import json
+    import socket
+
+    def run(raise_at):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+        env.update(LH_DIST_BACKEND="gloo", LH_BENCH_TEST_RAISE=raise_at)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only"]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        return r, [json.loads(ln) for ln in lines]
+
+    r, lines = run("first")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert lines == [{"n_gpus": 2, "max_rank": 1, "rendezvous": "ok", "stage": "a2a", "mode": "sharded", "a2a": "allgather"}]
+    r, lines = run("first,a2a")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert lines == [{"n_gpus": 2, "max_rank": 1, "rendezvous": "ok", "stage": "replicas", "mode": "replicas", "a2a": "allgather"}]
+    r, lines = run("first,a2a,replicas")  # nothing left to fall back to: the job fails, no line
+    assert r.returncode != 0 and lines == []
+
+
 COUNTERS_WORKER = textwrap.dedent("""
     # A numpy restatement of the sharded access counters (csrc/lasso.cpp lasso_counters_sharded: partition by address
     # owner, personalised exchange staged through an all-gather as the callback transports do, rank inside the address

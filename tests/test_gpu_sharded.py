@@ -240,6 +240,14 @@ def test_full_size_configs_sharded_on_one_gpu(tmp_path, hl, ctx, world, kind, n)
     hl.lasso_prove(pp, table, n, full, t)
     single = t.into_proof()
     del full, pp
+    # the full-size bytes are pinned to something independent of the prover: the host verifier accepts them (and rejects
+    # them with one byte flipped in the middle of the memory-checking argument)
+    vp = hl.MultilinearKzgVerifierParams.setup(bench.trapdoor(n))
+    hl.lasso_verify(vp, table, n, hl.Keccak256Transcript.from_proof(single))
+    bad = bytearray(single)
+    bad[len(bad) // 2] ^= 1
+    with pytest.raises(hl.Error):
+        hl.lasso_verify(vp, table, n, hl.Keccak256Transcript.from_proof(bytes(bad)))
     # (ranks that share one GPU pay ~0.5 s of GPU process switching per collective: the residual tables travel a little
     # earlier than by default - fewer sharded rounds - which changes no byte)
     outs = run_big(tmp_path, world, dict(kind=kind, n=n, shard_bit=shard_bit, xlog=20), 29480 + world + n)
