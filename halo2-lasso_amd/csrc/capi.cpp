@@ -123,6 +123,8 @@ void lh_ctx_destroy(lh_ctx* ctx) {
     comm_detach(ctx->c);
   } catch (...) {
   }
+  if (ctx->c.gkr_mbox) (void)hipHostFree(ctx->c.gkr_mbox);
+  if (ctx->c.gkr_relay) (void)hipFree(ctx->c.gkr_relay);
   if (ctx->c.comm_stage) (void)hipFree(ctx->c.comm_stage);
   if (ctx->c.pinned) (void)hipHostFree(ctx->c.pinned);
   if (ctx->c.stage) (void)hipHostFree(ctx->c.stage);
@@ -481,6 +483,8 @@ lh_status lh_lasso_prove(lh_ctx* ctx, const lh_srs* srs, const lh_lasso_table* t
 lh_status lh_lasso_last_timing(lh_ctx* ctx, double* out_ms) {
   LH_TRY NEED_CTX(ctx);
   NEED(out_ms);
+  LH_HIP(hipSetDevice(ctx->c.device));
+  ctx->c.phase_times_resolve();  // (the phase boundaries are events on the stream: lasso.cpp lap)
   memcpy(out_ms, ctx->c.lasso_ms, sizeof(ctx->c.lasso_ms));
   LH_CATCH
 }

@@ -168,6 +168,32 @@ void Ctx::mbox_abort() {
   for (int j = 0; j < 3; j++) store_chunk(&m->c[j], SC_TAIL_ABORT, 0, 0, 0);
 }
 
+void Ctx::gkr_boxes() {
+  if (gkr_mbox) return;
+  LH_HIP(hipHostMalloc((void**)&gkr_mbox, GKR_MSG_CHUNKS * sizeof(TailChunk), hipHostMallocCoherent | hipHostMallocMapped));
+  memset((void*)gkr_mbox, 0, GKR_MSG_CHUNKS * sizeof(TailChunk));
+  LH_HIP(hipMalloc((void**)&gkr_relay, (4 + GKR_MSG_CHUNKS) * sizeof(TailChunk)));
+  LH_HIP(hipMemset(gkr_relay, 0, (4 + GKR_MSG_CHUNKS) * sizeof(TailChunk)));
+}
+void Ctx::gkr_send_layer(const Fr* vals, size_t count, uint32_t seq) {
+  LH_REQUIRE(3 * count <= GKR_MSG_CHUNKS, LH_ERR_ARG, "resident layers: layer message too long");
+  for (size_t i = 0; i < count; i++) {
+    const Fr& r = vals[i];
+    store_chunk(&gkr_mbox[3 * i + 0], seq, r.l[0], r.l[1], r.l[2]);
+    store_chunk(&gkr_mbox[3 * i + 1], seq, r.l[3], r.l[4], r.l[5]);
+    store_chunk(&gkr_mbox[3 * i + 2], seq, r.l[6], r.l[7], 0);
+  }
+}
+void Ctx::gkr_abort() {
+  mbox_abort();
+  if (gkr_mbox) store_chunk(&gkr_mbox[0], SC_TAIL_ABORT, 0, 0, 0);
+}
+void Ctx::gkr_resync() {
+  if (gkr_relay) LH_HIP(hipMemsetAsync(gkr_relay, 0, (4 + GKR_MSG_CHUNKS) * sizeof(TailChunk), stream));
+  if (gkr_mbox) memset((void*)gkr_mbox, 0, GKR_MSG_CHUNKS * sizeof(TailChunk));
+  k_sc_tail_resync(*this);
+}
+
 void Ctx::wait_chunks(const TailChunk* chunks, size_t count, uint32_t seq, Fr* out) {
   alignas(16) uint32_t w[4];
   size_t have = 0;  // chunks 0..have-1 carry `seq` and are copied out

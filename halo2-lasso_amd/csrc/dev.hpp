@@ -117,7 +117,7 @@ struct Options {
 struct RouteStats {  // lh_lasso_route (include/lasso_hip.h): counters of the last Lasso prove on the ctx
   uint32_t v[LH_LASSO_ROUTE_WORDS] = {0};
   enum { OPEN_DEPTH, OPEN_PASSES, EF_ROUNDS, STD_ROUNDS, RW_ROUNDS, TAILS, TAIL_ROUNDS, PACKED_TS, DERIVED, SORTED_REUSE,
-         SHARDED_ROUNDS, SHARD_EXCHANGES, WIN_TABLE_JOBS, OPEN_PRECOMMIT };
+         SHARDED_ROUNDS, SHARD_EXCHANGES, WIN_TABLE_JOBS, OPEN_PRECOMMIT, RESIDENT_LAYERS };
 };
 
 // ------------------------------------------------------------------ a long-lived host thread (dev.cpp)
@@ -231,6 +231,14 @@ struct Ctx {
   struct TailMbox* mbox() { return (struct TailMbox*)((char*)flag + 64); }
   void mbox_send(const Fr& r, uint32_t seq);
   void mbox_abort();
+  // the resident grand-product kernel's boxes (kernels_gkr.hip): host -> kernel layer messages (pinned) and the device
+  // relay of whatever one workgroup fetched from the host; created on first use
+  struct TailChunk* gkr_mbox = nullptr;
+  struct TailChunk* gkr_relay = nullptr;
+  void gkr_boxes();
+  void gkr_send_layer(const Fr* vals, size_t count, uint32_t seq);
+  void gkr_abort();   // mbox_abort + the layer box
+  void gkr_resync();  // after an aborted launch: markers cleared, ticket counter re-read
   void wait_flag(uint32_t seq);
   // more than 64 KB of dynamic LDS for `fn` on this ctx's device (the attribute is per device: once per ctx and kernel)
   std::vector<const void*> lds_opted;
@@ -500,6 +508,27 @@ void k_sc_tail_launch(Ctx&, const ScRound& rd, int degree, size_t n0, bool first
                       TailChunk* msg_host, Fr* out_host);
 // after a tail that ended early: the ticket counter is wherever the workgroups left it
 void k_sc_tail_resync(Ctx&);
+
+// ------------------------------------------------------------------ resident grand-product layers (kernels_gkr.hip)
+// The layers of a product-tree argument (prove_grand_product) whose tables fit on-chip, in ONE launch: layer loop, eq
+// tables and rounds inside the kernel, host <-> kernel traffic in TailChunk messages.  Per layer the host sends
+// [c_0 .. c_{B-1}, y_0 .. y_{h-1}] (sequence number `seq`), the kernel answers every round j with q(1), q(2) of the
+// eq-factored round polynomial (seq + 1 + j; the challenge comes back under the same number through the ctx's TailMbox)
+// and ends the layer with the 2 B final evaluations (l'_k = c_k l_k and r_k per tree; flag = seq + h + 1).
+constexpr int GKR_MAX_TREES = 16;
+constexpr int GKR_MAX_VARS = 16;          // a resident layer has at most GKR_MAX_VARS - 2 variables
+constexpr uint32_t GKR_CAP = 128;         // entries of a table one workgroup holds
+constexpr uint32_t GKR_THREADS = 256;
+constexpr uint32_t GKR_MSG_CHUNKS = 3 * (GKR_MAX_TREES + GKR_MAX_VARS);
+struct GkrLayerDev {
+  const Fr* lv[GKR_MAX_TREES];  // the level of tree k: 2^(h + 1) nodes, left factors first
+  uint32_t h, B;                // variables of the layer's tables, trees
+  uint32_t g, s_log;            // g workgroups x 2^s_log entries = 2^h
+  uint32_t seq;
+};
+bool k_gkr_resident_geometry(uint32_t h, uint32_t* g, uint32_t* s_log);
+// returns immediately; msg_host: 6 chunks, out_host: 2 * GKR_MAX_TREES field elements (pinned)
+void k_gkr_resident_launch(Ctx&, const GkrLayerDev* layers, size_t num_layers, TailChunk* msg_host, Fr* out_host);
 
 // ------------------------------------------------------------------ general expressions (kernels_expr.hip)
 struct ExtRound {

@@ -60,6 +60,7 @@ struct FqParams {
 
 template <class P>
 struct alignas(16) Fp {
+  typedef P params;
   uint32_t l[8];
 
   static LH_HD Fp zero() {
@@ -359,6 +360,53 @@ __device__ __forceinline__ Fp<P> mul_scan(const Fp<P>& a, const Fp<P>& b) {
   for (int j = 0; j < 8; j++) out.l[j] = r[j];
   return reduce_once(out);  // a, b < p < 2^254: the result is < 2p < 2^255, no ninth word
 }
+// sum_j a[j] * b[j] * R^-1 mod p with ONE Montgomery reduction: the K operand products of a column go into the same
+// accumulator, the reduction digits are those of the sum (K * 64 + 65 multiply-adds instead of K * 129: 0.62x for K = 4,
+// 0.56x for K = 8).  The sum is < K p^2, so the unreduced result is < (K p / R + 1) p = (0.19 K + 1) p < 2^256 for
+// K <= 16 (BN254: p / R = 0.189 for both fields): it takes ceil(0.19 K) conditional subtractions.  The layer
+// expressions of the grand products (sum_k l_k r_k with the batching coefficients folded into l, kernels_gkr.hip and
+// the streaming rounds) and the curve formulas' two-term sums are the users.
+template <class P, int K>
+__device__ __forceinline__ Fp<P> dot_scan(const Fp<P>* a, const Fp<P>* b) {
+  static_assert(K >= 1 && K <= 16, "dot_scan: the result must stay below 2^256");
+  uint64_t acc = 0;
+  uint32_t top = 0;
+  uint32_t m[8], r[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+#pragma unroll
+      for (int i = 0; i <= k; i++) LH_MAC(a[j].l[i], b[j].l[k - i]);
+    }
+#pragma unroll
+    for (int i = 0; i < k; i++) LH_MACS(m[i], P::mod(k - i));
+    m[k] = (uint32_t)acc * P::INV;
+    LH_MACS(m[k], P::mod(0));
+    acc = (acc >> 32) | ((uint64_t)top << 32);
+    top = 0;
+  }
+#pragma unroll
+  for (int k = 8; k < 16; k++) {
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+#pragma unroll
+      for (int i = k - 7; i < 8; i++) LH_MAC(a[j].l[i], b[j].l[k - i]);
+    }
+#pragma unroll
+    for (int i = k - 7; i < 8; i++) LH_MACS(m[i], P::mod(k - i));
+    r[k - 8] = (uint32_t)acc;
+    acc = (acc >> 32) | ((uint64_t)top << 32);
+    top = 0;
+  }
+  Fp<P> out;
+#pragma unroll
+  for (int j = 0; j < 8; j++) out.l[j] = r[j];
+  constexpr int NRED = K <= 5 ? 1 : K <= 10 ? 2 : K <= 15 ? 3 : 4;  // (0.189 K + 1) p < (NRED + 1) p
+#pragma unroll
+  for (int t = 0; t < NRED; t++) out = reduce_once(out);
+  return out;
+}
 #undef LH_MAC
 #undef LH_MACS
 #endif
@@ -369,6 +417,18 @@ LH_HD Fp<P> mul(const Fp<P>& a, const Fp<P>& b) {
   return mul_scan(a, b);
 #else
   return mul_cios(a, b);
+#endif
+}
+
+// sum_j a[j] * b[j] (device: one reduction for the K products, dot_scan above)
+template <class P, int K>
+LH_HD Fp<P> dot(const Fp<P>* a, const Fp<P>* b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return dot_scan<P, K>(a, b);
+#else
+  Fp<P> s = mul_cios(a[0], b[0]);
+  for (int j = 1; j < K; j++) s = add_generic(s, mul_cios(a[j], b[j]));
+  return s;
 #endif
 }
 

@@ -1,0 +1,360 @@
+// Resident grand-product layers: the layers of a product-tree argument whose tables fit on-chip run in ONE launch.
+//
+// Replaces, for the layers near the root of the memory-checking trees (every tree level of <= 2^15 nodes: 14 of the 23
+// layers of a 2^24-lookup proof, all of them for small proofs), the per-layer sequence
+//   eq_xy kernels -> [launched small rounds] -> sc_tail launch -> final evaluations
+// i.e. the round loop piop/sum_check/classic.rs:208-240 inside the layer loop piop/gkr/fractional_sum_check.rs:146-181
+// (product-only form, oracle/pyref/gkr.py::prove_grand_product).  The kernel keeps the LAYER loop inside:
+//   per layer  wait for the host's layer message (batching coefficients c_k = lambda^k and the point y of the layer's eq
+//              factor: the previous layer's challenges and mu) -> load this workgroup's slice of every tree level, the
+//              coefficient folded into the left half (l'_k = c_k l_k) -> build the slice of the factored eq table in
+//              registers (one wave: doubling by lane shuffles for the slice-local variables, a lane product for the
+//              workgroup's own bits) -> rounds -> final evaluations to the host;
+//   per round  q(X) = sum_b E_j[b] sum_k l'_k(X, b) r_k(X, b) at X = 1, 2 (the host rebuilds the reference's message
+//              p(0..3) = S_j eq(y_j, X) q(X), host.hpp EqFactoring - identical bytes): one lane per (pair, X, four
+//              trees), the four products in ONE Montgomery reduction (ff.cuh dot_scan), lane shuffles over the tree
+//              groups, one product with the eq entry, a butterfly over the pairs; G > 1: partial sums and a ticket
+//              through device memory, the last arrival sends; challenge from the host's mailbox (relayed through
+//              device memory to the other workgroups); bind in place.
+// Against the generic resident tail (kernels_sumcheck.hip sc_tail_kernel: (term, X, pair) items of two products each at
+// three points, an eq table bound like any other) a round evaluates 2 x 4.5 instead of 3 x 32 products per pair of a
+// 16-tree layer, and nothing is launched, staged or drained between layers.
+// Two stages per layer: g workgroups with 2^s_log entries of every table each, then - the slices down to one pair -
+// the bound entries and the workgroups' eq scalars go through device memory to the workgroup that arrives last, which
+// finishes the layer alone (g <= 128 entries per table) and polls the host for the next layer's message.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include "dev.hpp"
+#include "reduce.cuh"
+#include "resident.cuh"
+
+namespace lh {
+
+struct GkrResArgs {
+  const GkrLayerDev* layers;  // device array, layers in the order they are proved (g never decreases)
+  uint32_t num_layers;
+  uint32_t cap;               // LDS carve-up: tab[2 * max_trees * cap], E[cap / 2], red[cap], cy[GKR_MAX_TREES + GKR_MAX_VARS]
+  uint32_t max_trees;
+  uint32_t ticket_base;       // value of *ticket before this launch
+  uint32_t* ticket;
+  Fr* part;                   // device: [2][G][2] partial sums of the even / odd rounds
+  Fr* hand;                   // device: [2 * max_trees + 1][G] hand-over (bound entries, eq scalars)
+  TailChunk* relay;           // device: chunks 0..2 the round challenge, 4.. the layer message, relayed by the polling workgroup
+  const TailChunk* mbox_round;  // host (dev.hpp TailMbox)
+  const TailChunk* mbox_layer;  // host: GKR_MSG_CHUNKS chunks
+  TailChunk* msg_host;        // device -> host: q(1), q(2) as 6 chunks
+  Fr* out_host;               // final evaluations (l'_k, r_k per tree), then the flag
+  uint32_t* flag;
+  uint64_t poll_ticks;
+};
+
+__device__ __forceinline__ Fr shfl_fr(const Fr& v, int src) {
+  Fr o;
+#pragma unroll
+  for (int i = 0; i < 8; i++) o.l[i] = __shfl(v.l[i], src, 64);
+  return o;
+}
+
+__global__ __launch_bounds__(GKR_THREADS) void gkr_resident_kernel(GkrResArgs a) {
+  extern __shared__ __align__(16) unsigned char gkr_lds_raw[];
+  __shared__ Fr r_sh;
+  __shared__ uint32_t stop_sh, last_sh;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, wg = blockIdx.x;
+  Fr* tab = (Fr*)gkr_lds_raw;                     // table t at t * stride
+  Fr* E = tab + (size_t)2 * a.max_trees * a.cap;  // the current level of the factored eq table: one entry per pair
+  Fr* red = E + a.cap / 2 + 1;                    // [2][P] products of a round, hand-over staging
+  Fr* cy = red + a.cap + 2;                       // coefficients c_k, then the point y
+  // the chains of a resident round are latency-bound: ahead of whatever else shares the SIMDs (a helper ctx's MSM)
+  __builtin_amdgcn_s_setprio(3);
+  bool i_poll = wg == 0;   // this workgroup finished the previous layer: it asks the host for the next layer's message
+  uint32_t tbase = a.ticket_base;
+  if (tid == 0) stop_sh = 0;
+  __syncthreads();
+  for (uint32_t li = 0; li < a.num_layers; li++) {
+    const GkrLayerDev& L = a.layers[li];
+    const uint32_t h = L.h, B = L.B, g = L.g, slog = L.s_log, T = 2 * B, seq0 = L.seq;
+    const uint32_t my_tbase = tbase;
+    tbase += g > 1 ? (slog + 1) * g : 0;
+    if (wg >= g) continue;  // (not one of this layer's workgroups; g never decreases, so it is not the poller either)
+    // ---- the layer message: 3 chunks per field element, c_0 .. c_{B-1}, y_0 .. y_{h-1}
+    {
+      const uint32_t nch = 3 * (B + h);
+      const TailChunk* src = i_poll ? a.mbox_layer : a.relay + 4;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      const uint64_t t0 = wall_clock64();
+      for (;;) {
+        bool ok = true;
+        if (tid < nch) {
+          v = load_sys_x4(&src[tid]);
+          ok = v.x == seq0;
+        }
+        if (__syncthreads_and(ok)) break;
+        const bool stop = (tid == 0 && (v.x == SC_TAIL_ABORT || wall_clock64() - t0 > a.poll_ticks));
+        if (__syncthreads_or(stop)) {
+          if (i_poll && tid == 0) {
+            store_sys_x4((void*)&a.relay[4], u32x4{SC_TAIL_ABORT, 0u, 0u, 0u});
+            store_sys_x4((void*)&a.relay[0], u32x4{SC_TAIL_ABORT, 0u, 0u, 0u});
+          }
+          return;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (tid < nch) {
+        if (i_poll) store_sys_x4((void*)&a.relay[4 + tid], v);
+        const uint32_t f = tid / 3, j = tid % 3;
+        cy[f].l[3 * j] = v.y, cy[f].l[3 * j + 1] = v.z;
+        if (j < 2) cy[f].l[3 * j + 2] = v.w;
+      }
+      __syncthreads();
+    }
+    const Fr* yv = cy + B;
+    // ---- stage 0: this workgroup's slice [wg * s, (wg + 1) * s) of every tree level; wave 3 builds the eq slice meanwhile
+    uint32_t s = 1u << slog, stride = s;
+    const size_t N = (size_t)1 << h;
+    if (wave == 3) {
+      // slice-local variables 1 .. slog-1 by doubling (lane b ends with prod_i eq(y_i, bit_{i-1}(b))), the variables
+      // slog .. h-1 are this workgroup's index bits
+      Fr low = Fr::one();
+      for (uint32_t i = slog; i-- > 1;) {
+        const Fr parent = shfl_fr(low, (int)(lane >> 1));
+        const Fr t = mul(parent, yv[i]);
+        low = (lane & 1u) ? t : sub(parent, t);
+      }
+      Fr hi = Fr::one();
+      if (lane < h - slog) {
+        const Fr yi = yv[slog + lane];
+        hi = ((wg >> lane) & 1u) ? yi : sub(Fr::one(), yi);
+      }
+      for (uint32_t off = 1; off < h - slog; off <<= 1) hi = mul(hi, shfl_xor_fr(hi, (int)off));
+      hi = shfl_fr(hi, 0);
+      if (lane < (s >> 1)) E[lane] = h - slog ? mul(hi, low) : low;
+    } else {
+      for (uint32_t e = tid; e < T * s; e += 192) {
+        const uint32_t t = e >> slog, idx = e & (s - 1), k = t >> 1;
+        Fr v = L.lv[k][((t & 1u) ? N : 0) + (size_t)wg * s + idx];
+        if (!(t & 1u)) v = mul(v, cy[k]);
+        tab[t * stride + idx] = v;
+      }
+    }
+    __syncthreads();
+    bool multi = g > 1;
+    const uint32_t clog = B <= 4 ? 0u : B <= 8 ? 1u : 2u, Cn = 1u << clog;
+    uint32_t round = 0, batch = 0;
+    bool finished = false, left = false;
+    while (!finished) {
+      const uint32_t P = s >> 1;
+      // ---- evaluate: item (pair p, point xi, tree group c) = sum over the group's four trees of l'_k(X) r_k(X)
+      const uint32_t items = (P * 2) << clog;
+      for (uint32_t base = wave * 64; base < items; base += GKR_THREADS) {
+        const uint32_t it = base + lane;
+        const bool valid = it < items;
+        const uint32_t c = it & (Cn - 1), xi = (it >> clog) & 1u, p = it >> (clog + 1);
+        Fr av[4], bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const uint32_t k = 4 * c + q;
+          if (valid && k < B) {
+            const Fr* pl = tab + (2 * k) * stride + 2 * p;
+            const Fr* pr = tab + (2 * k + 1) * stride + 2 * p;
+            const Fr l0 = pl[0], l1 = pl[1], r0 = pr[0], r1 = pr[1];
+            av[q] = xi ? sub(dbl(l1), l0) : l1;
+            bv[q] = xi ? sub(dbl(r1), r0) : r1;
+          } else {
+            av[q] = Fr::zero(), bv[q] = Fr::zero();
+          }
+        }
+        Fr t = dot<FrParams, 4>(av, bv);
+        if (clog >= 1) t = add(t, shfl_xor_fr(t, 1));
+        if (clog >= 2) t = add(t, shfl_xor_fr(t, 2));
+        if (valid && c == 0) red[xi * P + p] = mul(t, E[p]);
+      }
+      __syncthreads();
+      const uint32_t seq = seq0 + 1 + round;
+      if (wave == 0) {
+        // lanes 0..31 sum the pairs at X = 1, lanes 32..63 at X = 2
+        const uint32_t half = lane >> 5, l5 = lane & 31u;
+        Fr v = Fr::zero();
+        for (uint32_t p = l5; p < P; p += 32) v = add(v, red[half * P + p]);
+        for (uint32_t off = 1; off < 32 && off < P; off <<= 1) v = add(v, shfl_xor_fr(v, (int)off));
+        uint32_t last = 1;
+        if (!multi) {
+          if (l5 == 0) tail_send(a.msg_host, half, v, seq);
+        } else {
+          Fr* part = a.part + (size_t)(round & 1u) * g * 2;
+          if (l5 == 0) part[wg * 2 + half] = v;
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          last = 0;
+          if (lane == 0) last = tail_ticket(a.ticket, my_tbase + batch * g + g - 1) ? 1u : 0u;
+          last = __shfl(last, 0, 64);
+          if (last) {
+            Fr w = Fr::zero();
+            for (uint32_t x = l5; x < g; x += 32) w = add(w, part[x * 2 + half]);
+            for (uint32_t off = 1; off < 32 && off < g; off <<= 1) w = add(w, shfl_xor_fr(w, (int)off));
+            if (l5 == 0) tail_send(a.msg_host, half, w, seq);
+          }
+        }
+        // ---- the challenge: the workgroup that sent the message asks the host and relays it through device memory
+        const bool talker = last != 0;
+        const TailChunk* box = talker ? a.mbox_round : a.relay;
+        const uint64_t t0 = wall_clock64();
+        uint32_t stop = 0;
+        u32x4 v4 = {0u, 0u, 0u, 0u};
+        for (;;) {
+          if (lane < 3) v4 = load_sys_x4(&box[lane]);
+          const uint64_t ok = __ballot(lane >= 3 || v4.x == seq);
+          if (ok == ~0ull) break;
+          const uint64_t ab = __ballot(lane < 3 && v4.x == SC_TAIL_ABORT);
+          if (ab || wall_clock64() - t0 > a.poll_ticks) {
+            stop = 1;
+            break;
+          }
+        }
+        if (talker && multi && lane < 3) store_sys_x4((void*)&a.relay[lane], stop ? u32x4{SC_TAIL_ABORT, 0u, 0u, 0u} : v4);
+        if (talker && stop && lane == 0) store_sys_x4((void*)&a.relay[4], u32x4{SC_TAIL_ABORT, 0u, 0u, 0u});
+        if (lane < 3) {
+          r_sh.l[3 * lane] = v4.y, r_sh.l[3 * lane + 1] = v4.z;
+          if (lane < 2) r_sh.l[3 * lane + 2] = v4.w;
+        }
+        if (lane == 0) stop_sh = stop;
+      }
+      if (multi) batch++;
+      __syncthreads();
+      if (stop_sh) return;
+      const Fr r = r_sh;
+      round++;
+      if (multi && P == 1) {
+        // ---- hand-over: one bound entry per table and this workgroup's eq scalar -> the last arrival goes on alone
+        if (wave == 0) {
+          if (lane < T) {
+            const Fr v0 = tab[lane * stride], v1 = tab[lane * stride + 1];
+            a.hand[(size_t)lane * g + wg] = add(mul(sub(v1, v0), r), v0);
+          } else if (lane == T) {
+            a.hand[(size_t)T * g + wg] = E[0];
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0) last_sh = tail_ticket(a.ticket, my_tbase + batch * g + g - 1) ? 1u : 0u;
+        }
+        __syncthreads();
+        if (!last_sh) {
+          left = true;
+          break;
+        }
+        for (uint32_t e = tid; e < (T + 1) * g; e += GKR_THREADS) {
+          const Fr v = a.hand[e];
+          if (e < T * g) tab[e] = v;  // (table t at t * g: the new stride)
+          else red[e - T * g] = v;
+        }
+        __syncthreads();
+        if (tid < (g >> 1)) E[tid] = add(red[2 * tid], red[2 * tid + 1]);
+        __syncthreads();
+        stride = g, s = g, multi = false;
+        continue;
+      }
+      if (P == 1) {
+        // ---- the layer's final evaluations: l'_k(x), r_k(x)
+        if (tid < T) {
+          const Fr v0 = tab[tid * stride], v1 = tab[tid * stride + 1];
+          a.out_host[tid] = add(mul(sub(v1, v0), r), v0);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        }
+        __syncthreads();
+        if (tid == 0) publish_flag(a.flag, seq0 + h + 1);
+        finished = true;
+        break;
+      }
+      // ---- bind in place (every thread reads its inputs, then all write), next eq level by pair sums
+      Fr outv[8];
+      const uint32_t outputs = T * P, plog = 31u - (uint32_t)__clz(P);
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const uint32_t idx = tid + (uint32_t)i * GKR_THREADS;
+        if (idx < outputs) {
+          const uint32_t t = idx >> plog, e = idx & (P - 1);
+          const Fr v0 = tab[t * stride + 2 * e], v1 = tab[t * stride + 2 * e + 1];
+          outv[i] = add(mul(sub(v1, v0), r), v0);
+        }
+      }
+      Fr en = Fr::zero();
+      if (tid < (P >> 1)) en = add(E[2 * tid], E[2 * tid + 1]);
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const uint32_t idx = tid + (uint32_t)i * GKR_THREADS;
+        if (idx < outputs) tab[(idx >> plog) * stride + (idx & (P - 1))] = outv[i];
+      }
+      if (tid < (P >> 1)) E[tid] = en;
+      __syncthreads();
+      s = P;
+    }
+    i_poll = finished && !left;
+  }
+}
+
+size_t k_gkr_resident_lds_bytes(uint32_t max_trees, uint32_t cap) {
+  return ((size_t)2 * max_trees * cap + cap / 2 + 1 + cap + 2 + GKR_MAX_TREES + GKR_MAX_VARS) * sizeof(Fr);
+}
+
+// geometry of a resident layer over tables of 2^h entries: one workgroup while that is cheap (no ticket, no partial
+// sums through device memory: ~5 us per round), else slices of 64 entries, 128 when that takes more than 128 workgroups
+bool k_gkr_resident_geometry(uint32_t h, uint32_t* g, uint32_t* s_log) {
+  if (h < 1 || h > GKR_MAX_VARS - 2) return false;
+  if (h <= 7) {
+    *g = 1, *s_log = h;
+    return true;
+  }
+  uint32_t sl = 6;
+  while ((1u << (h - sl)) > GKR_CAP) sl++;
+  if ((1u << sl) > GKR_CAP) return false;
+  *g = 1u << (h - sl), *s_log = sl;
+  return true;
+}
+
+void k_gkr_resident_launch(Ctx& c, const GkrLayerDev* layers, size_t num_layers, TailChunk* msg_host, Fr* out_host) {
+  LH_REQUIRE(num_layers >= 1, LH_ERR_ARG, "resident layers: none");
+  uint32_t G = 1, max_trees = 1, tickets = 0, prev_g = 1;
+  for (size_t i = 0; i < num_layers; i++) {
+    const GkrLayerDev& L = layers[i];
+    LH_REQUIRE(L.B >= 1 && L.B <= (uint32_t)GKR_MAX_TREES && L.h >= 1 && L.h <= (uint32_t)GKR_MAX_VARS - 2 && L.g >= prev_g &&
+                   ((size_t)L.g << L.s_log) == ((size_t)1 << L.h) && (1u << L.s_log) <= GKR_CAP && L.g <= GKR_CAP && L.s_log >= 1,
+               LH_ERR_ARG, "resident layers: bad geometry");
+    prev_g = L.g;
+    G = std::max(G, L.g);
+    max_trees = std::max(max_trees, L.B);
+    if (L.g > 1) tickets += (L.s_log + 1) * L.g;
+  }
+  GkrResArgs a;
+  GkrLayerDev* d_layers = (GkrLayerDev*)c.arena.alloc(num_layers * sizeof(GkrLayerDev));
+  // (the descriptors travel through the ctx's pinned staging block: the caller's vector may die before the copy runs)
+  GkrLayerDev* staged = (GkrLayerDev*)((char*)c.pin(65536) + 32768);
+  LH_REQUIRE(num_layers * sizeof(GkrLayerDev) <= 32768, LH_ERR_ARG, "resident layers: too many");
+  memcpy(staged, layers, num_layers * sizeof(GkrLayerDev));
+  LH_HIP(hipMemcpyAsync(d_layers, staged, num_layers * sizeof(GkrLayerDev), hipMemcpyHostToDevice, c.stream));
+  a.layers = d_layers;
+  a.num_layers = (uint32_t)num_layers;
+  a.cap = GKR_CAP;
+  a.max_trees = max_trees;
+  a.ticket = c.ticket;
+  a.ticket_base = c.ticket_base;
+  c.ticket_base += tickets;
+  a.part = c.arena.alloc_n<Fr>((size_t)4 * G + (size_t)(2 * max_trees + 1) * G);
+  a.hand = a.part + (size_t)4 * G;
+  c.gkr_boxes();
+  a.relay = c.gkr_relay;
+  a.mbox_round = c.mbox()->c;
+  a.mbox_layer = c.gkr_mbox;
+  a.msg_host = msg_host;
+  a.out_host = out_host;
+  a.flag = c.flag;
+  const char* tmo = getenv("LH_SC_TAIL_TIMEOUT_MS");
+  const double ms = tmo && *tmo ? atof(tmo) : 2000.0;
+  a.poll_ticks = (uint64_t)(ms * (double)c.wall_clock_khz);
+  c.mbox_send(Fr::zero(), 0u);
+  const size_t lds = k_gkr_resident_lds_bytes(max_trees, GKR_CAP);
+  c.opt_in_lds((const void*)gkr_resident_kernel, (int)k_gkr_resident_lds_bytes(GKR_MAX_TREES, GKR_CAP));
+  hipLaunchKernelGGL(gkr_resident_kernel, dim3(G), dim3(GKR_THREADS), lds, c.stream, a);
+  LH_HIP(hipGetLastError());
+}
+
+}  // namespace lh

@@ -907,6 +907,127 @@ FracSumCheckResult prove_fractional_sum_check(Ctx& c, size_t B, size_t num_vars,
   return FracSumCheckResult{claimed_p, claimed_q, y};
 }
 
+// ------------------------------------------------------------------ resident layers of a grand product (kernels_gkr.hip)
+// Host side of the resident kernel: ONE launch serves the layers h = 1 .. H; per layer the host sends the batching
+// coefficients and the layer's point, turns every round's q(1), q(2) into the reference's message p(0..3) (the eq
+// factoring of host.hpp EqFactoring: p(X) = S eq(y_j, X) q(X), q(0) from the claim), squeezes the challenge and sends
+// it back, and at the end of the layer unfolds the coefficients from the left factors' evaluations.
+namespace {
+struct GkrResident {
+  Ctx& c;
+  size_t H = 0;            // resident layers 1 .. H (0: none)
+  bool live = false;       // the kernel is running and expects messages
+  std::vector<uint32_t> seq_of;  // layer h -> sequence number of its layer message
+  TailChunk* chunks = nullptr;
+  Fr* out_host = nullptr;
+  ArenaScope* scope = nullptr;
+  std::unique_ptr<ProfScope> prof;
+  explicit GkrResident(Ctx& c_) : c(c_) {}
+  ~GkrResident() { stop(false); }
+  // the kernel leaves (or has left): tell it, wait for it, put the ticket counter and the boxes back in order
+  void stop(bool finished) {
+    if (!live) return;
+    live = false;
+    if (!finished) {
+      c.gkr_abort();
+      (void)hipStreamSynchronize(c.stream);
+      try {
+        c.gkr_resync();
+      } catch (...) {
+      }
+    }
+    prof.reset();
+  }
+  void launch(const std::vector<GkrLayerDev>& layers) {
+    H = layers.size();
+    seq_of.assign(H + 1, 0);
+    std::vector<GkrLayerDev> ls(layers);
+    uint32_t seq = c.flag_seq + 1;
+    double entries = 0;
+    for (size_t i = 0; i < H; i++) {
+      ls[i].seq = seq;
+      seq_of[i + 1] = seq;
+      seq += ls[i].h + 2;
+      entries += (double)ls[i].B * 2.0 * (double)((size_t)1 << ls[i].h);
+    }
+    c.flag_seq = seq - 1;
+    Fr* pin = (Fr*)c.pin((16 + 2 * SC_MAX_TABLES) * sizeof(Fr));
+    chunks = (TailChunk*)pin;
+    memset((void*)chunks, 0, 6 * sizeof(TailChunk));
+    out_host = pin + 16;
+    prof.reset(new ProfScope(c, "gkr_resident", 32.0 * entries, 0, entries));
+    k_gkr_resident_launch(c, ls.data(), H, chunks, out_host);
+    live = true;
+  }
+  // one layer: false when the layer cannot run factored (a zero among 1 - y_j or the coefficients): the kernel is
+  // stopped and the caller goes on with launched sum-checks from this layer on
+  bool layer(size_t h, const std::vector<HFr>& coeff, const std::vector<HFr>& y, const HFr& claim, Transcript& tr,
+             std::vector<HFr>& x, std::vector<HFr>& evals) {
+    const size_t B = coeff.size();
+    const HFr one = HFr::one();
+    // (1 - y_j)^-1 and c_k^-1 with one inversion
+    std::vector<HFr> d(h + B), pre(h + B + 1);
+    bool ok = true;
+    for (size_t j = 0; j < h; j++) d[j] = one - y[j];
+    for (size_t k = 0; k < B; k++) d[h + k] = coeff[k];
+    pre[0] = one;
+    for (size_t i = 0; i < h + B; i++) {
+      ok = ok && !d[i].is_zero();
+      pre[i + 1] = pre[i] * d[i];
+    }
+    if (!ok) {
+      stop(false);
+      return false;
+    }
+    const uint32_t seq = seq_of[h];
+    std::vector<HFr> msg(coeff);
+    msg.insert(msg.end(), y.begin(), y.end());
+    c.gkr_send_layer((const Fr*)msg.data(), msg.size(), seq);
+    // (the kernel loads and folds its tables meanwhile)
+    HFr inv = pre[h + B].inv();
+    std::vector<HFr> dinv(h + B);
+    for (size_t i = h + B; i-- > 0;) {
+      dinv[i] = inv * pre[i];
+      inv = inv * d[i];
+    }
+    static const HFr inv2 = HFr::from_u64(2).inv();
+    const HFr two = HFr::from_u64(2), three = HFr::from_u64(3), five = HFr::from_u64(5);
+    HFr S = one, cq = claim, cl = claim;
+    x.clear();
+    Fr q12[2];
+    for (size_t j = 0; j < h; j++) {
+      c.wait_chunks(chunks, 6, seq + 1 + (uint32_t)j, q12);
+      const HFr q1 = hst(q12[0]), q2 = hst(q12[1]), yj = y[j];
+      const HFr q0 = (cq - yj * q1) * dinv[j];
+      const HFr q3 = (q2 - q1) * three + q0;  // the quadratic through q(0), q(1), q(2) at 3
+      std::vector<HFr> ev(4);
+      ev[1] = S * yj * q1;                       // eq(y_j, 1) = y_j
+      ev[2] = S * (yj * three - one) * q2;       // eq(y_j, 2) = 3 y_j - 1
+      ev[3] = S * (yj * five - two) * q3;        // eq(y_j, 3) = 5 y_j - 2
+      ev[0] = cl - ev[1];                        // eval.rs:129
+      tr.write_field_elements(ev);
+      const HFr r = tr.squeeze_challenge();
+      c.mbox_send(dev(r), seq + 1 + (uint32_t)j);
+      c.route.v[RouteStats::TAIL_ROUNDS]++;
+      // (off the critical path: the kernel binds and evaluates the next round meanwhile)
+      const HFr rm1 = r - one, rm2 = r - two;
+      cq = q0 * rm1 * rm2 * inv2 - q1 * r * rm2 + q2 * r * rm1 * inv2;
+      S = S * ((one - yj) * (one - r) + yj * r);
+      cl = S * cq;
+      x.push_back(r);
+    }
+    c.wait_flag(seq + (uint32_t)h + 1);
+    evals.resize(2 * B);
+    for (size_t k = 0; k < B; k++) {
+      evals[2 * k] = hst(out_host[2 * k]) * dinv[h + k];
+      evals[2 * k + 1] = hst(out_host[2 * k + 1]);
+    }
+    if (h == H) stop(true);
+    return true;
+  }
+};
+}  // namespace
+
 // ------------------------------------------------------------------ grand product (Lasso memory check)
 // Product-only layered circuit; schedule in oracle/pyref/gkr.py::prove_grand_product.
 GrandProductResult prove_grand_product(Ctx& c, size_t B, const Fr* const* d_leaves, const size_t* num_vars,
@@ -1007,6 +1128,35 @@ GrandProductResult prove_grand_product(Ctx& c, size_t B, const Fr* const* d_leav
   tr.write_field_elements(res.roots);
 
   std::vector<HFr> claims = res.roots, y;
+  HFr resident_lam;
+  bool have_resident_lam = false;
+  // the layers near the roots in ONE resident launch (kernels_gkr.hip; Options::gkr_resident): every layer from h = 1 up
+  // whose tables fit, as long as it is an ordinary layer (all trees given, no (A, A + 1) leaf pairs, not sharded)
+  GkrResident resident(c);
+  if (c.opt.gkr_resident && c.opt.sc_tail && c.opt.sc_eq_factoring) {
+    std::vector<GkrLayerDev> layers;
+    for (size_t h = 1; h < max_depth; h++) {
+      GkrLayerDev L;
+      memset(&L, 0, sizeof(L));
+      uint32_t nb = 0;
+      bool ok = !sh.sharded(h + 1) && k_gkr_resident_geometry((uint32_t)h, &L.g, &L.s_log);
+      bool any_leaf = false, all_leaf = true;
+      for (size_t b = 0; b < B && ok; b++) {
+        if (num_vars[b] <= h) continue;
+        ok = nb < (uint32_t)GKR_MAX_TREES && level[b][h] != nullptr;
+        if (!ok) break;
+        any_leaf = any_leaf || num_vars[b] == h + 1;
+        all_leaf = all_leaf && num_vars[b] == h + 1;
+        L.lv[nb++] = level[b][h];
+      }
+      // (a layer at which trees end may be a paired leaf layer: those keep their own kernel)
+      if (ok && plus_one && any_leaf && all_leaf) ok = false;
+      if (!ok || nb == 0) break;
+      L.h = (uint32_t)h, L.B = nb;
+      layers.push_back(L);
+    }
+    if (!layers.empty()) resident.launch(layers);
+  }
   if (c.gkr_hook) {  // (the trees are built: from here on the small layers leave most of the chip idle)
     std::function<void()> hook;
     hook.swap(c.gkr_hook);
@@ -1016,6 +1166,38 @@ GrandProductResult prove_grand_product(Ctx& c, size_t B, const Fr* const* d_leav
     std::vector<size_t> active;
     for (size_t b = 0; b < B; b++)
       if (num_vars[b] > h) active.push_back(b);
+    if (h >= 1 && resident.live && h <= resident.H) {
+      // a resident layer: same transcript schedule, the sum-check's device half is already running
+      HFr lam = tr.squeeze_challenge();
+      HFr claim = HFr::zero(), power = HFr::one();
+      std::vector<HFr> coeff;
+      for (size_t b : active) {
+        claim += claims[b] * power;
+        coeff.push_back(power);
+        power *= lam;
+      }
+      std::vector<HFr> x, evals;
+      if (resident.layer(h, coeff, y, claim, tr, x, evals)) {
+        c.route.v[RouteStats::RESIDENT_LAYERS]++;
+        tr.write_field_elements(evals);
+        HFr mu = tr.squeeze_challenge();
+        x.push_back(mu);
+        y = x;
+        for (size_t k = 0; k < active.size(); k++) {
+          const size_t b = active[k];
+          const HFr &l = evals[2 * k], &r = evals[2 * k + 1];
+          claims[b] = l + mu * (r - l);
+          if (num_vars[b] == h + 1) {
+            res.claims[b] = claims[b];
+            res.points[b] = y;
+          }
+        }
+        continue;
+      }
+      // (degenerate challenge: the kernel is gone; this layer and the following ones take the launched path - lambda is
+      // squeezed already)
+      resident_lam = lam, have_resident_lam = true;
+    }
     const bool layer_sh = sh.sharded(h + 1);  // this layer's tables (h variables each) are shards
     const size_t half = (size_t)1 << (layer_sh ? h - sh.rho : h);
     std::vector<HFr> x, evals;
@@ -1025,7 +1207,8 @@ GrandProductResult prove_grand_product(Ctx& c, size_t B, const Fr* const* d_leav
         evals.push_back(top[2 * b + 1]);
       }
     } else {
-      HFr lam = tr.squeeze_challenge();
+      HFr lam = have_resident_lam ? resident_lam : tr.squeeze_challenge();
+      have_resident_lam = false;
       HFr claim = HFr::zero(), power = HFr::one();
       lh_sop expr;
       memset(&expr, 0, sizeof(expr));

@@ -267,6 +267,11 @@ lh_status lh_lasso_last_timing(lh_ctx*, double* out_ms);
  *                             base, W-fold the level's memory): the W windows of a full-width column then fill ONE
  *                             bucket set - one bucket reduction, no doublings.  Measured neutral at 2^24 lookups (shorter
  *                             reduction, longer bucket runs): off by default
+ *   gkr_resident         1    the layers near the roots of a grand-product argument (tables of <= 2^14 entries, <= 16 trees)
+ *                             run in ONE resident launch - layer loop, eq tables, rounds and final evaluations inside the
+ *                             kernel (kernels_gkr.hip); 0: one sum-check per layer (eq kernels, launched rounds, a resident
+ *                             tail each).  Needs sc_tail and sc_eq_factoring
+ * Values outside an option's range are refused (LH_ERR_ARG).
  * lh_lasso_last_route reports which of these routes the last Lasso prove on the ctx actually took, so that a byte
  * mismatch in the field can be bisected from the outside. */
 lh_status lh_ctx_set_option(lh_ctx*, const char* name, int64_t value);
@@ -287,7 +292,8 @@ typedef struct lh_lasso_route {
   uint32_t shard_exchanges;     /* residual-table / tree-level / remainder exchanges (sharded proofs) */
   uint32_t window_table_jobs;   /* MSM jobs that ran over a window table (msm_window_tables) */
   uint32_t open_precommit;      /* 1: the opening's column-wise commitments were taken from the helper ctx (open_precommit) */
-  uint32_t reserved[2];
+  uint32_t resident_layers;     /* grand-product layers that ran inside the resident multi-layer kernel (gkr_resident) */
+  uint32_t reserved[1];
 } lh_lasso_route;
 lh_status lh_lasso_last_route(lh_ctx*, lh_lasso_route* out);
 

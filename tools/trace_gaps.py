@@ -1,5 +1,5 @@
 """Development aid: timeline of the LAST proof in a rocprofv3 (rocpd sqlite) kernel trace: busy time, idle gaps and
-the kernels around the largest gaps.  usage: python tools/trace_gaps.py <results.db> [proof_ms]"""
+the kernels around the largest gaps.  usage: [LH_TRACE_COLUMNS=4] python tools/trace_gaps.py <results.db> [kernel-name regex for a per-launch listing]"""
 import re
 import sqlite3
 import sys
@@ -8,9 +8,14 @@ db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select name, start, end, grid_x, workgroup_x, vgpr_count from kernels order by start").fetchall()
 short = lambda n: re.sub(r"\(.*", "", re.sub(r"^(void )?(lh::|rocprim::\w+::detail::)?", "", n))[:44]
 # the last proof starts at the last lasso iota kernel before which there is a long idle period
-starts = [i for i, r in enumerate(rows) if "lasso_iota_kernel" in r[0]]
-per = 2  # counters columns per proof (range table c = 2)
+# (the access counters of a proof launch lasso_run_start_kernel once per chunk column; the proof begins with the sort in
+# front of the first of them: walk back over the kernels that follow each other closely)
+import os
+starts = [i for i, r in enumerate(rows) if "lasso_run_start_kernel" in r[0]]
+per = int(os.environ.get("LH_TRACE_COLUMNS", "2"))  # chunk columns per proof (range table: 2, AND / XOR: 4)
 i0 = starts[-per]
+while i0 > 0 and rows[i0][1] - rows[i0 - 1][2] < 150e3:
+    i0 -= 1
 ks = rows[i0:]
 t0, t1 = ks[0][1], max(r[2] for r in ks)
 busy = sum(r[2] - r[1] for r in ks)
