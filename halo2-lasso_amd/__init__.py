@@ -943,7 +943,7 @@ def lasso_last_timing(ctx):
 
 ROUTE_FIELDS = ["open_small_depth", "open_small_passes", "eq_factored_rounds", "standard_rounds", "rw_leaf_rounds",
                 "resident_tails", "resident_rounds", "packed_ts_pairs", "derived_commitments", "sorted_dim_reuse",
-                "sharded_rounds", "shard_exchanges", "window_table_jobs", "open_precommit", "resident_layers"]
+                "sharded_rounds", "shard_exchanges", "window_table_jobs", "open_precommit", "resident_layers", "pp_folds"]
 
 
 def lasso_last_route(ctx):

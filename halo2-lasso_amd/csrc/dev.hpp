@@ -108,6 +108,9 @@ struct Options {
                                        // a Lasso prove (0: never; 1: always)
   int64_t msm_window_tables = 0;       // SRS levels of <= 2^this points get a window table (MsmJob::win_table) on first use:
                                        // full-width columns over them reduce ONE bucket set (0: no tables)
+  int64_t sc_pp_fold = 1;              // 0: the generic layers of the grand products keep their coefficients as products of
+                                       // every round (sc_round_e2) instead of folding them into the left factors and sharing
+                                       // Montgomery reductions (sc_round_pp)
   int64_t gkr_resident = 1;            // the layers of a grand-product argument whose tables fit the resident kernel run in ONE
                                        // launch (layer loop, eq tables and rounds inside; 0: one sum-check per layer)
   Options();                           // environment defaults (dev.cpp)
@@ -117,7 +120,7 @@ struct Options {
 struct RouteStats {  // lh_lasso_route (include/lasso_hip.h): counters of the last Lasso prove on the ctx
   uint32_t v[LH_LASSO_ROUTE_WORDS] = {0};
   enum { OPEN_DEPTH, OPEN_PASSES, EF_ROUNDS, STD_ROUNDS, RW_ROUNDS, TAILS, TAIL_ROUNDS, PACKED_TS, DERIVED, SORTED_REUSE,
-         SHARDED_ROUNDS, SHARD_EXCHANGES, WIN_TABLE_JOBS, OPEN_PRECOMMIT, RESIDENT_LAYERS };
+         SHARDED_ROUNDS, SHARD_EXCHANGES, WIN_TABLE_JOBS, OPEN_PRECOMMIT, RESIDENT_LAYERS, PP_FOLDS };
 };
 
 // ------------------------------------------------------------------ a long-lived host thread (dev.cpp)
@@ -170,6 +173,7 @@ struct Ctx {
   void wait_round(uint32_t seq) {  // the host's wait for a round kernel's sums (nothing to wait for when they stay on the device)
     if (!sc_redirect) wait_flag(seq);
   }
+  bool last_round_folded = false;  // k_sc_round: the launch it chose folded the coefficients into the left factors (ScRound::pp)
   uint64_t* tail_trace = nullptr;  // development: device stamps of the last resident tail (LH_SC_TAIL_TRACE)
   // eq tables of point tails y[1..n) built during one proof (prover.cpp eq_half_*): an evaluation, a sum-check and the batch
   // opening at the same point share one table.  Arena memory of the proof's scope: the proof clears the list (EqHalfScope).
@@ -441,6 +445,11 @@ struct ScRound {
   // "eq factoring" (prover.cpp): when set, global_eq is -1 and the eq factor of the expression is eq_level[b], the eq
   // table over the variables AFTER this round's; the kernel returns q(X) = sum_b eq_level[b] * g(X, b)
   const Fr* eq_level;
+  // product-pair shape (every term coeff_m * l_m * r_m over 2 num_terms distinct tables, factored eq; the generic layers of
+  // the grand products): 1 = the factored degree-2 rounds run sc_round_pp_kernel (four products per Montgomery reduction);
+  // 2 = this BIND round also FOLDS the coefficients into the left factors (l'_m = coeff_m l_m is what it stores: the
+  // caller treats the coefficients as one from then on and divides them out of the final evaluations)
+  uint8_t pp;
 };
 // evals_host[0..degree) receives sum_b expr at X = 1..degree (X = 0 is derived by the caller)
 void k_sc_round(Ctx&, const ScRound& rd, int degree, bool bind, size_t size, Fr* evals_host);

@@ -256,6 +256,78 @@ __global__ __launch_bounds__(256) LH_E_WAVES_ATTR(LH_E_WAVES_E2) void sc_round_e
   finish_round<2>(fin, partials, lds);
 }
 
+// The product-pair shape (ScRound::pp): q(1), q(2) of sum_b eq_level[b] sum_m c_m l_m r_m, one lane per bound entry as
+// above, the products of four terms in ONE Montgomery reduction (ff.cuh dot_scan: 4 x 64 + 65 multiply-adds instead of
+// 4 x 129) and the coefficients folded into the left factors at the first bind (ScRound::pp == 2: l'_m = c_m l_m is
+// stored; before that - round 0 - they are applied on the way, afterwards they are one).  Per lane of an 8-tree layer:
+// 16 binds + 2 four-term reductions (~5 products' worth) + the eq entry instead of 16 + 16 + 1.
+// Loads first: the entries of a PAIR of terms (four tables, eight 32-byte entries per lane when binding) are requested
+// before anything is computed or stored - written table by table (load, bind, store, next table) the stores keep the
+// compiler from moving the next table's loads up, and a wave has one table's 4 KB in flight at a time.
+template <bool BIND>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void sc_round_pp_kernel(ScArgs a, size_t size, Fr* __restrict__ partials, ScFinish fin) {
+  __shared__ Fr lds[4];
+  const ScRound& rd = a.rd;
+  Fr acc = Fr::zero();
+  const size_t items = 2 * size;
+  const bool odd = threadIdx.x & 1;
+  const bool fold = BIND && rd.pp == 2;
+  const uint32_t K = rd.num_terms;
+  const Fr rch = rd.r;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < items; i += (size_t)gridDim.x * blockDim.x) {
+    Fr s = Fr::zero();
+    for (uint32_t m0 = 0; m0 < K; m0 += 4) {
+      Fr av[4], bv[4];
+#pragma unroll
+      for (int h2 = 0; h2 < 2; h2++) {
+        // the four tables of terms m0 + 2 h2, m0 + 2 h2 + 1 (a term past the end reads term 0's tables again, unused)
+        const uint32_t ma = m0 + 2 * h2, mb = ma + 1;
+        const bool va = ma < K, vb = mb < K;
+        const int t0 = rd.fac[va ? ma : 0][0], t1 = rd.fac[va ? ma : 0][1], t2 = rd.fac[vb ? mb : 0][0], t3 = rd.fac[vb ? mb : 0][1];
+        const Fr* __restrict__ p0 = rd.in[t0];
+        const Fr* __restrict__ p1 = rd.in[t1];
+        const Fr* __restrict__ p2 = rd.in[t2];
+        const Fr* __restrict__ p3 = rd.in[t3];
+        Fr x0, x1, x2, x3;
+        if (BIND) {
+          const Fr e00 = p0[2 * i], e01 = p0[2 * i + 1], e10 = p1[2 * i], e11 = p1[2 * i + 1];
+          const Fr e20 = p2[2 * i], e21 = p2[2 * i + 1], e30 = p3[2 * i], e31 = p3[2 * i + 1];
+          x0 = add(mul(sub(e01, e00), rch), e00);
+          x1 = add(mul(sub(e11, e10), rch), e10);
+          x2 = add(mul(sub(e21, e20), rch), e20);
+          x3 = add(mul(sub(e31, e30), rch), e30);
+        } else {
+          x0 = p0[i], x1 = p1[i], x2 = p2[i], x3 = p3[i];
+        }
+        if (va && !rd.coeff_is_one[ma]) x0 = mul(x0, rd.coeff[ma]);
+        if (vb && !rd.coeff_is_one[mb]) x2 = mul(x2, rd.coeff[mb]);
+        if (BIND) {
+          if (va) rd.out[t0][i] = x0, rd.out[t1][i] = x1;   // (a folding round stores l' = c l; otherwise c is one here
+          if (vb) rd.out[t2][i] = x2, rd.out[t3][i] = x3;   //  or - round 0 - nothing is stored)
+        }
+        av[2 * h2] = va ? at_lane_point(x0, odd) : Fr::zero();
+        bv[2 * h2] = va ? at_lane_point(x1, odd) : Fr::zero();
+        av[2 * h2 + 1] = vb ? at_lane_point(x2, odd) : Fr::zero();
+        bv[2 * h2 + 1] = vb ? at_lane_point(x3, odd) : Fr::zero();
+      }
+      s = add(s, dot<FrParams, 4>(av, bv));
+    }
+    acc = add(acc, mul(s, rd.eq_level[i >> 1]));
+  }
+  (void)fold;
+  Fr q2, q1;
+  reduce_by_parity(acc, odd, lds, q2, q1);
+  if (threadIdx.x == 0) {
+    partials[(size_t)blockIdx.x * 2] = q1;
+    partials[(size_t)blockIdx.x * 2 + 1] = q2;
+  }
+  if (gridDim.x == 1) {
+    if (threadIdx.x == 0) publish_flag(fin.flag, fin.seq);
+    return;
+  }
+  finish_round<2>(fin, partials, lds);
+}
+
 // ------------------------------------------------------------------ small / medium rounds: LDS-staged
 // The late rounds of every sum-check (and whole GKR layers near the root) are latency-bound: few pairs,
 // but one thread walking a whole term is a chain of ~15 dependent field multiplications (~1 us each
@@ -913,6 +985,7 @@ void k_sc_round_rw(Ctx& c, const ScRwRound& rd, bool bind, size_t size, Fr* out_
 }
 
 void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, Fr* evals_host) {
+  c.last_round_folded = false;  // (set below when the product-pair kernel ran a folding round: ScRound::pp == 2)
   LH_REQUIRE(degree >= 1 && degree <= 6, LH_ERR_ARG, "sum-check degree must be in 1..6");
   LH_REQUIRE(size >= 1, LH_ERR_ARG, "sum-check round over an empty table");
   ScArgs a;
@@ -994,7 +1067,15 @@ void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, F
     size_t g2 = std::min<size_t>((2 * size + 255) / 256, (size_t)c.num_cus * sc_entry_blocks_per_cu());
     Fr* partials = g2 == 1 ? evals_host : c.arena.alloc_n<Fr>(g2 * 2);
     const ScFinish kflag = finish(g2);
-    {
+    c.last_round_folded = rd.pp == 2 && bind;
+    if (rd.pp) {
+      // products per pair: binds, one per coefficient still applied on the way, ~0.62 per term for the shared reductions
+      // (two points), the eq entry
+      const double mp = (bind ? 2.0 * nfac : 0.0) + ncoef + 2.0 * 0.62 * rd.num_terms + 2.0;
+      ProfScope ps(c, bind ? "sc_round_pp<bind>" : "sc_round_pp<first>", bytes, mp * (double)size, (double)size);
+      if (bind) hipLaunchKernelGGL((sc_round_pp_kernel<true>), dim3((unsigned)g2), dim3(256), 0, c.stream, a, size, partials, kflag);
+      else hipLaunchKernelGGL((sc_round_pp_kernel<false>), dim3((unsigned)g2), dim3(256), 0, c.stream, a, size, partials, kflag);
+    } else {
       ProfScope ps(c, bind ? "sc_round<2,bind>" : "sc_round<2,first>", bytes, muls_pair * (double)size, (double)size);
       if (bind) hipLaunchKernelGGL((sc_round_e2_kernel<true>), dim3((unsigned)g2), dim3(256), 0, c.stream, a, size, partials, kflag);
       else hipLaunchKernelGGL((sc_round_e2_kernel<false>), dim3((unsigned)g2), dim3(256), 0, c.stream, a, size, partials, kflag);

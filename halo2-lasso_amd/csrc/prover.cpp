@@ -699,6 +699,24 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
       use_ef = ok;
     }
   }
+  // product-pair shape (dev.hpp ScRound::pp): every term c_m l_m r_m over 2 num_terms distinct tables, non-zero
+  // coefficients.  Its factored rounds run sc_round_pp_kernel, and the first of them that binds folds the coefficients
+  // into the left factors: from then on every kernel of this sum-check (streaming, LDS-staged, resident tail) sees
+  // coefficients of one, and the final evaluations of the left factors are divided by c_m at the end.
+  bool pp_shape = use_ef && !ef.per_term && !rw && rd.num_terms >= 2 && c.opt.sc_pp_fold != 0;
+  {
+    std::vector<char> seen(T, 0);
+    for (uint32_t m = 0; m < rd.num_terms && pp_shape; m++) {
+      HFr co;
+      memcpy(&co, &rd.coeff[m], 32);
+      pp_shape = rd.nfac[m] == 2 && !co.is_zero();
+      for (int k = 0; k < 2 && pp_shape; k++) {
+        pp_shape = rd.fac[m][k] < num_polys && !seen[rd.fac[m][k]];
+        seen[rd.fac[m][k]] = 1;
+      }
+    }
+  }
+  std::vector<HFr> pp_folded;  // the coefficients that went into the left factors (empty: not folded)
   if (use_ef) {
     const Shard shg(c);
     const size_t half = (size_t)1 << (nvl - 1);
@@ -757,7 +775,18 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
         g.r = r;
         g.global_eq = -1;
         g.eq_level = ef.eqs[0].level[round];
+        g.pp = pp_shape && points == 2 ? 1 : 0;
+        if (g.pp && bind && pp_folded.empty()) g.pp = 2;  // this round stores l'_m = c_m l_m
         k_sc_round(c, g, points, bind, size, out_host);
+        if (g.pp == 2 && c.last_round_folded) {  // (the launch that was chosen for this size did fold)
+          pp_folded.resize(rd.num_terms);
+          for (uint32_t m = 0; m < rd.num_terms; m++) {
+            memcpy(&pp_folded[m], &rd.coeff[m], 32);
+            rd.coeff[m] = dev(HFr::one());
+            rd.coeff_is_one[m] = 1;
+          }
+          c.route.v[RouteStats::PP_FOLDS]++;
+        }
       } else {
         ScOpenRound g;
         g.num_terms = rd.num_terms;
@@ -782,8 +811,21 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
     else k_eq_xy(c, (const Fr*)(ys + jy * num_vars), num_vars, eq);
     cur[num_polys + jy] = eq;
   }
-  return sum_check_loop(c, prover_kind, num_vars, degree, cur, used, num_polys, sum, tr, sharded, round_fn, &rd,
-                        use_ef ? &ef : nullptr);
+  SumCheckResult res = sum_check_loop(c, prover_kind, num_vars, degree, cur, used, num_polys, sum, tr, sharded, round_fn, &rd,
+                                      use_ef ? &ef : nullptr);
+  if (!pp_folded.empty()) {
+    // the left factors came out times their coefficients: one inversion for all of them
+    const size_t K = pp_folded.size();
+    std::vector<HFr> pre(K + 1);
+    pre[0] = HFr::one();
+    for (size_t m = 0; m < K; m++) pre[m + 1] = pre[m] * pp_folded[m];
+    HFr inv = pre[K].inv();
+    for (size_t m = K; m-- > 0;) {
+      res.evals[rd.fac[m][0]] = res.evals[rd.fac[m][0]] * (inv * pre[m]);
+      inv = inv * pp_folded[m];
+    }
+  }
+  return res;
 }
 
 SumCheckResult sum_check_prove(Ctx& c, int prover_kind, size_t num_vars, const lh_sop& expr,
@@ -1133,6 +1175,7 @@ GrandProductResult prove_grand_product(Ctx& c, size_t B, const Fr* const* d_leav
   // the layers near the roots in ONE resident launch (kernels_gkr.hip; Options::gkr_resident): every layer from h = 1 up
   // whose tables fit, as long as it is an ordinary layer (all trees given, no (A, A + 1) leaf pairs, not sharded)
   GkrResident resident(c);
+  std::vector<GkrLayerDev> resident_layers;
   if (c.opt.gkr_resident && c.opt.sc_tail && c.opt.sc_eq_factoring) {
     std::vector<GkrLayerDev> layers;
     for (size_t h = 1; h < max_depth; h++) {
@@ -1155,13 +1198,16 @@ GrandProductResult prove_grand_product(Ctx& c, size_t B, const Fr* const* d_leav
       L.h = (uint32_t)h, L.B = nb;
       layers.push_back(L);
     }
-    if (!layers.empty()) resident.launch(layers);
+    resident_layers.swap(layers);
   }
   if (c.gkr_hook) {  // (the trees are built: from here on the small layers leave most of the chip idle)
+    // (before the resident launch: what the hook starts on another stream waits for an event recorded HERE on this
+    // ctx's stream - behind the resident kernel it would wait for the whole resident phase)
     std::function<void()> hook;
     hook.swap(c.gkr_hook);
     hook();
   }
+  if (!resident_layers.empty()) resident.launch(resident_layers);
   for (size_t h = 0; h < max_depth; h++) {
     std::vector<size_t> active;
     for (size_t b = 0; b < B; b++)

@@ -271,6 +271,9 @@ lh_status lh_lasso_last_timing(lh_ctx*, double* out_ms);
  *                             run in ONE resident launch - layer loop, eq tables, rounds and final evaluations inside the
  *                             kernel (kernels_gkr.hip); 0: one sum-check per layer (eq kernels, launched rounds, a resident
  *                             tail each).  Needs sc_tail and sc_eq_factoring
+ *   sc_pp_fold           1    sum-checks of the shape eq * sum_m c_m l_m r_m (the generic layers of the grand products):
+ *                             the streaming rounds share one Montgomery reduction among four products and the first
+ *                             binding round folds c_m into l_m (sc_round_pp_kernel); 0: sc_round_e2_kernel as before
  * Values outside an option's range are refused (LH_ERR_ARG).
  * lh_lasso_last_route reports which of these routes the last Lasso prove on the ctx actually took, so that a byte
  * mismatch in the field can be bisected from the outside. */
@@ -293,7 +296,7 @@ typedef struct lh_lasso_route {
   uint32_t window_table_jobs;   /* MSM jobs that ran over a window table (msm_window_tables) */
   uint32_t open_precommit;      /* 1: the opening's column-wise commitments were taken from the helper ctx (open_precommit) */
   uint32_t resident_layers;     /* grand-product layers that ran inside the resident multi-layer kernel (gkr_resident) */
-  uint32_t reserved[1];
+  uint32_t pp_folds;            /* sum-checks whose batching coefficients were folded into the left factors (sc_pp_fold) */
 } lh_lasso_route;
 lh_status lh_lasso_last_route(lh_ctx*, lh_lasso_route* out);
 
