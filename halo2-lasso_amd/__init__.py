@@ -925,6 +925,15 @@ def shard_of(column, rank, size, shard_bit):
     return column.reshape(n >> (shard_bit + rho), size, 1 << shard_bit)[:, rank, :].reshape(-1).copy()
 
 
+def shard_poly(poly, rank, size, shard_bit):
+    """This rank's shard of a device-resident MultilinearPolynomial (lh_shard_extract): a table of num_vars - rho variables"""
+    rho = size.bit_length() - 1
+    n_local = (1 << poly.num_vars) >> rho
+    out = poly.ctx.alloc(32 * n_local)
+    _check(poly.ctx.lib.lh_shard_extract(poly.ctx.h, poly.ptr, n_local, shard_bit, rho, rank, 32, out.ptr))
+    return MultilinearPolynomial(poly.ctx, out, poly.num_vars - rho)
+
+
 def lasso_prove_sharded(pp, table, num_vars, dims_local, transcript):
     """One proof over the ranks of the attached communicator; same bytes as lasso_prove.
     dims_local: THIS RANK'S shard of every chunk column (device u32[2^(num_vars - rho)], see shard_of)."""

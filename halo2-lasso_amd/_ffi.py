@@ -194,6 +194,9 @@ SIGNATURES = {
                                          C.POINTER(lh_transcript)]),
     "lh_hyperplonk_prove": (C.c_int, [_P, _P, C.POINTER(lh_hp_param), C.POINTER(C.POINTER(lh_fr)), C.POINTER(_P),
                                       C.POINTER(lh_transcript)]),
+    "lh_shard_extract": (C.c_int, [_P, _P, _SZ, _SZ, _SZ, _SZ, _SZ, _P]),
+    "lh_hyperplonk_prove_sharded": (C.c_int, [_P, _P, C.POINTER(lh_hp_param), C.POINTER(C.POINTER(lh_fr)), C.POINTER(_P),
+                                              C.POINTER(lh_transcript)]),
     "lh_hyperplonk_prove_phases": (C.c_int, [_P, _P, C.POINTER(lh_hp_param), _SZ, C.POINTER(_SZ), C.POINTER(_SZ),
                                              C.POINTER(C.POINTER(lh_fr)), C.POINTER(lh_hp_circuit),
                                              C.POINTER(lh_transcript)]),

@@ -626,6 +626,35 @@ lh_status lh_hyperplonk_prove(lh_ctx* ctx, const lh_srs* srs, const lh_hp_param*
   LH_CATCH
 }
 
+lh_status lh_shard_extract(lh_ctx* ctx, const void* d_global, size_t n_local, size_t shard_bit, size_t rho, size_t rank,
+                           size_t elem_bytes, void* d_local) {
+  LH_TRY NEED_CTX(ctx);
+  NEED(d_global);
+  NEED(d_local);
+  LH_REQUIRE(rho < 16 && rank < ((size_t)1 << rho) && shard_bit < 40, LH_ERR_ARG, "shard_extract: bad geometry");
+  k_shard_extract(ctx->c, d_global, n_local, shard_bit, rho, rank, elem_bytes, d_local);
+  ctx->c.sync();
+  LH_CATCH
+}
+lh_status lh_hyperplonk_prove_sharded(lh_ctx* ctx, const lh_srs* srs, const lh_hp_param* pp, const lh_fr* const* instances,
+                                      const lh_fr* const* d_witness_polys, lh_transcript* t) {
+  LH_TRY NEED_CTX(ctx);
+  NEED(srs);
+  NEED(pp);
+  Ctx& c = ctx->c;
+  LH_REQUIRE(c.has_comm, LH_ERR_ARG, "lh_hyperplonk_prove_sharded: no communicator attached");
+  const size_t R = (size_t)c.comm.size;
+  LH_REQUIRE(R >= 1 && (R & (R - 1)) == 0, LH_ERR_ARG, "sharded prove: the number of ranks must be a power of two");
+  struct Active {
+    Ctx& c;
+    explicit Active(Ctx& c_) : c(c_) { c.shard_active = true; }
+    ~Active() { c.shard_active = false; }
+  } active(c);
+  Transcript tr(t);
+  hyperplonk_prove(c, mkzg_pcs(c, srs->s), *pp, (const HFr* const*)instances, (const Fr* const*)d_witness_polys, tr);
+  LH_CATCH
+}
+
 // ---------------------------------------------------------------- verifiers (host only)
 lh_status lh_mkzg_vp_setup(const lh_fr* ss, size_t num_vars, lh_mkzg_vp** out) {
   LH_TRY

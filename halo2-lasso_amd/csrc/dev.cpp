@@ -1,5 +1,6 @@
 // Device context and workspace arena.
 #include <string.h>
+#include <stdlib.h>
 #include <ctype.h>
 #include <atomic>
 #include <condition_variable>
@@ -342,7 +343,11 @@ struct HostPool {
   std::shared_ptr<HostJob> job;
   HostPool() {
     unsigned hw = std::thread::hardware_concurrency();
-    unsigned workers = hw > 1 ? std::min(15u, hw - 1) : 0;
+    // (an MSM batch hands ~25-40 window combines of ~70 us each to this pool at the end of a commit or an opening - the
+    // GPU idles meanwhile: one round of them, not three, where the host has the cores; LH_HOST_THREADS overrides)
+    unsigned cap = 47;
+    if (const char* e = getenv("LH_HOST_THREADS")) cap = (unsigned)std::max(0, atoi(e) - 1);
+    unsigned workers = hw > 1 ? std::min(cap, hw - 1) : 0;
     for (unsigned i = 0; i < workers; i++) std::thread([this] { worker(); }).detach();
   }
   void worker() {

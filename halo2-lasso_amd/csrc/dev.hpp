@@ -555,6 +555,7 @@ struct ExtRound {
 void k_sc_round_ext(Ctx&, const ExtRound& rd, int degree, bool bind, size_t size, Fr* evals_host);
 void k_rotate_gather(Ctx&, const Fr* poly, size_t num_vars, int rot, uint32_t primitive, uint32_t x_inv, Fr* out);
 void k_identity_table(Ctx&, size_t n, Fr* out);
+void k_identity_table_shard(Ctx&, size_t n_local, size_t j, size_t rho, size_t rank, Fr* out);
 // BooleanHypercube::iter() order and its inverse (bh.rs:127-141), 2^num_vars entries each
 void k_bh_order(Ctx&, size_t num_vars, uint32_t primitive, uint32_t* order, uint32_t* nth);
 void k_one_hot_table(Ctx&, size_t n, size_t hot, Fr* out);
@@ -601,6 +602,11 @@ void k_lookup_h(Ctx&, const Fr* input, const Fr* table, const Fr* m, const Fr& g
 void k_permutation_z(Ctx&, const Fr* const* values, const Fr* const* perms, size_t num_perm, size_t num_chunks,
                      size_t num_vars, const Fr& beta, const Fr& gamma, const uint32_t* d_order, const uint32_t* d_nth,
                      Fr* const* z_out);
+void k_permutation_products(Ctx&, const Fr* const* values, const Fr* const* perms, size_t num_perm, size_t num_chunks,
+                            size_t num_vars, const Fr& beta, const Fr& gamma, size_t n, size_t sj, size_t srho, size_t srank,
+                            Fr* const* prod_out);
+void k_permutation_z_from_products(Ctx&, const Fr* const* prods, size_t num_chunks, size_t num_vars, const uint32_t* d_order,
+                                   const uint32_t* d_nth, Fr* const* z_out, size_t sj, size_t srho, size_t srank);
 void k_scatter_rows(Ctx&, const uint32_t* d_rows, const Fr* d_vals, size_t count, size_t n, Fr* table);
 
 // ------------------------------------------------------------------ Zeromorph / univariate KZG (kernels_zm.hip)

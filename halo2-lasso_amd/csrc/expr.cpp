@@ -297,11 +297,19 @@ static Program compile_program(const lh_expr& e, const HFr* challenges, size_t n
 // ------------------------------------------------------------------ ClassicSumCheck<EvaluationsProver> over an Expression
 SumCheckResult sum_check_prove_expr(Ctx& c, size_t num_vars, const lh_expr& expr, const Fr* const* d_polys,
                                     size_t num_polys, const HFr* challenges, size_t num_challenges, const HFr* ys,
-                                    size_t num_ys, const HFr& sum, Transcript& tr) {
+                                    size_t num_ys, const HFr& sum, Transcript& tr, bool sharded) {
   LH_REQUIRE(num_vars > 0 && num_vars < 32, LH_ERR_ARG, "sum-check needs 0 < num_vars < 32");  // classic.rs:42, bh.rs:85
   ExpandedExpr ex = expand_expr(expr, challenges, num_challenges);
   LH_REQUIRE(ex.degree >= 2 && ex.degree <= 8, LH_ERR_ARG, "EvaluationsProver: degree must be in 2..8");  // eval.rs:316
-  const size_t n = (size_t)1 << num_vars;
+  // `sharded` (one proof over several GPUs, dev.hpp Shard): d_polys are this rank's shards and so is every table built
+  // here - eq tables with the rank's factor, identity / Lagrange tables by global row; a ROTATED poly (classic.rs:104-126:
+  // the rotation is a multiplication in GF(2^n), it mixes every index bit) is the one thing that needs the other ranks'
+  // rows: the poly is gathered once, rotated, and this rank's rows are kept.  The rounds then run on the shards with
+  // their partial sums added over the ranks (sum_check_loop).
+  const Shard sh(c);
+  if (sharded) LH_REQUIRE(sh.on && sh.sharded(num_vars) && sh.j >= 1, LH_ERR_ARG, "sharded sum-check outside a sharded proof");
+  const size_t n_full = (size_t)1 << num_vars;
+  const size_t n = sharded ? n_full >> sh.rho : n_full;  // entries of every (local) table
   ArenaScope scope(c.arena);
 
   // tables: every poly at the current rotation first (all of them are bound and reported), then one
@@ -317,26 +325,46 @@ SumCheckResult sum_check_prove_expr(Ctx& c, size_t num_vars, const lh_expr& expr
         table_of[a] = at.a;
       } else {
         Fr* rot = c.arena.alloc_n<Fr>(n);
-        k_rotate_gather(c, d_polys[at.a], num_vars, at.b, bh_primitive(num_vars), bh_x_inv(num_vars), rot);
+        if (sharded) {
+          ArenaScope tmp(c.arena);
+          Fr* full = c.arena.alloc_n<Fr>(n_full);
+          Fr* full_rot = c.arena.alloc_n<Fr>(n_full);
+          comm_gather_tables(c, d_polys[at.a], 1, n, (size_t)1 << sh.j, &full);
+          c.route.v[RouteStats::SHARD_EXCHANGES]++;
+          k_rotate_gather(c, full, num_vars, at.b, bh_primitive(num_vars), bh_x_inv(num_vars), full_rot);
+          k_shard_extract(c, full_rot, n, sh.j, sh.rho, sh.rank, sizeof(Fr), rot);
+          c.sync();  // (the temporaries are released with this scope)
+        } else {
+          k_rotate_gather(c, d_polys[at.a], num_vars, at.b, bh_primitive(num_vars), bh_x_inv(num_vars), rot);
+        }
         table_of[a] = (int)tables.size();
         tables.push_back(rot);
       }
     } else if (at.kind == LH_EX_EQ_XY) {
       LH_REQUIRE((size_t)at.a < num_ys, LH_ERR_ARG, "expression: eq_xy index out of range");
       Fr* eq = c.arena.alloc_n<Fr>(n);
-      k_eq_xy(c, (const Fr*)(ys + (size_t)at.a * num_vars), num_vars, eq);
+      if (sharded) eq_xy_shard(c, sh, ys + (size_t)at.a * num_vars, num_vars, 0, eq);
+      else k_eq_xy(c, (const Fr*)(ys + (size_t)at.a * num_vars), num_vars, eq);
       table_of[a] = (int)tables.size();
       tables.push_back(eq);
     } else if (at.kind == LH_EX_IDENTITY) {
       Fr* id = c.arena.alloc_n<Fr>(n);
-      k_identity_table(c, n, id);
+      if (sharded) k_identity_table_shard(c, n, sh.j, sh.rho, sh.rank, id);
+      else k_identity_table(c, n, id);
       table_of[a] = (int)tables.size();
       tables.push_back(id);
     } else {  // Lagrange(i): 1 on row bh[i mod 2^n] (classic.rs:46-55)
-      long long m = (long long)at.a % (long long)n;
-      if (m < 0) m += (long long)n;
+      long long m = (long long)at.a % (long long)n_full;
+      if (m < 0) m += (long long)n_full;
       Fr* l = c.arena.alloc_n<Fr>(n);
-      k_one_hot_table(c, n, bh_nth(num_vars, (size_t)m), l);
+      const size_t hot = bh_nth(num_vars, (size_t)m);
+      if (!sharded) {
+        k_one_hot_table(c, n, hot, l);
+      } else if (((hot >> sh.j) & (sh.R - 1)) == sh.rank) {  // this rank's row
+        k_one_hot_table(c, n, ((hot >> (sh.j + sh.rho)) << sh.j) | (hot & (((size_t)1 << sh.j) - 1)), l);
+      } else {
+        LH_HIP(hipMemsetAsync(l, 0, n * sizeof(Fr), c.stream));
+      }
       table_of[a] = (int)tables.size();
       tables.push_back(l);
     }
@@ -424,7 +452,7 @@ SumCheckResult sum_check_prove_expr(Ctx& c, size_t num_vars, const lh_expr& expr
         for (size_t i = 0; i < T; i++) pr.in[i] = bind ? out[i] : in[i];
         k_sc_round_prog(c, pr, ex.degree, size, evals_host, jit);
       };
-      return sum_check_loop(c, LH_SC_EVALUATIONS, num_vars, ex.degree, tables, used, num_polys, sum, tr, false, prog_round);
+      return sum_check_loop(c, LH_SC_EVALUATIONS, num_vars, ex.degree, tables, used, num_polys, sum, tr, sharded, prog_round);
     }
   }
 
@@ -441,7 +469,7 @@ SumCheckResult sum_check_prove_expr(Ctx& c, size_t num_vars, const lh_expr& expr
     rd.r = r;
     k_sc_round_ext(c, rd, ex.degree, bind, size, evals_host);
   };
-  return sum_check_loop(c, LH_SC_EVALUATIONS, num_vars, ex.degree, tables, used, num_polys, sum, tr, false, round_fn);
+  return sum_check_loop(c, LH_SC_EVALUATIONS, num_vars, ex.degree, tables, used, num_polys, sum, tr, sharded, round_fn);
 }
 
 }  // namespace lh

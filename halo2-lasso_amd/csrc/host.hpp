@@ -182,7 +182,7 @@ SumCheckResult sum_check_loop(Ctx&, int prover_kind, size_t num_vars, int degree
 // general Expression (util/expression.rs) through EvaluationsProver; evals = every poly at x
 SumCheckResult sum_check_prove_expr(Ctx&, size_t num_vars, const lh_expr& expr, const Fr* const* d_polys,
                                     size_t num_polys, const HFr* challenges, size_t num_challenges, const HFr* ys,
-                                    size_t num_ys, const HFr& sum, Transcript& tr);
+                                    size_t num_ys, const HFr& sum, Transcript& tr, bool sharded = false);
 
 // one proof over several GPUs (dev.hpp Shard): tables are this rank's shards, results are global
 std::vector<HFr> evaluate_polys(Ctx&, const Fr* const* d_polys, size_t count, size_t num_vars, const HFr* point, bool sharded);
@@ -190,6 +190,8 @@ void comm_sum_fr(Ctx&, HFr* v, size_t n);
 void comm_sum_points(Ctx&, HG1* pts, size_t n);
 void comm_gather_tables(Ctx&, const Fr* local_block, size_t count, size_t n_local, size_t block, Fr* const* out);
 void comm_gather_concat(Ctx&, const Fr* local, size_t n_local, Fr* out);
+// this rank's shard of eq_xy(y[first..num_vars)) (the shard coordinates dropped, the rank's factor multiplied in)
+void eq_xy_shard(Ctx&, const Shard&, const HFr* y, size_t num_vars, size_t first, Fr* out_local);
 
 // ------------------------------------------------------------------ piop::gkr
 struct FracSumCheckResult {
@@ -419,6 +421,10 @@ struct PcsProver {
   std::function<void(size_t num_vars, const Fr* const* d_polys, size_t num_polys, const HFr* points, size_t num_points,
                      const lh_evaluation* evals, size_t num_evals, Transcript& tr)>
       batch_open;
+  // one proof over several GPUs (dev.hpp Shard): batch_commit / batch_open take this rank's shards and add the ranks'
+  // partial commitments; shard_bases: this rank's share of commit_bases
+  bool sharded_ok = false;
+  std::function<const G1Affine*(size_t nv)> shard_bases;
 };
 PcsProver mkzg_pcs(Ctx&, const Srs&);
 PcsProver zeromorph_pcs(Ctx&, const USrs&, size_t poly_size);

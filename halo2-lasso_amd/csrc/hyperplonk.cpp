@@ -116,6 +116,8 @@ static void compressed_poly(Ctx& c, const lh_expr* exprs, size_t width, const st
 PcsProver mkzg_pcs(Ctx& c, const Srs& srs) {
   PcsProver p;
   p.batch_commit = [&c, &srs](const Fr* const* polys, size_t n, size_t nv) { return mkzg_batch_commit(c, srs, polys, n, nv); };
+  p.sharded_ok = true;  // (mkzg_batch_commit / mkzg_batch_open read the ctx's Shard geometry)
+  p.shard_bases = [&c, &srs](size_t nv) { return srs_shard_level(c, srs, nv); };
   p.commit_bases = [&srs](size_t nv) {
     LH_REQUIRE(nv <= srs.num_vars, LH_ERR_INVALID_PCS_PARAM, "Too many variates of poly to commit");
     return srs.eq(nv);
@@ -180,6 +182,31 @@ void hyperplonk_prove_phases(Ctx& c, const PcsProver& pcs, const lh_hp_param& pp
              "hyperplonk: phases are malformed");  // zip_eq, hyperplonk.rs:186-190
   const size_t nv = pp.num_vars, n = (size_t)1 << nv;
   LH_REQUIRE(nv >= 1 && nv < 32, LH_ERR_ARG, "hyperplonk: bad num_vars");
+  // One proof over the 2^rho ranks of the ctx's communicator (dev.hpp Shard; lh_hyperplonk_prove_sharded): every poly the
+  // caller hands over - preprocess, permutation, witness - is THIS RANK'S shard (n_loc rows) and so is every poly made
+  // here.  What crosses ranks: partial commitments (one exchange per commit round), the zero-check's partial sums and its
+  // residual tables (sum_check_loop), the rows of polys queried at a rotation (gathered once, expr.cpp), the per-row
+  // products of the permutation argument (gathered once: the prefix product in hypercube order runs on every rank,
+  // prover.rs:308-323), the Lasso lookups' exchanges (lasso.cpp) and the shared batch opening's (prover.cpp).  LogUp
+  // lookups (the m poly is a global sort-merge join) are not sharded: such circuits run as replicas.
+  const Shard sh(c);
+  const bool shn = sh.on;
+  const size_t n_loc = shn ? n >> sh.rho : n;
+  if (shn) {
+    LH_REQUIRE(sh.j >= 1 && sh.sharded(nv), LH_ERR_ARG, "sharded hyperplonk: the circuit is too small for this shard geometry");
+    LH_REQUIRE(pp.num_lookups == 0, LH_ERR_ARG,
+               "sharded hyperplonk: LogUp lookups do not shard (global sort-merge join); use Lasso lookups or replicas");
+    LH_REQUIRE(pcs.sharded_ok, LH_ERR_ARG, "sharded hyperplonk: implemented for multilinear KZG");
+  }
+  auto local_row = [&](size_t g, size_t* loc) {  // global row -> this rank's local index (false: another rank's row)
+    if (!shn) {
+      *loc = g;
+      return true;
+    }
+    if (((g >> sh.j) & (sh.R - 1)) != sh.rank) return false;
+    *loc = ((g >> (sh.j + sh.rho)) << sh.j) | (g & (((size_t)1 << sh.j) - 1));
+    return true;
+  };
   ArenaScope scope(c.arena);
   EqHalfScope eq_scope(c);  // (lasso_argue shares eq tables of its points: arena memory of this scope)
 
@@ -194,21 +221,27 @@ void hyperplonk_prove_phases(Ctx& c, const PcsProver& pcs, const lh_hp_param& pp
   for (size_t i = 0; i < pp.num_instance_polys; i++) {
     const size_t cnt = pp.num_instances[i];
     LH_REQUIRE(cnt <= n, LH_ERR_ARG, "hyperplonk: too many instances");
-    std::vector<uint32_t> rows(cnt);
+    std::vector<uint32_t> rows;
+    std::vector<HFr> vals;
     size_t b = 1;  // bh.iter(): 0, 1, x, x^2, ...
     for (size_t k = 0; k < cnt; k++) {
       tr.common_field_element(instances[i][k]);
-      rows[k] = k + 1 < n ? (uint32_t)b : 0;  // row_mapping = bh.iter().skip(1).chain([0])
+      size_t loc;
+      if (local_row(k + 1 < n ? b : 0, &loc)) {  // row_mapping = bh.iter().skip(1).chain([0]); sharded: this rank's rows
+        rows.push_back((uint32_t)loc);
+        vals.push_back(instances[i][k]);
+      }
       b = bh_next(b, nv);
     }
-    Fr* tab = c.arena.alloc_n<Fr>(n);
-    uint32_t* d_rows = c.arena.alloc_n<uint32_t>(std::max<size_t>(cnt, 1));
-    Fr* d_vals = c.arena.alloc_n<Fr>(std::max<size_t>(cnt, 1));
-    if (cnt) {
-      LH_HIP(hipMemcpyAsync(d_rows, rows.data(), cnt * 4, hipMemcpyHostToDevice, c.stream));
-      LH_HIP(hipMemcpyAsync(d_vals, instances[i], cnt * sizeof(Fr), hipMemcpyHostToDevice, c.stream));
+    const size_t mine = rows.size();
+    Fr* tab = c.arena.alloc_n<Fr>(n_loc);
+    uint32_t* d_rows = c.arena.alloc_n<uint32_t>(std::max<size_t>(mine, 1));
+    Fr* d_vals = c.arena.alloc_n<Fr>(std::max<size_t>(mine, 1));
+    if (mine) {
+      LH_HIP(hipMemcpyAsync(d_rows, rows.data(), mine * 4, hipMemcpyHostToDevice, c.stream));
+      LH_HIP(hipMemcpyAsync(d_vals, vals.data(), mine * sizeof(Fr), hipMemcpyHostToDevice, c.stream));
     }
-    k_scatter_rows(c, d_rows, d_vals, cnt, n, tab);
+    k_scatter_rows(c, d_rows, d_vals, mine, n_loc, tab);
     c.sync();
     polys.push_back(tab);
   }
@@ -272,8 +305,11 @@ void hyperplonk_prove_phases(Ctx& c, const PcsProver& pcs, const lh_hp_param& pp
       LH_REQUIRE(total <= LH_HP_LASSO_MAX_COMMITMENTS, LH_ERR_ARG,
                  "hyperplonk: the Lasso lookups of one circuit commit to more than 63 polys (sum of 2 * chunks + memories)");
     }
-    const G1Affine* bases = pcs.commit_bases(nv);
+    const G1Affine* bases = shn ? pcs.shard_bases(nv) : pcs.commit_bases(nv);
+    const G1Affine* bases_full = pcs.commit_bases(nv);
     std::vector<MsmJob> jobs;
+    std::vector<char> job_sharded;  // (final_cts is replicated: committed in full on every rank, not summed)
+    uint32_t bad_input = 0;        // sharded: a rank that finds an invalid lookup must not leave its peers in a collective
     for (size_t k = 0; k < pp.num_lasso_lookups; k++) {
       LassoState& st = lasso[k];
       st.lk = &pp.lasso_lookups[k];
@@ -281,6 +317,7 @@ void hyperplonk_prove_phases(Ctx& c, const PcsProver& pcs, const lh_hp_param& pp
       lasso_check_table(tb);
       const size_t cc = tb.num_chunks, l = tb.chunk_bits, alpha = tb.num_memories, M = (size_t)1 << l;
       if (l > nv) throw Error(LH_ERR_INVALID_SNARK, "Lasso subtable larger than the circuit");
+      if (shn) LH_REQUIRE(l <= sh.j + sh.rho, LH_ERR_ARG, "sharded hyperplonk: need shard_bit + rho >= chunk_bits (subtables replicated)");
       // (the same range on the verifier's side, verifier.cpp: preprocess and witness polys - committed, and known before
       // the lookup argument starts)
       LH_REQUIRE(st.lk->output_poly >= pp.num_instance_polys && st.lk->output_poly < polys.size(), LH_ERR_ARG,
@@ -290,29 +327,60 @@ void hyperplonk_prove_phases(Ctx& c, const PcsProver& pcs, const lh_hp_param& pp
         LH_REQUIRE(st.lk->chunk_polys[j] >= pp.num_instance_polys && st.lk->chunk_polys[j] < polys.size(), LH_ERR_ARG,
                    "hyperplonk: lasso chunk poly out of range");
         st.dim_fr.push_back(polys[st.lk->chunk_polys[j]]);
-        st.dims[j] = c.arena.alloc_n<uint32_t>(n);
-        if (!k_fr_to_index(c, st.dim_fr[j], n, (uint32_t)l, st.dims[j]))
-          throw Error(LH_ERR_INVALID_SNARK, "Invalid lookup input");
+        st.dims[j] = c.arena.alloc_n<uint32_t>(n_loc);
+        if (!k_fr_to_index(c, st.dim_fr[j], n_loc, (uint32_t)l, st.dims[j])) {
+          if (!shn) throw Error(LH_ERR_INVALID_SNARK, "Invalid lookup input");
+          bad_input = 1;
+        }
+      }
+      if (shn) {  // every rank learns whether any rank saw an index out of range BEFORE the counters' exchange starts
+        std::vector<uint32_t> all(sh.R);
+        comm_all_gather_host(c, &bad_input, all.data(), sizeof(uint32_t));
+        for (uint32_t v : all)
+          if (v) throw Error(LH_ERR_INVALID_SNARK, "Invalid lookup input");
       }
       Fr* a = nullptr;
       st.cols = lasso_witness_columns(c, tb, nv, st.dims.data(), &a);
-      if (!k_fr_tables_equal(c, a, polys[st.lk->output_poly], n))
-        throw Error(LH_ERR_INVALID_SNARK, "Invalid lookup input");
+      if (!k_fr_tables_equal(c, a, polys[st.lk->output_poly], n_loc)) bad_input = 1;
+      if (shn) {
+        std::vector<uint32_t> all(sh.R);
+        comm_all_gather_host(c, &bad_input, all.data(), sizeof(uint32_t));
+        for (uint32_t v : all) bad_input |= v;
+      }
+      if (bad_input) throw Error(LH_ERR_INVALID_SNARK, "Invalid lookup input");
       auto fr_view = [&](const uint32_t* src, size_t len) {
-        Fr* d = c.arena.alloc_n<Fr>(n);
+        Fr* d = c.arena.alloc_n<Fr>(n_loc);
         k_fr_from_u32(c, src, len, d);
-        if (len < n) LH_HIP(hipMemsetAsync(d + len, 0, (n - len) * sizeof(Fr), c.stream));
+        if (len < n_loc) LH_HIP(hipMemsetAsync(d + len, 0, (n_loc - len) * sizeof(Fr), c.stream));
         return (const Fr*)d;
       };
-      for (size_t j = 0; j < cc; j++) st.rts_fr.push_back(fr_view(st.cols.rts[j], n));
-      for (size_t i = 0; i < alpha; i++) st.E_fr.push_back(fr_view(st.cols.E[i], n));
-      for (size_t j = 0; j < cc; j++) st.fcs_fr.push_back(fr_view(st.cols.fcs[j], M));
-      for (size_t j = 0; j < cc; j++) jobs.push_back(MsmJob{st.cols.rts[j], true, bases, n});
-      for (size_t i = 0; i < alpha; i++) jobs.push_back(MsmJob{st.cols.E[i], true, bases, n});
-      for (size_t j = 0; j < cc; j++) jobs.push_back(MsmJob{st.cols.fcs[j], true, bases, M});
+      for (size_t j = 0; j < cc; j++) st.rts_fr.push_back(fr_view(st.cols.rts[j], n_loc));
+      for (size_t i = 0; i < alpha; i++) st.E_fr.push_back(fr_view(st.cols.E[i], n_loc));
+      for (size_t j = 0; j < cc; j++) {
+        // final_cts as a poly of nv variables is the 2^l counts followed by zeros; sharded: this rank's rows of THAT are
+        // the slice [rank 2^shard_bit, (rank + 1) 2^shard_bit) of the (replicated) counts at its local rows [0, 2^shard_bit)
+        if (!shn) {
+          st.fcs_fr.push_back(fr_view(st.cols.fcs[j], M));
+        } else {
+          const size_t first = sh.rank << sh.j;
+          st.fcs_fr.push_back(first < M ? fr_view(st.cols.fcs[j] + first, std::min(M - first, (size_t)1 << sh.j)) : fr_view(st.cols.fcs[j], 0));
+        }
+      }
+      for (size_t j = 0; j < cc; j++) jobs.push_back(MsmJob{st.cols.rts[j], true, bases, n_loc}), job_sharded.push_back(1);
+      for (size_t i = 0; i < alpha; i++) jobs.push_back(MsmJob{st.cols.E[i], true, bases, n_loc}), job_sharded.push_back(1);
+      for (size_t j = 0; j < cc; j++) jobs.push_back(MsmJob{st.cols.fcs[j], true, bases_full, M}), job_sharded.push_back(0);
     }
     std::vector<HG1> comms(jobs.size());
     msm_batch(c, jobs.data(), jobs.size(), (G1Affine*)comms.data());
+    if (shn) {  // the shards' partial commitments -> their sums, one exchange
+      std::vector<HG1> part;
+      for (size_t k = 0; k < jobs.size(); k++)
+        if (job_sharded[k]) part.push_back(comms[k]);
+      comm_sum_points(c, part.data(), part.size());
+      size_t q = 0;
+      for (size_t k = 0; k < jobs.size(); k++)
+        if (job_sharded[k]) comms[k] = part[q++];
+    }
     lasso_write_commitments(tr, comms);
   }
 
@@ -321,7 +389,7 @@ void hyperplonk_prove_phases(Ctx& c, const PcsProver& pcs, const lh_hp_param& pp
   HFr gamma = tr.squeeze_challenge();
   for (size_t k = 0; k < pp.num_lookups; k++) k_lookup_h(c, comp_in[k], comp_tab[k], m_polys[k], dev(gamma), n, h_polys[k]);
   std::vector<Fr*> z_polys(pp.num_permutation_z_polys);
-  for (auto& z : z_polys) z = c.arena.alloc_n<Fr>(n);
+  for (auto& z : z_polys) z = c.arena.alloc_n<Fr>(n_loc);
   {
     std::vector<const Fr*> values(pp.num_permutation_polys), perms(pp.num_permutation_polys);
     for (size_t k = 0; k < pp.num_permutation_polys; k++) {
@@ -329,8 +397,26 @@ void hyperplonk_prove_phases(Ctx& c, const PcsProver& pcs, const lh_hp_param& pp
       values[k] = polys[pp.permutation_poly_index[k]];
       perms[k] = (const Fr*)pp.d_permutation_polys[k];
     }
-    k_permutation_z(c, values.data(), perms.data(), pp.num_permutation_polys, pp.num_permutation_z_polys, nv, dev(beta),
-                    dev(gamma), d_order, d_nth, z_polys.data());
+    if (!shn) {
+      k_permutation_z(c, values.data(), perms.data(), pp.num_permutation_polys, pp.num_permutation_z_polys, nv, dev(beta),
+                      dev(gamma), d_order, d_nth, z_polys.data());
+    } else if (pp.num_permutation_polys) {
+      // the per-row products on this rank's rows, ONE gather of them (num_z tables), then the hypercube-order prefix
+      // product on every rank (prover.rs:308-323 is serial in the rows' order, which no index-bit split respects),
+      // of which this rank keeps its rows
+      ArenaScope tmp(c.arena);
+      const size_t nz = pp.num_permutation_z_polys;
+      Fr* block = c.arena.alloc_n<Fr>(nz * n_loc);
+      std::vector<Fr*> prod_loc(nz), prod_full(nz);
+      for (size_t k = 0; k < nz; k++) prod_loc[k] = block + k * n_loc, prod_full[k] = c.arena.alloc_n<Fr>(n);
+      k_permutation_products(c, values.data(), perms.data(), pp.num_permutation_polys, nz, nv, dev(beta), dev(gamma), n_loc,
+                             sh.j, sh.rho, sh.rank, prod_loc.data());
+      comm_gather_tables(c, block, nz, n_loc, (size_t)1 << sh.j, prod_full.data());
+      c.route.v[RouteStats::SHARD_EXCHANGES]++;
+      std::vector<const Fr*> pf(prod_full.begin(), prod_full.end());
+      k_permutation_z_from_products(c, pf.data(), nz, nv, d_order, d_nth, z_polys.data(), sh.j, sh.rho, sh.rank);
+      c.sync();  // (the temporaries are released with this scope)
+    }
   }
   {
     std::vector<const Fr*> hz(h_polys.begin(), h_polys.end());
@@ -351,7 +437,7 @@ void hyperplonk_prove_phases(Ctx& c, const PcsProver& pcs, const lh_hp_param& pp
   challenges.push_back(gamma);
   challenges.push_back(alpha);
   SumCheckResult sc = sum_check_prove_expr(c, nv, pp.expression, polys.data(), polys.size(), challenges.data(),
-                                           challenges.size(), y.data(), 1, HFr::zero(), tr);
+                                           challenges.size(), y.data(), 1, HFr::zero(), tr, shn);
   const std::vector<HFr>& x = sc.challenges;
 
   pt.lap("zero-check sum-check");
@@ -380,7 +466,7 @@ void hyperplonk_prove_phases(Ctx& c, const PcsProver& pcs, const lh_hp_param& pp
     if (q.second == 0) {
       vals.push_back(sc.evals[q.first]);
     } else {  // evaluate_for_rotation (multilinear.rs:191-264): the poly at the rotation's points
-      for (auto& pt : rot_points[q.second]) vals.push_back(evaluate_polys(c, &polys[q.first], 1, nv, pt.data())[0]);
+      for (auto& pt : rot_points[q.second]) vals.push_back(evaluate_polys(c, &polys[q.first], 1, nv, pt.data(), shn)[0]);
     }
     for (size_t k = 0; k < vals.size(); k++) {
       lh_evaluation e;

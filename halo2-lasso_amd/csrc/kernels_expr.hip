@@ -97,6 +97,16 @@ __global__ void identity_table_kernel(size_t n, Fr* __restrict__ out) {
 void k_identity_table(Ctx& c, size_t n, Fr* out) {
   hipLaunchKernelGGL(identity_table_kernel, grid_for(n), 256, 0, c.stream, n, out);
 }
+// this rank's shard of the identity table (dev.hpp Shard): local index (hi || lo) holds the global row (hi, rank, lo)
+__global__ void identity_table_shard_kernel(size_t n_local, unsigned j, unsigned rho, size_t rank, Fr* __restrict__ out) {
+  GSTRIDE(i, n_local) {
+    const size_t lo = i & (((size_t)1 << j) - 1), hi = i >> j;
+    out[i] = from_u64<FrParams>((hi << (j + rho)) | (rank << j) | lo);
+  }
+}
+void k_identity_table_shard(Ctx& c, size_t n_local, size_t j, size_t rho, size_t rank, Fr* out) {
+  hipLaunchKernelGGL(identity_table_shard_kernel, grid_for(n_local), 256, 0, c.stream, n_local, (unsigned)j, (unsigned)rho, rank, out);
+}
 __global__ void set_one_at_kernel(Fr* p, size_t idx) { p[idx] = Fr::one(); }
 void k_one_hot_table(Ctx& c, size_t n, size_t hot, Fr* out) {
   LH_HIP(hipMemsetAsync(out, 0, n * sizeof(Fr), c.stream));
@@ -230,6 +240,7 @@ void k_sc_round_ext(Ctx& c, const ExtRound& rd, int degree, bool bind, size_t si
   size_t g = (size * tp + 255) / 256;
   size_t cap = (size_t)c.num_cus * 8;
   if (g > cap) g = cap;
+  evals_host = c.round_out(evals_host);  // (sharded rounds: the sums stay on the device, prover.cpp)
   Fr* partials = g == 1 ? evals_host : c.arena.alloc_n<Fr>(g * degree);
   const ScFinishArgs fin = c.finish_for((uint32_t)g, evals_host, seq);
   {
@@ -246,7 +257,7 @@ void k_sc_round_ext(Ctx& c, const ExtRound& rd, int degree, bool bind, size_t si
       default: launch_ext<8>(c, rd, bind, size, tp, (unsigned)g, partials, fin); break;
     }
   }
-  c.wait_flag(seq);
+  c.wait_round(seq);
 }
 
 // ------------------------------------------------------------------ sum-check round as a register program
@@ -373,6 +384,7 @@ void k_sc_round_prog(Ctx& c, const ProgRound& pr, int degree, size_t size, Fr* e
   // compiled form: one wave per workgroup and a grid of (g, degree) workgroups, all of which draw a ticket
   const size_t cap = jit ? std::max<size_t>(1, (size_t)c.num_cus * (size_t)per_cu / (size_t)degree) : (size_t)c.num_cus * (size_t)per_cu;
   if (g > cap) g = cap;
+  evals_host = c.round_out(evals_host);  // (sharded rounds: the sums stay on the device, prover.cpp)
   Fr* partials = (g == 1 && !jit) ? evals_host : c.arena.alloc_n<Fr>(g * degree);
   const ScFinishArgs fin = c.finish_for((uint32_t)(jit ? g * degree : g), evals_host, seq);
   {
@@ -385,7 +397,7 @@ void k_sc_round_prog(Ctx& c, const ProgRound& pr, int degree, size_t size, Fr* e
       hipLaunchKernelGGL(sc_round_prog_kernel, dim3((unsigned)g), dim3(threads), lds_bytes, c.stream, pr, size, degree,
                          partials, fin);
   }
-  c.wait_flag(seq);
+  c.wait_round(seq);
 }
 
 // ------------------------------------------------------------------ row-wise evaluation of a monomial list

@@ -124,13 +124,15 @@ __global__ void perm_den_kernel(PermPack p, Fr beta, Fr gamma, size_t n, Fr* __r
     prod[b] = acc;
   }
 }
-// prod[b] = inv[b] * prod_k (beta * (id_offset_k + b) + gamma + value_k[b])
+// prod[b] = inv[b] * prod_k (beta * (id_offset_k + row(b)) + gamma + value_k[b]); row(b) = b, or - the tables being a
+// rank's shards (dev.hpp Shard: rho > 0) - the global row (hi, rank, lo) of local index b = hi || lo
 __global__ void perm_num_kernel(PermPack p, Fr beta, Fr gamma, size_t n, const Fr* __restrict__ inv,
-                                Fr* __restrict__ prod) {
+                                Fr* __restrict__ prod, unsigned sj, unsigned srho, size_t srank) {
   GSTRIDE(b, n) {
     Fr acc = inv[b];
+    const size_t row = srho ? (((b >> sj) << (sj + srho)) | (srank << sj) | (b & (((size_t)1 << sj) - 1))) : b;
     for (int k = 0; k < p.count; k++) {
-      Fr id = from_u64<FrParams>(p.id_offset[k] + b);
+      Fr id = from_u64<FrParams>(p.id_offset[k] + row);
       acc = mul(acc, add(add(mul(beta, id), gamma), p.value[k][b]));
     }
     prod[b] = acc;
@@ -160,6 +162,20 @@ __global__ void perm_z_kernel(ChunkPack p, int num_chunks, const uint32_t* __res
     else if (pos == (size_t)num_chunks) v = Fr::one();
     else v = scan[pos - num_chunks - 1];
     p.z[c][b] = v;
+  }
+}
+// the same for this rank's shard of every z (local index i <-> global row b)
+__global__ void perm_z_shard_kernel(ChunkPack p, int num_chunks, const uint32_t* __restrict__ nth, size_t n_local,
+                                    const Fr* __restrict__ scan, unsigned sj, unsigned srho, size_t srank) {
+  GSTRIDE(t, n_local * num_chunks) {
+    size_t i = t / num_chunks, c = t % num_chunks;
+    const size_t b = ((i >> sj) << (sj + srho)) | (srank << sj) | (i & (((size_t)1 << sj) - 1));
+    size_t pos = c + (size_t)num_chunks * nth[b];
+    Fr v;
+    if (pos < (size_t)num_chunks) v = Fr::zero();
+    else if (pos == (size_t)num_chunks) v = Fr::one();
+    else v = scan[pos - num_chunks - 1];
+    p.z[c][i] = v;
   }
 }
 
@@ -235,19 +251,20 @@ static void fr_prefix_product(Ctx& c, const Fr* in, size_t n, Fr* out) {
   hipLaunchKernelGGL(scanp_apply_kernel, dim3((unsigned)ntiles), dim3(256), 0, c.stream, in, n, tiles, out);
 }
 
-// values[k], perms[k]: the k-th permutation poly's column values and sigma table; z_out[c]: 2^num_vars each
-void k_permutation_z(Ctx& c, const Fr* const* values, const Fr* const* perms, size_t num_perm, size_t num_chunks,
-                     size_t num_vars, const Fr& beta, const Fr& gamma, const uint32_t* d_order, const uint32_t* d_nth,
-                     Fr* const* z_out) {
-  ProfScope ps(c, "permutation_z", (2.0 * num_perm + 6.0 * num_chunks) * 32.0 * ((size_t)1 << num_vars), (2.0 * num_perm + 5.0 * num_chunks) * ((size_t)1 << num_vars), (double)((size_t)1 << num_vars));
+// values[k], perms[k]: the k-th permutation poly's column values and sigma table; z_out[c]: 2^num_vars each.
+// Two steps (prover.rs:262-345): the per-row quotients prod_c[b] of every chunk c - entry-wise, so they run on a rank's
+// shards as they are (`n` entries; srho > 0: local index -> global row for the identity polys) - and the z polys from
+// the products in BooleanHypercube order, a prefix product over ALL rows (the one step of HyperPlonk::prove that does not
+// shard, SURVEY.md 8e: a sharded prove gathers the products, runs it on every rank and keeps its own rows of z).
+void k_permutation_products(Ctx& c, const Fr* const* values, const Fr* const* perms, size_t num_perm, size_t num_chunks,
+                            size_t num_vars, const Fr& beta, const Fr& gamma, size_t n, size_t sj, size_t srho, size_t srank,
+                            Fr* const* prod_out) {
+  ProfScope ps(c, "permutation_products", (2.0 * num_perm + 3.0 * num_chunks) * 32.0 * n, (2.0 * num_perm + 4.0 * num_chunks) * n, (double)n);
   if (!num_perm) return;
   LH_REQUIRE(num_chunks >= 1 && num_chunks <= (size_t)PERM_MAX, LH_ERR_ARG, "permutation: too many z polys");
-  const size_t n = (size_t)1 << num_vars;
   const size_t chunk_size = (num_perm + num_chunks - 1) / num_chunks;
   LH_REQUIRE(chunk_size <= (size_t)PERM_MAX, LH_ERR_ARG, "permutation: chunk too large");
   ArenaScope scope(c.arena);
-  ChunkPack cp;
-  memset(&cp, 0, sizeof(cp));
   Fr* tmp = c.arena.alloc_n<Fr>(n);
   Fr* inv = c.arena.alloc_n<Fr>(n);
   for (size_t ch = 0; ch < num_chunks; ch++) {
@@ -260,19 +277,44 @@ void k_permutation_z(Ctx& c, const Fr* const* values, const Fr* const* perms, si
       pk.perm[k - lo] = perms[k];
       pk.id_offset[k - lo] = (uint64_t)k << num_vars;
     }
-    Fr* prod = c.arena.alloc_n<Fr>(n);
     hipLaunchKernelGGL(perm_den_kernel, grid_for(n), 256, 0, c.stream, pk, beta, gamma, n, tmp);
     k_fr_batch_invert(c, tmp, n, inv);
-    hipLaunchKernelGGL(perm_num_kernel, grid_for(n), 256, 0, c.stream, pk, beta, gamma, n, inv, prod);
-    cp.prod[ch] = prod;
-    cp.z[ch] = z_out[ch];
+    hipLaunchKernelGGL(perm_num_kernel, grid_for(n), 256, 0, c.stream, pk, beta, gamma, n, inv, prod_out[ch], (unsigned)sj,
+                       (unsigned)srho, srank);
   }
+}
+// prods[c]: 2^num_vars entries each (all rows); z_out[c]: 2^num_vars entries, or - srho > 0 - this rank's 2^(num_vars - srho)
+void k_permutation_z_from_products(Ctx& c, const Fr* const* prods, size_t num_chunks, size_t num_vars, const uint32_t* d_order,
+                                   const uint32_t* d_nth, Fr* const* z_out, size_t sj, size_t srho, size_t srank) {
+  const size_t n = (size_t)1 << num_vars;
+  ProfScope ps(c, "permutation_scan", 5.0 * num_chunks * 32.0 * n, 3.0 * num_chunks * n, (double)n);
+  LH_REQUIRE(num_chunks >= 1 && num_chunks <= (size_t)PERM_MAX, LH_ERR_ARG, "permutation: too many z polys");
+  ArenaScope scope(c.arena);
+  ChunkPack cp;
+  memset(&cp, 0, sizeof(cp));
+  for (size_t ch = 0; ch < num_chunks; ch++) cp.prod[ch] = prods[ch], cp.z[ch] = z_out[ch];
   const size_t total = (n - 1) * num_chunks;
   Fr* seq = c.arena.alloc_n<Fr>(std::max<size_t>(total, 1));
   Fr* scan = c.arena.alloc_n<Fr>(std::max<size_t>(total, 1));
   hipLaunchKernelGGL(perm_seq_kernel, grid_for(total), 256, 0, c.stream, cp, (int)num_chunks, d_order, n, seq);
   fr_prefix_product(c, seq, total, scan);
-  hipLaunchKernelGGL(perm_z_kernel, grid_for(n * num_chunks), 256, 0, c.stream, cp, (int)num_chunks, d_nth, n, scan);
+  if (srho)
+    hipLaunchKernelGGL(perm_z_shard_kernel, grid_for((n >> srho) * num_chunks), 256, 0, c.stream, cp, (int)num_chunks, d_nth,
+                       n >> srho, scan, (unsigned)sj, (unsigned)srho, srank);
+  else
+    hipLaunchKernelGGL(perm_z_kernel, grid_for(n * num_chunks), 256, 0, c.stream, cp, (int)num_chunks, d_nth, n, scan);
+}
+void k_permutation_z(Ctx& c, const Fr* const* values, const Fr* const* perms, size_t num_perm, size_t num_chunks,
+                     size_t num_vars, const Fr& beta, const Fr& gamma, const uint32_t* d_order, const uint32_t* d_nth,
+                     Fr* const* z_out) {
+  if (!num_perm) return;
+  const size_t n = (size_t)1 << num_vars;
+  ArenaScope scope(c.arena);
+  std::vector<Fr*> prods(num_chunks);
+  for (auto& pr : prods) pr = c.arena.alloc_n<Fr>(n);
+  k_permutation_products(c, values, perms, num_perm, num_chunks, num_vars, beta, gamma, n, 0, 0, 0, prods.data());
+  std::vector<const Fr*> cp(prods.begin(), prods.end());
+  k_permutation_z_from_products(c, cp.data(), num_chunks, num_vars, d_order, d_nth, z_out, 0, 0, 0);
 }
 
 // table[rows[i]] = vals[i] on a zeroed table (instance polys, prover.rs:32-48)

@@ -133,7 +133,7 @@ static size_t log2_exact(size_t v) {
 }
 
 // local shard of eq_xy(y[first..num_vars)): drop the shard coordinates, scale by eq_shard(y_shard)[rank]
-static void eq_xy_shard(Ctx& c, const Shard& sh, const HFr* y, size_t num_vars, size_t first, Fr* out_local) {
+void eq_xy_shard(Ctx& c, const Shard& sh, const HFr* y, size_t num_vars, size_t first, Fr* out_local) {
   std::vector<HFr> yl;
   HFr scale = HFr::one();
   for (size_t i = first; i < num_vars; i++) {
@@ -1368,6 +1368,19 @@ static void check_commit_vars(const Srs& srs, size_t num_vars, const char* what)
 std::vector<HG1> mkzg_batch_commit(Ctx& c, const Srs& srs, const Fr* const* d_polys, size_t num_polys,
                                    size_t num_vars) {
   check_commit_vars(srs, num_vars, "batch commit");
+  const Shard sh(c);
+  if (sh.on && sh.sharded(num_vars)) {
+    // inside a sharded proof the polys are this rank's shards: each is committed against the rank's share of the level's
+    // bases - the chunk-split-then-sum of util/arithmetic/msm.rs:101-114 with the shards as chunks - and the partial
+    // commitments are added over the ranks (one exchange per batch)
+    const G1Affine* bases = srs_shard_level(c, srs, num_vars);
+    std::vector<MsmJob> jobs(num_polys);
+    for (size_t i = 0; i < num_polys; i++) jobs[i] = MsmJob{d_polys[i], false, bases, (size_t)1 << (num_vars - sh.rho)};
+    std::vector<HG1> out(num_polys);
+    msm_batch(c, jobs.data(), num_polys, (G1Affine*)out.data());
+    if (num_polys) comm_sum_points(c, out.data(), num_polys);
+    return out;
+  }
   std::vector<MsmJob> jobs(num_polys);
   const Srs::WinTable* wt = srs_window_table(c, srs, num_vars);
   for (size_t i = 0; i < num_polys; i++) {

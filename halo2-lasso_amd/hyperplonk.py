@@ -163,13 +163,32 @@ class HyperPlonk:
         return pp, vp
 
     @staticmethod
-    def prove(pp, instances, witness_polys, transcript):
+    def shard_param(pp, rank, size, shard_bit):
+        """This rank's prover param of a sharded prove: preprocess and permutation polys as shards (device extraction),
+        everything else shared with `pp`."""
+        from . import shard_poly
+        sp = HyperPlonkProverParam()
+        sp.__dict__.update(pp.__dict__)
+        sp.preprocess_polys = [shard_poly(p, rank, size, shard_bit) for p in pp.preprocess_polys]
+        sp.permutation_polys = [shard_poly(p, rank, size, shard_bit) for p in pp.permutation_polys]
+        return sp
+
+    @staticmethod
+    def prove_sharded(pp_local, instances, witness_polys_local, transcript):
+        """lh_hyperplonk_prove_sharded: ONE proof over the ranks of the ctx's communicator, same bytes as `prove`.
+        `pp_local` from shard_param, `witness_polys_local`: this rank's shards of the witness polys."""
+        return HyperPlonk.prove(pp_local, instances, witness_polys_local, transcript, sharded=True)
+
+    @staticmethod
+    def prove(pp, instances, witness_polys, transcript, sharded=False):
         """hyperplonk.rs:164-291.  `witness_polys`: the device tables of a single-phase circuit (`synthesize(0, [])`),
         or a callable synthesize(round, challenges) -> list of MultilinearPolynomial (PlonkishCircuit::synthesize,
         backend.rs:139) which the phase loop of hyperplonk.rs:185-205 calls once per phase."""
         from . import _check, _ptr_array, _fr_array, lh_fr, ArgumentError
         info, ctx = pp.info, pp.pcs.ctx
         multi = callable(witness_polys)
+        if sharded and multi:
+            raise NotImplementedError("the sharded prove takes a single-phase circuit's witness tables")
         if len(info.num_witness_polys) != 1 and not multi:
             raise ArgumentError("multi-phase circuits need a synthesize(round, challenges) callable")
         keep = []
@@ -241,6 +260,11 @@ class HyperPlonk:
             _check(rc)
             return
         wit = _ptr_array(witness_polys)
+        if sharded:
+            if isinstance(pp.pcs, ZeromorphProverParam):
+                raise NotImplementedError("the sharded prove is wired for multilinear KZG")
+            _check(ctx.lib.lh_hyperplonk_prove_sharded(ctx.h, pp.pcs.h, C.byref(prm), inst, wit, transcript.p))
+            return
         if isinstance(pp.pcs, ZeromorphProverParam):
             _check(ctx.lib.lh_hyperplonk_prove_zeromorph(ctx.h, pp.pcs.params.h, pp.pcs.poly_size, C.byref(prm), inst, wit,
                                                          transcript.p))

@@ -409,6 +409,25 @@ typedef struct lh_hp_param { /* HyperPlonkProverParam (hyperplonk.rs:38-55), dev
 lh_status lh_hyperplonk_prove(lh_ctx*, const lh_srs*, const lh_hp_param*, const lh_fr* const* instances,
                               const lh_fr* const* d_witness_polys, lh_transcript* t);
 
+/* ONE HyperPlonk proof over the 2^rho ranks of the ctx's communicator (SURVEY.md 8e / BASELINE.json configs[4]: the
+ * Keccak-f circuit on 8 GPUs): HyperPlonk::prove (backend/hyperplonk.rs:164-291) with every table a shard.  Same proof
+ * bytes on every rank as lh_hyperplonk_prove on one GPU.  `pp`: num_vars is the circuit's; d_preprocess_polys,
+ * d_permutation_polys and d_witness_polys are THIS RANK'S shards - device lh_fr[2^(num_vars - rho)] in the shard layout
+ * of lh_lasso_prove_sharded (local index hi || lo <-> row (hi, rank, lo)); instances are the full lists on every rank.
+ * What crosses ranks: partial commitments (one exchange per commit round), the zero-check's partial sums per round and
+ * its residual tables once (piop/sum_check/classic.rs:90-141 over shards), the rows of polys queried at a rotation
+ * (gathered once in round 0, classic.rs:104-126), the per-row products of the permutation argument (gathered once; the
+ * prefix product in hypercube order, backend/hyperplonk/prover.rs:308-323, runs on every rank), the Lasso lookups'
+ * exchanges and the shared batch opening's as in lh_lasso_prove_sharded.  Circuits with LogUp lookups (a global
+ * sort-merge join, prover.rs:139-200) are refused with LH_ERR_ARG: they run as replicas.  Needs shard_bit >= 1,
+ * shard_bit + rho >= the Lasso lookups' chunk_bits and num_vars > shard_bit + rho; multilinear KZG. */
+/* this rank's shard of a full device table: local[hi || lo] = global[(hi, rank, lo)], n_local = n / 2^rho entries of
+ * elem_bytes (4, 32 or 64) each - how a caller that holds whole polys makes the inputs of the sharded proves */
+lh_status lh_shard_extract(lh_ctx*, const void* d_global, size_t n_local, size_t shard_bit, size_t rho, size_t rank,
+                           size_t elem_bytes, void* d_local);
+lh_status lh_hyperplonk_prove_sharded(lh_ctx*, const lh_srs*, const lh_hp_param*, const lh_fr* const* instances,
+                                      const lh_fr* const* d_witness_polys_local, lh_transcript* t);
+
 /* Multi-phase circuits: the phase loop of HyperPlonk::prove (backend/hyperplonk.rs:185-205).  Phase r calls
  * PlonkishCircuit::synthesize(r, challenges so far) (backend.rs:139) for num_witness_polys[r] polys, commits them and
  * squeezes num_challenges[r] challenges; Challenge(i) in expressions indexes the concatenation, then beta, gamma, alpha.
