@@ -346,13 +346,28 @@ def main_hyperplonk(args, hdist, dist, rank, local_rank, world):
     k = args.log_n
     trap = trapdoor(k)
     pcs_pp = hl.MultilinearKzg.setup(ctx, trap)
-    circ = make_hp_circuit(ctx, k, args, seed=hdist.batch_seed(k, rank) & 0xffffffff)
+    # N > 1, --mode sharded (default), a circuit whose lookups are Lasso lookups: ONE proof split over the N GPUs
+    # (lh_hyperplonk_prove_sharded: every rank holds its rows of every poly; strong scaling).  LogUp circuits do not
+    # shard (global sort-merge join) and run as replicas, as does --mode replicas.
+    sharded = world > 1 and args.mode == "sharded" and args.lookup == "lasso"
+    circ = make_hp_circuit(ctx, k, args, seed=hdist.batch_seed(k, 0 if sharded else rank) & 0xffffffff)
     pp = synthetic.prover_param(pcs_pp, circ)
     ctx.sync()
+    transport = None
+    if sharded:
+        rho = world.bit_length() - 1
+        assert 1 << rho == world, "sharded mode needs a power-of-two number of GPUs"
+        shard_bit = max(16 - rho, min(10, k - rho - 1), 1)  # (the replicated 2^16-entry subtables: shard_bit + rho >= 16)
+        pp_local = hp.HyperPlonk.shard_param(pp, rank, world, shard_bit)
+        wit_local = [hl.shard_poly(p, rank, world, shard_bit) for p in circ.d_witness]
+        transport = hdist.attach_sharded(ctx, dist, shard_bit)
 
-    def prove(p=pp, c=circ):
+    def prove(p=pp, c=circ, single=False):
         tr = hl.Keccak256Transcript()
-        hp.HyperPlonk.prove(p, c.instances, c.d_witness, tr)
+        if sharded and not single:
+            hp.HyperPlonk.prove_sharded(pp_local, c.instances, wit_local, tr)
+        else:
+            hp.HyperPlonk.prove(p, c.instances, c.d_witness, tr)
         return tr
 
     def barrier():
@@ -374,9 +389,9 @@ def main_hyperplonk(args, hdist, dist, rank, local_rank, world):
     ms_per_step = elapsed * 1e3 / max(args.steps, 1)
     if rank == 0:
         out = {
-            "metric": "hyperplonk_prove_time_ms", "value": round(ms_per_step / world, 3), "unit": "ms",
+            "metric": "hyperplonk_prove_time_ms", "value": round(ms_per_step / (1 if sharded else world), 3), "unit": "ms",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": False, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": "u256 (BN254 Fr/Fq, 8x u32 Montgomery)", "data": "synthetic",
             "config": {"workload": ("HyperPlonk + Lasso prove of a Keccak-f[1600] circuit (BASELINE configs[4]), 2^%d rows: %d "
                                     "permutations of 24 rounds, 35013 byte-operation rows each, every XOR / AND a Lasso "
@@ -391,17 +406,30 @@ def main_hyperplonk(args, hdist, dist, rank, local_rank, world):
                        ("HyperPlonk + LogUp prove, vanilla_plonk_with_lookup circuit, 2^%d rows (13 polys, one "
                         "3-column lookup on 1/4 of the rows, %d copy constraints, degree-5 zero-check)"
                         % (k, circ.num_copies)),
-                       "rows": 1 << k, "proofs_per_step": world, "pcs": "multilinear KZG (BN254)",
-                       "proof_bytes": len(tr.into_proof()), "parallelism": "1 proof per GPU" if world > 1 else "1 GPU"},
-            "rows_per_s": round((1 << k) * world / (ms_per_step / 1e3)),
+                       "rows": 1 << k, "proofs_per_step": 1 if sharded else world, "pcs": "multilinear KZG (BN254)",
+                       "proof_bytes": len(tr.into_proof()),
+                       "parallelism": ("1 proof sharded over %d GPUs (row index bits [%d, %d)), transport %s"
+                                       % (world, shard_bit, shard_bit + world.bit_length() - 1, transport)) if sharded
+                       else "1 proof per GPU" if world > 1 else "1 GPU"},
+            "rows_per_s": round((1 << k) * (1 if sharded else world) / (ms_per_step / 1e3)),
         }
-        if not args.no_profile:
+    if not args.no_profile and (sharded or rank == 0):
+        # (sharded: every rank takes part in the collectives of the profiled prove, rank 0 records)
+        if rank == 0:
             hl.profile_enable(ctx, True)
-            prove()
-            ctx.sync()
+        prove()
+        ctx.sync()
+        if rank == 0:
             aggs = aggregate(hl.profile_read(ctx))
             hl.profile_enable(ctx, False)
             out["roofline"], out["alu"], out["kernels"] = roofline_objects(hl, ctx, aggs)
+    if sharded:
+        stats = hl.comm_stats(ctx)
+        if rank == 0:
+            out["comm_collectives_per_run"] = stats
+            out["sharded_proof_equals_single_gpu"] = prove(single=True).into_proof() == tr.into_proof()
+        hl.detach_comm(ctx)
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
             def gpu_proof(pcs, c):
                 return prove(synthetic.prover_param(pcs, c), c).into_proof()
@@ -769,8 +797,7 @@ if __name__ == "__main__":
     try:
         main()
     except Exception as e:
-        if int(os.environ.get("WORLD_SIZE", "1")) > 1 and _args.mode == "sharded" and _args.workload == "lasso" \
-                and "LH_BENCH_MODE_FALLBACK" not in os.environ:
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1 and _args.mode == "sharded" and "LH_BENCH_MODE_FALLBACK" not in os.environ:
             sys.stdout.flush()
             os._exit(sharded_fallback(e))  # (no teardown of this process's half-finished job: the successor spoke for it)
         raise

@@ -163,3 +163,21 @@ def test_logup_circuits_are_refused(tmp_path):
     outs = run_ranks(tmp_path, 2, cfg, 29577)
     for o in outs:
         assert o["proof"] is None and "LogUp" in o["error"], o
+
+
+@pytest.mark.heavy(est=45)
+def test_bench_hyperplonk_keccak_two_ranks():
+    """`bench.py --workload hyperplonk --lookup lasso --circuit keccak --gpus 2` (both ranks on GPU 0, gloo): ONE proof of
+    the Keccak-f[1600] circuit sharded over the two ranks - strong scaling, bytes equal to the single-GPU proof."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(LH_DEVICE="0", LH_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--workload", "hyperplonk", "--lookup", "lasso", "--circuit",
+                        "keccak", "--log-n", "17", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-profile"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert d["metric"] == "hyperplonk_prove_time_ms" and d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["proofs_per_step"] == 1 and d["sharded_proof_equals_single_gpu"] is True
+    assert abs(d["value"] - d["ms_per_step"]) <= 1e-3

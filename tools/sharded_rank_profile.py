@@ -26,13 +26,73 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 
+def hyperplonk_keccak(hl, bench, ctx, k, args):
+    """the same measurement for lh_hyperplonk_prove_sharded over the loopback communicator"""
+    from halo2_lasso_amd import hyperplonk as hp, synthetic
+    pcs = hl.MultilinearKzg.setup(ctx, bench.trapdoor(k))
+    circ = synthetic.keccak_f(ctx, k, seed=k)
+    pp = synthetic.prover_param(pcs, circ)
+
+    def timed(fn):
+        for _ in range(2):
+            fn()
+        ts = []
+        for _ in range(args.steps):
+            ctx.sync()
+            t0 = time.perf_counter()
+            fn()
+            ctx.sync()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        hl.profile_enable(ctx, True)
+        fn()
+        ctx.sync()
+        aggs = bench.aggregate(hl.profile_read(ctx))
+        hl.profile_enable(ctx, False)
+        return round(statistics.median(ts), 3), aggs
+
+    wall, aggs = timed(lambda: hp.HyperPlonk.prove(pp, circ.instances, circ.d_witness, hl.Keccak256Transcript()))
+    single = {"wall_ms": wall, "busy_ms": round(sum(a["ms"] for a in aggs), 3)}
+    entry = {"workload": "HyperPlonk + Lasso prove of the Keccak-f[1600] circuit, 2^%d rows (%d permutations)" % (k, circ.num_permutations),
+             "single_gpu_hyperplonk_prove": single, "worlds": {}}
+    for world in [int(w) for w in args.worlds.split(",")]:
+        rho = world.bit_length() - 1
+        shard_bit = max(16 - rho, min(10, k - rho - 1), 1)
+        if k <= shard_bit + rho:
+            continue
+        ranks = list(range(world)) if args.all_ranks else sorted({0, world - 1})
+        per_rank = []
+        for rank in ranks:
+            pp_local = hp.HyperPlonk.shard_param(pp, rank, world, shard_bit)
+            wit_local = [hl.shard_poly(p, rank, world, shard_bit) for p in circ.d_witness]
+            hl.attach_comm_loopback(ctx, rank, world, shard_bit)
+            try:
+                stats0 = hl.comm_stats(ctx)
+                wall, aggs = timed(lambda: hp.HyperPlonk.prove_sharded(pp_local, circ.instances, wit_local, hl.Keccak256Transcript()))
+                stats1 = hl.comm_stats(ctx)
+            finally:
+                hl.detach_comm(ctx)
+            del pp_local, wit_local
+            per_rank.append({"rank": rank, "wall_ms": wall, "busy_ms": round(sum(a["ms"] for a in aggs), 3),
+                             "collectives_per_proof": {kk: (stats1[kk] - stats0[kk]) // (args.steps + 3) for kk in stats0},
+                             "top_kernels": [{"name": a["name"], "launches": a["launches"], "ms": round(a["ms"], 3)} for a in aggs[:8]]})
+        worst_wall = max(r["wall_ms"] for r in per_rank)
+        worst_busy = max(r["busy_ms"] for r in per_rank)
+        entry["worlds"][str(world)] = {
+            "shard_bit": shard_bit, "ranks": per_rank, "max_rank_wall_ms": worst_wall, "max_rank_busy_ms": worst_busy,
+            "ideal_ms": round(single["wall_ms"] / world, 3),
+            "compute_speedup_vs_single_gpu": round(single["wall_ms"] / worst_wall, 3)}
+        print("keccak%d world %d: max rank wall %.2f ms, busy %.2f ms (single GPU %.2f / %.2f)" % (
+            k, world, worst_wall, worst_busy, single["wall_ms"], single["busy_ms"]), file=sys.stderr, flush=True)
+    return entry
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", default="and24,range26")
     ap.add_argument("--worlds", default="1,2,4,8")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--all-ranks", action="store_true", help="every rank of each world (default: ranks 0 and R-1)")
-    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r03_sharded_rank_ms.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r04_sharded_rank_ms.json"))
     args = ap.parse_args()
     import halo2_lasso_amd as hl
     import bench
@@ -40,6 +100,9 @@ def main():
     result = {"note": __doc__.split("\n\n")[1].replace("\n", " "), "configs": {}}
     for cfg in args.configs.split(","):
         kind, n = cfg.rstrip("0123456789"), int(cfg[len(cfg.rstrip("0123456789")):])
+        if kind == "keccak":  # HyperPlonk + Lasso prove of the Keccak-f[1600] circuit of 2^n rows (BASELINE configs[4])
+            result["configs"][cfg] = hyperplonk_keccak(hl, bench, ctx, n, args)
+            continue
         table, desc = bench.make_table(hl, kind)
         pp = hl.MultilinearKzg.setup(ctx, bench.trapdoor(n))
         cols = bench.gen_dims(table, n, 0)
