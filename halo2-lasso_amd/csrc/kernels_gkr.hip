@@ -48,7 +48,9 @@ struct GkrResArgs {
   Fr* out_host;               // final evaluations (l'_k, r_k per tree), then the flag
   uint32_t* flag;
   uint64_t poll_ticks;
+  uint64_t* trace;  // development (LH_GKR_TRACE): per layer 8 stamps, per round 8 stamps, of workgroup 0 / the sender
 };
+constexpr uint32_t GKR_TRACE_ROUNDS = 160;
 
 __device__ __forceinline__ Fr shfl_fr(const Fr& v, int src) {
   Fr o;
@@ -109,6 +111,9 @@ __global__ __launch_bounds__(GKR_THREADS) void gkr_resident_kernel(GkrResArgs a)
       }
       __syncthreads();
     }
+    const bool tr0 = a.trace && tid == 0 && wg == 0;
+    uint64_t* trl = a.trace ? a.trace + (size_t)li * 8 : nullptr;
+    if (tr0) trl[0] = wall_clock64();  // layer message seen
     const Fr* yv = cy + B;
     // ---- stage 0: this workgroup's slice [wg * s, (wg + 1) * s) of every tree level; wave 3 builds the eq slice meanwhile
     uint32_t s = 1u << slog, stride = s;
@@ -139,6 +144,7 @@ __global__ __launch_bounds__(GKR_THREADS) void gkr_resident_kernel(GkrResArgs a)
       }
     }
     __syncthreads();
+    if (tr0) trl[1] = wall_clock64();  // tables loaded and folded, eq slice built
     bool multi = g > 1;
     const uint32_t clog = B <= 4 ? 0u : B <= 8 ? 1u : 2u, Cn = 1u << clog;
     uint32_t round = 0, batch = 0;
@@ -172,6 +178,10 @@ __global__ __launch_bounds__(GKR_THREADS) void gkr_resident_kernel(GkrResArgs a)
       }
       __syncthreads();
       const uint32_t seq = seq0 + 1 + round;
+      // (trace rows are indexed by the sequence number's offset from the first layer's: one row per round of the launch)
+      uint64_t* trq = a.trace ? a.trace + ((size_t)GKR_MAX_VARS + (seq - a.layers[0].seq)) * 8 : nullptr;
+      if (a.trace && seq - a.layers[0].seq >= GKR_TRACE_ROUNDS) trq = nullptr;
+      if (trq && tid == 0 && wg == 0) trq[0] = wall_clock64();  // evaluated
       if (wave == 0) {
         // lanes 0..31 sum the pairs at X = 1, lanes 32..63 at X = 2
         const uint32_t half = lane >> 5, l5 = lane & 31u;
@@ -197,6 +207,8 @@ __global__ __launch_bounds__(GKR_THREADS) void gkr_resident_kernel(GkrResArgs a)
         }
         // ---- the challenge: the workgroup that sent the message asks the host and relays it through device memory
         const bool talker = last != 0;
+        if (trq && lane == 0 && wg == 0) trq[1] = wall_clock64();        // workgroup 0: ticket drawn / message sent
+        if (trq && lane == 0 && talker) trq[2] = wall_clock64();         // the sender: message sent
         const TailChunk* box = talker ? a.mbox_round : a.relay;
         const uint64_t t0 = wall_clock64();
         uint32_t stop = 0;
@@ -218,6 +230,8 @@ __global__ __launch_bounds__(GKR_THREADS) void gkr_resident_kernel(GkrResArgs a)
           if (lane < 2) r_sh.l[3 * lane + 2] = v4.w;
         }
         if (lane == 0) stop_sh = stop;
+        if (trq && lane == 0 && talker) trq[3] = wall_clock64();         // the sender: challenge seen
+        if (trq && lane == 0 && wg == 0) trq[4] = wall_clock64();        // workgroup 0: challenge seen
       }
       if (multi) batch++;
       __syncthreads();
@@ -286,6 +300,7 @@ __global__ __launch_bounds__(GKR_THREADS) void gkr_resident_kernel(GkrResArgs a)
       }
       if (tid < (P >> 1)) E[tid] = en;
       __syncthreads();
+      if (trq && tid == 0 && wg == 0) trq[5] = wall_clock64();  // bound
       s = P;
     }
     i_poll = finished && !left;
@@ -350,6 +365,14 @@ void k_gkr_resident_launch(Ctx& c, const GkrLayerDev* layers, size_t num_layers,
   const char* tmo = getenv("LH_SC_TAIL_TIMEOUT_MS");
   const double ms = tmo && *tmo ? atof(tmo) : 2000.0;
   a.poll_ticks = (uint64_t)(ms * (double)c.wall_clock_khz);
+  static const bool trace_on = getenv("LH_GKR_TRACE") != nullptr;
+  a.trace = nullptr;
+  if (trace_on) {
+    const size_t words = ((size_t)GKR_MAX_VARS + GKR_TRACE_ROUNDS) * 8;
+    a.trace = (uint64_t*)c.arena.alloc(words * sizeof(uint64_t));
+    LH_HIP(hipMemsetAsync(a.trace, 0, words * sizeof(uint64_t), c.stream));
+    c.tail_trace = a.trace;
+  }
   c.mbox_send(Fr::zero(), 0u);
   const size_t lds = k_gkr_resident_lds_bytes(max_trees, GKR_CAP);
   c.opt_in_lds((const void*)gkr_resident_kernel, (int)k_gkr_resident_lds_bytes(GKR_MAX_TREES, GKR_CAP));

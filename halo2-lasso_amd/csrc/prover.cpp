@@ -999,6 +999,7 @@ struct GkrResident {
     out_host = pin + 16;
     prof.reset(new ProfScope(c, "gkr_resident", 32.0 * entries, 0, entries));
     k_gkr_resident_launch(c, ls.data(), H, chunks, out_host);
+    traced = ls;
     live = true;
   }
   // one layer: false when the layer cannot run factored (a zero among 1 - y_j or the coefficients): the kernel is
@@ -1064,8 +1065,40 @@ struct GkrResident {
       evals[2 * k] = hst(out_host[2 * k]) * dinv[h + k];
       evals[2 * k + 1] = hst(out_host[2 * k + 1]);
     }
-    if (h == H) stop(true);
+    if (h == H) {
+      if (c.tail_trace) print_trace();
+      stop(true);
+    }
     return true;
+  }
+  // development (LH_GKR_TRACE): device wall-clock stamps of the launch, per layer and per round
+  std::vector<GkrLayerDev> traced;
+  void print_trace() {
+    const size_t words = ((size_t)GKR_MAX_VARS + 160) * 8;
+    std::vector<uint64_t> st(words);
+    (void)hipStreamSynchronize(c.stream);
+    c.d2h(st.data(), c.tail_trace, words * sizeof(uint64_t));
+    c.tail_trace = nullptr;
+    const double us = 1e3 / (double)c.wall_clock_khz;
+    size_t row = 0;
+    uint64_t prev_end = 0;
+    for (size_t i = 0; i < traced.size(); i++) {
+      const GkrLayerDev& L = traced[i];
+      const uint64_t* tl = &st[i * 8];
+      fprintf(stderr, "[gkr trace] layer h %u B %u g %u s %u: message->ready %.2f us (since previous layer's last bind %.2f)\n", L.h, L.B,
+              L.g, 1u << L.s_log, (double)(int64_t)(tl[1] - tl[0]) * us, prev_end ? (double)(int64_t)(tl[0] - prev_end) * us : 0.0);
+      uint64_t t_prev = tl[1];
+      row = (size_t)(L.seq - traced[0].seq);
+      for (uint32_t j = 0; j < L.h && row + 1 + j < 160; j++) {
+        const uint64_t* q = &st[((size_t)GKR_MAX_VARS + row + 1 + j) * 8];
+        auto rel = [&](int k) { return q[k] && t_prev ? (double)(int64_t)(q[k] - t_prev) * us : -1.0; };
+        fprintf(stderr, "    round %2u: eval %.2f | wg0 ticket %.2f | sender sent %.2f challenge %.2f | wg0 challenge %.2f bound %.2f\n", j,
+                rel(0), rel(1), rel(2), rel(3), rel(4), rel(5));
+        if (q[5]) t_prev = q[5];
+        else if (q[4]) t_prev = q[4];
+        prev_end = t_prev;
+      }
+    }
   }
 };
 }  // namespace
@@ -1200,7 +1233,8 @@ GrandProductResult prove_grand_product(Ctx& c, size_t B, const Fr* const* d_leav
     }
     resident_layers.swap(layers);
   }
-  if (c.gkr_hook) {  // (the trees are built: from here on the small layers leave most of the chip idle)
+  static const int hook_at = getenv("LH_GKR_HOOK_AT") ? atoi(getenv("LH_GKR_HOOK_AT")) : 0;  // development: layer at which the hook fires
+  if (c.gkr_hook && hook_at <= 0) {  // (the trees are built: from here on the small layers leave most of the chip idle)
     // (before the resident launch: what the hook starts on another stream waits for an event recorded HERE on this
     // ctx's stream - behind the resident kernel it would wait for the whole resident phase)
     std::function<void()> hook;
@@ -1212,6 +1246,11 @@ GrandProductResult prove_grand_product(Ctx& c, size_t B, const Fr* const* d_leav
     std::vector<size_t> active;
     for (size_t b = 0; b < B; b++)
       if (num_vars[b] > h) active.push_back(b);
+    if (c.gkr_hook && hook_at > 0 && (int)h >= hook_at && !resident.live) {
+      std::function<void()> hook;
+      hook.swap(c.gkr_hook);
+      hook();
+    }
     if (h >= 1 && resident.live && h <= resident.H) {
       // a resident layer: same transcript schedule, the sum-check's device half is already running
       HFr lam = tr.squeeze_challenge();
