@@ -529,11 +529,22 @@ constexpr int GKR_MAX_VARS = 16;          // a resident layer has at most GKR_MA
 constexpr uint32_t GKR_CAP = 128;         // entries of a table one workgroup holds
 constexpr uint32_t GKR_THREADS = 256;
 constexpr uint32_t GKR_MSG_CHUNKS = 3 * (GKR_MAX_TREES + GKR_MAX_VARS);
+// A layer can also be the TAIL of a sum-check that ran its first rounds elsewhere (GKR_F_* flags): the tables come as
+// separate left / right pointers, possibly still to be bound with the previous challenge, the eq level of the first
+// resident round is read from memory, the coefficients (and the constant offsets of the read/write leaf layer,
+// cs (l + k)(r + k)) come with the descriptor instead of a layer message.
+enum { GKR_F_SPLIT = 1, GKR_F_BIND = 2, GKR_F_EQ = 4, GKR_F_NOMSG = 8, GKR_F_KOFF = 16 };
 struct GkrLayerDev {
-  const Fr* lv[GKR_MAX_TREES];  // the level of tree k: 2^(h + 1) nodes, left factors first
+  const Fr* lv[GKR_MAX_TREES];  // the level of tree k: 2^(h + 1) nodes, left factors first (GKR_F_SPLIT: the left table)
+  const Fr* rv[GKR_MAX_TREES];  // GKR_F_SPLIT: the right table
   uint32_t h, B;                // variables of the layer's tables, trees
   uint32_t g, s_log;            // g workgroups x 2^s_log entries = 2^h
   uint32_t seq;
+  uint32_t flags;
+  const Fr* eq_level;           // GKR_F_EQ: E of the first round, 2^(h - 1) entries
+  Fr r_prev;                    // GKR_F_BIND: the tables hold 2^(h + 1) entries and are bound with this first
+  Fr coef[GKR_MAX_TREES];       // GKR_F_NOMSG: the coefficients c_k
+  Fr koff[GKR_MAX_TREES];       // GKR_F_KOFF: l'_k = c_k (l_k + koff_k), r'_k = r_k + koff_k
 };
 bool k_gkr_resident_geometry(uint32_t h, uint32_t* g, uint32_t* s_log);
 // returns immediately; msg_host: 6 chunks, out_host: 2 * GKR_MAX_TREES field elements (pinned)

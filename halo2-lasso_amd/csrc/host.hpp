@@ -174,6 +174,12 @@ struct EqFactoring {
   std::function<void(const Fr* const* in, Fr* const* out, const Fr& r, bool bind, size_t size, size_t round, int points,
                      Fr* out_host)>
       round;
+  // the rest of the sum-check inside the resident kernel (kernels_gkr.hip, GKR_F_* tail mode) when the shape allows it:
+  // `cur` the current tables (pending their bind with r_prev when `bind`), n0 entries each after that bind, `round` the
+  // first resident round, `claim` the running claim.  Appends the challenges and fills the evaluations; false: not taken.
+  std::function<bool(const std::vector<const Fr*>& cur, bool bind, const HFr& r_prev, size_t n0, size_t round, const HFr& claim,
+                     Transcript& tr, SumCheckResult& res)>
+      resident_tail;
 };
 SumCheckResult sum_check_loop(Ctx&, int prover_kind, size_t num_vars, int degree, std::vector<const Fr*> cur,
                               const std::vector<char>& used, size_t num_polys, const HFr& sum, Transcript& tr,

@@ -76,12 +76,16 @@ __global__ __launch_bounds__(GKR_THREADS) void gkr_resident_kernel(GkrResArgs a)
   __syncthreads();
   for (uint32_t li = 0; li < a.num_layers; li++) {
     const GkrLayerDev& L = a.layers[li];
-    const uint32_t h = L.h, B = L.B, g = L.g, slog = L.s_log, T = 2 * B, seq0 = L.seq;
+    const uint32_t h = L.h, B = L.B, g = L.g, slog = L.s_log, T = 2 * B, seq0 = L.seq, flags = L.flags;
     const uint32_t my_tbase = tbase;
     tbase += g > 1 ? (slog + 1) * g : 0;
     if (wg >= g) continue;  // (not one of this layer's workgroups; g never decreases, so it is not the poller either)
     // ---- the layer message: 3 chunks per field element, c_0 .. c_{B-1}, y_0 .. y_{h-1}
-    {
+    if (flags & GKR_F_NOMSG) {  // (the tail of a sum-check: what a message would bring came with the descriptor)
+      if (tid < B) cy[tid] = L.coef[tid];
+      else if (tid >= GKR_MAX_TREES && tid < GKR_MAX_TREES + B) cy[tid] = L.koff[tid - GKR_MAX_TREES];
+      __syncthreads();
+    } else {
       const uint32_t nch = 3 * (B + h);
       const TailChunk* src = i_poll ? a.mbox_layer : a.relay + 4;
       u32x4 v = {0u, 0u, 0u, 0u};
@@ -118,7 +122,9 @@ __global__ __launch_bounds__(GKR_THREADS) void gkr_resident_kernel(GkrResArgs a)
     // ---- stage 0: this workgroup's slice [wg * s, (wg + 1) * s) of every tree level; wave 3 builds the eq slice meanwhile
     uint32_t s = 1u << slog, stride = s;
     const size_t N = (size_t)1 << h;
-    if (wave == 3) {
+    if (wave == 3 && (flags & GKR_F_EQ)) {
+      for (uint32_t b = lane; b < (s >> 1); b += 64) E[b] = L.eq_level[(size_t)wg * (s >> 1) + b];
+    } else if (wave == 3) {
       // slice-local variables 1 .. slog-1 by doubling (lane b ends with prod_i eq(y_i, bit_{i-1}(b))), the variables
       // slog .. h-1 are this workgroup's index bits
       Fr low = Fr::one();
@@ -138,7 +144,16 @@ __global__ __launch_bounds__(GKR_THREADS) void gkr_resident_kernel(GkrResArgs a)
     } else {
       for (uint32_t e = tid; e < T * s; e += 192) {
         const uint32_t t = e >> slog, idx = e & (s - 1), k = t >> 1;
-        Fr v = L.lv[k][((t & 1u) ? N : 0) + (size_t)wg * s + idx];
+        const size_t gi = (size_t)wg * s + idx;
+        const Fr* src = (flags & GKR_F_SPLIT) ? ((t & 1u) ? L.rv[k] : L.lv[k]) : L.lv[k] + ((t & 1u) ? N : 0);
+        Fr v;
+        if (flags & GKR_F_BIND) {
+          const Fr e0 = src[2 * gi], e1 = src[2 * gi + 1];
+          v = add(mul(sub(e1, e0), L.r_prev), e0);
+        } else {
+          v = src[gi];
+        }
+        if (flags & GKR_F_KOFF) v = add(v, cy[GKR_MAX_TREES + k]);
         if (!(t & 1u)) v = mul(v, cy[k]);
         tab[t * stride + idx] = v;
       }
