@@ -952,12 +952,12 @@ def lasso_last_timing(ctx):
 
 ROUTE_FIELDS = ["open_small_depth", "open_small_passes", "eq_factored_rounds", "standard_rounds", "rw_leaf_rounds",
                 "resident_tails", "resident_rounds", "packed_ts_pairs", "derived_commitments", "sorted_dim_reuse",
-                "sharded_rounds", "shard_exchanges", "window_table_jobs", "open_precommit", "resident_layers", "pp_folds"]
+                "sharded_rounds", "shard_exchanges", "window_table_jobs", "open_precommit", "resident_layers", "pp_folds", "msm29_batches"]
 
 
 def lasso_last_route(ctx):
     """lh_lasso_last_route: which routes the last Lasso prove on `ctx` took (include/lasso_hip.h lh_lasso_route)"""
-    out = (C.c_uint32 * 16)()
+    out = (C.c_uint32 * 24)()
     _check(ctx.lib.lh_lasso_last_route(ctx.h, out))
     return dict(zip(ROUTE_FIELDS, [int(v) for v in out]))
 

@@ -111,6 +111,10 @@ struct Options {
   int64_t sc_pp_fold = 1;              // 0: the generic layers of the grand products keep their coefficients as products of
                                        // every round (sc_round_e2) instead of folding them into the left factors and sharing
                                        // Montgomery reductions (sc_round_pp)
+  int64_t msm_limbs29 = 0;             // 1: MSM batches over registered bases (an SRS) accumulate in the 9 x 29-bit lazy-carry
+                                       // form of the base field (ec29.cuh: x1.25 on products, x1.15 on the mixed addition's
+                                       // arithmetic in isolation - and 0.95x inside the accumulation kernel, whose gathers pay
+                                       // for the lost wave of occupancy: measured, off); 0: the 8 x 32-bit form everywhere
   int64_t gkr_resident = 1;            // the layers of a grand-product argument whose tables fit the resident kernel run in ONE
                                        // launch (layer loop, eq tables and rounds inside; 0: one sum-check per layer)
   Options();                           // environment defaults (dev.cpp)
@@ -120,7 +124,7 @@ struct Options {
 struct RouteStats {  // lh_lasso_route (include/lasso_hip.h): counters of the last Lasso prove on the ctx
   uint32_t v[LH_LASSO_ROUTE_WORDS] = {0};
   enum { OPEN_DEPTH, OPEN_PASSES, EF_ROUNDS, STD_ROUNDS, RW_ROUNDS, TAILS, TAIL_ROUNDS, PACKED_TS, DERIVED, SORTED_REUSE,
-         SHARDED_ROUNDS, SHARD_EXCHANGES, WIN_TABLE_JOBS, OPEN_PRECOMMIT, RESIDENT_LAYERS, PP_FOLDS };
+         SHARDED_ROUNDS, SHARD_EXCHANGES, WIN_TABLE_JOBS, OPEN_PRECOMMIT, RESIDENT_LAYERS, PP_FOLDS, MSM29_BATCHES };
 };
 
 // ------------------------------------------------------------------ a long-lived host thread (dev.cpp)
@@ -685,6 +689,12 @@ Ctx& ctx_helper(Ctx&);            // the ctx's helper ctx (created on first use,
 void open_precommit_cancel(Ctx&);  // waits for a running precommit and drops it (prover.cpp)
 uint32_t msm_window_bits(size_t n);  // window width msm_batch picks for a full-width (254-bit) column of n points
 void k_msm_window_table(Ctx&, const G1Affine* bases, size_t n, uint32_t cbits, uint32_t W, G1Affine* out);
+// arrays of bases whose accumulation may run in the 9 x 29-bit form (ec29.cuh): registered by whoever owns them (an SRS),
+// twins made on first use (msm.hip)
+struct G1Affine29;
+void bases29_register(const G1Affine* base, size_t count);
+void bases29_unregister(const G1Affine* base);
+const G1Affine29* bases29_lookup(Ctx&, const G1Affine* bases, size_t n);
 // Runs all jobs as one batched Pippenger; out[j] is the affine sum (identity = (0,0)).
 void msm_batch(Ctx&, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host);
 int msm_slab_log();  // jobs of >= 2^this points are sorted slab by slab (and can take MsmJob::sorted_*)

@@ -274,12 +274,17 @@ lh_status lh_lasso_last_timing(lh_ctx*, double* out_ms);
  *   sc_pp_fold           1    sum-checks of the shape eq * sum_m c_m l_m r_m (the generic layers of the grand products):
  *                             the streaming rounds share one Montgomery reduction among four products and the first
  *                             binding round folds c_m into l_m (sc_round_pp_kernel); 0: sc_round_e2_kernel as before
+ *   msm_limbs29          0    1: MSM batches whose bases all belong to an SRS accumulate their buckets in the 9 x 29-bit
+ *                             lazy-carry form of the base field (a twin of the SRS in that form is made on first use):
+ *                             ~205 instead of ~310 instructions per Montgomery product, x1.15 on the mixed addition's
+ *                             arithmetic in isolation, but 0.95x inside the accumulation kernel (one wave of occupancy
+ *                             less for the gathers): measured neutral-to-negative, off by default
  * Values outside an option's range are refused (LH_ERR_ARG).
  * lh_lasso_last_route reports which of these routes the last Lasso prove on the ctx actually took, so that a byte
  * mismatch in the field can be bisected from the outside. */
 lh_status lh_ctx_set_option(lh_ctx*, const char* name, int64_t value);
 lh_status lh_ctx_get_option(lh_ctx*, const char* name, int64_t* out);
-#define LH_LASSO_ROUTE_WORDS 16
+#define LH_LASSO_ROUTE_WORDS 24
 typedef struct lh_lasso_route {
   uint32_t open_small_depth;    /* column-wise quotient levels of the opening (0: plain route) */
   uint32_t open_small_passes;   /* column passes (MSM jobs) of those levels */
@@ -297,6 +302,8 @@ typedef struct lh_lasso_route {
   uint32_t open_precommit;      /* 1: the opening's column-wise commitments were taken from the helper ctx (open_precommit) */
   uint32_t resident_layers;     /* grand-product layers that ran inside the resident multi-layer kernel (gkr_resident) */
   uint32_t pp_folds;            /* sum-checks whose batching coefficients were folded into the left factors (sc_pp_fold) */
+  uint32_t msm29_batches;       /* MSM batches whose bucket accumulation ran in the 9 x 29-bit form (msm_limbs29) */
+  uint32_t reserved[7];
 } lh_lasso_route;
 lh_status lh_lasso_last_route(lh_ctx*, lh_lasso_route* out);
 
