@@ -167,7 +167,10 @@ pub struct lh_lasso_route {
     pub shard_exchanges: u32,
     pub window_table_jobs: u32,
     pub open_precommit: u32,
-    pub reserved: [u32; 2],
+    pub resident_layers: u32,
+    pub pp_folds: u32,
+    pub msm29_batches: u32,
+    pub reserved: [u32; 7],
 }
 
 extern "C" {
@@ -239,6 +242,9 @@ extern "C" {
     pub fn lh_ctx_set_comm_rccl(ctx: *mut lh_ctx, rank: c_int, size: c_int, unique_id: *const u8, shard_bit: usize) -> lh_status;
     pub fn lh_ctx_set_comm_loopback(ctx: *mut lh_ctx, rank: c_int, size: c_int, shard_bit: usize) -> lh_status;
     pub fn lh_ctx_comm_stats(ctx: *mut lh_ctx, out: *mut u64) -> lh_status;
+    pub fn lh_ctx_comm_phase_stats(ctx: *mut lh_ctx, out: *mut u64, reset: c_int) -> lh_status;
+    pub fn lh_shard_extract(ctx: *mut lh_ctx, d_global: *const c_void, n_local: usize, shard_bit: usize, rho: usize,
+                            rank: usize, elem_bytes: usize, d_local: *mut c_void) -> lh_status;
     // route options (include/lasso_hip.h lists the names) and the route the last Lasso prove took
     pub fn lh_ctx_set_option(ctx: *mut lh_ctx, name: *const c_char, value: i64) -> lh_status;
     pub fn lh_ctx_get_option(ctx: *mut lh_ctx, name: *const c_char, out: *mut i64) -> lh_status;
@@ -249,6 +255,9 @@ extern "C" {
     pub fn lh_hyperplonk_prove(ctx: *mut lh_ctx, srs: *const lh_srs, pp: *const lh_hp_param,
                                instances: *const *const Fr, d_witness_polys: *const *const Fr,
                                t: *mut lh_transcript) -> lh_status;
+    pub fn lh_hyperplonk_prove_sharded(ctx: *mut lh_ctx, srs: *const lh_srs, pp: *const lh_hp_param,
+                                       instances: *const *const Fr, d_witness_polys_local: *const *const Fr,
+                                       t: *mut lh_transcript) -> lh_status;
     pub fn lh_hyperplonk_prove_phases(ctx: *mut lh_ctx, srs: *const lh_srs, pp: *const lh_hp_param, num_phases: usize,
                                       num_witness_polys: *const usize, num_challenges: *const usize,
                                       instances: *const *const Fr, circuit: *const lh_hp_circuit,

