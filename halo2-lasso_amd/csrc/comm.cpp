@@ -237,17 +237,24 @@ void comm_all_to_all_v(Ctx& c, const void* d_send, const size_t* send_off, const
     const char* e = getenv("LH_COMM_A2A");
     return e && strcmp(e, "allgather") == 0;
   }();
+  // LH_COMM_A2A_SELF=1 (tests): the segment a rank keeps for itself ALSO travels by ncclSend / ncclRecv - on a one-GPU box
+  // the only way the grouped point-to-point path (symbols, group semantics, stream ordering) ever executes before the
+  // first multi-GPU run
+  static const bool a2a_self = [] {
+    const char* e = getenv("LH_COMM_A2A_SELF");
+    return e && atoi(e) != 0;
+  }();
   if (c.rccl_comm && !a2a_by_gather) {
     const RcclApi& api = rccl();
     c.comm_stats[0]++;
     // (the segment a rank keeps for itself is a device copy: no self-send)
-    if (send_cnt[me])
+    if (send_cnt[me] && !a2a_self)
       LH_HIP(hipMemcpyAsync((char*)d_recv + recv_off[me] * elem, (const char*)d_send + send_off[me] * elem, send_cnt[me] * elem,
                             hipMemcpyDeviceToDevice, c.stream));
-    if (R > 1) {
+    if (R > 1 || a2a_self) {
       rccl_check(api.GroupStart(), "ncclGroupStart");
       for (size_t p = 0; p < R; p++) {
-        if (p == me) continue;
+        if (p == me && !a2a_self) continue;
         if (send_cnt[p])
           rccl_check(api.Send((const char*)d_send + send_off[p] * elem, send_cnt[p] * elem, ncclUint8, (int)p,
                               (ncclComm_t)c.rccl_comm, c.stream), "ncclSend");

@@ -198,12 +198,16 @@ void Ctx::gkr_resync() {
 }
 
 void Ctx::wait_chunks(const TailChunk* chunks, size_t count, uint32_t seq, Fr* out) {
+  (void)wait_chunks_or(chunks, count, seq, seq, out);
+}
+bool Ctx::wait_chunks_or(const TailChunk* chunks, size_t count, uint32_t seq, uint32_t alt, Fr* out) {
   alignas(16) uint32_t w[4];
   size_t have = 0;  // chunks 0..have-1 carry `seq` and are copied out
   bool gone = false;
   for (uint64_t spin = 0;; spin++) {
     while (have < count) {
       load_chunk(chunks + have, w);
+      if (have == 0 && alt != seq && w[0] == alt) return false;
       if (w[0] != seq) break;
       Fr& f = out[have / 3];
       const size_t j = have % 3;
@@ -211,7 +215,7 @@ void Ctx::wait_chunks(const TailChunk* chunks, size_t count, uint32_t seq, Fr* o
       if (j < 2) f.l[3 * j + 2] = w[3];
       have++;
     }
-    if (have == count) return;
+    if (have == count) return true;
     __builtin_ia32_pause();
     if ((spin & 0xfffff) == 0xfffff) {
       hipError_t e = hipStreamQuery(stream);

@@ -253,6 +253,8 @@ struct Ctx {
   void opt_in_lds(const void* fn, int bytes);
   // message of a resident tail round: `count` chunks that all carry `seq` -> `count` / 3 field elements
   void wait_chunks(const struct TailChunk* chunks, size_t count, uint32_t seq, Fr* out);
+  // the same; false (nothing copied) when the first chunk carries `alt` instead
+  bool wait_chunks_or(const struct TailChunk* chunks, size_t count, uint32_t seq, uint32_t alt, Fr* out);
 };
 
 // Geometry of a proof sharded over R = 2^rho ranks.  A table of 2^m entries is split on the index bits
@@ -533,6 +535,7 @@ constexpr int GKR_MAX_VARS = 16;          // a resident layer has at most GKR_MA
 constexpr uint32_t GKR_CAP = 128;         // entries of a table one workgroup holds
 constexpr uint32_t GKR_THREADS = 256;
 constexpr uint32_t GKR_MSG_CHUNKS = 3 * (GKR_MAX_TREES + GKR_MAX_VARS);
+constexpr uint32_t GKR_START_FAILED = 0xfffffffeu;  // first message chunk: the workgroups did not all start (see the kernel)
 // A layer can also be the TAIL of a sum-check that ran its first rounds elsewhere (GKR_F_* flags): the tables come as
 // separate left / right pointers, possibly still to be bound with the previous challenge, the eq level of the first
 // resident round is read from memory, the coefficients (and the constant offsets of the read/write leaf layer,

@@ -48,6 +48,7 @@ struct GkrResArgs {
   Fr* out_host;               // final evaluations (l'_k, r_k per tree), then the flag
   uint32_t* flag;
   uint64_t poll_ticks;
+  uint64_t start_ticks;  // how long the workgroups wait for each other at the start before they give the launch up
   uint64_t* trace;  // development (LH_GKR_TRACE): per layer 8 stamps, per round 8 stamps, of workgroup 0 / the sender
 };
 constexpr uint32_t GKR_TRACE_ROUNDS = 160;
@@ -74,6 +75,36 @@ __global__ __launch_bounds__(GKR_THREADS) void gkr_resident_kernel(GkrResArgs a)
   uint32_t tbase = a.ticket_base;
   if (tid == 0) stop_sh = 0;
   __syncthreads();
+  if (gridDim.x > 1) {
+    // check-in: the layers below hand work from workgroup to workgroup and only end when ALL of them run.  On a GPU shared
+    // with other processes' resident kernels (several ranks on one device: the tests) a launch may stay partly
+    // un-dispatched for as long as the others wait for THEIR missing workgroups; so everybody signs in first, and if the
+    // roll is not complete within `start_ticks` the kernel leaves before the transcript has seen anything of it
+    // (GKR_START_FAILED: the host takes the launched path for these layers instead).
+    if (tid == 0) {
+      __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint64_t t0 = wall_clock64();
+      uint32_t failed = 0;
+      while (__hip_atomic_load(a.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - tbase < gridDim.x) {
+        if (wall_clock64() - t0 > a.start_ticks || load_sys_x4(&a.relay[0]).x == SC_TAIL_ABORT) {
+          failed = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      // (a workgroup that is dispatched after the others gave up finds the roll complete - and their mark)
+      if (!failed && load_sys_x4(&a.relay[0]).x == SC_TAIL_ABORT) failed = 1;
+      if (failed) {
+        store_sys_x4((void*)&a.relay[0], u32x4{SC_TAIL_ABORT, 0u, 0u, 0u});
+        store_sys_x4((void*)&a.relay[4], u32x4{SC_TAIL_ABORT, 0u, 0u, 0u});
+        store_sys_x4((void*)&a.msg_host[0], u32x4{GKR_START_FAILED, 0u, 0u, 0u});
+      }
+      stop_sh = failed;
+    }
+    __syncthreads();
+    if (stop_sh) return;
+    tbase += gridDim.x;
+  }
   for (uint32_t li = 0; li < a.num_layers; li++) {
     const GkrLayerDev& L = a.layers[li];
     const uint32_t h = L.h, B = L.B, g = L.g, slog = L.s_log, T = 2 * B, seq0 = L.seq, flags = L.flags;
@@ -354,6 +385,7 @@ void k_gkr_resident_launch(Ctx& c, const GkrLayerDev* layers, size_t num_layers,
     max_trees = std::max(max_trees, L.B);
     if (L.g > 1) tickets += (L.s_log + 1) * L.g;
   }
+  if (G > 1) tickets += G;  // the check-in
   GkrResArgs a;
   GkrLayerDev* d_layers = (GkrLayerDev*)c.arena.alloc(num_layers * sizeof(GkrLayerDev));
   // (the descriptors travel through the ctx's pinned staging block: the caller's vector may die before the copy runs)
@@ -380,6 +412,8 @@ void k_gkr_resident_launch(Ctx& c, const GkrLayerDev* layers, size_t num_layers,
   const char* tmo = getenv("LH_SC_TAIL_TIMEOUT_MS");
   const double ms = tmo && *tmo ? atof(tmo) : 2000.0;
   a.poll_ticks = (uint64_t)(ms * (double)c.wall_clock_khz);
+  const char* smo = getenv("LH_GKR_START_TIMEOUT_MS");
+  a.start_ticks = (uint64_t)((smo && *smo ? atof(smo) : 25.0) * (double)c.wall_clock_khz);
   static const bool trace_on = getenv("LH_GKR_TRACE") != nullptr;
   a.trace = nullptr;
   if (trace_on) {

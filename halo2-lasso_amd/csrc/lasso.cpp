@@ -167,8 +167,14 @@ LassoColumns lasso_witness_columns(Ctx& c, const lh_lasso_table& tb, size_t n, c
     w.rts[j] = c.arena.alloc_n<uint32_t>(N);
     w.fcs[j] = c.arena.alloc_n<uint32_t>(M);
   }
-  keep_sorted = keep_sorted && sh.R == 1;
-  if (sh.on && sh.R > 1) {
+  // LH_SHARDED_COUNTERS_MIN_R=1 (tests): a world of one takes the repartitioned counters too (the personalised exchange
+  // then has one peer, itself: the transport's point-to-point path on a one-GPU box)
+  static const size_t counters_min_r = [] {
+    const char* e = getenv("LH_SHARDED_COUNTERS_MIN_R");
+    return e && atoi(e) >= 1 ? (size_t)atoi(e) : (size_t)2;
+  }();
+  keep_sorted = keep_sorted && !(sh.on && sh.R >= counters_min_r);
+  if (sh.on && sh.R >= counters_min_r) {
     lasso_counters_sharded(c, sh, d_dims, cc, n, l, w.rts.data(), w.fcs.data());
   } else {
     for (size_t j = 0; j < cc; j++) {

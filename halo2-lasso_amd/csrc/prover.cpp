@@ -205,13 +205,19 @@ namespace {
 // p(0..3) = S eq(y_j, X) q(X) (q(0) from the claim; `add_const`: a constant the kernel leaves out of every q value) ->
 // transcript -> challenge back to the kernel.  y[j], inv_1my[j]: the eq point's coordinate of round j and (1 - y_j)^-1;
 // S, cq = claim / S, cl = the claim on entry.  Appends the challenges to x.
-static void resident_rounds(Ctx& c, TailChunk* chunks, uint32_t seq, size_t rounds, const HFr* y, const HFr* inv_1my, HFr S, HFr cq,
-                            HFr cl, const HFr& add_const, Transcript& tr, std::vector<HFr>& x) {
+// Returns false - nothing absorbed, nothing written - when `first` is set and the kernel reports that its workgroups did not
+// all start (GKR_START_FAILED: a GPU shared with other resident kernels); the caller takes the launched path.
+static bool resident_rounds(Ctx& c, TailChunk* chunks, uint32_t seq, size_t rounds, const HFr* y, const HFr* inv_1my, HFr S, HFr cq,
+                            HFr cl, const HFr& add_const, Transcript& tr, std::vector<HFr>& x, bool first) {
   static const HFr inv2 = HFr::from_u64(2).inv();
   const HFr one = HFr::one(), two = HFr::from_u64(2), three = HFr::from_u64(3), five = HFr::from_u64(5);
   Fr q12[2];
   for (size_t j = 0; j < rounds; j++) {
-    c.wait_chunks(chunks, 6, seq + 1 + (uint32_t)j, q12);
+    if (first && j == 0) {
+      if (!c.wait_chunks_or(chunks, 6, seq + 1, GKR_START_FAILED, q12)) return false;
+    } else {
+      c.wait_chunks(chunks, 6, seq + 1 + (uint32_t)j, q12);
+    }
     const HFr q1 = hst(q12[0]) + add_const, q2 = hst(q12[1]) + add_const, yj = y[j];
     const HFr q0 = (cq - yj * q1) * inv_1my[j];
     const HFr q3 = (q2 - q1) * three + q0;  // the quadratic through q(0), q(1), q(2) at 3
@@ -231,6 +237,7 @@ static void resident_rounds(Ctx& c, TailChunk* chunks, uint32_t seq, size_t roun
     cl = S * cq;
     x.push_back(r);
   }
+  return true;
 }
 
 struct GkrResident {
@@ -312,7 +319,10 @@ struct GkrResident {
       inv = inv * d[i];
     }
     x.clear();
-    resident_rounds(c, chunks, seq, h, y.data(), dinv.data(), one, claim, claim, HFr::zero(), tr, x);
+    if (!resident_rounds(c, chunks, seq, h, y.data(), dinv.data(), one, claim, claim, HFr::zero(), tr, x, h == 1)) {
+      stop(false);  // (the launch never got all its workgroups: nothing of it reached the transcript)
+      return false;
+    }
     c.wait_flag(seq + (uint32_t)h + 1);
     evals.resize(2 * B);
     for (size_t k = 0; k < B; k++) {
@@ -369,7 +379,11 @@ static bool resident_tail_run(Ctx& c, GkrLayerDev L, size_t n0, const HFr* y, co
   run.launch(std::vector<GkrLayerDev>{L}, "gkr_tail");
   c.route.v[RouteStats::TAILS]++;
   const uint32_t seq = run.seq_of[1];
-  resident_rounds(c, run.chunks, seq, h, y, inv_1my, S, cq, cl, add_const, tr, x);
+  if (!resident_rounds(c, run.chunks, seq, h, y, inv_1my, S, cq, cl, add_const, tr, x, true)) {
+    run.stop(false);
+    c.route.v[RouteStats::TAILS]--;
+    return false;
+  }
   c.wait_flag(seq + h + 1);
   finals.resize(2 * (size_t)L.B);
   for (size_t i = 0; i < finals.size(); i++) finals[i] = hst(run.out_host[i]);

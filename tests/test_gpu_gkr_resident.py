@@ -124,3 +124,40 @@ def test_transcript_failure_inside_a_resident_layer(hl, ctx):
         roots, claims = hl.prove_grand_product(ctx, polys, t)
         assert time.perf_counter() - t1 < 1.0
         assert roots == o_roots and claims == o_claims and t.into_proof() == ot.into_proof()
+
+
+def test_a_launch_that_cannot_start_all_its_workgroups_falls_back(hl):
+    """On a GPU shared with other processes' resident kernels (several ranks on one device) a launch may never get all of its
+    workgroups dispatched; the kernel signs everybody in first and leaves - before the transcript has seen anything - when
+    the roll is not complete in time (GKR_START_FAILED); the prover then takes the launched path for those layers.  With
+    LH_GKR_START_TIMEOUT_MS=0 every multi-workgroup launch gives up: same proof bytes as the oracle, no resident layer."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, random
+        sys.path.insert(0, %r)
+        import numpy as np
+        import halo2_lasso_amd as hl
+        from oracle import cpu_oracle as co
+        n, nv = 17, 17
+        rng = random.Random(55)
+        ss = [rng.randrange(1, hl.R_MOD) for _ in range(nv)]
+        ctx = hl.Context(0)
+        table = hl.LassoTable.bitwise(hl.SUBTABLE_AND, 4, 16)
+        dims = [np.random.default_rng(550 + j).integers(0, 1 << 16, size=1 << n, dtype=np.uint32) for j in range(4)]
+        pp = hl.MultilinearKzg.setup(ctx, ss)
+        tr = hl.Keccak256Transcript()
+        hl.lasso_prove(pp, table, n, [ctx.upload(d.tobytes()) for d in dims], tr)
+        route = hl.lasso_last_route(ctx)
+        ot = co.Transcript()
+        co.lasso_prove(ot, pp.eqs_bytes(), nv, table.to_c(), n, [d.tobytes() for d in dims])
+        assert tr.into_proof() == ot.into_proof(), "bytes differ"
+        assert route["resident_layers"] == 0 and route["resident_tails"] >= 10, route
+        print("FALLBACK-OK", route["resident_layers"], route["resident_tails"])
+    """) % root
+    env = dict(os.environ, LH_GKR_START_TIMEOUT_MS="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "FALLBACK-OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]

@@ -283,6 +283,46 @@ def test_sharded_world1_over_rccl(hl, ctx):
     assert stats["device"] >= 15 and stats["host"] == 0, stats
 
 
+P2P_SELF_WORKER = textwrap.dedent("""
+    import sys, random
+    sys.path.insert(0, %r)
+    import numpy as np
+    import halo2_lasso_amd as hl
+    ctx = hl.Context(0)
+    n, shard_bit = 18, 16
+    table = hl.LassoTable.bitwise(hl.SUBTABLE_AND, 4, 16)
+    rng = np.random.default_rng(181)
+    prng = random.Random(181)
+    pp = hl.MultilinearKzg.setup(ctx, [prng.randrange(1, hl.R_MOD) for _ in range(n)])
+    cols = [rng.integers(0, 1 << 16, size=1 << n, dtype=np.uint32) for _ in range(4)]
+    cols[0][rng.random(1 << n) < 0.4] = 9                  # a hot address: long runs for the owner's ranking
+    dims = [ctx.upload(c.tobytes()) for c in cols]
+    single = hl.Keccak256Transcript()
+    hl.lasso_prove(pp, table, n, dims, single)
+    hl.attach_comm_rccl(ctx, 0, 1, hl.rccl_unique_id(), shard_bit)
+    t = hl.Keccak256Transcript()
+    hl.lasso_prove_sharded(pp, table, n, dims, t)
+    stats = hl.comm_stats(ctx)
+    by_phase = hl.comm_phase_stats(ctx)
+    hl.detach_comm(ctx)
+    assert t.into_proof() == single.into_proof(), "bytes differ"
+    assert stats["host"] == 0 and by_phase["witness"]["collectives"] >= 12, (stats, by_phase)   # 3 exchanges per chunk column
+    print("P2P-OK", stats, by_phase["witness"])
+""") % ROOT
+
+
+def test_rccl_grouped_send_recv_executes_on_one_gpu():
+    """the personalised exchange of the sharded access counters (grouped ncclSend / ncclRecv, csrc/comm.cpp)
+    had never executed - a world of one skipped the repartitioned counters and the exchange skipped the self segment.
+    With LH_SHARDED_COUNTERS_MIN_R=1 and LH_COMM_A2A_SELF=1 a world of ONE rank over real RCCL takes the repartitioned
+    counters and sends its own segment to itself through ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on the
+    prover's stream: symbols, group semantics and stream ordering run before the first multi-GPU job does; the proof
+    must be lasso_prove's."""
+    env = dict(os.environ, LH_SHARDED_COUNTERS_MIN_R="1", LH_COMM_A2A_SELF="1")
+    r = subprocess.run([sys.executable, "-c", P2P_SELF_WORKER], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "P2P-OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
 RCCL_WORKER = textwrap.dedent("""
     import os, sys, json
     sys.path.insert(0, %r)
