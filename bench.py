@@ -110,7 +110,9 @@ def aggregate(recs):
     return sorted(by.values(), key=lambda a: -a["ms"])
 
 
-PMC_KERNEL_NAMES = {"msm_accumulate0": "msm_accumulate0_kernel", "msm_bucket_reduce": "msm_segment_reduce_kernel",
+PMC_KERNEL_NAMES = {"msm_accumulate0": "msm_accumulate0_kernel<lh::Acc32>", "msm_bucket_reduce": "msm_segment_reduce_kernel",
+                    "sc_round_pp<bind>": "sc_round_pp_kernel<true>", "sc_round_pp<first>": "sc_round_pp_kernel<false>",
+                    "sc_round_rw<bind>": "sc_round_rw_kernel<4, true>", "gkr_resident": "gkr_resident_kernel",
                     "msm_accumulate_levels": "msm_accumulate_n_kernel", "lincomb": "lincomb_kernel",
                     "tree_up": "tree_up_kernel", "sc_round_open<bind>": "sc_round_open_kernel<true>",
                     "sc_round_open<first>": "sc_round_open_kernel<false>"}
@@ -136,7 +138,8 @@ def pmc_traffic(profile_name, log_n, table_kind, world=1, launches_per_proof=Non
     if not kern:
         return None, None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s_2p%d*.json" % (table_kind, log_n))), reverse=True):
-        rec = json.load(open(path))["kernels"].get(kern)
+        recs = json.load(open(path))["kernels"]
+        rec = recs.get(kern) or recs.get(kern.split("<")[0])  # (records of earlier rounds: the kernel was not a template)
         if not rec or "hbm_bytes_per_launch_avg" not in rec:
             continue
         if launches_per_proof is not None and abs(rec["launches_per_proof"] - launches_per_proof) > 1e-9:
@@ -207,12 +210,14 @@ def cpu_baseline(hl, ctx, pp, table, kind, args, gpu_proof_fn):
             "sample_log_n": n, "proof_bytes_equal_gpu": bool(same)}
 
 
-# Ceiling of the 32-bit integer multiplier the field arithmetic runs on (csrc/ff.cuh): one Montgomery product is
-# 129 v_mad_u64_u32 (64 operand products + 64 reduction products + 1).  v_mad_u64_u32 issues at a quarter of the
-# full 32-bit VALU rate (128 lanes per CU per cycle): 256 CUs x 128 x 2.4 GHz / 4 = 19.7 T mad/s = 152 G products/s;
-# the measured chain (tools/ubench/mul_forms.hip, lh_fr_mul_chain) reaches 86 % of that.
-MAD_PER_FR_MUL = 129
-MAD_CEILING_PER_S = 256 * 128 * 2.4e9 / 4
+# The integer-ALU ceiling of the field arithmetic (csrc/ff.cuh).  Rounds 1-3 priced it as "v_mad_u64_u32 at a quarter of the
+# VALU rate": measured in round 4 (tools/ubench/mul_fp64.hip, profiles/r04_ubench_mul_fp64.txt), EVERY VALU instruction of a
+# wave64 costs ~4.4-4.9 SIMD cycles here - v_mad_u64_u32 4.9, v_addc_co_u32 4.35 - so a Montgomery product is priced by its
+# instruction count: 129 multiply-adds + 128 add-with-carry + ~50 moves = ~307 instructions.  At the 4-cycle issue cost of a
+# wave64 instruction (one wave per SIMD in flight per issue, MI355X_MICROARCH.md) that is 1228 cycles per wave-product =
+# 256 CUs x 4 SIMDs x 2.4 GHz x 64 lanes / 1228 = 128 G products/s; the measured chains reach 119-131.
+INSTR_PER_FR_MUL = 307
+FR_MUL_CEILING_PER_S = 256 * 4 * 2.4e9 * 64 / (INSTR_PER_FR_MUL * 4)
 
 
 def dominant(aggs):
@@ -225,8 +230,8 @@ def dominant(aggs):
 def roofline_objects(hl, ctx, aggs, traffic=(None, None)):
     """`roofline`: the kernel with the largest total time in the profiled prove, priced in SURVEY.md §8(d)'s
     algorithmic bytes (sum over its launches) / its HIP-event time (sum over its launches) against 8 TB/s HBM;
-    `alu`: the same launches against the Fr-multiplication peak (measured, and the quarter-rate ceiling it is
-    derived from)."""
+    `alu`: the same launches against the Fr-multiplication peak (measured, and the instruction-issue ceiling next to
+    it)."""
     tot = sum(a["ms"] for a in aggs) or 1.0
     peak_mul = fr_mul_peak(hl, ctx)
     dom = dominant(aggs)
@@ -245,14 +250,16 @@ def roofline_objects(hl, ctx, aggs, traffic=(None, None)):
         roof["note"] = ("largest share of this prove: %s (%.0f %%, rounds resident in LDS: no HBM traffic, latency-bound); "
                         "the roofline is priced on the largest kernel that moves data" % (top["name"], 100.0 * top["ms"] / tot))
     mul_rate = dom["muls"] / (dom["ms"] * 1e-3) if dom["ms"] > 0 else 0.0
-    ceiling = MAD_CEILING_PER_S / MAD_PER_FR_MUL
+    ceiling = FR_MUL_CEILING_PER_S
     alu = {"bound": "int32-mul", "kernel": dom["name"], "achieved": round(mul_rate / 1e9, 2),
            "peak": round(peak_mul / 1e9, 2), "unit": "G Fr-mul/s", "frac": round(mul_rate / peak_mul, 4),
            "peak_source": "measured (lh_fr_mul_chain: two independent product chains per thread, 256 products per "
                           "element)",
            "ceiling": round(ceiling / 1e9, 1), "frac_of_ceiling": round(mul_rate / ceiling, 4),
-           "ceiling_derivation": "256 CU x 128 lanes/cycle x 2.4 GHz / 4 (v_mad_u64_u32 is quarter rate) = 19.7 T mad/s; "
-                                 "/ 129 v_mad_u64_u32 per Montgomery product"}
+           "ceiling_derivation": "instruction issue: ~307 VALU instructions per Montgomery product (129 v_mad_u64_u32 + 128 "
+                                 "v_addc_co_u32 + ~50), 4 SIMD cycles per wave64 instruction: 256 CU x 4 SIMD x 2.4 GHz x 64 / "
+                                 "1228 cycles (measured issue costs: profiles/r04_ubench_mul_fp64.txt); `achieved` counts a mixed "
+                                 "addition as 10 products, of which the two of Y3 share a reduction since round 4"}
     kernels = [{"name": a["name"], "launches": a["launches"], "ms": round(a["ms"], 3),
                 "GBps_all": round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1) if a["ms"] > 0 else 0.0,
                 "GBps_largest": round(a["big"]["bytes"] / (a["big"]["ms"] * 1e-3) / 1e9, 1) if a["big"]["ms"] > 0 else 0.0}
