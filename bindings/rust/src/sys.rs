@@ -267,6 +267,15 @@ extern "C" {
     pub fn lh_hyperplonk_verify_phases(vp: *const lh_mkzg_vp, hvp: *const lh_hp_vparam, num_phases: usize,
                                        num_witness_polys: *const usize, num_challenges: *const usize,
                                        instances: *const *const Fr, t: *mut lh_transcript) -> lh_status;
+    // multi-phase circuits over Zeromorph (hyperplonk.rs:185-205 is PCS-generic; lh_usrs / lh_zm_vp are opaque here)
+    pub fn lh_hyperplonk_prove_phases_zeromorph(ctx: *mut lh_ctx, srs: *const core::ffi::c_void, poly_size: usize,
+                                                pp: *const lh_hp_param, num_phases: usize,
+                                                num_witness_polys: *const usize, num_challenges: *const usize,
+                                                instances: *const *const Fr, circuit: *const lh_hp_circuit,
+                                                t: *mut lh_transcript) -> lh_status;
+    pub fn lh_hyperplonk_verify_phases_zeromorph(vp: *const core::ffi::c_void, hvp: *const lh_hp_vparam, num_phases: usize,
+                                                 num_witness_polys: *const usize, num_challenges: *const usize,
+                                                 instances: *const *const Fr, t: *mut lh_transcript) -> lh_status;
     // Zeromorph over univariate KZG: lh_ukzg_setup, lh_usrs_*, lh_zeromorph_* follow the same shapes
     // (include/lasso_hip.h, section f3) and are bound the same way when HyperPlonk<Zeromorph<..>> is wanted.
 }

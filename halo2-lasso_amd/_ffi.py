@@ -244,6 +244,11 @@ SIGNATURES = {
                                                 C.POINTER(_P), C.POINTER(lh_transcript)]),
     "lh_hyperplonk_verify_zeromorph": (C.c_int, [_P, C.POINTER(lh_hp_vparam), C.POINTER(C.POINTER(lh_fr)),
                                                  C.POINTER(lh_transcript)]),
+    "lh_hyperplonk_prove_phases_zeromorph": (C.c_int, [_P, _P, _SZ, C.POINTER(lh_hp_param), _SZ, C.POINTER(_SZ),
+                                                       C.POINTER(_SZ), C.POINTER(C.POINTER(lh_fr)),
+                                                       C.POINTER(lh_hp_circuit), C.POINTER(lh_transcript)]),
+    "lh_hyperplonk_verify_phases_zeromorph": (C.c_int, [_P, C.POINTER(lh_hp_vparam), _SZ, C.POINTER(_SZ), C.POINTER(_SZ),
+                                                        C.POINTER(C.POINTER(lh_fr)), C.POINTER(lh_transcript)]),
     "lh_profile_enable": (C.c_int, [_P, C.c_int]),
     "lh_profile_read": (C.c_int, [_P, C.POINTER(lh_prof_rec), _SZ, C.POINTER(_SZ)]),
 }

@@ -590,16 +590,11 @@ lh_status lh_lasso_prove_sharded(lh_ctx* ctx, const lh_srs* srs, const lh_lasso_
   LH_CATCH
 }
 
-lh_status lh_hyperplonk_prove_phases(lh_ctx* ctx, const lh_srs* srs, const lh_hp_param* pp, size_t num_phases,
-                                     const size_t* num_witness_polys, const size_t* num_challenges,
-                                     const lh_fr* const* instances, const lh_hp_circuit* circuit, lh_transcript* t) {
-  LH_TRY NEED_CTX(ctx);
-  NEED(srs);
-  NEED(pp);
-  NEED(circuit);
+// the phase loop's arguments as the prover wants them (hyperplonk.rs:185-205): shared by both PCS entry points
+static HpPhases hp_phases_of(const lh_hp_param* pp, size_t num_phases, const size_t* num_witness_polys,
+                             const size_t* num_challenges, const lh_hp_circuit* circuit) {
   LH_REQUIRE(circuit->synthesize, LH_ERR_ARG, "circuit: synthesize callback missing");
   LH_REQUIRE(num_phases == 0 || (num_witness_polys && num_challenges), LH_ERR_ARG, "null argument: phases");
-  Transcript tr(t);
   HpPhases ph;
   ph.num_witness_polys.assign(num_witness_polys, num_witness_polys + num_phases);
   ph.num_challenges.assign(num_challenges, num_challenges + num_phases);
@@ -607,8 +602,9 @@ lh_status lh_hyperplonk_prove_phases(lh_ctx* ctx, const lh_srs* srs, const lh_hp
   for (size_t r = 0; r < num_phases; r++) tw += num_witness_polys[r], tc += num_challenges[r];
   LH_REQUIRE(tw == pp->num_witness_polys && tc == pp->num_challenges, LH_ERR_ARG,
              "hyperplonk: phases do not add up to num_witness_polys / num_challenges");
-  ph.synthesize = [&](size_t round, const std::vector<HFr>& challenges) {
-    std::vector<const void*> out(ph.num_witness_polys[round], nullptr);
+  const std::vector<size_t> per_phase = ph.num_witness_polys;
+  ph.synthesize = [circuit, per_phase](size_t round, const std::vector<HFr>& challenges) {
+    std::vector<const void*> out(per_phase[round], nullptr);
     int rc = circuit->synthesize(circuit->user, round, (const lh_fr*)challenges.data(), challenges.size(), out.data(),
                                  out.size());
     if (rc != LH_OK) throw lh::Error(rc < 0 ? rc : LH_ERR_INVALID_SNARK, "circuit synthesize callback failed");
@@ -619,6 +615,18 @@ lh_status lh_hyperplonk_prove_phases(lh_ctx* ctx, const lh_srs* srs, const lh_hp
     }
     return w;
   };
+  return ph;
+}
+
+lh_status lh_hyperplonk_prove_phases(lh_ctx* ctx, const lh_srs* srs, const lh_hp_param* pp, size_t num_phases,
+                                     const size_t* num_witness_polys, const size_t* num_challenges,
+                                     const lh_fr* const* instances, const lh_hp_circuit* circuit, lh_transcript* t) {
+  LH_TRY NEED_CTX(ctx);
+  NEED(srs);
+  NEED(pp);
+  NEED(circuit);
+  Transcript tr(t);
+  const HpPhases ph = hp_phases_of(pp, num_phases, num_witness_polys, num_challenges, circuit);
   hyperplonk_prove_phases(ctx->c, mkzg_pcs(ctx->c, srs->s), *pp, ph, (const HFr* const*)instances, tr);
   LH_CATCH
 }
@@ -952,6 +960,36 @@ lh_status lh_hyperplonk_verify_zeromorph(const lh_zm_vp* vp, const lh_hp_vparam*
   hyperplonk_verify([&pcs](size_t nv, const HG1* comms, size_t nc, const HFr* points, size_t np, const lh_evaluation* evals,
                            size_t ne, Transcript& t2) { zeromorph_batch_verify(pcs, nv, comms, nc, points, np, evals, ne, t2); },
                     *hvp, (const HFr* const*)instances, tr);
+  LH_CATCH
+}
+
+lh_status lh_hyperplonk_prove_phases_zeromorph(lh_ctx* ctx, const lh_usrs* srs, size_t poly_size, const lh_hp_param* pp,
+                                               size_t num_phases, const size_t* num_witness_polys,
+                                               const size_t* num_challenges, const lh_fr* const* instances,
+                                               const lh_hp_circuit* circuit, lh_transcript* t) {
+  LH_TRY NEED_CTX(ctx);
+  NEED(srs);
+  NEED(pp);
+  NEED(circuit);
+  Transcript tr(t);
+  const HpPhases ph = hp_phases_of(pp, num_phases, num_witness_polys, num_challenges, circuit);
+  hyperplonk_prove_phases(ctx->c, zeromorph_pcs(ctx->c, srs->s, poly_size), *pp, ph, (const HFr* const*)instances, tr);
+  LH_CATCH
+}
+lh_status lh_hyperplonk_verify_phases_zeromorph(const lh_zm_vp* vp, const lh_hp_vparam* hvp, size_t num_phases,
+                                                const size_t* num_witness_polys, const size_t* num_challenges,
+                                                const lh_fr* const* instances, lh_transcript* t) {
+  LH_TRY
+  NEED(vp);
+  NEED(hvp);
+  LH_REQUIRE(num_phases == 0 || (num_witness_polys && num_challenges), LH_ERR_ARG, "null argument: phases");
+  Transcript tr(t);
+  const ZmVerifierParams& pcs = *vp->p;
+  hyperplonk_verify_phases(
+      [&pcs](size_t nv, const HG1* comms, size_t nc, const HFr* points, size_t np, const lh_evaluation* evals, size_t ne,
+             Transcript& t2) { zeromorph_batch_verify(pcs, nv, comms, nc, points, np, evals, ne, t2); },
+      *hvp, std::vector<size_t>(num_witness_polys, num_witness_polys + num_phases),
+      std::vector<size_t>(num_challenges, num_challenges + num_phases), (const HFr* const*)instances, tr);
   LH_CATCH
 }
 

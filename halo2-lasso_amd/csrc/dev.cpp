@@ -26,6 +26,20 @@ Arena::~Arena() {
 void* Arena::alloc(size_t bytes) {
   bytes = (bytes + 255) & ~(size_t)255;
   if (bytes == 0) bytes = 256;
+  // development (LH_ARENA_SKEW=bytes): large tables are power-of-two sized, so back-to-back allocations put the SAME index of
+  // every table a round kernel streams on addresses that differ by multiples of 2^28; a rotating skew in front of each large
+  // allocation staggers them (does the memory system spread channels well enough without it? measured: profiles/README.md)
+  static const size_t skew_unit = [] {
+    const char* e = getenv("LH_ARENA_SKEW");
+    return e ? (size_t)atoll(e) & ~(size_t)255 : (size_t)0;
+  }();
+  if (skew_unit && bytes >= ((size_t)1 << 20)) {
+    const size_t pad = (skew_count_++ % 61) * skew_unit;
+    return (char*)alloc_raw(bytes + pad) + pad;
+  }
+  return alloc_raw(bytes);
+}
+void* Arena::alloc_raw(size_t bytes) {
   while (true) {
     if (!blocks_.empty()) {
       Block& b = blocks_[cur_];

@@ -46,6 +46,7 @@ class Arena {
   };
   ~Arena();
   void* alloc(size_t bytes);
+  void* alloc_raw(size_t bytes);
   template <class T>
   T* alloc_n(size_t n) {
     return (T*)alloc(n * sizeof(T));
@@ -60,7 +61,7 @@ class Arena {
     size_t size, used;
   };
   std::vector<Block> blocks_;
-  size_t cur_ = 0, high_ = 0;
+  size_t cur_ = 0, high_ = 0, skew_count_ = 0;
 };
 
 struct ArenaScope {

@@ -230,8 +230,6 @@ class HyperPlonk:
         inst = (C.POINTER(lh_fr) * max(len(instances), 1))(*[C.cast(a, C.POINTER(lh_fr)) for a in inst_arrays])
         from . import ZeromorphProverParam
         if multi:
-            if isinstance(pp.pcs, ZeromorphProverParam):
-                raise NotImplementedError("multi-phase circuits are wired for multilinear KZG")
             from . import fr_from_bytes
             alive, failure = [], []
 
@@ -253,8 +251,12 @@ class HyperPlonk:
             nph = len(info.num_witness_polys)
             nw = (C.c_size_t * max(nph, 1))(*info.num_witness_polys)
             nc = (C.c_size_t * max(nph, 1))(*info.num_challenges)
-            rc = ctx.lib.lh_hyperplonk_prove_phases(ctx.h, pp.pcs.h, C.byref(prm), nph, nw, nc, inst, C.byref(circ),
-                                                    transcript.p)
+            if isinstance(pp.pcs, ZeromorphProverParam):
+                rc = ctx.lib.lh_hyperplonk_prove_phases_zeromorph(ctx.h, pp.pcs.params.h, pp.pcs.poly_size, C.byref(prm), nph,
+                                                                  nw, nc, inst, C.byref(circ), transcript.p)
+            else:
+                rc = ctx.lib.lh_hyperplonk_prove_phases(ctx.h, pp.pcs.h, C.byref(prm), nph, nw, nc, inst, C.byref(circ),
+                                                        transcript.p)
             if failure:
                 raise failure[0]
             _check(rc)
@@ -296,12 +298,12 @@ class HyperPlonk:
         inst = (C.POINTER(lh_fr) * max(len(instances), 1))(*[C.cast(a, C.POINTER(lh_fr)) for a in inst_arrays])
         from . import ZeromorphVerifierParam
         if len(info.num_witness_polys) != 1:
-            if isinstance(vp.pcs, ZeromorphVerifierParam):
-                raise NotImplementedError("multi-phase circuits are wired for multilinear KZG")
             nph = len(info.num_witness_polys)
             nw = (C.c_size_t * max(nph, 1))(*info.num_witness_polys)
             nc = (C.c_size_t * max(nph, 1))(*info.num_challenges)
-            _check(vp.pcs.lib.lh_hyperplonk_verify_phases(vp.pcs.h, C.byref(prm), nph, nw, nc, inst, transcript.p))
+            fn = vp.pcs.lib.lh_hyperplonk_verify_phases_zeromorph if isinstance(vp.pcs, ZeromorphVerifierParam) \
+                else vp.pcs.lib.lh_hyperplonk_verify_phases
+            _check(fn(vp.pcs.h, C.byref(prm), nph, nw, nc, inst, transcript.p))
             return
         fn = vp.pcs.lib.lh_hyperplonk_verify_zeromorph if isinstance(vp.pcs, ZeromorphVerifierParam) \
             else vp.pcs.lib.lh_hyperplonk_verify

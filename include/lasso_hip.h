@@ -545,6 +545,16 @@ lh_status lh_hyperplonk_prove_zeromorph(lh_ctx*, const lh_usrs*, size_t poly_siz
                                         lh_transcript* t);
 lh_status lh_hyperplonk_verify_zeromorph(const lh_zm_vp*, const lh_hp_vparam*, const lh_fr* const* instances,
                                          lh_transcript* t);
+/* multi-phase circuits over Zeromorph: the phase loop of backend/hyperplonk.rs:185-205 / 309-316 is generic over the PCS
+ * (the reference instantiates HyperPlonk<Zeromorph<..>> at hyperplonk.rs:426); arguments as lh_hyperplonk_prove_phases /
+ * lh_hyperplonk_verify_phases */
+lh_status lh_hyperplonk_prove_phases_zeromorph(lh_ctx*, const lh_usrs*, size_t poly_size, const lh_hp_param*,
+                                               size_t num_phases, const size_t* num_witness_polys,
+                                               const size_t* num_challenges, const lh_fr* const* instances,
+                                               const lh_hp_circuit* circuit, lh_transcript* t);
+lh_status lh_hyperplonk_verify_phases_zeromorph(const lh_zm_vp*, const lh_hp_vparam*, size_t num_phases,
+                                                const size_t* num_witness_polys, const size_t* num_challenges,
+                                                const lh_fr* const* instances, lh_transcript* t);
 
 /* ---------------------------------------------------------------- measurement (bench.py)
  * Per-kernel HIP-event timing on the ctx stream.  While enabled every instrumented launch is

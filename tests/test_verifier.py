@@ -299,6 +299,35 @@ def test_hyperplonk_verify_two_phase_circuit(hl, num_vars):
         g_hp.HyperPlonk.verify(vp, [[v + 1 for v in instances[0]]], hl.Keccak256Transcript.from_proof(proof))
 
 
+@pytest.mark.parametrize("num_vars", [3, 4])
+def test_hyperplonk_verify_two_phase_circuit_over_zeromorph(hl, num_vars):
+    """the same over Zeromorph (lh_hyperplonk_verify_phases_zeromorph): a proof of the specification is accepted, a
+    tampered one and wrong instances are rejected"""
+    from halo2_lasso_amd import hyperplonk as g_hp, expression as g_ex
+    from oracle.pyref import hyperplonk as o_hp, expression as o_ex, zeromorph as o_zm
+    from test_gpu_hyperplonk import _two_phase_circuit
+    s = random.Random(940 + num_vars).randrange(1, P)
+    o_info, instances, synth = _two_phase_circuit(o_ex, o_hp.CircuitInfo, num_vars, random.Random(num_vars), None)
+    o_pp = o_hp.preprocess(o_zm.trim(o_zm.setup(s, 1 << num_vars), 1 << num_vars), o_info, o_zm)
+    t = OT()
+    o_hp.prove(o_pp, instances, synth, t)
+    proof = t.into_proof()
+    g_info, _, _ = _two_phase_circuit(g_ex, g_hp.PlonkishCircuitInfo, num_vars, random.Random(num_vars), None)
+    vp = g_hp.HyperPlonkVerifierParam()
+    vp.pcs, vp.num_vars, vp.info = hl.ZeromorphVerifierParam.setup(s, 1 << num_vars, 1 << num_vars), num_vars, g_info
+    vp.num_permutation_z_polys, vp.expression = g_hp.compose(g_info)
+    vp.preprocess_comms, vp.permutation_comms = o_pp.preprocess_comms, o_pp.permutation_comms
+    r = hl.Keccak256Transcript.from_proof(proof)
+    g_hp.HyperPlonk.verify(vp, instances, r)
+    assert r.remaining() == 0
+    bad = bytearray(proof)
+    bad[3 * 64 + 40] ^= 1
+    with pytest.raises(hl.Error):
+        g_hp.HyperPlonk.verify(vp, instances, hl.Keccak256Transcript.from_proof(bytes(bad)))
+    with pytest.raises(hl.Error):
+        g_hp.HyperPlonk.verify(vp, [[v + 1 for v in instances[0]]], hl.Keccak256Transcript.from_proof(proof))
+
+
 LASSO_CIRCUITS = [("range", 2, 2, 4), ("and", 2, 4, 5), ("xor", 2, 4, 4)]
 
 
