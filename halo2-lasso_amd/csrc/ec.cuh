@@ -46,7 +46,7 @@ struct alignas(16) G1Xyzz {
 LH_HD Fq mul_sub_mul(const Fq& a, const Fq& c, const Fq& b, const Fq& d) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const Fq x[2] = {a, neg(b)}, y[2] = {c, d};
-  return dot_scan<FqParams, 2>(x, y);
+  return dot<FqParams, 2>(x, y);
 #else
   return sub(mul(a, c), mul(b, d));
 #endif

@@ -407,6 +407,87 @@ __device__ __forceinline__ Fp<P> dot_scan(const Fp<P>* a, const Fp<P>* b) {
   for (int t = 0; t < NRED; t++) out = reduce_once(out);
   return out;
 }
+// The same two routines with ONE asm block per column (ff_cols.inc, generated by tools/gen_ff_cols.py): after every asm
+// block whose result the next instruction reads the compiler's hazard recogniser puts an `s_nop 0` (it must assume a
+// dst_sel write), which with a block per multiply-add was 136 + ~16 extra issue slots next to the 307 instructions of a
+// product.  Same instructions otherwise, same results (tools/ubench/mul_cols.hip).
+#ifndef LH_FF_COLS
+#define LH_FF_COLS 1
+#endif
+#include "ff_cols.inc"
+#define LH_COL_STEP_LO(k)                       \
+  m[k] = (uint32_t)acc * P::INV;                \
+  LH_MACS(m[k], P::mod(0));                     \
+  acc = (acc >> 32) | ((uint64_t)top << 32);    \
+  top = 0
+#define LH_COL_STEP_HI(k)                       \
+  r[k - 8] = (uint32_t)acc;                     \
+  acc = (acc >> 32) | ((uint64_t)top << 32);    \
+  top = 0
+template <class P>
+__device__ __forceinline__ Fp<P> mul_scan_cols(const Fp<P>& a, const Fp<P>& b) {
+  uint64_t acc = 0;
+  uint32_t top = 0;
+  uint32_t m[8], r[8];
+  LH_COL_MUL_0(a, b, m, P); LH_COL_STEP_LO(0);
+  LH_COL_MUL_1(a, b, m, P); LH_COL_STEP_LO(1);
+  LH_COL_MUL_2(a, b, m, P); LH_COL_STEP_LO(2);
+  LH_COL_MUL_3(a, b, m, P); LH_COL_STEP_LO(3);
+  LH_COL_MUL_4(a, b, m, P); LH_COL_STEP_LO(4);
+  LH_COL_MUL_5(a, b, m, P); LH_COL_STEP_LO(5);
+  LH_COL_MUL_6(a, b, m, P); LH_COL_STEP_LO(6);
+  LH_COL_MUL_7(a, b, m, P); LH_COL_STEP_LO(7);
+  LH_COL_MUL_8(a, b, m, P); LH_COL_STEP_HI(8);
+  LH_COL_MUL_9(a, b, m, P); LH_COL_STEP_HI(9);
+  LH_COL_MUL_10(a, b, m, P); LH_COL_STEP_HI(10);
+  LH_COL_MUL_11(a, b, m, P); LH_COL_STEP_HI(11);
+  LH_COL_MUL_12(a, b, m, P); LH_COL_STEP_HI(12);
+  LH_COL_MUL_13(a, b, m, P); LH_COL_STEP_HI(13);
+  LH_COL_MUL_14(a, b, m, P); LH_COL_STEP_HI(14);
+  r[7] = (uint32_t)acc;  // (column 15 has no products: the last carry word)
+  Fp<P> out;
+#pragma unroll
+  for (int j = 0; j < 8; j++) out.l[j] = r[j];
+  return reduce_once(out);
+}
+#define LH_COL_DOT(k)                                       \
+  _Pragma("unroll") for (int j = 0; j < K; j++) {           \
+    LH_COL_VV_##k(a[j], b[j]);                              \
+  }                                                         \
+  LH_COL_VS_##k(m, P)
+template <class P, int K>
+__device__ __forceinline__ Fp<P> dot_scan_cols(const Fp<P>* a, const Fp<P>* b) {
+  static_assert(K >= 1 && K <= 16, "dot_scan: the result must stay below 2^256");
+  uint64_t acc = 0;
+  uint32_t top = 0;
+  uint32_t m[8], r[8];
+  LH_COL_DOT(0); LH_COL_STEP_LO(0);
+  LH_COL_DOT(1); LH_COL_STEP_LO(1);
+  LH_COL_DOT(2); LH_COL_STEP_LO(2);
+  LH_COL_DOT(3); LH_COL_STEP_LO(3);
+  LH_COL_DOT(4); LH_COL_STEP_LO(4);
+  LH_COL_DOT(5); LH_COL_STEP_LO(5);
+  LH_COL_DOT(6); LH_COL_STEP_LO(6);
+  LH_COL_DOT(7); LH_COL_STEP_LO(7);
+  LH_COL_DOT(8); LH_COL_STEP_HI(8);
+  LH_COL_DOT(9); LH_COL_STEP_HI(9);
+  LH_COL_DOT(10); LH_COL_STEP_HI(10);
+  LH_COL_DOT(11); LH_COL_STEP_HI(11);
+  LH_COL_DOT(12); LH_COL_STEP_HI(12);
+  LH_COL_DOT(13); LH_COL_STEP_HI(13);
+  LH_COL_DOT(14); LH_COL_STEP_HI(14);
+  r[7] = (uint32_t)acc;
+  Fp<P> out;
+#pragma unroll
+  for (int j = 0; j < 8; j++) out.l[j] = r[j];
+  constexpr int NRED = K <= 5 ? 1 : K <= 10 ? 2 : K <= 15 ? 3 : 4;
+#pragma unroll
+  for (int t = 0; t < NRED; t++) out = reduce_once(out);
+  return out;
+}
+#undef LH_COL_DOT
+#undef LH_COL_STEP_LO
+#undef LH_COL_STEP_HI
 #undef LH_MAC
 #undef LH_MACS
 #endif
@@ -414,7 +495,7 @@ __device__ __forceinline__ Fp<P> dot_scan(const Fp<P>* a, const Fp<P>* b) {
 template <class P>
 LH_HD Fp<P> mul(const Fp<P>& a, const Fp<P>& b) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return mul_scan(a, b);
+  return LH_FF_COLS ? mul_scan_cols(a, b) : mul_scan(a, b);
 #else
   return mul_cios(a, b);
 #endif
@@ -424,7 +505,7 @@ LH_HD Fp<P> mul(const Fp<P>& a, const Fp<P>& b) {
 template <class P, int K>
 LH_HD Fp<P> dot(const Fp<P>* a, const Fp<P>* b) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return dot_scan<P, K>(a, b);
+  return LH_FF_COLS ? dot_scan_cols<P, K>(a, b) : dot_scan<P, K>(a, b);
 #else
   Fp<P> s = mul_cios(a[0], b[0]);
   for (int j = 1; j < K; j++) s = add_generic(s, mul_cios(a[j], b[j]));

@@ -16,7 +16,7 @@
 #include <string>
 #include <vector>
 #include "dev.hpp"
-#include "jit_sources.inc"  // JIT_FF_CUH, JIT_REDUCE_CUH: the text of ff.cuh / reduce.cuh (Makefile)
+#include "jit_sources.inc"  // JIT_FF_CUH, JIT_FF_COLS_INC, JIT_REDUCE_CUH: the text of ff.cuh / ff_cols.inc / reduce.cuh (Makefile)
 
 namespace lh {
 
@@ -164,9 +164,9 @@ const JitKernel* jit_sc_round(const Ctx& c, const uint32_t* code, size_t num_ins
   const auto t0 = std::chrono::steady_clock::now();
   const std::string src = generate(code, num_instrs, num_regs, result_reg, degree);
   hiprtcProgram prog;
-  const char* hdr[] = {JIT_FF_CUH, JIT_REDUCE_CUH};
-  const char* names[] = {"ff.cuh", "reduce.cuh"};
-  if (hiprtcCreateProgram(&prog, src.c_str(), "sc_round_jit.hip", 2, hdr, names) != HIPRTC_SUCCESS) return nullptr;
+  const char* hdr[] = {JIT_FF_CUH, JIT_REDUCE_CUH, JIT_FF_COLS_INC};
+  const char* names[] = {"ff.cuh", "reduce.cuh", "ff_cols.inc"};
+  if (hiprtcCreateProgram(&prog, src.c_str(), "sc_round_jit.hip", 3, hdr, names) != HIPRTC_SUCCESS) return nullptr;
   const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
   const hiprtcResult r = hiprtcCompileProgram(prog, 3, opts);
   if (r != HIPRTC_SUCCESS) {
