@@ -28,6 +28,10 @@ template <class F> __global__ void check_kernel(const F* a, const F* b, uint32_t
   ok = ok && mul_scan_cols(c, F::r2()) == mul_cios(c, F::r2());
   const F cs[2] = {c, F::one()}, ds[2] = {F::r2(), c};
   ok = ok && dot_scan_cols<P, 2>(cs, ds) == add_generic(mul_cios(c, F::r2()), mul_cios(F::one(), c));
+  // the fused addition / subtraction / reduction blocks against the generic forms
+  ok = ok && add(x[0], y[0]) == add_generic(x[0], y[0]) && add(x[1], x[1]) == add_generic(x[1], x[1]);
+  ok = ok && sub(x[0], y[0]) == sub_generic(x[0], y[0]) && sub(y[0], x[0]) == sub_generic(y[0], x[0]) && sub(x[2], x[2]).is_zero();
+  ok = ok && neg(x[3]) == sub_generic(F::zero(), x[3]) && reduce_once(a[i]) == reduce_once_generic(a[i]);
   if (!ok) atomicAdd(bad, 1u);
 #endif
 }
