@@ -638,7 +638,7 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
   } precommit_guard{c};
   // (started when the memory-checking argument has built its product trees - Ctx::gkr_hook: beside the Surge rounds and the
   // tree kernels, which stream at the HBM bound, the helper's sorts only get in the way: tree_up 1.2 -> 5.0 ms per proof)
-  if (pcs.precommit && !shn)
+  if (pcs.precommit)
     c.gkr_hook = [&] { pcs.precommit(nv, small.data(), small.size(), evs.data(), evs.size()); };
 
   // ---- 2-7: Surge, memory checking, evaluations

@@ -1886,12 +1886,25 @@ void open_precommit_start(Ctx& c, const Srs& srs, size_t num_vars, const SmallPo
   open_precommit_cancel(c);
   // (the option is the smallest proof that does it; default 1: every proof that takes the column route - 2^17..2^19 range
   // lookups gain too: 7.0 -> 6.4-6.9, 8.1-9.1 -> 7.3-7.7, 9.7-9.9 -> 9.3-9.4 ms)
-  if (c.opt.open_precommit <= 0 || (int64_t)num_vars < c.opt.open_precommit || c.shard_active || !small || num_vars > srs.num_vars) return;
-  const size_t n = (size_t)1 << num_vars;
+  if (c.opt.open_precommit <= 0 || (int64_t)num_vars < c.opt.open_precommit || !small || num_vars > srs.num_vars) return;
+  // inside a sharded proof the columns are this rank's shards and the column-wise levels are committed against this rank's
+  // share of the levels' bases (mkzg_open's geometry): nothing in this half of the route needs a peer
+  const Shard sh(c);
+  const bool sharded = sh.sharded(num_vars);
+  const size_t lsh = sharded ? sh.rho : 0, cut = sharded ? sh.j + sh.rho : 0;
+  const size_t n = (size_t)1 << (num_vars - lsh);
   SmallOpen so;
   if (!small_open_columns(small, num_polys, evals, num_evals, n, nullptr, so)) return;
   std::vector<char> zero(so.cols.size(), 0);
-  if (!column_route_on(c, so.cols, zero, num_vars, 0, n, false, 0)) return;
+  if (!column_route_on(c, so.cols, zero, num_vars, lsh, n, sharded, cut)) return;
+  // the bases of the (at most two) column-wise levels, resolved here: a rank's share of a level is made on first use by a
+  // ctx that knows the shard geometry - this one
+  std::vector<const G1Affine*> bases_of(num_vars + 1, nullptr);
+  for (size_t d = 0; d < 2 && d + 1 <= num_vars; d++) {
+    const size_t lvl = num_vars - 1 - d;
+    if (sharded && lvl < cut) break;
+    bases_of[lvl] = sharded ? srs_shard_level(c, srs, lvl) : srs.eq(lvl);
+  }
   Ctx& h = ctx_helper(c);
   h.opt = c.opt;
   h.prof = c.prof;
@@ -1907,17 +1920,22 @@ void open_precommit_start(Ctx& c, const Srs& srs, size_t num_vars, const SmallPo
   const int device = c.device;
   if (!h.worker) h.worker = new HostWorker();
   pc->worker = h.worker;
-  h.worker->submit([pc, &h, &srs, num_vars, n, device, handoff] {
+  h.worker->submit([pc, &h, &srs, num_vars, n, lsh, cut, sharded, bases_of, device, handoff] {
     try {
       LH_HIP(hipSetDevice(device));
       LH_HIP(hipStreamWaitEvent(h.stream, handoff, 0));
       ArenaScope scope(h.arena);
-      column_shape(h, pc->cols, pc->zero, n, num_vars, 0, pc->plan);
-      column_jobs(h, srs, pc->cols, pc->zero, num_vars, 0, false, [&srs](size_t lvl) { return srs.eq(lvl); }, pc->plan);
+      column_shape(h, pc->cols, pc->zero, n, num_vars, cut, pc->plan);
+      column_jobs(h, srs, pc->cols, pc->zero, num_vars, lsh, sharded,
+                  [&bases_of](size_t lvl) {
+                    LH_REQUIRE(lvl < bases_of.size() && bases_of[lvl], LH_ERR_ARG, "open precommit: level without bases");
+                    return bases_of[lvl];
+                  },
+                  pc->plan);
       pc->out.resize(pc->plan.jobs.size());
       if (!pc->plan.jobs.empty()) msm_batch(h, pc->plan.jobs.data(), pc->plan.jobs.size(), (G1Affine*)pc->out.data());
       h.sync();
-      column_sums_store(srs, false, pc->plan, pc->out.data());
+      column_sums_store(srs, sharded, pc->plan, pc->out.data());
       pc->ok = true;
     } catch (const std::exception& e) {
       pc->err = e.what();

@@ -257,6 +257,7 @@ def test_full_size_configs_sharded_on_one_gpu(tmp_path, hl, ctx, world, kind, n)
         assert o["bytes"] == len(single) and o["sha256"] == want, "rank %d: the sharded proof differs" % o["rank"]
         r = o["route"]
         assert r["sharded_rounds"] > 0 and r["eq_factored_rounds"] > 0 and r["rw_leaf_rounds"] > 0 and r["open_small_depth"] >= 1, r
+        assert r["open_precommit"] == 1, r  # the shard's column-wise commitments ran on the helper ctx beside the sum-checks
 
 
 def test_sharded_world1_over_rccl(hl, ctx):
