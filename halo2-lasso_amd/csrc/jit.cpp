@@ -7,9 +7,15 @@
 // is gone - and compiled for gfx950 with hiprtc (the reference's counterpart: the per-expression `indexed_calculations`
 // of util/expression/evaluator.rs:135-323, which the Rust compiler specialises at build time because the expression
 // is a generic parameter there; here it is data, so the specialisation happens when the expression arrives).
-// One module per distinct program (hash of the code words, register count, degree), cached for the process.
+// One module per distinct program (hash of the code words, register count, degree), cached for the process - and its code
+// object on disk for the next process (disk_* below).
 #include <hip/hiprtc.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <cerrno>
 #include <chrono>
+#include <cstdio>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <sstream>
@@ -138,6 +144,86 @@ std::mutex g_mu;
 std::map<std::vector<uint32_t>, JitKernel*> g_cache;  // never freed: modules live as long as the process
 }  // namespace
 
+// ---- code objects kept on disk: a process's first HyperPlonk proof otherwise pays seconds of hiprtc per distinct program
+// (and every rank process of a node pays them again).  One file per (generated source, device headers, compiler version):
+// LH_JIT_CACHE_DIR, else $XDG_CACHE_HOME/lasso_hip/jit, else $HOME/.cache/lasso_hip/jit; LH_JIT_CACHE=0 switches it off.
+// A file is written under a temporary name and renamed; its header carries the payload's size and checksum, so a torn or
+// foreign file is ignored and rewritten.
+namespace {
+uint64_t fnv1a(const void* p, size_t n, uint64_t h) {
+  const unsigned char* b = (const unsigned char*)p;
+  for (size_t i = 0; i < n; i++) h = (h ^ b[i]) * 0x100000001b3ull;
+  return h;
+}
+struct DiskHeader {
+  char magic[8];
+  uint64_t size, sum;
+};
+const char DISK_MAGIC[8] = {'L', 'H', 'J', 'I', 'T', '0', '1', 0};
+bool make_dirs(const std::string& path) {  // mkdir -p
+  for (size_t i = 1; i <= path.size(); i++)
+    if (i == path.size() || path[i] == '/') {
+      const std::string sub = path.substr(0, i);
+      if (mkdir(sub.c_str(), 0700) != 0 && errno != EEXIST) return false;
+    }
+  return true;
+}
+const std::string& disk_dir() {  // empty: no disk cache
+  static const std::string dir = [] {
+    const char* on = getenv("LH_JIT_CACHE");
+    if (on && atoi(on) == 0) return std::string();
+    std::string d;
+    if (const char* e = getenv("LH_JIT_CACHE_DIR")) d = e;
+    else if (const char* x = getenv("XDG_CACHE_HOME")) d = std::string(x) + "/lasso_hip/jit";
+    else if (const char* h = getenv("HOME")) d = std::string(h) + "/.cache/lasso_hip/jit";
+    if (d.empty() || !make_dirs(d)) return std::string();
+    return d;
+  }();
+  return dir;
+}
+std::string disk_name(const std::string& src) {
+  static const uint64_t base[2] = {[] {
+                                     int major = 0, minor = 0;
+                                     (void)hiprtcVersion(&major, &minor);
+                                     uint64_t h = fnv1a(&major, sizeof major, 0xcbf29ce484222325ull);
+                                     h = fnv1a(&minor, sizeof minor, h);
+                                     h = fnv1a(JIT_FF_CUH, sizeof JIT_FF_CUH, h);
+                                     h = fnv1a(JIT_FF_COLS_INC, sizeof JIT_FF_COLS_INC, h);
+                                     return fnv1a(JIT_REDUCE_CUH, sizeof JIT_REDUCE_CUH, h);
+                                   }(),
+                                   0};
+  const uint64_t h0 = fnv1a(src.data(), src.size(), base[0]);
+  const uint64_t h1 = fnv1a(src.data(), src.size(), h0 ^ 0x9e3779b97f4a7c15ull);  // (a second, dependent pass: 128 bits of name)
+  char buf[64];
+  snprintf(buf, sizeof buf, "/gfx950-%016llx%016llx.co", (unsigned long long)h0, (unsigned long long)h1);
+  return disk_dir() + buf;
+}
+bool disk_load(const std::string& path, std::string& bin) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  DiskHeader hd;
+  bool ok = fread(&hd, sizeof hd, 1, f) == 1 && memcmp(hd.magic, DISK_MAGIC, 8) == 0 && hd.size > 0 && hd.size < ((uint64_t)1 << 30);
+  if (ok) {
+    bin.assign((size_t)hd.size, '\0');
+    ok = fread(&bin[0], 1, bin.size(), f) == bin.size() && fnv1a(bin.data(), bin.size(), 0xcbf29ce484222325ull) == hd.sum;
+  }
+  fclose(f);
+  return ok;
+}
+void disk_store(const std::string& path, const std::string& bin) {
+  char tmp[32];
+  snprintf(tmp, sizeof tmp, ".tmp%ld", (long)getpid());
+  const std::string t = path + tmp;
+  FILE* f = fopen(t.c_str(), "wb");
+  if (!f) return;
+  DiskHeader hd;
+  memcpy(hd.magic, DISK_MAGIC, 8);
+  hd.size = bin.size(), hd.sum = fnv1a(bin.data(), bin.size(), 0xcbf29ce484222325ull);
+  const bool ok = fwrite(&hd, sizeof hd, 1, f) == 1 && fwrite(bin.data(), 1, bin.size(), f) == bin.size();
+  if (fclose(f) != 0 || !ok || rename(t.c_str(), path.c_str()) != 0) (void)remove(t.c_str());
+}
+}  // namespace
+
 bool jit_enabled(size_t num_vars) {
   static const int on = [] {
     const char* e = getenv("LH_EXPR_JIT");  // 0: always interpret
@@ -163,28 +249,39 @@ const JitKernel* jit_sc_round(const Ctx& c, const uint32_t* code, size_t num_ins
   k->failed = true;
   const auto t0 = std::chrono::steady_clock::now();
   const std::string src = generate(code, num_instrs, num_regs, result_reg, degree);
-  hiprtcProgram prog;
-  const char* hdr[] = {JIT_FF_CUH, JIT_REDUCE_CUH, JIT_FF_COLS_INC};
-  const char* names[] = {"ff.cuh", "reduce.cuh", "ff_cols.inc"};
-  if (hiprtcCreateProgram(&prog, src.c_str(), "sc_round_jit.hip", 3, hdr, names) != HIPRTC_SUCCESS) return nullptr;
-  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
-  const hiprtcResult r = hiprtcCompileProgram(prog, 3, opts);
-  if (r != HIPRTC_SUCCESS) {
-    size_t n = 0;
-    (void)hiprtcGetProgramLogSize(prog, &n);
-    std::string log(n + 1, '\0');
-    (void)hiprtcGetProgramLog(prog, &log[0]);
-    fprintf(stderr, "[lasso-hip] runtime compilation of a sum-check program failed (%s), interpreting it instead:\n%.2000s\n",
-            hiprtcGetErrorString(r), log.c_str());
-    (void)hiprtcDestroyProgram(&prog);
-    return nullptr;
+  std::string bin;
+  const std::string disk = disk_dir().empty() ? std::string() : disk_name(src);
+  bool from_disk = !disk.empty() && disk_load(disk, bin);
+  if (from_disk && hipModuleLoadData(&k->mod, bin.data()) != hipSuccess) {  // (unloadable: compile it again and overwrite)
+    (void)hipGetLastError();
+    k->mod = nullptr;
+    from_disk = false;
   }
-  size_t n = 0;
-  (void)hiprtcGetCodeSize(prog, &n);
-  std::string bin(n, '\0');
-  (void)hiprtcGetCode(prog, &bin[0]);
-  (void)hiprtcDestroyProgram(&prog);
-  if (hipModuleLoadData(&k->mod, bin.data()) != hipSuccess) return nullptr;
+  size_t n = bin.size();
+  if (!from_disk) {
+    hiprtcProgram prog;
+    const char* hdr[] = {JIT_FF_CUH, JIT_REDUCE_CUH, JIT_FF_COLS_INC};
+    const char* names[] = {"ff.cuh", "reduce.cuh", "ff_cols.inc"};
+    if (hiprtcCreateProgram(&prog, src.c_str(), "sc_round_jit.hip", 3, hdr, names) != HIPRTC_SUCCESS) return nullptr;
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+    const hiprtcResult r = hiprtcCompileProgram(prog, 3, opts);
+    if (r != HIPRTC_SUCCESS) {
+      size_t ln = 0;
+      (void)hiprtcGetProgramLogSize(prog, &ln);
+      std::string log(ln + 1, '\0');
+      (void)hiprtcGetProgramLog(prog, &log[0]);
+      fprintf(stderr, "[lasso-hip] runtime compilation of a sum-check program failed (%s), interpreting it instead:\n%.2000s\n",
+              hiprtcGetErrorString(r), log.c_str());
+      (void)hiprtcDestroyProgram(&prog);
+      return nullptr;
+    }
+    (void)hiprtcGetCodeSize(prog, &n);
+    bin.assign(n, '\0');
+    (void)hiprtcGetCode(prog, &bin[0]);
+    (void)hiprtcDestroyProgram(&prog);
+    if (hipModuleLoadData(&k->mod, bin.data()) != hipSuccess) return nullptr;
+    if (!disk.empty()) disk_store(disk, bin);
+  }
   if (hipModuleGetFunction(&k->fn, k->mod, "sc_round_jit") != hipSuccess) return nullptr;
   k->threads = 256u;
   k->degree = (unsigned)degree;
@@ -196,8 +293,8 @@ const JitKernel* jit_sc_round(const Ctx& c, const uint32_t* code, size_t num_ins
     int vgprs = 0, scratch = 0;
     (void)hipFuncGetAttribute(&vgprs, HIP_FUNC_ATTRIBUTE_NUM_REGS, k->fn);
     (void)hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, k->fn);
-    fprintf(stderr, "[expr] compiled a %zu-instruction program for degree %d in %.2f s (%zu B of code, %d registers, %d B scratch, %u workgroups per CU)\n",
-            num_instrs, degree, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), n, vgprs, scratch,
+    fprintf(stderr, "[expr] %s a %zu-instruction program for degree %d in %.2f s (%zu B of code, %d registers, %d B scratch, %u workgroups per CU)\n",
+            from_disk ? "loaded from the disk cache" : "compiled", num_instrs, degree, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), n, vgprs, scratch,
             k->blocks_per_cu);
   }
   return k;

@@ -279,6 +279,53 @@ def test_hyperplonk_two_phase_circuit_over_zeromorph(hl, ctx, num_vars):
         g_hp.HyperPlonk.verify(g_vp, instances, hl.Keccak256Transcript.from_proof(bytes(bad)))
 
 
+def test_jit_code_objects_are_kept_on_disk(tmp_path):
+    """csrc/jit.cpp: the runtime-compiled round kernels of a HyperPlonk proof are written to LH_JIT_CACHE_DIR and the next
+    process loads them instead of compiling (LH_HP_DEBUG says which); a torn file is ignored and rewritten; same bytes."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, random, hashlib
+        sys.path.insert(0, %r)
+        import halo2_lasso_amd as hl
+        from halo2_lasso_amd import synthetic
+        ctx = hl.Context(0)
+        k = 10
+        rng = random.Random(5)
+        pcs = hl.MultilinearKzg.setup(ctx, [rng.randrange(1, hl.R_MOD) for _ in range(k)])
+        circ = synthetic.vanilla_plonk_with_lookup(ctx, k, seed=3)
+        pp = synthetic.prover_param(pcs, circ)
+        t = hl.Keccak256Transcript()
+        from halo2_lasso_amd import hyperplonk as g_hp
+        g_hp.HyperPlonk.prove(pp, circ.instances, circ.d_witness, t)
+        print("PROOF", hashlib.sha256(t.into_proof()).hexdigest())
+    """) % root
+    cache = tmp_path / "jit"
+    env = dict(os.environ, LH_JIT_CACHE_DIR=str(cache), LH_EXPR_JIT_MIN_VARS="4", LH_HP_DEBUG="1")
+
+    def run():
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        proof = [ln for ln in r.stdout.splitlines() if ln.startswith("PROOF")][0]
+        return proof, r.stderr.count("[expr] compiled"), r.stderr.count("[expr] loaded from the disk cache")
+
+    p1, compiled1, loaded1 = run()
+    files = sorted(cache.glob("gfx950-*.co"))
+    assert compiled1 >= 1 and loaded1 == 0 and len(files) == compiled1, (compiled1, loaded1, files)
+    p2, compiled2, loaded2 = run()
+    assert p2 == p1 and compiled2 == 0 and loaded2 == compiled1
+    files[0].write_bytes(files[0].read_bytes()[:100])   # a torn file: compiled again, rewritten
+    p3, compiled3, loaded3 = run()
+    assert p3 == p1 and compiled3 == 1 and loaded3 == compiled1 - 1
+    assert files[0].stat().st_size > 100
+    env["LH_JIT_CACHE"] = "0"                           # switched off: compiles, reads and writes nothing
+    p4, compiled4, loaded4 = run()
+    assert p4 == p1 and compiled4 == compiled1 and loaded4 == 0
+
+
 # ------------------------------------------------------------------ Lasso as HyperPlonk's lookup argument
 @pytest.mark.parametrize("kind,c,l,num_vars", [("range", 2, 2, 4), ("and", 2, 4, 5), ("xor", 2, 4, 4), ("range", 2, 4, 4),
                                                ("and", 4, 4, 7)])
