@@ -508,19 +508,18 @@ __device__ __forceinline__ Fp<P> dot_scan(const Fp<P>* a, const Fp<P>* b) {
 #define LH_FF_COLS 1
 #endif
 #include "ff_cols.inc"
+// (the next column's first block writes `top` afresh - the carry of its first multiply-add - so it is not zeroed here)
 #define LH_COL_STEP_LO(k)                       \
   m[k] = (uint32_t)acc * P::INV;                \
   LH_MACS(m[k], P::mod(0));                     \
-  acc = (acc >> 32) | ((uint64_t)top << 32);    \
-  top = 0
+  acc = (acc >> 32) | ((uint64_t)top << 32)
 #define LH_COL_STEP_HI(k)                       \
   r[k - 8] = (uint32_t)acc;                     \
-  acc = (acc >> 32) | ((uint64_t)top << 32);    \
-  top = 0
+  acc = (acc >> 32) | ((uint64_t)top << 32)
 template <class P>
 __device__ __forceinline__ Fp<P> mul_scan_cols(const Fp<P>& a, const Fp<P>& b) {
-  uint64_t acc = 0;
-  uint32_t top = 0;
+  uint64_t acc;
+  uint32_t top;
   uint32_t m[8], r[8];
   LH_COL_MUL_0(a, b, m, P); LH_COL_STEP_LO(0);
   LH_COL_MUL_1(a, b, m, P); LH_COL_STEP_LO(1);
@@ -544,15 +543,16 @@ __device__ __forceinline__ Fp<P> mul_scan_cols(const Fp<P>& a, const Fp<P>& b) {
   return reduce_once(out);
 }
 #define LH_COL_DOT(k)                                       \
-  _Pragma("unroll") for (int j = 0; j < K; j++) {           \
+  LH_COL_VV0_##k(a[0], b[0]);                               \
+  _Pragma("unroll") for (int j = 1; j < K; j++) {           \
     LH_COL_VV_##k(a[j], b[j]);                              \
   }                                                         \
   LH_COL_VS_##k(m, P)
 template <class P, int K>
 __device__ __forceinline__ Fp<P> dot_scan_cols(const Fp<P>* a, const Fp<P>* b) {
   static_assert(K >= 1 && K <= 16, "dot_scan: the result must stay below 2^256");
-  uint64_t acc = 0;
-  uint32_t top = 0;
+  uint64_t acc;
+  uint32_t top;
   uint32_t m[8], r[8];
   LH_COL_DOT(0); LH_COL_STEP_LO(0);
   LH_COL_DOT(1); LH_COL_STEP_LO(1);
