@@ -264,8 +264,11 @@ __global__ __launch_bounds__(256) LH_E_WAVES_ATTR(LH_E_WAVES_E2) void sc_round_e
 // Loads first: the entries of a PAIR of terms (four tables, eight 32-byte entries per lane when binding) are requested
 // before anything is computed or stored - written table by table (load, bind, store, next table) the stores keep the
 // compiler from moving the next table's loads up, and a wave has one table's 4 KB in flight at a time.
+#ifndef LH_PP_WAVES
+#define LH_PP_WAVES 3  // (build-time A/B knob, tools/ab_pp_waves.sh: 4 fits 128 registers with 100 B of spills)
+#endif
 template <bool BIND>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void sc_round_pp_kernel(ScArgs a, size_t size, Fr* __restrict__ partials, ScFinish fin) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LH_PP_WAVES, 8))) void sc_round_pp_kernel(ScArgs a, size_t size, Fr* __restrict__ partials, ScFinish fin) {
   __shared__ Fr lds[4];
   const ScRound& rd = a.rd;
   Fr acc = Fr::zero();
