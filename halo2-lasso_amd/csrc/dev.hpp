@@ -689,6 +689,10 @@ struct MsmJob {
   uint32_t win_table_c = 0, win_table_W = 0;
 };
 constexpr uint32_t MSM_PACK_MAX_BITS = 20;
+// two columns share a pass only while the pass saved (one mixed addition per point) outweighs the bucket set it adds to the
+// reduction (2^bits buckets at ~3.5 full additions each): from 8 points per bucket on.  (The single-GPU sizes that pack are
+// far above it; a rank's shard of a level - 2^20 points against 2^20 buckets at 8 ranks - is not.)
+constexpr size_t MSM_PACK_MIN_POINTS_PER_BUCKET = 8;
 Ctx& ctx_helper(Ctx&);            // the ctx's helper ctx (created on first use, destroyed with the ctx)
 void open_precommit_cancel(Ctx&);  // waits for a running precommit and drops it (prover.cpp)
 uint32_t msm_window_bits(size_t n);  // window width msm_batch picks for a full-width (254-bit) column of n points

@@ -495,7 +495,8 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
       auto bits_of = [](uint32_t v) { return v ? 32u - (uint32_t)__builtin_clz(v) : 0u; };
       for (size_t j = 0; j < cc; j++) {
         const uint32_t b0 = std::max(bits_of(ors[j]), 4u), b1 = j + 1 < cc ? bits_of(ors[j + 1]) : 0;
-        if (ors[j] && j + 1 < cc && ors[j + 1] && b0 + b1 <= MSM_PACK_MAX_BITS) {
+        if (ors[j] && j + 1 < cc && ors[j + 1] && b0 + b1 <= MSM_PACK_MAX_BITS &&
+            N >= ((size_t)MSM_PACK_MIN_POINTS_PER_BUCKET << (b0 + b1))) {  // (worth it while the points outnumber the buckets)
           uint32_t* packed = c.arena.alloc_n<uint32_t>(N);
           k_pack_u32(c, rts[j], rts[j + 1], b0, N, packed);
           add_job(1 + cc + j, packed, true, N);

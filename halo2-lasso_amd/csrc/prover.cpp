@@ -1758,7 +1758,10 @@ static void column_jobs(Ctx& c, const Srs& srs, const std::vector<SmallPoly>& co
     for (size_t i = 0; i < narrow.size(); i++) {
       const Narrow& x = narrow[i];
       const uint32_t shift = std::max(x.bits, 4u);
-      if (i + 1 < narrow.size() && shift + narrow[i + 1].bits <= MSM_PACK_MAX_BITS) {
+      // (a packed pair saves one pass over `half` points and reduces a bucket set indexed by the packed value - ~5 curve
+      // additions' worth per bucket: on a rank's shard of a level the second can outweigh the first)
+      if (i + 1 < narrow.size() && shift + narrow[i + 1].bits <= MSM_PACK_MAX_BITS &&
+          half >= ((size_t)MSM_PACK_MIN_POINTS_PER_BUCKET << (shift + narrow[i + 1].bits))) {
         const Narrow& y = narrow[i + 1];
         uint32_t* packed = c.arena.alloc_n<uint32_t>(half);
         k_pack_u32(c, x.col, y.col, shift, half, packed);
