@@ -393,6 +393,61 @@ __global__ __launch_bounds__(128) void msm_accumulate_n_quad_kernel(const uint32
   }
 }
 
+// The same level as a TREE for the short lists at the end of the chain (quad-cooperative arithmetic): a workgroup owns a
+// tile of T consecutive slots, one quad of lanes per slot, and sums every run of equal keys inside the tile by doubling
+// (slot p adds slot p + d while that slot carries the same key: log2 T dependent additions whatever the run lengths,
+// where the linear levels need G - 1 additions to shrink a run G-fold).  The piece of a run that begins in the tile is
+// added into its bucket; a run that continues from the previous tile leaves its piece in the next level's list, one slot
+// per tile - a list shrinks T-fold per launch instead of 4-fold.
+template <int T>
+__global__ __launch_bounds__(4 * T) void msm_accumulate_tree_quad_kernel(const uint32_t* __restrict__ in_key,
+                                                                         const G1Xyzz* __restrict__ in_pt, size_t n_in,
+                                                                         G1Xyzz* __restrict__ buckets,
+                                                                         uint32_t* __restrict__ out_key,
+                                                                         G1Xyzz* __restrict__ out_pt,
+                                                                         const uint32_t* __restrict__ in_count,
+                                                                         uint32_t* __restrict__ out_count) {
+  if (*in_count == 0) return;
+  __shared__ G1Xyzz pts[T];
+  __shared__ uint32_t keys[T];
+  const int slot = (int)(threadIdx.x >> 2);
+  const bool lead = (threadIdx.x & 3u) == 0;
+  const size_t ntiles = (n_in + T - 1) / T;
+  for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const size_t p = tile * T + (size_t)slot;
+    const uint32_t k = p < n_in ? in_key[p] : SENTINEL;
+    const bool valid = k != SENTINEL;
+    const bool prev_same = valid && p > 0 && in_key[p - 1] == k;
+    G1Xyzz acc = valid ? in_pt[p] : G1Xyzz::identity();
+    __syncthreads();  // (the previous tile's reads of the arrays are over)
+    if (lead) keys[slot] = k, pts[slot] = acc;
+    __syncthreads();
+    for (int d = 1; d < T; d <<= 1) {
+      const bool take = valid && slot + d < T && keys[slot + d] == k;
+      G1Xyzz other = G1Xyzz::identity();
+      if (take) other = pts[slot + d];
+      __syncthreads();
+      if (take) {
+        acc = add_quad(acc, other);
+        if (lead) pts[slot] = acc;
+      }
+      __syncthreads();
+    }
+    if (valid && !prev_same) {  // the run begins here: its sum inside the tile joins the bucket
+      const G1Xyzz sum = add_quad(buckets[k], acc);
+      if (lead) buckets[k] = sum;
+    }
+    if (slot == 0 && lead) {
+      const bool cont = valid && prev_same;  // the tile opens inside a run that began earlier
+      out_key[tile] = cont ? k : SENTINEL;
+      if (cont) {
+        out_pt[tile] = acc;
+        atomicAdd(out_count, 1u);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ 5: bucket reduce
 __device__ __forceinline__ G1Xyzz mul_small(const G1Xyzz& p, uint32_t k) {
   G1Xyzz acc = G1Xyzz::identity();
@@ -549,16 +604,50 @@ static int env_int(const char* name, int dflt) {
 // accumulate thread (0: by batch size)
 static const int MSM_C_OFF = env_int("LH_MSM_C_OFF", 4), MSM_C_MAX = env_int("LH_MSM_C_MAX", 17),
                  MSM_K = env_int("LH_MSM_K", 0),
-                 MSM_QUAD_MAX = env_int("LH_MSM_QUAD_MAX", 262144),  // lists / segment counts up to which a quad of lanes
+                 MSM_QUAD_MAX = env_int("LH_MSM_QUAD_MAX", 262144);  // lists / segment counts up to which a quad of lanes
                                                                       // shares one curve addition (0: never)
-                 MSM_K2 = env_int("LH_MSM_K2", 4);  // continuation fan-in: a level costs ~K2 dependent additions, there are
-                                                    // log_K2(chunks) levels; swept 2..16, 3-4 is best (2^16: 10.1 -> 9.3 ms)
 
 int msm_slab_log() {
   // (2^23 while every slab was a library call of its own; the batched sort has no per-slab cost: 2^16, tools sweep in
   // profiles/README.md round 3)
   static const int v = env_int("LH_MSM_SLAB_LOG", 16);
   return v;
+}
+
+// the continuation levels of one list: linear levels (fan-in K2) while the list is long, tree levels at the end
+static void msm_continuation_levels(Ctx& c, const uint32_t* ckey, const G1Xyzz* cpt, size_t n_in, G1Xyzz* buckets,
+                                    uint32_t* cnt) {
+  static const int MSM_K2 = env_int("LH_MSM_K2", 4);  // continuation fan-in: a level costs ~K2 dependent additions, there
+                                                      // are log_K2(chunks) levels; swept 2..16, 3-4 is best (2^16: 10.1 -> 9.3 ms)
+  static const int TREE_MAX = env_int("LH_MSM_TREE_MAX", 262144);  // lists of up to this many slots go by trees (0: never; sweep: profiles/r04_ab_msm_tree.txt)
+  static const int TREE_T = env_int("LH_MSM_TREE_T", 64);          // slots per tile: 64 (256 threads) or 256 (1024 threads)
+  const uint32_t K2 = (uint32_t)MSM_K2;
+  int lvl = 0;
+  while (true) {
+    const bool tree = n_in <= (size_t)TREE_MAX;
+    const size_t fan = tree ? (size_t)(TREE_T == 256 ? 256 : 64) : (size_t)K2;
+    const size_t nc = (n_in + fan - 1) / fan;
+    uint32_t* okey = c.arena.alloc_n<uint32_t>(nc);
+    G1Xyzz* opt = c.arena.alloc_n<G1Xyzz>(nc);
+    if (tree && fan == 256)
+      hipLaunchKernelGGL((msm_accumulate_tree_quad_kernel<256>), dim3((unsigned)std::min<size_t>(nc, 1 << 16)), dim3(1024), 0,
+                         c.stream, ckey, cpt, n_in, buckets, okey, opt, cnt + lvl, cnt + lvl + 1);
+    else if (tree)
+      hipLaunchKernelGGL((msm_accumulate_tree_quad_kernel<64>), dim3((unsigned)std::min<size_t>(nc, 1 << 16)), dim3(256), 0,
+                         c.stream, ckey, cpt, n_in, buckets, okey, opt, cnt + lvl, cnt + lvl + 1);
+    else if (n_in <= (size_t)MSM_QUAD_MAX)  // far below one wave per SIMD: a quad of lanes per entry
+      hipLaunchKernelGGL(msm_accumulate_n_quad_kernel, dim3((unsigned)((4 * n_in + 127) / 128)), dim3(128), 0, c.stream,
+                         ckey, cpt, n_in, K2, buckets, okey, opt, cnt + lvl, cnt + lvl + 1);
+    else
+      hipLaunchKernelGGL(msm_accumulate_n_kernel, dim3((unsigned)std::min<size_t>((n_in + 127) / 128, 1 << 16)), dim3(128), 0,
+                         c.stream, ckey, cpt, n_in, K2, buckets, okey, opt, cnt + lvl, cnt + lvl + 1);
+    lvl++;
+    LH_REQUIRE(lvl < 30, LH_ERR_ARG, "msm: continuation list too long");
+    if (n_in <= fan) break;  // a single chunk / tile: no continuation can remain
+    ckey = okey;
+    cpt = opt;
+    n_in = nc;
+  }
 }
 
 static uint32_t pick_window(size_t n, uint32_t bits) {
@@ -893,28 +982,9 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
         hipLaunchKernelGGL(msm_accumulate0_kernel<Acc32>, dim3((unsigned)std::min<size_t>((nchunks - c1 + 127) / 128, 1 << 16)),
                            dim3(128), 0, c.stream, plan, max_entries, skey, sidx, K, buckets, ckey, cpt, c1, nchunks, lvl_cnt);
       }
-      size_t n_in = nchunks;
-      const uint32_t K2 = (uint32_t)MSM_K2;
       {
         ProfScope ps(c, "msm_accumulate_levels", 0, 0, (double)nchunks);
-      int lvl = 0;
-      while (true) {
-        size_t nc = (n_in + K2 - 1) / K2;
-        uint32_t* okey = c.arena.alloc_n<uint32_t>(nc);
-        G1Xyzz* opt = c.arena.alloc_n<G1Xyzz>(nc);
-        if (n_in <= (size_t)MSM_QUAD_MAX)  // far below one wave per SIMD: a quad of lanes per entry
-          hipLaunchKernelGGL(msm_accumulate_n_quad_kernel, dim3((unsigned)((4 * n_in + 127) / 128)), dim3(128), 0, c.stream,
-                             ckey, cpt, n_in, K2, buckets, okey, opt, lvl_cnt + lvl, lvl_cnt + lvl + 1);
-        else
-          hipLaunchKernelGGL(msm_accumulate_n_kernel, dim3((unsigned)std::min<size_t>((n_in + 127) / 128, 1 << 16)),
-                             dim3(128), 0, c.stream, ckey, cpt, n_in, K2, buckets, okey, opt, lvl_cnt + lvl,
-                             lvl_cnt + lvl + 1);
-        lvl++;
-        if (n_in <= K2) break;  // a single chunk: no continuation can remain
-        ckey = okey;
-        cpt = opt;
-        n_in = nc;
-      }
+        msm_continuation_levels(c, ckey, cpt, nchunks, buckets, lvl_cnt);
       }
       if (num_derived) {
         // derived jobs: (key, parent bucket) lists sorted by key, summed into the derived buckets by the same
@@ -938,25 +1008,7 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
                            c.stream, dd, buckets, dkey, dpt);
         uint32_t* dcnt = lvl_cnt + 32;
         LH_HIP(hipMemsetAsync(dcnt, 1, sizeof(uint32_t), c.stream));  // "something continued into level 0"
-        size_t n_in2 = nd;
-        int lvl = 0;
-        while (true) {
-          size_t nc = (n_in2 + K2 - 1) / K2;
-          uint32_t* okey = c.arena.alloc_n<uint32_t>(nc);
-          G1Xyzz* opt = c.arena.alloc_n<G1Xyzz>(nc);
-          if (n_in2 <= (size_t)MSM_QUAD_MAX)
-            hipLaunchKernelGGL(msm_accumulate_n_quad_kernel, dim3((unsigned)((4 * n_in2 + 127) / 128)), dim3(128), 0, c.stream,
-                               dkey, dpt, n_in2, K2, buckets, okey, opt, dcnt + lvl, dcnt + lvl + 1);
-          else
-            hipLaunchKernelGGL(msm_accumulate_n_kernel, dim3((unsigned)std::min<size_t>((n_in2 + 127) / 128, 1 << 16)),
-                               dim3(128), 0, c.stream, dkey, dpt, n_in2, K2, buckets, okey, opt, dcnt + lvl, dcnt + lvl + 1);
-          lvl++;
-          LH_REQUIRE(lvl < 30, LH_ERR_ARG, "msm: derived list too long");
-          if (n_in2 <= K2) break;
-          dkey = okey;
-          dpt = opt;
-          n_in2 = nc;
-        }
+        msm_continuation_levels(c, dkey, dpt, nd, buckets, dcnt);
       }
       {
         ProfScope ps(c, "msm_bucket_reduce", 128.0 * nbuckets, 14.0 * 2.2 * nbuckets, (double)nbuckets);
