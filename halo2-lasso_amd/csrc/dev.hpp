@@ -495,7 +495,8 @@ struct ScRwRound {
   Fr rchal;
   uint32_t num_pairs;
 };
-void k_sc_round_rw(Ctx&, const ScRwRound& rd, bool bind, size_t size, Fr* out_host);
+// fold (BIND rounds): store l' = cs (l + k), r' = r + k instead of the bound l, r - the later rounds are ScRound::pp ones
+void k_sc_round_rw(Ctx&, const ScRwRound& rd, bool bind, size_t size, Fr* out_host, bool fold = false);
 
 // Resident tail: once the live tables of a sum-check fit the LDS of a few CUs, ONE launch runs all remaining rounds.
 // G workgroups each keep a contiguous slice of every table in LDS (binding never crosses a slice); per round every

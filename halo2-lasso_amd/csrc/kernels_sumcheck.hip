@@ -920,7 +920,12 @@ void k_sc_round_open(Ctx& c, const ScOpenRound& rd, bool bind, size_t size, Fr* 
 }
 
 // ------------------------------------------------------------------ grand-product layer over (A, A + 1) tree pairs
-template <int P, bool BIND>
+// FOLD (a BIND round): what is stored is l'_p = cs_p (l_p + k_p) and r'_p = r_p + k_p (binding is affine: the bound
+// tables of l', r' ARE the folded bound tables), so that every later round is the plain product-pair shape sum_p l'_p r'_p
+// and runs sc_round_pp_kernel (prover.cpp divides cs out of, and takes k off, the final evaluations).  Either way the P
+// products of a lane share one Montgomery reduction (ff.cuh dot): 2 P -> P + ~0.6 P products (fold round: the P
+// multiplications by cs are the fold itself).
+template <int P, bool BIND, bool FOLD>
 __global__ __launch_bounds__(256) LH_E_WAVES_ATTR(LH_E_WAVES_RW) void sc_round_rw_kernel(ScRwRound rd, size_t size, Fr* __restrict__ partials, ScFinish fin) {
   // one lane per bound entry (see sc_round_e2_kernel): odd lanes evaluate X = 1, even lanes X = 2
   __shared__ Fr lds[4];
@@ -928,14 +933,21 @@ __global__ __launch_bounds__(256) LH_E_WAVES_ATTR(LH_E_WAVES_RW) void sc_round_r
   const size_t items = 2 * size;
   const bool odd = threadIdx.x & 1;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < items; i += (size_t)gridDim.x * blockDim.x) {
-    Fr s = Fr::zero();
+    Fr av[P], bv[P];
 #pragma unroll
     for (int p = 0; p < P; p++) {
-      const Fr a = add(at_lane_point(load_entry<BIND>(rd.l[p], rd.lo[p], i, rd.rchal, true), odd), rd.k[p]);
-      const Fr b = add(at_lane_point(load_entry<BIND>(rd.r[p], rd.ro[p], i, rd.rchal, true), odd), rd.k[p]);
-      s = add(s, mul(mul(a, b), rd.cs[p]));
+      if (BIND && FOLD) {
+        const Fr lf = mul(add(load_entry<true>(rd.l[p], rd.lo[p], i, rd.rchal, false), rd.k[p]), rd.cs[p]);
+        const Fr rf = add(load_entry<true>(rd.r[p], rd.ro[p], i, rd.rchal, false), rd.k[p]);
+        rd.lo[p][i] = lf, rd.ro[p][i] = rf;
+        av[p] = at_lane_point(lf, odd), bv[p] = at_lane_point(rf, odd);  // (the lane point of an affine image is the image)
+      } else {
+        const Fr a = add(at_lane_point(load_entry<BIND>(rd.l[p], rd.lo[p], i, rd.rchal, true), odd), rd.k[p]);
+        av[p] = mul(a, rd.cs[p]);
+        bv[p] = add(at_lane_point(load_entry<BIND>(rd.r[p], rd.ro[p], i, rd.rchal, true), odd), rd.k[p]);
+      }
     }
-    acc = add(acc, mul(s, rd.eq_level[i >> 1]));
+    acc = add(acc, mul(dot<FrParams, P>(av, bv), rd.eq_level[i >> 1]));
   }
   Fr q2, q1;
   reduce_by_parity(acc, odd, lds, q2, q1);
@@ -951,14 +963,17 @@ __global__ __launch_bounds__(256) LH_E_WAVES_ATTR(LH_E_WAVES_RW) void sc_round_r
 }
 
 template <int P>
-static void launch_rw(Ctx& c, const ScRwRound& rd, bool bind, size_t size, unsigned g, Fr* partials, const ScFinish& fin) {
-  if (bind)
-    hipLaunchKernelGGL((sc_round_rw_kernel<P, true>), dim3(g), dim3(256), 0, c.stream, rd, size, partials, fin);
+static void launch_rw(Ctx& c, const ScRwRound& rd, bool bind, bool fold, size_t size, unsigned g, Fr* partials, const ScFinish& fin) {
+  if (bind && fold)
+    hipLaunchKernelGGL((sc_round_rw_kernel<P, true, true>), dim3(g), dim3(256), 0, c.stream, rd, size, partials, fin);
+  else if (bind)
+    hipLaunchKernelGGL((sc_round_rw_kernel<P, true, false>), dim3(g), dim3(256), 0, c.stream, rd, size, partials, fin);
   else
-    hipLaunchKernelGGL((sc_round_rw_kernel<P, false>), dim3(g), dim3(256), 0, c.stream, rd, size, partials, fin);
+    hipLaunchKernelGGL((sc_round_rw_kernel<P, false, false>), dim3(g), dim3(256), 0, c.stream, rd, size, partials, fin);
 }
 
-void k_sc_round_rw(Ctx& c, const ScRwRound& rd, bool bind, size_t size, Fr* out_host) {
+void k_sc_round_rw(Ctx& c, const ScRwRound& rd, bool bind, size_t size, Fr* out_host, bool fold) {
+  LH_REQUIRE(!fold || bind, LH_ERR_ARG, "sc_round_rw: folding is part of a binding round");
   LH_REQUIRE(rd.num_pairs >= 1 && rd.num_pairs <= (uint32_t)SC_RW_MAX_PAIRS && size >= 1 && rd.eq_level, LH_ERR_ARG,
              "sc_round_rw: bad shape");
   const uint32_t seq = c.next_seq();
@@ -974,14 +989,14 @@ void k_sc_round_rw(Ctx& c, const ScRwRound& rd, bool bind, size_t size, Fr* out_
     ProfScope ps(c, bind ? "sc_round_rw<bind>" : "sc_round_rw<first>", ((bind ? 192.0 : 64.0) * 2.0 * P + 32.0) * (double)size,
                  ((bind ? 8.0 : 4.0) * P + 2.0) * (double)size, (double)size);
     switch (rd.num_pairs) {
-      case 1: launch_rw<1>(c, rd, bind, size, (unsigned)g, partials, fin); break;
-      case 2: launch_rw<2>(c, rd, bind, size, (unsigned)g, partials, fin); break;
-      case 3: launch_rw<3>(c, rd, bind, size, (unsigned)g, partials, fin); break;
-      case 4: launch_rw<4>(c, rd, bind, size, (unsigned)g, partials, fin); break;
-      case 5: launch_rw<5>(c, rd, bind, size, (unsigned)g, partials, fin); break;
-      case 6: launch_rw<6>(c, rd, bind, size, (unsigned)g, partials, fin); break;
-      case 7: launch_rw<7>(c, rd, bind, size, (unsigned)g, partials, fin); break;
-      default: launch_rw<8>(c, rd, bind, size, (unsigned)g, partials, fin); break;
+      case 1: launch_rw<1>(c, rd, bind, fold, size, (unsigned)g, partials, fin); break;
+      case 2: launch_rw<2>(c, rd, bind, fold, size, (unsigned)g, partials, fin); break;
+      case 3: launch_rw<3>(c, rd, bind, fold, size, (unsigned)g, partials, fin); break;
+      case 4: launch_rw<4>(c, rd, bind, fold, size, (unsigned)g, partials, fin); break;
+      case 5: launch_rw<5>(c, rd, bind, fold, size, (unsigned)g, partials, fin); break;
+      case 6: launch_rw<6>(c, rd, bind, fold, size, (unsigned)g, partials, fin); break;
+      case 7: launch_rw<7>(c, rd, bind, fold, size, (unsigned)g, partials, fin); break;
+      default: launch_rw<8>(c, rd, bind, fold, size, (unsigned)g, partials, fin); break;
     }
   }
   c.wait_round(seq);

@@ -939,6 +939,7 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
     }
   }
   std::vector<HFr> pp_folded;  // the coefficients that went into the left factors (empty: not folded)
+  bool rw_folded = false;      // tree-pair rounds (ScRwPairs): the tables hold l' = cs (l + k), r' = r + k since the first bind
   if (use_ef) {
     const Shard shg(c);
     const size_t half = (size_t)1 << (nvl - 1);
@@ -977,7 +978,24 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
           Fr* lvl = (Fr*)one.level[round];
           k_eq_levels(c, one.level[round - 1], 2 * size, &lvl, 1);
         }
-      if (!ef.per_term && rw && points == 2) {
+      if (!ef.per_term && rw && rw_folded) {
+        // the tables hold l' = cs (l + k), r' = r + k since the fold round: sum_p l'_p r'_p, the product-pair shape
+        LH_REQUIRE(points == 2, LH_ERR_ARG, "sum-check: tree-pair rounds asked for an extra point after the fold");
+        ScRound g;
+        memset(&g, 0, sizeof(g));
+        g.num_tables = 2 * rw->num_pairs, g.num_terms = rw->num_pairs;
+        for (size_t i = 0; i < 2 * (size_t)rw->num_pairs; i++) g.in[i] = in[i], g.out[i] = out[i];
+        for (uint32_t m = 0; m < rw->num_pairs; m++) {
+          g.coeff[m] = dev(HFr::one()), g.coeff_is_one[m] = 1;
+          g.nfac[m] = 2, g.fac[m][0] = (uint8_t)(2 * m), g.fac[m][1] = (uint8_t)(2 * m + 1);
+        }
+        g.r = r;
+        g.global_eq = -1;
+        g.eq_level = ef.eqs[0].level[round];
+        g.pp = 1;
+        k_sc_round(c, g, points, bind, size, out_host);
+        ef.add_const = rw->const_total;
+      } else if (!ef.per_term && rw && points == 2) {
         ScRwRound g;
         memset(&g, 0, sizeof(g));
         g.num_pairs = rw->num_pairs;
@@ -988,7 +1006,21 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
         }
         g.eq_level = ef.eqs[0].level[round];
         g.rchal = r;
-        k_sc_round_rw(c, g, bind, size, out_host);
+        const bool fold = bind && c.opt.sc_pp_fold != 0;  // the first binding round folds cs and k into the tables
+        k_sc_round_rw(c, g, bind, size, out_host, fold);
+        if (fold) {
+          rw_folded = true;
+          c.route.v[RouteStats::PP_FOLDS]++;
+          // the expression over the tables as they are now, for whoever evaluates it in its general form from here on (the
+          // launched small rounds, the generic resident tail): sum_p l'_p r'_p + const_total
+          const uint32_t P = rw->num_pairs;
+          rd.num_terms = P + 1;
+          for (uint32_t m = 0; m < P; m++) {
+            rd.coeff[m] = dev(HFr::one()), rd.coeff_is_one[m] = 1;
+            rd.nfac[m] = 2, rd.fac[m][0] = (uint8_t)(2 * m), rd.fac[m][1] = (uint8_t)(2 * m + 1);
+          }
+          rd.coeff[P] = dev(rw->const_total), rd.coeff_is_one[P] = 0, rd.nfac[P] = 0;
+        }
         c.route.v[RouteStats::RW_ROUNDS]++;
         ef.add_const = rw->const_total;  // added to q(1), q(2) by the round loop (the suffix eq sums to one - over all ranks)
       } else if (!ef.per_term) {
@@ -1029,12 +1061,13 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
       GkrLayerDev L;
       memset(&L, 0, sizeof(L));
       L.B = (uint32_t)Bt;
-      L.flags = GKR_F_SPLIT | GKR_F_NOMSG | GKR_F_EQ | (bind ? GKR_F_BIND : 0) | (rw ? GKR_F_KOFF : 0);
+      L.flags = GKR_F_SPLIT | GKR_F_NOMSG | GKR_F_EQ | (bind ? GKR_F_BIND : 0) | (rw && !rw_folded ? GKR_F_KOFF : 0);
       std::vector<size_t> li(Bt), ri(Bt);
       std::vector<HFr> co(Bt), ko(Bt, HFr::zero());
       for (size_t m = 0; m < Bt; m++) {
         li[m] = rw ? 2 * m : rd.fac[m][0], ri[m] = rw ? 2 * m + 1 : rd.fac[m][1];
-        if (rw) co[m] = rw->cs[m], ko[m] = rw->k[m];
+        if (rw && rw_folded) co[m] = HFr::one();  // (l', r' as they are: the end of sum_check_prove_impl unfolds)
+        else if (rw) co[m] = rw->cs[m], ko[m] = rw->k[m];
         else memcpy(&co[m], &rd.coeff[m], 32);
         if (co[m].is_zero()) return false;
         L.lv[m] = cur_t[li[m]], L.rv[m] = cur_t[ri[m]];
@@ -1076,6 +1109,19 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
   }
   SumCheckResult res = sum_check_loop(c, prover_kind, num_vars, degree, cur, used, num_polys, sum, tr, sharded, round_fn, &rd,
                                       use_ef ? &ef : nullptr);
+  if (rw_folded) {
+    // l' = cs (l + k), r' = r + k came out: l = l' / cs - k, r = r' - k (one inversion for the coefficients)
+    const size_t K = rw->num_pairs;
+    std::vector<HFr> pre(K + 1);
+    pre[0] = HFr::one();
+    for (size_t m = 0; m < K; m++) pre[m + 1] = pre[m] * rw->cs[m];
+    HFr inv = pre[K].inv();
+    for (size_t m = K; m-- > 0;) {
+      res.evals[2 * m] = res.evals[2 * m] * (inv * pre[m]) - rw->k[m];
+      res.evals[2 * m + 1] = res.evals[2 * m + 1] - rw->k[m];
+      inv = inv * rw->cs[m];
+    }
+  }
   if (!pp_folded.empty()) {
     // the left factors came out times their coefficients: one inversion for all of them
     const size_t K = pp_folded.size();
