@@ -279,10 +279,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LH_PP_WAVES
   const Fr rch = rd.r;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < items; i += (size_t)gridDim.x * blockDim.x) {
     Fr s = Fr::zero();
-    for (uint32_t m0 = 0; m0 < K; m0 += 4) {
-      Fr av[4], bv[4];
+#ifndef LH_PP_GROUP
+#define LH_PP_GROUP 4  // terms per shared reduction (build-time A/B knob: 2 = a reduction per pair of terms, fewer registers)
+#endif
+    for (uint32_t m0 = 0; m0 < K; m0 += LH_PP_GROUP) {
+      Fr av[LH_PP_GROUP], bv[LH_PP_GROUP];
 #pragma unroll
-      for (int h2 = 0; h2 < 2; h2++) {
+      for (int h2 = 0; h2 < LH_PP_GROUP / 2; h2++) {
         // the four tables of terms m0 + 2 h2, m0 + 2 h2 + 1 (a term past the end reads term 0's tables again, unused)
         const uint32_t ma = m0 + 2 * h2, mb = ma + 1;
         const bool va = ma < K, vb = mb < K;
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LH_PP_WAVES
         av[2 * h2 + 1] = vb ? at_lane_point(x2, odd) : Fr::zero();
         bv[2 * h2 + 1] = vb ? at_lane_point(x3, odd) : Fr::zero();
       }
-      s = add(s, dot<FrParams, 4>(av, bv));
+      s = add(s, dot<FrParams, LH_PP_GROUP>(av, bv));
     }
     acc = add(acc, mul(s, rd.eq_level[i >> 1]));
   }
