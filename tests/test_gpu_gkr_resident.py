@@ -161,3 +161,37 @@ def test_a_launch_that_cannot_start_all_its_workgroups_falls_back(hl):
     env = dict(os.environ, LH_GKR_START_TIMEOUT_MS="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "FALLBACK-OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_folded_layers_give_the_same_bytes_on_every_path(hl, ctx):
+    """Coefficient folding (option sc_pp_fold): the generic layers store c_m l_m at their first bind, the leaf layers of the
+    lookup-sized trees store cs (l + k) and r + k and go on as product-pair rounds - with the resident kernel finishing
+    the layers, with the launched small rounds and the generic tail finishing them (gkr_resident = 0: they evaluate the
+    REWRITTEN general expression over the folded tables), and not folding at all: one proof, the oracle's."""
+    n, nv = 18, 18
+    rng = random.Random(18)
+    ss = [rng.randrange(1, P) for _ in range(nv)]
+    table = hl.LassoTable.bitwise(hl.SUBTABLE_XOR, 4, 16)
+    dims = [np.random.default_rng(180 + j).integers(0, 1 << 16, size=1 << n, dtype=np.uint32) for j in range(4)]
+    pp = hl.MultilinearKzg.setup(ctx, ss)
+    bufs = [ctx.upload(d.tobytes()) for d in dims]
+    ot = co.Transcript()
+    co.lasso_prove(ot, pp.eqs_bytes(), nv, table.to_c(), n, [d.tobytes() for d in dims])
+    want = ot.into_proof()
+    seen = {}
+    for fold, resident in ((1, 1), (1, 0), (0, 1), (0, 0)):
+        hl.set_option(ctx, "sc_pp_fold", fold)
+        hl.set_option(ctx, "gkr_resident", resident)
+        try:
+            tr = hl.Keccak256Transcript()
+            hl.lasso_prove(pp, table, n, bufs, tr)
+            seen[(fold, resident)] = (tr.into_proof(), hl.lasso_last_route(ctx))
+        finally:
+            hl.set_option(ctx, "sc_pp_fold", 1)
+            hl.set_option(ctx, "gkr_resident", 1)
+    for key, (proof, route) in seen.items():
+        assert proof == want, key
+        assert (route["pp_folds"] > 0) == (key[0] == 1), (key, route)
+        assert route["rw_leaf_rounds"] > 0, (key, route)
+    # with folding the leaf layers run the leaf kernel twice (first round, folding round), without it in every streaming round
+    assert seen[(1, 1)][1]["rw_leaf_rounds"] < seen[(0, 1)][1]["rw_leaf_rounds"]
