@@ -111,7 +111,8 @@ struct Options {
                                        // full-width columns over them reduce ONE bucket set (0: no tables)
   int64_t sc_pp_fold = 1;              // 0: the generic layers of the grand products keep their coefficients as products of
                                        // every round (sc_round_e2) instead of folding them into the left factors and sharing
-                                       // Montgomery reductions (sc_round_pp)
+                                       // Montgomery reductions (sc_round_pp); the leaf layers (ScRwRound) keep cs and k
+                                       // outside their tables and run the leaf kernel in every streaming round
   int64_t msm_limbs29 = 0;             // 1: MSM batches over registered bases (an SRS) accumulate in the 9 x 29-bit lazy-carry
                                        // form of the base field (ec29.cuh: x1.25 on products, x1.15 on the mixed addition's
                                        // arithmetic in isolation - and 0.95x inside the accumulation kernel, whose gathers pay

@@ -273,7 +273,9 @@ lh_status lh_lasso_last_timing(lh_ctx*, double* out_ms);
  *                             tail each).  Needs sc_tail and sc_eq_factoring
  *   sc_pp_fold           1    sum-checks of the shape eq * sum_m c_m l_m r_m (the generic layers of the grand products):
  *                             the streaming rounds share one Montgomery reduction among four products and the first
- *                             binding round folds c_m into l_m (sc_round_pp_kernel); 0: sc_round_e2_kernel as before
+ *                             binding round folds c_m into l_m (sc_round_pp_kernel); the leaf layers of the lookup-sized
+ *                             trees, sum_p cs_p (l_p + k_p)(r_p + k_p), store cs_p (l_p + k_p) and r_p + k_p at their first
+ *                             bind and go on as such rounds; 0: sc_round_e2_kernel / sc_round_rw_kernel in every round
  *   msm_limbs29          0    1: MSM batches whose bases all belong to an SRS accumulate their buckets in the 9 x 29-bit
  *                             lazy-carry form of the base field (a twin of the SRS in that form is made on first use):
  *                             ~205 instead of ~310 instructions per Montgomery product, x1.15 on the mixed addition's
