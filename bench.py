@@ -213,10 +213,13 @@ def cpu_baseline(hl, ctx, pp, table, kind, args, gpu_proof_fn):
 # The integer-ALU ceiling of the field arithmetic (csrc/ff.cuh).  Rounds 1-3 priced it as "v_mad_u64_u32 at a quarter of the
 # VALU rate": measured in round 4 (tools/ubench/mul_fp64.hip, profiles/r04_ubench_mul_fp64.txt), EVERY VALU instruction of a
 # wave64 costs ~4.4-4.9 SIMD cycles here - v_mad_u64_u32 4.9, v_addc_co_u32 4.35 - so a Montgomery product is priced by its
-# instruction count: 129 multiply-adds + 128 add-with-carry + ~50 moves = ~307 instructions.  At the 4-cycle issue cost of a
-# wave64 instruction (one wave per SIMD in flight per issue, MI355X_MICROARCH.md) that is 1228 cycles per wave-product =
-# 256 CUs x 4 SIMDs x 2.4 GHz x 64 lanes / 1228 = 128 G products/s; the measured chains reach 119-131.
-INSTR_PER_FR_MUL = 307
+# instruction count: 129 multiply-adds + 128 add-with-carry + ~50 moves = ~307 instructions until the asm blocks went from one
+# per multiply-add to one per column (csrc/ff_cols.inc); since then 129 + 128 + 15 moves + 8 quotient digits + the 16 of the
+# conditional subtraction = ~296 (the 16 hazard nops that remain are not vector instructions).  At the 4-cycle issue cost of a
+# wave64 instruction (one wave per SIMD in flight per issue, MI355X_MICROARCH.md) that is 1184 cycles per wave-product =
+# 256 CUs x 4 SIMDs x 2.4 GHz x 64 lanes / 1184 = 133 G products/s; the measured chains reach 125-137 (a few instructions -
+# moves, selects - seem to issue in less than four cycles: the model is a ceiling of the model, not of the chip).
+INSTR_PER_FR_MUL = 296
 FR_MUL_CEILING_PER_S = 256 * 4 * 2.4e9 * 64 / (INSTR_PER_FR_MUL * 4)
 
 
@@ -256,10 +259,12 @@ def roofline_objects(hl, ctx, aggs, traffic=(None, None)):
            "peak_source": "measured (lh_fr_mul_chain: two independent product chains per thread, 256 products per "
                           "element)",
            "ceiling": round(ceiling / 1e9, 1), "frac_of_ceiling": round(mul_rate / ceiling, 4),
-           "ceiling_derivation": "instruction issue: ~307 VALU instructions per Montgomery product (129 v_mad_u64_u32 + 128 "
-                                 "v_addc_co_u32 + ~50), 4 SIMD cycles per wave64 instruction: 256 CU x 4 SIMD x 2.4 GHz x 64 / "
-                                 "1228 cycles (measured issue costs: profiles/r04_ubench_mul_fp64.txt); `achieved` counts a mixed "
-                                 "addition as 10 products, of which the two of Y3 share a reduction since round 4"}
+           "ceiling_derivation": "instruction issue: ~296 VALU instructions per Montgomery product (129 v_mad_u64_u32 + 128 "
+                                 "v_addc_co_u32 + 15 moves + 8 quotient digits + 16 for the conditional subtraction), 4 SIMD "
+                                 "cycles per wave64 instruction: 256 CU x 4 SIMD x 2.4 GHz x 64 / 1184 cycles (measured issue "
+                                 "costs: profiles/r04_ubench_mul_fp64.txt; the measured chain can sit a few percent above this "
+                                 "model); `achieved` counts a mixed addition as 10 products, of which the two of Y3 share a "
+                                 "reduction since round 4"}
     kernels = [{"name": a["name"], "launches": a["launches"], "ms": round(a["ms"], 3),
                 "GBps_all": round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1) if a["ms"] > 0 else 0.0,
                 "GBps_largest": round(a["big"]["bytes"] / (a["big"]["ms"] * 1e-3) / 1e9, 1) if a["big"]["ms"] > 0 else 0.0}
