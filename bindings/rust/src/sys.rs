@@ -276,6 +276,9 @@ extern "C" {
     pub fn lh_hyperplonk_verify_phases_zeromorph(vp: *const core::ffi::c_void, hvp: *const lh_hp_vparam, num_phases: usize,
                                                  num_witness_polys: *const usize, num_challenges: *const usize,
                                                  instances: *const *const Fr, t: *mut lh_transcript) -> lh_status;
+    // (development) the source text of a runtime-compiled round kernel
+    pub fn lh_debug_jit_source(code: *const u32, num_instrs: usize, num_regs: u32, result_reg: u32, degree: i32,
+                               out: *mut core::ffi::c_char, cap: usize, len: *mut usize) -> lh_status;
     // Zeromorph over univariate KZG: lh_ukzg_setup, lh_usrs_*, lh_zeromorph_* follow the same shapes
     // (include/lasso_hip.h, section f3) and are bound the same way when HyperPlonk<Zeromorph<..>> is wanted.
 }

@@ -249,6 +249,8 @@ SIGNATURES = {
                                                        C.POINTER(lh_hp_circuit), C.POINTER(lh_transcript)]),
     "lh_hyperplonk_verify_phases_zeromorph": (C.c_int, [_P, C.POINTER(lh_hp_vparam), _SZ, C.POINTER(_SZ), C.POINTER(_SZ),
                                                         C.POINTER(C.POINTER(lh_fr)), C.POINTER(lh_transcript)]),
+    "lh_debug_jit_source": (C.c_int, [C.POINTER(C.c_uint32), _SZ, C.c_uint32, C.c_uint32, C.c_int, C.c_char_p, _SZ,
+                                      C.POINTER(_SZ)]),
     "lh_profile_enable": (C.c_int, [_P, C.c_int]),
     "lh_profile_read": (C.c_int, [_P, C.POINTER(lh_prof_rec), _SZ, C.POINTER(_SZ)]),
 }

@@ -993,6 +993,22 @@ lh_status lh_hyperplonk_verify_phases_zeromorph(const lh_zm_vp* vp, const lh_hp_
   LH_CATCH
 }
 
+lh_status lh_debug_jit_source(const uint32_t* code, size_t num_instrs, uint32_t num_regs, uint32_t result_reg, int degree,
+                              char* out, size_t cap, size_t* len) {
+  LH_TRY
+  NEED(code);
+  NEED(len);
+  LH_REQUIRE(num_regs >= 1 && num_regs <= 16 && result_reg < num_regs && degree >= 1, LH_ERR_ARG, "jit source: bad program header");
+  const std::string src = lh::jit_debug_source(code, num_instrs, num_regs, result_reg, degree);
+  *len = src.size();
+  if (out && cap) {
+    const size_t n = std::min(cap - 1, src.size());
+    memcpy(out, src.data(), n);
+    out[n] = 0;
+  }
+  LH_CATCH
+}
+
 lh_status lh_profile_enable(lh_ctx* ctx, int on) {
   LH_TRY NEED_CTX(ctx);
   ctx->c.sync();

@@ -595,6 +595,8 @@ struct ProgRound {
 // runtime-compiled form of a program (jit.cpp); nullptr = not compiled (disabled, too small, or compilation failed)
 struct JitKernel;
 bool jit_enabled(size_t num_vars);
+// development / tests: the source the runtime compiler would be given (host code only)
+std::string jit_debug_source(const uint32_t* code, size_t num_instrs, uint32_t num_regs, uint32_t result_reg, int degree);
 const JitKernel* jit_sc_round(const Ctx&, const uint32_t* host_code, size_t num_instrs, uint32_t num_regs, uint32_t result_reg, int degree);
 unsigned jit_blocks_per_cu(const JitKernel*);
 void jit_launch(Ctx&, const JitKernel*, const ProgRound& pr, unsigned grid, size_t size, Fr* partials, const ScFinishArgs& fin);

@@ -16,6 +16,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <sstream>
@@ -89,21 +90,110 @@ std::string generate(const uint32_t* code, size_t num_instrs, uint32_t num_regs,
     loaded[idx] = true;
     s << "      const Fr t" << idx << " = at_x(a.in[" << idx << "], b, wave);\n";
   };
+  // Sums of products share Montgomery reductions (ff.cuh dot: K x 64 + 65 multiply-adds instead of K x 129): a product is
+  // not emitted where the program has it but kept PENDING in its destination register - as long as additions and
+  // subtractions only combine pending registers the terms pile up (up to JIT_DOT_MAX per reduction), and the register is
+  // materialised (one product, or one dot) when something else reads it, when one of the terms' operand registers is about
+  // to be overwritten, or at the end.  LH_EXPR_JIT_DOT=0: every product where it stands.
+  static const bool fuse = !(getenv("LH_EXPR_JIT_DOT") && atoi(getenv("LH_EXPR_JIT_DOT")) == 0);
+  constexpr size_t JIT_DOT_MAX = 4;
+  struct Term {
+    bool neg;
+    uint32_t ak, ai, bk, bi;
+  };
+  std::vector<std::vector<Term>> pending(16);
+  auto reads = [](const Term& t, uint32_t reg) { return (t.ak == PROG_REG && t.ai == reg) || (t.bk == PROG_REG && t.bi == reg); };
+  // Materialising a register WRITES its variable: every other register whose terms still name that variable's old value
+  // goes first.  The value itself is computed into a temporary before that (two registers may name each other's old
+  // values: each needs the other's variable untouched while it is computed).
+  std::function<void(uint32_t)> flush;
+  size_t num_tmp = 0;
+  auto before_write = [&](uint32_t reg) {
+    for (uint32_t q = 0; q < 16; q++) {
+      if (q == reg) continue;
+      for (const Term& t : pending[q])
+        if (reads(t, reg)) {
+          flush(q);
+          break;
+        }
+    }
+  };
+  flush = [&](uint32_t reg) {
+    if (pending[reg].empty()) return;
+    const std::vector<Term> ts = pending[reg];
+    pending[reg].clear();
+    const size_t K = ts.size(), id = num_tmp++;
+    if (K == 1) {
+      const Term& t = ts[0];
+      s << "      const Fr f" << id << " = " << (t.neg ? "sub(Fr::zero(), " : "") << "mul(" << operand(t.ak, t.ai) << ", "
+        << operand(t.bk, t.bi) << ")" << (t.neg ? ")" : "") << ";\n";
+    } else {
+      s << "      Fr f" << id << ";\n      {\n        const Fr xa[" << K << "] = {";
+      for (size_t k = 0; k < K; k++)
+        s << (k ? ", " : "") << (ts[k].neg ? "sub(Fr::zero(), " : "") << operand(ts[k].ak, ts[k].ai) << (ts[k].neg ? ")" : "");
+      s << "};\n        const Fr xb[" << K << "] = {";
+      for (size_t k = 0; k < K; k++) s << (k ? ", " : "") << operand(ts[k].bk, ts[k].bi);
+      s << "};\n        f" << id << " = dot<FrParams, " << K << ">(xa, xb);\n      }\n";
+    }
+    before_write(reg);
+    s << "      r" << reg << " = f" << id << ";\n";
+  };
+  auto is_pending = [&](uint32_t kind, uint32_t idx) { return kind == PROG_REG && !pending[idx].empty(); };
+  auto value_of = [&](uint32_t kind, uint32_t idx) {  // an operand read as a VALUE
+    if (is_pending(kind, idx)) flush(idx);
+  };
   for (size_t i = 0; i < num_instrs; i++) {
     const uint32_t w0 = code[2 * i], w1 = code[2 * i + 1];
     const uint32_t op = w0 & 15u, dst = (w0 >> 4) & 15u, ak = (w0 >> 8) & 3u, bk = (w0 >> 10) & 3u;
     const uint32_t ai = w1 & 0xffffu, bi = w1 >> 16;
     need(ak, ai);
+    if (op != PROG_NEG && op != PROG_MOV) need(bk, bi);
+    if (fuse && op == PROG_MUL) {
+      value_of(ak, ai), value_of(bk, bi);
+      before_write(dst);
+      // (dst may be one of the operands: the term then names the register's OLD value, which is what the variable holds
+      //  until the register is materialised - nothing writes the variable before that: whoever overwrites a register
+      //  first materialises every OTHER register whose terms name it, and its own pending value is either consumed or dead)
+      pending[dst].assign(1, Term{false, ak, ai, bk, bi});
+      continue;
+    }
+    if (fuse && (op == PROG_ADD || op == PROG_SUB) && is_pending(ak, ai) && is_pending(bk, bi) && ai != bi &&
+        pending[ai].size() + pending[bi].size() <= JIT_DOT_MAX) {
+      std::vector<Term> merged = pending[ai];
+      for (Term t : pending[bi]) {
+        if (op == PROG_SUB) t.neg = !t.neg;
+        merged.push_back(t);
+      }
+      // (an operand register that is not the destination keeps its pending value: the expression compiler never reads a
+      //  register twice, but nothing here relies on that)
+      // (the new value is registered first: materialising the registers that still name the destination's old value writes
+      //  THEIR variables, which the merged terms may name in turn - they must be visible to that bookkeeping)
+      pending[dst] = merged;
+      before_write(dst);
+      continue;
+    }
+    if (fuse && op == PROG_NEG && is_pending(ak, ai)) {
+      std::vector<Term> moved = pending[ai];
+      for (Term& t : moved) t.neg = !t.neg;
+      pending[dst] = moved;
+      before_write(dst);
+      continue;
+    }
+    // everything else reads values and writes where it stands
+    value_of(ak, ai);
+    if (op != PROG_NEG && op != PROG_MOV) value_of(bk, bi);
+    before_write(dst);
+    pending[dst].clear();
     if (op == PROG_NEG) {
       s << "      r" << dst << " = sub(Fr::zero(), " << operand(ak, ai) << ");\n";
     } else if (op == PROG_MOV) {
       s << "      r" << dst << " = " << operand(ak, ai) << ";\n";
     } else {
-      need(bk, bi);
       const char* f = op == PROG_MUL ? "mul" : op == PROG_ADD ? "add" : "sub";
       s << "      r" << dst << " = " << f << "(" << operand(ak, ai) << ", " << operand(bk, bi) << ");\n";
     }
   }
+  flush(result_reg);
   s << "      acc = add(acc, r" << result_reg
     << ");\n"
        "    }\n"
@@ -139,6 +229,12 @@ std::string generate(const uint32_t* code, size_t num_instrs, uint32_t num_regs,
 }
 
 
+}  // namespace
+// development / tests: the source text the runtime compiler would be given for this program
+std::string jit_debug_source(const uint32_t* code, size_t num_instrs, uint32_t num_regs, uint32_t result_reg, int degree) {
+  return generate(code, num_instrs, num_regs, result_reg, degree);
+}
+namespace {
 std::mutex g_mu;
 // keyed on the whole program (device, register count, result register, degree, code words): no hash that could collide
 std::map<std::vector<uint32_t>, JitKernel*> g_cache;  // never freed: modules live as long as the process

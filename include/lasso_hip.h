@@ -558,6 +558,13 @@ lh_status lh_hyperplonk_verify_phases_zeromorph(const lh_zm_vp*, const lh_hp_vpa
                                                 const size_t* num_witness_polys, const size_t* num_challenges,
                                                 const lh_fr* const* instances, lh_transcript* t);
 
+/* development / tests: the HIP source the runtime compiler (csrc/jit.cpp) is given for a register program - words
+ * {op | dst << 4 | a.kind << 8 | b.kind << 10, a.idx | b.idx << 16} with op ADD 0, SUB 1, MUL 2, NEG 3, MOV 4 and operand
+ * kinds register 0, table 1, constant 2 (csrc/dev.hpp PROG_*).  Host code only (no GPU needed): tests/test_jit_source.py
+ * evaluates the emitted statements against the program.  *len = length of the text; `out` may be null. */
+lh_status lh_debug_jit_source(const uint32_t* code, size_t num_instrs, uint32_t num_regs, uint32_t result_reg, int degree,
+                              char* out, size_t cap, size_t* len);
+
 /* ---------------------------------------------------------------- measurement (bench.py)
  * Per-kernel HIP-event timing on the ctx stream.  While enabled every instrumented launch is
  * synchronised, so whole-prove wall time is NOT representative; use a separate pass. */
