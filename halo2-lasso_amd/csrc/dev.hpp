@@ -267,10 +267,11 @@ struct Ctx {
 // `on` false (no sharded proof running): rho = 0 and nothing is sharded - the single-GPU prover is the world of one.
 struct Shard {
   bool on = false;
+  bool loopback = false;  // the measurement communicator (every peer is a copy of this rank)
   size_t rho = 0, j = 0, rank = 0, R = 1;
   explicit Shard(const Ctx& c) {
     if (!c.shard_active) return;
-    on = true, j = c.shard_bit, rank = (size_t)c.comm.rank, R = (size_t)c.comm.size;
+    on = true, j = c.shard_bit, rank = (size_t)c.comm.rank, R = (size_t)c.comm.size, loopback = c.comm_loopback;
     while (((size_t)1 << rho) < R) rho++;
   }
   // is a table of `num_vars` variables held in shards?  Smaller ones are replicated and worked on redundantly.  (A
@@ -278,6 +279,27 @@ struct Shard {
   bool sharded(size_t num_vars) const { return on && num_vars >= j + (rho ? rho : 1) + 1; }
   size_t local_vars(size_t num_vars) const { return sharded(num_vars) ? num_vars - rho : num_vars; }
   size_t local_len(size_t num_vars) const { return (size_t)1 << local_vars(num_vars); }
+};
+
+// A REPLICATED array of `len` entries (final_cts, a quotient level below the replication point) whose MSM every rank would
+// repeat: an MSM is additive over point ranges (the chunk-then-sum of util/arithmetic/msm.rs:101-114), so rank s takes the
+// entries [first, first + count) = [s len / R, (s + 1) len / R) and the partial commitments are added over the ranks.
+// Arrays shorter than the world go to rank 0 whole; outside a sharded proof the range is the whole array.
+struct ReplicatedRange {
+  size_t first = 0, count = 0;
+  ReplicatedRange(const Shard& sh, size_t len) {
+    if (!sh.on || sh.R <= 1) {
+      count = len;
+    } else if (len < sh.R) {
+      // (over the loopback communicator "the sum over the ranks" is R copies of this rank's part: a part that is empty on
+      // every rank but 0 would make the sum the identity there, which no transcript can carry - a handful of points)
+      count = sh.rank == 0 || sh.loopback ? len : 0;
+    } else {
+      const size_t per = len / sh.R;  // (len and R are powers of two in every use; a remainder would go to the last rank)
+      first = sh.rank * per;
+      count = sh.rank + 1 == sh.R ? len - first : per;
+    }
+  }
 };
 
 // Persistent host worker threads for the short host-side tails (window combines of an MSM batch): spawning
@@ -433,6 +455,8 @@ void k_gather_interleave(Ctx&, const Fr* gathered, size_t count, size_t n_local,
 void k_sum_publish(Ctx&, const Fr* all, size_t R, size_t D, Fr* out_host, uint32_t seq);
 // local[idx] = global[((idx >> j) << (j + rho)) | (s << j) | (idx & (2^j - 1))], elements of `elem` bytes (4, 32, 64)
 void k_shard_extract(Ctx&, const void* global, size_t n_local, size_t j, size_t rho, size_t s, size_t elem, void* local);
+// the loopback communicator's all-gather: recv block s = send rotated by 32 s bytes (comm.cpp), one launch
+void k_loopback_gather(Ctx&, const void* d_send, void* d_recv, size_t bytes, size_t R);
 // out[i] = in[i] * w
 void k_scale(Ctx&, const Fr* in, const Fr& w, size_t n, Fr* out);
 
@@ -708,7 +732,9 @@ void bases29_register(const G1Affine* base, size_t count);
 void bases29_unregister(const G1Affine* base);
 const G1Affine29* bases29_lookup(Ctx&, const G1Affine* bases, size_t n);
 // Runs all jobs as one batched Pippenger; out[j] is the affine sum (identity = (0,0)).
-void msm_batch(Ctx&, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host);
+// `overlap` (optional): host work that needs none of this batch's results - run once, after the batch's kernels are
+// queued and before the host waits for the window sums (it overlaps the device's work instead of following it)
+void msm_batch(Ctx&, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, const std::function<void()>* overlap = nullptr);
 int msm_slab_log();  // jobs of >= 2^this points are sorted slab by slab (and can take MsmJob::sorted_*)
 // out[i] = scalars[i] * G (fixed-base), normalised to affine; all on device
 void k_fixed_base_mul_g(Ctx&, const Fr* scalars, size_t n, G1Affine* out);

@@ -3,6 +3,7 @@
 // claim bookkeeping and the final window combine / normalisation of an MSM.
 // Same Montgomery representation as the device code (ff.cuh) and as halo2curves.
 #pragma once
+#include <vector>
 #include <stdint.h>
 #include <string.h>
 
@@ -208,6 +209,21 @@ inline G1Affine g1_to_affine(const G1Xyzz& p) {
   // x = X/ZZ, y = Y/ZZZ ; one inversion: i = 1/(ZZ*ZZZ)
   Fq i = (p.zz * p.zzz).inv();
   return G1Affine{p.x * (i * p.zzz), p.y * (i * p.zz)};
+}
+// out[i] = affine form of p[i], i < n, with ONE field inversion (Montgomery's trick over the ZZ * ZZZ of the finite points)
+inline void g1_batch_to_affine(const G1Xyzz* p, size_t n, G1Affine* out) {
+  std::vector<Fq> d(n), pre(n + 1);
+  pre[0] = Fq::one();
+  for (size_t i = 0; i < n; i++) {
+    d[i] = p[i].is_identity() ? Fq::one() : p[i].zz * p[i].zzz;
+    pre[i + 1] = pre[i] * d[i];
+  }
+  Fq inv = pre[n].inv();
+  for (size_t i = n; i-- > 0;) {
+    const Fq di = inv * pre[i];  // 1 / d[i]
+    inv = inv * d[i];
+    out[i] = p[i].is_identity() ? G1Affine{Fq::zero(), Fq::zero()} : G1Affine{p[i].x * (di * p[i].zzz), p[i].y * (di * p[i].zz)};
+  }
 }
 inline G1Xyzz g1_from_affine(const G1Affine& a) {
   if (a.is_identity()) return G1Xyzz::identity();

@@ -308,7 +308,6 @@ void hyperplonk_prove_phases(Ctx& c, const PcsProver& pcs, const lh_hp_param& pp
     const G1Affine* bases = shn ? pcs.shard_bases(nv) : pcs.commit_bases(nv);
     const G1Affine* bases_full = pcs.commit_bases(nv);
     std::vector<MsmJob> jobs;
-    std::vector<char> job_sharded;  // (final_cts is replicated: committed in full on every rank, not summed)
     uint32_t bad_input = 0;        // sharded: a rank that finds an invalid lookup must not leave its peers in a collective
     for (size_t k = 0; k < pp.num_lasso_lookups; k++) {
       LassoState& st = lasso[k];
@@ -366,21 +365,15 @@ void hyperplonk_prove_phases(Ctx& c, const PcsProver& pcs, const lh_hp_param& pp
           st.fcs_fr.push_back(first < M ? fr_view(st.cols.fcs[j] + first, std::min(M - first, (size_t)1 << sh.j)) : fr_view(st.cols.fcs[j], 0));
         }
       }
-      for (size_t j = 0; j < cc; j++) jobs.push_back(MsmJob{st.cols.rts[j], true, bases, n_loc}), job_sharded.push_back(1);
-      for (size_t i = 0; i < alpha; i++) jobs.push_back(MsmJob{st.cols.E[i], true, bases, n_loc}), job_sharded.push_back(1);
-      for (size_t j = 0; j < cc; j++) jobs.push_back(MsmJob{st.cols.fcs[j], true, bases_full, M}), job_sharded.push_back(0);
+      for (size_t j = 0; j < cc; j++) jobs.push_back(MsmJob{st.cols.rts[j], true, bases, n_loc});
+      for (size_t i = 0; i < alpha; i++) jobs.push_back(MsmJob{st.cols.E[i], true, bases, n_loc});
+      // (final_cts is replicated: every rank commits ITS range of the counts - lasso.cpp - and the parts are summed)
+      const ReplicatedRange fc_range(sh, M);
+      for (size_t j = 0; j < cc; j++) jobs.push_back(MsmJob{st.cols.fcs[j] + fc_range.first, true, bases_full + fc_range.first, fc_range.count});
     }
     std::vector<HG1> comms(jobs.size());
     msm_batch(c, jobs.data(), jobs.size(), (G1Affine*)comms.data());
-    if (shn) {  // the shards' partial commitments -> their sums, one exchange
-      std::vector<HG1> part;
-      for (size_t k = 0; k < jobs.size(); k++)
-        if (job_sharded[k]) part.push_back(comms[k]);
-      comm_sum_points(c, part.data(), part.size());
-      size_t q = 0;
-      for (size_t k = 0; k < jobs.size(); k++)
-        if (job_sharded[k]) comms[k] = part[q++];
-    }
+    if (shn) comm_sum_points(c, comms.data(), comms.size());  // the ranks' partial commitments -> their sums, one exchange
     lasso_write_commitments(tr, comms);
   }
 

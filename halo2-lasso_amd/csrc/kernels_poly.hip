@@ -379,6 +379,31 @@ void k_sum_publish(Ctx& c, const Fr* all, size_t R, size_t D, Fr* out_host, uint
   hipLaunchKernelGGL(sum_publish_kernel, dim3(1), dim3(64), 0, c.stream, all, (unsigned)R, (unsigned)D, out_host, c.flag, seq);
 }
 
+// the loopback communicator's all-gather (comm.cpp comm_attach_loopback: every peer is a copy of this rank) as ONE launch:
+// block s of the result is the send buffer rotated by `rot` * s bytes (whole field elements; rot = 0: plain copies).
+// (R to 2 R hipMemcpyAsync blits per collective cost a rank of an 8-rank world 4.5 ms per 2^24 AND proof - a tenth of a
+// real job's collectives would have to be that slow for the emulation to be honest.)
+template <class T>
+__global__ void loopback_gather_kernel(const T* __restrict__ send, size_t n, size_t rot, unsigned R, T* __restrict__ recv) {
+  GSTRIDE(e, n * R) {
+    const size_t s = e / n, i = e % n;
+    size_t k = i + rot * s;
+    if (k >= n) k -= n;
+    recv[e] = send[k];
+  }
+}
+void k_loopback_gather(Ctx& c, const void* d_send, void* d_recv, size_t bytes, size_t R) {
+  if (!bytes || !R) return;
+  const bool vec = bytes % 16 == 0 && ((uintptr_t)d_send | (uintptr_t)d_recv) % 16 == 0;
+  const size_t rot_bytes = bytes % 32 == 0 && bytes >= 64 * R ? 32 : 0;
+  if (vec)
+    hipLaunchKernelGGL(loopback_gather_kernel<uint4>, grid_for(bytes / 16 * R), 256, 0, c.stream, (const uint4*)d_send, bytes / 16,
+                       rot_bytes / 16, (unsigned)R, (uint4*)d_recv);
+  else
+    hipLaunchKernelGGL(loopback_gather_kernel<uint8_t>, grid_for(bytes * R), 256, 0, c.stream, (const uint8_t*)d_send, bytes,
+                       rot_bytes, (unsigned)R, (uint8_t*)d_recv);
+}
+
 __global__ void scale_kernel(const Fr* __restrict__ in, Fr w, size_t n, Fr* __restrict__ out) {
   GSTRIDE(i, n) out[i] = mul(in[i], w);
 }

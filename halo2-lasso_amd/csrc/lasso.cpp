@@ -528,21 +528,24 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
         }
         jobs.back().known_bits = (uint32_t)(l / 2);  // AND / XOR of two (l/2)-bit halves
       }
-    const size_t num_sharded = jobs.size();
-    for (size_t j = 0; j < cc; j++) {  // (final_cts is replicated: committed in full on every rank)
-      add_job(1 + 2 * cc + alpha + j, fcs[j], true, M);
-      jobs.back().bases = pcs.commit_bases(nv);
+    // final_cts (2^l entries) is replicated - but an MSM is additive over point ranges (the chunk-then-sum of
+    // util/arithmetic/msm.rs:101-114): rank s commits the counts [s 2^l / R, (s + 1) 2^l / R) against the same range of
+    // the level's first bases, and the partial commitments join the exchange below - no rank repeats another's additions
+    const ReplicatedRange fc_range(sh, M);
+    for (size_t j = 0; j < cc; j++) {
+      add_job(1 + 2 * cc + alpha + j, fcs[j] + fc_range.first, true, fc_range.count);
+      jobs.back().bases = pcs.commit_bases(nv) + fc_range.first;
       jobs.back().known_bits = count_ors[j] ? 32u - (uint32_t)__builtin_clz(count_ors[j]) : 0u;
     }
     std::vector<HG1> part(jobs.size()), comms(total);
     msm_batch(c, jobs.data(), jobs.size(), (G1Affine*)part.data());
     if (shn) {
       // partial commitments of the shards (the second outputs of packed jobs included) -> their sums, one exchange
-      std::vector<HG1> sums(part.begin(), part.begin() + num_sharded);
+      std::vector<HG1> sums(part);
       for (size_t j : second_of) sums.push_back(second[j]);
       comm_sum_points(c, sums.data(), sums.size());
-      for (size_t k = 0; k < num_sharded; k++) part[k] = sums[k];
-      for (size_t q = 0; q < second_of.size(); q++) second[second_of[q]] = sums[num_sharded + q];
+      for (size_t k = 0; k < part.size(); k++) part[k] = sums[k];
+      for (size_t q = 0; q < second_of.size(); q++) second[second_of[q]] = sums[part.size() + q];
     }
     for (size_t k = 0; k < jobs.size(); k++) comms[slot[k]] = part[k];
     for (size_t j : second_of) comms[1 + cc + j] = second[j];

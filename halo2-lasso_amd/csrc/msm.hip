@@ -27,6 +27,8 @@
 // the key space is (job, window, digit), so the latency-bound tails are paid once per batch.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <exception>
+#include <functional>
 #include <thread>
 #include <vector>
 #include <mutex>
@@ -666,7 +668,15 @@ static inline host::G1Xyzz to_host(const G1Xyzz& p) {
   return r;
 }
 
-void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) {
+void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, const std::function<void()>* overlap) {
+  bool overlap_done = overlap == nullptr;
+  struct OverlapGuard {  // (a batch without entries, or one that throws on the way, still owes the caller its host work)
+    const std::function<void()>* fn;
+    bool& done;
+    ~OverlapGuard() noexcept(false) {
+      if (!done && !std::uncaught_exceptions()) done = true, (*fn)();
+    }
+  } overlap_guard{overlap, overlap_done};
   for (size_t base = 0; base < num_jobs; base += MSM_MAX_JOBS) {
     size_t nj = std::min(num_jobs - base, (size_t)MSM_MAX_JOBS);
     MsmPlanDev plan;
@@ -1021,6 +1031,7 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host) 
       const uint32_t seq = c.next_seq();
       const ScFinishArgs fin = c.finish_for(nshares, nullptr, seq);
       hipLaunchKernelGGL(msm_window_sum_kernel, dim3(nshares), dim3(512), 0, c.stream, plan, seg_out, win_out, fin);
+      if (!overlap_done) overlap_done = true, (*overlap)();  // (the device is busy with this batch: the caller's host work now)
       if (c.prof) c.sync();
       c.wait_flag(seq);
       }

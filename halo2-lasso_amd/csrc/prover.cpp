@@ -102,11 +102,12 @@ void comm_sum_points(Ctx& c, HG1* pts, size_t n) {
   const size_t R = (size_t)c.comm.size;
   std::vector<HG1> all(n * R);
   comm_all_gather_host(c, pts, all.data(), n * sizeof(HG1));
-  for (size_t i = 0; i < n; i++) {
-    host::G1Xyzz acc = host::G1Xyzz::identity();
-    for (size_t r = 0; r < R; r++) acc = host::g1_add(acc, host::g1_from_affine(all[r * n + i]));
-    pts[i] = host::g1_to_affine(acc);
-  }
+  // (one inversion for all the sums: ~20 points per exchange at ~10 us of host time per inversion were 0.2 ms on the
+  // critical path of every commit and opening)
+  std::vector<host::G1Xyzz> acc(n, host::G1Xyzz::identity());
+  for (size_t i = 0; i < n; i++)
+    for (size_t r = 0; r < R; r++) acc[i] = host::g1_add(acc[i], host::g1_from_affine(all[r * n + i]));
+  host::g1_batch_to_affine(acc.data(), n, pts);
 }
 
 // `count` local tables back to back (count * n_local entries) -> the full tables on every rank: ONE device all-gather and
@@ -2110,8 +2111,15 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
   for (size_t i = 0; i < plain; i++) {
     size_t half = (size_t)1 << (i >= cut ? i - lsh : i);
     jobs[i] = MsmJob{q_of[i], false, level_bases(i), half};
+    if (sharded && i < cut) {
+      // a level below the replication point is the same on every rank: each commits ITS range of the quotient's entries
+      // (dev.hpp ReplicatedRange: the chunk-then-sum of util/arithmetic/msm.rs:101-114) and the parts are added with the
+      // sharded levels' partial commitments below - 2^cut points x ~20 windows that every rank used to repeat
+      const ReplicatedRange rr(sh, half);
+      jobs[i] = MsmJob{q_of[i] + rr.first, false, srs.eq(i) + rr.first, rr.count};
+    }
     if (small) jobs[i].known_bits = 254;  // quotients of a random combination: full-size scalars, nothing to measure
-    if (!(i >= cut && sharded))           // (a rank's share of a sharded level has no window table)
+    if (!sharded)                         // (a rank's share of a level has no window table)
       if (const Srs::WinTable* wt = srs_window_table(c, srs, i))
         jobs[i].win_table = wt->d, jobs[i].win_table_c = wt->c, jobs[i].win_table_W = wt->W;
   }
@@ -2140,10 +2148,11 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
       jobs.push_back(MsmJob{q_of[lvl], false, level_bases(lvl), half});
     }
   std::vector<HG1> out(jobs.size());
-  msm_batch(c, jobs.data(), jobs.size(), (G1Affine*)out.data());
-  std::vector<HG1> comms(out.begin(), out.begin() + plain);
-  if (plan && !pre_out) column_sums_store(srs, sharded, own, out.data() + col_base);
-  for (size_t d = depth; d-- > 0;) {  // levels in ascending order after the plain ones
+  std::vector<HG1> col_comms(depth);  // commitments of the column-wise levels (index d: level num_vars - 1 - d)
+  // the column-wise levels' commitments from the jobs' results (scalar multiplications on the host's threads, ~0.15 ms):
+  // with the results committed ahead this runs WHILE the device works on the plain levels' MSM
+  const std::function<void()> combine_columns = [&] {
+  for (size_t d = depth; d-- > 0;) {
     const ColLevel& cl = plan->levels[d];
     // weights of the settings of the top d index bits (bit n-1-j of the index is bit d-1-j of sidx)
     std::vector<HFr> w_s((size_t)1 << d, HFr::one());
@@ -2172,14 +2181,25 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
     });
     host::G1Xyzz acc = host::G1Xyzz::identity();
     for (const host::G1Xyzz& pt : parts) acc = host::g1_add(acc, pt);
-    comms.push_back(host::g1_to_affine(acc));
+    col_comms[d] = host::g1_to_affine(acc);
+  }
+  };
+  const bool ahead = plan && pre_out && depth > 0;
+  msm_batch(c, jobs.data(), jobs.size(), (G1Affine*)out.data(), ahead ? &combine_columns : nullptr);
+  std::vector<HG1> comms(out.begin(), out.begin() + plain);
+  if (plan && !pre_out) column_sums_store(srs, sharded, own, out.data() + col_base);
+  if (!ahead) combine_columns();
+  for (size_t d = depth; d-- > 0;) {  // levels in ascending order after the plain ones
+    comms.push_back(col_comms[d]);
     if (self_check && d >= check_from && memcmp(&comms.back(), &out[check_base + d - check_from], sizeof(HG1)) != 0)
-      fprintf(stderr, "[open] column-wise commitment of level %zu (depth %zu of %zu) differs from the plain one\n", cl.level, d, depth);
+      fprintf(stderr, "[open] column-wise commitment of level %zu (depth %zu of %zu) differs from the plain one\n",
+              plan->levels[d].level, d, depth);
   }
   download(c, &remainder, rem, sizeof(Fr));
-  // sharded levels: what every rank holds is the commitment of its shard (column-wise levels: of its share of the columns,
-  // offset term included - everything above is linear in the bases) -> their sums, one exchange
-  if (sharded) comm_sum_points(c, comms.data() + cut, num_vars - cut);
+  // what every rank holds is the commitment of its part of each quotient - its shard of a sharded level (column-wise
+  // levels: of its share of the columns, offset term included - everything above is linear in the bases), its range of a
+  // replicated one -> their sums, one exchange
+  if (sharded) comm_sum_points(c, comms.data(), num_vars);
   tr.write_commitments(comms);  // identity -> Error::Transcript (transcript.rs:172-179,216-219)
   return remainder;
 }

@@ -1,5 +1,5 @@
 """Development aid: timeline of the LAST proof in a rocprofv3 (rocpd sqlite) kernel trace: busy time, idle gaps and
-the kernels around the largest gaps.  usage: [LH_TRACE_COLUMNS=4] python tools/trace_gaps.py <results.db> [kernel-name regex for a per-launch listing]"""
+the kernels around the largest gaps.  usage: [LH_TRACE_COLUMNS=4 | LH_TRACE_SPLIT_IDLE_MS=50] python tools/trace_gaps.py <results.db> [kernel-name regex for a per-launch listing]"""
 import re
 import sqlite3
 import sys
@@ -11,11 +11,18 @@ short = lambda n: re.sub(r"\(.*", "", re.sub(r"^(void )?(lh::|rocprim::\w+::deta
 # (the access counters of a proof launch lasso_run_start_kernel once per chunk column; the proof begins with the sort in
 # front of the first of them: walk back over the kernels that follow each other closely)
 import os
-starts = [i for i, r in enumerate(rows) if "lasso_run_start_kernel" in r[0]]
-per = int(os.environ.get("LH_TRACE_COLUMNS", "2"))  # chunk columns per proof (range table: 2, AND / XOR: 4)
-i0 = starts[-per]
-while i0 > 0 and rows[i0][1] - rows[i0 - 1][2] < 150e3:
-    i0 -= 1
+split_ms = float(os.environ.get("LH_TRACE_SPLIT_IDLE_MS", "0"))  # > 0: the trace's tail after the last idle gap this long
+if split_ms > 0:
+    i0 = 0
+    for i in range(1, len(rows)):
+        if rows[i][1] - rows[i - 1][2] >= split_ms * 1e6:
+            i0 = i
+else:
+    starts = [i for i, r in enumerate(rows) if "lasso_run_start_kernel" in r[0]]
+    per = int(os.environ.get("LH_TRACE_COLUMNS", "2"))  # chunk columns per proof (range table: 2, AND / XOR: 4)
+    i0 = starts[-per]
+    while i0 > 0 and rows[i0][1] - rows[i0 - 1][2] < 150e3:
+        i0 -= 1
 ks = rows[i0:]
 t0, t1 = ks[0][1], max(r[2] for r in ks)
 busy = sum(r[2] - r[1] for r in ks)
