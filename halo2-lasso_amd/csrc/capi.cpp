@@ -79,6 +79,7 @@ lh_status lh_ctx_create(int device_id, lh_ctx** out) {
   if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device_id) == hipSuccess && khz > 0)
     ctx->c.wall_clock_khz = khz;
   ctx->c.pin(65536);
+  ctx->c.host_trace_on = getenv("LH_HOST_TRACE") != nullptr && atoi(getenv("LH_HOST_TRACE")) != 0;
   // line 0: device -> host sequence flag; lines 1-2: host -> device mailbox of the resident sum-check tail
   LH_HIP(hipHostMalloc((void**)&ctx->c.flag, 256, hipHostMallocCoherent | hipHostMallocMapped));
   memset(ctx->c.flag, 0, 256);

@@ -277,4 +277,92 @@ void comm_sum_publish(Ctx& c, const Fr* d_part, Fr* d_scratch, size_t count, Fr*
   k_sum_publish(c, d_scratch, (size_t)c.comm.size, count, out_host, seq);
 }
 
+
+// ------------------------------------------------------------------ the all-reduce variant of a sharded round (Options::comm_round)
+// north_star's collective: "per-round partial sums combined via RCCL all-reduce".  A field element is 8 limbs of 32 bits;
+// every limb travels in a u64 lane, so ncclSum over at most 2^8 ranks cannot lose a carry (a lane's low 40 bits hold the
+// sum), and the lane's upper 24 bits carry a tag every rank stamps alike: a lane whose upper bits read R * tag IS the
+// finished sum of this round.  The collective writes the lanes where the host polls them (pinned memory; comm_round 2:
+// into device memory, then a copy), the host adds the limbs up as one wide integer and reduces it mod r - no kernel runs
+// behind the collective.  Never run on more than one GPU: tests cover a world of one over RCCL and 2 / 4 ranks over the
+// callback transports (the lanes are then all-gathered through the host and added there).
+uint32_t comm_next_tag(Ctx& c) {
+  const uint32_t R = (uint32_t)std::max(c.comm.size, 1);
+  const uint32_t span = (1u << 24) / R;  // tags below this: R * tag < 2^24
+  c.sc_tag_seq = c.sc_tag_seq % (span - 1) + 1;  // 1 .. span - 1, consecutive rounds differ
+  return c.sc_tag_seq;
+}
+
+void comm_sum_lanes(Ctx& c, uint64_t* d_lanes, uint64_t* d_scratch, size_t count, Fr* out_host) {
+  require_comm(c);
+  const size_t R = (size_t)c.comm.size, n = 8 * count;
+  LH_REQUIRE(count >= 1 && count <= 16 && R <= 256, LH_ERR_ARG, "comm_sum_lanes: bad size");
+  comm_trace(c, "all_reduce_lanes", n * sizeof(uint64_t));
+  if (!c.lanes_host) {
+    LH_HIP(hipHostMalloc((void**)&c.lanes_host, 128 * sizeof(uint64_t), hipHostMallocCoherent | hipHostMallocMapped));
+    memset(c.lanes_host, 0, 128 * sizeof(uint64_t));
+  }
+  volatile uint64_t* hl = c.lanes_host;
+  const bool via_device = c.opt.comm_round == 2;
+  uint64_t* dst = via_device ? d_scratch : c.lanes_host;
+  if (c.comm_loopback) {
+    c.comm_stats[0]++;
+    k_loopback_allreduce_lanes(c, d_lanes, n, R, dst);
+    if (via_device) LH_HIP(hipMemcpyAsync(c.lanes_host, d_scratch, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c.stream));
+  } else if (c.rccl_comm) {
+    c.comm_stats[0]++;
+    rccl_check(rccl().AllReduce(d_lanes, dst, n, ncclUint64, ncclSum, (ncclComm_t)c.rccl_comm, c.stream), "ncclAllReduce");
+    if (via_device) LH_HIP(hipMemcpyAsync(c.lanes_host, d_scratch, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c.stream));
+  } else {
+    // callback transports (gloo in the tests): the lanes are all-gathered through the host and added there - the same
+    // arithmetic, the same lanes, the same wait below
+    std::vector<uint64_t> mine(n), all(n * R);
+    c.d2h(mine.data(), d_lanes, n * sizeof(uint64_t));
+    comm_all_gather_host(c, mine.data(), all.data(), n * sizeof(uint64_t));
+    for (size_t i = 0; i < n; i++) {
+      uint64_t acc = 0;
+      for (size_t s = 0; s < R; s++) acc += all[s * n + i];
+      hl[i] = acc;
+    }
+  }
+  // every lane validates itself: wait until each carries the ranks' tags
+  const uint64_t expect = ((uint64_t)R * c.sc_tag) & 0xffffffull;
+  for (size_t i = 0; i < n; i++) {
+    for (uint64_t spin = 0; (hl[i] >> SC_LANE_TAG_SHIFT) != expect; spin++) {
+      __builtin_ia32_pause();
+      if ((spin & 0xfffff) == 0xfffff) {
+        hipError_t e = hipStreamQuery(c.stream);
+        if (e == hipSuccess) {
+          if ((hl[i] >> SC_LANE_TAG_SHIFT) == expect) break;
+          throw Error(LH_ERR_DEVICE, "all-reduce finished without delivering the round's sums");
+        }
+        if (e != hipErrorNotReady) throw Error(LH_ERR_DEVICE, std::string("stream error: ") + hipGetErrorString(e));
+      }
+    }
+  }
+  // lazy reduction: sum_k lane_k 2^(32 k) < R r as a 320-bit integer, minus r while it is not below it
+  const uint64_t mask = ((uint64_t)1 << SC_LANE_TAG_SHIFT) - 1;
+  for (size_t x = 0; x < count; x++) {
+    uint64_t w[5] = {0, 0, 0, 0, 0};
+    for (int k = 0; k < 8; k++) {
+      const unsigned __int128 v = (unsigned __int128)(hl[8 * x + k] & mask) << (32 * (k & 1));
+      unsigned __int128 cy = v;
+      for (int q = k >> 1; q < 5 && cy; q++) {
+        cy += w[q];
+        w[q] = (uint64_t)cy;
+        cy >>= 64;
+      }
+    }
+    while (w[4] || host::F<host::FrTag>::geq_mod(w)) {
+      unsigned __int128 bw = 0;
+      for (int q = 0; q < 5; q++) {
+        const unsigned __int128 d = (unsigned __int128)w[q] - (q < 4 ? host::FrTag::MOD[q] : 0) - bw;
+        w[q] = (uint64_t)d;
+        bw = (d >> 64) & 1;
+      }
+    }
+    memcpy(&out_host[x], w, 32);
+  }
+}
+
 }  // namespace lh

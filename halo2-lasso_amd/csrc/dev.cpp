@@ -11,6 +11,7 @@
 #include <emmintrin.h>
 #include <hip/hip_ext.h>
 #include <vector>
+#include <chrono>
 #include "dev.hpp"
 
 namespace lh {
@@ -92,6 +93,7 @@ static const struct {
     {"open_precommit", &Options::open_precommit, 0, 64},           {"gkr_resident", &Options::gkr_resident, 0, 1},
     {"sc_pp_fold", &Options::sc_pp_fold, 0, 1},
     {"msm_limbs29", &Options::msm_limbs29, 0, 1},
+    {"comm_round", &Options::comm_round, 0, 2},
 };
 
 int64_t* Options::find(const char* name) {
@@ -121,6 +123,19 @@ Options::Options() {
     this->*o.field = v;
     if (o.field == &Options::open_small_min_vars) open_small_min_vars_forced = true;
   }
+}
+
+void Ctx::host_stamp(const char* tag) {
+  if (!host_trace_on) return;
+  host_stamps.emplace_back(tag, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count());
+}
+void Ctx::host_stamps_print() {
+  if (!host_trace_on || host_stamps.empty()) return;
+  fprintf(stderr, "[host trace]");
+  for (size_t i = 0; i < host_stamps.size(); i++)
+    fprintf(stderr, " %s +%.1f", host_stamps[i].first, i ? host_stamps[i].second - host_stamps[i - 1].second : 0.0);
+  fprintf(stderr, " us\n");
+  host_stamps.clear();
 }
 
 void Ctx::wait_flag(uint32_t seq) {
@@ -159,8 +174,8 @@ hipStream_t Ctx::second_stream(int cu_share) {
 }
 
 ScFinishArgs Ctx::finish_for(uint32_t grid, Fr* out_host, uint32_t seq) {
-  ScFinishArgs f{ticket, (uint32_t)(ticket_base + grid - 1), out_host, flag, seq};
-  if (sc_redirect) f.out_host = sc_redirect, f.flag = ticket + 8;  // sharded round: a device word nobody waits on
+  ScFinishArgs f{ticket, (uint32_t)(ticket_base + grid - 1), out_host, flag, seq, nullptr, 0};
+  if (sc_redirect) f.out_host = sc_redirect, f.flag = ticket + 8, f.wide = sc_wide, f.tag = sc_tag;  // sharded round: a device word nobody waits on
   if (grid > 1) ticket_base += grid;  // single-workgroup launches draw no ticket
   return f;
 }

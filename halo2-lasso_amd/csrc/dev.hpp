@@ -7,6 +7,7 @@
 #include <functional>
 #include <string>
 #include <vector>
+#include <utility>
 #include <stdexcept>
 
 #include "../../include/lasso_hip.h"
@@ -89,7 +90,16 @@ struct ScFinishArgs {
   Fr* out_host;          // pinned
   uint32_t* flag;        // pinned
   uint32_t seq;
+  // sharded rounds, all-reduce variant (Options::comm_round, comm.cpp comm_sum_publish): the sums ALSO leave as 8 u64
+  // lanes each, lane = 32-bit limb | tag << SC_LANE_TAG_SHIFT - what ncclAllReduce(ncclSum, ncclUint64) adds over the ranks
+  // without losing a carry; null otherwise
+  uint64_t* wide;
+  uint32_t tag;
 };
+// a lane of the all-reduce variant: bits [0, 40) the sum of <= 2^8 32-bit limbs, bits [40, 64) the sum of the ranks' tags -
+// every rank stamps the same tag < 2^24 / R, so a lane whose upper bits read R * tag is the finished sum of THIS round
+// (lanes are 8-byte stores: each validates itself, no flag and no ordering between them is needed)
+constexpr unsigned SC_LANE_TAG_SHIFT = 40;
 
 // ------------------------------------------------------------------ route options and the route a proof took
 // The switches that decide WHICH code proves (not how fast a kernel runs).  Per ctx: set through lh_ctx_set_option
@@ -119,6 +129,12 @@ struct Options {
                                        // for the lost wave of occupancy: measured, off); 0: the 8 x 32-bit form everywhere
   int64_t gkr_resident = 1;            // the layers of a grand-product argument whose tables fit the resident kernel run in ONE
                                        // launch (layer loop, eq tables and rounds inside; 0: one sum-check per layer)
+  int64_t comm_round = 0;              // how the partial sums of a sharded sum-check round are combined: 0 = all-gather +
+                                       // a sum-and-publish kernel; 1 = ONE collective, ncclAllReduce(ncclSum) over u64 lanes
+                                       // of 32-bit limbs straight into the pinned memory the host polls (lazy reduction mod
+                                       // r on the host, no kernel behind the collective); 2 = the same all-reduce into
+                                       // device memory followed by a copy to the host (should a fabric refuse host memory
+                                       // as a receive buffer).  Same proof bytes; unmeasured on more than one GPU.
   Options();                           // environment defaults (dev.cpp)
   int64_t* find(const char* name);
   static bool in_range(const char* name, int64_t value);  // the range lh_ctx_set_option accepts
@@ -175,12 +191,22 @@ struct Ctx {
   // sharded sum-check rounds: the round kernel leaves its D sums in this DEVICE buffer (and "publishes" to a device
   // word) instead of pinned host memory; the all-gather and the sum-and-publish kernel follow on the stream
   Fr* sc_redirect = nullptr;
+  uint64_t* sc_wide = nullptr;  // all-reduce variant: the round kernel also leaves its sums as tagged u64 lanes here (device)
+  uint32_t sc_tag = 0;          // the tag of the round in progress (ScFinishArgs::tag)
+  uint32_t sc_tag_seq = 0;      // tags handed out so far
+  uint64_t* lanes_host = nullptr;  // pinned: where the all-reduce leaves the lanes' sums (created on first use)
   Fr* round_out(Fr* out_host) const { return sc_redirect ? sc_redirect : out_host; }
   void wait_round(uint32_t seq) {  // the host's wait for a round kernel's sums (nothing to wait for when they stay on the device)
     if (!sc_redirect) wait_flag(seq);
   }
   bool last_round_folded = false;  // k_sc_round: the launch it chose folded the coefficients into the left factors (ScRound::pp)
   uint64_t* tail_trace = nullptr;  // development: device stamps of the last resident tail (LH_SC_TAIL_TRACE)
+  // development (LH_HOST_TRACE=1): host wall-clock stamps at named points of a prove, printed (deltas in us) when the prove
+  // ends - where the host's share of a gap between two kernels goes
+  std::vector<std::pair<const char*, double>> host_stamps;
+  bool host_trace_on = false;
+  void host_stamp(const char* tag);
+  void host_stamps_print();
   // eq tables of point tails y[1..n) built during one proof (prover.cpp eq_half_*): an evaluation, a sum-check and the batch
   // opening at the same point share one table.  Arena memory of the proof's scope: the proof clears the list (EqHalfScope).
   struct EqHalfEntry {
@@ -443,6 +469,14 @@ void comm_all_to_all_v(Ctx&, const void* d_send, const size_t* send_off, const s
 // v[i] = sum over the ranks of v[i], `count` field elements in a device buffer the ctx's stream owns; the sums are left in
 // out_host (pinned) followed by the flag `seq` (the closing steps of a sharded sum-check round)
 void comm_sum_publish(Ctx&, const Fr* d_part, Fr* d_scratch, size_t count, Fr* out_host, uint32_t seq);
+// the all-reduce variant of the same step (Options::comm_round 1 / 2): d_lanes = the 8 * count tagged u64 lanes the round
+// kernel left (ScFinishArgs::wide, tag = c.sc_tag); ONE collective adds them over the ranks into pinned host memory, the
+// host waits until every lane carries the ranks' tags and reduces mod r.  Synchronous: out_host holds the sums on return.
+void comm_sum_lanes(Ctx&, uint64_t* d_lanes, uint64_t* d_scratch, size_t count, Fr* out_host);
+// a fresh tag for the next all-reduce round (never 0, below 2^24 / R)
+uint32_t comm_next_tag(Ctx&);
+// loopback all-reduce: out[i] = in[i] * R (every peer is a copy of this rank), one launch (kernels_poly.hip)
+void k_loopback_allreduce_lanes(Ctx&, const uint64_t* d_in, size_t n, size_t R, uint64_t* out);
 
 // ------------------------------------------------------------------ sharding helpers (kernels_poly.hip)
 // inverse of k_shard_extract over the all-gathered shards: global[g] = gathered[s(g) * n_local + local(g)]

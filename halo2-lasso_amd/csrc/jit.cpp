@@ -55,7 +55,7 @@ std::string operand(uint32_t kind, uint32_t idx) {
 std::string generate(const uint32_t* code, size_t num_instrs, uint32_t num_regs, uint32_t result_reg, int D) {
   std::ostringstream s;
   s << "#include \"ff.cuh\"\n#include \"reduce.cuh\"\nusing namespace lh;\n"
-       "struct Fin { unsigned* ticket; unsigned last_ticket; Fr* out_host; unsigned* flag; unsigned seq; };\n"
+       "struct Fin { unsigned* ticket; unsigned last_ticket; Fr* out_host; unsigned* flag; unsigned seq; unsigned long long* wide; unsigned tag; };\n"
        "struct Args { const Fr* in["
     << SC_MAX_TABLES
     << "]; const Fr* consts; unsigned long long size; Fr* partials; Fin fin; };\n"
@@ -223,7 +223,19 @@ std::string generate(const uint32_t* code, size_t num_instrs, uint32_t num_regs,
        "    }\n"
        "  }\n"
        "  __syncthreads();\n"
-       "  if (threadIdx.x == 0) __hip_atomic_store(a.fin.flag, a.fin.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);\n"
+       // (dev.hpp ScFinishArgs::wide - sharded rounds of the all-reduce variant: the sums once more as tagged u64 lanes,
+       //  the protocol of resident.cuh publish_round)
+       "  if (threadIdx.x == 0) {\n"
+       "    if (a.fin.wide)\n"
+       "      for (int x = 0; x < D; x++)\n"
+       "        for (int k = 0; k < 8; k++) {\n"
+       "          const unsigned limb = __hip_atomic_load(&a.fin.out_host[x].l[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
+       "          a.fin.wide[8 * x + k] = (unsigned long long)limb | ((unsigned long long)a.fin.tag << "
+    << SC_LANE_TAG_SHIFT
+    << ");\n"
+       "        }\n"
+       "    __hip_atomic_store(a.fin.flag, a.fin.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);\n"
+       "  }\n"
        "}\n";
   return s.str();
 }

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include "dev.hpp"
 #include "reduce.cuh"
+#include "resident.cuh"
 
 namespace lh {
 
@@ -132,10 +133,6 @@ __device__ __forceinline__ void load_pair_ext(const Fr* __restrict__ in, Fr* __r
   }
 }
 
-__device__ __forceinline__ void publish_flag_ext(uint32_t* flag, uint32_t seq) {
-  __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 template <int D, bool BIND>
 __global__ __launch_bounds__(256) void sc_round_ext_kernel(ExtRound rd, size_t size, uint32_t tp,
                                                            Fr* __restrict__ partials, ScFinishArgs fin) {
@@ -190,7 +187,7 @@ __global__ __launch_bounds__(256) void sc_round_ext_kernel(ExtRound rd, size_t s
     if (threadIdx.x == 0) partials[(size_t)blockIdx.x * D + x] = v;
   }
   if (gridDim.x == 1) {
-    if (threadIdx.x == 0) publish_flag_ext(fin.flag, fin.seq);
+    if (threadIdx.x == 0) publish_round(fin, D);
     return;
   }
   // last-workgroup final reduction (same protocol as kernels_sumcheck.hip::finish_round)
@@ -218,7 +215,7 @@ __global__ __launch_bounds__(256) void sc_round_ext_kernel(ExtRound rd, size_t s
     a2 = block_reduce_sum(a2, lds);
     if (threadIdx.x == 0) fin.out_host[x] = a2;
   }
-  if (threadIdx.x == 0) publish_flag_ext(fin.flag, fin.seq);
+  if (threadIdx.x == 0) publish_round(fin, D);
 }
 
 template <int D>
@@ -329,7 +326,7 @@ __global__ __launch_bounds__(512) void sc_round_prog_kernel(ProgRound pr, size_t
       __threadfence_system();
     }
     __syncthreads();
-    if (threadIdx.x == 0) publish_flag_ext(fin.flag, fin.seq);
+    if (threadIdx.x == 0) publish_round(fin, D);
     return;
   }
   if (lane == 0) {
@@ -352,7 +349,7 @@ __global__ __launch_bounds__(512) void sc_round_prog_kernel(ProgRound pr, size_t
     __threadfence_system();
   }
   __syncthreads();
-  if (threadIdx.x == 0) publish_flag_ext(fin.flag, fin.seq);
+  if (threadIdx.x == 0) publish_round(fin, D);
 }
 
 void k_sc_round_prog(Ctx& c, const ProgRound& pr, int degree, size_t size, Fr* evals_host, const JitKernel* jit) {

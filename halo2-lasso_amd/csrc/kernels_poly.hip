@@ -404,6 +404,17 @@ void k_loopback_gather(Ctx& c, const void* d_send, void* d_recv, size_t bytes, s
                        rot_bytes, (unsigned)R, (uint8_t*)d_recv);
 }
 
+// the loopback communicator's all-reduce of u64 lanes (comm.cpp comm_sum_lanes): the sum over R copies of this rank
+__global__ void loopback_allreduce_lanes_kernel(const uint64_t* __restrict__ in, unsigned n, uint64_t R, uint64_t* __restrict__ out) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) __hip_atomic_store(&out[i], in[i] * R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (out may be host memory)
+}
+void k_loopback_allreduce_lanes(Ctx& c, const uint64_t* d_in, size_t n, size_t R, uint64_t* out) {
+  if (!n) return;
+  hipLaunchKernelGGL(loopback_allreduce_lanes_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, c.stream, d_in, (unsigned)n,
+                     (uint64_t)R, out);
+}
+
 __global__ void scale_kernel(const Fr* __restrict__ in, Fr w, size_t n, Fr* __restrict__ out) {
   GSTRIDE(i, n) out[i] = mul(in[i], w);
 }

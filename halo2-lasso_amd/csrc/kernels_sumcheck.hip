@@ -82,7 +82,7 @@ __device__ __forceinline__ void finish_round(const ScFinish& f, const Fr* __rest
     acc = block_reduce_sum(acc, lds);
     if (threadIdx.x == 0) f.out_host[x] = acc;
   }
-  if (threadIdx.x == 0) publish_flag(f.flag, f.seq);
+  if (threadIdx.x == 0) publish_round(f, D);
 }
 
 // Occupancy of the streaming round kernels: the degree-2 instantiations (GKR layers, Surge, the batch opening: the
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) LH_SC_WAVES_ATTR(D) void sc_round_kernel(ScArg
     if (threadIdx.x == 0) partials[(size_t)blockIdx.x * D + x] = v;
   }
   if (gridDim.x == 1) {  // single workgroup: `partials` IS the host buffer
-    if (threadIdx.x == 0) publish_flag(fin.flag, fin.seq);
+    if (threadIdx.x == 0) publish_round(fin, D);
     return;
   }
   finish_round<D>(fin, partials, lds);
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) LH_E_WAVES_ATTR(LH_E_WAVES_E2) void sc_round_e
     partials[(size_t)blockIdx.x * 2 + 1] = q2;
   }
   if (gridDim.x == 1) {
-    if (threadIdx.x == 0) publish_flag(fin.flag, fin.seq);
+    if (threadIdx.x == 0) publish_round(fin, 2);
     return;
   }
   finish_round<2>(fin, partials, lds);
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LH_PP_WAVES
     partials[(size_t)blockIdx.x * 2 + 1] = q2;
   }
   if (gridDim.x == 1) {
-    if (threadIdx.x == 0) publish_flag(fin.flag, fin.seq);
+    if (threadIdx.x == 0) publish_round(fin, 2);
     return;
   }
   finish_round<2>(fin, partials, lds);
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256) void sc_round_lds_kernel(ScLdsArgs g, size_t s
   }
   if (gridDim.x == 1) {  // single workgroup: `partials` IS the host buffer
     __syncthreads();
-    if (threadIdx.x == 0) publish_flag(fin.flag, fin.seq);
+    if (threadIdx.x == 0) publish_round(fin, D);
     return;
   }
   finish_round<D>(fin, partials, vals);  // vals is free again: 4 slots of it serve as reduction scratch
@@ -883,7 +883,7 @@ __global__ __launch_bounds__(256) LH_E_WAVES_ATTR(LH_E_WAVES_OPEN) void sc_round
     }
   }
   if (gridDim.x == 1) {
-    if (threadIdx.x == 0) publish_flag(fin.flag, fin.seq);
+    if (threadIdx.x == 0) publish_round(fin, NQ);
     return;
   }
   finish_round<NQ>(fin, partials, lds);
@@ -959,7 +959,7 @@ __global__ __launch_bounds__(256) LH_E_WAVES_ATTR(LH_E_WAVES_RW) void sc_round_r
     partials[(size_t)blockIdx.x * 2 + 1] = q2;
   }
   if (gridDim.x == 1) {
-    if (threadIdx.x == 0) publish_flag(fin.flag, fin.seq);
+    if (threadIdx.x == 0) publish_round(fin, 2);
     return;
   }
   finish_round<2>(fin, partials, lds);

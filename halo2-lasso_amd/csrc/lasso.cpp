@@ -260,6 +260,7 @@ LassoClaims lasso_argue(Ctx& c, const lh_lasso_table& tb, size_t n, const LassoC
   LassoClaims cl;
   // ---- 2-4: Surge primary sum-check
   cl.r = tr.squeeze_challenges(n);
+  c.host_stamp("argue:squeezed");
   if (a_small && n >= 2) {
     // against the eq table of r[1..] (half the entries), which the Surge sum-check and the batch opening at r use as well
     const Fr* eq_half = eq_half_get(c, cl.r.data(), n, shn);
@@ -539,6 +540,7 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
     }
     std::vector<HG1> part(jobs.size()), comms(total);
     msm_batch(c, jobs.data(), jobs.size(), (G1Affine*)part.data());
+    c.host_stamp("commit:msm_done");
     if (shn) {
       // partial commitments of the shards (the second outputs of packed jobs included) -> their sums, one exchange
       std::vector<HG1> sums(part);
@@ -547,6 +549,7 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
       for (size_t k = 0; k < part.size(); k++) part[k] = sums[k];
       for (size_t q = 0; q < second_of.size(); q++) second[second_of[q]] = sums[part.size() + q];
     }
+    c.host_stamp("commit:summed");
     for (size_t k = 0; k < jobs.size(); k++) comms[slot[k]] = part[k];
     for (size_t j : second_of) comms[1 + cc + j] = second[j];
     for (size_t i = 0; i < alpha; i++)
@@ -562,7 +565,9 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
       for (auto& t : terms) acc = host::g1_add(acc, t);
       comms[0] = host::g1_to_affine(acc);
     }
+    c.host_stamp("commit:linear");
     lasso_write_commitments(tr, comms);
+    c.host_stamp("commit:written");
   }
   lap(1);
 
@@ -646,7 +651,9 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
     c.gkr_hook = [&] { pcs.precommit(nv, small.data(), small.size(), evs.data(), evs.size()); };
 
   // ---- 2-7: Surge, memory checking, evaluations
+  c.host_stamp("argue:start");
   LassoClaims cl = lasso_argue(c, tb, n, w, d_dims, polys_n[0], E_fr, tr, lap, a_small);
+  c.host_stamp("argue:end");
   const std::vector<HFr>&r = cl.r, &r_z = cl.r_z, &r_N = cl.r_N, &r_M = cl.r_M, &ev_n = cl.ev_n, &ev_l = cl.ev_l;
   const HFr& v = cl.v;
 
@@ -671,6 +678,8 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
     pcs.batch_open(nv, all.data(), all.size(), points.data(), 4, evs.data(), evs.size(), tr, small.data());
   }
   lap(6);
+  c.host_stamp("open:end");
+  c.host_stamps_print();
   ph[7] = 0;
   ph[8] = now_ms() - t0;
   c.phase_ev_pending = true;

@@ -1033,7 +1033,9 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, 
       hipLaunchKernelGGL(msm_window_sum_kernel, dim3(nshares), dim3(512), 0, c.stream, plan, seg_out, win_out, fin);
       if (!overlap_done) overlap_done = true, (*overlap)();  // (the device is busy with this batch: the caller's host work now)
       if (c.prof) c.sync();
+      c.host_stamp("msm:queued");
       c.wait_flag(seq);
+      c.host_stamp("msm:window_sums");
       }
       if (getenv("LH_MSM_DEBUG")) {
         uint32_t h_cnt[16];
@@ -1069,6 +1071,7 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, 
       memcpy(&out_host[base + j], &a, sizeof(G1Affine));
     };
     host_parallel_for(nj, combine);  // ~70 us of dependent doublings per job
+    c.host_stamp("msm:combined");
   }
 }
 

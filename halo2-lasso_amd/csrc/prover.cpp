@@ -669,14 +669,17 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
       // [round kernel -> all-gather of the partial sums -> sum and publish], all on the ctx's stream.  With factored eq
       // tables the partial sums are those of q (this rank's eq-level entries carry its factor of the shard coordinates).
       const size_t R = (size_t)c.comm.size;
+      const bool lanes = c.opt.comm_round != 0;  // ONE collective per round: all-reduce of u64 lanes (comm.cpp comm_sum_lanes)
       if (!d_part) {
         d_part = c.arena.alloc_n<Fr>(16);
-        d_all = c.arena.alloc_n<Fr>(16 * R);
+        d_all = c.arena.alloc_n<Fr>(std::max<size_t>(16 * R, 64));  // (the lanes variant: 2 x 16 sums of 8 u64 = 2 KB)
       }
       // (the device buffers hold 16 sums: degree <= 6, at most SC_OPEN_MAX_TERMS = 6 factored terms)
       const size_t nvals = !ef_on ? (size_t)degree : ef->per_term ? 2 * ef->eqs.size() : (size_t)degree - 1;
       LH_REQUIRE(nvals >= 1 && nvals <= 16, LH_ERR_ARG, "sharded sum-check: too many partial sums per round");
       c.sc_redirect = d_part;
+      uint64_t* d_lanes = (uint64_t*)d_all;  // [0, 128): this rank's lanes, [128, 256): the sums (comm_round 2)
+      if (lanes) c.sc_wide = d_lanes, c.sc_tag = comm_next_tag(c);
       try {
         if (ef_on) {
           ef->add_const = HFr::zero();
@@ -686,15 +689,19 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
           round_fn(cur.data(), dst.data(), dev(r_prev), bind, size, evals_host);
         }
       } catch (...) {
-        c.sc_redirect = nullptr;
+        c.sc_redirect = nullptr, c.sc_wide = nullptr;
         throw;
       }
-      c.sc_redirect = nullptr;
+      c.sc_redirect = nullptr, c.sc_wide = nullptr;
       c.route.v[RouteStats::SHARDED_ROUNDS]++;
       c.route.v[factored_round ? RouteStats::EF_ROUNDS : RouteStats::STD_ROUNDS]++;
-      const uint32_t seq = c.next_seq();
-      comm_sum_publish(c, d_part, d_all, nvals, evals_host, seq);
-      c.wait_flag(seq);
+      if (lanes) {
+        comm_sum_lanes(c, d_lanes, d_lanes + 128, nvals, evals_host);
+      } else {
+        const uint32_t seq = c.next_seq();
+        comm_sum_publish(c, d_part, d_all, nvals, evals_host, seq);
+        c.wait_flag(seq);
+      }
       if (factored_round && !ef->per_term)  // (constants the factored kernel leaves to the host: the eq level sums to one)
         for (size_t x = 0; x < nvals; x++) evals_host[x] = dev(hst(evals_host[x]) + ef->add_const);
     } else if (ef_on) {
@@ -2195,12 +2202,16 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
       fprintf(stderr, "[open] column-wise commitment of level %zu (depth %zu of %zu) differs from the plain one\n",
               plan->levels[d].level, d, depth);
   }
+  c.host_stamp("open:columns");
   download(c, &remainder, rem, sizeof(Fr));
+  c.host_stamp("open:remainder");
   // what every rank holds is the commitment of its part of each quotient - its shard of a sharded level (column-wise
   // levels: of its share of the columns, offset term included - everything above is linear in the bases), its range of a
   // replicated one -> their sums, one exchange
   if (sharded) comm_sum_points(c, comms.data(), num_vars);
+  c.host_stamp("open:summed");
   tr.write_commitments(comms);  // identity -> Error::Transcript (transcript.rs:172-179,216-219)
+  c.host_stamp("open:written");
   return remainder;
 }
 

@@ -11,6 +11,21 @@ __device__ __forceinline__ void publish_flag(uint32_t* flag, uint32_t seq) {
   __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// the closing step of a round kernel, by the ONE thread that publishes, once the launch's D sums are in f.out_host and
+// visible to it (its own stores, or the workgroup's before a barrier).  Sharded rounds of the all-reduce variant
+// (ScFinishArgs::wide): the sums leave a second time as tagged u64 lanes - re-read with agent-scope loads, the stores
+// may be another wave's.
+__device__ __forceinline__ void publish_round(const ScFinishArgs& f, int D) {
+  if (f.wide) {
+    for (int x = 0; x < D; x++)
+      for (int k = 0; k < 8; k++) {
+        const uint32_t limb = __hip_atomic_load(&f.out_host[x].l[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        f.wide[8 * x + k] = (uint64_t)limb | ((uint64_t)f.tag << SC_LANE_TAG_SHIFT);
+      }
+  }
+  publish_flag(f.flag, f.seq);
+}
+
 __device__ __forceinline__ Fr shfl_xor_fr(const Fr& v, int mask) {
   Fr o;
 #pragma unroll

@@ -281,6 +281,13 @@ lh_status lh_lasso_last_timing(lh_ctx*, double* out_ms);
  *                             ~205 instead of ~310 instructions per Montgomery product, x1.15 on the mixed addition's
  *                             arithmetic in isolation, but 0.95x inside the accumulation kernel (one wave of occupancy
  *                             less for the gathers): measured neutral-to-negative, off by default
+ *   comm_round           0    how the partial sums of a sharded sum-check round are combined over the ranks:
+ *                             0 = ncclAllGather of every rank's sums + a one-thread sum-and-publish kernel;
+ *                             1 = ONE collective: the round kernel leaves its sums as u64 lanes (32-bit limb | tag << 40),
+ *                                 ncclAllReduce(ncclSum, ncclUint64) adds them straight into the pinned memory the host
+ *                                 polls (a lane whose upper bits read R * tag is finished), the host reduces mod r;
+ *                             2 = the same all-reduce into device memory, then a copy to the host.
+ *                             Same proof bytes; which is faster has never been measured on more than one GPU
  * Values outside an option's range are refused (LH_ERR_ARG).
  * lh_lasso_last_route reports which of these routes the last Lasso prove on the ctx actually took, so that a byte
  * mismatch in the field can be bisected from the outside. */

@@ -45,6 +45,8 @@ WORKER = textwrap.dedent("""
     hl.attach_comm(ctx, rank, world, hdist.host_all_gather(d), cfg["shard_bit"])
     if "xlog" in cfg:                        # when the residual tables of a sharded sum-check travel (0: at the last moment)
         hl.set_option(ctx, "shard_exchange_log", cfg["xlog"])
+    if "comm_round" in cfg:                  # 1 / 2: the rounds' partial sums by ONE all-reduce of u64 lanes (lasso_hip.h)
+        hl.set_option(ctx, "comm_round", cfg["comm_round"])
     t = hl.Keccak256Transcript()
     hl.lasso_prove_sharded(pp, table, cfg["n"], d_dims, t)
     # (to a file: a proof of this size does not fit a pipe's buffer, and the parent reads the pipes only at the end)
@@ -135,6 +137,37 @@ def test_sharded_proof_equals_single_gpu_and_oracle(tmp_path, world, kind, c, l,
     o_lasso.verify(opp, spec, n, OT(ot.into_proof()))
 
 
+@pytest.mark.parametrize("world,kind,c,l,n,shard_bit,comm_round", [(2, "range", 2, 3, 9, 5, 1), (4, "xor", 3, 4, 7, 3, 1),
+                                                                   (8, "and", 2, 4, 9, 2, 1), (2, "nonlinear", 3, 4, 9, 3, 2)])
+def test_sharded_rounds_by_all_reduce_equal_the_specification(tmp_path, world, kind, c, l, n, shard_bit, comm_round):
+    """Option comm_round: every sharded sum-check round combines its partial sums by ONE all-reduce of
+    u64 lanes (32-bit limb | tag << 40; over gloo the lanes are all-gathered through the host and added there - the same
+    lanes, the same self-validating wait, the same lazy reduction mod r) instead of all-gather + sum-and-publish kernel:
+    same proof bytes as the Python specification, on 2 / 4 / 8 ranks, with every sum-check kept sharded to the last moment."""
+    from oracle.pyref import lasso as o_lasso, kzg as o_kzg
+    from oracle.pyref.field import R_MOD
+    from oracle.pyref.transcript import Keccak256Transcript as OT
+    seed = zlib.crc32(repr((world, kind, c, l, n, "lanes")).encode())
+    cfg = dict(seed=seed, kind=kind, c=c, l=l, n=n, shard_bit=shard_bit, xlog=0, comm_round=comm_round)
+    outs = run_ranks(tmp_path, world, cfg, 29300 + (seed % 150))
+    proofs = {o["proof"] for o in outs}
+    assert len(proofs) == 1, "ranks disagree on the proof"
+    assert all(o["route"]["sharded_rounds"] > 0 for o in outs)
+    rng = random.Random(seed)
+    ss = [rng.randrange(R_MOD) for _ in range(n)]
+    dims = [[rng.randrange(1 << l) for _ in range(1 << n)] for _ in range(c)]
+    if kind == "nonlinear":
+        import halo2_lasso_amd as hl
+        from test_gpu_parity import _nonlinear_tables
+        spec = _nonlinear_tables(hl, c, l)[0]
+    else:
+        spec = o_lasso.range_table(c, l) if kind == "range" else o_lasso.bitwise_table(
+            o_lasso.SUBTABLE_AND if kind == "and" else o_lasso.SUBTABLE_XOR, c, l)
+    ot = OT()
+    o_lasso.prove(o_kzg.setup(ss), spec, dims, ot)
+    assert proofs.pop() == ot.into_proof().hex()
+
+
 LARGE = [
     # world, kind, c, l, n, shard_bit, xlog: the streaming kernels on shards - eq-factored rounds, the read/write leaf
     # kernel, packed and derived commitments, the column-wise top quotient - checked against the C++ oracle
@@ -152,6 +185,8 @@ def test_sharded_proof_large_vs_cpp_oracle(tmp_path, world, kind, c, l, n, shard
     cfg = dict(seed=seed, kind=kind, c=c, l=l, n=n, shard_bit=shard_bit)
     if xlog is not None:
         cfg["xlog"] = xlog
+    if world == 2:
+        cfg["comm_round"] = 1  # (the streaming kernels' epilogues write the all-reduce variant's lanes at this size)
     outs = run_ranks(tmp_path, world, cfg, 29900 + (seed % 90))
     proofs = {o["proof"] for o in outs}
     assert len(proofs) == 1, "ranks disagree on the proof"
@@ -260,10 +295,13 @@ def test_full_size_configs_sharded_on_one_gpu(tmp_path, hl, ctx, world, kind, n)
         assert r["open_precommit"] == 1, r  # the shard's column-wise commitments ran on the helper ctx beside the sum-checks
 
 
-def test_sharded_world1_over_rccl(hl, ctx):
+@pytest.mark.parametrize("comm_round", [0, 1, 2])
+def test_sharded_world1_over_rccl(hl, ctx, comm_round):
     """The RCCL transport on the one GPU of the test box: a world of ONE rank runs the whole sharded prover - every
-    exchange an ncclAllGather on the prover's stream followed by the sum-and-publish kernel - and must give the bytes
-    of lasso_prove.  Asserts that the device-side path was taken and nothing went through a host callback."""
+    exchange an ncclAllGather on the prover's stream followed by the sum-and-publish kernel (comm_round 0), or every
+    round's sums by ONE ncclAllReduce of u64 lanes into the pinned memory the host polls (1) / into device memory and a
+    copy (2) - and must give the bytes of lasso_prove.  Asserts that the device-side path was taken and nothing went
+    through a host callback."""
     import numpy as np
     n, shard_bit = 18, 16  # (a world of one: rho = 0, the replicated subtables need shard_bit >= 16, the tables two more variables)
     table = hl.LassoTable.bitwise(hl.SUBTABLE_XOR, 4, 16)
@@ -274,11 +312,13 @@ def test_sharded_world1_over_rccl(hl, ctx):
     single = hl.Keccak256Transcript()
     hl.lasso_prove(pp, table, n, dims, single)
     hl.attach_comm_rccl(ctx, 0, 1, hl.rccl_unique_id(), shard_bit)
+    hl.set_option(ctx, "comm_round", comm_round)
     try:
         t = hl.Keccak256Transcript()
         hl.lasso_prove_sharded(pp, table, n, dims, t)
         stats = hl.comm_stats(ctx)
     finally:
+        hl.set_option(ctx, "comm_round", 0)
         hl.detach_comm(ctx)
     assert t.into_proof() == single.into_proof()
     assert stats["device"] >= 15 and stats["host"] == 0, stats
