@@ -373,40 +373,79 @@ struct HostJob {
 struct HostPool {
   std::mutex mu;
   std::condition_variable cv;
-  uint64_t gen = 0;
+  std::atomic<uint64_t> gen{0};
+  uint64_t spin_gen = 0;       // bumped by prewake(): `spin_want` sleeping workers wake up and poll `gen` until `spin_until`
+  int spin_want = 0;
+  std::chrono::steady_clock::time_point spin_until;
+  std::atomic<int> spinning{0};
   std::shared_ptr<HostJob> job;
+  unsigned workers = 0;
   HostPool() {
     unsigned hw = std::thread::hardware_concurrency();
     // (an MSM batch hands ~25-40 window combines of ~70 us each to this pool at the end of a commit or an opening - the
     // GPU idles meanwhile: one round of them, not three, where the host has the cores; LH_HOST_THREADS overrides)
     unsigned cap = 47;
     if (const char* e = getenv("LH_HOST_THREADS")) cap = (unsigned)std::max(0, atoi(e) - 1);
-    unsigned workers = hw > 1 ? std::min(cap, hw - 1) : 0;
+    workers = hw > 1 ? std::min(cap, hw - 1) : 0;
     for (unsigned i = 0; i < workers; i++) std::thread([this] { worker(); }).detach();
   }
   void worker() {
-    uint64_t seen = 0;
+    uint64_t seen = 0, seen_spin = 0;
     for (;;) {
       std::shared_ptr<HostJob> mine;
+      bool spin = false;
+      std::chrono::steady_clock::time_point until;
       {
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return gen != seen; });
-        seen = gen;
-        mine = job;
+        cv.wait(lk, [&] { return gen.load(std::memory_order_relaxed) != seen || (spin_gen != seen_spin && spin_want > 0); });
+        if (gen.load(std::memory_order_relaxed) != seen) {
+          seen = gen.load(std::memory_order_relaxed);
+          seen_spin = spin_gen;
+          mine = job;
+        } else {  // woken ahead of a job that is about to come: poll for it instead of sleeping through its arrival
+          seen_spin = spin_gen;
+          spin_want--;
+          spin = true;
+          until = spin_until;
+        }
+      }
+      if (spin) {
+        spinning.fetch_add(1, std::memory_order_relaxed);
+        while (gen.load(std::memory_order_acquire) == seen && std::chrono::steady_clock::now() < until) __builtin_ia32_pause();
+        spinning.fetch_sub(1, std::memory_order_relaxed);
+        continue;  // (takes the job under the lock if one came, sleeps again otherwise)
       }
       if (mine) mine->run();
     }
+  }
+  // a parallel_for of about `count` items will be posted within `us` microseconds: have workers awake and polling by then
+  // (waking a sleeping thread costs the poster ~50 us of the ~70 us an item takes)
+  void prewake(size_t count, unsigned us) {
+    if (!workers || count <= 1) return;
+    const int want = (int)std::min<size_t>(count - 1, workers) - spinning.load(std::memory_order_relaxed);
+    if (want <= 0) return;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      spin_gen++;
+      spin_want = want;
+      spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(us);
+    }
+    if (want >= (int)workers) cv.notify_all();
+    else
+      for (int i = 0; i < want; i++) cv.notify_one();
   }
   void parallel_for(size_t count, const std::function<void(size_t)>& f) {
     auto j = std::make_shared<HostJob>();
     j->fn = f;  // a copy: the job outlives the caller's frame for workers that wake late
     j->n = count;
+    const bool enough_awake = (size_t)spinning.load(std::memory_order_relaxed) + 1 >= count;
     {
       std::lock_guard<std::mutex> lk(mu);
       job = j;
-      gen++;
+      gen.fetch_add(1, std::memory_order_release);
+      spin_want = 0;
     }
-    cv.notify_all();
+    if (!enough_awake) cv.notify_all();  // (polling workers see `gen` move by themselves)
     j->run();
     while (j->done.load(std::memory_order_acquire) != count) __builtin_ia32_pause();
     {
@@ -417,13 +456,17 @@ struct HostPool {
 };
 }  // namespace
 
+static HostPool& host_pool() {
+  static HostPool* pool = new HostPool();  // never destroyed: workers sleep on the condition variable
+  return *pool;
+}
 void host_parallel_for(size_t n, const std::function<void(size_t)>& fn) {
   if (n <= 1) {
     for (size_t i = 0; i < n; i++) fn(i);
     return;
   }
-  static HostPool* pool = new HostPool();  // never destroyed: workers sleep on the condition variable
-  pool->parallel_for(n, fn);
+  host_pool().parallel_for(n, fn);
 }
+void host_parallel_prewake(size_t n, unsigned us) { host_pool().prewake(n, us); }
 
 }  // namespace lh

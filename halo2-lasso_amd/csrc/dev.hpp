@@ -331,6 +331,9 @@ struct ReplicatedRange {
 // Persistent host worker threads for the short host-side tails (window combines of an MSM batch): spawning
 // std::threads per call costs ~50 us each, more than the work itself.
 void host_parallel_for(size_t n, const std::function<void(size_t)>& fn);
+// a host_parallel_for over about n items follows within `us` microseconds: wake that many workers now and let them poll
+// for it (the poster otherwise pays the sleepers' wake-up, ~50 us, on the critical path between two kernels)
+void host_parallel_prewake(size_t n, unsigned us);
 
 struct ProfScope {
   Ctx& c;

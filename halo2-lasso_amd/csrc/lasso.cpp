@@ -556,11 +556,25 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
       if (tb.memory_subtable[i] == LH_SUBTABLE_IDENTITY) comms[1 + 2 * cc + i] = comms[1 + tb.memory_chunk[i]];
     if (linear_g) {
       std::vector<host::G1Xyzz> terms(tb.num_terms);
-      host_parallel_for(tb.num_terms, [&](size_t m) {
+      // (the coefficients of the range / AND / XOR tables are powers of two below 2^64: a few dozen doublings each, done
+      // here - waking the host pool for them cost more than they do; wide coefficients go to the pool)
+      bool small_coeffs = true;
+      for (uint32_t m = 0; m < tb.num_terms && small_coeffs; m++) {
+        HFr co;
+        memcpy(&co, &tb.g_coeff[m], 32);
+        uint64_t canon[4];
+        co.to_canonical(canon);
+        small_coeffs = !canon[1] && !canon[2] && !canon[3];
+      }
+      auto term = [&](size_t m) {
         HFr co;
         memcpy(&co, &tb.g_coeff[m], 32);
         terms[m] = host::g1_mul(host::g1_from_affine(comms[1 + 2 * cc + tb.g_factor[m][0]]), co);
-      });
+      };
+      if (small_coeffs)
+        for (size_t m = 0; m < tb.num_terms; m++) term(m);
+      else
+        host_parallel_for(tb.num_terms, term);
       host::G1Xyzz acc = host::G1Xyzz::identity();
       for (auto& t : terms) acc = host::g1_add(acc, t);
       comms[0] = host::g1_to_affine(acc);

@@ -1032,6 +1032,13 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, 
       const ScFinishArgs fin = c.finish_for(nshares, nullptr, seq);
       hipLaunchKernelGGL(msm_window_sum_kernel, dim3(nshares), dim3(512), 0, c.stream, plan, seg_out, win_out, fin);
       if (!overlap_done) overlap_done = true, (*overlap)();  // (the device is busy with this batch: the caller's host work now)
+      {
+        // the window combines follow when the device is through: workers awake and polling by then (batches of up to a few
+        // milliseconds; a longer one lets them sleep again and pays the wake-up, which then no longer matters)
+        size_t heavy_jobs = 0;
+        for (size_t j = 0; j < nj; j++) heavy_jobs += plan.job[j].red_W > 1 && !plan.job[j].pack_shift && !plan.job[j].merged;
+        if (heavy_jobs > 1 && !c.prof) host_parallel_prewake(heavy_jobs, 4000);
+      }
       if (c.prof) c.sync();
       c.host_stamp("msm:queued");
       c.wait_flag(seq);
@@ -1047,30 +1054,44 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, 
       }
       memcpy(wins.data(), win_out, nshares * sizeof(G1Xyzz));
     }
-    // 6: host combine  sum_w 2^(c*w) * win[w]  and normalise
-    auto combine = [&](size_t j) {
+    // 6: host combine  sum_w 2^(c*w) * win[w]  and normalise.  Jobs with doublings (~70 us of dependent doublings each)
+    // go to the host pool, the others (one window, packed pairs: a few additions) are done here; ONE inversion
+    // normalises every result of the batch (an inversion per job was ~10 us each, and a job's worth of wake-up for the
+    // pool when no job needed it)
+    std::vector<host::G1Xyzz> sums(2 * nj, host::G1Xyzz::identity());  // [2 j]: out[j], [2 j + 1]: out_second of a packed job
+    auto share_sum = [&](const MsmJobDev& jd, uint32_t w) {
+      host::G1Xyzz acc = host::G1Xyzz::identity();
+      for (uint32_t part = 0; part < jd.nsplit; part++)
+        acc = host::g1_add(acc, to_host(wins[(size_t)jd.share_base + (size_t)w * jd.nsplit + part]));
+      return acc;
+    };
+    std::vector<size_t> heavy;
+    for (size_t j = 0; j < nj; j++) {
       const MsmJobDev& jd = plan.job[j];
       if (jd.pack_shift) {  // the two "windows" are the two results
-        for (uint32_t v = 0; v < 2; v++) {
-          host::G1Xyzz acc = host::G1Xyzz::identity();
-          if (jd.red_W)
-            for (uint32_t part = 0; part < jd.nsplit; part++)
-              acc = host::g1_add(acc, to_host(wins[(size_t)jd.share_base + (size_t)v * jd.nsplit + part]));
-          host::G1Affine a = host::g1_to_affine(acc);
-          memcpy(v == 0 ? &out_host[base + j] : jobs[base + j].out_second, &a, sizeof(G1Affine));
-        }
-        return;
+        if (jd.red_W) sums[2 * j] = share_sum(jd, 0), sums[2 * j + 1] = share_sum(jd, 1);
+      } else if (jd.red_W <= 1 || jd.merged) {  // (a window table's job has one "window": no doublings)
+        if (jd.red_W) sums[2 * j] = share_sum(jd, 0);
+      } else {
+        heavy.push_back(j);
       }
+    }
+    host_parallel_for(heavy.size(), [&](size_t k) {
+      const size_t j = heavy[k];
+      const MsmJobDev& jd = plan.job[j];
       host::G1Xyzz acc = host::G1Xyzz::identity();
-      for (int w = (int)jd.red_W - 1; w >= 0; w--) {  // (a window table's job has one "window": no doublings)
-        for (uint32_t k = 0; k < jd.c && !jd.merged; k++) acc = host::g1_dbl(acc);
-        for (uint32_t part = 0; part < jd.nsplit; part++)
-          acc = host::g1_add(acc, to_host(wins[(size_t)jd.share_base + (size_t)w * jd.nsplit + part]));
+      for (int w = (int)jd.red_W - 1; w >= 0; w--) {
+        for (uint32_t q = 0; q < jd.c; q++) acc = host::g1_dbl(acc);
+        acc = host::g1_add(acc, share_sum(jd, (uint32_t)w));
       }
-      host::G1Affine a = host::g1_to_affine(acc);
-      memcpy(&out_host[base + j], &a, sizeof(G1Affine));
-    };
-    host_parallel_for(nj, combine);  // ~70 us of dependent doublings per job
+      sums[2 * j] = acc;
+    });
+    std::vector<host::G1Affine> aff(2 * nj);
+    host::g1_batch_to_affine(sums.data(), 2 * nj, aff.data());
+    for (size_t j = 0; j < nj; j++) {
+      memcpy(&out_host[base + j], &aff[2 * j], sizeof(G1Affine));
+      if (plan.job[j].pack_shift) memcpy(jobs[base + j].out_second, &aff[2 * j + 1], sizeof(G1Affine));
+    }
     c.host_stamp("msm:combined");
   }
 }
