@@ -215,16 +215,18 @@ void comm_all_gather_host(Ctx& c, const void* send, void* recv, size_t bytes) {
   c.d2h(recv, d + bytes, bytes * R);
 }
 
-// Personalised exchange (the sharded access counters: lookups to their address owners and the ranks back).  RCCL:
-// grouped ncclSend / ncclRecv on the ctx's stream - on xGMI's full mesh every pair of GPUs has its own link, so an
-// all-to-all costs each link 1/(R-1) of a rank's traffic.  Callback transports have no point-to-point primitive: every
-// rank's whole send buffer is all-gathered and the segments meant for this rank are picked out (tests only).
-void comm_all_to_all_v(Ctx& c, const void* d_send, const size_t* send_off, const size_t* send_cnt, void* d_recv,
-                       const size_t* recv_off, const size_t* recv_cnt, const size_t* peer_off, size_t send_span, size_t elem) {
+// Personalised exchange (the sharded access counters: lookups to their address owners and the ranks back), all chunk
+// columns in ONE collective.  RCCL: grouped ncclSend / ncclRecv on the ctx's stream - on xGMI's full mesh every pair of GPUs
+// has its own link, so an all-to-all costs each link 1/(R-1) of a rank's traffic.  Callback transports have no
+// point-to-point primitive: every rank's whole send allocation is all-gathered and the segments meant for this rank are
+// picked out (tests only).
+void comm_all_to_all_multi(Ctx& c, size_t nbuf, const void* const* d_send, const size_t* send_off, const size_t* send_cnt,
+                           void* const* d_recv, const size_t* recv_off, const size_t* recv_cnt, const size_t* peer_off,
+                           const void* send_base, size_t send_stride, size_t elem) {
   require_comm(c);
   const size_t R = (size_t)c.comm.size, me = (size_t)c.comm.rank;
   size_t total = 0;
-  for (size_t p = 0; p < R; p++) total += send_cnt[p] + recv_cnt[p];
+  for (size_t q = 0; q < nbuf * R; q++) total += send_cnt[q] + recv_cnt[q];
   comm_trace(c, "all_to_all_v", total * elem);
   // LH_COMM_A2A=allgather: stage the personalised exchange through ncclAllGather under RCCL as well (a fallback should
   // grouped send / recv misbehave on some fabric; R times the traffic)
@@ -243,31 +245,39 @@ void comm_all_to_all_v(Ctx& c, const void* d_send, const size_t* send_off, const
     const RcclApi& api = rccl();
     c.comm_stats[0]++;
     // (the segment a rank keeps for itself is a device copy: no self-send)
-    if (send_cnt[me] && !a2a_self)
-      LH_HIP(hipMemcpyAsync((char*)d_recv + recv_off[me] * elem, (const char*)d_send + send_off[me] * elem, send_cnt[me] * elem,
-                            hipMemcpyDeviceToDevice, c.stream));
+    if (!a2a_self)
+      for (size_t b = 0; b < nbuf; b++)
+        if (send_cnt[b * R + me])
+          LH_HIP(hipMemcpyAsync((char*)d_recv[b] + recv_off[b * R + me] * elem, (const char*)d_send[b] + send_off[b * R + me] * elem,
+                                send_cnt[b * R + me] * elem, hipMemcpyDeviceToDevice, c.stream));
     if (R > 1 || a2a_self) {
       rccl_check(api.GroupStart(), "ncclGroupStart");
+      // (sends and receives between a pair of ranks match in the order they are issued: buffer by buffer on both sides)
       for (size_t p = 0; p < R; p++) {
         if (p == me && !a2a_self) continue;
-        if (send_cnt[p])
-          rccl_check(api.Send((const char*)d_send + send_off[p] * elem, send_cnt[p] * elem, ncclUint8, (int)p,
-                              (ncclComm_t)c.rccl_comm, c.stream), "ncclSend");
-        if (recv_cnt[p])
-          rccl_check(api.Recv((char*)d_recv + recv_off[p] * elem, recv_cnt[p] * elem, ncclUint8, (int)p,
-                              (ncclComm_t)c.rccl_comm, c.stream), "ncclRecv");
+        for (size_t b = 0; b < nbuf; b++) {
+          if (send_cnt[b * R + p])
+            rccl_check(api.Send((const char*)d_send[b] + send_off[b * R + p] * elem, send_cnt[b * R + p] * elem, ncclUint8, (int)p,
+                                (ncclComm_t)c.rccl_comm, c.stream), "ncclSend");
+          if (recv_cnt[b * R + p])
+            rccl_check(api.Recv((char*)d_recv[b] + recv_off[b * R + p] * elem, recv_cnt[b * R + p] * elem, ncclUint8, (int)p,
+                                (ncclComm_t)c.rccl_comm, c.stream), "ncclRecv");
+        }
       }
       rccl_check(api.GroupEnd(), "ncclGroupEnd");
     }
     return;
   }
   ArenaScope scope(c.arena);
-  char* all = (char*)c.arena.alloc(std::max<size_t>(send_span * elem * R, 256));
-  comm_all_gather_dev(c, d_send, all, send_span * elem);
-  for (size_t p = 0; p < R; p++)
-    if (recv_cnt[p])
-      LH_HIP(hipMemcpyAsync((char*)d_recv + recv_off[p] * elem, all + (p * send_span + peer_off[p]) * elem, recv_cnt[p] * elem,
-                            hipMemcpyDeviceToDevice, c.stream));
+  const size_t span = nbuf * send_stride;  // elements of a rank's send allocation
+  char* all = (char*)c.arena.alloc(std::max<size_t>(span * elem * R, 256));
+  comm_all_gather_dev(c, send_base, all, span * elem);
+  for (size_t b = 0; b < nbuf; b++)
+    for (size_t p = 0; p < R; p++)
+      if (recv_cnt[b * R + p])
+        LH_HIP(hipMemcpyAsync((char*)d_recv[b] + recv_off[b * R + p] * elem,
+                              all + (p * span + b * send_stride + peer_off[b * R + p]) * elem, recv_cnt[b * R + p] * elem,
+                              hipMemcpyDeviceToDevice, c.stream));
   c.sync();  // (`all` is released with the scope)
 }
 

@@ -259,7 +259,8 @@ struct Ctx {
   uint32_t* flag = nullptr;  // pinned, coherent
   uint32_t flag_seq = 0;
   uint32_t* ticket = nullptr;  // device counter for in-launch final reductions; only ever grows (word 8: device flag;
-                               // words 32..47: the resident tail's relay chunks)
+                               // word 10: the resident grand-product kernel's start verdict; words 32..47: the resident
+                               // tail's relay chunks)
   uint32_t ticket_base = 0;    // its value before the next launch
   struct ScFinishArgs finish_for(uint32_t grid, Fr* out_host, uint32_t seq);
   uint32_t next_seq() { return ++flag_seq; }
@@ -423,15 +424,16 @@ void k_pack_u32(Ctx&, const uint32_t* a, const uint32_t* b, uint32_t shift, size
 void k_delta_u32(Ctx&, const uint32_t* col, size_t len, size_t half, uint64_t offset, uint32_t* out_lo, uint32_t* out_hi);
 void k_lasso_counters(Ctx&, const uint32_t* dim, size_t n, size_t m, uint32_t* read_ts, uint32_t* final_cts,
                       uint32_t* keep_sorted = nullptr, uint32_t* keep_index = nullptr);
-// the sharded counters' steps (lasso.cpp lasso_counters_sharded): partition the local lookups by address owner (sidx: local
-// indices in send order; send: (address on the owner) << n_bits | global index; start_host[o]: first send position of
-// owner o, R + 1 entries), rank the received lookups on the owner, scatter the returned ranks, assemble final_cts
-void k_cs_partition(Ctx&, const uint32_t* dim, size_t n, size_t m, unsigned rho, unsigned j, uint32_t rank, unsigned n_bits,
-                    uint32_t* sidx, uint64_t* send, uint32_t* start_host, bool* bad_out);
-void k_cs_rank(Ctx&, const uint64_t* recv, size_t n, unsigned n_bits, unsigned a_bits, size_t m_loc, uint32_t* ret,
-               uint32_t* counts);
-void k_cs_scatter(Ctx&, const uint32_t* back, const uint32_t* sidx, size_t n, uint32_t* read_ts);
-void k_cs_final(Ctx&, const uint32_t* all_counts, size_t m, unsigned rho, size_t m_loc, uint32_t* final_cts);
+// the sharded counters' steps (lasso.cpp lasso_counters_sharded), ALL `cc` chunk columns per call: partition the local
+// lookups by address owner (sidx[q]: local indices in send order; send[q]: (address on the owner) << hi_bits | local index >>
+// shard_bit; start_host[q * (R + 1) + o]: first send position of owner o in column q), rank the received lookups on the
+// owner (recv[q]: n_recv[q] keys, one segment per sender; counts: cc * m_loc), scatter the returned ranks, assemble final_cts
+void k_cs_partition(Ctx&, const uint32_t* const* dims, size_t cc, size_t n, size_t m, unsigned rho, unsigned j, unsigned hi_bits,
+                    uint32_t* const* sidx, uint32_t* const* send, uint32_t* start_host, bool* bad_out);
+void k_cs_rank(Ctx&, const uint32_t* const* recv, const size_t* n_recv, size_t cc, unsigned hi_bits, unsigned a_bits, size_t m_loc,
+               uint32_t* const* ret, uint32_t* counts);
+void k_cs_scatter(Ctx&, const uint32_t* const* back, const uint32_t* const* sidx, size_t cc, size_t n, uint32_t* const* read_ts);
+void k_cs_final(Ctx&, const uint32_t* all_counts, size_t cc, size_t m, unsigned rho, size_t m_loc, uint32_t* const* final_cts);
 void k_lasso_subtable_read(Ctx&, int subtable, uint32_t chunk_bits, const uint32_t* dim, size_t n, uint32_t* e);
 // a[k] = g(E_0[k],..): small-integer evaluation into Fr
 struct LassoG {
@@ -463,12 +465,15 @@ void comm_detach(Ctx&);
 // the communicator has no device collective); _host: host buffers, synchronous
 void comm_all_gather_dev(Ctx&, const void* d_send, void* d_recv, size_t bytes);
 void comm_all_gather_host(Ctx&, const void* send, void* recv, size_t bytes);
-// personalised exchange of device buffers (elements of `elem` bytes): this rank sends send_cnt[p] elements from
-// d_send + send_off[p] to every peer p and receives recv_cnt[p] from it at d_recv + recv_off[p].  peer_off[p]: where,
-// inside p's send buffer, the segment for this rank starts; send_span: elements every rank's send buffer spans at least
-// (equal on all ranks) - both only used by transports without point-to-point sends (staged through an all-gather).
-void comm_all_to_all_v(Ctx&, const void* d_send, const size_t* send_off, const size_t* send_cnt, void* d_recv,
-                       const size_t* recv_off, const size_t* recv_cnt, const size_t* peer_off, size_t send_span, size_t elem);
+// personalised exchange of `nbuf` device buffers at once (elements of `elem` bytes; the chunk columns of the sharded access
+// counters): from buffer b this rank sends send_cnt[b * R + p] elements at d_send[b] + send_off[b * R + p] to every peer p and
+// receives recv_cnt[b * R + p] from it at d_recv[b] + recv_off[b * R + p] - ONE collective (RCCL: one group of sends and
+// receives).  peer_off[b * R + p]: where, inside p's send buffer b, the segment for this rank starts; the send buffers are
+// slices of ONE allocation, buffer b at send_base + b * send_stride elements, the same stride on every rank - both only used
+// by transports without point-to-point sends (the whole allocation is staged through an all-gather).
+void comm_all_to_all_multi(Ctx&, size_t nbuf, const void* const* d_send, const size_t* send_off, const size_t* send_cnt,
+                           void* const* d_recv, const size_t* recv_off, const size_t* recv_cnt, const size_t* peer_off,
+                           const void* send_base, size_t send_stride, size_t elem);
 // v[i] = sum over the ranks of v[i], `count` field elements in a device buffer the ctx's stream owns; the sums are left in
 // out_host (pinned) followed by the flag `seq` (the closing steps of a sharded sum-check round)
 void comm_sum_publish(Ctx&, const Fr* d_part, Fr* d_scratch, size_t count, Fr* out_host, uint32_t seq);

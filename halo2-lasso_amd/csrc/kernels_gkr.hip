@@ -49,6 +49,8 @@ struct GkrResArgs {
   uint32_t* flag;
   uint64_t poll_ticks;
   uint64_t start_ticks;  // how long the workgroups wait for each other at the start before they give the launch up
+  uint32_t* start_word;  // device: the start verdict of the launch in progress, launch id << 1 | failed
+  uint32_t start_id;     // this launch's id (the first layer's sequence number: unique per launch on a ctx)
   uint64_t* trace;  // development (LH_GKR_TRACE): per layer 8 stamps, per round 8 stamps, of workgroup 0 / the sender
 };
 constexpr uint32_t GKR_TRACE_ROUNDS = 160;
@@ -81,20 +83,41 @@ __global__ __launch_bounds__(GKR_THREADS) void gkr_resident_kernel(GkrResArgs a)
     // un-dispatched for as long as the others wait for THEIR missing workgroups; so everybody signs in first, and if the
     // roll is not complete within `start_ticks` the kernel leaves before the transcript has seen anything of it
     // (GKR_START_FAILED: the host takes the launched path for these layers instead).
+    // The verdict is ONE word every workgroup agrees on (a.start_word = launch id << 1 | failed): the last arrival tries to
+    // set "go", a workgroup whose patience runs out (or that sees the host's abort) tries to set "failed", a compare-and-
+    // swap lets exactly one of them win, and everybody - late arrivals included - acts on what the word says.  (Deciding
+    // from the ticket count and an abort marker, as round 4 did, let a workgroup that saw the roll complete run on while a
+    // neighbour that had timed out a microsecond earlier was still writing its marker: messages of a launch that was
+    // about to die could reach the transcript.)
     if (tid == 0) {
-      __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const uint64_t t0 = wall_clock64();
-      uint32_t failed = 0;
-      while (__hip_atomic_load(a.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - tbase < gridDim.x) {
-        if (wall_clock64() - t0 > a.start_ticks || load_sys_x4(&a.relay[0]).x == SC_TAIL_ABORT) {
-          failed = 1;
-          break;
+      const uint32_t id = (a.start_id & 0x3fffffffu) | 0x40000000u;  // (never 0: the word's initial state is "undecided")
+      auto decide = [&](uint32_t failed) {  // returns the word as decided (by us or by somebody before us)
+        uint32_t cur = __hip_atomic_load(a.start_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while ((cur >> 1) != id) {
+          if (__hip_atomic_compare_exchange_strong(a.start_word, &cur, (id << 1) | failed, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT))
+            return (id << 1) | failed;
         }
-        __builtin_amdgcn_s_sleep(8);
+        return cur;
+      };
+      const uint32_t mine = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - tbase;
+      uint32_t word = 0;
+      if (mine == gridDim.x - 1) {
+        word = decide(0);  // the roll is complete
+      } else {
+        const uint64_t t0 = wall_clock64();
+        for (;;) {
+          word = __hip_atomic_load(a.start_word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          if ((word >> 1) == id) break;
+          if (wall_clock64() - t0 > a.start_ticks || load_sys_x4(&a.relay[0]).x == SC_TAIL_ABORT) {
+            word = decide(1);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(8);
+        }
       }
-      // (a workgroup that is dispatched after the others gave up finds the roll complete - and their mark)
-      if (!failed && load_sys_x4(&a.relay[0]).x == SC_TAIL_ABORT) failed = 1;
-      if (failed) {
+      const uint32_t failed = word & 1u;
+      if (failed) {  // (every workgroup that leaves says so: idempotent)
         store_sys_x4((void*)&a.relay[0], u32x4{SC_TAIL_ABORT, 0u, 0u, 0u});
         store_sys_x4((void*)&a.relay[4], u32x4{SC_TAIL_ABORT, 0u, 0u, 0u});
         store_sys_x4((void*)&a.msg_host[0], u32x4{GKR_START_FAILED, 0u, 0u, 0u});
@@ -130,7 +153,9 @@ __global__ __launch_bounds__(GKR_THREADS) void gkr_resident_kernel(GkrResArgs a)
         if (__syncthreads_and(ok)) break;
         const bool stop = (tid == 0 && (v.x == SC_TAIL_ABORT || wall_clock64() - t0 > a.poll_ticks));
         if (__syncthreads_or(stop)) {
-          if (i_poll && tid == 0) {
+          // (whoever gives up says so - the poller or a workgroup waiting for the relay: its peers and the host learn of
+          // it from the markers, not from timeouts of their own)
+          if (tid == 0) {
             store_sys_x4((void*)&a.relay[4], u32x4{SC_TAIL_ABORT, 0u, 0u, 0u});
             store_sys_x4((void*)&a.relay[0], u32x4{SC_TAIL_ABORT, 0u, 0u, 0u});
           }
@@ -414,6 +439,8 @@ void k_gkr_resident_launch(Ctx& c, const GkrLayerDev* layers, size_t num_layers,
   a.poll_ticks = (uint64_t)(ms * (double)c.wall_clock_khz);
   const char* smo = getenv("LH_GKR_START_TIMEOUT_MS");
   a.start_ticks = (uint64_t)((smo && *smo ? atof(smo) : 25.0) * (double)c.wall_clock_khz);
+  a.start_word = c.ticket + 10;  // (word 0: tickets, word 8: the sharded rounds' device flag, words 32..: the tail's relay)
+  a.start_id = layers[0].seq;    // (sequence numbers only grow: no two launches of a ctx share one)
   static const bool trace_on = getenv("LH_GKR_TRACE") != nullptr;
   a.trace = nullptr;
   if (trace_on) {

@@ -956,120 +956,172 @@ void k_lasso_counters(Ctx& c, const uint32_t* dim, size_t n, size_t m, uint32_t*
 }
 
 // ---- access counters of a sharded proof (dev.hpp Shard): the lookups of a column are repartitioned by ADDRESS (owner =
-// address mod R), the owner ranks every lookup of its addresses in the global lookup order, the ranks travel back.
-__global__ void cs_owner_keys_kernel(const uint32_t* __restrict__ dim, size_t n, size_t m, uint32_t owner_mask,
-                                     uint32_t* __restrict__ okey, uint32_t* __restrict__ idx, uint32_t* __restrict__ bad) {
+// address mod R), the owner ranks every lookup of its addresses in the global lookup order, the ranks travel back.  ALL
+// chunk columns of the table go through every step together (blockIdx.y = column, one batched sort): the steps and the
+// three exchanges are per proof, not per column.
+//
+// What travels is a 32-bit key per lookup, (address on the owner) << hi_bits | hi, hi = the bits of the GLOBAL lookup index
+// above the shard bits (= local index >> shard_bit).  An owner receives one segment per sender s, each in the sender's
+// local order, i.e. ascending (hi, lo): the receive buffer is ordered (s, hi, lo), and a STABLE sort by (address, hi)
+// leaves every address run in the order (hi, s, lo) - the global lookup order - without s or lo ever being sent.
+constexpr int CS_MAX_COLS = LH_LASSO_MAX_CHUNKS;
+struct CsCols {
+  const uint32_t* in[CS_MAX_COLS];
+  const uint32_t* in2[CS_MAX_COLS];
+  uint32_t* out[CS_MAX_COLS];
+  uint32_t* out2[CS_MAX_COLS];
+  uint32_t n[CS_MAX_COLS];
+};
+__global__ void cs_owner_keys_kernel(CsCols k, size_t n, size_t m, uint32_t owner_mask, uint32_t* __restrict__ bad) {
+  const uint32_t* __restrict__ dim = k.in[blockIdx.y];
+  uint32_t* __restrict__ okey = k.out[blockIdx.y];
   GSTRIDE(i, n) {
     const uint32_t a = dim[i];
     okey[i] = a & owner_mask;
-    idx[i] = (uint32_t)i;
     if (a >= m) *bad = 1u;
   }
 }
-// start[o] = first position of owner o in the owner-sorted list (left at `n` for owners that do not occur)
-__global__ void cs_owner_starts_kernel(const uint32_t* __restrict__ sown, size_t n, uint32_t* __restrict__ start) {
+// start[col][o] = first position of owner o in the owner-sorted list (left at `n` for owners that do not occur)
+__global__ void cs_owner_starts_kernel(CsCols k, size_t n, uint32_t R1, uint32_t* __restrict__ start) {
+  const uint32_t* __restrict__ sown = k.in[blockIdx.y];
   GSTRIDE(p, n)
-    if (p == 0 || sown[p - 1] != sown[p]) start[sown[p]] = (uint32_t)p;
+    if (p == 0 || sown[p - 1] != sown[p]) start[(size_t)blockIdx.y * R1 + sown[p]] = (uint32_t)p;
 }
-// send[p] = (address on its owner) << n_bits | global lookup index, in owner-sorted order (stable: within an owner the
-// lookups stay in local = global order)
-__global__ void cs_send_keys_kernel(const uint32_t* __restrict__ dim, const uint32_t* __restrict__ sidx, size_t n,
-                                    unsigned rho, unsigned j, uint32_t rank, unsigned n_bits, uint64_t* __restrict__ send) {
-  const uint64_t lo_mask = ((uint64_t)1 << j) - 1;
+// send[p] = (address on its owner) << hi_bits | (local index >> shard_bit), in owner-sorted order (stable: within an owner
+// the lookups stay in local order)
+__global__ void cs_send_keys_kernel(CsCols k, size_t n, unsigned rho, unsigned j, unsigned hi_bits) {
+  const uint32_t* __restrict__ dim = k.in[blockIdx.y];
+  const uint32_t* __restrict__ sidx = k.in2[blockIdx.y];
+  uint32_t* __restrict__ send = k.out[blockIdx.y];
   GSTRIDE(p, n) {
     const uint32_t li = sidx[p];
-    const uint64_t g = (((uint64_t)li >> j) << (j + rho)) | ((uint64_t)rank << j) | ((uint64_t)li & lo_mask);
-    send[p] = ((uint64_t)(dim[li] >> rho) << n_bits) | g;
+    send[p] = ((dim[li] >> rho) << hi_bits) | (li >> j);
   }
 }
-__global__ void cs_iota_kernel(uint32_t* __restrict__ out, size_t n) {
-  GSTRIDE(i, n) out[i] = (uint32_t)i;
-}
-__global__ void cs_run_start_kernel(const uint64_t* __restrict__ skey, size_t n, unsigned n_bits, uint32_t* __restrict__ start) {
+__global__ void cs_run_start_kernel(CsCols k, unsigned hi_bits, size_t m_loc, uint32_t* __restrict__ start) {
+  const uint32_t* __restrict__ skey = k.in[blockIdx.y];
+  const size_t n = k.n[blockIdx.y];
   GSTRIDE(i, n) {
-    const uint64_t a = skey[i] >> n_bits;
-    if (i == 0 || (skey[i - 1] >> n_bits) != a) start[a] = (uint32_t)i;
+    const uint32_t a = skey[i] >> hi_bits;
+    if (i == 0 || (skey[i - 1] >> hi_bits) != a) start[(size_t)blockIdx.y * m_loc + a] = (uint32_t)i;
   }
 }
 // ret[position in the receive buffer] = rank of the lookup among the lookups of its address; counts[a] = run length
-__global__ void cs_rank_kernel(const uint64_t* __restrict__ skey, const uint32_t* __restrict__ spos, size_t n, unsigned n_bits,
-                               const uint32_t* __restrict__ start, uint32_t* __restrict__ ret, uint32_t* __restrict__ counts) {
+__global__ void cs_rank_kernel(CsCols k, unsigned hi_bits, size_t m_loc, const uint32_t* __restrict__ start,
+                               uint32_t* __restrict__ counts) {
+  const uint32_t* __restrict__ skey = k.in[blockIdx.y];
+  const uint32_t* __restrict__ spos = k.in2[blockIdx.y];
+  uint32_t* __restrict__ ret = k.out[blockIdx.y];
+  const size_t n = k.n[blockIdx.y];
   GSTRIDE(i, n) {
-    const uint64_t a = skey[i] >> n_bits;
-    const uint32_t r = (uint32_t)i - start[a];
+    const uint32_t a = skey[i] >> hi_bits;
+    const uint32_t r = (uint32_t)i - start[(size_t)blockIdx.y * m_loc + a];
     ret[spos[i]] = r;
-    if (i + 1 == n || (skey[i + 1] >> n_bits) != a) counts[a] = r + 1;
+    if (i + 1 == n || (skey[i + 1] >> hi_bits) != a) counts[(size_t)blockIdx.y * m_loc + a] = r + 1;
   }
 }
-__global__ void cs_scatter_kernel(const uint32_t* __restrict__ back, const uint32_t* __restrict__ sidx, size_t n,
-                                  uint32_t* __restrict__ read_ts) {
+__global__ void cs_scatter_kernel(CsCols k, size_t n) {
+  const uint32_t* __restrict__ back = k.in[blockIdx.y];
+  const uint32_t* __restrict__ sidx = k.in2[blockIdx.y];
+  uint32_t* __restrict__ read_ts = k.out[blockIdx.y];
   GSTRIDE(p, n) read_ts[sidx[p]] = back[p];
 }
-// final_cts[a] = (owner a mod R).counts[a >> rho]
-__global__ void cs_final_kernel(const uint32_t* __restrict__ all_counts, size_t m, unsigned rho, size_t m_loc,
-                                uint32_t* __restrict__ final_cts) {
+// final_cts[col][a] = (owner a mod R).counts[col][a >> rho]; all_counts: rank-major blocks of cc * m_loc counts
+__global__ void cs_final_kernel(CsCols k, const uint32_t* __restrict__ all_counts, size_t m, unsigned rho, size_t m_loc, size_t cc) {
   const uint32_t mask = (1u << rho) - 1u;
-  GSTRIDE(a, m) final_cts[a] = all_counts[(size_t)(a & mask) * m_loc + (a >> rho)];
+  uint32_t* __restrict__ final_cts = k.out[blockIdx.y];
+  GSTRIDE(a, m) final_cts[a] = all_counts[((size_t)(a & mask) * cc + blockIdx.y) * m_loc + (a >> rho)];
+}
+static dim3 cs_grid(size_t n, size_t cc) {
+  dim3 g = grid_for(n);
+  g.y = (unsigned)cc;
+  return g;
 }
 
-void k_cs_partition(Ctx& c, const uint32_t* dim, size_t n, size_t m, unsigned rho, unsigned j, uint32_t rank, unsigned n_bits,
-                    uint32_t* sidx, uint64_t* send, uint32_t* start_host, bool* bad_out) {
-  ProfScope ps(c, "lasso_counters/partition", 24.0 * n, 0.0, (double)n);
+void k_cs_partition(Ctx& c, const uint32_t* const* dims, size_t cc, size_t n, size_t m, unsigned rho, unsigned j, unsigned hi_bits,
+                    uint32_t* const* sidx, uint32_t* const* send, uint32_t* start_host, bool* bad_out) {
+  LH_REQUIRE(cc >= 1 && cc <= (size_t)CS_MAX_COLS && n < ((size_t)1 << 32), LH_ERR_ARG, "sharded counters: bad shape");
+  ProfScope ps(c, "lasso_counters/partition", 16.0 * n * cc, 0.0, (double)(n * cc));
   ArenaScope scope(c.arena);
-  const size_t R = (size_t)1 << rho;
-  uint32_t* okey = c.arena.alloc_n<uint32_t>(n);
-  uint32_t* idx = c.arena.alloc_n<uint32_t>(n);
-  uint32_t* sown = c.arena.alloc_n<uint32_t>(n);
-  uint32_t* start = c.arena.alloc_n<uint32_t>(R + 1);
-  uint32_t* bad = start + R;
-  std::vector<uint32_t> init(R + 1, (uint32_t)n);
-  init[R] = 0;
-  LH_HIP(hipMemcpyAsync(start, init.data(), (R + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
-  hipLaunchKernelGGL(cs_owner_keys_kernel, grid_for(n), 256, 0, c.stream, dim, n, m, (uint32_t)(R - 1), okey, idx, bad);
-  if (rho) {
-    sort_pairs_u32(c, okey, sown, idx, sidx, n, rho);
-  } else {
-    LH_HIP(hipMemcpyAsync(sown, okey, n * 4, hipMemcpyDeviceToDevice, c.stream));
-    LH_HIP(hipMemcpyAsync(sidx, idx, n * 4, hipMemcpyDeviceToDevice, c.stream));
+  const size_t R = (size_t)1 << rho, R1 = R + 1;
+  uint32_t* okey = c.arena.alloc_n<uint32_t>(cc * n);
+  uint32_t* sown = c.arena.alloc_n<uint32_t>(cc * n);
+  uint32_t* start = c.arena.alloc_n<uint32_t>(cc * R1 + 1);
+  uint32_t* bad = start + cc * R1;
+  std::vector<uint32_t> init(cc * R1 + 1, (uint32_t)n);
+  init[cc * R1] = 0;
+  LH_HIP(hipMemcpyAsync(start, init.data(), init.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
+  CsCols k;
+  memset(&k, 0, sizeof(k));
+  for (size_t q = 0; q < cc; q++) k.in[q] = dims[q], k.out[q] = okey + q * n;
+  hipLaunchKernelGGL(cs_owner_keys_kernel, cs_grid(n, cc), 256, 0, c.stream, k, n, m, (uint32_t)(R - 1), bad);
+  {  // stable sort by owner, values = local positions: ONE batch for all columns
+    std::vector<SortSlab> slabs;
+    for (size_t q = 0; q < cc; q++) slabs.push_back(SortSlab{okey + q * n, sown + q * n, nullptr, sidx[q], n, std::max(rho, 1u)});
+    sort_pairs_u32_batched(c, slabs.data(), slabs.size());
   }
-  hipLaunchKernelGGL(cs_owner_starts_kernel, grid_for(n), 256, 0, c.stream, sown, n, start);
-  hipLaunchKernelGGL(cs_send_keys_kernel, grid_for(n), 256, 0, c.stream, dim, sidx, n, rho, j, rank, n_bits, send);
-  std::vector<uint32_t> h(R + 1);
-  c.d2h(h.data(), start, (R + 1) * sizeof(uint32_t));  // (synchronises: `init` may go)
+  for (size_t q = 0; q < cc; q++) k.in[q] = sown + q * n;
+  hipLaunchKernelGGL(cs_owner_starts_kernel, cs_grid(n, cc), 256, 0, c.stream, k, n, (uint32_t)R1, start);
+  for (size_t q = 0; q < cc; q++) k.in[q] = dims[q], k.in2[q] = sidx[q], k.out[q] = send[q];
+  hipLaunchKernelGGL(cs_send_keys_kernel, cs_grid(n, cc), 256, 0, c.stream, k, n, rho, j, hi_bits);
+  std::vector<uint32_t> h(cc * R1 + 1);
+  c.d2h(h.data(), start, h.size() * sizeof(uint32_t));  // (synchronises: `init` may go)
   // (an index >= 2^chunk_bits: NOT raised here - this rank's peers are about to enter a collective and would wait forever;
   // the caller lets the verdict travel with the segment boundaries and raises on every rank)
-  *bad_out = h[R] != 0;
-  // owners that do not occur start where the next one does
-  uint32_t next = (uint32_t)n;
-  for (size_t o = R; o-- > 0;) {
-    if (h[o] == (uint32_t)n) h[o] = next;
-    next = h[o];
+  *bad_out = h[cc * R1] != 0;
+  for (size_t q = 0; q < cc; q++) {
+    // owners that do not occur start where the next one does
+    uint32_t next = (uint32_t)n;
+    for (size_t o = R; o-- > 0;) {
+      if (h[q * R1 + o] == (uint32_t)n) h[q * R1 + o] = next;
+      next = h[q * R1 + o];
+    }
+    for (size_t o = 0; o < R; o++) start_host[q * R1 + o] = h[q * R1 + o];
+    start_host[q * R1 + R] = (uint32_t)n;
   }
-  for (size_t o = 0; o < R; o++) start_host[o] = h[o];
-  start_host[R] = (uint32_t)n;
 }
 
-void k_cs_rank(Ctx& c, const uint64_t* recv, size_t n, unsigned n_bits, unsigned a_bits, size_t m_loc, uint32_t* ret,
-               uint32_t* counts) {
-  ProfScope ps(c, "lasso_counters/rank", 28.0 * n, 0.0, (double)n);
+void k_cs_rank(Ctx& c, const uint32_t* const* recv, const size_t* n_recv, size_t cc, unsigned hi_bits, unsigned a_bits, size_t m_loc,
+               uint32_t* const* ret, uint32_t* counts) {
+  LH_REQUIRE(cc >= 1 && cc <= (size_t)CS_MAX_COLS && hi_bits + a_bits <= 32, LH_ERR_ARG, "sharded counters: bad shape");
+  size_t total = 0, n_max = 0;
+  for (size_t q = 0; q < cc; q++) total += n_recv[q], n_max = std::max(n_max, n_recv[q]);
+  ProfScope ps(c, "lasso_counters/rank", 24.0 * total, 0.0, (double)total);
   ArenaScope scope(c.arena);
-  LH_HIP(hipMemsetAsync(counts, 0, m_loc * sizeof(uint32_t), c.stream));
-  if (!n) return;
-  uint32_t* pos = c.arena.alloc_n<uint32_t>(n);
-  uint32_t* spos = c.arena.alloc_n<uint32_t>(n);
-  uint64_t* skey = c.arena.alloc_n<uint64_t>(n);
-  uint32_t* start = c.arena.alloc_n<uint32_t>(m_loc);
-  hipLaunchKernelGGL(cs_iota_kernel, grid_for(n), 256, 0, c.stream, pos, n);
-  sort_pairs_u64(c, recv, skey, pos, spos, n, n_bits + a_bits);
-  hipLaunchKernelGGL(cs_run_start_kernel, grid_for(n), 256, 0, c.stream, skey, n, n_bits, start);
-  hipLaunchKernelGGL(cs_rank_kernel, grid_for(n), 256, 0, c.stream, skey, spos, n, n_bits, start, ret, counts);
+  LH_HIP(hipMemsetAsync(counts, 0, cc * m_loc * sizeof(uint32_t), c.stream));
+  if (!total) return;
+  LH_REQUIRE(n_max < ((size_t)1 << 32), LH_ERR_ARG, "sharded counters: too many lookups on one owner");
+  uint32_t* skey = c.arena.alloc_n<uint32_t>(total);
+  uint32_t* spos = c.arena.alloc_n<uint32_t>(total);
+  uint32_t* start = c.arena.alloc_n<uint32_t>(cc * m_loc);
+  CsCols k;
+  memset(&k, 0, sizeof(k));
+  std::vector<SortSlab> slabs;
+  size_t off = 0;
+  for (size_t q = 0; q < cc; q++) {
+    // stable sort by (address, hi), values = positions in the receive buffer
+    slabs.push_back(SortSlab{recv[q], skey + off, nullptr, spos + off, n_recv[q], std::max(hi_bits + a_bits, 1u)});
+    k.in[q] = skey + off, k.in2[q] = spos + off, k.out[q] = ret[q], k.n[q] = (uint32_t)n_recv[q];
+    off += n_recv[q];
+  }
+  sort_pairs_u32_batched(c, slabs.data(), slabs.size());
+  hipLaunchKernelGGL(cs_run_start_kernel, cs_grid(n_max, cc), 256, 0, c.stream, k, hi_bits, m_loc, start);
+  hipLaunchKernelGGL(cs_rank_kernel, cs_grid(n_max, cc), 256, 0, c.stream, k, hi_bits, m_loc, start, counts);
 }
 
-void k_cs_scatter(Ctx& c, const uint32_t* back, const uint32_t* sidx, size_t n, uint32_t* read_ts) {
-  if (n) hipLaunchKernelGGL(cs_scatter_kernel, grid_for(n), 256, 0, c.stream, back, sidx, n, read_ts);
+void k_cs_scatter(Ctx& c, const uint32_t* const* back, const uint32_t* const* sidx, size_t cc, size_t n, uint32_t* const* read_ts) {
+  if (!n) return;
+  CsCols k;
+  memset(&k, 0, sizeof(k));
+  for (size_t q = 0; q < cc; q++) k.in[q] = back[q], k.in2[q] = sidx[q], k.out[q] = read_ts[q];
+  hipLaunchKernelGGL(cs_scatter_kernel, cs_grid(n, cc), 256, 0, c.stream, k, n);
 }
-void k_cs_final(Ctx& c, const uint32_t* all_counts, size_t m, unsigned rho, size_t m_loc, uint32_t* final_cts) {
-  if (m) hipLaunchKernelGGL(cs_final_kernel, grid_for(m), 256, 0, c.stream, all_counts, m, rho, m_loc, final_cts);
+void k_cs_final(Ctx& c, const uint32_t* all_counts, size_t cc, size_t m, unsigned rho, size_t m_loc, uint32_t* const* final_cts) {
+  if (!m) return;
+  CsCols k;
+  memset(&k, 0, sizeof(k));
+  for (size_t q = 0; q < cc; q++) k.out[q] = final_cts[q];
+  hipLaunchKernelGGL(cs_final_kernel, cs_grid(m, cc), 256, 0, c.stream, k, all_counts, m, rho, m_loc, cc);
 }
 
 __global__ void lasso_subtable_read_kernel(int kind, uint32_t bits, const uint32_t* __restrict__ dim, size_t n,

@@ -90,67 +90,80 @@ void lasso_check_table(const lh_lasso_table& tb) {
 // Access counters of a sharded proof: read_ts[k] = number of earlier lookups - in the GLOBAL lookup order - of the same
 // address, final_cts[a] = number of lookups of a.  rts[j]: this rank's shard (2^(n - rho)), fcs[j]: replicated (2^l).
 // No rank ever holds a whole column: the lookups are repartitioned by address (owner = address mod R), the owner sorts
-// its (address, global index) pairs and ranks every lookup inside its address run, the ranks travel back the same way;
-// per column two personalised exchanges of ~2^(n - rho) entries per rank (8 B out, 4 B back) and one all-gather of the
-// 2^l / R counts of every owner.  Work and traffic per rank shrink with R (a column that hits one address only
-// degenerates to the single-GPU sort on that address's owner).
+// the keys it receives and ranks every lookup inside its address run, the ranks travel back the same way.  All chunk
+// columns go together: per PROOF two personalised exchanges of ~cc 2^(n - rho) entries per rank (4 B out - kernels_poly.hip:
+// the key needs neither the sender nor the low index bits -, 4 B back), one host all-gather of the segment boundaries and
+// one all-gather of the cc 2^l / R counts of every owner.  Work and traffic per rank shrink with R (a column that hits one
+// address only degenerates to the single-GPU sort on that address's owner).
 static void lasso_counters_sharded(Ctx& c, const Shard& sh, const uint32_t* const* d_dims_local, size_t cc, size_t n, size_t l,
                                    uint32_t* const* rts, uint32_t* const* fcs) {
   const size_t R = sh.R, me = sh.rank, M = (size_t)1 << l, NL = (size_t)1 << (n - sh.rho);
-  const size_t m_loc = std::max<size_t>(M >> sh.rho, 1);
+  const size_t m_loc = std::max<size_t>(M >> sh.rho, 1), R1 = R + 1;
   unsigned a_bits = 0;
   while (((size_t)1 << a_bits) < m_loc) a_bits++;
-  for (size_t col = 0; col < cc; col++) {
-    ArenaScope scope(c.arena);
-    uint32_t* sidx = c.arena.alloc_n<uint32_t>(NL);
-    uint64_t* send = c.arena.alloc_n<uint64_t>(NL);
-    std::vector<uint32_t> start(R + 2);
-    bool bad = false;
-    k_cs_partition(c, d_dims_local[col], NL, M, (unsigned)sh.rho, (unsigned)sh.j, (uint32_t)me, (unsigned)n, sidx, send,
-                   start.data(), &bad);
-    start[R + 1] = bad ? 1u : 0u;
-    // everybody's segment boundaries: starts[s][o] = where, in rank s's send buffer, the lookups for owner o begin - and
-    // everybody's verdict on its own shard: an index out of range on ANY rank fails the prove on EVERY rank, after the
-    // exchange (a rank that threw on its own would leave its peers waiting in this collective)
-    const size_t W = R + 2;
-    std::vector<uint32_t> starts(W * R);
-    comm_all_gather_host(c, start.data(), starts.data(), W * sizeof(uint32_t));
-    for (size_t s = 0; s < R; s++)
-      LH_REQUIRE(!starts[s * W + R + 1], LH_ERR_ARG, "lasso: chunk index out of range (>= 2^chunk_bits)");
-    auto seg = [&](size_t s, size_t o) { return (size_t)(starts[s * W + o + 1] - starts[s * W + o]); };
-    std::vector<size_t> s_off(R), s_cnt(R), r_off(R), r_cnt(R), peer_off(R);
-    size_t recv_total = 0, recv_max = 0;
+  const unsigned hi_bits = (unsigned)(n - sh.rho - sh.j);  // the local index bits above the shard bits
+  ArenaScope scope(c.arena);
+  uint32_t* sidx_all = c.arena.alloc_n<uint32_t>(cc * NL);
+  uint32_t* send_all = c.arena.alloc_n<uint32_t>(cc * NL);
+  std::vector<uint32_t*> sidx(cc), send(cc);
+  for (size_t q = 0; q < cc; q++) sidx[q] = sidx_all + q * NL, send[q] = send_all + q * NL;
+  // everybody's segment boundaries: starts[s][q][o] = where, in rank s's send buffer of column q, the lookups for owner o
+  // begin - and everybody's verdict on its own shard: an index out of range on ANY rank fails the prove on EVERY rank,
+  // after the exchange (a rank that threw on its own would leave its peers waiting in this collective)
+  const size_t W = cc * R1 + 1;
+  std::vector<uint32_t> start(W), starts(W * R);
+  bool bad = false;
+  k_cs_partition(c, d_dims_local, cc, NL, M, (unsigned)sh.rho, (unsigned)sh.j, hi_bits, sidx.data(), send.data(), start.data(), &bad);
+  start[cc * R1] = bad ? 1u : 0u;
+  comm_all_gather_host(c, start.data(), starts.data(), W * sizeof(uint32_t));
+  for (size_t s = 0; s < R; s++)
+    LH_REQUIRE(!starts[s * W + cc * R1], LH_ERR_ARG, "lasso: chunk index out of range (>= 2^chunk_bits)");
+  auto seg = [&](size_t s, size_t q, size_t o) { return (size_t)(starts[s * W + q * R1 + o + 1] - starts[s * W + q * R1 + o]); };
+  std::vector<size_t> s_off(cc * R), s_cnt(cc * R), r_off(cc * R), r_cnt(cc * R), peer_off(cc * R), back_peer_off(cc * R, 0);
+  std::vector<size_t> recv_total(cc, 0);
+  size_t recv_max = 0, recv_sum = 0;
+  for (size_t q = 0; q < cc; q++) {
     for (size_t p = 0; p < R; p++) {
-      s_off[p] = start[p], s_cnt[p] = seg(me, p);
-      r_off[p] = recv_total, r_cnt[p] = seg(p, me), peer_off[p] = starts[p * W + me];
-      recv_total += r_cnt[p];
+      s_off[q * R + p] = start[q * R1 + p], s_cnt[q * R + p] = seg(me, q, p);
+      r_off[q * R + p] = recv_total[q], r_cnt[q * R + p] = seg(p, q, me), peer_off[q * R + p] = starts[p * W + q * R1 + me];
+      recv_total[q] += r_cnt[q * R + p];
+      // (where, in owner p's return buffer, the segment for this rank begins: the lookups of ranks 0..me-1 come first)
+      for (size_t s = 0; s < me; s++) back_peer_off[q * R + p] += seg(s, q, p);
     }
-    for (size_t o = 0; o < R; o++) {  // (the largest receive buffer of any owner: the span of the way back)
+    recv_sum += recv_total[q];
+    for (size_t o = 0; o < R; o++) {  // (the largest receive buffer of any owner and column: the stride of the way back)
       size_t t = 0;
-      for (size_t s = 0; s < R; s++) t += seg(s, o);
+      for (size_t s = 0; s < R; s++) t += seg(s, q, o);
       recv_max = std::max(recv_max, t);
     }
-    uint64_t* recv = c.arena.alloc_n<uint64_t>(std::max<size_t>(recv_total, 1));
-    comm_all_to_all_v(c, send, s_off.data(), s_cnt.data(), recv, r_off.data(), r_cnt.data(), peer_off.data(), NL, sizeof(uint64_t));
-    // the owner's side: rank inside the address run, per-address totals
-    uint32_t* ret = c.arena.alloc_n<uint32_t>(std::max<size_t>(recv_max, 1));
-    uint32_t* counts = c.arena.alloc_n<uint32_t>(m_loc);
-    k_cs_rank(c, recv, recv_total, (unsigned)n, a_bits, m_loc, ret, counts);
-    // the ranks go back along the same segments (the send side of the way back is this rank's receive layout)
-    uint32_t* back = c.arena.alloc_n<uint32_t>(NL);
-    // (where, in owner p's return buffer, the segment for this rank begins: the lookups of ranks 0..me-1 come first)
-    std::vector<size_t> back_peer_off(R, 0);
-    for (size_t p = 0; p < R; p++)
-      for (size_t s = 0; s < me; s++) back_peer_off[p] += seg(s, p);
-    comm_all_to_all_v(c, ret, r_off.data(), r_cnt.data(), back, s_off.data(), s_cnt.data(), back_peer_off.data(), recv_max,
-                      sizeof(uint32_t));
-    k_cs_scatter(c, back, sidx, NL, rts[col]);
-    uint32_t* all_counts = c.arena.alloc_n<uint32_t>(m_loc * R);
-    comm_all_gather_dev(c, counts, all_counts, m_loc * sizeof(uint32_t));
-    k_cs_final(c, all_counts, M, (unsigned)sh.rho, m_loc, fcs[col]);
-    c.sync();  // (the scope's buffers are released)
   }
-  c.route.v[RouteStats::SHARD_EXCHANGES] += (uint32_t)(3 * cc);
+  recv_max = std::max<size_t>(recv_max, 1);
+  uint32_t* recv_all = c.arena.alloc_n<uint32_t>(std::max<size_t>(recv_sum, 1));
+  uint32_t* ret_all = c.arena.alloc_n<uint32_t>(cc * recv_max);
+  uint32_t* back_all = c.arena.alloc_n<uint32_t>(cc * NL);
+  uint32_t* counts = c.arena.alloc_n<uint32_t>(cc * m_loc);
+  std::vector<uint32_t*> recv(cc), ret(cc), back(cc);
+  {
+    size_t off = 0;
+    for (size_t q = 0; q < cc; q++) recv[q] = recv_all + off, off += recv_total[q], ret[q] = ret_all + q * recv_max, back[q] = back_all + q * NL;
+  }
+  std::vector<const void*> csend(send.begin(), send.end()), cret(ret.begin(), ret.end());
+  std::vector<void*> vrecv(recv.begin(), recv.end()), vback(back.begin(), back.end());
+  comm_all_to_all_multi(c, cc, csend.data(), s_off.data(), s_cnt.data(), vrecv.data(), r_off.data(), r_cnt.data(), peer_off.data(),
+                        send_all, NL, sizeof(uint32_t));
+  // the owner's side: rank inside the address run, per-address totals
+  std::vector<const uint32_t*> crecv(recv.begin(), recv.end());
+  k_cs_rank(c, crecv.data(), recv_total.data(), cc, hi_bits, a_bits, m_loc, ret.data(), counts);
+  // the ranks go back along the same segments (the send side of the way back is this rank's receive layout)
+  comm_all_to_all_multi(c, cc, cret.data(), r_off.data(), r_cnt.data(), vback.data(), s_off.data(), s_cnt.data(),
+                        back_peer_off.data(), ret_all, recv_max, sizeof(uint32_t));
+  std::vector<const uint32_t*> cback(back.begin(), back.end()), csidx(sidx.begin(), sidx.end());
+  k_cs_scatter(c, cback.data(), csidx.data(), cc, NL, rts);
+  uint32_t* all_counts = c.arena.alloc_n<uint32_t>(cc * m_loc * R);
+  comm_all_gather_dev(c, counts, all_counts, cc * m_loc * sizeof(uint32_t));
+  k_cs_final(c, all_counts, cc, M, (unsigned)sh.rho, m_loc, fcs);
+  c.sync();  // (the scope's buffers are released)
+  c.route.v[RouteStats::SHARD_EXCHANGES] += 3;
 }
 
 // witness: access counters, subtable reads and (optionally) the lookup outputs a = g(E); arena memory of the caller's scope.
