@@ -411,7 +411,6 @@ lh_status lh_srs_upload(lh_ctx* ctx, const lh_g1* eqs_flat, size_t num_vars, lh_
   LH_HIP(hipMalloc((void**)&w->s.d_eqs, total * sizeof(G1Affine)));
   LH_HIP(hipMemcpyAsync(w->s.d_eqs, eqs_flat, total * sizeof(G1Affine), hipMemcpyHostToDevice, ctx->c.stream));
   ctx->c.sync();
-  bases29_register(w->s.d_eqs, total);
   *out = w;
   LH_CATCH
 }
@@ -428,12 +427,10 @@ void lh_srs_free(lh_ctx* ctx, lh_srs* srs) {
   if (!srs) return;
   if (ctx) (void)hipStreamSynchronize(ctx->c.stream);
   if (srs->s.d_eqs) {
-    bases29_unregister(srs->s.d_eqs);
     (void)hipFree(srs->s.d_eqs);
   }
   for (G1Affine* p : srs->s.shard_levels)
     if (p) {
-      bases29_unregister(p);
       (void)hipFree(p);
     }
   for (auto& kv : srs->s.win_tables)

@@ -92,7 +92,6 @@ static const struct {
     {"shard_exchange_log", &Options::shard_exchange_log, 0, 40},   {"msm_window_tables", &Options::msm_window_tables, 0, 40},
     {"open_precommit", &Options::open_precommit, 0, 64},           {"gkr_resident", &Options::gkr_resident, 0, 1},
     {"sc_pp_fold", &Options::sc_pp_fold, 0, 1},
-    {"msm_limbs29", &Options::msm_limbs29, 0, 1},
     {"comm_round", &Options::comm_round, 0, 2},
 };
 

@@ -123,10 +123,6 @@ struct Options {
                                        // every round (sc_round_e2) instead of folding them into the left factors and sharing
                                        // Montgomery reductions (sc_round_pp); the leaf layers (ScRwRound) keep cs and k
                                        // outside their tables and run the leaf kernel in every streaming round
-  int64_t msm_limbs29 = 0;             // 1: MSM batches over registered bases (an SRS) accumulate in the 9 x 29-bit lazy-carry
-                                       // form of the base field (ec29.cuh: x1.25 on products, x1.15 on the mixed addition's
-                                       // arithmetic in isolation - and 0.95x inside the accumulation kernel, whose gathers pay
-                                       // for the lost wave of occupancy: measured, off); 0: the 8 x 32-bit form everywhere
   int64_t gkr_resident = 1;            // the layers of a grand-product argument whose tables fit the resident kernel run in ONE
                                        // launch (layer loop, eq tables and rounds inside; 0: one sum-check per layer)
   int64_t comm_round = 0;              // how the partial sums of a sharded sum-check round are combined: 0 = all-gather +
@@ -142,7 +138,7 @@ struct Options {
 struct RouteStats {  // lh_lasso_route (include/lasso_hip.h): counters of the last Lasso prove on the ctx
   uint32_t v[LH_LASSO_ROUTE_WORDS] = {0};
   enum { OPEN_DEPTH, OPEN_PASSES, EF_ROUNDS, STD_ROUNDS, RW_ROUNDS, TAILS, TAIL_ROUNDS, PACKED_TS, DERIVED, SORTED_REUSE,
-         SHARDED_ROUNDS, SHARD_EXCHANGES, WIN_TABLE_JOBS, OPEN_PRECOMMIT, RESIDENT_LAYERS, PP_FOLDS, MSM29_BATCHES };
+         SHARDED_ROUNDS, SHARD_EXCHANGES, WIN_TABLE_JOBS, OPEN_PRECOMMIT, RESIDENT_LAYERS, PP_FOLDS, RESERVED_29 };
 };
 
 // ------------------------------------------------------------------ a long-lived host thread (dev.cpp)
@@ -767,12 +763,6 @@ Ctx& ctx_helper(Ctx&);            // the ctx's helper ctx (created on first use,
 void open_precommit_cancel(Ctx&);  // waits for a running precommit and drops it (prover.cpp)
 uint32_t msm_window_bits(size_t n);  // window width msm_batch picks for a full-width (254-bit) column of n points
 void k_msm_window_table(Ctx&, const G1Affine* bases, size_t n, uint32_t cbits, uint32_t W, G1Affine* out);
-// arrays of bases whose accumulation may run in the 9 x 29-bit form (ec29.cuh): registered by whoever owns them (an SRS),
-// twins made on first use (msm.hip)
-struct G1Affine29;
-void bases29_register(const G1Affine* base, size_t count);
-void bases29_unregister(const G1Affine* base);
-const G1Affine29* bases29_lookup(Ctx&, const G1Affine* bases, size_t n);
 // Runs all jobs as one batched Pippenger; out[j] is the affine sum (identity = (0,0)).
 // `overlap` (optional): host work that needs none of this batch's results - run once, after the batch's kernels are
 // queued and before the host waits for the window sums (it overlaps the device's work instead of following it)

@@ -33,7 +33,6 @@
 #include <vector>
 #include <mutex>
 #include "dev.hpp"
-#include "ec29.cuh"
 #include "ff_host.hpp"
 
 namespace lh {
@@ -45,7 +44,6 @@ constexpr uint32_t SKIP_IDX = 0x7fffffffu;   // sorted entries: a zero digit (no
 struct MsmJobDev {
   const void* scalars;
   const G1Affine* bases;
-  const G1Affine29* bases29;  // the same points in the 9 x 29-bit form (ec29.cuh; bases29_lookup) or null
   uint32_t is_u32;
   uint32_t n;
   uint32_t c, W;        // window bits, number of windows
@@ -172,59 +170,6 @@ __global__ void msm_emit_kernel(MsmPlanDev plan, uint32_t* __restrict__ keys, ui
 }
 
 
-// ------------------------------------------------------------------ bases in the 9 x 29-bit form (ec29.cuh)
-// The SRS is static: every registered array of bases (an SRS's flat array, a rank's shard of a level) gets a twin in the
-// form the accumulation's arithmetic wants, made on first use by whichever ctx asks and owned by the registry (process-
-// wide: several contexts share one SRS).  A batch runs the 29-bit kernel when every job's bases lie in a registered array.
-__global__ void bases_to29_kernel(const G1Affine* __restrict__ in, size_t n, G1Affine29* __restrict__ out) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const G1Affine p = in[i];
-    G1Affine29 q;
-    q.x = to261(p.x), q.y = to261(p.y);
-    out[i] = q;
-  }
-}
-namespace {
-struct Bases29Range {
-  const G1Affine* base;
-  size_t count;
-  G1Affine29* twin;  // null until first used
-};
-std::mutex bases29_mu;
-std::vector<Bases29Range> bases29_ranges;
-}  // namespace
-void bases29_register(const G1Affine* base, size_t count) {
-  if (!base || !count) return;
-  std::lock_guard<std::mutex> lk(bases29_mu);
-  bases29_ranges.push_back(Bases29Range{base, count, nullptr});
-}
-void bases29_unregister(const G1Affine* base) {
-  std::lock_guard<std::mutex> lk(bases29_mu);
-  for (size_t i = 0; i < bases29_ranges.size(); i++)
-    if (bases29_ranges[i].base == base) {
-      if (bases29_ranges[i].twin) (void)hipFree(bases29_ranges[i].twin);
-      bases29_ranges.erase(bases29_ranges.begin() + (long)i);
-      return;
-    }
-}
-// the twin of `bases` (a pointer into a registered array with at least n points behind it) or null
-const G1Affine29* bases29_lookup(Ctx& c, const G1Affine* bases, size_t n) {
-  std::lock_guard<std::mutex> lk(bases29_mu);
-  for (Bases29Range& r : bases29_ranges) {
-    if (bases < r.base || bases + n > r.base + r.count) continue;
-    if (!r.twin) {
-      G1Affine29* t = nullptr;
-      if (hipMalloc((void**)&t, r.count * sizeof(G1Affine29)) != hipSuccess) return nullptr;  // (no memory: the standard form)
-      hipLaunchKernelGGL(bases_to29_kernel, dim3((unsigned)std::min<size_t>((r.count + 255) / 256, 1 << 16)), dim3(256), 0,
-                         c.stream, r.base, r.count, t);
-      c.sync();
-      r.twin = t;
-    }
-    return r.twin + (bases - r.base);
-  }
-  return nullptr;
-}
-
 // ------------------------------------------------------------------ 4: segmented accumulate
 // O(1): this runs at every bucket boundary of the accumulate loop, and a wave takes the branch whenever ANY of
 // its lanes crosses a boundary (nearly every iteration), so a linear scan of the job list costs a multiplication.
@@ -238,33 +183,7 @@ __device__ __forceinline__ const MsmJobDev& job_of_key(const MsmPlanDev& plan, u
 // cache lines per wave instruction and keep every line alive for 32 iterations (measured: 2.7x the algorithmic
 // fetch traffic).  (Requesting the next base point one iteration ahead was tried and lost 5 %: more registers.)
 constexpr int ACC_GROUP = 16;
-// the arithmetic of the accumulation: the standard 8 x 32-bit form, or - every job of the batch having its bases in that
-// form too - the 9 x 29-bit lazy-carry form (ec29.cuh: x1.15 on the mixed addition's instruction mix), whose sums are
-// converted back when they leave for the bucket / continuation arrays
-struct Acc32 {
-  typedef G1Xyzz acc_t;
-  typedef G1Affine base_t;
-  static __device__ __forceinline__ acc_t identity() { return G1Xyzz::identity(); }
-  static __device__ __forceinline__ const base_t* bases(const MsmJobDev& jd) { return jd.bases; }
-  static __device__ __forceinline__ acc_t add(const acc_t& a, const base_t& b, bool neg) { return add_mixed(a, b, neg); }
-  static __device__ __forceinline__ G1Xyzz out(const acc_t& a) { return a; }
-};
-struct Acc29 {
-  typedef G1Xyzz29 acc_t;
-  typedef G1Affine29 base_t;
-  static __device__ __forceinline__ acc_t identity() { return identity29(); }
-  static __device__ __forceinline__ const base_t* bases(const MsmJobDev& jd) { return jd.bases29; }
-  static __device__ __forceinline__ acc_t add(const acc_t& a, const base_t& b, bool neg) { return add_mixed29(a, b, neg); }
-  static __device__ __forceinline__ G1Xyzz out(const acc_t& a) { return to_xyzz(a); }
-};
-#ifndef LH_ACC29_WAVES
-#define LH_ACC29_WAVES 0
-#endif
-template <class A>
 __global__ __launch_bounds__(128)
-#if LH_ACC29_WAVES
-__attribute__((amdgpu_waves_per_eu(LH_ACC29_WAVES, LH_ACC29_WAVES)))
-#endif
 void msm_accumulate0_kernel(MsmPlanDev plan, size_t total,
                                                               const uint32_t* __restrict__ sorted_key,
                                                               const uint32_t* __restrict__ sorted_idx, uint32_t K,
@@ -280,8 +199,8 @@ void msm_accumulate0_kernel(MsmPlanDev plan, size_t total,
     if (p0 < p1) {
       uint32_t cur = sorted_key[p0];
       bool cont = p0 > 0 && sorted_key[p0 - 1] == cur;
-      const typename A::base_t* bases = A::bases(job_of_key(plan, cur));
-      typename A::acc_t acc = A::identity();
+      const G1Affine* bases = job_of_key(plan, cur).bases;
+      G1Xyzz acc = G1Xyzz::identity();
       for (size_t g0 = p0; g0 < p1; g0 += ACC_GROUP) {
         // K is a multiple of 4 and the arrays are padded past the last chunk: whole 16-byte loads stay in bounds
         const uint32_t cnt = (uint32_t)(p1 - g0 < (size_t)ACC_GROUP ? p1 - g0 : (size_t)ACC_GROUP);
@@ -297,24 +216,24 @@ void msm_accumulate0_kernel(MsmPlanDev plan, size_t total,
           if (k != cur) {
             if (cont) {
               ck = cur;
-              cont_pt[t] = A::out(acc);
+              cont_pt[t] = acc;
             } else {
-              buckets[cur] = A::out(acc);
+              buckets[cur] = acc;
             }
             cont = false;
-            acc = A::identity();
+            acc = G1Xyzz::identity();
             cur = k;
-            bases = A::bases(job_of_key(plan, cur));
+            bases = job_of_key(plan, cur).bases;
           }
           const uint32_t iv = lds_idx[j * 128 + threadIdx.x];
-          if (iv != SKIP_IDX) acc = A::add(acc, bases[iv & 0x7fffffffu], (iv >> 31) != 0);
+          if (iv != SKIP_IDX) acc = add_mixed(acc, bases[iv & 0x7fffffffu], (iv >> 31) != 0);
         }
       }
       if (cont) {
         ck = cur;
-        cont_pt[t] = A::out(acc);
+        cont_pt[t] = acc;
       } else {
-        buckets[cur] = A::out(acc);
+        buckets[cur] = acc;
       }
     }
     cont_key[t] = ck;
@@ -765,7 +684,6 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, 
       MsmJobDev& jd = plan.job[j];
       uint32_t bits = job_bits[j];
       jd.bases = in.bases;
-      jd.bases29 = nullptr;
       if (derived[j]) jd.n = 0;  // emits no (point, window) entries: its buckets are filled from the parent's
       jd.c = pick_window(in.n ? in.n : 1, bits ? bits : 1);
       jd.pack_shift = 0;
@@ -941,16 +859,6 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, 
         if (first_group) sort_pairs_u32_batched(c, sorts.data(), first_group);
       }
 
-      // the 29-bit arithmetic when every job that emits entries has its bases in that form (Options::msm_limbs29)
-      bool use29 = c.opt.msm_limbs29 != 0;
-      for (size_t j = 0; j < nj && use29; j++) {
-        MsmJobDev& jd = plan.job[j];
-        if (!jd.n || !jd.W) continue;
-        const MsmJob& in = jobs[base + j];
-        jd.bases29 = in.win_table ? nullptr : bases29_lookup(c, jd.bases, jd.n);
-        use29 = jd.bases29 != nullptr;
-      }
-      if (use29) c.route.v[RouteStats::MSM29_BATCHES]++;
       // segmented accumulate, level 0 then K-fold shrinking continuation lists
       // entries per thread: enough chunks to fill the chip, few enough that the continuation list stays small
       // (measured: tools/msm_sweep.sh; 2^24 lookups 141 -> 132 ms with K 32 -> 128)
@@ -973,24 +881,16 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, 
           LH_HIP(hipEventRecord(c.join3_ev, c.stream));
           LH_HIP(hipStreamWaitEvent(sa, c.join3_ev, 0));
         }
-        if (use29)
-          hipLaunchKernelGGL(msm_accumulate0_kernel<Acc29>, dim3((unsigned)std::min<size_t>((c1 + 127) / 128, 1 << 16)), dim3(128), 0, sa,
-                             plan, max_entries, skey, sidx, K, buckets, ckey, cpt, (size_t)0, c1, lvl_cnt);
-        else
-          hipLaunchKernelGGL(msm_accumulate0_kernel<Acc32>, dim3((unsigned)std::min<size_t>((c1 + 127) / 128, 1 << 16)), dim3(128), 0, sa,
-                             plan, max_entries, skey, sidx, K, buckets, ckey, cpt, (size_t)0, c1, lvl_cnt);
+        hipLaunchKernelGGL(msm_accumulate0_kernel, dim3((unsigned)std::min<size_t>((c1 + 127) / 128, 1 << 16)), dim3(128), 0, sa,
+                           plan, max_entries, skey, sidx, K, buckets, ckey, cpt, (size_t)0, c1, lvl_cnt);
         if (c.stream3) {
           LH_HIP(hipEventRecord(c.join3_ev, sa));
           LH_HIP(hipStreamWaitEvent(c.stream, c.join3_ev, 0));
         }
       }
       if (e_split) LH_HIP(hipStreamWaitEvent(c.stream, c.join_ev, 0));
-      if (use29)
-        hipLaunchKernelGGL(msm_accumulate0_kernel<Acc29>, dim3((unsigned)std::min<size_t>((nchunks - c1 + 127) / 128, 1 << 16)),
-                           dim3(128), 0, c.stream, plan, max_entries, skey, sidx, K, buckets, ckey, cpt, c1, nchunks, lvl_cnt);
-      else
-        hipLaunchKernelGGL(msm_accumulate0_kernel<Acc32>, dim3((unsigned)std::min<size_t>((nchunks - c1 + 127) / 128, 1 << 16)),
-                           dim3(128), 0, c.stream, plan, max_entries, skey, sidx, K, buckets, ckey, cpt, c1, nchunks, lvl_cnt);
+      hipLaunchKernelGGL(msm_accumulate0_kernel, dim3((unsigned)std::min<size_t>((nchunks - c1 + 127) / 128, 1 << 16)),
+                         dim3(128), 0, c.stream, plan, max_entries, skey, sidx, K, buckets, ckey, cpt, c1, nchunks, lvl_cnt);
       }
       {
         ProfScope ps(c, "msm_accumulate_levels", 0, 0, (double)nchunks);

@@ -1557,7 +1557,6 @@ Srs* mkzg_setup(Ctx& c, const HFr* ss, size_t num_vars) {
   // eqs[k] = eq table of (s_0..s_{k-1}) with s_{k-1} the top bit (kzg.rs:178-194) == eq_xy(s[..k])
   for (size_t k = 0; k <= num_vars; k++) k_eq_xy(c, (const Fr*)ss, k, scal + (((size_t)1 << k) - 1));
   k_fixed_base_mul_g(c, scal, total, srs->d_eqs);
-  bases29_register(srs->d_eqs, total);
   return srs;
 }
 
@@ -1626,7 +1625,6 @@ const G1Affine* srs_shard_level(Ctx& c, const Srs& srs, size_t lvl) {
   if (srs.shard_rank != (int)g.rank || srs.shard_R != g.R || srs.shard_j != g.j) {
     for (G1Affine* p : srs.shard_levels)
       if (p) {
-        bases29_unregister(p);
         (void)hipFree(p);
       }
     srs.shard_levels.assign(srs.num_vars + 1, nullptr);
@@ -1640,7 +1638,6 @@ const G1Affine* srs_shard_level(Ctx& c, const Srs& srs, size_t lvl) {
     LH_HIP(hipMalloc((void**)&p, n_local * sizeof(G1Affine)));
     k_shard_extract(c, srs.eq(lvl), n_local, g.j, g.rho, g.rank, sizeof(G1Affine), p);
     c.sync();
-    bases29_register(p, n_local);
     srs.shard_levels[lvl] = p;
   }
   return srs.shard_levels[lvl];

@@ -276,11 +276,6 @@ lh_status lh_lasso_last_timing(lh_ctx*, double* out_ms);
  *                             binding round folds c_m into l_m (sc_round_pp_kernel); the leaf layers of the lookup-sized
  *                             trees, sum_p cs_p (l_p + k_p)(r_p + k_p), store cs_p (l_p + k_p) and r_p + k_p at their first
  *                             bind and go on as such rounds; 0: sc_round_e2_kernel / sc_round_rw_kernel in every round
- *   msm_limbs29          0    1: MSM batches whose bases all belong to an SRS accumulate their buckets in the 9 x 29-bit
- *                             lazy-carry form of the base field (a twin of the SRS in that form is made on first use):
- *                             ~205 instead of ~310 instructions per Montgomery product, x1.15 on the mixed addition's
- *                             arithmetic in isolation, but 0.95x inside the accumulation kernel (one wave of occupancy
- *                             less for the gathers): measured neutral-to-negative, off by default
  *   comm_round           0    how the partial sums of a sharded sum-check round are combined over the ranks:
  *                             0 = ncclAllGather of every rank's sums + a one-thread sum-and-publish kernel;
  *                             1 = ONE collective: the round kernel leaves its sums as u64 lanes (32-bit limb | tag << 40),
@@ -311,7 +306,8 @@ typedef struct lh_lasso_route {
   uint32_t open_precommit;      /* 1: the opening's column-wise commitments were taken from the helper ctx (open_precommit) */
   uint32_t resident_layers;     /* grand-product layers that ran inside the resident multi-layer kernel (gkr_resident) */
   uint32_t pp_folds;            /* sum-checks whose batching coefficients were folded into the left factors (sc_pp_fold) */
-  uint32_t msm29_batches;       /* MSM batches whose bucket accumulation ran in the 9 x 29-bit form (msm_limbs29) */
+  uint32_t msm29_batches;       /* reserved, always 0 (round 4's 9 x 29-bit bucket accumulation - measured slower inside the
+                                   kernel - left the library in round 5; tools/ubench/mul29.hip keeps the experiment) */
   uint32_t reserved[7];
 } lh_lasso_route;
 lh_status lh_lasso_last_route(lh_ctx*, lh_lasso_route* out);

@@ -113,7 +113,7 @@ CASES = [
     pytest.param(4, dict(circuit="keccak_small", w=8, ub=4, rounds=2, k=10, seed=910), 6, None, id="keccak_small-4"),
     pytest.param(2, dict(circuit="keccak_small", w=4, ub=4, rounds=1, k=9, seed=909), 7, 3, id="keccak_tiny-2"),
     pytest.param(2, dict(circuit="vanilla_lasso", k=17, seed=171), 15, None, marks=pytest.mark.heavy(est=25), id="vanilla_lasso_2p17-2"),
-    pytest.param(2, dict(circuit="keccak", k=17, seed=16), 15, None, marks=pytest.mark.heavy(est=40), id="keccak_f1600_2p17-2"),
+    pytest.param(2, dict(circuit="keccak", k=17, seed=16), 15, None, marks=pytest.mark.heavy(est=50), id="keccak_f1600_2p17-2"),
 ]
 
 
@@ -129,6 +129,16 @@ def test_sharded_hyperplonk_proof_equals_single_gpu(tmp_path, hl, ctx, world, cf
     assert proofs.pop() == want.hex(), "the sharded proof differs from the single-GPU proof"
     for o in outs:
         assert o["stats"]["host"] > 0 and o["route"]["sharded_rounds"] > 0 and o["route"]["shard_exchanges"] > 0, o
+    if cfg["circuit"] == "keccak":
+        # ... and, directly, from the C++ oracle's proof of the same Keccak-f[1600] circuit (not only through
+        # the single-GPU prover)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from test_gpu_keccak import cpp_oracle_keccak_proof
+        from halo2_lasso_amd import synthetic
+        prng = random.Random(cfg["seed"])
+        pcs = hl.MultilinearKzg.setup(ctx, [prng.randrange(1, hl.R_MOD) for _ in range(cfg["k"])])
+        circ = synthetic.keccak_f(ctx, cfg["k"], seed=cfg["seed"])
+        assert cpp_oracle_keccak_proof(hl, ctx, pcs, circ, cfg["k"]) == want, "the C++ oracle's proof differs"
 
 
 def test_small_sharded_keccak_matches_the_specification(tmp_path, hl, ctx):

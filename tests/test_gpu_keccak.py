@@ -47,6 +47,23 @@ def test_small_keccak_circuit_matches_the_specification(hl, ctx, w, ub, rounds, 
         g_hp.HyperPlonk.prove(g_pp, [[]], [hl.MultilinearPolynomial.new(ctx, x) for x in bad], hl.Keccak256Transcript())
 
 
+def cpp_oracle_keccak_proof(hl, ctx, pcs, circ, k):
+    """the C++ oracle's HyperPlonk + Lasso proof of a synthetic.keccak_f circuit of 2^k rows (same SRS, same polys)"""
+    import ctypes as C
+    from oracle import cpu_oracle as co
+    srs = C.create_string_buffer(64 * ((2 << k) - 1))
+    hl._check(ctx.lib.lh_srs_download(ctx.h, pcs.h, srs))
+    o_info = o_hp.keccak_circuit_info(k, [[]] * 7, [[(8, 1)], [(9, 1)], [(10, 1)]],
+                                      o_lasso.bitwise_table(o_lasso.SUBTABLE_XOR, 1, 16), o_lasso.bitwise_table(o_lasso.SUBTABLE_AND, 1, 16))
+    num_z, expression = o_hp.compose(o_info)
+    lasso_lookups = [(lk.table.to_c(), lk.output_poly, lk.chunk_polys) for lk in circ.info.lasso_lookups]
+    ot = co.Transcript()
+    co.hyperplonk_prove(ot, srs, k, k, [0], [a.tobytes() for a in circ.h_preprocess], len(circ.h_witness), 0, [], [8, 9, 10],
+                        [p.buf.read() for p in circ.d_permutation], num_z, co.flatten_expression(expression), [[]],
+                        [a.tobytes() for a in circ.h_witness], lasso_lookups=lasso_lookups)
+    return ot.into_proof()
+
+
 def test_keccak_f_1600_circuit_matches_cpp_oracle(hl, ctx):
     """one full Keccak-f[1600] - 24 rounds, 35013 rows of byte operations: 17536 XOR and 17477 AND / rotation rows, two
     Lasso lookups into the 2^16-entry XOR and AND subtables - in a 2^16-row circuit built on the device
@@ -77,14 +94,4 @@ def test_keccak_f_1600_circuit_matches_cpp_oracle(hl, ctx):
     proof = t.into_proof()
     g_hp.HyperPlonk.verify(vp, circ.instances, hl.Keccak256Transcript.from_proof(proof))
     # the C++ oracle on the same polys
-    srs = C.create_string_buffer(64 * ((2 << k) - 1))
-    hl._check(ctx.lib.lh_srs_download(ctx.h, pcs.h, srs))
-    o_info = o_hp.keccak_circuit_info(k, [[]] * 7, [[(8, 1)], [(9, 1)], [(10, 1)]],
-                                      o_lasso.bitwise_table(o_lasso.SUBTABLE_XOR, 1, 16), o_lasso.bitwise_table(o_lasso.SUBTABLE_AND, 1, 16))
-    num_z, expression = o_hp.compose(o_info)
-    lasso_lookups = [(lk.table.to_c(), lk.output_poly, lk.chunk_polys) for lk in circ.info.lasso_lookups]
-    ot = co.Transcript()
-    co.hyperplonk_prove(ot, srs, k, k, [0], [a.tobytes() for a in circ.h_preprocess], len(circ.h_witness), 0, [], [8, 9, 10],
-                        [p.buf.read() for p in circ.d_permutation], num_z, co.flatten_expression(expression), [[]],
-                        [a.tobytes() for a in circ.h_witness], lasso_lookups=lasso_lookups)
-    assert proof == ot.into_proof()
+    assert proof == cpp_oracle_keccak_proof(hl, ctx, pcs, circ, k)

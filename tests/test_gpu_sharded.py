@@ -173,6 +173,8 @@ LARGE = [
     # kernel, packed and derived commitments, the column-wise top quotient - checked against the C++ oracle
     pytest.param(2, "range", 2, 16, 18, 15, None, marks=pytest.mark.heavy(est=8)),
     pytest.param(4, "xor", 4, 16, 18, 14, 0, marks=pytest.mark.heavy(est=25)),
+    # (the sharded prover against the ORACLE, not only against the single-GPU prover, at 2^20 lookups on 4 ranks)
+    pytest.param(4, "and", 4, 16, 20, 14, None, marks=pytest.mark.heavy(est=45)),
 ]
 
 

@@ -17,7 +17,8 @@ def test_fp64_fma_montgomery_product_matches_big_integers():
 
 def test_29_bit_limb_product_matches_cios(tmp_path):
     exe = str(tmp_path / "mul29_host_check")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "halo2-lasso_amd", "csrc"), "-o", exe,
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "halo2-lasso_amd", "csrc"), "-I",
+                           os.path.join(ROOT, "tools", "ubench"), "-o", exe,
                            os.path.join(ROOT, "tools", "ubench", "mul29_host_check.cpp")])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.startswith("bad 0 "), r.stdout + r.stderr

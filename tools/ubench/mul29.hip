@@ -1,8 +1,8 @@
-// The 9 x 29-bit lazy-carry Montgomery product (halo2-lasso_amd/csrc/ff29.cuh) against the 8 x 32-bit product-scanning
+// The 9 x 29-bit lazy-carry Montgomery product (tools/ubench/ff29.cuh) against the 8 x 32-bit product-scanning
 // form: bit check through mul_cios (the radices differ: x 2^5) on random and extreme inputs, both fields, inputs up to
 // 16 p; throughput of dependent product chains (two per thread) and of a chain that mixes additions and subtractions in
 // the proportion of an XYZZ mixed addition.
-// build: hipcc -O3 --offload-arch=gfx950 -I halo2-lasso_amd/csrc tools/ubench/mul29.hip -o tools/ubench/mul29.bin
+// build: hipcc -O3 --offload-arch=gfx950 -I halo2-lasso_amd/csrc -I tools/ubench tools/ubench/mul29.hip -o tools/ubench/mul29.bin
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>

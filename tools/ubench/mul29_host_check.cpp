@@ -1,4 +1,4 @@
-// Host check of halo2-lasso_amd/csrc/ff29.cuh (9 x 29-bit lazy-carry limbs): the generic forms of mul29 / add29 / sub29 /
+// Host check of tools/ubench/ff29.cuh (9 x 29-bit lazy-carry limbs): the generic forms of mul29 / add29 / sub29 /
 // slice29 against ff.cuh's CIOS product on random inputs (the device form - the same columns as v_mad_u64_u32 groups - is
 // checked on the GPU by tools/ubench/mul29.hip).  build: g++ -O1 -std=c++17 -I halo2-lasso_amd/csrc tools/ubench/mul29_host_check.cpp
 #include <stdio.h>
