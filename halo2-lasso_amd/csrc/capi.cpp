@@ -133,14 +133,6 @@ void lh_ctx_destroy(lh_ctx* ctx) {
     if (ctx->c.sort_stage[k]) (void)hipHostFree(ctx->c.sort_stage[k]);
     if (ctx->c.sort_ev[k]) (void)hipEventDestroy(ctx->c.sort_ev[k]);
   }
-  if (ctx->c.stream2) {
-    (void)hipStreamSynchronize(ctx->c.stream2);
-    (void)hipStreamDestroy(ctx->c.stream2);
-    (void)hipEventDestroy(ctx->c.fork_ev);
-    (void)hipEventDestroy(ctx->c.join_ev);
-    if (ctx->c.stream3) (void)hipStreamDestroy(ctx->c.stream3);
-    if (ctx->c.join3_ev) (void)hipEventDestroy(ctx->c.join3_ev);
-  }
   if (ctx->c.flag) (void)hipHostFree(ctx->c.flag);
   if (ctx->c.ticket) (void)hipFree(ctx->c.ticket);
   (void)hipStreamDestroy(ctx->c.stream);

@@ -27,17 +27,6 @@ Arena::~Arena() {
 void* Arena::alloc(size_t bytes) {
   bytes = (bytes + 255) & ~(size_t)255;
   if (bytes == 0) bytes = 256;
-  // development (LH_ARENA_SKEW=bytes): large tables are power-of-two sized, so back-to-back allocations put the SAME index of
-  // every table a round kernel streams on addresses that differ by multiples of 2^28; a rotating skew in front of each large
-  // allocation staggers them (does the memory system spread channels well enough without it? measured: profiles/README.md)
-  static const size_t skew_unit = [] {
-    const char* e = getenv("LH_ARENA_SKEW");
-    return e ? (size_t)atoll(e) & ~(size_t)255 : (size_t)0;
-  }();
-  if (skew_unit && bytes >= ((size_t)1 << 20)) {
-    const size_t pad = (skew_count_++ % 61) * skew_unit;
-    return (char*)alloc_raw(bytes + pad) + pad;
-  }
   return alloc_raw(bytes);
 }
 void* Arena::alloc_raw(size_t bytes) {
@@ -152,24 +141,6 @@ void Ctx::wait_flag(uint32_t seq) {
       if (e != hipErrorNotReady) throw Error(LH_ERR_DEVICE, std::string("stream error: ") + hipGetErrorString(e));
     }
   }
-}
-
-hipStream_t Ctx::second_stream(int cu_share) {
-  if (!stream2) {
-    if (cu_share > 1) {
-      const int words = (num_cus + 31) / 32;
-      std::vector<uint32_t> ma(words, 0), mb(words, 0);
-      for (int cu = 0; cu < num_cus; cu++) (cu % cu_share == 0 ? mb : ma)[cu / 32] |= 1u << (cu % 32);
-      LH_HIP(hipExtStreamCreateWithCUMask(&stream2, words, mb.data()));
-      LH_HIP(hipExtStreamCreateWithCUMask(&stream3, words, ma.data()));
-      LH_HIP(hipEventCreateWithFlags(&join3_ev, hipEventDisableTiming));
-    } else {
-      LH_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
-    }
-    LH_HIP(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
-    LH_HIP(hipEventCreateWithFlags(&join_ev, hipEventDisableTiming));
-  }
-  return stream2;
 }
 
 ScFinishArgs Ctx::finish_for(uint32_t grid, Fr* out_host, uint32_t seq) {

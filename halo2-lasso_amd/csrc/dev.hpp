@@ -62,7 +62,7 @@ class Arena {
     size_t size, used;
   };
   std::vector<Block> blocks_;
-  size_t cur_ = 0, high_ = 0, skew_count_ = 0;
+  size_t cur_ = 0, high_ = 0;
 };
 
 struct ArenaScope {
@@ -142,7 +142,7 @@ struct RouteStats {  // lh_lasso_route (include/lasso_hip.h): counters of the la
 };
 
 // ------------------------------------------------------------------ a long-lived host thread (dev.cpp)
-// Runs submitted tasks one after the other: the driver of a helper ctx (prover.cpp open_precommit_*) - starting a
+// Runs submitted tasks one after the other: the driver of a helper ctx (open_columns.cpp open_precommit_*) - starting a
 // std::thread per proof costs tens of microseconds on the prover's critical path, a condition variable costs two.
 class HostWorker {
  public:
@@ -203,7 +203,7 @@ struct Ctx {
   bool host_trace_on = false;
   void host_stamp(const char* tag);
   void host_stamps_print();
-  // eq tables of point tails y[1..n) built during one proof (prover.cpp eq_half_*): an evaluation, a sum-check and the batch
+  // eq tables of point tails y[1..n) built during one proof (sumcheck.cpp eq_half_*): an evaluation, a sum-check and the batch
   // opening at the same point share one table.  Arena memory of the proof's scope: the proof clears the list (EqHalfScope).
   struct EqHalfEntry {
     std::vector<uint8_t> key;  // the bytes of y[1..n)
@@ -214,7 +214,7 @@ struct Ctx {
   bool prof = false;
   std::vector<ProfRec> prof_recs;
   // helper ctx (same device, own stream / arena / pinned blocks; capi.cpp ctx_helper) and what it is committing ahead of
-  // the opening (prover.cpp open_precommit_*): both owned by this ctx
+  // the opening (open_columns.cpp open_precommit_*): both owned by this ctx
   Ctx* helper = nullptr;
   void* helper_handle = nullptr;
   void* precommit = nullptr;
@@ -241,12 +241,6 @@ struct Ctx {
     if (!sort_ev[side]) LH_HIP(hipEventCreateWithFlags(&sort_ev[side], hipEventDisableTiming));
     return sort_ev[side];
   }
-  // second stream + fork / join events: memory-bound work of an MSM batch (the sort of the slabs it accumulates last)
-  // beside the ALU-bound accumulation on the main stream (msm.hip)
-  hipStream_t stream2 = nullptr, stream3 = nullptr;  // stream3: the complement CU mask of a masked stream2 (else null)
-  hipEvent_t fork_ev = nullptr, join_ev = nullptr, join3_ev = nullptr;
-  // cu_share > 0: stream2 gets every cu_share-th CU, stream3 the others (hipExtStreamCreateWithCUMask)
-  hipStream_t second_stream(int cu_share = 0);
   void d2h(void* dst, const void* d_src, size_t bytes);
   void sync() { LH_HIP(hipStreamSynchronize(stream)); }
   // Round-trip fast path: a kernel publishes its (small) result into pinned memory and then stores a
@@ -512,7 +506,7 @@ struct ScRound {
   uint8_t nfac[LH_SC_MAX_TERMS];
   uint8_t fac[LH_SC_MAX_TERMS][LH_SC_MAX_FACTORS];
   Fr r;  // challenge of the previous round (BIND only)
-  // "eq factoring" (prover.cpp): when set, global_eq is -1 and the eq factor of the expression is eq_level[b], the eq
+  // "eq factoring" (sumcheck.cpp): when set, global_eq is -1 and the eq factor of the expression is eq_level[b], the eq
   // table over the variables AFTER this round's; the kernel returns q(X) = sum_b eq_level[b] * g(X, b)
   const Fr* eq_level;
   // product-pair shape (every term coeff_m * l_m * r_m over 2 num_terms distinct tables, factored eq; the generic layers of
@@ -717,7 +711,7 @@ struct SortSlab {
 void sort_pairs_u32(Ctx&, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, size_t n,
                     unsigned bits, unsigned first_bit = 0);
 // `count` independent sorts as ONE launch set per radix pass (temporary storage from the arena: the caller's ArenaScope)
-void sort_pairs_u32_batched(Ctx&, const SortSlab* slabs, size_t count, int side = 0);  // side 1: on the ctx's second stream
+void sort_pairs_u32_batched(Ctx&, const SortSlab* slabs, size_t count);
 void sort_pairs_u64(Ctx&, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, size_t n,
                     unsigned bits);
 
@@ -760,7 +754,7 @@ constexpr uint32_t MSM_PACK_MAX_BITS = 20;
 // far above it; a rank's shard of a level - 2^20 points against 2^20 buckets at 8 ranks - is not.)
 constexpr size_t MSM_PACK_MIN_POINTS_PER_BUCKET = 8;
 Ctx& ctx_helper(Ctx&);            // the ctx's helper ctx (created on first use, destroyed with the ctx)
-void open_precommit_cancel(Ctx&);  // waits for a running precommit and drops it (prover.cpp)
+void open_precommit_cancel(Ctx&);  // waits for a running precommit and drops it (open_columns.cpp)
 uint32_t msm_window_bits(size_t n);  // window width msm_batch picks for a full-width (254-bit) column of n points
 void k_msm_window_table(Ctx&, const G1Affine* bases, size_t n, uint32_t cbits, uint32_t W, G1Affine* out);
 // Runs all jobs as one batched Pippenger; out[j] is the affine sum (identity = (0,0)).

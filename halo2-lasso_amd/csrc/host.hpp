@@ -144,7 +144,7 @@ struct EqHalfScope {  // forgets, on exit, what was cached after its creation
   ~EqHalfScope() { c.eq_half_cache.resize(mark); }
 };
 
-// the round loop shared by every sum-check front end (prover.cpp)
+// the round loop shared by every sum-check front end (sumcheck.cpp)
 typedef std::function<void(const Fr* const*, Fr* const*, const Fr&, bool, size_t, Fr*)> RoundFn;
 // Eq factoring of the streaming rounds.  eq(y, x) = prod_i eq(y_i, x_i), so in round j (prefix bound to rho):
 //   eq(y, (rho, X, b)) = S_j * eq(y_j, X) * E_j[b],   S_j = prod_{i<j} eq(y_i, rho_i),   E_j = eq table over variables > j.
@@ -229,7 +229,7 @@ struct Srs {
   mutable int shard_rank = -1;
   mutable size_t shard_R = 0, shard_j = 0;
   // sum of all bases of a level (mkzg_open over small-valued columns), computed on first use
-  mutable std::map<size_t, HG1> level_sums;  // (guarded by one process-wide mutex in prover.cpp)
+  mutable std::map<size_t, HG1> level_sums;  // (guarded by one process-wide mutex, open_columns.hpp srs_cache_mu)
   mutable std::map<size_t, HG1> shard_level_sums;  // the same over this rank's share of a sharded level
   // window tables of whole levels (dev.hpp MsmJob::win_table; Options::msm_window_tables), built on first use
   struct WinTable {
@@ -247,7 +247,7 @@ std::vector<HG1> mkzg_batch_commit_u32(Ctx&, const Srs&, const uint32_t* const* 
                                        size_t num_vars);
 struct SmallOpen;
 // small (optional): d_poly = sum_k coef[k] * cols[k] with small-valued columns: the largest quotient is then committed
-// column by column from 32-bit differences (prover.cpp)
+// column by column from 32-bit differences (mkzg.cpp, open_columns.cpp)
 HFr mkzg_open(Ctx&, const Srs&, const Fr* d_poly, size_t num_vars, const HFr* point, Transcript& tr,
               const SmallOpen* small = nullptr);
 // a poly handed over as its small-valued u32 column (`len` entries, zero beyond): Lasso's dim / read_ts / E / final_cts

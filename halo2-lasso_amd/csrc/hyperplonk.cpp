@@ -187,7 +187,7 @@ void hyperplonk_prove_phases(Ctx& c, const PcsProver& pcs, const lh_hp_param& pp
   // here.  What crosses ranks: partial commitments (one exchange per commit round), the zero-check's partial sums and its
   // residual tables (sum_check_loop), the rows of polys queried at a rotation (gathered once, expr.cpp), the per-row
   // products of the permutation argument (gathered once: the prefix product in hypercube order runs on every rank,
-  // prover.rs:308-323), the Lasso lookups' exchanges (lasso.cpp) and the shared batch opening's (prover.cpp).  LogUp
+  // prover.rs:308-323), the Lasso lookups' exchanges (lasso.cpp) and the shared batch opening's (mkzg.cpp).  LogUp
   // lookups (the m poly is a global sort-merge join) are not sharded: such circuits run as replicas.
   const Shard sh(c);
   const bool shn = sh.on;

@@ -237,7 +237,7 @@ void k_sc_round_ext(Ctx& c, const ExtRound& rd, int degree, bool bind, size_t si
   size_t g = (size * tp + 255) / 256;
   size_t cap = (size_t)c.num_cus * 8;
   if (g > cap) g = cap;
-  evals_host = c.round_out(evals_host);  // (sharded rounds: the sums stay on the device, prover.cpp)
+  evals_host = c.round_out(evals_host);  // (sharded rounds: the sums stay on the device, sumcheck.cpp)
   Fr* partials = g == 1 ? evals_host : c.arena.alloc_n<Fr>(g * degree);
   const ScFinishArgs fin = c.finish_for((uint32_t)g, evals_host, seq);
   {
@@ -381,7 +381,7 @@ void k_sc_round_prog(Ctx& c, const ProgRound& pr, int degree, size_t size, Fr* e
   // compiled form: one wave per workgroup and a grid of (g, degree) workgroups, all of which draw a ticket
   const size_t cap = jit ? std::max<size_t>(1, (size_t)c.num_cus * (size_t)per_cu / (size_t)degree) : (size_t)c.num_cus * (size_t)per_cu;
   if (g > cap) g = cap;
-  evals_host = c.round_out(evals_host);  // (sharded rounds: the sums stay on the device, prover.cpp)
+  evals_host = c.round_out(evals_host);  // (sharded rounds: the sums stay on the device, sumcheck.cpp)
   Fr* partials = (g == 1 && !jit) ? evals_host : c.arena.alloc_n<Fr>(g * degree);
   const ScFinishArgs fin = c.finish_for((uint32_t)(jit ? g * degree : g), evals_host, seq);
   {

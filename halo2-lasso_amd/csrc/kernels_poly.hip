@@ -436,7 +436,7 @@ __global__ void lincomb_kernel(LcPack pk, int count, size_t n, Fr* __restrict__ 
   }
 }
 // first step of an mKZG opening of g = sum_k w_k p_k without forming g: out[b] = lo + x (hi - lo) with lo = g[b],
-// hi = g[b + half] (the quotient hi - lo itself is committed another way: prover.cpp mkzg_open, SmallOpen)
+// hi = g[b + half] (the quotient hi - lo itself is committed another way: mkzg.cpp mkzg_open, SmallOpen)
 __global__ void lincomb_fold_kernel(LcPack pk, int count, size_t half, Fr x, Fr* __restrict__ out) {
   GSTRIDE(i, half) {
     Fr lo = Fr::zero(), hi = Fr::zero();

@@ -852,7 +852,7 @@ static size_t sc_entry_blocks_per_cu() {
 
 // ------------------------------------------------------------------ batch-opening rounds with factored eq tables
 // expression sum_m eq_m(x) * poly_m(x) (pcs/multilinear.rs:182-190): per term and pair one bind (2 multiplications),
-// two products with the term's eq-level entry; the eq tables are neither read in full nor bound (prover.cpp).
+// two products with the term's eq-level entry; the eq tables are neither read in full nor bound (sumcheck.cpp).
 // (the number of terms is a template parameter: an accumulator array indexed by a run-time term count lives in scratch
 // memory - 400 B per lane of spills doubled the kernel's HBM writes)
 template <int M, bool BIND>
@@ -901,7 +901,7 @@ void k_sc_round_open(Ctx& c, const ScOpenRound& rd, bool bind, size_t size, Fr* 
   LH_REQUIRE(rd.num_terms >= 1 && rd.num_terms <= (uint32_t)SC_OPEN_MAX_TERMS && size >= 1, LH_ERR_ARG, "sc_round_open: bad shape");
   const uint32_t seq = c.next_seq();
   ArenaScope scope(c.arena);
-  out_host = c.round_out(out_host);  // (sharded rounds: the sums stay on the device, prover.cpp)
+  out_host = c.round_out(out_host);  // (sharded rounds: the sums stay on the device, sumcheck.cpp)
   size_t g = std::min<size_t>((2 * size + 255) / 256, (size_t)c.num_cus * sc_entry_blocks_per_cu());
   const int nq = 2 * (int)rd.num_terms;
   Fr* partials = g == 1 ? out_host : c.arena.alloc_n<Fr>(g * nq);
@@ -925,7 +925,7 @@ void k_sc_round_open(Ctx& c, const ScOpenRound& rd, bool bind, size_t size, Fr* 
 // ------------------------------------------------------------------ grand-product layer over (A, A + 1) tree pairs
 // FOLD (a BIND round): what is stored is l'_p = cs_p (l_p + k_p) and r'_p = r_p + k_p (binding is affine: the bound
 // tables of l', r' ARE the folded bound tables), so that every later round is the plain product-pair shape sum_p l'_p r'_p
-// and runs sc_round_pp_kernel (prover.cpp divides cs out of, and takes k off, the final evaluations).  Either way the P
+// and runs sc_round_pp_kernel (sumcheck.cpp divides cs out of, and takes k off, the final evaluations).  Either way the P
 // products of a lane share one Montgomery reduction (ff.cuh dot): 2 P -> P + ~0.6 P products (fold round: the P
 // multiplications by cs are the fold itself).
 template <int P, bool BIND, bool FOLD>
@@ -1031,7 +1031,7 @@ void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, F
   const double bytes = (bind ? 192.0 : 64.0) * (double)size * (double)tabs + (rd.eq_level ? 32.0 * (double)size : 0.0);
   const uint32_t seq = c.next_seq();
   ArenaScope scope(c.arena);
-  // sharded rounds (prover.cpp): the D sums stay on the device (all-gather and sum-and-publish follow on the stream)
+  // sharded rounds (sumcheck.cpp): the D sums stay on the device (all-gather and sum-and-publish follow on the stream)
   evals_host = c.round_out(evals_host);
   auto finish = [&](size_t grid) { return c.finish_for((uint32_t)grid, evals_host, seq); };
 

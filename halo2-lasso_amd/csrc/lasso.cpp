@@ -424,7 +424,7 @@ void lasso_prove(Ctx& c, const LassoPcs& pcs, const lh_lasso_table& tb, size_t n
   // every committed poly is zero-padded to nv = max(n, l) variables (spec step 1)
   // Inside a sharded proof (dev.hpp Shard, lasso_prove_sharded below) d_dims are this rank's shards of the lookup columns
   // and every n-variable column below is a shard of N = 2^(n - rho) entries; what crosses ranks: the access counters'
-  // exchange, partial commitments, partial sums per round, residual tables (prover.cpp).  World of one: nothing.
+  // exchange, partial commitments, partial sums per round, residual tables (sumcheck.cpp, gkr.cpp, mkzg.cpp).  World of one: nothing.
   const Shard sh(c);
   const bool shn = sh.on;
   if (shn) {

@@ -189,11 +189,10 @@ void msm_accumulate0_kernel(MsmPlanDev plan, size_t total,
                                                               const uint32_t* __restrict__ sorted_idx, uint32_t K,
                                                               G1Xyzz* __restrict__ buckets,
                                                               uint32_t* __restrict__ cont_key,
-                                                              G1Xyzz* __restrict__ cont_pt, size_t chunk0, size_t nchunks,
+                                                              G1Xyzz* __restrict__ cont_pt, size_t nchunks,
                                                               uint32_t* __restrict__ cont_count) {
   __shared__ uint32_t lds_key[ACC_GROUP * 128], lds_idx[ACC_GROUP * 128];
-  // chunks [chunk0, nchunks) (a batch whose last slabs are still being sorted accumulates in two launches)
-  for (size_t t = chunk0 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < nchunks; t += (size_t)gridDim.x * blockDim.x) {
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < nchunks; t += (size_t)gridDim.x * blockDim.x) {
     const size_t p0 = t * K < total ? t * K : total, p1 = p0 + K < total ? p0 + K : total;
     uint32_t ck = SENTINEL;
     if (p0 < p1) {
@@ -800,7 +799,6 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, 
       for (size_t j = 0; j < nj; j++) total_pts += plan.job[j].n, full_pts += plan.job[j].is_u32 ? 0 : plan.job[j].n;
       unsigned key_bits = 1;
       while (((size_t)1 << key_bits) <= nbuckets) key_bits++;
-      size_t e_split = 0;  // != 0: entries from here on are being sorted on the second stream (join_ev)
       {
         ProfScope ps(c, "msm_digits", 32.0 * full_pts + 4.0 * (total_pts - full_pts) + 8.0 * max_entries, full_pts,
                      total_pts);
@@ -809,7 +807,6 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, 
       }
       {
         ProfScope ps(c, "msm_sort", 32.0 * max_entries, 0, (double)max_entries);
-        e_split = 0;
         // small jobs: one sort by the whole key; big jobs: every (job, window) slab by its digit bits only - all of them
         // as ONE batch of the radix sort (sort.hip): three launches per pass for the whole MSM batch
         std::vector<SortSlab> sorts;
@@ -834,29 +831,7 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, 
             sorts.push_back(SortSlab{ukey + e, skey + e, uidx + e, sidx + e, jd.n, sort_bits[j]});
           }
         }
-        // Pipeline: the accumulation is ALU-bound, the sort memory-bound, and two streams overlap such kernels almost
-        // perfectly (tools/ubench/overlap_mask.hip).  The entries the accumulation reaches first - everything before
-        // `e_split`, a slab boundary about 30 % into the stream - are sorted on the main stream; the remaining slabs sort
-        // on the ctx's second stream while the first accumulate launch runs, the second launch waits for them.
-        static const int pipe_mode = env_int("LH_MSM_PIPELINE", 0);  // 1: two plain streams; k >= 2: every k-th CU for the sorts
-        const bool pipe_on = pipe_mode != 0;
-        size_t first_group = sorts.size();
-        if (pipe_on && !c.prof && max_entries >= ((size_t)1 << 22)) {
-          for (size_t k = 0; k < sorts.size(); k++)
-            if ((size_t)(sorts[k].keys_in - ukey) >= (max_entries * 3) / 10) {
-              first_group = k;
-              break;
-            }
-        }
-        if (first_group < sorts.size()) {
-          e_split = (size_t)(sorts[first_group].keys_in - ukey);
-          hipStream_t s2 = c.second_stream(pipe_mode);
-          LH_HIP(hipEventRecord(c.fork_ev, c.stream));  // (after the emit and the pre-sorted copies)
-          LH_HIP(hipStreamWaitEvent(s2, c.fork_ev, 0));
-          sort_pairs_u32_batched(c, sorts.data() + first_group, sorts.size() - first_group, 1);
-          LH_HIP(hipEventRecord(c.join_ev, s2));
-        }
-        if (first_group) sort_pairs_u32_batched(c, sorts.data(), first_group);
+        if (!sorts.empty()) sort_pairs_u32_batched(c, sorts.data(), sorts.size());
       }
 
       // segmented accumulate, level 0 then K-fold shrinking continuation lists
@@ -872,25 +847,8 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, 
         // MSM algorithmic bytes: 96 B per point (32 B scalar + 64 B base), 68 B for a u32 column,
         // whatever the number of windows; `items` = sorted (point, window) entries, a mixed add is 10 Fq muls
         ProfScope ps(c, "msm_accumulate0", 96.0 * full_pts + 68.0 * (total_pts - full_pts), 10.0 * h_total, (double)h_total);
-      // (two launches when the tail of the stream is still being sorted: chunks that end before e_split first)
-      const size_t c1 = e_split ? e_split / K : 0;
-      if (c1) {
-        // (with CU masks: the first launch on the stream that owns the CUs the sorts do not)
-        hipStream_t sa = c.stream3 ? c.stream3 : c.stream;
-        if (c.stream3) {
-          LH_HIP(hipEventRecord(c.join3_ev, c.stream));
-          LH_HIP(hipStreamWaitEvent(sa, c.join3_ev, 0));
-        }
-        hipLaunchKernelGGL(msm_accumulate0_kernel, dim3((unsigned)std::min<size_t>((c1 + 127) / 128, 1 << 16)), dim3(128), 0, sa,
-                           plan, max_entries, skey, sidx, K, buckets, ckey, cpt, (size_t)0, c1, lvl_cnt);
-        if (c.stream3) {
-          LH_HIP(hipEventRecord(c.join3_ev, sa));
-          LH_HIP(hipStreamWaitEvent(c.stream, c.join3_ev, 0));
-        }
-      }
-      if (e_split) LH_HIP(hipStreamWaitEvent(c.stream, c.join_ev, 0));
-      hipLaunchKernelGGL(msm_accumulate0_kernel, dim3((unsigned)std::min<size_t>((nchunks - c1 + 127) / 128, 1 << 16)),
-                         dim3(128), 0, c.stream, plan, max_entries, skey, sidx, K, buckets, ckey, cpt, c1, nchunks, lvl_cnt);
+      hipLaunchKernelGGL(msm_accumulate0_kernel, dim3((unsigned)std::min<size_t>((nchunks + 127) / 128, 1 << 16)), dim3(128), 0,
+                         c.stream, plan, max_entries, skey, sidx, K, buckets, ckey, cpt, nchunks, lvl_cnt);
       }
       {
         ProfScope ps(c, "msm_accumulate_levels", 0, 0, (double)nchunks);
@@ -997,7 +955,7 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, 
 }
 
 // ------------------------------------------------------------------ window tables (MsmJob::win_table)
-// out[w * n + i] = 2^(c w) * bases[i], affine, w < W.  Built once per SRS level (prover.cpp srs_window_table): with the
+// out[w * n + i] = 2^(c w) * bases[i], affine, w < W.  Built once per SRS level (mkzg.cpp srs_window_table): with the
 // multiples at hand the W windows of a full-width scalar file into ONE bucket set - the bucket reduction, the window sums
 // and the host's doublings of that job shrink W-fold, the additions of the accumulation stay what they were.
 __global__ __launch_bounds__(128) void msm_window_table_kernel(const G1Affine* __restrict__ bases, size_t n, uint32_t cbits,

@@ -292,12 +292,11 @@ size_t rs_batch_bytes(const RsJob* slabs, size_t count, size_t key_bytes) {
   for (size_t i = 0; i < count; i++) bytes += rs_plan(slabs[i].n, slabs[i].bits, key_bytes).bytes;
   return bytes;
 }
-// `side` (0 / 1): 0 = the ctx's stream; 1 = the ctx's second stream (an MSM batch sorts the slabs it accumulates last on
-// it, beside the accumulation of the first ones); each side has its own pinned descriptor staging
 template <class K>
-void rs_sort_batch(Ctx& c, const RsJob* slabs, size_t count, void* temp, int side = 0) {
+void rs_sort_batch(Ctx& c, const RsJob* slabs, size_t count, void* temp) {
+  const int side = 0;  // (one pinned descriptor staging per ctx)
   const size_t key_bytes = sizeof(K);
-  hipStream_t stream = side ? c.second_stream() : c.stream;
+  hipStream_t stream = c.stream;
   std::vector<RsSlab> host;
   char* cur = (char*)(((uintptr_t)temp + 255) & ~(uintptr_t)255);
   RsSlab* d_slabs = (RsSlab*)cur;
@@ -359,12 +358,12 @@ void rs_sort_batch(Ctx& c, const RsJob* slabs, size_t count, void* temp, int sid
 }
 }  // namespace
 
-void sort_pairs_u32_batched(Ctx& c, const SortSlab* slabs, size_t count, int side) {
+void sort_pairs_u32_batched(Ctx& c, const SortSlab* slabs, size_t count) {
   std::vector<RsJob> jobs(count);
   for (size_t i = 0; i < count; i++)
     jobs[i] = RsJob{slabs[i].keys_in, slabs[i].keys_out, slabs[i].vals_in, slabs[i].vals_out, slabs[i].n, slabs[i].bits};
   void* temp = c.arena.alloc(rs_batch_bytes(jobs.data(), count, 4));  // caller's ArenaScope releases it
-  rs_sort_batch<uint32_t>(c, jobs.data(), count, temp, side);
+  rs_sort_batch<uint32_t>(c, jobs.data(), count, temp);
 }
 
 void sort_pairs_u32(Ctx& c, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
