@@ -61,6 +61,10 @@ struct MsmJobDev {
   uint32_t red_W;       // windows of the reduction (= W except for packed jobs)
   uint32_t nsplit;      // workgroups (shares) per window in the window-sum kernel
   uint32_t share_base;  // first share (workgroup / output slot) of this job
+  uint32_t two_level;   // bucket reduction in two levels (msm_group_reduce_kernel): the segment kernel leaves A_s and T_s,
+                        // groups of MSM_GROUP segments are weighed together - one small multiple per group instead of per segment
+  uint32_t grp_base;    // first group slot of this job (two_level)
+  uint32_t sum_per_win; // partials per window the window-sum kernel adds: groups (two_level) or segments
   uint32_t merged;      // `bases` is a window table (MsmJob::win_table: entry w * n + i = 2^(c w) * base i): all W windows
                         // fill ONE bucket set (red_W = 1), the entry's index carries the window
 };
@@ -378,8 +382,65 @@ __device__ __forceinline__ G1Xyzz mul_small(const G1Xyzz& p, uint32_t k) {
   return k ? acc : G1Xyzz::identity();
 }
 
+// quad-cooperative small multiple (the reductions of batches with few segments, the group kernel)
+__device__ __forceinline__ G1Xyzz mul_small_quad(const G1Xyzz& p, uint32_t k) {
+  G1Xyzz acc = G1Xyzz::identity();
+  for (int b = 31 - __clz(k | 1u); b >= 0; b--) {
+    acc = dbl_quad(acc);
+    if ((k >> b) & 1u) acc = add_quad(acc, p);
+  }
+  return k ? acc : G1Xyzz::identity();
+}
+
+// Two-level reduction (jobs with >= MSM_GROUP^2 segments per window, throughput-bound batches).  sum_b (b + 1) B_b over a
+// window, segment s = S consecutive buckets from d0 = s S:  the running sums of the segment give A_s = sum_d d B_{d0 + d}
+// (zero-based) and T_s = sum_d B_{d0 + d}, and the window's sum is  sum_s [A_s + (d0 + 1) T_s].  One small-scalar
+// multiplication per SEGMENT (~1.5 log2(buckets) curve operations next to the 2 S of the running sums: 40 % of the
+// reduction's work at S = 16) becomes one per GROUP of MSM_GROUP segments: over a group g (s = G g + j) the same running
+// sums over the T_j give  sum_j j T_j  and  sum_j T_j, and
+//   sum_j [A_j + (S (G g + j) + 1) T_j] = sum_j A_j + S sum_j j T_j + (S G g + 1) sum_j T_j.
+// 2.3 instead of 3.5 curve operations per bucket.  Packed jobs (bucket index = lo | hi << shift, shift >= log2(S G)): the
+// low part weighs  sum_j A_j + S sum_j j T_j + lo(g) sum_j T_j,  the high part  hi(g) sum_j T_j.
+constexpr uint32_t MSM_GROUP = 16;
+__global__ __launch_bounds__(64) void msm_group_reduce_kernel(MsmPlanDev plan, const G1Xyzz* __restrict__ seg_a,
+                                                              const G1Xyzz* __restrict__ seg_t, G1Xyzz* __restrict__ grp_out,
+                                                              size_t total_groups) {
+  // one QUAD of lanes per group (ec.cuh quad-cooperative arithmetic): there are MSM_GROUP times fewer groups than segments -
+  // far too few to fill the chip - and a group is a chain of ~85 dependent curve operations
+  const bool lead = (threadIdx.x & 3u) == 0;
+  const size_t quads = ((size_t)gridDim.x * blockDim.x) >> 2;
+  for (size_t gi = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; gi < total_groups; gi += quads) {
+    int j = 0;
+    while (j + 1 < plan.num_jobs && plan.job[j + 1].grp_base <= gi) j++;
+    const MsmJobDev& jb = plan.job[j];  // (jobs that are not two_level own no group: grp_base repeats, the search passes them)
+    const uint32_t local = (uint32_t)(gi - jb.grp_base), gpw = jb.seg_per_win / MSM_GROUP;
+    const uint32_t w = local / gpw, g = local % gpw;
+    if (jb.pack_shift && w) continue;  // (written by the quad of "window" 0)
+    const size_t s0 = (size_t)jb.seg_base + (size_t)w * jb.seg_per_win + (size_t)g * MSM_GROUP;
+    G1Xyzz run = G1Xyzz::identity(), acc = G1Xyzz::identity(), sum_a = G1Xyzz::identity();
+    for (int d = (int)MSM_GROUP - 1; d >= 0; d--) {
+      acc = add_quad(acc, run);
+      run = add_quad(run, seg_t[s0 + d]);
+      sum_a = add_quad(sum_a, seg_a[s0 + d]);
+    }
+    for (uint32_t k = 1; k < jb.seg_size; k <<= 1) acc = dbl_quad(acc);  // S sum_j j T_j
+    sum_a = add_quad(sum_a, acc);
+    const uint32_t d0 = g * MSM_GROUP * jb.seg_size;  // first bucket of the group
+    if (jb.pack_shift) {
+      const uint32_t lo = d0 & ((1u << jb.pack_shift) - 1u), hi = d0 >> jb.pack_shift;
+      const G1Xyzz high = mul_small_quad(run, hi);
+      const G1Xyzz low = add_quad(sum_a, mul_small_quad(run, lo));
+      if (lead) grp_out[gi + gpw] = high, grp_out[gi] = low;
+    } else {
+      const G1Xyzz r = add_quad(sum_a, mul_small_quad(run, d0 + 1));  // bucket index b holds digit b + 1
+      if (lead) grp_out[gi] = r;
+    }
+  }
+}
+
 __global__ __launch_bounds__(64) void msm_segment_reduce_kernel(MsmPlanDev plan, const G1Xyzz* __restrict__ buckets,
-                                                                G1Xyzz* __restrict__ seg_out, size_t total_segs) {
+                                                                G1Xyzz* __restrict__ seg_out, G1Xyzz* __restrict__ seg_t,
+                                                                size_t total_segs) {
   for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < total_segs; s += (size_t)gridDim.x * blockDim.x) {
     int j = 0;
     while (j + 1 < plan.num_jobs && plan.job[j + 1].seg_base <= s) j++;
@@ -393,6 +454,11 @@ __global__ __launch_bounds__(64) void msm_segment_reduce_kernel(MsmPlanDev plan,
     for (int d = (int)jb.seg_size - 1; d >= 0; d--) {
       acc = add(acc, run);
       run = add(run, b[d]);
+    }
+    if (jb.two_level) {  // A_s and T_s: the multiples are the group kernel's business
+      seg_out[s] = acc;
+      seg_t[s] = run;
+      continue;
     }
     if (jb.pack_shift) {
       // bucket index = packed value: "window" 0 weighs it with its low part (linear inside the aligned segment), 1 with
@@ -408,15 +474,6 @@ __global__ __launch_bounds__(64) void msm_segment_reduce_kernel(MsmPlanDev plan,
 }
 
 // quad-cooperative form for batches with few segments (latency-bound: the chain is 2 S additions + a small multiple)
-__device__ __forceinline__ G1Xyzz mul_small_quad(const G1Xyzz& p, uint32_t k) {
-  G1Xyzz acc = G1Xyzz::identity();
-  for (int b = 31 - __clz(k | 1u); b >= 0; b--) {
-    acc = dbl_quad(acc);
-    if ((k >> b) & 1u) acc = add_quad(acc, p);
-  }
-  return k ? acc : G1Xyzz::identity();
-}
-
 __global__ __launch_bounds__(64) void msm_segment_reduce_quad_kernel(MsmPlanDev plan, const G1Xyzz* __restrict__ buckets,
                                                                      G1Xyzz* __restrict__ seg_out, size_t total_segs) {
   const bool lead = (threadIdx.x & 3u) == 0;
@@ -454,7 +511,8 @@ __global__ __launch_bounds__(64) void msm_segment_reduce_quad_kernel(MsmPlanDev 
 // The sums go straight into pinned host memory; the workgroup that finishes last publishes the flag the
 // host spins on (same ticket protocol as the sum-check rounds): no device-to-host copy, no stream synchronise.
 __global__ __launch_bounds__(512) void msm_window_sum_kernel(MsmPlanDev plan, const G1Xyzz* __restrict__ seg_out,
-                                                             G1Xyzz* __restrict__ win_out, ScFinishArgs fin) {
+                                                             const G1Xyzz* __restrict__ grp_out, G1Xyzz* __restrict__ win_out,
+                                                             ScFinishArgs fin) {
   // 128 quads of lanes (ec.cuh: quad-cooperative additions): a share of <= 1024 partials is 8 + 7 dependent additions
   __shared__ G1Xyzz lds[128];
   int j = 0;
@@ -464,9 +522,10 @@ __global__ __launch_bounds__(512) void msm_window_sum_kernel(MsmPlanDev plan, co
   const uint32_t w = (blockIdx.x - jb.share_base) / nsplit, part = (blockIdx.x - jb.share_base) % nsplit;
   const uint32_t q = threadIdx.x >> 2;
   const bool lead = (threadIdx.x & 3u) == 0;
-  const uint32_t share = (jb.seg_per_win + nsplit - 1) / nsplit;
-  const uint32_t lo = part * share, hi = min(lo + share, jb.seg_per_win);
-  const G1Xyzz* src = seg_out + jb.seg_base + (size_t)w * jb.seg_per_win;
+  const uint32_t share = (jb.sum_per_win + nsplit - 1) / nsplit;
+  const uint32_t lo = part * share, hi = min(lo + share, jb.sum_per_win);
+  // (two-level jobs: the groups' partials, one per MSM_GROUP segments)
+  const G1Xyzz* src = jb.two_level ? grp_out + jb.grp_base + (size_t)w * jb.sum_per_win : seg_out + jb.seg_base + (size_t)w * jb.seg_per_win;
   G1Xyzz acc = G1Xyzz::identity();
   for (uint32_t i = lo + q; i < hi; i += 128) acc = add_quad(acc, src[i]);
   if (lead) lds[q] = acc;
@@ -725,6 +784,7 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, 
       jd.key_base = key;
       jd.seg_base = seg;
       jd.win_base = win;
+      jd.two_level = 0, jd.grp_base = 0, jd.sum_per_win = jd.seg_per_win;  // (decided below, once the batch's size is known)
       key += (jd.merged ? 1 : jd.W) * jd.win_stride;
       seg += jd.red_W * jd.seg_per_win;
       win += jd.red_W;
@@ -742,13 +802,29 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, 
         if (!pass) small_entries = max_entries;
       }
     const size_t nbuckets = key, nsegs = seg, nwins = win;
+    // two-level reduction: throughput-bound batches (the plain segment kernel runs), jobs whose windows hold at least
+    // MSM_GROUP^2 segments, packed jobs only when a group never straddles a change of the high part
+    static const int two_level_on = env_int("LH_MSM_TWO_LEVEL", 1);
+    const bool plain_reduce = nsegs > (size_t)MSM_QUAD_MAX / 2;
+    size_t ngroups = 0;
+    for (size_t j = 0; j < nj; j++) {
+      MsmJobDev& jd = plan.job[j];
+      jd.grp_base = (uint32_t)ngroups;
+      const bool ok = two_level_on && plain_reduce && jd.red_W && jd.seg_size >= 2 && (jd.seg_size & (jd.seg_size - 1)) == 0 &&
+                      jd.seg_per_win >= MSM_GROUP * MSM_GROUP && jd.seg_per_win % MSM_GROUP == 0 &&
+                      (!jd.pack_shift || ((1u << jd.pack_shift) % (MSM_GROUP * jd.seg_size)) == 0);
+      if (!ok) continue;
+      jd.two_level = 1;
+      jd.sum_per_win = jd.seg_per_win / MSM_GROUP;
+      ngroups += (size_t)jd.red_W * jd.sum_per_win;
+    }
     // window-sum shares: enough workgroups that no thread adds more than ~4 segment partials in sequence, few enough
     // that the host's share of the additions stays in the microseconds
     uint32_t nsplit = 1;
     {
       uint32_t max_spw = 1;
       for (size_t j = 0; j < nj; j++)
-        if (plan.job[j].W && plan.job[j].seg_per_win < 16384) max_spw = std::max(max_spw, plan.job[j].seg_per_win);
+        if (plan.job[j].W && plan.job[j].sum_per_win < 16384) max_spw = std::max(max_spw, plan.job[j].sum_per_win);
       static const int forced = env_int("LH_MSM_NSPLIT", 0);
       while (nsplit < 32 && max_spw / nsplit > 1024 && nwins * nsplit * 2 <= 4096) nsplit *= 2;
       if (forced > 0) nsplit = (uint32_t)forced;
@@ -756,7 +832,7 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, 
     uint32_t nshares = 0;
     for (size_t j = 0; j < nj; j++) {
       MsmJobDev& jd = plan.job[j];
-      jd.nsplit = jd.seg_per_win >= 16384 ? std::max<uint32_t>(nsplit, 32u) : nsplit;
+      jd.nsplit = jd.sum_per_win >= 16384 ? std::max<uint32_t>(nsplit, 32u) : nsplit;
       jd.share_base = nshares;
       nshares += jd.red_W * jd.nsplit;
     }
@@ -777,6 +853,8 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, 
       uint32_t* sidx = c.arena.alloc_n<uint32_t>(max_entries + 256);
       G1Xyzz* buckets = c.arena.alloc_n<G1Xyzz>(nbuckets);
       G1Xyzz* seg_out = c.arena.alloc_n<G1Xyzz>(nsegs);
+      G1Xyzz* seg_t = ngroups ? c.arena.alloc_n<G1Xyzz>(nsegs) : nullptr;   // T_s of the two-level jobs' segments
+      G1Xyzz* grp_out = ngroups ? c.arena.alloc_n<G1Xyzz>(ngroups) : nullptr;
       // pinned host memory: the window sums (written by the last kernel) followed by the key-block table staging
       const size_t nblocks = (nbuckets >> KEY_BLOCK_BITS) + 1;
       uint8_t* pin_base = (uint8_t*)c.pin(nshares * sizeof(G1Xyzz) + nblocks);
@@ -885,10 +963,13 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, 
                            plan, buckets, seg_out, nsegs);
       else
         hipLaunchKernelGGL(msm_segment_reduce_kernel, dim3((unsigned)std::min<size_t>((nsegs + 63) / 64, 1 << 16)),
-                           dim3(64), 0, c.stream, plan, buckets, seg_out, nsegs);
+                           dim3(64), 0, c.stream, plan, buckets, seg_out, seg_t, nsegs);
+      if (ngroups)
+        hipLaunchKernelGGL(msm_group_reduce_kernel, dim3((unsigned)std::min<size_t>((4 * ngroups + 63) / 64, 1 << 16)), dim3(64), 0,
+                           c.stream, plan, seg_out, seg_t, grp_out, ngroups);
       const uint32_t seq = c.next_seq();
       const ScFinishArgs fin = c.finish_for(nshares, nullptr, seq);
-      hipLaunchKernelGGL(msm_window_sum_kernel, dim3(nshares), dim3(512), 0, c.stream, plan, seg_out, win_out, fin);
+      hipLaunchKernelGGL(msm_window_sum_kernel, dim3(nshares), dim3(512), 0, c.stream, plan, seg_out, grp_out, win_out, fin);
       if (!overlap_done) overlap_done = true, (*overlap)();  // (the device is busy with this batch: the caller's host work now)
       {
         // the window combines follow when the device is through: workers awake and polling by then (batches of up to a few

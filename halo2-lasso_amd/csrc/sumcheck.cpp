@@ -278,6 +278,7 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
   bool factored_round = false;
   Fr *d_part = nullptr, *d_all = nullptr;  // sharded rounds: this rank's D sums, every rank's
   bool tail_ok = true;  // cleared when a resident tail ended early: the remaining rounds are launched one by one
+  bool resident_ok = true;  // cleared when the resident kernel's tail mode was tried and not taken
   for (size_t round = 0; round < num_vars; round++) {
     bool bind = round > 0;
     if (sh && round == x_round) {
@@ -328,27 +329,38 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
       sh = false;
       bind = false;
     }
-    if (ef_on && !sh && tail_ok && ef->resident_tail) {
+    if (ef_on && !sh && tail_ok && resident_ok && ef->resident_tail) {
       // the factored rounds go on INSIDE the resident kernel once the tables fit it (kernels_gkr.hip tail mode): no eq
-      // table is materialised, no round is launched any more
+      // table is materialised, no round is launched any more.  (Not in round 0 of a claim that has yet to be checked.)
       const size_t n0 = bind ? len >> 1 : len;
-      if (n0 >= 2 && n0 <= ((size_t)GKR_CAP * GKR_CAP)) {
+      if (n0 >= 2 && n0 <= ((size_t)GKR_CAP * GKR_CAP) && (round > 0 || ef->trusted_claim)) {
         resolve_claim();
         if (ef->resident_tail(cur, bind, r_prev, n0, round, claim, tr, res)) return res;
+        resident_ok = false;  // (the kernel did not start, or a coefficient is zero: launched rounds and the generic tail)
       }
     }
     const bool tail_now = !sh && tail_ok && tail_cap && (bind ? len >> 1 : len) <= tail_cap;
-    // (a sharded sum-check whose tail can run in the resident kernel stays factored until its exchange: the few small
-    // rounds before it run the factored kernels below their best size rather than lose the factoring - and with it the
-    // resident tail - to materialised eq tables)
-    const bool keep_factored = sh && tail_ok && ef_on && ef->resident_tail && !ef->per_term;
+    // A sum-check whose tail can run in the resident kernel stays factored until its tables fit it (sharded: until its
+    // exchange): the one or two rounds before that run the factored kernels below their best size rather than lose the
+    // factoring - and with it the resident tail - to materialised eq tables.  (Layers of four trees at 2^20 lookups leave the
+    // streaming size at 2^15 entries per table, one round short of the resident kernel's 2^14: every one of them used to
+    // fall back to eq tables, launched small rounds and the generic tail.)
+    const bool keep_factored = tail_ok && resident_ok && ef_on && ef->resident_tail && !ef->per_term &&
+                               (sh || (bind ? len >> 1 : len) > ((size_t)GKR_CAP * GKR_CAP));
     if (ef_on && !keep_factored && (tail_now || !ef->streams(bind, bind ? len >> 2 : len >> 1))) {
       // the rounds leave the streaming kernel: materialise every factored eq table in the form the standard path
-      // expects (the tables of the previous round, pending their bind with r_prev): S_{round-1} * E_{round-2}
-      LH_REQUIRE(round >= 2 && bind, LH_ERR_ARG, "sum-check: eq factoring ended before it began");
+      // expects (the tables of the previous round, pending their bind with r_prev): S_{round-1} * E_{round-2}; before
+      // round 2 that is the whole eq table of the point (S_0 = 1)
       for (EqFactoring::One& one : ef->eqs) {
         Fr* tab = c.arena.alloc_n<Fr>(len);
-        k_scale(c, one.level[round - 2], dev(one.S_prev), len, tab);
+        if (round >= 2) {
+          LH_REQUIRE(bind, LH_ERR_ARG, "sum-check: internal round mismatch");
+          k_scale(c, one.level[round - 2], dev(one.S_prev), len, tab);
+        } else if (sharded) {
+          eq_xy_shard(c, Shard(c), one.y, num_vars, 0, tab);
+        } else {
+          k_eq_xy(c, (const Fr*)one.y, num_vars, tab);
+        }
         cur[one.table] = tab;
       }
       ef_on = false;
@@ -679,8 +691,30 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
   std::vector<size_t> term_poly;  // per-term shape: the poly of term m
   const size_t nvl = num_vars - rho;  // variables of the local tables
   // (sharded: the first two rounds must be local ones, and the claim is not checked against partial sums)
-  if (ef_enabled && nvl >= 3 && (!sharded || j >= 2) && k_sc_round_streams(rd, degree, (size_t)1 << (nvl - 1)) &&
-      k_sc_round_streams(rd, degree, (size_t)1 << (nvl - 2))) {
+  // product-pair shape (dev.hpp ScRound::pp): every term c_m l_m r_m over 2 num_terms distinct tables, non-zero
+  // coefficients - the generic layers of the grand products
+  bool pp_terms = !rw && rd.num_terms >= 2 && c.opt.sc_pp_fold != 0;
+  {
+    std::vector<char> seen(T, 0);
+    for (uint32_t m = 0; m < rd.num_terms && pp_terms; m++) {
+      HFr co;
+      memcpy(&co, &rd.coeff[m], 32);
+      pp_terms = rd.nfac[m] == 2 && !co.is_zero();
+      for (int k = 0; k < 2 && pp_terms; k++) {
+        pp_terms = rd.fac[m][k] < num_polys && !seen[rd.fac[m][k]];
+        seen[rd.fac[m][k]] = 1;
+      }
+    }
+  }
+  // ... whose tail the resident kernel takes (kernels_gkr.hip tail mode): then the factoring pays even when the first
+  // rounds are below the streaming size - the tail runs factored inside the kernel, no eq table is ever built
+  const uint32_t tail_B = rw ? rw->num_pairs : rd.num_terms;
+  const bool tail_shape = c.opt.gkr_resident && c.opt.sc_tail && (pp_terms || rw) && num_polys == 2 * (size_t)tail_B &&
+                          tail_B <= (uint32_t)GKR_MAX_TREES && rd.global_eq >= 0 && prover_kind == LH_SC_EVALUATIONS &&
+                          degree >= 2 && sum_is_exact;
+  const bool streams2 = nvl >= 3 && k_sc_round_streams(rd, degree, (size_t)1 << (nvl - 1)) &&
+                        k_sc_round_streams(rd, degree, (size_t)1 << (nvl - 2));
+  if (ef_enabled && nvl >= 3 && (!sharded || j >= 2) && (streams2 || tail_shape)) {
     if (rd.global_eq >= 0 && prover_kind == LH_SC_EVALUATIONS && degree >= 2 && (!sharded || sum_is_exact)) {
       // shape A: eq(ys[global_eq]) times a sum of products that does not use that eq table as a factor
       bool ok = true;
@@ -733,23 +767,10 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
       use_ef = ok;
     }
   }
-  // product-pair shape (dev.hpp ScRound::pp): every term c_m l_m r_m over 2 num_terms distinct tables, non-zero
-  // coefficients.  Its factored rounds run sc_round_pp_kernel, and the first of them that binds folds the coefficients
-  // into the left factors: from then on every kernel of this sum-check (streaming, LDS-staged, resident tail) sees
-  // coefficients of one, and the final evaluations of the left factors are divided by c_m at the end.
-  bool pp_shape = use_ef && !ef.per_term && !rw && rd.num_terms >= 2 && c.opt.sc_pp_fold != 0;
-  {
-    std::vector<char> seen(T, 0);
-    for (uint32_t m = 0; m < rd.num_terms && pp_shape; m++) {
-      HFr co;
-      memcpy(&co, &rd.coeff[m], 32);
-      pp_shape = rd.nfac[m] == 2 && !co.is_zero();
-      for (int k = 0; k < 2 && pp_shape; k++) {
-        pp_shape = rd.fac[m][k] < num_polys && !seen[rd.fac[m][k]];
-        seen[rd.fac[m][k]] = 1;
-      }
-    }
-  }
+  // Its factored rounds run sc_round_pp_kernel, and the first of them that binds folds the coefficients into the left
+  // factors: from then on every kernel of this sum-check (streaming, LDS-staged, resident tail) sees coefficients of one,
+  // and the final evaluations of the left factors are divided by c_m at the end.
+  const bool pp_shape = use_ef && !ef.per_term && pp_terms;
   std::vector<HFr> pp_folded;  // the coefficients that went into the left factors (empty: not folded)
   bool rw_folded = false;      // tree-pair rounds (ScRwPairs): the tables hold l' = cs (l + k), r' = r + k since the first bind
   if (use_ef) {
