@@ -210,17 +210,10 @@ def cpu_baseline(hl, ctx, pp, table, kind, args, gpu_proof_fn):
             "sample_log_n": n, "proof_bytes_equal_gpu": bool(same)}
 
 
-# The integer-ALU ceiling of the field arithmetic (csrc/ff.cuh).  Rounds 1-3 priced it as "v_mad_u64_u32 at a quarter of the
-# VALU rate": measured in round 4 (tools/ubench/mul_fp64.hip, profiles/r04_ubench_mul_fp64.txt), EVERY VALU instruction of a
-# wave64 costs ~4.4-4.9 SIMD cycles here - v_mad_u64_u32 4.9, v_addc_co_u32 4.35 - so a Montgomery product is priced by its
-# instruction count: 129 multiply-adds + 128 add-with-carry + ~50 moves = ~307 instructions until the asm blocks went from one
-# per multiply-add to one per column (csrc/ff_cols.inc); since then 129 + 128 + 15 moves + 8 quotient digits + the 16 of the
-# conditional subtraction = ~296 (the 16 hazard nops that remain are not vector instructions).  At the 4-cycle issue cost of a
-# wave64 instruction (one wave per SIMD in flight per issue, MI355X_MICROARCH.md) that is 1184 cycles per wave-product =
-# 256 CUs x 4 SIMDs x 2.4 GHz x 64 lanes / 1184 = 133 G products/s; the measured chains reach 125-137 (a few instructions -
-# moves, selects - seem to issue in less than four cycles: the model is a ceiling of the model, not of the chip).
-INSTR_PER_FR_MUL = 296
-FR_MUL_CEILING_PER_S = 256 * 4 * 2.4e9 * 64 / (INSTR_PER_FR_MUL * 4)
+# The integer-ALU reference of the field arithmetic (csrc/ff.cuh) is the MEASURED chain (lh_fr_mul_chain: two independent
+# product chains per thread).  Rounds 1-4 printed a modelled "ceiling" next to it (~296 VALU instructions per product at a
+# 4-cycle wave64 issue: 133 G products/s); the measured chain sits at 125-138 G/s, i.e. it could beat the model - a ceiling
+# the chip beats is not one, so it is gone: `alu.frac` is against the measured chain only.
 
 
 def dominant(aggs):
@@ -233,8 +226,7 @@ def dominant(aggs):
 def roofline_objects(hl, ctx, aggs, traffic=(None, None)):
     """`roofline`: the kernel with the largest total time in the profiled prove, priced in SURVEY.md §8(d)'s
     algorithmic bytes (sum over its launches) / its HIP-event time (sum over its launches) against 8 TB/s HBM;
-    `alu`: the same launches against the Fr-multiplication peak (measured, and the instruction-issue ceiling next to
-    it)."""
+    `alu`: the same launches against the measured Fr-multiplication peak."""
     tot = sum(a["ms"] for a in aggs) or 1.0
     peak_mul = fr_mul_peak(hl, ctx)
     dom = dominant(aggs)
@@ -253,18 +245,12 @@ def roofline_objects(hl, ctx, aggs, traffic=(None, None)):
         roof["note"] = ("largest share of this prove: %s (%.0f %%, rounds resident in LDS: no HBM traffic, latency-bound); "
                         "the roofline is priced on the largest kernel that moves data" % (top["name"], 100.0 * top["ms"] / tot))
     mul_rate = dom["muls"] / (dom["ms"] * 1e-3) if dom["ms"] > 0 else 0.0
-    ceiling = FR_MUL_CEILING_PER_S
     alu = {"bound": "int32-mul", "kernel": dom["name"], "achieved": round(mul_rate / 1e9, 2),
            "peak": round(peak_mul / 1e9, 2), "unit": "G Fr-mul/s", "frac": round(mul_rate / peak_mul, 4),
            "peak_source": "measured (lh_fr_mul_chain: two independent product chains per thread, 256 products per "
                           "element)",
-           "ceiling": round(ceiling / 1e9, 1), "frac_of_ceiling": round(mul_rate / ceiling, 4),
-           "ceiling_derivation": "instruction issue: ~296 VALU instructions per Montgomery product (129 v_mad_u64_u32 + 128 "
-                                 "v_addc_co_u32 + 15 moves + 8 quotient digits + 16 for the conditional subtraction), 4 SIMD "
-                                 "cycles per wave64 instruction: 256 CU x 4 SIMD x 2.4 GHz x 64 / 1184 cycles (measured issue "
-                                 "costs: profiles/r04_ubench_mul_fp64.txt; the measured chain can sit a few percent above this "
-                                 "model); `achieved` counts a mixed addition as 10 products, of which the two of Y3 share a "
-                                 "reduction since round 4"}
+           "counting": "`achieved` counts a mixed addition as 10 products (the two of Y3 share a reduction); ~296 VALU "
+                       "instructions per product, each a ~4-cycle wave64 issue (profiles/r04_ubench_mul_fp64.txt)"}
     kernels = [{"name": a["name"], "launches": a["launches"], "ms": round(a["ms"], 3),
                 "GBps_all": round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1) if a["ms"] > 0 else 0.0,
                 "GBps_largest": round(a["big"]["bytes"] / (a["big"]["ms"] * 1e-3) / 1e9, 1) if a["big"]["ms"] > 0 else 0.0}
@@ -654,7 +640,18 @@ def main():
             dom = dominant(aggs)
             out["roofline"], out["alu"], out["kernels"] = roofline_objects(
                 hl, ctx, aggs, pmc_traffic(dom["name"], n, args.table, world, dom["launches"]))
+    if world > 1:
+        # device memory per rank after the headline's proofs (the workspace arena's high-water mark; SRS and lookup columns are
+        # on top of it): gathered over the control plane
+        mem = hdist.gather_objects(dist, hl.memory_stats(ctx))
+        if rank == 0:
+            out["memory_by_rank"] = [{"arena_high_water_mib": round(m["arena_high_water_bytes"] / 2**20, 1),
+                                      "device_used_mib": round((m["device_total_bytes"] - m["device_free_bytes"]) / 2**20, 1)}
+                                     for m in mem]
     if sharded:
+        if rank == 0:
+            out["comm_round"] = {0: "all-gather + sum-and-publish kernel", 1: "one all-reduce of u64 lanes into host memory",
+                                 2: "one all-reduce of u64 lanes, then a copy"}[hl.get_option(ctx, "comm_round")]
         # the sharded proof against the single-GPU prover on the same lookups (rank 0 holds the whole batch for it)
         stats = hl.comm_stats(ctx)
         if rank == 0:

@@ -243,6 +243,7 @@ extern "C" {
     pub fn lh_ctx_set_comm_loopback(ctx: *mut lh_ctx, rank: c_int, size: c_int, shard_bit: usize) -> lh_status;
     pub fn lh_ctx_comm_stats(ctx: *mut lh_ctx, out: *mut u64) -> lh_status;
     pub fn lh_ctx_comm_phase_stats(ctx: *mut lh_ctx, out: *mut u64, reset: c_int) -> lh_status;
+    pub fn lh_ctx_memory_stats(ctx: *mut lh_ctx, out: *mut u64) -> lh_status;
     pub fn lh_shard_extract(ctx: *mut lh_ctx, d_global: *const c_void, n_local: usize, shard_bit: usize, rho: usize,
                             rank: usize, elem_bytes: usize, d_local: *mut c_void) -> lh_status;
     // route options (include/lasso_hip.h lists the names) and the route the last Lasso prove took

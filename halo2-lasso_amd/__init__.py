@@ -907,6 +907,14 @@ def comm_phase_stats(ctx, reset=False):
     return {nm: {"collectives": int(out[2 * i]), "bytes": int(out[2 * i + 1])} for i, nm in enumerate(names) if out[2 * i]}
 
 
+def memory_stats(ctx):
+    """lh_ctx_memory_stats: the workspace arena's high-water mark and reservation, the device's free / total bytes"""
+    out = (C.c_uint64 * 4)()
+    _check(ctx.lib.lh_ctx_memory_stats(ctx.h, out))
+    return {"arena_high_water_bytes": int(out[0]), "arena_reserved_bytes": int(out[1]), "device_free_bytes": int(out[2]),
+            "device_total_bytes": int(out[3])}
+
+
 def attach_comm_loopback(ctx, rank, size, shard_bit):
     """lh_ctx_set_comm_loopback: measurement aid - every peer is a copy of this rank (the transcript is not a valid proof)"""
     _check(ctx.lib.lh_ctx_set_comm_loopback(ctx.h, rank, size, shard_bit))

@@ -569,6 +569,16 @@ lh_status lh_ctx_comm_phase_stats(lh_ctx* ctx, uint64_t out[16], int reset) {
   }
   LH_CATCH
 }
+lh_status lh_ctx_memory_stats(lh_ctx* ctx, uint64_t out[4]) {
+  LH_TRY NEED_CTX(ctx);
+  NEED(out);
+  out[0] = ctx->c.arena.high_water() + (ctx->c.helper ? ctx->c.helper->arena.high_water() : 0);
+  out[1] = ctx->c.arena.reserved() + (ctx->c.helper ? ctx->c.helper->arena.reserved() : 0);
+  size_t free_b = 0, total_b = 0;
+  LH_HIP(hipMemGetInfo(&free_b, &total_b));
+  out[2] = free_b, out[3] = total_b;
+  LH_CATCH
+}
 lh_status lh_lasso_prove_sharded(lh_ctx* ctx, const lh_srs* srs, const lh_lasso_table* table, size_t num_vars,
                                  const uint32_t* const* d_dims, lh_transcript* t) {
   LH_TRY NEED_CTX(ctx);

@@ -55,6 +55,11 @@ class Arena {
   Mark mark() const { return {cur_, blocks_.empty() ? 0 : blocks_[cur_].used}; }
   void release(Mark m);
   size_t high_water() const { return high_; }
+  size_t reserved() const {  // bytes held from the device
+    size_t t = 0;
+    for (const Block& b : blocks_) t += b.size;
+    return t;
+  }
 
  private:
   struct Block {

@@ -56,6 +56,15 @@ def max_over_ranks(dist, seconds):
     return float(t.item())
 
 
+def gather_objects(dist, obj):
+    """every rank's `obj` (anything picklable, small) on every rank, in rank order"""
+    if dist is None:
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj, group=control_group(dist))
+    return out
+
+
 def barrier(dist):
     if dist is not None:
         dist.barrier()

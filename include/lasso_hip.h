@@ -355,6 +355,10 @@ lh_status lh_ctx_comm_stats(lh_ctx*, uint64_t out[2]);
  * open; p = 7: outside a Lasso prove.  reset != 0 clears the counters after reading.  (bench.py prints them next to
  * the N > 1 line so that a measured scaling curve can be read against the per-rank compute profile.) */
 lh_status lh_ctx_comm_phase_stats(lh_ctx*, uint64_t out[16], int reset);
+/* device memory of a ctx (diagnostics; bench.py prints it per rank on the N > 1 line): out[0] = high-water mark of the
+ * ctx's workspace arena in bytes (the prover's temporaries; its helper ctx's arena included), out[1] = bytes the arena
+ * holds from the device now, out[2] / out[3] = free / total bytes of the device as the runtime reports them (all processes) */
+lh_status lh_ctx_memory_stats(lh_ctx*, uint64_t out[4]);
 /* Same proof bytes as lh_lasso_prove on one GPU - it IS lh_lasso_prove with every table a shard: the same kernels (eq-
  * factored rounds, leaf-layer kernel, derived / packed commitments, column-wise top quotient) run on the shards, with a
  * collective where a round's partial sums or an MSM's partial commitments are added.  d_dims_local[j]: THIS RANK'S shard
