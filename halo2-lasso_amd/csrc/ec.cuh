@@ -111,6 +111,48 @@ LH_HD G1Xyzz add_mixed(const G1Xyzz& p, const G1Affine& q_in, bool negate = fals
   return r;
 }
 
+#if defined(__HIPCC__)
+// P + Q, Q affine and canonical, P with LAZY coordinates (every coordinate in [0, 2 q), ff.cuh): the accumulator of the
+// MSM's bucket accumulation never leaves the lazy range between two flushes, and 8 of the 10 products of the formulas
+// run without their final conditional subtraction (-4 % of the addition's instructions).  The result is lazy too;
+// canon_xyzz makes it canonical (before it is stored: everything else in the library expects canonical coordinates).
+__device__ __forceinline__ G1Xyzz add_mixed_lazy(const G1Xyzz& p, const G1Affine& q_in, bool negate) {
+  if (q_in.is_identity()) return p;
+  G1Affine q = q_in;
+  if (negate) q.y = neg(q.y);
+  if (p.is_identity()) return G1Xyzz::from_affine(q);  // (ZZ = 0 exactly: only the identity is ever given a zero ZZ)
+  const Fq u2 = mul_lazy(q.x, p.zz);
+  const Fq s2 = mul_lazy(q.y, p.zzz);
+  const Fq pp_ = sub_lazy(u2, p.x);
+  const Fq r_ = sub_lazy(s2, p.y);
+  if (is_zero_lazy(pp_)) {
+    if (is_zero_lazy(r_)) return dbl_affine(q);
+    return G1Xyzz::identity();
+  }
+  const Fq pp = mul_lazy(pp_, pp_);
+  const Fq ppp = mul_lazy(pp_, pp);
+  const Fq qq = mul_lazy(p.x, pp);
+  G1Xyzz r;
+  // (2 Q as two subtractions: the subtraction takes 2 q as literals, the addition would hold its limbs in registers - and the
+  // kernel is one wave of occupancy from the edge)
+  r.x = sub_lazy(sub_lazy(sub_lazy(mul_lazy(r_, r_), ppp), qq), qq);
+  {
+    // R (Q - X3) - Y PPP with one Montgomery reduction; the negated factor 2 q - Y lies in (0, 2 q]: the dot product stays
+    // below q (8 q / R + 1) < 2.51 q, one conditional subtraction of q leaves it below 1.51 q
+    const Fq x[2] = {r_, sub_lazy(Fq::zero(), p.y)}, y[2] = {sub_lazy(qq, r.x), ppp};
+    r.y = dot<FqParams, 2>(x, y);
+  }
+  r.zz = mul_lazy(p.zz, pp);
+  r.zzz = mul_lazy(p.zzz, ppp);
+  return r;
+}
+__device__ __forceinline__ G1Xyzz canon_xyzz(const G1Xyzz& p) {
+  G1Xyzz r;
+  r.x = canon(p.x), r.y = canon(p.y), r.zz = canon(p.zz), r.zzz = canon(p.zzz);
+  return r;
+}
+#endif
+
 // P + Q (add-2008-s)
 LH_HD G1Xyzz add(const G1Xyzz& p, const G1Xyzz& q) {
   if (p.is_identity()) return q;

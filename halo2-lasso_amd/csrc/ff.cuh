@@ -58,6 +58,12 @@ struct FqParams {
   static constexpr uint32_t INV = 0xe4866389u;  // -q^{-1} mod 2^32
 };
 
+// 2 p as a modulus provider (p < 2^254: 2 p fits 8 limbs) - the lazy forms below keep values in [0, 2 p)
+template <class P>
+struct Twice {
+  static LH_HD constexpr uint32_t mod(int i) { return (P::mod(i) << 1) | (i ? P::mod(i - 1) >> 31 : 0u); }
+};
+
 template <class P>
 struct alignas(16) Fp {
   typedef P params;
@@ -226,7 +232,7 @@ __device__ __forceinline__ uint32_t sub_chain(Fp<P>& d, const Fp<P>& a, const Fp
 // The same chains fused with what follows them, one asm block each (fewer instructions - the select is a v_cndmask by the
 // borrow instead of a mask and three logic operations per limb - and one hazard nop instead of three, see ff_cols.inc):
 // r = a < p ? a : a - p                                  (16 instructions)
-template <class P>
+template <class P, class M = P>
 __device__ __forceinline__ void reduce_sel(Fp<P>& r, const Fp<P>& a) {
   asm("v_subrev_co_u32 %0, vcc, %16, %8\n\t"
       "v_subbrev_co_u32 %1, vcc, %17, %9, vcc\n\t"
@@ -246,11 +252,11 @@ __device__ __forceinline__ void reduce_sel(Fp<P>& r, const Fp<P>& a) {
       "v_cndmask_b32 %7, %7, %15, vcc"
       : "=&v"(r.l[0]), "=&v"(r.l[1]), "=&v"(r.l[2]), "=&v"(r.l[3]), "=&v"(r.l[4]), "=&v"(r.l[5]), "=&v"(r.l[6]), "=&v"(r.l[7])
       : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]),
-        "v"(P::mod(0)), "v"(P::mod(1)), "v"(P::mod(2)), "v"(P::mod(3)), "v"(P::mod(4)), "v"(P::mod(5)), "v"(P::mod(6)), "v"(P::mod(7))
+        "v"(M::mod(0)), "v"(M::mod(1)), "v"(M::mod(2)), "v"(M::mod(3)), "v"(M::mod(4)), "v"(M::mod(5)), "v"(M::mod(6)), "v"(M::mod(7))
       : "vcc");
 }
 // r = a + b mod p for a, b < p                          (24 instructions)
-template <class P>
+template <class P, class M = P>
 __device__ __forceinline__ void add_sel(Fp<P>& r, const Fp<P>& a, const Fp<P>& b) {
   Fp<P> t;
   asm("v_add_co_u32 %8, vcc, %16, %24\n\t"
@@ -281,11 +287,11 @@ __device__ __forceinline__ void add_sel(Fp<P>& r, const Fp<P>& a, const Fp<P>& b
         "=&v"(t.l[0]), "=&v"(t.l[1]), "=&v"(t.l[2]), "=&v"(t.l[3]), "=&v"(t.l[4]), "=&v"(t.l[5]), "=&v"(t.l[6]), "=&v"(t.l[7])
       : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]),
         "v"(b.l[0]), "v"(b.l[1]), "v"(b.l[2]), "v"(b.l[3]), "v"(b.l[4]), "v"(b.l[5]), "v"(b.l[6]), "v"(b.l[7]),
-        "v"(P::mod(0)), "v"(P::mod(1)), "v"(P::mod(2)), "v"(P::mod(3)), "v"(P::mod(4)), "v"(P::mod(5)), "v"(P::mod(6)), "v"(P::mod(7))
+        "v"(M::mod(0)), "v"(M::mod(1)), "v"(M::mod(2)), "v"(M::mod(3)), "v"(M::mod(4)), "v"(M::mod(5)), "v"(M::mod(6)), "v"(M::mod(7))
       : "vcc");
 }
 // r = a - b mod p for a, b < p                          (25 instructions; the modulus as literals)
-template <class P>
+template <class P, class M = P>
 __device__ __forceinline__ void sub_sel(Fp<P>& r, const Fp<P>& a, const Fp<P>& b) {
   Fp<P> d;
   uint32_t mask;
@@ -318,7 +324,7 @@ __device__ __forceinline__ void sub_sel(Fp<P>& r, const Fp<P>& a, const Fp<P>& b
         "=&v"(d.l[0]), "=&v"(d.l[1]), "=&v"(d.l[2]), "=&v"(d.l[3]), "=&v"(d.l[4]), "=&v"(d.l[5]), "=&v"(d.l[6]), "=&v"(d.l[7]), "=&v"(mask)
       : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]),
         "v"(b.l[0]), "v"(b.l[1]), "v"(b.l[2]), "v"(b.l[3]), "v"(b.l[4]), "v"(b.l[5]), "v"(b.l[6]), "v"(b.l[7]),
-        "n"(P::mod(0)), "n"(P::mod(1)), "n"(P::mod(2)), "n"(P::mod(3)), "n"(P::mod(4)), "n"(P::mod(5)), "n"(P::mod(6)), "n"(P::mod(7))
+        "n"(M::mod(0)), "n"(M::mod(1)), "n"(M::mod(2)), "n"(M::mod(3)), "n"(M::mod(4)), "n"(M::mod(5)), "n"(M::mod(6)), "n"(M::mod(7))
       : "vcc");
 }
 #endif
@@ -581,8 +587,6 @@ __device__ __forceinline__ Fp<P> dot_scan_cols(const Fp<P>* a, const Fp<P>* b) {
 #undef LH_COL_DOT
 #undef LH_COL_STEP_LO
 #undef LH_COL_STEP_HI
-#undef LH_MAC
-#undef LH_MACS
 #endif
 
 template <class P>
@@ -605,6 +609,88 @@ LH_HD Fp<P> dot(const Fp<P>* a, const Fp<P>* b) {
   return s;
 #endif
 }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// ------------------------------------------------------------------ lazy forms: values in [0, 2 p) (device only)
+// With R = 2^256 > 4 p (both BN254 moduli are below 2^254) the Montgomery product of two values below 2 p is
+// (a b + m p) / R < p (4 p / R + 1) < 2 p WITHOUT the final conditional subtraction (16 of a product's ~296 instructions);
+// additions and subtractions stay in the range with a conditional subtraction / addition of 2 p - what they cost against
+// p.  A dot product of two pairs lands below p (8 p / R + 1) < 2.51 p: one conditional subtraction of p brings it below
+// 1.51 p.  Canonical values (< p) are lazy values; `canon` makes a lazy value canonical again.  Used by the MSM's bucket
+// accumulation (ec.cuh add_mixed_lazy): 8 of the 10 products of a mixed addition lose their subtraction.
+template <class P>
+__device__ __forceinline__ Fp<P> mul_lazy(const Fp<P>& a, const Fp<P>& b) {
+  uint64_t acc;
+  uint32_t top;
+  uint32_t m[8], r[8];
+#define LH_COL_STEP_LO(k)                       \
+  m[k] = (uint32_t)acc * P::INV;                \
+  LH_MACS(m[k], P::mod(0));                     \
+  acc = (acc >> 32) | ((uint64_t)top << 32)
+#define LH_COL_STEP_HI(k)                       \
+  r[k - 8] = (uint32_t)acc;                     \
+  acc = (acc >> 32) | ((uint64_t)top << 32)
+  LH_COL_MUL_0(a, b, m, P); LH_COL_STEP_LO(0);
+  LH_COL_MUL_1(a, b, m, P); LH_COL_STEP_LO(1);
+  LH_COL_MUL_2(a, b, m, P); LH_COL_STEP_LO(2);
+  LH_COL_MUL_3(a, b, m, P); LH_COL_STEP_LO(3);
+  LH_COL_MUL_4(a, b, m, P); LH_COL_STEP_LO(4);
+  LH_COL_MUL_5(a, b, m, P); LH_COL_STEP_LO(5);
+  LH_COL_MUL_6(a, b, m, P); LH_COL_STEP_LO(6);
+  LH_COL_MUL_7(a, b, m, P); LH_COL_STEP_LO(7);
+  LH_COL_MUL_8(a, b, m, P); LH_COL_STEP_HI(8);
+  LH_COL_MUL_9(a, b, m, P); LH_COL_STEP_HI(9);
+  LH_COL_MUL_10(a, b, m, P); LH_COL_STEP_HI(10);
+  LH_COL_MUL_11(a, b, m, P); LH_COL_STEP_HI(11);
+  LH_COL_MUL_12(a, b, m, P); LH_COL_STEP_HI(12);
+  LH_COL_MUL_13(a, b, m, P); LH_COL_STEP_HI(13);
+  LH_COL_MUL_14(a, b, m, P); LH_COL_STEP_HI(14);
+#undef LH_COL_STEP_LO
+#undef LH_COL_STEP_HI
+  r[7] = (uint32_t)acc;
+  Fp<P> out;
+#pragma unroll
+  for (int j = 0; j < 8; j++) out.l[j] = r[j];
+  return out;
+}
+template <class P>
+__device__ __forceinline__ Fp<P> add_lazy(const Fp<P>& a, const Fp<P>& b) {  // a + b < 4 p < 2^256
+  Fp<P> r;
+  add_sel<P, Twice<P>>(r, a, b);
+  return r;
+}
+template <class P>
+__device__ __forceinline__ Fp<P> sub_lazy(const Fp<P>& a, const Fp<P>& b) {  // a - b, plus 2 p when that borrowed
+  Fp<P> r;
+  sub_sel<P, Twice<P>>(r, a, b);
+  return r;
+}
+template <class P>
+__device__ __forceinline__ Fp<P> canon(const Fp<P>& a) {  // [0, 2 p) -> [0, p)
+  return reduce_once(a);
+}
+template <class P>
+__device__ __forceinline__ bool is_zero_lazy(const Fp<P>& a) {  // a = 0 mod p for a in [0, 2 p): 0 or p
+  bool z = true, m = true;
+#pragma unroll
+  for (int i = 0; i < 8; i++) z = z && a.l[i] == 0, m = m && a.l[i] == P::mod(i);
+  return z || m;
+}
+#undef LH_MAC
+#undef LH_MACS
+#elif defined(__HIPCC__)
+// (the host pass over device code only needs the names: canonical arithmetic is a valid lazy arithmetic)
+template <class P>
+LH_HD Fp<P> mul_lazy(const Fp<P>& a, const Fp<P>& b) { return mul(a, b); }
+template <class P>
+LH_HD Fp<P> add_lazy(const Fp<P>& a, const Fp<P>& b) { return add(a, b); }
+template <class P>
+LH_HD Fp<P> sub_lazy(const Fp<P>& a, const Fp<P>& b) { return sub(a, b); }
+template <class P>
+LH_HD Fp<P> canon(const Fp<P>& a) { return a; }
+template <class P>
+LH_HD bool is_zero_lazy(const Fp<P>& a) { return a.is_zero(); }
+#endif
 
 template <class P>
 LH_HD Fp<P> sqr(const Fp<P>& a) {

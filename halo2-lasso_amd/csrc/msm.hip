@@ -187,6 +187,8 @@ __device__ __forceinline__ const MsmJobDev& job_of_key(const MsmPlanDev& plan, u
 // cache lines per wave instruction and keep every line alive for 32 iterations (measured: 2.7x the algorithmic
 // fetch traffic).  (Requesting the next base point one iteration ahead was tried and lost 5 %: more registers.)
 constexpr int ACC_GROUP = 16;
+// (137 registers, three waves per SIMD since the lazy forms; forcing four - 128 registers, 44 bytes of spills - measured the
+// same 25.07 ms per 2^24 AND proof, tools/ab_acc0_lazy.sh: the allocator's choice stays)
 __global__ __launch_bounds__(128)
 void msm_accumulate0_kernel(MsmPlanDev plan, size_t total,
                                                               const uint32_t* __restrict__ sorted_key,
@@ -219,9 +221,9 @@ void msm_accumulate0_kernel(MsmPlanDev plan, size_t total,
           if (k != cur) {
             if (cont) {
               ck = cur;
-              cont_pt[t] = acc;
+              cont_pt[t] = canon_xyzz(acc);
             } else {
-              buckets[cur] = acc;
+              buckets[cur] = canon_xyzz(acc);
             }
             cont = false;
             acc = G1Xyzz::identity();
@@ -229,14 +231,14 @@ void msm_accumulate0_kernel(MsmPlanDev plan, size_t total,
             bases = job_of_key(plan, cur).bases;
           }
           const uint32_t iv = lds_idx[j * 128 + threadIdx.x];
-          if (iv != SKIP_IDX) acc = add_mixed(acc, bases[iv & 0x7fffffffu], (iv >> 31) != 0);
+          if (iv != SKIP_IDX) acc = add_mixed_lazy(acc, bases[iv & 0x7fffffffu], (iv >> 31) != 0);  // (lazy coordinates until the flush)
         }
       }
       if (cont) {
         ck = cur;
-        cont_pt[t] = acc;
+        cont_pt[t] = canon_xyzz(acc);
       } else {
-        buckets[cur] = acc;
+        buckets[cur] = canon_xyzz(acc);
       }
     }
     cont_key[t] = ck;

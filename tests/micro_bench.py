@@ -51,11 +51,18 @@ def main():
     o = ctx.alloc(16 * n)
     x = hl._fr_array([0x1234567])
     ms = gpu_time(ctx, lambda: lib.lh_fix_var(ctx.h, a.ptr, n, x, o.ptr))
-    out["fix_var_2p25"] = {"ms": ms, "GBps_algorithmic": 96.0 * (n / 2) / ms / 1e6}
+    gb = 96.0 * (n / 2) / ms / 1e6
+    out["fix_var_2p25"] = {"ms": ms, "GBps_algorithmic": gb, "frac_of_8TBps": gb / 8000.0,
+                           "bytes": "96 B per bound entry (SURVEY.md 8d); a 1 GiB table: beyond the 256 MiB MALL"}
+    n22 = 1 << 22
+    ms = gpu_time(ctx, lambda: lib.lh_fix_var(ctx.h, a.ptr, n22, x, o.ptr), reps=10)
+    gb = 96.0 * (n22 / 2) / ms / 1e6
+    out["fix_var_2p22"] = {"ms": ms, "GBps_algorithmic": gb, "frac_of_8TBps": gb / 8000.0, "bytes": "a 128 MiB table: MALL-resident"}
     m = 1 << 22
     b = ctx.alloc(32 * m)
     ms = gpu_time(ctx, lambda: lib.lh_fr_mul_chain(ctx.h, a.ptr, a.ptr + 32 * m, m, 64, b.ptr))
-    out["fr_mul_chain"] = {"ms": ms, "G_mul_per_s": m * 64 / ms / 1e6}
+    peak_mul = m * 64 / ms / 1e6  # G Fr-mul/s: the reference every `alu` fraction below is taken against
+    out["fr_mul_chain"] = {"ms": ms, "G_mul_per_s": peak_mul}
     del a, o, b
 
     # ---- mKZG commit / open (benches/pcs.rs)
@@ -85,8 +92,17 @@ def main():
             hl.MultilinearKzg.open(pp, poly, point, gt)
             cpu["open_bytes_equal"] = gt.into_proof() == tr.into_proof()
             cpu["commit_equal"] = hl.MultilinearKzg.commit(pp, poly) == co.g1_point(outp.raw)
+        # algorithmic bytes: commit = MSM of 2^nv points, 96 B each; open = the quotient pass (128 B per pair
+        # at every level: 128 (2^nv - 1)) + the MSMs of the nv quotients (96 B per point, 2^nv - 1 points); the MSM is
+        # integer-ALU work: 10 Fq products per mixed addition x (255 / window) windows per point, against the measured chain
+        npts = 1 << nv
+        cbits = max(4, min(17, nv - 4))
+        wins = -(-255 // cbits)
         out["mkzg"].append({"num_vars": nv, "gpu_commit_ms": g_commit, "gpu_open_ms": g_open,
-                            "gpu_commit_Mpts_per_s": (1 << nv) / g_commit / 1e3, **cpu})
+                            "gpu_commit_Mpts_per_s": npts / g_commit / 1e3,
+                            "commit_GBps_algorithmic": 96.0 * npts / g_commit / 1e6,
+                            "commit_frac_of_mul_chain": 10.0 * wins * npts / g_commit / 1e6 / peak_mul,
+                            "open_GBps_algorithmic": (128.0 + 96.0) * (npts - 1) / g_open / 1e6, **cpu})
 
     # ---- GKR fractional sum-check, 3 fractions (fractional_sum_check.rs:327-370)
     out["frac_gkr"] = []
@@ -97,7 +113,9 @@ def main():
         polys = [hl.MultilinearPolynomial(ctx, ctx.upload(r), nv) for r in raws]
         g = gpu_time(ctx, lambda: hl.prove_fractional_sum_check(ctx, [None] * 3, [None] * 3, polys[:3], polys[3:],
                                                                 hl.Keccak256Transcript()))
-        rec = {"num_vars": nv, "batch": 3, "gpu_ms": g}
+        # algorithmic bytes: layer-up 192 B per output and fraction at every level (192 x 3 x 2^nv in all), the layer
+        # sum-checks 96 B per bound entry over 4 x 3 + 1 tables, levels of 2^(nv-1) .. 2 entries (96 x 13 x 2^nv in all)
+        rec = {"num_vars": nv, "batch": 3, "gpu_ms": g, "GBps_algorithmic": (192.0 * 3 + 96.0 * 13) * (1 << nv) / g / 1e6}
         if nv <= 16:
             arr, keep = co._ptrs(raws[:3])
             arr2, keep2 = co._ptrs(raws[3:])
@@ -122,7 +140,12 @@ def main():
         ys = [[int(v) for v in rng.integers(1, 1 << 62, size=nv)]]
         g = gpu_time(ctx, lambda: hl.sum_check_prove_expression(ctx, nv, expr, polys, challenges, ys, 0,
                                                                 hl.Keccak256Transcript()))
-        out["zero_check"].append({"num_vars": nv, "gpu_ms": g, "polys": 13, "degree": expr.degree()})
+        # 96 B per bound entry over the 13 polys (the eq table is factored out of the streaming rounds): 96 x 13 x 2^nv; the
+        # compiled round is integer-ALU work; CPU: the oracle's expression sum-check is only exposed
+        # inside hyperplonk_prove (bench.py --workload hyperplonk times it)
+        out["zero_check"].append({"num_vars": nv, "gpu_ms": g, "polys": 13, "degree": expr.degree(),
+                                  "GBps_algorithmic": 96.0 * 13 * (1 << nv) / g / 1e6,
+                                  "frac_of_8TBps": 96.0 * 13 * (1 << nv) / g / 1e6 / 8000.0})
         del polys
     print(json.dumps(out, indent=1))
 
