@@ -118,7 +118,9 @@ struct Options {
   int64_t lasso_pack_ts = 1;           // 0: one MSM pass per read_ts column
   int64_t sc_tail = 1;                 // 0: one launch per sum-check round all the way down (no resident tail)
   int64_t sc_tail_max_len = 8192;      // longest table that enters the resident tail
-  int64_t shard_exchange_log = 17;     // sharded sum-check: the residual tables travel once they hold <= 2^this entries
+  int64_t shard_exchange_log = 19;     // sharded sum-check: the residual tables travel once they hold <= 2^this entries
+                                       // (17 until round 5; 19 removes two sharded rounds - two collectives - per sum-check at
+                                       // the same per-rank compute time, 20 two more for +2 % of it: tools/r05_xlog_sweep.sh)
   int64_t open_precommit = 1;          // proofs of >= 2^this lookups run the challenge-free half of the opening's column route
                                        // (the MSMs over differences of witness columns) on a helper ctx beside the sum-checks of
                                        // a Lasso prove (0: never; 1: always)

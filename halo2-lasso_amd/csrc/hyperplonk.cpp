@@ -248,44 +248,6 @@ void hyperplonk_prove_phases(Ctx& c, const PcsProver& pcs, const lh_hp_param& pp
   for (size_t i = 0; i < pp.num_preprocess_polys; i++) polys.push_back((const Fr*)pp.d_preprocess_polys[i]);
 
   pt.lap("instance polys");
-  // rounds 0..n (hyperplonk.rs:185-205): per phase synthesize from the challenges so far, commit, squeeze
-  std::vector<HFr> challenges;
-  for (size_t round = 0; round < ph.num_witness_polys.size(); round++) {
-    std::vector<const Fr*> w = ph.synthesize(round, challenges);
-    LH_REQUIRE(w.size() == ph.num_witness_polys[round], LH_ERR_ARG,
-               "hyperplonk: synthesize returned the wrong number of witness polys");  // assert_eq hyperplonk.rs:198
-    std::vector<HG1> comms = pcs.batch_commit(w.data(), w.size(), nv);
-    tr.write_commitments(comms);
-    polys.insert(polys.end(), w.begin(), w.end());
-    std::vector<HFr> ch = tr.squeeze_challenges(ph.num_challenges[round]);
-    challenges.insert(challenges.end(), ch.begin(), ch.end());
-  }
-
-  pt.lap("witness commitments");
-  // round n: beta, lookup m polys
-  HFr beta = tr.squeeze_challenge();
-  size_t width = 0;
-  for (size_t k = 0; k < pp.num_lookups; k++) width = std::max(width, pp.lookups[k].width);
-  std::vector<HFr> betas(width);
-  for (size_t i = 0; i < width; i++) betas[i] = i ? betas[i - 1] * beta : HFr::one();
-  std::vector<Fr*> comp_in(pp.num_lookups), comp_tab(pp.num_lookups), m_polys(pp.num_lookups), h_polys(pp.num_lookups);
-  for (size_t k = 0; k < pp.num_lookups; k++) {
-    comp_in[k] = c.arena.alloc_n<Fr>(n);
-    comp_tab[k] = c.arena.alloc_n<Fr>(n);
-    m_polys[k] = c.arena.alloc_n<Fr>(n);
-    h_polys[k] = c.arena.alloc_n<Fr>(n);
-    compressed_poly(c, pp.lookups[k].inputs, pp.lookups[k].width, betas, polys, challenges.data(), challenges.size(), nv,
-                    comp_in[k]);
-    compressed_poly(c, pp.lookups[k].tables, pp.lookups[k].width, betas, polys, challenges.data(), challenges.size(), nv,
-                    comp_tab[k]);
-    if (!k_lookup_m(c, comp_in[k], comp_tab[k], n, m_polys[k]))
-      throw Error(LH_ERR_INVALID_SNARK, "Invalid lookup input");  // prover.rs:176-178
-  }
-  {
-    std::vector<const Fr*> mp(m_polys.begin(), m_polys.end());
-    std::vector<HG1> comms = pcs.batch_commit(mp.data(), mp.size(), nv);
-    tr.write_commitments(comms);
-  }
   // Lasso lookups (oracle/pyref/hyperplonk.py LassoLookup): witness columns from the circuit's chunk polys, the
   // small-valued columns committed as u32 MSMs, framed with the identity mask
   struct LassoState {
@@ -295,7 +257,9 @@ void hyperplonk_prove_phases(Ctx& c, const PcsProver& pcs, const lh_hp_param& pp
     std::vector<const Fr*> dim_fr, rts_fr, E_fr, fcs_fr;  // fcs_fr: 2^nv entries (zero padded), read as l-variable tables too
   };
   std::vector<LassoState> lasso(pp.num_lasso_lookups);
-  if (pp.num_lasso_lookups) {
+  std::vector<MsmJob> lasso_jobs;  // the Lasso columns' commitments (u32 MSMs), filled by lasso_prepare
+  auto lasso_prepare = [&] {
+    if (!pp.num_lasso_lookups) return;
     LH_REQUIRE(pp.lasso_lookups != nullptr, LH_ERR_ARG, "hyperplonk: lasso_lookups is null");
     {
       // all Lasso commitments of a proof share ONE identity mask (a field element read as 63 bits, lasso.cpp)
@@ -307,7 +271,7 @@ void hyperplonk_prove_phases(Ctx& c, const PcsProver& pcs, const lh_hp_param& pp
     }
     const G1Affine* bases = shn ? pcs.shard_bases(nv) : pcs.commit_bases(nv);
     const G1Affine* bases_full = pcs.commit_bases(nv);
-    std::vector<MsmJob> jobs;
+    std::vector<MsmJob>& jobs = lasso_jobs;
     uint32_t bad_input = 0;        // sharded: a rank that finds an invalid lookup must not leave its peers in a collective
     for (size_t k = 0; k < pp.num_lasso_lookups; k++) {
       LassoState& st = lasso[k];
@@ -371,10 +335,77 @@ void hyperplonk_prove_phases(Ctx& c, const PcsProver& pcs, const lh_hp_param& pp
       const ReplicatedRange fc_range(sh, M);
       for (size_t j = 0; j < cc; j++) jobs.push_back(MsmJob{st.cols.fcs[j] + fc_range.first, true, bases_full + fc_range.first, fc_range.count});
     }
-    std::vector<HG1> comms(jobs.size());
-    msm_batch(c, jobs.data(), jobs.size(), (G1Affine*)comms.data());
-    if (shn) comm_sum_points(c, comms.data(), comms.size());  // the ranks' partial commitments -> their sums, one exchange
-    lasso_write_commitments(tr, comms);
+  };
+  std::vector<HG1> lasso_comms;
+  bool lasso_committed = false;
+  // rounds 0..n (hyperplonk.rs:185-205): per phase synthesize from the challenges so far, commit, squeeze
+  std::vector<HFr> challenges;
+  for (size_t round = 0; round < ph.num_witness_polys.size(); round++) {
+    std::vector<const Fr*> w = ph.synthesize(round, challenges);
+    LH_REQUIRE(w.size() == ph.num_witness_polys[round], LH_ERR_ARG,
+               "hyperplonk: synthesize returned the wrong number of witness polys");  // assert_eq hyperplonk.rs:198
+    polys.insert(polys.end(), w.begin(), w.end());
+    std::vector<HG1> comms;
+    if (round + 1 == ph.num_witness_polys.size() && pp.num_lasso_lookups && pcs.commit_bases && (!shn || pcs.shard_bases)) {
+      // The Lasso lookups' witness columns (access counters, subtable reads) are functions of the circuit's polys alone -
+      // no challenge enters them - and every poly exists once the last phase is synthesized: their commitments join THIS
+      // phase's witness commitments in one MSM batch (a batch's latency-bound tail - continuation levels, bucket
+      // reduction, window sums, the host's combine: ~0.6 ms - is paid once instead of twice).  What the transcript sees
+      // and when is unchanged: the Lasso commitments are written where oracle/pyref/hyperplonk.py writes them.
+      lasso_prepare();
+      std::vector<MsmJob> jobs;
+      const G1Affine* wb = shn ? pcs.shard_bases(nv) : pcs.commit_bases(nv);
+      for (const Fr* poly : w) jobs.push_back(MsmJob{poly, false, wb, n_loc});
+      jobs.insert(jobs.end(), lasso_jobs.begin(), lasso_jobs.end());
+      std::vector<HG1> out(jobs.size());
+      msm_batch(c, jobs.data(), jobs.size(), (G1Affine*)out.data());
+      if (shn) comm_sum_points(c, out.data(), out.size());  // the ranks' partial commitments -> their sums, one exchange
+      comms.assign(out.begin(), out.begin() + w.size());
+      lasso_comms.assign(out.begin() + w.size(), out.end());
+      lasso_committed = true;
+    } else {
+      comms = pcs.batch_commit(w.data(), w.size(), nv);
+    }
+    tr.write_commitments(comms);
+    std::vector<HFr> ch = tr.squeeze_challenges(ph.num_challenges[round]);
+    challenges.insert(challenges.end(), ch.begin(), ch.end());
+  }
+
+  pt.lap("witness commitments");
+  // round n: beta, lookup m polys
+  HFr beta = tr.squeeze_challenge();
+  size_t width = 0;
+  for (size_t k = 0; k < pp.num_lookups; k++) width = std::max(width, pp.lookups[k].width);
+  std::vector<HFr> betas(width);
+  for (size_t i = 0; i < width; i++) betas[i] = i ? betas[i - 1] * beta : HFr::one();
+  std::vector<Fr*> comp_in(pp.num_lookups), comp_tab(pp.num_lookups), m_polys(pp.num_lookups), h_polys(pp.num_lookups);
+  for (size_t k = 0; k < pp.num_lookups; k++) {
+    comp_in[k] = c.arena.alloc_n<Fr>(n);
+    comp_tab[k] = c.arena.alloc_n<Fr>(n);
+    m_polys[k] = c.arena.alloc_n<Fr>(n);
+    h_polys[k] = c.arena.alloc_n<Fr>(n);
+    compressed_poly(c, pp.lookups[k].inputs, pp.lookups[k].width, betas, polys, challenges.data(), challenges.size(), nv,
+                    comp_in[k]);
+    compressed_poly(c, pp.lookups[k].tables, pp.lookups[k].width, betas, polys, challenges.data(), challenges.size(), nv,
+                    comp_tab[k]);
+    if (!k_lookup_m(c, comp_in[k], comp_tab[k], n, m_polys[k]))
+      throw Error(LH_ERR_INVALID_SNARK, "Invalid lookup input");  // prover.rs:176-178
+  }
+  {
+    std::vector<const Fr*> mp(m_polys.begin(), m_polys.end());
+    std::vector<HG1> comms = pcs.batch_commit(mp.data(), mp.size(), nv);
+    tr.write_commitments(comms);
+  }
+  // Lasso lookups: their commitments - computed together with the last phase's witness commitments when the PCS allows
+  // it (below) - enter the transcript here, framed with the identity mask (lasso.cpp)
+  if (pp.num_lasso_lookups) {
+    if (!lasso_committed) {
+      lasso_prepare();
+      lasso_comms.resize(lasso_jobs.size());
+      msm_batch(c, lasso_jobs.data(), lasso_jobs.size(), (G1Affine*)lasso_comms.data());
+      if (shn) comm_sum_points(c, lasso_comms.data(), lasso_comms.size());  // the ranks' partial commitments -> their sums
+    }
+    lasso_write_commitments(tr, lasso_comms);
   }
 
   pt.lap("lookup compressed + m + commit");

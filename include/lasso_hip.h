@@ -257,7 +257,7 @@ lh_status lh_lasso_last_timing(lh_ctx*, double* out_ms);
  *   lasso_pack_ts        1    0: one MSM pass per read_ts column instead of packed pairs
  *   sc_tail              1    0: one kernel launch per sum-check round all the way down (no resident tail kernel)
  *   sc_tail_max_len      8192 longest table (entries) that enters the resident tail
- *   shard_exchange_log   17   sharded proofs: a sum-check goes on replicated once its residual tables hold <= 2^this
+ *   shard_exchange_log   19   sharded proofs: a sum-check goes on replicated once its residual tables hold <= 2^this
  *                             entries together (one all-gather), at the latest when the shard bits reach bit 0
  *   open_precommit       1    Lasso proofs of >= 2^this lookups (0: never, 1: always) run the column-wise quotient
  *                             commitments of their opening - MSMs over differences of witness columns, challenge-free - on
