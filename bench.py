@@ -110,7 +110,7 @@ def aggregate(recs):
     return sorted(by.values(), key=lambda a: -a["ms"])
 
 
-PMC_KERNEL_NAMES = {"msm_accumulate0": "msm_accumulate0_kernel<lh::Acc32>", "msm_bucket_reduce": "msm_segment_reduce_kernel",
+PMC_KERNEL_NAMES = {"msm_accumulate0": "msm_accumulate0_kernel", "msm_bucket_reduce": "msm_segment_reduce_kernel",
                     "sc_round_pp<bind>": "sc_round_pp_kernel<true>", "sc_round_pp<first>": "sc_round_pp_kernel<false>",
                     "sc_round_rw<bind>": "sc_round_rw_kernel<4, true>", "gkr_resident": "gkr_resident_kernel",
                     "msm_accumulate_levels": "msm_accumulate_n_kernel", "lincomb": "lincomb_kernel",

@@ -10,6 +10,8 @@
 // One module per distinct program (hash of the code words, register count, degree), cached for the process - and its code
 // object on disk for the next process (disk_* below).
 #include <hip/hiprtc.h>
+#include <fcntl.h>
+#include <hip/hip_version.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <cerrno>
@@ -266,8 +268,15 @@ uint64_t fnv1a(const void* p, size_t n, uint64_t h) {
 struct DiskHeader {
   char magic[8];
   uint64_t size, sum;
+  uint64_t src_hash[2];  // of the full generated source, the device headers and the compile options: compared on load
 };
-const char DISK_MAGIC[8] = {'L', 'H', 'J', 'I', 'T', '0', '1', 0};
+const char DISK_MAGIC[8] = {'L', 'H', 'J', 'I', 'T', '0', '2', 0};
+// the compile options are part of what a cached code object was made from
+const char* const JIT_OPTS[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+constexpr int JIT_NUM_OPTS = 3;
+// only a directory / file that belongs to this user and that nobody else can write is trusted with code that decides proof
+// bytes and writes device memory: anything else is ignored (the kernel is compiled, nothing is stored)
+bool private_to_us(const struct stat& st) { return st.st_uid == geteuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0; }
 bool make_dirs(const std::string& path) {  // mkdir -p
   for (size_t i = 1; i <= path.size(); i++)
     if (i == path.size() || path[i] == '/') {
@@ -285,16 +294,25 @@ const std::string& disk_dir() {  // empty: no disk cache
     else if (const char* x = getenv("XDG_CACHE_HOME")) d = std::string(x) + "/lasso_hip/jit";
     else if (const char* h = getenv("HOME")) d = std::string(h) + "/.cache/lasso_hip/jit";
     if (d.empty() || !make_dirs(d)) return std::string();
+    struct stat st;
+    if (stat(d.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || !private_to_us(st)) {
+      fprintf(stderr, "[lasso-hip] the JIT cache directory %s is not a private directory of this user: not used\n", d.c_str());
+      return std::string();
+    }
     return d;
   }();
   return dir;
 }
+void source_hash(const std::string& src, uint64_t out[2]);
 std::string disk_name(const std::string& src) {
   static const uint64_t base[2] = {[] {
                                      int major = 0, minor = 0;
                                      (void)hiprtcVersion(&major, &minor);
                                      uint64_t h = fnv1a(&major, sizeof major, 0xcbf29ce484222325ull);
                                      h = fnv1a(&minor, sizeof minor, h);
+                                     h = fnv1a(HIP_VERSION_GITHASH, sizeof HIP_VERSION_GITHASH, h);  // (the ROCm build the compiler came with)
+                                     { const int patch = HIP_VERSION_PATCH; h = fnv1a(&patch, sizeof patch, h); }
+                                     for (int i = 0; i < JIT_NUM_OPTS; i++) h = fnv1a(JIT_OPTS[i], strlen(JIT_OPTS[i]) + 1, h);
                                      h = fnv1a(JIT_FF_CUH, sizeof JIT_FF_CUH, h);
                                      h = fnv1a(JIT_FF_COLS_INC, sizeof JIT_FF_COLS_INC, h);
                                      return fnv1a(JIT_REDUCE_CUH, sizeof JIT_REDUCE_CUH, h);
@@ -306,11 +324,29 @@ std::string disk_name(const std::string& src) {
   snprintf(buf, sizeof buf, "/gfx950-%016llx%016llx.co", (unsigned long long)h0, (unsigned long long)h1);
   return disk_dir() + buf;
 }
-bool disk_load(const std::string& path, std::string& bin) {
+// two independent 64-bit passes over everything a code object depends on (name and header use the same pair)
+void source_hash(const std::string& src, uint64_t out[2]) {
+  uint64_t h = 0xcbf29ce484222325ull;
+  for (int i = 0; i < JIT_NUM_OPTS; i++) h = fnv1a(JIT_OPTS[i], strlen(JIT_OPTS[i]) + 1, h);
+  h = fnv1a(JIT_FF_CUH, sizeof JIT_FF_CUH, h);
+  h = fnv1a(JIT_FF_COLS_INC, sizeof JIT_FF_COLS_INC, h);
+  h = fnv1a(JIT_REDUCE_CUH, sizeof JIT_REDUCE_CUH, h);
+  out[0] = fnv1a(src.data(), src.size(), h);
+  out[1] = fnv1a(src.data(), src.size(), out[0] ^ 0x9e3779b97f4a7c15ull);
+}
+bool disk_load(const std::string& path, const std::string& src, std::string& bin) {
   FILE* f = fopen(path.c_str(), "rb");
   if (!f) return false;
+  struct stat st;
+  if (fstat(fileno(f), &st) != 0 || !S_ISREG(st.st_mode) || !private_to_us(st)) {  // (somebody else's file: not ours to run)
+    fclose(f);
+    return false;
+  }
   DiskHeader hd;
-  bool ok = fread(&hd, sizeof hd, 1, f) == 1 && memcmp(hd.magic, DISK_MAGIC, 8) == 0 && hd.size > 0 && hd.size < ((uint64_t)1 << 30);
+  uint64_t want[2];
+  source_hash(src, want);
+  bool ok = fread(&hd, sizeof hd, 1, f) == 1 && memcmp(hd.magic, DISK_MAGIC, 8) == 0 && hd.size > 0 && hd.size < ((uint64_t)1 << 30) &&
+            hd.src_hash[0] == want[0] && hd.src_hash[1] == want[1];
   if (ok) {
     bin.assign((size_t)hd.size, '\0');
     ok = fread(&bin[0], 1, bin.size(), f) == bin.size() && fnv1a(bin.data(), bin.size(), 0xcbf29ce484222325ull) == hd.sum;
@@ -318,15 +354,20 @@ bool disk_load(const std::string& path, std::string& bin) {
   fclose(f);
   return ok;
 }
-void disk_store(const std::string& path, const std::string& bin) {
+void disk_store(const std::string& path, const std::string& src, const std::string& bin) {
   char tmp[32];
   snprintf(tmp, sizeof tmp, ".tmp%ld", (long)getpid());
   const std::string t = path + tmp;
-  FILE* f = fopen(t.c_str(), "wb");
-  if (!f) return;
+  const int fd = open(t.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW, 0600);
+  FILE* f = fd >= 0 ? fdopen(fd, "wb") : nullptr;
+  if (!f) {
+    if (fd >= 0) close(fd);
+    return;
+  }
   DiskHeader hd;
   memcpy(hd.magic, DISK_MAGIC, 8);
   hd.size = bin.size(), hd.sum = fnv1a(bin.data(), bin.size(), 0xcbf29ce484222325ull);
+  source_hash(src, hd.src_hash);
   const bool ok = fwrite(&hd, sizeof hd, 1, f) == 1 && fwrite(bin.data(), 1, bin.size(), f) == bin.size();
   if (fclose(f) != 0 || !ok || rename(t.c_str(), path.c_str()) != 0) (void)remove(t.c_str());
 }
@@ -359,7 +400,7 @@ const JitKernel* jit_sc_round(const Ctx& c, const uint32_t* code, size_t num_ins
   const std::string src = generate(code, num_instrs, num_regs, result_reg, degree);
   std::string bin;
   const std::string disk = disk_dir().empty() ? std::string() : disk_name(src);
-  bool from_disk = !disk.empty() && disk_load(disk, bin);
+  bool from_disk = !disk.empty() && disk_load(disk, src, bin);
   if (from_disk && hipModuleLoadData(&k->mod, bin.data()) != hipSuccess) {  // (unloadable: compile it again and overwrite)
     (void)hipGetLastError();
     k->mod = nullptr;
@@ -371,8 +412,7 @@ const JitKernel* jit_sc_round(const Ctx& c, const uint32_t* code, size_t num_ins
     const char* hdr[] = {JIT_FF_CUH, JIT_REDUCE_CUH, JIT_FF_COLS_INC};
     const char* names[] = {"ff.cuh", "reduce.cuh", "ff_cols.inc"};
     if (hiprtcCreateProgram(&prog, src.c_str(), "sc_round_jit.hip", 3, hdr, names) != HIPRTC_SUCCESS) return nullptr;
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
-    const hiprtcResult r = hiprtcCompileProgram(prog, 3, opts);
+    const hiprtcResult r = hiprtcCompileProgram(prog, JIT_NUM_OPTS, (const char**)JIT_OPTS);
     if (r != HIPRTC_SUCCESS) {
       size_t ln = 0;
       (void)hiprtcGetProgramLogSize(prog, &ln);
@@ -388,7 +428,7 @@ const JitKernel* jit_sc_round(const Ctx& c, const uint32_t* code, size_t num_ins
     (void)hiprtcGetCode(prog, &bin[0]);
     (void)hiprtcDestroyProgram(&prog);
     if (hipModuleLoadData(&k->mod, bin.data()) != hipSuccess) return nullptr;
-    if (!disk.empty()) disk_store(disk, bin);
+    if (!disk.empty()) disk_store(disk, src, bin);
   }
   if (hipModuleGetFunction(&k->fn, k->mod, "sc_round_jit") != hipSuccess) return nullptr;
   k->threads = 256u;

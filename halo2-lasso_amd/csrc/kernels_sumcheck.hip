@@ -1089,6 +1089,11 @@ void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, F
     Fr* partials = g2 == 1 ? evals_host : c.arena.alloc_n<Fr>(g2 * 2);
     const ScFinish kflag = finish(g2);
     c.last_round_folded = rd.pp == 2 && bind;
+    if (rd.pp == 1 && bind)
+      // (sc_round_pp_kernel<true> stores the left factor times every coefficient that is not one: right for the folding
+      // round, pp == 2, and a silent corruption of the tables in any other binding round - the caller must have folded)
+      for (uint32_t m = 0; m < rd.num_terms; m++)
+        LH_REQUIRE(rd.coeff_is_one[m], LH_ERR_ARG, "sc_round_pp: a binding round after the fold still carries a coefficient");
     if (rd.pp) {
       // products per pair: binds, one per coefficient still applied on the way, ~0.62 per term for the shared reductions
       // (two points), the eq entry

@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--worlds", default="1,2,4,8")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--all-ranks", action="store_true", help="every rank of each world (default: ranks 0 and R-1)")
-    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r04_sharded_rank_ms.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r05_sharded_rank_ms.json"))
     args = ap.parse_args()
     import halo2_lasso_amd as hl
     import bench
