@@ -248,10 +248,10 @@ GrandProductResult prove_grand_product(Ctx& c, size_t B, const Fr* const* d_leav
     }
     resident_layers.swap(layers);
   }
-  static const int hook_at = getenv("LH_GKR_HOOK_AT") ? atoi(getenv("LH_GKR_HOOK_AT")) : 0;  // development: layer at which the hook fires
-  if (c.gkr_hook && hook_at <= 0) {  // (the trees are built: from here on the small layers leave most of the chip idle)
+  if (c.gkr_hook) {  // (the trees are built: from here on the small layers leave most of the chip idle)
     // (before the resident launch: what the hook starts on another stream waits for an event recorded HERE on this
-    // ctx's stream - behind the resident kernel it would wait for the whole resident phase)
+    // ctx's stream - behind the resident kernel it would wait for the whole resident phase.  Later starts - at the layer
+    // with 2^12 .. 2^21 entries - were measured in rounds 3 and 4 and are monotonically worse: profiles/README.md)
     std::function<void()> hook;
     hook.swap(c.gkr_hook);
     hook();
@@ -261,11 +261,6 @@ GrandProductResult prove_grand_product(Ctx& c, size_t B, const Fr* const* d_leav
     std::vector<size_t> active;
     for (size_t b = 0; b < B; b++)
       if (num_vars[b] > h) active.push_back(b);
-    if (c.gkr_hook && hook_at > 0 && (int)h >= hook_at && !resident.live) {
-      std::function<void()> hook;
-      hook.swap(c.gkr_hook);
-      hook();
-    }
     if (h >= 1 && resident.live && h <= resident.H) {
       // a resident layer: same transcript schedule, the sum-check's device half is already running
       HFr lam = tr.squeeze_challenge();

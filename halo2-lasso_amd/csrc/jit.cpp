@@ -96,8 +96,8 @@ std::string generate(const uint32_t* code, size_t num_instrs, uint32_t num_regs,
   // not emitted where the program has it but kept PENDING in its destination register - as long as additions and
   // subtractions only combine pending registers the terms pile up (up to JIT_DOT_MAX per reduction), and the register is
   // materialised (one product, or one dot) when something else reads it, when one of the terms' operand registers is about
-  // to be overwritten, or at the end.  LH_EXPR_JIT_DOT=0: every product where it stands.
-  static const bool fuse = !(getenv("LH_EXPR_JIT_DOT") && atoi(getenv("LH_EXPR_JIT_DOT")) == 0);
+  // to be overwritten, or at the end.
+  const bool fuse = true;
   constexpr size_t JIT_DOT_MAX = 4;
   struct Term {
     bool neg;

@@ -932,9 +932,8 @@ void k_lasso_counters(Ctx& c, const uint32_t* dim, size_t n, size_t m, uint32_t*
   hipLaunchKernelGGL(lasso_run_start_kernel, grid_for(n), 256, 0, c.stream, skey, n, m, start, bad);
   unsigned lg = 0;
   while (((size_t)1 << lg) < n) lg++;
-  static const bool two_step = !(getenv("LH_LASSO_UNPERMUTE") && atoi(getenv("LH_LASSO_UNPERMUTE")) == 0);  // (A/B)
   // (2^17 .. 2^24 lookups: one partition pass; beyond, the second pass costs what the scatter did - 2^26: 5.3 -> 5.8 ms)
-  if (two_step && lg >= 17 && lg <= UNPERM_WINDOW_LOG + 9 && n == ((size_t)1 << lg)) {
+  if (lg >= 17 && lg <= UNPERM_WINDOW_LOG + 9 && n == ((size_t)1 << lg)) {
     uint32_t* ranks = c.arena.alloc_n<uint32_t>(n);
     uint32_t* pidx = c.arena.alloc_n<uint32_t>(n);
     uint32_t* prank = c.arena.alloc_n<uint32_t>(n);

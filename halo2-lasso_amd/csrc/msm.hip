@@ -601,19 +601,15 @@ static void msm_continuation_levels(Ctx& c, const uint32_t* ckey, const G1Xyzz* 
   static const int MSM_K2 = env_int("LH_MSM_K2", 4);  // continuation fan-in: a level costs ~K2 dependent additions, there
                                                       // are log_K2(chunks) levels; swept 2..16, 3-4 is best (2^16: 10.1 -> 9.3 ms)
   static const int TREE_MAX = env_int("LH_MSM_TREE_MAX", 262144);  // lists of up to this many slots go by trees (0: never; sweep: profiles/r04_ab_msm_tree.txt)
-  static const int TREE_T = env_int("LH_MSM_TREE_T", 64);          // slots per tile: 64 (256 threads) or 256 (1024 threads)
   const uint32_t K2 = (uint32_t)MSM_K2;
   int lvl = 0;
   while (true) {
     const bool tree = n_in <= (size_t)TREE_MAX;
-    const size_t fan = tree ? (size_t)(TREE_T == 256 ? 256 : 64) : (size_t)K2;
+    const size_t fan = tree ? (size_t)64 : (size_t)K2;  // (256-slot tiles measured slower: profiles/r04_ab_msm_tree.txt)
     const size_t nc = (n_in + fan - 1) / fan;
     uint32_t* okey = c.arena.alloc_n<uint32_t>(nc);
     G1Xyzz* opt = c.arena.alloc_n<G1Xyzz>(nc);
-    if (tree && fan == 256)
-      hipLaunchKernelGGL((msm_accumulate_tree_quad_kernel<256>), dim3((unsigned)std::min<size_t>(nc, 1 << 16)), dim3(1024), 0,
-                         c.stream, ckey, cpt, n_in, buckets, okey, opt, cnt + lvl, cnt + lvl + 1);
-    else if (tree)
+    if (tree)
       hipLaunchKernelGGL((msm_accumulate_tree_quad_kernel<64>), dim3((unsigned)std::min<size_t>(nc, 1 << 16)), dim3(256), 0,
                          c.stream, ckey, cpt, n_in, buckets, okey, opt, cnt + lvl, cnt + lvl + 1);
     else if (n_in <= (size_t)MSM_QUAD_MAX)  // far below one wave per SIMD: a quad of lanes per entry
@@ -827,9 +823,7 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, 
       uint32_t max_spw = 1;
       for (size_t j = 0; j < nj; j++)
         if (plan.job[j].W && plan.job[j].sum_per_win < 16384) max_spw = std::max(max_spw, plan.job[j].sum_per_win);
-      static const int forced = env_int("LH_MSM_NSPLIT", 0);
       while (nsplit < 32 && max_spw / nsplit > 1024 && nwins * nsplit * 2 <= 4096) nsplit *= 2;
-      if (forced > 0) nsplit = (uint32_t)forced;
     }
     uint32_t nshares = 0;
     for (size_t j = 0; j < nj; j++) {

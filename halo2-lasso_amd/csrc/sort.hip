@@ -342,13 +342,7 @@ void rs_sort_batch(Ctx& c, const RsJob* slabs, size_t count, void* temp) {
     unsigned rb_max = 1;
     for (const RsSlab& s : host)
       if (q < s.passes) rb_max = std::max(rb_max, s.rb[q]);
-    static const int hist_bs = [] {  // development: LH_RS_HIST_BS = 128 / 256 / 512 threads per histogram workgroup
-      const char* e = getenv("LH_RS_HIST_BS");
-      return e && *e ? atoi(e) : 512;
-    }();
-    if (hist_bs == 128) hipLaunchKernelGGL((rs_hist_kernel<K, 128>), dim3(tiles), dim3(128), 0, stream, d_slabs, ns, q);
-    else if (hist_bs == 256) hipLaunchKernelGGL((rs_hist_kernel<K, 256>), dim3(tiles), dim3(256), 0, stream, d_slabs, ns, q);
-    else hipLaunchKernelGGL((rs_hist_kernel<K, 512>), dim3(tiles), dim3(512), 0, stream, d_slabs, ns, q);
+    hipLaunchKernelGGL((rs_hist_kernel<K, 512>), dim3(tiles), dim3(512), 0, stream, d_slabs, ns, q);  // (128 / 256 threads: slower, round 3)
     hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1u << rb_max, ns), dim3(256), 0, stream, d_slabs, q);
     hipLaunchKernelGGL(rs_scatter_kernel<K>, dim3(tiles), dim3(RS_BS), rs_lds_bytes(rb_max, key_bytes), stream, d_slabs, ns, q);
   }

@@ -776,7 +776,6 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
   if (use_ef) {
     const Shard shg(c);
     const size_t half = (size_t)1 << (nvl - 1);
-    static const bool eq_levels_ahead = !(getenv("LH_SC_EQ_LEVELS_AHEAD") && atoi(getenv("LH_SC_EQ_LEVELS_AHEAD")) == 0);
     for (EqFactoring::One& one : ef.eqs) {
       // consecutive blocks of halving size in one buffer; E_0 (the eq table over variables 1..n-1; sharded: this rank's
       // shard of it) comes from the proof's shared tables when an evaluation at the same point built it already
@@ -800,17 +799,11 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
       // them now, nine per launch (one launch per round in front of the round's kernel was 76 launches per 2^24 proof)
       std::vector<Fr*> lower;
       for (size_t jl = 1; jl < nvl; jl++) lower.push_back((Fr*)one.level[jl]);
-      if (eq_levels_ahead) k_eq_levels(c, one.level[0], half, lower.data(), lower.size());
+      k_eq_levels(c, one.level[0], half, lower.data(), lower.size());
     }
     ef.streams = [&](bool, size_t size) { return k_sc_round_streams(rd, degree, size); };
     ef.round = [&](const Fr* const* in, Fr* const* out, const Fr& r, bool bind, size_t size, size_t round, int points,
                    Fr* out_host) {
-      static const bool eq_levels_ahead = !(getenv("LH_SC_EQ_LEVELS_AHEAD") && atoi(getenv("LH_SC_EQ_LEVELS_AHEAD")) == 0);
-      if (!eq_levels_ahead && round > 0)  // (A/B: one level per round, in front of the round's kernel, as before)
-        for (EqFactoring::One& one : ef.eqs) {
-          Fr* lvl = (Fr*)one.level[round];
-          k_eq_levels(c, one.level[round - 1], 2 * size, &lvl, 1);
-        }
       if (!ef.per_term && rw && rw_folded) {
         // the tables hold l' = cs (l + k), r' = r + k since the fold round: sum_p l'_p r'_p, the product-pair shape
         LH_REQUIRE(points == 2, LH_ERR_ARG, "sum-check: tree-pair rounds asked for an extra point after the fold");

@@ -461,7 +461,8 @@ def test_context_used_from_another_thread(hl, ctx):
 @pytest.mark.heavy(est=7)
 @pytest.mark.parametrize("env", [{"LH_SC_TAIL_G": "64"}, {"LH_SC_TAIL_G": "2", "LH_SC_TAIL_MAX_LEN": "16384"},
                                  {"LH_SC_TAIL": "0", "LH_LASSO_PACK_TS": "0", "LH_MSM_SLAB_LOG": "31"},
-                                 {"LH_OPEN_SMALL_MIN_VARS": "2", "LH_MSM_SLAB_LOG": "4", "LH_MSM_PIPELINE": "1"},
+                                 {"LH_OPEN_SMALL_MIN_VARS": "2", "LH_MSM_SLAB_LOG": "4"},
+                                 {"LH_MSM_QUAD_MAX": "0", "LH_MSM_SEG": "16", "LH_MSM_TREE_MAX": "0"},
                                  {"LH_OPEN_SMALL_MIN_VARS": "2", "LH_OPEN_SMALL_DEPTH": "2", "LH_OPEN_SMALL_CHECK": "1"},
                                  {"LH_MSM_WINDOW_TABLES": "24", "LH_MSM_SLAB_LOG": "6"}])
 def test_small_parity_suite_under_forced_shapes(env):
@@ -472,11 +473,13 @@ def test_small_parity_suite_under_forced_shapes(env):
     counters' sorts), every Lasso batch opening through the small-column route for its largest quotient (32-bit
     differences, packed column pairs, base-sum offsets: by default only from 2^21 lookups on), read_ts columns
     committed one by one instead of in packed pairs, and the two largest quotients column by column whatever the table
-    (with the route's own comparison against the plain commitments switched on), and every full-width MSM job over a
-    window table of its SRS level (one bucket set for all windows)."""
+    (with the route's own comparison against the plain commitments switched on), every full-width MSM job over a
+    window table of its SRS level (one bucket set for all windows), and the MSM tails in their throughput forms whatever
+    the size: plain (not quad-cooperative) kernels, 16-bucket segments with the two-level group reduction wherever a window
+    has 4096 buckets, linear continuation levels instead of trees."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "tests/test_gpu_golden.py", "-m", "gpu",
-                          "-x", "-q", "-k", "sum_check or grand_product or fractional or lasso or batch_open or golden"],
+                          "-x", "-q", "-k", "sum_check or grand_product or fractional or lasso or batch_open or golden or msm"],
                          cwd=root, env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
