@@ -97,6 +97,7 @@ Ctx& ctx_helper(Ctx& c) {
     if (lh_ctx_create(c.device, &h) != LH_OK || !h) throw Error(LH_ERR_DEVICE, std::string("helper ctx: ") + get_last_error());
     c.helper_handle = h;
     c.helper = &h->c;
+    h->c.is_helper = true;
   }
   return *c.helper;
 }

@@ -222,6 +222,7 @@ struct Ctx {
   std::vector<ProfRec> prof_recs;
   // helper ctx (same device, own stream / arena / pinned blocks; capi.cpp ctx_helper) and what it is committing ahead of
   // the opening (open_columns.cpp open_precommit_*): both owned by this ctx
+  bool is_helper = false;  // this ctx is somebody's helper: its throughput kernels leave wave slots to the owner's stream
   Ctx* helper = nullptr;
   void* helper_handle = nullptr;
   void* precommit = nullptr;

@@ -921,7 +921,10 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, 
         // MSM algorithmic bytes: 96 B per point (32 B scalar + 64 B base), 68 B for a u32 column,
         // whatever the number of windows; `items` = sorted (point, window) entries, a mixed add is 10 Fq muls
         ProfScope ps(c, "msm_accumulate0", 96.0 * full_pts + 68.0 * (total_pts - full_pts), 10.0 * h_total, (double)h_total);
-      hipLaunchKernelGGL(msm_accumulate0_kernel, dim3((unsigned)std::min<size_t>((nchunks + 127) / 128, 1 << 16)), dim3(128), 0,
+      // (a grid capped to the chip's resident workgroups - for a helper ctx, so that the owner's latency-bound kernels find
+      // wave slots, or for every ctx, persistent style - was measured in round 5 and bought nothing: profiles/README.md)
+      const size_t acc_grid = std::min<size_t>((nchunks + 127) / 128, 1 << 16);
+      hipLaunchKernelGGL(msm_accumulate0_kernel, dim3((unsigned)acc_grid), dim3(128), 0,
                          c.stream, plan, max_entries, skey, sidx, K, buckets, ckey, cpt, nchunks, lvl_cnt);
       }
       {
