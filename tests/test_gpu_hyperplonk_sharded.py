@@ -67,6 +67,8 @@ WORKER = COMMON + textwrap.dedent("""
     hl.attach_comm(ctx, rank, world, hdist.host_all_gather(d), sb)
     if "xlog" in cfg:
         hl.set_option(ctx, "shard_exchange_log", cfg["xlog"])
+    if "comm_round" in cfg:                  # the rounds' partial sums by one all-reduce of u64 lanes (lasso_hip.h)
+        hl.set_option(ctx, "comm_round", cfg["comm_round"])
     t = hl.Keccak256Transcript()
     err = None
     try:
@@ -112,7 +114,9 @@ CASES = [
     pytest.param(2, dict(circuit="keccak_small", w=8, ub=4, rounds=2, k=10, seed=910), 7, 0, id="keccak_small-2"),
     pytest.param(4, dict(circuit="keccak_small", w=8, ub=4, rounds=2, k=10, seed=910), 6, None, id="keccak_small-4"),
     pytest.param(2, dict(circuit="keccak_small", w=4, ub=4, rounds=1, k=9, seed=909), 7, 3, id="keccak_tiny-2"),
-    pytest.param(2, dict(circuit="vanilla_lasso", k=17, seed=171), 15, None, marks=pytest.mark.heavy(est=25), id="vanilla_lasso_2p17-2"),
+    # (the zero-check's sharded rounds - interpreted program, LDS-staged and streaming kernels - through the all-reduce variant)
+    pytest.param(4, dict(circuit="keccak_small", w=8, ub=4, rounds=2, k=10, seed=911, comm_round=1), 6, 0, id="keccak_small-4-allreduce"),
+    pytest.param(2, dict(circuit="vanilla_lasso", k=17, seed=171, comm_round=1), 15, None, marks=pytest.mark.heavy(est=25), id="vanilla_lasso_2p17-2"),
     pytest.param(2, dict(circuit="keccak", k=17, seed=16), 15, None, marks=pytest.mark.heavy(est=50), id="keccak_f1600_2p17-2"),
 ]
 
