@@ -392,7 +392,9 @@ struct HostPool {
   // (waking a sleeping thread costs the poster ~50 us of the ~70 us an item takes)
   void prewake(size_t count, unsigned us) {
     if (!workers || count <= 1) return;
-    const int want = (int)std::min<size_t>(count - 1, workers) - spinning.load(std::memory_order_relaxed);
+    // (polling threads burn a core each: at most an eighth of the host's - eight ranks may share it, one process per GPU)
+    static const size_t spin_cap = std::max<size_t>(1, std::thread::hardware_concurrency() / 8);
+    const int want = (int)std::min<size_t>(std::min<size_t>(count - 1, workers), spin_cap) - spinning.load(std::memory_order_relaxed);
     if (want <= 0) return;
     {
       std::lock_guard<std::mutex> lk(mu);

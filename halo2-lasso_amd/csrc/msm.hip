@@ -348,16 +348,31 @@ __global__ __launch_bounds__(4 * T) void msm_accumulate_tree_quad_kernel(const u
     __syncthreads();  // (the previous tile's reads of the arrays are over)
     if (lead) keys[slot] = k, pts[slot] = acc;
     __syncthreads();
-    for (int d = 1; d < T; d <<= 1) {
-      const bool take = valid && slot + d < T && keys[slot + d] == k;
-      G1Xyzz other = G1Xyzz::identity();
-      if (take) other = pts[slot + d];
-      __syncthreads();
-      if (take) {
-        acc = add_quad(acc, other);
-        if (lead) pts[slot] = acc;
+    // One key over the whole tile (sorted keys: first == last) - the long runs of a derived job's list, of a skewed column:
+    // a halving tree with sequential addressing (slot p < h adds slot p + h) needs 2 + 1 + 1 + ... wave-additions for the
+    // T slots, because the active slots stay packed in the first waves; the doubling form below, which copes with any run
+    // boundaries, keeps all T slots adding in each of its log2 T steps.
+    const bool uniform = keys[0] != SENTINEL && keys[0] == keys[T - 1];  // (workgroup-uniform: the same LDS words for everyone)
+    if (uniform) {
+      for (int h = T / 2; h >= 1; h >>= 1) {
+        if (slot < h) {
+          acc = add_quad(acc, pts[slot + h]);
+          if (lead) pts[slot] = acc;
+        }
+        __syncthreads();
       }
-      __syncthreads();
+    } else {
+      for (int d = 1; d < T; d <<= 1) {
+        const bool take = valid && slot + d < T && keys[slot + d] == k;
+        G1Xyzz other = G1Xyzz::identity();
+        if (take) other = pts[slot + d];
+        __syncthreads();
+        if (take) {
+          acc = add_quad(acc, other);
+          if (lead) pts[slot] = acc;
+        }
+        __syncthreads();
+      }
     }
     if (valid && !prev_same) {  // the run begins here: its sum inside the tile joins the bucket
       const G1Xyzz sum = add_quad(buckets[k], acc);
