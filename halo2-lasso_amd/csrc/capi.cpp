@@ -135,6 +135,7 @@ void lh_ctx_destroy(lh_ctx* ctx) {
     if (ctx->c.sort_ev[k]) (void)hipEventDestroy(ctx->c.sort_ev[k]);
   }
   if (ctx->c.flag) (void)hipHostFree(ctx->c.flag);
+  if (ctx->c.lanes_host) (void)hipHostFree(ctx->c.lanes_host);
   if (ctx->c.ticket) (void)hipFree(ctx->c.ticket);
   (void)hipStreamDestroy(ctx->c.stream);
   delete ctx;

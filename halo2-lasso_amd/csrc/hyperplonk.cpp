@@ -537,6 +537,7 @@ void hyperplonk_prove_phases(Ctx& c, const PcsProver& pcs, const lh_hp_param& pp
   if (!lasso.empty()) pt.lap("lasso lookups");
   pcs.batch_open(nv, polys.data(), polys.size(), points.data(), num_points, evals.data(), evals.size(), tr);
   pt.lap("batch open");
+  c.host_stamps_print();  // (LH_HOST_TRACE: the stamps of this prove's MSM batches and openings)
 }
 
 }  // namespace lh
