@@ -815,6 +815,11 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, 
         if (!pass) small_entries = max_entries;
       }
     const size_t nbuckets = key, nsegs = seg, nwins = win;
+    if (getenv("LH_MSM_DEBUG"))
+      for (size_t j = 0; j < nj; j++)
+        fprintf(stderr, "[msm] job %zu n %u bits %u c %u W %u entries %zu%s%s%s%s\n", j, plan.job[j].n, job_bits[j], plan.job[j].c,
+                plan.job[j].W, (size_t)plan.job[j].n * plan.job[j].W, plan.job[j].is_signed ? " fr" : " u32",
+                derived[j] ? " derived" : "", plan.job[j].merged ? " table" : "", plan.job[j].pack_shift ? " packed" : "");
     // two-level reduction: throughput-bound batches (the plain segment kernel runs), jobs whose windows hold at least
     // MSM_GROUP^2 segments, packed jobs only when a group never straddles a change of the high part
     static const int two_level_on = env_int("LH_MSM_TWO_LEVEL", 1);
