@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of one environment switch on the three bench configurations (2^24 AND, 2^20 range, the Keccak circuit), three
-# repetitions each.  usage (GPU box): tools/ab_env.sh NAME [values...]   e.g. tools/ab_env.sh LH_SC_EQ_LEVELS_AHEAD 0 1
+# repetitions each.  usage (GPU box): tools/ab_env.sh NAME [values...]   e.g. tools/ab_env.sh LH_OPEN_PRECOMMIT 0 1
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 NAME=$1; shift

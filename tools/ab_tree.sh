@@ -1,3 +1,5 @@
+# HISTORICAL: the knob this script sweeps (see profiles/README.md for its result) was removed from the library in round 5;
+# kept as the record of how the committed numbers were made, it no longer changes anything.
 # development: the continuation levels as trees (LH_MSM_TREE_MAX = longest list that goes by trees, 0: never; LH_MSM_TREE_T
 # = slots per tile)
 set -u

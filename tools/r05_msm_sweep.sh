@@ -14,6 +14,6 @@ run default LH_NOP=1
 for s in 4 8 16; do run "SEG=$s" LH_MSM_SEG=$s; done
 for k in 2 8 16; do run "K=$k" LH_MSM_K=$k; done
 for t in 65536 1048576 4194304; do run "TREE_MAX=$t" LH_MSM_TREE_MAX=$t; done
-run "TREE_T=256" LH_MSM_TREE_T=256
+# (the tile-size line of the committed sweep, LH_MSM_TREE_T=256, went with the knob: 64-slot tiles won)
 for k2 in 2 8; do run "K2=$k2" LH_MSM_K2=$k2; done
 for c in 3 5 6; do run "C_OFF=$c" LH_MSM_C_OFF=$c; done

@@ -149,12 +149,14 @@ def main():
                         ts.append((time.perf_counter() - t0) * 1e3)
                     phases = hl.lasso_last_timing(ctx)
                     stats0 = hl.comm_stats(ctx)
+                    hl.comm_phase_stats(ctx, reset=True)
                     hl.profile_enable(ctx, True)
                     hl.lasso_prove_sharded(pp, table, n, d_dims, hl.Keccak256Transcript())
                     ctx.sync()
                     aggs = bench.aggregate(hl.profile_read(ctx))
                     hl.profile_enable(ctx, False)
                     stats1 = hl.comm_stats(ctx)
+                    by_phase = hl.comm_phase_stats(ctx, reset=True)
                 finally:
                     hl.detach_comm(ctx)
                 del d_dims
@@ -162,6 +164,7 @@ def main():
                     "rank": rank, "wall_ms": round(statistics.median(ts), 3),
                     "busy_ms": round(sum(a["ms"] for a in aggs), 3),
                     "collectives_per_proof": {k: stats1[k] - stats0[k] for k in stats0},
+                    "collectives_by_phase": {k: v["collectives"] for k, v in by_phase.items() if v["collectives"]},
                     "phases_ms": {k: round(v, 3) for k, v in phases.items()},
                     "route": hl.lasso_last_route(ctx),
                     "top_kernels": [{"name": a["name"], "launches": a["launches"], "ms": round(a["ms"], 3)} for a in aggs[:8]]})
