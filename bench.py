@@ -59,6 +59,9 @@ def parse():
                          "permutations (35013 rows each) packed into 2^log-n rows, every byte XOR / AND a Lasso lookup "
                          "(halo2-lasso_amd/keccak_circuit.py); 'vanilla' = vanilla gates + one 32-bit --table lookup")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bind-host", action="store_true",
+                    help="bind the process to the CPUs on its GPU's NUMA node (Context.bind_host; default: wherever the "
+                         "scheduler puts it - on the shared hosts of the development pool the binding measured within the noise)")
     ap.add_argument("--cpu-sample-log-n", type=int, default=0, help="force the CPU sample size")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-inflight", action="store_true",
@@ -169,6 +172,7 @@ def fr_mul_peak(hl, ctx):
 
 
 def cpu_baseline(hl, ctx, pp, table, kind, args, gpu_proof_fn):
+    unbind_host()
     co = use_native_oracle()
     cores = co.num_threads()
     zm = isinstance(pp, hl.ZeromorphProverParam)
@@ -214,6 +218,30 @@ def cpu_baseline(hl, ctx, pp, table, kind, args, gpu_proof_fn):
 # product chains per thread).  Rounds 1-4 printed a modelled "ceiling" next to it (~296 VALU instructions per product at a
 # 4-cycle wave64 issue: 133 G products/s); the measured chain sits at 125-138 G/s, i.e. it could beat the model - a ceiling
 # the chip beats is not one, so it is gone: `alu.frac` is against the measured chain only.
+
+
+# --bind-host: one process per GPU, bound to the CPUs on the GPU's NUMA node (what numactl does in a deployment): the
+# proving thread and the device exchange a few hundred small messages per proof, and each is longer across the socket
+# interconnect (tools/numa_ab.sh on a quiet host: 2^20 lookups 8.09 local / 8.26 remote ms; on a host shared with other
+# jobs the difference drowns).  The CPU baseline runs on EVERY core the process was given: the binding is undone before it.
+_HOST_BINDING = {"before": None}
+
+
+def bind_host(ctx, args):
+    if not args.bind_host:
+        return {"bound": False}
+    bus, local = ctx.host_cpus()
+    before = ctx.bind_host()
+    _HOST_BINDING["before"] = before
+    if before is None:
+        return {"bound": False, "device": bus, "why": "no local CPU list, or already inside it"}
+    return {"bound": True, "device": bus, "cpus": len(local & before), "of": len(before)}
+
+
+def unbind_host():
+    if _HOST_BINDING["before"] is not None:
+        os.sched_setaffinity(0, _HOST_BINDING["before"])
+        _HOST_BINDING["before"] = None
 
 
 def dominant(aggs):
@@ -284,6 +312,7 @@ def make_hp_circuit(ctx, k, args, seed=None):
 
 def hyperplonk_cpu_baseline(hl, ctx, args, trap, gpu_proof_fn):
     """the C++ oracle's HyperPlonk restatement on the same synthetic circuit (bounded sample), proof bytes compared"""
+    unbind_host()
     from halo2_lasso_amd import synthetic
     from oracle.pyref import hyperplonk as o_hp
     co = use_native_oracle()
@@ -341,6 +370,7 @@ def main_hyperplonk(args, hdist, dist, rank, local_rank, world):
     import halo2_lasso_amd as hl
     from halo2_lasso_amd import hyperplonk as hp, synthetic
     ctx = hl.Context(int(os.environ.get("LH_DEVICE", local_rank)))
+    host_binding = bind_host(ctx, args)
     k = args.log_n
     trap = trapdoor(k)
     pcs_pp = hl.MultilinearKzg.setup(ctx, trap)
@@ -410,6 +440,7 @@ def main_hyperplonk(args, hdist, dist, rank, local_rank, world):
                                        % (world, shard_bit, shard_bit + world.bit_length() - 1, transport)) if sharded
                        else "1 proof per GPU" if world > 1 else "1 GPU"},
             "rows_per_s": round((1 << k) * (1 if sharded else world) / (ms_per_step / 1e3)),
+            "host_binding": host_binding,
         }
     if not args.no_profile and (sharded or rank == 0):
         # (sharded: every rank takes part in the collectives of the profiled prove, rank 0 records)
@@ -470,6 +501,7 @@ def main():
 
     import halo2_lasso_amd as hl
     ctx = hl.Context(int(os.environ.get("LH_DEVICE", local_rank)))  # LH_DEVICE: several ranks on one GPU (tests)
+    host_binding = bind_host(ctx, args)
     n = args.log_n
     table, desc = make_table(hl, args.table)
     zm = args.pcs == "zeromorph"
@@ -604,6 +636,7 @@ def main():
                                        if sharded else "1 proof per GPU" if world > 1 else "1 GPU")},
             "lookups_per_s": round((1 << n) * proofs_per_step / (ms_per_step / 1e3)),
             "phases_ms": {k: round(v, 3) for k, v in phases.items()},
+            "host_binding": host_binding,
         }
         if sharded:
             out["config"]["transport"] = transport

@@ -244,6 +244,7 @@ extern "C" {
     pub fn lh_ctx_comm_stats(ctx: *mut lh_ctx, out: *mut u64) -> lh_status;
     pub fn lh_ctx_comm_phase_stats(ctx: *mut lh_ctx, out: *mut u64, reset: c_int) -> lh_status;
     pub fn lh_ctx_memory_stats(ctx: *mut lh_ctx, out: *mut u64) -> lh_status;
+    pub fn lh_ctx_host_cpus(ctx: *mut lh_ctx, bus_id: *mut c_char, bus_id_cap: usize, cpulist: *mut c_char, cpulist_cap: usize) -> lh_status;
     pub fn lh_shard_extract(ctx: *mut lh_ctx, d_global: *const c_void, n_local: usize, shard_bit: usize, rho: usize,
                             rank: usize, elem_bytes: usize, d_local: *mut c_void) -> lh_status;
     // route options (include/lasso_hip.h lists the names) and the route the last Lasso prove took

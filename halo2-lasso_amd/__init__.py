@@ -126,6 +126,17 @@ def _fr_list(arr, n):
 
 
 # ------------------------------------------------------------------ context / device memory
+def parse_cpulist(text):
+    """the kernel's CPU list format ("0-63,128-191") as a set"""
+    out = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.update(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
 class Context:
     """One per process per GPU (`lh_ctx`)."""
 
@@ -148,6 +159,27 @@ class Context:
 
     def sync(self):
         _check(self.lib.lh_ctx_sync(self.h))
+
+    def host_cpus(self):
+        """(PCI address of the ctx's device, the CPUs on its NUMA node as a set) - lh_ctx_host_cpus; the set is empty where
+        the system does not say"""
+        bus, cpus = C.create_string_buffer(64), C.create_string_buffer(4096)
+        _check(self.lib.lh_ctx_host_cpus(self.h, bus, 64, cpus, 4096))
+        return bus.value.decode(), parse_cpulist(cpus.value.decode())
+
+    def bind_host(self):
+        """Bind the CALLING thread (and with it every thread the library starts for this ctx from now on: its host pool, the
+        helper ctx's worker) to the CPUs next to the ctx's device - what a one-process-per-GPU deployment does with
+        numactl.  Returns the previous affinity mask (give it to os.sched_setaffinity to undo), or None when nothing was
+        changed: no such list, or none of its CPUs is in the present mask."""
+        import os
+        _, local = self.host_cpus()
+        before = os.sched_getaffinity(0)
+        want = local & before
+        if not want or want == before:
+            return None
+        os.sched_setaffinity(0, want)
+        return before
 
     @property
     def stream(self):

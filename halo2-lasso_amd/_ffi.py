@@ -191,6 +191,7 @@ SIGNATURES = {
     "lh_ctx_comm_stats": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "lh_ctx_comm_phase_stats": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_int]),
     "lh_ctx_memory_stats": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "lh_ctx_host_cpus": (C.c_int, [_P, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
     "lh_lasso_prove_sharded": (C.c_int, [_P, _P, C.POINTER(lh_lasso_table), _SZ, C.POINTER(_P),
                                          C.POINTER(lh_transcript)]),
     "lh_hyperplonk_prove": (C.c_int, [_P, _P, C.POINTER(lh_hp_param), C.POINTER(C.POINTER(lh_fr)), C.POINTER(_P),

@@ -581,6 +581,28 @@ lh_status lh_ctx_memory_stats(lh_ctx* ctx, uint64_t out[4]) {
   out[2] = free_b, out[3] = total_b;
   LH_CATCH
 }
+lh_status lh_ctx_host_cpus(lh_ctx* ctx, char* bus_id, size_t bus_id_cap, char* cpulist, size_t cpulist_cap) {
+  LH_TRY NEED_CTX(ctx);
+  NEED(bus_id);
+  NEED(cpulist);
+  LH_REQUIRE(bus_id_cap >= 16 && cpulist_cap >= 2, LH_ERR_ARG, "host cpus: buffers too small");
+  char id[64] = {0};
+  LH_HIP(hipDeviceGetPCIBusId(id, (int)sizeof(id), ctx->c.device));
+  for (char* p = id; *p; p++) *p = (char)tolower((unsigned char)*p);  // (sysfs spells the address in lower case)
+  snprintf(bus_id, bus_id_cap, "%s", id);
+  cpulist[0] = 0;
+  const std::string path = std::string("/sys/bus/pci/devices/") + id + "/local_cpulist";
+  if (FILE* f = fopen(path.c_str(), "r")) {
+    if (fgets(cpulist, (int)cpulist_cap, f)) {
+      size_t n = strlen(cpulist);
+      while (n && (cpulist[n - 1] == '\n' || cpulist[n - 1] == ' ')) cpulist[--n] = 0;
+    } else {
+      cpulist[0] = 0;
+    }
+    fclose(f);
+  }
+  LH_CATCH
+}
 lh_status lh_lasso_prove_sharded(lh_ctx* ctx, const lh_srs* srs, const lh_lasso_table* table, size_t num_vars,
                                  const uint32_t* const* d_dims, lh_transcript* t) {
   LH_TRY NEED_CTX(ctx);

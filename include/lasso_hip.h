@@ -359,6 +359,12 @@ lh_status lh_ctx_comm_phase_stats(lh_ctx*, uint64_t out[16], int reset);
  * ctx's workspace arena in bytes (the prover's temporaries; its helper ctx's arena included), out[1] = bytes the arena
  * holds from the device now, out[2] / out[3] = free / total bytes of the device as the runtime reports them (all processes) */
 lh_status lh_ctx_memory_stats(lh_ctx*, uint64_t out[4]);
+/* the CPUs next to the ctx's device: its PCI address ("0000:72:00.0") into bus_id and the kernel's list of the CPUs on its
+ * NUMA node ("0-63,128-191", sysfs local_cpulist) into cpulist - empty where the system does not say.  A deployment binds
+ * the thread that proves to them (one process per GPU, bound to the GPU's node): the small proofs are a few hundred PCIe
+ * round trips between that thread and the device, each one longer across the socket interconnect (tools/numa_ab.sh on a
+ * quiet host: 2^20 lookups 8.09 against 8.26 ms).  The library never changes a caller's affinity itself. */
+lh_status lh_ctx_host_cpus(lh_ctx*, char* bus_id, size_t bus_id_cap, char* cpulist, size_t cpulist_cap);
 /* Same proof bytes as lh_lasso_prove on one GPU - it IS lh_lasso_prove with every table a shard: the same kernels (eq-
  * factored rounds, leaf-layer kernel, derived / packed commitments, column-wise top quotient) run on the shards, with a
  * collective where a round's partial sums or an MSM's partial commitments are added.  d_dims_local[j]: THIS RANK'S shard

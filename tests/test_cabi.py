@@ -68,3 +68,29 @@ def test_no_gpu_means_loud_failure(hl):
         pytest.skip("GPU present")
     with pytest.raises(hl.DeviceError):
         hl.Context(0)
+
+
+def test_cpu_list_format(hl):
+    """the kernel's CPU list format of sysfs local_cpulist, as Context.host_cpus reads it"""
+    assert hl.parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    assert hl.parse_cpulist("") == set() and hl.parse_cpulist("5") == {5}
+    assert len(hl.parse_cpulist("0-63,128-191")) == 128
+
+
+@pytest.mark.gpu
+def test_host_binding_next_to_the_device(hl, ctx):
+    """lh_ctx_host_cpus names the device's PCI address and the CPUs on its NUMA node; Context.bind_host narrows the calling
+    thread's affinity to them (never widens it, never leaves it empty) and hands back what it replaced."""
+    bus, local = ctx.host_cpus()
+    assert re.fullmatch(r"[0-9a-f]{4}:[0-9a-f]{2}:[0-9a-f]{2}\.[0-9a-f]", bus), bus
+    assert os.path.isdir("/sys/bus/pci/devices/" + bus)
+    before = os.sched_getaffinity(0)
+    prev = ctx.bind_host()
+    try:
+        now = os.sched_getaffinity(0)
+        if prev is None:
+            assert now == before and (not (local & before) or (local & before) == before)
+        else:
+            assert prev == before and now == (local & before) and now and now < before
+    finally:
+        os.sched_setaffinity(0, before)
