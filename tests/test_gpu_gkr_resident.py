@@ -195,3 +195,32 @@ def test_folded_layers_give_the_same_bytes_on_every_path(hl, ctx):
         assert route["rw_leaf_rounds"] > 0, (key, route)
     # with folding the leaf layers run the leaf kernel twice (first round, folding round), without it in every streaming round
     assert seen[(1, 1)][1]["rw_leaf_rounds"] < seen[(0, 1)][1]["rw_leaf_rounds"]
+
+
+def test_a_proof_repeated_two_hundred_times_is_the_same_proof(hl, ctx):
+    """What one parity test cannot see (tools/soak.py in small): the same 2^13 AND proof 200 times on one ctx - identical
+    bytes, the same route every time (no resident launch that sometimes falls back, no sequence number that runs into a
+    stale one), and a workspace arena whose high-water mark stops growing after the first proofs."""
+    n, nv = 13, 16
+    rng = random.Random(9)
+    ss = [rng.randrange(1, P) for _ in range(nv)]
+    table = hl.LassoTable.bitwise(hl.SUBTABLE_AND, 4, 16)
+    dims = [np.random.default_rng(90 + j).integers(0, 1 << 16, size=1 << n, dtype=np.uint32) for j in range(4)]
+    pp = hl.MultilinearKzg.setup(ctx, ss)
+    bufs = [ctx.upload(d.tobytes()) for d in dims]
+    first = route = mark = None
+    for i in range(200):
+        tr = hl.Keccak256Transcript()
+        hl.lasso_prove(pp, table, n, bufs, tr)
+        proof, rt = tr.into_proof(), hl.lasso_last_route(ctx)
+        if i == 0:
+            first = proof
+        assert proof == first, "proof %d differs" % i
+        if i == 2:
+            route, mark = rt, hl.memory_stats(ctx)["arena_high_water_bytes"]
+        if i > 2:
+            assert rt == route, (i, rt, route)
+    assert route["resident_layers"] >= 12 and hl.memory_stats(ctx)["arena_high_water_bytes"] == mark
+    ot = co.Transcript()
+    co.lasso_prove(ot, pp.eqs_bytes(), nv, table.to_c(), n, [d.tobytes() for d in dims])
+    assert first == ot.into_proof()
