@@ -147,7 +147,8 @@ def pmc_traffic(profile_name, log_n, table_kind, world=1, launches_per_proof=Non
             continue
         if launches_per_proof is not None and abs(rec["launches_per_proof"] - launches_per_proof) > 1e-9:
             continue
-        note = "" if rec.get("calibrated", True) else "; gather kernel: counter uncalibrated for this access shape"
+        note = "" if rec.get("calibrated", True) else ("; gather kernel: a 64-byte gather counts as its whole 128-byte line, "
+                                                        "profiles/r05_gather_calib.txt")
         return rec["hbm_bytes_per_launch_avg"], "profiles/%s (%s, average over %d launches%s)" % (
             os.path.basename(path), kern, rec["launches_in_run"], note)
     return None, None

@@ -2,8 +2,9 @@
 per-kernel HBM traffic: per-launch average (what bench.py's roofline.traffic reports next to the per-launch `achieved`),
 total over the run, and the largest launch.  Corrections per MI355X_MICROARCH.md §HBM: counters are in KB; on gfx950
 FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced streaming read (16 B per lane), WRITE_SIZE is exact for
-16-B-per-lane streaming stores.  Other access shapes are uncalibrated and flagged: a gather kernel such as
-msm_accumulate0 (64-byte random reads pulling 128-byte lines) is listed with the same formula for comparison only.
+16-B-per-lane streaming stores.  Gather kernels are flagged: for msm_accumulate0's shape (a random 64-byte record per lane)
+the same formula gives the LINE traffic - a 64-byte gather counts, and costs, as its whole 128-byte line
+(tools/gather_calib.sh, profiles/r05_gather_calib.txt) - i.e. twice the bytes the lanes use.
 
 usage: pmc_extract.py FETCH.csv WRITE.csv "workload description" proofs_in_run OUT.json"""
 import collections
@@ -46,6 +47,6 @@ for k in sorted(set(fetch) | set(write)):
                                  "WRITE_SIZE_KB": w["big"], "hbm_bytes_corrected": int((2.0 * f["big"] + w["big"]) * 1024)},
               "calibrated": k.split("<")[0] not in GATHER}
 json.dump({"note": "hbm bytes = (2 * FETCH_SIZE + WRITE_SIZE) KB, the streaming-read correction of MI355X_MICROARCH.md; "
-                   "calibrated = false marks gather kernels, for which the counter is uncalibrated",
+                   "calibrated = false marks gather kernels: the formula gives their 128-byte-line traffic, twice the 64-byte records the lanes use (tools/gather_calib.sh)",
            "workload": sys.argv[3], "proofs_in_run": proofs, "kernels": out}, open(sys.argv[5], "w"), indent=1)
 print("wrote", sys.argv[5], len(out), "kernels")
