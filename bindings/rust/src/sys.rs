@@ -169,7 +169,7 @@ pub struct lh_lasso_route {
     pub open_precommit: u32,
     pub resident_layers: u32,
     pub pp_folds: u32,
-    pub msm29_batches: u32,
+    pub msm_half_batches: u32,
     pub reserved: [u32; 7],
 }
 

@@ -992,7 +992,7 @@ def lasso_last_timing(ctx):
 
 ROUTE_FIELDS = ["open_small_depth", "open_small_passes", "eq_factored_rounds", "standard_rounds", "rw_leaf_rounds",
                 "resident_tails", "resident_rounds", "packed_ts_pairs", "derived_commitments", "sorted_dim_reuse",
-                "sharded_rounds", "shard_exchanges", "window_table_jobs", "open_precommit", "resident_layers", "pp_folds", "msm29_batches"]
+                "sharded_rounds", "shard_exchanges", "window_table_jobs", "open_precommit", "resident_layers", "pp_folds", "msm_half_batches"]
 
 
 def lasso_last_route(ctx):

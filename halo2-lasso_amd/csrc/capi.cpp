@@ -1,5 +1,6 @@
 // extern "C" boundary: thin wrappers translating C++ exceptions into lh_status codes.
 #include "host.hpp"
+#include <memory>
 
 using namespace lh;
 
@@ -33,6 +34,8 @@ struct lh_zm_vp {
   return LH_OK;
 
 #define NEED(p) LH_REQUIRE((p) != nullptr, LH_ERR_ARG, "null argument: " #p)
+// (a vector argument may be null only when it is empty)
+#define NEED_N(p, n) LH_REQUIRE((p) != nullptr || (n) == 0, LH_ERR_ARG, "null argument: " #p)
 
 // The current HIP device is a per-host-thread setting: every entry point that takes a ctx makes the ctx's device
 // current for the duration of the call (workspace growth, SRS shards and runtime-compiled modules must land on the
@@ -118,6 +121,8 @@ void lh_ctx_destroy(lh_ctx* ctx) {
   delete ctx->c.worker;  // (joins; after the precommit it may still be running was cancelled above)
   ctx->c.worker = nullptr;
   if (ctx->c.handoff_ev) (void)hipEventDestroy(ctx->c.handoff_ev);
+  if (ctx->c.aux_stream) (void)hipStreamSynchronize(ctx->c.aux_stream), (void)hipStreamDestroy(ctx->c.aux_stream);
+  if (ctx->c.aux_ev) (void)hipEventDestroy(ctx->c.aux_ev);
   for (hipEvent_t& ev : ctx->c.phase_ev)
     if (ev) (void)hipEventDestroy(ev), ev = nullptr;
   (void)hipStreamSynchronize(ctx->c.stream);
@@ -166,6 +171,8 @@ lh_status lh_free(lh_ctx* ctx, void* d_ptr) {
 lh_status lh_upload(lh_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
   LH_TRY
   NEED_CTX(ctx);
+  NEED_N(d_dst, bytes);
+  NEED_N(src, bytes);
   if (bytes) {
     LH_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->c.stream));
     ctx->c.sync();
@@ -175,6 +182,8 @@ lh_status lh_upload(lh_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
 lh_status lh_download(lh_ctx* ctx, void* dst, const void* d_src, size_t bytes) {
   LH_TRY
   NEED_CTX(ctx);
+  NEED_N(dst, bytes);
+  NEED_N(d_src, bytes);
   if (bytes) {
     LH_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->c.stream));
     ctx->c.sync();
@@ -224,46 +233,68 @@ lh_status lh_keccak_transcript_remaining(lh_transcript* t, size_t* out) {
 // ---------------------------------------------------------------- Fr vectors
 lh_status lh_fr_from_u64(lh_ctx* ctx, const uint64_t* d_in, size_t n, lh_fr* d_out) {
   LH_TRY NEED_CTX(ctx);
+  NEED_N(d_in, n);
+  NEED_N(d_out, n);
   k_fr_from_u64(ctx->c, d_in, n, (Fr*)d_out);
   LH_CATCH
 }
 lh_status lh_fr_from_u32(lh_ctx* ctx, const uint32_t* d_in, size_t n, lh_fr* d_out) {
   LH_TRY NEED_CTX(ctx);
+  NEED_N(d_in, n);
+  NEED_N(d_out, n);
   k_fr_from_u32(ctx->c, d_in, n, (Fr*)d_out);
   LH_CATCH
 }
 lh_status lh_fr_to_repr(lh_ctx* ctx, const lh_fr* d_in, size_t n, uint8_t* d_out32) {
   LH_TRY NEED_CTX(ctx);
+  NEED_N(d_in, n);
+  NEED_N(d_out32, n);
   k_fr_to_repr(ctx->c, (const Fr*)d_in, n, (Fr*)d_out32);
   LH_CATCH
 }
 lh_status lh_fr_from_repr(lh_ctx* ctx, const uint8_t* d_in32, size_t n, lh_fr* d_out) {
   LH_TRY NEED_CTX(ctx);
+  NEED_N(d_in32, n);
+  NEED_N(d_out, n);
   k_fr_from_repr(ctx->c, (const Fr*)d_in32, n, (Fr*)d_out);
   LH_CATCH
 }
 lh_status lh_fr_add(lh_ctx* ctx, const lh_fr* a, const lh_fr* b, size_t n, lh_fr* out) {
   LH_TRY NEED_CTX(ctx);
+  NEED_N(a, n);
+  NEED_N(b, n);
+  NEED_N(out, n);
   k_fr_binop(ctx->c, 0, (const Fr*)a, (const Fr*)b, n, (Fr*)out);
   LH_CATCH
 }
 lh_status lh_fr_sub(lh_ctx* ctx, const lh_fr* a, const lh_fr* b, size_t n, lh_fr* out) {
   LH_TRY NEED_CTX(ctx);
+  NEED_N(a, n);
+  NEED_N(b, n);
+  NEED_N(out, n);
   k_fr_binop(ctx->c, 1, (const Fr*)a, (const Fr*)b, n, (Fr*)out);
   LH_CATCH
 }
 lh_status lh_fr_mul(lh_ctx* ctx, const lh_fr* a, const lh_fr* b, size_t n, lh_fr* out) {
   LH_TRY NEED_CTX(ctx);
+  NEED_N(a, n);
+  NEED_N(b, n);
+  NEED_N(out, n);
   k_fr_binop(ctx->c, 2, (const Fr*)a, (const Fr*)b, n, (Fr*)out);
   LH_CATCH
 }
 lh_status lh_fr_mul_chain(lh_ctx* ctx, const lh_fr* a, const lh_fr* b, size_t n, int iters, lh_fr* out) {
   LH_TRY NEED_CTX(ctx);
+  NEED_N(a, n);
+  NEED_N(b, n);
+  NEED_N(out, n);
   k_fr_mul_chain(ctx->c, (const Fr*)a, (const Fr*)b, n, iters, (Fr*)out);
   LH_CATCH
 }
 lh_status lh_fr_batch_invert(lh_ctx* ctx, const lh_fr* d_in, size_t n, lh_fr* d_out) {
   LH_TRY NEED_CTX(ctx);
+  NEED_N(d_in, n);
+  NEED_N(d_out, n);
   k_fr_batch_invert(ctx->c, (const Fr*)d_in, n, (Fr*)d_out);
   LH_CATCH
 }
@@ -274,6 +305,8 @@ static bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
 lh_status lh_fix_var(lh_ctx* ctx, const lh_fr* d_in, size_t n_in, const lh_fr* x, lh_fr* d_out) {
   LH_TRY NEED_CTX(ctx);
   NEED(x);
+  NEED(d_in);
+  NEED(d_out);
   LH_REQUIRE(is_pow2(n_in) && n_in >= 2, LH_ERR_ARG, "fix_var: table must have 2^m >= 2 entries");
   Fr xr;
   memcpy(&xr, x, 32);
@@ -282,6 +315,8 @@ lh_status lh_fix_var(lh_ctx* ctx, const lh_fr* d_in, size_t n_in, const lh_fr* x
 }
 lh_status lh_eq_xy(lh_ctx* ctx, const lh_fr* y, size_t num_vars, lh_fr* d_out) {
   LH_TRY NEED_CTX(ctx);
+  NEED_N(y, num_vars);
+  NEED(d_out);
   LH_REQUIRE(num_vars < 32, LH_ERR_ARG, "eq_xy: num_vars too large");
   k_eq_xy(ctx->c, (const Fr*)y, num_vars, (Fr*)d_out);
   LH_CATCH
@@ -289,6 +324,9 @@ lh_status lh_eq_xy(lh_ctx* ctx, const lh_fr* y, size_t num_vars, lh_fr* d_out) {
 lh_status lh_evaluate(lh_ctx* ctx, const lh_fr* const* d_polys, size_t num_polys, size_t num_vars,
                       const lh_fr* point, lh_fr* out_evals) {
   LH_TRY NEED_CTX(ctx);
+  NEED_N(d_polys, num_polys);
+  NEED_N(out_evals, num_polys);
+  NEED_N(point, num_vars);
   std::vector<HFr> ev = evaluate_polys(ctx->c, (const Fr* const*)d_polys, num_polys, num_vars, (const HFr*)point);
   memcpy(out_evals, ev.data(), num_polys * 32);
   LH_CATCH
@@ -296,6 +334,9 @@ lh_status lh_evaluate(lh_ctx* ctx, const lh_fr* const* d_polys, size_t num_polys
 lh_status lh_lincomb(lh_ctx* ctx, const lh_fr* const* d_polys, const lh_fr* w, size_t num_polys, size_t n,
                      lh_fr* d_out) {
   LH_TRY NEED_CTX(ctx);
+  NEED_N(d_polys, num_polys);
+  NEED_N(w, num_polys);
+  NEED_N(d_out, n);
   k_lincomb(ctx->c, (const Fr* const*)d_polys, (const Fr*)w, num_polys, n, (Fr*)d_out);
   LH_CATCH
 }
@@ -307,6 +348,8 @@ lh_status lh_sumcheck_prove(lh_ctx* ctx, int prover_kind, size_t num_vars, const
   LH_TRY NEED_CTX(ctx);
   NEED(expr);
   NEED(sum);
+  NEED_N(d_polys, num_polys);
+  NEED_N(ys, num_ys);
   LH_REQUIRE(prover_kind == LH_SC_EVALUATIONS || prover_kind == LH_SC_COEFFICIENTS, LH_ERR_ARG, "bad prover kind");
   Transcript tr(t);
   HFr s;
@@ -325,6 +368,9 @@ lh_status lh_sumcheck_prove_expr(lh_ctx* ctx, size_t num_vars, const lh_expr* ex
   LH_TRY NEED_CTX(ctx);
   NEED(expr);
   NEED(sum);
+  NEED_N(d_polys, num_polys);
+  NEED_N(challenges, num_challenges);
+  NEED_N(ys, num_ys);
   Transcript tr(t);
   HFr s;
   memcpy(&s, sum, 32);
@@ -340,6 +386,10 @@ lh_status lh_gkr_fractional_prove(lh_ctx* ctx, size_t num_batching, size_t num_v
                                   const lh_fr* const* d_ps, const lh_fr* const* d_qs, lh_transcript* t,
                                   lh_fr* out_p_xs, lh_fr* out_q_xs, lh_fr* out_x) {
   LH_TRY NEED_CTX(ctx);
+  NEED_N(claimed_p_0s, num_batching);
+  NEED_N(claimed_q_0s, num_batching);
+  NEED_N(d_ps, num_batching);
+  NEED_N(d_qs, num_batching);
   Transcript tr(t);
   FracSumCheckResult r =
       prove_fractional_sum_check(ctx->c, num_batching, num_vars, (const HFr* const*)claimed_p_0s,
@@ -354,6 +404,7 @@ lh_status lh_grand_product_prove(lh_ctx* ctx, size_t num_trees, const lh_fr* con
                                  lh_transcript* t, lh_fr* out_roots, lh_fr* out_claims, lh_fr* out_points) {
   LH_TRY NEED_CTX(ctx);
   NEED(num_vars);
+  NEED_N(d_leaves, num_trees);
   Transcript tr(t);
   GrandProductResult r = prove_grand_product(ctx->c, num_trees, (const Fr* const*)d_leaves, num_vars, tr);
   if (out_roots) memcpy(out_roots, r.roots.data(), num_trees * 32);
@@ -372,6 +423,8 @@ lh_status lh_grand_product_prove(lh_ctx* ctx, size_t num_trees, const lh_fr* con
 lh_status lh_msm(lh_ctx* ctx, const lh_fr* d_scalars, const lh_g1* d_bases, size_t n, lh_g1* out) {
   LH_TRY NEED_CTX(ctx);
   NEED(out);
+  NEED_N(d_scalars, n);
+  NEED_N(d_bases, n);
   MsmJob job{d_scalars, false, (const G1Affine*)d_bases, n};
   msm_batch(ctx->c, &job, 1, (G1Affine*)out);
   LH_CATCH
@@ -379,6 +432,8 @@ lh_status lh_msm(lh_ctx* ctx, const lh_fr* d_scalars, const lh_g1* d_bases, size
 lh_status lh_msm_u32(lh_ctx* ctx, const uint32_t* d_scalars, const lh_g1* d_bases, size_t n, lh_g1* out) {
   LH_TRY NEED_CTX(ctx);
   NEED(out);
+  NEED_N(d_scalars, n);
+  NEED_N(d_bases, n);
   MsmJob job{d_scalars, true, (const G1Affine*)d_bases, n};
   msm_batch(ctx->c, &job, 1, (G1Affine*)out);
   LH_CATCH
@@ -388,6 +443,7 @@ lh_status lh_msm_u32(lh_ctx* ctx, const uint32_t* d_scalars, const lh_g1* d_base
 lh_status lh_mkzg_setup(lh_ctx* ctx, const lh_fr* ss, size_t num_vars, lh_srs** out) {
   LH_TRY NEED_CTX(ctx);
   NEED(out);
+  NEED_N(ss, num_vars);
   Srs* s = mkzg_setup(ctx->c, (const HFr*)ss, num_vars);
   lh_srs* w = new lh_srs();
   w->s = *s;
@@ -398,19 +454,24 @@ lh_status lh_mkzg_setup(lh_ctx* ctx, const lh_fr* ss, size_t num_vars, lh_srs** 
 lh_status lh_srs_upload(lh_ctx* ctx, const lh_g1* eqs_flat, size_t num_vars, lh_srs** out) {
   LH_TRY NEED_CTX(ctx);
   NEED(out);
+  NEED(eqs_flat);
   LH_REQUIRE(num_vars < 31, LH_ERR_ARG, "srs: num_vars too large");
-  lh_srs* w = new lh_srs();
+  std::unique_ptr<lh_srs> w(new lh_srs());  // (a failed allocation or copy below must not leak the wrapper)
   w->s.num_vars = num_vars;
   size_t total = ((size_t)2 << num_vars) - 1;
   LH_HIP(hipMalloc((void**)&w->s.d_eqs, total * sizeof(G1Affine)));
-  LH_HIP(hipMemcpyAsync(w->s.d_eqs, eqs_flat, total * sizeof(G1Affine), hipMemcpyHostToDevice, ctx->c.stream));
-  ctx->c.sync();
-  *out = w;
+  if (hipMemcpyAsync(w->s.d_eqs, eqs_flat, total * sizeof(G1Affine), hipMemcpyHostToDevice, ctx->c.stream) != hipSuccess ||
+      hipStreamSynchronize(ctx->c.stream) != hipSuccess) {
+    (void)hipFree(w->s.d_eqs);
+    throw lh::Error(LH_ERR_DEVICE, "srs upload failed");
+  }
+  *out = w.release();
   LH_CATCH
 }
 lh_status lh_srs_download(lh_ctx* ctx, const lh_srs* srs, lh_g1* eqs_flat) {
   LH_TRY NEED_CTX(ctx);
   NEED(srs);
+  NEED(eqs_flat);
   size_t total = ((size_t)2 << srs->s.num_vars) - 1;
   LH_HIP(hipMemcpyAsync(eqs_flat, srs->s.d_eqs, total * sizeof(G1Affine), hipMemcpyDeviceToHost, ctx->c.stream));
   ctx->c.sync();
@@ -435,6 +496,8 @@ void lh_srs_free(lh_ctx* ctx, lh_srs* srs) {
 lh_status lh_mkzg_commit(lh_ctx* ctx, const lh_srs* srs, const lh_fr* d_poly, size_t num_vars, lh_g1* out) {
   LH_TRY NEED_CTX(ctx);
   NEED(srs);
+  NEED(d_poly);
+  NEED(out);
   const Fr* p = (const Fr*)d_poly;
   std::vector<HG1> c = mkzg_batch_commit(ctx->c, srs->s, &p, 1, num_vars);
   memcpy(out, c.data(), 64);
@@ -444,14 +507,18 @@ lh_status lh_mkzg_batch_commit(lh_ctx* ctx, const lh_srs* srs, const lh_fr* cons
                                size_t num_vars, lh_g1* out_comms) {
   LH_TRY NEED_CTX(ctx);
   NEED(srs);
+  NEED_N(d_polys, num_polys);
+  NEED_N(out_comms, num_polys);
   std::vector<HG1> c = mkzg_batch_commit(ctx->c, srs->s, (const Fr* const*)d_polys, num_polys, num_vars);
-  memcpy(out_comms, c.data(), num_polys * 64);
+  if (num_polys) memcpy(out_comms, c.data(), num_polys * 64);
   LH_CATCH
 }
 lh_status lh_mkzg_open(lh_ctx* ctx, const lh_srs* srs, const lh_fr* d_poly, size_t num_vars, const lh_fr* point,
                        lh_transcript* t, lh_fr* out_eval) {
   LH_TRY NEED_CTX(ctx);
   NEED(srs);
+  NEED(d_poly);
+  NEED_N(point, num_vars);
   Transcript tr(t);
   HFr e = mkzg_open(ctx->c, srs->s, (const Fr*)d_poly, num_vars, (const HFr*)point, tr);
   if (out_eval) memcpy(out_eval, &e, 32);
@@ -462,6 +529,9 @@ lh_status lh_mkzg_batch_open(lh_ctx* ctx, const lh_srs* srs, size_t num_vars, co
                              size_t num_evals, lh_transcript* t) {
   LH_TRY NEED_CTX(ctx);
   NEED(srs);
+  NEED_N(d_polys, num_polys);
+  NEED_N(points, num_points);
+  NEED_N(evals, num_evals);
   Transcript tr(t);
   mkzg_batch_open(ctx->c, srs->s, num_vars, (const Fr* const*)d_polys, num_polys, (const HFr*)points, num_points,
                   evals, num_evals, tr);
@@ -660,6 +730,7 @@ lh_status lh_hyperplonk_prove(lh_ctx* ctx, const lh_srs* srs, const lh_hp_param*
   LH_TRY NEED_CTX(ctx);
   NEED(srs);
   NEED(pp);
+  NEED_N(d_witness_polys, pp->num_witness_polys);
   Transcript tr(t);
   hyperplonk_prove(ctx->c, mkzg_pcs(ctx->c, srs->s), *pp, (const HFr* const*)instances, (const Fr* const*)d_witness_polys, tr);
   LH_CATCH
@@ -680,6 +751,7 @@ lh_status lh_hyperplonk_prove_sharded(lh_ctx* ctx, const lh_srs* srs, const lh_h
   LH_TRY NEED_CTX(ctx);
   NEED(srs);
   NEED(pp);
+  NEED_N(d_witness_polys, pp->num_witness_polys);
   Ctx& c = ctx->c;
   LH_REQUIRE(c.has_comm, LH_ERR_ARG, "lh_hyperplonk_prove_sharded: no communicator attached");
   const size_t R = (size_t)c.comm.size;
@@ -714,6 +786,9 @@ lh_status lh_mkzg_vp_new(const lh_g1* g1, const lh_g2* g2, const lh_g2* ss, size
 lh_status lh_mkzg_vp_export(const lh_mkzg_vp* vp, lh_g1* g1, lh_g2* g2, lh_g2* ss) {
   LH_TRY
   NEED(vp);
+  NEED(g1);
+  NEED(g2);
+  NEED_N(ss, mkzg_vp_num_vars(*vp->p));
   mkzg_vp_export(*vp->p, g1, g2, ss);
   LH_CATCH
 }
@@ -750,9 +825,9 @@ lh_status lh_mkzg_batch_verify(const lh_mkzg_vp* vp, size_t num_vars, const lh_g
                                lh_transcript* t) {
   LH_TRY
   NEED(vp);
-  NEED(comms);
-  NEED(points);
-  NEED(evals);
+  NEED_N(comms, num_comms);
+  NEED_N(points, num_points);
+  NEED_N(evals, num_evals);
   Transcript tr(t);
   mkzg_batch_verify(*vp->p, num_vars, (const HG1*)comms, num_comms, (const HFr*)points, num_points, evals, num_evals,
                     tr);
@@ -827,12 +902,15 @@ lh_status lh_usrs_upload(lh_ctx* ctx, const lh_g1* powers, size_t poly_size, lh_
   NEED(powers);
   NEED(out);
   LH_REQUIRE(poly_size >= 1 && poly_size < ((size_t)1 << 31), LH_ERR_ARG, "univariate srs: bad poly_size");
-  lh_usrs* w = new lh_usrs();
+  std::unique_ptr<lh_usrs> w(new lh_usrs());
   w->s.size = poly_size;
   LH_HIP(hipMalloc((void**)&w->s.d_powers, poly_size * sizeof(G1Affine)));
-  LH_HIP(hipMemcpyAsync(w->s.d_powers, powers, poly_size * sizeof(G1Affine), hipMemcpyHostToDevice, ctx->c.stream));
-  ctx->c.sync();
-  *out = w;
+  if (hipMemcpyAsync(w->s.d_powers, powers, poly_size * sizeof(G1Affine), hipMemcpyHostToDevice, ctx->c.stream) != hipSuccess ||
+      hipStreamSynchronize(ctx->c.stream) != hipSuccess) {
+    (void)hipFree(w->s.d_powers);
+    throw lh::Error(LH_ERR_DEVICE, "univariate srs upload failed");
+  }
+  *out = w.release();
   LH_CATCH
 }
 lh_status lh_usrs_download(lh_ctx* ctx, const lh_usrs* srs, lh_g1* powers) {
@@ -864,7 +942,7 @@ lh_status lh_zeromorph_open(lh_ctx* ctx, const lh_usrs* srs, size_t poly_size, c
   LH_TRY NEED_CTX(ctx);
   NEED(srs);
   NEED(d_poly);
-  NEED(point);
+  NEED_N(point, num_vars);
   Transcript tr(t);
   zeromorph_open(ctx->c, srs->s, poly_size, (const Fr*)d_poly, num_vars, (const HFr*)point, tr);
   LH_CATCH
@@ -874,9 +952,9 @@ lh_status lh_zeromorph_batch_open(lh_ctx* ctx, const lh_usrs* srs, size_t poly_s
                                   size_t num_points, const lh_evaluation* evals, size_t num_evals, lh_transcript* t) {
   LH_TRY NEED_CTX(ctx);
   NEED(srs);
-  NEED(d_polys);
-  NEED(points);
-  NEED(evals);
+  NEED_N(d_polys, num_polys);
+  NEED_N(points, num_points);
+  NEED_N(evals, num_evals);
   Transcript tr(t);
   zeromorph_batch_open(ctx->c, srs->s, poly_size, num_vars, (const Fr* const*)d_polys, num_polys, (const HFr*)points,
                        num_points, evals, num_evals, tr);
@@ -905,6 +983,10 @@ lh_status lh_zeromorph_vp_new(const lh_g1* g1, const lh_g2* g2, const lh_g2* s_g
 lh_status lh_zeromorph_vp_export(const lh_zm_vp* vp, lh_g1* g1, lh_g2* g2, lh_g2* s_g2, lh_g2* s_offset_g2) {
   LH_TRY
   NEED(vp);
+  NEED(g1);
+  NEED(g2);
+  NEED(s_g2);
+  NEED(s_offset_g2);
   zeromorph_vp_export(*vp->p, g1, g2, s_g2, s_offset_g2);
   LH_CATCH
 }
@@ -933,9 +1015,9 @@ lh_status lh_zeromorph_batch_verify(const lh_zm_vp* vp, size_t num_vars, const l
                                     size_t num_evals, lh_transcript* t) {
   LH_TRY
   NEED(vp);
-  NEED(comms);
-  NEED(points);
-  NEED(evals);
+  NEED_N(comms, num_comms);
+  NEED_N(points, num_points);
+  NEED_N(evals, num_evals);
   Transcript tr(t);
   zeromorph_batch_verify(*vp->p, num_vars, (const HG1*)comms, num_comms, (const HFr*)points, num_points, evals,
                          num_evals, tr);
@@ -969,6 +1051,7 @@ lh_status lh_hyperplonk_prove_zeromorph(lh_ctx* ctx, const lh_usrs* srs, size_t 
   LH_TRY NEED_CTX(ctx);
   NEED(srs);
   NEED(pp);
+  NEED_N(d_witness_polys, pp->num_witness_polys);
   Transcript tr(t);
   hyperplonk_prove(ctx->c, zeromorph_pcs(ctx->c, srs->s, poly_size), *pp, (const HFr* const*)instances,
                    (const Fr* const*)d_witness_polys, tr);

@@ -80,7 +80,7 @@ static const struct {
     {"sc_tail", &Options::sc_tail, 0, 1},                          {"sc_tail_max_len", &Options::sc_tail_max_len, 0, (int64_t)1 << 20},
     {"shard_exchange_log", &Options::shard_exchange_log, 0, 40},   {"msm_window_tables", &Options::msm_window_tables, 0, 40},
     {"open_precommit", &Options::open_precommit, 0, 64},           {"gkr_resident", &Options::gkr_resident, 0, 1},
-    {"sc_pp_fold", &Options::sc_pp_fold, 0, 1},
+    {"sc_pp_fold", &Options::sc_pp_fold, 0, 2},                    {"msm_half_batches", &Options::msm_half_batches, 0, 1},
     {"comm_round", &Options::comm_round, 0, 2},
 };
 
@@ -139,6 +139,35 @@ void Ctx::wait_flag(uint32_t seq) {
         throw Error(LH_ERR_DEVICE, "kernel finished without publishing its result");
       }
       if (e != hipErrorNotReady) throw Error(LH_ERR_DEVICE, std::string("stream error: ") + hipGetErrorString(e));
+    }
+  }
+}
+
+void Ctx::aux_streams() {
+  if (aux_stream) return;
+  // (the highest priority the device offers: what runs here is the latency-bound half of a pipeline)
+  int prio_lo = 0, prio_hi = 0;
+  LH_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+  LH_HIP(hipStreamCreateWithPriority(&aux_stream, hipStreamNonBlocking, prio_hi));
+  LH_HIP(hipEventCreateWithFlags(&aux_ev, hipEventDisableTiming));
+}
+ScFinishArgs Ctx::finish_for_aux(uint32_t grid, uint32_t seq) {
+  ScFinishArgs f{ticket + 16, (uint32_t)(aux_ticket_base + grid - 1), nullptr, flag + 4, seq, nullptr, 0};
+  if (grid > 1) aux_ticket_base += grid;
+  return f;
+}
+void Ctx::wait_flag_aux(uint32_t seq) {
+  volatile uint32_t* f = flag + 4;
+  for (uint64_t spin = 0;; spin++) {
+    if (*f == seq) return;
+    __builtin_ia32_pause();
+    if ((spin & 0xfffff) == 0xfffff) {
+      hipError_t e = hipStreamQuery(aux_stream ? aux_stream : stream);
+      if (e == hipSuccess) {
+        if (*f == seq) return;
+        throw Error(LH_ERR_DEVICE, "kernel on the aux stream finished without publishing its result");
+      }
+      if (e != hipErrorNotReady) throw Error(LH_ERR_DEVICE, std::string("aux stream error: ") + hipGetErrorString(e));
     }
   }
 }

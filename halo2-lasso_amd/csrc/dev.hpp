@@ -130,6 +130,10 @@ struct Options {
                                        // every round (sc_round_e2) instead of folding them into the left factors and sharing
                                        // Montgomery reductions (sc_round_pp); the leaf layers (ScRwRound) keep cs and k
                                        // outside their tables and run the leaf kernel in every streaming round
+                                       // 2: sc_round_pp in every streaming round, nothing folded (coefficients applied on the way)
+  int64_t msm_half_batches = 1;        // an MSM batch of >= 2^24 entries runs as two halves: the first half's latency-bound tails
+                                       // (continuation levels, bucket reduction, window sums) on the aux stream beside the
+                                       // second half's accumulation (msm.hip msm_pick_split; 0: one batch, one stream)
   int64_t gkr_resident = 1;            // the layers of a grand-product argument whose tables fit the resident kernel run in ONE
                                        // launch (layer loop, eq tables and rounds inside; 0: one sum-check per layer)
   int64_t comm_round = 0;              // how the partial sums of a sharded sum-check round are combined: 0 = all-gather +
@@ -145,7 +149,7 @@ struct Options {
 struct RouteStats {  // lh_lasso_route (include/lasso_hip.h): counters of the last Lasso prove on the ctx
   uint32_t v[LH_LASSO_ROUTE_WORDS] = {0};
   enum { OPEN_DEPTH, OPEN_PASSES, EF_ROUNDS, STD_ROUNDS, RW_ROUNDS, TAILS, TAIL_ROUNDS, PACKED_TS, DERIVED, SORTED_REUSE,
-         SHARDED_ROUNDS, SHARD_EXCHANGES, WIN_TABLE_JOBS, OPEN_PRECOMMIT, RESIDENT_LAYERS, PP_FOLDS, RESERVED_29 };
+         SHARDED_ROUNDS, SHARD_EXCHANGES, WIN_TABLE_JOBS, OPEN_PRECOMMIT, RESIDENT_LAYERS, PP_FOLDS, MSM_HALF_BATCHES };
 };
 
 // ------------------------------------------------------------------ a long-lived host thread (dev.cpp)
@@ -260,6 +264,14 @@ struct Ctx {
                                // word 10: the resident grand-product kernel's start verdict; words 32..47: the resident
                                // tail's relay chunks)
   uint32_t ticket_base = 0;    // its value before the next launch
+  // a second stream of the ctx for work that runs BESIDE the ctx's stream inside one call (msm.hip: the tails of a batch's
+  // first half); its kernels draw tickets from word 16 and publish to flag word 4, so the two streams never share a counter
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t aux_ev = nullptr;
+  uint32_t aux_ticket_base = 0;
+  void aux_streams();  // creates them on first use
+  struct ScFinishArgs finish_for_aux(uint32_t grid, uint32_t seq);
+  void wait_flag_aux(uint32_t seq);
   struct ScFinishArgs finish_for(uint32_t grid, Fr* out_host, uint32_t seq);
   uint32_t next_seq() { return ++flag_seq; }
   // host -> resident kernel mailbox (second cache line of the flag allocation)
@@ -420,8 +432,10 @@ void k_pack_u32(Ctx&, const uint32_t* a, const uint32_t* b, uint32_t shift, size
 // v = col[i + half] - col[i] + offset (entries beyond `len` are zero; 0 < v < 2^33): out_lo[i] = v, or with out_hi:
 // out_lo[i] = v & 0xffff, out_hi[i] = v >> 16
 void k_delta_u32(Ctx&, const uint32_t* col, size_t len, size_t half, uint64_t offset, uint32_t* out_lo, uint32_t* out_hi);
-void k_lasso_counters(Ctx&, const uint32_t* dim, size_t n, size_t m, uint32_t* read_ts, uint32_t* final_cts,
-                      uint32_t* keep_sorted = nullptr, uint32_t* keep_index = nullptr);
+// access counters of all `cc` chunk columns (n lookups into m cells each) in one launch set, one bad-index readback per call;
+// keep_sorted / keep_index: null, or per column where to leave the sorted values and their positions
+void k_lasso_counters(Ctx&, const uint32_t* const* dims, size_t cc, size_t n, size_t m, uint32_t* const* read_ts,
+                      uint32_t* const* final_cts, uint32_t* const* keep_sorted = nullptr, uint32_t* const* keep_index = nullptr);
 // the sharded counters' steps (lasso.cpp lasso_counters_sharded), ALL `cc` chunk columns per call: partition the local
 // lookups by address owner (sidx[q]: local indices in send order; send[q]: (address on the owner) << hi_bits | local index >>
 // shard_bit; start_host[q * (R + 1) + o]: first send position of owner o in column q), rank the received lookups on the
@@ -714,6 +728,7 @@ struct SortSlab {
   uint32_t* vals_out;
   size_t n;
   unsigned bits;
+  unsigned first_bit = 0;
 };
 // (vals_in == nullptr: the values are the positions 0 .. n - 1; the sort is by the key bits [first_bit, first_bit + bits))
 void sort_pairs_u32(Ctx&, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, size_t n,
@@ -768,7 +783,9 @@ void k_msm_window_table(Ctx&, const G1Affine* bases, size_t n, uint32_t cbits, u
 // Runs all jobs as one batched Pippenger; out[j] is the affine sum (identity = (0,0)).
 // `overlap` (optional): host work that needs none of this batch's results - run once, after the batch's kernels are
 // queued and before the host waits for the window sums (it overlaps the device's work instead of following it)
-void msm_batch(Ctx&, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, const std::function<void()>* overlap = nullptr);
+// Returns whether the host waited for the ctx's stream on the way (false only for a batch without a single entry and with every
+// width promised: then nothing queued before the call is known to have run).
+bool msm_batch(Ctx&, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, const std::function<void()>* overlap = nullptr);
 int msm_slab_log();  // jobs of >= 2^this points are sorted slab by slab (and can take MsmJob::sorted_*)
 // out[i] = scalars[i] * G (fixed-base), normalised to affine; all on device
 void k_fixed_base_mul_g(Ctx&, const Fr* scalars, size_t n, G1Affine* out);

@@ -859,49 +859,67 @@ __device__ __forceinline__ uint32_t subtable_entry(int kind, uint32_t m, uint32_
 // Stable radix sort of (address, lookup index) pairs, then a lookup's rank inside its run of equal addresses is
 // its position minus the run start: O(n) traffic whatever the table size (a tile x address histogram, the
 // obvious counting-sort formulation, moves tiles * m counters - 2 GB per column at 2^24 lookups).
-__global__ void lasso_run_start_kernel(const uint32_t* __restrict__ skey, size_t n, size_t m,
-                                       uint32_t* __restrict__ start, uint32_t* __restrict__ bad) {
-  GSTRIDE(i, n) {
-    const uint32_t k = skey[i];
-    if (k >= m) *bad = 1u;  // benign race: every writer stores the same value
-    else if (i == 0 || skey[i - 1] != k) start[k] = (uint32_t)i;
-  }
-}
-__global__ void lasso_rank_kernel(const uint32_t* __restrict__ skey, const uint32_t* __restrict__ sidx, size_t n,
-                                  size_t m, const uint32_t* __restrict__ start, uint32_t* __restrict__ read_ts,
-                                  uint32_t* __restrict__ final_cts) {
-  GSTRIDE(i, n) {
-    const uint32_t k = skey[i];
-    if (k >= m) continue;  // reported through `bad`
-    const uint32_t r = (uint32_t)i - start[k];
-    read_ts[sidx[i]] = r;
-    if (i + 1 == n || skey[i + 1] != k) final_cts[k] = r + 1;
-  }
-}
 // Large columns: the scatter read_ts[sidx[i]] = rank above drags a whole line through the caches for every 4 bytes.  Here
 // the ranks stay in sorted order (`ranks`, coalesced), the (lookup index, rank) pairs are partitioned by the top bits of the
 // index (one or two passes of the radix sort) and every window of 2^15 consecutive read_ts entries is assembled in LDS and
 // written out as whole lines.
-__global__ void lasso_rank_sorted_kernel(const uint32_t* __restrict__ skey, size_t n, size_t m,
-                                         const uint32_t* __restrict__ start, uint32_t* __restrict__ ranks,
-                                         uint32_t* __restrict__ final_cts) {
+constexpr uint32_t UNPERM_WINDOW_LOG = 15;  // read_ts entries per workgroup: 128 KB of LDS
+// pairs (idx, rank) grouped by idx >> group_log (group g = positions [g << group_log, (g + 1) << group_log), idx a
+// permutation); workgroup (g, h) assembles window h of group g
+// All chunk columns of a table per launch (blockIdx.y = column): the steps above for up to LH_LASSO_MAX_CHUNKS columns of n
+// lookups into m cells each
+struct CtCols {
+  const uint32_t* skey[LH_LASSO_MAX_CHUNKS];
+  const uint32_t* sidx[LH_LASSO_MAX_CHUNKS];
+  uint32_t* start[LH_LASSO_MAX_CHUNKS];
+  uint32_t* ranks[LH_LASSO_MAX_CHUNKS];
+  uint32_t* read_ts[LH_LASSO_MAX_CHUNKS];
+  uint32_t* final_cts[LH_LASSO_MAX_CHUNKS];
+  const uint32_t* pidx[LH_LASSO_MAX_CHUNKS];
+  const uint32_t* prank[LH_LASSO_MAX_CHUNKS];
+};
+__global__ void lasso_run_start_cols_kernel(CtCols k, size_t n, size_t m, uint32_t* __restrict__ bad) {
+  const uint32_t* __restrict__ skey = k.skey[blockIdx.y];
+  uint32_t* __restrict__ start = k.start[blockIdx.y];
   GSTRIDE(i, n) {
-    const uint32_t k = skey[i];
+    const uint32_t a = skey[i];
+    if (a >= m) *bad = 1u;  // benign race: every writer stores the same value
+    else if (i == 0 || skey[i - 1] != a) start[a] = (uint32_t)i;
+  }
+}
+__global__ void lasso_rank_cols_kernel(CtCols k, size_t n, size_t m) {
+  const uint32_t* __restrict__ skey = k.skey[blockIdx.y];
+  const uint32_t* __restrict__ sidx = k.sidx[blockIdx.y];
+  const uint32_t* __restrict__ start = k.start[blockIdx.y];
+  uint32_t* __restrict__ read_ts = k.read_ts[blockIdx.y];
+  uint32_t* __restrict__ final_cts = k.final_cts[blockIdx.y];
+  GSTRIDE(i, n) {
+    const uint32_t a = skey[i];
+    if (a >= m) continue;  // reported through `bad`
+    const uint32_t r = (uint32_t)i - start[a];
+    read_ts[sidx[i]] = r;
+    if (i + 1 == n || skey[i + 1] != a) final_cts[a] = r + 1;
+  }
+}
+__global__ void lasso_rank_sorted_cols_kernel(CtCols k, size_t n, size_t m) {
+  const uint32_t* __restrict__ skey = k.skey[blockIdx.y];
+  const uint32_t* __restrict__ start = k.start[blockIdx.y];
+  uint32_t* __restrict__ ranks = k.ranks[blockIdx.y];
+  uint32_t* __restrict__ final_cts = k.final_cts[blockIdx.y];
+  GSTRIDE(i, n) {
+    const uint32_t a = skey[i];
     uint32_t r = 0;
-    if (k < m) {
-      r = (uint32_t)i - start[k];
-      if (i + 1 == n || skey[i + 1] != k) final_cts[k] = r + 1;
+    if (a < m) {
+      r = (uint32_t)i - start[a];
+      if (i + 1 == n || skey[i + 1] != a) final_cts[a] = r + 1;
     }
     ranks[i] = r;
   }
 }
-constexpr uint32_t UNPERM_WINDOW_LOG = 15;  // read_ts entries per workgroup: 128 KB of LDS
-// pairs (idx, rank) grouped by idx >> group_log (group g = positions [g << group_log, (g + 1) << group_log), idx a
-// permutation); workgroup (g, h) assembles window h of group g
-__global__ __launch_bounds__(1024) void lasso_unpermute_kernel(const uint32_t* __restrict__ pidx,
-                                                               const uint32_t* __restrict__ prank, unsigned group_log,
-                                                               uint32_t* __restrict__ read_ts) {
+__global__ __launch_bounds__(1024) void lasso_unpermute_cols_kernel(CtCols k, unsigned group_log) {
   extern __shared__ uint32_t win[];
+  const uint32_t* __restrict__ pidx = k.pidx[blockIdx.y];
+  const uint32_t* __restrict__ prank = k.prank[blockIdx.y];
   const unsigned parts_log = group_log - UNPERM_WINDOW_LOG;
   const size_t g = blockIdx.x >> parts_log;
   const uint32_t h = blockIdx.x & ((1u << parts_log) - 1u);
@@ -912,43 +930,80 @@ __global__ __launch_bounds__(1024) void lasso_unpermute_kernel(const uint32_t* _
     if (((idx >> UNPERM_WINDOW_LOG) & ((1u << parts_log) - 1u)) == h) win[idx & wmask] = prank[p0 + q];
   }
   __syncthreads();
-  uint32_t* out = read_ts + (g << group_log) + ((size_t)h << UNPERM_WINDOW_LOG);
+  uint32_t* out = k.read_ts[blockIdx.y] + (g << group_log) + ((size_t)h << UNPERM_WINDOW_LOG);
   for (uint32_t q = threadIdx.x; q <= wmask; q += blockDim.x) out[q] = win[q];
 }
-void k_lasso_counters(Ctx& c, const uint32_t* dim, size_t n, size_t m, uint32_t* read_ts, uint32_t* final_cts,
-                      uint32_t* keep_sorted, uint32_t* keep_index) {
-  ProfScope ps(c, "lasso_counters", 8.0 * n + 4.0 * m, 0.0, (double)n);
-  ArenaScope scope(c.arena);
+// the launch set of the columns dims[0 .. cc): batched sort, run starts, ranks, partition pass, un-permute
+static void lasso_counters_launch(Ctx& c, const uint32_t* const* dims, size_t cc, size_t n, size_t m, uint32_t* const* read_ts,
+                                  uint32_t* const* final_cts, uint32_t* const* keep_sorted, uint32_t* const* keep_index,
+                                  uint32_t* bad) {
+  ArenaScope scope(c.arena);  // (everything below is queued on the ctx's stream: the next user of this memory comes behind it)
   unsigned bits = 1;
   while (((size_t)1 << bits) < m) bits++;
-  uint32_t* skey = keep_sorted ? keep_sorted : c.arena.alloc_n<uint32_t>(n);
-  uint32_t* sidx = keep_index ? keep_index : c.arena.alloc_n<uint32_t>(n);
-  uint32_t* start = c.arena.alloc_n<uint32_t>(m);
-  uint32_t* bad = c.arena.alloc_n<uint32_t>(1);
-  LH_HIP(hipMemsetAsync(final_cts, 0, m * sizeof(uint32_t), c.stream));
-  LH_HIP(hipMemsetAsync(bad, 0, sizeof(uint32_t), c.stream));
-  if (!n) return;
-  sort_pairs_u32(c, dim, skey, nullptr, sidx, n, bits);  // (address, lookup index) pairs: the index is the position
-  hipLaunchKernelGGL(lasso_run_start_kernel, grid_for(n), 256, 0, c.stream, skey, n, m, start, bad);
+  CtCols k;
+  memset(&k, 0, sizeof(k));
+  std::vector<uint32_t*> skey(cc), sidx(cc);
+  for (size_t j = 0; j < cc; j++) {
+    skey[j] = keep_sorted ? keep_sorted[j] : c.arena.alloc_n<uint32_t>(n);
+    sidx[j] = keep_index ? keep_index[j] : c.arena.alloc_n<uint32_t>(n);
+    k.skey[j] = skey[j], k.sidx[j] = sidx[j];
+    k.start[j] = c.arena.alloc_n<uint32_t>(m);
+    k.read_ts[j] = read_ts[j], k.final_cts[j] = final_cts[j];
+    LH_HIP(hipMemsetAsync(final_cts[j], 0, m * sizeof(uint32_t), c.stream));
+  }
+  std::vector<SortSlab> sorts(cc);
+  // (address, lookup index) pairs: the index is the position
+  for (size_t j = 0; j < cc; j++) sorts[j] = SortSlab{dims[j], skey[j], nullptr, sidx[j], n, bits};
+  sort_pairs_u32_batched(c, sorts.data(), cc);
+  dim3 g = grid_for(n);
+  g.y = (unsigned)cc;
+  hipLaunchKernelGGL(lasso_run_start_cols_kernel, g, 256, 0, c.stream, k, n, m, bad);
   unsigned lg = 0;
   while (((size_t)1 << lg) < n) lg++;
   // (2^17 .. 2^24 lookups: one partition pass; beyond, the second pass costs what the scatter did - 2^26: 5.3 -> 5.8 ms)
   if (lg >= 17 && lg <= UNPERM_WINDOW_LOG + 9 && n == ((size_t)1 << lg)) {
-    uint32_t* ranks = c.arena.alloc_n<uint32_t>(n);
-    uint32_t* pidx = c.arena.alloc_n<uint32_t>(n);
-    uint32_t* prank = c.arena.alloc_n<uint32_t>(n);
-    hipLaunchKernelGGL(lasso_rank_sorted_kernel, grid_for(n), 256, 0, c.stream, skey, n, m, start, ranks, final_cts);
+    std::vector<uint32_t*> pidx(cc), prank(cc);
+    for (size_t j = 0; j < cc; j++) {
+      k.ranks[j] = c.arena.alloc_n<uint32_t>(n);
+      pidx[j] = c.arena.alloc_n<uint32_t>(n), prank[j] = c.arena.alloc_n<uint32_t>(n);
+      k.pidx[j] = pidx[j], k.prank[j] = prank[j];
+    }
+    hipLaunchKernelGGL(lasso_rank_sorted_cols_kernel, g, 256, 0, c.stream, k, n, m);
     // groups of 2^15 (one window per workgroup) when that takes one pass of <= 8 bits, 2^16 (two windows, the pairs read
     // twice) at 2^24
     const unsigned top = lg - UNPERM_WINDOW_LOG;
     const unsigned pbits = top == 9 ? 8 : top, group_log = lg - pbits;
-    sort_pairs_u32(c, sidx, pidx, ranks, prank, n, pbits, group_log);
-    c.opt_in_lds((const void*)lasso_unpermute_kernel, (int)(4u << UNPERM_WINDOW_LOG));
-    hipLaunchKernelGGL(lasso_unpermute_kernel, dim3((unsigned)(n >> UNPERM_WINDOW_LOG)), dim3(1024), 4u << UNPERM_WINDOW_LOG,
-                       c.stream, pidx, prank, group_log, read_ts);
+    for (size_t j = 0; j < cc; j++) sorts[j] = SortSlab{sidx[j], pidx[j], k.ranks[j], prank[j], n, pbits, group_log};
+    sort_pairs_u32_batched(c, sorts.data(), cc);
+    c.opt_in_lds((const void*)lasso_unpermute_cols_kernel, (int)(4u << UNPERM_WINDOW_LOG));
+    hipLaunchKernelGGL(lasso_unpermute_cols_kernel, dim3((unsigned)(n >> UNPERM_WINDOW_LOG), (unsigned)cc), dim3(1024),
+                       4u << UNPERM_WINDOW_LOG, c.stream, k, group_log);
   } else {
-    hipLaunchKernelGGL(lasso_rank_kernel, grid_for(n), 256, 0, c.stream, skey, sidx, n, m, start, read_ts, final_cts);
+    hipLaunchKernelGGL(lasso_rank_cols_kernel, g, 256, 0, c.stream, k, n, m);
   }
+}
+// The access counters of all `cc` chunk columns with ONE readback of the bad-index flag per call (until round 6: a blocking
+// 4-byte download per column).  Small columns (launch-bound) go through every step together - one batched sort per step,
+// blockIdx.y = column; from 2^22 lookups on the columns go one after the other: a column's working set (its sorted keys
+// and positions, 8 n bytes) then stays in the 256 MB memory-side cache between two steps, which four columns side by
+// side do not (measured at 2^24 AND lookups: 2.43 ms column by column, 2.58 ms batched).
+// keep_sorted / keep_index (null, or one pointer per column): the columns' values in ascending order and the positions
+// they came from - the commit MSM's entry stream for that column (MsmJob::sorted_scalars).
+void k_lasso_counters(Ctx& c, const uint32_t* const* dims, size_t cc, size_t n, size_t m, uint32_t* const* read_ts,
+                      uint32_t* const* final_cts, uint32_t* const* keep_sorted, uint32_t* const* keep_index) {
+  LH_REQUIRE(cc >= 1 && cc <= (size_t)LH_LASSO_MAX_CHUNKS, LH_ERR_ARG, "lasso counters: bad column count");
+  ProfScope ps(c, "lasso_counters", (8.0 * n + 4.0 * m) * cc, 0.0, (double)(n * cc));
+  ArenaScope scope(c.arena);
+  uint32_t* bad = c.arena.alloc_n<uint32_t>(1);
+  LH_HIP(hipMemsetAsync(bad, 0, sizeof(uint32_t), c.stream));
+  if (!n) {
+    for (size_t j = 0; j < cc; j++) LH_HIP(hipMemsetAsync(final_cts[j], 0, m * sizeof(uint32_t), c.stream));
+    return;
+  }
+  const size_t step = n >= ((size_t)1 << 22) ? 1 : cc;
+  for (size_t j = 0; j < cc; j += step)
+    lasso_counters_launch(c, dims + j, std::min(step, cc - j), n, m, read_ts + j, final_cts + j,
+                          keep_sorted ? keep_sorted + j : nullptr, keep_index ? keep_index + j : nullptr, bad);
   uint32_t h_bad = 0;
   c.d2h(&h_bad, bad, sizeof(uint32_t));
   LH_REQUIRE(!h_bad, LH_ERR_ARG, "lasso: chunk index out of range (>= 2^chunk_bits)");

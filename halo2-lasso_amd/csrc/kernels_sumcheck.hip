@@ -305,11 +305,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LH_PP_WAVES
         } else {
           x0 = p0[i], x1 = p1[i], x2 = p2[i], x3 = p3[i];
         }
+        // a folding round stores l' = c l; any other binding round stores the bound entries as they are and applies a
+        // coefficient that is still there to the lane's value only (sc_pp_fold = 2 runs every round that way)
+        if (BIND && !fold) {
+          if (va) rd.out[t0][i] = x0, rd.out[t1][i] = x1;
+          if (vb) rd.out[t2][i] = x2, rd.out[t3][i] = x3;
+        }
         if (va && !rd.coeff_is_one[ma]) x0 = mul(x0, rd.coeff[ma]);
         if (vb && !rd.coeff_is_one[mb]) x2 = mul(x2, rd.coeff[mb]);
-        if (BIND) {
-          if (va) rd.out[t0][i] = x0, rd.out[t1][i] = x1;   // (a folding round stores l' = c l; otherwise c is one here
-          if (vb) rd.out[t2][i] = x2, rd.out[t3][i] = x3;   //  or - round 0 - nothing is stored)
+        if (BIND && fold) {
+          if (va) rd.out[t0][i] = x0, rd.out[t1][i] = x1;
+          if (vb) rd.out[t2][i] = x2, rd.out[t3][i] = x3;
         }
         av[2 * h2] = va ? at_lane_point(x0, odd) : Fr::zero();
         bv[2 * h2] = va ? at_lane_point(x1, odd) : Fr::zero();
@@ -320,7 +326,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LH_PP_WAVES
     }
     acc = add(acc, mul(s, rd.eq_level[i >> 1]));
   }
-  (void)fold;
   Fr q2, q1;
   reduce_by_parity(acc, odd, lds, q2, q1);
   if (threadIdx.x == 0) {
@@ -1089,11 +1094,6 @@ void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, F
     Fr* partials = g2 == 1 ? evals_host : c.arena.alloc_n<Fr>(g2 * 2);
     const ScFinish kflag = finish(g2);
     c.last_round_folded = rd.pp == 2 && bind;
-    if (rd.pp == 1 && bind)
-      // (sc_round_pp_kernel<true> stores the left factor times every coefficient that is not one: right for the folding
-      // round, pp == 2, and a silent corruption of the tables in any other binding round - the caller must have folded)
-      for (uint32_t m = 0; m < rd.num_terms; m++)
-        LH_REQUIRE(rd.coeff_is_one[m], LH_ERR_ARG, "sc_round_pp: a binding round after the fold still carries a coefficient");
     if (rd.pp) {
       // products per pair: binds, one per coefficient still applied on the way, ~0.62 per term for the shared reductions
       // (two points), the eq entry

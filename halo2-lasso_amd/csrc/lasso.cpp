@@ -190,15 +190,14 @@ LassoColumns lasso_witness_columns(Ctx& c, const lh_lasso_table& tb, size_t n, c
   if (sh.on && sh.R >= counters_min_r) {
     lasso_counters_sharded(c, sh, d_dims, cc, n, l, w.rts.data(), w.fcs.data());
   } else {
-    for (size_t j = 0; j < cc; j++) {
-      if (keep_sorted) {
+    if (keep_sorted)
+      for (size_t j = 0; j < cc; j++) {
         w.dim_sorted.push_back(c.arena.alloc_n<uint32_t>(N));
         w.dim_index.push_back(c.arena.alloc_n<uint32_t>(N));
-        k_lasso_counters(c, d_dims[j], N, M, w.rts[j], w.fcs[j], w.dim_sorted[j], w.dim_index[j]);
-      } else {
-        k_lasso_counters(c, d_dims[j], N, M, w.rts[j], w.fcs[j]);
       }
-    }
+    // all chunk columns in one launch set, one bad-index readback (kernels_poly.hip)
+    k_lasso_counters(c, d_dims, cc, N, M, w.rts.data(), w.fcs.data(), keep_sorted ? w.dim_sorted.data() : nullptr,
+                     keep_sorted ? w.dim_index.data() : nullptr);
   }
   LassoG g;
   memset(&g, 0, sizeof(g));

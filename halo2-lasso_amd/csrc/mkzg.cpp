@@ -309,7 +309,7 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
   // and read behind it (fourth cache line of the ctx's pinned flag block) - not a synchronising download after it
   Fr* rem_host = (Fr*)((char*)c.flag + 192);
   LH_HIP(hipMemcpyAsync(rem_host, rem, sizeof(Fr), hipMemcpyDeviceToHost, c.stream));
-  msm_batch(c, jobs.data(), jobs.size(), (G1Affine*)out.data(), ahead ? &combine_columns : nullptr);
+  const bool batch_waited = msm_batch(c, jobs.data(), jobs.size(), (G1Affine*)out.data(), ahead ? &combine_columns : nullptr);
   std::vector<HG1> comms(out.begin(), out.begin() + plain);
   if (plan && !pre_out) column_sums_store(srs, sharded, own, out.data() + col_base);
   if (!ahead) combine_columns();
@@ -320,7 +320,8 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
               plan->levels[d].level, d, depth);
   }
   c.host_stamp("open:columns");
-  if (jobs.empty()) c.sync();  // (no batch ran: nothing waited for the stream yet)
+  if (!batch_waited) c.sync();  // (no entry anywhere in the batch - e.g. a rank whose ranges of the replicated levels are all
+                                // empty -: nothing waited for the stream yet, the copy above may not have landed)
   memcpy(&remainder, rem_host, sizeof(Fr));
   // what every rank holds is the commitment of its part of each quotient - its shard of a sharded level (column-wise
   // levels: of its share of the columns, offset term included - everything above is linear in the bases), its range of a

@@ -611,7 +611,7 @@ int msm_slab_log() {
 }
 
 // the continuation levels of one list: linear levels (fan-in K2) while the list is long, tree levels at the end
-static void msm_continuation_levels(Ctx& c, const uint32_t* ckey, const G1Xyzz* cpt, size_t n_in, G1Xyzz* buckets,
+static void msm_continuation_levels(Ctx& c, hipStream_t stream, const uint32_t* ckey, const G1Xyzz* cpt, size_t n_in, G1Xyzz* buckets,
                                     uint32_t* cnt) {
   static const int MSM_K2 = env_int("LH_MSM_K2", 4);  // continuation fan-in: a level costs ~K2 dependent additions, there
                                                       // are log_K2(chunks) levels; swept 2..16, 3-4 is best (2^16: 10.1 -> 9.3 ms)
@@ -626,13 +626,13 @@ static void msm_continuation_levels(Ctx& c, const uint32_t* ckey, const G1Xyzz* 
     G1Xyzz* opt = c.arena.alloc_n<G1Xyzz>(nc);
     if (tree)
       hipLaunchKernelGGL((msm_accumulate_tree_quad_kernel<64>), dim3((unsigned)std::min<size_t>(nc, 1 << 16)), dim3(256), 0,
-                         c.stream, ckey, cpt, n_in, buckets, okey, opt, cnt + lvl, cnt + lvl + 1);
+                         stream, ckey, cpt, n_in, buckets, okey, opt, cnt + lvl, cnt + lvl + 1);
     else if (n_in <= (size_t)MSM_QUAD_MAX)  // far below one wave per SIMD: a quad of lanes per entry
-      hipLaunchKernelGGL(msm_accumulate_n_quad_kernel, dim3((unsigned)((4 * n_in + 127) / 128)), dim3(128), 0, c.stream,
+      hipLaunchKernelGGL(msm_accumulate_n_quad_kernel, dim3((unsigned)((4 * n_in + 127) / 128)), dim3(128), 0, stream,
                          ckey, cpt, n_in, K2, buckets, okey, opt, cnt + lvl, cnt + lvl + 1);
     else
       hipLaunchKernelGGL(msm_accumulate_n_kernel, dim3((unsigned)std::min<size_t>((n_in + 127) / 128, 1 << 16)), dim3(128), 0,
-                         c.stream, ckey, cpt, n_in, K2, buckets, okey, opt, cnt + lvl, cnt + lvl + 1);
+                         stream, ckey, cpt, n_in, K2, buckets, okey, opt, cnt + lvl, cnt + lvl + 1);
     lvl++;
     LH_REQUIRE(lvl < 30, LH_ERR_ARG, "msm: continuation list too long");
     if (n_in <= fan) break;  // a single chunk / tile: no continuation can remain
@@ -658,38 +658,444 @@ static inline host::G1Xyzz to_host(const G1Xyzz& p) {
   return r;
 }
 
-void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, const std::function<void()>* overlap) {
-  bool overlap_done = overlap == nullptr;
-  struct OverlapGuard {  // (a batch without entries, or one that throws on the way, still owes the caller its host work)
-    const std::function<void()>* fn;
-    bool& done;
-    ~OverlapGuard() noexcept(false) {
-      if (!done && !std::uncaught_exceptions()) done = true, (*fn)();
+// One planned sub-batch: the jobs `idx` (positions in the caller's array) with their own key / segment / share numbering,
+// buffers and flag.  A batch is one sub-batch, or - msm_pick_split - two that run as a pipeline: the second half's entry
+// stream and accumulation on the ctx's stream, the first half's latency-bound tails beside them on the ctx's aux stream.
+namespace {
+struct MsmSub {
+  std::vector<size_t> idx;
+  MsmPlanDev plan;
+  std::vector<uint32_t> bits, sort_bits;
+  std::vector<char> derived, slab;
+  size_t num_derived = 0, max_entries = 0, small_entries = 0, max_n = 0, nbuckets = 0, nsegs = 0, nwins = 0, ngroups = 0, nblocks = 0;
+  size_t nchunks = 0;
+  uint32_t nshares = 0, K = 0, seg_size = 0;
+  bool plain_reduce = false;
+  double total_pts = 0, full_pts = 0;
+  uint32_t *ukey = nullptr, *uidx = nullptr, *skey = nullptr, *sidx = nullptr, *lvl_cnt = nullptr, *ckey = nullptr;
+  G1Xyzz *buckets = nullptr, *seg_out = nullptr, *seg_t = nullptr, *grp_out = nullptr, *cpt = nullptr;
+  G1Xyzz* win_out = nullptr;  // pinned
+  uint8_t* h_tab = nullptr;   // pinned staging of the key-block table
+  std::vector<G1Xyzz> wins;
+  size_t pin_bytes() const { return ((size_t)nshares * sizeof(G1Xyzz) + nblocks + 255) & ~(size_t)255; }
+};
+
+// the shape a job will get: window bits, windows, sorted entries and buckets (what msm_plan_sub decides, without the layout)
+struct MsmShape {
+  uint32_t c, W, sort_bits;
+  size_t entries, buckets;
+};
+MsmShape msm_job_shape(const MsmJob& in, uint32_t bits, bool derived) {
+  MsmShape s;
+  s.c = pick_window(in.n ? in.n : 1, bits ? bits : 1);
+  if (in.pack_shift) s.c = std::max<uint32_t>(bits, 4);
+  const bool is_signed = !in.scalars_u32;
+  if (is_signed && s.c < 2) s.c = 2;
+  s.W = bits ? ((is_signed ? bits + 1 : bits) + s.c - 1) / s.c : 0;
+  if (!in.n) s.W = 0;
+  s.sort_bits = is_signed ? s.c - 1 : s.c;
+  s.entries = derived ? 0 : (size_t)in.n * s.W;
+  s.buckets = (size_t)s.W << s.sort_bits;
+  return s;
+}
+}  // namespace
+
+// Which jobs of a chunk go into the SECOND half of a pipelined batch (empty: no split).  The first half's tails
+// (continuation levels, bucket reduction, window sums: ~0.5 ns per bucket of dependent curve additions on an under-filled
+// chip) run beside the second half's accumulation (~0.085 ns per entry at the multiplier's rate), the second half's tails
+// stay exposed: the jobs with the most entries per bucket go last, as many as it takes to cover the first half's tails.
+// A derived job goes where its parent goes.
+static std::vector<char> msm_pick_split(Ctx& c, const MsmJob* jobs, const std::vector<size_t>& idx, const std::vector<uint32_t>& bits,
+                                        const std::vector<char>& derived) {
+  const size_t nj = idx.size();
+  std::vector<char> second(nj, 0);
+  if (!c.opt.msm_half_batches || nj < 2) return {};
+  std::vector<size_t> E(nj), T(nj);
+  size_t Et = 0, Tt = 0;
+  for (size_t j = 0; j < nj; j++) {
+    const MsmShape s = msm_job_shape(jobs[idx[j]], bits[j], derived[j] != 0);
+    E[j] = s.entries, T[j] = s.buckets;
+    Et += E[j], Tt += T[j];
+  }
+  // derived jobs count with their parents
+  std::vector<long> parent(nj, -1);
+  for (size_t j = 0; j < nj; j++) {
+    if (!derived[j]) continue;
+    for (size_t p = 0; p < nj; p++)
+      if ((long)idx[p] == (long)jobs[idx[j]].derived_parent) parent[j] = (long)p;
+    if (parent[j] >= 0) T[parent[j]] += T[j], T[j] = 0;
+  }
+  static const size_t min_entries = (size_t)env_int("LH_MSM_HALF_MIN_LOG", 24);
+  static const int cover = env_int("LH_MSM_HALF_COVER", 12);  // entries of the second half per bucket of the first
+  if (Et < ((size_t)1 << min_entries) || Tt < ((size_t)1 << 17)) return {};
+  std::vector<size_t> order;
+  for (size_t j = 0; j < nj; j++)
+    if (parent[j] < 0 && E[j]) order.push_back(j);
+  std::sort(order.begin(), order.end(), [&](size_t a, size_t b) {
+    const double ra = (double)E[a] / (double)(T[a] + 1), rb = (double)E[b] / (double)(T[b] + 1);
+    return ra != rb ? ra > rb : a < b;
+  });
+  size_t Eb = 0, Tb = 0, taken = 0;
+  for (size_t j : order) {
+    if (Eb >= (size_t)cover * (Tt - Tb) || taken + 1 == order.size()) break;
+    second[j] = 1, Eb += E[j], Tb += T[j], taken++;
+  }
+  // worth it only when the first half has tails to hide and both halves still fill the chip
+  if (!taken || Tt - Tb < ((size_t)1 << 16) || Eb < ((size_t)1 << 22) || Et - Eb < ((size_t)1 << 20)) return {};
+  for (size_t j = 0; j < nj; j++)
+    if (parent[j] >= 0) second[j] = second[parent[j]];
+  return second;
+}
+
+// layout of one sub-batch: windows, key / segment / share ranges, entry positions (no device work)
+// (`whole`: the plan of the undivided batch this sub-batch is a half of - segment size, reduction form and entries per
+// accumulate thread are the batch's, not the half's: a half must not fall back to the latency-bound forms of a small batch)
+static void msm_plan_sub(Ctx& c, const MsmJob* jobs, MsmSub& s, const MsmSub* whole = nullptr) {
+  const size_t nj = s.idx.size();
+  MsmPlanDev& plan = s.plan;
+  plan.num_jobs = (int)nj;
+  plan.job_of_block = nullptr;
+  s.sort_bits.assign(nj, 0), s.slab.assign(nj, 0);
+  s.num_derived = 0;
+  for (size_t j = 0; j < nj; j++) s.num_derived += s.derived[j] ? 1 : 0;
+  // buckets per reduce thread: the segment kernel is a chain of 2 S additions plus a small-scalar multiplication
+  // per thread.  Few buckets in total = too few threads to fill the chip = pure latency: shorter segments then
+  // (S = 4: ~30 dependent curve operations instead of ~51); many buckets = throughput: S = 16 does least work.
+  uint32_t seg_size = 16;
+  {
+    size_t est = 0;
+    for (size_t j = 0; j < nj; j++) {
+      const MsmJob& in = jobs[s.idx[j]];
+      const uint32_t bits = s.bits[j];
+      if (!in.n || !bits) continue;
+      const uint32_t cw = pick_window(in.n, bits);
+      est += ((size_t)(bits + cw) / cw) << (in.scalars_u32 ? cw : cw - 1);
     }
-  } overlap_guard{overlap, overlap_done};
+    static const int forced = env_int("LH_MSM_SEG", 0);
+    seg_size = forced ? (uint32_t)forced : est <= ((size_t)1 << 18) ? 4u : est <= ((size_t)1 << 20) ? 8u : 16u;
+    if (whole) seg_size = whole->seg_size;
+    s.seg_size = seg_size;
+  }
+  uint32_t key = 0, seg = 0, win = 0;
+  // a job of >= 2^LH_MSM_SLAB_LOG points sorts each of its (window) slabs by the digit bits alone
+  static const int slab_log = msm_slab_log();
+  for (size_t j = 0; j < nj; j++) {
+    const MsmJob& in = jobs[s.idx[j]];
+    MsmJobDev& jd = plan.job[j];
+    const uint32_t bits = s.bits[j];
+    jd.scalars = in.scalars;
+    jd.is_u32 = in.scalars_u32 ? 1 : 0;
+    jd.n = (uint32_t)in.n;
+    jd.bases = in.bases;
+    if (s.derived[j]) jd.n = 0;  // emits no (point, window) entries: its buckets are filled from the parent's
+    jd.c = pick_window(in.n ? in.n : 1, bits ? bits : 1);
+    jd.pack_shift = 0;
+    if (in.pack_shift) {
+      LH_REQUIRE(in.scalars_u32 && in.out_second && in.pack_shift >= 4 && bits <= MSM_PACK_MAX_BITS && !s.derived[j],
+                 LH_ERR_ARG, "msm: bad packed job");
+      jd.pack_shift = in.pack_shift;
+      jd.c = std::max<uint32_t>(bits, 4);  // one window: the bucket index is the packed value
+    }
+    jd.is_signed = in.scalars_u32 ? 0 : 1;
+    if (jd.is_signed && jd.c < 2) jd.c = 2;
+    // signed digits need one extra bit of head room for the last carry
+    jd.W = bits ? ((jd.is_signed ? bits + 1 : bits) + jd.c - 1) / jd.c : 0;
+    if (!in.n) jd.W = 0;
+    // window table (MsmJob::win_table): the windows of the table's width share one bucket set
+    jd.merged = 0;
+    if (in.win_table && jd.is_signed && !s.derived[j] && in.n && in.win_table_c >= 2) {
+      const uint32_t Wt = (bits + 1 + in.win_table_c - 1) / in.win_table_c;
+      if (Wt >= 2 && Wt <= in.win_table_W && (size_t)Wt * in.n < ((size_t)1 << 31)) {
+        jd.merged = 1;
+        jd.c = in.win_table_c;
+        jd.W = Wt;
+        jd.bases = in.win_table;
+      }
+    }
+    // digit d > 0 lives in bucket d - 1: signed digits 1 .. 2^(c-1), unsigned 1 .. 2^c - 1
+    s.sort_bits[j] = jd.is_signed ? jd.c - 1 : jd.c;
+    const uint32_t nb = 1u << s.sort_bits[j];
+    jd.red_W = jd.pack_shift && jd.W ? 2 : jd.merged ? 1 : jd.W;
+    jd.seg_size = seg_size;
+    jd.seg_per_win = (nb + jd.seg_size - 1) / jd.seg_size;
+    jd.win_stride = jd.seg_per_win * jd.seg_size;
+    s.slab[j] = jd.n >= (1u << slab_log) && jd.W > 0 && nb >= jd.seg_size &&
+                s.sort_bits[j] <= (jd.pack_shift ? MSM_PACK_MAX_BITS : 16u);
+    jd.presorted = s.slab[j] && jd.W == 1 && in.scalars_u32 && in.sorted_scalars && in.sorted_index && !s.derived[j];
+    // a slab-sorted job's bucket ranges start at multiples of 2^sort_bits: the low bits of a key are the bucket index
+    const uint32_t align_bits = s.slab[j] ? std::max<uint32_t>(KEY_BLOCK_BITS, s.sort_bits[j]) : KEY_BLOCK_BITS;
+    key = (key + (1u << align_bits) - 1) & ~((1u << align_bits) - 1);
+    jd.key_base = key;
+    jd.seg_base = seg;
+    jd.win_base = win;
+    jd.two_level = 0, jd.grp_base = 0, jd.sum_per_win = jd.seg_per_win;  // (decided below, once the batch's size is known)
+    key += (jd.merged ? 1 : jd.W) * jd.win_stride;
+    seg += jd.red_W * jd.seg_per_win;
+    win += jd.red_W;
+    LH_REQUIRE(in.n < 0x7fffffffu, LH_ERR_ARG, "msm: too many points");
+    s.max_n = std::max(s.max_n, in.n);
+  }
+  // entry layout: the slabs of the small jobs first (one global sort), then the big jobs' slabs
+  s.max_entries = s.small_entries = 0;
+  for (int pass = 0; pass < 2; pass++)
+    for (size_t j = 0; j < nj; j++) {
+      if ((int)s.slab[j] != pass) continue;
+      plan.job[j].entry_base = (uint32_t)s.max_entries;
+      s.max_entries += (size_t)plan.job[j].n * plan.job[j].W;
+      LH_REQUIRE(s.max_entries < ((size_t)1 << 32), LH_ERR_ARG, "msm: batch too large for 32-bit entry indices");
+      if (!pass) s.small_entries = s.max_entries;
+    }
+  s.nbuckets = key, s.nsegs = seg, s.nwins = win;
+  if (getenv("LH_MSM_DEBUG"))
+    for (size_t j = 0; j < nj; j++)
+      fprintf(stderr, "[msm] job %zu n %u bits %u c %u W %u entries %zu%s%s%s%s\n", s.idx[j], plan.job[j].n, s.bits[j], plan.job[j].c,
+              plan.job[j].W, (size_t)plan.job[j].n * plan.job[j].W, plan.job[j].is_signed ? " fr" : " u32",
+              s.derived[j] ? " derived" : "", plan.job[j].merged ? " table" : "", plan.job[j].pack_shift ? " packed" : "");
+  // two-level reduction: throughput-bound batches (the plain segment kernel runs), jobs whose windows hold at least
+  // MSM_GROUP^2 segments, packed jobs only when a group never straddles a change of the high part
+  static const int two_level_on = env_int("LH_MSM_TWO_LEVEL", 1);
+  const bool plain_reduce = whole ? whole->plain_reduce : s.nsegs > (size_t)MSM_QUAD_MAX / 2;
+  s.plain_reduce = plain_reduce;
+  s.ngroups = 0;
+  for (size_t j = 0; j < nj; j++) {
+    MsmJobDev& jd = plan.job[j];
+    jd.grp_base = (uint32_t)s.ngroups;
+    const bool ok = two_level_on && plain_reduce && jd.red_W && jd.seg_size >= 2 && (jd.seg_size & (jd.seg_size - 1)) == 0 &&
+                    jd.seg_per_win >= MSM_GROUP * MSM_GROUP && jd.seg_per_win % MSM_GROUP == 0 &&
+                    (!jd.pack_shift || ((1u << jd.pack_shift) % (MSM_GROUP * jd.seg_size)) == 0);
+    if (!ok) continue;
+    jd.two_level = 1;
+    jd.sum_per_win = jd.seg_per_win / MSM_GROUP;
+    s.ngroups += (size_t)jd.red_W * jd.sum_per_win;
+  }
+  // window-sum shares: enough workgroups that no thread adds more than ~4 segment partials in sequence, few enough
+  // that the host's share of the additions stays in the microseconds
+  uint32_t nsplit = 1;
+  {
+    uint32_t max_spw = 1;
+    for (size_t j = 0; j < nj; j++)
+      if (plan.job[j].W && plan.job[j].sum_per_win < 16384) max_spw = std::max(max_spw, plan.job[j].sum_per_win);
+    while (nsplit < 32 && max_spw / nsplit > 1024 && s.nwins * nsplit * 2 <= 4096) nsplit *= 2;
+  }
+  s.nshares = 0;
+  for (size_t j = 0; j < nj; j++) {
+    MsmJobDev& jd = plan.job[j];
+    jd.nsplit = jd.sum_per_win >= 16384 ? std::max<uint32_t>(nsplit, 32u) : nsplit;
+    jd.share_base = s.nshares;
+    s.nshares += jd.red_W * jd.nsplit;
+  }
+  s.nblocks = (s.nbuckets >> KEY_BLOCK_BITS) + 1;
+  s.total_pts = s.full_pts = 0;
+  for (size_t j = 0; j < nj; j++) s.total_pts += plan.job[j].n, s.full_pts += plan.job[j].is_u32 ? 0 : plan.job[j].n;
+  // entries per accumulate thread: enough chunks to fill the chip, few enough that the continuation list stays small
+  // (measured: tools/msm_sweep.sh; 2^24 lookups 141 -> 132 ms with K 32 -> 128)
+  const size_t me = s.max_entries;
+  s.K = me > ((size_t)1 << 26) ? 128 : me > ((size_t)1 << 25) ? 64 : me > ((size_t)1 << 23) ? 32 : me > ((size_t)1 << 21) ? 16 : me > ((size_t)1 << 18) ? 8 : 4;
+  if (MSM_K > 0) s.K = (uint32_t)MSM_K;
+  if (whole) s.K = whole->K;
+  s.nchunks = (me + s.K - 1) / s.K;
+  s.wins.assign(s.nshares, G1Xyzz::identity());
+}
+
+// workspace of a sub-batch (the caller's ArenaScope owns it) and its share of the batch's pinned block
+static void msm_sub_alloc(Ctx& c, MsmSub& s, uint8_t* pin_at) {
+  s.ukey = c.arena.alloc_n<uint32_t>(s.max_entries);
+  s.uidx = c.arena.alloc_n<uint32_t>(s.max_entries);
+  // + 256: accumulate0 reads whole 16-byte groups up to the end of the last (padded) chunk
+  s.skey = c.arena.alloc_n<uint32_t>(s.max_entries + 256);
+  s.sidx = c.arena.alloc_n<uint32_t>(s.max_entries + 256);
+  s.buckets = c.arena.alloc_n<G1Xyzz>(s.nbuckets);
+  s.seg_out = c.arena.alloc_n<G1Xyzz>(s.nsegs);
+  s.seg_t = s.ngroups ? c.arena.alloc_n<G1Xyzz>(s.nsegs) : nullptr;   // T_s of the two-level jobs' segments
+  s.grp_out = s.ngroups ? c.arena.alloc_n<G1Xyzz>(s.ngroups) : nullptr;
+  s.lvl_cnt = c.arena.alloc_n<uint32_t>(64);
+  s.ckey = c.arena.alloc_n<uint32_t>(s.nchunks);
+  s.cpt = c.arena.alloc_n<G1Xyzz>(s.nchunks);
+  // pinned host memory: the window sums (written by the last kernel) followed by the key-block table staging
+  s.win_out = (G1Xyzz*)pin_at;
+  s.h_tab = pin_at + (size_t)s.nshares * sizeof(G1Xyzz);
+}
+
+// steps 1-2 on the ctx's stream: digits and sort
+static void msm_sub_entries(Ctx& c, const MsmJob* jobs, MsmSub& s) {
+  const size_t nj = s.idx.size();
+  MsmPlanDev& plan = s.plan;
+  {
+    for (size_t j = 0; j < nj; j++) {
+      const size_t b0 = plan.job[j].key_base >> KEY_BLOCK_BITS;
+      const size_t b1 = j + 1 < nj ? plan.job[j + 1].key_base >> KEY_BLOCK_BITS : s.nblocks;
+      for (size_t b = b0; b < b1; b++) s.h_tab[b] = (uint8_t)j;
+    }
+    uint8_t* d_tab = c.arena.alloc_n<uint8_t>(s.nblocks);
+    LH_HIP(hipMemcpyAsync(d_tab, s.h_tab, s.nblocks, hipMemcpyHostToDevice, c.stream));
+    plan.job_of_block = d_tab;
+  }
+  for (size_t j = 0; j < nj; j++) c.route.v[RouteStats::WIN_TABLE_JOBS] += plan.job[j].merged ? 1 : 0;
+  LH_HIP(hipMemsetAsync(s.lvl_cnt, 0, 64 * sizeof(uint32_t), c.stream));
+  LH_HIP(hipMemsetAsync(s.buckets, 0, s.nbuckets * sizeof(G1Xyzz), c.stream));
+  unsigned key_bits = 1;
+  while (((size_t)1 << key_bits) <= s.nbuckets) key_bits++;
+  {
+    ProfScope ps(c, "msm_digits", 32.0 * s.full_pts + 4.0 * (s.total_pts - s.full_pts) + 8.0 * s.max_entries, s.full_pts,
+                 s.total_pts);
+    dim3 g((unsigned)std::min<size_t>((s.max_n + 255) / 256, 2048), (unsigned)nj);
+    hipLaunchKernelGGL(msm_emit_kernel, g, dim3(256), 0, c.stream, plan, s.ukey, s.uidx);
+  }
+  {
+    ProfScope ps(c, "msm_sort", 32.0 * s.max_entries, 0, (double)s.max_entries);
+    // small jobs: one sort by the whole key; big jobs: every (job, window) slab by its digit bits only - all of them
+    // as ONE batch of the radix sort (sort.hip): three launches per pass for the whole MSM batch
+    std::vector<SortSlab> sorts;
+    if (s.small_entries) sorts.push_back(SortSlab{s.ukey, s.skey, s.uidx, s.sidx, s.small_entries, key_bits});
+    for (size_t j = 0; j < nj; j++) {
+      if (!s.slab[j]) continue;
+      const MsmJobDev& jd = plan.job[j];
+      if (jd.presorted) {
+        const MsmJob& in = jobs[s.idx[j]];
+        hipLaunchKernelGGL(msm_presorted_kernel, dim3((unsigned)std::min<size_t>((jd.n + 255) / 256, 4096)), dim3(256), 0,
+                           c.stream, jd.key_base, in.sorted_scalars, in.sorted_index, (size_t)jd.n, s.skey + jd.entry_base,
+                           s.sidx + jd.entry_base);
+        continue;
+      }
+      if (jd.merged) {  // one bucket set: the entries of all windows are one slab
+        const size_t e = jd.entry_base;
+        sorts.push_back(SortSlab{s.ukey + e, s.skey + e, s.uidx + e, s.sidx + e, (size_t)jd.n * jd.W, s.sort_bits[j]});
+        continue;
+      }
+      for (uint32_t w = 0; w < jd.W; w++) {
+        const size_t e = (size_t)jd.entry_base + (size_t)w * jd.n;
+        sorts.push_back(SortSlab{s.ukey + e, s.skey + e, s.uidx + e, s.sidx + e, jd.n, s.sort_bits[j]});
+      }
+    }
+    if (!sorts.empty()) sort_pairs_u32_batched(c, sorts.data(), sorts.size());
+  }
+}
+
+// step 3 on `stream`: level 0 of the segmented accumulation
+static void msm_sub_accumulate(Ctx& c, MsmSub& s, hipStream_t stream) {
+  MsmPlanDev& plan = s.plan;
+  {
+    // MSM algorithmic bytes: 96 B per point (32 B scalar + 64 B base), 68 B for a u32 column,
+    // whatever the number of windows; `items` = sorted (point, window) entries, a mixed add is 10 Fq muls
+    ProfScope ps(c, "msm_accumulate0", 96.0 * s.full_pts + 68.0 * (s.total_pts - s.full_pts), 10.0 * (double)s.max_entries, (double)s.max_entries);
+    // (a grid capped to the chip's resident workgroups - for a helper ctx, so that the owner's latency-bound kernels find
+    // wave slots, or for every ctx, persistent style - was measured in round 5 and bought nothing: profiles/README.md)
+    const size_t acc_grid = std::min<size_t>((s.nchunks + 127) / 128, 1 << 16);
+    hipLaunchKernelGGL(msm_accumulate0_kernel, dim3((unsigned)acc_grid), dim3(128), 0, stream, plan, s.max_entries, s.skey, s.sidx,
+                       s.K, s.buckets, s.ckey, s.cpt, s.nchunks, s.lvl_cnt);
+  }
+}
+
+// steps 4-5 on `stream` (the ctx's, or its aux stream beside the next half's front): continuation levels, derived jobs,
+// bucket reduction, window sums; the last workgroup publishes `fin.seq` to `fin.flag`
+static void msm_sub_tail(Ctx& c, const MsmJob* jobs, MsmSub& s, hipStream_t stream, const ScFinishArgs& fin) {
+  const size_t nj = s.idx.size();
+  MsmPlanDev& plan = s.plan;
+  {
+    ProfScope ps(c, "msm_accumulate_levels", 0, 0, (double)s.nchunks);
+    msm_continuation_levels(c, stream, s.ckey, s.cpt, s.nchunks, s.buckets, s.lvl_cnt);
+  }
+  if (s.num_derived) {
+    // derived jobs: (key, parent bucket) lists sorted by key, summed into the derived buckets by the same
+    // continuation levels (a run shrinks K2-fold per level)
+    MsmDerivedDev dd;
+    memset(&dd, 0, sizeof(dd));
+    for (size_t j = 0; j < nj; j++) {
+      if (!s.derived[j]) continue;
+      const MsmJob& in = jobs[s.idx[j]];
+      size_t p = nj;
+      for (size_t q = 0; q < nj; q++)
+        if ((long)s.idx[q] == (long)in.derived_parent) p = q;
+      LH_REQUIRE(p < nj, LH_ERR_ARG, "msm: a derived job lost its parent");
+      const uint32_t k = dd.count++;
+      dd.off[k + 1] = dd.off[k] + (1u << in.table_in_bits);
+      dd.key_base[k] = plan.job[j].key_base;
+      dd.parent_key_base[k] = plan.job[p].key_base;
+      dd.table[k] = in.d_table, dd.order[k] = in.d_order;
+    }
+    const size_t nd = dd.off[dd.count];
+    ProfScope ps(c, "msm_derived", 132.0 * nd, 14.0 * nd, (double)nd);
+    uint32_t* dkey = c.arena.alloc_n<uint32_t>(nd);
+    G1Xyzz* dpt = c.arena.alloc_n<G1Xyzz>(nd);
+    hipLaunchKernelGGL(msm_derived_gather_kernel, dim3((unsigned)std::min<size_t>((nd + 255) / 256, 1024)), dim3(256), 0,
+                       stream, dd, s.buckets, dkey, dpt);
+    uint32_t* dcnt = s.lvl_cnt + 32;
+    LH_HIP(hipMemsetAsync(dcnt, 1, sizeof(uint32_t), stream));  // "something continued into level 0"
+    msm_continuation_levels(c, stream, dkey, dpt, nd, s.buckets, dcnt);
+  }
+  {
+    ProfScope ps(c, "msm_bucket_reduce", 128.0 * s.nbuckets, 14.0 * 2.2 * s.nbuckets, (double)s.nbuckets);
+    if (!s.plain_reduce)
+      hipLaunchKernelGGL(msm_segment_reduce_quad_kernel, dim3((unsigned)((4 * s.nsegs + 63) / 64)), dim3(64), 0, stream,
+                         plan, s.buckets, s.seg_out, s.nsegs);
+    else
+      hipLaunchKernelGGL(msm_segment_reduce_kernel, dim3((unsigned)std::min<size_t>((s.nsegs + 63) / 64, 1 << 16)),
+                         dim3(64), 0, stream, plan, s.buckets, s.seg_out, s.seg_t, s.nsegs);
+    if (s.ngroups)
+      hipLaunchKernelGGL(msm_group_reduce_kernel, dim3((unsigned)std::min<size_t>((4 * s.ngroups + 63) / 64, 1 << 16)), dim3(64), 0,
+                         stream, plan, s.seg_out, s.seg_t, s.grp_out, s.ngroups);
+    hipLaunchKernelGGL(msm_window_sum_kernel, dim3(s.nshares), dim3(512), 0, stream, plan, s.seg_out, s.grp_out, s.win_out, fin);
+    if (c.prof) c.sync();
+  }
+}
+
+// step 6 on the host: sum_w 2^(c w) win[w] per job.  Jobs with doublings (~70 us of dependent doublings each) go to the
+// host pool, the others (one window, packed pairs: a few additions) are done here
+static void msm_sub_combine(MsmSub& s, std::vector<host::G1Xyzz>& sums /* [2 global job], [.. + 1]: out_second */) {
+  const size_t nj = s.idx.size();
+  const MsmPlanDev& plan = s.plan;
+  auto share_sum = [&](const MsmJobDev& jd, uint32_t w) {
+    host::G1Xyzz acc = host::G1Xyzz::identity();
+    for (uint32_t part = 0; part < jd.nsplit; part++)
+      acc = host::g1_add(acc, to_host(s.wins[(size_t)jd.share_base + (size_t)w * jd.nsplit + part]));
+    return acc;
+  };
+  std::vector<size_t> heavy;
+  for (size_t j = 0; j < nj; j++) {
+    const MsmJobDev& jd = plan.job[j];
+    if (jd.pack_shift) {  // the two "windows" are the two results
+      if (jd.red_W) sums[2 * s.idx[j]] = share_sum(jd, 0), sums[2 * s.idx[j] + 1] = share_sum(jd, 1);
+    } else if (jd.red_W <= 1 || jd.merged) {  // (a window table's job has one "window": no doublings)
+      if (jd.red_W) sums[2 * s.idx[j]] = share_sum(jd, 0);
+    } else {
+      heavy.push_back(j);
+    }
+  }
+  host_parallel_for(heavy.size(), [&](size_t k) {
+    const size_t j = heavy[k];
+    const MsmJobDev& jd = plan.job[j];
+    host::G1Xyzz acc = host::G1Xyzz::identity();
+    for (int w = (int)jd.red_W - 1; w >= 0; w--) {
+      for (uint32_t q = 0; q < jd.c; q++) acc = host::g1_dbl(acc);
+      acc = host::g1_add(acc, share_sum(jd, (uint32_t)w));
+    }
+    sums[2 * s.idx[j]] = acc;
+  });
+}
+
+bool msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, const std::function<void()>* overlap) {
+  bool overlap_done = overlap == nullptr;
+  bool waited = false;  // the host waited for the ctx's stream at least once (everything queued before the batch has run)
   for (size_t base = 0; base < num_jobs; base += MSM_MAX_JOBS) {
-    size_t nj = std::min(num_jobs - base, (size_t)MSM_MAX_JOBS);
-    MsmPlanDev plan;
-    plan.num_jobs = (int)nj;
+    const size_t nj = std::min(num_jobs - base, (size_t)MSM_MAX_JOBS);
     // significant bits of every column (one cheap pass)
     std::vector<uint32_t> job_bits(nj, 32);
     {
-      bool any_fr = false;
+      MsmPlanDev or_plan;  // (jobs whose width the caller promises take no part in the pass)
+      or_plan.num_jobs = (int)nj;
+      or_plan.job_of_block = nullptr;
+      bool any_fr = false, any_unknown = false;
       size_t max_n0 = 0;
       for (size_t j = 0; j < nj; j++) {
         const MsmJob& in = jobs[base + j];
         LH_REQUIRE(in.n < ((size_t)1 << 31), LH_ERR_ARG, "msm: too many points");
-        plan.job[j].scalars = in.scalars;
-        plan.job[j].is_u32 = in.scalars_u32 ? 1 : 0;
-        plan.job[j].n = (uint32_t)in.n;
+        memset(&or_plan.job[j], 0, sizeof(MsmJobDev));
+        or_plan.job[j].scalars = in.scalars;
+        or_plan.job[j].is_u32 = in.scalars_u32 ? 1 : 0;
+        or_plan.job[j].n = in.known_bits ? 0u : (uint32_t)in.n;
         any_fr |= in.n != 0;
+        any_unknown |= !in.known_bits && in.n != 0;
         max_n0 = std::max(max_n0, in.n);
-      }
-      bool any_unknown = false;
-      MsmPlanDev or_plan = plan;  // (jobs whose width the caller promises take no part in the pass)
-      for (size_t j = 0; j < nj; j++) {
-        if (jobs[base + j].known_bits) or_plan.job[j].n = 0;
-        else any_unknown |= jobs[base + j].n != 0;
       }
       if (any_fr && any_unknown) {
         ArenaScope scope(c.arena);
@@ -700,6 +1106,7 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, 
         uint32_t* h_or = (uint32_t*)c.pin(8 * MSM_MAX_JOBS * sizeof(uint32_t));
         LH_HIP(hipMemcpyAsync(h_or, d_or, 8 * nj * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
         c.sync();
+        waited = true;
         for (size_t j = 0; j < nj; j++) {
           uint32_t bits = 0;
           for (int k = 7; k >= 0 && !bits; k--)
@@ -728,330 +1135,112 @@ void msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, 
       job_bits[j] = std::min(job_bits[j], in.table_out_bits);  // (0 stays 0: an all-zero column)
       if (!job_bits[j] || pick_window(in.n, job_bits[j]) != job_bits[j]) derived[j] = 0, num_derived--;
     }
-    // buckets per reduce thread: the segment kernel is a chain of 2 S additions plus a small-scalar multiplication
-    // per thread.  Few buckets in total = too few threads to fill the chip = pure latency: shorter segments then
-    // (S = 4: ~30 dependent curve operations instead of ~51); many buckets = throughput: S = 16 does least work.
-    uint32_t seg_size = 16;
-    {
-      size_t est = 0;
-      for (size_t j = 0; j < nj; j++) {
-        const MsmJob& in = jobs[base + j];
-        const uint32_t bits = job_bits[j];
-        if (!in.n || !bits) continue;
-        const uint32_t cw = pick_window(in.n, bits);
-        est += ((size_t)(bits + cw) / cw) << (in.scalars_u32 ? cw : cw - 1);
-      }
-      static const int forced = env_int("LH_MSM_SEG", 0);
-      seg_size = forced ? (uint32_t)forced : est <= ((size_t)1 << 18) ? 4u : est <= ((size_t)1 << 20) ? 8u : 16u;
-    }
-    uint32_t key = 0, seg = 0, win = 0;
-    size_t max_entries = 0, max_n = 0;
-    // a job of >= 2^LH_MSM_SLAB_LOG points sorts each of its (window) slabs by the digit bits alone
-    static const int slab_log = msm_slab_log();
-    std::vector<char> slab(nj, 0);
-    std::vector<uint32_t> sort_bits(nj, 0);
+    // one sub-batch, or two halves that run as a pipeline (msm_pick_split)
+    std::vector<size_t> all(nj);
+    for (size_t j = 0; j < nj; j++) all[j] = base + j;
+    const std::vector<char> second = msm_pick_split(c, jobs, all, job_bits, derived);
+    std::vector<MsmSub> subs(second.empty() ? 1 : 2);
     for (size_t j = 0; j < nj; j++) {
-      const MsmJob& in = jobs[base + j];
-      MsmJobDev& jd = plan.job[j];
-      uint32_t bits = job_bits[j];
-      jd.bases = in.bases;
-      if (derived[j]) jd.n = 0;  // emits no (point, window) entries: its buckets are filled from the parent's
-      jd.c = pick_window(in.n ? in.n : 1, bits ? bits : 1);
-      jd.pack_shift = 0;
-      if (in.pack_shift) {
-        LH_REQUIRE(in.scalars_u32 && in.out_second && in.pack_shift >= 4 && bits <= MSM_PACK_MAX_BITS && !derived[j],
-                   LH_ERR_ARG, "msm: bad packed job");
-        jd.pack_shift = in.pack_shift;
-        jd.c = std::max<uint32_t>(bits, 4);  // one window: the bucket index is the packed value
-      }
-      jd.is_signed = in.scalars_u32 ? 0 : 1;
-      if (jd.is_signed && jd.c < 2) jd.c = 2;
-      // signed digits need one extra bit of head room for the last carry
-      jd.W = bits ? ((jd.is_signed ? bits + 1 : bits) + jd.c - 1) / jd.c : 0;
-      if (!in.n) jd.W = 0;
-      // window table (MsmJob::win_table): the windows of the table's width share one bucket set
-      jd.merged = 0;
-      if (in.win_table && jd.is_signed && !derived[j] && in.n && in.win_table_c >= 2) {
-        const uint32_t Wt = (bits + 1 + in.win_table_c - 1) / in.win_table_c;
-        if (Wt >= 2 && Wt <= in.win_table_W && (size_t)Wt * in.n < ((size_t)1 << 31)) {
-          jd.merged = 1;
-          c.route.v[RouteStats::WIN_TABLE_JOBS]++;
-          jd.c = in.win_table_c;
-          jd.W = Wt;
-          jd.bases = in.win_table;
-        }
-      }
-      // digit d > 0 lives in bucket d - 1: signed digits 1 .. 2^(c-1), unsigned 1 .. 2^c - 1
-      sort_bits[j] = jd.is_signed ? jd.c - 1 : jd.c;
-      const uint32_t nb = 1u << sort_bits[j];
-      jd.red_W = jd.pack_shift && jd.W ? 2 : jd.merged ? 1 : jd.W;
-      jd.seg_size = seg_size;
-      jd.seg_per_win = (nb + jd.seg_size - 1) / jd.seg_size;
-      jd.win_stride = jd.seg_per_win * jd.seg_size;
-      slab[j] = jd.n >= (1u << slab_log) && jd.W > 0 && nb >= jd.seg_size &&
-                sort_bits[j] <= (jd.pack_shift ? MSM_PACK_MAX_BITS : 16u);
-      jd.presorted = slab[j] && jd.W == 1 && in.scalars_u32 && in.sorted_scalars && in.sorted_index && !derived[j];
-      // a slab-sorted job's bucket ranges start at multiples of 2^sort_bits: the low bits of a key are the bucket index
-      const uint32_t align_bits = slab[j] ? std::max<uint32_t>(KEY_BLOCK_BITS, sort_bits[j]) : KEY_BLOCK_BITS;
-      key = (key + (1u << align_bits) - 1) & ~((1u << align_bits) - 1);
-      jd.key_base = key;
-      jd.seg_base = seg;
-      jd.win_base = win;
-      jd.two_level = 0, jd.grp_base = 0, jd.sum_per_win = jd.seg_per_win;  // (decided below, once the batch's size is known)
-      key += (jd.merged ? 1 : jd.W) * jd.win_stride;
-      seg += jd.red_W * jd.seg_per_win;
-      win += jd.red_W;
-      LH_REQUIRE(in.n < 0x7fffffffu, LH_ERR_ARG, "msm: too many points");
-      max_n = std::max(max_n, in.n);
+      MsmSub& s = subs[second.empty() ? 0 : (size_t)second[j]];
+      s.idx.push_back(base + j), s.bits.push_back(job_bits[j]), s.derived.push_back(derived[j]);
     }
-    // entry layout: the slabs of the small jobs first (one global sort), then the big jobs' slabs
-    size_t small_entries = 0;
-    for (int pass = 0; pass < 2; pass++)
-      for (size_t j = 0; j < nj; j++) {
-        if ((int)slab[j] != pass) continue;
-        plan.job[j].entry_base = (uint32_t)max_entries;
-        max_entries += (size_t)plan.job[j].n * plan.job[j].W;
-        LH_REQUIRE(max_entries < ((size_t)1 << 32), LH_ERR_ARG, "msm: batch too large for 32-bit entry indices");
-        if (!pass) small_entries = max_entries;
-      }
-    const size_t nbuckets = key, nsegs = seg, nwins = win;
-    if (getenv("LH_MSM_DEBUG"))
-      for (size_t j = 0; j < nj; j++)
-        fprintf(stderr, "[msm] job %zu n %u bits %u c %u W %u entries %zu%s%s%s%s\n", j, plan.job[j].n, job_bits[j], plan.job[j].c,
-                plan.job[j].W, (size_t)plan.job[j].n * plan.job[j].W, plan.job[j].is_signed ? " fr" : " u32",
-                derived[j] ? " derived" : "", plan.job[j].merged ? " table" : "", plan.job[j].pack_shift ? " packed" : "");
-    // two-level reduction: throughput-bound batches (the plain segment kernel runs), jobs whose windows hold at least
-    // MSM_GROUP^2 segments, packed jobs only when a group never straddles a change of the high part
-    static const int two_level_on = env_int("LH_MSM_TWO_LEVEL", 1);
-    const bool plain_reduce = nsegs > (size_t)MSM_QUAD_MAX / 2;
-    size_t ngroups = 0;
-    for (size_t j = 0; j < nj; j++) {
-      MsmJobDev& jd = plan.job[j];
-      jd.grp_base = (uint32_t)ngroups;
-      const bool ok = two_level_on && plain_reduce && jd.red_W && jd.seg_size >= 2 && (jd.seg_size & (jd.seg_size - 1)) == 0 &&
-                      jd.seg_per_win >= MSM_GROUP * MSM_GROUP && jd.seg_per_win % MSM_GROUP == 0 &&
-                      (!jd.pack_shift || ((1u << jd.pack_shift) % (MSM_GROUP * jd.seg_size)) == 0);
-      if (!ok) continue;
-      jd.two_level = 1;
-      jd.sum_per_win = jd.seg_per_win / MSM_GROUP;
-      ngroups += (size_t)jd.red_W * jd.sum_per_win;
+    size_t total_entries = 0, pin_total = 0;
+    MsmSub whole;
+    if (subs.size() == 2) {
+      whole.idx = all, whole.bits = job_bits, whole.derived = derived;
+      msm_plan_sub(c, jobs, whole);
     }
-    // window-sum shares: enough workgroups that no thread adds more than ~4 segment partials in sequence, few enough
-    // that the host's share of the additions stays in the microseconds
-    uint32_t nsplit = 1;
-    {
-      uint32_t max_spw = 1;
-      for (size_t j = 0; j < nj; j++)
-        if (plan.job[j].W && plan.job[j].sum_per_win < 16384) max_spw = std::max(max_spw, plan.job[j].sum_per_win);
-      while (nsplit < 32 && max_spw / nsplit > 1024 && nwins * nsplit * 2 <= 4096) nsplit *= 2;
+    static const int last_own = env_int("LH_MSM_HALF_LAST_OWN", 0);  // 1: the second half picks its forms by its own size
+    for (MsmSub& s : subs) {
+      msm_plan_sub(c, jobs, s, subs.size() == 2 && !(last_own && &s == &subs[1]) ? &whole : nullptr);
+      total_entries += s.max_entries, pin_total += s.pin_bytes();
     }
-    uint32_t nshares = 0;
-    for (size_t j = 0; j < nj; j++) {
-      MsmJobDev& jd = plan.job[j];
-      jd.nsplit = jd.sum_per_win >= 16384 ? std::max<uint32_t>(nsplit, 32u) : nsplit;
-      jd.share_base = nshares;
-      nshares += jd.red_W * jd.nsplit;
-    }
-    std::vector<G1Xyzz> wins(nshares);
-    if (max_entries == 0) {
+    if (total_entries == 0) {
       for (size_t j = 0; j < nj; j++) {
         memset(&out_host[base + j], 0, sizeof(G1Affine));
         if (jobs[base + j].out_second) memset(jobs[base + j].out_second, 0, sizeof(G1Affine));
       }
       continue;
     }
+    if (subs.size() == 2 && (!subs[0].max_entries || !subs[1].max_entries)) {  // (cannot happen with msm_pick_split's floors)
+      subs.assign(1, whole);
+      pin_total = subs[0].pin_bytes();
+    }
     {
       ArenaScope scope(c.arena);
-      uint32_t* ukey = c.arena.alloc_n<uint32_t>(max_entries);
-      uint32_t* uidx = c.arena.alloc_n<uint32_t>(max_entries);
-      // + 256: accumulate0 reads whole 16-byte groups up to the end of the last (padded) chunk
-      uint32_t* skey = c.arena.alloc_n<uint32_t>(max_entries + 256);
-      uint32_t* sidx = c.arena.alloc_n<uint32_t>(max_entries + 256);
-      G1Xyzz* buckets = c.arena.alloc_n<G1Xyzz>(nbuckets);
-      G1Xyzz* seg_out = c.arena.alloc_n<G1Xyzz>(nsegs);
-      G1Xyzz* seg_t = ngroups ? c.arena.alloc_n<G1Xyzz>(nsegs) : nullptr;   // T_s of the two-level jobs' segments
-      G1Xyzz* grp_out = ngroups ? c.arena.alloc_n<G1Xyzz>(ngroups) : nullptr;
-      // pinned host memory: the window sums (written by the last kernel) followed by the key-block table staging
-      const size_t nblocks = (nbuckets >> KEY_BLOCK_BITS) + 1;
-      uint8_t* pin_base = (uint8_t*)c.pin(nshares * sizeof(G1Xyzz) + nblocks);
-      G1Xyzz* win_out = (G1Xyzz*)pin_base;
-      uint32_t* lvl_cnt = c.arena.alloc_n<uint32_t>(64);
-      {
-        uint8_t* h_tab = pin_base + nshares * sizeof(G1Xyzz);
-        for (size_t j = 0; j < nj; j++) {
-          const size_t b0 = plan.job[j].key_base >> KEY_BLOCK_BITS;
-          const size_t b1 = j + 1 < nj ? plan.job[j + 1].key_base >> KEY_BLOCK_BITS : nblocks;
-          for (size_t b = b0; b < b1; b++) h_tab[b] = (uint8_t)j;
+      uint8_t* pin_base = (uint8_t*)c.pin(pin_total);
+      for (MsmSub& s : subs) {
+        msm_sub_alloc(c, s, pin_base);
+        pin_base += s.pin_bytes();
+      }
+      const bool piped = subs.size() == 2;
+      uint32_t seq_aux = 0;
+      if (piped) {
+        // both halves' entry streams on the ctx's stream; then the first half's accumulation and tails on the aux stream (the
+        // higher priority: its workgroups are dispatched first) and the second half's on the ctx's stream - the second
+        // accumulation fills the chip as the first drains (two launches on one stream would each pay their own drain) and
+        // goes on beside the first half's tails.  Under the profiler: one stream, the same launches one after the other.
+        c.route.v[RouteStats::MSM_HALF_BATCHES]++;
+        msm_sub_entries(c, jobs, subs[0]);
+        msm_sub_entries(c, jobs, subs[1]);
+        hipStream_t side = c.stream;
+        if (!c.prof) {
+          c.aux_streams();
+          LH_HIP(hipEventRecord(c.aux_ev, c.stream));
+          LH_HIP(hipStreamWaitEvent(c.aux_stream, c.aux_ev, 0));
+          side = c.aux_stream;
         }
-        uint8_t* d_tab = c.arena.alloc_n<uint8_t>(nblocks);
-        LH_HIP(hipMemcpyAsync(d_tab, h_tab, nblocks, hipMemcpyHostToDevice, c.stream));
-        plan.job_of_block = d_tab;
+        seq_aux = c.next_seq();
+        msm_sub_accumulate(c, subs[0], side);
+        msm_sub_tail(c, jobs, subs[0], side, c.finish_for_aux(subs[0].nshares, seq_aux));
+      } else {
+        msm_sub_entries(c, jobs, subs[0]);
       }
-      LH_HIP(hipMemsetAsync(lvl_cnt, 0, 64 * sizeof(uint32_t), c.stream));
-      LH_HIP(hipMemsetAsync(buckets, 0, nbuckets * sizeof(G1Xyzz), c.stream));
-      double total_pts = 0, full_pts = 0;
-      for (size_t j = 0; j < nj; j++) total_pts += plan.job[j].n, full_pts += plan.job[j].is_u32 ? 0 : plan.job[j].n;
-      unsigned key_bits = 1;
-      while (((size_t)1 << key_bits) <= nbuckets) key_bits++;
-      {
-        ProfScope ps(c, "msm_digits", 32.0 * full_pts + 4.0 * (total_pts - full_pts) + 8.0 * max_entries, full_pts,
-                     total_pts);
-        dim3 g((unsigned)std::min<size_t>((max_n + 255) / 256, 2048), (unsigned)nj);
-        hipLaunchKernelGGL(msm_emit_kernel, g, dim3(256), 0, c.stream, plan, ukey, uidx);
-      }
-      {
-        ProfScope ps(c, "msm_sort", 32.0 * max_entries, 0, (double)max_entries);
-        // small jobs: one sort by the whole key; big jobs: every (job, window) slab by its digit bits only - all of them
-        // as ONE batch of the radix sort (sort.hip): three launches per pass for the whole MSM batch
-        std::vector<SortSlab> sorts;
-        if (small_entries) sorts.push_back(SortSlab{ukey, skey, uidx, sidx, small_entries, key_bits});
-        for (size_t j = 0; j < nj; j++) {
-          if (!slab[j]) continue;
-          const MsmJobDev& jd = plan.job[j];
-          if (jd.presorted) {
-            const MsmJob& in = jobs[base + j];
-            hipLaunchKernelGGL(msm_presorted_kernel, dim3((unsigned)std::min<size_t>((jd.n + 255) / 256, 4096)), dim3(256), 0,
-                               c.stream, jd.key_base, in.sorted_scalars, in.sorted_index, (size_t)jd.n, skey + jd.entry_base,
-                               sidx + jd.entry_base);
-            continue;
-          }
-          if (jd.merged) {  // one bucket set: the entries of all windows are one slab
-            const size_t e = jd.entry_base;
-            sorts.push_back(SortSlab{ukey + e, skey + e, uidx + e, sidx + e, (size_t)jd.n * jd.W, sort_bits[j]});
-            continue;
-          }
-          for (uint32_t w = 0; w < jd.W; w++) {
-            const size_t e = (size_t)jd.entry_base + (size_t)w * jd.n;
-            sorts.push_back(SortSlab{ukey + e, skey + e, uidx + e, sidx + e, jd.n, sort_bits[j]});
-          }
-        }
-        if (!sorts.empty()) sort_pairs_u32_batched(c, sorts.data(), sorts.size());
-      }
-
-      // segmented accumulate, level 0 then K-fold shrinking continuation lists
-      // entries per thread: enough chunks to fill the chip, few enough that the continuation list stays small
-      // (measured: tools/msm_sweep.sh; 2^24 lookups 141 -> 132 ms with K 32 -> 128)
-      uint32_t K = max_entries > ((size_t)1 << 26) ? 128 : max_entries > ((size_t)1 << 25) ? 64 : max_entries > ((size_t)1 << 23) ? 32 : max_entries > ((size_t)1 << 21) ? 16 : max_entries > ((size_t)1 << 18) ? 8 : 4;
-      if (MSM_K > 0) K = (uint32_t)MSM_K;
-      size_t nchunks = (max_entries + K - 1) / K;
-      uint32_t* ckey = c.arena.alloc_n<uint32_t>(nchunks);
-      G1Xyzz* cpt = c.arena.alloc_n<G1Xyzz>(nchunks);
-      const size_t h_total = max_entries;  // (point, window) entries, zero digits included
-      {
-        // MSM algorithmic bytes: 96 B per point (32 B scalar + 64 B base), 68 B for a u32 column,
-        // whatever the number of windows; `items` = sorted (point, window) entries, a mixed add is 10 Fq muls
-        ProfScope ps(c, "msm_accumulate0", 96.0 * full_pts + 68.0 * (total_pts - full_pts), 10.0 * h_total, (double)h_total);
-      // (a grid capped to the chip's resident workgroups - for a helper ctx, so that the owner's latency-bound kernels find
-      // wave slots, or for every ctx, persistent style - was measured in round 5 and bought nothing: profiles/README.md)
-      const size_t acc_grid = std::min<size_t>((nchunks + 127) / 128, 1 << 16);
-      hipLaunchKernelGGL(msm_accumulate0_kernel, dim3((unsigned)acc_grid), dim3(128), 0,
-                         c.stream, plan, max_entries, skey, sidx, K, buckets, ckey, cpt, nchunks, lvl_cnt);
-      }
-      {
-        ProfScope ps(c, "msm_accumulate_levels", 0, 0, (double)nchunks);
-        msm_continuation_levels(c, ckey, cpt, nchunks, buckets, lvl_cnt);
-      }
-      if (num_derived) {
-        // derived jobs: (key, parent bucket) lists sorted by key, summed into the derived buckets by the same
-        // continuation levels (a run shrinks K2-fold per level)
-        MsmDerivedDev dd;
-        memset(&dd, 0, sizeof(dd));
-        for (size_t j = 0; j < nj; j++) {
-          if (!derived[j]) continue;
-          const MsmJob& in = jobs[base + j];
-          const uint32_t k = dd.count++;
-          dd.off[k + 1] = dd.off[k] + (1u << in.table_in_bits);
-          dd.key_base[k] = plan.job[j].key_base;
-          dd.parent_key_base[k] = plan.job[(size_t)in.derived_parent - base].key_base;
-          dd.table[k] = in.d_table, dd.order[k] = in.d_order;
-        }
-        const size_t nd = dd.off[dd.count];
-        ProfScope ps(c, "msm_derived", 132.0 * nd, 14.0 * nd, (double)nd);
-        uint32_t* dkey = c.arena.alloc_n<uint32_t>(nd);
-        G1Xyzz* dpt = c.arena.alloc_n<G1Xyzz>(nd);
-        hipLaunchKernelGGL(msm_derived_gather_kernel, dim3((unsigned)std::min<size_t>((nd + 255) / 256, 1024)), dim3(256), 0,
-                           c.stream, dd, buckets, dkey, dpt);
-        uint32_t* dcnt = lvl_cnt + 32;
-        LH_HIP(hipMemsetAsync(dcnt, 1, sizeof(uint32_t), c.stream));  // "something continued into level 0"
-        msm_continuation_levels(c, dkey, dpt, nd, buckets, dcnt);
-      }
-      {
-        ProfScope ps(c, "msm_bucket_reduce", 128.0 * nbuckets, 14.0 * 2.2 * nbuckets, (double)nbuckets);
-      if (nsegs <= (size_t)MSM_QUAD_MAX / 2)
-        hipLaunchKernelGGL(msm_segment_reduce_quad_kernel, dim3((unsigned)((4 * nsegs + 63) / 64)), dim3(64), 0, c.stream,
-                           plan, buckets, seg_out, nsegs);
-      else
-        hipLaunchKernelGGL(msm_segment_reduce_kernel, dim3((unsigned)std::min<size_t>((nsegs + 63) / 64, 1 << 16)),
-                           dim3(64), 0, c.stream, plan, buckets, seg_out, seg_t, nsegs);
-      if (ngroups)
-        hipLaunchKernelGGL(msm_group_reduce_kernel, dim3((unsigned)std::min<size_t>((4 * ngroups + 63) / 64, 1 << 16)), dim3(64), 0,
-                           c.stream, plan, seg_out, seg_t, grp_out, ngroups);
+      MsmSub& last = subs.back();
+      msm_sub_accumulate(c, last, c.stream);
       const uint32_t seq = c.next_seq();
-      const ScFinishArgs fin = c.finish_for(nshares, nullptr, seq);
-      hipLaunchKernelGGL(msm_window_sum_kernel, dim3(nshares), dim3(512), 0, c.stream, plan, seg_out, grp_out, win_out, fin);
+      msm_sub_tail(c, jobs, last, c.stream, c.finish_for(last.nshares, nullptr, seq));
       if (!overlap_done) overlap_done = true, (*overlap)();  // (the device is busy with this batch: the caller's host work now)
       {
         // the window combines follow when the device is through: workers awake and polling by then (batches of up to a few
         // milliseconds; a longer one lets them sleep again and pays the wake-up, which then no longer matters)
         size_t heavy_jobs = 0;
-        for (size_t j = 0; j < nj; j++) heavy_jobs += plan.job[j].red_W > 1 && !plan.job[j].pack_shift && !plan.job[j].merged;
+        for (const MsmSub& s : subs)
+          for (size_t j = 0; j < s.idx.size(); j++) heavy_jobs += s.plan.job[j].red_W > 1 && !s.plan.job[j].pack_shift && !s.plan.job[j].merged;
         if (heavy_jobs > 1 && !c.prof) host_parallel_prewake(heavy_jobs, 4000);
       }
-      if (c.prof) c.sync();
       c.host_stamp("msm:queued");
+      if (piped) c.wait_flag_aux(seq_aux);
       c.wait_flag(seq);
+      waited = true;
       c.host_stamp("msm:window_sums");
-      }
-      if (getenv("LH_MSM_DEBUG")) {
-        uint32_t h_cnt[16];
-        c.d2h(h_cnt, lvl_cnt, sizeof(h_cnt));
-        fprintf(stderr, "[msm] jobs %zu entries %zu K %u nchunks %zu buckets %zu | continuation counts:", nj, max_entries, K,
-                nchunks, nbuckets);
-        for (int i = 0; i < 10; i++) fprintf(stderr, " %u", h_cnt[i]);
-        fprintf(stderr, "\n");
-      }
-      memcpy(wins.data(), win_out, nshares * sizeof(G1Xyzz));
-    }
-    // 6: host combine  sum_w 2^(c*w) * win[w]  and normalise.  Jobs with doublings (~70 us of dependent doublings each)
-    // go to the host pool, the others (one window, packed pairs: a few additions) are done here; ONE inversion
-    // normalises every result of the batch (an inversion per job was ~10 us each, and a job's worth of wake-up for the
-    // pool when no job needed it)
-    std::vector<host::G1Xyzz> sums(2 * nj, host::G1Xyzz::identity());  // [2 j]: out[j], [2 j + 1]: out_second of a packed job
-    auto share_sum = [&](const MsmJobDev& jd, uint32_t w) {
-      host::G1Xyzz acc = host::G1Xyzz::identity();
-      for (uint32_t part = 0; part < jd.nsplit; part++)
-        acc = host::g1_add(acc, to_host(wins[(size_t)jd.share_base + (size_t)w * jd.nsplit + part]));
-      return acc;
-    };
-    std::vector<size_t> heavy;
-    for (size_t j = 0; j < nj; j++) {
-      const MsmJobDev& jd = plan.job[j];
-      if (jd.pack_shift) {  // the two "windows" are the two results
-        if (jd.red_W) sums[2 * j] = share_sum(jd, 0), sums[2 * j + 1] = share_sum(jd, 1);
-      } else if (jd.red_W <= 1 || jd.merged) {  // (a window table's job has one "window": no doublings)
-        if (jd.red_W) sums[2 * j] = share_sum(jd, 0);
-      } else {
-        heavy.push_back(j);
+      for (MsmSub& s : subs) {
+        if (getenv("LH_MSM_DEBUG")) {
+          uint32_t h_cnt[16];
+          c.d2h(h_cnt, s.lvl_cnt, sizeof(h_cnt));
+          fprintf(stderr, "[msm] jobs %zu entries %zu K %u nchunks %zu buckets %zu%s | continuation counts:", s.idx.size(), s.max_entries,
+                  s.K, s.nchunks, s.nbuckets, piped ? (&s == &subs[0] ? " (first half)" : " (second half)") : "");
+          for (int i = 0; i < 10; i++) fprintf(stderr, " %u", h_cnt[i]);
+          fprintf(stderr, "\n");
+        }
+        memcpy(s.wins.data(), s.win_out, (size_t)s.nshares * sizeof(G1Xyzz));
       }
     }
-    host_parallel_for(heavy.size(), [&](size_t k) {
-      const size_t j = heavy[k];
-      const MsmJobDev& jd = plan.job[j];
-      host::G1Xyzz acc = host::G1Xyzz::identity();
-      for (int w = (int)jd.red_W - 1; w >= 0; w--) {
-        for (uint32_t q = 0; q < jd.c; q++) acc = host::g1_dbl(acc);
-        acc = host::g1_add(acc, share_sum(jd, (uint32_t)w));
-      }
-      sums[2 * j] = acc;
-    });
+    // 6: host combine and normalise: ONE inversion for every result of the batch (an inversion per job was ~10 us each, and a
+    // job's worth of wake-up for the pool when no job needed it)
+    std::vector<host::G1Xyzz> sums_all(2 * num_jobs, host::G1Xyzz::identity());
+    for (MsmSub& s : subs) msm_sub_combine(s, sums_all);
     std::vector<host::G1Affine> aff(2 * nj);
-    host::g1_batch_to_affine(sums.data(), 2 * nj, aff.data());
+    host::g1_batch_to_affine(sums_all.data() + 2 * base, 2 * nj, aff.data());
     for (size_t j = 0; j < nj; j++) {
       memcpy(&out_host[base + j], &aff[2 * j], sizeof(G1Affine));
-      if (plan.job[j].pack_shift) memcpy(jobs[base + j].out_second, &aff[2 * j + 1], sizeof(G1Affine));
+      if (jobs[base + j].pack_shift) memcpy(jobs[base + j].out_second, &aff[2 * j + 1], sizeof(G1Affine));
     }
     c.host_stamp("msm:combined");
   }
+  // (a batch without entries still owes the caller its host work)
+  if (!overlap_done) (*overlap)();
+  return waited;
 }
 
 // ------------------------------------------------------------------ window tables (MsmJob::win_table)

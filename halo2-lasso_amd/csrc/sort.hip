@@ -355,7 +355,7 @@ void rs_sort_batch(Ctx& c, const RsJob* slabs, size_t count, void* temp) {
 void sort_pairs_u32_batched(Ctx& c, const SortSlab* slabs, size_t count) {
   std::vector<RsJob> jobs(count);
   for (size_t i = 0; i < count; i++)
-    jobs[i] = RsJob{slabs[i].keys_in, slabs[i].keys_out, slabs[i].vals_in, slabs[i].vals_out, slabs[i].n, slabs[i].bits};
+    jobs[i] = RsJob{slabs[i].keys_in, slabs[i].keys_out, slabs[i].vals_in, slabs[i].vals_out, slabs[i].n, slabs[i].bits, slabs[i].first_bit};
   void* temp = c.arena.alloc(rs_batch_bytes(jobs.data(), count, 4));  // caller's ArenaScope releases it
   rs_sort_batch<uint32_t>(c, jobs.data(), count, temp);
 }

@@ -832,7 +832,7 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
         }
         g.eq_level = ef.eqs[0].level[round];
         g.rchal = r;
-        const bool fold = bind && c.opt.sc_pp_fold != 0;  // the first binding round folds cs and k into the tables
+        const bool fold = bind && c.opt.sc_pp_fold == 1;  // the first binding round folds cs and k into the tables
         k_sc_round_rw(c, g, bind, size, out_host, fold);
         if (fold) {
           rw_folded = true;
@@ -856,7 +856,7 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
         g.global_eq = -1;
         g.eq_level = ef.eqs[0].level[round];
         g.pp = pp_shape && points == 2 ? 1 : 0;
-        if (g.pp && bind && pp_folded.empty()) g.pp = 2;  // this round stores l'_m = c_m l_m
+        if (g.pp && bind && pp_folded.empty() && c.opt.sc_pp_fold == 1) g.pp = 2;  // this round stores l'_m = c_m l_m
         k_sc_round(c, g, points, bind, size, out_host);
         if (g.pp == 2 && c.last_round_folded) {  // (the launch that was chosen for this size did fold)
           pp_folded.resize(rd.num_terms);

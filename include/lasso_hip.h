@@ -267,6 +267,10 @@ lh_status lh_lasso_last_timing(lh_ctx*, double* out_ms);
  *                             base, W-fold the level's memory): the W windows of a full-width column then fill ONE
  *                             bucket set - one bucket reduction, no doublings.  Measured neutral at 2^24 lookups (shorter
  *                             reduction, longer bucket runs): off by default
+ *   msm_half_batches     1    an MSM batch of >= 2^24 (point, window) entries runs as two halves: the latency-bound tails of
+ *                             the first half (continuation levels, bucket reduction, window sums) run on a second stream of
+ *                             the ctx beside the second half's bucket accumulation; the jobs with the most entries per
+ *                             bucket go last (csrc/msm.hip msm_pick_split).  0: one batch on one stream
  *   gkr_resident         1    the layers near the roots of a grand-product argument (tables of <= 2^14 entries, <= 16 trees)
  *                             run in ONE resident launch - layer loop, eq tables, rounds and final evaluations inside the
  *                             kernel (kernels_gkr.hip); 0: one sum-check per layer (eq kernels, launched rounds, a resident
@@ -276,6 +280,8 @@ lh_status lh_lasso_last_timing(lh_ctx*, double* out_ms);
  *                             binding round folds c_m into l_m (sc_round_pp_kernel); the leaf layers of the lookup-sized
  *                             trees, sum_p cs_p (l_p + k_p)(r_p + k_p), store cs_p (l_p + k_p) and r_p + k_p at their first
  *                             bind and go on as such rounds; 0: sc_round_e2_kernel / sc_round_rw_kernel in every round
+ *                             2: the product-pair kernel in every streaming round of the generic layers WITHOUT the fold
+ *                             (the coefficients are applied to the lane's value, the tables stay as they are; a test shape)
  *   comm_round           0    how the partial sums of a sharded sum-check round are combined over the ranks:
  *                             0 = ncclAllGather of every rank's sums + a one-thread sum-and-publish kernel;
  *                             1 = ONE collective: the round kernel leaves its sums as u64 lanes (32-bit limb | tag << 40),
@@ -306,8 +312,8 @@ typedef struct lh_lasso_route {
   uint32_t open_precommit;      /* 1: the opening's column-wise commitments were taken from the helper ctx (open_precommit) */
   uint32_t resident_layers;     /* grand-product layers that ran inside the resident multi-layer kernel (gkr_resident) */
   uint32_t pp_folds;            /* sum-checks whose batching coefficients were folded into the left factors (sc_pp_fold) */
-  uint32_t msm29_batches;       /* reserved, always 0 (round 4's 9 x 29-bit bucket accumulation - measured slower inside the
-                                   kernel - left the library in round 5; tools/ubench/mul29.hip keeps the experiment) */
+  uint32_t msm_half_batches;    /* MSM batches that ran as two pipelined halves (msm_half_batches; the slot was msm29_batches,
+                                   always 0 since round 5) */
   uint32_t reserved[7];
 } lh_lasso_route;
 lh_status lh_lasso_last_route(lh_ctx*, lh_lasso_route* out);

@@ -94,3 +94,51 @@ def test_host_binding_next_to_the_device(hl, ctx):
             assert prev == before and now == (local & before) and now and now < before
     finally:
         os.sched_setaffinity(0, before)
+
+
+@pytest.mark.gpu
+def test_null_arguments_are_errors_not_crashes(hl, ctx):
+    """Every pointer an entry point dereferences is checked at the boundary (capi.cpp NEED / NEED_N): NULL is LH_ERR_ARG with
+    a message naming the argument, never a segfault inside the library; an empty vector may be NULL."""
+    from halo2_lasso_amd import _ffi
+    lib, h = ctx.lib, ctx.h
+    pp = hl.MultilinearKzg.setup(ctx, [3, 5, 7])
+    poly = ctx.upload(b"".join(hl.fr_to_bytes(v) for v in range(8)))
+    out, fr = _ffi.lh_g1(), _ffi.lh_fr()
+    tr = hl.Keccak256Transcript()
+    bad = [
+        lib.lh_mkzg_commit(h, pp.h, None, 3, C.byref(out)),
+        lib.lh_mkzg_commit(h, pp.h, poly.ptr, 3, None),
+        lib.lh_mkzg_commit(h, None, poly.ptr, 3, C.byref(out)),
+        lib.lh_mkzg_batch_commit(h, pp.h, None, 1, 3, C.byref(out)),
+        lib.lh_mkzg_batch_commit(h, pp.h, (C.c_void_p * 1)(poly.ptr), 1, 3, None),
+        lib.lh_mkzg_open(h, pp.h, None, 3, (_ffi.lh_fr * 3)(), tr.p, C.byref(fr)),
+        lib.lh_mkzg_open(h, pp.h, poly.ptr, 3, None, tr.p, C.byref(fr)),
+        lib.lh_mkzg_open(h, pp.h, poly.ptr, 3, (_ffi.lh_fr * 3)(), None, C.byref(fr)),
+        lib.lh_mkzg_batch_open(h, pp.h, 3, None, 1, (_ffi.lh_fr * 3)(), 1, (_ffi.lh_evaluation * 1)(), 1, tr.p),
+        lib.lh_mkzg_batch_open(h, pp.h, 3, (C.c_void_p * 1)(poly.ptr), 1, None, 1, (_ffi.lh_evaluation * 1)(), 1, tr.p),
+        lib.lh_mkzg_batch_open(h, pp.h, 3, (C.c_void_p * 1)(poly.ptr), 1, (_ffi.lh_fr * 3)(), 1, None, 1, tr.p),
+        lib.lh_mkzg_setup(h, None, 3, C.byref(C.c_void_p())),
+        lib.lh_srs_upload(h, None, 3, C.byref(C.c_void_p())),
+        lib.lh_srs_download(h, pp.h, None),
+        lib.lh_msm(h, None, None, 4, C.byref(out)),
+        lib.lh_msm_u32(h, poly.ptr, None, 4, C.byref(out)),
+        lib.lh_fr_add(h, poly.ptr, None, 8, poly.ptr),
+        lib.lh_fr_batch_invert(h, None, 8, poly.ptr),
+        lib.lh_fix_var(h, poly.ptr, 8, C.byref(fr), None),
+        lib.lh_eq_xy(h, None, 3, poly.ptr),
+        lib.lh_evaluate(h, None, 1, 3, (_ffi.lh_fr * 3)(), C.byref(fr)),
+        lib.lh_lincomb(h, (C.c_void_p * 1)(poly.ptr), None, 1, 8, poly.ptr),
+        lib.lh_upload(h, None, b"1234", 4),
+        lib.lh_download(h, None, poly.ptr, 4),
+        lib.lh_zeromorph_open(h, None, 8, poly.ptr, 3, (_ffi.lh_fr * 3)(), tr.p),
+        lib.lh_zeromorph_batch_commit(h, None, 8, (C.c_void_p * 1)(poly.ptr), 1, 3, C.byref(out)),
+    ]
+    assert bad == [_ffi.LH_ERR_ARG] * len(bad), bad
+    assert b"null argument" in lib.lh_last_error() or b"transcript" in lib.lh_last_error()
+    # an empty vector may be NULL: nothing to read, nothing written
+    assert lib.lh_mkzg_batch_commit(h, pp.h, None, 0, 3, None) == _ffi.LH_OK
+    assert lib.lh_fr_add(h, None, None, 0, None) == _ffi.LH_OK
+    assert lib.lh_upload(h, None, None, 0) == _ffi.LH_OK
+    # ... and the ctx still proves after all of that
+    assert hl.MultilinearKzg.commit(pp, hl.MultilinearPolynomial(ctx, poly, 3)) is not None

@@ -167,7 +167,8 @@ def test_folded_layers_give_the_same_bytes_on_every_path(hl, ctx):
     """Coefficient folding (option sc_pp_fold): the generic layers store c_m l_m at their first bind, the leaf layers of the
     lookup-sized trees store cs (l + k) and r + k and go on as product-pair rounds - with the resident kernel finishing
     the layers, with the launched small rounds and the generic tail finishing them (gkr_resident = 0: they evaluate the
-    REWRITTEN general expression over the folded tables), and not folding at all: one proof, the oracle's."""
+    REWRITTEN general expression over the folded tables), not folding at all, and (2) the product-pair kernel binding round
+    after round with coefficients that are not one and tables it must leave unscaled: one proof, the oracle's."""
     n, nv = 18, 18
     rng = random.Random(18)
     ss = [rng.randrange(1, P) for _ in range(nv)]
@@ -179,7 +180,7 @@ def test_folded_layers_give_the_same_bytes_on_every_path(hl, ctx):
     co.lasso_prove(ot, pp.eqs_bytes(), nv, table.to_c(), n, [d.tobytes() for d in dims])
     want = ot.into_proof()
     seen = {}
-    for fold, resident in ((1, 1), (1, 0), (0, 1), (0, 0)):
+    for fold, resident in ((1, 1), (1, 0), (0, 1), (0, 0), (2, 1), (2, 0)):
         hl.set_option(ctx, "sc_pp_fold", fold)
         hl.set_option(ctx, "gkr_resident", resident)
         try:
