@@ -145,10 +145,10 @@ void Ctx::wait_flag(uint32_t seq) {
 
 void Ctx::aux_streams() {
   if (aux_stream) return;
-  // (the highest priority the device offers: what runs here is the latency-bound half of a pipeline)
-  int prio_lo = 0, prio_hi = 0;
-  LH_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-  LH_HIP(hipStreamCreateWithPriority(&aux_stream, hipStreamNonBlocking, prio_hi));
+  // (the LOWEST priority the device offers: what runs here fills the wave slots the ctx's stream leaves idle)
+  int prio_least = 0, prio_greatest = 0;
+  LH_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+  LH_HIP(hipStreamCreateWithPriority(&aux_stream, hipStreamNonBlocking, prio_least));
   LH_HIP(hipEventCreateWithFlags(&aux_ev, hipEventDisableTiming));
 }
 ScFinishArgs Ctx::finish_for_aux(uint32_t grid, uint32_t seq) {

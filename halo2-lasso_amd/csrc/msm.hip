@@ -659,8 +659,8 @@ static inline host::G1Xyzz to_host(const G1Xyzz& p) {
 }
 
 // One planned sub-batch: the jobs `idx` (positions in the caller's array) with their own key / segment / share numbering,
-// buffers and flag.  A batch is one sub-batch, or - msm_pick_split - two that run as a pipeline: the second half's entry
-// stream and accumulation on the ctx's stream, the first half's latency-bound tails beside them on the ctx's aux stream.
+// buffers and flag.  A batch is one sub-batch, or - msm_pick_split - two that run as a pipeline: the first half on the ctx's
+// stream, the second half's accumulation and tails on the ctx's low-priority aux stream beside the first half's tails.
 namespace {
 struct MsmSub {
   std::vector<size_t> idx;
@@ -709,7 +709,8 @@ static std::vector<char> msm_pick_split(Ctx& c, const MsmJob* jobs, const std::v
                                         const std::vector<char>& derived) {
   const size_t nj = idx.size();
   std::vector<char> second(nj, 0);
-  if (!c.opt.msm_half_batches || nj < 2) return {};
+  // (a helper ctx works beside its owner's latency-bound kernels: no second, high-priority stream there)
+  if (!c.opt.msm_half_batches || c.is_helper || nj < 2) return {};
   std::vector<size_t> E(nj), T(nj);
   size_t Et = 0, Tt = 0;
   for (size_t j = 0; j < nj; j++) {
@@ -725,9 +726,11 @@ static std::vector<char> msm_pick_split(Ctx& c, const MsmJob* jobs, const std::v
       if ((long)idx[p] == (long)jobs[idx[j]].derived_parent) parent[j] = (long)p;
     if (parent[j] >= 0) T[parent[j]] += T[j], T[j] = 0;
   }
+  // (LH_MSM_HALF_MIN_LOG below 24 is a test shape: every batch with two jobs that have entries is split, whatever its size)
   static const size_t min_entries = (size_t)env_int("LH_MSM_HALF_MIN_LOG", 24);
   static const int cover = env_int("LH_MSM_HALF_COVER", 12);  // entries of the second half per bucket of the first
-  if (Et < ((size_t)1 << min_entries) || Tt < ((size_t)1 << 17)) return {};
+  const bool forced = min_entries < 24;
+  if (Et < ((size_t)1 << min_entries) || (!forced && Tt < ((size_t)1 << 17))) return {};
   std::vector<size_t> order;
   for (size_t j = 0; j < nj; j++)
     if (parent[j] < 0 && E[j]) order.push_back(j);
@@ -741,7 +744,8 @@ static std::vector<char> msm_pick_split(Ctx& c, const MsmJob* jobs, const std::v
     second[j] = 1, Eb += E[j], Tb += T[j], taken++;
   }
   // worth it only when the first half has tails to hide and both halves still fill the chip
-  if (!taken || Tt - Tb < ((size_t)1 << 16) || Eb < ((size_t)1 << 22) || Et - Eb < ((size_t)1 << 20)) return {};
+  if (!taken || Eb == 0 || Et == Eb) return {};
+  if (!forced && (Tt - Tb < ((size_t)1 << 16) || Eb < ((size_t)1 << 22) || Et - Eb < ((size_t)1 << 20))) return {};
   for (size_t j = 0; j < nj; j++)
     if (parent[j] >= 0) second[j] = second[parent[j]];
   return second;
@@ -750,7 +754,7 @@ static std::vector<char> msm_pick_split(Ctx& c, const MsmJob* jobs, const std::v
 // layout of one sub-batch: windows, key / segment / share ranges, entry positions (no device work)
 // (`whole`: the plan of the undivided batch this sub-batch is a half of - segment size, reduction form and entries per
 // accumulate thread are the batch's, not the half's: a half must not fall back to the latency-bound forms of a small batch)
-static void msm_plan_sub(Ctx& c, const MsmJob* jobs, MsmSub& s, const MsmSub* whole = nullptr) {
+static void msm_plan_sub(Ctx& c, const MsmJob* jobs, MsmSub& s, const MsmSub* whole = nullptr, int own = 0) {
   const size_t nj = s.idx.size();
   MsmPlanDev& plan = s.plan;
   plan.num_jobs = (int)nj;
@@ -773,7 +777,7 @@ static void msm_plan_sub(Ctx& c, const MsmJob* jobs, MsmSub& s, const MsmSub* wh
     }
     static const int forced = env_int("LH_MSM_SEG", 0);
     seg_size = forced ? (uint32_t)forced : est <= ((size_t)1 << 18) ? 4u : est <= ((size_t)1 << 20) ? 8u : 16u;
-    if (whole) seg_size = whole->seg_size;
+    if (whole && !(own & 1)) seg_size = whole->seg_size;
     s.seg_size = seg_size;
   }
   uint32_t key = 0, seg = 0, win = 0;
@@ -854,7 +858,7 @@ static void msm_plan_sub(Ctx& c, const MsmJob* jobs, MsmSub& s, const MsmSub* wh
   // two-level reduction: throughput-bound batches (the plain segment kernel runs), jobs whose windows hold at least
   // MSM_GROUP^2 segments, packed jobs only when a group never straddles a change of the high part
   static const int two_level_on = env_int("LH_MSM_TWO_LEVEL", 1);
-  const bool plain_reduce = whole ? whole->plain_reduce : s.nsegs > (size_t)MSM_QUAD_MAX / 2;
+  const bool plain_reduce = whole && !(own & 1) ? whole->plain_reduce : s.nsegs > (size_t)MSM_QUAD_MAX / 2;
   s.plain_reduce = plain_reduce;
   s.ngroups = 0;
   for (size_t j = 0; j < nj; j++) {
@@ -892,7 +896,7 @@ static void msm_plan_sub(Ctx& c, const MsmJob* jobs, MsmSub& s, const MsmSub* wh
   const size_t me = s.max_entries;
   s.K = me > ((size_t)1 << 26) ? 128 : me > ((size_t)1 << 25) ? 64 : me > ((size_t)1 << 23) ? 32 : me > ((size_t)1 << 21) ? 16 : me > ((size_t)1 << 18) ? 8 : 4;
   if (MSM_K > 0) s.K = (uint32_t)MSM_K;
-  if (whole) s.K = whole->K;
+  if (whole && !(own & 2)) s.K = whole->K;
   s.nchunks = (me + s.K - 1) / s.K;
   s.wins.assign(s.nshares, G1Xyzz::identity());
 }
@@ -1150,9 +1154,10 @@ bool msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, 
       whole.idx = all, whole.bits = job_bits, whole.derived = derived;
       msm_plan_sub(c, jobs, whole);
     }
-    static const int last_own = env_int("LH_MSM_HALF_LAST_OWN", 0);  // 1: the second half picks its forms by its own size
+    // (development: bit 0 - the second half picks its reduction forms by its own size, bit 1 - its entries per thread too)
+    static const int last_own = env_int("LH_MSM_HALF_LAST_OWN", 0);
     for (MsmSub& s : subs) {
-      msm_plan_sub(c, jobs, s, subs.size() == 2 && !(last_own && &s == &subs[1]) ? &whole : nullptr);
+      msm_plan_sub(c, jobs, s, subs.size() == 2 ? &whole : nullptr, &s == &subs[0] ? 0 : last_own);
       total_entries += s.max_entries, pin_total += s.pin_bytes();
     }
     if (total_entries == 0) {
@@ -1166,6 +1171,7 @@ bool msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, 
       subs.assign(1, whole);
       pin_total = subs[0].pin_bytes();
     }
+    std::vector<host::G1Xyzz> sums_all(2 * num_jobs, host::G1Xyzz::identity());
     {
       ArenaScope scope(c.arena);
       uint8_t* pin_base = (uint8_t*)c.pin(pin_total);
@@ -1174,32 +1180,32 @@ bool msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, 
         pin_base += s.pin_bytes();
       }
       const bool piped = subs.size() == 2;
+      // One batch: everything on the ctx's stream.  Two halves: both entry streams on the ctx's stream; then the FIRST half's
+      // accumulation and tails stay there, and the second half's go to the aux stream, whose priority is the lowest the device
+      // offers - its accumulation gets the wave slots the first half's kernels do not ask for: the drain of the first
+      // accumulation (two launches on one stream would each pay their own), then everything the first half's latency-bound
+      // tails leave idle.  The second half's tails end the batch.  Under the profiler: one stream, the launches one after
+      // the other.
+      for (MsmSub& s : subs) msm_sub_entries(c, jobs, s);
+      hipStream_t side = c.stream;
       uint32_t seq_aux = 0;
       if (piped) {
-        // both halves' entry streams on the ctx's stream; then the first half's accumulation and tails on the aux stream (the
-        // higher priority: its workgroups are dispatched first) and the second half's on the ctx's stream - the second
-        // accumulation fills the chip as the first drains (two launches on one stream would each pay their own drain) and
-        // goes on beside the first half's tails.  Under the profiler: one stream, the same launches one after the other.
         c.route.v[RouteStats::MSM_HALF_BATCHES]++;
-        msm_sub_entries(c, jobs, subs[0]);
-        msm_sub_entries(c, jobs, subs[1]);
-        hipStream_t side = c.stream;
         if (!c.prof) {
           c.aux_streams();
           LH_HIP(hipEventRecord(c.aux_ev, c.stream));
           LH_HIP(hipStreamWaitEvent(c.aux_stream, c.aux_ev, 0));
           side = c.aux_stream;
         }
-        seq_aux = c.next_seq();
-        msm_sub_accumulate(c, subs[0], side);
-        msm_sub_tail(c, jobs, subs[0], side, c.finish_for_aux(subs[0].nshares, seq_aux));
-      } else {
-        msm_sub_entries(c, jobs, subs[0]);
       }
-      MsmSub& last = subs.back();
-      msm_sub_accumulate(c, last, c.stream);
+      msm_sub_accumulate(c, subs[0], c.stream);
+      if (piped) msm_sub_accumulate(c, subs[1], side);
       const uint32_t seq = c.next_seq();
-      msm_sub_tail(c, jobs, last, c.stream, c.finish_for(last.nshares, nullptr, seq));
+      msm_sub_tail(c, jobs, subs[0], c.stream, c.finish_for(subs[0].nshares, nullptr, seq));
+      if (piped) {
+        seq_aux = c.next_seq();
+        msm_sub_tail(c, jobs, subs[1], side, c.finish_for_aux(subs[1].nshares, seq_aux));
+      }
       if (!overlap_done) overlap_done = true, (*overlap)();  // (the device is busy with this batch: the caller's host work now)
       {
         // the window combines follow when the device is through: workers awake and polling by then (batches of up to a few
@@ -1210,9 +1216,15 @@ bool msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, 
         if (heavy_jobs > 1 && !c.prof) host_parallel_prewake(heavy_jobs, 4000);
       }
       c.host_stamp("msm:queued");
-      if (piped) c.wait_flag_aux(seq_aux);
       c.wait_flag(seq);
       waited = true;
+      if (piped) {
+        // the first half's window sums are in: its doublings run on the host while the device works through the second half
+        memcpy(subs[0].wins.data(), subs[0].win_out, (size_t)subs[0].nshares * sizeof(G1Xyzz));
+        msm_sub_combine(subs[0], sums_all);
+        c.host_stamp("msm:first_half_combined");
+        c.wait_flag_aux(seq_aux);
+      }
       c.host_stamp("msm:window_sums");
       for (MsmSub& s : subs) {
         if (getenv("LH_MSM_DEBUG")) {
@@ -1223,13 +1235,12 @@ bool msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, 
           for (int i = 0; i < 10; i++) fprintf(stderr, " %u", h_cnt[i]);
           fprintf(stderr, "\n");
         }
-        memcpy(s.wins.data(), s.win_out, (size_t)s.nshares * sizeof(G1Xyzz));
+        if (!piped || &s == &subs[1]) memcpy(s.wins.data(), s.win_out, (size_t)s.nshares * sizeof(G1Xyzz));
       }
     }
     // 6: host combine and normalise: ONE inversion for every result of the batch (an inversion per job was ~10 us each, and a
     // job's worth of wake-up for the pool when no job needed it)
-    std::vector<host::G1Xyzz> sums_all(2 * num_jobs, host::G1Xyzz::identity());
-    for (MsmSub& s : subs) msm_sub_combine(s, sums_all);
+    msm_sub_combine(subs.back(), sums_all);
     std::vector<host::G1Affine> aff(2 * nj);
     host::g1_batch_to_affine(sums_all.data() + 2 * base, 2 * nj, aff.data());
     for (size_t j = 0; j < nj; j++) {

@@ -376,8 +376,9 @@ def test_lasso_default_route_at_2p21_matches_cpp_oracle(hl, ctx, srs22, kind, n)
 # ------------------------------------------------------------------ BASELINE.json configs[2]
 @pytest.mark.parametrize("kind", ["and", pytest.param("xor", marks=pytest.mark.heavy(est=8))])
 def test_lasso_2p24_and_prove_verify(hl, ctx, kind):
-    """2^24 AND / XOR lookups (32-bit operands, 4 chunks of 8+8 bits) on one GPU: the proof verifies, is deterministic,
-    and a flipped lookup index changes it.  (Bytes against the oracle at this size are checked by bench.py's cpu_baseline
+    """2^24 AND / XOR lookups (32-bit operands, 4 chunks of 8+8 bits) on one GPU: the proof verifies, is the same
+    with its two large MSM batches pipelined in halves (msm_half_batches, the default) and undivided, and a flipped lookup
+    index changes it.  (Bytes against the oracle at this size are checked by bench.py's cpu_baseline
     on the largest sample that fits its time bound; the XOR columns are skewed - a quarter of the lookups hit 16 cells -
     so the access counts are wide and the packed read_ts pairs take their large-bucket shape.)"""
     n = 24
@@ -392,10 +393,15 @@ def test_lasso_2p24_and_prove_verify(hl, ctx, kind):
             d[hot] = rng.integers(0, 16, size=int(hot.sum()), dtype=np.uint32) * 4099 % (1 << 16)
     bufs = [ctx.upload(d.tobytes()) for d in dims]
     proofs = []
-    for _ in range(2):
-        t = hl.Keccak256Transcript()
-        hl.lasso_prove(pp, table, n, bufs, t)
+    for half in (1, 0):  # (the commit and the opening's remainder as two pipelined halves on two streams, then as one batch each)
+        hl.set_option(ctx, "msm_half_batches", half)
+        try:
+            t = hl.Keccak256Transcript()
+            hl.lasso_prove(pp, table, n, bufs, t)
+        finally:
+            hl.set_option(ctx, "msm_half_batches", 1)
         proofs.append(t.into_proof())
+        assert hl.lasso_last_route(ctx)["msm_half_batches"] == (2 if half else 0), hl.lasso_last_route(ctx)
     assert proofs[0] == proofs[1]
     hl.lasso_verify(hl.MultilinearKzgVerifierParams.setup(ss), table, n, hl.Keccak256Transcript.from_proof(proofs[0]))
     dims[2][12345] ^= 1
@@ -464,7 +470,9 @@ def test_context_used_from_another_thread(hl, ctx):
                                  {"LH_OPEN_SMALL_MIN_VARS": "2", "LH_MSM_SLAB_LOG": "4"},
                                  {"LH_MSM_QUAD_MAX": "0", "LH_MSM_SEG": "16", "LH_MSM_TREE_MAX": "0"},
                                  {"LH_OPEN_SMALL_MIN_VARS": "2", "LH_OPEN_SMALL_DEPTH": "2", "LH_OPEN_SMALL_CHECK": "1"},
-                                 {"LH_MSM_WINDOW_TABLES": "24", "LH_MSM_SLAB_LOG": "6"}])
+                                 {"LH_MSM_WINDOW_TABLES": "24", "LH_MSM_SLAB_LOG": "6"},
+                                 {"LH_MSM_HALF_MIN_LOG": "6", "LH_MSM_SLAB_LOG": "12"},
+                                 {"LH_MSM_HALF_MIN_LOG": "6", "LH_MSM_HALF_LAST_OWN": "3", "LH_MSM_HALF_COVER": "1"}])
 def test_small_parity_suite_under_forced_shapes(env):
     """The byte-parity tests of test_gpu_parity.py / test_gpu_golden.py again in a child process with the shape
     knobs forced (they are read once per process): 64 workgroups with slices of two entries (hand-over right after
@@ -476,7 +484,9 @@ def test_small_parity_suite_under_forced_shapes(env):
     (with the route's own comparison against the plain commitments switched on), every full-width MSM job over a
     window table of its SRS level (one bucket set for all windows), and the MSM tails in their throughput forms whatever
     the size: plain (not quad-cooperative) kernels, 16-bucket segments with the two-level group reduction wherever a window
-    has 4096 buckets, linear continuation levels instead of trees."""
+    has 4096 buckets, linear continuation levels instead of trees; and every MSM batch with two jobs as two pipelined halves
+    on two streams (msm_half_batches: by default only from 2^24 entries on), derived jobs next to their parents, the second
+    half with the batch's forms or with its own."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "tests/test_gpu_golden.py", "-m", "gpu",

@@ -18,8 +18,8 @@ if split_ms > 0:
         if rows[i][1] - rows[i - 1][2] >= split_ms * 1e6:
             i0 = i
 else:
-    starts = [i for i, r in enumerate(rows) if "lasso_run_start_kernel" in r[0]]
-    per = int(os.environ.get("LH_TRACE_COLUMNS", "2"))  # chunk columns per proof (range table: 2, AND / XOR: 4)
+    starts = [i for i, r in enumerate(rows) if "lasso_run_start" in r[0]]
+    per = int(os.environ.get("LH_TRACE_COLUMNS", "1"))  # run-start launches per proof: 1 below 2^22 lookups (all columns together), else the chunk columns (range: 2, AND / XOR: 4)
     i0 = starts[-per]
     while i0 > 0 and rows[i0][1] - rows[i0 - 1][2] < 150e3:
         i0 -= 1
@@ -52,6 +52,6 @@ if len(sys.argv) > 2:  # detail: every launch of the kernels matching the patter
     prev_end = None
     for r in ks:
         if pat.search(r[0]):
-            print("  %-40s grid %6d x %4d  %7.1f us  gap %6.1f" % (short(r[0]), r[3] // max(r[4], 1), r[4], (r[2] - r[1]) / 1e3,
-                                                                 (r[1] - prev_end) / 1e3 if prev_end else 0.0))
+            print("  %-40s grid %6d x %4d  %7.1f us  gap %6.1f   [%8.3f .. %8.3f ms]" % (short(r[0]), r[3] // max(r[4], 1), r[4], (r[2] - r[1]) / 1e3,
+                                                                 (r[1] - prev_end) / 1e3 if prev_end else 0.0, (r[1] - t0) / 1e6, (r[2] - t0) / 1e6))
         prev_end = r[2]
