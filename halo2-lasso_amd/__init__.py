@@ -168,10 +168,12 @@ class Context:
         return bus.value.decode(), parse_cpulist(cpus.value.decode())
 
     def bind_host(self):
-        """Bind the CALLING thread (and with it every thread the library starts for this ctx from now on: its host pool, the
-        helper ctx's worker) to the CPUs next to the ctx's device - what a one-process-per-GPU deployment does with
-        numactl.  Returns the previous affinity mask (give it to os.sched_setaffinity to undo), or None when nothing was
-        changed: no such list, or none of its CPUs is in the present mask."""
+        """Bind the CALLING thread to the CPUs next to the ctx's device - what a one-process-per-GPU deployment does with
+        numactl.  Threads the library starts AFTERWARDS from this thread inherit the mask (its host pool, which also sizes
+        itself by the mask; the helper ctx's worker); threads that exist already keep theirs, and threads created while
+        bound stay bound when the caller restores its own mask: call this BEFORE the first proof of the process.  Returns
+        the previous affinity mask (give it to os.sched_setaffinity to undo), or None when nothing was changed: no such
+        list, or none of its CPUs is in the present mask."""
         import os
         _, local = self.host_cpus()
         before = os.sched_getaffinity(0)

@@ -18,6 +18,7 @@
 #include <dlfcn.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 #include <rccl/rccl.h>  // types and enums only: every function is resolved with dlsym
 #include <mutex>
 #include "host.hpp"
@@ -128,6 +129,67 @@ void comm_attach_rccl(Ctx& c, int rank, int size, const uint8_t id_bytes[LH_RCCL
   c.comm = lh_comm{rank, size, nullptr, nullptr, nullptr};
   c.has_comm = true;
   c.shard_bit = shard_bit;
+  comm_probe_host_recv(c);
+}
+
+// One-time self-test of what comm_round = 1 relies on (every rank runs it at attach, it is a collective): does this
+// fabric's ncclAllReduce accept PINNED HOST memory as its receive buffer and deliver every u64 lane there?  Each rank
+// contributes lanes tagged like a round's (comm_sum_lanes), the collective writes into the ctx's pinned lane block, and
+// the host waits - bounded - for lanes that read size * tag.  The ranks then agree on the verdict through an all-reduce
+// into DEVICE memory (ncclMin over a 0 / 1 word), so that every rank takes the same variant: Ctx::comm_host_recv_ok false
+// makes comm_round = 1 behave as 2 (device receive buffer + copy), with a note on stderr.  LH_COMM_PROBE=0 skips the
+// probe (the variant is then taken on trust), LH_COMM_PROBE_FAIL=1 makes it fail (tests).
+void comm_probe_host_recv(Ctx& c) {
+  c.comm_host_recv_ok = true;
+  if (!c.rccl_comm) return;
+  static const bool skip = [] { const char* e = getenv("LH_COMM_PROBE"); return e && atoi(e) == 0; }();
+  static const bool force_fail = [] { const char* e = getenv("LH_COMM_PROBE_FAIL"); return e && atoi(e) != 0; }();
+  if (skip) return;
+  const RcclApi& api = rccl();
+  const size_t R = (size_t)c.comm.size, n = 16;
+  if (!c.lanes_host) {
+    LH_HIP(hipHostMalloc((void**)&c.lanes_host, 128 * sizeof(uint64_t), hipHostMallocCoherent | hipHostMallocMapped));
+    memset(c.lanes_host, 0, 128 * sizeof(uint64_t));
+  }
+  ArenaScope scope(c.arena);
+  uint64_t* d = c.arena.alloc_n<uint64_t>(2 * n);
+  const uint64_t tag = 0x5a5;  // (R * tag < 2^24 for R <= 256; a lane is a limb | tag << 40, as in a round)
+  uint64_t h[n];
+  for (size_t i = 0; i < n; i++) h[i] = (uint64_t)(i + 1) | (tag << SC_LANE_TAG_SHIFT);
+  LH_HIP(hipMemcpyAsync(d, h, sizeof(h), hipMemcpyHostToDevice, c.stream));
+  c.sync();
+  bool ok = !force_fail;
+  volatile uint64_t* hl = c.lanes_host;
+  for (size_t i = 0; i < n; i++) hl[64 + i] = 0;
+  if (ok) {
+    const ncclResult_t r = api.AllReduce(d, c.lanes_host + 64, n, ncclUint64, ncclSum, (ncclComm_t)c.rccl_comm, c.stream);
+    ok = r == ncclSuccess;
+    if (ok) {
+      const auto t0 = std::chrono::steady_clock::now();
+      for (size_t i = 0; i < n && ok; i++)
+        while (hl[64 + i] != (uint64_t)R * h[i]) {
+          __builtin_ia32_pause();
+          if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2000)) {
+            ok = false;
+            break;
+          }
+        }
+      if (hipStreamSynchronize(c.stream) != hipSuccess) ok = false;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  // the ranks agree (a device-to-device all-reduce: the path comm_round = 2 uses)
+  uint32_t mine = ok ? 1u : 0u, all = 0;
+  uint32_t* dv = (uint32_t*)(d + n);
+  LH_HIP(hipMemcpyAsync(dv, &mine, sizeof(mine), hipMemcpyHostToDevice, c.stream));
+  rccl_check(api.AllReduce(dv, dv + 1, 1, ncclUint32, ncclMin, (ncclComm_t)c.rccl_comm, c.stream), "ncclAllReduce (probe verdict)");
+  LH_HIP(hipMemcpyAsync(&all, dv + 1, sizeof(all), hipMemcpyDeviceToHost, c.stream));
+  c.sync();
+  c.comm_host_recv_ok = all == 1;
+  if (!c.comm_host_recv_ok && c.comm.rank == 0)
+    fprintf(stderr, "[comm] ncclAllReduce into pinned host memory failed the attach-time probe on %zu ranks: comm_round = 1 runs as 2 "
+                    "(device receive buffer + copy)\n", R);
 }
 
 // Measurement aid (lh_ctx_set_comm_loopback): every peer is a copy of this rank.  Rank `rank` of a `size`-rank proof then
@@ -313,7 +375,7 @@ void comm_sum_lanes(Ctx& c, uint64_t* d_lanes, uint64_t* d_scratch, size_t count
     memset(c.lanes_host, 0, 128 * sizeof(uint64_t));
   }
   volatile uint64_t* hl = c.lanes_host;
-  const bool via_device = c.opt.comm_round == 2;
+  const bool via_device = c.opt.comm_round == 2 || !c.comm_host_recv_ok;  // (comm_probe_host_recv: this fabric refused host memory)
   uint64_t* dst = via_device ? d_scratch : c.lanes_host;
   if (c.comm_loopback) {
     c.comm_stats[0]++;
@@ -336,11 +398,16 @@ void comm_sum_lanes(Ctx& c, uint64_t* d_lanes, uint64_t* d_scratch, size_t count
     }
   }
   // every lane validates itself: wait until each carries the ranks' tags
+  // (bounded: a peer that never arrives - hipErrorNotReady for ever - must not hang this rank: LH_COMM_WAIT_TIMEOUT_MS)
+  static const long wait_ms = [] { const char* e = getenv("LH_COMM_WAIT_TIMEOUT_MS"); return e && atol(e) > 0 ? atol(e) : 30000L; }();
+  const auto wait_t0 = std::chrono::steady_clock::now();
   const uint64_t expect = ((uint64_t)R * c.sc_tag) & 0xffffffull;
   for (size_t i = 0; i < n; i++) {
     for (uint64_t spin = 0; (hl[i] >> SC_LANE_TAG_SHIFT) != expect; spin++) {
       __builtin_ia32_pause();
       if ((spin & 0xfffff) == 0xfffff) {
+        if (std::chrono::steady_clock::now() - wait_t0 > std::chrono::milliseconds(wait_ms))
+          throw Error(LH_ERR_DEVICE, "all-reduce of a sharded round: the sums of all ranks did not arrive in time (a peer is gone?)");
         hipError_t e = hipStreamQuery(c.stream);
         if (e == hipSuccess) {
           if ((hl[i] >> SC_LANE_TAG_SHIFT) == expect) break;

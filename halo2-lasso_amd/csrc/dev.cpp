@@ -2,6 +2,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <ctype.h>
+#include <sched.h>
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
@@ -379,8 +380,16 @@ struct HostPool {
   std::atomic<int> spinning{0};
   std::shared_ptr<HostJob> job;
   unsigned workers = 0;
+  // the CPUs this process may run on (taskset, a cgroup, Context.bind_host: fewer than the machine's)
+  static unsigned usable_cpus() {
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) return (unsigned)CPU_COUNT(&set);
+    const unsigned hw = std::thread::hardware_concurrency();
+    return hw ? hw : 1;
+  }
   HostPool() {
-    unsigned hw = std::thread::hardware_concurrency();
+    unsigned hw = usable_cpus();
     // (an MSM batch hands ~25-40 window combines of ~70 us each to this pool at the end of a commit or an opening - the
     // GPU idles meanwhile: one round of them, not three, where the host has the cores; LH_HOST_THREADS overrides)
     unsigned cap = 47;
@@ -390,12 +399,16 @@ struct HostPool {
   }
   void worker() {
     uint64_t seen = 0, seen_spin = 0;
+    bool was_spinning = false;
     for (;;) {
       std::shared_ptr<HostJob> mine;
       bool spin = false;
       std::chrono::steady_clock::time_point until;
       {
         std::unique_lock<std::mutex> lk(mu);
+        // (`spinning` only changes under the lock: a poster that counts the pollers under the lock counts exactly the
+        // workers that will look at `gen` again before they sleep)
+        if (was_spinning) spinning--, was_spinning = false;
         cv.wait(lk, [&] { return gen.load(std::memory_order_relaxed) != seen || (spin_gen != seen_spin && spin_want > 0); });
         if (gen.load(std::memory_order_relaxed) != seen) {
           seen = gen.load(std::memory_order_relaxed);
@@ -406,12 +419,11 @@ struct HostPool {
           spin_want--;
           spin = true;
           until = spin_until;
+          spinning++, was_spinning = true;
         }
       }
       if (spin) {
-        spinning.fetch_add(1, std::memory_order_relaxed);
         while (gen.load(std::memory_order_acquire) == seen && std::chrono::steady_clock::now() < until) __builtin_ia32_pause();
-        spinning.fetch_sub(1, std::memory_order_relaxed);
         continue;  // (takes the job under the lock if one came, sleeps again otherwise)
       }
       if (mine) mine->run();
@@ -422,11 +434,12 @@ struct HostPool {
   void prewake(size_t count, unsigned us) {
     if (!workers || count <= 1) return;
     // (polling threads burn a core each: at most an eighth of the host's - eight ranks may share it, one process per GPU)
-    static const size_t spin_cap = std::max<size_t>(1, std::thread::hardware_concurrency() / 8);
-    const int want = (int)std::min<size_t>(std::min<size_t>(count - 1, workers), spin_cap) - spinning.load(std::memory_order_relaxed);
-    if (want <= 0) return;
+    static const size_t spin_cap = std::max<size_t>(1, usable_cpus() / 8);
+    int want;
     {
       std::lock_guard<std::mutex> lk(mu);
+      want = (int)std::min<size_t>(std::min<size_t>(count - 1, workers), spin_cap) - spinning;
+      if (want <= 0) return;
       spin_gen++;
       spin_want = want;
       spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(us);
@@ -439,9 +452,10 @@ struct HostPool {
     auto j = std::make_shared<HostJob>();
     j->fn = f;  // a copy: the job outlives the caller's frame for workers that wake late
     j->n = count;
-    const bool enough_awake = (size_t)spinning.load(std::memory_order_relaxed) + 1 >= count;
+    bool enough_awake;
     {
       std::lock_guard<std::mutex> lk(mu);
+      enough_awake = (size_t)spinning + 1 >= count;  // (decided under the lock: see worker())
       job = j;
       gen.fetch_add(1, std::memory_order_release);
       spin_want = 0;

@@ -202,6 +202,7 @@ struct Ctx {
   uint32_t sc_tag = 0;          // the tag of the round in progress (ScFinishArgs::tag)
   uint32_t sc_tag_seq = 0;      // tags handed out so far
   uint64_t* lanes_host = nullptr;  // pinned: where the all-reduce leaves the lanes' sums (created on first use)
+  bool comm_host_recv_ok = true;   // the attach-time probe (comm.cpp comm_probe_host_recv): RCCL delivers into pinned host memory here
   Fr* round_out(Fr* out_host) const { return sc_redirect ? sc_redirect : out_host; }
   void wait_round(uint32_t seq) {  // the host's wait for a round kernel's sums (nothing to wait for when they stay on the device)
     if (!sc_redirect) wait_flag(seq);
@@ -471,6 +472,7 @@ bool k_fr_tables_equal(Ctx&, const Fr* a, const Fr* b, size_t n);
 // ------------------------------------------------------------------ communicator (comm.cpp)
 void rccl_unique_id(uint8_t out[LH_RCCL_UNIQUE_ID_BYTES]);
 void comm_attach_rccl(Ctx&, int rank, int size, const uint8_t id[LH_RCCL_UNIQUE_ID_BYTES], size_t shard_bit);
+void comm_probe_host_recv(Ctx&);  // attach-time self-test of the all-reduce into pinned host memory (sets Ctx::comm_host_recv_ok)
 void comm_attach_loopback(Ctx&, int rank, int size, size_t shard_bit);
 void comm_detach(Ctx&);
 // recv = size * bytes, rank-major.  _dev: device buffers, enqueued on the ctx's stream (staged through the host when

@@ -310,7 +310,11 @@ std::string disk_name(const std::string& src) {
                                      (void)hiprtcVersion(&major, &minor);
                                      uint64_t h = fnv1a(&major, sizeof major, 0xcbf29ce484222325ull);
                                      h = fnv1a(&minor, sizeof minor, h);
-                                     h = fnv1a(HIP_VERSION_GITHASH, sizeof HIP_VERSION_GITHASH, h);  // (the ROCm build the compiler came with)
+                                     // (the runtime the code objects are made by and loaded into - hiprtc above and the HIP
+                                     // runtime below, as they answer at RUN time - and the headers this library was built against)
+                                     { int rt = 0; (void)hipRuntimeGetVersion(&rt); h = fnv1a(&rt, sizeof rt, h); }
+                                     { int drv = 0; (void)hipDriverGetVersion(&drv); h = fnv1a(&drv, sizeof drv, h); }
+                                     h = fnv1a(HIP_VERSION_GITHASH, sizeof HIP_VERSION_GITHASH, h);
                                      { const int patch = HIP_VERSION_PATCH; h = fnv1a(&patch, sizeof patch, h); }
                                      for (int i = 0; i < JIT_NUM_OPTS; i++) h = fnv1a(JIT_OPTS[i], strlen(JIT_OPTS[i]) + 1, h);
                                      h = fnv1a(JIT_FF_CUH, sizeof JIT_FF_CUH, h);

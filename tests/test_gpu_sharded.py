@@ -366,6 +366,44 @@ def test_rccl_grouped_send_recv_executes_on_one_gpu():
     assert r.returncode == 0 and "P2P-OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
 
 
+PROBE_FAIL_WORKER = textwrap.dedent("""
+    import sys, random
+    sys.path.insert(0, %r)
+    import numpy as np
+    import halo2_lasso_amd as hl
+    ctx = hl.Context(0)
+    n, shard_bit = 18, 16
+    table = hl.LassoTable.bitwise(hl.SUBTABLE_XOR, 4, 16)
+    rng = np.random.default_rng(191)
+    prng = random.Random(191)
+    pp = hl.MultilinearKzg.setup(ctx, [prng.randrange(1, hl.R_MOD) for _ in range(n)])
+    dims = [ctx.upload(rng.integers(0, 1 << 16, size=1 << n, dtype=np.uint32).tobytes()) for _ in range(4)]
+    single = hl.Keccak256Transcript()
+    hl.lasso_prove(pp, table, n, dims, single)
+    hl.attach_comm_rccl(ctx, 0, 1, hl.rccl_unique_id(), shard_bit)   # (the probe runs here - and is told to fail)
+    hl.set_option(ctx, "comm_round", 1)
+    t = hl.Keccak256Transcript()
+    hl.lasso_prove_sharded(pp, table, n, dims, t)
+    stats = hl.comm_stats(ctx)
+    hl.detach_comm(ctx)
+    assert t.into_proof() == single.into_proof(), "bytes differ"
+    print("PROBE-FALLBACK-OK", stats)
+""") % ROOT
+
+
+def test_all_reduce_into_host_memory_is_probed_at_attach():
+    """comm_round = 1 lets ncclAllReduce write straight into pinned host memory; whether a fabric accepts that across ranks
+    is unknown until a multi-GPU job runs.  lh_ctx_set_comm_rccl therefore runs the collective once at attach
+    (comm.cpp comm_probe_host_recv: tagged lanes, bounded wait, the ranks agree on the verdict through a device-side
+    all-reduce); a failed probe makes comm_round = 1 behave as 2 with a note on stderr.  Here the probe is told to fail
+    (LH_COMM_PROBE_FAIL=1) in a world of one over real RCCL: the note appears, the proof is lasso_prove's.  (The passing
+    probe runs in every other RCCL test of this file.)"""
+    env = dict(os.environ, LH_COMM_PROBE_FAIL="1")
+    r = subprocess.run([sys.executable, "-c", PROBE_FAIL_WORKER], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "PROBE-FALLBACK-OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "comm_round = 1 runs as 2" in r.stderr, r.stderr[-2000:]
+
+
 RCCL_WORKER = textwrap.dedent("""
     import os, sys, json
     sys.path.insert(0, %r)
