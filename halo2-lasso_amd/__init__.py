@@ -490,8 +490,13 @@ class Evaluation:
 
 
 class MultilinearKzgParams:
-    def __init__(self, ctx, handle):
-        self.ctx, self.h = ctx, handle
+    def __init__(self, ctx, handle, borrowed=False):
+        self.ctx, self.h, self.borrowed = ctx, handle, borrowed
+
+    def view(self, ctx):
+        """The same SRS (device memory, owned by this object - keep it alive) for use through another ctx of the same
+        device: a second proof in flight on its own stream (bench.py two_proofs_in_flight / sharded_two_in_flight)."""
+        return MultilinearKzgParams(ctx, self.h, borrowed=True)
 
     @property
     def num_vars(self):
@@ -514,7 +519,7 @@ class MultilinearKzgParams:
         return [pts[(1 << k) - 1:(2 << k) - 1] for k in range(n + 1)]
 
     def free(self):
-        if self.h and self.ctx.h:
+        if self.h and self.ctx.h and not self.borrowed:
             self.ctx.lib.lh_srs_free(self.ctx.h, self.h)
         self.h = None
 

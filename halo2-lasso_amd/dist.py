@@ -92,8 +92,16 @@ def host_all_gather(dist, group=None):
     return all_gather
 
 
-def attach_sharded(ctx, dist, shard_bit):
-    """Give `ctx` the communicator of a sharded proof over all ranks of `dist`; returns "rccl" or "host"."""
+def flight_group(dist):
+    """A gloo group of all ranks for the host-side exchanges of a SECOND sharded proof in flight on every rank: two proofs
+    driven by two host threads must not share one ordered channel.  (Collective: every rank calls it, once.)"""
+    return dist.new_group(backend="gloo")
+
+
+def attach_sharded(ctx, dist, shard_bit, group=None):
+    """Give `ctx` the communicator of a sharded proof over all ranks of `dist`; returns "rccl" or "host".
+    `group`: the gloo group the host transport uses (default: the control group) - a second proof in flight on the same
+    ranks takes its own (flight_group); the RCCL transport creates a communicator of its own per call anyway."""
     import halo2_lasso_amd as hl
     rank, world = dist.get_rank(), dist.get_world_size()
     if dist.get_backend() == "nccl" and os.environ.get("LH_SHARDED_TRANSPORT", "rccl") == "rccl":
@@ -119,7 +127,7 @@ def attach_sharded(ctx, dist, shard_bit):
         if int(flag.item()) == 1:
             return "rccl"
         hl.detach_comm(ctx)
-    hl.attach_comm(ctx, rank, world, host_all_gather(dist, control_group(dist)), shard_bit)
+    hl.attach_comm(ctx, rank, world, host_all_gather(dist, group if group is not None else control_group(dist)), shard_bit)
     return "host"
 
 

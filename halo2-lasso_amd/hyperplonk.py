@@ -174,6 +174,15 @@ class HyperPlonk:
         return sp
 
     @staticmethod
+    def rebind_param(pp, ctx):
+        """The same prover param for use through another ctx of the same device (a second proof in flight): the polys and
+        the SRS are device memory and stay shared, only the ctx the library is called with changes."""
+        sp = HyperPlonkProverParam()
+        sp.__dict__.update(pp.__dict__)
+        sp.pcs = pp.pcs.view(ctx)
+        return sp
+
+    @staticmethod
     def prove_sharded(pp_local, instances, witness_polys_local, transcript):
         """lh_hyperplonk_prove_sharded: ONE proof over the ranks of the ctx's communicator, same bytes as `prove`.
         `pp_local` from shard_param, `witness_polys_local`: this rank's shards of the witness polys."""

@@ -48,10 +48,36 @@ WORKER = textwrap.dedent("""
     if "comm_round" in cfg:                  # 1 / 2: the rounds' partial sums by ONE all-reduce of u64 lanes (lasso_hip.h)
         hl.set_option(ctx, "comm_round", cfg["comm_round"])
     t = hl.Keccak256Transcript()
-    hl.lasso_prove_sharded(pp, table, cfg["n"], d_dims, t)
+    second = None
+    if cfg.get("in_flight") == 2:
+        # TWO sharded proofs in flight on every rank (bench.py sharded_two_in_flight): a second ctx on the same device with its
+        # own communicator over its own gloo group, a host thread per proof; the second proof is of a DIFFERENT batch
+        import threading
+        ctx2 = hl.Context(0)
+        hl.attach_comm(ctx2, rank, world, hdist.host_all_gather(d, hdist.flight_group(d)), cfg["shard_bit"])
+        for name in ("shard_exchange_log", "comm_round"):
+            hl.set_option(ctx2, name, hl.get_option(ctx, name))
+        dims2 = [[rng.randrange(1 << cfg["l"]) for _ in range(1 << cfg["n"])] for _ in range(cfg["c"])]
+        d_dims2 = [ctx2.upload(hl.shard_of(np.array(col, dtype=np.uint32), rank, world, cfg["shard_bit"]).tobytes())
+                   for col in dims2]
+        t2 = hl.Keccak256Transcript()
+        errs = []
+        def run(p, cols, tr):
+            try:
+                hl.lasso_prove_sharded(p, table, cfg["n"], cols, tr)
+            except Exception as e:
+                errs.append(repr(e))
+        th = [threading.Thread(target=run, args=(pp, d_dims, t)), threading.Thread(target=run, args=(pp.view(ctx2), d_dims2, t2))]
+        for x in th: x.start()
+        for x in th: x.join()
+        assert not errs, errs
+        second = t2.into_proof().hex()
+        hl.detach_comm(ctx2)
+    else:
+        hl.lasso_prove_sharded(pp, table, cfg["n"], d_dims, t)
     # (to a file: a proof of this size does not fit a pipe's buffer, and the parent reads the pipes only at the end)
     with open(sys.argv[2] + ".%%d" %% rank, "w") as f:
-        json.dump({"rank": rank, "proof": t.into_proof().hex(), "stats": hl.comm_stats(ctx),
+        json.dump({"rank": rank, "proof": t.into_proof().hex(), "second": second, "stats": hl.comm_stats(ctx),
                    "route": hl.lasso_last_route(ctx)}, f)
     hdist.barrier(d)
     d.destroy_process_group()
@@ -135,6 +161,33 @@ def test_sharded_proof_equals_single_gpu_and_oracle(tmp_path, world, kind, c, l,
     o_lasso.prove(opp, spec, dims, ot)
     assert proofs.pop() == ot.into_proof().hex()
     o_lasso.verify(opp, spec, n, OT(ot.into_proof()))
+
+
+@pytest.mark.parametrize("world,kind,c,l,n,shard_bit,xlog", [(2, "and", 2, 4, 9, 3, 0), (4, "range", 2, 4, 9, 2, 0), (2, "xor", 2, 4, 9, 4, None)])
+def test_two_sharded_proofs_in_flight_per_rank(tmp_path, world, kind, c, l, n, shard_bit, xlog):
+    """every rank drives TWO sharded proofs at once - two ctxs on its device, each with its own
+    communicator (here: its own gloo group), a host thread each - so that one proof's latency-bound stretches and waits for
+    peers run under the other's kernels.  Both proofs (of two different batches) must be the specification's, on every rank."""
+    from oracle.pyref import lasso as o_lasso, kzg as o_kzg
+    from oracle.pyref.field import R_MOD
+    from oracle.pyref.transcript import Keccak256Transcript as OT
+    seed = zlib.crc32(repr((world, kind, c, l, n, "two in flight")).encode())
+    cfg = dict(seed=seed, kind=kind, c=c, l=l, n=n, shard_bit=shard_bit, in_flight=2)
+    if xlog is not None:
+        cfg["xlog"] = xlog
+    outs = run_ranks(tmp_path, world, cfg, 29150 + (seed % 140))
+    assert len({o["proof"] for o in outs}) == 1 and len({o["second"] for o in outs}) == 1, "ranks disagree on a proof"
+    rng = random.Random(seed)
+    ss = [rng.randrange(R_MOD) for _ in range(n)]
+    dims = [[rng.randrange(1 << l) for _ in range(1 << n)] for _ in range(c)]
+    dims2 = [[rng.randrange(1 << l) for _ in range(1 << n)] for _ in range(c)]
+    spec = o_lasso.range_table(c, l) if kind == "range" else o_lasso.bitwise_table(
+        o_lasso.SUBTABLE_AND if kind == "and" else o_lasso.SUBTABLE_XOR, c, l)
+    opp = o_kzg.setup(ss)
+    for cols, got in ((dims, outs[0]["proof"]), (dims2, outs[0]["second"])):
+        ot = OT()
+        o_lasso.prove(opp, spec, cols, ot)
+        assert got == ot.into_proof().hex()
 
 
 @pytest.mark.parametrize("world,kind,c,l,n,shard_bit,comm_round", [(2, "range", 2, 3, 9, 5, 1), (4, "xor", 3, 4, 7, 3, 1),

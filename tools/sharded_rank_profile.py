@@ -26,6 +26,31 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 
+def in_flight(ctxs, fns, steps):
+    """ms per proof with one proof per ctx in flight at a time (one host thread per ctx, `steps` proofs each): what a rank
+    gains when the latency-bound stretches of one sharded proof - resident rounds, MSM tails, collectives - run under the
+    streaming kernels of another (bench.py two_proofs_in_flight, for shards)"""
+    import threading
+
+    def worker(fn, k):
+        for _ in range(k):
+            fn()
+    dt = 0.0
+    for k in (1, steps):
+        th = [threading.Thread(target=worker, args=(fn, k)) for fn in fns]
+        for c in ctxs:
+            c.sync()
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for c in ctxs:
+            c.sync()
+        dt = time.perf_counter() - t0
+    return round(dt * 1e3 / (len(fns) * steps), 3)
+
+
 def hyperplonk_keccak(hl, bench, ctx, k, args):
     """the same measurement for lh_hyperplonk_prove_sharded over the loopback communicator"""
     from halo2_lasso_amd import hyperplonk as hp, synthetic
@@ -65,14 +90,25 @@ def hyperplonk_keccak(hl, bench, ctx, k, args):
             pp_local = hp.HyperPlonk.shard_param(pp, rank, world, shard_bit)
             wit_local = [hl.shard_poly(p, rank, world, shard_bit) for p in circ.d_witness]
             hl.attach_comm_loopback(ctx, rank, world, shard_bit)
+            two = None
             try:
                 stats0 = hl.comm_stats(ctx)
                 wall, aggs = timed(lambda: hp.HyperPlonk.prove_sharded(pp_local, circ.instances, wit_local, hl.Keccak256Transcript()))
                 stats1 = hl.comm_stats(ctx)
+                if args.in_flight > 1:
+                    ctx2 = args.ctx2
+                    hl.attach_comm_loopback(ctx2, rank, world, shard_bit)
+                    try:
+                        pp2 = hp.HyperPlonk.rebind_param(pp_local, ctx2)
+                        two = in_flight([ctx, ctx2], [
+                            lambda: hp.HyperPlonk.prove_sharded(pp_local, circ.instances, wit_local, hl.Keccak256Transcript()),
+                            lambda: hp.HyperPlonk.prove_sharded(pp2, circ.instances, wit_local, hl.Keccak256Transcript())], args.steps)
+                    finally:
+                        hl.detach_comm(ctx2)
             finally:
                 hl.detach_comm(ctx)
             del pp_local, wit_local
-            per_rank.append({"rank": rank, "wall_ms": wall, "busy_ms": round(sum(a["ms"] for a in aggs), 3),
+            per_rank.append({"rank": rank, "wall_ms": wall, "two_in_flight_ms_per_proof": two, "busy_ms": round(sum(a["ms"] for a in aggs), 3),
                              "collectives_per_proof": {kk: (stats1[kk] - stats0[kk]) // (args.steps + 3) for kk in stats0},
                              "top_kernels": [{"name": a["name"], "launches": a["launches"], "ms": round(a["ms"], 3)} for a in aggs[:8]]})
         worst_wall = max(r["wall_ms"] for r in per_rank)
@@ -81,8 +117,14 @@ def hyperplonk_keccak(hl, bench, ctx, k, args):
             "shard_bit": shard_bit, "ranks": per_rank, "max_rank_wall_ms": worst_wall, "max_rank_busy_ms": worst_busy,
             "ideal_ms": round(single["wall_ms"] / world, 3),
             "compute_speedup_vs_single_gpu": round(single["wall_ms"] / worst_wall, 3)}
-        print("keccak%d world %d: max rank wall %.2f ms, busy %.2f ms (single GPU %.2f / %.2f)" % (
-            k, world, worst_wall, worst_busy, single["wall_ms"], single["busy_ms"]), file=sys.stderr, flush=True)
+        two_txt = ""
+        if args.in_flight > 1:
+            worst_two = max(r["two_in_flight_ms_per_proof"] for r in per_rank)
+            entry["worlds"][str(world)].update(max_rank_two_in_flight_ms_per_proof=worst_two,
+                                               two_in_flight_speedup_vs_single_gpu=round(single["wall_ms"] / worst_two, 3))
+            two_txt = ", two in flight %.2f ms per proof" % worst_two
+        print("keccak%d world %d: max rank wall %.2f ms, busy %.2f ms (single GPU %.2f / %.2f)%s" % (
+            k, world, worst_wall, worst_busy, single["wall_ms"], single["busy_ms"], two_txt), file=sys.stderr, flush=True)
     return entry
 
 
@@ -92,11 +134,14 @@ def main():
     ap.add_argument("--worlds", default="1,2,4,8")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--all-ranks", action="store_true", help="every rank of each world (default: ranks 0 and R-1)")
-    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r05_sharded_rank_ms.json"))
+    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2],
+                    help="2: also ms per proof with TWO sharded proofs in flight on the rank (two ctxs, two host threads)")
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r06_sharded_rank_ms.json"))
     args = ap.parse_args()
     import halo2_lasso_amd as hl
     import bench
     ctx = hl.Context(0)
+    args.ctx2 = hl.Context(0) if args.in_flight > 1 else None
     result = {"note": __doc__.split("\n\n")[1].replace("\n", " "), "configs": {}}
     for cfg in args.configs.split(","):
         kind, n = cfg.rstrip("0123456789"), int(cfg[len(cfg.rstrip("0123456789")):])
@@ -157,16 +202,28 @@ def main():
                     hl.profile_enable(ctx, False)
                     stats1 = hl.comm_stats(ctx)
                     by_phase = hl.comm_phase_stats(ctx, reset=True)
+                    route = hl.lasso_last_route(ctx)
+                    two = None
+                    if args.in_flight > 1:
+                        ctx2 = args.ctx2
+                        pp2 = pp.view(ctx2)  # (the SRS is device memory: shared, owned by `pp`)
+                        hl.attach_comm_loopback(ctx2, rank, world, shard_bit)
+                        try:
+                            two = in_flight([ctx, ctx2], [
+                                lambda: hl.lasso_prove_sharded(pp, table, n, d_dims, hl.Keccak256Transcript()),
+                                lambda: hl.lasso_prove_sharded(pp2, table, n, d_dims, hl.Keccak256Transcript())], args.steps)
+                        finally:
+                            hl.detach_comm(ctx2)
                 finally:
                     hl.detach_comm(ctx)
                 del d_dims
                 per_rank.append({
-                    "rank": rank, "wall_ms": round(statistics.median(ts), 3),
+                    "rank": rank, "wall_ms": round(statistics.median(ts), 3), "two_in_flight_ms_per_proof": two,
                     "busy_ms": round(sum(a["ms"] for a in aggs), 3),
                     "collectives_per_proof": {k: stats1[k] - stats0[k] for k in stats0},
                     "collectives_by_phase": {k: v["collectives"] for k, v in by_phase.items() if v["collectives"]},
                     "phases_ms": {k: round(v, 3) for k, v in phases.items()},
-                    "route": hl.lasso_last_route(ctx),
+                    "route": route,
                     "top_kernels": [{"name": a["name"], "launches": a["launches"], "ms": round(a["ms"], 3)} for a in aggs[:8]]})
             worst_wall = max(r["wall_ms"] for r in per_rank)
             worst_busy = max(r["busy_ms"] for r in per_rank)
@@ -176,14 +233,21 @@ def main():
                 "wall_over_ideal": round(worst_wall / (single["wall_ms"] / world), 3),
                 "busy_over_ideal": round(worst_busy / (single["busy_ms"] / world), 3),
                 "compute_speedup_vs_single_gpu": round(single["wall_ms"] / worst_wall, 3)}
-            print("%s world %d: max rank wall %.2f ms, busy %.2f ms (single GPU %.2f / %.2f)" % (
-                cfg, world, worst_wall, worst_busy, single["wall_ms"], single["busy_ms"]), file=sys.stderr, flush=True)
+            two_txt = ""
+            if args.in_flight > 1:
+                worst_two = max(r["two_in_flight_ms_per_proof"] for r in per_rank)
+                entry["worlds"][str(world)].update(max_rank_two_in_flight_ms_per_proof=worst_two,
+                                                   two_in_flight_speedup_vs_single_gpu=round(single["wall_ms"] / worst_two, 3))
+                two_txt = ", two in flight %.2f ms per proof" % worst_two
+            print("%s world %d: max rank wall %.2f ms, busy %.2f ms (single GPU %.2f / %.2f)%s" % (
+                cfg, world, worst_wall, worst_busy, single["wall_ms"], single["busy_ms"], two_txt), file=sys.stderr, flush=True)
         result["configs"][cfg] = entry
         del pp
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     with open(args.out, "w") as f:
         json.dump(result, f, indent=1)
-    print(json.dumps({k: {w: (v["worlds"][w]["max_rank_wall_ms"], v["worlds"][w]["max_rank_busy_ms"]) for w in v["worlds"]}
+    print(json.dumps({k: {w: (v["worlds"][w]["max_rank_wall_ms"], v["worlds"][w]["max_rank_busy_ms"],
+                              v["worlds"][w].get("max_rank_two_in_flight_ms_per_proof")) for w in v["worlds"]}
                       for k, v in result["configs"].items()}))
 
 
