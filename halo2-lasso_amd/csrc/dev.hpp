@@ -664,7 +664,8 @@ void k_one_hot_table(Ctx&, size_t n, size_t hot, Fr* out);
 // reference's ExpressionRegistry calculations, util/expression/evaluator.rs:135-323): instruction i is
 //   code[2i]   = op | dst << 4 | a_kind << 8 | b_kind << 10        code[2i+1] = a_idx | b_idx << 16
 enum { PROG_ADD = 0, PROG_SUB = 1, PROG_MUL = 2, PROG_NEG = 3, PROG_MOV = 4 };
-enum { PROG_REG = 0, PROG_ATOM = 1, PROG_CONST = 2 };
+// (PROG_PAIR: table `idx` holds ONE entry per pair, the same at every evaluation point - the level of a factored eq table)
+enum { PROG_REG = 0, PROG_ATOM = 1, PROG_CONST = 2, PROG_PAIR = 3 };
 constexpr int PROG_MAX_REGS = 8;
 struct ProgRound {
   const Fr* in[SC_MAX_TABLES];  // tables of 2 * size entries (already bound)
@@ -679,9 +680,18 @@ bool jit_enabled(size_t num_vars);
 std::string jit_debug_source(const uint32_t* code, size_t num_instrs, uint32_t num_regs, uint32_t result_reg, int degree);
 const JitKernel* jit_sc_round(const Ctx&, const uint32_t* host_code, size_t num_instrs, uint32_t num_regs, uint32_t result_reg, int degree);
 unsigned jit_blocks_per_cu(const JitKernel*);
-void jit_launch(Ctx&, const JitKernel*, const ProgRound& pr, unsigned grid, size_t size, Fr* partials, const ScFinishArgs& fin);
-// evals_host[0..degree) = sum over pairs of program(tables at X), X = 1..degree; `jit`: run the compiled form
-void k_sc_round_prog(Ctx&, const ProgRound& pr, int degree, size_t size, Fr* evals_host, const JitKernel* jit = nullptr);
+void jit_launch(Ctx&, const JitKernel*, const ProgRound& pr, unsigned points, unsigned grid, size_t size, Fr* partials, const ScFinishArgs& fin);
+// evals_host[0..points) = sum over pairs of program(tables at X), X = 1..points; `jit`: run the compiled form
+void k_sc_round_prog(Ctx&, const ProgRound& pr, int points, size_t size, Fr* evals_host, const JitKernel* jit = nullptr);
+// the linear part of a zero-check beside its eq-factored part (expr.cpp): out_host[0] = sum_i coeff_i sum_b t_i[2 b],
+// out_host[1] = the same over the odd entries; queued in FRONT of the round's kernel, nobody waits for it alone
+constexpr int LIN_MAX_TABLES = 8;
+struct LinSums {
+  const Fr* t[LIN_MAX_TABLES];
+  Fr coeff[LIN_MAX_TABLES];
+  uint32_t count;
+};
+void k_lin_sums(Ctx&, const LinSums& ls, size_t size, Fr* out_host);
 enum { ROWS_ATOM_POLY = 0, ROWS_ATOM_IDENTITY = 1, ROWS_ATOM_LAGRANGE = 2 };
 struct RowsAtom {
   const Fr* table;

@@ -52,7 +52,12 @@ static void add_into(PolyMap& dst, const PolyMap& src, bool negate) {
   }
 }
 
+static ExpandedExpr expand_expr_nodes(const lh_expr& e, const HFr* challenges, size_t num_challenges, std::vector<PolyMap>* node_vals);
 ExpandedExpr expand_expr(const lh_expr& e, const HFr* challenges, size_t num_challenges) {
+  return expand_expr_nodes(e, challenges, num_challenges, nullptr);
+}
+// (node_vals: every node's expanded value, for find_eq_factor_shape)
+static ExpandedExpr expand_expr_nodes(const lh_expr& e, const HFr* challenges, size_t num_challenges, std::vector<PolyMap>* node_vals) {
   LH_REQUIRE(e.nodes && e.num_nodes >= 1 && e.num_nodes < 100000, LH_ERR_ARG, "expression: empty or too large");
   ExpandedExpr out;
   std::vector<PolyMap> val(e.num_nodes);
@@ -125,7 +130,71 @@ ExpandedExpr expand_expr(const lh_expr& e, const HFr* challenges, size_t num_cha
   out.degree = deg.back();  // Expression::degree() is structural (expression.rs:171-182)
   for (auto& kv : val.back())
     if (!kv.second.is_zero()) out.monos.push_back(ExprMono{kv.second, kv.first});
+  if (node_vals) *node_vals = std::move(val);
   return out;
+}
+
+EqFactorShape find_eq_factor_shape(const lh_expr& e, const HFr* challenges, size_t num_challenges, const ExpandedExpr& ex) {
+  EqFactorShape sh;
+  // exactly one eq atom in the whole expression
+  int eq_atom = -1;
+  for (size_t a = 0; a < ex.atoms.size(); a++)
+    if (ex.atoms[a].kind == LH_EX_EQ_XY) {
+      if (eq_atom >= 0) return sh;
+      eq_atom = (int)a;
+    }
+  if (eq_atom < 0) return sh;
+  // the product node C * eq (the last such node: the one the composition puts on top of the constraints)
+  int c_node = -1;
+  for (size_t i = 0; i < e.num_nodes; i++) {
+    const lh_expr_node& nd = e.nodes[i];
+    if (nd.op != LH_EX_PRODUCT) continue;
+    if (e.nodes[nd.b].op == LH_EX_EQ_XY) c_node = nd.a;
+    else if (e.nodes[nd.a].op == LH_EX_EQ_XY) c_node = nd.b;
+  }
+  if (c_node < 0) return sh;
+  std::vector<PolyMap> val;
+  ExpandedExpr again = expand_expr_nodes(e, challenges, num_challenges, &val);
+  // (atom ids are assigned in node order by the same routine: `again` numbers them as `ex` does)
+  if (again.atoms.size() != ex.atoms.size()) return sh;
+  const PolyMap& C = val[(size_t)c_node];
+  const PolyMap& E = val.back();
+  if (C.empty()) return sh;
+  auto with_eq = [&](const std::vector<uint16_t>& m) {
+    std::vector<uint16_t> k(m);
+    k.push_back((uint16_t)eq_atom);
+    std::sort(k.begin(), k.end());
+    return k;
+  };
+  // kappa from one monomial, then every monomial of E accounted for
+  HFr kappa = HFr::zero();
+  int c_degree = 0;
+  for (auto& kv : C) {
+    if (kv.second.is_zero()) continue;
+    for (uint16_t a : kv.first)
+      if (a == (uint16_t)eq_atom) return sh;  // eq inside C: not this shape
+    auto it = E.find(with_eq(kv.first));
+    if (it == E.end()) return sh;
+    if (kappa.is_zero()) kappa = it->second * kv.second.inv();
+    if (it->second != kappa * kv.second) return sh;
+    c_degree = std::max<int>(c_degree, (int)kv.first.size());
+  }
+  if (kappa.is_zero()) return sh;
+  size_t eq_monos = 0, c_monos = 0;
+  for (auto& kv : C) c_monos += kv.second.is_zero() ? 0 : 1;
+  for (auto& kv : E) {
+    if (kv.second.is_zero()) continue;
+    const bool has_eq = std::find(kv.first.begin(), kv.first.end(), (uint16_t)eq_atom) != kv.first.end();
+    if (has_eq) {
+      eq_monos++;
+      continue;
+    }
+    if (kv.first.size() != 1) return sh;  // the part beside eq * C must be linear in single atoms (no constant either)
+    sh.lin.push_back({kv.first[0], kv.second});
+  }
+  if (eq_monos != c_monos || sh.lin.size() > (size_t)LIN_MAX_TABLES || c_degree < 1 || c_degree + 1 != ex.degree) return sh;
+  sh.ok = true, sh.c_node = c_node, sh.eq_atom = (uint16_t)eq_atom, sh.kappa = kappa, sh.c_degree = c_degree;
+  return sh;
 }
 
 // ------------------------------------------------------------------ expression -> register program
@@ -240,8 +309,9 @@ struct ProgBuilder {
 }  // namespace
 
 // leaf_table(node index) -> table index of an atom leaf
+// (pair_table >= 0: the result is multiplied by the per-pair entry of that table - PROG_PAIR - at the end)
 static Program compile_program(const lh_expr& e, const HFr* challenges, size_t num_challenges,
-                               const std::function<int(const lh_expr_node&)>& leaf_table) {
+                               const std::function<int(const lh_expr_node&)>& leaf_table, int pair_table = -1) {
   ProgBuilder pb(e);
   const size_t N = e.num_nodes;
   pb.is_const.assign(N, 0);
@@ -284,6 +354,7 @@ static Program compile_program(const lh_expr& e, const HFr* challenges, size_t n
     }
   }
   Opnd res = pb.gen((int)N - 1);
+  if (pair_table >= 0) res = pb.binary(PROG_MUL, res, Opnd{PROG_PAIR, (uint32_t)pair_table});
   if (res.kind != PROG_REG) {
     uint32_t dst = pb.alloc_reg();
     pb.emit(PROG_MOV, dst, res, Opnd{PROG_REG, 0});
@@ -311,6 +382,25 @@ SumCheckResult sum_check_prove_expr(Ctx& c, size_t num_vars, const lh_expr& expr
   const size_t n_full = (size_t)1 << num_vars;
   const size_t n = sharded ? n_full >> sh.rho : n_full;  // entries of every (local) table
   ArenaScope scope(c.arena);
+
+  // eq factoring of the zero-check shape E = linear part + kappa eq(y, .) C (host.hpp EqFactoring, expr.hpp EqFactorShape):
+  // the streaming rounds evaluate C alone at one point fewer, weighted with ONE entry of a halving eq level per pair,
+  // instead of E over a streamed and bound eq table; the host rebuilds the reference's message.  Single-GPU sum-checks
+  // of >= 2^14 rows through the register program; LH_SC_EQ_FACTORING=0 / option sc_eq_factoring switch it off.
+  static const bool use_prog = !(getenv("LH_EXPR_MONOMIALS") && atoi(getenv("LH_EXPR_MONOMIALS")));
+  EqFactorShape shp;
+  // (below 2^14 rows the rounds are latency-bound and the levels' set-up is not worth it; LH_EXPR_EF_MIN_VARS: tests)
+  static const size_t ef_min_vars = [] {
+    const char* e = getenv("LH_EXPR_EF_MIN_VARS");
+    return e && atoi(e) >= 2 ? (size_t)atoi(e) : (size_t)14;
+  }();
+  if (c.opt.sc_eq_factoring != 0 && use_prog && !sharded && num_vars >= ef_min_vars)
+    shp = find_eq_factor_shape(expr, challenges, num_challenges, ex);
+  if (shp.ok) {  // (1 - y_j) must be invertible in every round
+    const HFr* y = ys + (size_t)ex.atoms[shp.eq_atom].a * num_vars;
+    LH_REQUIRE((size_t)ex.atoms[shp.eq_atom].a < num_ys, LH_ERR_ARG, "expression: eq_xy index out of range");
+    for (size_t i = 0; i < num_vars; i++) shp.ok = shp.ok && !(HFr::one() - y[i]).is_zero();
+  }
 
   // tables: every poly at the current rotation first (all of them are bound and reported), then one
   // table per remaining atom
@@ -342,9 +432,12 @@ SumCheckResult sum_check_prove_expr(Ctx& c, size_t num_vars, const lh_expr& expr
       }
     } else if (at.kind == LH_EX_EQ_XY) {
       LH_REQUIRE((size_t)at.a < num_ys, LH_ERR_ARG, "expression: eq_xy index out of range");
-      Fr* eq = c.arena.alloc_n<Fr>(n);
-      if (sharded) eq_xy_shard(c, sh, ys + (size_t)at.a * num_vars, num_vars, 0, eq);
-      else k_eq_xy(c, (const Fr*)(ys + (size_t)at.a * num_vars), num_vars, eq);
+      Fr* eq = nullptr;
+      if (!shp.ok) {  // (factored: the slot is filled when - if - the rounds leave the factored form, sum_check_loop)
+        eq = c.arena.alloc_n<Fr>(n);
+        if (sharded) eq_xy_shard(c, sh, ys + (size_t)at.a * num_vars, num_vars, 0, eq);
+        else k_eq_xy(c, (const Fr*)(ys + (size_t)at.a * num_vars), num_vars, eq);
+      }
       table_of[a] = (int)tables.size();
       tables.push_back(eq);
     } else if (at.kind == LH_EX_IDENTITY) {
@@ -405,7 +498,6 @@ SumCheckResult sum_check_prove_expr(Ctx& c, size_t num_vars, const lh_expr& expr
   c.sync();  // the host vectors go out of scope before the first round is queued otherwise
 
   // preferred path: the expression as a register program (bind pass + evaluation from the bound tables)
-  static const bool use_prog = !(getenv("LH_EXPR_MONOMIALS") && atoi(getenv("LH_EXPR_MONOMIALS")));
   if (use_prog) {
     auto leaf_table = [&](const lh_expr_node& nd) -> int {
       for (size_t a = 0; a < ex.atoms.size(); a++)
@@ -415,6 +507,23 @@ SumCheckResult sum_check_prove_expr(Ctx& c, size_t num_vars, const lh_expr& expr
       throw Error(LH_ERR_ARG, "expression: leaf without a table");
     };
     Program prog = compile_program(expr, challenges, num_challenges, leaf_table);
+    // the factored form's program: C times the pair's eq-level entry
+    Program progc;
+    if (shp.ok && prog.ok) {
+      lh_expr sub = expr;
+      sub.num_nodes = (size_t)shp.c_node + 1;  // (a node only refers to earlier nodes: C's subtree lies in this prefix)
+      progc = compile_program(sub, challenges, num_challenges, leaf_table, table_of[shp.eq_atom]);
+      if (progc.ok && getenv("LH_HP_DEBUG"))
+        fprintf(stderr, "[expr] factored: eq * C with C of degree %d in %zu instructions, %zu linear atoms beside it\n", shp.c_degree,
+                progc.code.size() / 2, shp.lin.size());
+    }
+    if (shp.ok && !(prog.ok && progc.ok)) {  // not factored after all: the eq table the atoms' loop left out
+      const ExprAtom& at = ex.atoms[shp.eq_atom];
+      Fr* eq = c.arena.alloc_n<Fr>(n);
+      k_eq_xy(c, (const Fr*)(ys + (size_t)at.a * num_vars), num_vars, eq);
+      tables[(size_t)table_of[shp.eq_atom]] = eq;
+      shp.ok = false;
+    }
     if (prog.ok && getenv("LH_HP_DEBUG")) {
       size_t muls = 0, atoms = 0;
       for (size_t i = 0; i < prog.code.size(); i += 2) {
@@ -438,10 +547,16 @@ SumCheckResult sum_check_prove_expr(Ctx& c, size_t num_vars, const lh_expr& expr
       pr.num_tables = (uint32_t)T;
       pr.num_instrs = (uint32_t)prog.code.size() / 2, pr.num_regs = prog.num_regs, pr.result_reg = prog.result_reg;
       pr.code = d_code, pr.consts = d_consts;
-      // large sum-checks run the program as compiled straight-line code (jit.cpp), the rest interpret it
-      const JitKernel* jit =
-          jit_enabled(num_vars) ? jit_sc_round(c, prog.code.data(), pr.num_instrs, pr.num_regs, pr.result_reg, ex.degree) : nullptr;
+      // large sum-checks run the program as compiled straight-line code (jit.cpp), the rest interpret it.  (Factored: the
+      // program of E is compiled only if a round of a large table ever needs it - a claim that is not the true sum; the small
+      // rounds behind the factored ones interpret it.)
+      const JitKernel* jit = nullptr;
+      bool jit_asked = false;
       auto prog_round = [&](const Fr* const* in, Fr* const* out, const Fr& r, bool bind, size_t size, Fr* evals_host) {
+        if (!jit_asked && jit_enabled(num_vars) && (!shp.ok || size >= ((size_t)1 << 15))) {
+          jit = jit_sc_round(c, prog.code.data(), pr.num_instrs, pr.num_regs, pr.result_reg, ex.degree);
+          jit_asked = true;
+        }
         if (bind) {
           std::vector<const Fr*> src;
           std::vector<Fr*> dst;
@@ -452,6 +567,84 @@ SumCheckResult sum_check_prove_expr(Ctx& c, size_t num_vars, const lh_expr& expr
         for (size_t i = 0; i < T; i++) pr.in[i] = bind ? out[i] : in[i];
         k_sc_round_prog(c, pr, ex.degree, size, evals_host, jit);
       };
+      // ---- the factored form: C's program, the linear part's pair sums beside it
+      if (shp.ok) {
+        uint32_t* d_codec = c.arena.alloc_n<uint32_t>(progc.code.size());
+        Fr* d_constsc = c.arena.alloc_n<Fr>(std::max<size_t>(progc.consts.size(), 1));
+        LH_HIP(hipMemcpyAsync(d_codec, progc.code.data(), progc.code.size() * 4, hipMemcpyHostToDevice, c.stream));
+        if (!progc.consts.empty())
+          LH_HIP(hipMemcpyAsync(d_constsc, progc.consts.data(), progc.consts.size() * sizeof(Fr), hipMemcpyHostToDevice, c.stream));
+        c.sync();
+        ProgRound prc;
+        memset(&prc, 0, sizeof(prc));
+        prc.num_tables = (uint32_t)T;
+        prc.num_instrs = (uint32_t)progc.code.size() / 2, prc.num_regs = progc.num_regs, prc.result_reg = progc.result_reg;
+        prc.code = d_codec, prc.consts = d_constsc;
+        const JitKernel* jitc =
+            jit_enabled(num_vars) ? jit_sc_round(c, progc.code.data(), prc.num_instrs, prc.num_regs, prc.result_reg, ex.degree - 1) : nullptr;
+        const size_t t_eq = (size_t)table_of[shp.eq_atom];
+        const HFr* y = ys + (size_t)ex.atoms[shp.eq_atom].a * num_vars;
+        EqFactoring ef;
+        {
+          std::vector<HFr> d(num_vars), pre(num_vars + 1);
+          pre[0] = HFr::one();
+          for (size_t i = 0; i < num_vars; i++) d[i] = HFr::one() - y[i], pre[i + 1] = pre[i] * d[i];
+          HFr inv = pre[num_vars].inv();  // (1 - y_j)^-1 for all rounds with one inversion
+          ef.inv_1my.resize(num_vars);
+          for (size_t i = num_vars; i-- > 0;) {
+            ef.inv_1my[i] = inv * pre[i];
+            inv = inv * d[i];
+          }
+        }
+        ef.per_term = false, ef.trusted_claim = false;
+        ef.kappa = shp.kappa;
+        const HFr kappa_inv = shp.kappa.inv();
+        ef.c = sum * kappa_inv;  // (round 0 takes the linear part's sum off it, below)
+        EqFactoring::One one;
+        one.table = t_eq, one.y = y, one.S = one.S_prev = HFr::one();
+        {
+          // E_0 = eq table of y[1..], then every lower level by adding pairs (sumcheck.cpp: the same tables)
+          const size_t half = n >> 1;
+          Fr* buf = c.arena.alloc_n<Fr>(2 * half);
+          one.level.resize(num_vars);
+          size_t off = 0;
+          for (size_t jl = 0; jl < num_vars; jl++) one.level[jl] = buf + off, off += half >> jl;
+          k_eq_xy(c, (const Fr*)(y + 1), num_vars - 1, buf);
+          std::vector<Fr*> lower;
+          for (size_t jl = 1; jl < num_vars; jl++) lower.push_back((Fr*)one.level[jl]);
+          k_eq_levels(c, one.level[0], half, lower.data(), lower.size());
+        }
+        ef.eqs.push_back(one);
+        // (factored down to the last round: every eq level exists, the compiled program of C serves every size, and the
+        //  program of E - with its eq table - is never needed)
+        ef.streams = [](bool, size_t) { return true; };
+        LinSums ls;
+        memset(&ls, 0, sizeof(ls));
+        ls.count = (uint32_t)shp.lin.size();
+        for (uint32_t i = 0; i < ls.count; i++) ls.coeff[i] = dev(shp.lin[i].second);
+        ef.round = [&](const Fr* const* in, Fr* const* out, const Fr& r, bool bind, size_t size, size_t round, int points,
+                       Fr* out_host) {
+          ArenaScope round_scope(c.arena);
+          if (bind) {
+            std::vector<const Fr*> src;
+            std::vector<Fr*> dst;
+            for (size_t i = 0; i < T; i++)
+              if (used[i] && i != t_eq) src.push_back(in[i]), dst.push_back(out[i]);
+            k_fix_var_multi(c, src.data(), dst.data(), src.size(), 4 * size, r);
+          }
+          for (size_t i = 0; i < T; i++) prc.in[i] = bind ? out[i] : in[i];
+          prc.in[t_eq] = ef.eqs[0].level[round];
+          if (ls.count) {
+            for (uint32_t i = 0; i < ls.count; i++) ls.t[i] = prc.in[table_of[shp.lin[i].first]];
+            k_lin_sums(c, ls, size, out_host + 12);
+          }
+          k_sc_round_prog(c, prc, points, size, out_host, jitc);
+          ef.lin0 = ls.count ? hst(out_host[12]) : HFr::zero();
+          ef.lin1 = ls.count ? hst(out_host[13]) : HFr::zero();
+          if (round == 0) ef.c = (sum - ef.lin0 - ef.lin1) * kappa_inv;
+        };
+        return sum_check_loop(c, LH_SC_EVALUATIONS, num_vars, ex.degree, tables, used, num_polys, sum, tr, sharded, prog_round, nullptr, &ef);
+      }
       return sum_check_loop(c, LH_SC_EVALUATIONS, num_vars, ex.degree, tables, used, num_polys, sum, tr, sharded, prog_round);
     }
   }

@@ -19,6 +19,20 @@ struct ExpandedExpr {
   int degree = 0;  // Expression::degree() of the original AST
 };
 ExpandedExpr expand_expr(const lh_expr& e, const HFr* challenges, size_t num_challenges);
+// The zero-check shape  E = (linear part) + kappa * eq(y, .) * C  (preprocessor.rs:43-57: DP([h_0, .., h_{L-1}, DP(constraints,
+// alpha) * eq_0], alpha)): `c_node` is the AST node of C (a factor of the one product node that has the eq leaf as its other
+// factor), the linear part a sum of single atoms.  Found structurally and then VERIFIED on the expanded monomials - E's
+// monomials are exactly the linear part's plus kappa * eq * (C's monomials) - so a tree of another shape is simply not
+// factored.  ok = false: no such shape.
+struct EqFactorShape {
+  bool ok = false;
+  int c_node = -1;
+  uint16_t eq_atom = 0;  // id into ExpandedExpr::atoms
+  HFr kappa;
+  std::vector<std::pair<uint16_t, HFr>> lin;  // (atom id, coefficient)
+  int c_degree = 0;
+};
+EqFactorShape find_eq_factor_shape(const lh_expr& e, const HFr* challenges, size_t num_challenges, const ExpandedExpr& ex);
 
 uint32_t bh_primitive(size_t num_vars);
 uint32_t bh_x_inv(size_t num_vars);

@@ -164,9 +164,18 @@ struct EqFactoring {
   std::vector<One> eqs;    // global-eq shape: one entry; per-term shape (sum_m eq_m * poly_m): one per term, in term order
   bool per_term = false;
   bool trusted_claim = false;  // the claim is known to be the true sum: no check (and no extra point) in round 0
+  // set by the round loop when round 0 found the claim NOT to be the true sum (the reference still sends the true p(1..D),
+  // eval.rs:129 - benches/zero_check.rs proves a false claim over random tables): every round then evaluates q at D points
+  // and takes nothing from the claim; the eq table stays factored
+  bool untrusted = false;
   std::vector<HFr> inv_1my;  // global-eq shape: (1 - y_j)^-1 for every round
   HFr c;                     // global-eq shape: claim / S_j
   HFr add_const;             // set by `round`: a constant the kernel left out of every q value (ScRwPairs::const_total)
+  // global-eq shape beside a LINEAR part (the zero-check of HyperPlonk, expr.cpp): the round polynomial is
+  //   p(X) = A(X) + kappa S_j eq(y_j, X) q(X),  A(X) = lin0 + X (lin1 - lin0)
+  // with lin0 / lin1 = the linear part's sums over the even / odd entries of this round's tables, set by `round`;
+  // `c` then is the eq part's claim alone (round 0: set by `round` too, (sum - lin0 - lin1) / kappa)
+  HFr kappa = HFr::one(), lin0 = HFr::zero(), lin1 = HFr::zero();
   // would this round run the streaming kernel (else the eq tables are materialised and the standard path takes over)
   std::function<bool(bool bind, size_t size)> streams;
   // launches the factored round; device output: q(1..points) (global-eq shape; points = D - 1, or D in round 0 where the

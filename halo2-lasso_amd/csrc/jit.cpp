@@ -50,6 +50,7 @@ std::string operand(uint32_t kind, uint32_t idx) {
   std::ostringstream o;
   if (kind == PROG_REG) o << "r" << idx;
   else if (kind == PROG_CONST) o << "a.consts[" << idx << "]";
+  else if (kind == PROG_PAIR) o << "p" << idx;
   else o << "t" << idx;
   return o.str();
 }
@@ -86,8 +87,12 @@ std::string generate(const uint32_t* code, size_t num_instrs, uint32_t num_regs,
        "    const unsigned long long b = base + lane;\n"
        "    if (b < a.size) {\n";
   for (uint32_t r = 0; r < num_regs; r++) s << "      Fr r" << r << ";\n";
-  std::map<uint32_t, bool> loaded;
+  std::map<uint32_t, bool> loaded, loaded_pair;
   auto need = [&](uint32_t kind, uint32_t idx) {
+    if (kind == PROG_PAIR && !loaded_pair[idx]) {  // one entry per pair, the same at every evaluation point
+      loaded_pair[idx] = true;
+      s << "      const Fr p" << idx << " = a.in[" << idx << "][b];\n";
+    }
     if (kind != PROG_ATOM || loaded[idx]) return;
     loaded[idx] = true;
     s << "      const Fr t" << idx << " = at_x(a.in[" << idx << "], b, wave);\n";
@@ -454,7 +459,9 @@ const JitKernel* jit_sc_round(const Ctx& c, const uint32_t* code, size_t num_ins
 
 unsigned jit_blocks_per_cu(const JitKernel* k) { return k->blocks_per_cu; }
 
-void jit_launch(Ctx& c, const JitKernel* k, const ProgRound& pr, unsigned grid, size_t size, Fr* partials,
+// (`points`: the launch evaluates at X = 1..points - the kernel reads it off its grid: the expression's degree, or fewer in
+//  an eq-factored round)
+void jit_launch(Ctx& c, const JitKernel* k, const ProgRound& pr, unsigned points, unsigned grid, size_t size, Fr* partials,
                 const ScFinishArgs& fin) {
   JitArgs a;
   for (int i = 0; i < SC_MAX_TABLES; i++) a.in[i] = pr.in[i];
@@ -464,7 +471,7 @@ void jit_launch(Ctx& c, const JitKernel* k, const ProgRound& pr, unsigned grid, 
   a.fin = fin;
   size_t bytes = sizeof(a);
   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &bytes, HIP_LAUNCH_PARAM_END};
-  LH_HIP(hipModuleLaunchKernel(k->fn, k->degree, grid, 1, k->threads, 1, 1, 0, c.stream, nullptr, extra));
+  LH_HIP(hipModuleLaunchKernel(k->fn, points, grid, 1, k->threads, 1, 1, 0, c.stream, nullptr, extra));
 }
 
 }  // namespace lh

@@ -276,6 +276,7 @@ __device__ __forceinline__ Fr prog_operand(const ProgRound& pr, const uint32_t* 
                                            size_t b, int xm1, uint32_t nthreads) {
   if (kind == PROG_REG) return prog_reg_load(regs, idx, nthreads);
   if (kind == PROG_CONST) return pr.consts[idx];
+  if (kind == PROG_PAIR) return pr.in[idx][b];
   const Fr* t = pr.in[idx];
   const Fr lo = t[2 * b], hi = t[2 * b + 1];
   Fr v = hi;
@@ -352,8 +353,9 @@ __global__ __launch_bounds__(512) void sc_round_prog_kernel(ProgRound pr, size_t
   if (threadIdx.x == 0) publish_round(fin, D);
 }
 
+// (`degree`: the evaluation points X = 1..degree of this launch - the expression's degree, or one fewer in an eq-factored round)
 void k_sc_round_prog(Ctx& c, const ProgRound& pr, int degree, size_t size, Fr* evals_host, const JitKernel* jit) {
-  LH_REQUIRE(degree >= 2 && degree <= 8, LH_ERR_ARG, "sum-check degree must be in 2..8");
+  LH_REQUIRE(degree >= 1 && degree <= 8, LH_ERR_ARG, "sum-check round: 1..8 evaluation points");
   LH_REQUIRE(size >= 1 && pr.num_regs >= 1 && pr.num_regs <= PROG_MAX_REGS, LH_ERR_ARG, "sum-check program: bad shape");
   const uint32_t seq = c.next_seq();
   ArenaScope scope(c.arena);
@@ -382,19 +384,76 @@ void k_sc_round_prog(Ctx& c, const ProgRound& pr, int degree, size_t size, Fr* e
   const size_t cap = jit ? std::max<size_t>(1, (size_t)c.num_cus * (size_t)per_cu / (size_t)degree) : (size_t)c.num_cus * (size_t)per_cu;
   if (g > cap) g = cap;
   evals_host = c.round_out(evals_host);  // (sharded rounds: the sums stay on the device, sumcheck.cpp)
-  Fr* partials = (g == 1 && !jit) ? evals_host : c.arena.alloc_n<Fr>(g * degree);
+  // (compiled form: a workgroup is four groups of 64 pairs, each with a partial sum per point)
+  Fr* partials = (g == 1 && !jit) ? evals_host : c.arena.alloc_n<Fr>((jit ? 4 : 1) * g * degree);
   const ScFinishArgs fin = c.finish_for((uint32_t)(jit ? g * degree : g), evals_host, seq);
+  // (the compiled kernel draws a ticket even when it is the launch's only workgroup - one point of an eq-factored round over a
+  //  few pairs -, which finish_for does not count)
+  if (jit && g * (size_t)degree == 1) c.ticket_base += 1;
   {
     char name[40];
     snprintf(name, sizeof name, jit ? "sc_round_jit<%d>" : "sc_round_prog<%d>", degree);
     ProfScope ps(c, name, 64.0 * (double)size * pr.num_tables, 0, (double)size);
     if (jit)
-      jit_launch(c, jit, pr, (unsigned)g, size, partials, fin);
+      jit_launch(c, jit, pr, (unsigned)degree, (unsigned)g, size, partials, fin);
     else
       hipLaunchKernelGGL(sc_round_prog_kernel, dim3((unsigned)g), dim3(threads), lds_bytes, c.stream, pr, size, degree,
                          partials, fin);
   }
   c.wait_round(seq);
+}
+
+// ------------------------------------------------------------------ plain pair sums of a few tables (the zero-check's linear part)
+__global__ __launch_bounds__(256) void lin_sums_kernel(LinSums ls, size_t size, Fr* __restrict__ partials, ScFinishArgs fin) {
+  __shared__ Fr lds[4];
+  __shared__ int is_last;
+  Fr ev = Fr::zero(), od = Fr::zero();
+  for (uint32_t i = 0; i < ls.count; i++) {
+    const Fr* __restrict__ t = ls.t[i];
+    Fr e = Fr::zero(), o = Fr::zero();
+    for (size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x; b < size; b += (size_t)gridDim.x * blockDim.x) {
+      e = add(e, t[2 * b]);
+      o = add(o, t[2 * b + 1]);
+    }
+    ev = add(ev, mul(e, ls.coeff[i]));
+    od = add(od, mul(o, ls.coeff[i]));
+  }
+  ev = block_reduce_sum(ev, lds);
+  od = block_reduce_sum(od, lds);
+  if (gridDim.x == 1) {
+    if (threadIdx.x == 0) {
+      fin.out_host[0] = ev, fin.out_host[1] = od;
+      publish_round(fin, 2);
+    }
+    return;
+  }
+  if (threadIdx.x == 0) {
+    partials[(size_t)blockIdx.x * 2] = ev, partials[(size_t)blockIdx.x * 2 + 1] = od;
+    __threadfence();
+    const uint32_t t = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = t == fin.last_ticket;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  for (int x = 0; x < 2; x++) {
+    Fr a2 = Fr::zero();
+    for (uint32_t i = threadIdx.x; i < gridDim.x; i += blockDim.x) a2 = add(a2, partials[(size_t)i * 2 + x]);
+    a2 = block_reduce_sum(a2, lds);
+    if (threadIdx.x == 0) fin.out_host[x] = a2;
+  }
+  if (threadIdx.x == 0) publish_round(fin, 2);
+}
+void k_lin_sums(Ctx& c, const LinSums& ls, size_t size, Fr* out_host) {
+  LH_REQUIRE(ls.count >= 1 && ls.count <= (uint32_t)LIN_MAX_TABLES && size >= 1, LH_ERR_ARG, "lin_sums: bad shape");
+  const size_t g = std::min<size_t>((size + 255) / 256, (size_t)c.num_cus * 4);
+  // (nobody waits for this launch alone: the round's kernel behind it publishes the sequence number the host waits for;
+  //  the partials live as long as the caller's arena scope - the round's)
+  Fr* partials = c.arena.alloc_n<Fr>(2 * g);
+  const uint32_t seq = c.next_seq();
+  const ScFinishArgs fin = c.finish_for((uint32_t)g, c.round_out(out_host), seq);
+  ProfScope ps(c, "lin_sums", 64.0 * (double)size * ls.count, 0, (double)size);
+  hipLaunchKernelGGL(lin_sums_kernel, dim3((unsigned)g), dim3(256), 0, c.stream, ls, size, partials, fin);
 }
 
 // ------------------------------------------------------------------ row-wise evaluation of a monomial list

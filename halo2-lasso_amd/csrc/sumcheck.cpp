@@ -303,7 +303,7 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
       comm_gather_tables(c, block, L, len, (size_t)1 << (j - round), rep.data());
       c.route.v[RouteStats::SHARD_EXCHANGES]++;
       for (size_t k = 0; k < L; k++) cur[live[k]] = rep[k];
-      if (ef_on && tail_ok && ef->resident_tail && !ef->per_term && full >= 4 && full <= ((size_t)GKR_CAP * GKR_CAP)) {
+      if (ef_on && tail_ok && ef->resident_tail && !ef->per_term && !ef->untrusted && full >= 4 && full <= ((size_t)GKR_CAP * GKR_CAP)) {
         // replicated from here on, and small enough for the resident kernel: its eq level of THIS round (the eq table over
         // the variables after it - no shard coordinate is left among them) is built on every rank, and the rest of the
         // sum-check runs inside the kernel, factored, instead of as launched rounds over materialised eq tables
@@ -333,7 +333,7 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
       // the factored rounds go on INSIDE the resident kernel once the tables fit it (kernels_gkr.hip tail mode): no eq
       // table is materialised, no round is launched any more.  (Not in round 0 of a claim that has yet to be checked.)
       const size_t n0 = bind ? len >> 1 : len;
-      if (n0 >= 2 && n0 <= ((size_t)GKR_CAP * GKR_CAP) && (round > 0 || ef->trusted_claim)) {
+      if (n0 >= 2 && n0 <= ((size_t)GKR_CAP * GKR_CAP) && (round > 0 || ef->trusted_claim) && !ef->untrusted) {
         resolve_claim();
         if (ef->resident_tail(cur, bind, r_prev, n0, round, claim, tr, res)) return res;
         resident_ok = false;  // (the kernel did not start, or a coefficient is zero: launched rounds and the generic tail)
@@ -345,7 +345,7 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
     // factoring - and with it the resident tail - to materialised eq tables.  (Layers of four trees at 2^20 lookups leave the
     // streaming size at 2^15 entries per table, one round short of the resident kernel's 2^14: every one of them used to
     // fall back to eq tables, launched small rounds and the generic tail.)
-    const bool keep_factored = tail_ok && resident_ok && ef_on && ef->resident_tail && !ef->per_term &&
+    const bool keep_factored = tail_ok && resident_ok && ef_on && ef->resident_tail && !ef->per_term && !ef->untrusted &&
                                (sh || (bind ? len >> 1 : len) > ((size_t)GKR_CAP * GKR_CAP));
     if (ef_on && !keep_factored && (tail_now || !ef->streams(bind, bind ? len >> 2 : len >> 1))) {
       // the rounds leave the streaming kernel: materialise every factored eq table in the form the standard path
@@ -523,34 +523,28 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
     } else if (ef_on) {
       // global-eq shape, round 0: one point more (q at 1..D determines q(0) too), so that the claim can be CHECKED instead
       // of trusted: with a claim that is not the true sum the reference still sends the true p(1..D), and so must we
+      // (a claim found untrue in round 0 - EqFactoring::untrusted - costs that point in every round: q(1..D) is all of q)
       const bool check_claim = !ef->per_term && round == 0 && !ef->trusted_claim;
+      const bool all_points = check_claim || (!ef->per_term && ef->untrusted);
+      const int npoints = all_points ? degree : degree - 1;
       ef->add_const = HFr::zero();
-      ef->round(cur.data(), dst.data(), dev(r_prev), bind, size, round, check_claim ? degree : degree - 1, evals_host);
+      ef->round(cur.data(), dst.data(), dev(r_prev), bind, size, round, npoints, evals_host);
       factored_round = true;
       c.route.v[RouteStats::EF_ROUNDS]++;
       if (!ef->add_const.is_zero())
-        for (int x = 0; x < degree - 1; x++) evals_host[x] = dev(hst(evals_host[x]) + ef->add_const);
-      if (check_claim) {
+        for (int x = 0; x < npoints; x++) evals_host[x] = dev(hst(evals_host[x]) + ef->add_const);
+      if (all_points) {
         EqFactoring::One& e = ef->eqs[0];
         std::vector<HFr> shifted(degree);  // t -> q(t + 1), t = 0..D-1
         for (int x = 0; x < degree; x++) shifted[x] = hst(evals_host[x]);
         const HFr q0 = interpolate_evals(shifted, HFr::zero() - HFr::one());
         const HFr y0 = e.y[0];
-        if ((HFr::one() - y0) * q0 + y0 * shifted[0] != ef->c) {
-          // not the true sum: every round takes the standard path (eq tables built in full)
-          for (EqFactoring::One& one : ef->eqs) {
-            Fr* tab = c.arena.alloc_n<Fr>(len);
-            k_eq_xy(c, (const Fr*)one.y, num_vars, tab);
-            cur[one.table] = tab;
-          }
-          ef_on = factored_round = false;
-          c.route.v[RouteStats::EF_ROUNDS]--, c.route.v[RouteStats::STD_ROUNDS]++;
-          round_fn(cur.data(), dst.data(), dev(r_prev), bind, size, evals_host);
-        } else {
-          e.q.assign(degree, HFr::zero());
-          e.q[0] = q0;
-          for (int x = 1; x < degree; x++) e.q[x] = shifted[x - 1];
-        }
+        // not the true sum: the factored rounds go on, with nothing taken from the claim (until round 5 every round then
+        // took the standard path over an eq table built in full - and round 0 ran twice)
+        if (check_claim && (HFr::one() - y0) * q0 + y0 * shifted[0] != ef->c) ef->untrusted = true;
+        e.q.assign(degree, HFr::zero());
+        e.q[0] = q0;
+        for (int x = 1; x < degree; x++) e.q[x] = shifted[x - 1];
       }
     } else {
       round_fn(cur.data(), dst.data(), dev(r_prev), bind, size, evals_host);
@@ -569,7 +563,7 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
       if (!ef->per_term) {
         EqFactoring::One& e = ef->eqs[0];
         const HFr yj = e.y[round];
-        if (round > 0 || ef->trusted_claim) {
+        if ((round > 0 || ef->trusted_claim) && !ef->untrusted) {
           e.q.assign(degree, HFr::zero());  // q has degree D - 1: D values q(0..D-1)
           for (int x = 1; x < degree; x++) e.q[x] = hst(evals_host[x - 1]);
           e.q[0] = (ef->c - yj * e.q[1]) * ef->inv_1my[round];
@@ -577,7 +571,7 @@ SumCheckResult sum_check_loop(Ctx& c, int prover_kind, size_t num_vars, int degr
         for (int x = 1; x <= degree; x++) {
           const HFr fx = HFr::from_u64((uint64_t)x);
           const HFr qx = x < degree ? e.q[x] : interpolate_evals(e.q, fx);
-          std_sums[x - 1] = dev(e.S * eq_at(yj, fx) * qx);
+          std_sums[x - 1] = dev(ef->kappa * e.S * eq_at(yj, fx) * qx + ef->lin0 + fx * (ef->lin1 - ef->lin0));
         }
         const HFr r = message(std_sums);
         ef->c = interpolate_evals(e.q, r);

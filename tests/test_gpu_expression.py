@@ -154,3 +154,21 @@ def test_runtime_compiled_round_kernel_matches_golden():
     m = re.search(r"(\d+) passed", r.stdout)
     assert m and int(m.group(1)) >= 15, r.stdout[-500:]
     assert "[expr] compiled a" in r.stderr + r.stdout  # the compiled form really ran
+
+
+@pytest.mark.heavy(est=40)
+@pytest.mark.parametrize("env", [{"LH_EXPR_EF_MIN_VARS": "2"}, {"LH_EXPR_EF_MIN_VARS": "2", "LH_EXPR_JIT_MIN_VARS": "2"}])
+def test_eq_factored_expression_rounds_match_the_oracle(env):
+    """The zero-check shape  linear part + kappa eq(y, .) C  (preprocessor.rs:43-57) runs its rounds factored from 2^14 rows on
+    (csrc/expr.cpp: C's program times one eq-level entry per pair, the linear part's pair sums beside it, one evaluation
+    point fewer; a claim that is not the true sum - most of this file's random tables - keeps the factored rounds and pays
+    the point).  Here every test of this file and the golden vectors run again in a child process with the threshold at
+    2^2 rows: interpreted, then runtime-compiled - byte for byte the oracle's messages either way."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_expression.py", "tests/test_gpu_golden.py",
+                          "tests/test_gpu_hyperplonk.py", "-m", "gpu", "-x", "-q",
+                          "-k", "(lagrange or rotation or zero_check or golden or hyperplonk) and not runtime_compiled and not fallback "
+                                "and not eq_factored and not sharded"],
+                         cwd=root, env=dict(os.environ, **env), capture_output=True, text=True, timeout=1500)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]

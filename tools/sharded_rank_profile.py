@@ -96,15 +96,16 @@ def hyperplonk_keccak(hl, bench, ctx, k, args):
                 wall, aggs = timed(lambda: hp.HyperPlonk.prove_sharded(pp_local, circ.instances, wit_local, hl.Keccak256Transcript()))
                 stats1 = hl.comm_stats(ctx)
                 if args.in_flight > 1:
-                    ctx2 = args.ctx2
-                    hl.attach_comm_loopback(ctx2, rank, world, shard_bit)
+                    for c2 in args.more:
+                        hl.attach_comm_loopback(c2, rank, world, shard_bit)
                     try:
-                        pp2 = hp.HyperPlonk.rebind_param(pp_local, ctx2)
-                        two = in_flight([ctx, ctx2], [
-                            lambda: hp.HyperPlonk.prove_sharded(pp_local, circ.instances, wit_local, hl.Keccak256Transcript()),
-                            lambda: hp.HyperPlonk.prove_sharded(pp2, circ.instances, wit_local, hl.Keccak256Transcript())], args.steps)
+                        views = [pp_local] + [hp.HyperPlonk.rebind_param(pp_local, c2) for c2 in args.more]
+                        two = in_flight([ctx] + args.more, [
+                            (lambda p=p: hp.HyperPlonk.prove_sharded(p, circ.instances, wit_local, hl.Keccak256Transcript())) for p in views],
+                            args.steps)
                     finally:
-                        hl.detach_comm(ctx2)
+                        for c2 in args.more:
+                            hl.detach_comm(c2)
             finally:
                 hl.detach_comm(ctx)
             del pp_local, wit_local
@@ -122,7 +123,7 @@ def hyperplonk_keccak(hl, bench, ctx, k, args):
             worst_two = max(r["two_in_flight_ms_per_proof"] for r in per_rank)
             entry["worlds"][str(world)].update(max_rank_two_in_flight_ms_per_proof=worst_two,
                                                two_in_flight_speedup_vs_single_gpu=round(single["wall_ms"] / worst_two, 3))
-            two_txt = ", two in flight %.2f ms per proof" % worst_two
+            two_txt = ", %d in flight %.2f ms per proof" % (args.in_flight, worst_two)
         print("keccak%d world %d: max rank wall %.2f ms, busy %.2f ms (single GPU %.2f / %.2f)%s" % (
             k, world, worst_wall, worst_busy, single["wall_ms"], single["busy_ms"], two_txt), file=sys.stderr, flush=True)
     return entry
@@ -134,14 +135,14 @@ def main():
     ap.add_argument("--worlds", default="1,2,4,8")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--all-ranks", action="store_true", help="every rank of each world (default: ranks 0 and R-1)")
-    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2],
-                    help="2: also ms per proof with TWO sharded proofs in flight on the rank (two ctxs, two host threads)")
+    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2, 3, 4],
+                    help="k > 1: also ms per proof with k sharded proofs in flight on the rank (k ctxs, a host thread each)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r06_sharded_rank_ms.json"))
     args = ap.parse_args()
     import halo2_lasso_amd as hl
     import bench
     ctx = hl.Context(0)
-    args.ctx2 = hl.Context(0) if args.in_flight > 1 else None
+    args.more = [hl.Context(0) for _ in range(args.in_flight - 1)]
     result = {"note": __doc__.split("\n\n")[1].replace("\n", " "), "configs": {}}
     for cfg in args.configs.split(","):
         kind, n = cfg.rstrip("0123456789"), int(cfg[len(cfg.rstrip("0123456789")):])
@@ -205,15 +206,15 @@ def main():
                     route = hl.lasso_last_route(ctx)
                     two = None
                     if args.in_flight > 1:
-                        ctx2 = args.ctx2
-                        pp2 = pp.view(ctx2)  # (the SRS is device memory: shared, owned by `pp`)
-                        hl.attach_comm_loopback(ctx2, rank, world, shard_bit)
+                        views = [pp] + [pp.view(c2) for c2 in args.more]  # (the SRS is device memory: shared, owned by `pp`)
+                        for c2 in args.more:
+                            hl.attach_comm_loopback(c2, rank, world, shard_bit)
                         try:
-                            two = in_flight([ctx, ctx2], [
-                                lambda: hl.lasso_prove_sharded(pp, table, n, d_dims, hl.Keccak256Transcript()),
-                                lambda: hl.lasso_prove_sharded(pp2, table, n, d_dims, hl.Keccak256Transcript())], args.steps)
+                            two = in_flight([ctx] + args.more, [
+                                (lambda p=p: hl.lasso_prove_sharded(p, table, n, d_dims, hl.Keccak256Transcript())) for p in views], args.steps)
                         finally:
-                            hl.detach_comm(ctx2)
+                            for c2 in args.more:
+                                hl.detach_comm(c2)
                 finally:
                     hl.detach_comm(ctx)
                 del d_dims
@@ -238,7 +239,7 @@ def main():
                 worst_two = max(r["two_in_flight_ms_per_proof"] for r in per_rank)
                 entry["worlds"][str(world)].update(max_rank_two_in_flight_ms_per_proof=worst_two,
                                                    two_in_flight_speedup_vs_single_gpu=round(single["wall_ms"] / worst_two, 3))
-                two_txt = ", two in flight %.2f ms per proof" % worst_two
+                two_txt = ", %d in flight %.2f ms per proof" % (args.in_flight, worst_two)
             print("%s world %d: max rank wall %.2f ms, busy %.2f ms (single GPU %.2f / %.2f)%s" % (
                 cfg, world, worst_wall, worst_busy, single["wall_ms"], single["busy_ms"], two_txt), file=sys.stderr, flush=True)
         result["configs"][cfg] = entry
