@@ -458,6 +458,40 @@ def main_hyperplonk(args, hdist, dist, rank, local_rank, world):
         if rank == 0:
             out["comm_collectives_per_run"] = stats
             out["sharded_proof_equals_single_gpu"] = prove(single=True).into_proof() == tr.into_proof()
+        if not args.no_extra:
+            # TWO sharded proofs in flight per rank (main(): sharded_two_in_flight): a second ctx with its own communicator, a
+            # host thread each - at this size a sharded proof IS its latency-bound floor, which a second proof fills
+            try:
+                import threading
+                ctx2 = hl.Context(int(os.environ.get("LH_DEVICE", local_rank)))
+                pp2 = hp.HyperPlonk.rebind_param(pp_local, ctx2)
+                transport2 = hdist.attach_sharded(ctx2, dist, shard_bit, group=hdist.flight_group(dist))
+
+                def flight(p, n_proofs):
+                    for _ in range(n_proofs):
+                        hp.HyperPlonk.prove_sharded(p, circ.instances, wit_local, hl.Keccak256Transcript())
+                tif_steps = max(1, min(args.steps, 5))
+                elapsed2 = None
+                for n_proofs in (1, tif_steps):
+                    th = [threading.Thread(target=flight, args=(p, n_proofs)) for p in (pp_local, pp2)]
+                    ctx2.sync()
+                    barrier()
+                    t0 = time.perf_counter()
+                    for t in th:
+                        t.start()
+                    for t in th:
+                        t.join()
+                    ctx.sync(), ctx2.sync()
+                    elapsed2 = hdist.max_over_ranks(dist, time.perf_counter() - t0)
+                    hdist.barrier(dist)
+                hl.detach_comm(ctx2)
+                if rank == 0:
+                    out["sharded_two_in_flight"] = {"ms_per_proof": round(elapsed2 * 1e3 / (2 * tif_steps), 3),
+                                                    "steps_per_flight": tif_steps, "transport": transport2}
+                del pp2, ctx2
+            except Exception as e:
+                if rank == 0:
+                    out["sharded_two_in_flight"] = {"error": "%s: %s" % (type(e).__name__, e)}
         hl.detach_comm(ctx)
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only

@@ -194,3 +194,4 @@ def test_bench_hyperplonk_keccak_two_ranks():
     assert d["metric"] == "hyperplonk_prove_time_ms" and d["n_gpus"] == 2 and d["scaling"] == "strong"
     assert d["config"]["proofs_per_step"] == 1 and d["sharded_proof_equals_single_gpu"] is True
     assert abs(d["value"] - d["ms_per_step"]) <= 1e-3
+    assert d["sharded_two_in_flight"]["ms_per_proof"] > 0, d["sharded_two_in_flight"]  # two sharded proofs in flight per rank

@@ -561,3 +561,9 @@ def test_bench_two_ranks_launched_like_the_driver():
         del os.environ["LH_BENCH_CONFIG3_LOG_N"]
     assert d["scaling"] == "strong" and d["sharded_proof_equals_single_gpu"] is True
     assert d["config3_2p26_range_sharded"]["ms_per_proof"] > 0 and d["replicas"]["proofs_per_step"] == 2
+    # ... the A/B of the two link-dependent switches (four runs, a best one; byte equality is asserted inside bench.py when the
+    # headline is re-timed with it) and two sharded proofs in flight per rank
+    assert len(d["ab"]["runs"]) == 4 and all(r["ms_per_proof"] > 0 for r in d["ab"]["runs"]) and "error" not in d["ab"], d["ab"]
+    assert {(r["comm_round"], r["shard_exchange_log"]) for r in d["ab"]["runs"]} == {(0, 19), (0, 20), (1, 19), (1, 20)}
+    assert d["ab"]["best"]["ms_per_proof"] <= min(r["ms_per_proof"] for r in d["ab"]["runs"]) + 1e-6
+    assert d["sharded_two_in_flight"]["ms_per_proof"] > 0, d["sharded_two_in_flight"]
