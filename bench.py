@@ -252,14 +252,38 @@ def dominant(aggs):
     return max(moving or aggs, key=lambda a: a["ms"])
 
 
-def roofline_objects(hl, ctx, aggs, traffic=(None, None)):
+def live_accumulate(recs):
+    """the live records of the timed region (lh_profile_enable(ctx, 2): a HIP-event pair around every msm_accumulate0
+    launch on its own stream, nothing synchronised) -> {launches, ms, bytes, muls, items, batches, batch_ms}: `ms` adds the
+    launches' SPANS (the two halves of a pipelined batch run at the same time: what a kernel trace adds up too), `batch_ms`
+    the batches' spans (first start to last end: the time the chip spent on them)"""
+    one = [r for r in recs if r["name"] == "msm_accumulate0"]
+    bat = [r for r in recs if r["name"] == "msm_accumulate0/batch"]
+    if not one or not bat:
+        return None
+    return {"launches": len(one), "ms": sum(r["ms"] for r in one), "bytes": sum(r["bytes"] for r in one),
+            "muls": sum(r["muls"] for r in one), "items": sum(r["items"] for r in one), "batches": len(bat),
+            "batch_ms": sum(r["ms"] for r in bat)}
+
+
+def roofline_objects(hl, ctx, aggs, traffic=(None, None), live=None, steps=1):
     """`roofline`: the kernel with the largest total time in the profiled prove, priced in SURVEY.md §8(d)'s
     algorithmic bytes (sum over its launches) / its HIP-event time (sum over its launches) against 8 TB/s HBM;
-    `alu`: the same launches against the measured Fr-multiplication peak."""
+    `alu`: the same launches against the measured Fr-multiplication peak.  When that kernel is the bucket accumulation and
+    `live` (live_accumulate) holds its launches of the TIMED region, the durations are those - measured while the proofs ran,
+    on the streams the launches went to - and the profiled prove only supplies the table of the other kernels."""
     tot = sum(a["ms"] for a in aggs) or 1.0
     peak_mul = fr_mul_peak(hl, ctx)
     dom = dominant(aggs)
     top = max(aggs, key=lambda a: a["ms"])
+    share = dom["ms"] / tot
+    live_note = None
+    if live and dom["name"] == "msm_accumulate0":
+        dom = dict(dom, ms=live["ms"], launches=live["launches"], bytes=live["bytes"], muls=live["muls"], items=live["items"])
+        live_note = ("durations: HIP events around every launch of the %d TIMED proofs, on the stream each launch went to, "
+                     "nothing synchronised; a pipelined MSM batch runs its two halves at the same time on two streams, so a "
+                     "launch's duration is its span (a kernel trace shows the same) and the chip's rate is `alu.frac_chip`"
+                     % steps)
     avg_ms = dom["ms"] / dom["launches"]
     ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 if dom["ms"] > 0 else 0.0
     roof = {"bound": "hbm", "kernel": dom["name"], "achieved": round(ach, 1), "peak": 8000.0,
@@ -267,10 +291,15 @@ def roofline_objects(hl, ctx, aggs, traffic=(None, None)):
             "launches": dom["launches"], "avg_launch_ms": round(avg_ms, 4),
             "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
             "items_per_launch": dom["items"] / dom["launches"],
-            "share_of_profiled_prove": round(dom["ms"] / tot, 3),
+            "share_of_profiled_prove": round(share, 3),
             "accounting": "SURVEY.md 8(d): MSM 96 B per point with a 32-byte scalar, 68 B with a u32 scalar, summed "
                           "over the jobs of the batch; sum-check 96 B per bound entry; see DESIGN.md section 3"}
-    if top is not dom:
+    if live_note:
+        roof["timing"] = live_note
+        if live["batch_ms"] > 0:  # the same bytes against the time the chip spent on the batches (overlapping launches counted once)
+            chip = live["bytes"] / (live["batch_ms"] * 1e-3) / 1e9
+            roof["achieved_chip"], roof["frac_chip"] = round(chip, 1), round(chip / 8000.0, 4)
+    if top["name"] != dom["name"]:
         roof["note"] = ("largest share of this prove: %s (%.0f %%, rounds resident in LDS: no HBM traffic, latency-bound); "
                         "the roofline is priced on the largest kernel that moves data" % (top["name"], 100.0 * top["ms"] / tot))
     mul_rate = dom["muls"] / (dom["ms"] * 1e-3) if dom["ms"] > 0 else 0.0
@@ -280,6 +309,12 @@ def roofline_objects(hl, ctx, aggs, traffic=(None, None)):
                           "element)",
            "counting": "`achieved` counts a mixed addition as 10 products (the two of Y3 share a reduction); ~296 VALU "
                        "instructions per product, each a ~4-cycle wave64 issue (profiles/r04_ubench_mul_fp64.txt)"}
+    if live_note and live["batch_ms"] > 0:
+        # the same products against the time the chip spent on the batches (launches that overlap counted once)
+        chip = live["muls"] / (live["batch_ms"] * 1e-3)
+        alu["achieved_chip"] = round(chip / 1e9, 2)
+        alu["frac_chip"] = round(chip / peak_mul, 4)
+        alu["batch_ms_per_proof"] = round(live["batch_ms"] / max(steps, 1), 3)
     kernels = [{"name": a["name"], "launches": a["launches"], "ms": round(a["ms"], 3),
                 "GBps_all": round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1) if a["ms"] > 0 else 0.0,
                 "GBps_largest": round(a["big"]["bytes"] / (a["big"]["ms"] * 1e-3) / 1e9, 1) if a["big"]["ms"] > 0 else 0.0}
@@ -584,9 +619,13 @@ def main():
             torch.cuda.synchronize()
         hdist.barrier(dist)
 
-    def timed(steps, warmup, **kw):
+    live_box = {}
+
+    def timed(steps, warmup, live=False, **kw):
         for _ in range(warmup):
             prove(**kw)
+        if live:  # event pairs around the accumulation launches of the timed proofs (no synchronisation: lasso_hip.h)
+            hl.profile_enable(ctx, 2)
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -597,6 +636,9 @@ def main():
             torch.cuda.synchronize()
         elapsed = hdist.max_over_ranks(dist, time.perf_counter() - t0)
         hdist.barrier(dist)
+        if live:
+            live_box["acc"] = live_accumulate(hl.profile_read(ctx))
+            hl.profile_enable(ctx, 0)
         return elapsed * 1e3 / max(steps, 1), tr
 
     replicas = None
@@ -652,7 +694,7 @@ def main():
         watchdog.start()
         transport = hdist.attach_sharded(ctx, dist, shard_bit)
 
-    ms_per_step, tr = timed(args.steps, args.warmup)
+    ms_per_step, tr = timed(args.steps, args.warmup, live=not args.no_profile)
     phases = hl.lasso_last_timing(ctx)
     proof = tr.into_proof()
     proofs_per_step = 1 if sharded else world
@@ -707,7 +749,7 @@ def main():
             hl.profile_enable(ctx, False)
             dom = dominant(aggs)
             out["roofline"], out["alu"], out["kernels"] = roofline_objects(
-                hl, ctx, aggs, pmc_traffic(dom["name"], n, args.table, world, dom["launches"]))
+                hl, ctx, aggs, pmc_traffic(dom["name"], n, args.table, world, dom["launches"]), live_box.get("acc"), args.steps)
     if world > 1:
         # device memory per rank after the headline's proofs (the workspace arena's high-water mark; SRS and lookup columns are
         # on top of it): gathered over the control plane

@@ -1021,7 +1021,9 @@ def get_option(ctx, name):
 
 
 def profile_enable(ctx, on=True):
-    _check(ctx.lib.lh_profile_enable(ctx.h, 1 if on else 0))
+    """lh_profile_enable: True / 1 = every instrumented launch synchronised (a separate, slower prove); 2 = live records of the
+    bucket-accumulation launches only, nothing synchronised (usable inside a timed region); False / 0 = off"""
+    _check(ctx.lib.lh_profile_enable(ctx.h, int(on)))
 
 
 def profile_read(ctx):

@@ -1119,14 +1119,29 @@ lh_status lh_debug_jit_source(const uint32_t* code, size_t num_instrs, uint32_t 
 lh_status lh_profile_enable(lh_ctx* ctx, int on) {
   LH_TRY NEED_CTX(ctx);
   ctx->c.sync();
-  ctx->c.prof = on != 0;
+  ctx->c.prof = on == 1;
   ctx->c.prof_recs.clear();
+  // 2: live records of the bucket-accumulation launches only (dev.hpp Ctx::live); the helper ctx's launches count too
+  std::vector<ProfRec> drop;
+  ctx->c.live_resolve(drop);
+  ctx->c.live = on == 2;
+  if (ctx->c.helper) {
+    ctx->c.helper->live_resolve(drop);
+    ctx->c.helper->live = on == 2;
+  }
   LH_CATCH
 }
 lh_status lh_profile_read(lh_ctx* ctx, lh_prof_rec* out, size_t cap, size_t* count) {
   LH_TRY NEED_CTX(ctx);
   NEED(count);
   static_assert(sizeof(lh_prof_rec) == sizeof(lh::ProfRec), "profile record layout");
+  if (ctx->c.live) {  // (resolved at the first read after the timed region: waits for the streams)
+    ctx->c.live_resolve(ctx->c.prof_recs);
+    if (ctx->c.helper) {
+      LH_HIP(hipStreamSynchronize(ctx->c.helper->stream));
+      ctx->c.helper->live_resolve(ctx->c.prof_recs);
+    }
+  }
   size_t n = ctx->c.prof_recs.size();
   *count = n;
   if (out && cap) memcpy(out, ctx->c.prof_recs.data(), (n < cap ? n : cap) * sizeof(lh_prof_rec));

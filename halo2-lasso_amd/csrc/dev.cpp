@@ -144,6 +144,43 @@ void Ctx::wait_flag(uint32_t seq) {
   }
 }
 
+hipEvent_t Ctx::live_event() {
+  if (!live_pool.empty()) {
+    hipEvent_t e = live_pool.back();
+    live_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  LH_HIP(hipEventCreate(&e));
+  return e;
+}
+void Ctx::live_resolve(std::vector<ProfRec>& out) {
+  LH_HIP(hipStreamSynchronize(stream));
+  if (aux_stream) LH_HIP(hipStreamSynchronize(aux_stream));
+  for (size_t i = 0; i < live_recs.size();) {
+    size_t j = i;
+    ProfRec sum = live_recs[i].rec;
+    snprintf(sum.name, sizeof sum.name, "%s/batch", live_recs[i].rec.name);
+    sum.bytes = sum.muls = sum.items = 0;
+    float span = 0;
+    for (; j < live_recs.size() && live_recs[j].batch == live_recs[i].batch; j++) {
+      LiveRec& r = live_recs[j];
+      float ms = 0, end = 0;
+      (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+      (void)hipEventElapsedTime(&end, live_recs[i].e0, r.e1);  // (the batch's first launch starts first: the others wait for an event behind it)
+      r.rec.ms = ms;
+      span = std::max(span, end);
+      sum.bytes += r.rec.bytes, sum.muls += r.rec.muls, sum.items += r.rec.items;
+      out.push_back(r.rec);
+    }
+    sum.ms = span;
+    out.push_back(sum);
+    i = j;
+  }
+  for (LiveRec& r : live_recs) live_pool.push_back(r.e0), live_pool.push_back(r.e1);
+  live_recs.clear();
+}
+
 void Ctx::aux_streams() {
   if (aux_stream) return;
   // (the LOWEST priority the device offers: what runs here fills the wave slots the ctx's stream leaves idle)

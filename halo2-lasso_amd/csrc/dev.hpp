@@ -225,6 +225,21 @@ struct Ctx {
   std::vector<EqHalfEntry> eq_half_cache;
   bool prof = false;
   std::vector<ProfRec> prof_recs;
+  // LIVE records (lh_profile_enable(ctx, 2)): a HIP-event pair around every bucket-accumulation launch, on the stream it is
+  // launched on, nothing synchronised and nothing serialised - the timed region as it runs.  The two halves of a pipelined
+  // MSM batch run at the same time on two streams, so a launch's duration is its SPAN (what a kernel trace shows too) and
+  // the chip's rate follows from the batch's span (first start to last end): lh_profile_read resolves both.
+  bool live = false;
+  struct LiveRec {
+    ProfRec rec;
+    hipEvent_t e0, e1;
+    uint32_t batch;
+  };
+  std::vector<LiveRec> live_recs;
+  std::vector<hipEvent_t> live_pool;  // events not in use
+  uint32_t live_batch = 0;
+  hipEvent_t live_event();
+  void live_resolve(std::vector<ProfRec>& out);  // waits for the streams, appends per-launch and per-batch records, recycles the events
   // helper ctx (same device, own stream / arena / pinned blocks; capi.cpp ctx_helper) and what it is committing ahead of
   // the opening (open_columns.cpp open_precommit_*): both owned by this ctx
   bool is_helper = false;  // this ctx is somebody's helper: its throughput kernels leave wave slots to the owner's stream

@@ -985,8 +985,21 @@ static void msm_sub_accumulate(Ctx& c, MsmSub& s, hipStream_t stream) {
     // (a grid capped to the chip's resident workgroups - for a helper ctx, so that the owner's latency-bound kernels find
     // wave slots, or for every ctx, persistent style - was measured in round 5 and bought nothing: profiles/README.md)
     const size_t acc_grid = std::min<size_t>((s.nchunks + 127) / 128, 1 << 16);
+    Ctx::LiveRec lr;
+    if (c.live) {  // (dev.hpp: the launch's span on its own stream, nothing waited for)
+      memset(&lr.rec, 0, sizeof(lr.rec));
+      snprintf(lr.rec.name, sizeof lr.rec.name, "msm_accumulate0");
+      lr.rec.bytes = 96.0 * s.full_pts + 68.0 * (s.total_pts - s.full_pts), lr.rec.muls = 10.0 * (double)s.max_entries;
+      lr.rec.items = (double)s.max_entries;
+      lr.e0 = c.live_event(), lr.e1 = c.live_event(), lr.batch = c.live_batch;
+      LH_HIP(hipEventRecord(lr.e0, stream));
+    }
     hipLaunchKernelGGL(msm_accumulate0_kernel, dim3((unsigned)acc_grid), dim3(128), 0, stream, plan, s.max_entries, s.skey, s.sidx,
                        s.K, s.buckets, s.ckey, s.cpt, s.nchunks, s.lvl_cnt);
+    if (c.live) {
+      LH_HIP(hipEventRecord(lr.e1, stream));
+      c.live_recs.push_back(lr);
+    }
   }
 }
 
@@ -1189,6 +1202,13 @@ bool msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, 
       for (MsmSub& s : subs) msm_sub_entries(c, jobs, s);
       hipStream_t side = c.stream;
       uint32_t seq_aux = 0;
+      struct AuxGuard {  // an exception on the way out must not release the arena under kernels still queued on the aux stream
+        Ctx& c;
+        bool armed = false;
+        ~AuxGuard() {
+          if (armed && c.aux_stream) (void)hipStreamSynchronize(c.aux_stream);
+        }
+      } aux_guard{c};
       if (piped) {
         c.route.v[RouteStats::MSM_HALF_BATCHES]++;
         if (!c.prof) {
@@ -1196,8 +1216,10 @@ bool msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, 
           LH_HIP(hipEventRecord(c.aux_ev, c.stream));
           LH_HIP(hipStreamWaitEvent(c.aux_stream, c.aux_ev, 0));
           side = c.aux_stream;
+          aux_guard.armed = true;
         }
       }
+      c.live_batch++;
       msm_sub_accumulate(c, subs[0], c.stream);
       if (piped) msm_sub_accumulate(c, subs[1], side);
       const uint32_t seq = c.next_seq();
@@ -1224,6 +1246,7 @@ bool msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, 
         msm_sub_combine(subs[0], sums_all);
         c.host_stamp("msm:first_half_combined");
         c.wait_flag_aux(seq_aux);
+        aux_guard.armed = false;  // (its last kernel has published: nothing of the batch is queued any more)
       }
       c.host_stamp("msm:window_sums");
       for (MsmSub& s : subs) {

@@ -251,6 +251,7 @@ void open_precommit_start(Ctx& c, const Srs& srs, size_t num_vars, const SmallPo
   Ctx& h = ctx_helper(c);
   h.opt = c.opt;
   h.prof = c.prof;
+  h.live = c.live;  // (live records of the helper's accumulation launches are read with the owner's: capi.cpp)
   h.prof_recs.clear();
   OpenPrecommit* pc = new OpenPrecommit();
   pc->srs = &srs, pc->num_vars = num_vars, pc->cols = so.cols, pc->zero = zero;

@@ -594,7 +594,12 @@ typedef struct lh_prof_rec {
   double muls;  /* field multiplications of the launch */
   double items; /* work items of the launch */
 } lh_prof_rec;
-lh_status lh_profile_enable(lh_ctx*, int on); /* also clears the record list */
+/* on = 1: every instrumented launch bracketed by HIP events and SYNCHRONISED (exact per-kernel durations, a slower prove: not
+ * for a timed region).  on = 2: LIVE records - an event pair around every bucket-accumulation launch (the dominant kernel), on
+ * the stream it is launched on, nothing waited for: usable inside a timed region.  The two halves of a pipelined MSM batch
+ * run at the same time, so a launch's `ms` is its span and a record named "msm_accumulate0/batch" carries the span of all
+ * launches of one batch (first start to last end) with their bytes / muls / items added up.  Also clears the record list. */
+lh_status lh_profile_enable(lh_ctx*, int on);
 /* copies up to `cap` records, returns the total number recorded in *count */
 lh_status lh_profile_read(lh_ctx*, lh_prof_rec* out, size_t cap, size_t* count);
 
