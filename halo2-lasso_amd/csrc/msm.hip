@@ -709,7 +709,7 @@ static std::vector<char> msm_pick_split(Ctx& c, const MsmJob* jobs, const std::v
                                         const std::vector<char>& derived) {
   const size_t nj = idx.size();
   std::vector<char> second(nj, 0);
-  // (a helper ctx works beside its owner's kernels already: a second stream of its own there was measured -0.7 ms)
+  // (a helper ctx works beside its owner's kernels already: a second stream of its own there cost the proof 0.7 ms)
   if (!c.opt.msm_half_batches || c.is_helper || nj < 2) return {};
   std::vector<size_t> E(nj), T(nj);
   size_t Et = 0, Tt = 0;
@@ -754,7 +754,7 @@ static std::vector<char> msm_pick_split(Ctx& c, const MsmJob* jobs, const std::v
 // layout of one sub-batch: windows, key / segment / share ranges, entry positions (no device work)
 // (`whole`: the plan of the undivided batch this sub-batch is a half of - segment size, reduction form and entries per
 // accumulate thread are the batch's, not the half's: a half must not fall back to the latency-bound forms of a small batch)
-static void msm_plan_sub(Ctx& c, const MsmJob* jobs, MsmSub& s, const MsmSub* whole = nullptr, int own = 0) {
+static void msm_plan_sub(Ctx& c, const MsmJob* jobs, MsmSub& s, const MsmSub* whole = nullptr) {
   const size_t nj = s.idx.size();
   MsmPlanDev& plan = s.plan;
   plan.num_jobs = (int)nj;
@@ -777,7 +777,7 @@ static void msm_plan_sub(Ctx& c, const MsmJob* jobs, MsmSub& s, const MsmSub* wh
     }
     static const int forced = env_int("LH_MSM_SEG", 0);
     seg_size = forced ? (uint32_t)forced : est <= ((size_t)1 << 18) ? 4u : est <= ((size_t)1 << 20) ? 8u : 16u;
-    if (whole && !(own & 1)) seg_size = whole->seg_size;
+    if (whole) seg_size = whole->seg_size;
     s.seg_size = seg_size;
   }
   uint32_t key = 0, seg = 0, win = 0;
@@ -858,7 +858,7 @@ static void msm_plan_sub(Ctx& c, const MsmJob* jobs, MsmSub& s, const MsmSub* wh
   // two-level reduction: throughput-bound batches (the plain segment kernel runs), jobs whose windows hold at least
   // MSM_GROUP^2 segments, packed jobs only when a group never straddles a change of the high part
   static const int two_level_on = env_int("LH_MSM_TWO_LEVEL", 1);
-  const bool plain_reduce = whole && !(own & 1) ? whole->plain_reduce : s.nsegs > (size_t)MSM_QUAD_MAX / 2;
+  const bool plain_reduce = whole ? whole->plain_reduce : s.nsegs > (size_t)MSM_QUAD_MAX / 2;
   s.plain_reduce = plain_reduce;
   s.ngroups = 0;
   for (size_t j = 0; j < nj; j++) {
@@ -896,7 +896,7 @@ static void msm_plan_sub(Ctx& c, const MsmJob* jobs, MsmSub& s, const MsmSub* wh
   const size_t me = s.max_entries;
   s.K = me > ((size_t)1 << 26) ? 128 : me > ((size_t)1 << 25) ? 64 : me > ((size_t)1 << 23) ? 32 : me > ((size_t)1 << 21) ? 16 : me > ((size_t)1 << 18) ? 8 : 4;
   if (MSM_K > 0) s.K = (uint32_t)MSM_K;
-  if (whole && !(own & 2)) s.K = whole->K;
+  if (whole) s.K = whole->K;
   s.nchunks = (me + s.K - 1) / s.K;
   s.wins.assign(s.nshares, G1Xyzz::identity());
 }
@@ -1167,10 +1167,10 @@ bool msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, 
       whole.idx = all, whole.bits = job_bits, whole.derived = derived;
       msm_plan_sub(c, jobs, whole);
     }
-    // (development: bit 0 - the second half picks its reduction forms by its own size, bit 1 - its entries per thread too)
-    static const int last_own = env_int("LH_MSM_HALF_LAST_OWN", 0);
+    // (the second half with forms of its own - segment size, reduction kernels, entries per thread by ITS size - was measured
+    //  and lost: the opening 19.8 -> 20.6 ms, tools/ab_half.sh of round 6)
     for (MsmSub& s : subs) {
-      msm_plan_sub(c, jobs, s, subs.size() == 2 ? &whole : nullptr, &s == &subs[0] ? 0 : last_own);
+      msm_plan_sub(c, jobs, s, subs.size() == 2 ? &whole : nullptr);
       total_entries += s.max_entries, pin_total += s.pin_bytes();
     }
     if (total_entries == 0) {

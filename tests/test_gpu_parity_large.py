@@ -472,7 +472,7 @@ def test_context_used_from_another_thread(hl, ctx):
                                  {"LH_OPEN_SMALL_MIN_VARS": "2", "LH_OPEN_SMALL_DEPTH": "2", "LH_OPEN_SMALL_CHECK": "1"},
                                  {"LH_MSM_WINDOW_TABLES": "24", "LH_MSM_SLAB_LOG": "6"},
                                  {"LH_MSM_HALF_MIN_LOG": "6", "LH_MSM_SLAB_LOG": "12"},
-                                 {"LH_MSM_HALF_MIN_LOG": "6", "LH_MSM_HALF_LAST_OWN": "3", "LH_MSM_HALF_COVER": "1"}])
+                                 {"LH_MSM_HALF_MIN_LOG": "6", "LH_MSM_HALF_COVER": "1"}])
 def test_small_parity_suite_under_forced_shapes(env):
     """The byte-parity tests of test_gpu_parity.py / test_gpu_golden.py again in a child process with the shape
     knobs forced (they are read once per process): 64 workgroups with slices of two entries (hand-over right after
@@ -485,8 +485,8 @@ def test_small_parity_suite_under_forced_shapes(env):
     window table of its SRS level (one bucket set for all windows), and the MSM tails in their throughput forms whatever
     the size: plain (not quad-cooperative) kernels, 16-bucket segments with the two-level group reduction wherever a window
     has 4096 buckets, linear continuation levels instead of trees; and every MSM batch with two jobs as two pipelined halves
-    on two streams (msm_half_batches: by default only from 2^24 entries on), derived jobs next to their parents, the second
-    half with the batch's forms or with its own."""
+    on two streams (msm_half_batches: by default only from 2^24 entries on), derived jobs next to their parents, with the
+    default and with the smallest second half."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "tests/test_gpu_golden.py", "-m", "gpu",
