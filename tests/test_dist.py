@@ -189,3 +189,44 @@ def test_sharded_access_counters_algorithm_two_ranks_gloo(tmp_path):
         o, err = p.communicate(timeout=240)
         assert p.returncode == 0, err[-3000:]
         assert json.loads(o.strip().splitlines()[-1])["ok"] is True
+
+
+FLIGHT_WORKER = textwrap.dedent("""
+    import os, sys, json, threading
+    sys.path.insert(0, %r)
+    from halo2_lasso_amd import dist as hdist
+    rank, _, world = hdist.env_rank()
+    d = hdist.init("gloo")
+    # the channels of two sharded proofs in flight on every rank (bench.py sharded_two_in_flight): the default group for the
+    # first, a flight group of its own for the second; one host thread per proof, collectives in each thread's own order
+    ag = [hdist.host_all_gather(d, None), hdist.host_all_gather(d, hdist.flight_group(d))]
+    bad = []
+    def flight(k):
+        for it in range(200):
+            mine = bytes([k, rank, it %% 251]) * (1 + (it %% 7) * (k + 1))    # the two flights send different sizes
+            got = ag[k](mine)
+            want = b"".join(bytes([k, r, it %% 251]) * (1 + (it %% 7) * (k + 1)) for r in range(world))
+            if got != want:
+                bad.append((k, it))
+    th = [threading.Thread(target=flight, args=(k,)) for k in (0, 1)]
+    for t in th: t.start()
+    for t in th: t.join()
+    print(json.dumps({"rank": rank, "bad": bad}), flush=True)
+    hdist.barrier(d)
+    d.destroy_process_group()
+""") % ROOT
+
+
+def test_two_flights_on_two_groups_do_not_mix(tmp_path):
+    """Two sharded proofs in flight per rank talk over two process groups from two host threads (dist.flight_group): 200
+    all-gathers per flight with payloads of different sizes, issued by each thread at its own pace, every result the
+    concatenation of that flight's contributions in rank order."""
+    script = tmp_path / "flight_worker.py"
+    script.write_text(FLIGHT_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29581", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(2)]
+    for p in procs:
+        o, err = p.communicate(timeout=240)
+        assert p.returncode == 0, err[-3000:]
+        assert __import__("json").loads(o.strip().splitlines()[-1])["bad"] == []
