@@ -726,10 +726,10 @@ static std::vector<char> msm_pick_split(Ctx& c, const MsmJob* jobs, const std::v
       if ((long)idx[p] == (long)jobs[idx[j]].derived_parent) parent[j] = (long)p;
     if (parent[j] >= 0) T[parent[j]] += T[j], T[j] = 0;
   }
-  // (LH_MSM_HALF_MIN_LOG below 24 is a test shape: every batch with two jobs that have entries is split, whatever its size)
+  // (LH_MSM_HALF_MIN_LOG below 16 is a test shape: every batch with two jobs that have entries is split, whatever its size)
   static const size_t min_entries = (size_t)env_int("LH_MSM_HALF_MIN_LOG", 24);
   static const int cover = env_int("LH_MSM_HALF_COVER", 12);  // entries of the second half per bucket of the first
-  const bool forced = min_entries < 24;
+  const bool forced = min_entries < 16;  // (16 .. 23: a lower threshold with the floors below in force - measurements)
   if (Et < ((size_t)1 << min_entries) || (!forced && Tt < ((size_t)1 << 17))) return {};
   std::vector<size_t> order;
   for (size_t j = 0; j < nj; j++)
