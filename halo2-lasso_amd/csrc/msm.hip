@@ -1056,6 +1056,10 @@ static void msm_sub_tail(Ctx& c, const MsmJob* jobs, MsmSub& s, hipStream_t stre
   }
 }
 
+// a job whose window combine is at most ~40 doublings (~15 us on a host core): done inline - a 16-bit column of 2^16 points
+// has two 12-bit windows, and handing its 12 doublings to the sleeping host pool cost ~100 us per batch of a 2^16 proof
+static inline bool msm_job_is_light(const MsmJobDev& jd) { return jd.red_W >= 2 && (jd.red_W - 1) * jd.c <= 40; }
+
 // step 6 on the host: sum_w 2^(c w) win[w] per job.  Jobs with doublings (~70 us of dependent doublings each) go to the
 // host pool, the others (one window, packed pairs: a few additions) are done here
 static void msm_sub_combine(MsmSub& s, std::vector<host::G1Xyzz>& sums /* [2 global job], [.. + 1]: out_second */) {
@@ -1074,6 +1078,13 @@ static void msm_sub_combine(MsmSub& s, std::vector<host::G1Xyzz>& sums /* [2 glo
       if (jd.red_W) sums[2 * s.idx[j]] = share_sum(jd, 0), sums[2 * s.idx[j] + 1] = share_sum(jd, 1);
     } else if (jd.red_W <= 1 || jd.merged) {  // (a window table's job has one "window": no doublings)
       if (jd.red_W) sums[2 * s.idx[j]] = share_sum(jd, 0);
+    } else if (msm_job_is_light(jd)) {  // a few dozen doublings: here, now (waking the pool costs more than they do)
+      host::G1Xyzz acc = host::G1Xyzz::identity();
+      for (int w = (int)jd.red_W - 1; w >= 0; w--) {
+        for (uint32_t q = 0; q < jd.c; q++) acc = host::g1_dbl(acc);
+        acc = host::g1_add(acc, share_sum(jd, (uint32_t)w));
+      }
+      sums[2 * s.idx[j]] = acc;
     } else {
       heavy.push_back(j);
     }
@@ -1234,7 +1245,8 @@ bool msm_batch(Ctx& c, const MsmJob* jobs, size_t num_jobs, G1Affine* out_host, 
         // milliseconds; a longer one lets them sleep again and pays the wake-up, which then no longer matters)
         size_t heavy_jobs = 0;
         for (const MsmSub& s : subs)
-          for (size_t j = 0; j < s.idx.size(); j++) heavy_jobs += s.plan.job[j].red_W > 1 && !s.plan.job[j].pack_shift && !s.plan.job[j].merged;
+          for (size_t j = 0; j < s.idx.size(); j++)
+            heavy_jobs += s.plan.job[j].red_W > 1 && !s.plan.job[j].pack_shift && !s.plan.job[j].merged && !msm_job_is_light(s.plan.job[j]);
         if (heavy_jobs > 1 && !c.prof) host_parallel_prewake(heavy_jobs, 4000);
       }
       c.host_stamp("msm:queued");
