@@ -195,6 +195,14 @@ struct Ctx {
   // gkr, evals, open; 7 = outside a Lasso prove): [phase][0] collectives, [phase][1] bytes this rank contributed
   uint64_t comm_phase_stats[8][2] = {};
   int comm_phase = 7;
+  // hint for the NEXT sum_check_prove (consumed and cleared at its entry): its single table d_polys[0] has NOT been written -
+  // its values are this 32-bit column.  The sum-check either runs its first three rounds from the column (sumcheck.cpp: the
+  // sums of k_inner_products_small_quads are rounds 0 and 1, k_sc_round_u32_bind2 is round 2) or fills the table itself.
+  struct ScU32 {
+    const uint32_t* col = nullptr;
+    bool have_sums = false;
+    Fr odd, s2, s3;  // (when have_sums: out_host[1..3] of k_inner_products_small_quads against the sum-check's E_0)
+  } sc_u32;
   // sharded sum-check rounds: the round kernel leaves its D sums in this DEVICE buffer (and "publishes" to a device
   // word) instead of pinned host memory; the all-gather and the sum-and-publish kernel follow on the stream
   Fr* sc_redirect = nullptr;
@@ -416,6 +424,14 @@ void k_inner_products_small(Ctx&, const uint32_t* const* polys, size_t count, co
 // the same against eq(y) given as the eq table of y[1..] (`half` entries) and y0
 void k_inner_products_small_half(Ctx&, const uint32_t* const* polys, size_t count, const Fr* eq_half, size_t half,
                                  const Fr& y0, Fr* out_host);
+// An eq-factored degree-2 sum-check over ONE table that still is a 32-bit column (Surge over the output column, lasso.cpp):
+// out_host[0..3] = sum_b e0[b] col[2b], sum_b e0[b] col[2b+1], sum_q (e0[2q] + e0[2q+1]) col[4q+2], the same with col[4q+3]
+// (the claim's two halves - and the sums of rounds 0 and 1), b < 2 quads, q < quads
+void k_inner_products_small_quads(Ctx&, const uint32_t* col, const Fr* e0, size_t quads, Fr* out_host);
+// round 2 binds r0 and r1 at once: out[i] = the column's entries 4i..4i+3 bound with (r0, r1), i < 2 size;
+// out_host[0] = sum_b eq_level[b] out[2b+1]
+void k_sc_round_u32_bind2(Ctx&, const uint32_t* col, const Fr* eq_level, const Fr& r0, const Fr& r1, size_t size, Fr* out,
+                          Fr* out_host);
 // out[i] = sum_k wfr[k] fr[k][i] + sum_k wsm[k] sm[k][i], i < n; u32 column k has sm_len[k] entries (zero beyond)
 void k_lincomb_mixed(Ctx&, const Fr* const* fr, const Fr* wfr, size_t num_fr, const uint32_t* const* sm,
                      const size_t* sm_len, const Fr* wsm, size_t num_sm, size_t n, Fr* out);

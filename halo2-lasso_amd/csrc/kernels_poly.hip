@@ -736,6 +736,121 @@ void k_inner_products_small_half(Ctx& c, const uint32_t* const* polys, size_t co
   }
 }
 
+// A degree-2 eq-factored sum-check over ONE table whose values still are a 32-bit column (Surge over the output column of a
+// linear g): nothing of its first two rounds needs the challenges.  Round 0 sends q(1) = sum_b E_0[b] a[2b + 1]; round 1, after
+// binding r0, sends q(1) = sum_b E_1[b] ((1 - r0) a[4b + 2] + r0 a[4b + 3]) = (1 - r0) S2 + r0 S3 with E_1[b] = E_0[2b] +
+// E_0[2b + 1].  One pass over the column and E_0 makes the claim's two halves (even, odd) and S2, S3: 8 multiply-adds per term
+// into wide accumulators (wide_mac above).  out_host[0..3] = even, odd, S2, S3.
+__global__ __launch_bounds__(256) void inner_products_small_quads_kernel(const uint32_t* __restrict__ col, const Fr* __restrict__ e0,
+                                                                         size_t quads, Fr* __restrict__ partials) {
+  __shared__ Fr lds[4];
+  Wide acc[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) acc[k] = Wide::zero();
+  GSTRIDE(b, quads) {
+    const uint4 a = ((const uint4*)col)[b];
+    const Fr h0 = e0[2 * b], h1 = e0[2 * b + 1];
+    wide_mac(acc[0], h0, a.x), wide_mac(acc[0], h1, a.z);
+    wide_mac(acc[1], h0, a.y), wide_mac(acc[1], h1, a.w);
+    const Fr h = add(h0, h1);
+    wide_mac(acc[2], h, a.z), wide_mac(acc[3], h, a.w);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    Fr v = block_reduce_sum(wide_reduce(acc[k]), lds);
+    if (threadIdx.x == 0) partials[(size_t)k * gridDim.x + blockIdx.x] = v;
+  }
+}
+void k_inner_products_small_quads(Ctx& c, const uint32_t* col, const Fr* eq_half, size_t quads, Fr* out_host) {
+  ProfScope ps(c, "inner_products<quads>", 80.0 * quads, 0.45 * quads, (double)quads);
+  LH_REQUIRE(quads >= 1, LH_ERR_ARG, "inner_products_small_quads: empty column");
+  ArenaScope scope(c.arena);
+  dim3 g = grid_for(quads, 256, 1024);  // (a thread's accumulators: at most 2^33 terms of 2^288 each fit 10 limbs)
+  Fr* partials = c.arena.alloc_n<Fr>((size_t)g.x * 4);
+  Fr* d_out = c.arena.alloc_n<Fr>(4);
+  hipLaunchKernelGGL(inner_products_small_quads_kernel, g, 256, 0, c.stream, col, eq_half, quads, partials);
+  hipLaunchKernelGGL(reduce_rows_kernel, 4, 256, 0, c.stream, partials, (int)g.x, d_out);
+  c.d2h(out_host, d_out, 4 * sizeof(Fr));
+}
+
+// Round 2 of the same sum-check binds r0 AND r1 straight from the column: bound entry i is
+//   (1 - r1) ((1 - r0) a[4i] + r0 a[4i + 1]) + r1 ((1 - r0) a[4i + 2] + r0 a[4i + 3]),
+// four 8-multiply-add terms and ONE Montgomery reduction (the four weights arrive times R: prescale_r / wide_redc), read at
+// 16 bytes per lane and stored like the plain bind kernel's; the round's q(1) = sum_b E_2[b] out[2b + 1] rides on the odd
+// lanes.  No field-element view of the column, and no table of 2^(n-1) entries, is ever written: at 2^24 AND lookups
+// fr_from_u32 0.18 + sc_round<1,first> 0.21 + sc_round<1,bind> 0.28 + 0.18 ms of launches became this one.
+struct U32Bind2 {
+  Fr w[4];  // (1-r1)(1-r0), (1-r1) r0, r1 (1-r0), r1 r0 - times R
+};
+__global__ __launch_bounds__(256) void sc_round_u32_bind2_kernel(const uint32_t* __restrict__ col, const Fr* __restrict__ eq_level,
+                                                                 U32Bind2 k, size_t entries, Fr* __restrict__ out,
+                                                                 Fr* __restrict__ partials, ScFinishArgs fin) {
+  __shared__ Fr lds[4];
+  __shared__ int is_last;
+  Fr acc = Fr::zero();
+  GSTRIDE(i, entries) {
+    const uint4 a = ((const uint4*)col)[i];
+    Wide t = Wide::zero();
+    wide_mac(t, k.w[0], a.x), wide_mac(t, k.w[1], a.y), wide_mac(t, k.w[2], a.z), wide_mac(t, k.w[3], a.w);
+    const Fr v = wide_redc(t);
+    out[i] = v;
+    if (i & 1) acc = add(acc, mul(v, eq_level[i >> 1]));
+  }
+  acc = block_reduce_sum(acc, lds);
+  if (gridDim.x == 1) {
+    if (threadIdx.x == 0) {
+      fin.out_host[0] = acc;
+      __threadfence_system();
+      __hip_atomic_store(fin.flag, fin.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
+  }
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x] = acc;
+    __threadfence();
+    const uint32_t t = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = t == fin.last_ticket;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  Fr a2 = Fr::zero();
+  for (uint32_t i = threadIdx.x; i < gridDim.x; i += blockDim.x) a2 = add(a2, partials[i]);
+  a2 = block_reduce_sum(a2, lds);
+  if (threadIdx.x == 0) {
+    fin.out_host[0] = a2;
+    __threadfence_system();
+    __hip_atomic_store(fin.flag, fin.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+void k_sc_round_u32_bind2(Ctx& c, const uint32_t* col, const Fr* eq_level, const Fr& r0, const Fr& r1, size_t size, Fr* out,
+                          Fr* out_host) {
+  LH_REQUIRE(size >= 1 && !c.sc_redirect, LH_ERR_ARG, "sc_round_u32_bind2: bad shape");
+  const uint32_t seq = c.next_seq();
+  ArenaScope scope(c.arena);
+  const size_t entries = 2 * size;
+  const size_t g = std::min<size_t>((entries + 255) / 256, (size_t)c.num_cus * 8);
+  Fr* partials = c.arena.alloc_n<Fr>(g);
+  const ScFinishArgs fin = c.finish_for((uint32_t)g, out_host, seq);
+  host::Fr h0, h1;
+  const host::Fr one = host::Fr::one();
+  memcpy(&h0, &r0, sizeof(h0));
+  memcpy(&h1, &r1, sizeof(h1));
+  const host::Fr w[4] = {(one - h1) * (one - h0), (one - h1) * h0, h1 * (one - h0), h1 * h0};
+  U32Bind2 k;
+  for (int i = 0; i < 4; i++) {
+    Fr d;
+    memcpy(&d, &w[i], sizeof(d));
+    k.w[i] = prescale_r(d);
+  }
+  {
+    // per bound entry: 16 B of column, 32 B stored, 16 B of eq level; a reduction and half a product
+    ProfScope ps(c, "sc_round_u32<bind2>", 64.0 * (double)entries, 1.2 * (double)entries, (double)size);
+    hipLaunchKernelGGL(sc_round_u32_bind2_kernel, dim3((unsigned)g), dim3(256), 0, c.stream, col, eq_level, k, entries, out, partials, fin);
+  }
+  c.wait_round(seq);
+}
+
 // ------------------------------------------------------------------ GKR layer-up
 // product tree (Lasso memory check): out[i] = in[i] * in[half+i]
 __global__ void tree_up_kernel(const Fr* __restrict__ in, size_t half, Fr* __restrict__ out) {

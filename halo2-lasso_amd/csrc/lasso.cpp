@@ -273,10 +273,21 @@ LassoClaims lasso_argue(Ctx& c, const lh_lasso_table& tb, size_t n, const LassoC
   // ---- 2-4: Surge primary sum-check
   cl.r = tr.squeeze_challenges(n);
   c.host_stamp("argue:squeezed");
+  bool linear_g = true;
+  for (uint32_t m = 0; m < tb.num_terms; m++) linear_g = linear_g && tb.g_num_factors[m] == 1;
+  Fr a_sums[4];  // (k_inner_products_small_quads: the claim's two halves - and rounds 0 and 1 of the Surge sum-check over a)
+  bool have_a_sums = false;
   if (a_small && n >= 2) {
     // against the eq table of r[1..] (half the entries), which the Surge sum-check and the batch opening at r use as well
     const Fr* eq_half = eq_half_get(c, cl.r.data(), n, shn);
-    k_inner_products_small_half(c, &a_small, 1, eq_half, N / 2, dev(cl.r[0]), (Fr*)&cl.v);
+    if (!a && linear_g && !shn && n >= 3) {
+      k_inner_products_small_quads(c, a_small, eq_half, N / 4, a_sums);
+      const HFr r0 = cl.r[0];
+      cl.v = (HFr::one() - r0) * hst(a_sums[0]) + r0 * hst(a_sums[1]);
+      have_a_sums = true;
+    } else {
+      k_inner_products_small_half(c, &a_small, 1, eq_half, N / 2, dev(cl.r[0]), (Fr*)&cl.v);
+    }
     sum_ranks(&cl.v, 1);
   } else if (a_small) {
     ArenaScope scope(c.arena);
@@ -287,8 +298,6 @@ LassoClaims lasso_argue(Ctx& c, const lh_lasso_table& tb, size_t n, const LassoC
     cl.v = evaluate_polys(c, &a, 1, n, cl.r.data(), shn)[0];
   }
   tr.write_field_element(cl.v);
-  bool linear_g = true;
-  for (uint32_t m = 0; m < tb.num_terms; m++) linear_g = linear_g && tb.g_num_factors[m] == 1;
   SumCheckResult sc;
   if (linear_g) {
     // g linear (range / AND / XOR): the summand eq * sum_m coeff_m E_m IS eq * a entry by entry, and binding is linear
@@ -299,9 +308,12 @@ LassoClaims lasso_argue(Ctx& c, const lh_lasso_table& tb, size_t n, const LassoC
       ArenaScope scope(c.arena);
       const Fr* a_tab = a;
       if (!a_tab) {
-        Fr* view = c.arena.alloc_n<Fr>(N);
-        k_fr_from_u32(c, a_small, N, view);
-        a_tab = view;
+        // no field-element view of the output column: the sum-check runs its first three rounds from the 32-bit column where
+        // it can (a_sums above are rounds 0 and 1) and fills this table itself where it cannot (dev.hpp Ctx::sc_u32)
+        a_tab = c.arena.alloc_n<Fr>(N);
+        c.sc_u32.col = a_small;
+        c.sc_u32.have_sums = have_a_sums;
+        if (have_a_sums) c.sc_u32.odd = a_sums[1], c.sc_u32.s2 = a_sums[2], c.sc_u32.s3 = a_sums[3];
       }
       lh_sop one_term;
       memset(&one_term, 0, sizeof(one_term));

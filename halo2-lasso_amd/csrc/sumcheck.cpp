@@ -667,6 +667,9 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
 
   ArenaScope scope(c.arena);
   const size_t len0 = (size_t)1 << (num_vars - rho);
+  const Ctx::ScU32 u32 = c.sc_u32;  // (dev.hpp: poly 0 still is a 32-bit column; decided below who turns it into field elements)
+  c.sc_u32 = Ctx::ScU32();
+  bool u32_rounds = false;
   std::vector<const Fr*> cur(T);
   for (size_t i = 0; i < num_polys; i++) cur[i] = d_polys[i];
   auto round_fn = [&](const Fr* const* in, Fr* const* out, const Fr& r, bool bind, size_t size, Fr* evals_host) {
@@ -764,6 +767,22 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
   // Its factored rounds run sc_round_pp_kernel, and the first of them that binds folds the coefficients into the left
   // factors: from then on every kernel of this sum-check (streaming, LDS-staged, resident tail) sees coefficients of one,
   // and the final evaluations of the left factors are divided by c_m at the end.
+  // The first three rounds straight from a 32-bit column (Surge over the output column): one table, coefficient one, a
+  // claim that is the true sum, one GPU, and a column long enough for round 2 to be a launched streaming round.  The sums of
+  // rounds 0 and 1 need no challenge (k_inner_products_small_quads: the caller's, or made here), round 2 binds r0 and r1 from
+  // the column (k_sc_round_u32_bind2); from round 3 on the table is field elements.  Round 1 binds nothing: the loop's
+  // table pointer of that round names memory nobody reads.
+  Ctx::ScU32 u32s = u32;
+  Fr u32_r0;
+  bool u32_bound = false;
+  if (u32.col) {
+    static const bool u32_off = getenv("LH_SC_U32") && atoi(getenv("LH_SC_U32")) == 0;  // (development A/B)
+    u32_rounds = !u32_off && use_ef && !ef.per_term && !sharded && !rw && num_polys == 1 && rd.num_terms == 1 && rd.nfac[0] == 1 &&
+                 rd.fac[0][0] == 0 && rd.coeff_is_one[0] && degree == 2 && sum_is_exact && streams2 && num_vars >= 6 &&
+                 k_sc_round_streams(rd, degree, len0 >> 3) &&
+                 (len0 >> 2) > std::max<size_t>(k_sc_tail_capacity(c, rd, degree), (size_t)GKR_CAP * GKR_CAP);
+    if (!u32_rounds) k_fr_from_u32(c, u32.col, len0, const_cast<Fr*>(d_polys[0]));
+  }
   const bool pp_shape = use_ef && !ef.per_term && pp_terms;
   std::vector<HFr> pp_folded;  // the coefficients that went into the left factors (empty: not folded)
   bool rw_folded = false;      // tree-pair rounds (ScRwPairs): the tables hold l' = cs (l + k), r' = r + k since the first bind
@@ -843,6 +862,23 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
         }
         c.route.v[RouteStats::RW_ROUNDS]++;
         ef.add_const = rw->const_total;  // added to q(1), q(2) by the round loop (the suffix eq sums to one - over all ranks)
+      } else if (!ef.per_term && u32_rounds && round <= 2) {
+        LH_REQUIRE(points == 1 && bind == (round >= 1), LH_ERR_ARG, "sum-check: the 32-bit rounds met another shape");
+        if (round == 0) {
+          if (!u32s.have_sums) {
+            Fr s4[4];
+            k_inner_products_small_quads(c, u32.col, ef.eqs[0].level[0], size >> 1, s4);
+            u32s.odd = s4[1], u32s.s2 = s4[2], u32s.s3 = s4[3], u32s.have_sums = true;
+          }
+          out_host[0] = u32s.odd;
+        } else if (round == 1) {  // q(1) = (1 - r0) S2 + r0 S3; the bind waits for r1
+          u32_r0 = r;
+          const HFr r0 = hst(r);
+          out_host[0] = dev((HFr::one() - r0) * hst(u32s.s2) + r0 * hst(u32s.s3));
+        } else {
+          k_sc_round_u32_bind2(c, u32.col, ef.eqs[0].level[2], u32_r0, r, size, out[0], out_host);
+          u32_bound = true;
+        }
       } else if (!ef.per_term) {
         ScRound g = rd;
         for (size_t i = 0; i < T; i++) g.in[i] = in[i], g.out[i] = out[i];
@@ -929,6 +965,7 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
   }
   SumCheckResult res = sum_check_loop(c, prover_kind, num_vars, degree, cur, used, num_polys, sum, tr, sharded, round_fn, &rd,
                                       use_ef ? &ef : nullptr);
+  LH_REQUIRE(!u32_rounds || u32_bound, LH_ERR_DEVICE, "sum-check: the 32-bit column was never bound");
   if (rw_folded) {
     // l' = cs (l + k), r' = r + k came out: l = l' / cs - k, r = r' - k (one inversion for the coefficients)
     const size_t K = rw->num_pairs;

@@ -363,8 +363,17 @@ def test_lasso_default_route_at_2p21_matches_cpp_oracle(hl, ctx, srs22, kind, n)
     ot = co.Transcript()
     co.lasso_prove(ot, flat, 22, table.to_c(), n, [d.tobytes() for d in dims])
     t = hl.Keccak256Transcript()
-    hl.lasso_prove(pp, table, n, [ctx.upload(d.tobytes()) for d in dims], t)
+    hl.profile_enable(ctx, True)
+    try:
+        hl.lasso_prove(pp, table, n, [ctx.upload(d.tobytes()) for d in dims], t)
+        names = {r["name"] for r in hl.profile_read(ctx)}
+    finally:
+        hl.profile_enable(ctx, False)
     assert t.into_proof() == ot.into_proof()
+    # linear g: the Surge sum-check runs over the 32-bit output column, and while round 2 still is a streaming round (from 2^20
+    # lookups on) its first three rounds never see a field-element view of it (csrc/sumcheck.cpp: two rounds of sums made
+    # with the claim, one double-bind kernel)
+    assert "sc_round_u32<bind2>" in names and "inner_products<quads>" in names, sorted(names)
     route = hl.lasso_last_route(ctx)
     assert route["open_small_depth"] == (2 if kind == "range" else 1) and route["open_small_passes"] >= 3, route
     assert route["eq_factored_rounds"] > 0 and route["rw_leaf_rounds"] > 0, route
