@@ -307,6 +307,10 @@ LassoClaims lasso_argue(Ctx& c, const lh_lasso_table& tb, size_t n, const LassoC
     {
       ArenaScope scope(c.arena);
       const Fr* a_tab = a;
+      struct HintGuard {  // the hint is this sum-check's alone, whatever way it ends
+        Ctx& c;
+        ~HintGuard() { c.sc_u32 = Ctx::ScU32(); }
+      } hint_guard{c};
       if (!a_tab) {
         // no field-element view of the output column: the sum-check runs its first three rounds from the 32-bit column where
         // it can (a_sums above are rounds 0 and 1) and fills this table itself where it cannot (dev.hpp Ctx::sc_u32)
