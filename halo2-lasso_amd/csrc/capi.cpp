@@ -88,6 +88,8 @@ lh_status lh_ctx_create(int device_id, lh_ctx** out) {
   memset(ctx->c.flag, 0, 256);
   LH_HIP(hipMalloc((void**)&ctx->c.ticket, 256));  // word 0: ticket, word 8: device flag, words 32..47: the tail's relay chunks
   LH_HIP(hipMemset(ctx->c.ticket, 0, 256));
+  LH_HIP(hipMalloc((void**)&ctx->c.fin_lanes, (size_t)FIN_LANE_SUMS * 64));
+  LH_HIP(hipMemset(ctx->c.fin_lanes, 0, (size_t)FIN_LANE_SUMS * 64));
   *out = ctx;
   LH_CATCH
 }
@@ -142,6 +144,7 @@ void lh_ctx_destroy(lh_ctx* ctx) {
   if (ctx->c.flag) (void)hipHostFree(ctx->c.flag);
   if (ctx->c.lanes_host) (void)hipHostFree(ctx->c.lanes_host);
   if (ctx->c.ticket) (void)hipFree(ctx->c.ticket);
+  if (ctx->c.fin_lanes) (void)hipFree(ctx->c.fin_lanes);
   (void)hipStreamDestroy(ctx->c.stream);
   delete ctx;
 }

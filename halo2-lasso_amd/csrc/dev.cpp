@@ -190,7 +190,7 @@ void Ctx::aux_streams() {
   LH_HIP(hipEventCreateWithFlags(&aux_ev, hipEventDisableTiming));
 }
 ScFinishArgs Ctx::finish_for_aux(uint32_t grid, uint32_t seq) {
-  ScFinishArgs f{ticket + 16, (uint32_t)(aux_ticket_base + grid - 1), nullptr, flag + 4, seq, nullptr, 0};
+  ScFinishArgs f{ticket + 16, (uint32_t)(aux_ticket_base + grid - 1), nullptr, flag + 4, seq, nullptr, 0, nullptr};
   if (grid > 1) aux_ticket_base += grid;
   return f;
 }
@@ -211,7 +211,10 @@ void Ctx::wait_flag_aux(uint32_t seq) {
 }
 
 ScFinishArgs Ctx::finish_for(uint32_t grid, Fr* out_host, uint32_t seq) {
-  ScFinishArgs f{ticket, (uint32_t)(ticket_base + grid - 1), out_host, flag, seq, nullptr, 0};
+  // (the lane buffer serves launches of at most 16 sums per workgroup, one at a time: the kernels of this ctx's stream)
+  static const bool lanes_on = !(getenv("LH_FIN_LANES") && atoi(getenv("LH_FIN_LANES")) == 0);
+  ScFinishArgs f{ticket, (uint32_t)(ticket_base + grid - 1), out_host, flag, seq, nullptr, 0,
+                 lanes_on && grid > 1 && (uint64_t)grid * 16 <= FIN_LANE_SUMS ? fin_lanes : nullptr};
   if (sc_redirect) f.out_host = sc_redirect, f.flag = ticket + 8, f.wide = sc_wide, f.tag = sc_tag;  // sharded round: a device word nobody waits on
   if (grid > 1) ticket_base += grid;  // single-workgroup launches draw no ticket
   return f;

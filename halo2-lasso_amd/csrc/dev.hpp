@@ -100,7 +100,14 @@ struct ScFinishArgs {
   // without losing a carry; null otherwise
   uint64_t* wide;
   uint32_t tag;
+  // the workgroups' partial sums on their way to the workgroup that draws the launch's last ticket, as 8-byte lanes
+  // (limb | seq << 32) in a buffer that holds nothing else (Ctx::fin_lanes, resident.cuh fin_put / fin_get): each lane
+  // validates itself, so the hand-off needs no fence - an agent-scope release per workgroup makes the L2 of its XCD walk its
+  // dirty lines, ~27 ns per workgroup of a launch that has just stored a table (tools/ubench/u32_bind.hip: a 2^24-entry
+  // bind 0.147 -> 0.108 ms).  Null: the partials travel through `partials` under release / acquire fences.
+  uint64_t* lanes;
 };
+constexpr uint32_t FIN_LANE_SUMS = 65536;  // partial sums the lane buffer holds (a launch's workgroups x its sums per workgroup)
 // a lane of the all-reduce variant: bits [0, 40) the sum of <= 2^8 32-bit limbs, bits [40, 64) the sum of the ranks' tags -
 // every rank stamps the same tag < 2^24 / R, so a lane whose upper bits read R * tag is the finished sum of THIS round
 // (lanes are 8-byte stores: each validates itself, no flag and no ordering between them is needed)
@@ -288,6 +295,7 @@ struct Ctx {
                                // word 10: the resident grand-product kernel's start verdict; words 32..47: the resident
                                // tail's relay chunks)
   uint32_t ticket_base = 0;    // its value before the next launch
+  uint64_t* fin_lanes = nullptr;  // ScFinishArgs::lanes: 8 lanes per partial sum, FIN_LANE_SUMS of them; zeroed once, then only tagged lanes
   // a second stream of the ctx for work that runs BESIDE the ctx's stream inside one call (msm.hip: the tails of a batch's
   // first half); its kernels draw tickets from word 16 and publish to flag word 4, so the two streams never share a counter
   hipStream_t aux_stream = nullptr;

@@ -58,7 +58,7 @@ std::string operand(uint32_t kind, uint32_t idx) {
 std::string generate(const uint32_t* code, size_t num_instrs, uint32_t num_regs, uint32_t result_reg, int D) {
   std::ostringstream s;
   s << "#include \"ff.cuh\"\n#include \"reduce.cuh\"\nusing namespace lh;\n"
-       "struct Fin { unsigned* ticket; unsigned last_ticket; Fr* out_host; unsigned* flag; unsigned seq; unsigned long long* wide; unsigned tag; };\n"
+       "struct Fin { unsigned* ticket; unsigned last_ticket; Fr* out_host; unsigned* flag; unsigned seq; unsigned long long* wide; unsigned tag; unsigned long long* lanes; };\n"
        "struct Args { const Fr* in["
     << SC_MAX_TABLES
     << "]; const Fr* consts; unsigned long long size; Fr* partials; Fin fin; };\n"
@@ -208,21 +208,47 @@ std::string generate(const uint32_t* code, size_t num_instrs, uint32_t num_regs,
        // epilogue: wave sums to global memory, the workgroup that draws the launch's last ticket adds them up per
        // evaluation point and publishes to pinned memory + flag (the protocol of sc_round_prog_kernel)
        "  acc = wave_reduce_sum(acc);\n"
+       // (with a lane buffer - dev.hpp ScFinishArgs::lanes, the protocol of resident.cuh fin_put / fin_get - the wave sums
+       //  travel as self-validating 8-byte lanes and nobody fences)
+       "  unsigned long long* const lanes = a.fin.lanes;\n"
        "  if (lane == 0) {\n"
-       "    a.partials[group * D + wave] = acc;\n"
-       "    __threadfence();\n"
+       "    if (lanes) {\n"
+       "      for (int k = 0; k < 8; k++)\n"
+       "        __hip_atomic_store(&lanes[(group * D + wave) * 8 + k], (unsigned long long)acc.l[k] | ((unsigned long long)a.fin.seq << 32),\n"
+       "                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
+       "    } else {\n"
+       "      a.partials[group * D + wave] = acc;\n"
+       "      __threadfence();\n"
+       "    }\n"
        "  }\n"
        "  __syncthreads();\n"
        "  if (threadIdx.x == 0) {\n"
-       "    const unsigned t = __hip_atomic_fetch_add(a.fin.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);\n"
+       "    const unsigned t = lanes ? __hip_atomic_fetch_add(a.fin.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)\n"
+       "                             : __hip_atomic_fetch_add(a.fin.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);\n"
        "    is_last = t == a.fin.last_ticket;\n"
        "  }\n"
        "  __syncthreads();\n"
        "  if (!is_last) return;\n"
-       "  __threadfence();\n"
+       "  if (!lanes) __threadfence();\n"
        "  for (int x = w; x < D; x += NW) {\n"
        "    Fr a2 = Fr::zero();\n"
-       "    for (unsigned long long i = lane; i < ngroups; i += 64) a2 = add(a2, a.partials[i * D + x]);\n"
+       "    for (unsigned long long i = lane; i < ngroups; i += 64) {\n"
+       "      Fr p;\n"
+       "      if (lanes) {\n"
+       "        for (int k = 0; k < 8; k++) {\n"
+       "          unsigned long long v = __hip_atomic_load(&lanes[(i * D + x) * 8 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
+       "          for (unsigned spin = 0; (unsigned)(v >> 32) != a.fin.seq; spin++) {\n"
+       "            if (spin > (1u << 22)) __builtin_trap();\n"
+       "            __builtin_amdgcn_s_sleep(1);\n"
+       "            v = __hip_atomic_load(&lanes[(i * D + x) * 8 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
+       "          }\n"
+       "          p.l[k] = (unsigned)v;\n"
+       "        }\n"
+       "      } else {\n"
+       "        p = a.partials[i * D + x];\n"
+       "      }\n"
+       "      a2 = add(a2, p);\n"
+       "    }\n"
        "    a2 = wave_reduce_sum(a2);\n"
        "    if (lane == 0) {\n"
        "      a.fin.out_host[x] = a2;\n"

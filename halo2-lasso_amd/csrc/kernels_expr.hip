@@ -330,20 +330,22 @@ __global__ __launch_bounds__(512) void sc_round_prog_kernel(ProgRound pr, size_t
     if (threadIdx.x == 0) publish_round(fin, D);
     return;
   }
+  // (the partial sums travel as self-validating lanes when the launch has a lane buffer - resident.cuh fin_put: no fence)
   if (lane == 0) {
-    partials[(size_t)blockIdx.x * D + wave] = acc;
-    __threadfence();
+    fin_put(fin, partials, (size_t)blockIdx.x * D + wave, acc);
+    if (!fin.lanes) __threadfence();
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const uint32_t t = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t t = fin.lanes ? __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                 : __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     is_last = t == fin.last_ticket;
   }
   __syncthreads();
   if (!is_last) return;
-  __threadfence();
+  if (!fin.lanes) __threadfence();
   Fr a2 = Fr::zero();
-  for (uint32_t i = lane; i < gridDim.x; i += 64) a2 = add(a2, partials[(size_t)i * D + wave]);
+  for (uint32_t i = lane; i < gridDim.x; i += 64) a2 = add(a2, fin_get(fin, partials, (size_t)i * D + wave));
   a2 = wave_reduce_sum(a2);
   if (lane == 0) {
     fin.out_host[wave] = a2;
@@ -428,17 +430,12 @@ __global__ __launch_bounds__(256) void lin_sums_kernel(LinSums ls, size_t size, 
     return;
   }
   if (threadIdx.x == 0) {
-    partials[(size_t)blockIdx.x * 2] = ev, partials[(size_t)blockIdx.x * 2 + 1] = od;
-    __threadfence();
-    const uint32_t t = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    is_last = t == fin.last_ticket;
+    fin_put(fin, partials, (size_t)blockIdx.x * 2, ev), fin_put(fin, partials, (size_t)blockIdx.x * 2 + 1, od);
   }
-  __syncthreads();
-  if (!is_last) return;
-  __threadfence();
+  if (!fin_ticket(fin, &is_last)) return;
   for (int x = 0; x < 2; x++) {
     Fr a2 = Fr::zero();
-    for (uint32_t i = threadIdx.x; i < gridDim.x; i += blockDim.x) a2 = add(a2, partials[(size_t)i * 2 + x]);
+    for (uint32_t i = threadIdx.x; i < gridDim.x; i += blockDim.x) a2 = add(a2, fin_get(fin, partials, (size_t)i * 2 + x));
     a2 = block_reduce_sum(a2, lds);
     if (threadIdx.x == 0) fin.out_host[x] = a2;
   }

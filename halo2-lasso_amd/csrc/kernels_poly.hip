@@ -7,6 +7,7 @@
 #include "dev.hpp"
 #include "ff_host.hpp"
 #include "reduce.cuh"
+#include "resident.cuh"
 
 namespace lh {
 
@@ -800,27 +801,18 @@ __global__ __launch_bounds__(256) void sc_round_u32_bind2_kernel(const uint32_t*
   if (gridDim.x == 1) {
     if (threadIdx.x == 0) {
       fin.out_host[0] = acc;
-      __threadfence_system();
-      __hip_atomic_store(fin.flag, fin.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      publish_round(fin, 1);
     }
     return;
   }
-  if (threadIdx.x == 0) {
-    partials[blockIdx.x] = acc;
-    __threadfence();
-    const uint32_t t = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    is_last = t == fin.last_ticket;
-  }
-  __syncthreads();
-  if (!is_last) return;
-  __threadfence();
+  if (threadIdx.x == 0) fin_put(fin, partials, blockIdx.x, acc);
+  if (!fin_ticket(fin, &is_last)) return;
   Fr a2 = Fr::zero();
-  for (uint32_t i = threadIdx.x; i < gridDim.x; i += blockDim.x) a2 = add(a2, partials[i]);
+  for (uint32_t i = threadIdx.x; i < gridDim.x; i += blockDim.x) a2 = add(a2, fin_get(fin, partials, i));
   a2 = block_reduce_sum(a2, lds);
   if (threadIdx.x == 0) {
     fin.out_host[0] = a2;
-    __threadfence_system();
-    __hip_atomic_store(fin.flag, fin.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    publish_round(fin, 1);
   }
 }
 void k_sc_round_u32_bind2(Ctx& c, const uint32_t* col, const Fr* eq_level, const Fr& r0, const Fr& r1, size_t size, Fr* out,

@@ -58,27 +58,12 @@ typedef ScFinishArgs ScFinish;
 template <int D>
 __device__ __forceinline__ void finish_round(const ScFinish& f, const Fr* __restrict__ partials, Fr* lds) {
   __shared__ int is_last;
-  if (threadIdx.x < 64) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's partial stores have left
-    if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const uint32_t t = __hip_atomic_fetch_add(f.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = t == f.last_ticket;
-      if (last) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      is_last = last;
-    }
-  }
-  __syncthreads();
-  if (!is_last) return;
+  if (!fin_ticket(f, &is_last)) return;
   const uint32_t blocks = gridDim.x;
 #pragma unroll
   for (int x = 0; x < D; x++) {
     Fr acc = Fr::zero();
-    for (uint32_t i = threadIdx.x; i < blocks; i += blockDim.x) acc = add(acc, partials[(size_t)i * D + x]);
+    for (uint32_t i = threadIdx.x; i < blocks; i += blockDim.x) acc = add(acc, fin_get(f, partials, (size_t)i * D + x));
     acc = block_reduce_sum(acc, lds);
     if (threadIdx.x == 0) f.out_host[x] = acc;
   }
@@ -166,7 +151,7 @@ __global__ __launch_bounds__(256) LH_SC_WAVES_ATTR(D) void sc_round_kernel(ScArg
 #pragma unroll
   for (int x = 0; x < D; x++) {
     Fr v = block_reduce_sum(acc[x], lds);
-    if (threadIdx.x == 0) partials[(size_t)blockIdx.x * D + x] = v;
+    if (threadIdx.x == 0) fin_put(fin, partials, (size_t)blockIdx.x * D + x, v);
   }
   if (gridDim.x == 1) {  // single workgroup: `partials` IS the host buffer
     if (threadIdx.x == 0) publish_round(fin, D);
@@ -246,8 +231,8 @@ __global__ __launch_bounds__(256) LH_E_WAVES_ATTR(LH_E_WAVES_E2) void sc_round_e
   Fr q2, q1;
   reduce_by_parity(acc, odd, lds, q2, q1);
   if (threadIdx.x == 0) {
-    partials[(size_t)blockIdx.x * 2] = q1;
-    partials[(size_t)blockIdx.x * 2 + 1] = q2;
+    fin_put(fin, partials, (size_t)blockIdx.x * 2, q1);
+    fin_put(fin, partials, (size_t)blockIdx.x * 2 + 1, q2);
   }
   if (gridDim.x == 1) {
     if (threadIdx.x == 0) publish_round(fin, 2);
@@ -329,8 +314,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LH_PP_WAVES
   Fr q2, q1;
   reduce_by_parity(acc, odd, lds, q2, q1);
   if (threadIdx.x == 0) {
-    partials[(size_t)blockIdx.x * 2] = q1;
-    partials[(size_t)blockIdx.x * 2 + 1] = q2;
+    fin_put(fin, partials, (size_t)blockIdx.x * 2, q1);
+    fin_put(fin, partials, (size_t)blockIdx.x * 2 + 1, q2);
   }
   if (gridDim.x == 1) {
     if (threadIdx.x == 0) publish_round(fin, 2);
@@ -428,7 +413,7 @@ __global__ __launch_bounds__(256) void sc_round_lds_kernel(ScLdsArgs g, size_t s
   if (threadIdx.x < D) {
     Fr s = Fr::zero();
     for (uint32_t m = 0; m < rd.num_terms; m++) s = add(s, red[m * D + threadIdx.x]);
-    partials[(size_t)blockIdx.x * D + threadIdx.x] = s;
+    fin_put(fin, partials, (size_t)blockIdx.x * D + threadIdx.x, s);
     if (gridDim.x == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
   }
   if (gridDim.x == 1) {  // single workgroup: `partials` IS the host buffer
@@ -883,8 +868,8 @@ __global__ __launch_bounds__(256) LH_E_WAVES_ATTR(LH_E_WAVES_OPEN) void sc_round
     Fr q0, q1;
     reduce_by_parity(acc[m], odd, lds, q0, q1);
     if (threadIdx.x == 0) {
-      partials[(size_t)blockIdx.x * NQ + 2 * m] = q0;
-      partials[(size_t)blockIdx.x * NQ + 2 * m + 1] = q1;
+      fin_put(fin, partials, (size_t)blockIdx.x * NQ + 2 * m, q0);
+      fin_put(fin, partials, (size_t)blockIdx.x * NQ + 2 * m + 1, q1);
     }
   }
   if (gridDim.x == 1) {
@@ -960,8 +945,8 @@ __global__ __launch_bounds__(256) LH_E_WAVES_ATTR(LH_E_WAVES_RW) void sc_round_r
   Fr q2, q1;
   reduce_by_parity(acc, odd, lds, q2, q1);
   if (threadIdx.x == 0) {
-    partials[(size_t)blockIdx.x * 2] = q1;
-    partials[(size_t)blockIdx.x * 2 + 1] = q2;
+    fin_put(fin, partials, (size_t)blockIdx.x * 2, q1);
+    fin_put(fin, partials, (size_t)blockIdx.x * 2 + 1, q2);
   }
   if (gridDim.x == 1) {
     if (threadIdx.x == 0) publish_round(fin, 2);

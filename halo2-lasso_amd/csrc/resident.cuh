@@ -11,6 +11,59 @@ __device__ __forceinline__ void publish_flag(uint32_t* flag, uint32_t seq) {
   __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// A workgroup's partial sum number idx on its way to the workgroup that finishes the launch (dev.hpp ScFinishArgs::lanes):
+// eight self-validating 8-byte lanes when the launch has a lane buffer, a plain store (under the fences of the ticket
+// protocol - or straight into the host buffer of a single-workgroup launch) when not.
+__device__ __forceinline__ void fin_put(const ScFinishArgs& f, Fr* partials, size_t idx, const Fr& v) {
+  if (f.lanes && gridDim.x * gridDim.y > 1) {
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+      __hip_atomic_store(&f.lanes[idx * 8 + k], (uint64_t)v.l[k] | ((uint64_t)f.seq << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    partials[idx] = v;
+  }
+}
+// (by the finishing workgroup, after the last ticket: every lane was stored before its workgroup drew its ticket, so the
+//  poll is a formality - a lane that never arrives is a bug, and ends the kernel rather than hanging the device)
+__device__ __forceinline__ Fr fin_get(const ScFinishArgs& f, const Fr* partials, size_t idx) {
+  if (!f.lanes) return partials[idx];
+  Fr p;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    uint64_t v = __hip_atomic_load(&f.lanes[idx * 8 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t spin = 0; (uint32_t)(v >> 32) != f.seq; spin++) {
+      if (spin > (1u << 22)) __builtin_trap();
+      __builtin_amdgcn_s_sleep(1);
+      v = __hip_atomic_load(&f.lanes[idx * 8 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    p.l[k] = (uint32_t)v;
+  }
+  return p;
+}
+// the ticket of a workgroup whose partial sums are on their way (its wave 0 stored them): true for the workgroup that
+// finishes the launch.  With lanes: no fence (resident.cuh fin_put); without: agent-scope release by every producer,
+// agent-scope acquire by the one consumer (cdna_hip_programming.md Guideline 16).  Every thread of the workgroup calls it.
+__device__ __forceinline__ bool fin_ticket(const ScFinishArgs& f, int* is_last_lds) {
+  if (threadIdx.x < 64) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's partial stores have left
+    if (threadIdx.x == 0) {
+      if (!f.lanes) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      const uint32_t t = __hip_atomic_fetch_add(f.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = t == f.last_ticket;
+      if (last && !f.lanes) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      *is_last_lds = last;
+    }
+  }
+  __syncthreads();
+  return *is_last_lds != 0;
+}
+
 // the closing step of a round kernel, by the ONE thread that publishes, once the launch's D sums are in f.out_host and
 // visible to it (its own stores, or the workgroup's before a barrier).  Sharded rounds of the all-reduce variant
 // (ScFinishArgs::wide): the sums leave a second time as tagged u64 lanes - re-read with agent-scope loads, the stores
