@@ -210,11 +210,14 @@ void Ctx::wait_flag_aux(uint32_t seq) {
   }
 }
 
-ScFinishArgs Ctx::finish_for(uint32_t grid, Fr* out_host, uint32_t seq) {
+ScFinishArgs Ctx::finish_for(uint32_t grid, Fr* out_host, uint32_t seq, double stored_bytes) {
   // (the lane buffer serves launches of at most 16 sums per workgroup, one at a time: the kernels of this ctx's stream)
-  static const bool lanes_on = !(getenv("LH_FIN_LANES") && atoi(getenv("LH_FIN_LANES")) == 0);
-  ScFinishArgs f{ticket, (uint32_t)(ticket_base + grid - 1), out_host, flag, seq, nullptr, 0,
-                 lanes_on && grid > 1 && (uint64_t)grid * 16 <= FIN_LANE_SUMS ? fin_lanes : nullptr};
+  // Every launch hands over in lanes (measured on 2^24 AND lookups: no launch 58.9-59.0 ms, launches that store >= 2^28 bytes
+  // 58.0, >= 2^25 bytes 57.4, every launch 57.1; 2^22 range 15.67 / 15.37 / 15.30; 2^20: within the noise).
+  // LH_FIN_LANES_MIN_BYTES: the smallest launch (by the bytes its workgroups store) that does - development A/B; -1: none
+  static const double lanes_min = getenv("LH_FIN_LANES_MIN_BYTES") ? atof(getenv("LH_FIN_LANES_MIN_BYTES")) : 0.0;
+  const bool lanes = lanes_min >= 0 && stored_bytes >= lanes_min && grid > 1 && (uint64_t)grid * 16 <= FIN_LANE_SUMS;
+  ScFinishArgs f{ticket, (uint32_t)(ticket_base + grid - 1), out_host, flag, seq, nullptr, 0, lanes ? fin_lanes : nullptr};
   if (sc_redirect) f.out_host = sc_redirect, f.flag = ticket + 8, f.wide = sc_wide, f.tag = sc_tag;  // sharded round: a device word nobody waits on
   if (grid > 1) ticket_base += grid;  // single-workgroup launches draw no ticket
   return f;

@@ -304,7 +304,8 @@ struct Ctx {
   void aux_streams();  // creates them on first use
   struct ScFinishArgs finish_for_aux(uint32_t grid, uint32_t seq);
   void wait_flag_aux(uint32_t seq);
-  struct ScFinishArgs finish_for(uint32_t grid, Fr* out_host, uint32_t seq);
+  // (`stored_bytes`: what the launch's workgroups store besides their sums - LH_FIN_LANES_MIN_BYTES, development)
+  struct ScFinishArgs finish_for(uint32_t grid, Fr* out_host, uint32_t seq, double stored_bytes = 0);
   uint32_t next_seq() { return ++flag_seq; }
   // host -> resident kernel mailbox (second cache line of the flag allocation)
   struct TailMbox* mbox() { return (struct TailMbox*)((char*)flag + 64); }

@@ -823,7 +823,7 @@ void k_sc_round_u32_bind2(Ctx& c, const uint32_t* col, const Fr* eq_level, const
   const size_t entries = 2 * size;
   const size_t g = std::min<size_t>((entries + 255) / 256, (size_t)c.num_cus * 8);
   Fr* partials = c.arena.alloc_n<Fr>(g);
-  const ScFinishArgs fin = c.finish_for((uint32_t)g, out_host, seq);
+  const ScFinishArgs fin = c.finish_for((uint32_t)g, out_host, seq, 32.0 * (double)entries);
   host::Fr h0, h1;
   const host::Fr one = host::Fr::one();
   memcpy(&h0, &r0, sizeof(h0));

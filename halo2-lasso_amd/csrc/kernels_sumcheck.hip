@@ -895,7 +895,7 @@ void k_sc_round_open(Ctx& c, const ScOpenRound& rd, bool bind, size_t size, Fr* 
   size_t g = std::min<size_t>((2 * size + 255) / 256, (size_t)c.num_cus * sc_entry_blocks_per_cu());
   const int nq = 2 * (int)rd.num_terms;
   Fr* partials = g == 1 ? out_host : c.arena.alloc_n<Fr>(g * nq);
-  const ScFinish fin = c.finish_for((uint32_t)g, out_host, seq);
+  const ScFinish fin = c.finish_for((uint32_t)g, out_host, seq, bind ? 64.0 * (double)size * rd.num_terms : 0.0);
   {
     // algorithmic bytes: 96 B per bound entry of the polys (192 B per pair and term) + the eq-level entry
     ProfScope ps(c, bind ? "sc_round_open<bind>" : "sc_round_open<first>", ((bind ? 192.0 : 64.0) + 32.0) * (double)size * rd.num_terms,
@@ -974,7 +974,7 @@ void k_sc_round_rw(Ctx& c, const ScRwRound& rd, bool bind, size_t size, Fr* out_
   out_host = c.round_out(out_host);
   size_t g = std::min<size_t>((2 * size + 255) / 256, (size_t)c.num_cus * sc_entry_blocks_per_cu());
   Fr* partials = g == 1 ? out_host : c.arena.alloc_n<Fr>(g * 2);
-  const ScFinish fin = c.finish_for((uint32_t)g, out_host, seq);
+  const ScFinish fin = c.finish_for((uint32_t)g, out_host, seq, bind ? 64.0 * (double)size * 2.0 * rd.num_pairs : 0.0);
   {
     // algorithmic bytes: 96 B per bound entry of the 2 P tables read (192 B per pair and table) + the eq-level entry;
     // products per pair: 4 per tree pair (+ 4 binds), 2 for the eq factor
@@ -1023,7 +1023,10 @@ void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, F
   ArenaScope scope(c.arena);
   // sharded rounds (sumcheck.cpp): the D sums stay on the device (all-gather and sum-and-publish follow on the stream)
   evals_host = c.round_out(evals_host);
-  auto finish = [&](size_t grid) { return c.finish_for((uint32_t)grid, evals_host, seq); };
+  // (bytes a binding round stores: half of what it moves)
+  auto finish = [&](size_t grid, bool streams = false) {
+    return c.finish_for((uint32_t)grid, evals_host, seq, streams && bind ? bytes / 3.0 : 0.0);
+  };
 
   // pairs per workgroup of the LDS-staged kernel
   uint32_t P = (uint32_t)std::min<size_t>(size, 64);
@@ -1077,7 +1080,7 @@ void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, F
     // the factored degree-2 rounds (GKR layers, Surge over one table): one lane per bound entry
     size_t g2 = std::min<size_t>((2 * size + 255) / 256, (size_t)c.num_cus * sc_entry_blocks_per_cu());
     Fr* partials = g2 == 1 ? evals_host : c.arena.alloc_n<Fr>(g2 * 2);
-    const ScFinish kflag = finish(g2);
+    const ScFinish kflag = finish(g2, true);
     c.last_round_folded = rd.pp == 2 && bind;
     if (rd.pp) {
       // products per pair: binds, one per coefficient still applied on the way, ~0.62 per term for the shared reductions
@@ -1098,7 +1101,7 @@ void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, F
   size_t cap = (size_t)c.num_cus * 4;
   if (g > cap) g = cap;
   Fr* partials = g == 1 ? evals_host : c.arena.alloc_n<Fr>(g * degree);
-  const ScFinish kflag = finish(g);
+  const ScFinish kflag = finish(g, true);
   {
     char name[40];
     snprintf(name, sizeof name, "sc_round<%d,%s>%s", degree, bind ? "bind" : "first", tp > 1 ? "/tp" : "");

@@ -27,17 +27,20 @@ __device__ __forceinline__ void fin_put(const ScFinishArgs& f, Fr* partials, siz
 //  poll is a formality - a lane that never arrives is a bug, and ends the kernel rather than hanging the device)
 __device__ __forceinline__ Fr fin_get(const ScFinishArgs& f, const Fr* partials, size_t idx) {
   if (!f.lanes) return partials[idx];
+  uint64_t v[8];
+  for (uint32_t spin = 0;; spin++) {  // all eight loads in flight, then the tags
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = __hip_atomic_load(&f.lanes[idx * 8 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int k = 0; k < 8; k++) ok = ok && (uint32_t)(v[k] >> 32) == f.seq;
+    if (ok) break;
+    if (spin > (1u << 22)) __builtin_trap();
+    __builtin_amdgcn_s_sleep(1);
+  }
   Fr p;
 #pragma unroll
-  for (int k = 0; k < 8; k++) {
-    uint64_t v = __hip_atomic_load(&f.lanes[idx * 8 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (uint32_t spin = 0; (uint32_t)(v >> 32) != f.seq; spin++) {
-      if (spin > (1u << 22)) __builtin_trap();
-      __builtin_amdgcn_s_sleep(1);
-      v = __hip_atomic_load(&f.lanes[idx * 8 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    p.l[k] = (uint32_t)v;
-  }
+  for (int k = 0; k < 8; k++) p.l[k] = (uint32_t)v[k];
   return p;
 }
 // the ticket of a workgroup whose partial sums are on their way (its wave 0 stored them): true for the workgroup that

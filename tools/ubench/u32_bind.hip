@@ -55,7 +55,7 @@ __device__ __forceinline__ Fr wide_redc(const Wide& acc) {
 struct W4 { Fr w[4]; };
 template <int MODE>  // 0 full, 1 no eq product, 2 no store, 3 neither (loads + reduction only), 4 copy-shaped (no arithmetic)
 __global__ __launch_bounds__(256) void bind2(const uint32_t* __restrict__ col, const Fr* __restrict__ eq, W4 k, size_t entries,
-                                             Fr* __restrict__ out, Fr* __restrict__ partials, uint32_t* ticket, uint32_t seq) {
+                                             Fr* __restrict__ out, Fr* __restrict__ partials, uint32_t* ticket, uint32_t seq, int getenv_batched) {
   Fr acc = Fr::zero();
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < entries; i += (size_t)gridDim.x * blockDim.x) {
     const uint4 a = ((const uint4*)col)[i];
@@ -101,12 +101,26 @@ __global__ __launch_bounds__(256) void bind2(const uint32_t* __restrict__ col, c
     Fr a2 = Fr::zero();
     for (uint32_t i = threadIdx.x; i < gridDim.x; i += blockDim.x) {
       Fr p;
+      if (getenv_batched) {  // all eight loads in flight, then the tags
+        uint64_t v[8];
+        bool ok;
+        do {
+          ok = true;
 #pragma unroll
-      for (int k = 0; k < 8; k++) {
-        uint64_t v;
-        do v = __hip_atomic_load(&lanes[(size_t)i * 8 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while ((uint32_t)(v >> 32) != seq);
-        p.l[k] = (uint32_t)v;
+          for (int k = 0; k < 8; k++) v[k] = __hip_atomic_load(&lanes[(size_t)i * 8 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+          for (int k = 0; k < 8; k++) ok = ok && (uint32_t)(v[k] >> 32) == seq;
+        } while (!ok);
+#pragma unroll
+        for (int k = 0; k < 8; k++) p.l[k] = (uint32_t)v[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          uint64_t v;
+          do v = __hip_atomic_load(&lanes[(size_t)i * 8 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          while ((uint32_t)(v >> 32) != seq);
+          p.l[k] = (uint32_t)v;
+        }
       }
       a2 = add(a2, p);
     }
@@ -160,7 +174,7 @@ static void run(const char* name, const uint32_t* col, const Fr* eq, const W4& k
       usleep(atoi(idle));
     }
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL(bind2<MODE>, dim3(grid), dim3(256), 0, 0, col, eq, k, entries, out, partials, ticket, ++g_seq);
+    hipLaunchKernelGGL(bind2<MODE>, dim3(grid), dim3(256), 0, 0, col, eq, k, entries, out, partials, ticket, ++g_seq, getenv("BATCHED") ? 1 : 0);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms;
