@@ -840,6 +840,20 @@ static size_t sc_entry_blocks_per_cu() {
   return v;
 }
 
+// grid of an entry-per-lane round kernel over `entries` bound entries: every workgroup ends with block reductions, a ticket
+// and 8 lanes per partial sum for the finishing workgroup to collect, so a launch of few entries gives a lane
+// LH_SC_ENTRIES_PER_LANE of them (default 4) rather than one - but never fewer than two workgroups per CU
+static size_t sc_entry_grid(const Ctx& c, size_t entries) {
+  static const size_t per_lane = [] {
+    const char* e = getenv("LH_SC_ENTRIES_PER_LANE");
+    return e && atoi(e) > 0 ? (size_t)atoi(e) : (size_t)4;
+  }();
+  const size_t full = (entries + 255) / 256, cap = (size_t)c.num_cus * sc_entry_blocks_per_cu();
+  size_t g = (entries + 256 * per_lane - 1) / (256 * per_lane);
+  g = std::max(g, std::min(full, (size_t)c.num_cus * 2));
+  return std::max<size_t>(1, std::min(std::min(g, full), cap));
+}
+
 // ------------------------------------------------------------------ batch-opening rounds with factored eq tables
 // expression sum_m eq_m(x) * poly_m(x) (pcs/multilinear.rs:182-190): per term and pair one bind (2 multiplications),
 // two products with the term's eq-level entry; the eq tables are neither read in full nor bound (sumcheck.cpp).
@@ -892,7 +906,7 @@ void k_sc_round_open(Ctx& c, const ScOpenRound& rd, bool bind, size_t size, Fr* 
   const uint32_t seq = c.next_seq();
   ArenaScope scope(c.arena);
   out_host = c.round_out(out_host);  // (sharded rounds: the sums stay on the device, sumcheck.cpp)
-  size_t g = std::min<size_t>((2 * size + 255) / 256, (size_t)c.num_cus * sc_entry_blocks_per_cu());
+  size_t g = sc_entry_grid(c, 2 * size);
   const int nq = 2 * (int)rd.num_terms;
   Fr* partials = g == 1 ? out_host : c.arena.alloc_n<Fr>(g * nq);
   const ScFinish fin = c.finish_for((uint32_t)g, out_host, seq, bind ? 64.0 * (double)size * rd.num_terms : 0.0);
@@ -972,7 +986,7 @@ void k_sc_round_rw(Ctx& c, const ScRwRound& rd, bool bind, size_t size, Fr* out_
   const uint32_t seq = c.next_seq();
   ArenaScope scope(c.arena);
   out_host = c.round_out(out_host);
-  size_t g = std::min<size_t>((2 * size + 255) / 256, (size_t)c.num_cus * sc_entry_blocks_per_cu());
+  size_t g = sc_entry_grid(c, 2 * size);
   Fr* partials = g == 1 ? out_host : c.arena.alloc_n<Fr>(g * 2);
   const ScFinish fin = c.finish_for((uint32_t)g, out_host, seq, bind ? 64.0 * (double)size * 2.0 * rd.num_pairs : 0.0);
   {
@@ -1078,7 +1092,7 @@ void k_sc_round(Ctx& c, const ScRound& rd, int degree, bool bind, size_t size, F
   const uint32_t tp = (rd.num_terms > 1 && size * rd.num_terms <= tp_max) ? rd.num_terms : 1u;
   if (degree == 2 && rd.eq_level && tp == 1) {
     // the factored degree-2 rounds (GKR layers, Surge over one table): one lane per bound entry
-    size_t g2 = std::min<size_t>((2 * size + 255) / 256, (size_t)c.num_cus * sc_entry_blocks_per_cu());
+    size_t g2 = sc_entry_grid(c, 2 * size);
     Fr* partials = g2 == 1 ? evals_host : c.arena.alloc_n<Fr>(g2 * 2);
     const ScFinish kflag = finish(g2, true);
     c.last_round_folded = rd.pp == 2 && bind;
