@@ -423,6 +423,9 @@ void k_gather_heads(Ctx&, const Fr* const* in, size_t count, int k, Fr* out_host
 void k_lincomb(Ctx&, const Fr* const* polys, const Fr* w, size_t count, size_t n, Fr* out);
 // out[b] = lo + x (hi - lo), lo = sum_k w_k p_k[b], hi = sum_k w_k p_k[b + half]
 void k_lincomb_fold(Ctx&, const Fr* const* polys, const Fr* w, size_t count, size_t half, const Fr& x, Fr* out);
+// the same first step of g = sum_k coef_k col_k over 32-bit columns (entries beyond lens[k] are zero); false: too many columns
+bool k_lincomb_fold_small(Ctx&, const uint32_t* const* cols, const size_t* lens, const Fr* coef, size_t count, size_t half,
+                          const Fr& x, Fr* out);
 // out[i] = <polys[i], weights>, i < count ; result on host
 void k_inner_products(Ctx&, const Fr* const* polys, size_t count, const Fr* weights, size_t n, Fr* out_host);
 // same with u32-valued polys

@@ -655,6 +655,56 @@ void k_lincomb_mixed(Ctx& c, const Fr* const* fr, const Fr* wfr, size_t num_fr, 
   c.sync();  // the pinned staging block is reused by the next caller
 }
 
+// First step of an mKZG opening of g = sum_k coef_k col_k over 32-bit columns (SmallOpen) without g or any field-element
+// view: out[i] = (1 - x) g[i] + x g[i + half] is 2 x 8 multiply-adds per column into one wide accumulator and ONE Montgomery
+// reduction (the weights coef_k (1 - x), coef_k x arrive times R).  Reads 8 B per column and output entry where the fold of
+// the batch opening's merged tables (k_lincomb_fold) read 64 B per table: 2^24 AND lookups, 12 columns against 4 tables.
+constexpr int LCF_MAX = 24;
+struct LcFoldSmall {
+  const uint32_t* p[LCF_MAX];
+  uint64_t len[LCF_MAX];
+  Fr lo[LCF_MAX], hi[LCF_MAX];
+  int count;
+};
+__global__ __launch_bounds__(256) void lincomb_fold_small_kernel(const LcFoldSmall* __restrict__ pkp, size_t half, Fr* __restrict__ out) {
+  const LcFoldSmall& pk = *pkp;
+  GSTRIDE(i, half) {
+    Wide t = Wide::zero();
+    for (int k = 0; k < pk.count; k++) {
+      if (i < pk.len[k]) wide_mac(t, pk.lo[k], pk.p[k][i]);
+      if (i + half < pk.len[k]) wide_mac(t, pk.hi[k], pk.p[k][i + half]);
+    }
+    out[i] = wide_redc(t);
+  }
+}
+bool k_lincomb_fold_small(Ctx& c, const uint32_t* const* cols, const size_t* lens, const Fr* coef, size_t count, size_t half,
+                          const Fr& x, Fr* out) {
+  if (count < 1 || count > (size_t)LCF_MAX || !half) return false;
+  ProfScope ps(c, "lincomb<fold,u32>", 8.0 * half * count + 32.0 * half, 0.15 * half * count + 0.6 * half, (double)half);
+  LcFoldSmall pk;
+  memset(&pk, 0, sizeof(pk));
+  pk.count = (int)count;
+  host::Fr hx, one = host::Fr::one();
+  memcpy(&hx, &x, sizeof(hx));
+  for (size_t k = 0; k < count; k++) {
+    host::Fr ck;
+    memcpy(&ck, &coef[k], sizeof(ck));
+    const host::Fr l = ck * (one - hx), h = ck * hx;
+    Fr dl, dh;
+    memcpy(&dl, &l, sizeof(dl));
+    memcpy(&dh, &h, sizeof(dh));
+    pk.p[k] = cols[k], pk.len[k] = lens[k], pk.lo[k] = prescale_r(dl), pk.hi[k] = prescale_r(dh);
+  }
+  ArenaScope scope(c.arena);  // (the argument block travels through memory: 24 columns are 2 KB)
+  LcFoldSmall* d_pk = (LcFoldSmall*)c.arena.alloc(sizeof(LcFoldSmall));
+  LcFoldSmall* h_pk = (LcFoldSmall*)c.pin(65536);
+  memcpy(h_pk, &pk, sizeof(pk));
+  LH_HIP(hipMemcpyAsync(d_pk, h_pk, sizeof(pk), hipMemcpyHostToDevice, c.stream));
+  hipLaunchKernelGGL(lincomb_fold_small_kernel, grid_for(half), 256, 0, c.stream, d_pk, half, out);
+  c.sync();  // the pinned staging block is reused by the next caller
+  return true;
+}
+
 // out[k] = <u32 column k, weights> for up to IPS_GROUP columns per launch row: the weight is loaded once per entry
 constexpr int IPS_GROUP = 4;  // 6 accumulators of 10 limbs spill (256 B of scratch per lane); 4 keep 4 waves per SIMD
 struct IpSmallPack {

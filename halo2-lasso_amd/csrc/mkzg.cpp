@@ -193,8 +193,16 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
     size_t half = (size_t)1 << (i - lsh);
     Fr* dst = ((num_vars - i) & 1) ? remA : remB;
     const bool keep_q = !(i + depth >= num_vars && !self_check);
-    if (!rem)  // first step of the column route straight from the merged tables (g' is never formed)
-      k_lincomb_fold(c, small->merged.data(), small->merged_w.data(), small->merged.size(), half, dev(point[i]), dst);
+    if (!rem) {  // first step of the column route straight from the 32-bit columns (g' is never formed), else the merged tables
+      std::vector<const uint32_t*> cp;
+      std::vector<size_t> cl;
+      std::vector<Fr> cf;
+      for (size_t k = 0; k < small->cols.size(); k++)
+        if (!small->coef[k].is_zero()) cp.push_back(small->cols[k].ptr), cl.push_back(small->cols[k].len), cf.push_back(dev(small->coef[k]));
+      static const bool from_cols = !(getenv("LH_OPEN_FOLD_COLS") && atoi(getenv("LH_OPEN_FOLD_COLS")) == 0);  // (development A/B)
+      if (!(from_cols && !cp.empty() && k_lincomb_fold_small(c, cp.data(), cl.data(), cf.data(), cp.size(), half, dev(point[i]), dst)))
+        k_lincomb_fold(c, small->merged.data(), small->merged_w.data(), small->merged.size(), half, dev(point[i]), dst);
+    }
     else
       k_quotient_step(c, rem, half, dev(point[i]), keep_q ? q + q_off : nullptr, dst);
     if (keep_q && rem) q_of[i] = q + q_off;
