@@ -210,6 +210,19 @@ struct Ctx {
     bool have_sums = false;
     Fr odd, s2, s3;  // (when have_sums: out_host[1..3] of k_inner_products_small_quads against the sum-check's E_0)
   } sc_u32;
+  // hint for the NEXT sum-check of the batch-opening shape sum_m eq(y_m, .) poly_m (consumed and cleared at its entry):
+  // poly b = sum_k w[k] col[k] over 32-bit columns (entries beyond len[k] are zero) and d_polys[b] has NOT been written.  The
+  // sum-check runs its first three rounds from the columns (sumcheck.cpp: k_inner_products_quads, k_lincomb_bind2) or
+  // fills the tables itself (k_lincomb_mixed) and says so in `built`.
+  struct ScU32Terms {
+    struct Poly {
+      std::vector<const uint32_t*> col;
+      std::vector<size_t> len;
+      std::vector<Fr> w;
+    };
+    std::vector<Poly> polys;  // empty: no hint
+    bool built = false;       // out: the tables of d_polys hold the polys in full
+  } sc_u32_terms;
   // sharded sum-check rounds: the round kernel leaves its D sums in this DEVICE buffer (and "publishes" to a device
   // word) instead of pinned host memory; the all-gather and the sum-and-publish kernel follow on the stream
   Fr* sc_redirect = nullptr;
@@ -440,6 +453,12 @@ void k_inner_products_small_half(Ctx&, const uint32_t* const* polys, size_t coun
 // out_host[0..3] = sum_b e0[b] col[2b], sum_b e0[b] col[2b+1], sum_q (e0[2q] + e0[2q+1]) col[4q+2], the same with col[4q+3]
 // (the claim's two halves - and the sums of rounds 0 and 1), b < 2 quads, q < quads
 void k_inner_products_small_quads(Ctx&, const uint32_t* col, const Fr* e0, size_t quads, Fr* out_host);
+// d_out[4 k + t] (DEVICE, queued on the stream) = sum_q e1[q] cols[k][4 q + t], t = 0..3, q < quads; lens: multiples of 4
+void k_inner_products_quads(Ctx&, const uint32_t* const* cols, const size_t* lens, size_t count, const Fr* e1, size_t quads,
+                            Fr* d_out);
+// out[i] = sum_k w[k] (cols[k][4i..4i+3] bound with (r0, r1)), i < 2 size; out_host[e] = sum_b eq_level[b] out[2b + e]
+void k_lincomb_bind2(Ctx&, const uint32_t* const* cols, const size_t* lens, const Fr* w, size_t count, const Fr& r0, const Fr& r1,
+                     const Fr* eq_level, size_t size, Fr* out, Fr* out_host);
 // round 2 binds r0 and r1 at once: out[i] = the column's entries 4i..4i+3 bound with (r0, r1), i < 2 size;
 // out_host[0] = sum_b eq_level[b] out[2b+1]
 void k_sc_round_u32_bind2(Ctx&, const uint32_t* col, const Fr* eq_level, const Fr& r0, const Fr& r1, size_t size, Fr* out,

@@ -285,6 +285,9 @@ struct SmallOpen {
   // handed a null g', it forms what it needs from these (the first fold directly, g' itself only on the plain route)
   std::vector<const Fr*> merged;
   std::vector<Fr> merged_w;
+  // the merged tables may not have been written yet (the batch opening's sum-check ran from the columns: sumcheck.cpp,
+  // Ctx::sc_u32_terms): whoever needs them calls this first (null: they are there)
+  std::function<void()> ensure_merged;
 };
 // Options::open_precommit: commit the challenge-free half of the coming batch opening's column route on the ctx's helper
 // ctx, starting now (the opening's polys, their small columns and the (poly, point) pairs as mkzg_batch_open will get them;

@@ -824,6 +824,153 @@ void k_inner_products_small_quads(Ctx& c, const uint32_t* col, const Fr* eq_half
   c.d2h(out_host, d_out, 4 * sizeof(Fr));
 }
 
+// The same for the batch opening's sum-check (mkzg.cpp additive_batch_open: terms eq(y_m, .) * merged_m with merged_m a
+// combination of 32-bit columns): S_t = sum_q e1[q] col[4q + t], t = 0..3, of two columns per launch against ONE
+// read of e1 = eq(y[2..]) (the eq levels of a term: E_1; E_0[2q + e] = eq(y_1, e) E_1[q], so the round-0 sums over E_0 are
+// (1 - y_1) S_e + y_1 S_{e+2}).  Rounds 0 and 1 of a term are host combinations of its columns' S_t - no table of the
+// merged polynomial is read or even written.  out[4 k + t] (device) = S_t of column k; entries beyond a column's length are zero.
+constexpr int IPQ_GROUP = 2;  // 8 ten-limb accumulators, 168 registers, 3 waves per SIMD (three columns: 243 registers and spills)
+struct IpQuadPack {
+  const uint32_t* p[IPQ_GROUP];
+  uint64_t quads[IPQ_GROUP];  // len / 4 of each column
+};
+template <int G>
+__global__ __launch_bounds__(256) void inner_products_quads_kernel(IpQuadPack pk, const Fr* __restrict__ e1, size_t quads,
+                                                                   Fr* __restrict__ partials) {
+  __shared__ Fr lds[4];
+  Wide acc[G][4];
+#pragma unroll
+  for (int k = 0; k < G; k++)
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc[k][t] = Wide::zero();
+  GSTRIDE(q, quads) {
+    const Fr h = e1[q];
+#pragma unroll
+    for (int k = 0; k < G; k++)
+      if (q < pk.quads[k]) {
+        const uint4 a = ((const uint4*)pk.p[k])[q];
+        wide_mac(acc[k][0], h, a.x), wide_mac(acc[k][1], h, a.y), wide_mac(acc[k][2], h, a.z), wide_mac(acc[k][3], h, a.w);
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < G; k++)
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      Fr v = block_reduce_sum(wide_reduce(acc[k][t]), lds);
+      if (threadIdx.x == 0) partials[(size_t)(4 * k + t) * gridDim.x + blockIdx.x] = v;
+    }
+}
+void k_inner_products_quads(Ctx& c, const uint32_t* const* cols, const size_t* lens, size_t count, const Fr* e1, size_t quads,
+                            Fr* d_out) {
+  ProfScope ps(c, "inner_products<quads>", 4.0 * 4 * quads * count + 32.0 * quads * ((count + IPQ_GROUP - 1) / IPQ_GROUP),
+               0.25 * quads * count, (double)quads);
+  if (!count) return;
+  // (a thread's accumulator: at most 2^32 / 1024 / 256 terms of 2^288 - far inside ten limbs)
+  dim3 g = grid_for(quads, 256, 1024);
+  Fr* partials = c.arena.alloc_n<Fr>((size_t)g.x * 4 * IPQ_GROUP);  // (queued work reads it: the caller's arena scope holds it)
+  for (size_t base = 0; base < count; base += IPQ_GROUP) {
+    IpQuadPack pk;
+    const int k = (int)std::min<size_t>(IPQ_GROUP, count - base);
+    size_t most = 0;
+    for (int i = 0; i < IPQ_GROUP; i++) {
+      pk.p[i] = i < k ? cols[base + i] : nullptr;
+      pk.quads[i] = i < k ? std::min(lens[base + i] / 4, quads) : 0;
+      most = std::max<size_t>(most, pk.quads[i]);
+    }
+    dim3 gg = grid_for(std::max<size_t>(most, 1), 256, 1024);
+    if (k == 1) hipLaunchKernelGGL(inner_products_quads_kernel<1>, gg, 256, 0, c.stream, pk, e1, most, partials);
+    else hipLaunchKernelGGL(inner_products_quads_kernel<2>, gg, 256, 0, c.stream, pk, e1, most, partials);
+    hipLaunchKernelGGL(reduce_rows_kernel, 4 * k, 256, 0, c.stream, partials, (int)gg.x, d_out + 4 * base);
+  }
+}
+
+// Round 2 of such a term: merged_m bound with (r0, r1) straight from its columns -
+//   out[i] = sum_k w_k ((1-r1)(1-r0) col_k[4i] + (1-r1) r0 col_k[4i+1] + r1 (1-r0) col_k[4i+2] + r1 r0 col_k[4i+3]),
+// 4 x 8 multiply-adds per column and ONE Montgomery reduction per bound entry (the 4 weights of a column arrive times R) -
+// and the round's q(0), q(1) = sum_b eq_level[b] out[2b + e] from the even / odd lanes.
+constexpr int LCB_MAX = 24;
+struct LcBind2 {
+  const uint32_t* p[LCB_MAX];
+  uint64_t quads[LCB_MAX];
+  Fr w[LCB_MAX][4];
+  int count;
+};
+__global__ __launch_bounds__(256) void lincomb_bind2_kernel(const LcBind2* __restrict__ pkp, const Fr* __restrict__ eq_level,
+                                                            size_t entries, Fr* __restrict__ out, Fr* __restrict__ partials,
+                                                            ScFinishArgs fin) {
+  __shared__ Fr lds[4];
+  __shared__ int is_last;
+  const LcBind2& pk = *pkp;
+  const bool odd = threadIdx.x & 1;
+  Fr acc = Fr::zero();
+  GSTRIDE(i, entries) {
+    Wide t = Wide::zero();
+    for (int k = 0; k < pk.count; k++)
+      if (i < pk.quads[k]) {
+        const uint4 a = ((const uint4*)pk.p[k])[i];
+        wide_mac(t, pk.w[k][0], a.x), wide_mac(t, pk.w[k][1], a.y), wide_mac(t, pk.w[k][2], a.z), wide_mac(t, pk.w[k][3], a.w);
+      }
+    const Fr v = wide_redc(t);
+    out[i] = v;
+    acc = add(acc, mul(v, eq_level[i >> 1]));
+  }
+  const Fr q0 = block_reduce_sum(odd ? Fr::zero() : acc, lds);
+  const Fr q1 = block_reduce_sum(odd ? acc : Fr::zero(), lds);
+  if (gridDim.x == 1) {
+    if (threadIdx.x == 0) {
+      fin.out_host[0] = q0, fin.out_host[1] = q1;
+      publish_round(fin, 2);
+    }
+    return;
+  }
+  if (threadIdx.x == 0) fin_put(fin, partials, (size_t)blockIdx.x * 2, q0), fin_put(fin, partials, (size_t)blockIdx.x * 2 + 1, q1);
+  if (!fin_ticket(fin, &is_last)) return;
+  for (int x = 0; x < 2; x++) {
+    Fr a2 = Fr::zero();
+    for (uint32_t i = threadIdx.x; i < gridDim.x; i += blockDim.x) a2 = add(a2, fin_get(fin, partials, (size_t)i * 2 + x));
+    a2 = block_reduce_sum(a2, lds);
+    if (threadIdx.x == 0) fin.out_host[x] = a2;
+  }
+  if (threadIdx.x == 0) publish_round(fin, 2);
+}
+void k_lincomb_bind2(Ctx& c, const uint32_t* const* cols, const size_t* lens, const Fr* w, size_t count, const Fr& r0, const Fr& r1,
+                     const Fr* eq_level, size_t size, Fr* out, Fr* out_host) {
+  LH_REQUIRE(count >= 1 && count <= (size_t)LCB_MAX && size >= 1 && !c.sc_redirect, LH_ERR_ARG, "lincomb_bind2: bad shape");
+  const uint32_t seq = c.next_seq();
+  ArenaScope scope(c.arena);
+  const size_t entries = 2 * size;
+  host::Fr h0, h1;
+  const host::Fr one = host::Fr::one();
+  memcpy(&h0, &r0, sizeof(h0));
+  memcpy(&h1, &r1, sizeof(h1));
+  const host::Fr b4[4] = {(one - h1) * (one - h0), (one - h1) * h0, h1 * (one - h0), h1 * h0};
+  // (the front of the pinned block is the round loop's message buffer: the argument block is staged behind it)
+  LcBind2* h_pk = (LcBind2*)((char*)c.pin(65536) + 8192);
+  memset(h_pk, 0, sizeof(LcBind2));
+  h_pk->count = (int)count;
+  for (size_t k = 0; k < count; k++) {
+    host::Fr wk;
+    memcpy(&wk, &w[k], sizeof(wk));
+    h_pk->p[k] = cols[k], h_pk->quads[k] = std::min(lens[k] / 4, entries);
+    for (int t = 0; t < 4; t++) {
+      const host::Fr x = wk * b4[t];
+      Fr d;
+      memcpy(&d, &x, sizeof(d));
+      h_pk->w[k][t] = prescale_r(d);
+    }
+  }
+  LcBind2* d_pk = (LcBind2*)c.arena.alloc(sizeof(LcBind2));
+  LH_HIP(hipMemcpyAsync(d_pk, h_pk, sizeof(LcBind2), hipMemcpyHostToDevice, c.stream));
+  const size_t g = std::min<size_t>((entries + 255) / 256, (size_t)c.num_cus * 8);
+  Fr* partials = c.arena.alloc_n<Fr>(g * 2);
+  const ScFinishArgs fin = c.finish_for((uint32_t)g, out_host, seq, 32.0 * (double)entries);
+  {
+    ProfScope ps(c, "lincomb<bind2,u32>", (16.0 * count + 32.0 + 16.0) * (double)entries, (0.25 * count + 1.6) * (double)entries, (double)size);
+    hipLaunchKernelGGL(lincomb_bind2_kernel, dim3((unsigned)g), dim3(256), 0, c.stream, d_pk, eq_level, entries, out, partials, fin);
+  }
+  c.wait_round(seq);  // (the pinned staging block is free again: the copy in front of the kernel has run)
+}
+
 // Round 2 of the same sum-check binds r0 AND r1 straight from the column: bound entry i is
 //   (1 - r1) ((1 - r0) a[4i] + r0 a[4i + 1]) + r1 ((1 - r0) a[4i + 2] + r0 a[4i + 3]),
 // four 8-multiply-add terms and ONE Montgomery reduction (the four weights arrive times R: prescale_r / wide_redc), read at

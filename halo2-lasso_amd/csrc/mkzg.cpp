@@ -161,6 +161,7 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
   if (!d_poly) {
     LH_REQUIRE(given && !given->merged.empty(), LH_ERR_ARG, "open: no polynomial");
     if (!small) {  // the plain route needs g' itself
+      if (given->ensure_merged) given->ensure_merged();
       Fr* g = c.arena.alloc_n<Fr>(n);
       k_lincomb(c, given->merged.data(), given->merged_w.data(), given->merged.size(), n, g);
       d_poly = g;
@@ -200,8 +201,10 @@ HFr mkzg_open(Ctx& c, const Srs& srs, const Fr* d_poly, size_t num_vars, const H
       for (size_t k = 0; k < small->cols.size(); k++)
         if (!small->coef[k].is_zero()) cp.push_back(small->cols[k].ptr), cl.push_back(small->cols[k].len), cf.push_back(dev(small->coef[k]));
       static const bool from_cols = !(getenv("LH_OPEN_FOLD_COLS") && atoi(getenv("LH_OPEN_FOLD_COLS")) == 0);  // (development A/B)
-      if (!(from_cols && !cp.empty() && k_lincomb_fold_small(c, cp.data(), cl.data(), cf.data(), cp.size(), half, dev(point[i]), dst)))
+      if (!(from_cols && !cp.empty() && k_lincomb_fold_small(c, cp.data(), cl.data(), cf.data(), cp.size(), half, dev(point[i]), dst))) {
+        if (small->ensure_merged) small->ensure_merged();
         k_lincomb_fold(c, small->merged.data(), small->merged_w.data(), small->merged.size(), half, dev(point[i]), dst);
+      }
     }
     else
       k_quotient_step(c, rem, half, dev(point[i]), keep_q ? q + q_off : nullptr, dst);
@@ -369,6 +372,12 @@ void additive_batch_open(Ctx& c, size_t num_vars, const Fr* const* d_polys, size
   const size_t n = (size_t)1 << (num_vars - (sharded ? sh.rho : 0));
   // merged_j = sum_{i : point(i) = j} eq_xt[i] * poly_i  (:155-170; the lazy first scalar there is a
   // representation detail, every field value below is the same)
+  // Every opened poly a 32-bit column and an opening that takes them as columns (one GPU): the merged tables are not even
+  // written - the sum-check gets the columns and their weights (Ctx::sc_u32_terms), runs its first three rounds from them
+  // and binds the merged polys twice in one pass; whoever still needs a table in full (the plain opening route) makes it then.
+  bool all_small = small != nullptr && open_small != nullptr && !sharded;
+  for (size_t i = 0; i < num_evals && all_small; i++) all_small = small[evals[i].poly].ptr != nullptr;
+  Ctx::ScU32Terms hint;
   std::vector<const Fr*> merged(num_points);
   for (size_t j = 0; j < num_points; j++) {
     std::vector<const Fr*> src;
@@ -389,10 +398,20 @@ void additive_batch_open(Ctx& c, size_t num_vars, const Fr* const* d_polys, size
       }
     LH_REQUIRE(!src.empty() || !sm.empty(), LH_ERR_ARG, "batch open: a point without evaluations");
     Fr* m = c.arena.alloc_n<Fr>(n);
-    if (sm.empty()) k_lincomb(c, src.data(), w.data(), src.size(), n, m);
+    if (all_small) hint.polys.push_back(Ctx::ScU32Terms::Poly{sm, sm_len, wsm});
+    else if (sm.empty()) k_lincomb(c, src.data(), w.data(), src.size(), n, m);
     else k_lincomb_mixed(c, src.data(), w.data(), src.size(), sm.data(), sm_len.data(), wsm.data(), sm.size(), n, m);
     merged[j] = m;
   }
+  bool merged_there = !all_small;
+  auto ensure_merged = [&] {
+    if (merged_there) return;
+    for (size_t j = 0; j < num_points; j++) {
+      const Ctx::ScU32Terms::Poly& pl = hint.polys[j];
+      k_lincomb_mixed(c, nullptr, nullptr, 0, pl.col.data(), pl.len.data(), pl.w.data(), pl.col.size(), n, const_cast<Fr*>(merged[j]));
+    }
+    merged_there = true;
+  };
   lh_sop expr;
   memset(&expr, 0, sizeof(expr));
   expr.global_eq = -1;
@@ -410,8 +429,14 @@ void additive_batch_open(Ctx& c, size_t num_vars, const Fr* const* d_polys, size
     memcpy(&v, &evals[i].value, 32);
     tilde_gs_sum += v * eq_xt[i];
   }
+  struct HintGuard {  // the hint is this sum-check's alone, whatever way it ends
+    Ctx& c;
+    ~HintGuard() { c.sc_u32_terms = Ctx::ScU32Terms(); }
+  } hint_guard{c};
+  if (all_small) c.sc_u32_terms = hint;
   SumCheckResult sc = sum_check_prove(c, LH_SC_COEFFICIENTS, num_vars, expr, merged.data(), num_points, points,
                                       num_points, tilde_gs_sum, tr, false, nullptr, sharded);
+  if (all_small) merged_there = c.sc_u32_terms.built;
   // g' = sum_j eq_xy_eval(challenges, z_j) * merged_j  (:200-213)
   std::vector<Fr> w(num_points);
   for (size_t j = 0; j < num_points; j++)
@@ -424,10 +449,12 @@ void additive_batch_open(Ctx& c, size_t num_vars, const Fr* const* d_polys, size
     if (small_open_columns(small, num_polys, evals, num_evals, n, coef.data(), so)) {
       so.merged = merged;
       so.merged_w = w;
+      so.ensure_merged = ensure_merged;
       open_small(nullptr, sc.challenges.data(), so);  // (g' is formed by the opening if it needs it)
       return;
     }
   }
+  ensure_merged();
   Fr* g_prime = c.arena.alloc_n<Fr>(n);
   k_lincomb(c, merged.data(), w.data(), num_points, n, g_prime);
   open(g_prime, sc.challenges.data());

@@ -669,6 +669,9 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
   const size_t len0 = (size_t)1 << (num_vars - rho);
   const Ctx::ScU32 u32 = c.sc_u32;  // (dev.hpp: poly 0 still is a 32-bit column; decided below who turns it into field elements)
   c.sc_u32 = Ctx::ScU32();
+  Ctx::ScU32Terms u32t;  // (dev.hpp: the polys still are combinations of 32-bit columns)
+  std::swap(u32t, c.sc_u32_terms);
+  bool u32t_rounds = false, u32t_bound = false;
   bool u32_rounds = false;
   std::vector<const Fr*> cur(T);
   for (size_t i = 0; i < num_polys; i++) cur[i] = d_polys[i];
@@ -782,6 +785,29 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
                  k_sc_round_streams(rd, degree, len0 >> 3) &&
                  (len0 >> 2) > std::max<size_t>(k_sc_tail_capacity(c, rd, degree), (size_t)GKR_CAP * GKR_CAP);
     if (!u32_rounds) k_fr_from_u32(c, u32.col, len0, const_cast<Fr*>(d_polys[0]));
+  }
+  // The batch opening's polys as combinations of 32-bit columns: rounds 0 and 1 from the columns' quad sums against E_1 of each
+  // term (no challenge needed), round 2 binds r0 and r1 from the columns (k_lincomb_bind2).  Same conditions as above; when they
+  // do not hold the tables are filled here the way the caller would have (k_lincomb_mixed).
+  std::vector<Fr> u32t_sums;  // [term][4]: sum over the term's columns of w_k S_t(col_k)
+  Fr u32t_r0;
+  if (!u32t.polys.empty()) {
+    static const bool u32t_off = getenv("LH_OPEN_U32_ROUNDS") && atoi(getenv("LH_OPEN_U32_ROUNDS")) == 0;  // (development A/B)
+    LH_REQUIRE(u32t.polys.size() == num_polys, LH_ERR_ARG, "sum-check: the column hint does not match the polys");
+    bool ok = !u32t_off && use_ef && ef.per_term && !sharded && degree == 2 && streams2 && num_vars >= 6 &&
+              k_sc_round_streams(rd, degree, len0 >> 3) &&
+              (len0 >> 2) > std::max<size_t>(k_sc_tail_capacity(c, rd, degree), (size_t)GKR_CAP * GKR_CAP);
+    for (const Ctx::ScU32Terms::Poly& pl : u32t.polys) {
+      ok = ok && !pl.col.empty() && pl.col.size() <= 24;
+      for (size_t ln : pl.len) ok = ok && ln % 4 == 0;
+    }
+    u32t_rounds = ok;
+    if (!ok)
+      for (size_t b = 0; b < num_polys; b++) {
+        const Ctx::ScU32Terms::Poly& pl = u32t.polys[b];
+        k_lincomb_mixed(c, nullptr, nullptr, 0, pl.col.data(), pl.len.data(), pl.w.data(), pl.col.size(), len0, const_cast<Fr*>(d_polys[b]));
+      }
+    c.sc_u32_terms.built = !ok;
   }
   const bool pp_shape = use_ef && !ef.per_term && pp_terms;
   std::vector<HFr> pp_folded;  // the coefficients that went into the left factors (empty: not folded)
@@ -897,6 +923,55 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
           }
           c.route.v[RouteStats::PP_FOLDS]++;
         }
+      } else if (u32t_rounds && round <= 2) {
+        LH_REQUIRE(bind == (round >= 1), LH_ERR_ARG, "sum-check: the column rounds met another shape");
+        const uint32_t M = rd.num_terms;
+        if (round == 0) {
+          // the quad sums of every column against its term's E_1, one download; then per term the weighted sums
+          ArenaScope scope(c.arena);
+          size_t total = 0;
+          for (uint32_t m = 0; m < M; m++) total += u32t.polys[term_poly[m]].col.size();
+          Fr* d_s = c.arena.alloc_n<Fr>(4 * total);
+          size_t off = 0;
+          for (uint32_t m = 0; m < M; m++) {
+            const Ctx::ScU32Terms::Poly& pl = u32t.polys[term_poly[m]];
+            k_inner_products_quads(c, pl.col.data(), pl.len.data(), pl.col.size(), ef.eqs[m].level[1], size >> 1, d_s + 4 * off);
+            off += pl.col.size();
+          }
+          std::vector<Fr> hs(4 * total);
+          c.d2h(hs.data(), d_s, hs.size() * sizeof(Fr));
+          u32t_sums.assign(4 * (size_t)M, dev(HFr::zero()));
+          off = 0;
+          for (uint32_t m = 0; m < M; m++) {
+            const Ctx::ScU32Terms::Poly& pl = u32t.polys[term_poly[m]];
+            HFr t4[4] = {HFr::zero(), HFr::zero(), HFr::zero(), HFr::zero()};
+            for (size_t k = 0; k < pl.col.size(); k++)
+              for (int t = 0; t < 4; t++) t4[t] += hst(pl.w[k]) * hst(hs[4 * (off + k) + t]);
+            off += pl.col.size();
+            for (int t = 0; t < 4; t++) u32t_sums[4 * m + t] = dev(t4[t]);
+            // round 0 sums over E_0[2q + e] = eq(y_1, e) E_1[q]: even entries (1 - y1) S0 + y1 S2, odd ones (1 - y1) S1 + y1 S3
+            const HFr y1 = ef.eqs[m].y[1], n1 = HFr::one() - y1;
+            out_host[2 * m] = dev(n1 * t4[0] + y1 * t4[2]);
+            out_host[2 * m + 1] = dev(n1 * t4[1] + y1 * t4[3]);
+          }
+        } else if (round == 1) {  // the table bound with r0, against E_1: entries 2q are (1 - r0) m[4q] + r0 m[4q+1]
+          u32t_r0 = r;
+          const HFr r0 = hst(r), n0 = HFr::one() - r0;
+          for (uint32_t m = 0; m < M; m++) {
+            const Fr* t4 = &u32t_sums[4 * m];
+            out_host[2 * m] = dev(n0 * hst(t4[0]) + r0 * hst(t4[1]));
+            out_host[2 * m + 1] = dev(n0 * hst(t4[2]) + r0 * hst(t4[3]));
+          }
+        } else {
+          Fr* two = (Fr*)c.pin(65536) + 1024;  // (behind the argument block of k_lincomb_bind2; a launch per term)
+          for (uint32_t m = 0; m < M; m++) {
+            const Ctx::ScU32Terms::Poly& pl = u32t.polys[term_poly[m]];
+            k_lincomb_bind2(c, pl.col.data(), pl.len.data(), pl.w.data(), pl.col.size(), u32t_r0, r, ef.eqs[m].level[2], size,
+                            out[term_poly[m]], two);
+            out_host[2 * m] = two[0], out_host[2 * m + 1] = two[1];
+          }
+          u32t_bound = true;
+        }
       } else {
         ScOpenRound g;
         g.num_terms = rd.num_terms;
@@ -966,6 +1041,7 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
   SumCheckResult res = sum_check_loop(c, prover_kind, num_vars, degree, cur, used, num_polys, sum, tr, sharded, round_fn, &rd,
                                       use_ef ? &ef : nullptr);
   LH_REQUIRE(!u32_rounds || u32_bound, LH_ERR_DEVICE, "sum-check: the 32-bit column was never bound");
+  LH_REQUIRE(!u32t_rounds || u32t_bound, LH_ERR_DEVICE, "sum-check: the 32-bit columns were never bound");
   if (rw_folded) {
     // l' = cs (l + k), r' = r + k came out: l = l' / cs - k, r = r' - k (one inversion for the coefficients)
     const size_t K = rw->num_pairs;
