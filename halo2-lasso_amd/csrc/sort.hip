@@ -16,6 +16,7 @@
 // sorts - the (job, window) slabs of an MSM batch - runs as ONE launch set per pass.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include "dev.hpp"
 
@@ -138,12 +139,24 @@ __host__ __device__ constexpr int rs_per(unsigned rb) { return ((1 << rb) * RS_C
 __host__ __device__ constexpr int rs_cnt_words(unsigned rb) { return (RS_BS * ((rs_per(rb) + 1) / 2 + 1) + 1) & ~1; }
 static size_t rs_lds_bytes(unsigned rb, size_t key_bytes) { return (size_t)rs_cnt_words(rb) * 4 + RS_TILE * (key_bytes + 4); }
 
+// XCD-aware tile order of the scatter pass: workgroups go to the 8 XCDs round-robin, each XCD with its own L2.  A tile's run
+// for a digit is ~16 pairs (64 B) and continues, in the output, where the PREVIOUS tile's run ended: with tile = blockIdx
+// the two halves of a 128-byte line are written through two different L2s, each evicting a partial line (a read-modify-write
+// at the ECC-protected HBM).  Here workgroup b takes flattened tile (b mod 8)'s share + b / 8: an XCD works through a
+// contiguous range of tiles in order, and neighbouring runs meet in ONE L2 before they leave it.
+__device__ __forceinline__ uint32_t rs_xcd_tile(uint32_t b, uint32_t total, uint32_t xcd_order) {
+  if (!xcd_order || total < 64) return b;
+  const uint32_t qn = total / 8, r = total % 8, x = b % 8, j = b / 8;
+  return x * qn + (x < r ? x : r) + j;  // (XCD x owns qn + (x < r) tiles: exactly the b with b mod 8 = x)
+}
 template <class K>
-__global__ __launch_bounds__(RS_BS) void rs_scatter_kernel(const RsSlab* __restrict__ slabs, uint32_t num_slabs, unsigned q) {
+__global__ __launch_bounds__(RS_BS) void rs_scatter_kernel(const RsSlab* __restrict__ slabs, uint32_t num_slabs, unsigned q,
+                                                           uint32_t xcd_order) {
   extern __shared__ uint32_t lds[];
-  const RsSlab& sl = slabs[rs_find_slab(slabs, num_slabs, blockIdx.x)];
+  const uint32_t vb = rs_xcd_tile(blockIdx.x, gridDim.x, xcd_order);
+  const RsSlab& sl = slabs[rs_find_slab(slabs, num_slabs, vb)];
   if (q >= sl.passes) return;
-  const uint32_t tile = blockIdx.x - sl.tile0, ntiles = sl.ntiles;
+  const uint32_t tile = vb - sl.tile0, ntiles = sl.ntiles;
   const unsigned rb = sl.rb[q], shift = rs_shift(sl, q);
   const size_t n = sl.n;
   const K* keys_in;
@@ -344,7 +357,8 @@ void rs_sort_batch(Ctx& c, const RsJob* slabs, size_t count, void* temp) {
       if (q < s.passes) rb_max = std::max(rb_max, s.rb[q]);
     hipLaunchKernelGGL((rs_hist_kernel<K, 512>), dim3(tiles), dim3(512), 0, stream, d_slabs, ns, q);  // (128 / 256 threads: slower, round 3)
     hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1u << rb_max, ns), dim3(256), 0, stream, d_slabs, q);
-    hipLaunchKernelGGL(rs_scatter_kernel<K>, dim3(tiles), dim3(RS_BS), rs_lds_bytes(rb_max, key_bytes), stream, d_slabs, ns, q);
+    static const uint32_t xcd_order = !(getenv("LH_SORT_XCD_ORDER") && atoi(getenv("LH_SORT_XCD_ORDER")) == 0);  // (development A/B)
+    hipLaunchKernelGGL(rs_scatter_kernel<K>, dim3(tiles), dim3(RS_BS), rs_lds_bytes(rb_max, key_bytes), stream, d_slabs, ns, q, xcd_order);
   }
   LH_HIP(hipGetLastError());
   // `stage` is reused by the next batch: its copy must have been consumed by then (the sorts themselves stay queued)
