@@ -794,7 +794,10 @@ static SumCheckResult sum_check_prove_impl(Ctx& c, int prover_kind, size_t num_v
   if (!u32t.polys.empty()) {
     static const bool u32t_off = getenv("LH_OPEN_U32_ROUNDS") && atoi(getenv("LH_OPEN_U32_ROUNDS")) == 0;  // (development A/B)
     LH_REQUIRE(u32t.polys.size() == num_polys, LH_ERR_ARG, "sum-check: the column hint does not match the polys");
-    bool ok = !u32t_off && use_ef && ef.per_term && !sharded && degree == 2 && streams2 && num_vars >= 6 &&
+    // (from 2^22 entries on: below that the ~11 quad-sum launches of a proof are latency - 2^20 AND 11.35 -> 12.1 ms, 2^20 range
+    //  +0.15, 2^21 even, 2^22 range -0.25 ms; LH_OPEN_U32_MIN_VARS: development A/B)
+    static const size_t u32t_min_vars = getenv("LH_OPEN_U32_MIN_VARS") ? (size_t)atoi(getenv("LH_OPEN_U32_MIN_VARS")) : 22;
+    bool ok = !u32t_off && use_ef && ef.per_term && !sharded && degree == 2 && streams2 && num_vars >= u32t_min_vars &&
               k_sc_round_streams(rd, degree, len0 >> 3) &&
               (len0 >> 2) > std::max<size_t>(k_sc_tail_capacity(c, rd, degree), (size_t)GKR_CAP * GKR_CAP);
     for (const Ctx::ScU32Terms::Poly& pl : u32t.polys) {

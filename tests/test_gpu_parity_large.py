@@ -348,7 +348,7 @@ def srs22(hl, ctx):
 
 
 @pytest.mark.heavy(est=10)
-@pytest.mark.parametrize("kind,n", [("and", 21), ("xor", 21), ("range", 22)])
+@pytest.mark.parametrize("kind,n", [("and", 21), ("xor", 21), ("range", 22), ("and", 22)])
 def test_lasso_default_route_at_2p21_matches_cpp_oracle(hl, ctx, srs22, kind, n):
     """The route the 2^24 headline proof takes switches on at 2^21 lookups: the largest quotient(s) of the opening are
     committed column by column (mkzg_open's column route: packed pairs with 2^18-2^20 buckets, 32-share window sums, the
@@ -374,6 +374,8 @@ def test_lasso_default_route_at_2p21_matches_cpp_oracle(hl, ctx, srs22, kind, n)
     # lookups on) its first three rounds never see a field-element view of it (csrc/sumcheck.cpp: two rounds of sums made
     # with the claim, one double-bind kernel)
     assert "sc_round_u32<bind2>" in names and "inner_products<quads>" in names, sorted(names)
+    # the batch opening: no merged tables - its sum-check's first three rounds and its first fold from the columns (from 2^22)
+    assert "lincomb<fold,u32>" in names and ("lincomb<bind2,u32>" in names) == (n >= 22), sorted(names)
     route = hl.lasso_last_route(ctx)
     assert route["open_small_depth"] == (2 if kind == "range" else 1) and route["open_small_passes"] >= 3, route
     assert route["eq_factored_rounds"] > 0 and route["rw_leaf_rounds"] > 0, route
