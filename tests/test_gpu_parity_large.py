@@ -504,3 +504,41 @@ def test_small_parity_suite_under_forced_shapes(env):
                           "-x", "-q", "-k", "sum_check or grand_product or fractional or lasso or batch_open or golden or msm"],
                          cwd=root, env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+
+
+_ROUTE_HASH = """
+import hashlib, sys
+sys.path.insert(0, %r)
+import bench
+import halo2_lasso_amd as hl
+n, kind = int(sys.argv[1]), sys.argv[2]
+ctx = hl.Context(0)
+table, _ = bench.make_table(hl, kind)
+pp = hl.MultilinearKzg.setup(ctx, bench.trapdoor(max(n, table.l)))
+dims = [ctx.upload(c.tobytes()) for c in bench.gen_dims(table, n, 0)]
+t = hl.Keccak256Transcript()
+hl.lasso_prove(pp, table, n, dims, t)
+print("proof", hashlib.sha256(t.into_proof()).hexdigest())
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.heavy(est=25)
+def test_round6_route_switches_change_the_route_not_the_bytes():
+    """Round 6's routes each have an environment switch for A/B timing: the fence-free hand-off of the round
+    kernels, Surge's and the batch opening's first rounds from the 32-bit columns, the opening's fold from the columns, the
+    sort's XCD tile order.  A 2^22 range-check proof made with all of them OFF (a child process: they are read once) is byte
+    for byte the proof made with the defaults - which test_lasso_default_route_at_2p21_matches_cpp_oracle pins to the oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    off = {"LH_FIN_LANES_MIN_BYTES": "-1", "LH_SC_U32": "0", "LH_OPEN_U32_ROUNDS": "0", "LH_OPEN_FOLD_COLS": "0",
+           "LH_SORT_XCD_ORDER": "0"}
+    got = []
+    for env in ({}, off):
+        r = subprocess.run([sys.executable, "-c", _ROUTE_HASH % root, "22", "range"], cwd=root, env=dict(os.environ, **env),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        got.append([l for l in r.stdout.splitlines() if l.startswith("proof ")][-1])
+    assert got[0] == got[1], got
