@@ -523,7 +523,7 @@ print("proof", hashlib.sha256(t.into_proof()).hexdigest())
 
 
 @pytest.mark.gpu
-@pytest.mark.heavy(est=25)
+@pytest.mark.heavy(est=5)
 def test_round6_route_switches_change_the_route_not_the_bytes():
     """Round 6's routes each have an environment switch for A/B timing: the fence-free hand-off of the round
     kernels, Surge's and the batch opening's first rounds from the 32-bit columns, the opening's fold from the columns, the
