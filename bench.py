@@ -539,7 +539,7 @@ def main_hyperplonk(args, hdist, dist, rank, local_rank, world):
                     raise
                 out["cpu_baseline"] = {"value": None, "unit": "ms", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "unavailable: %s" % e}
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -561,7 +561,7 @@ def main():
             line = {"n_gpus": world, "max_rank": int(total), "rendezvous": "ok"}
             if stage != "first":
                 line.update(stage=stage, mode=args.mode, a2a=os.environ.get("LH_COMM_A2A", ""))
-            print(json.dumps(line), flush=True)
+            emit(line)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -670,14 +670,14 @@ def main():
                     late["extras_error"] = ("an extra object after the headline did not complete within "
                                             "LH_BENCH_EXTRAS_TIMEOUT seconds; the headline above was measured before it")
                     late.setdefault("replicas", replicas)
-                    print(json.dumps(late), flush=True)
+                    emit(late)
                 os._exit(0)
             if rank == 0:
                 err = "the sharded proof did not complete within LH_BENCH_SHARDED_TIMEOUT seconds; exit code 3"
                 sys.stderr.write(json.dumps({"error": err, "replicas_measured_before": replicas}) + "\n")
                 sys.stderr.flush()
                 if replicas is not None:
-                    print(json.dumps({
+                    emit({
                         "metric": "lasso_prove_time_ms", "value": replicas["ms_per_proof"], "unit": "ms", "n_gpus": world,
                         "steps": max(1, min(args.steps, 3)), "warmup": 1, "ms_per_step": replicas["ms_per_step"],
                         "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
@@ -686,7 +686,7 @@ def main():
                                    "pcs": "multilinear KZG (BN254)", "parallelism": "1 proof per GPU"},
                         "lookups_per_s": replicas["lookups_per_s"],
                         "mode_fallback": {"ran": "replicas (measured before the sharded proof was started)",
-                                          "sharded_error": err}}), flush=True)
+                                          "sharded_error": err}})
             os._exit(3)
         import threading
         watchdog = threading.Timer(float(os.environ.get("LH_BENCH_SHARDED_TIMEOUT", "240")), give_up)
@@ -933,12 +933,35 @@ def main():
             except Exception as e:  # the oracle is a checker; its absence must not hide the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "ms", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "unavailable: %s" % e}
-        print(json.dumps(out), flush=True)
+        emit(out)
     if sharded:
         hl.detach_comm(ctx)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+_REAL_STDOUT = None  # the process's stdout as it was started with, once claim_stdout() has moved fd 1 to stderr
+
+
+def claim_stdout():
+    """bench.py's contract is ONE JSON line on stdout.  Libraries print there too (gloo notes every connected rank, RCCL may
+    print a banner): from here on file descriptor 1 is stderr - for this process, its libraries and whatever it starts -
+    and only emit() writes to the real stdout."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    data = (json.dumps(obj) + "\n").encode()
+    if _REAL_STDOUT is None:  # (imported as a module: no claim)
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, data)
 
 
 def spawn_ranks(n, argv, extra_env=None):
@@ -955,7 +978,7 @@ def spawn_ranks(n, argv, extra_env=None):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
+                                      stdout=_REAL_STDOUT if r == 0 else subprocess.DEVNULL))
     rc = 0
     while procs:
         for p in list(procs):
@@ -996,13 +1019,14 @@ def sharded_fallback(err):
     argv = [a for a in sys.argv[1:]]
     if os.environ.get("LH_COMM_A2A") != "allgather" and "LH_BENCH_A2A_RETRY" not in os.environ:
         env = successor_env({"LH_COMM_A2A": "allgather", "LH_BENCH_A2A_RETRY": what})
-        return subprocess.call([sys.executable, os.path.abspath(__file__)] + argv, env=env)
+        return subprocess.call([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=_REAL_STDOUT)
     env = successor_env({"LH_BENCH_MODE_FALLBACK": what})
-    return subprocess.call([sys.executable, os.path.abspath(__file__)] + argv + ["--mode", "replicas"], env=env)
+    return subprocess.call([sys.executable, os.path.abspath(__file__)] + argv + ["--mode", "replicas"], env=env, stdout=_REAL_STDOUT)
 
 
 if __name__ == "__main__":
     _args = parse()
+    claim_stdout()
     if _args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: this process only starts the ranks (no GPU call before this point)
         sys.exit(spawn_ranks(_args.gpus, sys.argv[1:]))
